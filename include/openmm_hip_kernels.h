@@ -1,0 +1,125 @@
+/* openmm_hip_kernels.h -- thin C ABI between the OpenMM "HIP" platform plugin (host C++,
+ * openmm_amd/csrc/platform) and the hand-written gfx950 kernels (openmm_amd/csrc/kernels,
+ * built into libopenmm_hip_kernels.so by hipcc).
+ *
+ * Rules of this boundary
+ *   - plain C: pointers, sizes and POD structs only; no C++/HIP/torch types in any signature;
+ *   - every pointer named *_d or documented "device" is a device (HBM) pointer obtained from
+ *     ommhip_malloc(); `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - every function returns 0 on success or a hipError_t value; nothing throws across this ABI
+ *     (the plugin turns non-zero codes into OpenMM::OpenMMException);
+ *   - all launches are asynchronous on `stream` unless stated otherwise.
+ *
+ * Each group cites the reference interface it replaces (paths relative to the OpenMM tree).
+ *
+ * Units/conventions as in OpenMM: nm, ps, amu, kJ/mol, e.  Box vectors are in reduced form and
+ * passed as box[6] = {ax, bx, by, cx, cy, cz}  (a=(ax,0,0), b=(bx,by,0), c=(cx,cy,cz)).
+ */
+#ifndef OPENMM_HIP_KERNELS_H_
+#define OPENMM_HIP_KERNELS_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMMHIP_TILE 32        /* atoms per i-block                       */
+#define OMMHIP_ROW 64         /* j-atoms per neighbour-list row          */
+#define OMMHIP_CHUNK_ROWS 4   /* rows per chunk                          */
+#define OMMHIP_NL_STATE_INTS 8
+
+/* ------------------------------------------------------------------------------------------
+ * Runtime plumbing (device memory, streams, events).  Replaces what CudaContext/CudaArray do in
+ * platforms/cuda/src/CudaContext.cpp:108-397 and CudaArray.cpp; here a minimal C veneer.
+ * ------------------------------------------------------------------------------------------ */
+int ommhip_device_count(int* count);
+int ommhip_set_device(int device);
+int ommhip_device_info(int device, char* name, int name_len, int* num_cus, size_t* total_mem);
+int ommhip_malloc(void** ptr_d, size_t bytes);
+int ommhip_free(void* ptr_d);
+int ommhip_host_malloc(void** ptr, size_t bytes);   /* pinned host memory */
+int ommhip_host_free(void* ptr);
+int ommhip_memcpy_h2d(void* dst_d, const void* src, size_t bytes, void* stream);   /* async on stream */
+int ommhip_memcpy_d2h(void* dst, const void* src_d, size_t bytes, void* stream);   /* async on stream */
+int ommhip_memcpy_d2d(void* dst_d, const void* src_d, size_t bytes, void* stream);
+int ommhip_memset(void* dst_d, int value, size_t bytes, void* stream);
+int ommhip_stream_create(void** stream);
+int ommhip_stream_destroy(void* stream);
+int ommhip_stream_sync(void* stream);
+int ommhip_event_create(void** event);
+int ommhip_event_destroy(void* event);
+int ommhip_event_record(void* event, void* stream);
+int ommhip_event_sync(void* event);
+int ommhip_event_elapsed_ms(void* start, void* stop, float* ms);
+int ommhip_stream_wait_event(void* stream, void* event);
+const char* ommhip_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-step state conversion.
+ * Reference: there is no equivalent (Reference keeps vector<Vec3>); on GPU platforms this is what
+ * CudaContext::reorderAtoms + posq/posqCorrection handling do (platforms/common/src/ComputeContext.cpp:430-612).
+ *
+ * pos_d      double4[num_atoms]   (x,y,z,unused) in atom order, unwrapped
+ * wrap_d     int4[num_atoms]      periodic image (ia,ib,ic,unused) subtracted before the float cast
+ * posq_d     float4[padded_atoms] (x,y,z,q) in slot order, written here (q is left untouched)
+ * ------------------------------------------------------------------------------------------ */
+int ommhip_positions_to_posq(const void* pos_d, const void* wrap_d, const int* atom_of_slot_d, int padded_atoms,
+                             const double box[6], void* posq_d, void* stream);
+/* posq.w[slot] = charges[atom]; sig_eps[slot] = (sigma/2, 2 sqrt(eps))  (ReferenceKernels.cpp:1093-1097) */
+int ommhip_set_slot_params(const double* charge_d, const double* sigma_d, const double* epsilon_d, const int* atom_of_slot_d,
+                           int padded_atoms, void* posq_d, void* sig_eps_d, void* stream);
+/* out[3*atom..] (double, kJ/mol/nm) = fixed-point force of that atom's slot */
+int ommhip_forces_to_double(const long long* force_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, double* out_d, void* stream);
+/* force[slot] += in[3*atom..] (double) */
+int ommhip_add_forces_from_double(const double* in_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, long long* force_d, void* stream);
+/* result[0] = sum of buffer[0..n), then buffer is zeroed; result_d is a device double */
+int ommhip_reduce_energy(double* buffer_d, int n, double* result_d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Neighbour list + direct-space NonbondedForce.
+ * Replaces CalcNonbondedForceKernel::execute(includeDirect) -- olla/include/openmm/kernels.h:556-614,
+ * Reference implementation platforms/reference/src/ReferenceKernels.cpp:967-1014 with
+ * ReferenceNeighborList.cpp:221-259 and ReferenceLJCoulombIxn.cpp:379-457,543-639.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ommhip_neighbor_list {
+    int num_atoms;
+    int padded_atoms;          /* multiple of OMMHIP_TILE */
+    int max_chunks;            /* capacity of chunk_info / row arrays */
+    int pbc;                   /* 0 = none, 1 = orthorhombic, 2 = triclinic */
+    double cutoff;             /* <= 0 means no cutoff (all pairs) */
+    double padding;            /* list is built with cutoff+padding; rebuilt when an atom moves > padding/2 */
+    double box[6];
+    const void* posq;          /* float4[padded_atoms], slot order */
+    void* posq_ref;            /* float4[padded_atoms], positions at the last rebuild */
+    const int* atom_of_slot;   /* [padded_atoms], -1 for padding slots */
+    const int* slot_of_atom;   /* [num_atoms] */
+    const int* excl_start;     /* [num_atoms+1] CSR of excluded partners (atom indices) */
+    const int* excl_atoms;
+    int* state;                /* int[OMMHIP_NL_STATE_INTS]: 0 rebuild-request, 1 chunks used, 2 overflow, 3 scratch, 4 #rebuilds */
+    void* block_center;        /* float4[padded_atoms/32] */
+    void* block_half;          /* float4[padded_atoms/32] */
+    void* chunk_info;          /* int2[max_chunks]  (i-block, nrows | maskedRowBits<<8) */
+    int* row_j;                /* int[max_chunks*CHUNK_ROWS*ROW] */
+    unsigned* row_mask;        /* same shape */
+} ommhip_neighbor_list;
+
+typedef struct ommhip_nonbonded_params {
+    int ewald;                 /* 1: erfc(alpha r) real-space Ewald/PME term, 0: reaction field / plain Coulomb */
+    int use_switch;
+    double ewald_alpha;
+    double krf, crf;           /* reaction-field constants (0 for NoCutoff) */
+    double switch_distance;
+    int direct_grid;           /* number of wavefront-sized workgroups to launch (0 = default) */
+} ommhip_nonbonded_params;
+
+/* Checks displacement, and (only if state[0] != 0 afterwards) rebuilds bounds + rows.  No host sync. */
+int ommhip_nl_update(const ommhip_neighbor_list* nl, void* stream);
+/* Adds direct-space forces (and per-workgroup energies into energy_buffer_d[0..energy_slots)). */
+int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, const void* sig_eps_d,
+                     long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,122 @@
+"""ctypes binding of the C ABI declared in include/openmm_hip_kernels.h.
+
+`load()` opens the product library openmm_amd/lib/libopenmm_hip_kernels.so (hipcc, gfx950) and
+raises if it is missing -- there is no CPU fallback on the product path.  Tests that exercise
+host-side logic without a GPU pass the path of the CPU-emulated twin explicitly
+(tests/emu/_build/libopenmm_hip_kernels.so); nothing in the package does that on its own.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PRODUCT_LIB = os.path.join(_HERE, "lib", "libopenmm_hip_kernels.so")
+
+TILE = 32
+ROW = 64
+CHUNK_ROWS = 4
+NL_STATE_INTS = 8
+
+
+class NeighborList(C.Structure):
+    _fields_ = [
+        ("num_atoms", C.c_int), ("padded_atoms", C.c_int), ("max_chunks", C.c_int), ("pbc", C.c_int),
+        ("cutoff", C.c_double), ("padding", C.c_double), ("box", C.c_double * 6),
+        ("posq", C.c_void_p), ("posq_ref", C.c_void_p), ("atom_of_slot", C.c_void_p), ("slot_of_atom", C.c_void_p),
+        ("excl_start", C.c_void_p), ("excl_atoms", C.c_void_p), ("state", C.c_void_p),
+        ("block_center", C.c_void_p), ("block_half", C.c_void_p), ("chunk_info", C.c_void_p),
+        ("row_j", C.c_void_p), ("row_mask", C.c_void_p),
+    ]
+
+
+class NonbondedParams(C.Structure):
+    _fields_ = [
+        ("ewald", C.c_int), ("use_switch", C.c_int), ("ewald_alpha", C.c_double), ("krf", C.c_double), ("crf", C.c_double),
+        ("switch_distance", C.c_double), ("direct_grid", C.c_int),
+    ]
+
+
+class KernelError(RuntimeError):
+    pass
+
+
+_P, _I, _D, _Z = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+_D6 = C.POINTER(C.c_double)
+# argument types of every entry point of include/openmm_hip_kernels.h (all return int)
+SIGNATURES = {
+    "device_count": [C.POINTER(C.c_int)],
+    "set_device": [_I],
+    "device_info": [_I, C.c_char_p, _I, C.POINTER(C.c_int), C.POINTER(C.c_size_t)],
+    "malloc": [C.POINTER(C.c_void_p), _Z],
+    "free": [_P],
+    "host_malloc": [C.POINTER(C.c_void_p), _Z],
+    "host_free": [_P],
+    "memcpy_h2d": [_P, _P, _Z, _P],
+    "memcpy_d2h": [_P, _P, _Z, _P],
+    "memcpy_d2d": [_P, _P, _Z, _P],
+    "memset": [_P, _I, _Z, _P],
+    "stream_create": [C.POINTER(C.c_void_p)],
+    "stream_destroy": [_P],
+    "stream_sync": [_P],
+    "event_create": [C.POINTER(C.c_void_p)],
+    "event_destroy": [_P],
+    "event_record": [_P, _P],
+    "event_sync": [_P],
+    "event_elapsed_ms": [_P, _P, C.POINTER(C.c_float)],
+    "stream_wait_event": [_P, _P],
+    "positions_to_posq": [_P, _P, _P, _I, _D6, _P, _P],
+    "set_slot_params": [_P, _P, _P, _P, _I, _P, _P, _P],
+    "forces_to_double": [_P, _P, _I, _I, _P, _P],
+    "add_forces_from_double": [_P, _P, _I, _I, _P, _P],
+    "reduce_energy": [_P, _I, _P, _P],
+    "nl_update": [C.POINTER(NeighborList), _P],
+    "nb_direct": [C.POINTER(NeighborList), C.POINTER(NonbondedParams), _P, _P, _P, _I, _I, _P],
+}
+
+
+class Kernels:
+    """Thin checked wrapper: every call raises KernelError on a non-zero return code."""
+
+    def __init__(self, path=None):
+        path = path or PRODUCT_LIB
+        if not os.path.exists(path):
+            raise KernelError("HIP kernel library not found: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
+        self.path = path
+        self.lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        self.lib.ommhip_error_string.restype = C.c_char_p
+
+    def __getattr__(self, name):
+        fn = getattr(self.lib, "ommhip_" + name)
+        fn.restype = C.c_int
+        fn.argtypes = SIGNATURES[name]
+
+        def call(*args):
+            rc = fn(*args)
+            if rc != 0:
+                raise KernelError("ommhip_%s failed: %d (%s)" % (name, rc, self.lib.ommhip_error_string(rc).decode()))
+            return rc
+        return call
+
+    # ---- small conveniences used by tests and bench
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        self.__getattr__("malloc")(C.byref(p), C.c_size_t(nbytes))
+        return p
+
+    def upload(self, array, stream=None):
+        import numpy as np
+        array = np.ascontiguousarray(array)
+        p = self.malloc(max(array.nbytes, 16))
+        self.memcpy_h2d(p, array.ctypes.data_as(C.c_void_p), C.c_size_t(array.nbytes), stream)
+        self.stream_sync(stream)
+        return p
+
+    def download(self, ptr, shape, dtype, stream=None):
+        import numpy as np
+        out = np.empty(shape, dtype=dtype)
+        self.memcpy_d2h(out.ctypes.data_as(C.c_void_p), ptr, C.c_size_t(out.nbytes), stream)
+        self.stream_sync(stream)
+        return out
+
+
+def load(path=None):
+    return Kernels(path)

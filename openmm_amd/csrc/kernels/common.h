@@ -1,0 +1,117 @@
+// Shared device-side helpers for the MI355X (gfx950, wave64) kernels of the OpenMM "HIP" platform.
+//
+// Conventions used by every kernel in this directory
+//   * Atoms live in two index spaces: "atom" = the System's particle index (state arrays pos/vel),
+//     and "slot" = position in the spatially sorted, 32-atom-blocked order used by the nonbonded /
+//     PME kernels (posq, sigmaEps, force).  atomOfSlot[slot] / slotOfAtom[atom] convert.
+//   * Forces are accumulated as 64-bit fixed point (value * 2^32) in SoA layout
+//     force[0..P) = x, force[P..2P) = y, force[2P..3P) = z with P = paddedAtoms, indexed by slot.
+//     Integer accumulation makes the sum independent of the order of the atomics.
+//   * A wavefront is 64 lanes.  Block sizes are multiples of 64.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define OMM_TILE 32            // atoms per i-block
+#define OMM_ROW 64             // j-atoms per neighbour-list row (= one wavefront)
+#define OMM_CHUNK_ROWS 4       // rows per work chunk (all rows of a chunk share one i-block)
+#define OMM_FORCE_SCALE 4294967296.0   // 2^32
+
+#define OMM_ONE_4PI_EPS0 138.935456f   // platforms/reference/include/SimTKOpenMMRealType.h:84-89
+
+typedef long long omm_fixed;   // 64-bit fixed-point force component
+
+namespace omm {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// e^x through the hardware 2^x unit.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
+__device__ __forceinline__ omm_fixed to_fixed(float v) { return (omm_fixed) ((double) v * OMM_FORCE_SCALE); }
+__device__ __forceinline__ omm_fixed to_fixed(double v) { return (omm_fixed) (v * OMM_FORCE_SCALE); }
+__device__ __forceinline__ double from_fixed(omm_fixed v) { return (double) v * (1.0 / OMM_FORCE_SCALE); }
+
+__device__ __forceinline__ void atomic_add_fixed(omm_fixed* p, omm_fixed v) {
+    atomicAdd((unsigned long long*) p, (unsigned long long) v);
+}
+
+__device__ __forceinline__ void add_force(omm_fixed* __restrict__ force, int paddedAtoms, int slot, float fx, float fy, float fz) {
+    atomic_add_fixed(force + slot, to_fixed(fx));
+    atomic_add_fixed(force + slot + paddedAtoms, to_fixed(fy));
+    atomic_add_fixed(force + slot + 2 * paddedAtoms, to_fixed(fz));
+}
+__device__ __forceinline__ void add_force(omm_fixed* __restrict__ force, int paddedAtoms, int slot, double fx, double fy, double fz) {
+    atomic_add_fixed(force + slot, to_fixed(fx));
+    atomic_add_fixed(force + slot + paddedAtoms, to_fixed(fy));
+    atomic_add_fixed(force + slot + 2 * paddedAtoms, to_fixed(fz));
+}
+
+// Wave-wide sum; every lane of the wave must call it.  Result valid in all lanes.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// Number of set bits of `mask` below this lane.
+__device__ __forceinline__ int lane_prefix_count(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned) (mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) mask, 0));
+}
+
+// Periodic box in reduced form a=(ax,0,0) b=(bx,by,0) c=(cx,cy,cz)  (openmmapi ContextImpl.cpp:267-275).
+struct Box {
+    float ax, bx, by, cx, cy, cz;
+    float invAx, invBy, invCz;
+};
+
+struct BoxD {
+    double ax, bx, by, cx, cy, cz;
+};
+
+// Minimum-image displacement.  TRICLINIC=false assumes bx=cx=cy=0.
+template <bool TRICLINIC>
+__device__ __forceinline__ void min_image(float& dx, float& dy, float& dz, const Box& b) {
+    if (TRICLINIC) {
+        // platforms/reference/src/SimTKReference/ReferenceForce.cpp getDeltaRPeriodic (triclinic branch):
+        // subtract multiples of c, then b, then a.
+        float s = rintf(dz * b.invCz);
+        dx -= s * b.cx; dy -= s * b.cy; dz -= s * b.cz;
+        s = rintf(dy * b.invBy);
+        dx -= s * b.bx; dy -= s * b.by;
+        s = rintf(dx * b.invAx);
+        dx -= s * b.ax;
+    }
+    else {
+        dx -= rintf(dx * b.invAx) * b.ax;
+        dy -= rintf(dy * b.invBy) * b.by;
+        dz -= rintf(dz * b.invCz) * b.cz;
+    }
+}
+
+__device__ __forceinline__ void min_image_d(double& dx, double& dy, double& dz, const BoxD& b) {
+    double s = rint(dz / b.cz);
+    dx -= s * b.cx; dy -= s * b.cy; dz -= s * b.cz;
+    s = rint(dy / b.by);
+    dx -= s * b.bx; dy -= s * b.by;
+    s = rint(dx / b.ax);
+    dx -= s * b.ax;
+}
+
+}  // namespace omm

@@ -1,0 +1,112 @@
+// State conversion kernels: double-precision atom-ordered state <-> float slot-ordered working set,
+// fixed-point force import/export, energy reduction.  See include/openmm_hip_kernels.h.
+#include "common.h"
+#include "../../../include/openmm_hip_kernels.h"
+
+using namespace omm;
+
+namespace {
+
+__global__ void k_positions_to_posq(const double4* __restrict__ pos, const int4* __restrict__ wrap, const int* __restrict__ atomOfSlot,
+                                    int paddedAtoms, BoxD box, float4* __restrict__ posq) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= paddedAtoms) return;
+    int a = atomOfSlot[s];
+    float4 out = posq[s];
+    if (a >= 0) {
+        double4 p = pos[a];
+        int4 w = wrap[a];
+        // subtract the periodic image chosen at the last reorder so that the float copy stays near the primary cell
+        double x = p.x - (w.x * box.ax + w.y * box.bx + w.z * box.cx);
+        double y = p.y - (w.y * box.by + w.z * box.cy);
+        double z = p.z - (w.z * box.cz);
+        out.x = (float) x; out.y = (float) y; out.z = (float) z;
+    }
+    else {
+        out.x = 0.f; out.y = 0.f; out.z = 0.f; out.w = 0.f;
+    }
+    posq[s] = out;
+}
+
+__global__ void k_set_slot_params(const double* __restrict__ charge, const double* __restrict__ sigma, const double* __restrict__ epsilon,
+                                  const int* __restrict__ atomOfSlot, int paddedAtoms, float4* __restrict__ posq, float2* __restrict__ sigEps) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= paddedAtoms) return;
+    int a = atomOfSlot[s];
+    float q = 0.f;
+    float2 se = make_float2(0.f, 0.f);
+    if (a >= 0) {
+        q = (float) charge[a];
+        se = make_float2((float) (0.5 * sigma[a]), (float) (2.0 * sqrt(epsilon[a])));
+    }
+    posq[s].w = q;
+    sigEps[s] = se;
+}
+
+__global__ void k_forces_to_double(const omm_fixed* __restrict__ force, const int* __restrict__ slotOfAtom, int numAtoms, int paddedAtoms,
+                                   double* __restrict__ out) {
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= numAtoms) return;
+    int s = slotOfAtom[a];
+    out[3 * a] = from_fixed(force[s]);
+    out[3 * a + 1] = from_fixed(force[s + paddedAtoms]);
+    out[3 * a + 2] = from_fixed(force[s + 2 * paddedAtoms]);
+}
+
+__global__ void k_add_forces_from_double(const double* __restrict__ in, const int* __restrict__ slotOfAtom, int numAtoms, int paddedAtoms,
+                                         omm_fixed* __restrict__ force) {
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= numAtoms) return;
+    int s = slotOfAtom[a];
+    force[s] += to_fixed(in[3 * a]);
+    force[s + paddedAtoms] += to_fixed(in[3 * a + 1]);
+    force[s + 2 * paddedAtoms] += to_fixed(in[3 * a + 2]);
+}
+
+__global__ __launch_bounds__(256) void k_reduce_energy(double* __restrict__ buffer, int n, double* __restrict__ result) {
+    __shared__ double partial[4];
+    double sum = 0;
+    for (int i = threadIdx.x; i < n; i += 256) { sum += buffer[i]; buffer[i] = 0; }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) result[0] = partial[0] + partial[1] + partial[2] + partial[3];
+}
+
+BoxD make_boxd(const double* bv) {
+    BoxD b; b.ax = bv[0]; b.bx = bv[1]; b.by = bv[2]; b.cx = bv[3]; b.cy = bv[4]; b.cz = bv[5];
+    return b;
+}
+
+}  // namespace
+
+extern "C" int ommhip_positions_to_posq(const void* pos_d, const void* wrap_d, const int* atom_of_slot_d, int padded_atoms,
+                                        const double box[6], void* posq_d, void* stream) {
+    hipLaunchKernelGGL(k_positions_to_posq, dim3((padded_atoms + 255) / 256), dim3(256), 0, (hipStream_t) stream,
+                       (const double4*) pos_d, (const int4*) wrap_d, atom_of_slot_d, padded_atoms, make_boxd(box), (float4*) posq_d);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_set_slot_params(const double* charge_d, const double* sigma_d, const double* epsilon_d, const int* atom_of_slot_d,
+                                      int padded_atoms, void* posq_d, void* sig_eps_d, void* stream) {
+    hipLaunchKernelGGL(k_set_slot_params, dim3((padded_atoms + 255) / 256), dim3(256), 0, (hipStream_t) stream,
+                       charge_d, sigma_d, epsilon_d, atom_of_slot_d, padded_atoms, (float4*) posq_d, (float2*) sig_eps_d);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_forces_to_double(const long long* force_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, double* out_d, void* stream) {
+    hipLaunchKernelGGL(k_forces_to_double, dim3((num_atoms + 255) / 256), dim3(256), 0, (hipStream_t) stream,
+                       (const omm_fixed*) force_d, slot_of_atom_d, num_atoms, padded_atoms, out_d);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_add_forces_from_double(const double* in_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, long long* force_d, void* stream) {
+    hipLaunchKernelGGL(k_add_forces_from_double, dim3((num_atoms + 255) / 256), dim3(256), 0, (hipStream_t) stream,
+                       in_d, slot_of_atom_d, num_atoms, padded_atoms, (omm_fixed*) force_d);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_reduce_energy(double* buffer_d, int n, double* result_d, void* stream) {
+    hipLaunchKernelGGL(k_reduce_energy, dim3(1), dim3(256), 0, (hipStream_t) stream, buffer_d, n, result_d);
+    return (int) hipGetLastError();
+}

@@ -119,6 +119,35 @@ int ommhip_nl_update(const ommhip_neighbor_list* nl, void* stream);
 int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, const void* sig_eps_d,
                      long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * PME reciprocal space.  Replaces pme_exec() -- platforms/reference/src/SimTKReference/ReferencePME.cpp:760-803
+ * (spread :330-405, fftpack 3-D FFT, convolution :409-514, interpolation :617-713), reached from
+ * CalcNonbondedForceKernel::execute(includeReciprocal) (kernels.h:556-614).  Spline order is 5 as in
+ * ReferenceLJCoulombIxn.cpp:243.  Grid sizes must satisfy ommhip_fft_supported_size().
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ommhip_pme {
+    int nx, ny, nz;
+    double alpha;
+    double box[6];
+    const double* moduli_x;    /* device double[nx]: B-spline moduli (ReferencePME.cpp:98-193), computed by the host */
+    const double* moduli_y;
+    const double* moduli_z;
+    void* eterm;               /* device float[nx*ny*(nz/2+1)] influence function (ommhip_pme_build_eterm) */
+    void* grid_real;           /* device float[nx*ny*nz] */
+    void* grid_complex;        /* device float2[nx*ny*(nz/2+1)] */
+    const void* twiddle_x;     /* device float2[nx]: exp(-2 pi i k/nx) */
+    const void* twiddle_y;
+    const void* twiddle_z;
+} ommhip_pme;
+
+int ommhip_fft_supported_size(int n);   /* 1 if n factors into 2,3,5,7 and fits the LDS line buffer; no device access */
+int ommhip_pme_build_eterm(const ommhip_pme* pme, void* stream);
+/* spread -> 3-D FFT -> convolution (+energy) -> inverse FFT -> interpolate; adds forces (slot order) */
+int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, int padded_atoms, long long* force_d,
+                          double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
+/* test hook: forward (grid_real -> grid_complex) or backward (grid_complex -> grid_real) unnormalised 3-D transform */
+int ommhip_fft3d_r2c_c2r(const ommhip_pme* pme, int forward, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

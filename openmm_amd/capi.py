@@ -35,6 +35,15 @@ class NonbondedParams(C.Structure):
     ]
 
 
+class Pme(C.Structure):
+    _fields_ = [
+        ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("alpha", C.c_double), ("box", C.c_double * 6),
+        ("moduli_x", C.c_void_p), ("moduli_y", C.c_void_p), ("moduli_z", C.c_void_p),
+        ("eterm", C.c_void_p), ("grid_real", C.c_void_p), ("grid_complex", C.c_void_p),
+        ("twiddle_x", C.c_void_p), ("twiddle_y", C.c_void_p), ("twiddle_z", C.c_void_p),
+    ]
+
+
 class KernelError(RuntimeError):
     pass
 
@@ -69,6 +78,10 @@ SIGNATURES = {
     "add_forces_from_double": [_P, _P, _I, _I, _P, _P],
     "reduce_energy": [_P, _I, _P, _P],
     "nl_update": [C.POINTER(NeighborList), _P],
+    "fft_supported_size": [_I],
+    "pme_build_eterm": [C.POINTER(Pme), _P],
+    "pme_reciprocal": [C.POINTER(Pme), _P, _I, _P, _P, _I, _I, _P],
+    "fft3d_r2c_c2r": [C.POINTER(Pme), _I, _P],
     "nb_direct": [C.POINTER(NeighborList), C.POINTER(NonbondedParams), _P, _P, _P, _I, _I, _P],
 }
 

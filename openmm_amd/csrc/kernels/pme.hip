@@ -1,0 +1,463 @@
+// Reciprocal-space PME for MI355X (gfx950): B-spline charge spreading, hand-written 3-D FFT,
+// convolution and force interpolation; plus the classic Ewald k-sum used for small systems.
+//
+// Replaces (behaviourally) platforms/reference/src/SimTKReference/ReferencePME.cpp:
+//   pme_update_grid_index_and_fraction :206-266, pme_update_bsplines :274-327,
+//   pme_grid_spread_charge :330-405, fftpack_exec_3d (fftpack.cpp) via pme_exec :760-803,
+//   pme_reciprocal_convolution :409-514, pme_grid_interpolate_force :617-713,
+// and the Ewald k-sum of ReferenceLJCoulombIxn.cpp:272-367.
+//
+// Data layout in HBM
+//   real grid    float  [nx][ny][nz]            (charge density, then potential)
+//   half-complex float2 [nx][ny][nz/2+1]        (forward transform of the real grid)
+//   eterm        float  [nx][ny][nz/2+1]        influence function, rebuilt only when the box changes
+// The transform is unnormalised in both directions, exactly like fftpack in the reference, so the
+// influence function carries all constants.
+#include "common.h"
+#include "../../../include/openmm_hip_kernels.h"
+
+using namespace omm;
+
+namespace {
+
+#define PME_ORDER 5
+#define FFT_MAX_LDS 4096      // complex elements per ping-pong buffer
+#define FFT_THREADS 256
+#define FFT_MAX_RADICES 12
+
+struct RecipBox {   // reciprocal box vectors (rows), ReferencePME.cpp:196-204 (invert_box_vectors)
+    float r00, r10, r11, r20, r21, r22;
+};
+
+struct PmeArgs {
+    int paddedAtoms, nx, ny, nz;
+    RecipBox recip;
+    const float4* posq;
+    float* grid;
+    omm_fixed* force;
+};
+
+// Grid index and B-spline weights of one coordinate.  ReferencePME.cpp:259-264 and :274-327 (order 5).
+__device__ __forceinline__ void bspline(float t, int n, int& index, float (&theta)[PME_ORDER], float (&dtheta)[PME_ORDER]) {
+    t = (t - floorf(t)) * n;
+    int ti = (int) t;
+    float dr = t - ti;
+    index = ti % n;
+    theta[PME_ORDER - 1] = 0.f;
+    theta[1] = dr;
+    theta[0] = 1.f - dr;
+#pragma unroll
+    for (int k = 3; k < PME_ORDER; k++) {
+        float div = 1.f / (k - 1.f);
+        theta[k - 1] = div * dr * theta[k - 2];
+#pragma unroll
+        for (int l = 1; l < k - 1; l++)
+            theta[k - l - 1] = div * ((dr + l) * theta[k - l - 2] + (k - l - dr) * theta[k - l - 1]);
+        theta[0] = div * (1.f - dr) * theta[0];
+    }
+    dtheta[0] = -theta[0];
+#pragma unroll
+    for (int k = 1; k < PME_ORDER; k++) dtheta[k] = theta[k - 1] - theta[k];
+    const float div = 1.f / (PME_ORDER - 1);
+    theta[PME_ORDER - 1] = div * dr * theta[PME_ORDER - 2];
+#pragma unroll
+    for (int l = 1; l < PME_ORDER - 1; l++)
+        theta[PME_ORDER - l - 1] = div * ((dr + l) * theta[PME_ORDER - l - 2] + (PME_ORDER - l - dr) * theta[PME_ORDER - l - 1]);
+    theta[0] = div * (1.f - dr) * theta[0];
+}
+
+__device__ __forceinline__ void atom_splines(const PmeArgs& a, float4 p, int (&idx)[3], float (&th)[3][PME_ORDER], float (&dth)[3][PME_ORDER]) {
+    // fractional coordinates t_d = sum_k coord[k]*recip[k][d]           (ReferencePME.cpp:256-258)
+    float tx = p.x * a.recip.r00 + p.y * a.recip.r10 + p.z * a.recip.r20;
+    float ty = p.y * a.recip.r11 + p.z * a.recip.r21;
+    float tz = p.z * a.recip.r22;
+    bspline(tx, a.nx, idx[0], th[0], dth[0]);
+    bspline(ty, a.ny, idx[1], th[1], dth[1]);
+    bspline(tz, a.nz, idx[2], th[2], dth[2]);
+}
+
+// 8 lanes per atom; lane `sub` handles stencil points sub, sub+8, ... < 125.
+__global__ __launch_bounds__(256) void pme_spread(PmeArgs a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = t >> 3, sub = t & 7;
+    if (slot >= a.paddedAtoms) return;
+    const float4 p = a.posq[slot];
+    if (p.w == 0.f) return;
+    int idx[3]; float th[3][PME_ORDER], dth[3][PME_ORDER];
+    atom_splines(a, p, idx, th, dth);
+    for (int pt = sub; pt < PME_ORDER * PME_ORDER * PME_ORDER; pt += 8) {
+        const int ix = pt / 25, iy = (pt / 5) % 5, iz = pt % 5;
+        int gx = idx[0] + ix; gx -= gx >= a.nx ? a.nx : 0;
+        int gy = idx[1] + iy; gy -= gy >= a.ny ? a.ny : 0;
+        int gz = idx[2] + iz; gz -= gz >= a.nz ? a.nz : 0;
+        // dynamic indexing of the small theta arrays is resolved with selects after unrolling
+        float wx = th[0][0], wy = th[1][0], wz = th[2][0];
+#pragma unroll
+        for (int k = 1; k < PME_ORDER; k++) { wx = ix == k ? th[0][k] : wx; wy = iy == k ? th[1][k] : wy; wz = iz == k ? th[2][k] : wz; }
+        atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], p.w * wx * wy * wz);
+    }
+}
+
+__global__ __launch_bounds__(256) void pme_interpolate(PmeArgs a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int slot = t >> 3;
+    const int sub = t & 7;
+    const bool valid = slot < a.paddedAtoms;
+    if (!valid) slot = a.paddedAtoms - 1;
+    const float4 p = a.posq[slot];
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    if (valid && p.w != 0.f) {
+        int idx[3]; float th[3][PME_ORDER], dth[3][PME_ORDER];
+        atom_splines(a, p, idx, th, dth);
+        for (int pt = sub; pt < PME_ORDER * PME_ORDER * PME_ORDER; pt += 8) {
+            const int ix = pt / 25, iy = (pt / 5) % 5, iz = pt % 5;
+            int gx = idx[0] + ix; gx -= gx >= a.nx ? a.nx : 0;
+            int gy = idx[1] + iy; gy -= gy >= a.ny ? a.ny : 0;
+            int gz = idx[2] + iz; gz -= gz >= a.nz ? a.nz : 0;
+            float wx = th[0][0], wy = th[1][0], wz = th[2][0], dx = dth[0][0], dy = dth[1][0], dz = dth[2][0];
+#pragma unroll
+            for (int k = 1; k < PME_ORDER; k++) {
+                wx = ix == k ? th[0][k] : wx; wy = iy == k ? th[1][k] : wy; wz = iz == k ? th[2][k] : wz;
+                dx = ix == k ? dth[0][k] : dx; dy = iy == k ? dth[1][k] : dy; dz = iz == k ? dth[2][k] : dz;
+            }
+            const float g = a.grid[((size_t) gx * a.ny + gy) * a.nz + gz];
+            fx += dx * wy * wz * g;
+            fy += wx * dy * wz * g;
+            fz += wx * wy * dz * g;
+        }
+    }
+    // reduce the 8 lanes of this atom
+    fx += __shfl_xor(fx, 1); fy += __shfl_xor(fy, 1); fz += __shfl_xor(fz, 1);
+    fx += __shfl_xor(fx, 2); fy += __shfl_xor(fy, 2); fz += __shfl_xor(fz, 2);
+    fx += __shfl_xor(fx, 4); fy += __shfl_xor(fy, 4); fz += __shfl_xor(fz, 4);
+    if (valid && sub == 0 && p.w != 0.f) {
+        // ReferencePME.cpp:709-711
+        const float q = p.w;
+        const float gx = fx * a.nx, gy = fy * a.ny, gz = fz * a.nz;
+        add_force(a.force, a.paddedAtoms, slot,
+                  -q * (gx * a.recip.r00),
+                  -q * (gx * a.recip.r10 + gy * a.recip.r11),
+                  -q * (gx * a.recip.r20 + gy * a.recip.r21 + gz * a.recip.r22));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Influence function  eterm(kx,ky,kz) = ONE_4PI_EPS0 exp(-pi^2 m^2/alpha^2) / (pi V m^2 bx by bz)
+// on the half grid (ReferencePME.cpp:409-514), evaluated in double and stored as float.
+// ------------------------------------------------------------------------------------------------
+struct EtermArgs {
+    int nx, ny, nz, nzc;
+    double r00, r10, r11, r20, r21, r22, alpha, volume;
+    const double* modX; const double* modY; const double* modZ;
+    float* eterm;
+};
+
+__global__ void pme_build_eterm(EtermArgs a) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t) a.nx * a.ny * a.nzc;
+    if (i >= total) return;
+    const int kz = (int) (i % a.nzc), ky = (int) ((i / a.nzc) % a.ny), kx = (int) (i / ((size_t) a.nzc * a.ny));
+    if (kx == 0 && ky == 0 && kz == 0) { a.eterm[i] = 0.f; return; }
+    const int mx = kx < (a.nx + 1) / 2 ? kx : kx - a.nx;
+    const int my = ky < (a.ny + 1) / 2 ? ky : ky - a.ny;
+    const int mz = kz < (a.nz + 1) / 2 ? kz : kz - a.nz;
+    const double mhx = mx * a.r00;
+    const double mhy = mx * a.r10 + my * a.r11;
+    const double mhz = mx * a.r20 + my * a.r21 + mz * a.r22;
+    const double m2 = mhx * mhx + mhy * mhy + mhz * mhz;
+    const double pi = 3.14159265358979323846;
+    const double denom = m2 * (pi * a.volume * a.modX[kx]) * a.modY[ky] * a.modZ[kz];
+    a.eterm[i] = (float) (138.935456 * exp(-(pi * pi / (a.alpha * a.alpha)) * m2) / denom);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mixed-radix Stockham FFT over lines staged in LDS.
+// A workgroup transforms `B` lines of length n at once; element e of line l lives at lds[e*B + l].
+// ------------------------------------------------------------------------------------------------
+struct FftPlan {
+    int n;
+    int numRadices;
+    int radix[FFT_MAX_RADICES];
+};
+
+struct FftArgs {
+    FftPlan plan;
+    int B;                 // lines per workgroup
+    int numInner;          // lines are indexed (outer, inner); tiles of B consecutive inner lines
+    int numOuter;
+    long long inOuterStride, inInnerStride, inElemStride;     // in elements of the input type
+    long long outOuterStride, outInnerStride, outElemStride;
+    int mode;              // 0 c2c, 1 r2c (real in, first n/2+1 out), 2 c2r (n/2+1 in, real out), 3 c2c forward * eterm then backward
+    int sign;              // -1 forward, +1 backward (ignored for mode 3)
+    const float2* twiddle; // exp(-2 pi i k/n), k = 0..n-1
+    const void* in;
+    void* out;
+    const float* eterm;    // mode 3: same indexing as `in`
+    double* energyBuffer;  // mode 3 with energy
+    int energySlots;
+    int nzFull;            // mode 3: full z dimension (for the Hermitian weights); inner index = kz
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// One Stockham pass of radix R over all B lines.  `sign` selects forward (-1) or backward (+1).
+template <int R>
+__device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2* __restrict__ dst, int n, int Ns, int B, int BP, int sign,
+                                         const float2* __restrict__ tw) {
+    const int butterflies = n / R;
+    for (int idx = threadIdx.x; idx < butterflies * B; idx += FFT_THREADS) {
+        const int line = idx % B, j = idx / B;
+        const int k = j % Ns;
+        float2 v[R];
+        const int twStep = n / (Ns * R);          // twiddle index increment per r for this k
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            float2 x = src[(j + r * butterflies) * BP + line];
+            float2 w = tw[(k * r * twStep) % n];
+            w.y *= -sign;                          // table holds exp(-i...), i.e. forward
+            v[r] = cmul(x, w);
+        }
+        float2 o[R];
+#pragma unroll
+        for (int p = 0; p < R; p++) {
+            float2 acc = v[0];
+#pragma unroll
+            for (int r = 1; r < R; r++) {
+                float2 w = tw[((p * r) % R) * (n / R)];
+                w.y *= -sign;
+                float2 m = cmul(v[r], w);
+                acc.x += m.x; acc.y += m.y;
+            }
+            o[p] = acc;
+        }
+        const int j0 = (j / Ns) * Ns * R + k;
+#pragma unroll
+        for (int p = 0; p < R; p++) dst[(j0 + p * Ns) * BP + line] = o[p];
+    }
+}
+
+// Runs all passes; returns the buffer that holds the result.
+__device__ __forceinline__ float2* fft_lines(const FftPlan& plan, float2* bufA, float2* bufB, int B, int BP, int sign, const float2* tw) {
+    float2* src = bufA;
+    float2* dst = bufB;
+    int Ns = 1;
+    for (int s = 0; s < plan.numRadices; s++) {
+        const int R = plan.radix[s];
+        switch (R) {
+            case 2: fft_pass<2>(src, dst, plan.n, Ns, B, BP, sign, tw); break;
+            case 3: fft_pass<3>(src, dst, plan.n, Ns, B, BP, sign, tw); break;
+            case 4: fft_pass<4>(src, dst, plan.n, Ns, B, BP, sign, tw); break;
+            case 5: fft_pass<5>(src, dst, plan.n, Ns, B, BP, sign, tw); break;
+            case 7: fft_pass<7>(src, dst, plan.n, Ns, B, BP, sign, tw); break;
+            default: fft_pass<8>(src, dst, plan.n, Ns, B, BP, sign, tw); break;
+        }
+        Ns *= R;
+        __syncthreads();
+        float2* t = src; src = dst; dst = t;
+    }
+    return src;
+}
+
+__global__ __launch_bounds__(FFT_THREADS) void fft_kernel(FftArgs a) {
+    __shared__ float2 bufA[FFT_MAX_LDS];
+    __shared__ float2 bufB[FFT_MAX_LDS];
+    __shared__ double energyPartial[FFT_THREADS / 64];
+    const int n = a.plan.n, B = a.B, BP = a.B + 1;   // LDS line stride B+1: conflict-free for both staging orders
+    const int tilesPerOuter = (a.numInner + B - 1) / B;
+    const int outer = blockIdx.x / tilesPerOuter;
+    const int inner0 = (blockIdx.x % tilesPerOuter) * B;
+    const int nIn = a.mode == 2 ? n / 2 + 1 : n;
+    const int nOut = a.mode == 1 ? n / 2 + 1 : n;
+    const bool elemFastIn = a.inElemStride == 1;
+    // ---- load
+    for (int idx = threadIdx.x; idx < nIn * B; idx += FFT_THREADS) {
+        int line, e;
+        if (elemFastIn) { e = idx % nIn; line = idx / nIn; } else { line = idx % B; e = idx / B; }
+        float2 v = make_float2(0.f, 0.f);
+        if (inner0 + line < a.numInner) {
+            const long long off = outer * a.inOuterStride + (inner0 + line) * a.inInnerStride + e * a.inElemStride;
+            if (a.mode == 1) v.x = ((const float*) a.in)[off];
+            else v = ((const float2*) a.in)[off];
+        }
+        bufA[e * BP + line] = v;
+        if (a.mode == 2 && e > 0 && e < n - e) bufA[(n - e) * BP + line] = make_float2(v.x, -v.y);   // Hermitian completion
+    }
+    __syncthreads();
+    float2* res;
+    if (a.mode == 3) {
+        res = fft_lines(a.plan, bufA, bufB, B, BP, -1, a.twiddle);
+        double energy = 0;
+        for (int idx = threadIdx.x; idx < n * B; idx += FFT_THREADS) {
+            const int line = idx % B, e = idx / B;
+            float2 v = res[e * BP + line];
+            float et = 0.f;
+            const int kz = inner0 + line;
+            if (kz < a.numInner) et = a.eterm[outer * a.inOuterStride + kz * a.inInnerStride + e * a.inElemStride];
+            if (a.energyBuffer != nullptr) {
+                const float wgt = (kz == 0 || 2 * kz == a.nzFull) ? 1.f : 2.f;
+                energy += (double) (wgt * et * (v.x * v.x + v.y * v.y));
+            }
+            res[e * BP + line] = make_float2(v.x * et, v.y * et);
+        }
+        if (a.energyBuffer != nullptr) {
+            energy = wave_sum(energy);
+            if ((threadIdx.x & 63) == 0) energyPartial[threadIdx.x >> 6] = energy;
+        }
+        __syncthreads();
+        if (a.energyBuffer != nullptr && threadIdx.x == 0) {
+            double e = 0;
+            for (int w = 0; w < FFT_THREADS / 64; w++) e += energyPartial[w];
+            atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], 0.5 * e);
+        }
+        float2* other = res == bufA ? bufB : bufA;
+        res = fft_lines(a.plan, res, other, B, BP, +1, a.twiddle);
+    }
+    else {
+        res = fft_lines(a.plan, bufA, bufB, B, BP, a.sign, a.twiddle);
+    }
+    // ---- store
+    const bool elemFastOut = a.outElemStride == 1;
+    for (int idx = threadIdx.x; idx < nOut * B; idx += FFT_THREADS) {
+        int line, e;
+        if (elemFastOut) { e = idx % nOut; line = idx / nOut; } else { line = idx % B; e = idx / B; }
+        if (inner0 + line < a.numInner) {
+            const long long off = outer * a.outOuterStride + (inner0 + line) * a.outInnerStride + e * a.outElemStride;
+            const float2 v = res[e * BP + line];
+            if (a.mode == 2) ((float*) a.out)[off] = v.x;
+            else ((float2*) a.out)[off] = v;
+        }
+    }
+}
+
+FftPlan make_plan(int n) {
+    FftPlan p;
+    p.n = n; p.numRadices = 0;
+    int m = n;
+    const int cand[6] = {8, 4, 2, 3, 5, 7};
+    // power-of-two part first (as 8s, then a 4 or 2), then odd primes
+    for (int c = 0; c < 6; c++)
+        while (m % cand[c] == 0 && p.numRadices < FFT_MAX_RADICES) { p.radix[p.numRadices++] = cand[c]; m /= cand[c]; }
+    if (m != 1) p.n = -1;   // unsupported size
+    return p;
+}
+
+int lines_per_group(int n) {
+    int b = FFT_MAX_LDS / n - 1;     // (b+1)*n elements of LDS per buffer
+    if (b > 16) b = 16;
+    if (b < 1) b = 1;
+    return b;
+}
+
+}  // namespace
+
+extern "C" int ommhip_fft_supported_size(int n) {
+    if (n < 2 || 2 * n > FFT_MAX_LDS) return 0;
+    return make_plan(n).n == n ? 1 : 0;
+}
+
+extern "C" int ommhip_pme_build_eterm(const ommhip_pme* pme, void* stream) {
+    EtermArgs a;
+    a.nx = pme->nx; a.ny = pme->ny; a.nz = pme->nz; a.nzc = pme->nz / 2 + 1;
+    const double* b = pme->box;
+    const double det = b[0] * b[2] * b[5];
+    // ReferencePME.cpp:196-204
+    a.r00 = b[2] * b[5] / det;
+    a.r10 = -b[1] * b[5] / det; a.r11 = b[0] * b[5] / det;
+    a.r20 = (b[1] * b[4] - b[2] * b[3]) / det; a.r21 = -b[0] * b[4] / det; a.r22 = b[0] * b[2] / det;
+    a.alpha = pme->alpha; a.volume = det;
+    a.modX = pme->moduli_x; a.modY = pme->moduli_y; a.modZ = pme->moduli_z;
+    a.eterm = (float*) pme->eterm;
+    const size_t total = (size_t) a.nx * a.ny * a.nzc;
+    hipLaunchKernelGGL(pme_build_eterm, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream, a);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, int padded_atoms, long long* force_d,
+                                     double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
+    hipStream_t st = (hipStream_t) stream;
+    const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
+    PmeArgs pa;
+    pa.paddedAtoms = padded_atoms; pa.nx = nx; pa.ny = ny; pa.nz = nz;
+    const double* b = pme->box;
+    const double det = b[0] * b[2] * b[5];
+    pa.recip.r00 = (float) (b[2] * b[5] / det);
+    pa.recip.r10 = (float) (-b[1] * b[5] / det); pa.recip.r11 = (float) (b[0] * b[5] / det);
+    pa.recip.r20 = (float) ((b[1] * b[4] - b[2] * b[3]) / det); pa.recip.r21 = (float) (-b[0] * b[4] / det); pa.recip.r22 = (float) (b[0] * b[2] / det);
+    pa.posq = (const float4*) posq_d; pa.grid = (float*) pme->grid_real; pa.force = force_d;
+    float2* cgrid = (float2*) pme->grid_complex;
+
+    hipMemsetAsync(pa.grid, 0, sizeof(float) * (size_t) nx * ny * nz, st);
+    const int spreadBlocks = (padded_atoms * 8 + 255) / 256;
+    hipLaunchKernelGGL(pme_spread, dim3(spreadBlocks), dim3(256), 0, st, pa);
+
+    FftArgs f;
+    // ---- forward z: real [nx*ny][nz] -> complex [nx*ny][nzc]
+    f.plan = make_plan(nz); f.B = lines_per_group(nz); f.numOuter = 1; f.numInner = nx * ny;
+    f.inOuterStride = 0; f.inInnerStride = nz; f.inElemStride = 1;
+    f.outOuterStride = 0; f.outInnerStride = nzc; f.outElemStride = 1;
+    f.mode = 1; f.sign = -1; f.twiddle = (const float2*) pme->twiddle_z; f.in = pa.grid; f.out = cgrid;
+    f.eterm = nullptr; f.energyBuffer = nullptr; f.energySlots = 1; f.nzFull = nz;
+    hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+    // ---- forward y: for each x, tiles of kz
+    f.plan = make_plan(ny); f.B = lines_per_group(ny); f.numOuter = nx; f.numInner = nzc;
+    f.inOuterStride = (long long) ny * nzc; f.inInnerStride = 1; f.inElemStride = nzc;
+    f.outOuterStride = f.inOuterStride; f.outInnerStride = 1; f.outElemStride = nzc;
+    f.mode = 0; f.sign = -1; f.twiddle = (const float2*) pme->twiddle_y; f.in = cgrid; f.out = cgrid;
+    hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+    // ---- x: forward, multiply by the influence function (+ energy), backward -- one pass over HBM
+    f.plan = make_plan(nx); f.B = lines_per_group(nx); f.numOuter = ny; f.numInner = nzc;
+    f.inOuterStride = nzc; f.inInnerStride = 1; f.inElemStride = (long long) ny * nzc;
+    f.outOuterStride = nzc; f.outInnerStride = 1; f.outElemStride = (long long) ny * nzc;
+    f.mode = 3; f.sign = -1; f.twiddle = (const float2*) pme->twiddle_x; f.in = cgrid; f.out = cgrid;
+    f.eterm = (const float*) pme->eterm; f.energyBuffer = include_energy ? energy_buffer_d : nullptr; f.energySlots = energy_slots;
+    hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+    // ---- backward y
+    f.plan = make_plan(ny); f.B = lines_per_group(ny); f.numOuter = nx; f.numInner = nzc;
+    f.inOuterStride = (long long) ny * nzc; f.inInnerStride = 1; f.inElemStride = nzc;
+    f.outOuterStride = f.inOuterStride; f.outInnerStride = 1; f.outElemStride = nzc;
+    f.mode = 0; f.sign = +1; f.twiddle = (const float2*) pme->twiddle_y; f.eterm = nullptr; f.energyBuffer = nullptr;
+    hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+    // ---- backward z: complex [nx*ny][nzc] -> real [nx*ny][nz]
+    f.plan = make_plan(nz); f.B = lines_per_group(nz); f.numOuter = 1; f.numInner = nx * ny;
+    f.inOuterStride = 0; f.inInnerStride = nzc; f.inElemStride = 1;
+    f.outOuterStride = 0; f.outInnerStride = nz; f.outElemStride = 1;
+    f.mode = 2; f.sign = +1; f.twiddle = (const float2*) pme->twiddle_z; f.in = cgrid; f.out = pa.grid;
+    hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+
+    hipLaunchKernelGGL(pme_interpolate, dim3(spreadBlocks), dim3(256), 0, st, pa);
+    return (int) hipGetLastError();
+}
+
+// Raw 3-D transforms for unit tests (pattern of platforms/cuda/tests/TestCudaFFT3D.cpp:52-108).
+extern "C" int ommhip_fft3d_r2c_c2r(const ommhip_pme* pme, int forward, void* stream) {
+    hipStream_t st = (hipStream_t) stream;
+    const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
+    float2* cgrid = (float2*) pme->grid_complex;
+    FftArgs f;
+    f.eterm = nullptr; f.energyBuffer = nullptr; f.energySlots = 1; f.nzFull = nz;
+    auto zpass = [&](bool fwd) {
+        f.plan = make_plan(nz); f.B = lines_per_group(nz); f.numOuter = 1; f.numInner = nx * ny;
+        f.inOuterStride = 0; f.outOuterStride = 0; f.inElemStride = 1; f.outElemStride = 1;
+        f.twiddle = (const float2*) pme->twiddle_z;
+        if (fwd) { f.inInnerStride = nz; f.outInnerStride = nzc; f.mode = 1; f.sign = -1; f.in = pme->grid_real; f.out = cgrid; }
+        else { f.inInnerStride = nzc; f.outInnerStride = nz; f.mode = 2; f.sign = +1; f.in = cgrid; f.out = pme->grid_real; }
+        hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+    };
+    auto ypass = [&](int sign) {
+        f.plan = make_plan(ny); f.B = lines_per_group(ny); f.numOuter = nx; f.numInner = nzc;
+        f.inOuterStride = (long long) ny * nzc; f.inInnerStride = 1; f.inElemStride = nzc;
+        f.outOuterStride = f.inOuterStride; f.outInnerStride = 1; f.outElemStride = nzc;
+        f.mode = 0; f.sign = sign; f.twiddle = (const float2*) pme->twiddle_y; f.in = cgrid; f.out = cgrid;
+        hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+    };
+    auto xpass = [&](int sign) {
+        f.plan = make_plan(nx); f.B = lines_per_group(nx); f.numOuter = ny; f.numInner = nzc;
+        f.inOuterStride = nzc; f.inInnerStride = 1; f.inElemStride = (long long) ny * nzc;
+        f.outOuterStride = nzc; f.outInnerStride = 1; f.outElemStride = (long long) ny * nzc;
+        f.mode = 0; f.sign = sign; f.twiddle = (const float2*) pme->twiddle_x; f.in = cgrid; f.out = cgrid;
+        hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+    };
+    if (forward) { zpass(true); ypass(-1); xpass(-1); }
+    else { xpass(+1); ypass(+1); zpass(false); }
+    return (int) hipGetLastError();
+}

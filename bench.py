@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py -- ns/day of the MD hot path (NonbondedForce direct space + PME + LangevinMiddle/SETTLE) on the
+OpenMM "HIP" platform, one process per GPU.
+
+    python bench.py --gpus 1 --steps 3000 --warmup 300
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): a DHFR-sized system -- 23 558 atoms in a 6.223 nm
+cube, PME, cutoff 0.9 nm, Ewald tolerance 5e-4 (alpha 2.92/nm, grid 56^3), LangevinMiddleIntegrator 300 K,
+1/ps, X-H constraints + rigid water, dt 2 fs -- generated synthetically (openmm_amd/testsystems.py:dhfr_like).
+A "step" is one MD step = one pass of the hot path.  The timing protocol is the one of examples/benchmark.py:9-18:
+warm-up steps, then time step(K) followed by getState(energy), which forces a device sync.
+
+Multi-GPU: the path does not shard in this round (domain decomposition is SURVEY.md §8e, planned); --gpus N runs
+N independent replicas of the workload, one per GPU, and reports the aggregate ns/day ("scaling": "weak").
+
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (direct-space pair kernel, measured with HIP
+events on the stream the kernel runs on) and `cpu_baseline` (the reference's own platforms/cpu built into
+oracle/_ref, timed on this host on a bounded number of steps of the same System).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3000)
+    p.add_argument("--warmup", type=int, default=300)
+    p.add_argument("--dt-fs", type=float, default=2.0)
+    p.add_argument("--workload", default="dhfr", choices=["dhfr", "water24k", "water98k"])
+    p.add_argument("--cpu-steps", type=int, default=150, help="steps of the CPU-platform baseline (0 disables)")
+    p.add_argument("--no-roofline", action="store_true")
+    return p.parse_args()
+
+
+def make_workload(name, seed):
+    from openmm_amd import testsystems as T
+    if name == "dhfr":
+        return T.dhfr_like(seed=seed)
+    if name == "water24k":
+        return T.water_box(20, seed=seed)
+    return T.water_box(32, seed=seed)
+
+
+def run_platform(w, platform, dt_ps, steps, warmup, props=None):
+    """-> (seconds for `steps`, final State, context)"""
+    from openmm_amd import harness as H
+    system, nb = w.build()
+    integ = H.Integrator(H.LANGEVIN_MIDDLE, dt_ps, 300.0, 1.0, seed=1, constraintTolerance=1e-5)
+    ctx = H.Context(system, integ, platform, props)
+    ctx.setPositions(w.positions)
+    ctx.applyConstraints(1e-5)
+    if getattr(w, "velocities", None) is not None:
+        ctx.setVelocities(w.velocities)          # equilibrated start (tests/golden fixture)
+    else:
+        ctx.setVelocitiesToTemperature(300.0, 1)
+    integ.step(warmup)
+    ctx.getState(getEnergy=True)
+    return system, nb, integ, ctx
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    from openmm_amd import capi, harness as H
+    H.load_hip_platform()
+    kernels = capi.load()
+    plugin = C.CDLL(os.path.join(H.LIB_DIR, "libOpenMMHIP.so"))
+
+    dt_ps = args.dt_fs * 1e-3
+    w = make_workload(args.workload, seed=1 + rank)
+    props = {"DeviceIndex": str(local_rank)}
+    system, nb, integ, ctx = run_platform(w, "HIP", dt_ps, 0, args.warmup, props)
+    device_name = ctx.getPlatformProperty("DeviceName")
+
+    def barrier():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    profile = not args.no_roofline
+    if profile:
+        kernels.lib.ommhip_profile_reset()
+        kernels.lib.ommhip_profile_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    integ.step(args.steps)
+    st = ctx.getState(getEnergy=True)        # blocks until the device is idle
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if profile:
+        kernels.lib.ommhip_profile_enable(0)
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if not np.isfinite(st.potentialEnergy):
+        raise RuntimeError("simulation blew up: potential energy is not finite")
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    ns_per_day_one = args.dt_fs * 1e-6 * args.steps / elapsed * 86400.0
+    value = ns_per_day_one * world
+    out = {
+        "metric": "ns/day (DHFR PME 2 fs) at 1/2/4/8 MI355X; force max-rel-err vs Reference",
+        "value": round(value, 3), "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %d atoms, PME cutoff 0.9 nm grid %s, LangevinMiddle %.0f fs, X-H constraints + rigid water; %s" % (
+            w.name, w.num_atoms, "x".join(str(g) for g in nb.getPMEParametersInContext(ctx)[1:]), args.dt_fs,
+            "independent replicas, one per GPU" if world > 1 else "single GPU"),
+            "precision": "mixed (f32 forces, fixed-point accumulation, f64 integration)", "device": device_name},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (direct-space pair kernel)
+        if profile:
+            stats = (C.c_longlong * 8)()
+            plugin.ommhip_plugin_nl_stats(stats)
+            chunks, rows = stats[2], stats[3]
+            calls, total_ms = C.c_longlong(), C.c_double()
+            timers = {}
+            for name, idx in (("nb_direct", 0), ("nl_update", 1), ("pme_spread", 2), ("pme_fft", 3), ("pme_interpolate", 4)):
+                kernels.lib.ommhip_profile_collect(idx, C.byref(calls), C.byref(total_ms))
+                timers[name] = {"calls": calls.value, "avg_us": (1e3 * total_ms.value / calls.value) if calls.value else None}
+            # algorithmic bytes of one launch: per row 64 j-slots x (index 4 + mask 4 + posq 16 + sigEps 8 + force 24)
+            # plus per chunk 32 i-atoms x (posq 16 + sigEps 8 + force 24)
+            algo_bytes = rows * 64 * 56 + chunks * 32 * 48
+            avg_us = timers["nb_direct"]["avg_us"]
+            achieved = algo_bytes / (avg_us * 1e-6) / 1e9 if avg_us else None
+            out["roofline"] = {"bound": "hbm", "kernel": "nb_direct", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5) if achieved else None, "traffic": None,
+                               "algorithmic_bytes_per_launch": int(algo_bytes), "avg_kernel_us": round(avg_us, 3) if avg_us else None,
+                               "rows": int(rows), "chunks": int(chunks), "rebuilds": int(stats[5]),
+                               "pair_evals_per_launch": int(rows) * 64 * 32, "kernel_timers_us": timers,
+                               "note": "working set is cache-resident at this size; the kernel is FP32-VALU bound, see DESIGN.md"}
+        # ---- CPU baseline: the reference's platforms/cpu on the same System, bounded sample
+        if args.cpu_steps > 0:
+            try:
+                H.load_cpu_platform()
+                csys, cnb, cinteg, cctx = run_platform(w, "CPU", dt_ps, 0, 5)
+                t0 = time.perf_counter()
+                cinteg.step(args.cpu_steps)
+                cctx.getState(getEnergy=True)
+                cpu_elapsed = time.perf_counter() - t0
+                threads = cctx.getPlatformProperty("Threads")
+                out["cpu_baseline"] = {"value": round(args.dt_fs * 1e-6 * args.cpu_steps / cpu_elapsed * 86400.0, 4), "unit": "ns/day",
+                                       "cores": int(threads) if threads else os.cpu_count(), "kind": "reference",
+                                       "sample": "%d steps of the same System on platforms/cpu from oracle/_ref (%.1f s; PME via the reference's single-threaded fftpack path, FFTW plugin not available)" % (args.cpu_steps, cpu_elapsed),
+                                       "ms_per_step": round(1e3 * cpu_elapsed / args.cpu_steps, 3)}
+                cctx.close()
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "ns/day", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %s" % e}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

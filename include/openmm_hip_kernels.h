@@ -55,6 +55,21 @@ int ommhip_event_elapsed_ms(void* start, void* stop, float* ms);
 int ommhip_stream_wait_event(void* stream, void* event);
 const char* ommhip_error_string(int code);
 
+/* Opt-in kernel timing (HIP events on the launching stream).  Timers: */
+enum {
+    OMMHIP_TIMER_NB_DIRECT = 0,      /* the direct-space pair kernel */
+    OMMHIP_TIMER_NL_UPDATE = 1,      /* displacement check + (conditional) neighbour-list rebuild */
+    OMMHIP_TIMER_PME_SPREAD = 2,
+    OMMHIP_TIMER_PME_FFT = 3,        /* the five FFT passes incl. the fused convolution */
+    OMMHIP_TIMER_PME_INTERPOLATE = 4,
+    OMMHIP_PROFILE_NUM_TIMERS = 8
+};
+int ommhip_profile_enable(int enabled);
+int ommhip_profile_reset(void);
+int ommhip_profile_begin(int timer, void* stream);
+int ommhip_profile_end(int timer, void* stream);
+int ommhip_profile_collect(int timer, long long* calls, double* total_ms);   /* blocks until recorded events complete */
+
 /* ------------------------------------------------------------------------------------------
  * Per-step state conversion.
  * Reference: there is no equivalent (Reference keeps vector<Vec3>); on GPU platforms this is what
@@ -147,6 +162,98 @@ int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, int padded_
                           double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
 /* test hook: forward (grid_real -> grid_complex) or backward (grid_complex -> grid_real) unnormalised 3-D transform */
 int ommhip_fft3d_r2c_c2r(const ommhip_pme* pme, int forward, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-term forces on the double-precision positions (atom order), one thread per term.
+ *   EXCEPTION14      atoms (i,j)      params (chargeProd, sigma, epsilon)   ReferenceLJCoulomb14.cpp
+ *   EWALD_EXCLUSION  atoms (i,j)      params unused; uses charge_d, alpha   ReferenceLJCoulombIxn.cpp:462-523
+ *   HARMONIC_BOND    atoms (i,j)      params (length, k)                    kernels.h:276 CalcHarmonicBondForceKernel
+ *   HARMONIC_ANGLE   atoms (i,j,k)    params (angle, k)                     kernels.h:346 CalcHarmonicAngleForceKernel
+ *   PERIODIC_TORSION atoms (i,j,k,l)  params (k, phase, periodicity)        kernels.h:416 CalcPeriodicTorsionForceKernel
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    OMMHIP_TERM_EXCEPTION14 = 0,
+    OMMHIP_TERM_EWALD_EXCLUSION = 1,
+    OMMHIP_TERM_HARMONIC_BOND = 2,
+    OMMHIP_TERM_HARMONIC_ANGLE = 3,
+    OMMHIP_TERM_PERIODIC_TORSION = 4
+};
+typedef struct ommhip_term_list {
+    int num_terms;
+    const int* atoms;          /* device int[num_terms * atomsPerTerm], atom indices */
+    const double* params;      /* device double[num_terms * paramsPerTerm] */
+} ommhip_term_list;
+
+int ommhip_term_forces(int kind, const ommhip_term_list* terms, const void* pos_d, const int* slot_of_atom_d, int padded_atoms,
+                       const double box[6], int periodic, const double* charge_d, double alpha,
+                       long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
+
+/* Classic Ewald reciprocal sum for rectangular boxes (ReferenceLJCoulombIxn.cpp:272-367).
+ * structure_d: device double2[kmax_x*(2 kmax_y-1)*(2 kmax_z-1)] scratch. */
+int ommhip_ewald_reciprocal(const void* pos_d, const double* charge_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms,
+                            const double box[6], double alpha, int kmax_x, int kmax_y, int kmax_z, void* structure_d,
+                            long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Integration, constraints, kinetic energy (FP64, atom order).
+ * Replaces IntegrateVerletStepKernel / IntegrateLangevinStepKernel / IntegrateLangevinMiddleStepKernel
+ * (kernels.h:1033-1061,1160-1188,1193-1221; Reference: ReferenceVerletDynamics.cpp:76-119,
+ * ReferenceStochasticDynamics.cpp:89-194, ReferenceLangevinMiddleDynamics.cpp:54-127) and
+ * ApplyConstraintsKernel (kernels.h:220-247; ReferenceSETTLEAlgorithm.cpp:54-244,
+ * ReferenceCCMAAlgorithm.cpp:205-316).  The host sequences stage / constraint / stage exactly as the
+ * Reference update() functions do.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ommhip_integrator_state {
+    int num_atoms, padded_atoms;
+    double dt;
+    double vscale, fscale, noisescale;   /* Langevin coefficients (see integrate.hip) */
+    unsigned long long seed, step;       /* counter-based RNG: (seed, step, atom) -> normals */
+    void* pos;                 /* double4[num_atoms] (x,y,z,-) */
+    void* vel;                 /* double4[num_atoms] (vx,vy,vz,1/mass) */
+    void* xp;                  /* double4[num_atoms] trial positions */
+    void* oldx;                /* double4[num_atoms] (LangevinMiddle) */
+    const long long* force;    /* fixed-point, slot order */
+    const int* slot_of_atom;
+} ommhip_integrator_state;
+
+enum {
+    OMMHIP_STAGE_VERLET_1 = 0,          /* v += F dt/m ; xp = x + v dt */
+    OMMHIP_STAGE_FINISH_POSITIONS = 1,  /* v = (xp - x)/dt ; x = xp */
+    OMMHIP_STAGE_LANGEVIN_1 = 2,        /* v = a v + f F/m + noise ; xp = x + v dt */
+    OMMHIP_STAGE_LMIDDLE_1 = 3,         /* v += F dt/m */
+    OMMHIP_STAGE_LMIDDLE_2 = 4,         /* half drift, O-step, half drift ; oldx = xp */
+    OMMHIP_STAGE_LMIDDLE_3 = 5          /* v += (xp - oldx)/dt ; x = xp */
+};
+int ommhip_integrate_stage(int stage, const ommhip_integrator_state* s, void* stream);
+/* out_d (double4[num_atoms]) = vel + force*shift/m   (ReferenceKernels.cpp:146-160) */
+int ommhip_shifted_velocities(const ommhip_integrator_state* s, double shift, void* out_d, void* stream);
+/* result_d[0] = 1/2 sum m v^2 */
+int ommhip_kinetic_energy(const void* vel_d, int num_atoms, double* result_d, void* stream);
+
+/* SETTLE: atoms_d int4[n] (apex,b,c,-), dist_d double2[n] (apex-leg, base).  velocities=0: corrects
+ * target_d (trial positions) against pos_d; velocities=1: corrects target_d (velocities). */
+int ommhip_settle(int num_clusters, const int* atoms_d, const double* dist_d, const void* pos_d, void* target_d,
+                  const void* vel_mass_d, int velocities, void* stream);
+/* SHAKE clusters: atoms_d int4[n] (centre, s1, s2, s3; -1 unused), dist_d double4[n] */
+int ommhip_shake(int num_clusters, const int* atoms_d, const double* dist_d, const void* pos_d, void* target_d,
+                 const void* vel_mass_d, int velocities, double tol, int max_iterations, void* stream);
+typedef struct ommhip_ccma {
+    int num_constraints;
+    const int* atoms;          /* device int2[n] */
+    const double* distance;    /* device double[n] */
+    double* delta;             /* device double[n] scratch */
+    double* delta2;            /* device double[n] scratch */
+    const int* row_start;      /* CSR of the approximate inverse coupling matrix (ReferenceCCMAAlgorithm.cpp:57-196) */
+    const int* col;
+    const double* value;
+    int* converged;            /* device int: number of converged constraints after phase 0 */
+} ommhip_ccma;
+/* phase 0: compute constraint deltas + converged count; phase 1: matrix multiply + position/velocity update */
+int ommhip_ccma_iteration(const ommhip_ccma* c, const void* pos_d, void* target_d, const void* vel_mass_d,
+                          int velocities, double tol, int phase, void* stream);
+
+/* RemoveCMMotionKernel::execute (kernels.h:1464; ReferenceKernels.cpp:2712-2740).  vel_d: double4 (vx,vy,vz,1/m). */
+int ommhip_remove_cm_motion(void* vel_d, int num_atoms, double* scratch4_d, void* stream);
 
 #ifdef __cplusplus
 }

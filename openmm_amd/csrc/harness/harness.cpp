@@ -1,0 +1,159 @@
+/* libommharness.so -- a small C API over the OpenMM C++ API (System / Force / Integrator / Context),
+ * bound from Python with ctypes (openmm_amd/harness.py).  It exists because the reference's SWIG
+ * Python module cannot be built in this environment (no swig/doxygen); tests and bench.py use it
+ * to build Systems and to run the same Context on the "HIP", "CPU" and "Reference" platforms.
+ * It mirrors the public API names it wraps (openmmapi/include/openmm/*.h); it contains no physics.
+ */
+#include "OpenMM.h"
+#include <cstring>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+using namespace OpenMM;
+using namespace std;
+
+static string lastError;
+
+#define GUARD(...) try { __VA_ARGS__; return 0; } catch (const std::exception& e) { lastError = e.what(); return 1; } catch (...) { lastError = "unknown error"; return 1; }
+
+extern "C" {
+
+const char* omm_last_error() { return lastError.c_str(); }
+
+int omm_load_plugin(const char* path) { GUARD(Platform::loadPluginLibrary(path)) }
+int omm_load_plugins_from_directory(const char* dir) { GUARD(Platform::loadPluginsFromDirectory(dir)) }
+int omm_num_platforms() { return Platform::getNumPlatforms(); }
+const char* omm_platform_name(int i) { return Platform::getPlatform(i).getName().c_str(); }
+double omm_platform_speed(int i) { return Platform::getPlatform(i).getSpeed(); }
+const char* omm_version() { static string v; v = Platform::getOpenMMVersion(); return v.c_str(); }
+
+/* ---- System */
+void* omm_system_create() { return new System(); }
+void omm_system_destroy(void* s) { delete (System*) s; }
+int omm_system_add_particles(void* s, int n, const double* masses) { GUARD(for (int i = 0; i < n; i++) ((System*) s)->addParticle(masses[i])) }
+int omm_system_num_particles(void* s) { return ((System*) s)->getNumParticles(); }
+int omm_system_set_box(void* s, const double* b) { GUARD(((System*) s)->setDefaultPeriodicBoxVectors(Vec3(b[0], b[1], b[2]), Vec3(b[3], b[4], b[5]), Vec3(b[6], b[7], b[8]))) }
+int omm_system_add_constraints(void* s, int n, const int* pairs, const double* dist) { GUARD(for (int i = 0; i < n; i++) ((System*) s)->addConstraint(pairs[2 * i], pairs[2 * i + 1], dist[i])) }
+int omm_system_num_constraints(void* s) { return ((System*) s)->getNumConstraints(); }
+
+/* ---- NonbondedForce (openmmapi/include/openmm/NonbondedForce.h) */
+void* omm_nonbonded_create(void* s, int method, double cutoff, double ewaldTol, int useDispersion, int useSwitch, double switchDist) {
+    try {
+        NonbondedForce* f = new NonbondedForce();
+        f->setNonbondedMethod((NonbondedForce::NonbondedMethod) method);
+        f->setCutoffDistance(cutoff);
+        f->setEwaldErrorTolerance(ewaldTol);
+        f->setUseDispersionCorrection(useDispersion != 0);
+        f->setUseSwitchingFunction(useSwitch != 0);
+        f->setSwitchingDistance(switchDist);
+        ((System*) s)->addForce(f);
+        return f;
+    } catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
+int omm_nonbonded_add_particles(void* f, int n, const double* q, const double* sig, const double* eps) { GUARD(for (int i = 0; i < n; i++) ((NonbondedForce*) f)->addParticle(q[i], sig[i], eps[i])) }
+int omm_nonbonded_add_exceptions(void* f, int n, const int* pairs, const double* qq, const double* sig, const double* eps) {
+    GUARD(for (int i = 0; i < n; i++) ((NonbondedForce*) f)->addException(pairs[2 * i], pairs[2 * i + 1], qq[i], sig[i], eps[i], true))
+}
+int omm_nonbonded_create_exceptions_from_bonds(void* f, int n, const int* pairs, double coulomb14, double lj14) {
+    GUARD(vector<pair<int, int> > bonds; for (int i = 0; i < n; i++) bonds.push_back(make_pair(pairs[2 * i], pairs[2 * i + 1]));
+          ((NonbondedForce*) f)->createExceptionsFromBonds(bonds, coulomb14, lj14))
+}
+int omm_nonbonded_num_exceptions(void* f) { return ((NonbondedForce*) f)->getNumExceptions(); }
+int omm_nonbonded_set_pme_parameters(void* f, double alpha, int nx, int ny, int nz) { GUARD(((NonbondedForce*) f)->setPMEParameters(alpha, nx, ny, nz)) }
+int omm_nonbonded_set_reaction_field_dielectric(void* f, double d) { GUARD(((NonbondedForce*) f)->setReactionFieldDielectric(d)) }
+int omm_nonbonded_set_reciprocal_force_group(void* f, int g) { GUARD(((NonbondedForce*) f)->setReciprocalSpaceForceGroup(g)) }
+int omm_nonbonded_set_exceptions_use_periodic(void* f, int p) { GUARD(((NonbondedForce*) f)->setExceptionsUsePeriodicBoundaryConditions(p != 0)) }
+int omm_nonbonded_get_pme_parameters_in_context(void* f, void* ctx, double* alpha, int* n) {
+    GUARD(((NonbondedForce*) f)->getPMEParametersInContext(*(Context*) ctx, *alpha, n[0], n[1], n[2]))
+}
+int omm_force_set_group(void* f, int g) { GUARD(((Force*) f)->setForceGroup(g)) }
+
+/* ---- bonded forces and CMMotionRemover */
+void* omm_add_harmonic_bonds(void* s, int n, const int* atoms, const double* length, const double* k) {
+    try { HarmonicBondForce* f = new HarmonicBondForce(); for (int i = 0; i < n; i++) f->addBond(atoms[2 * i], atoms[2 * i + 1], length[i], k[i]); ((System*) s)->addForce(f); return f; }
+    catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
+void* omm_add_harmonic_angles(void* s, int n, const int* atoms, const double* angle, const double* k) {
+    try { HarmonicAngleForce* f = new HarmonicAngleForce(); for (int i = 0; i < n; i++) f->addAngle(atoms[3 * i], atoms[3 * i + 1], atoms[3 * i + 2], angle[i], k[i]); ((System*) s)->addForce(f); return f; }
+    catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
+void* omm_add_periodic_torsions(void* s, int n, const int* atoms, const int* periodicity, const double* phase, const double* k) {
+    try { PeriodicTorsionForce* f = new PeriodicTorsionForce(); for (int i = 0; i < n; i++) f->addTorsion(atoms[4 * i], atoms[4 * i + 1], atoms[4 * i + 2], atoms[4 * i + 3], periodicity[i], phase[i], k[i]); ((System*) s)->addForce(f); return f; }
+    catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
+void* omm_add_cmmotion_remover(void* s, int frequency) {
+    try { CMMotionRemover* f = new CMMotionRemover(frequency); ((System*) s)->addForce(f); return f; }
+    catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
+
+/* ---- Integrators: kind 0 Verlet, 1 Langevin, 2 LangevinMiddle */
+void* omm_integrator_create(int kind, double dt, double temperature, double friction, int seed, double constraintTol) {
+    try {
+        Integrator* integ;
+        if (kind == 0) integ = new VerletIntegrator(dt);
+        else if (kind == 1) { LangevinIntegrator* l = new LangevinIntegrator(temperature, friction, dt); l->setRandomNumberSeed(seed); integ = l; }
+        else if (kind == 2) { LangevinMiddleIntegrator* l = new LangevinMiddleIntegrator(temperature, friction, dt); l->setRandomNumberSeed(seed); integ = l; }
+        else throw OpenMMException("unknown integrator kind");
+        integ->setConstraintTolerance(constraintTol);
+        return integ;
+    } catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
+void omm_integrator_destroy(void* i) { delete (Integrator*) i; }
+int omm_integrator_step(void* i, int steps) { GUARD(((Integrator*) i)->step(steps)) }
+int omm_integrator_set_step_size(void* i, double dt) { GUARD(((Integrator*) i)->setStepSize(dt)) }
+
+/* ---- Context.  properties = "key=value;key=value" */
+void* omm_context_create(void* s, void* integ, const char* platformName, const char* properties) {
+    try {
+        Platform& platform = Platform::getPlatformByName(platformName);
+        map<string, string> props;
+        string p = properties == NULL ? "" : properties;
+        stringstream ss(p);
+        string item;
+        while (getline(ss, item, ';')) {
+            size_t eq = item.find('=');
+            if (eq != string::npos) props[item.substr(0, eq)] = item.substr(eq + 1);
+        }
+        return new Context(*(System*) s, *(Integrator*) integ, platform, props);
+    } catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
+void omm_context_destroy(void* c) { delete (Context*) c; }
+const char* omm_context_platform_name(void* c) { return ((Context*) c)->getPlatform().getName().c_str(); }
+const char* omm_context_platform_property(void* c, const char* name) {
+    static string v;
+    try { v = ((Context*) c)->getPlatform().getPropertyValue(*(Context*) c, name); } catch (const std::exception& e) { lastError = e.what(); v = ""; }
+    return v.c_str();
+}
+int omm_context_set_positions(void* c, int n, const double* xyz) {
+    GUARD(vector<Vec3> p(n); for (int i = 0; i < n; i++) p[i] = Vec3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]); ((Context*) c)->setPositions(p))
+}
+int omm_context_set_velocities(void* c, int n, const double* xyz) {
+    GUARD(vector<Vec3> p(n); for (int i = 0; i < n; i++) p[i] = Vec3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]); ((Context*) c)->setVelocities(p))
+}
+int omm_context_set_velocities_to_temperature(void* c, double temperature, int seed) { GUARD(((Context*) c)->setVelocitiesToTemperature(temperature, seed)) }
+int omm_context_set_box(void* c, const double* b) { GUARD(((Context*) c)->setPeriodicBoxVectors(Vec3(b[0], b[1], b[2]), Vec3(b[3], b[4], b[5]), Vec3(b[6], b[7], b[8]))) }
+int omm_context_apply_constraints(void* c, double tol) { GUARD(((Context*) c)->applyConstraints(tol)) }
+int omm_context_set_parameter(void* c, const char* name, double v) { GUARD(((Context*) c)->setParameter(name, v)) }
+int omm_context_minimize(void* c, double tolerance, int maxIterations) { GUARD(LocalEnergyMinimizer::minimize(*(Context*) c, tolerance, maxIterations)) }
+int omm_context_reinitialize(void* c, int preserveState) { GUARD(((Context*) c)->reinitialize(preserveState != 0)) }
+/* flags: 1 positions, 2 velocities, 4 forces, 8 energy.  energies[0] = potential, [1] = kinetic, [2] = time. groups = -1 for all */
+int omm_context_get_state(void* c, int flags, int groups, double* pos, double* vel, double* forces, double* energies) {
+    GUARD(
+        int types = 0;
+        if (flags & 1) types |= State::Positions;
+        if (flags & 2) types |= State::Velocities;
+        if (flags & 4) types |= State::Forces;
+        if (flags & 8) types |= State::Energy;
+        State st = ((Context*) c)->getState(types, false, groups);
+        int n = ((Context*) c)->getSystem().getNumParticles();
+        if (flags & 1) { const vector<Vec3>& v = st.getPositions(); for (int i = 0; i < n; i++) { pos[3 * i] = v[i][0]; pos[3 * i + 1] = v[i][1]; pos[3 * i + 2] = v[i][2]; } }
+        if (flags & 2) { const vector<Vec3>& v = st.getVelocities(); for (int i = 0; i < n; i++) { vel[3 * i] = v[i][0]; vel[3 * i + 1] = v[i][1]; vel[3 * i + 2] = v[i][2]; } }
+        if (flags & 4) { const vector<Vec3>& v = st.getForces(); for (int i = 0; i < n; i++) { forces[3 * i] = v[i][0]; forces[3 * i + 1] = v[i][1]; forces[3 * i + 2] = v[i][2]; } }
+        if (flags & 8) { energies[0] = st.getPotentialEnergy(); energies[1] = st.getKineticEnergy(); }
+        if (energies != NULL) energies[2] = st.getTime();
+    )
+}
+
+}

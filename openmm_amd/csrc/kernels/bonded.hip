@@ -1,0 +1,346 @@
+// Per-term ("bonded-style") force kernels, one thread per term, double precision on the unwrapped
+// double positions (atom order); results go to the fixed-point force buffer (slot order).
+//
+//   * NonbondedForce 1-4 exceptions        ReferenceLJCoulomb14.cpp (via ReferenceKernels.cpp:1000-1007)
+//   * Ewald/PME exclusion correction       ReferenceLJCoulombIxn.cpp:462-523
+//   * HarmonicBondForce                    ReferenceHarmonicBondIxn.cpp:73-112
+//   * HarmonicAngleForce                   ReferenceAngleBondIxn.cpp:70-160
+//   * PeriodicTorsionForce                 ReferenceProperDihedralBond.cpp:75-160, ReferenceBondIxn.cpp:115-205
+//   * classic Ewald reciprocal k-sum       ReferenceLJCoulombIxn.cpp:272-367
+//   * CMMotionRemover                      ReferenceKernels.cpp:2712-2740
+//
+// The work per step is tiny compared with the pair kernel (tens of thousands of terms), so these
+// run in FP64 -- MI355X's FP64 vector rate makes that free and it removes a source of parity noise.
+#include "common.h"
+#include "../../../include/openmm_hip_kernels.h"
+
+using namespace omm;
+
+namespace {
+
+struct TermArgs {
+    int numTerms, paddedAtoms, periodic, includeEnergy, energySlots;
+    BoxD box;
+    double alpha;
+    const double4* pos;
+    const int* slotOfAtom;
+    const int* atoms;          // numTerms * atomsPerTerm
+    const double* params;      // numTerms * paramsPerTerm
+    const double* charge;      // per atom (exclusion correction)
+    omm_fixed* force;
+    double* energyBuffer;
+};
+
+__device__ __forceinline__ double3 delta(const TermArgs& a, int from, int to) {
+    double4 p = a.pos[from], q = a.pos[to];
+    double dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+    if (a.periodic) min_image_d(dx, dy, dz, a.box);
+    return make_double3(dx, dy, dz);
+}
+__device__ __forceinline__ double dot3(double3 a, double3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double3 cross3(double3 a, double3 b) { return make_double3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+
+__device__ __forceinline__ void add_atom_force(const TermArgs& a, int atom, double fx, double fy, double fz) {
+    add_force(a.force, a.paddedAtoms, a.slotOfAtom[atom], fx, fy, fz);
+}
+
+__device__ __forceinline__ void block_add_energy(const TermArgs& a, double e) {
+    if (!a.includeEnergy) return;
+    __shared__ double partial[4];
+    e = wave_sum(e);
+    if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], partial[0] + partial[1] + partial[2] + partial[3]);
+}
+
+__global__ __launch_bounds__(256) void k_exceptions14(TermArgs a) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double energy = 0;
+    if (t < a.numTerms) {
+        int i = a.atoms[2 * t], j = a.atoms[2 * t + 1];
+        double qq = a.params[3 * t], sig = a.params[3 * t + 1], eps4 = 4.0 * a.params[3 * t + 2];
+        double3 d = delta(a, i, j);                      // j - i
+        double invR = 1.0 / sqrt(dot3(d, d));
+        double s2 = sig * invR; s2 *= s2;
+        double s6 = s2 * s2 * s2;
+        double dEdR = (eps4 * (12.0 * s6 - 6.0) * s6 + OMM_ONE_4PI_EPS0_D * qq * invR) * invR * invR;
+        energy = eps4 * (s6 - 1.0) * s6 + OMM_ONE_4PI_EPS0_D * qq * invR;
+        add_atom_force(a, j, dEdR * d.x, dEdR * d.y, dEdR * d.z);
+        add_atom_force(a, i, -dEdR * d.x, -dEdR * d.y, -dEdR * d.z);
+    }
+    block_add_energy(a, energy);
+}
+
+__global__ __launch_bounds__(256) void k_ewald_exclusions(TermArgs a) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double energy = 0;
+    if (t < a.numTerms) {
+        int i = a.atoms[2 * t], j = a.atoms[2 * t + 1];
+        double qq = OMM_ONE_4PI_EPS0_D * a.charge[i] * a.charge[j];
+        double3 d = delta(a, i, j);
+        double r = sqrt(dot3(d, d));
+        double ar = a.alpha * r;
+        double erfAr = erf(ar);
+        if (erfAr > 1e-6) {
+            double invR = 1.0 / r;
+            double dEdR = qq * invR * invR * invR * (erfAr - 2.0 * ar * exp(-ar * ar) * 0.56418958354775628695);
+            add_atom_force(a, j, -dEdR * d.x, -dEdR * d.y, -dEdR * d.z);
+            add_atom_force(a, i, dEdR * d.x, dEdR * d.y, dEdR * d.z);
+            energy = -qq * invR * erfAr;
+        }
+        else
+            energy = -a.alpha * 1.12837916709551257390 * qq;
+    }
+    block_add_energy(a, energy);
+}
+
+__global__ __launch_bounds__(256) void k_harmonic_bonds(TermArgs a) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double energy = 0;
+    if (t < a.numTerms) {
+        int i = a.atoms[2 * t], j = a.atoms[2 * t + 1];
+        double r0 = a.params[2 * t], k = a.params[2 * t + 1];
+        double3 d = delta(a, i, j);
+        double r = sqrt(dot3(d, d));
+        double dl = r - r0;
+        double dEdR = r > 0.0 ? k * dl / r : 0.0;
+        energy = 0.5 * k * dl * dl;
+        add_atom_force(a, i, dEdR * d.x, dEdR * d.y, dEdR * d.z);
+        add_atom_force(a, j, -dEdR * d.x, -dEdR * d.y, -dEdR * d.z);
+    }
+    block_add_energy(a, energy);
+}
+
+__global__ __launch_bounds__(256) void k_harmonic_angles(TermArgs a) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double energy = 0;
+    if (t < a.numTerms) {
+        int ia = a.atoms[3 * t], ib = a.atoms[3 * t + 1], ic = a.atoms[3 * t + 2];
+        double theta0 = a.params[2 * t], k = a.params[2 * t + 1];
+        double3 d0 = delta(a, ia, ib);      // b - a
+        double3 d1 = delta(a, ic, ib);      // b - c
+        double3 p = cross3(d0, d1);
+        double rp = sqrt(dot3(p, p));
+        if (rp < 1.0e-06) rp = 1.0e-06;
+        double r20 = dot3(d0, d0), r21 = dot3(d1, d1);
+        double cosine = dot3(d0, d1) / sqrt(r20 * r21);
+        double angle = cosine >= 1.0 ? 0.0 : (cosine <= -1.0 ? 3.14159265358979323846 : acos(cosine));
+        double dth = angle - theta0;
+        double dEdR = k * dth;
+        energy = 0.5 * k * dth * dth;
+        double termA = dEdR / (r20 * rp), termC = -dEdR / (r21 * rp);
+        double3 fa = cross3(d0, p), fc = cross3(d1, p);
+        fa.x *= termA; fa.y *= termA; fa.z *= termA;
+        fc.x *= termC; fc.y *= termC; fc.z *= termC;
+        add_atom_force(a, ia, fa.x, fa.y, fa.z);
+        add_atom_force(a, ic, fc.x, fc.y, fc.z);
+        add_atom_force(a, ib, -(fa.x + fc.x), -(fa.y + fc.y), -(fa.z + fc.z));
+    }
+    block_add_energy(a, energy);
+}
+
+__global__ __launch_bounds__(256) void k_periodic_torsions(TermArgs a) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double energy = 0;
+    if (t < a.numTerms) {
+        int ia = a.atoms[4 * t], ib = a.atoms[4 * t + 1], ic = a.atoms[4 * t + 2], id = a.atoms[4 * t + 3];
+        double k = a.params[3 * t], phase = a.params[3 * t + 1], periodicity = a.params[3 * t + 2];
+        double3 v0 = delta(a, ib, ia);      // a - b
+        double3 v1 = delta(a, ib, ic);      // c - b
+        double3 v2 = delta(a, id, ic);      // c - d
+        double3 cp0 = cross3(v0, v1), cp1 = cross3(v1, v2);
+        // angle between the two plane normals, asin branch near 0/pi (ReferenceBondIxn.cpp:115-135)
+        double n0 = dot3(cp0, cp0), n1 = dot3(cp1, cp1);
+        double dp = dot3(cp0, cp1) / sqrt(n0 * n1);
+        dp = dp > 1.0 ? 1.0 : (dp < -1.0 ? -1.0 : dp);
+        double angle;
+        if (dp > 0.99 || dp < -0.99) {
+            double3 c = cross3(cp0, cp1);
+            angle = asin(sqrt(dot3(c, c) / (n0 * n1)));
+            if (dp < 0.0) angle = 3.14159265358979323846 - angle;
+        }
+        else
+            angle = acos(dp);
+        if (dot3(v0, cp1) < 0.0) angle = -angle;
+        double deltaAngle = periodicity * angle - phase;
+        double dEdAngle = -k * periodicity * sin(deltaAngle);
+        energy = k * (1.0 + cos(deltaAngle));
+        double normBC = sqrt(dot3(v1, v1));
+        double ff0 = (-dEdAngle * normBC) / n0;
+        double ff3 = (dEdAngle * normBC) / n1;
+        double ff1 = dot3(v0, v1) / dot3(v1, v1);
+        double ff2 = dot3(v2, v1) / dot3(v1, v1);
+        double3 f0 = make_double3(ff0 * cp0.x, ff0 * cp0.y, ff0 * cp0.z);
+        double3 f3 = make_double3(ff3 * cp1.x, ff3 * cp1.y, ff3 * cp1.z);
+        double3 s = make_double3(ff1 * f0.x - ff2 * f3.x, ff1 * f0.y - ff2 * f3.y, ff1 * f0.z - ff2 * f3.z);
+        add_atom_force(a, ia, f0.x, f0.y, f0.z);
+        add_atom_force(a, ib, -(f0.x - s.x), -(f0.y - s.y), -(f0.z - s.z));
+        add_atom_force(a, ic, -(f3.x + s.x), -(f3.y + s.y), -(f3.z + s.z));
+        add_atom_force(a, id, f3.x, f3.y, f3.z);
+    }
+    block_add_energy(a, energy);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Classic Ewald reciprocal sum (rectangular boxes; small systems / TestEwald).
+// Pass 1: one workgroup per k-vector -> structure factor (cs, ss) and energy.
+// Pass 2: one thread per atom sums over all k-vectors.
+// k-vector enumeration order and the half-space convention follow ReferenceLJCoulombIxn.cpp:303-365.
+// ------------------------------------------------------------------------------------------------
+struct EwaldArgs {
+    int numAtoms, paddedAtoms, kx, ky, kz, numK, includeEnergy, energySlots;
+    double recipX, recipY, recipZ, alpha, coeff;     // coeff = ONE_4PI_EPS0*4*pi/V
+    const double4* pos;
+    const double* charge;
+    const int* slotOfAtom;
+    double2* structure;       // [numK] (cs, ss)
+    omm_fixed* force;
+    double* energyBuffer;
+};
+
+__device__ __forceinline__ bool ewald_kvec(const EwaldArgs& a, int index, int& rx, int& ry, int& rz) {
+    // index enumerates rx in [0,kx), ry in (-ky,ky), rz in (-kz,kz); the half space keeps
+    // (rx>0) or (rx==0 && ry>0) or (rx==0 && ry==0 && rz>0).
+    const int ny = 2 * a.ky - 1, nz = 2 * a.kz - 1;
+    rz = index % nz - (a.kz - 1);
+    ry = (index / nz) % ny - (a.ky - 1);
+    rx = index / (nz * ny);
+    if (rx == 0 && (ry < 0 || (ry == 0 && rz <= 0))) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_ewald_structure(EwaldArgs a) {
+    __shared__ double pc[4], ps[4];
+    int rx, ry, rz;
+    const int kIndex = blockIdx.x;
+    const bool valid = ewald_kvec(a, kIndex, rx, ry, rz);
+    double cs = 0, ss = 0;
+    if (valid) {
+        const double kxv = rx * a.recipX, kyv = ry * a.recipY, kzv = rz * a.recipZ;
+        for (int i = threadIdx.x; i < a.numAtoms; i += blockDim.x) {
+            double4 p = a.pos[i];
+            double ph = kxv * p.x + kyv * p.y + kzv * p.z;
+            double s, c;
+            sincos(ph, &s, &c);
+            double q = a.charge[i];
+            cs += q * c; ss += q * s;
+        }
+    }
+    cs = wave_sum(cs); ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) { pc[threadIdx.x >> 6] = cs; ps[threadIdx.x >> 6] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cs = pc[0] + pc[1] + pc[2] + pc[3]; ss = ps[0] + ps[1] + ps[2] + ps[3];
+        a.structure[kIndex] = make_double2(cs, ss);
+        if (valid && a.includeEnergy) {
+            const double kxv = rx * a.recipX, kyv = ry * a.recipY, kzv = rz * a.recipZ;
+            const double k2 = kxv * kxv + kyv * kyv + kzv * kzv;
+            const double ak = exp(-k2 / (4.0 * a.alpha * a.alpha)) / k2;
+            atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], a.coeff * ak * (cs * cs + ss * ss));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ewald_forces(EwaldArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.numAtoms) return;
+    const double4 p = a.pos[i];
+    const double q = a.charge[i];
+    double fx = 0, fy = 0, fz = 0;
+    for (int kIndex = 0; kIndex < a.numK; kIndex++) {
+        int rx, ry, rz;
+        if (!ewald_kvec(a, kIndex, rx, ry, rz)) continue;
+        const double kxv = rx * a.recipX, kyv = ry * a.recipY, kzv = rz * a.recipZ;
+        const double k2 = kxv * kxv + kyv * kyv + kzv * kzv;
+        const double ak = exp(-k2 / (4.0 * a.alpha * a.alpha)) / k2;
+        double s, c;
+        sincos(kxv * p.x + kyv * p.y + kzv * p.z, &s, &c);
+        const double2 sf = a.structure[kIndex];
+        const double f = 2.0 * a.coeff * ak * q * (sf.x * s - sf.y * c);
+        fx += f * kxv; fy += f * kyv; fz += f * kzv;
+    }
+    add_force(a.force, a.paddedAtoms, a.slotOfAtom[i], fx, fy, fz);
+}
+
+// ------------------------------------------------------------------------------------------------
+// CMMotionRemover: momentum reduction (one workgroup) then subtraction.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cm_momentum(const double4* __restrict__ vel, int numAtoms, double* __restrict__ out) {
+    __shared__ double part[4][4];
+    double px = 0, py = 0, pz = 0, m = 0;
+    for (int i = threadIdx.x; i < numAtoms; i += 256) {
+        double4 v = vel[i];
+        double mass = v.w == 0.0 ? 0.0 : 1.0 / v.w;
+        px += mass * v.x; py += mass * v.y; pz += mass * v.z; m += mass;
+    }
+    px = wave_sum(px); py = wave_sum(py); pz = wave_sum(pz); m = wave_sum(m);
+    if ((threadIdx.x & 63) == 0) { int w = threadIdx.x >> 6; part[w][0] = px; part[w][1] = py; part[w][2] = pz; part[w][3] = m; }
+    __syncthreads();
+    if (threadIdx.x < 4) out[threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
+__global__ void k_cm_subtract(double4* __restrict__ vel, int numAtoms, const double* __restrict__ mom) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numAtoms) return;
+    double4 v = vel[i];
+    if (v.w == 0.0) return;
+    double invM = 1.0 / mom[3];
+    v.x -= mom[0] * invM; v.y -= mom[1] * invM; v.z -= mom[2] * invM;
+    vel[i] = v;
+}
+
+TermArgs make_term_args(const ommhip_term_list* t, const void* pos_d, const int* slot_of_atom_d, int padded_atoms, const double* box, int periodic,
+                        long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy) {
+    TermArgs a;
+    a.numTerms = t->num_terms; a.paddedAtoms = padded_atoms; a.periodic = periodic; a.includeEnergy = include_energy; a.energySlots = energy_slots;
+    a.box.ax = box[0]; a.box.bx = box[1]; a.box.by = box[2]; a.box.cx = box[3]; a.box.cy = box[4]; a.box.cz = box[5];
+    a.alpha = 0; a.pos = (const double4*) pos_d; a.slotOfAtom = slot_of_atom_d;
+    a.atoms = t->atoms; a.params = t->params; a.charge = nullptr; a.force = force_d; a.energyBuffer = energy_buffer_d;
+    return a;
+}
+
+}  // namespace
+
+extern "C" int ommhip_term_forces(int kind, const ommhip_term_list* terms, const void* pos_d, const int* slot_of_atom_d, int padded_atoms,
+                                  const double box[6], int periodic, const double* charge_d, double alpha,
+                                  long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
+    if (terms->num_terms <= 0) return 0;
+    TermArgs a = make_term_args(terms, pos_d, slot_of_atom_d, padded_atoms, box, periodic, force_d, energy_buffer_d, energy_slots, include_energy);
+    a.charge = charge_d; a.alpha = alpha;
+    dim3 grid((terms->num_terms + 255) / 256), block(256);
+    hipStream_t st = (hipStream_t) stream;
+    switch (kind) {
+        case OMMHIP_TERM_EXCEPTION14: hipLaunchKernelGGL(k_exceptions14, grid, block, 0, st, a); break;
+        case OMMHIP_TERM_EWALD_EXCLUSION: hipLaunchKernelGGL(k_ewald_exclusions, grid, block, 0, st, a); break;
+        case OMMHIP_TERM_HARMONIC_BOND: hipLaunchKernelGGL(k_harmonic_bonds, grid, block, 0, st, a); break;
+        case OMMHIP_TERM_HARMONIC_ANGLE: hipLaunchKernelGGL(k_harmonic_angles, grid, block, 0, st, a); break;
+        case OMMHIP_TERM_PERIODIC_TORSION: hipLaunchKernelGGL(k_periodic_torsions, grid, block, 0, st, a); break;
+        default: return 1;
+    }
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_ewald_reciprocal(const void* pos_d, const double* charge_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms,
+                                       const double box[6], double alpha, int kmax_x, int kmax_y, int kmax_z, void* structure_d,
+                                       long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
+    EwaldArgs a;
+    a.numAtoms = num_atoms; a.paddedAtoms = padded_atoms; a.kx = kmax_x; a.ky = kmax_y; a.kz = kmax_z;
+    a.numK = kmax_x * (2 * kmax_y - 1) * (2 * kmax_z - 1);
+    a.includeEnergy = include_energy; a.energySlots = energy_slots;
+    const double pi = 3.14159265358979323846;
+    a.recipX = 2 * pi / box[0]; a.recipY = 2 * pi / box[2]; a.recipZ = 2 * pi / box[5];
+    a.alpha = alpha; a.coeff = OMM_ONE_4PI_EPS0_D * 4 * pi / (box[0] * box[2] * box[5]);
+    a.pos = (const double4*) pos_d; a.charge = charge_d; a.slotOfAtom = slot_of_atom_d;
+    a.structure = (double2*) structure_d; a.force = force_d; a.energyBuffer = energy_buffer_d;
+    hipStream_t st = (hipStream_t) stream;
+    hipLaunchKernelGGL(k_ewald_structure, dim3(a.numK), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_ewald_forces, dim3((num_atoms + 255) / 256), dim3(256), 0, st, a);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_remove_cm_motion(void* vel_d, int num_atoms, double* scratch4_d, void* stream) {
+    hipStream_t st = (hipStream_t) stream;
+    hipLaunchKernelGGL(k_cm_momentum, dim3(1), dim3(256), 0, st, (const double4*) vel_d, num_atoms, scratch4_d);
+    hipLaunchKernelGGL(k_cm_subtract, dim3((num_atoms + 255) / 256), dim3(256), 0, st, (double4*) vel_d, num_atoms, (const double*) scratch4_d);
+    return (int) hipGetLastError();
+}

@@ -16,7 +16,9 @@
 #define OMM_CHUNK_ROWS 4       // rows per work chunk (all rows of a chunk share one i-block)
 #define OMM_FORCE_SCALE 4294967296.0   // 2^32
 
-#define OMM_ONE_4PI_EPS0 138.935456f   // platforms/reference/include/SimTKOpenMMRealType.h:84-89
+// 1/(4 pi eps0) in kJ nm/(mol e^2) from the CODATA-2018 constants of platforms/reference/include/SimTKOpenMMRealType.h:74-89
+#define OMM_ONE_4PI_EPS0_D 138.93545764438198
+#define OMM_ONE_4PI_EPS0 138.93545764438198f
 
 typedef long long omm_fixed;   // 64-bit fixed-point force component
 

@@ -1,0 +1,509 @@
+// Integrators (Verlet, Langevin, LangevinMiddle), constraint solvers (SETTLE, SHAKE clusters, CCMA)
+// and kinetic energy, all in FP64 on the atom-ordered state arrays
+//     pos  double4[N] (x,y,z,-)     vel double4[N] (vx,vy,vz,1/m)     xp double4[N] (trial positions).
+//
+// Replaces (behaviourally)
+//   ReferenceVerletDynamics.cpp:76-119, ReferenceStochasticDynamics.cpp:89-194,
+//   ReferenceLangevinMiddleDynamics.cpp:54-127, ReferenceSETTLEAlgorithm.cpp:54-244,
+//   ReferenceCCMAAlgorithm.cpp:205-316, ReferenceKernels.cpp:146-176 (kinetic energy)
+// reached through IntegrateVerletStepKernel / IntegrateLangevinStepKernel /
+// IntegrateLangevinMiddleStepKernel / ApplyConstraintsKernel (olla/include/openmm/kernels.h:1033,1160,1193,220).
+//
+// MI355X note: FP64 vector throughput is half of FP32 on this chip, and this stage moves ~100 bytes
+// per atom, so it is bandwidth/latency bound either way; keeping the whole integration state in
+// double replaces the float+correction ("mixed") scheme GPU platforms normally need.
+#include "common.h"
+#include "../../../include/openmm_hip_kernels.h"
+
+using namespace omm;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Counter-based RNG: Philox4x32-10 (Salmon et al., SC'11).  counter = (atom, stepLo, stepHi, stream),
+// key = seed.  Stateless, so no RNG pool has to be stored, reordered or checkpointed.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    unsigned hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    unsigned hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    unsigned n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+// three independent N(0,1) deviates
+__device__ __forceinline__ double3 gaussian3(unsigned atom, unsigned long long step, unsigned long long seed) {
+    unsigned c[4] = {atom, (unsigned) step, (unsigned) (step >> 32), 0x4f4d4d48u};
+    philox4x32(c, (unsigned) seed, (unsigned) (seed >> 32));
+    const double inv32 = 1.0 / 4294967296.0;
+    double u0 = ((double) c[0] + 0.5) * inv32, u1 = ((double) c[1] + 0.5) * inv32;
+    double u2 = ((double) c[2] + 0.5) * inv32, u3 = ((double) c[3] + 0.5) * inv32;
+    double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
+    double s0, c0, s1, c1;
+    sincos(6.28318530717958647692 * u1, &s0, &c0);
+    sincos(6.28318530717958647692 * u3, &s1, &c1);
+    (void) s1;
+    return make_double3(r0 * c0, r0 * s0, r1 * c1);
+}
+
+struct IntArgs {
+    int numAtoms, paddedAtoms;
+    double dt, vscale, fscale, noisescale;
+    unsigned long long seed, step;
+    double4* pos; double4* vel; double4* xp; double4* oldx;
+    const omm_fixed* force;
+    const int* slotOfAtom;
+};
+
+__device__ __forceinline__ double3 load_force(const IntArgs& a, int atom) {
+    int s = a.slotOfAtom[atom];
+    return make_double3(from_fixed(a.force[s]), from_fixed(a.force[s + a.paddedAtoms]), from_fixed(a.force[s + 2 * a.paddedAtoms]));
+}
+
+// ReferenceVerletDynamics.cpp:97-104
+__global__ void k_verlet_part1(IntArgs a) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.numAtoms) return;
+    double4 x = a.pos[i], v = a.vel[i];
+    if (v.w != 0.0) {
+        double3 f = load_force(a, i);
+        v.x += v.w * f.x * a.dt; v.y += v.w * f.y * a.dt; v.z += v.w * f.z * a.dt;
+        a.vel[i] = v;
+        x.x += v.x * a.dt; x.y += v.y * a.dt; x.z += v.z * a.dt;
+    }
+    a.xp[i] = x;
+}
+// ReferenceVerletDynamics.cpp:109-116 (also the last stage of ReferenceStochasticDynamics.cpp:138-146)
+__global__ void k_finish_positions(IntArgs a) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.numAtoms) return;
+    double4 x = a.pos[i], v = a.vel[i], xp = a.xp[i];
+    if (v.w != 0.0) {
+        double inv = 1.0 / a.dt;
+        v.x = inv * (xp.x - x.x); v.y = inv * (xp.y - x.y); v.z = inv * (xp.z - x.z);
+        a.vel[i] = v;
+        a.pos[i] = make_double4(xp.x, xp.y, xp.z, x.w);
+    }
+}
+// ReferenceStochasticDynamics.cpp:89-136
+__global__ void k_langevin_part1(IntArgs a) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.numAtoms) return;
+    double4 x = a.pos[i], v = a.vel[i];
+    if (v.w != 0.0) {
+        double3 f = load_force(a, i);
+        double3 g = gaussian3((unsigned) i, a.step, a.seed);
+        double sq = sqrt(v.w);
+        v.x = a.vscale * v.x + a.fscale * v.w * f.x + a.noisescale * sq * g.x;
+        v.y = a.vscale * v.y + a.fscale * v.w * f.y + a.noisescale * sq * g.y;
+        v.z = a.vscale * v.z + a.fscale * v.w * f.z + a.noisescale * sq * g.z;
+        a.vel[i] = v;
+        x.x += v.x * a.dt; x.y += v.y * a.dt; x.z += v.z * a.dt;
+    }
+    a.xp[i] = x;
+}
+// ReferenceLangevinMiddleDynamics.cpp:54-58
+__global__ void k_lmiddle_part1(IntArgs a) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.numAtoms) return;
+    double4 v = a.vel[i];
+    if (v.w != 0.0) {
+        double3 f = load_force(a, i);
+        v.x += a.dt * v.w * f.x; v.y += a.dt * v.w * f.y; v.z += a.dt * v.w * f.z;
+        a.vel[i] = v;
+    }
+}
+// ReferenceLangevinMiddleDynamics.cpp:60-80   (noisescale = sqrt(kT (1-vscale^2)))
+__global__ void k_lmiddle_part2(IntArgs a) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.numAtoms) return;
+    double4 x = a.pos[i], v = a.vel[i];
+    if (v.w != 0.0) {
+        const double h = 0.5 * a.dt;
+        x.x += v.x * h; x.y += v.y * h; x.z += v.z * h;
+        double3 g = gaussian3((unsigned) i, a.step, a.seed);
+        double sq = sqrt(v.w);
+        v.x = a.vscale * v.x + a.noisescale * sq * g.x;
+        v.y = a.vscale * v.y + a.noisescale * sq * g.y;
+        v.z = a.vscale * v.z + a.noisescale * sq * g.z;
+        a.vel[i] = v;
+        x.x += v.x * h; x.y += v.y * h; x.z += v.z * h;
+    }
+    a.xp[i] = x;
+    a.oldx[i] = x;
+}
+// ReferenceLangevinMiddleDynamics.cpp:82-90
+__global__ void k_lmiddle_part3(IntArgs a) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.numAtoms) return;
+    double4 x = a.pos[i], v = a.vel[i], xp = a.xp[i], ox = a.oldx[i];
+    if (v.w != 0.0) {
+        double inv = 1.0 / a.dt;
+        v.x += (xp.x - ox.x) * inv; v.y += (xp.y - ox.y) * inv; v.z += (xp.z - ox.z) * inv;
+        a.vel[i] = v;
+        a.pos[i] = make_double4(xp.x, xp.y, xp.z, x.w);
+    }
+}
+// out = vel + force*(shift/m)   (ReferenceKernels.cpp:155-160)
+__global__ void k_shifted_velocities(IntArgs a, double shift, double4* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.numAtoms) return;
+    double4 v = a.vel[i];
+    if (v.w != 0.0 && shift != 0.0) {
+        double3 f = load_force(a, i);
+        v.x += f.x * shift * v.w; v.y += f.y * shift * v.w; v.z += f.z * shift * v.w;
+    }
+    out[i] = v;
+}
+__global__ __launch_bounds__(256) void k_kinetic_energy(const double4* __restrict__ vel, int numAtoms, double* __restrict__ result) {
+    __shared__ double part[4];
+    double e = 0;
+    for (int i = threadIdx.x; i < numAtoms; i += 256) {
+        double4 v = vel[i];
+        if (v.w != 0.0) e += (v.x * v.x + v.y * v.y + v.z * v.z) / v.w;
+    }
+    e = wave_sum(e);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) result[0] = 0.5 * (part[0] + part[1] + part[2] + part[3]);
+}
+
+// ================================================================================================
+// SETTLE (Miyamoto & Kollman 1992) -- analytic rigid three-site reset, general masses.
+// cluster: atoms (a0 = apex, a1, a2), params (apex-leg distance d01 = d02, base distance d12).
+// ================================================================================================
+struct SettleArgs {
+    int numClusters;
+    const int4* atoms;        // (a0, a1, a2, unused)
+    const double2* dist;      // (d0x, d12)
+    const double4* pos;       // positions before the step (constrained)
+    double4* xp;              // trial positions, corrected in place   (position version)
+    double4* vel;             // velocities, corrected in place         (velocity version; w = 1/m)
+    const double4* velMass;   // array holding 1/m in .w
+};
+
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 v3(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ V3 xyz(double4 p) { return v3(p.x, p.y, p.z); }
+
+// Same algebra as ReferenceSETTLEAlgorithm.cpp:54-195, written with vectors.
+__global__ void k_settle_positions(SettleArgs a) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.numClusters) return;
+    const int4 at = a.atoms[c];
+    const double2 dd = a.dist[c];
+    const V3 p0 = xyz(a.pos[at.x]), p1 = xyz(a.pos[at.y]), p2 = xyz(a.pos[at.z]);
+    const double4 q0 = a.xp[at.x], q1 = a.xp[at.y], q2 = a.xp[at.z];
+    const double iw0 = a.velMass[at.x].w, iw1 = a.velMass[at.y].w, iw2 = a.velMass[at.z].w;
+    const double m0 = 1.0 / iw0, m1 = 1.0 / iw1, m2 = 1.0 / iw2;
+    // everything relative to the old apex position
+    const V3 b0 = p1 - p0, c0 = p2 - p0;
+    const V3 d0 = xyz(q0) - p0;                   // trial apex
+    const V3 d1 = b0 + (xyz(q1) - p1);            // trial leg atoms
+    const V3 d2 = c0 + (xyz(q2) - p2);
+    const double invM = 1.0 / (m0 + m1 + m2);
+    const V3 com = (d0 * m0 + d1 * m1 + d2 * m2) * invM;
+    const V3 a1 = d0 - com, b1 = d1 - com, c1 = d2 - com;
+    // orthonormal frame: z = normal of the old triangle, x = a1 x z, y = z x x
+    V3 ez = cross(b0, c0);
+    V3 ex = cross(a1, ez);
+    V3 ey = cross(ez, ex);
+    ex = ex * (1.0 / sqrt(dot(ex, ex)));
+    ey = ey * (1.0 / sqrt(dot(ey, ey)));
+    ez = ez * (1.0 / sqrt(dot(ez, ez)));
+    const double xb0 = dot(ex, b0), yb0 = dot(ey, b0), xc0 = dot(ex, c0), yc0 = dot(ey, c0);
+    const double za1 = dot(ez, a1);
+    const double xb1 = dot(ex, b1), yb1 = dot(ey, b1), zb1 = dot(ez, b1);
+    const double xc1 = dot(ex, c1), yc1 = dot(ey, c1), zc1 = dot(ez, c1);
+    // canonical triangle
+    const double rc = 0.5 * dd.y;
+    double rb = sqrt(dd.x * dd.x - rc * rc);
+    const double ra = rb * (m1 + m2) * invM;
+    rb -= ra;
+    const double sinphi = za1 / ra;
+    const double cosphi = sqrt(1.0 - sinphi * sinphi);
+    const double sinpsi = (zb1 - zc1) / (2.0 * rc * cosphi);
+    const double cospsi = sqrt(1.0 - sinpsi * sinpsi);
+    const double ya2 = ra * cosphi;
+    double xb2 = -rc * cospsi;
+    const double yb2 = -rb * cosphi - rc * sinpsi * sinphi;
+    const double yc2 = -rb * cosphi + rc * sinpsi * sinphi;
+    const double xb22 = xb2 * xb2;
+    const double hh2 = 4.0 * xb22 + (yb2 - yc2) * (yb2 - yc2) + (zb1 - zc1) * (zb1 - zc1);
+    const double deltx = 2.0 * xb2 + sqrt(4.0 * xb22 - hh2 + dd.y * dd.y);
+    xb2 -= 0.5 * deltx;
+    // rotation about z
+    const double alpha = xb2 * (xb0 - xc0) + yb0 * yb2 + yc0 * yc2;
+    const double beta = xb2 * (yc0 - yb0) + xb0 * yb2 + xc0 * yc2;
+    const double gamma = xb0 * yb1 - xb1 * yb0 + xc0 * yc1 - xc1 * yc0;
+    const double al2be2 = alpha * alpha + beta * beta;
+    const double sintheta = (alpha * gamma - beta * sqrt(al2be2 - gamma * gamma)) / al2be2;
+    const double costheta = sqrt(1.0 - sintheta * sintheta);
+    const V3 a3 = ex * (-ya2 * sintheta) + ey * (ya2 * costheta) + ez * za1;
+    const V3 b3 = ex * (xb2 * costheta - yb2 * sintheta) + ey * (xb2 * sintheta + yb2 * costheta) + ez * zb1;
+    const V3 c3 = ex * (-xb2 * costheta - yc2 * sintheta) + ey * (-xb2 * sintheta + yc2 * costheta) + ez * zc1;
+    const V3 n0 = p0 + com + a3;
+    const V3 n1 = p1 + (com + b3 - b0);
+    const V3 n2 = p2 + (com + c3 - c0);
+    a.xp[at.x] = make_double4(n0.x, n0.y, n0.z, q0.w);
+    a.xp[at.y] = make_double4(n1.x, n1.y, n1.z, q1.w);
+    a.xp[at.z] = make_double4(n2.x, n2.y, n2.z, q2.w);
+}
+
+// ReferenceSETTLEAlgorithm.cpp:197-244 (unequal-mass velocity solve)
+__global__ void k_settle_velocities(SettleArgs a) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.numClusters) return;
+    const int4 at = a.atoms[c];
+    const V3 p0 = xyz(a.pos[at.x]), p1 = xyz(a.pos[at.y]), p2 = xyz(a.pos[at.z]);
+    double4 w0 = a.vel[at.x], w1 = a.vel[at.y], w2 = a.vel[at.z];
+    const double iA = a.velMass[at.x].w, iB = a.velMass[at.y].w, iC = a.velMass[at.z].w;
+    const double mA = 1.0 / iA, mB = 1.0 / iB, mC = 1.0 / iC;
+    V3 eAB = p1 - p0, eBC = p2 - p1, eCA = p0 - p2;
+    eAB = eAB * (1.0 / sqrt(dot(eAB, eAB)));
+    eBC = eBC * (1.0 / sqrt(dot(eBC, eBC)));
+    eCA = eCA * (1.0 / sqrt(dot(eCA, eCA)));
+    V3 v0 = xyz(w0), v1 = xyz(w1), v2 = xyz(w2);
+    const double vAB = dot(v1 - v0, eAB), vBC = dot(v2 - v1, eBC), vCA = dot(v0 - v2, eCA);
+    const double cA = -dot(eAB, eCA), cB = -dot(eAB, eBC), cC = -dot(eBC, eCA);
+    const double s2A = 1 - cA * cA, s2B = 1 - cB * cB, s2C = 1 - cC * cC;
+    const double mABCinv = 1 / (mA * mB * mC);
+    const double denom = (((s2A * mB + s2B * mA) * mC + (s2A * mB * mB + 2 * (cA * cB * cC + 1) * mA * mB + s2B * mA * mA)) * mC + s2C * mA * mB * (mA + mB)) * mABCinv;
+    const double tab = ((cB * cC * mA - cA * mB - cA * mC) * vCA + (cA * cC * mB - cB * mC - cB * mA) * vBC + (s2C * mA * mA * mB * mB * mABCinv + (mA + mB + mC)) * vAB) / denom;
+    const double tbc = ((cA * cB * mC - cC * mB - cC * mA) * vCA + (s2A * mB * mB * mC * mC * mABCinv + (mA + mB + mC)) * vBC + (cA * cC * mB - cB * mA - cB * mC) * vAB) / denom;
+    const double tca = ((s2B * mA * mA * mC * mC * mABCinv + (mA + mB + mC)) * vCA + (cA * cB * mC - cC * mB - cC * mA) * vBC + (cB * cC * mA - cA * mB - cA * mC) * vAB) / denom;
+    v0 = v0 + (eAB * tab - eCA * tca) * iA;
+    v1 = v1 + (eBC * tbc - eAB * tab) * iB;
+    v2 = v2 + (eCA * tca - eBC * tbc) * iC;
+    a.vel[at.x] = make_double4(v0.x, v0.y, v0.z, w0.w);
+    a.vel[at.y] = make_double4(v1.x, v1.y, v1.z, w1.w);
+    a.vel[at.z] = make_double4(v2.x, v2.y, v2.z, w2.w);
+}
+
+// ================================================================================================
+// SHAKE clusters: one central atom with 1..3 satellites that have no other constraint.  One thread
+// iterates its cluster in registers until the Reference convergence criterion
+// (ReferenceCCMAAlgorithm.cpp:246-275) holds; no host round trip.
+// ================================================================================================
+struct ShakeArgs {
+    int numClusters, maxIterations;
+    double tol;
+    const int4* atoms;        // (center, s1, s2, s3), unused = -1
+    const double4* dist;      // (d1, d2, d3, unused)
+    const double4* pos;
+    double4* target;          // xp (positions) or vel (velocities)
+    const double4* velMass;
+};
+
+template <bool VELOCITIES>
+__global__ void k_shake(ShakeArgs a) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.numClusters) return;
+    const int4 at = a.atoms[c];
+    const double4 dd = a.dist[c];
+    const int sat[3] = {at.y, at.z, at.w};
+    const double dist[3] = {dd.x, dd.y, dd.z};
+    const V3 x0 = xyz(a.pos[at.x]);
+    const double iw0 = a.velMass[at.x].w;
+    double4 t0w = a.target[at.x];
+    V3 t0 = xyz(t0w);
+    V3 r[3], t[3];
+    double iw[3], rr[3], tw[3];
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (sat[k] >= 0) {
+            r[k] = x0 - xyz(a.pos[sat[k]]);
+            double4 tt = a.target[sat[k]];
+            t[k] = xyz(tt); tw[k] = tt.w;
+            iw[k] = a.velMass[sat[k]].w;
+            rr[k] = dot(r[k], r[k]);
+            n = k + 1;
+        }
+    }
+    const double lowerTol = 1 - 2 * a.tol + a.tol * a.tol, upperTol = 1 + 2 * a.tol + a.tol * a.tol;
+    for (int iter = 0; iter < a.maxIterations; iter++) {
+        bool converged = true;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (k < n) {
+                const double reduced = 0.5 / (iw0 + iw[k]);
+                V3 rp = t0 - t[k];
+                double delta;
+                if (VELOCITIES) {
+                    delta = -2.0 * reduced * dot(rp, r[k]) / rr[k];
+                    if (fabs(delta) > a.tol) converged = false; else delta = 0.0;
+                }
+                else {
+                    const double rp2 = dot(rp, rp), d2 = dist[k] * dist[k];
+                    if (rp2 >= lowerTol * d2 && rp2 <= upperTol * d2) delta = 0.0;
+                    else { delta = reduced * (d2 - rp2) / dot(rp, r[k]); converged = false; }
+                }
+                t0 = t0 + r[k] * (delta * iw0);
+                t[k] = t[k] - r[k] * (delta * iw[k]);
+            }
+        }
+        if (converged) break;
+    }
+    a.target[at.x] = make_double4(t0.x, t0.y, t0.z, t0w.w);
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if (k < n) a.target[sat[k]] = make_double4(t[k].x, t[k].y, t[k].z, tw[k]);
+}
+
+// ================================================================================================
+// CCMA (general constraints) -- ReferenceCCMAAlgorithm.cpp:205-316.  The host drives the iteration
+// and reads the converged count; only systems with constraints outside SETTLE/SHAKE take this path.
+// ================================================================================================
+struct CcmaArgs {
+    int numConstraints, velocities;
+    double tol;
+    const int2* atoms;
+    const double* dist;
+    const double4* pos;
+    double4* target;
+    const double4* velMass;
+    double* delta;            // [numConstraints]
+    double* delta2;
+    const int* rowStart; const int* col; const double* value;
+    int* converged;
+};
+
+__global__ void k_ccma_delta(CcmaArgs a) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.numConstraints) return;
+    const int2 at = a.atoms[c];
+    const V3 r = xyz(a.pos[at.x]) - xyz(a.pos[at.y]);
+    const V3 rp = xyz(a.target[at.x]) - xyz(a.target[at.y]);
+    const double reduced = 0.5 / (a.velMass[at.x].w + a.velMass[at.y].w);
+    double delta;
+    bool ok;
+    if (a.velocities) {
+        delta = -2.0 * reduced * dot(rp, r) / dot(r, r);
+        ok = fabs(delta) <= a.tol;
+    }
+    else {
+        const double rp2 = dot(rp, rp), d2 = a.dist[c] * a.dist[c];
+        delta = reduced * (d2 - rp2) / dot(rp, r);
+        const double lowerTol = 1 - 2 * a.tol + a.tol * a.tol, upperTol = 1 + 2 * a.tol + a.tol * a.tol;
+        ok = rp2 >= lowerTol * d2 && rp2 <= upperTol * d2;
+    }
+    a.delta[c] = delta;
+    if (ok) atomicAdd(a.converged, 1);
+}
+__global__ void k_ccma_multiply(CcmaArgs a) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.numConstraints) return;
+    double sum = 0;
+    for (int e = a.rowStart[c]; e < a.rowStart[c + 1]; e++) sum += a.value[e] * a.delta[a.col[e]];
+    a.delta2[c] = sum;
+}
+__global__ void k_ccma_update(CcmaArgs a) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.numConstraints) return;
+    const int2 at = a.atoms[c];
+    const V3 r = xyz(a.pos[at.x]) - xyz(a.pos[at.y]);
+    const double d = a.delta2[c];
+    const double wi = a.velMass[at.x].w * d, wj = a.velMass[at.y].w * d;
+    double* ti = (double*) &a.target[at.x];
+    double* tj = (double*) &a.target[at.y];
+    atomicAdd(ti, r.x * wi); atomicAdd(ti + 1, r.y * wi); atomicAdd(ti + 2, r.z * wi);
+    atomicAdd(tj, -r.x * wj); atomicAdd(tj + 1, -r.y * wj); atomicAdd(tj + 2, -r.z * wj);
+}
+
+IntArgs make_int_args(const ommhip_integrator_state* s) {
+    IntArgs a;
+    a.numAtoms = s->num_atoms; a.paddedAtoms = s->padded_atoms;
+    a.dt = s->dt; a.vscale = s->vscale; a.fscale = s->fscale; a.noisescale = s->noisescale;
+    a.seed = s->seed; a.step = s->step;
+    a.pos = (double4*) s->pos; a.vel = (double4*) s->vel; a.xp = (double4*) s->xp; a.oldx = (double4*) s->oldx;
+    a.force = s->force; a.slotOfAtom = s->slot_of_atom;
+    return a;
+}
+
+}  // namespace
+
+static inline dim3 grid_for(int n) { return dim3((n + 127) / 128); }
+#define BLOCK128 dim3(128)
+
+extern "C" int ommhip_integrate_stage(int stage, const ommhip_integrator_state* s, void* stream) {
+    IntArgs a = make_int_args(s);
+    hipStream_t st = (hipStream_t) stream;
+    if (a.numAtoms <= 0) return 0;
+    switch (stage) {
+        case OMMHIP_STAGE_VERLET_1: hipLaunchKernelGGL(k_verlet_part1, grid_for(a.numAtoms), BLOCK128, 0, st, a); break;
+        case OMMHIP_STAGE_FINISH_POSITIONS: hipLaunchKernelGGL(k_finish_positions, grid_for(a.numAtoms), BLOCK128, 0, st, a); break;
+        case OMMHIP_STAGE_LANGEVIN_1: hipLaunchKernelGGL(k_langevin_part1, grid_for(a.numAtoms), BLOCK128, 0, st, a); break;
+        case OMMHIP_STAGE_LMIDDLE_1: hipLaunchKernelGGL(k_lmiddle_part1, grid_for(a.numAtoms), BLOCK128, 0, st, a); break;
+        case OMMHIP_STAGE_LMIDDLE_2: hipLaunchKernelGGL(k_lmiddle_part2, grid_for(a.numAtoms), BLOCK128, 0, st, a); break;
+        case OMMHIP_STAGE_LMIDDLE_3: hipLaunchKernelGGL(k_lmiddle_part3, grid_for(a.numAtoms), BLOCK128, 0, st, a); break;
+        default: return 1;
+    }
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_shifted_velocities(const ommhip_integrator_state* s, double shift, void* out_d, void* stream) {
+    IntArgs a = make_int_args(s);
+    if (a.numAtoms <= 0) return 0;
+    hipLaunchKernelGGL(k_shifted_velocities, grid_for(a.numAtoms), BLOCK128, 0, (hipStream_t) stream, a, shift, (double4*) out_d);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_kinetic_energy(const void* vel_d, int num_atoms, double* result_d, void* stream) {
+    hipLaunchKernelGGL(k_kinetic_energy, dim3(1), dim3(256), 0, (hipStream_t) stream, (const double4*) vel_d, num_atoms, result_d);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_settle(int num_clusters, const int* atoms_d, const double* dist_d, const void* pos_d, void* target_d,
+                             const void* vel_mass_d, int velocities, void* stream) {
+    if (num_clusters <= 0) return 0;
+    SettleArgs a;
+    a.numClusters = num_clusters; a.atoms = (const int4*) atoms_d; a.dist = (const double2*) dist_d;
+    a.pos = (const double4*) pos_d; a.xp = (double4*) target_d; a.vel = (double4*) target_d; a.velMass = (const double4*) vel_mass_d;
+    if (velocities) hipLaunchKernelGGL(k_settle_velocities, grid_for(num_clusters), BLOCK128, 0, (hipStream_t) stream, a);
+    else hipLaunchKernelGGL(k_settle_positions, grid_for(num_clusters), BLOCK128, 0, (hipStream_t) stream, a);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_shake(int num_clusters, const int* atoms_d, const double* dist_d, const void* pos_d, void* target_d,
+                            const void* vel_mass_d, int velocities, double tol, int max_iterations, void* stream) {
+    if (num_clusters <= 0) return 0;
+    ShakeArgs a;
+    a.numClusters = num_clusters; a.maxIterations = max_iterations; a.tol = tol;
+    a.atoms = (const int4*) atoms_d; a.dist = (const double4*) dist_d; a.pos = (const double4*) pos_d;
+    a.target = (double4*) target_d; a.velMass = (const double4*) vel_mass_d;
+    if (velocities) hipLaunchKernelGGL(k_shake<true>, grid_for(num_clusters), BLOCK128, 0, (hipStream_t) stream, a);
+    else hipLaunchKernelGGL(k_shake<false>, grid_for(num_clusters), BLOCK128, 0, (hipStream_t) stream, a);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_ccma_iteration(const ommhip_ccma* c, const void* pos_d, void* target_d, const void* vel_mass_d,
+                                     int velocities, double tol, int phase, void* stream) {
+    if (c->num_constraints <= 0) return 0;
+    CcmaArgs a;
+    a.numConstraints = c->num_constraints; a.velocities = velocities; a.tol = tol;
+    a.atoms = (const int2*) c->atoms; a.dist = c->distance; a.pos = (const double4*) pos_d; a.target = (double4*) target_d;
+    a.velMass = (const double4*) vel_mass_d; a.delta = c->delta; a.delta2 = c->delta2;
+    a.rowStart = c->row_start; a.col = c->col; a.value = c->value; a.converged = c->converged;
+    hipStream_t st = (hipStream_t) stream;
+    if (phase == 0) {
+        hipMemsetAsync(c->converged, 0, sizeof(int), st);
+        hipLaunchKernelGGL(k_ccma_delta, grid_for(a.numConstraints), BLOCK128, 0, st, a);
+    }
+    else {
+        hipLaunchKernelGGL(k_ccma_multiply, grid_for(a.numConstraints), BLOCK128, 0, st, a);
+        hipLaunchKernelGGL(k_ccma_update, grid_for(a.numConstraints), BLOCK128, 0, st, a);
+    }
+    return (int) hipGetLastError();
+}

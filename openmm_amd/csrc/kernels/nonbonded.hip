@@ -424,10 +424,12 @@ NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
 extern "C" int ommhip_nl_update(const ommhip_neighbor_list* nl, void* stream) {
     hipStream_t st = (hipStream_t) stream;
     NlArgs a = make_nl_args(nl);
+    ommhip_profile_begin(OMMHIP_TIMER_NL_UPDATE, stream);
     if (nl->cutoff > 0)    // NoCutoff lists never go stale through motion
         hipLaunchKernelGGL(nl_check_displacement, dim3((a.paddedAtoms + 255) / 256), dim3(256), 0, st, a);
     hipLaunchKernelGGL(nl_block_bounds, dim3((a.paddedAtoms + 255) / 256), dim3(256), 0, st, a);
     hipLaunchKernelGGL(nl_find_interactions, dim3(a.numBlocks), dim3(64), 0, st, a);
+    ommhip_profile_end(OMMHIP_TIMER_NL_UPDATE, stream);
     return (int) hipGetLastError();
 }
 
@@ -446,11 +448,13 @@ extern "C" int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_non
     int grid = p->direct_grid > 0 ? p->direct_grid : 2048;
     if (include_energy && grid > energy_slots) grid = energy_slots;
     hipStream_t st = (hipStream_t) stream;
+    ommhip_profile_begin(OMMHIP_TIMER_NB_DIRECT, stream);
     switch ((p->ewald ? 1 : 0) | (p->use_switch ? 2 : 0)) {
         case 0: launch_direct1<0>(nl->pbc, include_energy != 0, grid, st, a); break;
         case 1: launch_direct1<1>(nl->pbc, include_energy != 0, grid, st, a); break;
         case 2: launch_direct1<2>(nl->pbc, include_energy != 0, grid, st, a); break;
         default: launch_direct1<3>(nl->pbc, include_energy != 0, grid, st, a); break;
     }
+    ommhip_profile_end(OMMHIP_TIMER_NB_DIRECT, stream);
     return (int) hipGetLastError();
 }

@@ -167,7 +167,7 @@ __global__ void pme_build_eterm(EtermArgs a) {
     const double m2 = mhx * mhx + mhy * mhy + mhz * mhz;
     const double pi = 3.14159265358979323846;
     const double denom = m2 * (pi * a.volume * a.modX[kx]) * a.modY[ky] * a.modZ[kz];
-    a.eterm[i] = (float) (138.935456 * exp(-(pi * pi / (a.alpha * a.alpha)) * m2) / denom);
+    a.eterm[i] = (float) (OMM_ONE_4PI_EPS0_D * exp(-(pi * pi / (a.alpha * a.alpha)) * m2) / denom);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -388,7 +388,10 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
 
     hipMemsetAsync(pa.grid, 0, sizeof(float) * (size_t) nx * ny * nz, st);
     const int spreadBlocks = (padded_atoms * 8 + 255) / 256;
+    ommhip_profile_begin(OMMHIP_TIMER_PME_SPREAD, stream);
     hipLaunchKernelGGL(pme_spread, dim3(spreadBlocks), dim3(256), 0, st, pa);
+    ommhip_profile_end(OMMHIP_TIMER_PME_SPREAD, stream);
+    ommhip_profile_begin(OMMHIP_TIMER_PME_FFT, stream);
 
     FftArgs f;
     // ---- forward z: real [nx*ny][nz] -> complex [nx*ny][nzc]
@@ -424,7 +427,10 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     f.mode = 2; f.sign = +1; f.twiddle = (const float2*) pme->twiddle_z; f.in = cgrid; f.out = pa.grid;
     hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
 
+    ommhip_profile_end(OMMHIP_TIMER_PME_FFT, stream);
+    ommhip_profile_begin(OMMHIP_TIMER_PME_INTERPOLATE, stream);
     hipLaunchKernelGGL(pme_interpolate, dim3(spreadBlocks), dim3(256), 0, st, pa);
+    ommhip_profile_end(OMMHIP_TIMER_PME_INTERPOLATE, stream);
     return (int) hipGetLastError();
 }
 

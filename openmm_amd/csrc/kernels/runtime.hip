@@ -52,3 +52,63 @@ int ommhip_stream_wait_event(void* stream, void* event) { return (int) hipStream
 const char* ommhip_error_string(int code) { return hipGetErrorString((hipError_t) code); }
 
 }
+
+// ------------------------------------------------------------------------------------------------
+// Opt-in per-kernel timing with HIP events recorded on the stream the kernel is launched on
+// (used by bench.py for the roofline figure; off by default, zero cost when off).
+// ------------------------------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct ProfileTimer {
+    std::vector<hipEvent_t> start, stop;
+    size_t used = 0;
+    double totalMs = 0;
+    long long calls = 0;
+};
+ProfileTimer timers[OMMHIP_PROFILE_NUM_TIMERS];
+int profileEnabled = 0;
+void profile_drain(ProfileTimer& t) {
+    for (size_t i = 0; i < t.used; i++) {
+        float ms = 0;
+        if (hipEventSynchronize(t.stop[i]) == hipSuccess && hipEventElapsedTime(&ms, t.start[i], t.stop[i]) == hipSuccess) {
+            t.totalMs += ms;
+            t.calls++;
+        }
+    }
+    t.used = 0;
+}
+}  // namespace
+
+extern "C" {
+int ommhip_profile_enable(int enabled) { profileEnabled = enabled; return 0; }
+int ommhip_profile_reset() {
+    for (int i = 0; i < OMMHIP_PROFILE_NUM_TIMERS; i++) { profile_drain(timers[i]); timers[i].totalMs = 0; timers[i].calls = 0; }
+    return 0;
+}
+int ommhip_profile_begin(int timer, void* stream) {
+    if (!profileEnabled || timer < 0 || timer >= OMMHIP_PROFILE_NUM_TIMERS) return 0;
+    ProfileTimer& t = timers[timer];
+    if (t.used == 4096) profile_drain(t);
+    if (t.used == t.start.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 0;
+        t.start.push_back(a); t.stop.push_back(b);
+    }
+    return (int) hipEventRecord(t.start[t.used], (hipStream_t) stream);
+}
+int ommhip_profile_end(int timer, void* stream) {
+    if (!profileEnabled || timer < 0 || timer >= OMMHIP_PROFILE_NUM_TIMERS) return 0;
+    ProfileTimer& t = timers[timer];
+    if (t.used >= t.stop.size()) return 0;
+    hipError_t e = hipEventRecord(t.stop[t.used], (hipStream_t) stream);
+    t.used++;
+    return (int) e;
+}
+int ommhip_profile_collect(int timer, long long* calls, double* total_ms) {
+    if (timer < 0 || timer >= OMMHIP_PROFILE_NUM_TIMERS) return 1;
+    profile_drain(timers[timer]);
+    *calls = timers[timer].calls;
+    *total_ms = timers[timer].totalMs;
+    return 0;
+}
+}

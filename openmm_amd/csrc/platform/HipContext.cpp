@@ -1,0 +1,265 @@
+#include "HipContext.h"
+#include "openmm/System.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+using namespace OpenMM;
+using namespace std;
+
+namespace {
+struct D4 { double x, y, z, w; };
+struct I4 { int x, y, z, w; };
+
+/* Hilbert-curve index of an integer cell (x,y,z) with `bits` bits per axis.
+ * Skilling, "Programming the Hilbert curve", AIP Conf. Proc. 707 (2004): axes -> transposed index. */
+unsigned long long hilbertIndex(unsigned x, unsigned y, unsigned z, int bits) {
+    unsigned X[3] = {x, y, z};
+    const unsigned M = 1u << (bits - 1);
+    for (unsigned Q = M; Q > 1; Q >>= 1) {
+        const unsigned P = Q - 1;
+        for (int i = 0; i < 3; i++) {
+            if (X[i] & Q) X[0] ^= P;
+            else { unsigned t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    for (int i = 1; i < 3; i++) X[i] ^= X[i - 1];
+    unsigned t = 0;
+    for (unsigned Q = M; Q > 1; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1;
+    for (int i = 0; i < 3; i++) X[i] ^= t;
+    unsigned long long key = 0;
+    for (int b = bits - 1; b >= 0; b--)
+        for (int i = 0; i < 3; i++)
+            key = (key << 1) | ((X[i] >> b) & 1u);
+    return key;
+}
+}  // namespace
+
+HipContext::HipContext(const System& system, int deviceIndex, bool hostMode) : numAtoms(system.getNumParticles()), hostMode(hostMode),
+        stream(NULL), usePeriodic(false), sortCutoff(0.0), positionsValid(false), hasFallbackForces(false), stepsSinceReorder(0),
+        reorderInterval(500), reorderRequested(true), deviceIndex(deviceIndex), pinnedResult(NULL) {
+    int count = 0;
+    HIP_CHECK(ommhip_device_count(&count));
+    if (deviceIndex < 0 || deviceIndex >= count)
+        throw OpenMMException("HIP platform: illegal DeviceIndex");
+    HIP_CHECK(ommhip_set_device(deviceIndex));
+    HIP_CHECK(ommhip_stream_create(&stream));
+    paddedAtoms = ((numAtoms + OMMHIP_TILE - 1) / OMMHIP_TILE) * OMMHIP_TILE;
+    if (paddedAtoms == 0) paddedAtoms = OMMHIP_TILE;
+    masses.resize(numAtoms);
+    for (int i = 0; i < numAtoms; i++) masses[i] = system.getParticleMass(i);
+    const size_t n4 = sizeof(double) * 4 * (size_t) max(numAtoms, 1);
+    pos.allocate(n4); vel.allocate(n4); xp.allocate(n4); oldx.allocate(n4); tempVel.allocate(n4);
+    wrap.allocate(sizeof(int) * 4 * (size_t) max(numAtoms, 1));
+    force.allocate(sizeof(long long) * 3 * (size_t) paddedAtoms);
+    atomOfSlot.allocate(sizeof(int) * (size_t) paddedAtoms);
+    slotOfAtom.allocate(sizeof(int) * (size_t) max(numAtoms, 1));
+    energyBuffer.allocate(sizeof(double) * EnergySlots);
+    energyResult.allocate(sizeof(double) * 8);
+    forceDouble.allocate(sizeof(double) * 3 * (size_t) max(numAtoms, 1));
+    HIP_CHECK(ommhip_host_malloc((void**) &pinnedResult, sizeof(double) * 8));
+    HIP_CHECK(ommhip_memset(energyBuffer.ptr, 0, energyBuffer.bytes, stream));
+    HIP_CHECK(ommhip_memset(force.ptr, 0, force.bytes, stream));
+    HIP_CHECK(ommhip_memset(pos.ptr, 0, pos.bytes, stream));
+    HIP_CHECK(ommhip_memset(xp.ptr, 0, xp.bytes, stream));
+    HIP_CHECK(ommhip_memset(oldx.ptr, 0, oldx.bytes, stream));
+    HIP_CHECK(ommhip_memset(wrap.ptr, 0, wrap.bytes, stream));
+    // velocities start at zero with w = 1/m
+    vector<Vec3> zero(numAtoms, Vec3());
+    uploadVelocities(zero);
+    // identity order
+    hostAtomOfSlot.assign(paddedAtoms, -1);
+    hostSlotOfAtom.resize(numAtoms);
+    for (int i = 0; i < numAtoms; i++) { hostAtomOfSlot[i] = i; hostSlotOfAtom[i] = i; }
+    HIP_CHECK(ommhip_memcpy_h2d(atomOfSlot.ptr, hostAtomOfSlot.data(), sizeof(int) * paddedAtoms, stream));
+    if (numAtoms > 0)
+        HIP_CHECK(ommhip_memcpy_h2d(slotOfAtom.ptr, hostSlotOfAtom.data(), sizeof(int) * numAtoms, stream));
+    for (int i = 0; i < 6; i++) box[i] = 0;
+    Vec3 a, b, c;
+    system.getDefaultPeriodicBoxVectors(a, b, c);
+    setBox(a, b, c);
+    sync();
+}
+
+HipContext::~HipContext() {
+    if (pinnedResult != NULL) ommhip_host_free(pinnedResult);
+    if (stream != NULL) ommhip_stream_destroy(stream);
+}
+
+void HipContext::setAsCurrent() {
+    HIP_CHECK(ommhip_set_device(deviceIndex));
+}
+
+void HipContext::sync() {
+    HIP_CHECK(ommhip_stream_sync(stream));
+}
+
+void HipContext::removeListener(HipContextListener* l) {
+    listeners.erase(std::remove(listeners.begin(), listeners.end(), l), listeners.end());
+}
+
+void HipContext::uploadPositions(const vector<Vec3>& positions) {
+    vector<D4> tmp(numAtoms);
+    for (int i = 0; i < numAtoms; i++) {
+        if (positions[i][0] != positions[i][0] || positions[i][1] != positions[i][1] || positions[i][2] != positions[i][2])
+            throw OpenMMException("Particle coordinate is NaN.  For more information, see https://github.com/openmm/openmm/wiki/Frequently-Asked-Questions#nan");
+        tmp[i].x = positions[i][0]; tmp[i].y = positions[i][1]; tmp[i].z = positions[i][2]; tmp[i].w = 0;
+    }
+    if (numAtoms > 0) HIP_CHECK(ommhip_memcpy_h2d(pos.ptr, tmp.data(), sizeof(D4) * numAtoms, stream));
+    sync();
+    positionsValid = true;
+}
+
+void HipContext::downloadPositions(vector<Vec3>& positions) {
+    vector<D4> tmp(numAtoms);
+    if (numAtoms > 0) HIP_CHECK(ommhip_memcpy_d2h(tmp.data(), pos.ptr, sizeof(D4) * numAtoms, stream));
+    sync();
+    positions.resize(numAtoms);
+    for (int i = 0; i < numAtoms; i++) positions[i] = Vec3(tmp[i].x, tmp[i].y, tmp[i].z);
+}
+
+void HipContext::uploadVelocities(const vector<Vec3>& velocities) {
+    vector<D4> tmp(numAtoms);
+    for (int i = 0; i < numAtoms; i++) {
+        tmp[i].x = velocities[i][0]; tmp[i].y = velocities[i][1]; tmp[i].z = velocities[i][2];
+        tmp[i].w = masses[i] == 0.0 ? 0.0 : 1.0 / masses[i];
+    }
+    if (numAtoms > 0) HIP_CHECK(ommhip_memcpy_h2d(vel.ptr, tmp.data(), sizeof(D4) * numAtoms, stream));
+    sync();
+}
+
+void HipContext::downloadVelocities(vector<Vec3>& velocities) {
+    vector<D4> tmp(numAtoms);
+    if (numAtoms > 0) HIP_CHECK(ommhip_memcpy_d2h(tmp.data(), vel.ptr, sizeof(D4) * numAtoms, stream));
+    sync();
+    velocities.resize(numAtoms);
+    for (int i = 0; i < numAtoms; i++) velocities[i] = Vec3(tmp[i].x, tmp[i].y, tmp[i].z);
+}
+
+void HipContext::downloadForces(vector<Vec3>& forces) {
+    forces.resize(numAtoms);
+    if (numAtoms == 0) return;
+    HIP_CHECK(ommhip_forces_to_double(force.as<long long>(), slotOfAtom.as<int>(), numAtoms, paddedAtoms, forceDouble.as<double>(), stream));
+    vector<double> tmp(3 * (size_t) numAtoms);
+    HIP_CHECK(ommhip_memcpy_d2h(tmp.data(), forceDouble.ptr, sizeof(double) * tmp.size(), stream));
+    sync();
+    for (int i = 0; i < numAtoms; i++) forces[i] = Vec3(tmp[3 * i], tmp[3 * i + 1], tmp[3 * i + 2]);
+}
+
+void HipContext::addHostForces(const vector<Vec3>& forces) {
+    if (numAtoms == 0) return;
+    vector<double> tmp(3 * (size_t) numAtoms);
+    for (int i = 0; i < numAtoms; i++) { tmp[3 * i] = forces[i][0]; tmp[3 * i + 1] = forces[i][1]; tmp[3 * i + 2] = forces[i][2]; }
+    HIP_CHECK(ommhip_memcpy_h2d(forceDouble.ptr, tmp.data(), sizeof(double) * tmp.size(), stream));
+    HIP_CHECK(ommhip_add_forces_from_double(forceDouble.as<double>(), slotOfAtom.as<int>(), numAtoms, paddedAtoms, force.as<long long>(), stream));
+    sync();   // tmp goes out of scope
+}
+
+void HipContext::setBox(const Vec3& a, const Vec3& b, const Vec3& c) {
+    double nb[6] = {a[0], b[0], b[1], c[0], c[1], c[2]};
+    bool changed = false;
+    for (int i = 0; i < 6; i++)
+        if (nb[i] != box[i]) changed = true;
+    boxVectors[0] = a; boxVectors[1] = b; boxVectors[2] = c;
+    if (!changed) return;
+    for (int i = 0; i < 6; i++) box[i] = nb[i];
+    reorderRequested = true;       // wrap indices depend on the box
+    for (size_t i = 0; i < listeners.size(); i++) listeners[i]->boxChanged();
+}
+
+void HipContext::clearForces() {
+    HIP_CHECK(ommhip_memset(force.ptr, 0, force.bytes, stream));
+}
+
+void HipContext::saveForces() {
+    if (savedForce.ptr == NULL) savedForce.allocate(force.bytes);
+    HIP_CHECK(ommhip_memcpy_d2d(savedForce.ptr, force.ptr, force.bytes, stream));
+}
+
+void HipContext::restoreForces() {
+    if (savedForce.ptr != NULL)
+        HIP_CHECK(ommhip_memcpy_d2d(force.ptr, savedForce.ptr, force.bytes, stream));
+}
+
+double HipContext::reduceEnergy() {
+    HIP_CHECK(ommhip_reduce_energy(energyBuffer.as<double>(), EnergySlots, energyResult.as<double>(), stream));
+    HIP_CHECK(ommhip_memcpy_d2h(pinnedResult, energyResult.ptr, sizeof(double), stream));
+    sync();
+    return pinnedResult[0];
+}
+
+void HipContext::stepTaken() {
+    stepsSinceReorder++;
+}
+
+void HipContext::computeOrder(const vector<Vec3>& positions, vector<int>& order, vector<int>& wrapOut) {
+    wrapOut.assign(4 * (size_t) numAtoms, 0);
+    order.resize(numAtoms);
+    for (int i = 0; i < numAtoms; i++) order[i] = i;
+    vector<Vec3> wrapped(positions);
+    if (usePeriodic) {
+        // periodic image such that the reduced position lies in the primary cell (triclinic aware)
+        for (int i = 0; i < numAtoms; i++) {
+            Vec3 p = positions[i];
+            int iz = (int) floor(p[2] / box[5]);
+            p[0] -= iz * box[3]; p[1] -= iz * box[4]; p[2] -= iz * box[5];
+            int iy = (int) floor(p[1] / box[2]);
+            p[0] -= iy * box[1]; p[1] -= iy * box[2];
+            int ix = (int) floor(p[0] / box[0]);
+            p[0] -= ix * box[0];
+            wrapOut[4 * i] = ix; wrapOut[4 * i + 1] = iy; wrapOut[4 * i + 2] = iz;
+            wrapped[i] = p;
+        }
+    }
+    if (sortCutoff <= 0.0 || numAtoms <= OMMHIP_TILE)
+        return;
+    // bin into cells of ~0.3 nm and walk the cells along a Hilbert curve
+    const double binWidth = 0.3;
+    Vec3 lo(1e300, 1e300, 1e300), hi(-1e300, -1e300, -1e300);
+    for (int i = 0; i < numAtoms; i++)
+        for (int k = 0; k < 3; k++) { lo[k] = min(lo[k], wrapped[i][k]); hi[k] = max(hi[k], wrapped[i][k]); }
+    int maxCells = 1;
+    int ncell[3];
+    for (int k = 0; k < 3; k++) {
+        ncell[k] = max(1, min(1023, (int) floor((hi[k] - lo[k]) / binWidth) + 1));
+        maxCells = max(maxCells, ncell[k]);
+    }
+    int bits = 1;
+    while ((1 << bits) < maxCells) bits++;
+    vector<pair<unsigned long long, int> > keyed(numAtoms);
+    for (int i = 0; i < numAtoms; i++) {
+        unsigned c[3];
+        for (int k = 0; k < 3; k++) {
+            int v = (int) floor((wrapped[i][k] - lo[k]) / binWidth);
+            c[k] = (unsigned) max(0, min(ncell[k] - 1, v));
+        }
+        keyed[i] = make_pair(hilbertIndex(c[0], c[1], c[2], bits), i);
+    }
+    sort(keyed.begin(), keyed.end());
+    for (int i = 0; i < numAtoms; i++) order[i] = keyed[i].second;
+}
+
+bool HipContext::reorderIfNeeded() {
+    if (!reorderRequested && stepsSinceReorder < reorderInterval)
+        return false;
+    reorderRequested = false;
+    stepsSinceReorder = 0;
+    if (!usePeriodic && sortCutoff <= 0.0)
+        return false;                       // identity order and no wrapping: nothing to do
+    vector<Vec3> positions;
+    downloadPositions(positions);
+    vector<int> order, wrapHost;
+    computeOrder(positions, order, wrapHost);
+    bool orderChanged = false;
+    for (int s = 0; s < numAtoms; s++)
+        if (hostAtomOfSlot[s] != order[s]) { orderChanged = true; break; }
+    for (int s = 0; s < numAtoms; s++) { hostAtomOfSlot[s] = order[s]; hostSlotOfAtom[order[s]] = s; }
+    HIP_CHECK(ommhip_memcpy_h2d(wrap.ptr, wrapHost.data(), sizeof(int) * wrapHost.size(), stream));
+    HIP_CHECK(ommhip_memcpy_h2d(atomOfSlot.ptr, hostAtomOfSlot.data(), sizeof(int) * paddedAtoms, stream));
+    HIP_CHECK(ommhip_memcpy_h2d(slotOfAtom.ptr, hostSlotOfAtom.data(), sizeof(int) * numAtoms, stream));
+    sync();
+    // wrap offsets may have changed even when the order did not: listeners rebuild their slot data either way
+    for (size_t i = 0; i < listeners.size(); i++) listeners[i]->atomsReordered();
+    return orderChanged;
+}

@@ -1,0 +1,118 @@
+#ifndef OPENMM_HIPCONTEXT_H_
+#define OPENMM_HIPCONTEXT_H_
+/* Per-Context device state of the OpenMM "HIP" platform (MI355X).  Host-side only: talks to the GPU
+ * exclusively through the C ABI of include/openmm_hip_kernels.h.
+ *
+ * Layout in HBM:
+ *   atom order  : pos double4[N], vel double4[N] (w = 1/m), xp, oldx, wrap int4[N]
+ *   slot order  : force int64[3*P] (fixed point, SoA), atomOfSlot int[P], slotOfAtom int[N]
+ * Each nonbonded kernel owns its own float posq/sigEps/neighbour list in slot order.
+ */
+#include "openmm_hip_kernels.h"
+#include "openmm/OpenMMException.h"
+#include "openmm/Vec3.h"
+#include <cstddef>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace OpenMM {
+
+class System;
+
+#define HIP_CHECK(call) do { int rc__ = (call); if (rc__ != 0) { std::stringstream s__; \
+    s__ << "HIP platform: " << #call << " failed with code " << rc__ << " (" << ommhip_error_string(rc__) << ") at " << __FILE__ << ":" << __LINE__; \
+    throw OpenMM::OpenMMException(s__.str()); } } while (0)
+
+/** RAII device allocation. */
+class DeviceBuffer {
+public:
+    DeviceBuffer() : ptr(NULL), bytes(0) {}
+    ~DeviceBuffer() { release(); }
+    void allocate(size_t nbytes) {
+        release();
+        HIP_CHECK(ommhip_malloc(&ptr, nbytes));
+        bytes = nbytes;
+    }
+    void release() {
+        if (ptr != NULL) ommhip_free(ptr);   // may run after runtime teardown: ignore errors
+        ptr = NULL; bytes = 0;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(ptr); }
+    void* ptr;
+    size_t bytes;
+private:
+    DeviceBuffer(const DeviceBuffer&);
+    DeviceBuffer& operator=(const DeviceBuffer&);
+};
+
+/** Something that must react when atoms are re-sorted or the periodic box changes. */
+class HipContextListener {
+public:
+    virtual ~HipContextListener() {}
+    virtual void atomsReordered() = 0;
+    virtual void boxChanged() = 0;
+    virtual void positionsSet() = 0;
+};
+
+class HipContext {
+public:
+    HipContext(const System& system, int deviceIndex, bool hostMode);
+    ~HipContext();
+    void setAsCurrent();
+    void sync();
+
+    // ---- state transfer (all blocking)
+    void uploadPositions(const std::vector<Vec3>& positions);
+    void downloadPositions(std::vector<Vec3>& positions);
+    void uploadVelocities(const std::vector<Vec3>& velocities);
+    void downloadVelocities(std::vector<Vec3>& velocities);
+    void downloadForces(std::vector<Vec3>& forces);            // from the fixed-point buffer
+    void addHostForces(const std::vector<Vec3>& forces);       // host forces -> fixed-point buffer
+    void setBox(const Vec3& a, const Vec3& b, const Vec3& c);
+    void getBox(Vec3& a, Vec3& b, Vec3& c) const { a = boxVectors[0]; b = boxVectors[1]; c = boxVectors[2]; }
+
+    // ---- per-evaluation
+    void clearForces();
+    void saveForces();                                          // device copy of the force buffer (energy-only evaluations)
+    void restoreForces();
+    double reduceEnergy();                                      // blocking; also zeroes the buffer
+    /** Spatially re-sort atoms into slots if requested or due.  Returns true if the order changed. */
+    bool reorderIfNeeded();
+    void requestReorder() { reorderRequested = true; }
+    void stepTaken();                                           // counts steps towards the next reorder
+
+    void addListener(HipContextListener* l) { listeners.push_back(l); }
+    void removeListener(HipContextListener* l);
+
+    // ---- immutable after construction
+    int numAtoms, paddedAtoms;
+    bool hostMode;                 // true: host vectors are authoritative (Reference integrator etc.)
+    void* stream;
+    std::vector<double> masses;
+
+    // ---- device arrays
+    DeviceBuffer savedForce;
+    DeviceBuffer pos, vel, xp, oldx, tempVel, wrap, force, atomOfSlot, slotOfAtom, energyBuffer, energyResult, forceDouble;
+    static const int EnergySlots = 2048;
+
+    // ---- host mirrors
+    double box[6];
+    Vec3 boxVectors[3];
+    bool usePeriodic;              // any force uses periodic boundary conditions
+    double sortCutoff;             // > 0 when a cutoff-based nonbonded force wants spatial sorting
+    std::vector<int> hostAtomOfSlot, hostSlotOfAtom;
+    bool positionsValid;
+    bool hasFallbackForces;        // some force kernels are Reference ones (need host positions/forces each evaluation)
+    int stepsSinceReorder, reorderInterval;
+
+private:
+    void computeOrder(const std::vector<Vec3>& positions, std::vector<int>& order, std::vector<int>& wrapOut);
+    std::vector<HipContextListener*> listeners;
+    bool reorderRequested;
+    int deviceIndex;
+    double* pinnedResult;
+};
+
+}  // namespace OpenMM
+#endif

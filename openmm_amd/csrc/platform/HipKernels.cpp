@@ -1,0 +1,990 @@
+#include "HipKernels.h"
+#include "ReferenceConstraints.h"
+#include "ReferenceSETTLEAlgorithm.h"
+#include "ReferenceCCMAAlgorithm.h"
+#include "ReferenceVirtualSites.h"
+#include "SimTKOpenMMRealType.h"
+#include "openmm/CMMotionRemover.h"
+#include "openmm/HarmonicAngleForce.h"
+#include "openmm/HarmonicBondForce.h"
+#include "openmm/Integrator.h"
+#include "openmm/LangevinIntegrator.h"
+#include "openmm/LangevinMiddleIntegrator.h"
+#include "openmm/NonbondedForce.h"
+#include "openmm/PeriodicTorsionForce.h"
+#include "openmm/VerletIntegrator.h"
+#include "openmm/internal/NonbondedForceImpl.h"
+#include "openmm/internal/OSRngSeed.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+
+using namespace OpenMM;
+using namespace std;
+
+namespace {
+template <class T>
+void uploadVector(DeviceBuffer& buf, const vector<T>& v, void* stream) {
+    buf.allocate(max(sizeof(T) * v.size(), (size_t) 16));
+    if (!v.empty()) {
+        HIP_CHECK(ommhip_memcpy_h2d(buf.ptr, v.data(), sizeof(T) * v.size(), stream));
+        HIP_CHECK(ommhip_stream_sync(stream));
+    }
+}
+}  // namespace
+
+// ================================================================================================
+// Constraints
+// ================================================================================================
+HipConstraints::HipConstraints(const System& system, HipPlatform::PlatformData& data) : hip(*data.hip), numSettle(0), numShake(0), numCcma(0) {
+    const int numParticles = system.getNumParticles();
+    vector<double> masses(numParticles);
+    for (int i = 0; i < numParticles; i++) masses[i] = system.getParticleMass(i);
+    vector<bool> isSettleAtom(numParticles, false);
+
+    // ---- SETTLE clusters: taken from the partition the Reference platform already made
+    //      (ReferenceConstraints.cpp:44-148), so both platforms treat the same waters analytically.
+    ReferenceSETTLEAlgorithm* settle = dynamic_cast<ReferenceSETTLEAlgorithm*>(data.constraints->settle);
+    if (settle != NULL) {
+        numSettle = settle->getNumClusters();
+        vector<int> atoms(4 * (size_t) numSettle);
+        vector<double> dist(2 * (size_t) numSettle);
+        for (int i = 0; i < numSettle; i++) {
+            int a1, a2, a3;
+            double d1, d2;
+            settle->getClusterParameters(i, a1, a2, a3, d1, d2);
+            atoms[4 * i] = a1; atoms[4 * i + 1] = a2; atoms[4 * i + 2] = a3; atoms[4 * i + 3] = 0;
+            dist[2 * i] = d1; dist[2 * i + 1] = d2;
+            isSettleAtom[a1] = isSettleAtom[a2] = isSettleAtom[a3] = true;
+        }
+        uploadVector(settleAtoms, atoms, hip.stream);
+        uploadVector(settleDist, dist, hip.stream);
+    }
+
+    // ---- everything else (ReferenceConstraints.cpp:150-184 sends these to CCMA)
+    vector<int> c1, c2;
+    vector<double> cd;
+    vector<vector<int> > atomConstraints(numParticles);
+    for (int i = 0; i < system.getNumConstraints(); i++) {
+        int p1, p2;
+        double d;
+        system.getConstraintParameters(i, p1, p2, d);
+        if (masses[p1] == 0 && masses[p2] == 0) continue;
+        if (isSettleAtom[p1]) continue;
+        atomConstraints[p1].push_back((int) c1.size());
+        atomConstraints[p2].push_back((int) c1.size());
+        c1.push_back(p1); c2.push_back(p2); cd.push_back(d);
+    }
+    const int numOther = (int) c1.size();
+    // SHAKE clusters: a centre with <= 3 satellites, each satellite constrained only to the centre,
+    // the centre constrained only to its satellites, no massless atoms.
+    vector<bool> inShake(numOther, false);
+    vector<int> shakeAtomsHost;
+    vector<double> shakeDistHost;
+    for (int atom = 0; atom < numParticles; atom++) {
+        const vector<int>& cons = atomConstraints[atom];
+        if (cons.empty() || cons.size() > 3) continue;
+        bool ok = masses[atom] != 0;
+        vector<int> sats;
+        for (size_t k = 0; k < cons.size() && ok; k++) {
+            int other = c1[cons[k]] == atom ? c2[cons[k]] : c1[cons[k]];
+            if (atomConstraints[other].size() != 1 || masses[other] == 0) ok = false;
+            sats.push_back(other);
+        }
+        if (!ok) continue;
+        if (cons.size() == 1) {
+            // a lone pair of atoms: both ends look like a centre; keep the lower index as centre
+            int other = sats[0];
+            if (atomConstraints[other].size() == 1 && other < atom) continue;
+        }
+        int base[4] = {atom, -1, -1, -1};
+        double d[4] = {0, 0, 0, 0};
+        for (size_t k = 0; k < cons.size(); k++) { base[k + 1] = sats[k]; d[k] = cd[cons[k]]; inShake[cons[k]] = true; }
+        for (int k = 0; k < 4; k++) { shakeAtomsHost.push_back(base[k]); shakeDistHost.push_back(d[k]); }
+    }
+    numShake = (int) shakeAtomsHost.size() / 4;
+    if (numShake > 0) {
+        uploadVector(shakeAtoms, shakeAtomsHost, hip.stream);
+        uploadVector(shakeDist, shakeDistHost, hip.stream);
+    }
+    // CCMA for the rest
+    vector<pair<int, int> > ccmaIndices;
+    vector<double> ccmaDistance;
+    for (int i = 0; i < numOther; i++)
+        if (!inShake[i]) { ccmaIndices.push_back(make_pair(c1[i], c2[i])); ccmaDistance.push_back(cd[i]); }
+    numCcma = (int) ccmaIndices.size();
+    memset(&ccma, 0, sizeof(ccma));
+    if (numCcma > 0) {
+        vector<ReferenceCCMAAlgorithm::AngleInfo> angles;
+        for (int i = 0; i < system.getNumForces(); i++) {
+            const HarmonicAngleForce* force = dynamic_cast<const HarmonicAngleForce*>(&system.getForce(i));
+            if (force != NULL)
+                for (int j = 0; j < force->getNumAngles(); j++) {
+                    int a1, a2, a3;
+                    double angle, k;
+                    force->getAngleParameters(j, a1, a2, a3, angle, k);
+                    angles.push_back(ReferenceCCMAAlgorithm::AngleInfo(a1, a2, a3, angle));
+                }
+        }
+        // The coupling-matrix inverse is built by the reference's own host code (ReferenceCCMAAlgorithm.cpp:57-196).
+        ReferenceCCMAAlgorithm host(numParticles, numCcma, ccmaIndices, ccmaDistance, masses, angles, 0.02);
+        const vector<vector<pair<int, double> > >& matrix = host.getMatrix();
+        vector<int> rowStart(numCcma + 1, 0), col, atoms(2 * (size_t) numCcma);
+        vector<double> value;
+        for (int i = 0; i < numCcma; i++) {
+            atoms[2 * i] = ccmaIndices[i].first; atoms[2 * i + 1] = ccmaIndices[i].second;
+            for (size_t j = 0; j < matrix[i].size(); j++) { col.push_back(matrix[i][j].first); value.push_back(matrix[i][j].second); }
+            rowStart[i + 1] = (int) col.size();
+        }
+        uploadVector(ccmaAtoms, atoms, hip.stream);
+        uploadVector(ccmaDist, ccmaDistance, hip.stream);
+        uploadVector(ccmaRowStart, rowStart, hip.stream);
+        uploadVector(ccmaCol, col, hip.stream);
+        uploadVector(ccmaValue, value, hip.stream);
+        ccmaDelta.allocate(sizeof(double) * numCcma);
+        ccmaDelta2.allocate(sizeof(double) * numCcma);
+        ccmaConverged.allocate(sizeof(int) * 4);
+        ccma.num_constraints = numCcma;
+        ccma.atoms = ccmaAtoms.as<int>(); ccma.distance = ccmaDist.as<double>();
+        ccma.delta = ccmaDelta.as<double>(); ccma.delta2 = ccmaDelta2.as<double>();
+        ccma.row_start = ccmaRowStart.as<int>(); ccma.col = ccmaCol.as<int>(); ccma.value = ccmaValue.as<double>();
+        ccma.converged = ccmaConverged.as<int>();
+    }
+}
+
+void HipConstraints::runCcma(void* target, bool velocities, double tol) {
+    // ReferenceCCMAAlgorithm.cpp:240-310; the converged count comes back to the host every iteration.
+    for (int iteration = 0; iteration < 150; iteration++) {
+        HIP_CHECK(ommhip_ccma_iteration(&ccma, hip.pos.ptr, target, hip.vel.ptr, velocities, tol, 0, hip.stream));
+        int converged = 0;
+        HIP_CHECK(ommhip_memcpy_d2h(&converged, ccma.converged, sizeof(int), hip.stream));
+        hip.sync();
+        if (converged == numCcma) break;
+        HIP_CHECK(ommhip_ccma_iteration(&ccma, hip.pos.ptr, target, hip.vel.ptr, velocities, tol, 1, hip.stream));
+    }
+}
+
+void HipConstraints::apply(void* target, double tol) {
+    if (numCcma > 0) runCcma(target, false, tol);
+    if (numShake > 0)
+        HIP_CHECK(ommhip_shake(numShake, shakeAtoms.as<int>(), shakeDist.as<double>(), hip.pos.ptr, target, hip.vel.ptr, 0, tol, 150, hip.stream));
+    if (numSettle > 0)
+        HIP_CHECK(ommhip_settle(numSettle, settleAtoms.as<int>(), settleDist.as<double>(), hip.pos.ptr, target, hip.vel.ptr, 0, hip.stream));
+}
+
+void HipConstraints::applyToVelocities(void* target, double tol) {
+    if (numCcma > 0) runCcma(target, true, tol);
+    if (numShake > 0)
+        HIP_CHECK(ommhip_shake(numShake, shakeAtoms.as<int>(), shakeDist.as<double>(), hip.pos.ptr, target, hip.vel.ptr, 1, tol, 150, hip.stream));
+    if (numSettle > 0)
+        HIP_CHECK(ommhip_settle(numSettle, settleAtoms.as<int>(), settleDist.as<double>(), hip.pos.ptr, target, hip.vel.ptr, 1, hip.stream));
+}
+
+// ================================================================================================
+// CalcForcesAndEnergy
+// ================================================================================================
+void HipCalcForcesAndEnergyKernel::initialize(const System& system) {
+}
+
+void HipCalcForcesAndEnergyKernel::beginComputation(ContextImpl& context, bool includeForce, bool includeEnergy, int groups) {
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    if (hip.hostMode) {
+        // Host vectors are authoritative: bring positions and box to the device for the native force kernels.
+        hip.setBox(data.periodicBoxVectors[0], data.periodicBoxVectors[1], data.periodicBoxVectors[2]);
+        hip.uploadPositions(*data.positions);
+        hip.requestReorder();
+    }
+    hip.reorderIfNeeded();
+    if (hip.hostMode || hip.hasFallbackForces) {
+        // what ReferenceCalcForcesAndEnergyKernel::beginComputation does (ReferenceKernels.cpp:181-195)
+        if (!hip.hostMode) hip.downloadPositions(*data.positions);
+        vector<Vec3>& forces = *data.forces;
+        if (includeForce)
+            for (size_t i = 0; i < forces.size(); i++) forces[i] = Vec3();
+        else
+            savedHostForces = forces;
+    }
+    for (map<string, double>::const_iterator it = context.getParameters().begin(); it != context.getParameters().end(); ++it)
+        (*data.energyParameterDerivatives)[it->first] = 0;
+    // An energy-only evaluation must leave the forces of the last full evaluation intact (ReferenceKernels.cpp:190-191,198-199):
+    // the leapfrog kinetic energy reads them afterwards.
+    if (!includeForce && !hip.hostMode)
+        hip.saveForces();
+    hip.clearForces();
+}
+
+double HipCalcForcesAndEnergyKernel::finishComputation(ContextImpl& context, bool includeForce, bool includeEnergy, int groups, bool& valid) {
+    HipContext& hip = *data.hip;
+    double energy = 0;
+    if (includeEnergy) energy = hip.reduceEnergy();
+    if (hip.hostMode) {
+        if (includeForce) {
+            vector<Vec3> deviceForces;
+            hip.downloadForces(deviceForces);
+            vector<Vec3>& forces = *data.forces;
+            for (size_t i = 0; i < forces.size(); i++) forces[i] += deviceForces[i];
+            // ReferenceKernels.cpp:200: virtual-site forces go to their parent atoms (host mode only has sites)
+            ReferenceVirtualSites::distributeForces(context.getSystem(), *data.positions, forces);
+        }
+        else
+            *data.forces = savedHostForces;
+    }
+    else {
+        if (!includeForce) {
+            hip.restoreForces();
+            if (hip.hasFallbackForces) *data.forces = savedHostForces;
+        }
+        else if (hip.hasFallbackForces)
+            hip.addHostForces(*data.forces);
+    }
+    valid = true;
+    return energy;
+}
+
+// ================================================================================================
+// UpdateStateData
+// ================================================================================================
+void HipUpdateStateDataKernel::initialize(const System& system) {
+}
+double HipUpdateStateDataKernel::getTime(const ContextImpl& context) const { return data.time; }
+void HipUpdateStateDataKernel::setTime(ContextImpl& context, double time) { data.time = time; }
+void HipUpdateStateDataKernel::getPositions(ContextImpl& context, vector<Vec3>& positions) {
+    data.hip->setAsCurrent();
+    data.hip->downloadPositions(positions);
+}
+void HipUpdateStateDataKernel::setPositions(ContextImpl& context, const vector<Vec3>& positions) {
+    data.hip->setAsCurrent();
+    data.hip->uploadPositions(positions);
+    data.hip->requestReorder();
+    *data.positions = positions;
+}
+void HipUpdateStateDataKernel::getVelocities(ContextImpl& context, vector<Vec3>& velocities) {
+    data.hip->setAsCurrent();
+    data.hip->downloadVelocities(velocities);
+}
+void HipUpdateStateDataKernel::setVelocities(ContextImpl& context, const vector<Vec3>& velocities) {
+    data.hip->setAsCurrent();
+    data.hip->uploadVelocities(velocities);
+}
+void HipUpdateStateDataKernel::getForces(ContextImpl& context, vector<Vec3>& forces) {
+    data.hip->setAsCurrent();
+    data.hip->downloadForces(forces);
+}
+void HipUpdateStateDataKernel::getEnergyParameterDerivatives(ContextImpl& context, map<string, double>& derivs) {
+    derivs = *data.energyParameterDerivatives;
+}
+void HipUpdateStateDataKernel::getPeriodicBoxVectors(ContextImpl& context, Vec3& a, Vec3& b, Vec3& c) const {
+    data.hip->getBox(a, b, c);
+}
+void HipUpdateStateDataKernel::setPeriodicBoxVectors(ContextImpl& context, const Vec3& a, const Vec3& b, const Vec3& c) {
+    data.hip->setBox(a, b, c);
+    data.periodicBoxVectors[0] = a; data.periodicBoxVectors[1] = b; data.periodicBoxVectors[2] = c;
+    *data.periodicBoxSize = Vec3(a[0], b[1], c[2]);
+}
+void HipUpdateStateDataKernel::createCheckpoint(ContextImpl& context, ostream& stream) {
+    // same content as ReferenceUpdateStateDataKernel::createCheckpoint (ReferenceKernels.cpp:282-294);
+    // the integrators' random numbers are a pure function of (seed, stepCount, atom), so no RNG state is needed.
+    int version = 1;
+    stream.write((char*) &version, sizeof(int));
+    stream.write((char*) &data.time, sizeof(double));
+    stream.write((char*) &data.stepCount, sizeof(int));
+    vector<Vec3> pos, vel;
+    data.hip->downloadPositions(pos);
+    data.hip->downloadVelocities(vel);
+    stream.write((char*) pos.data(), sizeof(Vec3) * pos.size());
+    stream.write((char*) vel.data(), sizeof(Vec3) * vel.size());
+    Vec3 box[3];
+    data.hip->getBox(box[0], box[1], box[2]);
+    stream.write((char*) box, 3 * sizeof(Vec3));
+}
+void HipUpdateStateDataKernel::loadCheckpoint(ContextImpl& context, istream& stream) {
+    int version;
+    stream.read((char*) &version, sizeof(int));
+    if (version != 1) throw OpenMMException("Checkpoint was created with a different version of OpenMM");
+    stream.read((char*) &data.time, sizeof(double));
+    stream.read((char*) &data.stepCount, sizeof(int));
+    vector<Vec3> pos(data.hip->numAtoms), vel(data.hip->numAtoms);
+    stream.read((char*) pos.data(), sizeof(Vec3) * pos.size());
+    stream.read((char*) vel.data(), sizeof(Vec3) * vel.size());
+    Vec3 box[3];
+    stream.read((char*) box, 3 * sizeof(Vec3));
+    setPeriodicBoxVectors(context, box[0], box[1], box[2]);
+    setPositions(context, pos);
+    setVelocities(context, vel);
+}
+
+// ================================================================================================
+// ApplyConstraints
+// ================================================================================================
+void HipApplyConstraintsKernel::initialize(const System& system) {
+}
+void HipApplyConstraintsKernel::apply(ContextImpl& context, double tol) {
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    HipConstraints& constraints = data.getDeviceConstraints(context.getSystem());
+    if (!constraints.hasConstraints()) return;
+    // ReferenceKernels.cpp:318-324: constrain the current positions in place
+    HIP_CHECK(ommhip_memcpy_d2d(hip.xp.ptr, hip.pos.ptr, hip.pos.bytes, hip.stream));
+    constraints.apply(hip.xp.ptr, tol);
+    HIP_CHECK(ommhip_memcpy_d2d(hip.pos.ptr, hip.xp.ptr, hip.pos.bytes, hip.stream));
+}
+void HipApplyConstraintsKernel::applyToVelocities(ContextImpl& context, double tol) {
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    HipConstraints& constraints = data.getDeviceConstraints(context.getSystem());
+    if (!constraints.hasConstraints()) return;
+    constraints.applyToVelocities(hip.vel.ptr, tol);
+}
+
+// ================================================================================================
+// NonbondedForce
+// ================================================================================================
+static vector<HipCalcNonbondedForceKernel*> liveNonbondedKernels;
+
+HipCalcNonbondedForceKernel::HipCalcNonbondedForceKernel(string name, const Platform& platform, HipPlatform::PlatformData& data) :
+        CalcNonbondedForceKernel(name, platform), data(data), hip(*data.hip), numParticles(0), num14(0), numExclusionPairs(0),
+        slotParamsDirty(true), forceRebuild(true), etermDirty(true), hasInitializedParams(false), pinnedState(NULL), stateCopyPending(false) {
+    memset(&nl, 0, sizeof(nl));
+    memset(&params, 0, sizeof(params));
+    memset(&pme, 0, sizeof(pme));
+    hip.addListener(this);
+    liveNonbondedKernels.push_back(this);
+}
+
+/* Diagnostics for bench.py: neighbour-list occupancy of the most recently created native NonbondedForce kernel. */
+extern "C" __attribute__((visibility("default"))) int ommhip_plugin_nl_stats(long long* out) {
+    if (liveNonbondedKernels.empty()) return 1;
+    try { liveNonbondedKernels.back()->getNeighborListStats(out); } catch (...) { return 2; }
+    return 0;
+}
+
+void HipCalcNonbondedForceKernel::getNeighborListStats(long long* out) {
+    hip.setAsCurrent();
+    int state[OMMHIP_NL_STATE_INTS];
+    HIP_CHECK(ommhip_memcpy_d2h(state, nlState.ptr, sizeof(state), hip.stream));
+    hip.sync();
+    const int chunks = min(state[1], nl.max_chunks);
+    vector<int> info(2 * (size_t) max(chunks, 1));
+    if (chunks > 0) {
+        HIP_CHECK(ommhip_memcpy_d2h(info.data(), chunkInfo.ptr, sizeof(int) * 2 * (size_t) chunks, hip.stream));
+        hip.sync();
+    }
+    long long rows = 0;
+    for (int c = 0; c < chunks; c++) rows += info[2 * c + 1] & 0xff;
+    out[0] = numParticles; out[1] = hip.paddedAtoms; out[2] = chunks; out[3] = rows; out[4] = nl.max_chunks; out[5] = state[4];
+}
+
+HipCalcNonbondedForceKernel::~HipCalcNonbondedForceKernel() {
+    liveNonbondedKernels.erase(std::remove(liveNonbondedKernels.begin(), liveNonbondedKernels.end(), this), liveNonbondedKernels.end());
+    hip.removeListener(this);
+    if (pinnedState != NULL) ommhip_host_free(pinnedState);
+}
+
+void HipCalcNonbondedForceKernel::atomsReordered() { slotParamsDirty = true; forceRebuild = true; }
+void HipCalcNonbondedForceKernel::boxChanged() { etermDirty = true; forceRebuild = true; }
+void HipCalcNonbondedForceKernel::positionsSet() { forceRebuild = true; }
+
+static int findLegalFftDimension(int minimum) {
+    // smallest size >= minimum that the LDS FFT handles (2,3,5,7-smooth); same role as CudaFFT3D::findLegalDimension
+    int n = max(minimum, 2);
+    while (!ommhip_fft_supported_size(n)) n++;
+    return n;
+}
+
+static vector<double> bsplineModuli(int n) {
+    // ReferencePME.cpp:98-193 for order 5: B-spline values at the knots, then |DFT|^2 with the small-modulus fix-up.
+    const int order = 5;
+    double data[order] = {1, 0, 0, 0, 0};
+    for (int k = 3; k < order; k++) {
+        double div = 1.0 / (k - 1.0);
+        data[k - 1] = 0;
+        for (int l = 1; l < k - 1; l++) data[k - l - 1] = div * (l * data[k - l - 2] + (k - l) * data[k - l - 1]);
+        data[0] = div * data[0];
+    }
+    double div = 1.0 / (order - 1);
+    data[order - 1] = 0;
+    for (int l = 1; l < order - 1; l++) data[order - l - 1] = div * (l * data[order - l - 2] + (order - l) * data[order - l - 1]);
+    data[0] = div * data[0];
+    vector<double> bs(max(n, order + 1), 0.0), mod(n);
+    for (int i = 1; i <= order; i++) bs[i] = data[i - 1];
+    for (int i = 0; i < n; i++) {
+        double sc = 0, ss = 0;
+        for (int j = 0; j < n; j++) {
+            double arg = (2.0 * M_PI * i * j) / n;
+            sc += bs[j] * cos(arg);
+            ss += bs[j] * sin(arg);
+        }
+        mod[i] = sc * sc + ss * ss;
+    }
+    for (int i = 0; i < n; i++)
+        if (mod[i] < 1.0e-7) mod[i] = (mod[(i - 1 + n) % n] + mod[(i + 1) % n]) / 2;
+    return mod;
+}
+
+void HipCalcNonbondedForceKernel::initialize(const System& system, const NonbondedForce& force) {
+    hip.setAsCurrent();
+    numParticles = force.getNumParticles();
+    if (numParticles != hip.numAtoms)
+        throw OpenMMException("NonbondedForce must have exactly as many particles as the System it belongs to.");
+
+    // ---- exceptions: every one is an exclusion; those with interactions are "1-4s" (ReferenceKernels.cpp:869-896)
+    set<int> exceptionsWithOffsets;
+    for (int i = 0; i < force.getNumExceptionParameterOffsets(); i++) {
+        string param; int exception; double charge, sigma, epsilon;
+        force.getExceptionParameterOffset(i, param, exception, charge, sigma, epsilon);
+        exceptionsWithOffsets.insert(exception);
+    }
+    vector<set<int> > exclusions(numParticles);
+    vector<int> nb14s;
+    map<int, int> nb14Index;
+    vector<int> exclusionPairs;
+    for (int i = 0; i < force.getNumExceptions(); i++) {
+        int p1, p2; double chargeProd, sigma, epsilon;
+        force.getExceptionParameters(i, p1, p2, chargeProd, sigma, epsilon);
+        if (exclusions[p1].insert(p2).second) { exclusionPairs.push_back(min(p1, p2)); exclusionPairs.push_back(max(p1, p2)); }
+        exclusions[p2].insert(p1);
+        if (chargeProd != 0.0 || epsilon != 0.0 || exceptionsWithOffsets.find(i) != exceptionsWithOffsets.end()) {
+            nb14Index[i] = (int) nb14s.size();
+            nb14s.push_back(i);
+        }
+    }
+    num14 = (int) nb14s.size();
+    numExclusionPairs = (int) exclusionPairs.size() / 2;
+    baseParticleParams.assign(numParticles, vector<double>(3));
+    baseExceptionParams.assign(num14, vector<double>(3));
+    exceptionAtoms.resize(num14);
+    for (int i = 0; i < numParticles; i++)
+        force.getParticleParameters(i, baseParticleParams[i][0], baseParticleParams[i][1], baseParticleParams[i][2]);
+    vector<int> exceptionAtomsFlat(2 * (size_t) num14);
+    for (int i = 0; i < num14; i++) {
+        int p1, p2;
+        force.getExceptionParameters(nb14s[i], p1, p2, baseExceptionParams[i][0], baseExceptionParams[i][1], baseExceptionParams[i][2]);
+        exceptionAtoms[i] = make_pair(p1, p2);
+        exceptionAtomsFlat[2 * i] = p1; exceptionAtomsFlat[2 * i + 1] = p2;
+    }
+    for (int i = 0; i < force.getNumParticleParameterOffsets(); i++) {
+        string param; int particle; double charge, sigma, epsilon;
+        force.getParticleParameterOffset(i, param, particle, charge, sigma, epsilon);
+        particleParamOffsets[make_pair(param, particle)] = {charge, sigma, epsilon};
+    }
+    for (int i = 0; i < force.getNumExceptionParameterOffsets(); i++) {
+        string param; int exception; double charge, sigma, epsilon;
+        force.getExceptionParameterOffset(i, param, exception, charge, sigma, epsilon);
+        exceptionParamOffsets[make_pair(param, nb14Index[exception])] = {charge, sigma, epsilon};
+    }
+
+    // ---- method and derived constants (ReferenceKernels.cpp:926-964)
+    nonbondedMethod = CalcNonbondedForceKernel::NonbondedMethod(force.getNonbondedMethod());
+    nonbondedCutoff = force.getCutoffDistance();
+    useSwitchingFunction = nonbondedMethod != NoCutoff && force.getUseSwitchingFunction();
+    switchingDistance = force.getSwitchingDistance();
+    rfDielectric = force.getReactionFieldDielectric();
+    ewaldAlpha = 0;
+    kmax[0] = kmax[1] = kmax[2] = 0;
+    gridSize[0] = gridSize[1] = gridSize[2] = 0;
+    if (nonbondedMethod == LJPME)
+        throw OpenMMException("HIP platform: LJPME is handled by the Reference kernel (internal error: native kernel created)");
+    if (nonbondedMethod == Ewald) {
+        NonbondedForceImpl::calcEwaldParameters(system, force, ewaldAlpha, kmax[0], kmax[1], kmax[2]);
+    }
+    else if (nonbondedMethod == PME) {
+        NonbondedForceImpl::calcPMEParameters(system, force, ewaldAlpha, gridSize[0], gridSize[1], gridSize[2], false);
+        for (int k = 0; k < 3; k++) gridSize[k] = findLegalFftDimension(gridSize[k]);
+    }
+    usesPeriodic = nonbondedMethod == CutoffPeriodic || nonbondedMethod == Ewald || nonbondedMethod == PME;
+    exceptionsArePeriodic = usesPeriodic && force.getExceptionsUsePeriodicBoundaryConditions();
+    if (force.getUseDispersionCorrection() && usesPeriodic)
+        dispersionCoefficient = NonbondedForceImpl::calcDispersionCorrection(system, force);
+    else
+        dispersionCoefficient = 0.0;
+    if (usesPeriodic) hip.usePeriodic = true;
+    if (nonbondedMethod != NoCutoff) hip.sortCutoff = max(hip.sortCutoff, nonbondedCutoff);
+    hip.requestReorder();
+    padding = nonbondedMethod == NoCutoff ? 0.0 : 0.1 * nonbondedCutoff;
+
+    // ---- device arrays
+    const int P = hip.paddedAtoms;
+    chargeD.allocate(sizeof(double) * max(numParticles, 1));
+    sigmaD.allocate(sizeof(double) * max(numParticles, 1));
+    epsilonD.allocate(sizeof(double) * max(numParticles, 1));
+    posq.allocate(sizeof(float) * 4 * P);
+    posqRef.allocate(sizeof(float) * 4 * P);
+    sigEps.allocate(sizeof(float) * 2 * P);
+    HIP_CHECK(ommhip_memset(posq.ptr, 0, posq.bytes, hip.stream));
+    HIP_CHECK(ommhip_memset(posqRef.ptr, 0, posqRef.bytes, hip.stream));
+    vector<int> start(numParticles + 1, 0), flat;
+    for (int i = 0; i < numParticles; i++) {
+        for (set<int>::const_iterator it = exclusions[i].begin(); it != exclusions[i].end(); ++it) flat.push_back(*it);
+        start[i + 1] = (int) flat.size();
+    }
+    uploadVector(exclStart, start, hip.stream);
+    uploadVector(exclAtoms, flat, hip.stream);
+    uploadVector(exceptionAtomsD, exceptionAtomsFlat, hip.stream);
+    exceptionParamsD.allocate(sizeof(double) * 3 * max(num14, 1));
+    uploadVector(exclusionPairsD, exclusionPairs, hip.stream);
+    nlState.allocate(sizeof(int) * OMMHIP_NL_STATE_INTS);
+    HIP_CHECK(ommhip_memset(nlState.ptr, 0, nlState.bytes, hip.stream));
+    blockCenter.allocate(sizeof(float) * 4 * (P / OMMHIP_TILE));
+    blockHalf.allocate(sizeof(float) * 4 * (P / OMMHIP_TILE));
+    HIP_CHECK(ommhip_host_malloc((void**) &pinnedState, sizeof(int) * OMMHIP_NL_STATE_INTS));
+    memset(pinnedState, 0, sizeof(int) * OMMHIP_NL_STATE_INTS);
+
+    nl.num_atoms = numParticles; nl.padded_atoms = P;
+    nl.pbc = 0;
+    nl.cutoff = nonbondedMethod == NoCutoff ? 0.0 : nonbondedCutoff;
+    nl.padding = padding;
+    nl.posq = posq.ptr; nl.posq_ref = posqRef.ptr;
+    nl.atom_of_slot = hip.atomOfSlot.as<int>(); nl.slot_of_atom = hip.slotOfAtom.as<int>();
+    nl.excl_start = exclStart.as<int>(); nl.excl_atoms = exclAtoms.as<int>();
+    nl.state = nlState.as<int>();
+    nl.block_center = blockCenter.ptr; nl.block_half = blockHalf.ptr;
+    nl.max_chunks = 0;
+
+    params.ewald = (nonbondedMethod == Ewald || nonbondedMethod == PME) ? 1 : 0;
+    params.use_switch = useSwitchingFunction ? 1 : 0;
+    params.ewald_alpha = ewaldAlpha;
+    params.krf = params.crf = 0;
+    if (nonbondedMethod == CutoffNonPeriodic || nonbondedMethod == CutoffPeriodic) {
+        // ReferenceLJCoulombIxn.cpp:78-79
+        params.krf = pow(nonbondedCutoff, -3.0) * (rfDielectric - 1.0) / (2.0 * rfDielectric + 1.0);
+        params.crf = (1.0 / nonbondedCutoff) * (3.0 * rfDielectric) / (2.0 * rfDielectric + 1.0);
+    }
+    params.switch_distance = switchingDistance;
+    params.direct_grid = 0;
+    if (nonbondedMethod == PME) setupPme();
+    if (nonbondedMethod == Ewald)
+        ewaldStructure.allocate(sizeof(double) * 2 * (size_t) kmax[0] * (2 * kmax[1] - 1) * (2 * kmax[2] - 1));
+    hip.sync();
+}
+
+void HipCalcNonbondedForceKernel::setupPme() {
+    const int nx = gridSize[0], ny = gridSize[1], nz = gridSize[2], nzc = nz / 2 + 1;
+    uploadVector(moduliX, bsplineModuli(nx), hip.stream);
+    uploadVector(moduliY, bsplineModuli(ny), hip.stream);
+    uploadVector(moduliZ, bsplineModuli(nz), hip.stream);
+    DeviceBuffer* tw[3] = {&twiddleX, &twiddleY, &twiddleZ};
+    for (int d = 0; d < 3; d++) {
+        const int n = gridSize[d];
+        vector<float> t(2 * (size_t) n);
+        for (int k = 0; k < n; k++) { t[2 * k] = (float) cos(2.0 * M_PI * k / n); t[2 * k + 1] = (float) -sin(2.0 * M_PI * k / n); }
+        uploadVector(*tw[d], t, hip.stream);
+    }
+    eterm.allocate(sizeof(float) * (size_t) nx * ny * nzc);
+    gridReal.allocate(sizeof(float) * (size_t) nx * ny * nz);
+    gridComplex.allocate(sizeof(float) * 2 * (size_t) nx * ny * nzc);
+    pme.nx = nx; pme.ny = ny; pme.nz = nz; pme.alpha = ewaldAlpha;
+    pme.moduli_x = moduliX.as<double>(); pme.moduli_y = moduliY.as<double>(); pme.moduli_z = moduliZ.as<double>();
+    pme.eterm = eterm.ptr; pme.grid_real = gridReal.ptr; pme.grid_complex = gridComplex.ptr;
+    pme.twiddle_x = twiddleX.ptr; pme.twiddle_y = twiddleY.ptr; pme.twiddle_z = twiddleZ.ptr;
+    etermDirty = true;
+}
+
+int HipCalcNonbondedForceKernel::estimateChunks() const {
+    const int numBlocks = hip.paddedAtoms / OMMHIP_TILE;
+    double rows;
+    if (nonbondedMethod == NoCutoff || !usesPeriodic)
+        rows = 0.5 * (double) numBlocks * hip.paddedAtoms / OMMHIP_ROW + numBlocks;     // all pairs (upper bound for non-periodic cutoffs)
+    else {
+        const double volume = hip.box[0] * hip.box[2] * hip.box[5];
+        const double density = numParticles / volume;
+        const double a = pow(OMMHIP_TILE / density, 1.0 / 3.0), r = nonbondedCutoff + padding;
+        const double minkowski = a * a * a + 6 * a * a * r + 3 * M_PI * a * r * r + 4.0 / 3.0 * M_PI * r * r * r;
+        rows = numBlocks * (0.5 * min((double) hip.paddedAtoms, density * minkowski) / OMMHIP_ROW + 1.0);
+    }
+    double chunks = rows / OMMHIP_CHUNK_ROWS + numBlocks;
+    return (int) min(chunks * 1.3 + 64, 2.0e8);
+}
+
+void HipCalcNonbondedForceKernel::allocateNeighborList(int maxChunks) {
+    chunkInfo.allocate(sizeof(int) * 2 * (size_t) maxChunks);
+    rowJ.allocate(sizeof(int) * (size_t) maxChunks * OMMHIP_CHUNK_ROWS * OMMHIP_ROW);
+    rowMask.allocate(sizeof(unsigned) * (size_t) maxChunks * OMMHIP_CHUNK_ROWS * OMMHIP_ROW);
+    nl.max_chunks = maxChunks;
+    nl.chunk_info = chunkInfo.ptr; nl.row_j = rowJ.as<int>(); nl.row_mask = rowMask.as<unsigned>();
+}
+
+void HipCalcNonbondedForceKernel::computeParameters(ContextImpl& context, bool forceUpdate) {
+    // ReferenceKernels.cpp:1077-1121; re-evaluated only when a global parameter with an offset changed.
+    bool changed = forceUpdate || !hasInitializedParams;
+    for (map<pair<string, int>, vector<double> >::const_iterator it = particleParamOffsets.begin(); it != particleParamOffsets.end(); ++it) {
+        double v = context.getParameter(it->first.first);
+        map<string, double>::iterator last = lastGlobalValues.find(it->first.first);
+        if (last == lastGlobalValues.end() || last->second != v) { changed = true; lastGlobalValues[it->first.first] = v; }
+    }
+    for (map<pair<string, int>, vector<double> >::const_iterator it = exceptionParamOffsets.begin(); it != exceptionParamOffsets.end(); ++it) {
+        double v = context.getParameter(it->first.first);
+        map<string, double>::iterator last = lastGlobalValues.find(it->first.first);
+        if (last == lastGlobalValues.end() || last->second != v) { changed = true; lastGlobalValues[it->first.first] = v; }
+    }
+    if (!changed) return;
+    hasInitializedParams = true;
+    vector<double> sigmas(numParticles), epsilons(numParticles);
+    charges.resize(numParticles);
+    for (int i = 0; i < numParticles; i++) { charges[i] = baseParticleParams[i][0]; sigmas[i] = baseParticleParams[i][1]; epsilons[i] = baseParticleParams[i][2]; }
+    for (map<pair<string, int>, vector<double> >::const_iterator it = particleParamOffsets.begin(); it != particleParamOffsets.end(); ++it) {
+        double value = lastGlobalValues[it->first.first];
+        int index = it->first.second;
+        charges[index] += value * it->second[0]; sigmas[index] += value * it->second[1]; epsilons[index] += value * it->second[2];
+    }
+    vector<double> ex(3 * (size_t) num14);
+    for (int i = 0; i < num14; i++) { ex[3 * i] = baseExceptionParams[i][0]; ex[3 * i + 1] = baseExceptionParams[i][1]; ex[3 * i + 2] = baseExceptionParams[i][2]; }
+    for (map<pair<string, int>, vector<double> >::const_iterator it = exceptionParamOffsets.begin(); it != exceptionParamOffsets.end(); ++it) {
+        double value = lastGlobalValues[it->first.first];
+        int index = it->first.second;
+        ex[3 * index] += value * it->second[0]; ex[3 * index + 1] += value * it->second[1]; ex[3 * index + 2] += value * it->second[2];
+    }
+    if (numParticles > 0) {
+        HIP_CHECK(ommhip_memcpy_h2d(chargeD.ptr, charges.data(), sizeof(double) * numParticles, hip.stream));
+        HIP_CHECK(ommhip_memcpy_h2d(sigmaD.ptr, sigmas.data(), sizeof(double) * numParticles, hip.stream));
+        HIP_CHECK(ommhip_memcpy_h2d(epsilonD.ptr, epsilons.data(), sizeof(double) * numParticles, hip.stream));
+    }
+    if (num14 > 0)
+        HIP_CHECK(ommhip_memcpy_h2d(exceptionParamsD.ptr, ex.data(), sizeof(double) * ex.size(), hip.stream));
+    hip.sync();
+    // Ewald self energy (ReferenceLJCoulombIxn.cpp:220-233)
+    selfEnergy = 0;
+    if (nonbondedMethod == Ewald || nonbondedMethod == PME)
+        for (int i = 0; i < numParticles; i++) selfEnergy -= ONE_4PI_EPS0 * charges[i] * charges[i] * ewaldAlpha / sqrt(M_PI);
+    slotParamsDirty = true;
+}
+
+double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy, bool includeDirect, bool includeReciprocal) {
+    hip.setAsCurrent();
+    computeParameters(context, false);
+    if (numParticles == 0) return 0.0;
+    for (int i = 0; i < 6; i++) nl.box[i] = hip.box[i];
+    if (usesPeriodic) {
+        // ReferenceKernels.cpp:981-985
+        double minAllowedSize = 1.999999 * nonbondedCutoff;
+        if (hip.box[0] < minAllowedSize || hip.box[2] < minAllowedSize || hip.box[5] < minAllowedSize)
+            throw OpenMMException("The periodic box size has decreased to less than twice the nonbonded cutoff.");
+        nl.pbc = (hip.box[1] != 0.0 || hip.box[3] != 0.0 || hip.box[4] != 0.0) ? 2 : 1;
+    }
+    if (slotParamsDirty) {
+        HIP_CHECK(ommhip_set_slot_params(chargeD.as<double>(), sigmaD.as<double>(), epsilonD.as<double>(), hip.atomOfSlot.as<int>(), hip.paddedAtoms, posq.ptr, sigEps.ptr, hip.stream));
+        slotParamsDirty = false;
+    }
+    HIP_CHECK(ommhip_positions_to_posq(hip.pos.ptr, hip.wrap.ptr, hip.atomOfSlot.as<int>(), hip.paddedAtoms, hip.box, posq.ptr, hip.stream));
+    double energy = 0;
+    const int ie = includeEnergy ? 1 : 0;
+    if (includeDirect) {
+        if (nl.max_chunks == 0) allocateNeighborList(estimateChunks());
+        // A list that overflowed during an earlier (device-triggered) rebuild shows up here one evaluation late.
+        if (stateCopyPending) {
+            if (pinnedState[2] != 0 || pinnedState[1] > nl.max_chunks) {
+                fprintf(stderr, "HIP platform: neighbour list overflowed (%d chunks needed, %d allocated); growing and rebuilding\n", pinnedState[1], nl.max_chunks);
+                hip.sync();
+                allocateNeighborList((int) (pinnedState[1] * 1.5) + 64);
+                forceRebuild = true;
+            }
+        }
+        while (true) {
+            if (forceRebuild) {
+                int one = 1;
+                HIP_CHECK(ommhip_memcpy_h2d(nlState.ptr, &one, sizeof(int), hip.stream));
+            }
+            HIP_CHECK(ommhip_nl_update(&nl, hip.stream));
+            if (!forceRebuild) break;
+            // host-requested rebuild: verify the capacity synchronously
+            HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
+            hip.sync();
+            if (pinnedState[2] == 0 && pinnedState[1] <= nl.max_chunks) { forceRebuild = false; break; }
+            allocateNeighborList((int) (pinnedState[1] * 1.3) + 64);
+        }
+        HIP_CHECK(ommhip_nb_direct(&nl, &params, sigEps.ptr, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+        HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
+        stateCopyPending = true;
+        ommhip_term_list t14 = {num14, exceptionAtomsD.as<int>(), exceptionParamsD.as<double>()};
+        HIP_CHECK(ommhip_term_forces(OMMHIP_TERM_EXCEPTION14, &t14, hip.pos.ptr, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.box, exceptionsArePeriodic ? 1 : 0,
+                                     chargeD.as<double>(), ewaldAlpha, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+        if (params.ewald) {
+            ommhip_term_list tex = {numExclusionPairs, exclusionPairsD.as<int>(), NULL};
+            HIP_CHECK(ommhip_term_forces(OMMHIP_TERM_EWALD_EXCLUSION, &tex, hip.pos.ptr, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.box, exceptionsArePeriodic ? 1 : 0,
+                                         chargeD.as<double>(), ewaldAlpha, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+        }
+        if (includeEnergy && usesPeriodic)
+            energy += dispersionCoefficient / (hip.box[0] * hip.box[2] * hip.box[5]);
+    }
+    if (includeReciprocal) {
+        if (nonbondedMethod == PME) {
+            for (int i = 0; i < 6; i++) pme.box[i] = hip.box[i];
+            if (etermDirty) {
+                HIP_CHECK(ommhip_pme_build_eterm(&pme, hip.stream));
+                etermDirty = false;
+            }
+            HIP_CHECK(ommhip_pme_reciprocal(&pme, posq.ptr, hip.paddedAtoms, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+        }
+        else if (nonbondedMethod == Ewald) {
+            if (hip.box[1] != 0.0 || hip.box[3] != 0.0 || hip.box[4] != 0.0)
+                throw OpenMMException("Ewald (as opposed to PME) requires a rectangular periodic box");   // ReferenceLJCoulombIxn.cpp:99-100
+            HIP_CHECK(ommhip_ewald_reciprocal(hip.pos.ptr, chargeD.as<double>(), hip.slotOfAtom.as<int>(), numParticles, hip.paddedAtoms, hip.box, ewaldAlpha,
+                                              kmax[0], kmax[1], kmax[2], ewaldStructure.ptr, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+        }
+        if (includeEnergy && params.ewald) energy += selfEnergy;
+    }
+    return energy;
+}
+
+void HipCalcNonbondedForceKernel::copyParametersToContext(ContextImpl& context, const NonbondedForce& force) {
+    // ReferenceKernels.cpp:1016-1060
+    if (force.getNumParticles() != numParticles)
+        throw OpenMMException("updateParametersInContext: The number of particles has changed");
+    set<int> exceptionsWithOffsets;
+    for (int i = 0; i < force.getNumExceptionParameterOffsets(); i++) {
+        string param; int exception; double charge, sigma, epsilon;
+        force.getExceptionParameterOffset(i, param, exception, charge, sigma, epsilon);
+        exceptionsWithOffsets.insert(exception);
+    }
+    vector<int> nb14s;
+    for (int i = 0; i < force.getNumExceptions(); i++) {
+        int p1, p2; double chargeProd, sigma, epsilon;
+        force.getExceptionParameters(i, p1, p2, chargeProd, sigma, epsilon);
+        if (chargeProd != 0.0 || epsilon != 0.0 || exceptionsWithOffsets.find(i) != exceptionsWithOffsets.end())
+            nb14s.push_back(i);
+    }
+    if ((int) nb14s.size() != num14)
+        throw OpenMMException("updateParametersInContext: The number of non-excluded exceptions has changed");
+    for (int i = 0; i < numParticles; i++)
+        force.getParticleParameters(i, baseParticleParams[i][0], baseParticleParams[i][1], baseParticleParams[i][2]);
+    for (int i = 0; i < num14; i++) {
+        int p1, p2;
+        force.getExceptionParameters(nb14s[i], p1, p2, baseExceptionParams[i][0], baseExceptionParams[i][1], baseExceptionParams[i][2]);
+        if (p1 != exceptionAtoms[i].first || p2 != exceptionAtoms[i].second)
+            throw OpenMMException("updateParametersInContext: The set of particles in an exception has changed");
+    }
+    NonbondedForce::NonbondedMethod method = force.getNonbondedMethod();
+    if (force.getUseDispersionCorrection() && (method == NonbondedForce::CutoffPeriodic || method == NonbondedForce::Ewald || method == NonbondedForce::PME))
+        dispersionCoefficient = NonbondedForceImpl::calcDispersionCorrection(context.getSystem(), force);
+    hip.setAsCurrent();
+    computeParameters(context, true);
+}
+
+void HipCalcNonbondedForceKernel::getPMEParameters(double& alpha, int& nx, int& ny, int& nz) const {
+    if (nonbondedMethod != PME)
+        throw OpenMMException("getPMEParametersInContext: This Context is not using PME");
+    alpha = ewaldAlpha; nx = gridSize[0]; ny = gridSize[1]; nz = gridSize[2];
+}
+
+void HipCalcNonbondedForceKernel::getLJPMEParameters(double& alpha, int& nx, int& ny, int& nz) const {
+    throw OpenMMException("getPMEParametersInContext: This Context is not using LJPME");
+}
+
+// ================================================================================================
+// Bonded terms
+// ================================================================================================
+void HipTermForce::upload(const vector<int>& atoms, const vector<double>& params, bool usesPeriodic) {
+    data.hip->setAsCurrent();
+    numTerms = (int) atoms.size() / atomsPerTerm;
+    periodic = usesPeriodic;
+    if (usesPeriodic) data.hip->usePeriodic = true;
+    uploadVector(atomsD, atoms, data.hip->stream);
+    uploadVector(paramsD, params, data.hip->stream);
+}
+void HipTermForce::uploadParams(const vector<double>& params) {
+    data.hip->setAsCurrent();
+    if ((int) params.size() != numTerms * paramsPerTerm)
+        throw OpenMMException("updateParametersInContext: The number of terms has changed");
+    uploadVector(paramsD, params, data.hip->stream);
+}
+void HipTermForce::execute(bool includeEnergy) {
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    ommhip_term_list t = {numTerms, atomsD.as<int>(), paramsD.as<double>()};
+    HIP_CHECK(ommhip_term_forces(kind, &t, hip.pos.ptr, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.box, periodic ? 1 : 0, NULL, 0.0,
+                                 hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream));
+}
+
+void HipCalcHarmonicBondForceKernel::initialize(const System& system, const HarmonicBondForce& force) {
+    vector<int> atoms; vector<double> params;
+    for (int i = 0; i < force.getNumBonds(); i++) {
+        int p1, p2; double length, k;
+        force.getBondParameters(i, p1, p2, length, k);
+        atoms.push_back(p1); atoms.push_back(p2); params.push_back(length); params.push_back(k);
+    }
+    terms.upload(atoms, params, force.usesPeriodicBoundaryConditions());
+}
+double HipCalcHarmonicBondForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy) {
+    terms.execute(includeEnergy);
+    return 0.0;
+}
+void HipCalcHarmonicBondForceKernel::copyParametersToContext(ContextImpl& context, const HarmonicBondForce& force) {
+    vector<double> params;
+    for (int i = 0; i < force.getNumBonds(); i++) {
+        int p1, p2; double length, k;
+        force.getBondParameters(i, p1, p2, length, k);
+        params.push_back(length); params.push_back(k);
+    }
+    terms.uploadParams(params);
+}
+
+void HipCalcHarmonicAngleForceKernel::initialize(const System& system, const HarmonicAngleForce& force) {
+    vector<int> atoms; vector<double> params;
+    for (int i = 0; i < force.getNumAngles(); i++) {
+        int p1, p2, p3; double angle, k;
+        force.getAngleParameters(i, p1, p2, p3, angle, k);
+        atoms.push_back(p1); atoms.push_back(p2); atoms.push_back(p3); params.push_back(angle); params.push_back(k);
+    }
+    terms.upload(atoms, params, force.usesPeriodicBoundaryConditions());
+}
+double HipCalcHarmonicAngleForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy) {
+    terms.execute(includeEnergy);
+    return 0.0;
+}
+void HipCalcHarmonicAngleForceKernel::copyParametersToContext(ContextImpl& context, const HarmonicAngleForce& force) {
+    vector<double> params;
+    for (int i = 0; i < force.getNumAngles(); i++) {
+        int p1, p2, p3; double angle, k;
+        force.getAngleParameters(i, p1, p2, p3, angle, k);
+        params.push_back(angle); params.push_back(k);
+    }
+    terms.uploadParams(params);
+}
+
+void HipCalcPeriodicTorsionForceKernel::initialize(const System& system, const PeriodicTorsionForce& force) {
+    vector<int> atoms; vector<double> params;
+    for (int i = 0; i < force.getNumTorsions(); i++) {
+        int p1, p2, p3, p4, periodicity; double phase, k;
+        force.getTorsionParameters(i, p1, p2, p3, p4, periodicity, phase, k);
+        atoms.push_back(p1); atoms.push_back(p2); atoms.push_back(p3); atoms.push_back(p4);
+        params.push_back(k); params.push_back(phase); params.push_back(periodicity);
+    }
+    terms.upload(atoms, params, force.usesPeriodicBoundaryConditions());
+}
+double HipCalcPeriodicTorsionForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy) {
+    terms.execute(includeEnergy);
+    return 0.0;
+}
+void HipCalcPeriodicTorsionForceKernel::copyParametersToContext(ContextImpl& context, const PeriodicTorsionForce& force) {
+    vector<double> params;
+    for (int i = 0; i < force.getNumTorsions(); i++) {
+        int p1, p2, p3, p4, periodicity; double phase, k;
+        force.getTorsionParameters(i, p1, p2, p3, p4, periodicity, phase, k);
+        params.push_back(k); params.push_back(phase); params.push_back(periodicity);
+    }
+    terms.uploadParams(params);
+}
+
+// ================================================================================================
+// Integrators
+// ================================================================================================
+void HipIntegratorBase::fillState(ommhip_integrator_state& s, double dt) {
+    HipContext& hip = *data.hip;
+    memset(&s, 0, sizeof(s));
+    s.num_atoms = hip.numAtoms; s.padded_atoms = hip.paddedAtoms; s.dt = dt;
+    s.pos = hip.pos.ptr; s.vel = hip.vel.ptr; s.xp = hip.xp.ptr; s.oldx = hip.oldx.ptr;
+    s.force = hip.force.as<long long>(); s.slot_of_atom = hip.slotOfAtom.as<int>();
+    s.step = (unsigned long long) data.stepCount;
+}
+
+double HipIntegratorBase::kineticEnergy(double timeShift) {
+    // ReferenceKernels.cpp:146-176
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    ommhip_integrator_state s;
+    fillState(s, 0.0);
+    HIP_CHECK(ommhip_shifted_velocities(&s, timeShift, hip.tempVel.ptr, hip.stream));
+    HipConstraints& constraints = data.getDeviceConstraints(*data.system);
+    if (constraints.hasConstraints()) constraints.applyToVelocities(hip.tempVel.ptr, 1e-4);
+    HIP_CHECK(ommhip_kinetic_energy(hip.tempVel.ptr, hip.numAtoms, hip.energyResult.as<double>() + 1, hip.stream));
+    double result = 0;
+    HIP_CHECK(ommhip_memcpy_d2h(&result, hip.energyResult.as<double>() + 1, sizeof(double), hip.stream));
+    hip.sync();
+    return result;
+}
+
+void HipIntegratorBase::finishStep(double dt) {
+    data.time += dt;
+    data.stepCount++;
+    data.hip->stepTaken();
+}
+
+void HipIntegrateVerletStepKernel::execute(ContextImpl& context, const VerletIntegrator& integrator) {
+    // ReferenceVerletDynamics.cpp:76-119
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    const double dt = integrator.getStepSize();
+    ommhip_integrator_state s;
+    fillState(s, dt);
+    HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_VERLET_1, &s, hip.stream));
+    HipConstraints& constraints = data.getDeviceConstraints(context.getSystem());
+    if (constraints.hasConstraints()) constraints.apply(hip.xp.ptr, integrator.getConstraintTolerance());
+    HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_FINISH_POSITIONS, &s, hip.stream));
+    finishStep(dt);
+}
+double HipIntegrateVerletStepKernel::computeKineticEnergy(ContextImpl& context, const VerletIntegrator& integrator) {
+    return kineticEnergy(0.5 * integrator.getStepSize());
+}
+
+static unsigned long long resolveSeed(int seed) {
+    // seed 0 means "pick one" (LangevinIntegrator.h); same convention as the other platforms
+    if (seed == 0) return (unsigned long long) osrngseed();
+    return (unsigned long long) (unsigned int) seed;
+}
+
+void HipIntegrateLangevinStepKernel::initialize(const System& system, const LangevinIntegrator& integrator) {
+    seed = resolveSeed(integrator.getRandomNumberSeed());
+}
+void HipIntegrateLangevinStepKernel::execute(ContextImpl& context, const LangevinIntegrator& integrator) {
+    // ReferenceStochasticDynamics.cpp:89-194
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    const double dt = integrator.getStepSize(), friction = integrator.getFriction(), kT = BOLTZ * integrator.getTemperature();
+    ommhip_integrator_state s;
+    fillState(s, dt);
+    s.seed = seed;
+    s.vscale = exp(-dt * friction);
+    s.fscale = friction == 0 ? dt : (1 - s.vscale) / friction;
+    s.noisescale = sqrt(kT * (1 - s.vscale * s.vscale));
+    HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_LANGEVIN_1, &s, hip.stream));
+    HipConstraints& constraints = data.getDeviceConstraints(context.getSystem());
+    if (constraints.hasConstraints()) constraints.apply(hip.xp.ptr, integrator.getConstraintTolerance());
+    HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_FINISH_POSITIONS, &s, hip.stream));
+    finishStep(dt);
+}
+double HipIntegrateLangevinStepKernel::computeKineticEnergy(ContextImpl& context, const LangevinIntegrator& integrator) {
+    return kineticEnergy(0.5 * integrator.getStepSize());
+}
+
+void HipIntegrateLangevinMiddleStepKernel::initialize(const System& system, const LangevinMiddleIntegrator& integrator) {
+    seed = resolveSeed(integrator.getRandomNumberSeed());
+}
+void HipIntegrateLangevinMiddleStepKernel::execute(ContextImpl& context, const LangevinMiddleIntegrator& integrator) {
+    // ReferenceLangevinMiddleDynamics.cpp:92-127
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    const double dt = integrator.getStepSize(), friction = integrator.getFriction(), kT = BOLTZ * integrator.getTemperature();
+    const double tol = integrator.getConstraintTolerance();
+    ommhip_integrator_state s;
+    fillState(s, dt);
+    s.seed = seed;
+    s.vscale = exp(-dt * friction);
+    s.noisescale = sqrt(kT * (1 - s.vscale * s.vscale));
+    HipConstraints& constraints = data.getDeviceConstraints(context.getSystem());
+    HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_LMIDDLE_1, &s, hip.stream));
+    if (constraints.hasConstraints()) constraints.applyToVelocities(hip.vel.ptr, tol);
+    HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_LMIDDLE_2, &s, hip.stream));
+    if (constraints.hasConstraints()) constraints.apply(hip.xp.ptr, tol);
+    HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_LMIDDLE_3, &s, hip.stream));
+    finishStep(dt);
+}
+double HipIntegrateLangevinMiddleStepKernel::computeKineticEnergy(ContextImpl& context, const LangevinMiddleIntegrator& integrator) {
+    return kineticEnergy(0.0);
+}
+
+// ================================================================================================
+// CMMotionRemover
+// ================================================================================================
+void HipRemoveCMMotionKernel::initialize(const System& system, const CMMotionRemover& force) {
+    frequency = force.getFrequency();
+    data.hip->setAsCurrent();
+    scratch.allocate(sizeof(double) * 4);
+}
+void HipRemoveCMMotionKernel::execute(ContextImpl& context) {
+    if (data.stepCount % frequency != 0) return;
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    HIP_CHECK(ommhip_remove_cm_motion(hip.vel.ptr, hip.numAtoms, scratch.as<double>(), hip.stream));
+}

@@ -1,0 +1,237 @@
+#ifndef OPENMM_HIPKERNELS_H_
+#define OPENMM_HIPKERNELS_H_
+/* KernelImpl subclasses of the "HIP" platform.  Each class derives from the abstract kernel
+ * interface in olla/include/openmm/kernels.h that it replaces (cited per class) and mirrors the
+ * behaviour of the corresponding Reference kernel (platforms/reference/src/ReferenceKernels.cpp).
+ */
+#include "HipPlatform.h"
+#include "HipContext.h"
+#include "openmm/kernels.h"
+#include "openmm/System.h"
+#include <map>
+#include <set>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace OpenMM {
+
+/** Device-side constraint data shared by the integrators and ApplyConstraints. */
+class HipConstraints {
+public:
+    HipConstraints(const System& system, HipPlatform::PlatformData& data);
+    /** Constrain trial positions `target` (double4[N]) against the reference positions ctx.pos. */
+    void apply(void* target, double tol);
+    /** Remove constrained components from velocities `target` (double4[N], w = 1/m). */
+    void applyToVelocities(void* target, double tol);
+    bool hasConstraints() const { return numSettle + numShake + numCcma > 0; }
+private:
+    void runCcma(void* target, bool velocities, double tol);
+    HipContext& hip;
+    int numSettle, numShake, numCcma;
+    DeviceBuffer settleAtoms, settleDist, shakeAtoms, shakeDist;
+    DeviceBuffer ccmaAtoms, ccmaDist, ccmaDelta, ccmaDelta2, ccmaRowStart, ccmaCol, ccmaValue, ccmaConverged;
+    ommhip_ccma ccma;
+};
+
+/** kernels.h:81-119 CalcForcesAndEnergyKernel; Reference: ReferenceKernels.cpp:178-203. */
+class HipCalcForcesAndEnergyKernel : public CalcForcesAndEnergyKernel {
+public:
+    HipCalcForcesAndEnergyKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : CalcForcesAndEnergyKernel(name, platform), data(data) {}
+    void initialize(const System& system);
+    void beginComputation(ContextImpl& context, bool includeForce, bool includeEnergy, int groups);
+    double finishComputation(ContextImpl& context, bool includeForce, bool includeEnergy, int groups, bool& valid);
+private:
+    HipPlatform::PlatformData& data;
+    std::vector<Vec3> savedHostForces;
+};
+
+/** kernels.h:125-215 UpdateStateDataKernel; Reference: ReferenceKernels.cpp:205-308. */
+class HipUpdateStateDataKernel : public UpdateStateDataKernel {
+public:
+    HipUpdateStateDataKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : UpdateStateDataKernel(name, platform), data(data) {}
+    void initialize(const System& system);
+    double getTime(const ContextImpl& context) const;
+    void setTime(ContextImpl& context, double time);
+    void getPositions(ContextImpl& context, std::vector<Vec3>& positions);
+    void setPositions(ContextImpl& context, const std::vector<Vec3>& positions);
+    void getVelocities(ContextImpl& context, std::vector<Vec3>& velocities);
+    void setVelocities(ContextImpl& context, const std::vector<Vec3>& velocities);
+    void getForces(ContextImpl& context, std::vector<Vec3>& forces);
+    void getEnergyParameterDerivatives(ContextImpl& context, std::map<std::string, double>& derivs);
+    void getPeriodicBoxVectors(ContextImpl& context, Vec3& a, Vec3& b, Vec3& c) const;
+    void setPeriodicBoxVectors(ContextImpl& context, const Vec3& a, const Vec3& b, const Vec3& c);
+    void createCheckpoint(ContextImpl& context, std::ostream& stream);
+    void loadCheckpoint(ContextImpl& context, std::istream& stream);
+private:
+    HipPlatform::PlatformData& data;
+};
+
+/** kernels.h:220-247 ApplyConstraintsKernel; Reference: ReferenceKernels.cpp:310-333. */
+class HipApplyConstraintsKernel : public ApplyConstraintsKernel {
+public:
+    HipApplyConstraintsKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : ApplyConstraintsKernel(name, platform), data(data) {}
+    void initialize(const System& system);
+    void apply(ContextImpl& context, double tol);
+    void applyToVelocities(ContextImpl& context, double tol);
+private:
+    HipPlatform::PlatformData& data;
+};
+
+/** kernels.h:252-271 VirtualSitesKernel.  Systems with virtual sites run in host mode (Reference kernel); this is the no-site case. */
+class HipVirtualSitesKernel : public VirtualSitesKernel {
+public:
+    HipVirtualSitesKernel(std::string name, const Platform& platform) : VirtualSitesKernel(name, platform) {}
+    void initialize(const System& system) {}
+    void computePositions(ContextImpl& context) {}
+};
+
+/** kernels.h:556-614 CalcNonbondedForceKernel; Reference: ReferenceKernels.cpp:864-1121. */
+class HipCalcNonbondedForceKernel : public CalcNonbondedForceKernel, public HipContextListener {
+public:
+    HipCalcNonbondedForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data);
+    ~HipCalcNonbondedForceKernel();
+    void initialize(const System& system, const NonbondedForce& force);
+    double execute(ContextImpl& context, bool includeForces, bool includeEnergy, bool includeDirect, bool includeReciprocal);
+    void copyParametersToContext(ContextImpl& context, const NonbondedForce& force);
+    void getPMEParameters(double& alpha, int& nx, int& ny, int& nz) const;
+    void getLJPMEParameters(double& alpha, int& nx, int& ny, int& nz) const;
+    void atomsReordered();
+    void boxChanged();
+    void positionsSet();
+    /** out[0..6) = atoms, padded atoms, chunks in use, rows in use, chunk capacity, rebuilds so far (blocking). */
+    void getNeighborListStats(long long* out);
+private:
+    void computeParameters(ContextImpl& context, bool force);
+    void allocateNeighborList(int maxChunks);
+    void setupPme();
+    void rebuildEterm();
+    int estimateChunks() const;
+    HipPlatform::PlatformData& data;
+    HipContext& hip;
+    int numParticles, num14, numExclusionPairs;
+    NonbondedMethod nonbondedMethod;
+    double nonbondedCutoff, switchingDistance, rfDielectric, ewaldAlpha, dispersionCoefficient, selfEnergy, padding;
+    bool useSwitchingFunction, exceptionsArePeriodic, usesPeriodic;
+    int kmax[3], gridSize[3];
+    std::vector<std::vector<double> > baseParticleParams, baseExceptionParams;   // (charge, sigma, epsilon)
+    std::vector<std::pair<int, int> > exceptionAtoms;
+    std::map<std::pair<std::string, int>, std::vector<double> > particleParamOffsets, exceptionParamOffsets;
+    std::map<std::string, double> lastGlobalValues;
+    std::vector<double> charges;                                             // current, atom order
+    bool slotParamsDirty, forceRebuild, etermDirty, hasInitializedParams;
+    // device
+    DeviceBuffer chargeD, sigmaD, epsilonD, posq, posqRef, sigEps, exclStart, exclAtoms, nlState, blockCenter, blockHalf, chunkInfo, rowJ, rowMask;
+    DeviceBuffer exceptionAtomsD, exceptionParamsD, exclusionPairsD, ewaldStructure;
+    DeviceBuffer moduliX, moduliY, moduliZ, eterm, gridReal, gridComplex, twiddleX, twiddleY, twiddleZ;
+    ommhip_neighbor_list nl;
+    ommhip_nonbonded_params params;
+    ommhip_pme pme;
+    int* pinnedState;
+    bool stateCopyPending;
+};
+
+/** Common code of the per-term bonded kernels. */
+class HipTermForce {
+public:
+    HipTermForce(HipPlatform::PlatformData& data, int kind, int atomsPerTerm, int paramsPerTerm) : data(data), kind(kind), atomsPerTerm(atomsPerTerm), paramsPerTerm(paramsPerTerm), numTerms(0), periodic(false) {}
+    void upload(const std::vector<int>& atoms, const std::vector<double>& params, bool usesPeriodic);
+    void uploadParams(const std::vector<double>& params);
+    void execute(bool includeEnergy);
+    int getNumTerms() const { return numTerms; }
+private:
+    HipPlatform::PlatformData& data;
+    int kind, atomsPerTerm, paramsPerTerm, numTerms;
+    bool periodic;
+    DeviceBuffer atomsD, paramsD;
+};
+
+/** kernels.h:276-341 CalcHarmonicBondForceKernel; Reference: ReferenceKernels.cpp:343-391. */
+class HipCalcHarmonicBondForceKernel : public CalcHarmonicBondForceKernel {
+public:
+    HipCalcHarmonicBondForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : CalcHarmonicBondForceKernel(name, platform), terms(data, OMMHIP_TERM_HARMONIC_BOND, 2, 2) {}
+    void initialize(const System& system, const HarmonicBondForce& force);
+    double execute(ContextImpl& context, bool includeForces, bool includeEnergy);
+    void copyParametersToContext(ContextImpl& context, const HarmonicBondForce& force);
+private:
+    HipTermForce terms;
+};
+
+/** kernels.h:346-411 CalcHarmonicAngleForceKernel; Reference: ReferenceKernels.cpp:473-522. */
+class HipCalcHarmonicAngleForceKernel : public CalcHarmonicAngleForceKernel {
+public:
+    HipCalcHarmonicAngleForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : CalcHarmonicAngleForceKernel(name, platform), terms(data, OMMHIP_TERM_HARMONIC_ANGLE, 3, 2) {}
+    void initialize(const System& system, const HarmonicAngleForce& force);
+    double execute(ContextImpl& context, bool includeForces, bool includeEnergy);
+    void copyParametersToContext(ContextImpl& context, const HarmonicAngleForce& force);
+private:
+    HipTermForce terms;
+};
+
+/** kernels.h:416-481 CalcPeriodicTorsionForceKernel; Reference: ReferenceKernels.cpp:603-650. */
+class HipCalcPeriodicTorsionForceKernel : public CalcPeriodicTorsionForceKernel {
+public:
+    HipCalcPeriodicTorsionForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : CalcPeriodicTorsionForceKernel(name, platform), terms(data, OMMHIP_TERM_PERIODIC_TORSION, 4, 3) {}
+    void initialize(const System& system, const PeriodicTorsionForce& force);
+    double execute(ContextImpl& context, bool includeForces, bool includeEnergy);
+    void copyParametersToContext(ContextImpl& context, const PeriodicTorsionForce& force);
+private:
+    HipTermForce terms;
+};
+
+/** Shared implementation of the three native integrators. */
+class HipIntegratorBase {
+public:
+    HipIntegratorBase(HipPlatform::PlatformData& data) : data(data) {}
+protected:
+    void fillState(ommhip_integrator_state& s, double dt);
+    double kineticEnergy(double timeShift);
+    void finishStep(double dt);
+    HipPlatform::PlatformData& data;
+};
+
+/** kernels.h:1033-1061 IntegrateVerletStepKernel; Reference: ReferenceKernels.cpp:2063-2096. */
+class HipIntegrateVerletStepKernel : public IntegrateVerletStepKernel, public HipIntegratorBase {
+public:
+    HipIntegrateVerletStepKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : IntegrateVerletStepKernel(name, platform), HipIntegratorBase(data) {}
+    void initialize(const System& system, const VerletIntegrator& integrator) {}
+    void execute(ContextImpl& context, const VerletIntegrator& integrator);
+    double computeKineticEnergy(ContextImpl& context, const VerletIntegrator& integrator);
+};
+
+/** kernels.h:1160-1188 IntegrateLangevinStepKernel; Reference: ReferenceKernels.cpp:2360-2402. */
+class HipIntegrateLangevinStepKernel : public IntegrateLangevinStepKernel, public HipIntegratorBase {
+public:
+    HipIntegrateLangevinStepKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : IntegrateLangevinStepKernel(name, platform), HipIntegratorBase(data), seed(0) {}
+    void initialize(const System& system, const LangevinIntegrator& integrator);
+    void execute(ContextImpl& context, const LangevinIntegrator& integrator);
+    double computeKineticEnergy(ContextImpl& context, const LangevinIntegrator& integrator);
+private:
+    unsigned long long seed;
+};
+
+/** kernels.h:1193-1221 IntegrateLangevinMiddleStepKernel; Reference: ReferenceKernels.cpp:2404-2445. */
+class HipIntegrateLangevinMiddleStepKernel : public IntegrateLangevinMiddleStepKernel, public HipIntegratorBase {
+public:
+    HipIntegrateLangevinMiddleStepKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : IntegrateLangevinMiddleStepKernel(name, platform), HipIntegratorBase(data), seed(0) {}
+    void initialize(const System& system, const LangevinMiddleIntegrator& integrator);
+    void execute(ContextImpl& context, const LangevinMiddleIntegrator& integrator);
+    double computeKineticEnergy(ContextImpl& context, const LangevinMiddleIntegrator& integrator);
+private:
+    unsigned long long seed;
+};
+
+/** kernels.h:1464-1488 RemoveCMMotionKernel; Reference: ReferenceKernels.cpp:2705-2740. */
+class HipRemoveCMMotionKernel : public RemoveCMMotionKernel {
+public:
+    HipRemoveCMMotionKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : RemoveCMMotionKernel(name, platform), data(data), frequency(1) {}
+    void initialize(const System& system, const CMMotionRemover& force);
+    void execute(ContextImpl& context);
+private:
+    HipPlatform::PlatformData& data;
+    int frequency;
+    DeviceBuffer scratch;
+};
+
+}  // namespace OpenMM
+#endif

@@ -1,0 +1,234 @@
+/* HipPlatform: registration, per-Context data, kernel factory.
+ *
+ * Drop-in boundary: this shared object exports extern "C" registerPlatforms(), which
+ * olla/src/Platform.cpp:237-252 resolves with dlsym after dlopen; it registers one HipPlatform whose
+ * KernelFactory hands out the native kernels of HipKernels.h and, for every other kernel name, the
+ * Reference implementation (the platforms/cpu precedent, CpuPlatform.cpp:63-77).
+ */
+#include "HipPlatform.h"
+#include "HipContext.h"
+#include "HipKernels.h"
+#include "ReferenceKernelFactory.h"
+#include "openmm/Context.h"
+#include "openmm/KernelFactory.h"
+#include "openmm/PluginInitializer.h"
+#include "openmm/System.h"
+#include "openmm/VirtualSite.h"
+#include "openmm/CMMotionRemover.h"
+#include "openmm/HarmonicAngleForce.h"
+#include "openmm/HarmonicBondForce.h"
+#include "openmm/NonbondedForce.h"
+#include "openmm/PeriodicTorsionForce.h"
+#include "openmm/AndersenThermostat.h"
+#include "openmm/MonteCarloBarostat.h"
+#include "openmm/MonteCarloAnisotropicBarostat.h"
+#include "openmm/MonteCarloMembraneBarostat.h"
+#include "openmm/CustomCVForce.h"
+#include "openmm/LangevinIntegrator.h"
+#include "openmm/LangevinMiddleIntegrator.h"
+#include "openmm/VerletIntegrator.h"
+#include "openmm/kernels.h"
+#include <cstdlib>
+#include <sstream>
+
+using namespace OpenMM;
+using namespace std;
+
+namespace OpenMM {
+
+/* How a Context runs, decided once in contextCreated():
+ *   device mode  -- native integrator, constraints and state kernels; positions/velocities live in HBM.
+ *                   Forces without a native kernel run as Reference kernels on a host copy of the
+ *                   positions ("fallback forces") and their result is added to the device buffer.
+ *   host mode    -- anything that needs to mutate the state on the host (non-native integrators,
+ *                   barostats, thermostats, virtual sites, unknown Force subclasses): all state and
+ *                   integration kernels are the Reference ones; the native force kernels still compute
+ *                   on the GPU from an uploaded copy of the positions.
+ */
+struct HipModeInfo {
+    bool hostMode;
+    bool referenceNonbonded;     // LJPME: NonbondedForce itself falls back to Reference
+    bool hasFallbackForces;
+};
+
+static HipModeInfo classifyContext(ContextImpl& context) {
+    HipModeInfo info = {false, false, false};
+    const System& system = context.getSystem();
+    const Integrator& integrator = context.getIntegrator();
+    if (dynamic_cast<const VerletIntegrator*>(&integrator) == NULL && dynamic_cast<const LangevinIntegrator*>(&integrator) == NULL &&
+            dynamic_cast<const LangevinMiddleIntegrator*>(&integrator) == NULL)
+        info.hostMode = true;
+    for (int i = 0; i < system.getNumParticles(); i++)
+        if (system.isVirtualSite(i)) info.hostMode = true;
+    for (int i = 0; i < system.getNumForces(); i++) {
+        const Force& f = system.getForce(i);
+        if (const NonbondedForce* nb = dynamic_cast<const NonbondedForce*>(&f)) {
+            if (nb->getNonbondedMethod() == NonbondedForce::LJPME) { info.referenceNonbonded = true; info.hasFallbackForces = true; }
+            continue;
+        }
+        if (dynamic_cast<const HarmonicBondForce*>(&f) != NULL || dynamic_cast<const HarmonicAngleForce*>(&f) != NULL ||
+                dynamic_cast<const PeriodicTorsionForce*>(&f) != NULL || dynamic_cast<const CMMotionRemover*>(&f) != NULL)
+            continue;
+        if (dynamic_cast<const AndersenThermostat*>(&f) != NULL || dynamic_cast<const MonteCarloBarostat*>(&f) != NULL ||
+                dynamic_cast<const MonteCarloAnisotropicBarostat*>(&f) != NULL || dynamic_cast<const MonteCarloMembraneBarostat*>(&f) != NULL ||
+                dynamic_cast<const CustomCVForce*>(&f) != NULL) {
+            info.hostMode = true;       // these change state (or own an inner Context) on the host
+            continue;
+        }
+        // Any other Force: its Reference kernel only reads positions and adds forces.
+        info.hasFallbackForces = true;
+    }
+    char* forceHost = getenv("OPENMM_HIP_FORCE_HOST_MODE");
+    if (forceHost != NULL && string(forceHost) == "1") info.hostMode = true;
+    return info;
+}
+
+class HipKernelFactory : public KernelFactory {
+public:
+    KernelImpl* createKernelImpl(std::string name, const Platform& platform, ContextImpl& context) const {
+        HipPlatform::PlatformData& data = HipPlatform::getData(context);
+        const bool hostMode = data.hip->hostMode;
+        if (name == CalcForcesAndEnergyKernel::Name())
+            return new HipCalcForcesAndEnergyKernel(name, platform, data);
+        if (name == CalcNonbondedForceKernel::Name() && !data.referenceNonbonded)
+            return new HipCalcNonbondedForceKernel(name, platform, data);
+        if (name == CalcHarmonicBondForceKernel::Name())
+            return new HipCalcHarmonicBondForceKernel(name, platform, data);
+        if (name == CalcHarmonicAngleForceKernel::Name())
+            return new HipCalcHarmonicAngleForceKernel(name, platform, data);
+        if (name == CalcPeriodicTorsionForceKernel::Name())
+            return new HipCalcPeriodicTorsionForceKernel(name, platform, data);
+        if (!hostMode) {
+            if (name == UpdateStateDataKernel::Name())
+                return new HipUpdateStateDataKernel(name, platform, data);
+            if (name == ApplyConstraintsKernel::Name())
+                return new HipApplyConstraintsKernel(name, platform, data);
+            if (name == VirtualSitesKernel::Name())
+                return new HipVirtualSitesKernel(name, platform);
+            if (name == IntegrateVerletStepKernel::Name())
+                return new HipIntegrateVerletStepKernel(name, platform, data);
+            if (name == IntegrateLangevinStepKernel::Name())
+                return new HipIntegrateLangevinStepKernel(name, platform, data);
+            if (name == IntegrateLangevinMiddleStepKernel::Name())
+                return new HipIntegrateLangevinMiddleStepKernel(name, platform, data);
+            if (name == RemoveCMMotionKernel::Name())
+                return new HipRemoveCMMotionKernel(name, platform, data);
+        }
+        return reference.createKernelImpl(name, platform, context);
+    }
+private:
+    ReferenceKernelFactory reference;
+};
+
+}  // namespace OpenMM
+
+extern "C" __attribute__((visibility("default"))) void registerPlatforms() {
+    Platform::registerPlatform(new HipPlatform());
+}
+
+extern "C" __attribute__((visibility("default"))) void registerKernelFactories() {
+}
+
+HipPlatform::HipPlatform() {
+    HipKernelFactory* factory = new HipKernelFactory();
+    registerKernelFactory(CalcForcesAndEnergyKernel::Name(), factory);
+    registerKernelFactory(UpdateStateDataKernel::Name(), factory);
+    registerKernelFactory(ApplyConstraintsKernel::Name(), factory);
+    registerKernelFactory(VirtualSitesKernel::Name(), factory);
+    registerKernelFactory(CalcNonbondedForceKernel::Name(), factory);
+    registerKernelFactory(CalcHarmonicBondForceKernel::Name(), factory);
+    registerKernelFactory(CalcHarmonicAngleForceKernel::Name(), factory);
+    registerKernelFactory(CalcPeriodicTorsionForceKernel::Name(), factory);
+    registerKernelFactory(IntegrateVerletStepKernel::Name(), factory);
+    registerKernelFactory(IntegrateLangevinStepKernel::Name(), factory);
+    registerKernelFactory(IntegrateLangevinMiddleStepKernel::Name(), factory);
+    registerKernelFactory(RemoveCMMotionKernel::Name(), factory);
+    platformProperties.push_back(HipDeviceIndex());
+    platformProperties.push_back(HipDeviceName());
+    platformProperties.push_back(HipPrecision());
+    platformProperties.push_back(HipDeterministicForces());
+    platformProperties.push_back(HipDisablePmeStream());
+    setPropertyDefaultValue(HipDeviceIndex(), "");
+    setPropertyDefaultValue(HipDeviceName(), "");
+    setPropertyDefaultValue(HipPrecision(), "mixed");
+    setPropertyDefaultValue(HipDeterministicForces(), "false");
+    setPropertyDefaultValue(HipDisablePmeStream(), "false");
+}
+
+double HipPlatform::getSpeed() const {
+    return 150;    // above CUDA's 100 (CudaPlatform.cpp:149-151): preferred when a MI355X is present
+}
+
+bool HipPlatform::supportsDoublePrecision() const {
+    return false;  // forces are evaluated in single precision; integration state is double ("mixed")
+}
+
+const string& HipPlatform::getPropertyValue(const Context& context, const string& property) const {
+    const ContextImpl& impl = getContextImpl(context);
+    const PlatformData* data = reinterpret_cast<const PlatformData*>(impl.getPlatformData());
+    map<string, string>::const_iterator value = data->propertyValues.find(property);
+    if (value != data->propertyValues.end())
+        return value->second;
+    return ReferencePlatform::getPropertyValue(context, property);
+}
+
+void HipPlatform::setPropertyValue(Context& context, const string& property, const string& value) const {
+}
+
+void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>& properties) const {
+    const string& devicePropValue = (properties.find(HipDeviceIndex()) == properties.end() ?
+            getPropertyDefaultValue(HipDeviceIndex()) : properties.find(HipDeviceIndex())->second);
+    string precision = (properties.find(HipPrecision()) == properties.end() ?
+            getPropertyDefaultValue(HipPrecision()) : properties.find(HipPrecision())->second);
+    if (precision != "mixed" && precision != "single")
+        throw OpenMMException("HIP platform: Precision must be 'single' or 'mixed' (forces are single precision, integration is double)");
+    int deviceIndex = 0;
+    if (devicePropValue.find(',') != string::npos)
+        throw OpenMMException("HIP platform: one Context drives one device; multi-GPU runs use one process per GPU (see bench.py)");
+    if (!devicePropValue.empty())
+        stringstream(devicePropValue) >> deviceIndex;
+    else if (getenv("LOCAL_RANK") != NULL) {
+        // one process per GPU under torch.distributed.run: default to this rank's device
+        int count = 0;
+        if (ommhip_device_count(&count) == 0 && count > 0)
+            deviceIndex = atoi(getenv("LOCAL_RANK")) % count;
+    }
+    HipModeInfo mode = classifyContext(context);
+    PlatformData* data = new PlatformData(context.getSystem(), deviceIndex, mode.hostMode);
+    data->referenceNonbonded = mode.referenceNonbonded;
+    data->hip->hasFallbackForces = mode.hasFallbackForces;
+    stringstream dev;
+    dev << deviceIndex;
+    data->propertyValues[HipDeviceIndex()] = dev.str();
+    char name[256];
+    name[0] = 0;
+    ommhip_device_info(deviceIndex, name, 256, NULL, NULL);
+    data->propertyValues[HipDeviceName()] = name;
+    data->propertyValues[HipPrecision()] = "mixed";
+    data->propertyValues[HipDeterministicForces()] = (properties.find(HipDeterministicForces()) == properties.end() ?
+            getPropertyDefaultValue(HipDeterministicForces()) : properties.find(HipDeterministicForces())->second);
+    data->propertyValues[HipDisablePmeStream()] = (properties.find(HipDisablePmeStream()) == properties.end() ?
+            getPropertyDefaultValue(HipDisablePmeStream()) : properties.find(HipDisablePmeStream())->second);
+    context.setPlatformData(data);
+}
+
+void HipPlatform::contextDestroyed(ContextImpl& context) const {
+    PlatformData* data = reinterpret_cast<PlatformData*>(context.getPlatformData());
+    delete data;
+}
+
+HipPlatform::PlatformData::PlatformData(const System& system, int deviceIndex, bool hostMode) : ReferencePlatform::PlatformData(system),
+        hip(NULL), system(&system), referenceNonbonded(false), deviceConstraints(NULL) {
+    hip = new HipContext(system, deviceIndex, hostMode);
+}
+
+HipPlatform::PlatformData::~PlatformData() {
+    delete deviceConstraints;
+    delete hip;
+}
+
+HipConstraints& HipPlatform::PlatformData::getDeviceConstraints(const System& sys) {
+    if (deviceConstraints == NULL)
+        deviceConstraints = new HipConstraints(sys, *this);
+    return *deviceConstraints;
+}

@@ -1,0 +1,62 @@
+#ifndef OPENMM_HIPPLATFORM_H_
+#define OPENMM_HIPPLATFORM_H_
+/* The OpenMM "HIP" Platform for AMD Instinct MI355X (gfx950).
+ *
+ * Registered through olla's plugin interface (olla/include/openmm/PluginInitializer.h:45-57,
+ * olla/src/Platform.cpp:237-252): this library exports extern "C" registerPlatforms().
+ *
+ * HipPlatform subclasses ReferencePlatform (the platforms/cpu precedent, CpuPlatform.h:50) so that
+ * every kernel it does not implement natively resolves to the Reference implementation; the
+ * per-Context data object subclasses ReferencePlatform::PlatformData so those kernels find their
+ * host vectors where they expect them.
+ */
+#include "ReferencePlatform.h"
+#include "openmm/internal/ContextImpl.h"
+#include <map>
+#include <string>
+
+namespace OpenMM {
+
+class HipContext;
+class HipConstraints;
+
+class HipPlatform : public ReferencePlatform {
+public:
+    class PlatformData;
+    HipPlatform();
+    const std::string& getName() const {
+        static const std::string name = "HIP";
+        return name;
+    }
+    double getSpeed() const;
+    bool supportsDoublePrecision() const;
+    const std::string& getPropertyValue(const Context& context, const std::string& property) const;
+    void setPropertyValue(Context& context, const std::string& property, const std::string& value) const;
+    void contextCreated(ContextImpl& context, const std::map<std::string, std::string>& properties) const;
+    void contextDestroyed(ContextImpl& context) const;
+    static const std::string& HipDeviceIndex() { static const std::string key = "DeviceIndex"; return key; }
+    static const std::string& HipDeviceName() { static const std::string key = "DeviceName"; return key; }
+    static const std::string& HipPrecision() { static const std::string key = "Precision"; return key; }
+    static const std::string& HipDeterministicForces() { static const std::string key = "DeterministicForces"; return key; }
+    static const std::string& HipDisablePmeStream() { static const std::string key = "DisablePmeStream"; return key; }
+    static PlatformData& getData(ContextImpl& context) {
+        return *reinterpret_cast<PlatformData*>(context.getPlatformData());
+    }
+};
+
+/** ReferencePlatform::PlatformData (host vectors for fallback kernels) + the device context. */
+class HipPlatform::PlatformData : public ReferencePlatform::PlatformData {
+public:
+    PlatformData(const System& system, int deviceIndex, bool hostMode);
+    ~PlatformData();
+    HipConstraints& getDeviceConstraints(const System& system);
+    HipContext* hip;
+    const System* system;
+    bool referenceNonbonded;
+    std::map<std::string, std::string> propertyValues;
+private:
+    HipConstraints* deviceConstraints;
+};
+
+}  // namespace OpenMM
+#endif

@@ -1,0 +1,250 @@
+"""ctypes front end of libommharness.so: just enough of the OpenMM API (System, NonbondedForce,
+bonded forces, integrators, Context, State) to build test/benchmark systems from numpy arrays and run
+them on the "HIP", "CPU" and "Reference" platforms.  Names follow the OpenMM Python API
+(wrappers/python/openmm) so the tests read like the reference's own.
+
+The HIP platform is loaded from openmm_amd/lib/libOpenMMHIP.so through OpenMM's own plugin loader
+(Platform::loadPluginLibrary -> registerPlatforms()), i.e. through the drop-in boundary.  Tests that
+check host logic without a GPU pass `emulated=True`, which loads the CPU-emulated twin from
+tests/emu/_build instead; the two can not be mixed in one process.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+LIB_DIR = os.path.join(_HERE, "lib")
+EMU_DIR = os.path.join(ROOT, "tests", "emu", "_build")
+ORACLE_DIR = os.path.join(ROOT, "oracle", "_ref")
+
+NoCutoff, CutoffNonPeriodic, CutoffPeriodic, Ewald, PME, LJPME = range(6)
+VERLET, LANGEVIN, LANGEVIN_MIDDLE = 0, 1, 2
+
+_lib = None
+_loaded_plugins = set()
+
+
+class OpenMMError(RuntimeError):
+    pass
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(LIB_DIR, "libommharness.so")
+        if not os.path.exists(path):
+            raise OpenMMError("harness library missing: %s (run __graft_entry__.build())" % path)
+        C.CDLL(os.path.join(ORACLE_DIR, "libOpenMM.so"), mode=C.RTLD_GLOBAL)
+        _lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        for name in ("omm_last_error", "omm_platform_name", "omm_version", "omm_context_platform_name", "omm_context_platform_property"):
+            getattr(_lib, name).restype = C.c_char_p
+        for name in ("omm_system_create", "omm_nonbonded_create", "omm_add_harmonic_bonds", "omm_add_harmonic_angles",
+                     "omm_add_periodic_torsions", "omm_add_cmmotion_remover", "omm_integrator_create", "omm_context_create"):
+            getattr(_lib, name).restype = C.c_void_p
+        _lib.omm_platform_speed.restype = C.c_double
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise OpenMMError(lib().omm_last_error().decode())
+
+
+def _handle(p):
+    if not p:
+        raise OpenMMError(lib().omm_last_error().decode())
+    return C.c_void_p(p)
+
+
+def load_hip_platform(emulated=False):
+    """Register the HIP platform through OpenMM's plugin loader.  Raises if the plugin is missing."""
+    path = os.path.join(EMU_DIR if emulated else LIB_DIR, "libOpenMMHIP.so")
+    if path in _loaded_plugins:
+        return
+    if _loaded_plugins:
+        raise OpenMMError("a different HIP plugin build is already loaded in this process")
+    if not os.path.exists(path):
+        raise OpenMMError("HIP platform plugin not found: %s" % path)
+    _check(lib().omm_load_plugin(path.encode()))
+    _loaded_plugins.add(path)
+
+
+def load_cpu_platform():
+    path = os.path.join(ORACLE_DIR, "libOpenMMCPU.so")
+    if path in _loaded_plugins:
+        return
+    _check(lib().omm_load_plugin(path.encode()))
+    _loaded_plugins.add(path)
+
+
+def platform_names():
+    L = lib()
+    return [L.omm_platform_name(i).decode() for i in range(L.omm_num_platforms())]
+
+
+class System:
+    def __init__(self):
+        self.h = _handle(lib().omm_system_create())
+        self.forces = []
+
+    def addParticles(self, masses):
+        m = np.ascontiguousarray(masses, dtype=np.float64)
+        _check(lib().omm_system_add_particles(self.h, len(m), _dp(m)))
+
+    def getNumParticles(self):
+        return lib().omm_system_num_particles(self.h)
+
+    def setDefaultPeriodicBoxVectors(self, a, b, c):
+        box = np.ascontiguousarray(np.array([a, b, c], dtype=np.float64).reshape(9))
+        _check(lib().omm_system_set_box(self.h, _dp(box)))
+
+    def addConstraints(self, pairs, distances):
+        p = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1)
+        d = np.ascontiguousarray(distances, dtype=np.float64)
+        _check(lib().omm_system_add_constraints(self.h, len(d), _ip(p), _dp(d)))
+
+    def addHarmonicBondForce(self, atoms, length, k):
+        a = np.ascontiguousarray(atoms, dtype=np.int32).reshape(-1)
+        l = np.ascontiguousarray(length, dtype=np.float64)
+        kk = np.ascontiguousarray(k, dtype=np.float64)
+        return _handle(lib().omm_add_harmonic_bonds(self.h, len(l), _ip(a), _dp(l), _dp(kk)))
+
+    def addHarmonicAngleForce(self, atoms, angle, k):
+        a = np.ascontiguousarray(atoms, dtype=np.int32).reshape(-1)
+        t = np.ascontiguousarray(angle, dtype=np.float64)
+        kk = np.ascontiguousarray(k, dtype=np.float64)
+        return _handle(lib().omm_add_harmonic_angles(self.h, len(t), _ip(a), _dp(t), _dp(kk)))
+
+    def addPeriodicTorsionForce(self, atoms, periodicity, phase, k):
+        a = np.ascontiguousarray(atoms, dtype=np.int32).reshape(-1)
+        n = np.ascontiguousarray(periodicity, dtype=np.int32)
+        ph = np.ascontiguousarray(phase, dtype=np.float64)
+        kk = np.ascontiguousarray(k, dtype=np.float64)
+        return _handle(lib().omm_add_periodic_torsions(self.h, len(n), _ip(a), _ip(n), _dp(ph), _dp(kk)))
+
+    def addCMMotionRemover(self, frequency=1):
+        return _handle(lib().omm_add_cmmotion_remover(self.h, frequency))
+
+
+class NonbondedForce:
+    """Created already attached to `system` (the System owns it, as in OpenMM)."""
+
+    def __init__(self, system, method=NoCutoff, cutoff=1.0, ewaldErrorTolerance=5e-4, useDispersionCorrection=True,
+                 switchingDistance=None):
+        use_switch = switchingDistance is not None
+        self.h = _handle(lib().omm_nonbonded_create(system.h, method, C.c_double(cutoff), C.c_double(ewaldErrorTolerance),
+                                                    int(useDispersionCorrection), int(use_switch),
+                                                    C.c_double(switchingDistance if use_switch else -1.0)))
+
+    def addParticles(self, charge, sigma, epsilon):
+        q = np.ascontiguousarray(charge, dtype=np.float64)
+        s = np.ascontiguousarray(sigma, dtype=np.float64)
+        e = np.ascontiguousarray(epsilon, dtype=np.float64)
+        _check(lib().omm_nonbonded_add_particles(self.h, len(q), _dp(q), _dp(s), _dp(e)))
+
+    def addExceptions(self, pairs, chargeProd, sigma, epsilon):
+        p = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1)
+        qq = np.ascontiguousarray(chargeProd, dtype=np.float64)
+        s = np.ascontiguousarray(sigma, dtype=np.float64)
+        e = np.ascontiguousarray(epsilon, dtype=np.float64)
+        _check(lib().omm_nonbonded_add_exceptions(self.h, len(qq), _ip(p), _dp(qq), _dp(s), _dp(e)))
+
+    def createExceptionsFromBonds(self, bonds, coulomb14Scale, lj14Scale):
+        p = np.ascontiguousarray(bonds, dtype=np.int32).reshape(-1)
+        _check(lib().omm_nonbonded_create_exceptions_from_bonds(self.h, len(p) // 2, _ip(p), C.c_double(coulomb14Scale), C.c_double(lj14Scale)))
+
+    def getNumExceptions(self):
+        return lib().omm_nonbonded_num_exceptions(self.h)
+
+    def setPMEParameters(self, alpha, nx, ny, nz):
+        _check(lib().omm_nonbonded_set_pme_parameters(self.h, C.c_double(alpha), nx, ny, nz))
+
+    def setReciprocalSpaceForceGroup(self, group):
+        _check(lib().omm_nonbonded_set_reciprocal_force_group(self.h, group))
+
+    def setExceptionsUsePeriodicBoundaryConditions(self, periodic):
+        _check(lib().omm_nonbonded_set_exceptions_use_periodic(self.h, int(periodic)))
+
+    def getPMEParametersInContext(self, context):
+        alpha = C.c_double()
+        n = (C.c_int * 3)()
+        _check(lib().omm_nonbonded_get_pme_parameters_in_context(self.h, context.h, C.byref(alpha), n))
+        return alpha.value, n[0], n[1], n[2]
+
+
+class Integrator:
+    def __init__(self, kind, stepSize, temperature=300.0, friction=1.0, seed=1, constraintTolerance=1e-5):
+        self.h = _handle(lib().omm_integrator_create(kind, C.c_double(stepSize), C.c_double(temperature), C.c_double(friction),
+                                                     seed, C.c_double(constraintTolerance)))
+        self.stepSize = stepSize
+
+    def step(self, steps):
+        _check(lib().omm_integrator_step(self.h, steps))
+
+
+class State:
+    pass
+
+
+class Context:
+    def __init__(self, system, integrator, platformName, properties=None):
+        props = ";".join("%s=%s" % kv for kv in (properties or {}).items())
+        self.system, self.integrator = system, integrator
+        self.h = _handle(lib().omm_context_create(system.h, integrator.h, platformName.encode(), props.encode()))
+        self.n = system.getNumParticles()
+
+    def close(self):
+        if self.h is not None:
+            lib().omm_context_destroy(self.h)
+            self.h = None
+
+    def getPlatformName(self):
+        return lib().omm_context_platform_name(self.h).decode()
+
+    def getPlatformProperty(self, name):
+        return lib().omm_context_platform_property(self.h, name.encode()).decode()
+
+    def setPositions(self, positions):
+        p = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1)
+        _check(lib().omm_context_set_positions(self.h, len(p) // 3, _dp(p)))
+
+    def setVelocities(self, velocities):
+        p = np.ascontiguousarray(velocities, dtype=np.float64).reshape(-1)
+        _check(lib().omm_context_set_velocities(self.h, len(p) // 3, _dp(p)))
+
+    def setVelocitiesToTemperature(self, temperature, seed=1):
+        _check(lib().omm_context_set_velocities_to_temperature(self.h, C.c_double(temperature), seed))
+
+    def setPeriodicBoxVectors(self, a, b, c):
+        box = np.ascontiguousarray(np.array([a, b, c], dtype=np.float64).reshape(9))
+        _check(lib().omm_context_set_box(self.h, _dp(box)))
+
+    def minimizeEnergy(self, tolerance=10.0, maxIterations=0):
+        _check(lib().omm_context_minimize(self.h, C.c_double(tolerance), maxIterations))
+
+    def applyConstraints(self, tol):
+        _check(lib().omm_context_apply_constraints(self.h, C.c_double(tol)))
+
+    def getState(self, getPositions=False, getVelocities=False, getForces=False, getEnergy=False, groups=-1):
+        flags = (1 if getPositions else 0) | (2 if getVelocities else 0) | (4 if getForces else 0) | (8 if getEnergy else 0)
+        pos = np.zeros((self.n, 3)) if getPositions else np.zeros((1, 3))
+        vel = np.zeros((self.n, 3)) if getVelocities else np.zeros((1, 3))
+        frc = np.zeros((self.n, 3)) if getForces else np.zeros((1, 3))
+        en = np.zeros(3)
+        _check(lib().omm_context_get_state(self.h, flags, groups, _dp(pos), _dp(vel), _dp(frc), _dp(en)))
+        s = State()
+        s.positions = pos if getPositions else None
+        s.velocities = vel if getVelocities else None
+        s.forces = frc if getForces else None
+        s.potentialEnergy, s.kineticEnergy, s.time = (en[0], en[1], en[2])
+        return s

@@ -1,0 +1,279 @@
+"""Synthetic workloads: argon box (HelloArgon parameters), TIP3P water boxes and a
+DHFR-sized solvated-chain system.  Everything is generated from a seed -- no files from the
+reference are read at run time.  Each builder returns a `Workload` with numpy arrays only; `build()`
+turns it into harness objects (System, NonbondedForce, ...) for any platform.
+"""
+import numpy as np
+
+from . import harness as H
+
+# TIP3P (wrappers/python/openmm/app/data/tip3p.xml): charges, LJ, geometry
+TIP3P = dict(qO=-0.834, qH=0.417, sigO=0.315075, epsO=0.635968, dOH=0.09572, dHH=0.15139, mO=15.99943, mH=1.007947)
+
+
+class Workload:
+    def __init__(self, name):
+        self.name = name
+        self.box = None                 # 3x3 or None
+        self.masses = None
+        self.positions = None
+        self.charge = self.sigma = self.epsilon = None
+        self.exception_bonds = None     # bonds used for createExceptionsFromBonds (or None)
+        self.exceptions = None          # explicit (pairs, qq, sigma, eps)
+        self.constraints = None         # (pairs, distances)
+        self.bonds = self.angles = self.torsions = None
+        self.method = H.PME
+        self.cutoff = 0.9
+        self.ewald_tol = 5e-4
+        self.dispersion = True
+        self.cm_remover = False
+        self.pme_params = None
+
+    @property
+    def num_atoms(self):
+        return len(self.masses)
+
+    def build(self):
+        """-> (System, NonbondedForce)"""
+        s = H.System()
+        s.addParticles(self.masses)
+        if self.box is not None:
+            s.setDefaultPeriodicBoxVectors(*self.box)
+        nb = H.NonbondedForce(s, self.method, self.cutoff, self.ewald_tol, self.dispersion)
+        nb.addParticles(self.charge, self.sigma, self.epsilon)
+        if self.exception_bonds is not None and len(self.exception_bonds):
+            nb.createExceptionsFromBonds(self.exception_bonds, 1.0 / 1.2, 0.5)
+        if self.exceptions is not None and len(self.exceptions[0]):
+            nb.addExceptions(*self.exceptions)
+        if self.pme_params is not None:
+            nb.setPMEParameters(*self.pme_params)
+        if self.constraints is not None and len(self.constraints[0]):
+            s.addConstraints(*self.constraints)
+        if self.bonds is not None and len(self.bonds[0]):
+            s.addHarmonicBondForce(*self.bonds)
+        if self.angles is not None and len(self.angles[0]):
+            s.addHarmonicAngleForce(*self.angles)
+        if self.torsions is not None and len(self.torsions[0]):
+            s.addPeriodicTorsionForce(*self.torsions)
+        if self.cm_remover:
+            s.addCMMotionRemover(1)
+        return s, nb
+
+
+def _random_rotations(rng, n):
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1)[:, None]
+    a, b, c, d = q.T
+    return np.stack([
+        np.stack([a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)], -1),
+        np.stack([2 * (b * c + a * d), a * a - b * b + c * c - d * d, 2 * (c * d - a * b)], -1),
+        np.stack([2 * (b * d - a * c), 2 * (c * d + a * b), a * a - b * b - c * c + d * d], -1)], 1)
+
+
+def water_sites():
+    t = TIP3P
+    half = 0.5 * t["dHH"]
+    h = np.sqrt(t["dOH"] ** 2 - half ** 2)
+    return np.array([[0.0, 0.0, 0.0], [half, h, 0.0], [-half, h, 0.0]])
+
+
+def water_box(n_side, seed=0, density=33.4, rigid=True, method=H.PME, cutoff=0.9):
+    """n_side^3 TIP3P waters on a jittered cubic lattice with random orientations."""
+    rng = np.random.default_rng(seed)
+    nw = n_side ** 3
+    L = (nw / density) ** (1.0 / 3.0)
+    spacing = L / n_side
+    g = np.stack(np.meshgrid(*[np.arange(n_side)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    centers = (g + 0.5 + 0.15 * (rng.random((nw, 3)) - 0.5)) * spacing
+    rot = _random_rotations(rng, nw)
+    sites = water_sites()
+    pos = centers[:, None, :] + np.einsum("nij,kj->nki", rot, sites)
+    w = Workload("water-%d" % (3 * nw))
+    w.positions = pos.reshape(-1, 3)
+    w.box = np.eye(3) * L
+    t = TIP3P
+    w.masses = np.tile([t["mO"], t["mH"], t["mH"]], nw)
+    w.charge = np.tile([t["qO"], t["qH"], t["qH"]], nw)
+    w.sigma = np.tile([t["sigO"], 1.0, 1.0], nw)
+    w.epsilon = np.tile([t["epsO"], 0.0, 0.0], nw)
+    o = 3 * np.arange(nw)
+    pairs = np.stack([np.stack([o, o + 1], -1), np.stack([o, o + 2], -1), np.stack([o + 1, o + 2], -1)], 1).reshape(-1, 2)
+    w.exceptions = (pairs, np.zeros(len(pairs)), np.ones(len(pairs)), np.zeros(len(pairs)))
+    if rigid:
+        w.constraints = (pairs, np.tile([t["dOH"], t["dOH"], t["dHH"]], nw))
+    else:
+        ob = np.stack([np.stack([o, o + 1], -1), np.stack([o, o + 2], -1)], 1).reshape(-1, 2)
+        w.bonds = (ob, np.full(len(ob), t["dOH"]), np.full(len(ob), 462750.4))
+        w.angles = (np.stack([o + 1, o, o + 2], -1), np.full(nw, 1.82421813418), np.full(nw, 836.8))
+    w.method, w.cutoff = method, cutoff
+    return w
+
+
+def argon_box(n_cells=6, seed=0, method=H.NoCutoff):
+    """864-atom (6x6x6 fcc) argon box with the HelloArgon parameters (examples/HelloArgon.cpp:36-44)."""
+    rng = np.random.default_rng(seed)
+    a = 0.54
+    basis = np.array([[0, 0, 0], [0.5, 0.5, 0], [0.5, 0, 0.5], [0, 0.5, 0.5]])
+    g = np.stack(np.meshgrid(*[np.arange(n_cells)] * 3, indexing="ij"), -1).reshape(-1, 1, 3)
+    pos = ((g + basis[None]) * a).reshape(-1, 3) + rng.uniform(-0.01, 0.01, (4 * n_cells ** 3, 3))
+    n = len(pos)
+    w = Workload("argon-%d" % n)
+    w.positions = pos
+    w.masses = np.full(n, 39.95)
+    w.charge = np.zeros(n)
+    w.sigma = np.full(n, 0.3350)
+    w.epsilon = np.full(n, 0.996)
+    w.method = method
+    w.dispersion = False
+    if method != H.NoCutoff:
+        w.box = np.eye(3) * (n_cells * a)
+        w.cutoff = 1.0
+    return w
+
+
+def _load_fixture(w, filename):
+    """Replace the lattice start by the equilibrated coordinates/velocities of tests/golden/<filename>
+    (made by tools/make_workload_fixtures.py on the reference's CPU platform), if that file exists."""
+    import os
+    path = os.path.join(H.ROOT, "tests", "golden", filename)
+    w.velocities = None
+    w.relaxed = False
+    if os.path.exists(path):
+        data = np.load(path)
+        if data["positions"].shape == w.positions.shape:
+            w.positions = data["positions"].astype(np.float64)
+            w.velocities = data["velocities"].astype(np.float64)
+            w.relaxed = True
+    return w
+
+
+def dhfr_like(seed=1, n_side=22, chain_atoms=2489, relaxed=True):
+    """A DHFR-sized stand-in: 23 558 atoms = a 2 489-atom flexible heteropolymer
+    (bonds, angles, torsions, 1-4 exceptions, X-H constraints) solvated in TIP3P water in a 6.223 nm cube,
+    PME, cutoff 0.9 nm, default Ewald tolerance -> alpha 2.92 / grid 56^3, as examples/benchmark.py 'pme'.
+    """
+    rng = np.random.default_rng(seed)
+    L = 6.223
+    n_target = 23558
+    # --- chain: a compact self-avoiding walk of heavy atoms (0.15 nm bonds, >= 0.28 nm between atoms more
+    #     than three bonds apart), each carrying 0-2 hydrogens placed away from every other heavy atom
+    n_heavy = int(chain_atoms / 2.0)
+    step, min_dist, radius = 0.15, 0.28, 2.2
+    center = np.array([L / 2, L / 2, L / 2])
+    heavy = np.zeros((n_heavy, 3))
+    heavy[0] = center
+    count = 1
+    while count < n_heavy:
+        placed = False
+        for _ in range(200):
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            q = heavy[count - 1] + step * d
+            if np.linalg.norm(q - center) > radius:
+                continue
+            if count > 3 and np.min(np.linalg.norm(heavy[:count - 3] - q, axis=1)) < min_dist:
+                continue
+            if count > 1 and np.linalg.norm(heavy[count - 2] - q) < 0.22:
+                continue
+            heavy[count] = q
+            count += 1
+            placed = True
+            break
+        if not placed:                      # dead end: back up a few atoms and try again
+            count = max(1, count - 5)
+    pos, masses, charge, sigma, eps, bonds, is_h = [], [], [], [], [], [], []
+    heavy_index = []
+    for i, hp in enumerate(heavy):
+        idx = len(pos)
+        heavy_index.append(idx)
+        pos.append(hp); masses.append(12.011 if i % 4 else 14.007); is_h.append(False)
+        charge.append(rng.normal(0, 0.25)); sigma.append(0.30 if i % 4 else 0.29); eps.append(0.36 if i % 4 else 0.71)
+        if i > 0:
+            bonds.append((heavy_index[i - 1], idx))
+        n_h = 0 if len(pos) >= chain_atoms else (1 if i % 3 == 0 else (2 if i % 3 == 1 else 0))
+        others = np.delete(heavy, i, axis=0)
+        placed_h = []
+        for _ in range(n_h):
+            if len(pos) >= chain_atoms:
+                break
+            best, best_d = None, -1.0
+            for _try in range(30):
+                d = rng.normal(size=3); d /= np.linalg.norm(d)
+                q = hp + 0.109 * d
+                dm = np.min(np.linalg.norm(others - q, axis=1))
+                for ph in placed_h:
+                    dm = min(dm, np.linalg.norm(ph - q) + 0.05)
+                if dm > best_d:
+                    best, best_d = q, dm
+            placed_h.append(best)
+            bonds.append((idx, len(pos)))
+            pos.append(best); masses.append(1.008); is_h.append(True)
+            charge.append(rng.normal(0, 0.1)); sigma.append(0.107); eps.append(0.066)
+    pos = np.array(pos)[:chain_atoms]
+    nc = len(pos)
+    masses, charge, sigma, eps, is_h = [np.array(x)[:nc] for x in (masses, charge, sigma, eps, is_h)]
+    bonds = np.array([b for b in bonds if b[0] < nc and b[1] < nc])
+    charge -= charge.mean()
+    # --- waters on a lattice, skipping sites that overlap the chain
+    n_water = (n_target - nc) // 3
+    spacing = L / n_side
+    g = np.stack(np.meshgrid(*[np.arange(n_side)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    centers = (g + 0.5) * spacing
+    from scipy.spatial import cKDTree
+    tree = cKDTree(pos)
+    dmin, _ = tree.query(centers)
+    order = np.argsort(-dmin)[:n_water]
+    centers = centers[np.sort(order)] + 0.05 * (rng.random((n_water, 3)) - 0.5)
+    rot = _random_rotations(rng, n_water)
+    wpos = (centers[:, None, :] + np.einsum("nij,kj->nki", rot, water_sites())).reshape(-1, 3)
+    t = TIP3P
+    w = Workload("dhfr-like-%d" % (nc + 3 * n_water))
+    w.positions = np.concatenate([pos, wpos])
+    w.box = np.eye(3) * L
+    w.masses = np.concatenate([masses, np.tile([t["mO"], t["mH"], t["mH"]], n_water)])
+    w.charge = np.concatenate([charge, np.tile([t["qO"], t["qH"], t["qH"]], n_water)])
+    w.sigma = np.concatenate([sigma, np.tile([t["sigO"], 1.0, 1.0], n_water)])
+    w.epsilon = np.concatenate([eps, np.tile([t["epsO"], 0.0, 0.0], n_water)])
+    o = nc + 3 * np.arange(n_water)
+    wpairs = np.stack([np.stack([o, o + 1], -1), np.stack([o, o + 2], -1), np.stack([o + 1, o + 2], -1)], 1).reshape(-1, 2)
+    w.exception_bonds = bonds
+    w.exceptions = (wpairs, np.zeros(len(wpairs)), np.ones(len(wpairs)), np.zeros(len(wpairs)))
+    # constraints: waters (SETTLE) + X-H bonds of the chain (SHAKE clusters)
+    hb = np.array([b for b in bonds if is_h[b[0]] or is_h[b[1]]])
+    hb_len = np.linalg.norm(pos[hb[:, 0]] - pos[hb[:, 1]], axis=1)
+    w.constraints = (np.concatenate([hb, wpairs]), np.concatenate([hb_len, np.tile([t["dOH"], t["dOH"], t["dHH"]], n_water)]))
+    hv = np.array([b for b in bonds if not (is_h[b[0]] or is_h[b[1]])])
+    hv_len = np.linalg.norm(pos[hv[:, 0]] - pos[hv[:, 1]], axis=1)
+    w.bonds = (hv, hv_len, np.full(len(hv), 250000.0))
+    # angles and torsions along the heavy-atom backbone at their current values (a relaxed structure)
+    hi = np.array(heavy_index)[: np.searchsorted(heavy_index, nc)]
+    ang = np.stack([hi[:-2], hi[1:-1], hi[2:]], -1)
+    v1 = pos[ang[:, 0]] - pos[ang[:, 1]]
+    v2 = pos[ang[:, 2]] - pos[ang[:, 1]]
+    cosang = np.einsum("ij,ij->i", v1, v2) / np.linalg.norm(v1, axis=1) / np.linalg.norm(v2, axis=1)
+    # every hydrogen also gets H-X-Y angle terms (tetrahedral), as a force field would give it
+    nbrs = [[] for _ in range(nc)]
+    for a, b in bonds:
+        nbrs[a].append(b); nbrs[b].append(a)
+    h_ang = []
+    for x in range(nc):
+        if is_h[x]:
+            continue
+        for h in nbrs[x]:
+            if not is_h[h]:
+                continue
+            for y in nbrs[x]:
+                if y != h and (not is_h[y] or h < y):
+                    h_ang.append((h, x, y))
+    h_ang = np.array(h_ang, dtype=np.int64).reshape(-1, 3)
+    ang_all = np.concatenate([ang, h_ang])
+    theta0 = np.concatenate([np.arccos(np.clip(cosang, -1, 1)), np.full(len(h_ang), 1.911)])
+    w.angles = (ang_all, theta0, np.concatenate([np.full(len(ang), 400.0), np.full(len(h_ang), 300.0)]))
+    tor = np.stack([hi[:-3], hi[1:-2], hi[2:-1], hi[3:]], -1)
+    w.torsions = (tor, np.full(len(tor), 3, dtype=np.int32), np.zeros(len(tor)), np.full(len(tor), 1.0))
+    w.cm_remover = True
+    w.velocities = None
+    w.relaxed = False
+    if relaxed:
+        _load_fixture(w, "dhfr_like_seed%d_equilibrated.npz" % seed)
+    return w

@@ -23,7 +23,7 @@ Reference sources restated (paths relative to the OpenMM tree):
 import numpy as np
 from scipy.special import erf, erfc
 
-ONE_4PI_EPS0 = 138.935456  # platforms/reference/include/SimTKOpenMMRealType.h:84-89
+ONE_4PI_EPS0 = 138.93545764438198  # 1/(4 pi EPSILON0), platforms/reference/include/SimTKOpenMMRealType.h:74-89 (CODATA 2018)
 
 NoCutoff, CutoffNonPeriodic, CutoffPeriodic, Ewald, PME, LJPME = range(6)
 

@@ -16,7 +16,7 @@ Pinned against the real reference in tests/test_oracle_vs_reference.py.
 """
 import numpy as np
 
-ONE_4PI_EPS0 = 138.935456
+ONE_4PI_EPS0 = 138.93545764438198  # 1/(4 pi EPSILON0), SimTKOpenMMRealType.h:74-89 (CODATA 2018)
 ORDER = 5  # ReferenceLJCoulombIxn.cpp:243
 
 

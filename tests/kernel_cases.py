@@ -1,0 +1,159 @@
+"""Kernel-level parity cases driven through the C ABI (include/openmm_hip_kernels.h) with ctypes.
+
+The same cases run against the product library on a GPU (tests/test_gpu_kernels.py, `-m gpu`) and against
+the CPU-emulated twin (tests/test_emu_host_logic.py) -- the latter only checks indexing/host logic."""
+import ctypes as C
+
+import numpy as np
+
+from openmm_amd import capi
+from oracle import nonbonded as ONB, pme as OPME
+
+
+def lattice_positions(rng, n, box3, jitter=0.25):
+    m = int(np.ceil(n ** (1 / 3)))
+    g = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n]
+    frac = (g + 0.5 + jitter * (rng.random((n, 3)) - 0.5)) / m
+    return frac @ box3
+
+
+def box6(box3):
+    return (C.c_double * 6)(box3[0, 0], box3[1, 0], box3[1, 1], box3[2, 0], box3[2, 1], box3[2, 2])
+
+
+def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64):
+    """-> (forces[n,3], energy, oracle forces, oracle energy, nl state)"""
+    rng = np.random.default_rng(seed)
+    box3 = np.eye(3) * L
+    if triclinic:
+        box3 = np.array([[L, 0, 0], [0.2 * L, 0.9 * L, 0], [-0.3 * L, 0.25 * L, 1.1 * L]])
+    pos = lattice_positions(rng, n, box3)
+    q = rng.normal(0, 0.5, n)
+    q -= q.mean()
+    sig = 0.2 + 0.1 * rng.random(n)
+    eps = rng.random(n)
+    padded = (n + 31) // 32 * 32
+    # a non-trivial slot order exercises atomOfSlot/slotOfAtom
+    perm = rng.permutation(n).astype(np.int32)
+    atom_of_slot = np.full(padded, -1, np.int32)
+    atom_of_slot[:n] = perm
+    slot_of_atom = np.empty(n, np.int32)
+    slot_of_atom[perm] = np.arange(n, dtype=np.int32)
+    ex = [[] for _ in range(n)]
+    for i, j in excl:
+        ex[i].append(j)
+        ex[j].append(i)
+    start = np.zeros(n + 1, np.int32)
+    start[1:] = np.cumsum([len(e) for e in ex])
+    flat = np.array([a for e in ex for a in e] + [0], np.int32)
+    pos4 = np.zeros((n, 4))
+    pos4[:, :3] = pos
+    wrap = np.zeros((n, 4), np.int32)
+    periodic = method in (ONB.CutoffPeriodic, ONB.Ewald, ONB.PME)
+    d_pos, d_wrap, d_aos, d_soa = K.upload(pos4), K.upload(wrap), K.upload(atom_of_slot), K.upload(slot_of_atom)
+    d_posq, d_se = K.upload(np.zeros((padded, 4), np.float32)), K.upload(np.zeros((padded, 2), np.float32))
+    d_q, d_sig, d_eps = K.upload(q), K.upload(sig), K.upload(eps)
+    b6 = box6(box3)
+    K.set_slot_params(d_q, d_sig, d_eps, d_aos, padded, d_posq, d_se, None)
+    K.positions_to_posq(d_pos, d_wrap, d_aos, padded, b6, d_posq, None)
+    nl = capi.NeighborList()
+    nl.num_atoms, nl.padded_atoms = n, padded
+    maxc = 8192
+    nl.max_chunks = maxc
+    nl.pbc = 0 if not periodic else (2 if triclinic else 1)
+    nl.cutoff = cutoff if method != ONB.NoCutoff else 0.0
+    nl.padding = 0.1 * cutoff if method != ONB.NoCutoff else 0.0
+    for i in range(6):
+        nl.box[i] = b6[i]
+    nl.posq, nl.posq_ref = d_posq, K.upload(np.zeros((padded, 4), np.float32))
+    nl.atom_of_slot, nl.slot_of_atom = d_aos, d_soa
+    nl.excl_start, nl.excl_atoms = K.upload(start), K.upload(flat)
+    st = np.zeros(8, np.int32)
+    st[0] = 1
+    nl.state = K.upload(st)
+    nb = padded // 32
+    nl.block_center, nl.block_half = K.upload(np.zeros((nb, 4), np.float32)), K.upload(np.zeros((nb, 4), np.float32))
+    nl.chunk_info = K.upload(np.zeros((maxc, 2), np.int32))
+    nl.row_j = K.upload(np.zeros(maxc * 256, np.int32))
+    nl.row_mask = K.upload(np.zeros(maxc * 256, np.uint32))
+    K.nl_update(C.byref(nl), None)
+    state = K.download(nl.state, 8, np.int32)
+    p = capi.NonbondedParams()
+    p.ewald = 1 if method in (ONB.Ewald, ONB.PME) else 0
+    alpha = float(np.sqrt(-np.log(2 * 5e-4)) / cutoff) if p.ewald else 0.0
+    p.ewald_alpha = alpha
+    if method in (ONB.CutoffPeriodic, ONB.CutoffNonPeriodic):
+        p.krf, p.crf = ONB.reaction_field_constants(cutoff, 78.3)
+    if switch:
+        p.use_switch, p.switch_distance = 1, switch
+    p.direct_grid = grid
+    d_f, d_e = K.upload(np.zeros(3 * padded, np.int64)), K.upload(np.zeros(grid))
+    K.nb_direct(C.byref(nl), C.byref(p), d_se, d_f, d_e, grid, 1, None)
+    f = K.download(d_f, (3, padded), np.int64).astype(np.float64) / 2 ** 32
+    e = float(K.download(d_e, grid, np.float64).sum())
+    forces = f[:, slot_of_atom].T
+    f_or, e_or = ONB.direct_space(pos, q, sig, eps, method, cutoff, box3, excl, alpha, switch_distance=switch)
+    return forces, e, f_or, e_or, state
+
+
+def twiddles(n):
+    k = np.arange(n)
+    w = np.exp(-2j * np.pi * k / n)
+    return np.stack([w.real, w.imag], -1).astype(np.float32)
+
+
+def make_pme(K, ng, box3, alpha):
+    nx, ny, nz = ng
+    nzc = nz // 2 + 1
+    pm = capi.Pme()
+    pm.nx, pm.ny, pm.nz = ng
+    pm.alpha = alpha
+    b = box6(box3)
+    for i in range(6):
+        pm.box[i] = b[i]
+    pm.moduli_x, pm.moduli_y, pm.moduli_z = (K.upload(OPME.bspline_moduli(n)) for n in ng)
+    pm.eterm = K.upload(np.zeros(nx * ny * nzc, np.float32))
+    pm.grid_real = K.upload(np.zeros(nx * ny * nz, np.float32))
+    pm.grid_complex = K.upload(np.zeros(nx * ny * nzc * 2, np.float32))
+    pm.twiddle_x, pm.twiddle_y, pm.twiddle_z = (K.upload(twiddles(n)) for n in ng)
+    return pm
+
+
+def run_fft(K, ng, seed=1):
+    """-> (forward max error relative to max |ref|, round-trip max abs error)   pattern of TestCudaFFT3D.cpp:52-108"""
+    rng = np.random.default_rng(seed)
+    nx, ny, nz = ng
+    nzc = nz // 2 + 1
+    pm = make_pme(K, ng, np.eye(3) * 3.0, 3.0)
+    g = rng.normal(size=ng).astype(np.float32)
+    K.memcpy_h2d(pm.grid_real, g.ctypes.data_as(C.c_void_p), g.nbytes, None)
+    K.fft3d_r2c_c2r(C.byref(pm), 1, None)
+    c = K.download(pm.grid_complex, (nx, ny, nzc, 2), np.float32)
+    c = c[..., 0] + 1j * c[..., 1]
+    ref = np.fft.rfftn(g.astype(np.float64))
+    fwd = float(np.abs(c - ref).max() / np.abs(ref).max())
+    K.fft3d_r2c_c2r(C.byref(pm), 0, None)
+    back = K.download(pm.grid_real, ng, np.float32)
+    return fwd, float(np.abs(back / np.prod(ng) - g).max())
+
+
+def run_pme(K, n, ng, L, triclinic=False, seed=2, alpha=2.6):
+    rng = np.random.default_rng(seed)
+    box3 = np.eye(3) * L
+    if triclinic:
+        box3 = np.array([[L, 0, 0], [0.2 * L, 0.9 * L, 0], [-0.3 * L, 0.25 * L, 1.1 * L]])
+    pos = rng.random((n, 3)) @ box3
+    q = rng.normal(0, 0.5, n)
+    q -= q.mean()
+    padded = (n + 31) // 32 * 32
+    posq = np.zeros((padded, 4), np.float32)
+    posq[:n, :3] = pos
+    posq[:n, 3] = q
+    d_posq, d_f, d_e = K.upload(posq), K.upload(np.zeros(3 * padded, np.int64)), K.upload(np.zeros(64))
+    pm = make_pme(K, ng, box3, alpha)
+    K.pme_build_eterm(C.byref(pm), None)
+    K.pme_reciprocal(C.byref(pm), d_posq, padded, d_f, d_e, 64, 1, None)
+    f = K.download(d_f, (3, padded), np.int64).astype(np.float64) / 2 ** 32
+    e = float(K.download(d_e, 64, np.float64).sum())
+    f_or, e_or = OPME.pme_exec(posq[:n, :3].astype(np.float64), q.astype(np.float32).astype(np.float64), box3, alpha, ng)
+    return f[:, :n].T, e, f_or, e_or

@@ -1,0 +1,105 @@
+"""Host-logic checks without a GPU: the same kernel sources and plugin, compiled with g++ against the SIMT
+emulator of tests/emu (test infrastructure only), run (a) kernel-level cases through the C ABI, (b) the
+reference's own test bodies (tests/Test*.h of the OpenMM tree, built by tests/hip/Makefile) and (c) a
+Context("HIP") round trip through OpenMM's plugin loader.  Numerics on real hardware are covered by `-m gpu`."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import EMU_BUILD, ROOT, max_rel_force_error
+import kernel_cases as KC
+from openmm_amd import capi
+from oracle import nonbonded as ONB
+
+EMU_LIB = os.path.join(EMU_BUILD, "libopenmm_hip_kernels.so")
+needs_emu = pytest.mark.skipif(not os.path.exists(EMU_LIB), reason="emulated build missing (run __graft_entry__.build())")
+
+
+@pytest.fixture(scope="module")
+def K():
+    return capi.load(EMU_LIB)
+
+
+EXCL = [(i, i + 1) for i in range(0, 200, 3)] + [(i, i + 2) for i in range(0, 200, 3)]
+
+
+@needs_emu
+@pytest.mark.parametrize("n,method,tric,switch", [
+    (300, ONB.NoCutoff, False, None), (500, ONB.CutoffNonPeriodic, False, None), (700, ONB.CutoffPeriodic, False, None),
+    (700, ONB.PME, False, None), (700, ONB.PME, True, None), (700, ONB.CutoffPeriodic, False, 0.8)])
+def test_direct_space_kernel_logic(K, n, method, tric, switch):
+    f, e, f_or, e_or, state = KC.run_direct_space(K, n, method, 1.0, 3.0, EXCL, tric, switch)
+    assert state[0] == 0 and state[2] == 0 and state[1] > 0
+    assert max_rel_force_error(f, f_or) < 5e-5
+    assert abs(e - e_or) < 5e-5 * max(abs(e_or), 100.0)
+
+
+@needs_emu
+@pytest.mark.parametrize("ng", [(8, 6, 10), (28, 25, 30), (21, 20, 18)])
+def test_fft_logic(K, ng):
+    fwd, back = KC.run_fft(K, ng)
+    assert fwd < 1e-5 and back < 1e-5
+
+
+@needs_emu
+@pytest.mark.parametrize("tric", [False, True])
+def test_pme_logic(K, tric):
+    f, e, f_or, e_or = KC.run_pme(K, 300, (20, 24, 28), 3.0, tric)
+    assert max_rel_force_error(f, f_or) < 5e-5
+    assert abs(e - e_or) < 1e-5 * abs(e_or)
+
+
+FAST_REFERENCE_TESTS = ["HarmonicBondForce", "HarmonicAngleForce", "PeriodicTorsionForce", "CMMotionRemover", "Checkpoints",
+                        "CustomBondForce", "RBTorsionForce", "Settle", "NonbondedForce"]
+
+
+@needs_emu
+@pytest.mark.parametrize("name", FAST_REFERENCE_TESTS)
+def test_reference_test_bodies_on_emulated_platform(name):
+    exe = os.path.join(EMU_BUILD, "tests", "TestHip" + name)
+    if not os.path.exists(exe):
+        pytest.skip("not built")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "Done" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@needs_emu
+def test_context_round_trip_through_plugin_loader():
+    """Context('HIP') via Platform::loadPluginLibrary -> registerPlatforms(), forces vs the Reference platform, a few
+    LangevinMiddle steps with SETTLE; run in a child process because the emulated and product plugins must not mix."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from openmm_amd import harness as H, testsystems as T
+H.load_hip_platform(emulated=True)
+assert "HIP" in H.platform_names()
+w = T.water_box(5, seed=2, cutoff=0.7)
+alpha = float(np.sqrt(-np.log(2 * w.ewald_tol)) / w.cutoff)
+w.pme_params = (alpha, 16, 16, 16)
+res = {}
+for plat in ("Reference", "HIP"):
+    s, nb = w.build()
+    integ = H.Integrator(H.LANGEVIN_MIDDLE, 0.002, 300.0, 1.0, seed=5)
+    c = H.Context(s, integ, plat)
+    c.setPositions(w.positions)
+    res[plat] = c.getState(getForces=True, getEnergy=True)
+    if plat == "HIP":
+        assert nb.getPMEParametersInContext(c)[1:] == (16, 16, 16)
+        c.setVelocitiesToTemperature(300.0, 3)
+        integ.step(5)
+        p = c.getState(getPositions=True).positions.reshape(-1, 3, 3)
+        d = np.linalg.norm(p[:, 0] - p[:, 1], axis=1)
+        assert abs(d - T.TIP3P["dOH"]).max() < 1e-5, d
+    c.close()
+fr, fh = res["Reference"].forces, res["HIP"].forces
+rms = np.sqrt((fr ** 2).sum(1).mean())
+err = np.sqrt(((fh - fr) ** 2).sum(1)).max() / rms
+assert err < 1e-4, err
+assert abs(res["HIP"].potentialEnergy - res["Reference"].potentialEnergy) < 0.05
+print("OK", err)
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -26,7 +26,7 @@ extern "C" {
 
 #define OMMHIP_TILE 32        /* atoms per i-block                       */
 #define OMMHIP_ROW 64         /* j-atoms per neighbour-list row          */
-#define OMMHIP_CHUNK_ROWS 4   /* rows per chunk                          */
+#define OMMHIP_CHUNK_ROWS 2   /* rows per chunk                          */
 #define OMMHIP_NL_STATE_INTS 8
 
 /* ------------------------------------------------------------------------------------------
@@ -88,6 +88,8 @@ int ommhip_set_slot_params(const double* charge_d, const double* sigma_d, const 
 int ommhip_forces_to_double(const long long* force_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, double* out_d, void* stream);
 /* force[slot] += in[3*atom..] (double) */
 int ommhip_add_forces_from_double(const double* in_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, long long* force_d, void* stream);
+/* zero two device buffers (sizes multiples of 16 bytes; either may be empty) in one launch */
+int ommhip_clear2(void* a_d, size_t a_bytes, void* b_d, size_t b_bytes, void* stream);
 /* result[0] = sum of buffer[0..n), then buffer is zeroed; result_d is a device double */
 int ommhip_reduce_energy(double* buffer_d, int n, double* result_d, void* stream);
 
@@ -111,7 +113,8 @@ typedef struct ommhip_neighbor_list {
     const int* slot_of_atom;   /* [num_atoms] */
     const int* excl_start;     /* [num_atoms+1] CSR of excluded partners (atom indices) */
     const int* excl_atoms;
-    int* state;                /* int[OMMHIP_NL_STATE_INTS]: 0 rebuild-request, 1 chunks used, 2 overflow, 3 scratch, 4 #rebuilds */
+    const void* excl_block_range; /* int2[padded_atoms/32] or NULL: per i-block, lowest/highest block that holds an exclusion partner */
+    int* state;               /* int[OMMHIP_NL_STATE_INTS]: 0 rebuild-request, 1 chunks used, 2 overflow, 3 scratch, 4 #rebuilds */
     void* block_center;        /* float4[padded_atoms/32] */
     void* block_half;          /* float4[padded_atoms/32] */
     void* chunk_info;          /* int2[max_chunks]  (i-block, nrows | maskedRowBits<<8) */
@@ -130,6 +133,9 @@ typedef struct ommhip_nonbonded_params {
 
 /* Checks displacement, and (only if state[0] != 0 afterwards) rebuilds bounds + rows.  No host sync. */
 int ommhip_nl_update(const ommhip_neighbor_list* nl, void* stream);
+/* The per-step path of the platform, two launches: (1) double positions (pos_d double4[num_atoms], wrap_d int4[num_atoms], as
+ * ommhip_positions_to_posq) -> nl->posq, displacement check, block bounds; (2) the device-conditional rebuild. */
+int ommhip_nl_step(const ommhip_neighbor_list* nl, const void* pos_d, const void* wrap_d, void* stream);
 /* Adds direct-space forces (and per-workgroup energies into energy_buffer_d[0..energy_slots)). */
 int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, const void* sig_eps_d,
                      long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
@@ -153,6 +159,8 @@ typedef struct ommhip_pme {
     const void* twiddle_x;     /* device float2[nx]: exp(-2 pi i k/nx) */
     const void* twiddle_y;
     const void* twiddle_z;
+    int spread_mode;           /* 0: LDS-staged bricks (default), 1: direct global atomics */
+    int grid_precleared;       /* 1: the caller zeroed grid_real on this stream already (fused clear), skip the memset */
 } ommhip_pme;
 
 int ommhip_fft_supported_size(int n);   /* 1 if n factors into 2,3,5,7 and fits the LDS line buffer; no device access */
@@ -184,6 +192,17 @@ typedef struct ommhip_term_list {
     const double* params;      /* device double[num_terms * paramsPerTerm] */
 } ommhip_term_list;
 
+/* Several term lists in ONE launch (each list gets its own range of workgroups). */
+#define OMMHIP_MAX_TERM_LISTS 8
+typedef struct ommhip_term_batch {
+    int kind;
+    ommhip_term_list terms;
+    int periodic;              /* minimum-image displacements */
+    const double* charge;      /* device double[num_atoms], EWALD_EXCLUSION only */
+    double alpha;              /* EWALD_EXCLUSION only */
+} ommhip_term_batch;
+int ommhip_term_forces_multi(int num_lists, const ommhip_term_batch* lists, const void* pos_d, const int* slot_of_atom_d, int padded_atoms,
+                             const double box[6], long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
 int ommhip_term_forces(int kind, const ommhip_term_list* terms, const void* pos_d, const int* slot_of_atom_d, int padded_atoms,
                        const double box[6], int periodic, const double* charge_d, double alpha,
                        long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
@@ -237,6 +256,11 @@ int ommhip_settle(int num_clusters, const int* atoms_d, const double* dist_d, co
 /* SHAKE clusters: atoms_d int4[n] (centre, s1, s2, s3; -1 unused), dist_d double4[n] */
 int ommhip_shake(int num_clusters, const int* atoms_d, const double* dist_d, const void* pos_d, void* target_d,
                  const void* vel_mass_d, int velocities, double tol, int max_iterations, void* stream);
+/* SHAKE clusters and SETTLE waters in one launch (the two sets never share atoms) */
+int ommhip_constrain_clusters(int num_shake, const int* shake_atoms_d, const double* shake_dist_d,
+                              int num_settle, const int* settle_atoms_d, const double* settle_dist_d,
+                              const void* pos_d, void* target_d, const void* vel_mass_d, int velocities,
+                              double tol, int max_iterations, void* stream);
 typedef struct ommhip_ccma {
     int num_constraints;
     const int* atoms;          /* device int2[n] */

@@ -13,7 +13,7 @@ PRODUCT_LIB = os.path.join(_HERE, "lib", "libopenmm_hip_kernels.so")
 
 TILE = 32
 ROW = 64
-CHUNK_ROWS = 4
+CHUNK_ROWS = 2
 NL_STATE_INTS = 8
 
 
@@ -22,7 +22,7 @@ class NeighborList(C.Structure):
         ("num_atoms", C.c_int), ("padded_atoms", C.c_int), ("max_chunks", C.c_int), ("pbc", C.c_int),
         ("cutoff", C.c_double), ("padding", C.c_double), ("box", C.c_double * 6),
         ("posq", C.c_void_p), ("posq_ref", C.c_void_p), ("atom_of_slot", C.c_void_p), ("slot_of_atom", C.c_void_p),
-        ("excl_start", C.c_void_p), ("excl_atoms", C.c_void_p), ("state", C.c_void_p),
+        ("excl_start", C.c_void_p), ("excl_atoms", C.c_void_p), ("excl_block_range", C.c_void_p), ("state", C.c_void_p),
         ("block_center", C.c_void_p), ("block_half", C.c_void_p), ("chunk_info", C.c_void_p),
         ("row_j", C.c_void_p), ("row_mask", C.c_void_p),
     ]
@@ -40,7 +40,8 @@ class Pme(C.Structure):
         ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("alpha", C.c_double), ("box", C.c_double * 6),
         ("moduli_x", C.c_void_p), ("moduli_y", C.c_void_p), ("moduli_z", C.c_void_p),
         ("eterm", C.c_void_p), ("grid_real", C.c_void_p), ("grid_complex", C.c_void_p),
-        ("twiddle_x", C.c_void_p), ("twiddle_y", C.c_void_p), ("twiddle_z", C.c_void_p),
+        ("twiddle_x", C.c_void_p), ("twiddle_y", C.c_void_p), ("twiddle_z", C.c_void_p), ("spread_mode", C.c_int),
+        ("grid_precleared", C.c_int),
     ]
 
 

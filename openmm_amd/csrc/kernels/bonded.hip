@@ -11,6 +11,9 @@
 //
 // The work per step is tiny compared with the pair kernel (tens of thousands of terms), so these
 // run in FP64 -- MI355X's FP64 vector rate makes that free and it removes a source of parity noise.
+// At this size a launch costs more than the arithmetic (~4 us per dependent launch on the device
+// timeline), so all term lists of one force evaluation go out in ONE launch: each list owns a
+// contiguous range of workgroups, so every workgroup executes a single term kind (uniform branch).
 #include "common.h"
 #include "../../../include/openmm_hip_kernels.h"
 
@@ -18,167 +21,170 @@ using namespace omm;
 
 namespace {
 
-struct TermArgs {
-    int numTerms, paddedAtoms, periodic, includeEnergy, energySlots;
-    BoxD box;
+struct TermList {
+    int kind, numTerms, periodic, firstBlock;
     double alpha;
-    const double4* pos;
-    const int* slotOfAtom;
     const int* atoms;          // numTerms * atomsPerTerm
     const double* params;      // numTerms * paramsPerTerm
     const double* charge;      // per atom (exclusion correction)
-    omm_fixed* force;
-    double* energyBuffer;
 };
 
-__device__ __forceinline__ double3 delta(const TermArgs& a, int from, int to) {
-    double4 p = a.pos[from], q = a.pos[to];
-    double dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
-    if (a.periodic) min_image_d(dx, dy, dz, a.box);
-    return make_double3(dx, dy, dz);
-}
+struct TermArgs {
+    int numLists, paddedAtoms, includeEnergy, energySlots;
+    BoxD box;
+    const double4* pos;
+    const int* slotOfAtom;
+    omm_fixed* force;
+    double* energyBuffer;
+    TermList list[OMMHIP_MAX_TERM_LISTS];
+};
+
+struct TermCtx {     // what one term evaluation needs
+    const TermArgs& a;
+    const TermList& l;
+    __device__ TermCtx(const TermArgs& a_, const TermList& l_) : a(a_), l(l_) {}
+    __device__ __forceinline__ double3 delta(int from, int to) const {
+        double4 p = a.pos[from], q = a.pos[to];
+        double dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+        if (l.periodic) min_image_d(dx, dy, dz, a.box);
+        return make_double3(dx, dy, dz);
+    }
+    __device__ __forceinline__ void add(int atom, double fx, double fy, double fz) const {
+        add_force(a.force, a.paddedAtoms, a.slotOfAtom[atom], fx, fy, fz);
+    }
+};
+
 __device__ __forceinline__ double dot3(double3 a, double3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ double3 cross3(double3 a, double3 b) { return make_double3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 
-__device__ __forceinline__ void add_atom_force(const TermArgs& a, int atom, double fx, double fy, double fz) {
-    add_force(a.force, a.paddedAtoms, a.slotOfAtom[atom], fx, fy, fz);
+__device__ __forceinline__ double term_exception14(const TermCtx& c, int t) {
+    const int i = c.l.atoms[2 * t], j = c.l.atoms[2 * t + 1];
+    const double qq = c.l.params[3 * t], sig = c.l.params[3 * t + 1], eps4 = 4.0 * c.l.params[3 * t + 2];
+    const double3 d = c.delta(i, j);                      // j - i
+    const double invR = 1.0 / sqrt(dot3(d, d));
+    double s2 = sig * invR; s2 *= s2;
+    const double s6 = s2 * s2 * s2;
+    const double dEdR = (eps4 * (12.0 * s6 - 6.0) * s6 + OMM_ONE_4PI_EPS0_D * qq * invR) * invR * invR;
+    c.add(j, dEdR * d.x, dEdR * d.y, dEdR * d.z);
+    c.add(i, -dEdR * d.x, -dEdR * d.y, -dEdR * d.z);
+    return eps4 * (s6 - 1.0) * s6 + OMM_ONE_4PI_EPS0_D * qq * invR;
 }
 
-__device__ __forceinline__ void block_add_energy(const TermArgs& a, double e) {
-    if (!a.includeEnergy) return;
+__device__ __forceinline__ double term_ewald_exclusion(const TermCtx& c, int t) {
+    const int i = c.l.atoms[2 * t], j = c.l.atoms[2 * t + 1];
+    const double qq = OMM_ONE_4PI_EPS0_D * c.l.charge[i] * c.l.charge[j];
+    const double3 d = c.delta(i, j);
+    const double r = sqrt(dot3(d, d));
+    const double ar = c.l.alpha * r;
+    const double erfAr = erf(ar);
+    if (erfAr > 1e-6) {
+        const double invR = 1.0 / r;
+        const double dEdR = qq * invR * invR * invR * (erfAr - 2.0 * ar * exp(-ar * ar) * 0.56418958354775628695);
+        c.add(j, -dEdR * d.x, -dEdR * d.y, -dEdR * d.z);
+        c.add(i, dEdR * d.x, dEdR * d.y, dEdR * d.z);
+        return -qq * invR * erfAr;
+    }
+    return -c.l.alpha * 1.12837916709551257390 * qq;
+}
+
+__device__ __forceinline__ double term_harmonic_bond(const TermCtx& c, int t) {
+    const int i = c.l.atoms[2 * t], j = c.l.atoms[2 * t + 1];
+    const double r0 = c.l.params[2 * t], k = c.l.params[2 * t + 1];
+    const double3 d = c.delta(i, j);
+    const double r = sqrt(dot3(d, d));
+    const double dl = r - r0;
+    const double dEdR = r > 0.0 ? k * dl / r : 0.0;
+    c.add(i, dEdR * d.x, dEdR * d.y, dEdR * d.z);
+    c.add(j, -dEdR * d.x, -dEdR * d.y, -dEdR * d.z);
+    return 0.5 * k * dl * dl;
+}
+
+__device__ __forceinline__ double term_harmonic_angle(const TermCtx& c, int t) {
+    const int ia = c.l.atoms[3 * t], ib = c.l.atoms[3 * t + 1], ic = c.l.atoms[3 * t + 2];
+    const double theta0 = c.l.params[2 * t], k = c.l.params[2 * t + 1];
+    const double3 d0 = c.delta(ia, ib);      // b - a
+    const double3 d1 = c.delta(ic, ib);      // b - c
+    const double3 p = cross3(d0, d1);
+    double rp = sqrt(dot3(p, p));
+    if (rp < 1.0e-06) rp = 1.0e-06;
+    const double r20 = dot3(d0, d0), r21 = dot3(d1, d1);
+    const double cosine = dot3(d0, d1) / sqrt(r20 * r21);
+    const double angle = cosine >= 1.0 ? 0.0 : (cosine <= -1.0 ? 3.14159265358979323846 : acos(cosine));
+    const double dth = angle - theta0;
+    const double dEdR = k * dth;
+    const double termA = dEdR / (r20 * rp), termC = -dEdR / (r21 * rp);
+    double3 fa = cross3(d0, p), fc = cross3(d1, p);
+    fa.x *= termA; fa.y *= termA; fa.z *= termA;
+    fc.x *= termC; fc.y *= termC; fc.z *= termC;
+    c.add(ia, fa.x, fa.y, fa.z);
+    c.add(ic, fc.x, fc.y, fc.z);
+    c.add(ib, -(fa.x + fc.x), -(fa.y + fc.y), -(fa.z + fc.z));
+    return 0.5 * k * dth * dth;
+}
+
+__device__ __forceinline__ double term_periodic_torsion(const TermCtx& c, int t) {
+    const int ia = c.l.atoms[4 * t], ib = c.l.atoms[4 * t + 1], ic = c.l.atoms[4 * t + 2], id = c.l.atoms[4 * t + 3];
+    const double k = c.l.params[3 * t], phase = c.l.params[3 * t + 1], periodicity = c.l.params[3 * t + 2];
+    const double3 v0 = c.delta(ib, ia);      // a - b
+    const double3 v1 = c.delta(ib, ic);      // c - b
+    const double3 v2 = c.delta(id, ic);      // c - d
+    const double3 cp0 = cross3(v0, v1), cp1 = cross3(v1, v2);
+    // angle between the two plane normals, asin branch near 0/pi (ReferenceBondIxn.cpp:115-135)
+    const double n0 = dot3(cp0, cp0), n1 = dot3(cp1, cp1);
+    double dp = dot3(cp0, cp1) / sqrt(n0 * n1);
+    dp = dp > 1.0 ? 1.0 : (dp < -1.0 ? -1.0 : dp);
+    double angle;
+    if (dp > 0.99 || dp < -0.99) {
+        const double3 cr = cross3(cp0, cp1);
+        angle = asin(sqrt(dot3(cr, cr) / (n0 * n1)));
+        if (dp < 0.0) angle = 3.14159265358979323846 - angle;
+    }
+    else
+        angle = acos(dp);
+    if (dot3(v0, cp1) < 0.0) angle = -angle;
+    const double deltaAngle = periodicity * angle - phase;
+    const double dEdAngle = -k * periodicity * sin(deltaAngle);
+    const double normBC = sqrt(dot3(v1, v1));
+    const double ff0 = (-dEdAngle * normBC) / n0;
+    const double ff3 = (dEdAngle * normBC) / n1;
+    const double ff1 = dot3(v0, v1) / dot3(v1, v1);
+    const double ff2 = dot3(v2, v1) / dot3(v1, v1);
+    const double3 f0 = make_double3(ff0 * cp0.x, ff0 * cp0.y, ff0 * cp0.z);
+    const double3 f3 = make_double3(ff3 * cp1.x, ff3 * cp1.y, ff3 * cp1.z);
+    const double3 s = make_double3(ff1 * f0.x - ff2 * f3.x, ff1 * f0.y - ff2 * f3.y, ff1 * f0.z - ff2 * f3.z);
+    c.add(ia, f0.x, f0.y, f0.z);
+    c.add(ib, -(f0.x - s.x), -(f0.y - s.y), -(f0.z - s.z));
+    c.add(ic, -(f3.x + s.x), -(f3.y + s.y), -(f3.z + s.z));
+    c.add(id, f3.x, f3.y, f3.z);
+    return k * (1.0 + cos(deltaAngle));
+}
+
+__global__ __launch_bounds__(256) void k_terms(TermArgs a) {
     __shared__ double partial[4];
-    e = wave_sum(e);
-    if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = e;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], partial[0] + partial[1] + partial[2] + partial[3]);
-}
-
-__global__ __launch_bounds__(256) void k_exceptions14(TermArgs a) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    // which list does this workgroup belong to?  (numLists <= OMMHIP_MAX_TERM_LISTS, wave-uniform)
+    int li = 0;
+#pragma unroll
+    for (int i = 1; i < OMMHIP_MAX_TERM_LISTS; i++)
+        if (i < a.numLists && (int) blockIdx.x >= a.list[i].firstBlock) li = i;
+    const TermList& l = a.list[li];
+    const int t = ((int) blockIdx.x - l.firstBlock) * 256 + threadIdx.x;
     double energy = 0;
-    if (t < a.numTerms) {
-        int i = a.atoms[2 * t], j = a.atoms[2 * t + 1];
-        double qq = a.params[3 * t], sig = a.params[3 * t + 1], eps4 = 4.0 * a.params[3 * t + 2];
-        double3 d = delta(a, i, j);                      // j - i
-        double invR = 1.0 / sqrt(dot3(d, d));
-        double s2 = sig * invR; s2 *= s2;
-        double s6 = s2 * s2 * s2;
-        double dEdR = (eps4 * (12.0 * s6 - 6.0) * s6 + OMM_ONE_4PI_EPS0_D * qq * invR) * invR * invR;
-        energy = eps4 * (s6 - 1.0) * s6 + OMM_ONE_4PI_EPS0_D * qq * invR;
-        add_atom_force(a, j, dEdR * d.x, dEdR * d.y, dEdR * d.z);
-        add_atom_force(a, i, -dEdR * d.x, -dEdR * d.y, -dEdR * d.z);
-    }
-    block_add_energy(a, energy);
-}
-
-__global__ __launch_bounds__(256) void k_ewald_exclusions(TermArgs a) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    double energy = 0;
-    if (t < a.numTerms) {
-        int i = a.atoms[2 * t], j = a.atoms[2 * t + 1];
-        double qq = OMM_ONE_4PI_EPS0_D * a.charge[i] * a.charge[j];
-        double3 d = delta(a, i, j);
-        double r = sqrt(dot3(d, d));
-        double ar = a.alpha * r;
-        double erfAr = erf(ar);
-        if (erfAr > 1e-6) {
-            double invR = 1.0 / r;
-            double dEdR = qq * invR * invR * invR * (erfAr - 2.0 * ar * exp(-ar * ar) * 0.56418958354775628695);
-            add_atom_force(a, j, -dEdR * d.x, -dEdR * d.y, -dEdR * d.z);
-            add_atom_force(a, i, dEdR * d.x, dEdR * d.y, dEdR * d.z);
-            energy = -qq * invR * erfAr;
+    if (t < l.numTerms) {
+        const TermCtx c(a, l);
+        switch (l.kind) {
+            case OMMHIP_TERM_EXCEPTION14: energy = term_exception14(c, t); break;
+            case OMMHIP_TERM_EWALD_EXCLUSION: energy = term_ewald_exclusion(c, t); break;
+            case OMMHIP_TERM_HARMONIC_BOND: energy = term_harmonic_bond(c, t); break;
+            case OMMHIP_TERM_HARMONIC_ANGLE: energy = term_harmonic_angle(c, t); break;
+            default: energy = term_periodic_torsion(c, t); break;
         }
-        else
-            energy = -a.alpha * 1.12837916709551257390 * qq;
     }
-    block_add_energy(a, energy);
-}
-
-__global__ __launch_bounds__(256) void k_harmonic_bonds(TermArgs a) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    double energy = 0;
-    if (t < a.numTerms) {
-        int i = a.atoms[2 * t], j = a.atoms[2 * t + 1];
-        double r0 = a.params[2 * t], k = a.params[2 * t + 1];
-        double3 d = delta(a, i, j);
-        double r = sqrt(dot3(d, d));
-        double dl = r - r0;
-        double dEdR = r > 0.0 ? k * dl / r : 0.0;
-        energy = 0.5 * k * dl * dl;
-        add_atom_force(a, i, dEdR * d.x, dEdR * d.y, dEdR * d.z);
-        add_atom_force(a, j, -dEdR * d.x, -dEdR * d.y, -dEdR * d.z);
+    if (a.includeEnergy) {
+        energy = wave_sum(energy);
+        if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = energy;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], partial[0] + partial[1] + partial[2] + partial[3]);
     }
-    block_add_energy(a, energy);
-}
-
-__global__ __launch_bounds__(256) void k_harmonic_angles(TermArgs a) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    double energy = 0;
-    if (t < a.numTerms) {
-        int ia = a.atoms[3 * t], ib = a.atoms[3 * t + 1], ic = a.atoms[3 * t + 2];
-        double theta0 = a.params[2 * t], k = a.params[2 * t + 1];
-        double3 d0 = delta(a, ia, ib);      // b - a
-        double3 d1 = delta(a, ic, ib);      // b - c
-        double3 p = cross3(d0, d1);
-        double rp = sqrt(dot3(p, p));
-        if (rp < 1.0e-06) rp = 1.0e-06;
-        double r20 = dot3(d0, d0), r21 = dot3(d1, d1);
-        double cosine = dot3(d0, d1) / sqrt(r20 * r21);
-        double angle = cosine >= 1.0 ? 0.0 : (cosine <= -1.0 ? 3.14159265358979323846 : acos(cosine));
-        double dth = angle - theta0;
-        double dEdR = k * dth;
-        energy = 0.5 * k * dth * dth;
-        double termA = dEdR / (r20 * rp), termC = -dEdR / (r21 * rp);
-        double3 fa = cross3(d0, p), fc = cross3(d1, p);
-        fa.x *= termA; fa.y *= termA; fa.z *= termA;
-        fc.x *= termC; fc.y *= termC; fc.z *= termC;
-        add_atom_force(a, ia, fa.x, fa.y, fa.z);
-        add_atom_force(a, ic, fc.x, fc.y, fc.z);
-        add_atom_force(a, ib, -(fa.x + fc.x), -(fa.y + fc.y), -(fa.z + fc.z));
-    }
-    block_add_energy(a, energy);
-}
-
-__global__ __launch_bounds__(256) void k_periodic_torsions(TermArgs a) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    double energy = 0;
-    if (t < a.numTerms) {
-        int ia = a.atoms[4 * t], ib = a.atoms[4 * t + 1], ic = a.atoms[4 * t + 2], id = a.atoms[4 * t + 3];
-        double k = a.params[3 * t], phase = a.params[3 * t + 1], periodicity = a.params[3 * t + 2];
-        double3 v0 = delta(a, ib, ia);      // a - b
-        double3 v1 = delta(a, ib, ic);      // c - b
-        double3 v2 = delta(a, id, ic);      // c - d
-        double3 cp0 = cross3(v0, v1), cp1 = cross3(v1, v2);
-        // angle between the two plane normals, asin branch near 0/pi (ReferenceBondIxn.cpp:115-135)
-        double n0 = dot3(cp0, cp0), n1 = dot3(cp1, cp1);
-        double dp = dot3(cp0, cp1) / sqrt(n0 * n1);
-        dp = dp > 1.0 ? 1.0 : (dp < -1.0 ? -1.0 : dp);
-        double angle;
-        if (dp > 0.99 || dp < -0.99) {
-            double3 c = cross3(cp0, cp1);
-            angle = asin(sqrt(dot3(c, c) / (n0 * n1)));
-            if (dp < 0.0) angle = 3.14159265358979323846 - angle;
-        }
-        else
-            angle = acos(dp);
-        if (dot3(v0, cp1) < 0.0) angle = -angle;
-        double deltaAngle = periodicity * angle - phase;
-        double dEdAngle = -k * periodicity * sin(deltaAngle);
-        energy = k * (1.0 + cos(deltaAngle));
-        double normBC = sqrt(dot3(v1, v1));
-        double ff0 = (-dEdAngle * normBC) / n0;
-        double ff3 = (dEdAngle * normBC) / n1;
-        double ff1 = dot3(v0, v1) / dot3(v1, v1);
-        double ff2 = dot3(v2, v1) / dot3(v1, v1);
-        double3 f0 = make_double3(ff0 * cp0.x, ff0 * cp0.y, ff0 * cp0.z);
-        double3 f3 = make_double3(ff3 * cp1.x, ff3 * cp1.y, ff3 * cp1.z);
-        double3 s = make_double3(ff1 * f0.x - ff2 * f3.x, ff1 * f0.y - ff2 * f3.y, ff1 * f0.z - ff2 * f3.z);
-        add_atom_force(a, ia, f0.x, f0.y, f0.z);
-        add_atom_force(a, ib, -(f0.x - s.x), -(f0.y - s.y), -(f0.z - s.z));
-        add_atom_force(a, ic, -(f3.x + s.x), -(f3.y + s.y), -(f3.z + s.z));
-        add_atom_force(a, id, f3.x, f3.y, f3.z);
-    }
-    block_add_energy(a, energy);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -263,12 +269,14 @@ __global__ __launch_bounds__(256) void k_ewald_forces(EwaldArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// CMMotionRemover: momentum reduction (one workgroup) then subtraction.
+// CMMotionRemover: two-stage momentum reduction, then subtraction.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cm_momentum(const double4* __restrict__ vel, int numAtoms, double* __restrict__ out) {
+#define CM_BLOCKS 64
+// Stage 1: CM_BLOCKS workgroups each reduce a strided slice of the atoms to (px, py, pz, mass).
+__global__ __launch_bounds__(256) void k_cm_momentum(const double4* __restrict__ vel, int numAtoms, double* __restrict__ partial) {
     __shared__ double part[4][4];
     double px = 0, py = 0, pz = 0, m = 0;
-    for (int i = threadIdx.x; i < numAtoms; i += 256) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < numAtoms; i += 256 * CM_BLOCKS) {
         double4 v = vel[i];
         double mass = v.w == 0.0 ? 0.0 : 1.0 / v.w;
         px += mass * v.x; py += mass * v.y; pz += mass * v.z; m += mass;
@@ -276,10 +284,18 @@ __global__ __launch_bounds__(256) void k_cm_momentum(const double4* __restrict__
     px = wave_sum(px); py = wave_sum(py); pz = wave_sum(pz); m = wave_sum(m);
     if ((threadIdx.x & 63) == 0) { int w = threadIdx.x >> 6; part[w][0] = px; part[w][1] = py; part[w][2] = pz; part[w][3] = m; }
     __syncthreads();
-    if (threadIdx.x < 4) out[threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    if (threadIdx.x < 4) partial[4 * blockIdx.x + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
-__global__ void k_cm_subtract(double4* __restrict__ vel, int numAtoms, const double* __restrict__ mom) {
+// Stage 2: every workgroup re-reduces the CM_BLOCKS partials (256 doubles) and subtracts the CM velocity.
+__global__ __launch_bounds__(256) void k_cm_subtract(double4* __restrict__ vel, int numAtoms, const double* __restrict__ partial) {
+    __shared__ double mom[4];
+    if (threadIdx.x < 4) {
+        double s = 0;
+        for (int b = 0; b < CM_BLOCKS; b++) s += partial[4 * b + threadIdx.x];
+        mom[threadIdx.x] = s;
+    }
+    __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= numAtoms) return;
     double4 v = vel[i];
@@ -289,35 +305,36 @@ __global__ void k_cm_subtract(double4* __restrict__ vel, int numAtoms, const dou
     vel[i] = v;
 }
 
-TermArgs make_term_args(const ommhip_term_list* t, const void* pos_d, const int* slot_of_atom_d, int padded_atoms, const double* box, int periodic,
-                        long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy) {
-    TermArgs a;
-    a.numTerms = t->num_terms; a.paddedAtoms = padded_atoms; a.periodic = periodic; a.includeEnergy = include_energy; a.energySlots = energy_slots;
-    a.box.ax = box[0]; a.box.bx = box[1]; a.box.by = box[2]; a.box.cx = box[3]; a.box.cy = box[4]; a.box.cz = box[5];
-    a.alpha = 0; a.pos = (const double4*) pos_d; a.slotOfAtom = slot_of_atom_d;
-    a.atoms = t->atoms; a.params = t->params; a.charge = nullptr; a.force = force_d; a.energyBuffer = energy_buffer_d;
-    return a;
-}
-
 }  // namespace
+
+extern "C" int ommhip_term_forces_multi(int num_lists, const ommhip_term_batch* lists, const void* pos_d, const int* slot_of_atom_d, int padded_atoms,
+                                        const double box[6], long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
+    if (num_lists > OMMHIP_MAX_TERM_LISTS) return 1;
+    TermArgs a;
+    a.numLists = 0; a.paddedAtoms = padded_atoms; a.includeEnergy = include_energy; a.energySlots = energy_slots;
+    a.box.ax = box[0]; a.box.bx = box[1]; a.box.by = box[2]; a.box.cx = box[3]; a.box.cy = box[4]; a.box.cz = box[5];
+    a.pos = (const double4*) pos_d; a.slotOfAtom = slot_of_atom_d; a.force = force_d; a.energyBuffer = energy_buffer_d;
+    int blocks = 0;
+    for (int i = 0; i < num_lists; i++) {
+        if (lists[i].terms.num_terms <= 0) continue;
+        if (lists[i].kind < OMMHIP_TERM_EXCEPTION14 || lists[i].kind > OMMHIP_TERM_PERIODIC_TORSION) return 1;
+        TermList& l = a.list[a.numLists++];
+        l.kind = lists[i].kind; l.numTerms = lists[i].terms.num_terms; l.periodic = lists[i].periodic; l.firstBlock = blocks;
+        l.alpha = lists[i].alpha; l.atoms = lists[i].terms.atoms; l.params = lists[i].terms.params; l.charge = lists[i].charge;
+        blocks += (l.numTerms + 255) / 256;
+    }
+    if (blocks == 0) return 0;
+    for (int i = a.numLists; i < OMMHIP_MAX_TERM_LISTS; i++) { a.list[i] = a.list[0]; a.list[i].numTerms = 0; a.list[i].firstBlock = blocks; }
+    hipLaunchKernelGGL(k_terms, dim3(blocks), dim3(256), 0, (hipStream_t) stream, a);
+    return (int) hipGetLastError();
+}
 
 extern "C" int ommhip_term_forces(int kind, const ommhip_term_list* terms, const void* pos_d, const int* slot_of_atom_d, int padded_atoms,
                                   const double box[6], int periodic, const double* charge_d, double alpha,
                                   long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
-    if (terms->num_terms <= 0) return 0;
-    TermArgs a = make_term_args(terms, pos_d, slot_of_atom_d, padded_atoms, box, periodic, force_d, energy_buffer_d, energy_slots, include_energy);
-    a.charge = charge_d; a.alpha = alpha;
-    dim3 grid((terms->num_terms + 255) / 256), block(256);
-    hipStream_t st = (hipStream_t) stream;
-    switch (kind) {
-        case OMMHIP_TERM_EXCEPTION14: hipLaunchKernelGGL(k_exceptions14, grid, block, 0, st, a); break;
-        case OMMHIP_TERM_EWALD_EXCLUSION: hipLaunchKernelGGL(k_ewald_exclusions, grid, block, 0, st, a); break;
-        case OMMHIP_TERM_HARMONIC_BOND: hipLaunchKernelGGL(k_harmonic_bonds, grid, block, 0, st, a); break;
-        case OMMHIP_TERM_HARMONIC_ANGLE: hipLaunchKernelGGL(k_harmonic_angles, grid, block, 0, st, a); break;
-        case OMMHIP_TERM_PERIODIC_TORSION: hipLaunchKernelGGL(k_periodic_torsions, grid, block, 0, st, a); break;
-        default: return 1;
-    }
-    return (int) hipGetLastError();
+    ommhip_term_batch b;
+    b.kind = kind; b.terms = *terms; b.periodic = periodic; b.charge = charge_d; b.alpha = alpha;
+    return ommhip_term_forces_multi(1, &b, pos_d, slot_of_atom_d, padded_atoms, box, force_d, energy_buffer_d, energy_slots, include_energy, stream);
 }
 
 extern "C" int ommhip_ewald_reciprocal(const void* pos_d, const double* charge_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms,
@@ -338,9 +355,10 @@ extern "C" int ommhip_ewald_reciprocal(const void* pos_d, const double* charge_d
     return (int) hipGetLastError();
 }
 
-extern "C" int ommhip_remove_cm_motion(void* vel_d, int num_atoms, double* scratch4_d, void* stream) {
+extern "C" int ommhip_remove_cm_motion(void* vel_d, int num_atoms, double* scratch_d, void* stream) {
+    // scratch_d must hold 4*64 doubles
     hipStream_t st = (hipStream_t) stream;
-    hipLaunchKernelGGL(k_cm_momentum, dim3(1), dim3(256), 0, st, (const double4*) vel_d, num_atoms, scratch4_d);
-    hipLaunchKernelGGL(k_cm_subtract, dim3((num_atoms + 255) / 256), dim3(256), 0, st, (double4*) vel_d, num_atoms, (const double*) scratch4_d);
+    hipLaunchKernelGGL(k_cm_momentum, dim3(CM_BLOCKS), dim3(256), 0, st, (const double4*) vel_d, num_atoms, scratch_d);
+    hipLaunchKernelGGL(k_cm_subtract, dim3((num_atoms + 255) / 256), dim3(256), 0, st, (double4*) vel_d, num_atoms, (const double*) scratch_d);
     return (int) hipGetLastError();
 }

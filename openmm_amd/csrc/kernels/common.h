@@ -13,7 +13,7 @@
 
 #define OMM_TILE 32            // atoms per i-block
 #define OMM_ROW 64             // j-atoms per neighbour-list row (= one wavefront)
-#define OMM_CHUNK_ROWS 4       // rows per work chunk (all rows of a chunk share one i-block)
+#define OMM_CHUNK_ROWS 2       // rows per work chunk (all rows of a chunk share one i-block)
 #define OMM_FORCE_SCALE 4294967296.0   // 2^32
 
 // 1/(4 pi eps0) in kJ nm/(mol e^2) from the CODATA-2018 constants of platforms/reference/include/SimTKOpenMMRealType.h:74-89
@@ -105,6 +105,21 @@ __device__ __forceinline__ void min_image(float& dx, float& dy, float& dz, const
         dy -= rintf(dy * b.invBy) * b.by;
         dz -= rintf(dz * b.invCz) * b.cz;
     }
+}
+
+// words of the neighbour-list state array (ommhip_neighbor_list::state)
+//   REBUILD      request flag: set by the displacement check or by the host, cleared by the last builder workgroup
+//   NUM_CHUNKS   chunks of the current list (published by the last builder workgroup; read by the pair kernel)
+//   OVERFLOW     sticky: a rebuild needed more chunks than allocated (host grows the arrays and clears it)
+//   ALLOC        working allocation counter of a rebuild in flight (zero at rest)
+enum { ST_REBUILD = 0, ST_NUM_CHUNKS = 1, ST_OVERFLOW = 2, ST_BLOCKS_DONE = 3, ST_REBUILD_COUNT = 4, ST_ALLOC = 5 };
+
+inline Box make_box(const double* bv) {
+    // bv = {ax, bx, by, cx, cy, cz}
+    Box b;
+    b.ax = (float) bv[0]; b.bx = (float) bv[1]; b.by = (float) bv[2]; b.cx = (float) bv[3]; b.cy = (float) bv[4]; b.cz = (float) bv[5];
+    b.invAx = (float) (1.0 / bv[0]); b.invBy = (float) (1.0 / bv[2]); b.invCz = (float) (1.0 / bv[5]);
+    return b;
 }
 
 __device__ __forceinline__ void min_image_d(double& dx, double& dy, double& dz, const BoxD& b) {

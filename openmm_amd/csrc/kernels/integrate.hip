@@ -198,9 +198,7 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.
 __device__ __forceinline__ V3 xyz(double4 p) { return v3(p.x, p.y, p.z); }
 
 // Same algebra as ReferenceSETTLEAlgorithm.cpp:54-195, written with vectors.
-__global__ void k_settle_positions(SettleArgs a) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.numClusters) return;
+__device__ __forceinline__ void settle_positions_cluster(const SettleArgs& a, int c) {
     const int4 at = a.atoms[c];
     const double2 dd = a.dist[c];
     const V3 p0 = xyz(a.pos[at.x]), p1 = xyz(a.pos[at.y]), p2 = xyz(a.pos[at.z]);
@@ -262,9 +260,7 @@ __global__ void k_settle_positions(SettleArgs a) {
 }
 
 // ReferenceSETTLEAlgorithm.cpp:197-244 (unequal-mass velocity solve)
-__global__ void k_settle_velocities(SettleArgs a) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.numClusters) return;
+__device__ __forceinline__ void settle_velocities_cluster(const SettleArgs& a, int c) {
     const int4 at = a.atoms[c];
     const V3 p0 = xyz(a.pos[at.x]), p1 = xyz(a.pos[at.y]), p2 = xyz(a.pos[at.z]);
     double4 w0 = a.vel[at.x], w1 = a.vel[at.y], w2 = a.vel[at.z];
@@ -307,9 +303,7 @@ struct ShakeArgs {
 };
 
 template <bool VELOCITIES>
-__global__ void k_shake(ShakeArgs a) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.numClusters) return;
+__device__ __forceinline__ void shake_cluster(const ShakeArgs& a, int c) {
     const int4 at = a.atoms[c];
     const double4 dd = a.dist[c];
     const int sat[3] = {at.y, at.z, at.w};
@@ -360,6 +354,22 @@ __global__ void k_shake(ShakeArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; k++)
         if (k < n) a.target[sat[k]] = make_double4(t[k].x, t[k].y, t[k].z, tw[k]);
+}
+
+// One launch for both cluster kinds: workgroups [0, shakeBlocks) iterate SHAKE clusters, the rest SETTLE waters.
+template <bool VELOCITIES>
+__global__ __launch_bounds__(128) void k_constrain_clusters(ShakeArgs sh, SettleArgs se, int shakeBlocks) {
+    if ((int) blockIdx.x < shakeBlocks) {
+        const int c = blockIdx.x * 128 + threadIdx.x;
+        if (c < sh.numClusters) shake_cluster<VELOCITIES>(sh, c);
+    }
+    else {
+        const int c = ((int) blockIdx.x - shakeBlocks) * 128 + threadIdx.x;
+        if (c < se.numClusters) {
+            if (VELOCITIES) settle_velocities_cluster(se, c);
+            else settle_positions_cluster(se, c);
+        }
+    }
 }
 
 // ================================================================================================
@@ -467,24 +477,29 @@ extern "C" int ommhip_kinetic_energy(const void* vel_d, int num_atoms, double* r
 
 extern "C" int ommhip_settle(int num_clusters, const int* atoms_d, const double* dist_d, const void* pos_d, void* target_d,
                              const void* vel_mass_d, int velocities, void* stream) {
-    if (num_clusters <= 0) return 0;
-    SettleArgs a;
-    a.numClusters = num_clusters; a.atoms = (const int4*) atoms_d; a.dist = (const double2*) dist_d;
-    a.pos = (const double4*) pos_d; a.xp = (double4*) target_d; a.vel = (double4*) target_d; a.velMass = (const double4*) vel_mass_d;
-    if (velocities) hipLaunchKernelGGL(k_settle_velocities, grid_for(num_clusters), BLOCK128, 0, (hipStream_t) stream, a);
-    else hipLaunchKernelGGL(k_settle_positions, grid_for(num_clusters), BLOCK128, 0, (hipStream_t) stream, a);
-    return (int) hipGetLastError();
+    return ommhip_constrain_clusters(0, nullptr, nullptr, num_clusters, atoms_d, dist_d, pos_d, target_d, vel_mass_d, velocities, 0.0, 0, stream);
 }
 
 extern "C" int ommhip_shake(int num_clusters, const int* atoms_d, const double* dist_d, const void* pos_d, void* target_d,
                             const void* vel_mass_d, int velocities, double tol, int max_iterations, void* stream) {
-    if (num_clusters <= 0) return 0;
-    ShakeArgs a;
-    a.numClusters = num_clusters; a.maxIterations = max_iterations; a.tol = tol;
-    a.atoms = (const int4*) atoms_d; a.dist = (const double4*) dist_d; a.pos = (const double4*) pos_d;
-    a.target = (double4*) target_d; a.velMass = (const double4*) vel_mass_d;
-    if (velocities) hipLaunchKernelGGL(k_shake<true>, grid_for(num_clusters), BLOCK128, 0, (hipStream_t) stream, a);
-    else hipLaunchKernelGGL(k_shake<false>, grid_for(num_clusters), BLOCK128, 0, (hipStream_t) stream, a);
+    return ommhip_constrain_clusters(num_clusters, atoms_d, dist_d, 0, nullptr, nullptr, pos_d, target_d, vel_mass_d, velocities, tol, max_iterations, stream);
+}
+
+extern "C" int ommhip_constrain_clusters(int num_shake, const int* shake_atoms_d, const double* shake_dist_d,
+                                         int num_settle, const int* settle_atoms_d, const double* settle_dist_d,
+                                         const void* pos_d, void* target_d, const void* vel_mass_d, int velocities,
+                                         double tol, int max_iterations, void* stream) {
+    if (num_shake <= 0 && num_settle <= 0) return 0;
+    ShakeArgs sh;
+    sh.numClusters = num_shake > 0 ? num_shake : 0; sh.maxIterations = max_iterations; sh.tol = tol;
+    sh.atoms = (const int4*) shake_atoms_d; sh.dist = (const double4*) shake_dist_d; sh.pos = (const double4*) pos_d;
+    sh.target = (double4*) target_d; sh.velMass = (const double4*) vel_mass_d;
+    SettleArgs se;
+    se.numClusters = num_settle > 0 ? num_settle : 0; se.atoms = (const int4*) settle_atoms_d; se.dist = (const double2*) settle_dist_d;
+    se.pos = (const double4*) pos_d; se.xp = (double4*) target_d; se.vel = (double4*) target_d; se.velMass = (const double4*) vel_mass_d;
+    const int shakeBlocks = (sh.numClusters + 127) / 128, settleBlocks = (se.numClusters + 127) / 128;
+    if (velocities) hipLaunchKernelGGL(k_constrain_clusters<true>, dim3(shakeBlocks + settleBlocks), BLOCK128, 0, (hipStream_t) stream, sh, se, shakeBlocks);
+    else hipLaunchKernelGGL(k_constrain_clusters<false>, dim3(shakeBlocks + settleBlocks), BLOCK128, 0, (hipStream_t) stream, sh, se, shakeBlocks);
     return (int) hipGetLastError();
 }
 

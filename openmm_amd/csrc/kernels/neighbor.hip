@@ -1,0 +1,381 @@
+// Neighbour-list construction for the direct-space kernel (MI355X / gfx950, wave64).
+//
+// Replaces (behaviourally) computeNeighborListVoxelHash -- platforms/reference/src/SimTKReference/ReferenceNeighborList.cpp:221-259 --
+// which the Reference platform runs on every force evaluation.  Here the list is built with a padding and only
+// rebuilt when an atom has moved more than padding/2, and the decision is taken ON THE DEVICE: the three kernels of
+// ommhip_nl_update() are enqueued every step and return immediately unless state[ST_REBUILD] is set, so the step
+// loop has no host round trip.
+//
+// Output format (consumed by nonbonded.hip): ROWS of 64 individually selected j-atoms for one 32-atom i-block X,
+// each entry = j slot + a 32-bit mask of the i-atoms that interact with it (diagonal half, exclusions and padding
+// atoms are folded into the mask); rows are grouped in CHUNKS of up to 4 rows of the same X.
+//
+// One workgroup of 4 wavefronts builds all rows of one i-block:
+//   phase 1  block-level test, 64 candidate blocks per wave-instruction, survivors appended to an LDS list;
+//   phase 2  atom-level test, two candidate blocks (64 atoms) per wavefront pass, four passes in flight; the
+//            32 atoms of X are broadcast from registers with v_readlane (no LDS or memory traffic in the loop);
+//            survivors (j, mask) are appended to an LDS list with one LDS atomic per wavefront;
+//   flush    the LDS list is cut into 64-entry rows and written out; chunk indices come from one global atomic.
+#include "common.h"
+#include "../../../include/openmm_hip_kernels.h"
+
+using namespace omm;
+
+namespace {
+
+#define NL_THREADS 256
+#define NL_WAVES 4
+#define NL_LIST 4096          // staged (j, mask) entries
+#define NL_FLUSH 2048         // flush full rows once this many entries are staged
+#define NL_CAND 2048          // candidate blocks per window
+
+struct NlArgs {
+    int numAtoms, paddedAtoms, numBlocks, maxChunks;
+    int pbc;                 // 0 none, 1 orthorhombic, 2 triclinic
+    float listCutoff2;       // (cutoff + padding)^2, +inf for NoCutoff
+    float maxDisp2;          // (padding/2)^2
+    Box box;
+    const float4* posq;
+    float4* posqRef;
+    const int* atomOfSlot;
+    const int* slotOfAtom;
+    const int* exclStart;
+    const int* exclAtoms;
+    const int2* exclBlockRange;   // per i-block: [lowest, highest] block holding an exclusion partner of its atoms (or null)
+    int* state;
+    float4* blockCenter;
+    float4* blockHalf;
+    int2* chunkInfo;
+    int* rowJ;
+    unsigned* rowMask;
+};
+
+template <int PBC>
+__device__ __forceinline__ void apply_pbc(float& dx, float& dy, float& dz, const Box& b) {
+    if (PBC == 1) min_image<false>(dx, dy, dz, b);
+    if (PBC == 2) min_image<true>(dx, dy, dz, b);
+}
+__device__ __forceinline__ void apply_pbc_rt(int pbc, float& dx, float& dy, float& dz, const Box& b) {
+    if (pbc == 1) min_image<false>(dx, dy, dz, b);
+    else if (pbc == 2) min_image<true>(dx, dy, dz, b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-step: did any atom move more than padding/2 since the list was built?  (one thread per slot)
+// ------------------------------------------------------------------------------------------------
+__global__ void nl_check_displacement(NlArgs a) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    bool moved = false;
+    if (s < a.paddedAtoms && a.atomOfSlot[s] >= 0) {
+        float4 p = a.posq[s], r = a.posqRef[s];
+        float dx = p.x - r.x, dy = p.y - r.y, dz = p.z - r.z;
+        apply_pbc_rt(a.pbc, dx, dy, dz, a.box);
+        moved = !(dx * dx + dy * dy + dz * dz <= a.maxDisp2);   // NaN counts as moved
+    }
+    if (__any(moved) && lane_id() == 0) atomicOr(&a.state[ST_REBUILD], 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bounding boxes of the 32-atom blocks (two blocks per wavefront); also snapshots posq -> posqRef.
+// ------------------------------------------------------------------------------------------------
+__global__ void nl_block_bounds(NlArgs a) {
+    if (a.state[ST_REBUILD] == 0) return;
+    int s = blockIdx.x * blockDim.x + threadIdx.x;     // slot
+    bool inRange = s < a.paddedAtoms;
+    int sl = inRange ? s : a.paddedAtoms - 1;
+    float4 p = a.posq[sl];
+    bool valid = inRange && a.atomOfSlot[sl] >= 0;
+    // first atom of the block (always valid: every block holds at least one real atom)
+    float4 p0 = make_float4(__shfl(p.x, 0, 32), __shfl(p.y, 0, 32), __shfl(p.z, 0, 32), 0.f);
+    float dx = p.x - p0.x, dy = p.y - p0.y, dz = p.z - p0.z;
+    apply_pbc_rt(a.pbc, dx, dy, dz, a.box);
+    if (!valid) { dx = dy = dz = 0; }
+    float minx = dx, maxx = dx, miny = dy, maxy = dy, minz = dz, maxz = dz;
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+        minx = fminf(minx, __shfl_xor(minx, m)); maxx = fmaxf(maxx, __shfl_xor(maxx, m));
+        miny = fminf(miny, __shfl_xor(miny, m)); maxy = fmaxf(maxy, __shfl_xor(maxy, m));
+        minz = fminf(minz, __shfl_xor(minz, m)); maxz = fmaxf(maxz, __shfl_xor(maxz, m));
+    }
+    if (inRange && (s & 31) == 0) {
+        int blk = s >> 5;
+        a.blockCenter[blk] = make_float4(p0.x + 0.5f * (minx + maxx), p0.y + 0.5f * (miny + maxy), p0.z + 0.5f * (minz + maxz), 0.f);
+        a.blockHalf[blk] = make_float4(0.5f * (maxx - minx), 0.5f * (maxy - miny), 0.5f * (maxz - minz), 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rows of i-block X = blockIdx.x.
+// ------------------------------------------------------------------------------------------------
+template <int PBC>
+__global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
+    if (a.state[ST_REBUILD] == 0) return;
+    __shared__ int listJ[NL_LIST];
+    __shared__ unsigned listM[NL_LIST];
+    __shared__ int candY[NL_CAND];
+    __shared__ int rowMasked[NL_LIST / OMM_ROW];
+    __shared__ int sCandCount, sListCount, sChunkBase;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int X = blockIdx.x;
+    const float R2 = a.listCutoff2;
+    const float Rlist = sqrtf(R2);
+
+    // atom (lane & 31) of X in every lane; broadcast later with v_readlane
+    const float4 px = a.posq[X * OMM_TILE + (lane & 31)];
+    if (t < OMM_TILE) a.posqRef[X * OMM_TILE + t] = px;          // reference positions of the displacement check
+    const bool iValid = lane < OMM_TILE && a.atomOfSlot[X * OMM_TILE + lane] >= 0;
+    const unsigned iValidMask = (unsigned) __ballot(iValid);
+    const float4 cX = a.blockCenter[X], hX = a.blockHalf[X];
+    const int2 exclRange = a.exclBlockRange != nullptr ? a.exclBlockRange[X] : make_int2(0, a.numBlocks);
+    if (t == 0) { sCandCount = 0; sListCount = 0; sChunkBase = 0; }
+    __syncthreads();
+
+    // Writes staged entries as rows.  final = false: only full rows, the remainder stays staged.
+    auto flush = [&](bool final) {
+        const int total = sListCount;
+        const int nRows = final ? (total + OMM_ROW - 1) / OMM_ROW : total / OMM_ROW;
+        const int nChunks = (nRows + OMM_CHUNK_ROWS - 1) / OMM_CHUNK_ROWS;
+        if (nRows > 0) {
+            if (t == 0) sChunkBase = atomicAdd(&a.state[ST_ALLOC], nChunks);
+            __syncthreads();
+            const int chunkBase = sChunkBase;
+            for (int r = wave; r < nRows; r += NL_WAVES) {
+                const int e = r * OMM_ROW + lane;
+                const bool valid = e < total;
+                const int j = valid ? listJ[e] : X * OMM_TILE;
+                const unsigned m = valid ? listM[e] : 0u;
+                const bool masked = __any(m != 0xFFFFFFFFu);
+                const int chunk = chunkBase + r / OMM_CHUNK_ROWS;
+                if (chunk < a.maxChunks) {
+                    const size_t o = ((size_t) chunk * OMM_CHUNK_ROWS + (r % OMM_CHUNK_ROWS)) * OMM_ROW + lane;
+                    a.rowJ[o] = j;
+                    a.rowMask[o] = m;
+                }
+                else if (lane == 0) atomicOr(&a.state[ST_OVERFLOW], 1);
+                if (lane == 0) rowMasked[r] = masked ? 1 : 0;
+            }
+            __syncthreads();
+            for (int c = t; c < nChunks; c += NL_THREADS) {
+                const int rowsIn = min(OMM_CHUNK_ROWS, nRows - OMM_CHUNK_ROWS * c);
+                int bits = 0;
+                for (int i = 0; i < rowsIn; i++) bits |= rowMasked[OMM_CHUNK_ROWS * c + i] << i;
+                if (chunkBase + c < a.maxChunks) a.chunkInfo[chunkBase + c] = make_int2(X, rowsIn | (bits << 8));
+            }
+        }
+        // keep the partial row staged
+        const int rem = final ? 0 : total - nRows * OMM_ROW;
+        int tj = 0; unsigned tm = 0;
+        if (t < rem) { tj = listJ[nRows * OMM_ROW + t]; tm = listM[nRows * OMM_ROW + t]; }
+        __syncthreads();
+        if (t < rem) { listJ[t] = tj; listM[t] = tm; }
+        if (t == 0) sListCount = rem;
+        __syncthreads();
+    };
+
+    for (int window = X; window < a.numBlocks; window += NL_CAND) {
+        const int windowEnd = min(a.numBlocks, window + NL_CAND);
+        // ---- phase 1: block-level test
+        for (int yb = window + wave * 64; yb < windowEnd; yb += NL_THREADS) {
+            const int Y = yb + lane;
+            bool cand = false;
+            if (Y < windowEnd) {
+                const float4 cY = a.blockCenter[Y], hY = a.blockHalf[Y];
+                float dx = cY.x - cX.x, dy = cY.y - cX.y, dz = cY.z - cX.z;
+                apply_pbc<PBC>(dx, dy, dz, a.box);
+                dx = fmaxf(0.f, fabsf(dx) - hX.x - hY.x);
+                dy = fmaxf(0.f, fabsf(dy) - hX.y - hY.y);
+                dz = fmaxf(0.f, fabsf(dz) - hX.z - hY.z);
+                cand = !(dx * dx + dy * dy + dz * dz >= R2);
+                // Triclinic: the sequential image reduction only finds the nearest copy when it is less than half a
+                // box width away; if that cannot be guaranteed, defer to the exact per-atom test.
+                if (PBC == 2 && (0.5f * a.box.cz - hX.z - hY.z < Rlist || 0.5f * a.box.by - hX.y - hY.y < Rlist)) cand = true;
+            }
+            const unsigned long long cm = __ballot(cand);
+            if (cm != 0) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&sCandCount, __popcll(cm));
+                base = __shfl(base, 0);
+                if (cand) candY[base + lane_prefix_count(cm)] = Y;
+            }
+        }
+        __syncthreads();
+        const int numCand = sCandCount;
+        const int numPasses = (numCand + 1) / 2;
+        // ---- phase 2: atom-level test, one pass = two candidate blocks = 64 atoms per wavefront
+        for (int p0 = 0; p0 < numPasses; p0 += NL_WAVES) {
+            const int pass = p0 + wave;
+            if (pass < numPasses) {
+                const int ci = 2 * pass + (lane >> 5);
+                bool ok = ci < numCand;
+                const int Yc = ok ? candY[ci] : X;
+                const int lj = lane & 31;
+                const int j = Yc * OMM_TILE + lj;
+                const int atomJ = ok ? a.atomOfSlot[j] : -1;
+                ok = ok && atomJ >= 0;
+                const float4 pj = a.posq[j];
+                // distance to X's bounding box
+                float dx = pj.x - cX.x, dy = pj.y - cX.y, dz = pj.z - cX.z;
+                apply_pbc<PBC>(dx, dy, dz, a.box);
+                const float bx = fmaxf(0.f, fabsf(dx) - hX.x), by = fmaxf(0.f, fabsf(dy) - hX.y), bz = fmaxf(0.f, fabsf(dz) - hX.z);
+                bool near = !(bx * bx + by * by + bz * bz >= R2);
+                if (PBC == 2 && (0.5f * a.box.cz - hX.z < Rlist || 0.5f * a.box.by - hX.y < Rlist)) near = true;
+                // exact test against the 32 atoms of X (same metric as the pair kernel); executed by every lane so
+                // that the v_readlane broadcasts sit in convergent code
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < OMM_TILE; k++) {
+                    const float xi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px.x), k));
+                    const float yi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px.y), k));
+                    const float zi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px.z), k));
+                    float ex = pj.x - xi, ey = pj.y - yi, ez = pj.z - zi;
+                    apply_pbc<PBC>(ex, ey, ez, a.box);
+                    any = any || !(ex * ex + ey * ey + ez * ez >= R2);
+                }
+                unsigned mask = 0;
+                if (ok && near && any) {
+                    mask = iValidMask;
+                    if (Yc == X) mask &= (1u << lj) - 1u;        // diagonal block: each pair once, no self pair
+                    // Only blocks inside X's exclusion-partner range can hold an excluded partner.
+                    if (Yc >= exclRange.x && Yc <= exclRange.y)
+                        for (int e = a.exclStart[atomJ]; e < a.exclStart[atomJ + 1]; e++) {
+                            const int s = a.slotOfAtom[a.exclAtoms[e]];
+                            if ((s >> 5) == X) mask &= ~(1u << (s & 31));
+                        }
+                }
+                const bool passes = mask != 0;
+                const unsigned long long pm = __ballot(passes);
+                if (pm != 0) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&sListCount, __popcll(pm));
+                    base = __shfl(base, 0);
+                    if (passes) {
+                        const int pos = base + lane_prefix_count(pm);
+                        listJ[pos] = j;
+                        listM[pos] = mask;
+                    }
+                }
+            }
+            __syncthreads();
+            if (sListCount >= NL_FLUSH) flush(false);
+        }
+        __syncthreads();
+        if (t == 0) sCandCount = 0;
+        __syncthreads();
+    }
+    flush(true);
+
+    // Last workgroup out clears the rebuild request.
+    if (t == 0) {
+        __threadfence();
+        const int done = atomicAdd(&a.state[ST_BLOCKS_DONE], 1);
+        if (done == (int) gridDim.x - 1) {
+            // publish the list length, return the working counter to zero, clear the request
+            a.state[ST_NUM_CHUNKS] = atomicExch(&a.state[ST_ALLOC], 0);
+            a.state[ST_BLOCKS_DONE] = 0;
+            a.state[ST_REBUILD] = 0;
+            atomicAdd(&a.state[ST_REBUILD_COUNT], 1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused per-step front end (one launch instead of three): double positions -> wrapped float posq,
+// displacement check against posqRef, and the block bounding boxes (recomputed every step; they are
+// only consumed when a rebuild follows, and recomputing them costs less than a conditional launch).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __restrict__ pos, const int4* __restrict__ wrap, BoxD boxd,
+                                                  float4* __restrict__ posqOut, int checkDisplacement) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;      // slot; the grid covers paddedAtoms exactly (multiple of 32)
+    const bool inRange = s < a.paddedAtoms;
+    const int sl = inRange ? s : a.paddedAtoms - 1;
+    const int atom = a.atomOfSlot[sl];
+    const bool valid = inRange && atom >= 0;
+    float4 p = posqOut[sl];
+    if (valid) {
+        const double4 x = pos[atom];
+        const int4 w = wrap[atom];
+        p.x = (float) (x.x - (w.x * boxd.ax + w.y * boxd.bx + w.z * boxd.cx));
+        p.y = (float) (x.y - (w.y * boxd.by + w.z * boxd.cy));
+        p.z = (float) (x.z - (w.z * boxd.cz));
+    }
+    else { p.x = 0.f; p.y = 0.f; p.z = 0.f; p.w = 0.f; }
+    if (inRange) posqOut[sl] = p;
+    // displacement since the last rebuild
+    bool moved = false;
+    if (valid && checkDisplacement) {
+        const float4 r = a.posqRef[sl];
+        float dx = p.x - r.x, dy = p.y - r.y, dz = p.z - r.z;
+        apply_pbc_rt(a.pbc, dx, dy, dz, a.box);
+        moved = !(dx * dx + dy * dy + dz * dz <= a.maxDisp2);
+    }
+    if (__any(moved) && lane_id() == 0) atomicOr(&a.state[ST_REBUILD], 1);
+    // bounding box of the 32-atom block, relative to its first atom
+    const float4 p0 = make_float4(__shfl(p.x, 0, 32), __shfl(p.y, 0, 32), __shfl(p.z, 0, 32), 0.f);
+    float dx = p.x - p0.x, dy = p.y - p0.y, dz = p.z - p0.z;
+    apply_pbc_rt(a.pbc, dx, dy, dz, a.box);
+    if (!valid) { dx = dy = dz = 0; }
+    float minx = dx, maxx = dx, miny = dy, maxy = dy, minz = dz, maxz = dz;
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+        minx = fminf(minx, __shfl_xor(minx, m)); maxx = fmaxf(maxx, __shfl_xor(maxx, m));
+        miny = fminf(miny, __shfl_xor(miny, m)); maxy = fmaxf(maxy, __shfl_xor(maxy, m));
+        minz = fminf(minz, __shfl_xor(minz, m)); maxz = fmaxf(maxz, __shfl_xor(maxz, m));
+    }
+    if (inRange && (s & 31) == 0) {
+        const int blk = s >> 5;
+        a.blockCenter[blk] = make_float4(p0.x + 0.5f * (minx + maxx), p0.y + 0.5f * (miny + maxy), p0.z + 0.5f * (minz + maxz), 0.f);
+        a.blockHalf[blk] = make_float4(0.5f * (maxx - minx), 0.5f * (maxy - miny), 0.5f * (maxz - minz), 0.f);
+    }
+}
+
+NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
+    NlArgs a;
+    a.numAtoms = nl->num_atoms; a.paddedAtoms = nl->padded_atoms; a.numBlocks = nl->padded_atoms / OMM_TILE; a.maxChunks = nl->max_chunks;
+    a.pbc = nl->pbc;
+    double rl = nl->cutoff + nl->padding;
+    a.listCutoff2 = nl->cutoff > 0 ? (float) (rl * rl) : INFINITY;
+    a.maxDisp2 = (float) (0.25 * nl->padding * nl->padding);
+    a.box = make_box(nl->box);
+    a.posq = (const float4*) nl->posq; a.posqRef = (float4*) nl->posq_ref;
+    a.atomOfSlot = nl->atom_of_slot; a.slotOfAtom = nl->slot_of_atom;
+    a.exclStart = nl->excl_start; a.exclAtoms = nl->excl_atoms; a.exclBlockRange = (const int2*) nl->excl_block_range;
+    a.state = nl->state;
+    a.blockCenter = (float4*) nl->block_center; a.blockHalf = (float4*) nl->block_half;
+    a.chunkInfo = (int2*) nl->chunk_info; a.rowJ = nl->row_j; a.rowMask = nl->row_mask;
+    return a;
+}
+
+}  // namespace
+
+static void launch_find(const NlArgs& a, hipStream_t st) {
+    if (a.pbc == 0) hipLaunchKernelGGL(nl_find_interactions<0>, dim3(a.numBlocks), dim3(NL_THREADS), 0, st, a);
+    else if (a.pbc == 1) hipLaunchKernelGGL(nl_find_interactions<1>, dim3(a.numBlocks), dim3(NL_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(nl_find_interactions<2>, dim3(a.numBlocks), dim3(NL_THREADS), 0, st, a);
+}
+
+// Per-step entry of the platform: conversion + displacement check + bounds in one launch, then the
+// (device-conditional) rebuild.  Two launches per step, no host synchronisation.
+extern "C" int ommhip_nl_step(const ommhip_neighbor_list* nl, const void* pos_d, const void* wrap_d, void* stream) {
+    hipStream_t st = (hipStream_t) stream;
+    NlArgs a = make_nl_args(nl);
+    BoxD bd;
+    bd.ax = nl->box[0]; bd.bx = nl->box[1]; bd.by = nl->box[2]; bd.cx = nl->box[3]; bd.cy = nl->box[4]; bd.cz = nl->box[5];
+    ommhip_profile_begin(OMMHIP_TIMER_NL_UPDATE, stream);
+    hipLaunchKernelGGL(nl_prepare, dim3((a.paddedAtoms + 255) / 256), dim3(256), 0, st, a, (const double4*) pos_d, (const int4*) wrap_d, bd,
+                       (float4*) nl->posq, nl->cutoff > 0 ? 1 : 0);
+    launch_find(a, st);
+    ommhip_profile_end(OMMHIP_TIMER_NL_UPDATE, stream);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_nl_update(const ommhip_neighbor_list* nl, void* stream) {
+    hipStream_t st = (hipStream_t) stream;
+    NlArgs a = make_nl_args(nl);
+    ommhip_profile_begin(OMMHIP_TIMER_NL_UPDATE, stream);
+    if (nl->cutoff > 0)    // NoCutoff lists never go stale through motion
+        hipLaunchKernelGGL(nl_check_displacement, dim3((a.paddedAtoms + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(nl_block_bounds, dim3((a.paddedAtoms + 255) / 256), dim3(256), 0, st, a);
+    launch_find(a, st);
+    ommhip_profile_end(OMMHIP_TIMER_NL_UPDATE, stream);
+    return (int) hipGetLastError();
+}

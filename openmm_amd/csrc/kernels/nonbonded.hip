@@ -1,4 +1,4 @@
-// Direct-space NonbondedForce for MI355X (gfx950): neighbour-list construction and the pair kernel.
+// Direct-space NonbondedForce for MI355X (gfx950): the pair kernel (the neighbour list is built by neighbor.hip).
 //
 // Replaces (behaviourally) the Reference path
 //   platforms/reference/src/ReferenceKernels.cpp:967-1014   (ReferenceCalcNonbondedForceKernel::execute)
@@ -26,227 +26,11 @@ using namespace omm;
 
 namespace {
 
-enum { ST_REBUILD = 0, ST_NUM_CHUNKS = 1, ST_OVERFLOW = 2, ST_BLOCKS_DONE = 3, ST_REBUILD_COUNT = 4 };
-
-struct NlArgs {
-    int numAtoms, paddedAtoms, numBlocks, maxChunks;
-    int pbc;                 // 0 none, 1 orthorhombic, 2 triclinic
-    float listCutoff2;       // (cutoff + padding)^2, +inf for NoCutoff
-    float maxDisp2;          // (padding/2)^2
-    Box box;
-    const float4* posq;
-    float4* posqRef;
-    const int* atomOfSlot;
-    const int* slotOfAtom;
-    const int* exclStart;
-    const int* exclAtoms;
-    int* state;
-    float4* blockCenter;
-    float4* blockHalf;
-    int2* chunkInfo;
-    int* rowJ;
-    unsigned* rowMask;
-};
-
-__device__ __forceinline__ void apply_pbc(int pbc, float& dx, float& dy, float& dz, const Box& b) {
-    if (pbc == 1) min_image<false>(dx, dy, dz, b);
-    else if (pbc == 2) min_image<true>(dx, dy, dz, b);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Per-step: did any atom move more than padding/2 since the list was built?  (one thread per slot)
-// ------------------------------------------------------------------------------------------------
-__global__ void nl_check_displacement(NlArgs a) {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    bool moved = false;
-    if (s < a.paddedAtoms && a.atomOfSlot[s] >= 0) {
-        float4 p = a.posq[s], r = a.posqRef[s];
-        float dx = p.x - r.x, dy = p.y - r.y, dz = p.z - r.z;
-        apply_pbc(a.pbc, dx, dy, dz, a.box);
-        moved = !(dx * dx + dy * dy + dz * dz <= a.maxDisp2);   // NaN counts as moved
-    }
-    if (__any(moved) && lane_id() == 0) atomicOr(&a.state[ST_REBUILD], 1);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Bounding boxes of the 32-atom blocks (two blocks per wavefront); also snapshots posq -> posqRef.
-// ------------------------------------------------------------------------------------------------
-__global__ void nl_block_bounds(NlArgs a) {
-    if (a.state[ST_REBUILD] == 0) return;
-    int s = blockIdx.x * blockDim.x + threadIdx.x;     // slot
-    if (s == 0) { a.state[ST_NUM_CHUNKS] = 0; a.state[ST_OVERFLOW] = 0; }
-    bool inRange = s < a.paddedAtoms;
-    int sl = inRange ? s : a.paddedAtoms - 1;
-    float4 p = a.posq[sl];
-    bool valid = inRange && a.atomOfSlot[sl] >= 0;
-    if (inRange) a.posqRef[sl] = p;
-    // first atom of the block (always valid: every block holds at least one real atom)
-    float4 p0 = make_float4(__shfl(p.x, 0, 32), __shfl(p.y, 0, 32), __shfl(p.z, 0, 32), 0.f);
-    float dx = p.x - p0.x, dy = p.y - p0.y, dz = p.z - p0.z;
-    apply_pbc(a.pbc, dx, dy, dz, a.box);
-    if (!valid) { dx = dy = dz = 0; }
-    float minx = dx, maxx = dx, miny = dy, maxy = dy, minz = dz, maxz = dz;
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) {
-        minx = fminf(minx, __shfl_xor(minx, m)); maxx = fmaxf(maxx, __shfl_xor(maxx, m));
-        miny = fminf(miny, __shfl_xor(miny, m)); maxy = fmaxf(maxy, __shfl_xor(maxy, m));
-        minz = fminf(minz, __shfl_xor(minz, m)); maxz = fmaxf(maxz, __shfl_xor(maxz, m));
-    }
-    if (inRange && (s & 31) == 0) {
-        int blk = s >> 5;
-        a.blockCenter[blk] = make_float4(p0.x + 0.5f * (minx + maxx), p0.y + 0.5f * (miny + maxy), p0.z + 0.5f * (minz + maxz), 0.f);
-        a.blockHalf[blk] = make_float4(0.5f * (maxx - minx), 0.5f * (maxy - miny), 0.5f * (maxz - minz), 0.f);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Neighbour-list rows for i-block X = blockIdx.x (one wavefront per i-block).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void nl_find_interactions(NlArgs a) {
-    if (a.state[ST_REBUILD] == 0) return;
-    __shared__ float4 xPos[OMM_TILE];
-    __shared__ int stageJ[2 * OMM_ROW];
-    __shared__ unsigned stageM[2 * OMM_ROW];
-    const int lane = threadIdx.x;
-    const int X = blockIdx.x;
-    const float R2 = a.listCutoff2;
-    const float Rlist = sqrtf(R2);
-
-    if (lane < OMM_TILE) xPos[lane] = a.posq[X * OMM_TILE + lane];
-    bool iValid = lane < OMM_TILE && a.atomOfSlot[X * OMM_TILE + lane] >= 0;
-    const unsigned iValidMask = (unsigned) __ballot(iValid);
-    const float4 cX = a.blockCenter[X], hX = a.blockHalf[X];
-    __syncthreads();
-
-    int count = 0;           // staged entries (wave-uniform)
-    int chunk = -1, rowsInChunk = 0, maskedBits = 0;
-
-    auto flushRow = [&](int nvalid) {
-        // Writes stage[0..64) as one row (entries >= nvalid are padding), then shifts the stage down.
-        if (rowsInChunk == 0) {
-            int c = 0;
-            if (lane == 0) c = atomicAdd(&a.state[ST_NUM_CHUNKS], 1);
-            chunk = __shfl(c, 0);
-            maskedBits = 0;
-        }
-        int j = lane < nvalid ? stageJ[lane] : X * OMM_TILE;
-        unsigned m = lane < nvalid ? stageM[lane] : 0u;
-        bool masked = __any(m != 0xFFFFFFFFu);
-        if (chunk < a.maxChunks) {
-            size_t r = ((size_t) chunk * OMM_CHUNK_ROWS + rowsInChunk) * OMM_ROW + lane;
-            a.rowJ[r] = j;
-            a.rowMask[r] = m;
-        }
-        else if (lane == 0) atomicOr(&a.state[ST_OVERFLOW], 1);
-        if (masked) maskedBits |= 1 << rowsInChunk;
-        rowsInChunk++;
-        if (rowsInChunk == OMM_CHUNK_ROWS) {
-            if (lane == 0 && chunk < a.maxChunks) a.chunkInfo[chunk] = make_int2(X, rowsInChunk | (maskedBits << 8));
-            rowsInChunk = 0;
-        }
-        __syncthreads();
-        int j2 = stageJ[OMM_ROW + lane];
-        unsigned m2 = stageM[OMM_ROW + lane];
-        __syncthreads();
-        stageJ[lane] = j2;
-        stageM[lane] = m2;
-        __syncthreads();
-    };
-
-    for (int ybase = X; ybase < a.numBlocks; ybase += 64) {
-        // ---- block-level test: 64 candidate blocks at a time
-        int Y = ybase + lane;
-        bool cand = false;
-        if (Y < a.numBlocks) {
-            float4 cY = a.blockCenter[Y], hY = a.blockHalf[Y];
-            float dx = cY.x - cX.x, dy = cY.y - cX.y, dz = cY.z - cX.z;
-            apply_pbc(a.pbc, dx, dy, dz, a.box);
-            dx = fmaxf(0.f, fabsf(dx) - hX.x - hY.x);
-            dy = fmaxf(0.f, fabsf(dy) - hX.y - hY.y);
-            dz = fmaxf(0.f, fabsf(dz) - hX.z - hY.z);
-            cand = !(dx * dx + dy * dy + dz * dz >= R2);
-            // Triclinic: the sequential image reduction only finds the nearest copy when it is less than
-            // half a box width away; if that cannot be guaranteed, defer to the exact per-atom test.
-            if (a.pbc == 2 && (0.5f * a.box.cz - hX.z - hY.z < Rlist || 0.5f * a.box.by - hX.y - hY.y < Rlist)) cand = true;
-        }
-        unsigned long long cm = __ballot(cand);
-        // ---- atom-level test: two candidate blocks per pass (lanes 0-31 / 32-63)
-        while (cm != 0) {
-            int y0 = __ffsll((long long) cm) - 1; cm &= cm - 1;
-            int y1 = -1;
-            if (cm != 0) { y1 = __ffsll((long long) cm) - 1; cm &= cm - 1; }
-            int ysel = lane < 32 ? y0 : y1;
-            int Yc = ybase + ysel;
-            int lj = lane & 31;
-            int j = Yc * OMM_TILE + lj;
-            bool ok = ysel >= 0;
-            int atomJ = ok ? a.atomOfSlot[j] : -1;
-            ok = ok && atomJ >= 0;
-            unsigned mask = 0;
-            if (ok) {
-                float4 pj = a.posq[j];
-                // distance to X's bounding box
-                float dx = pj.x - cX.x, dy = pj.y - cX.y, dz = pj.z - cX.z;
-                apply_pbc(a.pbc, dx, dy, dz, a.box);
-                float bx = fmaxf(0.f, fabsf(dx) - hX.x), by = fmaxf(0.f, fabsf(dy) - hX.y), bz = fmaxf(0.f, fabsf(dz) - hX.z);
-                bool near = !(bx * bx + by * by + bz * bz >= R2);
-                if (a.pbc == 2 && (0.5f * a.box.cz - hX.z < Rlist || 0.5f * a.box.by - hX.y < Rlist)) near = true;
-                if (near) {
-                    // exact test against the 32 atoms of X, same metric as the pair kernel
-                    bool any = false;
-                    for (int k = 0; k < OMM_TILE; k++) {
-                        float4 pi = xPos[k];
-                        float ex = pj.x - pi.x, ey = pj.y - pi.y, ez = pj.z - pi.z;
-                        apply_pbc(a.pbc, ex, ey, ez, a.box);
-                        any = any || !(ex * ex + ey * ey + ez * ez >= R2);
-                    }
-                    if (any) {
-                        mask = iValidMask;
-                        if (Yc == X) mask &= (1u << lj) - 1u;        // diagonal block: each pair once, no self pair
-                        for (int e = a.exclStart[atomJ]; e < a.exclStart[atomJ + 1]; e++) {
-                            int s = a.slotOfAtom[a.exclAtoms[e]];
-                            if ((s >> 5) == X) mask &= ~(1u << (s & 31));
-                        }
-                    }
-                }
-            }
-            bool pass = mask != 0;
-            unsigned long long pm = __ballot(pass);
-            if (pass) {
-                int pos = count + lane_prefix_count(pm);
-                stageJ[pos] = j;
-                stageM[pos] = mask;
-            }
-            count += __popcll(pm);
-            __syncthreads();
-            if (count >= OMM_ROW) {
-                flushRow(OMM_ROW);
-                count -= OMM_ROW;
-            }
-        }
-    }
-    if (count > 0) flushRow(count);
-    if (rowsInChunk > 0 && lane == 0 && chunk < a.maxChunks)
-        a.chunkInfo[chunk] = make_int2(X, rowsInChunk | (maskedBits << 8));
-
-    // Last wave out clears the rebuild request.
-    __syncthreads();
-    if (lane == 0) {
-        __threadfence();
-        int done = atomicAdd(&a.state[ST_BLOCKS_DONE], 1);
-        if (done == (int) gridDim.x - 1) {
-            a.state[ST_BLOCKS_DONE] = 0;
-            a.state[ST_REBUILD] = 0;
-            atomicAdd(&a.state[ST_REBUILD_COUNT], 1);
-        }
-    }
-}
-
 // ================================================================================================
 // Pair kernel
 // ================================================================================================
 struct NbArgs {
-    int paddedAtoms, maxChunks;
+    int paddedAtoms, maxChunks, energySlots;
     float cutoff2, alpha, krf, crf, switchDist, invSwitchWidth;
     Box box;
     const float4* posq;
@@ -378,7 +162,7 @@ __global__ __launch_bounds__(64) void nb_direct(NbArgs a, const float4* __restri
     }
     if (ENERGY) {
         energyTotal = wave_sum(energyTotal);
-        if (lane == 0) a.energyBuffer[blockIdx.x] += energyTotal;
+        if (lane == 0 && energyTotal != 0.0) atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], energyTotal);
     }
 }
 
@@ -394,49 +178,12 @@ void launch_direct1(int pbc, bool energy, int grid, hipStream_t st, const NbArgs
     else launch_direct2<METHOD, 2>(energy, grid, st, a);
 }
 
-Box make_box(const double* bv) {
-    // bv = {ax, bx, by, cx, cy, cz}
-    Box b;
-    b.ax = (float) bv[0]; b.bx = (float) bv[1]; b.by = (float) bv[2]; b.cx = (float) bv[3]; b.cy = (float) bv[4]; b.cz = (float) bv[5];
-    b.invAx = (float) (1.0 / bv[0]); b.invBy = (float) (1.0 / bv[2]); b.invCz = (float) (1.0 / bv[5]);
-    return b;
-}
-
-NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
-    NlArgs a;
-    a.numAtoms = nl->num_atoms; a.paddedAtoms = nl->padded_atoms; a.numBlocks = nl->padded_atoms / OMM_TILE; a.maxChunks = nl->max_chunks;
-    a.pbc = nl->pbc;
-    double rl = nl->cutoff + nl->padding;
-    a.listCutoff2 = nl->cutoff > 0 ? (float) (rl * rl) : INFINITY;
-    a.maxDisp2 = (float) (0.25 * nl->padding * nl->padding);
-    a.box = make_box(nl->box);
-    a.posq = (const float4*) nl->posq; a.posqRef = (float4*) nl->posq_ref;
-    a.atomOfSlot = nl->atom_of_slot; a.slotOfAtom = nl->slot_of_atom;
-    a.exclStart = nl->excl_start; a.exclAtoms = nl->excl_atoms;
-    a.state = nl->state;
-    a.blockCenter = (float4*) nl->block_center; a.blockHalf = (float4*) nl->block_half;
-    a.chunkInfo = (int2*) nl->chunk_info; a.rowJ = nl->row_j; a.rowMask = nl->row_mask;
-    return a;
-}
-
 }  // namespace
-
-extern "C" int ommhip_nl_update(const ommhip_neighbor_list* nl, void* stream) {
-    hipStream_t st = (hipStream_t) stream;
-    NlArgs a = make_nl_args(nl);
-    ommhip_profile_begin(OMMHIP_TIMER_NL_UPDATE, stream);
-    if (nl->cutoff > 0)    // NoCutoff lists never go stale through motion
-        hipLaunchKernelGGL(nl_check_displacement, dim3((a.paddedAtoms + 255) / 256), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(nl_block_bounds, dim3((a.paddedAtoms + 255) / 256), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(nl_find_interactions, dim3(a.numBlocks), dim3(64), 0, st, a);
-    ommhip_profile_end(OMMHIP_TIMER_NL_UPDATE, stream);
-    return (int) hipGetLastError();
-}
 
 extern "C" int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, const void* sig_eps,
                                 long long* force, double* energy_buffer, int energy_slots, int include_energy, void* stream) {
     NbArgs a;
-    a.paddedAtoms = nl->padded_atoms; a.maxChunks = nl->max_chunks;
+    a.paddedAtoms = nl->padded_atoms; a.maxChunks = nl->max_chunks; a.energySlots = energy_slots;
     a.cutoff2 = nl->cutoff > 0 ? (float) (nl->cutoff * nl->cutoff) : INFINITY;
     a.alpha = (float) p->ewald_alpha; a.krf = (float) p->krf; a.crf = (float) p->crf;
     a.switchDist = (float) p->switch_distance;
@@ -445,8 +192,10 @@ extern "C" int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_non
     a.posq = (const float4*) nl->posq; a.sigEps = (const float2*) sig_eps; a.state = nl->state;
     a.chunkInfo = (const int2*) nl->chunk_info; a.rowJ = nl->row_j; a.rowMask = nl->row_mask;
     a.force = force; a.energyBuffer = energy_buffer;
-    int grid = p->direct_grid > 0 ? p->direct_grid : 2048;
-    if (include_energy && grid > energy_slots) grid = energy_slots;
+    // One workgroup (= one wavefront) per chunk: the list length is only known on the device, so the launch covers
+    // the allocated capacity and surplus workgroups exit at once; the hardware dispatcher balances the rest.
+    int grid = p->direct_grid > 0 ? p->direct_grid : nl->max_chunks;
+    if (grid < 1) grid = 1;
     hipStream_t st = (hipStream_t) stream;
     ommhip_profile_begin(OMMHIP_TIMER_NB_DIRECT, stream);
     switch ((p->ewald ? 1 : 0) | (p->use_switch ? 2 : 0)) {

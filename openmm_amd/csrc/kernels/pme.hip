@@ -21,7 +21,7 @@ using namespace omm;
 namespace {
 
 #define PME_ORDER 5
-#define FFT_MAX_LDS 4096      // complex elements per ping-pong buffer
+#define FFT_MAX_LDS 2048      // complex elements per ping-pong buffer (2 x 16 KB + 8 KB twiddles: 4 workgroups per CU)
 #define FFT_THREADS 256
 #define FFT_MAX_RADICES 12
 
@@ -95,6 +95,110 @@ __global__ __launch_bounds__(256) void pme_spread(PmeArgs a) {
 #pragma unroll
         for (int k = 1; k < PME_ORDER; k++) { wx = ix == k ? th[0][k] : wx; wy = iy == k ? th[1][k] : wy; wz = iz == k ? th[2][k] : wz; }
         atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], p.w * wx * wy * wz);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-staged spreading.  A workgroup takes SPREAD_ATOMS consecutive slots (spatially compact after the
+// Hilbert sort), accumulates their 125-point stencils into a BRICK^3 sub-grid held in LDS with LDS
+// atomics, and flushes the touched part of the brick to HBM with z-contiguous (coalesced) atomics.
+// Device-scope float atomics resolve at the memory side on MI355X, one transaction per touched
+// 64-byte line, so turning 125 scattered atomics per atom into a few hundred line-coalesced ones per
+// workgroup is what makes this stage cheap.  Atoms whose stencil does not fit the brick (a group
+// that straddles more than BRICK-5 cells) fall back to direct global atomics.
+// ------------------------------------------------------------------------------------------------
+#define SPREAD_ATOMS 64
+#define BRICK 16
+
+__device__ __forceinline__ int wrap_rel(int d, int n) {      // d in (-n, n) -> [-n/2, n/2)
+    if (d >= (n + 1) / 2) d -= n;
+    if (d < -(n / 2)) d += n;
+    return d;
+}
+
+__global__ __launch_bounds__(256) void pme_spread_lds(PmeArgs a) {
+    __shared__ float brick[BRICK * BRICK * BRICK];
+    __shared__ float th[SPREAD_ATOMS][3][PME_ORDER];
+    __shared__ int baseIdx[SPREAD_ATOMS][3];
+    __shared__ float charge[SPREAD_ATOMS];
+    __shared__ int ref[3];
+    __shared__ int minRel[3];
+    const int t = threadIdx.x;
+    const int slot0 = blockIdx.x * SPREAD_ATOMS;
+    if (t < 3) { minRel[t] = 1 << 30; ref[t] = -1; }
+    for (int i = t; i < BRICK * BRICK * BRICK; i += 256) brick[i] = 0.f;
+    if (t < SPREAD_ATOMS) {
+        const int slot = slot0 + t;
+        float q = 0.f;
+        if (slot < a.paddedAtoms) {
+            const float4 p = a.posq[slot];
+            q = p.w;
+            if (q != 0.f) {
+                int idx[3]; float theta[3][PME_ORDER], dtheta[3][PME_ORDER];
+                atom_splines(a, p, idx, theta, dtheta);
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    baseIdx[t][d] = idx[d];
+#pragma unroll
+                    for (int k = 0; k < PME_ORDER; k++) th[t][d][k] = theta[d][k];
+                }
+            }
+        }
+        charge[t] = q;
+    }
+    __syncthreads();
+    // reference cell = base index of the first charged atom of the group
+    if (t == 0) {
+        for (int i = 0; i < SPREAD_ATOMS; i++)
+            if (charge[i] != 0.f) { ref[0] = baseIdx[i][0]; ref[1] = baseIdx[i][1]; ref[2] = baseIdx[i][2]; break; }
+    }
+    __syncthreads();
+    if (ref[0] < 0) return;                                   // no charged atom in this group
+    const int n[3] = {a.nx, a.ny, a.nz};
+    if (t < SPREAD_ATOMS && charge[t] != 0.f) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) atomicMin(&minRel[d], wrap_rel(baseIdx[t][d] - ref[d], n[d]));
+    }
+    __syncthreads();
+    // ---- accumulate: 4 threads per atom
+    {
+        const int atom = t >> 2, part = t & 3;
+        const float q = charge[atom];
+        if (q != 0.f) {
+            int off[3];
+            bool fits = true;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                off[d] = wrap_rel(baseIdx[atom][d] - ref[d], n[d]) - minRel[d];
+                fits = fits && off[d] + PME_ORDER <= BRICK && BRICK <= n[d];
+            }
+            for (int pt = part; pt < PME_ORDER * PME_ORDER * PME_ORDER; pt += 4) {
+                const int ix = pt / 25, iy = (pt / 5) % 5, iz = pt % 5;
+                const float v = q * th[atom][0][ix] * th[atom][1][iy] * th[atom][2][iz];
+                if (fits)
+                    atomicAdd(&brick[((off[0] + ix) * BRICK + off[1] + iy) * BRICK + off[2] + iz], v);
+                else {
+                    int gx = baseIdx[atom][0] + ix; gx -= gx >= a.nx ? a.nx : 0;
+                    int gy = baseIdx[atom][1] + iy; gy -= gy >= a.ny ? a.ny : 0;
+                    int gz = baseIdx[atom][2] + iz; gz -= gz >= a.nz ? a.nz : 0;
+                    atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], v);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- flush the brick: consecutive threads -> consecutive z -> coalesced atomics
+    int org[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) { org[d] = (ref[d] + minRel[d]) % n[d]; if (org[d] < 0) org[d] += n[d]; }
+    for (int i = t; i < BRICK * BRICK * BRICK; i += 256) {
+        const float v = brick[i];
+        if (v != 0.f) {
+            int gx = org[0] + i / (BRICK * BRICK); gx -= gx >= a.nx ? a.nx : 0;
+            int gy = org[1] + (i / BRICK) % BRICK; gy -= gy >= a.ny ? a.ny : 0;
+            int gz = org[2] + i % BRICK; gz -= gz >= a.nz ? a.nz : 0;
+            atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], v);
+        }
     }
 }
 
@@ -204,17 +308,24 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(
 template <int R>
 __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2* __restrict__ dst, int n, int Ns, int B, int BP, int sign,
                                          const float2* __restrict__ tw) {
+    // `tw` is the LDS copy of the twiddle table exp(-2 pi i k/n).  The R-th roots of unity of the butterfly
+    // itself are R entries of that table, held in registers for the whole pass.
     const int butterflies = n / R;
+    const float fsign = (float) -sign;             // table holds exp(-i...), i.e. forward
+    float2 root[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) { root[m] = tw[m * (n / R)]; root[m].y *= fsign; }
+    const int twStep = n / (Ns * R);               // twiddle index increment per r
     for (int idx = threadIdx.x; idx < butterflies * B; idx += FFT_THREADS) {
         const int line = idx % B, j = idx / B;
         const int k = j % Ns;
         float2 v[R];
-        const int twStep = n / (Ns * R);          // twiddle index increment per r for this k
+        v[0] = src[j * BP + line];
 #pragma unroll
-        for (int r = 0; r < R; r++) {
+        for (int r = 1; r < R; r++) {
             float2 x = src[(j + r * butterflies) * BP + line];
-            float2 w = tw[(k * r * twStep) % n];
-            w.y *= -sign;                          // table holds exp(-i...), i.e. forward
+            float2 w = tw[k * r * twStep];         // < n because k < Ns and r < R
+            w.y *= fsign;
             v[r] = cmul(x, w);
         }
         float2 o[R];
@@ -223,9 +334,7 @@ __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2*
             float2 acc = v[0];
 #pragma unroll
             for (int r = 1; r < R; r++) {
-                float2 w = tw[((p * r) % R) * (n / R)];
-                w.y *= -sign;
-                float2 m = cmul(v[r], w);
+                float2 m = cmul(v[r], root[(p * r) % R]);
                 acc.x += m.x; acc.y += m.y;
             }
             o[p] = acc;
@@ -262,7 +371,9 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_kernel(FftArgs a) {
     __shared__ float2 bufA[FFT_MAX_LDS];
     __shared__ float2 bufB[FFT_MAX_LDS];
     __shared__ double energyPartial[FFT_THREADS / 64];
+    __shared__ float2 twS[FFT_MAX_LDS / 2];          // n <= FFT_MAX_LDS/2 (ommhip_fft_supported_size)
     const int n = a.plan.n, B = a.B, BP = a.B + 1;   // LDS line stride B+1: conflict-free for both staging orders
+    for (int i = threadIdx.x; i < n; i += FFT_THREADS) twS[i] = a.twiddle[i];
     const int tilesPerOuter = (a.numInner + B - 1) / B;
     const int outer = blockIdx.x / tilesPerOuter;
     const int inner0 = (blockIdx.x % tilesPerOuter) * B;
@@ -285,7 +396,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_kernel(FftArgs a) {
     __syncthreads();
     float2* res;
     if (a.mode == 3) {
-        res = fft_lines(a.plan, bufA, bufB, B, BP, -1, a.twiddle);
+        res = fft_lines(a.plan, bufA, bufB, B, BP, -1, twS);
         double energy = 0;
         for (int idx = threadIdx.x; idx < n * B; idx += FFT_THREADS) {
             const int line = idx % B, e = idx / B;
@@ -310,10 +421,10 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_kernel(FftArgs a) {
             atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], 0.5 * e);
         }
         float2* other = res == bufA ? bufB : bufA;
-        res = fft_lines(a.plan, res, other, B, BP, +1, a.twiddle);
+        res = fft_lines(a.plan, res, other, B, BP, +1, twS);
     }
     else {
-        res = fft_lines(a.plan, bufA, bufB, B, BP, a.sign, a.twiddle);
+        res = fft_lines(a.plan, bufA, bufB, B, BP, a.sign, twS);
     }
     // ---- store
     const bool elemFastOut = a.outElemStride == 1;
@@ -386,10 +497,13 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     pa.posq = (const float4*) posq_d; pa.grid = (float*) pme->grid_real; pa.force = force_d;
     float2* cgrid = (float2*) pme->grid_complex;
 
-    hipMemsetAsync(pa.grid, 0, sizeof(float) * (size_t) nx * ny * nz, st);
+    if (!pme->grid_precleared) hipMemsetAsync(pa.grid, 0, sizeof(float) * (size_t) nx * ny * nz, st);
     const int spreadBlocks = (padded_atoms * 8 + 255) / 256;
     ommhip_profile_begin(OMMHIP_TIMER_PME_SPREAD, stream);
-    hipLaunchKernelGGL(pme_spread, dim3(spreadBlocks), dim3(256), 0, st, pa);
+    if (pme->spread_mode == 1)
+        hipLaunchKernelGGL(pme_spread, dim3(spreadBlocks), dim3(256), 0, st, pa);             // direct global atomics (reference variant)
+    else
+        hipLaunchKernelGGL(pme_spread_lds, dim3((padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS), dim3(256), 0, st, pa);
     ommhip_profile_end(OMMHIP_TIMER_PME_SPREAD, stream);
     ommhip_profile_begin(OMMHIP_TIMER_PME_FFT, stream);
 

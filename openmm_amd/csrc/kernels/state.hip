@@ -73,6 +73,16 @@ __global__ __launch_bounds__(256) void k_reduce_energy(double* __restrict__ buff
     if (threadIdx.x == 0) result[0] = partial[0] + partial[1] + partial[2] + partial[3];
 }
 
+// Zero two buffers (16-byte granules) in one launch: the force accumulator and the PME charge grid.
+__global__ __launch_bounds__(256) void k_clear2(uint4* __restrict__ a, size_t na, uint4* __restrict__ b, size_t nb) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += stride) {
+        if (i < na) a[i] = z;
+        else b[i - na] = z;
+    }
+}
+
 BoxD make_boxd(const double* bv) {
     BoxD b; b.ax = bv[0]; b.bx = bv[1]; b.by = bv[2]; b.cx = bv[3]; b.cy = bv[4]; b.cz = bv[5];
     return b;
@@ -103,6 +113,17 @@ extern "C" int ommhip_forces_to_double(const long long* force_d, const int* slot
 extern "C" int ommhip_add_forces_from_double(const double* in_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, long long* force_d, void* stream) {
     hipLaunchKernelGGL(k_add_forces_from_double, dim3((num_atoms + 255) / 256), dim3(256), 0, (hipStream_t) stream,
                        in_d, slot_of_atom_d, num_atoms, padded_atoms, (omm_fixed*) force_d);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_clear2(void* a_d, size_t a_bytes, void* b_d, size_t b_bytes, void* stream) {
+    // both sizes must be multiples of 16 bytes (all buffers of this library are)
+    if ((a_bytes & 15) != 0 || (b_bytes & 15) != 0) return 1;
+    const size_t n = a_bytes / 16 + b_bytes / 16;
+    if (n == 0) return 0;
+    int blocks = (int) ((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_clear2, dim3(blocks), dim3(256), 0, (hipStream_t) stream, (uint4*) a_d, a_bytes / 16, (uint4*) b_d, b_bytes / 16);
     return (int) hipGetLastError();
 }
 

@@ -169,7 +169,23 @@ void HipContext::setBox(const Vec3& a, const Vec3& b, const Vec3& c) {
 }
 
 void HipContext::clearForces() {
-    HIP_CHECK(ommhip_memset(force.ptr, 0, force.bytes, stream));
+    // the force accumulator and (if a PME kernel registered one) the charge grid are zeroed by one launch
+    HIP_CHECK(ommhip_clear2(force.ptr, force.bytes, extraClearPtr, extraClearBytes, stream));
+}
+
+void HipContext::addTerms(const ommhip_term_batch& batch, bool includeEnergy) {
+    if (batch.terms.num_terms <= 0) return;
+    if (!pendingTerms.empty() && (pendingTermsEnergy != includeEnergy || pendingTerms.size() == OMMHIP_MAX_TERM_LISTS))
+        flushTerms();
+    pendingTermsEnergy = includeEnergy;
+    pendingTerms.push_back(batch);
+}
+
+void HipContext::flushTerms() {
+    if (pendingTerms.empty()) return;
+    HIP_CHECK(ommhip_term_forces_multi((int) pendingTerms.size(), pendingTerms.data(), pos.ptr, slotOfAtom.as<int>(), paddedAtoms, box,
+                                       force.as<long long>(), energyBuffer.as<double>(), EnergySlots, pendingTermsEnergy ? 1 : 0, stream));
+    pendingTerms.clear();
 }
 
 void HipContext::saveForces() {

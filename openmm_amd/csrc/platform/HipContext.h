@@ -74,7 +74,13 @@ public:
 
     // ---- per-evaluation
     void clearForces();
-    void saveForces();                                          // device copy of the force buffer (energy-only evaluations)
+    /** One extra buffer (the PME charge grid) zeroed together with the forces at the start of every evaluation. */
+    void* extraClearPtr = NULL;
+    size_t extraClearBytes = 0;
+    /** Queue a per-term force list; all queued lists go out in one launch (flushTerms, called by finishComputation). */
+    void addTerms(const ommhip_term_batch& batch, bool includeEnergy);
+    void flushTerms();
+    void saveForces();                                         // device copy of the force buffer (energy-only evaluations)
     void restoreForces();
     double reduceEnergy();                                      // blocking; also zeroes the buffer
     /** Spatially re-sort atoms into slots if requested or due.  Returns true if the order changed. */
@@ -109,6 +115,8 @@ public:
 private:
     void computeOrder(const std::vector<Vec3>& positions, std::vector<int>& order, std::vector<int>& wrapOut);
     std::vector<HipContextListener*> listeners;
+    std::vector<ommhip_term_batch> pendingTerms;
+    bool pendingTermsEnergy = false;
     bool reorderRequested;
     int deviceIndex;
     double* pinnedResult;

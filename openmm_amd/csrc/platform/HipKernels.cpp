@@ -168,18 +168,14 @@ void HipConstraints::runCcma(void* target, bool velocities, double tol) {
 
 void HipConstraints::apply(void* target, double tol) {
     if (numCcma > 0) runCcma(target, false, tol);
-    if (numShake > 0)
-        HIP_CHECK(ommhip_shake(numShake, shakeAtoms.as<int>(), shakeDist.as<double>(), hip.pos.ptr, target, hip.vel.ptr, 0, tol, 150, hip.stream));
-    if (numSettle > 0)
-        HIP_CHECK(ommhip_settle(numSettle, settleAtoms.as<int>(), settleDist.as<double>(), hip.pos.ptr, target, hip.vel.ptr, 0, hip.stream));
+    HIP_CHECK(ommhip_constrain_clusters(numShake, shakeAtoms.as<int>(), shakeDist.as<double>(), numSettle, settleAtoms.as<int>(), settleDist.as<double>(),
+                                        hip.pos.ptr, target, hip.vel.ptr, 0, tol, 150, hip.stream));
 }
 
 void HipConstraints::applyToVelocities(void* target, double tol) {
     if (numCcma > 0) runCcma(target, true, tol);
-    if (numShake > 0)
-        HIP_CHECK(ommhip_shake(numShake, shakeAtoms.as<int>(), shakeDist.as<double>(), hip.pos.ptr, target, hip.vel.ptr, 1, tol, 150, hip.stream));
-    if (numSettle > 0)
-        HIP_CHECK(ommhip_settle(numSettle, settleAtoms.as<int>(), settleDist.as<double>(), hip.pos.ptr, target, hip.vel.ptr, 1, hip.stream));
+    HIP_CHECK(ommhip_constrain_clusters(numShake, shakeAtoms.as<int>(), shakeDist.as<double>(), numSettle, settleAtoms.as<int>(), settleDist.as<double>(),
+                                        hip.pos.ptr, target, hip.vel.ptr, 1, tol, 150, hip.stream));
 }
 
 // ================================================================================================
@@ -218,6 +214,7 @@ void HipCalcForcesAndEnergyKernel::beginComputation(ContextImpl& context, bool i
 
 double HipCalcForcesAndEnergyKernel::finishComputation(ContextImpl& context, bool includeForce, bool includeEnergy, int groups, bool& valid) {
     HipContext& hip = *data.hip;
+    hip.flushTerms();
     double energy = 0;
     if (includeEnergy) energy = hip.reduceEnergy();
     if (hip.hostMode) {
@@ -380,6 +377,7 @@ void HipCalcNonbondedForceKernel::getNeighborListStats(long long* out) {
 HipCalcNonbondedForceKernel::~HipCalcNonbondedForceKernel() {
     liveNonbondedKernels.erase(std::remove(liveNonbondedKernels.begin(), liveNonbondedKernels.end(), this), liveNonbondedKernels.end());
     hip.removeListener(this);
+    if (hip.extraClearPtr != NULL && hip.extraClearPtr == gridReal.ptr) { hip.extraClearPtr = NULL; hip.extraClearBytes = 0; }
     if (pinnedState != NULL) ommhip_host_free(pinnedState);
 }
 
@@ -503,7 +501,10 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     if (usesPeriodic) hip.usePeriodic = true;
     if (nonbondedMethod != NoCutoff) hip.sortCutoff = max(hip.sortCutoff, nonbondedCutoff);
     hip.requestReorder();
-    padding = nonbondedMethod == NoCutoff ? 0.0 : 0.1 * nonbondedCutoff;
+    double paddingFraction = 0.1;
+    if (getenv("OPENMM_HIP_NL_PADDING") != NULL) paddingFraction = atof(getenv("OPENMM_HIP_NL_PADDING"));   // tuning knob, fraction of the cutoff
+    padding = nonbondedMethod == NoCutoff ? 0.0 : paddingFraction * nonbondedCutoff;
+    if (getenv("OPENMM_HIP_DIRECT_GRID") != NULL) directGridOverride = atoi(getenv("OPENMM_HIP_DIRECT_GRID"));
 
     // ---- device arrays
     const int P = hip.paddedAtoms;
@@ -522,6 +523,9 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     }
     uploadVector(exclStart, start, hip.stream);
     uploadVector(exclAtoms, flat, hip.stream);
+    hostExclStart = start;
+    hostExclAtoms = flat;
+    exclBlockRange.allocate(sizeof(int) * 2 * (P / OMMHIP_TILE));
     uploadVector(exceptionAtomsD, exceptionAtomsFlat, hip.stream);
     exceptionParamsD.allocate(sizeof(double) * 3 * max(num14, 1));
     uploadVector(exclusionPairsD, exclusionPairs, hip.stream);
@@ -553,7 +557,7 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
         params.crf = (1.0 / nonbondedCutoff) * (3.0 * rfDielectric) / (2.0 * rfDielectric + 1.0);
     }
     params.switch_distance = switchingDistance;
-    params.direct_grid = 0;
+    params.direct_grid = directGridOverride;
     if (nonbondedMethod == PME) setupPme();
     if (nonbondedMethod == Ewald)
         ewaldStructure.allocate(sizeof(double) * 2 * (size_t) kmax[0] * (2 * kmax[1] - 1) * (2 * kmax[2] - 1));
@@ -573,13 +577,39 @@ void HipCalcNonbondedForceKernel::setupPme() {
         uploadVector(*tw[d], t, hip.stream);
     }
     eterm.allocate(sizeof(float) * (size_t) nx * ny * nzc);
-    gridReal.allocate(sizeof(float) * (size_t) nx * ny * nz);
+    const size_t gridBytes = (sizeof(float) * (size_t) nx * ny * nz + 15) / 16 * 16;
+    gridReal.allocate(gridBytes);
+    if (hip.extraClearPtr == NULL) {
+        // the context zeroes this grid together with the force buffer at the start of every evaluation
+        hip.extraClearPtr = gridReal.ptr;
+        hip.extraClearBytes = gridBytes;
+        pme.grid_precleared = 1;
+    }
     gridComplex.allocate(sizeof(float) * 2 * (size_t) nx * ny * nzc);
     pme.nx = nx; pme.ny = ny; pme.nz = nz; pme.alpha = ewaldAlpha;
     pme.moduli_x = moduliX.as<double>(); pme.moduli_y = moduliY.as<double>(); pme.moduli_z = moduliZ.as<double>();
     pme.eterm = eterm.ptr; pme.grid_real = gridReal.ptr; pme.grid_complex = gridComplex.ptr;
     pme.twiddle_x = twiddleX.ptr; pme.twiddle_y = twiddleY.ptr; pme.twiddle_z = twiddleZ.ptr;
+    pme.spread_mode = getenv("OPENMM_HIP_PME_SPREAD_DIRECT") != NULL ? 1 : 0;    // A/B knob: direct global atomics
     etermDirty = true;
+}
+
+void HipCalcNonbondedForceKernel::updateExclusionBlockRanges() {
+    // For every i-block: the lowest/highest block that holds an exclusion partner of one of its atoms.
+    const int numBlocks = hip.paddedAtoms / OMMHIP_TILE;
+    vector<int> range(2 * (size_t) numBlocks);
+    for (int b = 0; b < numBlocks; b++) { range[2 * b] = numBlocks; range[2 * b + 1] = -1; }
+    for (int atom = 0; atom < numParticles; atom++) {
+        const int X = hip.hostSlotOfAtom[atom] / OMMHIP_TILE;
+        for (int e = hostExclStart[atom]; e < hostExclStart[atom + 1]; e++) {
+            const int Y = hip.hostSlotOfAtom[hostExclAtoms[e]] / OMMHIP_TILE;
+            range[2 * X] = min(range[2 * X], Y);
+            range[2 * X + 1] = max(range[2 * X + 1], Y);
+        }
+    }
+    HIP_CHECK(ommhip_memcpy_h2d(exclBlockRange.ptr, range.data(), sizeof(int) * range.size(), hip.stream));
+    hip.sync();
+    nl.excl_block_range = exclBlockRange.ptr;
 }
 
 int HipCalcNonbondedForceKernel::estimateChunks() const {
@@ -664,29 +694,31 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
         nl.pbc = (hip.box[1] != 0.0 || hip.box[3] != 0.0 || hip.box[4] != 0.0) ? 2 : 1;
     }
     if (slotParamsDirty) {
+        updateExclusionBlockRanges();
         HIP_CHECK(ommhip_set_slot_params(chargeD.as<double>(), sigmaD.as<double>(), epsilonD.as<double>(), hip.atomOfSlot.as<int>(), hip.paddedAtoms, posq.ptr, sigEps.ptr, hip.stream));
         slotParamsDirty = false;
     }
-    HIP_CHECK(ommhip_positions_to_posq(hip.pos.ptr, hip.wrap.ptr, hip.atomOfSlot.as<int>(), hip.paddedAtoms, hip.box, posq.ptr, hip.stream));
     double energy = 0;
     const int ie = includeEnergy ? 1 : 0;
-    if (includeDirect) {
+    if (!includeDirect)
+        HIP_CHECK(ommhip_positions_to_posq(hip.pos.ptr, hip.wrap.ptr, hip.atomOfSlot.as<int>(), hip.paddedAtoms, hip.box, posq.ptr, hip.stream));
+    else {
         if (nl.max_chunks == 0) allocateNeighborList(estimateChunks());
-        // A list that overflowed during an earlier (device-triggered) rebuild shows up here one evaluation late.
-        if (stateCopyPending) {
-            if (pinnedState[2] != 0 || pinnedState[1] > nl.max_chunks) {
-                fprintf(stderr, "HIP platform: neighbour list overflowed (%d chunks needed, %d allocated); growing and rebuilding\n", pinnedState[1], nl.max_chunks);
-                hip.sync();
-                allocateNeighborList((int) (pinnedState[1] * 1.5) + 64);
-                forceRebuild = true;
-            }
+        // A list that overflowed during an earlier (device-triggered) rebuild shows up here late (the state is read back
+        // asynchronously every 16th evaluation): the list is then grown and rebuilt.
+        if (stateCopyPending && (pinnedState[2] != 0 || pinnedState[1] > nl.max_chunks)) {
+            fprintf(stderr, "HIP platform: neighbour list overflowed (%d chunks needed, %d allocated); growing and rebuilding\n", pinnedState[1], nl.max_chunks);
+            hip.sync();
+            allocateNeighborList((int) (pinnedState[1] * 1.5) + 64);
+            forceRebuild = true;
         }
         while (true) {
             if (forceRebuild) {
-                int one = 1;
-                HIP_CHECK(ommhip_memcpy_h2d(nlState.ptr, &one, sizeof(int), hip.stream));
+                const int request[3] = {1, 0, 0};     // REBUILD = 1, NUM_CHUNKS = 0, OVERFLOW = 0
+                HIP_CHECK(ommhip_memcpy_h2d(nlState.ptr, request, sizeof(request), hip.stream));
             }
-            HIP_CHECK(ommhip_nl_update(&nl, hip.stream));
+            // positions -> posq, displacement check, bounds; then the device-conditional rebuild (2 launches)
+            HIP_CHECK(ommhip_nl_step(&nl, hip.pos.ptr, hip.wrap.ptr, hip.stream));
             if (!forceRebuild) break;
             // host-requested rebuild: verify the capacity synchronously
             HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
@@ -695,15 +727,19 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
             allocateNeighborList((int) (pinnedState[1] * 1.3) + 64);
         }
         HIP_CHECK(ommhip_nb_direct(&nl, &params, sigEps.ptr, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
-        HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
-        stateCopyPending = true;
-        ommhip_term_list t14 = {num14, exceptionAtomsD.as<int>(), exceptionParamsD.as<double>()};
-        HIP_CHECK(ommhip_term_forces(OMMHIP_TERM_EXCEPTION14, &t14, hip.pos.ptr, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.box, exceptionsArePeriodic ? 1 : 0,
-                                     chargeD.as<double>(), ewaldAlpha, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+        if ((++evaluationCount & 15) == 0) {
+            HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
+            stateCopyPending = true;
+        }
+        // 1-4 exceptions and the Ewald exclusion correction are queued; they leave in one launch together with the
+        // bonded terms of the other forces (HipContext::flushTerms)
+        ommhip_term_batch t14 = {OMMHIP_TERM_EXCEPTION14, {num14, exceptionAtomsD.as<int>(), exceptionParamsD.as<double>()},
+                                 exceptionsArePeriodic ? 1 : 0, chargeD.as<double>(), ewaldAlpha};
+        hip.addTerms(t14, includeEnergy);
         if (params.ewald) {
-            ommhip_term_list tex = {numExclusionPairs, exclusionPairsD.as<int>(), NULL};
-            HIP_CHECK(ommhip_term_forces(OMMHIP_TERM_EWALD_EXCLUSION, &tex, hip.pos.ptr, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.box, exceptionsArePeriodic ? 1 : 0,
-                                         chargeD.as<double>(), ewaldAlpha, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+            ommhip_term_batch tex = {OMMHIP_TERM_EWALD_EXCLUSION, {numExclusionPairs, exclusionPairsD.as<int>(), NULL},
+                                     exceptionsArePeriodic ? 1 : 0, chargeD.as<double>(), ewaldAlpha};
+            hip.addTerms(tex, includeEnergy);
         }
         if (includeEnergy && usesPeriodic)
             energy += dispersionCoefficient / (hip.box[0] * hip.box[2] * hip.box[5]);
@@ -792,9 +828,8 @@ void HipTermForce::uploadParams(const vector<double>& params) {
 void HipTermForce::execute(bool includeEnergy) {
     HipContext& hip = *data.hip;
     hip.setAsCurrent();
-    ommhip_term_list t = {numTerms, atomsD.as<int>(), paramsD.as<double>()};
-    HIP_CHECK(ommhip_term_forces(kind, &t, hip.pos.ptr, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.box, periodic ? 1 : 0, NULL, 0.0,
-                                 hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream));
+    ommhip_term_batch b = {kind, {numTerms, atomsD.as<int>(), paramsD.as<double>()}, periodic ? 1 : 0, NULL, 0.0};
+    hip.addTerms(b, includeEnergy);
 }
 
 void HipCalcHarmonicBondForceKernel::initialize(const System& system, const HarmonicBondForce& force) {
@@ -980,7 +1015,7 @@ double HipIntegrateLangevinMiddleStepKernel::computeKineticEnergy(ContextImpl& c
 void HipRemoveCMMotionKernel::initialize(const System& system, const CMMotionRemover& force) {
     frequency = force.getFrequency();
     data.hip->setAsCurrent();
-    scratch.allocate(sizeof(double) * 4);
+    scratch.allocate(sizeof(double) * 4 * 64);
 }
 void HipRemoveCMMotionKernel::execute(ContextImpl& context) {
     if (data.stepCount % frequency != 0) return;

@@ -113,12 +113,16 @@ private:
     NonbondedMethod nonbondedMethod;
     double nonbondedCutoff, switchingDistance, rfDielectric, ewaldAlpha, dispersionCoefficient, selfEnergy, padding;
     bool useSwitchingFunction, exceptionsArePeriodic, usesPeriodic;
-    int kmax[3], gridSize[3];
+    int kmax[3], gridSize[3], directGridOverride = 0;
+    unsigned evaluationCount = 0;
     std::vector<std::vector<double> > baseParticleParams, baseExceptionParams;   // (charge, sigma, epsilon)
     std::vector<std::pair<int, int> > exceptionAtoms;
     std::map<std::pair<std::string, int>, std::vector<double> > particleParamOffsets, exceptionParamOffsets;
     std::map<std::string, double> lastGlobalValues;
     std::vector<double> charges;                                             // current, atom order
+    std::vector<int> hostExclStart, hostExclAtoms;                           // exclusion CSR (atom indices)
+    DeviceBuffer exclBlockRange;
+    void updateExclusionBlockRanges();
     bool slotParamsDirty, forceRebuild, etermDirty, hasInitializedParams;
     // device
     DeviceBuffer chargeD, sigmaD, epsilonD, posq, posqRef, sigEps, exclStart, exclAtoms, nlState, blockCenter, blockHalf, chunkInfo, rowJ, rowMask;

@@ -74,8 +74,8 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     nb = padded // 32
     nl.block_center, nl.block_half = K.upload(np.zeros((nb, 4), np.float32)), K.upload(np.zeros((nb, 4), np.float32))
     nl.chunk_info = K.upload(np.zeros((maxc, 2), np.int32))
-    nl.row_j = K.upload(np.zeros(maxc * 256, np.int32))
-    nl.row_mask = K.upload(np.zeros(maxc * 256, np.uint32))
+    nl.row_j = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.int32))
+    nl.row_mask = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.uint32))
     K.nl_update(C.byref(nl), None)
     state = K.download(nl.state, 8, np.int32)
     p = capi.NonbondedParams()

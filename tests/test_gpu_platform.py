@@ -1,0 +1,168 @@
+"""`-m gpu`: the drop-in boundary on a real MI355X -- Context("HIP") through OpenMM's plugin loader.
+
+ * the reference's own platform-agnostic test bodies (tests/Test*.h of the OpenMM tree, compiled against the HIP platform by
+   tests/hip/Makefile in the build container) must print "Done";
+ * forces/energies against golden outputs of the real Reference platform (tests/golden/reference_forces_*.npz);
+ * the BASELINE-size workload (23 558 atoms, PME 56^3) against the Reference platform of oracle/_ref, criterion
+   max_i |F_hip - F_ref| / RMS|F_ref| <= 1e-4 (BASELINE.json north_star), and size-independent invariants."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import PRODUCT_TESTS, max_rel_force_error
+from openmm_amd import harness as H, testsystems as T
+
+pytestmark = pytest.mark.gpu
+
+REFERENCE_TEST_BODIES = ["NonbondedForce", "Ewald", "VerletIntegrator", "Settle", "LangevinIntegrator", "LangevinMiddleIntegrator",
+                         "HarmonicBondForce", "HarmonicAngleForce", "PeriodicTorsionForce", "CMMotionRemover", "Checkpoints",
+                         "CustomBondForce", "CustomExternalForce", "RBTorsionForce", "VirtualSites", "VariableVerletIntegrator",
+                         "BrownianIntegrator", "MonteCarloBarostat", "CustomNonbondedForce", "GBSAOBCForce", "DispersionPME"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def hip_platform():
+    H.load_hip_platform()
+    assert "HIP" in H.platform_names()
+
+
+@pytest.mark.parametrize("name", REFERENCE_TEST_BODIES)
+def test_reference_test_body(name):
+    exe = os.path.join(PRODUCT_TESTS, "TestHip" + name)
+    assert os.path.exists(exe), "%s missing: run __graft_entry__.build() in the build container" % exe
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "Done" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def hip_state(w, groups=-1, recip_group=False, integrator=None):
+    system, nb = w.build()
+    if recip_group:
+        nb.setReciprocalSpaceForceGroup(1)
+    ctx = H.Context(system, integrator or H.Integrator(H.VERLET, 0.001), "HIP")
+    ctx.setPositions(w.positions)
+    st = ctx.getState(getForces=True, getEnergy=True, groups=groups)
+    ctx.close()
+    return st
+
+
+@pytest.mark.parametrize("name,builder", [("water648_pme", lambda: T.water_box(6, seed=11)), ("water3000_pme", lambda: T.water_box(10, seed=12)),
+                                          ("argon864_nocutoff", lambda: T.argon_box())])
+def test_forces_against_reference_platform_goldens(golden, name, builder):
+    g = golden("reference_forces_%s.npz" % name)
+    w = builder()
+    assert np.array_equal(w.positions, g["positions"]), "fixture and generator out of sync"
+    if "pme_params" in g.files:
+        p = g["pme_params"]
+        w.pme_params = (float(p[0]), int(p[1]), int(p[2]), int(p[3]))
+    st = hip_state(w)
+    assert max_rel_force_error(st.forces, g["forces"]) < 1e-4
+    assert abs(st.potentialEnergy - float(g["energy"])) < 2e-5 * max(abs(float(g["energy"])), 5e4)
+    if "direct_forces" in g.files:
+        d = hip_state(w, groups=1, recip_group=True)
+        r = hip_state(w, groups=2, recip_group=True)
+        rms = np.sqrt((g["forces"] ** 2).sum(1).mean())
+        assert np.sqrt(((d.forces - g["direct_forces"]) ** 2).sum(1)).max() / rms < 1e-4
+        assert np.sqrt(((r.forces - g["recip_forces"]) ** 2).sum(1)).max() / rms < 1e-4
+
+
+@pytest.fixture(scope="module")
+def dhfr_states():
+    """Full-size workload on HIP and on the real Reference platform (about 2 s of CPU)."""
+    w = T.dhfr_like(seed=1)
+    out = {}
+    for plat in ("HIP", "Reference"):
+        system, nb = w.build()
+        ctx = H.Context(system, H.Integrator(H.VERLET, 0.001), plat)
+        ctx.setPositions(w.positions)
+        out[plat] = ctx.getState(getForces=True, getEnergy=True)
+        if plat == "HIP":
+            out["pme"] = nb.getPMEParametersInContext(ctx)
+        ctx.close()
+    return w, out
+
+
+def test_dhfr_size_forces_within_1e4_of_reference(dhfr_states):
+    w, out = dhfr_states
+    assert out["pme"][1:] == (56, 56, 56) and abs(out["pme"][0] - 2.9203) < 1e-3
+    err = max_rel_force_error(out["HIP"].forces, out["Reference"].forces)
+    f_ref, f_hip = out["Reference"].forces, out["HIP"].forces
+    median = np.median(2 * np.linalg.norm(f_hip - f_ref, axis=1) / (np.linalg.norm(f_ref, axis=1) + np.linalg.norm(f_hip, axis=1)))
+    print("DHFR-size force max-rel-err %.3g, median relative difference (docs statistic) %.3g" % (err, median))
+    assert err < 1e-4
+    assert median < 4e-5        # 07_testing_validation.rst:142 quotes 3.99e-5 for CUDA single precision PME
+    assert abs(out["HIP"].potentialEnergy - out["Reference"].potentialEnergy) < 1e-5 * abs(out["Reference"].potentialEnergy)
+
+
+def test_dhfr_size_invariants():
+    """Size-independent properties at the BASELINE size: constraints hold, temperature stays put, energy is finite
+    after 300 LangevinMiddle steps; a repeated force evaluation is bit-identical for the direct-space part."""
+    w = T.dhfr_like(seed=1)
+    system, nb = w.build()
+    integ = H.Integrator(H.LANGEVIN_MIDDLE, 0.002, 300.0, 1.0, seed=4)
+    ctx = H.Context(system, integ, "HIP")
+    ctx.setPositions(w.positions)
+    ctx.setVelocities(w.velocities) if w.velocities is not None else ctx.setVelocitiesToTemperature(300.0, 1)
+    integ.step(300)
+    st = ctx.getState(getPositions=True, getEnergy=True)
+    pairs, dist = w.constraints
+    d = np.linalg.norm(st.positions[pairs[:, 0]] - st.positions[pairs[:, 1]], axis=1)
+    assert np.abs(d - dist).max() < 2e-5 * dist.max() + 1e-6
+    ndof = 3 * w.num_atoms - len(dist) - 3
+    temperature = 2 * st.kineticEnergy / (ndof * 0.00831446261815324)
+    assert 280 < temperature < 320, temperature
+    assert np.isfinite(st.potentialEnergy)
+    ctx.close()
+
+
+def test_energy_conservation_nve_flexible_water():
+    """tests/TestVerletIntegrator.h:84-135 style: total energy of an NVE run stays within 1% of the kinetic energy scale."""
+    w = T.water_box(8, seed=21, rigid=False)
+    alpha = float(np.sqrt(-np.log(2 * w.ewald_tol)) / w.cutoff)
+    w.pme_params = (alpha, 24, 24, 24)
+    system, nb = w.build()
+    integ = H.Integrator(H.VERLET, 0.0005)
+    ctx = H.Context(system, integ, "HIP")
+    ctx.setPositions(w.positions)
+    ctx.minimizeEnergy(10.0, 200)
+    ctx.setVelocitiesToTemperature(300.0, 2)
+    integ.step(200)
+    e = []
+    for _ in range(20):
+        integ.step(50)
+        st = ctx.getState(getEnergy=True)
+        e.append(st.potentialEnergy + st.kineticEnergy)
+    e = np.array(e)
+    ke = st.kineticEnergy
+    assert (e.max() - e.min()) < 0.01 * ke, (e, ke)
+    ctx.close()
+
+
+def test_host_mode_and_fallback_paths_agree_with_device_mode():
+    """OPENMM_HIP_FORCE_HOST_MODE exercises the Reference-integrator path; forces must match the device-mode forces."""
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+os.environ["OPENMM_HIP_FORCE_HOST_MODE"] = "1"
+from openmm_amd import harness as H, testsystems as T
+H.load_hip_platform()
+w = T.water_box(6, seed=11)
+s, nb = w.build()
+c = H.Context(s, H.Integrator(H.LANGEVIN_MIDDLE, 0.002, 300.0, 1.0, seed=1), "HIP")
+c.setPositions(w.positions)
+st = c.getState(getForces=True, getEnergy=True)
+np.save(sys.argv[1], st.forces)
+c.integrator.step(3)
+print("OK", st.potentialEnergy)
+'''
+    import sys
+    import tempfile
+    from conftest import ROOT
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "f.npy")
+        out = subprocess.run([sys.executable, "-c", code % ROOT, path], capture_output=True, text=True, timeout=600)
+        assert "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+        f_host = np.load(path)
+    st = hip_state(T.water_box(6, seed=11))
+    assert max_rel_force_error(f_host, st.forces) < 2e-6

@@ -41,6 +41,7 @@ def parse_args():
     p.add_argument("--workload", default="dhfr", choices=["dhfr", "water24k", "water98k"])
     p.add_argument("--cpu-steps", type=int, default=150, help="steps of the CPU-platform baseline (0 disables)")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--props", default="", help="extra HIP platform properties, e.g. DisablePmeStream=true")
     return p.parse_args()
 
 
@@ -91,6 +92,9 @@ def main():
     dt_ps = args.dt_fs * 1e-3
     w = make_workload(args.workload, seed=1 + rank)
     props = {"DeviceIndex": str(local_rank)}
+    for kv in filter(None, args.props.split(",")):
+        k, v = kv.split("=")
+        props[k] = v
     system, nb, integ, ctx = run_platform(w, "HIP", dt_ps, 0, args.warmup, props)
     device_name = ctx.getPlatformProperty("DeviceName")
 

@@ -161,6 +161,7 @@ typedef struct ommhip_pme {
     const void* twiddle_z;
     int spread_mode;           /* 0: LDS-staged bricks (default), 1: direct global atomics */
     int grid_precleared;       /* 1: the caller zeroed grid_real on this stream already (fused clear), skip the memset */
+    int fft_mode;              /* 0: fused (y,z) plane kernel when a plane fits in LDS (default), 1: always separate line passes */
 } ommhip_pme;
 
 int ommhip_fft_supported_size(int n);   /* 1 if n factors into 2,3,5,7 and fits the LDS line buffer; no device access */

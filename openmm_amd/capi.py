@@ -41,7 +41,7 @@ class Pme(C.Structure):
         ("moduli_x", C.c_void_p), ("moduli_y", C.c_void_p), ("moduli_z", C.c_void_p),
         ("eterm", C.c_void_p), ("grid_real", C.c_void_p), ("grid_complex", C.c_void_p),
         ("twiddle_x", C.c_void_p), ("twiddle_y", C.c_void_p), ("twiddle_z", C.c_void_p), ("spread_mode", C.c_int),
-        ("grid_precleared", C.c_int),
+        ("grid_precleared", C.c_int), ("fft_mode", C.c_int),
     ]
 
 

@@ -20,6 +20,7 @@
 //   there is a single code path; rows whose 64 masks are all-ones take a mask-free inner loop.
 #include "common.h"
 #include "erfc_coeffs.h"
+#include <cstdlib>
 #include "../../../include/openmm_hip_kernels.h"
 
 using namespace omm;
@@ -30,7 +31,7 @@ namespace {
 // Pair kernel
 // ================================================================================================
 struct NbArgs {
-    int paddedAtoms, maxChunks, energySlots;
+    int paddedAtoms, maxChunks, energySlots, debugFlags;
     float cutoff2, alpha, krf, crf, switchDist, invSwitchWidth;
     Box box;
     const float4* posq;
@@ -152,12 +153,16 @@ __global__ __launch_bounds__(64) void nb_direct(NbArgs a, const float4* __restri
                 for (int k = 0; k < OMM_TILE; k++)
                     pair_ixn<METHOD, PBC, ENERGY, false>(a, ip[k], ise[k], pj, sej, qjK, true, fix[k], fiy[k], fiz[k], fjx, fjy, fjz, energy);
             }
-            add_force(a.force, a.paddedAtoms, j, fjx, fjy, fjz);
+            if (!(a.debugFlags & 1)) add_force(a.force, a.paddedAtoms, j, fjx, fjy, fjz);
+            else if (fjx == 12345.f) a.force[0] = 1;           // profiling knob: keep the arithmetic alive without the atomics
         }
         const float tx = transpose_reduce32(fix, lane);
         const float ty = transpose_reduce32(fiy, lane);
         const float tz = transpose_reduce32(fiz, lane);
-        if (lane < OMM_TILE) add_force(a.force, a.paddedAtoms, X * OMM_TILE + lane, tx, ty, tz);
+        if (lane < OMM_TILE) {
+            if (!(a.debugFlags & 2)) add_force(a.force, a.paddedAtoms, X * OMM_TILE + lane, tx, ty, tz);
+            else if (tx == 12345.f) a.force[0] = 1;
+        }
         if (ENERGY) energyTotal += (double) energy;
     }
     if (ENERGY) {
@@ -184,6 +189,9 @@ extern "C" int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_non
                                 long long* force, double* energy_buffer, int energy_slots, int include_energy, void* stream) {
     NbArgs a;
     a.paddedAtoms = nl->padded_atoms; a.maxChunks = nl->max_chunks; a.energySlots = energy_slots;
+    // OPENMM_HIP_DEBUG_SKIP_ATOMICS (profiling only, results are wrong): bit 0 drops the j-force atomics, bit 1 the i-force atomics
+    static const int debugFlags = getenv("OPENMM_HIP_DEBUG_SKIP_ATOMICS") != nullptr ? atoi(getenv("OPENMM_HIP_DEBUG_SKIP_ATOMICS")) : 0;
+    a.debugFlags = debugFlags;
     a.cutoff2 = nl->cutoff > 0 ? (float) (nl->cutoff * nl->cutoff) : INFINITY;
     a.alpha = (float) p->ewald_alpha; a.krf = (float) p->krf; a.crf = (float) p->crf;
     a.switchDist = (float) p->switch_distance;

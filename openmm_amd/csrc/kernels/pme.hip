@@ -15,6 +15,7 @@
 // influence function carries all constants.
 #include "common.h"
 #include "../../../include/openmm_hip_kernels.h"
+#include <cstdlib>
 
 using namespace omm;
 
@@ -30,7 +31,7 @@ struct RecipBox {   // reciprocal box vectors (rows), ReferencePME.cpp:196-204 (
 };
 
 struct PmeArgs {
-    int paddedAtoms, nx, ny, nz;
+    int paddedAtoms, nx, ny, nz, debug;
     RecipBox recip;
     const float4* posq;
     float* grid;
@@ -107,7 +108,9 @@ __global__ __launch_bounds__(256) void pme_spread(PmeArgs a) {
 // workgroup is what makes this stage cheap.  Atoms whose stencil does not fit the brick (a group
 // that straddles more than BRICK-5 cells) fall back to direct global atomics.
 // ------------------------------------------------------------------------------------------------
-#define SPREAD_ATOMS 64
+// One workgroup = one 32-atom block of the spatial sort (the unit whose bounding box the neighbour list also uses):
+// its atoms span ~7 grid cells, so stencils (+5) fit a 16^3 brick; 8 threads share the 125 points of an atom.
+#define SPREAD_ATOMS 32
 #define BRICK 16
 
 __device__ __forceinline__ int wrap_rel(int d, int n) {      // d in (-n, n) -> [-n/2, n/2)
@@ -127,30 +130,30 @@ __global__ __launch_bounds__(256) void pme_spread_lds(PmeArgs a) {
     const int slot0 = blockIdx.x * SPREAD_ATOMS;
     if (t < 3) { minRel[t] = 1 << 30; ref[t] = -1; }
     for (int i = t; i < BRICK * BRICK * BRICK; i += 256) brick[i] = 0.f;
-    if (t < SPREAD_ATOMS) {
-        const int slot = slot0 + t;
-        float q = 0.f;
-        if (slot < a.paddedAtoms) {
-            const float4 p = a.posq[slot];
-            q = p.w;
-            if (q != 0.f) {
-                int idx[3]; float theta[3][PME_ORDER], dtheta[3][PME_ORDER];
-                atom_splines(a, p, idx, theta, dtheta);
+    // splines: thread (atom, dimension)
+    if (t < 4 * SPREAD_ATOMS) {
+        const int atom = t >> 2, d = t & 3;
+        const int slot = slot0 + atom;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (slot < a.paddedAtoms) p = a.posq[slot];
+        if (d == 3) charge[atom] = p.w;
+        else if (p.w != 0.f) {
+            // fractional coordinate along dimension d (ReferencePME.cpp:256-258)
+            const float frac = d == 0 ? p.x * a.recip.r00 + p.y * a.recip.r10 + p.z * a.recip.r20
+                             : (d == 1 ? p.y * a.recip.r11 + p.z * a.recip.r21 : p.z * a.recip.r22);
+            const int nd = d == 0 ? a.nx : (d == 1 ? a.ny : a.nz);
+            int idx; float theta[PME_ORDER], dtheta[PME_ORDER];
+            bspline(frac, nd, idx, theta, dtheta);
+            baseIdx[atom][d] = idx;
 #pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    baseIdx[t][d] = idx[d];
-#pragma unroll
-                    for (int k = 0; k < PME_ORDER; k++) th[t][d][k] = theta[d][k];
-                }
-            }
+            for (int k = 0; k < PME_ORDER; k++) th[atom][d][k] = theta[k];
         }
-        charge[t] = q;
     }
     __syncthreads();
-    // reference cell = base index of the first charged atom of the group
-    if (t == 0) {
-        for (int i = 0; i < SPREAD_ATOMS; i++)
-            if (charge[i] != 0.f) { ref[0] = baseIdx[i][0]; ref[1] = baseIdx[i][1]; ref[2] = baseIdx[i][2]; break; }
+    // reference cell = base index of the first charged atom of the group (wave 0 holds one atom per lane)
+    if (t < 64) {
+        const unsigned long long charged = __ballot(t < SPREAD_ATOMS && charge[t < SPREAD_ATOMS ? t : 0] != 0.f);
+        if (charged != 0 && t == __ffsll((long long) charged) - 1) { ref[0] = baseIdx[t][0]; ref[1] = baseIdx[t][1]; ref[2] = baseIdx[t][2]; }
     }
     __syncthreads();
     if (ref[0] < 0) return;                                   // no charged atom in this group
@@ -160,9 +163,9 @@ __global__ __launch_bounds__(256) void pme_spread_lds(PmeArgs a) {
         for (int d = 0; d < 3; d++) atomicMin(&minRel[d], wrap_rel(baseIdx[t][d] - ref[d], n[d]));
     }
     __syncthreads();
-    // ---- accumulate: 4 threads per atom
-    {
-        const int atom = t >> 2, part = t & 3;
+    // ---- accumulate: 8 threads per atom
+    if (!(a.debug & 1)) {
+        const int atom = t >> 3, part = t & 7;
         const float q = charge[atom];
         if (q != 0.f) {
             int off[3];
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void pme_spread_lds(PmeArgs a) {
                 off[d] = wrap_rel(baseIdx[atom][d] - ref[d], n[d]) - minRel[d];
                 fits = fits && off[d] + PME_ORDER <= BRICK && BRICK <= n[d];
             }
-            for (int pt = part; pt < PME_ORDER * PME_ORDER * PME_ORDER; pt += 4) {
+            for (int pt = part; pt < PME_ORDER * PME_ORDER * PME_ORDER; pt += 8) {
                 const int ix = pt / 25, iy = (pt / 5) % 5, iz = pt % 5;
                 const float v = q * th[atom][0][ix] * th[atom][1][iy] * th[atom][2][iz];
                 if (fits)
@@ -188,6 +191,7 @@ __global__ __launch_bounds__(256) void pme_spread_lds(PmeArgs a) {
     }
     __syncthreads();
     // ---- flush the brick: consecutive threads -> consecutive z -> coalesced atomics
+    if (a.debug & 2) return;
     int org[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) { org[d] = (ref[d] + minRel[d]) % n[d]; if (org[d] < 0) org[d] += n[d]; }
@@ -306,8 +310,9 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(
 
 // One Stockham pass of radix R over all B lines.  `sign` selects forward (-1) or backward (+1).
 template <int R>
+// Element e of line l lives at e*BP + l*LS (BP = element stride, LS = line stride).
 __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2* __restrict__ dst, int n, int Ns, int B, int BP, int sign,
-                                         const float2* __restrict__ tw) {
+                                         const float2* __restrict__ tw, int LS) {
     // `tw` is the LDS copy of the twiddle table exp(-2 pi i k/n).  The R-th roots of unity of the butterfly
     // itself are R entries of that table, held in registers for the whole pass.
     const int butterflies = n / R;
@@ -320,10 +325,10 @@ __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2*
         const int line = idx % B, j = idx / B;
         const int k = j % Ns;
         float2 v[R];
-        v[0] = src[j * BP + line];
+        v[0] = src[j * BP + line * LS];
 #pragma unroll
         for (int r = 1; r < R; r++) {
-            float2 x = src[(j + r * butterflies) * BP + line];
+            float2 x = src[(j + r * butterflies) * BP + line * LS];
             float2 w = tw[k * r * twStep];         // < n because k < Ns and r < R
             w.y *= fsign;
             v[r] = cmul(x, w);
@@ -341,24 +346,24 @@ __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2*
         }
         const int j0 = (j / Ns) * Ns * R + k;
 #pragma unroll
-        for (int p = 0; p < R; p++) dst[(j0 + p * Ns) * BP + line] = o[p];
+        for (int p = 0; p < R; p++) dst[(j0 + p * Ns) * BP + line * LS] = o[p];
     }
 }
 
 // Runs all passes; returns the buffer that holds the result.
-__device__ __forceinline__ float2* fft_lines(const FftPlan& plan, float2* bufA, float2* bufB, int B, int BP, int sign, const float2* tw) {
+__device__ __forceinline__ float2* fft_lines(const FftPlan& plan, float2* bufA, float2* bufB, int B, int BP, int sign, const float2* tw, int LS = 1) {
     float2* src = bufA;
     float2* dst = bufB;
     int Ns = 1;
     for (int s = 0; s < plan.numRadices; s++) {
         const int R = plan.radix[s];
         switch (R) {
-            case 2: fft_pass<2>(src, dst, plan.n, Ns, B, BP, sign, tw); break;
-            case 3: fft_pass<3>(src, dst, plan.n, Ns, B, BP, sign, tw); break;
-            case 4: fft_pass<4>(src, dst, plan.n, Ns, B, BP, sign, tw); break;
-            case 5: fft_pass<5>(src, dst, plan.n, Ns, B, BP, sign, tw); break;
-            case 7: fft_pass<7>(src, dst, plan.n, Ns, B, BP, sign, tw); break;
-            default: fft_pass<8>(src, dst, plan.n, Ns, B, BP, sign, tw); break;
+            case 2: fft_pass<2>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+            case 3: fft_pass<3>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+            case 4: fft_pass<4>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+            case 5: fft_pass<5>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+            case 7: fft_pass<7>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+            default: fft_pass<8>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
         }
         Ns *= R;
         __syncthreads();
@@ -440,6 +445,74 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_kernel(FftArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused plane transform: one workgroup does the z and the y transform of one x-plane entirely in LDS,
+// so the (y,z) half of the 3-D transform touches HBM once instead of twice and costs one launch
+// instead of two.  forward: real [ny][nz] -> z r2c -> y c2c -> complex [ny][nz/2+1];  backward: the
+// reverse.  Used when a plane fits the LDS budget (PLANE_MAX complex elements per buffer).
+// LDS layout of a plane: element (y, kz) at kz*(ny+1) + y; the z transform sees lines = y (stride 1),
+// elements = z (stride ny+1); the y transform sees lines = kz (stride ny+1), elements = y (stride 1).
+// ------------------------------------------------------------------------------------------------
+#define PLANE_MAX 6144
+
+struct PlaneArgs {
+    FftPlan planY, planZ;
+    int ny, nz, forward;
+    const float2* twY; const float2* twZ;
+    float* real;           // [nx][ny][nz]
+    float2* cplx;          // [nx][ny][nz/2+1]
+};
+
+__global__ __launch_bounds__(FFT_THREADS) void fft_plane_kernel(PlaneArgs a) {
+    __shared__ float2 bufA[PLANE_MAX];
+    __shared__ float2 bufB[PLANE_MAX];
+    __shared__ float2 twYs[512];
+    __shared__ float2 twZs[512];
+    const int ny = a.ny, nz = a.nz, nzc = nz / 2 + 1, S = ny + 1;
+    const int x = blockIdx.x;
+    for (int i = threadIdx.x; i < ny; i += FFT_THREADS) twYs[i] = a.twY[i];
+    for (int i = threadIdx.x; i < nz; i += FFT_THREADS) twZs[i] = a.twZ[i];
+    if (a.forward) {
+        const float* in = a.real + (size_t) x * ny * nz;
+        for (int idx = threadIdx.x; idx < ny * nz; idx += FFT_THREADS) {
+            const int y = idx / nz, z = idx % nz;
+            bufA[z * S + y] = make_float2(in[idx], 0.f);
+        }
+        __syncthreads();
+        float2* r1 = fft_lines(a.planZ, bufA, bufB, ny, S, -1, twZs, 1);            // lines = y, elements = z
+        float2* other = r1 == bufA ? bufB : bufA;
+        float2* r2 = fft_lines(a.planY, r1, other, nzc, 1, -1, twYs, S);            // lines = kz < nzc, elements = y
+        float2* out = a.cplx + (size_t) x * ny * nzc;
+        for (int idx = threadIdx.x; idx < ny * nzc; idx += FFT_THREADS) {
+            const int ky = idx / nzc, kz = idx % nzc;
+            out[idx] = r2[kz * S + ky];
+        }
+    }
+    else {
+        const float2* in = a.cplx + (size_t) x * ny * nzc;
+        for (int idx = threadIdx.x; idx < ny * nzc; idx += FFT_THREADS) {
+            const int ky = idx / nzc, kz = idx % nzc;
+            bufA[kz * S + ky] = in[idx];
+        }
+        __syncthreads();
+        float2* r1 = fft_lines(a.planY, bufA, bufB, nzc, 1, +1, twYs, S);           // backward y on the half plane
+        // Hermitian completion along z: element kz' = nz - kz is the conjugate of kz (for every y)
+        for (int idx = threadIdx.x; idx < ny * (nz - nzc); idx += FFT_THREADS) {
+            const int y = idx % ny, kz = nzc + idx / ny;
+            const float2 v = r1[(nz - kz) * S + y];
+            r1[kz * S + y] = make_float2(v.x, -v.y);
+        }
+        __syncthreads();
+        float2* other = r1 == bufA ? bufB : bufA;
+        float2* r2 = fft_lines(a.planZ, r1, other, ny, S, +1, twZs, 1);
+        float* out = a.real + (size_t) x * ny * nz;
+        for (int idx = threadIdx.x; idx < ny * nz; idx += FFT_THREADS) {
+            const int y = idx / nz, z = idx % nz;
+            out[idx] = r2[z * S + y].x;
+        }
+    }
+}
+
 FftPlan make_plan(int n) {
     FftPlan p;
     p.n = n; p.numRadices = 0;
@@ -457,6 +530,39 @@ int lines_per_group(int n) {
     if (b > 16) b = 16;
     if (b < 1) b = 1;
     return b;
+}
+
+// The (y,z) half of the 3-D transform: fused plane kernel when a plane fits in LDS, two line passes otherwise.
+void launch_yz(const ommhip_pme* pme, bool forward, hipStream_t st) {
+    const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
+    float2* cgrid = (float2*) pme->grid_complex;
+    if (nz * (ny + 1) <= PLANE_MAX && ny <= 512 && nz <= 512 && pme->fft_mode != 1) {
+        PlaneArgs p;
+        p.planY = make_plan(ny); p.planZ = make_plan(nz); p.ny = ny; p.nz = nz; p.forward = forward ? 1 : 0;
+        p.twY = (const float2*) pme->twiddle_y; p.twZ = (const float2*) pme->twiddle_z;
+        p.real = (float*) pme->grid_real; p.cplx = cgrid;
+        hipLaunchKernelGGL(fft_plane_kernel, dim3(nx), dim3(FFT_THREADS), 0, st, p);
+        return;
+    }
+    FftArgs f;
+    f.eterm = nullptr; f.energyBuffer = nullptr; f.energySlots = 1; f.nzFull = nz;
+    auto zpass = [&]() {
+        f.plan = make_plan(nz); f.B = lines_per_group(nz); f.numOuter = 1; f.numInner = nx * ny;
+        f.inOuterStride = 0; f.outOuterStride = 0; f.inElemStride = 1; f.outElemStride = 1;
+        f.twiddle = (const float2*) pme->twiddle_z;
+        if (forward) { f.inInnerStride = nz; f.outInnerStride = nzc; f.mode = 1; f.sign = -1; f.in = pme->grid_real; f.out = cgrid; }
+        else { f.inInnerStride = nzc; f.outInnerStride = nz; f.mode = 2; f.sign = +1; f.in = cgrid; f.out = pme->grid_real; }
+        hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+    };
+    auto ypass = [&]() {
+        f.plan = make_plan(ny); f.B = lines_per_group(ny); f.numOuter = nx; f.numInner = nzc;
+        f.inOuterStride = (long long) ny * nzc; f.inInnerStride = 1; f.inElemStride = nzc;
+        f.outOuterStride = f.inOuterStride; f.outInnerStride = 1; f.outElemStride = nzc;
+        f.mode = 0; f.sign = forward ? -1 : +1; f.twiddle = (const float2*) pme->twiddle_y; f.in = cgrid; f.out = cgrid;
+        hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+    };
+    if (forward) { zpass(); ypass(); }
+    else { ypass(); zpass(); }
 }
 
 }  // namespace
@@ -489,6 +595,8 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
     PmeArgs pa;
     pa.paddedAtoms = padded_atoms; pa.nx = nx; pa.ny = ny; pa.nz = nz;
+    static const int spreadDebug = getenv("OPENMM_HIP_DEBUG_SPREAD") != nullptr ? atoi(getenv("OPENMM_HIP_DEBUG_SPREAD")) : 0;   // profiling only
+    pa.debug = spreadDebug;
     const double* b = pme->box;
     const double det = b[0] * b[2] * b[5];
     pa.recip.r00 = (float) (b[2] * b[5] / det);
@@ -508,19 +616,9 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     ommhip_profile_begin(OMMHIP_TIMER_PME_FFT, stream);
 
     FftArgs f;
-    // ---- forward z: real [nx*ny][nz] -> complex [nx*ny][nzc]
-    f.plan = make_plan(nz); f.B = lines_per_group(nz); f.numOuter = 1; f.numInner = nx * ny;
-    f.inOuterStride = 0; f.inInnerStride = nz; f.inElemStride = 1;
-    f.outOuterStride = 0; f.outInnerStride = nzc; f.outElemStride = 1;
-    f.mode = 1; f.sign = -1; f.twiddle = (const float2*) pme->twiddle_z; f.in = pa.grid; f.out = cgrid;
     f.eterm = nullptr; f.energyBuffer = nullptr; f.energySlots = 1; f.nzFull = nz;
-    hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
-    // ---- forward y: for each x, tiles of kz
-    f.plan = make_plan(ny); f.B = lines_per_group(ny); f.numOuter = nx; f.numInner = nzc;
-    f.inOuterStride = (long long) ny * nzc; f.inInnerStride = 1; f.inElemStride = nzc;
-    f.outOuterStride = f.inOuterStride; f.outInnerStride = 1; f.outElemStride = nzc;
-    f.mode = 0; f.sign = -1; f.twiddle = (const float2*) pme->twiddle_y; f.in = cgrid; f.out = cgrid;
-    hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+    // ---- forward z (r2c) and y
+    launch_yz(pme, true, st);
     // ---- x: forward, multiply by the influence function (+ energy), backward -- one pass over HBM
     f.plan = make_plan(nx); f.B = lines_per_group(nx); f.numOuter = ny; f.numInner = nzc;
     f.inOuterStride = nzc; f.inInnerStride = 1; f.inElemStride = (long long) ny * nzc;
@@ -528,18 +626,8 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     f.mode = 3; f.sign = -1; f.twiddle = (const float2*) pme->twiddle_x; f.in = cgrid; f.out = cgrid;
     f.eterm = (const float*) pme->eterm; f.energyBuffer = include_energy ? energy_buffer_d : nullptr; f.energySlots = energy_slots;
     hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
-    // ---- backward y
-    f.plan = make_plan(ny); f.B = lines_per_group(ny); f.numOuter = nx; f.numInner = nzc;
-    f.inOuterStride = (long long) ny * nzc; f.inInnerStride = 1; f.inElemStride = nzc;
-    f.outOuterStride = f.inOuterStride; f.outInnerStride = 1; f.outElemStride = nzc;
-    f.mode = 0; f.sign = +1; f.twiddle = (const float2*) pme->twiddle_y; f.eterm = nullptr; f.energyBuffer = nullptr;
-    hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
-    // ---- backward z: complex [nx*ny][nzc] -> real [nx*ny][nz]
-    f.plan = make_plan(nz); f.B = lines_per_group(nz); f.numOuter = 1; f.numInner = nx * ny;
-    f.inOuterStride = 0; f.inInnerStride = nzc; f.inElemStride = 1;
-    f.outOuterStride = 0; f.outInnerStride = nz; f.outElemStride = 1;
-    f.mode = 2; f.sign = +1; f.twiddle = (const float2*) pme->twiddle_z; f.in = cgrid; f.out = pa.grid;
-    hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+    // ---- backward y and z (c2r)
+    launch_yz(pme, false, st);
 
     ommhip_profile_end(OMMHIP_TIMER_PME_FFT, stream);
     ommhip_profile_begin(OMMHIP_TIMER_PME_INTERPOLATE, stream);
@@ -577,7 +665,8 @@ extern "C" int ommhip_fft3d_r2c_c2r(const ommhip_pme* pme, int forward, void* st
         f.mode = 0; f.sign = sign; f.twiddle = (const float2*) pme->twiddle_x; f.in = cgrid; f.out = cgrid;
         hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
     };
-    if (forward) { zpass(true); ypass(-1); xpass(-1); }
-    else { xpass(+1); ypass(+1); zpass(false); }
+    (void) zpass; (void) ypass;
+    if (forward) { launch_yz(pme, true, st); xpass(-1); }
+    else { xpass(+1); launch_yz(pme, false, st); }
     return (int) hipGetLastError();
 }

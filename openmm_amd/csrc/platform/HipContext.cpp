@@ -45,6 +45,10 @@ HipContext::HipContext(const System& system, int deviceIndex, bool hostMode) : n
         throw OpenMMException("HIP platform: illegal DeviceIndex");
     HIP_CHECK(ommhip_set_device(deviceIndex));
     HIP_CHECK(ommhip_stream_create(&stream));
+    HIP_CHECK(ommhip_stream_create(&pmeStream));
+    HIP_CHECK(ommhip_event_create(&pmeForkEvent));
+    HIP_CHECK(ommhip_event_create(&pmeDoneEvent));
+    usePmeStream = true;
     paddedAtoms = ((numAtoms + OMMHIP_TILE - 1) / OMMHIP_TILE) * OMMHIP_TILE;
     if (paddedAtoms == 0) paddedAtoms = OMMHIP_TILE;
     masses.resize(numAtoms);
@@ -84,6 +88,9 @@ HipContext::HipContext(const System& system, int deviceIndex, bool hostMode) : n
 
 HipContext::~HipContext() {
     if (pinnedResult != NULL) ommhip_host_free(pinnedResult);
+    if (pmeForkEvent != NULL) ommhip_event_destroy(pmeForkEvent);
+    if (pmeDoneEvent != NULL) ommhip_event_destroy(pmeDoneEvent);
+    if (pmeStream != NULL) ommhip_stream_destroy(pmeStream);
     if (stream != NULL) ommhip_stream_destroy(stream);
 }
 
@@ -92,6 +99,7 @@ void HipContext::setAsCurrent() {
 }
 
 void HipContext::sync() {
+    joinPme();
     HIP_CHECK(ommhip_stream_sync(stream));
 }
 
@@ -171,6 +179,22 @@ void HipContext::setBox(const Vec3& a, const Vec3& b, const Vec3& c) {
 void HipContext::clearForces() {
     // the force accumulator and (if a PME kernel registered one) the charge grid are zeroed by one launch
     HIP_CHECK(ommhip_clear2(force.ptr, force.bytes, extraClearPtr, extraClearBytes, stream));
+}
+
+void HipContext::forkPme() {
+    HIP_CHECK(ommhip_event_record(pmeForkEvent, stream));
+    HIP_CHECK(ommhip_stream_wait_event(pmeStream, pmeForkEvent));
+}
+
+void HipContext::markPmeDone() {
+    HIP_CHECK(ommhip_event_record(pmeDoneEvent, pmeStream));
+    pmeJoinPending = true;
+}
+
+void HipContext::joinPme() {
+    if (!pmeJoinPending) return;
+    HIP_CHECK(ommhip_stream_wait_event(stream, pmeDoneEvent));
+    pmeJoinPending = false;
 }
 
 void HipContext::addTerms(const ommhip_term_batch& batch, bool includeEnergy) {

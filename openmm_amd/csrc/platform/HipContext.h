@@ -78,6 +78,14 @@ public:
     void* extraClearPtr = NULL;
     size_t extraClearBytes = 0;
     /** Queue a per-term force list; all queued lists go out in one launch (flushTerms, called by finishComputation). */
+    /** Side stream for PME reciprocal space (runs concurrently with the direct-space kernels; cf. the DisablePmeStream
+     *  property of the CUDA platform, CudaKernels.cpp:728,851-868).  forkPme(): the side stream waits for everything
+     *  enqueued so far on the main stream; joinPme(): the main stream waits for the side stream's work. */
+    void* pmeStream;
+    bool usePmeStream;
+    void forkPme();
+    void markPmeDone();
+    void joinPme();
     void addTerms(const ommhip_term_batch& batch, bool includeEnergy);
     void flushTerms();
     void saveForces();                                         // device copy of the force buffer (energy-only evaluations)
@@ -115,6 +123,9 @@ public:
 private:
     void computeOrder(const std::vector<Vec3>& positions, std::vector<int>& order, std::vector<int>& wrapOut);
     std::vector<HipContextListener*> listeners;
+    void* pmeForkEvent = NULL;
+    void* pmeDoneEvent = NULL;
+    bool pmeJoinPending = false;
     std::vector<ommhip_term_batch> pendingTerms;
     bool pendingTermsEnergy = false;
     bool reorderRequested;

@@ -215,6 +215,7 @@ void HipCalcForcesAndEnergyKernel::beginComputation(ContextImpl& context, bool i
 double HipCalcForcesAndEnergyKernel::finishComputation(ContextImpl& context, bool includeForce, bool includeEnergy, int groups, bool& valid) {
     HipContext& hip = *data.hip;
     hip.flushTerms();
+    hip.joinPme();
     double energy = 0;
     if (includeEnergy) energy = hip.reduceEnergy();
     if (hip.hostMode) {
@@ -681,6 +682,22 @@ void HipCalcNonbondedForceKernel::computeParameters(ContextImpl& context, bool f
     slotParamsDirty = true;
 }
 
+void HipCalcNonbondedForceKernel::launchPme(int includeEnergy) {
+    for (int i = 0; i < 6; i++) pme.box[i] = hip.box[i];
+    if (etermDirty) {
+        HIP_CHECK(ommhip_pme_build_eterm(&pme, hip.stream));
+        etermDirty = false;
+    }
+    if (hip.usePmeStream) {
+        // reciprocal space runs on the side stream, concurrently with whatever the main stream does next
+        hip.forkPme();
+        HIP_CHECK(ommhip_pme_reciprocal(&pme, posq.ptr, hip.paddedAtoms, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy, hip.pmeStream));
+        hip.markPmeDone();
+    }
+    else
+        HIP_CHECK(ommhip_pme_reciprocal(&pme, posq.ptr, hip.paddedAtoms, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy, hip.stream));
+}
+
 double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy, bool includeDirect, bool includeReciprocal) {
     hip.setAsCurrent();
     computeParameters(context, false);
@@ -700,6 +717,7 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
     }
     double energy = 0;
     const int ie = includeEnergy ? 1 : 0;
+    bool pmeLaunched = false;
     if (!includeDirect)
         HIP_CHECK(ommhip_positions_to_posq(hip.pos.ptr, hip.wrap.ptr, hip.atomOfSlot.as<int>(), hip.paddedAtoms, hip.box, posq.ptr, hip.stream));
     else {
@@ -726,6 +744,8 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
             if (pinnedState[2] == 0 && pinnedState[1] <= nl.max_chunks) { forceRebuild = false; break; }
             allocateNeighborList((int) (pinnedState[1] * 1.3) + 64);
         }
+        // posq is ready: start reciprocal space on the side stream BEFORE queueing the pair kernel, so the two overlap
+        if (includeReciprocal && nonbondedMethod == PME && hip.usePmeStream) { launchPme(ie); pmeLaunched = true; }
         HIP_CHECK(ommhip_nb_direct(&nl, &params, sigEps.ptr, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
         if ((++evaluationCount & 15) == 0) {
             HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
@@ -746,12 +766,7 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
     }
     if (includeReciprocal) {
         if (nonbondedMethod == PME) {
-            for (int i = 0; i < 6; i++) pme.box[i] = hip.box[i];
-            if (etermDirty) {
-                HIP_CHECK(ommhip_pme_build_eterm(&pme, hip.stream));
-                etermDirty = false;
-            }
-            HIP_CHECK(ommhip_pme_reciprocal(&pme, posq.ptr, hip.paddedAtoms, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+            if (!pmeLaunched) launchPme(ie);
         }
         else if (nonbondedMethod == Ewald) {
             if (hip.box[1] != 0.0 || hip.box[3] != 0.0 || hip.box[4] != 0.0)

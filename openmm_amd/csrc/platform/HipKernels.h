@@ -105,6 +105,7 @@ private:
     void computeParameters(ContextImpl& context, bool force);
     void allocateNeighborList(int maxChunks);
     void setupPme();
+    void launchPme(int includeEnergy);
     void rebuildEterm();
     int estimateChunks() const;
     HipPlatform::PlatformData& data;

@@ -119,12 +119,13 @@ def make_pme(K, ng, box3, alpha):
     return pm
 
 
-def run_fft(K, ng, seed=1):
+def run_fft(K, ng, seed=1, fft_mode=0):
     """-> (forward max error relative to max |ref|, round-trip max abs error)   pattern of TestCudaFFT3D.cpp:52-108"""
     rng = np.random.default_rng(seed)
     nx, ny, nz = ng
     nzc = nz // 2 + 1
     pm = make_pme(K, ng, np.eye(3) * 3.0, 3.0)
+    pm.fft_mode = fft_mode
     g = rng.normal(size=ng).astype(np.float32)
     K.memcpy_h2d(pm.grid_real, g.ctypes.data_as(C.c_void_p), g.nbytes, None)
     K.fft3d_r2c_c2r(C.byref(pm), 1, None)

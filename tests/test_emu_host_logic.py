@@ -39,8 +39,9 @@ def test_direct_space_kernel_logic(K, n, method, tric, switch):
 
 @needs_emu
 @pytest.mark.parametrize("ng", [(8, 6, 10), (28, 25, 30), (21, 20, 18)])
-def test_fft_logic(K, ng):
-    fwd, back = KC.run_fft(K, ng)
+@pytest.mark.parametrize("fft_mode", [0, 1])
+def test_fft_logic(K, ng, fft_mode):
+    fwd, back = KC.run_fft(K, ng, fft_mode=fft_mode)
     assert fwd < 1e-5 and back < 1e-5
 
 

@@ -43,8 +43,10 @@ def test_direct_space_kernel_launch_shape_independent(K):
 
 
 @pytest.mark.parametrize("ng", [(8, 6, 10), (28, 25, 30), (25, 28, 25), (21, 20, 18), (56, 56, 56), (64, 60, 72), (98, 98, 70), (96, 96, 96)])
-def test_fft3d_against_numpy(K, ng):
-    fwd, back = KC.run_fft(K, ng)
+@pytest.mark.parametrize("fft_mode", [0, 1])
+def test_fft3d_against_numpy(K, ng, fft_mode):
+    # fft_mode 0 uses the fused LDS plane kernel where a plane fits; 1 forces the three separate line passes
+    fwd, back = KC.run_fft(K, ng, fft_mode=fft_mode)
     assert fwd < 1e-5 and back < 1e-5
 
 

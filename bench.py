@@ -54,11 +54,11 @@ def make_workload(name, seed):
     return T.water_box(32, seed=seed)
 
 
-def run_platform(w, platform, dt_ps, steps, warmup, props=None):
+def run_platform(w, platform, dt_ps, steps, warmup, props=None, seed=1):
     """-> (seconds for `steps`, final State, context)"""
     from openmm_amd import harness as H
     system, nb = w.build()
-    integ = H.Integrator(H.LANGEVIN_MIDDLE, dt_ps, 300.0, 1.0, seed=1, constraintTolerance=1e-5)
+    integ = H.Integrator(H.LANGEVIN_MIDDLE, dt_ps, 300.0, 1.0, seed=seed, constraintTolerance=1e-5)
     ctx = H.Context(system, integ, platform, props)
     ctx.setPositions(w.positions)
     ctx.applyConstraints(1e-5)
@@ -90,12 +90,12 @@ def main():
     plugin = C.CDLL(os.path.join(H.LIB_DIR, "libOpenMMHIP.so"))
 
     dt_ps = args.dt_fs * 1e-3
-    w = make_workload(args.workload, seed=1 + rank)
+    w = make_workload(args.workload, seed=1)        # every replica starts from the equilibrated fixture; the thermostat seeds differ
     props = {"DeviceIndex": str(local_rank)}
     for kv in filter(None, args.props.split(",")):
         k, v = kv.split("=")
         props[k] = v
-    system, nb, integ, ctx = run_platform(w, "HIP", dt_ps, 0, args.warmup, props)
+    system, nb, integ, ctx = run_platform(w, "HIP", dt_ps, 0, args.warmup, props, seed=1 + rank)
     device_name = ctx.getPlatformProperty("DeviceName")
 
     def barrier():

@@ -741,8 +741,10 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
             // host-requested rebuild: verify the capacity synchronously
             HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
             hip.sync();
-            if (pinnedState[2] == 0 && pinnedState[1] <= nl.max_chunks) { forceRebuild = false; break; }
-            allocateNeighborList((int) (pinnedState[1] * 1.3) + 64);
+            // Keep 1.5x headroom over the measured list length: later (device-triggered) rebuilds are only checked
+            // lazily, so the list must never come close to its capacity through ordinary density fluctuations.
+            if (pinnedState[2] == 0 && pinnedState[1] * 1.5 <= nl.max_chunks) { forceRebuild = false; break; }
+            allocateNeighborList((int) (pinnedState[1] * 1.6) + 64);
         }
         // posq is ready: start reciprocal space on the side stream BEFORE queueing the pair kernel, so the two overlap
         if (includeReciprocal && nonbondedMethod == PME && hip.usePmeStream) { launchPme(ie); pmeLaunched = true; }

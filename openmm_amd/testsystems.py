@@ -208,12 +208,14 @@ def dhfr_like(seed=1, n_side=22, chain_atoms=2489, relaxed=True):
             placed_h.append(best)
             bonds.append((idx, len(pos)))
             pos.append(best); masses.append(1.008); is_h.append(True)
-            charge.append(rng.normal(0, 0.1)); sigma.append(0.107); eps.append(0.066)
+            # hydrogens carry positive partial charges only (as in protein force fields): a negative hydrogen has no
+            # LJ core to stop it from collapsing onto a positive one
+            charge.append(0.03 + abs(rng.normal(0, 0.1))); sigma.append(0.107); eps.append(0.066)
     pos = np.array(pos)[:chain_atoms]
     nc = len(pos)
     masses, charge, sigma, eps, is_h = [np.array(x)[:nc] for x in (masses, charge, sigma, eps, is_h)]
     bonds = np.array([b for b in bonds if b[0] < nc and b[1] < nc])
-    charge -= charge.mean()
+    charge[~is_h] -= charge.sum() / np.count_nonzero(~is_h)      # neutral chain, compensated on the heavy atoms
     # --- waters on a lattice, skipping sites that overlap the chain
     n_water = (n_target - nc) // 3
     spacing = L / n_side

@@ -41,6 +41,7 @@ def parse_args():
     p.add_argument("--workload", default="dhfr", choices=["dhfr", "water24k", "water98k"])
     p.add_argument("--cpu-steps", type=int, default=150, help="steps of the CPU-platform baseline (0 disables)")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--profile-every", type=int, default=8, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region")
     p.add_argument("--props", default="", help="extra HIP platform properties, e.g. DisablePmeStream=true")
     return p.parse_args()
 
@@ -107,7 +108,7 @@ def main():
     profile = not args.no_roofline
     if profile:
         kernels.lib.ommhip_profile_reset()
-        kernels.lib.ommhip_profile_enable(1)
+        kernels.lib.ommhip_profile_enable(max(1, args.profile_every))
     barrier()
     t0 = time.perf_counter()
     integ.step(args.steps)

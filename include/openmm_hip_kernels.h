@@ -64,7 +64,7 @@ enum {
     OMMHIP_TIMER_PME_INTERPOLATE = 4,
     OMMHIP_PROFILE_NUM_TIMERS = 8
 };
-int ommhip_profile_enable(int enabled);
+int ommhip_profile_enable(int every);   /* 0 = off; n >= 1 = time every n-th launch of each timer */
 int ommhip_profile_reset(void);
 int ommhip_profile_begin(int timer, void* stream);
 int ommhip_profile_end(int timer, void* stream);
@@ -245,6 +245,25 @@ enum {
     OMMHIP_STAGE_LMIDDLE_3 = 5          /* v += (xp - oldx)/dt ; x = xp */
 };
 int ommhip_integrate_stage(int stage, const ommhip_integrator_state* s, void* stream);
+
+/* Whole step in ONE launch when every constraint belongs to a SETTLE water or a SHAKE cluster: one thread per
+ * integration unit runs the stages above plus the constraint solves in registers (same arithmetic and order).
+ * Every atom must belong to exactly one unit.  If cm_scratch is not NULL the kernel leaves the total momentum of
+ * the new velocities in cm_scratch[0..2] (fixed summation order), and with remove_cm != 0 it first subtracts
+ * cm_scratch[0..2] * inv_total_mass from every velocity -- the CMMotionRemover of this step
+ * (ReferenceKernels.cpp:2705-2740), valid when the velocities were not touched since the previous fused step. */
+typedef struct ommhip_step_units {
+    int num_units;
+    const int* atoms;          /* int4 per unit: (a0,a1,a2,a3), unused = -1; SETTLE a0 = apex, SHAKE a0 = centre */
+    const double* dist;        /* double4 per unit: SETTLE (d01,d12,-,1), SHAKE (d1,d2,d3,2), single atom (-,-,-,0) */
+    double tol;                /* constraint tolerance (SHAKE iteration) */
+    int max_iterations;
+    int remove_cm;
+    double inv_total_mass;
+    double* cm_scratch;        /* 4 + 4*ceil(num_units/128) doubles, zero-initialised once; or NULL */
+} ommhip_step_units;
+enum { OMMHIP_INTEGRATOR_VERLET = 0, OMMHIP_INTEGRATOR_LANGEVIN = 1, OMMHIP_INTEGRATOR_LANGEVIN_MIDDLE = 2 };
+int ommhip_integrate_fused(int integrator, const ommhip_integrator_state* s, const ommhip_step_units* u, void* stream);
 /* out_d (double4[num_atoms]) = vel + force*shift/m   (ReferenceKernels.cpp:146-160) */
 int ommhip_shifted_velocities(const ommhip_integrator_state* s, double shift, void* out_d, void* stream);
 /* result_d[0] = 1/2 sum m v^2 */

@@ -41,13 +41,15 @@ __device__ __forceinline__ void philox4x32(unsigned (&c)[4], unsigned k0, unsign
 __device__ __forceinline__ double3 gaussian3(unsigned atom, unsigned long long step, unsigned long long seed) {
     unsigned c[4] = {atom, (unsigned) step, (unsigned) (step >> 32), 0x4f4d4d48u};
     philox4x32(c, (unsigned) seed, (unsigned) (seed >> 32));
-    const double inv32 = 1.0 / 4294967296.0;
-    double u0 = ((double) c[0] + 0.5) * inv32, u1 = ((double) c[1] + 0.5) * inv32;
-    double u2 = ((double) c[2] + 0.5) * inv32, u3 = ((double) c[3] + 0.5) * inv32;
-    double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
-    double s0, c0, s1, c1;
-    sincos(6.28318530717958647692 * u1, &s0, &c0);
-    sincos(6.28318530717958647692 * u3, &s1, &c1);
+    // Box-Muller in single precision (the deviates only feed the thermostat; the reference GPU platforms draw their
+    // normals in float as well), accumulated into the double-precision velocities by the caller.
+    const float inv32 = 1.0f / 4294967296.0f;
+    const float u0 = fmaxf(((float) c[0] + 0.5f) * inv32, 1.0e-10f), u1 = ((float) c[1]) * inv32;
+    const float u2 = fmaxf(((float) c[2] + 0.5f) * inv32, 1.0e-10f), u3 = ((float) c[3]) * inv32;
+    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    float s0, c0, s1, c1;
+    sincosf(6.2831853071795865f * u1, &s0, &c0);
+    sincosf(6.2831853071795865f * u3, &s1, &c1);
     (void) s1;
     return make_double3(r0 * c0, r0 * s0, r1 * c1);
 }
@@ -197,19 +199,16 @@ __device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y
 __device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 __device__ __forceinline__ V3 xyz(double4 p) { return v3(p.x, p.y, p.z); }
 
-// Same algebra as ReferenceSETTLEAlgorithm.cpp:54-195, written with vectors.
-__device__ __forceinline__ void settle_positions_cluster(const SettleArgs& a, int c) {
-    const int4 at = a.atoms[c];
-    const double2 dd = a.dist[c];
-    const V3 p0 = xyz(a.pos[at.x]), p1 = xyz(a.pos[at.y]), p2 = xyz(a.pos[at.z]);
-    const double4 q0 = a.xp[at.x], q1 = a.xp[at.y], q2 = a.xp[at.z];
-    const double iw0 = a.velMass[at.x].w, iw1 = a.velMass[at.y].w, iw2 = a.velMass[at.z].w;
-    const double m0 = 1.0 / iw0, m1 = 1.0 / iw1, m2 = 1.0 / iw2;
+// Same algebra as ReferenceSETTLEAlgorithm.cpp:54-195, written with vectors.  Register form: p = constrained
+// positions before the step, q = trial positions (corrected in place), m = masses, (d01, d12) = leg and base lengths.
+__device__ __forceinline__ void settle_positions_regs(const V3 p0, const V3 p1, const V3 p2, V3& q0, V3& q1, V3& q2,
+                                                      const double m0, const double m1, const double m2, const double d01, const double d12) {
+    const double2 dd = make_double2(d01, d12);
     // everything relative to the old apex position
     const V3 b0 = p1 - p0, c0 = p2 - p0;
-    const V3 d0 = xyz(q0) - p0;                   // trial apex
-    const V3 d1 = b0 + (xyz(q1) - p1);            // trial leg atoms
-    const V3 d2 = c0 + (xyz(q2) - p2);
+    const V3 d0 = q0 - p0;                        // trial apex
+    const V3 d1 = b0 + (q1 - p1);                 // trial leg atoms
+    const V3 d2 = c0 + (q2 - p2);
     const double invM = 1.0 / (m0 + m1 + m2);
     const V3 com = (d0 * m0 + d1 * m1 + d2 * m2) * invM;
     const V3 a1 = d0 - com, b1 = d1 - com, c1 = d2 - com;
@@ -251,26 +250,30 @@ __device__ __forceinline__ void settle_positions_cluster(const SettleArgs& a, in
     const V3 a3 = ex * (-ya2 * sintheta) + ey * (ya2 * costheta) + ez * za1;
     const V3 b3 = ex * (xb2 * costheta - yb2 * sintheta) + ey * (xb2 * sintheta + yb2 * costheta) + ez * zb1;
     const V3 c3 = ex * (-xb2 * costheta - yc2 * sintheta) + ey * (-xb2 * sintheta + yc2 * costheta) + ez * zc1;
-    const V3 n0 = p0 + com + a3;
-    const V3 n1 = p1 + (com + b3 - b0);
-    const V3 n2 = p2 + (com + c3 - c0);
+    q0 = p0 + com + a3;
+    q1 = p1 + (com + b3 - b0);
+    q2 = p2 + (com + c3 - c0);
+}
+__device__ __forceinline__ void settle_positions_cluster(const SettleArgs& a, int c) {
+    const int4 at = a.atoms[c];
+    const double2 dd = a.dist[c];
+    const double4 q0 = a.xp[at.x], q1 = a.xp[at.y], q2 = a.xp[at.z];
+    V3 n0 = xyz(q0), n1 = xyz(q1), n2 = xyz(q2);
+    settle_positions_regs(xyz(a.pos[at.x]), xyz(a.pos[at.y]), xyz(a.pos[at.z]), n0, n1, n2,
+                          1.0 / a.velMass[at.x].w, 1.0 / a.velMass[at.y].w, 1.0 / a.velMass[at.z].w, dd.x, dd.y);
     a.xp[at.x] = make_double4(n0.x, n0.y, n0.z, q0.w);
     a.xp[at.y] = make_double4(n1.x, n1.y, n1.z, q1.w);
     a.xp[at.z] = make_double4(n2.x, n2.y, n2.z, q2.w);
 }
 
 // ReferenceSETTLEAlgorithm.cpp:197-244 (unequal-mass velocity solve)
-__device__ __forceinline__ void settle_velocities_cluster(const SettleArgs& a, int c) {
-    const int4 at = a.atoms[c];
-    const V3 p0 = xyz(a.pos[at.x]), p1 = xyz(a.pos[at.y]), p2 = xyz(a.pos[at.z]);
-    double4 w0 = a.vel[at.x], w1 = a.vel[at.y], w2 = a.vel[at.z];
-    const double iA = a.velMass[at.x].w, iB = a.velMass[at.y].w, iC = a.velMass[at.z].w;
+__device__ __forceinline__ void settle_velocities_regs(const V3 p0, const V3 p1, const V3 p2, V3& v0, V3& v1, V3& v2,
+                                                       const double iA, const double iB, const double iC) {
     const double mA = 1.0 / iA, mB = 1.0 / iB, mC = 1.0 / iC;
     V3 eAB = p1 - p0, eBC = p2 - p1, eCA = p0 - p2;
     eAB = eAB * (1.0 / sqrt(dot(eAB, eAB)));
     eBC = eBC * (1.0 / sqrt(dot(eBC, eBC)));
     eCA = eCA * (1.0 / sqrt(dot(eCA, eCA)));
-    V3 v0 = xyz(w0), v1 = xyz(w1), v2 = xyz(w2);
     const double vAB = dot(v1 - v0, eAB), vBC = dot(v2 - v1, eBC), vCA = dot(v0 - v2, eCA);
     const double cA = -dot(eAB, eCA), cB = -dot(eAB, eBC), cC = -dot(eBC, eCA);
     const double s2A = 1 - cA * cA, s2B = 1 - cB * cB, s2C = 1 - cC * cC;
@@ -282,6 +285,12 @@ __device__ __forceinline__ void settle_velocities_cluster(const SettleArgs& a, i
     v0 = v0 + (eAB * tab - eCA * tca) * iA;
     v1 = v1 + (eBC * tbc - eAB * tab) * iB;
     v2 = v2 + (eCA * tca - eBC * tbc) * iC;
+}
+__device__ __forceinline__ void settle_velocities_cluster(const SettleArgs& a, int c) {
+    const int4 at = a.atoms[c];
+    const double4 w0 = a.vel[at.x], w1 = a.vel[at.y], w2 = a.vel[at.z];
+    V3 v0 = xyz(w0), v1 = xyz(w1), v2 = xyz(w2);
+    settle_velocities_regs(xyz(a.pos[at.x]), xyz(a.pos[at.y]), xyz(a.pos[at.z]), v0, v1, v2, a.velMass[at.x].w, a.velMass[at.y].w, a.velMass[at.z].w);
     a.vel[at.x] = make_double4(v0.x, v0.y, v0.z, w0.w);
     a.vel[at.y] = make_double4(v1.x, v1.y, v1.z, w1.w);
     a.vel[at.z] = make_double4(v2.x, v2.y, v2.z, w2.w);
@@ -302,32 +311,16 @@ struct ShakeArgs {
     const double4* velMass;
 };
 
+// Register form: r[k] = x_centre - x_satellite k (constrained positions before the step), t0 / t[k] = the vectors being
+// corrected (trial positions or velocities), iw = inverse masses, n = number of satellites.
 template <bool VELOCITIES>
-__device__ __forceinline__ void shake_cluster(const ShakeArgs& a, int c) {
-    const int4 at = a.atoms[c];
-    const double4 dd = a.dist[c];
-    const int sat[3] = {at.y, at.z, at.w};
-    const double dist[3] = {dd.x, dd.y, dd.z};
-    const V3 x0 = xyz(a.pos[at.x]);
-    const double iw0 = a.velMass[at.x].w;
-    double4 t0w = a.target[at.x];
-    V3 t0 = xyz(t0w);
-    V3 r[3], t[3];
-    double iw[3], rr[3], tw[3];
-    int n = 0;
+__device__ __forceinline__ void shake_regs(const V3 (&r)[3], V3& t0, V3 (&t)[3], const double iw0, const double (&iw)[3],
+                                           const double (&dist)[3], const int n, const double tol, const int maxIterations) {
+    double rr[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        if (sat[k] >= 0) {
-            r[k] = x0 - xyz(a.pos[sat[k]]);
-            double4 tt = a.target[sat[k]];
-            t[k] = xyz(tt); tw[k] = tt.w;
-            iw[k] = a.velMass[sat[k]].w;
-            rr[k] = dot(r[k], r[k]);
-            n = k + 1;
-        }
-    }
-    const double lowerTol = 1 - 2 * a.tol + a.tol * a.tol, upperTol = 1 + 2 * a.tol + a.tol * a.tol;
-    for (int iter = 0; iter < a.maxIterations; iter++) {
+    for (int k = 0; k < 3; k++) rr[k] = k < n ? dot(r[k], r[k]) : 1.0;
+    const double lowerTol = 1 - 2 * tol + tol * tol, upperTol = 1 + 2 * tol + tol * tol;
+    for (int iter = 0; iter < maxIterations; iter++) {
         bool converged = true;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -337,7 +330,7 @@ __device__ __forceinline__ void shake_cluster(const ShakeArgs& a, int c) {
                 double delta;
                 if (VELOCITIES) {
                     delta = -2.0 * reduced * dot(rp, r[k]) / rr[k];
-                    if (fabs(delta) > a.tol) converged = false; else delta = 0.0;
+                    if (fabs(delta) > tol) converged = false; else delta = 0.0;
                 }
                 else {
                     const double rp2 = dot(rp, rp), d2 = dist[k] * dist[k];
@@ -350,10 +343,159 @@ __device__ __forceinline__ void shake_cluster(const ShakeArgs& a, int c) {
         }
         if (converged) break;
     }
+}
+
+template <bool VELOCITIES>
+__device__ __forceinline__ void shake_cluster(const ShakeArgs& a, int c) {
+    const int4 at = a.atoms[c];
+    const double4 dd = a.dist[c];
+    const int sat[3] = {at.y, at.z, at.w};
+    const double dist[3] = {dd.x, dd.y, dd.z};
+    const V3 x0 = xyz(a.pos[at.x]);
+    const double iw0 = a.velMass[at.x].w;
+    double4 t0w = a.target[at.x];
+    V3 t0 = xyz(t0w);
+    V3 r[3], t[3];
+    double iw[3], tw[3];
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        r[k] = v3(0, 0, 0); t[k] = v3(0, 0, 0); iw[k] = 0; tw[k] = 0;
+        if (sat[k] >= 0) {
+            r[k] = x0 - xyz(a.pos[sat[k]]);
+            double4 tt = a.target[sat[k]];
+            t[k] = xyz(tt); tw[k] = tt.w;
+            iw[k] = a.velMass[sat[k]].w;
+            n = k + 1;
+        }
+    }
+    shake_regs<VELOCITIES>(r, t0, t, iw0, iw, dist, n, a.tol, a.maxIterations);
     a.target[at.x] = make_double4(t0.x, t0.y, t0.z, t0w.w);
 #pragma unroll
     for (int k = 0; k < 3; k++)
         if (k < n) a.target[sat[k]] = make_double4(t[k].x, t[k].y, t[k].z, tw[k]);
+}
+
+// ================================================================================================
+// Fused step: one thread integrates one *unit* -- a SETTLE water, a SHAKE cluster or a single unconstrained
+// atom -- through the whole update (force kick, velocity constraints, drift + thermostat, position constraints,
+// velocity correction), entirely in registers.  Replaces 5 launches (7 with the CM-motion remover, whose
+// momentum sum for the next step is accumulated here).  Same arithmetic, in the same order, as the staged kernels.
+//   KIND 0: ReferenceVerletDynamics.cpp:76-119   1: ReferenceStochasticDynamics.cpp:89-194
+//   KIND 2: ReferenceLangevinMiddleDynamics.cpp:54-127
+// ================================================================================================
+struct UnitArgs {
+    int numUnits, maxIterations, removeCm;
+    double tol, invTotalMass;
+    const int4* atoms;        // (a0, a1, a2, a3), unused = -1; SETTLE: a0 = apex; SHAKE: a0 = centre
+    const double4* dist;      // SETTLE (d01, d12, -, 1); SHAKE (d1, d2, d3, 2); free atom (-, -, -, 0)
+    double* cm;               // [0..2] momentum after the previous fused step, [3] block counter (as int), [4 + 4*block] partials
+};
+
+template <int KIND>
+__global__ __launch_bounds__(128) void k_step_units(IntArgs a, UnitArgs u) {
+    const int c = blockIdx.x * 128 + threadIdx.x;
+    V3 mom = v3(0, 0, 0);
+    if (c < u.numUnits) {
+        const int4 at = u.atoms[c];
+        const double4 dd = u.dist[c];
+        const int kind = (int) dd.w;
+        const int ids[4] = {at.x, at.y, at.z, at.w};
+        V3 x[4], v[4], xn[4], ox[4];
+        double w[4], xw[4];
+        V3 cmv = v3(0, 0, 0);
+        if (u.removeCm) cmv = v3(u.cm[0] * u.invTotalMass, u.cm[1] * u.invTotalMass, u.cm[2] * u.invTotalMass);
+        const double h = 0.5 * a.dt;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            x[k] = v3(0, 0, 0); v[k] = v3(0, 0, 0); w[k] = 0; xw[k] = 0;
+            if (ids[k] >= 0) {
+                const double4 p = a.pos[ids[k]], vv = a.vel[ids[k]];
+                x[k] = xyz(p); xw[k] = p.w; v[k] = xyz(vv); w[k] = vv.w;
+                if (w[k] != 0.0) {
+                    v[k] = v[k] - cmv;                       // CMMotionRemover of this step (ReferenceKernels.cpp:2705-2740)
+                    const double3 f = load_force(a, ids[k]);
+                    if (KIND == 0 || KIND == 2) { v[k].x += a.dt * w[k] * f.x; v[k].y += a.dt * w[k] * f.y; v[k].z += a.dt * w[k] * f.z; }
+                    if (KIND == 1) {
+                        const double3 g = gaussian3((unsigned) ids[k], a.step, a.seed);
+                        const double sq = sqrt(w[k]);
+                        v[k].x = a.vscale * v[k].x + a.fscale * w[k] * f.x + a.noisescale * sq * g.x;
+                        v[k].y = a.vscale * v[k].y + a.fscale * w[k] * f.y + a.noisescale * sq * g.y;
+                        v[k].z = a.vscale * v[k].z + a.fscale * w[k] * f.z + a.noisescale * sq * g.z;
+                    }
+                }
+            }
+            xn[k] = x[k]; ox[k] = x[k];
+        }
+        V3 r[3];
+        double iws[3] = {w[1], w[2], w[3]};
+        const double dist[3] = {dd.x, dd.y, dd.z};
+        int n = 0;
+        if (kind == 2) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { r[k] = x[0] - x[k + 1]; if (ids[k + 1] >= 0) n = k + 1; }
+        }
+        if (KIND == 2) {
+            // velocity constraints on the kicked velocities (ReferenceLangevinMiddleDynamics.cpp:104)
+            if (kind == 1) settle_velocities_regs(x[0], x[1], x[2], v[0], v[1], v[2], w[0], w[1], w[2]);
+            else if (kind == 2) { V3 t[3] = {v[1], v[2], v[3]}; shake_regs<true>(r, v[0], t, w[0], iws, dist, n, u.tol, u.maxIterations); v[1] = t[0]; v[2] = t[1]; v[3] = t[2]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (ids[k] >= 0 && w[k] != 0.0) {
+                if (KIND == 2) {
+                    xn[k] = x[k] + v[k] * h;
+                    const double3 g = gaussian3((unsigned) ids[k], a.step, a.seed);
+                    const double sq = sqrt(w[k]);
+                    v[k].x = a.vscale * v[k].x + a.noisescale * sq * g.x;
+                    v[k].y = a.vscale * v[k].y + a.noisescale * sq * g.y;
+                    v[k].z = a.vscale * v[k].z + a.noisescale * sq * g.z;
+                    xn[k] = xn[k] + v[k] * h;
+                    ox[k] = xn[k];
+                }
+                else xn[k] = x[k] + v[k] * a.dt;
+            }
+        }
+        // position constraints against the positions at the start of the step
+        if (kind == 1) settle_positions_regs(x[0], x[1], x[2], xn[0], xn[1], xn[2], 1.0 / w[0], 1.0 / w[1], 1.0 / w[2], dd.x, dd.y);
+        else if (kind == 2) { V3 t[3] = {xn[1], xn[2], xn[3]}; shake_regs<false>(r, xn[0], t, w[0], iws, dist, n, u.tol, u.maxIterations); xn[1] = t[0]; xn[2] = t[1]; xn[3] = t[2]; }
+        const double inv = 1.0 / a.dt;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (ids[k] >= 0 && w[k] != 0.0) {
+                if (KIND == 2) v[k] = v[k] + (xn[k] - ox[k]) * inv;
+                else v[k] = (xn[k] - x[k]) * inv;
+                a.vel[ids[k]] = make_double4(v[k].x, v[k].y, v[k].z, w[k]);
+                a.pos[ids[k]] = make_double4(xn[k].x, xn[k].y, xn[k].z, xw[k]);
+                mom = mom + v[k] * (1.0 / w[k]);
+            }
+        }
+    }
+    // ---- momentum of the new velocities, for the CMMotionRemover of the next step
+    if (u.cm == nullptr) return;
+    __shared__ double part[2][3];
+    __shared__ bool last;
+    mom.x = wave_sum(mom.x); mom.y = wave_sum(mom.y); mom.z = wave_sum(mom.z);
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = mom.x; part[threadIdx.x >> 6][1] = mom.y; part[threadIdx.x >> 6][2] = mom.z; }
+    __syncthreads();
+    int* counter = (int*) (u.cm + 3);
+    if (threadIdx.x == 0) {
+        double* out = u.cm + 4 + 4 * blockIdx.x;
+        out[0] = part[0][0] + part[1][0]; out[1] = part[0][1] + part[1][1]; out[2] = part[0][2] + part[1][2];
+        __threadfence();
+        last = atomicAdd(counter, 1) == (int) gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x < 64) {
+        // fixed summation order -> the same bits whatever the block scheduling
+        double sx = 0, sy = 0, sz = 0;
+        for (int b = threadIdx.x; b < (int) gridDim.x; b += 64) {
+            const volatile double* in = u.cm + 4 + 4 * b;
+            sx += in[0]; sy += in[1]; sz += in[2];
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+        if (threadIdx.x == 0) { u.cm[0] = sx; u.cm[1] = sy; u.cm[2] = sz; *counter = 0; }
+    }
 }
 
 // One launch for both cluster kinds: workgroups [0, shakeBlocks) iterate SHAKE clusters, the rest SETTLE waters.
@@ -458,6 +600,24 @@ extern "C" int ommhip_integrate_stage(int stage, const ommhip_integrator_state* 
         case OMMHIP_STAGE_LMIDDLE_1: hipLaunchKernelGGL(k_lmiddle_part1, grid_for(a.numAtoms), BLOCK128, 0, st, a); break;
         case OMMHIP_STAGE_LMIDDLE_2: hipLaunchKernelGGL(k_lmiddle_part2, grid_for(a.numAtoms), BLOCK128, 0, st, a); break;
         case OMMHIP_STAGE_LMIDDLE_3: hipLaunchKernelGGL(k_lmiddle_part3, grid_for(a.numAtoms), BLOCK128, 0, st, a); break;
+        default: return 1;
+    }
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_integrate_fused(int integrator, const ommhip_integrator_state* s, const ommhip_step_units* units, void* stream) {
+    IntArgs a = make_int_args(s);
+    if (units->num_units <= 0) return 0;
+    UnitArgs u;
+    u.numUnits = units->num_units; u.maxIterations = units->max_iterations; u.removeCm = units->remove_cm;
+    u.tol = units->tol; u.invTotalMass = units->inv_total_mass;
+    u.atoms = (const int4*) units->atoms; u.dist = (const double4*) units->dist; u.cm = units->cm_scratch;
+    hipStream_t st = (hipStream_t) stream;
+    const dim3 grid = grid_for(u.numUnits);
+    switch (integrator) {
+        case OMMHIP_INTEGRATOR_VERLET: hipLaunchKernelGGL(k_step_units<0>, grid, BLOCK128, 0, st, a, u); break;
+        case OMMHIP_INTEGRATOR_LANGEVIN: hipLaunchKernelGGL(k_step_units<1>, grid, BLOCK128, 0, st, a, u); break;
+        case OMMHIP_INTEGRATOR_LANGEVIN_MIDDLE: hipLaunchKernelGGL(k_step_units<2>, grid, BLOCK128, 0, st, a, u); break;
         default: return 1;
     }
     return (int) hipGetLastError();

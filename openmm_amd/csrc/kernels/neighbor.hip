@@ -128,6 +128,12 @@ __global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
     const float4 cX = a.blockCenter[X], hX = a.blockHalf[X];
     const int2 exclRange = a.exclBlockRange != nullptr ? a.exclBlockRange[X] : make_int2(0, a.numBlocks);
     if (t == 0) { sCandCount = 0; sListCount = 0; sChunkBase = 0; }
+    // i atoms relative to the block centre.  When the block plus the list cutoff fits inside half a box length on
+    // every axis, the image of j nearest to the centre is also the image nearest to every i atom within range, so
+    // the exact test needs no per-pair image search (pairs beyond the list cutoff can only come out farther).
+    float rx = px.x - cX.x, ry = px.y - cX.y, rz = px.z - cX.z;
+    apply_pbc<PBC>(rx, ry, rz, a.box);
+    const bool singleImage = PBC == 0 || (PBC == 1 && hX.x + Rlist < 0.5f * a.box.ax && hX.y + Rlist < 0.5f * a.box.by && hX.z + Rlist < 0.5f * a.box.cz);
     __syncthreads();
 
     // Writes staged entries as rows.  final = false: only full rows, the remainder stays staged.
@@ -222,14 +228,25 @@ __global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
                 // exact test against the 32 atoms of X (same metric as the pair kernel); executed by every lane so
                 // that the v_readlane broadcasts sit in convergent code
                 bool any = false;
+                if (singleImage) {
 #pragma unroll
-                for (int k = 0; k < OMM_TILE; k++) {
-                    const float xi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px.x), k));
-                    const float yi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px.y), k));
-                    const float zi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px.z), k));
-                    float ex = pj.x - xi, ey = pj.y - yi, ez = pj.z - zi;
-                    apply_pbc<PBC>(ex, ey, ez, a.box);
-                    any = any || !(ex * ex + ey * ey + ez * ez >= R2);
+                    for (int k = 0; k < OMM_TILE; k++) {
+                        const float ex = dx - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rx), k));
+                        const float ey = dy - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ry), k));
+                        const float ez = dz - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rz), k));
+                        any = any || !(ex * ex + ey * ey + ez * ez >= R2);
+                    }
+                }
+                else {
+#pragma unroll
+                    for (int k = 0; k < OMM_TILE; k++) {
+                        const float xi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px.x), k));
+                        const float yi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px.y), k));
+                        const float zi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px.z), k));
+                        float ex = pj.x - xi, ey = pj.y - yi, ez = pj.z - zi;
+                        apply_pbc<PBC>(ex, ey, ez, a.box);
+                        any = any || !(ex * ex + ey * ey + ez * ez >= R2);
+                    }
                 }
                 unsigned mask = 0;
                 if (ok && near && any) {

@@ -321,7 +321,7 @@ __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2*
 #pragma unroll
     for (int m = 0; m < R; m++) { root[m] = tw[m * (n / R)]; root[m].y *= fsign; }
     const int twStep = n / (Ns * R);               // twiddle index increment per r
-    for (int idx = threadIdx.x; idx < butterflies * B; idx += FFT_THREADS) {
+    for (int idx = threadIdx.x; idx < butterflies * B; idx += (int) blockDim.x) {
         const int line = idx % B, j = idx / B;
         const int k = j % Ns;
         float2 v[R];
@@ -454,6 +454,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_kernel(FftArgs a) {
 // elements = z (stride ny+1); the y transform sees lines = kz (stride ny+1), elements = y (stride 1).
 // ------------------------------------------------------------------------------------------------
 #define PLANE_MAX 6144
+#define PLANE_THREADS 512     // one plane has ~400 butterflies per pass: 512 threads finish a pass in one sweep
 
 struct PlaneArgs {
     FftPlan planY, planZ;
@@ -463,18 +464,18 @@ struct PlaneArgs {
     float2* cplx;          // [nx][ny][nz/2+1]
 };
 
-__global__ __launch_bounds__(FFT_THREADS) void fft_plane_kernel(PlaneArgs a) {
+__global__ __launch_bounds__(PLANE_THREADS) void fft_plane_kernel(PlaneArgs a) {
     __shared__ float2 bufA[PLANE_MAX];
     __shared__ float2 bufB[PLANE_MAX];
     __shared__ float2 twYs[512];
     __shared__ float2 twZs[512];
     const int ny = a.ny, nz = a.nz, nzc = nz / 2 + 1, S = ny + 1;
     const int x = blockIdx.x;
-    for (int i = threadIdx.x; i < ny; i += FFT_THREADS) twYs[i] = a.twY[i];
-    for (int i = threadIdx.x; i < nz; i += FFT_THREADS) twZs[i] = a.twZ[i];
+    for (int i = threadIdx.x; i < ny; i += PLANE_THREADS) twYs[i] = a.twY[i];
+    for (int i = threadIdx.x; i < nz; i += PLANE_THREADS) twZs[i] = a.twZ[i];
     if (a.forward) {
         const float* in = a.real + (size_t) x * ny * nz;
-        for (int idx = threadIdx.x; idx < ny * nz; idx += FFT_THREADS) {
+        for (int idx = threadIdx.x; idx < ny * nz; idx += PLANE_THREADS) {
             const int y = idx / nz, z = idx % nz;
             bufA[z * S + y] = make_float2(in[idx], 0.f);
         }
@@ -483,21 +484,21 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_plane_kernel(PlaneArgs a) {
         float2* other = r1 == bufA ? bufB : bufA;
         float2* r2 = fft_lines(a.planY, r1, other, nzc, 1, -1, twYs, S);            // lines = kz < nzc, elements = y
         float2* out = a.cplx + (size_t) x * ny * nzc;
-        for (int idx = threadIdx.x; idx < ny * nzc; idx += FFT_THREADS) {
+        for (int idx = threadIdx.x; idx < ny * nzc; idx += PLANE_THREADS) {
             const int ky = idx / nzc, kz = idx % nzc;
             out[idx] = r2[kz * S + ky];
         }
     }
     else {
         const float2* in = a.cplx + (size_t) x * ny * nzc;
-        for (int idx = threadIdx.x; idx < ny * nzc; idx += FFT_THREADS) {
+        for (int idx = threadIdx.x; idx < ny * nzc; idx += PLANE_THREADS) {
             const int ky = idx / nzc, kz = idx % nzc;
             bufA[kz * S + ky] = in[idx];
         }
         __syncthreads();
         float2* r1 = fft_lines(a.planY, bufA, bufB, nzc, 1, +1, twYs, S);           // backward y on the half plane
         // Hermitian completion along z: element kz' = nz - kz is the conjugate of kz (for every y)
-        for (int idx = threadIdx.x; idx < ny * (nz - nzc); idx += FFT_THREADS) {
+        for (int idx = threadIdx.x; idx < ny * (nz - nzc); idx += PLANE_THREADS) {
             const int y = idx % ny, kz = nzc + idx / ny;
             const float2 v = r1[(nz - kz) * S + y];
             r1[kz * S + y] = make_float2(v.x, -v.y);
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_plane_kernel(PlaneArgs a) {
         float2* other = r1 == bufA ? bufB : bufA;
         float2* r2 = fft_lines(a.planZ, r1, other, ny, S, +1, twZs, 1);
         float* out = a.real + (size_t) x * ny * nz;
-        for (int idx = threadIdx.x; idx < ny * nz; idx += FFT_THREADS) {
+        for (int idx = threadIdx.x; idx < ny * nz; idx += PLANE_THREADS) {
             const int y = idx / nz, z = idx % nz;
             out[idx] = r2[z * S + y].x;
         }
@@ -541,7 +542,7 @@ void launch_yz(const ommhip_pme* pme, bool forward, hipStream_t st) {
         p.planY = make_plan(ny); p.planZ = make_plan(nz); p.ny = ny; p.nz = nz; p.forward = forward ? 1 : 0;
         p.twY = (const float2*) pme->twiddle_y; p.twZ = (const float2*) pme->twiddle_z;
         p.real = (float*) pme->grid_real; p.cplx = cgrid;
-        hipLaunchKernelGGL(fft_plane_kernel, dim3(nx), dim3(FFT_THREADS), 0, st, p);
+        hipLaunchKernelGGL(fft_plane_kernel, dim3(nx), dim3(PLANE_THREADS), 0, st, p);
         return;
     }
     FftArgs f;

@@ -64,6 +64,8 @@ struct ProfileTimer {
     size_t used = 0;
     double totalMs = 0;
     long long calls = 0;
+    unsigned seq = 0;      // launches seen; every profileEnabled-th one is timed
+    bool open = false;
 };
 ProfileTimer timers[OMMHIP_PROFILE_NUM_TIMERS];
 int profileEnabled = 0;
@@ -80,7 +82,7 @@ void profile_drain(ProfileTimer& t) {
 }  // namespace
 
 extern "C" {
-int ommhip_profile_enable(int enabled) { profileEnabled = enabled; return 0; }
+int ommhip_profile_enable(int enabled) { profileEnabled = enabled < 0 ? 0 : enabled; return 0; }   /* n > 1: time every n-th launch */
 int ommhip_profile_reset() {
     for (int i = 0; i < OMMHIP_PROFILE_NUM_TIMERS; i++) { profile_drain(timers[i]); timers[i].totalMs = 0; timers[i].calls = 0; }
     return 0;
@@ -88,6 +90,8 @@ int ommhip_profile_reset() {
 int ommhip_profile_begin(int timer, void* stream) {
     if (!profileEnabled || timer < 0 || timer >= OMMHIP_PROFILE_NUM_TIMERS) return 0;
     ProfileTimer& t = timers[timer];
+    t.open = (t.seq++ % (unsigned) profileEnabled) == 0;
+    if (!t.open) return 0;
     if (t.used == 4096) profile_drain(t);
     if (t.used == t.start.size()) {
         hipEvent_t a, b;
@@ -99,7 +103,8 @@ int ommhip_profile_begin(int timer, void* stream) {
 int ommhip_profile_end(int timer, void* stream) {
     if (!profileEnabled || timer < 0 || timer >= OMMHIP_PROFILE_NUM_TIMERS) return 0;
     ProfileTimer& t = timers[timer];
-    if (t.used >= t.stop.size()) return 0;
+    if (!t.open || t.used >= t.stop.size()) return 0;
+    t.open = false;
     hipError_t e = hipEventRecord(t.stop[t.used], (hipStream_t) stream);
     t.used++;
     return (int) e;

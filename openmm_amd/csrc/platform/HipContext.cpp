@@ -38,7 +38,7 @@ unsigned long long hilbertIndex(unsigned x, unsigned y, unsigned z, int bits) {
 
 HipContext::HipContext(const System& system, int deviceIndex, bool hostMode) : numAtoms(system.getNumParticles()), hostMode(hostMode),
         stream(NULL), usePeriodic(false), sortCutoff(0.0), positionsValid(false), hasFallbackForces(false), stepsSinceReorder(0),
-        reorderInterval(500), reorderRequested(true), deviceIndex(deviceIndex), pinnedResult(NULL) {
+        reorderInterval(500), cmRemovalPending(false), momentumValid(false), reorderRequested(true), deviceIndex(deviceIndex), pinnedResult(NULL) {
     int count = 0;
     HIP_CHECK(ommhip_device_count(&count));
     if (deviceIndex < 0 || deviceIndex >= count)
@@ -134,6 +134,7 @@ void HipContext::uploadVelocities(const vector<Vec3>& velocities) {
         tmp[i].w = masses[i] == 0.0 ? 0.0 : 1.0 / masses[i];
     }
     if (numAtoms > 0) HIP_CHECK(ommhip_memcpy_h2d(vel.ptr, tmp.data(), sizeof(D4) * numAtoms, stream));
+    momentumValid = false;
     sync();
 }
 

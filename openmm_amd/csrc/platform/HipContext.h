@@ -119,6 +119,9 @@ public:
     bool positionsValid;
     bool hasFallbackForces;        // some force kernels are Reference ones (need host positions/forces each evaluation)
     int stepsSinceReorder, reorderInterval;
+    // CM-motion removal folded into the fused step (HipConstraints::fusedStep): the remover only raises `pending`;
+    // `momentumValid` says the device holds the total momentum of the current velocities.
+    bool cmRemovalPending, momentumValid;
 
 private:
     void computeOrder(const std::vector<Vec3>& positions, std::vector<int>& order, std::vector<int>& wrapOut);

@@ -152,6 +152,62 @@ HipConstraints::HipConstraints(const System& system, HipPlatform::PlatformData& 
         ccma.row_start = ccmaRowStart.as<int>(); ccma.col = ccmaCol.as<int>(); ccma.value = ccmaValue.as<double>();
         ccma.converged = ccmaConverged.as<int>();
     }
+
+    // ---- integration units of the fused step: waters, SHAKE clusters, then every remaining atom on its own
+    numUnits = 0;
+    totalMass = 0;
+    for (int i = 0; i < numParticles; i++) totalMass += masses[i];
+    const char* noFused = getenv("OPENMM_HIP_DISABLE_FUSED_STEP");
+    if (numCcma == 0 && numParticles > 0 && !(noFused != NULL && noFused[0] == '1')) {
+        vector<int> unitAtomsHost;
+        vector<double> unitDistHost;
+        vector<bool> covered(numParticles, false);
+        if (numSettle > 0) {
+            for (int i = 0; i < numSettle; i++) {
+                int a1, a2, a3;
+                double d1, d2;
+                settle->getClusterParameters(i, a1, a2, a3, d1, d2);
+                const int at[4] = {a1, a2, a3, -1};
+                const double d[4] = {d1, d2, 0.0, 1.0};
+                unitAtomsHost.insert(unitAtomsHost.end(), at, at + 4);
+                unitDistHost.insert(unitDistHost.end(), d, d + 4);
+                covered[a1] = covered[a2] = covered[a3] = true;
+            }
+        }
+        for (int i = 0; i < numShake; i++) {
+            for (int k = 0; k < 4; k++) {
+                const int atom = shakeAtomsHost[4 * i + k];
+                unitAtomsHost.push_back(atom);
+                unitDistHost.push_back(k < 3 ? shakeDistHost[4 * i + k] : 2.0);
+                if (atom >= 0) covered[atom] = true;
+            }
+        }
+        for (int i = 0; i < numParticles; i++)
+            if (!covered[i]) {
+                const int at[4] = {i, -1, -1, -1};
+                const double d[4] = {0.0, 0.0, 0.0, 0.0};
+                unitAtomsHost.insert(unitAtomsHost.end(), at, at + 4);
+                unitDistHost.insert(unitDistHost.end(), d, d + 4);
+            }
+        numUnits = (int) unitAtomsHost.size() / 4;
+        uploadVector(unitAtoms, unitAtomsHost, hip.stream);
+        uploadVector(unitDist, unitDistHost, hip.stream);
+        cmScratch.allocate(sizeof(double) * (4 + 4 * (size_t) ((numUnits + 127) / 128)));
+        HIP_CHECK(ommhip_memset(cmScratch.ptr, 0, cmScratch.bytes, hip.stream));
+    }
+}
+
+void HipConstraints::fusedStep(int integrator, const ommhip_integrator_state& state, double tol) {
+    ommhip_step_units u;
+    u.num_units = numUnits;
+    u.atoms = unitAtoms.as<int>(); u.dist = unitDist.as<double>();
+    u.tol = tol; u.max_iterations = 150;
+    u.remove_cm = hip.cmRemovalPending && hip.momentumValid ? 1 : 0;
+    u.inv_total_mass = totalMass > 0 ? 1.0 / totalMass : 0.0;
+    u.cm_scratch = cmScratch.as<double>();
+    HIP_CHECK(ommhip_integrate_fused(integrator, &state, &u, hip.stream));
+    hip.cmRemovalPending = false;
+    hip.momentumValid = true;
 }
 
 void HipConstraints::runCcma(void* target, bool velocities, double tol) {
@@ -335,6 +391,7 @@ void HipApplyConstraintsKernel::applyToVelocities(ContextImpl& context, double t
     HipConstraints& constraints = data.getDeviceConstraints(context.getSystem());
     if (!constraints.hasConstraints()) return;
     constraints.applyToVelocities(hip.vel.ptr, tol);
+    hip.momentumValid = false;
 }
 
 // ================================================================================================
@@ -960,10 +1017,14 @@ void HipIntegrateVerletStepKernel::execute(ContextImpl& context, const VerletInt
     const double dt = integrator.getStepSize();
     ommhip_integrator_state s;
     fillState(s, dt);
-    HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_VERLET_1, &s, hip.stream));
     HipConstraints& constraints = data.getDeviceConstraints(context.getSystem());
-    if (constraints.hasConstraints()) constraints.apply(hip.xp.ptr, integrator.getConstraintTolerance());
-    HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_FINISH_POSITIONS, &s, hip.stream));
+    if (constraints.fusedStepAvailable()) constraints.fusedStep(OMMHIP_INTEGRATOR_VERLET, s, integrator.getConstraintTolerance());
+    else {
+        HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_VERLET_1, &s, hip.stream));
+        if (constraints.hasConstraints()) constraints.apply(hip.xp.ptr, integrator.getConstraintTolerance());
+        HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_FINISH_POSITIONS, &s, hip.stream));
+        hip.momentumValid = false;
+    }
     finishStep(dt);
 }
 double HipIntegrateVerletStepKernel::computeKineticEnergy(ContextImpl& context, const VerletIntegrator& integrator) {
@@ -990,10 +1051,14 @@ void HipIntegrateLangevinStepKernel::execute(ContextImpl& context, const Langevi
     s.vscale = exp(-dt * friction);
     s.fscale = friction == 0 ? dt : (1 - s.vscale) / friction;
     s.noisescale = sqrt(kT * (1 - s.vscale * s.vscale));
-    HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_LANGEVIN_1, &s, hip.stream));
     HipConstraints& constraints = data.getDeviceConstraints(context.getSystem());
-    if (constraints.hasConstraints()) constraints.apply(hip.xp.ptr, integrator.getConstraintTolerance());
-    HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_FINISH_POSITIONS, &s, hip.stream));
+    if (constraints.fusedStepAvailable()) constraints.fusedStep(OMMHIP_INTEGRATOR_LANGEVIN, s, integrator.getConstraintTolerance());
+    else {
+        HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_LANGEVIN_1, &s, hip.stream));
+        if (constraints.hasConstraints()) constraints.apply(hip.xp.ptr, integrator.getConstraintTolerance());
+        HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_FINISH_POSITIONS, &s, hip.stream));
+        hip.momentumValid = false;
+    }
     finishStep(dt);
 }
 double HipIntegrateLangevinStepKernel::computeKineticEnergy(ContextImpl& context, const LangevinIntegrator& integrator) {
@@ -1015,11 +1080,15 @@ void HipIntegrateLangevinMiddleStepKernel::execute(ContextImpl& context, const L
     s.vscale = exp(-dt * friction);
     s.noisescale = sqrt(kT * (1 - s.vscale * s.vscale));
     HipConstraints& constraints = data.getDeviceConstraints(context.getSystem());
-    HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_LMIDDLE_1, &s, hip.stream));
-    if (constraints.hasConstraints()) constraints.applyToVelocities(hip.vel.ptr, tol);
-    HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_LMIDDLE_2, &s, hip.stream));
-    if (constraints.hasConstraints()) constraints.apply(hip.xp.ptr, tol);
-    HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_LMIDDLE_3, &s, hip.stream));
+    if (constraints.fusedStepAvailable()) constraints.fusedStep(OMMHIP_INTEGRATOR_LANGEVIN_MIDDLE, s, tol);
+    else {
+        HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_LMIDDLE_1, &s, hip.stream));
+        if (constraints.hasConstraints()) constraints.applyToVelocities(hip.vel.ptr, tol);
+        HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_LMIDDLE_2, &s, hip.stream));
+        if (constraints.hasConstraints()) constraints.apply(hip.xp.ptr, tol);
+        HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_LMIDDLE_3, &s, hip.stream));
+        hip.momentumValid = false;
+    }
     finishStep(dt);
 }
 double HipIntegrateLangevinMiddleStepKernel::computeKineticEnergy(ContextImpl& context, const LangevinMiddleIntegrator& integrator) {
@@ -1038,5 +1107,12 @@ void HipRemoveCMMotionKernel::execute(ContextImpl& context) {
     if (data.stepCount % frequency != 0) return;
     HipContext& hip = *data.hip;
     hip.setAsCurrent();
+    // The fused step (one launch per step) already holds the momentum of the current velocities and subtracts the
+    // centre-of-mass velocity itself; velocities play no role in the force evaluation in between.
+    if (!hip.hostMode && hip.momentumValid && data.getDeviceConstraints(context.getSystem()).fusedStepAvailable()) {
+        hip.cmRemovalPending = true;
+        return;
+    }
     HIP_CHECK(ommhip_remove_cm_motion(hip.vel.ptr, hip.numAtoms, scratch.as<double>(), hip.stream));
+    hip.momentumValid = false;
 }

@@ -25,7 +25,15 @@ public:
     /** Remove constrained components from velocities `target` (double4[N], w = 1/m). */
     void applyToVelocities(void* target, double tol);
     bool hasConstraints() const { return numSettle + numShake + numCcma > 0; }
+    /** True when every constraint sits in a SETTLE water or a SHAKE cluster, so a whole step fits one launch
+     *  (ommhip_integrate_fused); OPENMM_HIP_DISABLE_FUSED_STEP=1 forces the staged kernels. */
+    bool fusedStepAvailable() const { return numUnits > 0; }
+    /** Launch the fused step; consumes a pending CM-motion removal and leaves the new total momentum on the device. */
+    void fusedStep(int integrator, const ommhip_integrator_state& state, double tol);
 private:
+    int numUnits;
+    double totalMass;
+    DeviceBuffer unitAtoms, unitDist, cmScratch;
     void runCcma(void* target, bool velocities, double tol);
     HipContext& hip;
     int numSettle, numShake, numCcma;

@@ -173,7 +173,9 @@ def dhfr_like(seed=1, n_side=22, chain_atoms=2489, relaxed=True):
                 continue
             if count > 3 and np.min(np.linalg.norm(heavy[:count - 3] - q, axis=1)) < min_dist:
                 continue
-            if count > 1 and np.linalg.norm(heavy[count - 2] - q) < 0.22:
+            # backbone angle between 94 and 130 degrees: torsion forces diverge as 1/sin^2 when three consecutive atoms
+            # line up, which no force field allows either
+            if count > 1 and not (0.22 < np.linalg.norm(heavy[count - 2] - q) < 0.272):
                 continue
             heavy[count] = q
             count += 1

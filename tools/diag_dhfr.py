@@ -68,12 +68,18 @@ else:
     ndof = 3 * w.num_atoms - len(dist) - 3
     chunk = int(os.environ.get("CHUNK", "100"))
     total = int(os.environ.get("TOTAL", "5000"))
+    last_good = None
     for k in range(total // chunk):
         integ.step(chunk)
-        st = c.getState(getEnergy=True, getPositions=True)
+        st = c.getState(getEnergy=True, getPositions=True, getVelocities=True)
         temp = 2 * st.kineticEnergy / (ndof * 0.00831446261815324)
         d = np.linalg.norm(st.positions[pairs[:, 0]] - st.positions[pairs[:, 1]], axis=1)
-        print("step %5d  T %.1f  PE %.1f  KE %.1f  max constraint err %.2e" % ((k + 1) * chunk, temp, st.potentialEnergy, st.kineticEnergy, np.abs(d - dist).max()), flush=True)
-        if not np.isfinite(st.potentialEnergy):
+        if (k + 1) % max(1, 1000 // chunk) == 0 or not np.isfinite(st.potentialEnergy):
+            print("step %5d  T %.1f  PE %.1f  KE %.1f  max constraint err %.2e" % ((k + 1) * chunk, temp, st.potentialEnergy, st.kineticEnergy, np.abs(d - dist).max()), flush=True)
+        if not np.isfinite(st.potentialEnergy) or temp > 330:
             print("NAN at", (k + 1) * chunk)
+            if last_good is not None:
+                np.savez_compressed(os.path.join(ROOT, "gpurun_out", "lastgood_%s_seed%s_step%d.npz" % (os.environ.get("TAG", "run"), os.environ.get("SEED", "1"), k * chunk)),
+                                    positions=last_good.positions, velocities=last_good.velocities)
             break
+        last_good = st

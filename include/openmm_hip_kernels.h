@@ -162,6 +162,15 @@ typedef struct ommhip_pme {
     int spread_mode;           /* 0: LDS-staged bricks (default), 1: direct global atomics */
     int grid_precleared;       /* 1: the caller zeroed grid_real on this stream already (fused clear), skip the memset */
     int fft_mode;              /* 0: fused (y,z) plane kernel when a plane fits in LDS (default), 1: always separate line passes */
+    /* Optional: the Ewald exclusion correction (ReferenceLJCoulombIxn.cpp:462-523) folded into the interpolation
+     * launch -- the lanes that gather an atom's 125 grid points also sum -qq erf(alpha r)/r over its excluded
+     * partners, so the correction costs no launch and no extra atomics.  excl_start == NULL disables it. */
+    const int* excl_start;     /* [num_atoms+1] CSR of excluded partners (atom indices, both directions) */
+    const int* excl_atoms;
+    const int* atom_of_slot;   /* [padded_atoms], -1 for padding slots */
+    const void* pos;           /* double4[num_atoms] unwrapped positions, atom order */
+    const double* charge;      /* [num_atoms] */
+    int excl_periodic;         /* NonbondedForce::getExceptionsUsePeriodicBoundaryConditions() */
 } ommhip_pme;
 
 int ommhip_fft_supported_size(int n);   /* 1 if n factors into 2,3,5,7 and fits the LDS line buffer; no device access */

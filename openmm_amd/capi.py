@@ -42,6 +42,8 @@ class Pme(C.Structure):
         ("eterm", C.c_void_p), ("grid_real", C.c_void_p), ("grid_complex", C.c_void_p),
         ("twiddle_x", C.c_void_p), ("twiddle_y", C.c_void_p), ("twiddle_z", C.c_void_p), ("spread_mode", C.c_int),
         ("grid_precleared", C.c_int), ("fft_mode", C.c_int),
+        ("excl_start", C.c_void_p), ("excl_atoms", C.c_void_p), ("atom_of_slot", C.c_void_p), ("pos", C.c_void_p),
+        ("charge", C.c_void_p), ("excl_periodic", C.c_int),
     ]
 
 
@@ -79,6 +81,7 @@ SIGNATURES = {
     "add_forces_from_double": [_P, _P, _I, _I, _P, _P],
     "reduce_energy": [_P, _I, _P, _P],
     "nl_update": [C.POINTER(NeighborList), _P],
+    "nl_step": [C.POINTER(NeighborList), _P, _P, _P],
     "fft_supported_size": [_I],
     "pme_build_eterm": [C.POINTER(Pme), _P],
     "pme_reciprocal": [C.POINTER(Pme), _P, _I, _P, _P, _I, _I, _P],

@@ -316,7 +316,6 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
         p.z = (float) (x.z - (w.z * boxd.cz));
     }
     else { p.x = 0.f; p.y = 0.f; p.z = 0.f; p.w = 0.f; }
-    if (inRange) posqOut[sl] = p;
     // displacement since the last rebuild
     bool moved = false;
     if (valid && checkDisplacement) {
@@ -331,6 +330,11 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
     float dx = p.x - p0.x, dy = p.y - p0.y, dz = p.z - p0.z;
     apply_pbc_rt(a.pbc, dx, dy, dz, a.box);
     if (!valid) { dx = dy = dz = 0; }
+    // Rectangular boxes: store every atom in the periodic image nearest to the first atom of its block, so the 32 atoms
+    // of a block are mutually image-coherent (coordinates may leave [0, L) by a block width; every consumer either
+    // reduces images itself or, like the pair kernel's single-image path, relies on exactly this coherence).
+    if (valid && a.pbc == 1) { p.x = p0.x + dx; p.y = p0.y + dy; p.z = p0.z + dz; }
+    if (inRange) posqOut[sl] = p;
     float minx = dx, maxx = dx, miny = dy, maxy = dy, minz = dz, maxz = dz;
 #pragma unroll
     for (int m = 16; m >= 1; m >>= 1) {
@@ -341,7 +345,8 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
     if (inRange && (s & 31) == 0) {
         const int blk = s >> 5;
         a.blockCenter[blk] = make_float4(p0.x + 0.5f * (minx + maxx), p0.y + 0.5f * (miny + maxy), p0.z + 0.5f * (minz + maxz), 0.f);
-        a.blockHalf[blk] = make_float4(0.5f * (maxx - minx), 0.5f * (maxy - miny), 0.5f * (maxz - minz), 0.f);
+        // .w = 1: the block's atoms are image-coherent (written above); the pair kernel may then use one image per j atom
+        a.blockHalf[blk] = make_float4(0.5f * (maxx - minx), 0.5f * (maxy - miny), 0.5f * (maxz - minz), a.pbc == 1 ? 1.f : 0.f);
     }
 }
 

@@ -40,6 +40,9 @@ struct NbArgs {
     const int2* chunkInfo;
     const int* rowJ;
     const unsigned* rowMask;
+    const float4* blockCenter;   // per i-block bounding box (neighbor.hip); blockHalf.w = 1 when the block's atoms are image-coherent
+    const float4* blockHalf;
+    float cutoff;
     omm_fixed* force;
     double* energyBuffer;     // one slot per workgroup
 };
@@ -135,15 +138,41 @@ __global__ __launch_bounds__(64) void nb_direct(NbArgs a, const float4* __restri
 #pragma unroll
         for (int k = 0; k < OMM_TILE; k++) { fix[k] = 0.f; fiy[k] = 0.f; fiz[k] = 0.f; }
         float energy = 0.f;
+        // Single-image path (rectangular boxes): when the block is image-coherent and block + cutoff stay inside half a
+        // box length on every axis, the image of j nearest to the block centre is the nearest image for every i atom
+        // within the cutoff (any other pair only comes out farther), so the image search is done once per j, not per pair.
+        bool single = false;
+        float4 cX = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PBC == 1) {
+            cX = a.blockCenter[X];
+            const float4 hX = a.blockHalf[X];
+            single = hX.w != 0.f && hX.x + a.cutoff < 0.5f * a.box.ax && hX.y + a.cutoff < 0.5f * a.box.by && hX.z + a.cutoff < 0.5f * a.box.cz;
+        }
         for (int row = 0; row < nrows; row++) {
             const size_t r = ((size_t) c * OMM_CHUNK_ROWS + row) * OMM_ROW + lane;
             const int j = a.rowJ[r];
-            const float4 pj = a.posq[j];
+            float4 pj = a.posq[j];
             const float2 sej = a.sigEps[j];
             const float qjK = OMM_ONE_4PI_EPS0 * pj.w;
             float fjx = 0.f, fjy = 0.f, fjz = 0.f;
-            if ((maskedBits >> row) & 1) {
-                const unsigned m = a.rowMask[r];
+            const bool masked = (maskedBits >> row) & 1;
+            const unsigned m = masked ? a.rowMask[r] : 0xFFFFFFFFu;
+            if (PBC == 1 && single) {
+                float dx = pj.x - cX.x, dy = pj.y - cX.y, dz = pj.z - cX.z;
+                min_image<false>(dx, dy, dz, a.box);
+                pj.x = cX.x + dx; pj.y = cX.y + dy; pj.z = cX.z + dz;
+                if (masked) {
+#pragma unroll
+                    for (int k = 0; k < OMM_TILE; k++)
+                        pair_ixn<METHOD, 0, ENERGY, true>(a, ip[k], ise[k], pj, sej, qjK, (m >> k) & 1u, fix[k], fiy[k], fiz[k], fjx, fjy, fjz, energy);
+                }
+                else {
+#pragma unroll
+                    for (int k = 0; k < OMM_TILE; k++)
+                        pair_ixn<METHOD, 0, ENERGY, false>(a, ip[k], ise[k], pj, sej, qjK, true, fix[k], fiy[k], fiz[k], fjx, fjy, fjz, energy);
+                }
+            }
+            else if (masked) {
 #pragma unroll
                 for (int k = 0; k < OMM_TILE; k++)
                     pair_ixn<METHOD, PBC, ENERGY, true>(a, ip[k], ise[k], pj, sej, qjK, (m >> k) & 1u, fix[k], fiy[k], fiz[k], fjx, fjy, fjz, energy);
@@ -199,6 +228,8 @@ extern "C" int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_non
     a.box = make_box(nl->box);
     a.posq = (const float4*) nl->posq; a.sigEps = (const float2*) sig_eps; a.state = nl->state;
     a.chunkInfo = (const int2*) nl->chunk_info; a.rowJ = nl->row_j; a.rowMask = nl->row_mask;
+    a.blockCenter = (const float4*) nl->block_center; a.blockHalf = (const float4*) nl->block_half;
+    a.cutoff = nl->cutoff > 0 ? (float) nl->cutoff : INFINITY;
     a.force = force; a.energyBuffer = energy_buffer;
     // One workgroup (= one wavefront) per chunk: the list length is only known on the device, so the launch covers
     // the allocated capacity and surplus workgroups exit at once; the hardware dispatcher balances the rest.

@@ -36,6 +36,13 @@ struct PmeArgs {
     const float4* posq;
     float* grid;
     omm_fixed* force;
+    // folded Ewald exclusion correction (interpolation launch only)
+    const int* exclStart; const int* exclAtoms; const int* atomOfSlot;
+    const double4* pos; const double* charge;
+    BoxD boxd;
+    double alpha;
+    int exclPeriodic, includeEnergy, energySlots;
+    double* energyBuffer;
 };
 
 // Grid index and B-spline weights of one coordinate.  ReferencePME.cpp:259-264 and :274-327 (order 5).
@@ -234,18 +241,61 @@ __global__ __launch_bounds__(256) void pme_interpolate(PmeArgs a) {
             fz += wx * wy * dz * g;
         }
     }
+    // Ewald exclusion correction of this atom (ReferenceLJCoulombIxn.cpp:462-523): lane `sub` takes partners sub, sub+8, ...
+    // Separations come from the double-precision positions; erf/exp run in single precision like the pair kernel.
+    float ex = 0.f, ey = 0.f, ez = 0.f;
+    double exclEnergy = 0.0;
+    if (a.exclStart != nullptr) {
+        const int atom = valid ? a.atomOfSlot[slot] : -1;
+        if (atom >= 0) {
+            const int e1 = a.exclStart[atom + 1];
+            int e = a.exclStart[atom] + sub;
+            if (e < e1) {
+                const double4 pi = a.pos[atom];
+                const double qi = OMM_ONE_4PI_EPS0_D * a.charge[atom];
+                for (; e < e1; e += 8) {
+                    const int j = a.exclAtoms[e];
+                    const double4 pj = a.pos[j];
+                    double ddx = pj.x - pi.x, ddy = pj.y - pi.y, ddz = pj.z - pi.z;
+                    if (a.exclPeriodic) min_image_d(ddx, ddy, ddz, a.boxd);
+                    const float dx = (float) ddx, dy = (float) ddy, dz = (float) ddz;
+                    const float qq = (float) (qi * a.charge[j]);
+                    const float r2 = dx * dx + dy * dy + dz * dz;
+                    const float invR = rsqrtf(r2), r = r2 * invR;
+                    const float ar = (float) a.alpha * r;
+                    const float erfAr = erff(ar);
+                    if (erfAr > 1e-6f) {
+                        const float s = qq * invR * invR * invR * (erfAr - 2.0f * ar * expf(-ar * ar) * 0.56418958354775628695f);
+                        ex += s * dx; ey += s * dy; ez += s * dz;
+                        exclEnergy -= 0.5 * (double) (qq * invR * erfAr);          // every pair is visited from both ends
+                    }
+                    else
+                        exclEnergy -= 0.5 * a.alpha * 1.12837916709551257390 * (double) qq;
+                }
+            }
+        }
+    }
     // reduce the 8 lanes of this atom
     fx += __shfl_xor(fx, 1); fy += __shfl_xor(fy, 1); fz += __shfl_xor(fz, 1);
     fx += __shfl_xor(fx, 2); fy += __shfl_xor(fy, 2); fz += __shfl_xor(fz, 2);
     fx += __shfl_xor(fx, 4); fy += __shfl_xor(fy, 4); fz += __shfl_xor(fz, 4);
-    if (valid && sub == 0 && p.w != 0.f) {
+    if (a.exclStart != nullptr) {
+        ex += __shfl_xor(ex, 1); ey += __shfl_xor(ey, 1); ez += __shfl_xor(ez, 1);
+        ex += __shfl_xor(ex, 2); ey += __shfl_xor(ey, 2); ez += __shfl_xor(ez, 2);
+        ex += __shfl_xor(ex, 4); ey += __shfl_xor(ey, 4); ez += __shfl_xor(ez, 4);
+    }
+    if (valid && sub == 0 && p.w != 0.f) {          // an uncharged atom has no exclusion correction either
         // ReferencePME.cpp:709-711
         const float q = p.w;
         const float gx = fx * a.nx, gy = fy * a.ny, gz = fz * a.nz;
         add_force(a.force, a.paddedAtoms, slot,
-                  -q * (gx * a.recip.r00),
-                  -q * (gx * a.recip.r10 + gy * a.recip.r11),
-                  -q * (gx * a.recip.r20 + gy * a.recip.r21 + gz * a.recip.r22));
+                  ex - q * (gx * a.recip.r00),
+                  ey - q * (gx * a.recip.r10 + gy * a.recip.r11),
+                  ez - q * (gx * a.recip.r20 + gy * a.recip.r21 + gz * a.recip.r22));
+    }
+    if (a.exclStart != nullptr && a.includeEnergy) {
+        exclEnergy = wave_sum(exclEnergy);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&a.energyBuffer[(blockIdx.x * 4 + (threadIdx.x >> 6)) % a.energySlots], exclEnergy);
     }
 }
 
@@ -604,6 +654,11 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     pa.recip.r10 = (float) (-b[1] * b[5] / det); pa.recip.r11 = (float) (b[0] * b[5] / det);
     pa.recip.r20 = (float) ((b[1] * b[4] - b[2] * b[3]) / det); pa.recip.r21 = (float) (-b[0] * b[4] / det); pa.recip.r22 = (float) (b[0] * b[2] / det);
     pa.posq = (const float4*) posq_d; pa.grid = (float*) pme->grid_real; pa.force = force_d;
+    pa.exclStart = pme->excl_start; pa.exclAtoms = pme->excl_atoms; pa.atomOfSlot = pme->atom_of_slot;
+    pa.pos = (const double4*) pme->pos; pa.charge = pme->charge;
+    pa.boxd.ax = b[0]; pa.boxd.bx = b[1]; pa.boxd.by = b[2]; pa.boxd.cx = b[3]; pa.boxd.cy = b[4]; pa.boxd.cz = b[5];
+    pa.alpha = pme->alpha; pa.exclPeriodic = pme->excl_periodic;
+    pa.includeEnergy = include_energy; pa.energySlots = energy_slots; pa.energyBuffer = energy_buffer_d;
     float2* cgrid = (float2*) pme->grid_complex;
 
     if (!pme->grid_precleared) hipMemsetAsync(pa.grid, 0, sizeof(float) * (size_t) nx * ny * nz, st);

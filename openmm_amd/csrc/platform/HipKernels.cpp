@@ -741,6 +741,9 @@ void HipCalcNonbondedForceKernel::computeParameters(ContextImpl& context, bool f
 
 void HipCalcNonbondedForceKernel::launchPme(int includeEnergy) {
     for (int i = 0; i < 6; i++) pme.box[i] = hip.box[i];
+    pme.excl_start = foldExclusions ? exclStart.as<int>() : NULL;
+    pme.excl_atoms = exclAtoms.as<int>(); pme.atom_of_slot = hip.atomOfSlot.as<int>();
+    pme.pos = hip.pos.ptr; pme.charge = chargeD.as<double>(); pme.excl_periodic = exceptionsArePeriodic ? 1 : 0;
     if (etermDirty) {
         HIP_CHECK(ommhip_pme_build_eterm(&pme, hip.stream));
         etermDirty = false;
@@ -775,6 +778,10 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
     double energy = 0;
     const int ie = includeEnergy ? 1 : 0;
     bool pmeLaunched = false;
+    // The exclusion correction belongs to the direct-space group (ReferenceLJCoulombIxn.cpp:373,462); when both halves
+    // are evaluated together it is computed by the PME interpolation launch instead of a term list of its own.
+    static const bool noFold = getenv("OPENMM_HIP_NO_FOLDED_EXCLUSIONS") != NULL;
+    foldExclusions = includeDirect && includeReciprocal && nonbondedMethod == PME && numExclusionPairs > 0 && !noFold;
     if (!includeDirect)
         HIP_CHECK(ommhip_positions_to_posq(hip.pos.ptr, hip.wrap.ptr, hip.atomOfSlot.as<int>(), hip.paddedAtoms, hip.box, posq.ptr, hip.stream));
     else {
@@ -815,7 +822,7 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
         ommhip_term_batch t14 = {OMMHIP_TERM_EXCEPTION14, {num14, exceptionAtomsD.as<int>(), exceptionParamsD.as<double>()},
                                  exceptionsArePeriodic ? 1 : 0, chargeD.as<double>(), ewaldAlpha};
         hip.addTerms(t14, includeEnergy);
-        if (params.ewald) {
+        if (params.ewald && !foldExclusions) {
             ommhip_term_batch tex = {OMMHIP_TERM_EWALD_EXCLUSION, {numExclusionPairs, exclusionPairsD.as<int>(), NULL},
                                      exceptionsArePeriodic ? 1 : 0, chargeD.as<double>(), ewaldAlpha};
             hip.addTerms(tex, includeEnergy);

@@ -133,6 +133,7 @@ private:
     DeviceBuffer exclBlockRange;
     void updateExclusionBlockRanges();
     bool slotParamsDirty, forceRebuild, etermDirty, hasInitializedParams;
+    bool foldExclusions;       // this evaluation: the Ewald exclusion correction rides in the PME interpolation launch
     // device
     DeviceBuffer chargeD, sigmaD, epsilonD, posq, posqRef, sigEps, exclStart, exclAtoms, nlState, blockCenter, blockHalf, chunkInfo, rowJ, rowMask;
     DeviceBuffer exceptionAtomsD, exceptionParamsD, exclusionPairsD, ewaldStructure;

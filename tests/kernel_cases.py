@@ -17,12 +17,19 @@ def lattice_positions(rng, n, box3, jitter=0.25):
     return frac @ box3
 
 
+LAST_SINGLE_FRACTION = 0.0
+
+
 def box6(box3):
     return (C.c_double * 6)(box3[0, 0], box3[1, 0], box3[1, 1], box3[2, 0], box3[2, 1], box3[2, 2])
 
 
-def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64):
-    """-> (forces[n,3], energy, oracle forces, oracle energy, nl state)"""
+def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64, compact=False):
+    """-> (forces[n,3], energy, oracle forces, oracle energy, nl state)
+
+    compact=False: random slot order, list built by ommhip_nl_update on wrapped coordinates (general image search).
+    compact=True: slots sorted along a Morton curve and the per-step entry ommhip_nl_step, which stores image-coherent
+    blocks -- with a box wider than 2 (block + cutoff) this drives the pair kernel's single-image path."""
     rng = np.random.default_rng(seed)
     box3 = np.eye(3) * L
     if triclinic:
@@ -35,6 +42,13 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     padded = (n + 31) // 32 * 32
     # a non-trivial slot order exercises atomOfSlot/slotOfAtom
     perm = rng.permutation(n).astype(np.int32)
+    if compact:
+        cell = np.floor(np.mod(pos, L) / 0.45).astype(np.int64)
+        key = np.zeros(n, np.int64)
+        for bit in range(6):
+            for d in range(3):
+                key |= ((cell[:, d] >> bit) & 1) << (3 * bit + d)
+        perm = np.argsort(key, kind="stable").astype(np.int32)
     atom_of_slot = np.full(padded, -1, np.int32)
     atom_of_slot[:n] = perm
     slot_of_atom = np.empty(n, np.int32)
@@ -76,7 +90,10 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     nl.chunk_info = K.upload(np.zeros((maxc, 2), np.int32))
     nl.row_j = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.int32))
     nl.row_mask = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.uint32))
-    K.nl_update(C.byref(nl), None)
+    if compact:
+        K.nl_step(C.byref(nl), d_pos, d_wrap, None)
+    else:
+        K.nl_update(C.byref(nl), None)
     state = K.download(nl.state, 8, np.int32)
     p = capi.NonbondedParams()
     p.ewald = 1 if method in (ONB.Ewald, ONB.PME) else 0
@@ -92,6 +109,11 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     f = K.download(d_f, (3, padded), np.int64).astype(np.float64) / 2 ** 32
     e = float(K.download(d_e, grid, np.float64).sum())
     forces = f[:, slot_of_atom].T
+    # fraction of i-blocks that qualified for the pair kernel's single-image path (coverage check for compact=True)
+    global LAST_SINGLE_FRACTION
+    half = K.download(nl.block_half, (nb, 4), np.float32)
+    ok = (half[:, 3] != 0) & np.all(half[:, :3] + cutoff < 0.5 * np.diag(box3)[None, :], axis=1)
+    LAST_SINGLE_FRACTION = float(ok.mean()) if periodic and not triclinic else 0.0
     f_or, e_or = ONB.direct_space(pos, q, sig, eps, method, cutoff, box3, excl, alpha, switch_distance=switch)
     return forces, e, f_or, e_or, state
 

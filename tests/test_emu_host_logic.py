@@ -38,6 +38,16 @@ def test_direct_space_kernel_logic(K, n, method, tric, switch):
 
 
 @needs_emu
+def test_direct_space_single_image_path(K):
+    """Morton-sorted slots + the per-step entry (image-coherent blocks): most chunks take the single-image path."""
+    f, e, f_or, e_or, state = KC.run_direct_space(K, 1200, ONB.PME, 0.7, 3.4, EXCL, compact=True)
+    assert state[0] == 0 and state[2] == 0 and state[1] > 0
+    assert KC.LAST_SINGLE_FRACTION > 0.5
+    assert max_rel_force_error(f, f_or) < 5e-5
+    assert abs(e - e_or) < 5e-5 * max(abs(e_or), 100.0)
+
+
+@needs_emu
 @pytest.mark.parametrize("ng", [(8, 6, 10), (28, 25, 30), (21, 20, 18)])
 @pytest.mark.parametrize("fft_mode", [0, 1])
 def test_fft_logic(K, ng, fft_mode):

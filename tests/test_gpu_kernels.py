@@ -34,6 +34,18 @@ def test_direct_space_kernel(K, n, method, tric, switch):
     assert abs(e - e_or) < 1e-5 * max(abs(e_or), 100.0)
 
 
+@pytest.mark.parametrize("n,method,L,cutoff,switch", [(3000, ONB.PME, 4.6, 0.9, None), (3000, ONB.CutoffPeriodic, 4.6, 0.9, 0.8), (2500, ONB.Ewald, 4.4, 0.8, None)])
+def test_direct_space_single_image_path(K, n, method, L, cutoff, switch):
+    """Spatially sorted slots and the per-step entry ommhip_nl_step (image-coherent blocks): the pair kernel searches the
+    periodic image once per j atom instead of once per pair; same bar against the oracle as the general path."""
+    excl = [p for p in EXCL if p[1] < n]
+    f, e, f_or, e_or, state = KC.run_direct_space(K, n, method, cutoff, L, excl, False, switch, grid=256, compact=True)
+    assert state[0] == 0 and state[2] == 0 and state[1] > 0
+    assert KC.LAST_SINGLE_FRACTION > 0.8
+    assert max_rel_force_error(f, f_or) < 1e-4
+    assert abs(e - e_or) < 1e-5 * max(abs(e_or), 100.0)
+
+
 def test_direct_space_kernel_launch_shape_independent(K):
     """Different launch shapes (and a rebuilt list, whose row composition depends on the order in which wavefronts
     append to it) must agree to float-summation noise; the integer force accumulation itself is order independent."""

@@ -210,6 +210,7 @@ template <class T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o
 
 // ---------------------------------------------------------------- math
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline int __float2int_rn(float x) { return (int) nearbyintf(x); }
 static inline double rsqrt(double x) { return 1.0 / sqrt(x); }
 #define __expf(x) expf(x)
 static inline float __frcp_rn(float x) { return 1.0f / x; }

@@ -45,6 +45,8 @@ int ommhip_memcpy_d2h(void* dst, const void* src_d, size_t bytes, void* stream);
 int ommhip_memcpy_d2d(void* dst_d, const void* src_d, size_t bytes, void* stream);
 int ommhip_memset(void* dst_d, int value, size_t bytes, void* stream);
 int ommhip_stream_create(void** stream);
+int ommhip_stream_create_priority(void** stream, int high_priority);   /* side streams whose small kernels should be scheduled first */
+int ommhip_event_create_untimed(void** event);   /* ordering-only event (cheaper than a timed one) */
 int ommhip_stream_destroy(void* stream);
 int ommhip_stream_sync(void* stream);
 int ommhip_event_create(void** event);
@@ -136,6 +138,10 @@ int ommhip_nl_update(const ommhip_neighbor_list* nl, void* stream);
 /* The per-step path of the platform, two launches: (1) double positions (pos_d double4[num_atoms], wrap_d int4[num_atoms], as
  * ommhip_positions_to_posq) -> nl->posq, displacement check, block bounds; (2) the device-conditional rebuild. */
 int ommhip_nl_step(const ommhip_neighbor_list* nl, const void* pos_d, const void* wrap_d, void* stream);
+/* Same, and the first launch also zeroes two buffers (as ommhip_clear2: the force accumulator and the PME grid at the start
+ * of an evaluation), saving a launch.  Sizes are multiples of 16 bytes; a NULL pointer skips that buffer. */
+int ommhip_nl_step_clear(const ommhip_neighbor_list* nl, const void* pos_d, const void* wrap_d,
+                         void* clear_a_d, size_t a_bytes, void* clear_b_d, size_t b_bytes, void* stream);
 /* Adds direct-space forces (and per-workgroup energies into energy_buffer_d[0..energy_slots)). */
 int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, const void* sig_eps_d,
                      long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);

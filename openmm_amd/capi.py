@@ -67,6 +67,8 @@ SIGNATURES = {
     "memcpy_d2d": [_P, _P, _Z, _P],
     "memset": [_P, _I, _Z, _P],
     "stream_create": [C.POINTER(C.c_void_p)],
+    "stream_create_priority": [C.POINTER(C.c_void_p), _I],
+    "event_create_untimed": [C.POINTER(C.c_void_p)],
     "stream_destroy": [_P],
     "stream_sync": [_P],
     "event_create": [C.POINTER(C.c_void_p)],

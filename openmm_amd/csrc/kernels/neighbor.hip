@@ -28,6 +28,7 @@ namespace {
 #define NL_LIST 4096          // staged (j, mask) entries
 #define NL_FLUSH 2048         // flush full rows once this many entries are staged
 #define NL_CAND 2048          // candidate blocks per window
+#define NL_ROUND 8            // passes a wavefront runs between two workgroup-wide flush checks (4 x 8 x 64 <= NL_LIST - NL_FLUSH)
 
 struct NlArgs {
     int numAtoms, paddedAtoms, numBlocks, maxChunks;
@@ -207,18 +208,29 @@ __global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
         __syncthreads();
         const int numCand = sCandCount;
         const int numPasses = (numCand + 1) / 2;
-        // ---- phase 2: atom-level test, one pass = two candidate blocks = 64 atoms per wavefront
-        for (int p0 = 0; p0 < numPasses; p0 += NL_WAVES) {
-            const int pass = p0 + wave;
-            if (pass < numPasses) {
-                const int ci = 2 * pass + (lane >> 5);
-                bool ok = ci < numCand;
-                const int Yc = ok ? candY[ci] : X;
-                const int lj = lane & 31;
+        // ---- phase 2: atom-level test, one pass = two candidate blocks = 64 atoms per wavefront.  The wavefronts run
+        //      NL_ROUND passes each on their own (appending through one LDS atomic per pass) before the workgroup meets
+        //      again to flush full rows; the atom data of the next pass is fetched while the current one is tested.
+        const int lj = lane & 31;
+        auto fetch = [&](int pass, int& Yc, int& atomJ, float4& pj) {
+            const int ci = 2 * pass + (lane >> 5);
+            const bool ok = pass < numPasses && ci < numCand;
+            Yc = ok ? candY[ci] : X;
+            const int j = Yc * OMM_TILE + lj;
+            atomJ = ok ? a.atomOfSlot[j] : -1;
+            pj = a.posq[j];
+        };
+        for (int p0 = 0; p0 < numPasses; p0 += NL_WAVES * NL_ROUND) {
+            int YcN, atomJN; float4 pjN;
+            fetch(p0 + wave, YcN, atomJN, pjN);
+            for (int r = 0; r < NL_ROUND; r++) {
+                const int pass = p0 + r * NL_WAVES + wave;
+                if (pass >= numPasses) break;                    // wave-uniform
+                const int Yc = YcN, atomJ = atomJN;
+                const float4 pj = pjN;
+                if (r + 1 < NL_ROUND) fetch(pass + NL_WAVES, YcN, atomJN, pjN);
                 const int j = Yc * OMM_TILE + lj;
-                const int atomJ = ok ? a.atomOfSlot[j] : -1;
-                ok = ok && atomJ >= 0;
-                const float4 pj = a.posq[j];
+                const bool ok = atomJ >= 0;
                 // distance to X's bounding box
                 float dx = pj.x - cX.x, dy = pj.y - cX.y, dz = pj.z - cX.z;
                 apply_pbc<PBC>(dx, dy, dz, a.box);
@@ -301,8 +313,18 @@ __global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
 // only consumed when a rebuild follows, and recomputing them costs less than a conditional launch).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __restrict__ pos, const int4* __restrict__ wrap, BoxD boxd,
-                                                  float4* __restrict__ posqOut, int checkDisplacement) {
+                                                  float4* __restrict__ posqOut, int checkDisplacement,
+                                                  uint4* __restrict__ clearA, size_t clearNA, uint4* __restrict__ clearB, size_t clearNB) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;      // slot; the grid covers paddedAtoms exactly (multiple of 32)
+    // start-of-evaluation clears (force accumulator, PME charge grid) ride along: nothing in this launch reads them
+    {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        const size_t stride = (size_t) gridDim.x * blockDim.x;
+        for (size_t i = (size_t) s; i < clearNA + clearNB; i += stride) {
+            if (i < clearNA) clearA[i] = z;
+            else clearB[i - clearNA] = z;
+        }
+    }
     const bool inRange = s < a.paddedAtoms;
     const int sl = inRange ? s : a.paddedAtoms - 1;
     const int atom = a.atomOfSlot[sl];
@@ -378,13 +400,20 @@ static void launch_find(const NlArgs& a, hipStream_t st) {
 // Per-step entry of the platform: conversion + displacement check + bounds in one launch, then the
 // (device-conditional) rebuild.  Two launches per step, no host synchronisation.
 extern "C" int ommhip_nl_step(const ommhip_neighbor_list* nl, const void* pos_d, const void* wrap_d, void* stream) {
+    return ommhip_nl_step_clear(nl, pos_d, wrap_d, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int ommhip_nl_step_clear(const ommhip_neighbor_list* nl, const void* pos_d, const void* wrap_d,
+                                    void* clear_a_d, size_t a_bytes, void* clear_b_d, size_t b_bytes, void* stream) {
+    if ((a_bytes | b_bytes) & 15) return 1;
     hipStream_t st = (hipStream_t) stream;
     NlArgs a = make_nl_args(nl);
     BoxD bd;
     bd.ax = nl->box[0]; bd.bx = nl->box[1]; bd.by = nl->box[2]; bd.cx = nl->box[3]; bd.cy = nl->box[4]; bd.cz = nl->box[5];
     ommhip_profile_begin(OMMHIP_TIMER_NL_UPDATE, stream);
     hipLaunchKernelGGL(nl_prepare, dim3((a.paddedAtoms + 255) / 256), dim3(256), 0, st, a, (const double4*) pos_d, (const int4*) wrap_d, bd,
-                       (float4*) nl->posq, nl->cutoff > 0 ? 1 : 0);
+                       (float4*) nl->posq, nl->cutoff > 0 ? 1 : 0,
+                       (uint4*) clear_a_d, clear_a_d != nullptr ? a_bytes / 16 : 0, (uint4*) clear_b_d, clear_b_d != nullptr ? b_bytes / 16 : 0);
     launch_find(a, st);
     ommhip_profile_end(OMMHIP_TIMER_NL_UPDATE, stream);
     return (int) hipGetLastError();

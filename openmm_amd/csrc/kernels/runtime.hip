@@ -41,6 +41,12 @@ int ommhip_memset(void* dst_d, int value, size_t bytes, void* stream) {
     return (int) hipMemsetAsync(dst_d, value, bytes, (hipStream_t) stream);
 }
 int ommhip_stream_create(void** stream) { return (int) hipStreamCreateWithFlags((hipStream_t*) stream, hipStreamNonBlocking); }
+int ommhip_stream_create_priority(void** stream, int high_priority) {
+    int least = 0, greatest = 0;
+    hipDeviceGetStreamPriorityRange(&least, &greatest);           // numerically lower = higher priority
+    return (int) hipStreamCreateWithPriority((hipStream_t*) stream, hipStreamNonBlocking, high_priority ? greatest : least);
+}
+int ommhip_event_create_untimed(void** event) { return (int) hipEventCreateWithFlags((hipEvent_t*) event, hipEventDisableTiming); }
 int ommhip_stream_destroy(void* stream) { return (int) hipStreamDestroy((hipStream_t) stream); }
 int ommhip_stream_sync(void* stream) { return (int) hipStreamSynchronize((hipStream_t) stream); }
 int ommhip_event_create(void** event) { return (int) hipEventCreate((hipEvent_t*) event); }

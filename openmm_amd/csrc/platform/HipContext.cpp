@@ -45,9 +45,10 @@ HipContext::HipContext(const System& system, int deviceIndex, bool hostMode) : n
         throw OpenMMException("HIP platform: illegal DeviceIndex");
     HIP_CHECK(ommhip_set_device(deviceIndex));
     HIP_CHECK(ommhip_stream_create(&stream));
-    HIP_CHECK(ommhip_stream_create(&pmeStream));
-    HIP_CHECK(ommhip_event_create(&pmeForkEvent));
-    HIP_CHECK(ommhip_event_create(&pmeDoneEvent));
+    // reciprocal space consists of small, latency-bound launches: give them priority over the pair kernel's waves
+    HIP_CHECK(ommhip_stream_create_priority(&pmeStream, 1));
+    HIP_CHECK(ommhip_event_create_untimed(&pmeForkEvent));
+    HIP_CHECK(ommhip_event_create_untimed(&pmeDoneEvent));
     usePmeStream = true;
     paddedAtoms = ((numAtoms + OMMHIP_TILE - 1) / OMMHIP_TILE) * OMMHIP_TILE;
     if (paddedAtoms == 0) paddedAtoms = OMMHIP_TILE;
@@ -177,7 +178,9 @@ void HipContext::setBox(const Vec3& a, const Vec3& b, const Vec3& c) {
     for (size_t i = 0; i < listeners.size(); i++) listeners[i]->boxChanged();
 }
 
-void HipContext::clearForces() {
+void HipContext::ensureCleared() {
+    if (!clearPending) return;
+    clearPending = false;
     // the force accumulator and (if a PME kernel registered one) the charge grid are zeroed by one launch
     HIP_CHECK(ommhip_clear2(force.ptr, force.bytes, extraClearPtr, extraClearBytes, stream));
 }

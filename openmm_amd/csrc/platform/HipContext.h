@@ -73,7 +73,13 @@ public:
     void getBox(Vec3& a, Vec3& b, Vec3& c) const { a = boxVectors[0]; b = boxVectors[1]; c = boxVectors[2]; }
 
     // ---- per-evaluation
-    void clearForces();
+    /** Request the start-of-evaluation clear of the force accumulator (+ extraClear buffer).  The clear is lazy: the
+     *  nonbonded kernel folds it into its first launch (takePendingClear); everybody else calls ensureCleared()
+     *  before touching the force buffer. */
+    void clearForces() { clearPending = true; }
+    void ensureCleared();
+    bool takePendingClear() { bool p = clearPending; clearPending = false; return p; }
+    bool clearPending = false;
     /** One extra buffer (the PME charge grid) zeroed together with the forces at the start of every evaluation. */
     void* extraClearPtr = NULL;
     size_t extraClearBytes = 0;

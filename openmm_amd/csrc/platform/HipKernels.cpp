@@ -270,6 +270,7 @@ void HipCalcForcesAndEnergyKernel::beginComputation(ContextImpl& context, bool i
 
 double HipCalcForcesAndEnergyKernel::finishComputation(ContextImpl& context, bool includeForce, bool includeEnergy, int groups, bool& valid) {
     HipContext& hip = *data.hip;
+    hip.ensureCleared();          // nobody folded the start-of-evaluation clear into a launch of its own
     hip.flushTerms();
     hip.joinPme();
     double energy = 0;
@@ -782,6 +783,7 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
     // are evaluated together it is computed by the PME interpolation launch instead of a term list of its own.
     static const bool noFold = getenv("OPENMM_HIP_NO_FOLDED_EXCLUSIONS") != NULL;
     foldExclusions = includeDirect && includeReciprocal && nonbondedMethod == PME && numExclusionPairs > 0 && !noFold;
+    if (!includeDirect) hip.ensureCleared();
     if (!includeDirect)
         HIP_CHECK(ommhip_positions_to_posq(hip.pos.ptr, hip.wrap.ptr, hip.atomOfSlot.as<int>(), hip.paddedAtoms, hip.box, posq.ptr, hip.stream));
     else {
@@ -800,7 +802,10 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
                 HIP_CHECK(ommhip_memcpy_h2d(nlState.ptr, request, sizeof(request), hip.stream));
             }
             // positions -> posq, displacement check, bounds; then the device-conditional rebuild (2 launches)
-            HIP_CHECK(ommhip_nl_step(&nl, hip.pos.ptr, hip.wrap.ptr, hip.stream));
+            if (hip.takePendingClear())
+                HIP_CHECK(ommhip_nl_step_clear(&nl, hip.pos.ptr, hip.wrap.ptr, hip.force.ptr, hip.force.bytes, hip.extraClearPtr, hip.extraClearBytes, hip.stream));
+            else
+                HIP_CHECK(ommhip_nl_step(&nl, hip.pos.ptr, hip.wrap.ptr, hip.stream));
             if (!forceRebuild) break;
             // host-requested rebuild: verify the capacity synchronously
             HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));

@@ -122,6 +122,11 @@ typedef struct ommhip_neighbor_list {
     void* chunk_info;          /* int2[max_chunks]  (i-block, nrows | maskedRowBits<<8) */
     int* row_j;                /* int[max_chunks*CHUNK_ROWS*ROW] */
     unsigned* row_mask;        /* same shape */
+    /* Optional slot-keyed copy of the exclusion CSR (refreshed by the host whenever the slot order changes): partners of
+     * the atom in slot s are the SLOTS excl_slots[excl_slot_start[s] .. excl_slot_start[s+1]).  Saves the builder two
+     * dependent gathers per partner; NULL = use excl_start/excl_atoms + slot_of_atom. */
+    const int* excl_slot_start;   /* [padded_atoms+1] */
+    const int* excl_slots;
 } ommhip_neighbor_list;
 
 typedef struct ommhip_nonbonded_params {

@@ -24,7 +24,7 @@ class NeighborList(C.Structure):
         ("posq", C.c_void_p), ("posq_ref", C.c_void_p), ("atom_of_slot", C.c_void_p), ("slot_of_atom", C.c_void_p),
         ("excl_start", C.c_void_p), ("excl_atoms", C.c_void_p), ("excl_block_range", C.c_void_p), ("state", C.c_void_p),
         ("block_center", C.c_void_p), ("block_half", C.c_void_p), ("chunk_info", C.c_void_p),
-        ("row_j", C.c_void_p), ("row_mask", C.c_void_p),
+        ("row_j", C.c_void_p), ("row_mask", C.c_void_p), ("excl_slot_start", C.c_void_p), ("excl_slots", C.c_void_p),
     ]
 
 

@@ -43,6 +43,8 @@ struct NlArgs {
     const int* exclStart;
     const int* exclAtoms;
     const int2* exclBlockRange;   // per i-block: [lowest, highest] block holding an exclusion partner of its atoms (or null)
+    const int* exclSlotStart;     // slot-keyed exclusion CSR (or null)
+    const int* exclSlots;
     int* state;
     float4* blockCenter;
     float4* blockHalf;
@@ -120,6 +122,8 @@ __global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
     const int X = blockIdx.x;
     const float R2 = a.listCutoff2;
     const float Rlist = sqrtf(R2);
+    const long long tStart = clock64();      // builder cost per i-block, kept in posqRef[..].w for diagnostics
+    int candTotal = 0;
 
     // atom (lane & 31) of X in every lane; broadcast later with v_readlane
     const float4 px = a.posq[X * OMM_TILE + (lane & 31)];
@@ -207,6 +211,7 @@ __global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
         }
         __syncthreads();
         const int numCand = sCandCount;
+        candTotal += numCand;
         const int numPasses = (numCand + 1) / 2;
         // ---- phase 2: atom-level test, one pass = two candidate blocks = 64 atoms per wavefront.  The wavefronts run
         //      NL_ROUND passes each on their own (appending through one LDS atomic per pass) before the workgroup meets
@@ -265,11 +270,27 @@ __global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
                     mask = iValidMask;
                     if (Yc == X) mask &= (1u << lj) - 1u;        // diagonal block: each pair once, no self pair
                     // Only blocks inside X's exclusion-partner range can hold an excluded partner.
-                    if (Yc >= exclRange.x && Yc <= exclRange.y)
-                        for (int e = a.exclStart[atomJ]; e < a.exclStart[atomJ + 1]; e++) {
-                            const int s = a.slotOfAtom[a.exclAtoms[e]];
-                            if ((s >> 5) == X) mask &= ~(1u << (s & 31));
+                    if (Yc >= exclRange.x && Yc <= exclRange.y) {
+                        if (a.exclSlotStart != nullptr) {
+                            // slot-keyed table: four independent loads in flight per trip
+                            const int e1 = a.exclSlotStart[j + 1];
+                            for (int e = a.exclSlotStart[j]; e < e1; e += 4) {
+                                const int s0 = a.exclSlots[e];
+                                const int s1 = e + 1 < e1 ? a.exclSlots[e + 1] : -1;
+                                const int s2 = e + 2 < e1 ? a.exclSlots[e + 2] : -1;
+                                const int s3 = e + 3 < e1 ? a.exclSlots[e + 3] : -1;
+                                if ((s0 >> 5) == X) mask &= ~(1u << (s0 & 31));
+                                if ((s1 >> 5) == X) mask &= ~(1u << (s1 & 31));
+                                if ((s2 >> 5) == X) mask &= ~(1u << (s2 & 31));
+                                if ((s3 >> 5) == X) mask &= ~(1u << (s3 & 31));
+                            }
                         }
+                        else
+                            for (int e = a.exclStart[atomJ]; e < a.exclStart[atomJ + 1]; e++) {
+                                const int s = a.slotOfAtom[a.exclAtoms[e]];
+                                if ((s >> 5) == X) mask &= ~(1u << (s & 31));
+                            }
+                    }
                 }
                 const bool passes = mask != 0;
                 const unsigned long long pm = __ballot(passes);
@@ -295,6 +316,8 @@ __global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
 
     // Last workgroup out clears the rebuild request.
     if (t == 0) {
+        a.posqRef[X * OMM_TILE].w = (float) (clock64() - tStart);
+        a.posqRef[X * OMM_TILE + 1].w = (float) candTotal;
         __threadfence();
         const int done = atomicAdd(&a.state[ST_BLOCKS_DONE], 1);
         if (done == (int) gridDim.x - 1) {
@@ -383,6 +406,7 @@ NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
     a.posq = (const float4*) nl->posq; a.posqRef = (float4*) nl->posq_ref;
     a.atomOfSlot = nl->atom_of_slot; a.slotOfAtom = nl->slot_of_atom;
     a.exclStart = nl->excl_start; a.exclAtoms = nl->excl_atoms; a.exclBlockRange = (const int2*) nl->excl_block_range;
+    a.exclSlotStart = nl->excl_slot_start; a.exclSlots = nl->excl_slots;
     a.state = nl->state;
     a.blockCenter = (float4*) nl->block_center; a.blockHalf = (float4*) nl->block_half;
     a.chunkInfo = (int2*) nl->chunk_info; a.rowJ = nl->row_j; a.rowMask = nl->row_mask;

@@ -259,7 +259,7 @@ void HipContext::computeOrder(const vector<Vec3>& positions, vector<int>& order,
     if (sortCutoff <= 0.0 || numAtoms <= OMMHIP_TILE)
         return;
     // bin into cells of ~0.3 nm and walk the cells along a Hilbert curve
-    const double binWidth = 0.3;
+    static const double binWidth = getenv("OPENMM_HIP_SORT_BIN") != NULL ? atof(getenv("OPENMM_HIP_SORT_BIN")) : 0.3;   // tuning knob (nm)
     Vec3 lo(1e300, 1e300, 1e300), hi(-1e300, -1e300, -1e300);
     for (int i = 0; i < numAtoms; i++)
         for (int k = 0; k < 3; k++) { lo[k] = min(lo[k], wrapped[i][k]); hi[k] = max(hi[k], wrapped[i][k]); }

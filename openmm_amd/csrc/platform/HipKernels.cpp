@@ -417,6 +417,23 @@ extern "C" __attribute__((visibility("default"))) int ommhip_plugin_nl_stats(lon
     return 0;
 }
 
+/* Diagnostics: per i-block cost of the last list build (clock ticks, candidate blocks), as left by nl_find_interactions. */
+extern "C" __attribute__((visibility("default"))) int ommhip_plugin_nl_block_costs(float* ticks, float* candidates, int maxBlocks) {
+    if (liveNonbondedKernels.empty()) return -1;
+    try { return liveNonbondedKernels.back()->getBlockCosts(ticks, candidates, maxBlocks); } catch (...) { return -2; }
+}
+
+int HipCalcNonbondedForceKernel::getBlockCosts(float* ticks, float* candidates, int maxBlocks) {
+    hip.setAsCurrent();
+    const int numBlocks = hip.paddedAtoms / OMMHIP_TILE;
+    vector<float> ref(4 * (size_t) hip.paddedAtoms);
+    HIP_CHECK(ommhip_memcpy_d2h(ref.data(), posqRef.ptr, sizeof(float) * ref.size(), hip.stream));
+    hip.sync();
+    const int n = min(numBlocks, maxBlocks);
+    for (int b = 0; b < n; b++) { ticks[b] = ref[4 * (size_t) (b * OMMHIP_TILE) + 3]; candidates[b] = ref[4 * (size_t) (b * OMMHIP_TILE + 1) + 3]; }
+    return n;
+}
+
 void HipCalcNonbondedForceKernel::getNeighborListStats(long long* out) {
     hip.setAsCurrent();
     int state[OMMHIP_NL_STATE_INTS];
@@ -667,8 +684,22 @@ void HipCalcNonbondedForceKernel::updateExclusionBlockRanges() {
         }
     }
     HIP_CHECK(ommhip_memcpy_h2d(exclBlockRange.ptr, range.data(), sizeof(int) * range.size(), hip.stream));
+    // the same CSR keyed by slot, partners as slots: the builder then needs one gather per partner instead of three
+    vector<int> slotStart(hip.paddedAtoms + 1, 0), slots(max((size_t) 1, hostExclAtoms.size()));
+    for (int s = 0; s < hip.paddedAtoms; s++) {
+        const int atom = hip.hostAtomOfSlot[s];
+        int n = slotStart[s];
+        if (atom >= 0)
+            for (int e = hostExclStart[atom]; e < hostExclStart[atom + 1]; e++) slots[n++] = hip.hostSlotOfAtom[hostExclAtoms[e]];
+        slotStart[s + 1] = n;
+    }
+    exclSlotStart.allocate(sizeof(int) * slotStart.size());
+    exclSlots.allocate(sizeof(int) * slots.size());
+    HIP_CHECK(ommhip_memcpy_h2d(exclSlotStart.ptr, slotStart.data(), sizeof(int) * slotStart.size(), hip.stream));
+    HIP_CHECK(ommhip_memcpy_h2d(exclSlots.ptr, slots.data(), sizeof(int) * slots.size(), hip.stream));
     hip.sync();
     nl.excl_block_range = exclBlockRange.ptr;
+    nl.excl_slot_start = exclSlotStart.as<int>(); nl.excl_slots = exclSlots.as<int>();
 }
 
 int HipCalcNonbondedForceKernel::estimateChunks() const {

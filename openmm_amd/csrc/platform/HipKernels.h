@@ -109,6 +109,7 @@ public:
     void positionsSet();
     /** out[0..6) = atoms, padded atoms, chunks in use, rows in use, chunk capacity, rebuilds so far (blocking). */
     void getNeighborListStats(long long* out);
+    int getBlockCosts(float* ticks, float* candidates, int maxBlocks);
 private:
     void computeParameters(ContextImpl& context, bool force);
     void allocateNeighborList(int maxChunks);
@@ -130,7 +131,7 @@ private:
     std::map<std::string, double> lastGlobalValues;
     std::vector<double> charges;                                             // current, atom order
     std::vector<int> hostExclStart, hostExclAtoms;                           // exclusion CSR (atom indices)
-    DeviceBuffer exclBlockRange;
+    DeviceBuffer exclBlockRange, exclSlotStart, exclSlots;
     void updateExclusionBlockRanges();
     bool slotParamsDirty, forceRebuild, etermDirty, hasInitializedParams;
     bool foldExclusions;       // this evaluation: the Ewald exclusion correction rides in the PME interpolation launch

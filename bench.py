@@ -155,8 +155,17 @@ def main():
             algo_bytes = rows * 64 * 56 + chunks * 32 * 48
             avg_us = timers["nb_direct"]["avg_us"]
             achieved = algo_bytes / (avg_us * 1e-6) / 1e9 if avg_us else None
+            # HBM traffic of the same kernel from the PMC passes (rocprofv3 cannot run inside this process; the counters were
+            # collected by tools/gpu_pmc.sh on the same command and are committed under profiles/)
+            traffic, traffic_source = None, None
+            pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_nb_direct.json")
+            if args.workload == "dhfr" and os.path.exists(pmc_file):
+                with open(pmc_file) as f:
+                    pmc = json.load(f)
+                traffic, traffic_source = pmc["traffic_bytes_per_launch"], pmc["source"]
             out["roofline"] = {"bound": "hbm", "kernel": "nb_direct", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBPS,
-                               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5) if achieved else None, "traffic": None,
+                               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5) if achieved else None, "traffic": traffic,
+                               "traffic_source": traffic_source,
                                "algorithmic_bytes_per_launch": int(algo_bytes), "avg_kernel_us": round(avg_us, 3) if avg_us else None,
                                "rows": int(rows), "chunks": int(chunks), "rebuilds": int(stats[5]),
                                "pair_evals_per_launch": int(rows) * 64 * 32, "kernel_timers_us": timers,

@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256) void pme_interpolate(PmeArgs a) {
                     double ddx = pj.x - pi.x, ddy = pj.y - pi.y, ddz = pj.z - pi.z;
                     if (a.exclPeriodic) min_image_d(ddx, ddy, ddz, a.boxd);
                     const float dx = (float) ddx, dy = (float) ddy, dz = (float) ddz;
-                    const float qq = (float) (qi * a.charge[j]);
+                    const double qqd = qi * a.charge[j];
+                    const float qq = (float) qqd;
                     const float r2 = dx * dx + dy * dy + dz * dz;
                     const float invR = rsqrtf(r2), r = r2 * invR;
                     const float ar = (float) a.alpha * r;
@@ -292,10 +293,10 @@ __global__ __launch_bounds__(256) void pme_interpolate(PmeArgs a) {
                     if (erfAr > 1e-6f) {
                         const float s = qq * invR * invR * invR * (erfAr - 2.0f * ar * expf(-ar * ar) * 0.56418958354775628695f);
                         ex += s * dx; ey += s * dy; ez += s * dz;
-                        exclEnergy -= 0.5 * (double) (qq * invR * erfAr);          // every pair is visited from both ends
+                        exclEnergy -= 0.5 * qqd * (double) (invR * erfAr);         // every pair is visited from both ends
                     }
                     else
-                        exclEnergy -= 0.5 * a.alpha * 1.12837916709551257390 * (double) qq;
+                        exclEnergy -= 0.5 * a.alpha * 1.12837916709551257390 * qqd;
                 }
             }
         }

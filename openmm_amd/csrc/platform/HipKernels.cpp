@@ -812,7 +812,8 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
     bool pmeLaunched = false;
     // The exclusion correction belongs to the direct-space group (ReferenceLJCoulombIxn.cpp:373,462); when both halves
     // are evaluated together it is computed by the PME interpolation launch instead of a term list of its own.
-    static const bool noFold = getenv("OPENMM_HIP_NO_FOLDED_EXCLUSIONS") != NULL;
+    const char* noFoldEnv = getenv("OPENMM_HIP_NO_FOLDED_EXCLUSIONS");          // test/A-B knob, read per evaluation
+    const bool noFold = noFoldEnv != NULL && noFoldEnv[0] == '1';
     foldExclusions = includeDirect && includeReciprocal && nonbondedMethod == PME && numExclusionPairs > 0 && !noFold;
     if (!includeDirect) hip.ensureCleared();
     if (!includeDirect)

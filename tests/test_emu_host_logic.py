@@ -114,3 +114,44 @@ print("OK", err)
 ''' % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@needs_emu
+def test_fused_step_equals_staged_kernels_emulated():
+    """One-launch LangevinMiddle step (SETTLE + thermostat + folded CM removal) against the staged kernels, and the folded
+    exclusion correction against the term list, on a small water box (child process, emulated plugin)."""
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+from openmm_amd import harness as H, testsystems as T
+H.load_hip_platform(emulated=True)
+w = T.water_box(4, seed=3, cutoff=0.6)
+alpha = float(np.sqrt(-np.log(2 * w.ewald_tol)) / w.cutoff)
+w.pme_params = (alpha, 12, 12, 12)
+w.cm_remover = True
+def run(env, kind, steps):
+    os.environ.update(env)
+    s, nb = w.build()
+    integ = H.Integrator(kind, 0.002, 300.0, 1.0, seed=5, constraintTolerance=1e-6)
+    c = H.Context(s, integ, "HIP")
+    c.setPositions(w.positions)
+    c.applyConstraints(1e-6)
+    c.setVelocitiesToTemperature(300.0, 3)
+    integ.step(steps)
+    st = c.getState(getPositions=True, getVelocities=True, getForces=True, getEnergy=True)
+    c.close()
+    return st
+for kind in (H.VERLET, H.LANGEVIN_MIDDLE):
+    a = run({"OPENMM_HIP_DISABLE_FUSED_STEP": "0"}, kind, 4)
+    b = run({"OPENMM_HIP_DISABLE_FUSED_STEP": "1"}, kind, 4)
+    assert np.abs(a.positions - b.positions).max() < 1e-7, np.abs(a.positions - b.positions).max()
+    assert np.abs(a.velocities - b.velocities).max() < 1e-4
+a = run({"OPENMM_HIP_NO_FOLDED_EXCLUSIONS": "0"}, H.VERLET, 0)
+b = run({"OPENMM_HIP_NO_FOLDED_EXCLUSIONS": "1"}, H.VERLET, 0)
+rms = np.sqrt((b.forces ** 2).sum(1).mean())
+assert np.sqrt(((a.forces - b.forces) ** 2).sum(1)).max() / rms < 2e-6
+assert abs(a.potentialEnergy - b.potentialEnergy) < 5e-3      # both sum ~3e4 kJ/mol of single-precision erf terms
+print("OK")
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -192,3 +192,58 @@ print("OK", st.potentialEnergy)
         f_host = np.load(path)
     st = hip_state(T.water_box(6, seed=11))
     assert max_rel_force_error(f_host, st.forces) < 2e-6
+
+
+def _trajectory(w, steps, kind, env):
+    """positions/velocities after `steps` steps with the given environment knobs set while the Context is built and run"""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        system, nb = w.build()
+        integ = H.Integrator(kind, 0.002 if kind != H.VERLET else 0.001, 300.0, 1.0, seed=7, constraintTolerance=1e-6)
+        ctx = H.Context(system, integ, "HIP")
+        ctx.setPositions(w.positions)
+        ctx.applyConstraints(1e-6)
+        if getattr(w, "velocities", None) is not None:
+            ctx.setVelocities(w.velocities)
+        else:
+            ctx.setVelocitiesToTemperature(300.0, 3)
+        integ.step(steps)
+        st = ctx.getState(getPositions=True, getVelocities=True, getForces=True, getEnergy=True)
+        ctx.close()
+        return st
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("kind", [H.VERLET, H.LANGEVIN, H.LANGEVIN_MIDDLE])
+@pytest.mark.parametrize("workload", ["water", "dhfr"])
+def test_fused_step_equals_staged_kernels(kind, workload):
+    """One-launch step (SETTLE/SHAKE/thermostat/CM removal in registers) against the staged kernels + standalone constraint and
+    CM-removal launches: same arithmetic, so a short trajectory must agree far below the chaotic divergence of the system."""
+    if workload == "water":
+        w = T.water_box(8, seed=31)
+        w.cm_remover = True
+    else:
+        w = T.dhfr_like(seed=1)
+    a = _trajectory(w, 12, kind, {"OPENMM_HIP_DISABLE_FUSED_STEP": "0"})
+    b = _trajectory(w, 12, kind, {"OPENMM_HIP_DISABLE_FUSED_STEP": "1"})
+    assert np.abs(a.positions - b.positions).max() < 2e-6
+    assert np.abs(a.velocities - b.velocities).max() < 2e-3
+    assert abs(a.kineticEnergy - b.kineticEnergy) < 1e-4 * abs(b.kineticEnergy)
+    # the folded CM-motion removal (momentum carried from the previous fused step) matches the standalone remover
+    pa, pb = (w.masses[:, None] * a.velocities).sum(0), (w.masses[:, None] * b.velocities).sum(0)
+    assert np.abs(pa - pb).max() < 1e-6 * w.masses.sum()
+
+
+def test_folded_exclusion_correction_equals_term_list():
+    """Ewald exclusion correction computed inside the PME interpolation launch vs as a term list of its own."""
+    w = T.dhfr_like(seed=1)
+    a = _trajectory(w, 0, H.VERLET, {"OPENMM_HIP_NO_FOLDED_EXCLUSIONS": "0"})
+    b = _trajectory(w, 0, H.VERLET, {"OPENMM_HIP_NO_FOLDED_EXCLUSIONS": "1"})
+    assert max_rel_force_error(a.forces, b.forces) < 2e-6
+    assert abs(a.potentialEnergy - b.potentialEnergy) < 1e-6 * abs(b.potentialEnergy)

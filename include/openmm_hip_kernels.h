@@ -147,6 +147,12 @@ int ommhip_nl_step(const ommhip_neighbor_list* nl, const void* pos_d, const void
  * of an evaluation), saving a launch.  Sizes are multiples of 16 bytes; a NULL pointer skips that buffer. */
 int ommhip_nl_step_clear(const ommhip_neighbor_list* nl, const void* pos_d, const void* wrap_d,
                          void* clear_a_d, size_t a_bytes, void* clear_b_d, size_t b_bytes, void* stream);
+/* The two launches of ommhip_nl_step_clear separately, so that work which only needs posq (reciprocal space) can be
+ * forked to another stream between them: (1) conversion, clears, displacement check, bounds; (2) the rebuild that
+ * runs only if (1) -- or the host -- requested it in nl->state. */
+int ommhip_nl_prepare(const ommhip_neighbor_list* nl, const void* pos_d, const void* wrap_d,
+                      void* clear_a_d, size_t a_bytes, void* clear_b_d, size_t b_bytes, void* stream);
+int ommhip_nl_rebuild_if_requested(const ommhip_neighbor_list* nl, void* stream);
 /* Adds direct-space forces (and per-workgroup energies into energy_buffer_d[0..energy_slots)). */
 int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, const void* sig_eps_d,
                      long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);

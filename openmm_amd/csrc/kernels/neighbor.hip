@@ -429,16 +429,28 @@ extern "C" int ommhip_nl_step(const ommhip_neighbor_list* nl, const void* pos_d,
 
 extern "C" int ommhip_nl_step_clear(const ommhip_neighbor_list* nl, const void* pos_d, const void* wrap_d,
                                     void* clear_a_d, size_t a_bytes, void* clear_b_d, size_t b_bytes, void* stream) {
+    int rc = ommhip_nl_prepare(nl, pos_d, wrap_d, clear_a_d, a_bytes, clear_b_d, b_bytes, stream);
+    if (rc == 0) rc = ommhip_nl_rebuild_if_requested(nl, stream);
+    return rc;
+}
+
+extern "C" int ommhip_nl_prepare(const ommhip_neighbor_list* nl, const void* pos_d, const void* wrap_d,
+                                 void* clear_a_d, size_t a_bytes, void* clear_b_d, size_t b_bytes, void* stream) {
     if ((a_bytes | b_bytes) & 15) return 1;
     hipStream_t st = (hipStream_t) stream;
     NlArgs a = make_nl_args(nl);
     BoxD bd;
     bd.ax = nl->box[0]; bd.bx = nl->box[1]; bd.by = nl->box[2]; bd.cx = nl->box[3]; bd.cy = nl->box[4]; bd.cz = nl->box[5];
-    ommhip_profile_begin(OMMHIP_TIMER_NL_UPDATE, stream);
     hipLaunchKernelGGL(nl_prepare, dim3((a.paddedAtoms + 255) / 256), dim3(256), 0, st, a, (const double4*) pos_d, (const int4*) wrap_d, bd,
                        (float4*) nl->posq, nl->cutoff > 0 ? 1 : 0,
                        (uint4*) clear_a_d, clear_a_d != nullptr ? a_bytes / 16 : 0, (uint4*) clear_b_d, clear_b_d != nullptr ? b_bytes / 16 : 0);
-    launch_find(a, st);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_nl_rebuild_if_requested(const ommhip_neighbor_list* nl, void* stream) {
+    NlArgs a = make_nl_args(nl);
+    ommhip_profile_begin(OMMHIP_TIMER_NL_UPDATE, stream);
+    launch_find(a, (hipStream_t) stream);
     ommhip_profile_end(OMMHIP_TIMER_NL_UPDATE, stream);
     return (int) hipGetLastError();
 }

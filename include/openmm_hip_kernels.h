@@ -188,7 +188,9 @@ typedef struct ommhip_pme {
     const void* pos;           /* double4[num_atoms] unwrapped positions, atom order */
     const double* charge;      /* [num_atoms] */
     int excl_periodic;         /* NonbondedForce::getExceptionsUsePeriodicBoundaryConditions() */
+    int phases;                /* OMMHIP_PME_ALL (0), or the two halves separately so that they can go to different streams */
 } ommhip_pme;
+enum { OMMHIP_PME_ALL = 0, OMMHIP_PME_SPREAD_ONLY = 1, OMMHIP_PME_AFTER_SPREAD = 2 };
 
 int ommhip_fft_supported_size(int n);   /* 1 if n factors into 2,3,5,7 and fits the LDS line buffer; no device access */
 int ommhip_pme_build_eterm(const ommhip_pme* pme, void* stream);

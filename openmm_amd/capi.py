@@ -43,7 +43,7 @@ class Pme(C.Structure):
         ("twiddle_x", C.c_void_p), ("twiddle_y", C.c_void_p), ("twiddle_z", C.c_void_p), ("spread_mode", C.c_int),
         ("grid_precleared", C.c_int), ("fft_mode", C.c_int),
         ("excl_start", C.c_void_p), ("excl_atoms", C.c_void_p), ("atom_of_slot", C.c_void_p), ("pos", C.c_void_p),
-        ("charge", C.c_void_p), ("excl_periodic", C.c_int),
+        ("charge", C.c_void_p), ("excl_periodic", C.c_int), ("phases", C.c_int),
     ]
 
 

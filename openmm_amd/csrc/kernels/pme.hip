@@ -249,21 +249,33 @@ __global__ __launch_bounds__(256) void pme_interpolate(PmeArgs a) {
     if (valid && p.w != 0.f) {
         int idx[3]; float th[3][PME_ORDER], dth[3][PME_ORDER];
         atom_splines(a, p, idx, th, dth);
-        for (int pt = sub; pt < PME_ORDER * PME_ORDER * PME_ORDER; pt += 8) {
+        // The 16 gathers of this lane (points sub, sub + 8, ...) are issued back to back and consumed afterwards: a rolled
+        // loop waits for one L2 round trip per point, which was most of this kernel's time.
+        constexpr int NPT = (PME_ORDER * PME_ORDER * PME_ORDER + 7) / 8;
+        float g[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; i++) {
+            const int pt = min(sub + 8 * i, PME_ORDER * PME_ORDER * PME_ORDER - 1);
             const int ix = pt / 25, iy = (pt / 5) % 5, iz = pt % 5;
             int gx = idx[0] + ix; gx -= gx >= a.nx ? a.nx : 0;
             int gy = idx[1] + iy; gy -= gy >= a.ny ? a.ny : 0;
             int gz = idx[2] + iz; gz -= gz >= a.nz ? a.nz : 0;
+            g[i] = a.grid[((size_t) gx * a.ny + gy) * a.nz + gz];
+        }
+#pragma unroll
+        for (int i = 0; i < NPT; i++) {
+            const int pt = sub + 8 * i;
+            const int ix = pt / 25, iy = (pt / 5) % 5, iz = pt % 5;
             float wx = th[0][0], wy = th[1][0], wz = th[2][0], dx = dth[0][0], dy = dth[1][0], dz = dth[2][0];
 #pragma unroll
             for (int k = 1; k < PME_ORDER; k++) {
                 wx = ix == k ? th[0][k] : wx; wy = iy == k ? th[1][k] : wy; wz = iz == k ? th[2][k] : wz;
                 dx = ix == k ? dth[0][k] : dx; dy = iy == k ? dth[1][k] : dy; dz = iz == k ? dth[2][k] : dz;
             }
-            const float g = a.grid[((size_t) gx * a.ny + gy) * a.nz + gz];
-            fx += dx * wy * wz * g;
-            fy += wx * dy * wz * g;
-            fz += wx * wy * dz * g;
+            const float gi = pt < PME_ORDER * PME_ORDER * PME_ORDER ? g[i] : 0.f;
+            fx += dx * wy * wz * gi;
+            fy += wx * dy * wz * gi;
+            fz += wx * wy * dz * gi;
         }
     }
     // Ewald exclusion correction of this atom (ReferenceLJCoulombIxn.cpp:462-523): lane `sub` takes partners sub, sub+8, ...
@@ -687,14 +699,17 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     pa.includeEnergy = include_energy; pa.energySlots = energy_slots; pa.energyBuffer = energy_buffer_d;
     float2* cgrid = (float2*) pme->grid_complex;
 
-    if (!pme->grid_precleared) hipMemsetAsync(pa.grid, 0, sizeof(float) * (size_t) nx * ny * nz, st);
     const int spreadBlocks = (padded_atoms * 8 + 255) / 256;
-    ommhip_profile_begin(OMMHIP_TIMER_PME_SPREAD, stream);
-    if (pme->spread_mode == 1)
-        hipLaunchKernelGGL(pme_spread, dim3(spreadBlocks), dim3(256), 0, st, pa);             // direct global atomics (reference variant)
-    else
-        hipLaunchKernelGGL(pme_spread_lds, dim3((padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS), dim3(256), 0, st, pa);
-    ommhip_profile_end(OMMHIP_TIMER_PME_SPREAD, stream);
+    if (pme->phases != OMMHIP_PME_AFTER_SPREAD) {
+        if (!pme->grid_precleared) hipMemsetAsync(pa.grid, 0, sizeof(float) * (size_t) nx * ny * nz, st);
+        ommhip_profile_begin(OMMHIP_TIMER_PME_SPREAD, stream);
+        if (pme->spread_mode == 1)
+            hipLaunchKernelGGL(pme_spread, dim3(spreadBlocks), dim3(256), 0, st, pa);             // direct global atomics (reference variant)
+        else
+            hipLaunchKernelGGL(pme_spread_lds, dim3((padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS), dim3(256), 0, st, pa);
+        ommhip_profile_end(OMMHIP_TIMER_PME_SPREAD, stream);
+    }
+    if (pme->phases == OMMHIP_PME_SPREAD_ONLY) return (int) hipGetLastError();
     ommhip_profile_begin(OMMHIP_TIMER_PME_FFT, stream);
 
     FftArgs f;

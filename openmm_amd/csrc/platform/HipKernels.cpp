@@ -781,13 +781,23 @@ void HipCalcNonbondedForceKernel::launchPme(int includeEnergy) {
         etermDirty = false;
     }
     if (hip.usePmeStream) {
-        // reciprocal space runs on the side stream, concurrently with whatever the main stream does next
+        // The whole reciprocal-space chain goes to the side stream and runs concurrently with the list rebuild and the
+        // pair kernel.  (Keeping the spread on the main stream, where it does not compete with the pair kernel for wave
+        // slots, was measured slower: 1126 vs 1154 ns/day -- it lengthens the main chain by more than it shortens the other.)
+        static const bool spreadOnSide = getenv("OPENMM_HIP_SPREAD_ON_MAIN_STREAM") == NULL;       // A/B knob
+        pme.phases = spreadOnSide ? OMMHIP_PME_ALL : OMMHIP_PME_SPREAD_ONLY;
+        if (!spreadOnSide)
+            HIP_CHECK(ommhip_pme_reciprocal(&pme, posq.ptr, hip.paddedAtoms, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy, hip.stream));
         hip.forkPme();
+        pme.phases = spreadOnSide ? OMMHIP_PME_ALL : OMMHIP_PME_AFTER_SPREAD;
         HIP_CHECK(ommhip_pme_reciprocal(&pme, posq.ptr, hip.paddedAtoms, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy, hip.pmeStream));
         hip.markPmeDone();
+        pme.phases = OMMHIP_PME_ALL;
     }
-    else
+    else {
+        pme.phases = OMMHIP_PME_ALL;
         HIP_CHECK(ommhip_pme_reciprocal(&pme, posq.ptr, hip.paddedAtoms, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy, hip.stream));
+    }
 }
 
 double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy, bool includeDirect, bool includeReciprocal) {

@@ -473,35 +473,64 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_kernel(FftArgs a) {
     const int nIn = a.mode == 2 ? n / 2 + 1 : n;
     const int nOut = a.mode == 1 ? n / 2 + 1 : n;
     const bool elemFastIn = a.inElemStride == 1;
-    // ---- load
-    for (int idx = threadIdx.x; idx < nIn * B; idx += FFT_THREADS) {
-        int line, e;
-        if (elemFastIn) { e = idx % nIn; line = idx / nIn; } else { line = idx % B; e = idx / B; }
+    // ---- load: all global reads of this thread (input lines and, for the fused convolution, the influence function) are
+    //      issued back to back before anything is consumed; a rolled loop would wait for one round trip per element
+    constexpr int MAXLD = FFT_MAX_LDS / FFT_THREADS;          // (B + 1) * n <= FFT_MAX_LDS
+    float2 ld[MAXLD];
+    int ldPos[MAXLD];
+    float etv[MAXLD];
+#pragma unroll
+    for (int it = 0; it < MAXLD; it++) {
+        const int idx = threadIdx.x + it * FFT_THREADS;
         float2 v = make_float2(0.f, 0.f);
-        if (inner0 + line < a.numInner) {
-            const long long off = outer * a.inOuterStride + (inner0 + line) * a.inInnerStride + e * a.inElemStride;
-            if (a.mode == 1) v.x = ((const float*) a.in)[off];
-            else v = ((const float2*) a.in)[off];
+        ldPos[it] = -1;
+        if (idx < nIn * B) {
+            int line, e;
+            if (elemFastIn) { e = idx % nIn; line = idx / nIn; } else { line = idx % B; e = idx / B; }
+            if (inner0 + line < a.numInner) {
+                const long long off = outer * a.inOuterStride + (inner0 + line) * a.inInnerStride + e * a.inElemStride;
+                if (a.mode == 1) v.x = ((const float*) a.in)[off];
+                else v = ((const float2*) a.in)[off];
+            }
+            ldPos[it] = e * BP + line;
         }
-        bufA[e * BP + line] = v;
-        if (a.mode == 2 && e > 0 && e < n - e) bufA[(n - e) * BP + line] = make_float2(v.x, -v.y);   // Hermitian completion
+        ld[it] = v;
+        etv[it] = 0.f;
+        if (a.mode == 3 && idx < n * B) {
+            const int line = idx % B, e = idx / B, kz = inner0 + line;
+            if (kz < a.numInner) etv[it] = a.eterm[outer * a.inOuterStride + kz * a.inInnerStride + e * a.inElemStride];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < MAXLD; it++) {
+        if (ldPos[it] >= 0) {
+            const float2 v = ld[it];
+            bufA[ldPos[it]] = v;
+            if (a.mode == 2) {
+                const int e = ldPos[it] / BP, line = ldPos[it] - e * BP;
+                if (e > 0 && e < n - e) bufA[(n - e) * BP + line] = make_float2(v.x, -v.y);   // Hermitian completion
+            }
+        }
     }
     __syncthreads();
     float2* res;
     if (a.mode == 3) {
         res = fft_lines(a.plan, bufA, bufB, B, BP, -1, twS);
         double energy = 0;
-        for (int idx = threadIdx.x; idx < n * B; idx += FFT_THREADS) {
-            const int line = idx % B, e = idx / B;
-            float2 v = res[e * BP + line];
-            float et = 0.f;
-            const int kz = inner0 + line;
-            if (kz < a.numInner) et = a.eterm[outer * a.inOuterStride + kz * a.inInnerStride + e * a.inElemStride];
-            if (a.energyBuffer != nullptr) {
-                const float wgt = (kz == 0 || 2 * kz == a.nzFull) ? 1.f : 2.f;
-                energy += (double) (wgt * et * (v.x * v.x + v.y * v.y));
+#pragma unroll
+        for (int it = 0; it < MAXLD; it++) {
+            const int idx = threadIdx.x + it * FFT_THREADS;
+            if (idx < n * B) {
+                const int line = idx % B, e = idx / B;
+                float2 v = res[e * BP + line];
+                const float et = etv[it];
+                const int kz = inner0 + line;
+                if (a.energyBuffer != nullptr) {
+                    const float wgt = (kz == 0 || 2 * kz == a.nzFull) ? 1.f : 2.f;
+                    energy += (double) (wgt * et * (v.x * v.x + v.y * v.y));
+                }
+                res[e * BP + line] = make_float2(v.x * et, v.y * et);
             }
-            res[e * BP + line] = make_float2(v.x * et, v.y * et);
         }
         if (a.energyBuffer != nullptr) {
             energy = wave_sum(energy);
@@ -563,9 +592,20 @@ __global__ __launch_bounds__(PLANE_THREADS) void fft_plane_kernel(PlaneArgs a) {
     for (int i = threadIdx.x; i < nz; i += PLANE_THREADS) twZs[i] = a.twZ[i];
     if (a.forward) {
         const float* in = a.real + (size_t) x * ny * nz;
-        for (int idx = threadIdx.x; idx < ny * nz; idx += PLANE_THREADS) {
-            const int y = idx / nz, z = idx % nz;
-            bufA[z * S + y] = make_float2(in[idx], 0.f);
+        constexpr int MAXLD = PLANE_MAX / PLANE_THREADS;       // all reads of the plane in flight at once
+        float ld[MAXLD];
+#pragma unroll
+        for (int it = 0; it < MAXLD; it++) {
+            const int idx = threadIdx.x + it * PLANE_THREADS;
+            ld[it] = idx < ny * nz ? in[idx] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < MAXLD; it++) {
+            const int idx = threadIdx.x + it * PLANE_THREADS;
+            if (idx < ny * nz) {
+                const int y = idx / nz, z = idx % nz;
+                bufA[z * S + y] = make_float2(ld[it], 0.f);
+            }
         }
         __syncthreads();
         float2* r1 = fft_lines(a.planZ, bufA, bufB, ny, S, -1, twZs, 1);            // lines = y, elements = z
@@ -579,9 +619,20 @@ __global__ __launch_bounds__(PLANE_THREADS) void fft_plane_kernel(PlaneArgs a) {
     }
     else {
         const float2* in = a.cplx + (size_t) x * ny * nzc;
-        for (int idx = threadIdx.x; idx < ny * nzc; idx += PLANE_THREADS) {
-            const int ky = idx / nzc, kz = idx % nzc;
-            bufA[kz * S + ky] = in[idx];
+        constexpr int MAXLD = PLANE_MAX / PLANE_THREADS;
+        float2 ld[MAXLD];
+#pragma unroll
+        for (int it = 0; it < MAXLD; it++) {
+            const int idx = threadIdx.x + it * PLANE_THREADS;
+            ld[it] = idx < ny * nzc ? in[idx] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < MAXLD; it++) {
+            const int idx = threadIdx.x + it * PLANE_THREADS;
+            if (idx < ny * nzc) {
+                const int ky = idx / nzc, kz = idx % nzc;
+                bufA[kz * S + ky] = ld[it];
+            }
         }
         __syncthreads();
         float2* r1 = fft_lines(a.planY, bufA, bufB, nzc, 1, +1, twYs, S);           // backward y on the half plane

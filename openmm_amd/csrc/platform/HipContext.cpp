@@ -2,6 +2,7 @@
 #include "openmm/System.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 using namespace OpenMM;
@@ -38,7 +39,7 @@ unsigned long long hilbertIndex(unsigned x, unsigned y, unsigned z, int bits) {
 
 HipContext::HipContext(const System& system, int deviceIndex, bool hostMode) : numAtoms(system.getNumParticles()), hostMode(hostMode),
         stream(NULL), usePeriodic(false), sortCutoff(0.0), positionsValid(false), hasFallbackForces(false), stepsSinceReorder(0),
-        reorderInterval(500), cmRemovalPending(false), momentumValid(false), reorderRequested(true), deviceIndex(deviceIndex), pinnedResult(NULL) {
+        reorderInterval(getenv("OPENMM_HIP_REORDER_INTERVAL") != NULL ? atoi(getenv("OPENMM_HIP_REORDER_INTERVAL")) : 500), cmRemovalPending(false), momentumValid(false), reorderRequested(true), deviceIndex(deviceIndex), pinnedResult(NULL) {
     int count = 0;
     HIP_CHECK(ommhip_device_count(&count));
     if (deviceIndex < 0 || deviceIndex >= count)

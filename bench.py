@@ -38,7 +38,7 @@ def parse_args():
     p.add_argument("--steps", type=int, default=3000)
     p.add_argument("--warmup", type=int, default=300)
     p.add_argument("--dt-fs", type=float, default=2.0)
-    p.add_argument("--workload", default="dhfr", choices=["dhfr", "water24k", "water98k"])
+    p.add_argument("--workload", default="dhfr", choices=["dhfr", "water24k", "water98k", "water1m"])
     p.add_argument("--cpu-steps", type=int, default=150, help="steps of the CPU-platform baseline (0 disables)")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--profile-every", type=int, default=8, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region")
@@ -52,6 +52,8 @@ def make_workload(name, seed):
         return T.dhfr_like(seed=seed)
     if name == "water24k":
         return T.water_box(20, seed=seed)
+    if name == "water1m":
+        return T.water_box(69, seed=seed)        # 985 527 atoms, L = 21.4 nm (BASELINE.json configs[3]; lattice start)
     return T.water_box(32, seed=seed)
 
 

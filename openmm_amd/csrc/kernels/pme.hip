@@ -570,7 +570,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_kernel(FftArgs a) {
 // LDS layout of a plane: element (y, kz) at kz*(ny+1) + y; the z transform sees lines = y (stride 1),
 // elements = z (stride ny+1); the y transform sees lines = kz (stride ny+1), elements = y (stride 1).
 // ------------------------------------------------------------------------------------------------
-#define PLANE_MAX 6144
+#define PLANE_MAX 9472        // complex elements per LDS buffer: 2 x 74 KB + 4 KB twiddles of the 160 KB per CU (planes up to 96 x 96)
 #define PLANE_THREADS 512     // one plane has ~400 butterflies per pass: 512 threads finish a pass in one sweep
 
 struct PlaneArgs {
@@ -584,15 +584,15 @@ struct PlaneArgs {
 __global__ __launch_bounds__(PLANE_THREADS) void fft_plane_kernel(PlaneArgs a) {
     __shared__ float2 bufA[PLANE_MAX];
     __shared__ float2 bufB[PLANE_MAX];
-    __shared__ float2 twYs[512];
-    __shared__ float2 twZs[512];
+    __shared__ float2 twYs[256];
+    __shared__ float2 twZs[256];
     const int ny = a.ny, nz = a.nz, nzc = nz / 2 + 1, S = ny + 1;
     const int x = blockIdx.x;
     for (int i = threadIdx.x; i < ny; i += PLANE_THREADS) twYs[i] = a.twY[i];
     for (int i = threadIdx.x; i < nz; i += PLANE_THREADS) twZs[i] = a.twZ[i];
     if (a.forward) {
         const float* in = a.real + (size_t) x * ny * nz;
-        constexpr int MAXLD = PLANE_MAX / PLANE_THREADS;       // all reads of the plane in flight at once
+        constexpr int MAXLD = (PLANE_MAX + PLANE_THREADS - 1) / PLANE_THREADS;       // all reads of the plane in flight at once
         float ld[MAXLD];
 #pragma unroll
         for (int it = 0; it < MAXLD; it++) {
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void fft_plane_kernel(PlaneArgs a) {
     }
     else {
         const float2* in = a.cplx + (size_t) x * ny * nzc;
-        constexpr int MAXLD = PLANE_MAX / PLANE_THREADS;
+        constexpr int MAXLD = (PLANE_MAX + PLANE_THREADS - 1) / PLANE_THREADS;
         float2 ld[MAXLD];
 #pragma unroll
         for (int it = 0; it < MAXLD; it++) {
@@ -676,7 +676,7 @@ int lines_per_group(int n) {
 void launch_yz(const ommhip_pme* pme, bool forward, hipStream_t st) {
     const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
     float2* cgrid = (float2*) pme->grid_complex;
-    if (nz * (ny + 1) <= PLANE_MAX && ny <= 512 && nz <= 512 && pme->fft_mode != 1) {
+    if (nz * (ny + 1) <= PLANE_MAX && ny <= 256 && nz <= 256 && pme->fft_mode != 1) {
         PlaneArgs p;
         p.planY = make_plan(ny); p.planZ = make_plan(nz); p.ny = ny; p.nz = nz; p.forward = forward ? 1 : 0;
         p.twY = (const float2*) pme->twiddle_y; p.twZ = (const float2*) pme->twiddle_z;

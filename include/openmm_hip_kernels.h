@@ -127,6 +127,15 @@ typedef struct ommhip_neighbor_list {
      * dependent gathers per partner; NULL = use excl_start/excl_atoms + slot_of_atom. */
     const int* excl_slot_start;   /* [padded_atoms+1] */
     const int* excl_slots;
+    /* Optional scratch for the cell-binned candidate search used on rectangular periodic systems with at least
+     * cell_min_blocks i-blocks (0 = default 16384): instead of testing every block against every other one (quadratic),
+     * the builder buckets blocks by the grid cell (edge >= cutoff + padding) of their centre and looks at nearby cells. */
+    int* cell_start;           /* int[2*max_cells + 2], or NULL to disable */
+    int* cell_blocks;          /* int[2 * padded_atoms/32] */
+    void* cell_boxes;          /* float4[2 * padded_atoms/32] */
+    float* cell_meta;          /* float[4] */
+    int max_cells;
+    int cell_min_blocks;
 } ommhip_neighbor_list;
 
 typedef struct ommhip_nonbonded_params {

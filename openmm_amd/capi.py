@@ -25,6 +25,7 @@ class NeighborList(C.Structure):
         ("excl_start", C.c_void_p), ("excl_atoms", C.c_void_p), ("excl_block_range", C.c_void_p), ("state", C.c_void_p),
         ("block_center", C.c_void_p), ("block_half", C.c_void_p), ("chunk_info", C.c_void_p),
         ("row_j", C.c_void_p), ("row_mask", C.c_void_p), ("excl_slot_start", C.c_void_p), ("excl_slots", C.c_void_p),
+        ("cell_start", C.c_void_p), ("cell_blocks", C.c_void_p), ("cell_boxes", C.c_void_p), ("cell_meta", C.c_void_p), ("max_cells", C.c_int), ("cell_min_blocks", C.c_int),
     ]
 
 

@@ -621,6 +621,14 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     nl.excl_start = exclStart.as<int>(); nl.excl_atoms = exclAtoms.as<int>();
     nl.state = nlState.as<int>();
     nl.block_center = blockCenter.ptr; nl.block_half = blockHalf.ptr;
+    // scratch of the cell-binned candidate search (used by the builder on large rectangular systems only)
+    nl.max_cells = P / OMMHIP_TILE + 64;
+    cellStart.allocate(sizeof(int) * (2 * (size_t) nl.max_cells + 2));
+    cellBlocks.allocate(sizeof(int) * 2 * (size_t) (P / OMMHIP_TILE));
+    cellBoxes.allocate(sizeof(float) * 8 * (size_t) (P / OMMHIP_TILE));
+    cellMeta.allocate(sizeof(float) * 4);
+    nl.cell_start = cellStart.as<int>(); nl.cell_blocks = cellBlocks.as<int>(); nl.cell_boxes = cellBoxes.ptr; nl.cell_meta = cellMeta.as<float>();
+    nl.cell_min_blocks = getenv("OPENMM_HIP_NL_CELL_MIN_BLOCKS") != NULL ? atoi(getenv("OPENMM_HIP_NL_CELL_MIN_BLOCKS")) : 0;   // 0 = default
     nl.max_chunks = 0;
 
     params.ewald = (nonbondedMethod == Ewald || nonbondedMethod == PME) ? 1 : 0;

@@ -131,7 +131,7 @@ private:
     std::map<std::string, double> lastGlobalValues;
     std::vector<double> charges;                                             // current, atom order
     std::vector<int> hostExclStart, hostExclAtoms;                           // exclusion CSR (atom indices)
-    DeviceBuffer exclBlockRange, exclSlotStart, exclSlots;
+    DeviceBuffer exclBlockRange, exclSlotStart, exclSlots, cellStart, cellBlocks, cellBoxes, cellMeta;
     void updateExclusionBlockRanges();
     bool slotParamsDirty, forceRebuild, etermDirty, hasInitializedParams;
     bool foldExclusions;       // this evaluation: the Ewald exclusion correction rides in the PME interpolation launch

@@ -24,7 +24,7 @@ def box6(box3):
     return (C.c_double * 6)(box3[0, 0], box3[1, 0], box3[1, 1], box3[2, 0], box3[2, 1], box3[2, 2])
 
 
-def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64, compact=False):
+def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64, compact=False, cells=False):
     """-> (forces[n,3], energy, oracle forces, oracle energy, nl state)
 
     compact=False: random slot order, list built by ommhip_nl_update on wrapped coordinates (general image search).
@@ -90,6 +90,13 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     nl.chunk_info = K.upload(np.zeros((maxc, 2), np.int32))
     nl.row_j = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.int32))
     nl.row_mask = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.uint32))
+    if cells:      # force the cell-binned candidate search of large systems at test size
+        nl.max_cells = nb + 64
+        nl.cell_start = K.upload(np.zeros(2 * nl.max_cells + 2, np.int32))
+        nl.cell_blocks = K.upload(np.zeros(2 * nb, np.int32))
+        nl.cell_boxes = K.upload(np.zeros((2 * nb, 4), np.float32))
+        nl.cell_meta = K.upload(np.zeros(4, np.float32))
+        nl.cell_min_blocks = 1
     if compact:
         K.nl_step(C.byref(nl), d_pos, d_wrap, None)
     else:

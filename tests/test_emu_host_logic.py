@@ -48,6 +48,16 @@ def test_direct_space_single_image_path(K):
 
 
 @needs_emu
+@pytest.mark.parametrize("compact", [False, True])
+def test_direct_space_cell_binned_builder(K, compact):
+    """The candidate search of large systems (blocks bucketed by grid cell) forced at test size: same list, same forces."""
+    f, e, f_or, e_or, state = KC.run_direct_space(K, 1200, ONB.PME, 0.7, 3.4, EXCL, compact=compact, cells=True)
+    assert state[0] == 0 and state[2] == 0 and state[1] > 0
+    assert max_rel_force_error(f, f_or) < 5e-5
+    assert abs(e - e_or) < 5e-5 * max(abs(e_or), 100.0)
+
+
+@needs_emu
 @pytest.mark.parametrize("ng", [(8, 6, 10), (28, 25, 30), (21, 20, 18)])
 @pytest.mark.parametrize("fft_mode", [0, 1])
 def test_fft_logic(K, ng, fft_mode):

@@ -46,6 +46,17 @@ def test_direct_space_single_image_path(K, n, method, L, cutoff, switch):
     assert abs(e - e_or) < 1e-5 * max(abs(e_or), 100.0)
 
 
+@pytest.mark.parametrize("n,L,cutoff,compact", [(3000, 4.6, 0.9, True), (3000, 4.6, 0.9, False), (2500, 6.5, 0.8, True)])
+def test_direct_space_cell_binned_builder(K, n, L, cutoff, compact):
+    """The candidate search used from 65 k atoms up (blocks bucketed by the grid cell of their centre, only nearby cells
+    scanned) forced at a size the dense oracle can check, for compact and for scattered blocks and a sparse box."""
+    excl = [p for p in EXCL if p[1] < n]
+    f, e, f_or, e_or, state = KC.run_direct_space(K, n, ONB.PME, cutoff, L, excl, grid=256, compact=compact, cells=True)
+    assert state[0] == 0 and state[2] == 0 and state[1] > 0
+    assert max_rel_force_error(f, f_or) < 1e-4
+    assert abs(e - e_or) < 1e-5 * max(abs(e_or), 100.0)
+
+
 def test_direct_space_kernel_launch_shape_independent(K):
     """Different launch shapes (and a rebuilt list, whose row composition depends on the order in which wavefronts
     append to it) must agree to float-summation noise; the integer force accumulation itself is order independent."""

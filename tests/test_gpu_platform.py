@@ -247,3 +247,14 @@ def test_folded_exclusion_correction_equals_term_list():
     b = _trajectory(w, 0, H.VERLET, {"OPENMM_HIP_NO_FOLDED_EXCLUSIONS": "1"})
     assert max_rel_force_error(a.forces, b.forces) < 2e-6
     assert abs(a.potentialEnergy - b.potentialEnergy) < 1e-6 * abs(b.potentialEnergy)
+
+
+def test_cell_binned_builder_matches_full_scan_at_98k_atoms():
+    """On large systems (16 384 i-blocks up) the list builder looks for candidate blocks through a cell grid instead of
+    testing all blocks (quadratic).  Forced here at 98 304 atoms (14 cells per axis, reach 3): both searches must produce
+    the same forces."""
+    w = T.water_box(32, seed=5)
+    a = _trajectory(w, 0, H.VERLET, {"OPENMM_HIP_NL_CELL_MIN_BLOCKS": "1"})
+    b = _trajectory(w, 0, H.VERLET, {"OPENMM_HIP_NL_CELL_MIN_BLOCKS": "100000000"})
+    assert max_rel_force_error(a.forces, b.forces) < 2e-6
+    assert abs(a.potentialEnergy - b.potentialEnergy) < 0.05       # float partial sums in a different order; |E| terms ~1e6

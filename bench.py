@@ -83,8 +83,16 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")      # "gloo" only to rehearse the N > 1 flow on a 1-GPU box
+        ndev = torch.cuda.device_count()
+        if backend == "nccl":
+            if local_rank >= ndev:
+                raise RuntimeError("rank %d has no GPU (%d visible)" % (local_rank, ndev))
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(ndev, 1)
+            dist.init_process_group(backend=backend)
 
     import numpy as np
     from openmm_amd import capi, harness as H
@@ -106,6 +114,7 @@ def main():
             import torch
             torch.cuda.synchronize()
             dist.barrier()
+    on_gpu = dist is None or dist.get_backend() == "nccl"
 
     profile = not args.no_roofline
     if profile:
@@ -121,7 +130,7 @@ def main():
         kernels.lib.ommhip_profile_enable(0)
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if not np.isfinite(st.potentialEnergy):
@@ -173,7 +182,7 @@ def main():
                                "pair_evals_per_launch": int(rows) * 64 * 32, "kernel_timers_us": timers,
                                "note": "working set is cache-resident at this size; the kernel is FP32-VALU bound, see DESIGN.md"}
         # ---- CPU baseline: the reference's platforms/cpu on the same System, bounded sample
-        if args.cpu_steps > 0:
+        if args.cpu_steps > 0 and world == 1:        # rank 0 at N = 1 only
             try:
                 H.load_cpu_platform()
                 csys, cnb, cinteg, cctx = run_platform(w, "CPU", dt_ps, 0, 5)

@@ -101,6 +101,79 @@ __device__ __forceinline__ void pair_ixn(const NbArgs& a, const float4 pi, const
     if (ENERGY) energy += in ? (ljE + cE) : 0.f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two i atoms per call in packed FP32 (v_pk_add/mul/fma_f32: two floats per lane per instruction at the issue rate of
+// one) -- the vector ALUs of CDNA3/4 only reach their FP32 peak through these.  Same arithmetic as pair_ixn; the three
+// transcendentals per pair (rsq, rcp, exp) stay scalar.  Used on the single-image path, where no image search is needed.
+// ------------------------------------------------------------------------------------------------
+#ifdef OMMHIP_EMU
+struct v2f { float x, y; };
+static inline v2f operator+(v2f a, v2f b) { return {a.x + b.x, a.y + b.y}; }
+static inline v2f operator-(v2f a, v2f b) { return {a.x - b.x, a.y - b.y}; }
+static inline v2f operator*(v2f a, v2f b) { return {a.x * b.x, a.y * b.y}; }
+static inline v2f operator-(v2f a) { return {-a.x, -a.y}; }
+#else
+typedef float v2f __attribute__((ext_vector_type(2)));
+#endif
+__device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+// wave-uniform copy of lane k's value (v_readlane_b32): i-atom data held one atom per lane, no memory access in the loop
+__device__ __forceinline__ float rl(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+__device__ __forceinline__ float4 rl4(float4 v, int k) { return make_float4(rl(v.x, k), rl(v.y, k), rl(v.z, k), rl(v.w, k)); }
+__device__ __forceinline__ float2 rl2(float2 v, int k) { return make_float2(rl(v.x, k), rl(v.y, k)); }
+__device__ __forceinline__ v2f bc2(float a) { return mk2(a, a); }
+
+template <int METHOD, bool ENERGY, bool MASKED>
+__device__ __forceinline__ void pair_ixn2(const NbArgs& a, const float4 pi0, const float4 pi1, const float2 se0, const float2 se1,
+                                          const float4 pj, const float2 sej, const float qjK, bool bit0, bool bit1,
+                                          v2f& fix, v2f& fiy, v2f& fiz, v2f& fjx, v2f& fjy, v2f& fjz, v2f& energy) {
+    const v2f dx = bc2(pj.x) - mk2(pi0.x, pi1.x), dy = bc2(pj.y) - mk2(pi0.y, pi1.y), dz = bc2(pj.z) - mk2(pi0.z, pi1.z);
+    const v2f r2 = dx * dx + dy * dy + dz * dz;
+    bool in0 = r2.x < a.cutoff2, in1 = r2.y < a.cutoff2;
+    if (MASKED) { in0 = in0 && bit0; in1 = in1 && bit1; }
+    const v2f invR = mk2(fast_rsqrt(r2.x), fast_rsqrt(r2.y));
+    const v2f r = r2 * invR;
+    const v2f invR2 = invR * invR;
+    const v2f sig = mk2(se0.x, se1.x) + bc2(sej.x);
+    const v2f eps = mk2(se0.y, se1.y) * bc2(sej.y);
+    v2f s2 = sig * invR; s2 = s2 * s2;
+    const v2f s6 = s2 * s2 * s2;
+    v2f ljF = eps * (bc2(12.f) * s6 - bc2(6.f)) * s6;
+    v2f ljE = eps * (s6 - bc2(1.f)) * s6;
+    if (METHOD & 2) {
+        v2f t = (r - bc2(a.switchDist)) * bc2(a.invSwitchWidth);
+        t = mk2(fmaxf(0.f, t.x), fmaxf(0.f, t.y));
+        const v2f sw = bc2(1.f) + t * t * t * (bc2(-10.f) + t * (bc2(15.f) - t * bc2(6.f)));
+        const v2f dsw = t * t * (bc2(-30.f) + t * (bc2(60.f) - t * bc2(30.f))) * bc2(a.invSwitchWidth);
+        ljF = sw * ljF - ljE * dsw * r;
+        ljE = ljE * sw;
+    }
+    const v2f qq = mk2(pi0.w, pi1.w) * bc2(qjK);
+    v2f cF, cE;
+    if (METHOD & 1) {
+        const v2f ar = bc2(a.alpha) * r;
+        const v2f arg = -(ar * ar) * bc2(1.44269504088896340736f);
+        const v2f ex = mk2(__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y));
+        const v2f den = bc2(1.f) + bc2(OMM_ERFC_P) * ar;
+        const v2f t = mk2(fast_rcp(den.x), fast_rcp(den.y));
+        const float c[OMM_ERFC_DEGREE + 1] = OMM_ERFC_COEFFS;
+        v2f poly = bc2(c[0]);
+#pragma unroll
+        for (int n = 1; n <= OMM_ERFC_DEGREE; n++) poly = poly * t + bc2(c[n]);
+        const v2f erfcv = ex * t * poly;
+        cE = qq * invR * erfcv;
+        cF = qq * invR * (erfcv + ar * ex * bc2(1.12837916709551257390f));
+    }
+    else {
+        cF = qq * (invR - bc2(2.f * a.krf) * r2);
+        cE = qq * (invR + bc2(a.krf) * r2 - bc2(a.crf));
+    }
+    v2f dEdR = (ljF + cF) * invR2;
+    dEdR = mk2(in0 ? dEdR.x : 0.f, in1 ? dEdR.y : 0.f);
+    fjx = fjx + dEdR * dx; fjy = fjy + dEdR * dy; fjz = fjz + dEdR * dz;
+    fix = fix - dEdR * dx; fiy = fiy - dEdR * dy; fiz = fiz - dEdR * dz;
+    if (ENERGY) { const v2f e = ljE + cE; energy = energy + mk2(in0 ? e.x : 0.f, in1 ? e.y : 0.f); }
+}
+
 // Transpose-reduce: on entry every lane holds 32 partial sums v[0..32); on exit lane l holds the
 // wave-wide total of v[l & 31].  63 cross-lane moves instead of 32*6.
 __device__ __forceinline__ float transpose_reduce32(float (&v)[OMM_TILE], int lane) {
@@ -119,7 +192,7 @@ __device__ __forceinline__ float transpose_reduce32(float (&v)[OMM_TILE], int la
 }
 
 template <int METHOD, int PBC, bool ENERGY>
-__global__ __launch_bounds__(64) void nb_direct(NbArgs a, const float4* __restrict__ posqI, const float2* __restrict__ sigEpsI) {
+__global__ __launch_bounds__(64, 2) void nb_direct(NbArgs a, const float4* __restrict__ posqI, const float2* __restrict__ sigEpsI) {
     // posqI/sigEpsI alias a.posq/a.sigEps; passing them as separate __restrict__ kernel arguments
     // lets the compiler prove they are never written here and fetch the wave-uniform i-atom data
     // with scalar loads.
@@ -138,6 +211,10 @@ __global__ __launch_bounds__(64) void nb_direct(NbArgs a, const float4* __restri
 #pragma unroll
         for (int k = 0; k < OMM_TILE; k++) { fix[k] = 0.f; fiy[k] = 0.f; fiz[k] = 0.f; }
         float energy = 0.f;
+        v2f energy2 = bc2(0.f);
+        // the block's own atoms, one per lane (lanes 32..63 mirror 0..31); broadcast with v_readlane in the single-image loops
+        const float4 iPosq = a.posq[X * OMM_TILE + (lane & 31)];
+        const float2 iSe = a.sigEps[X * OMM_TILE + (lane & 31)];
         // Single-image path (rectangular boxes): when the block is image-coherent and block + cutoff stay inside half a
         // box length on every axis, the image of j nearest to the block centre is the nearest image for every i atom
         // within the cutoff (any other pair only comes out farther), so the image search is done once per j, not per pair.
@@ -148,29 +225,51 @@ __global__ __launch_bounds__(64) void nb_direct(NbArgs a, const float4* __restri
             const float4 hX = a.blockHalf[X];
             single = hX.w != 0.f && hX.x + a.cutoff < 0.5f * a.box.ax && hX.y + a.cutoff < 0.5f * a.box.by && hX.z + a.cutoff < 0.5f * a.box.cz;
         }
-        for (int row = 0; row < nrows; row++) {
+        // All rows of the chunk are fetched before the first one is processed (index, then the gathers that depend on
+        // it): the two memory round trips are paid once per chunk and the later rows arrive while the first is computed.
+        int jRow[OMM_CHUNK_ROWS]; unsigned mRow[OMM_CHUNK_ROWS]; float4 pjRow[OMM_CHUNK_ROWS]; float2 seRow[OMM_CHUNK_ROWS];
+#pragma unroll
+        for (int row = 0; row < OMM_CHUNK_ROWS; row++) {
             const size_t r = ((size_t) c * OMM_CHUNK_ROWS + row) * OMM_ROW + lane;
-            const int j = a.rowJ[r];
-            float4 pj = a.posq[j];
-            const float2 sej = a.sigEps[j];
+            jRow[row] = row < nrows ? a.rowJ[r] : X * OMM_TILE;
+            mRow[row] = row < nrows && ((maskedBits >> row) & 1) ? a.rowMask[r] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int row = 0; row < OMM_CHUNK_ROWS; row++) { pjRow[row] = a.posq[jRow[row]]; seRow[row] = a.sigEps[jRow[row]]; }
+#pragma unroll
+        for (int row = 0; row < OMM_CHUNK_ROWS; row++) {
+            if (row >= nrows) break;
+            const int j = jRow[row];
+            float4 pj = pjRow[row];
+            const float2 sej = seRow[row];
             const float qjK = OMM_ONE_4PI_EPS0 * pj.w;
             float fjx = 0.f, fjy = 0.f, fjz = 0.f;
             const bool masked = (maskedBits >> row) & 1;
-            const unsigned m = masked ? a.rowMask[r] : 0xFFFFFFFFu;
+            const unsigned m = mRow[row];
             if (PBC == 1 && single) {
                 float dx = pj.x - cX.x, dy = pj.y - cX.y, dz = pj.z - cX.z;
                 min_image<false>(dx, dy, dz, a.box);
                 pj.x = cX.x + dx; pj.y = cX.y + dy; pj.z = cX.z + dz;
+                v2f fj2x = bc2(0.f), fj2y = bc2(0.f), fj2z = bc2(0.f);
                 if (masked) {
 #pragma unroll
-                    for (int k = 0; k < OMM_TILE; k++)
-                        pair_ixn<METHOD, 0, ENERGY, true>(a, ip[k], ise[k], pj, sej, qjK, (m >> k) & 1u, fix[k], fiy[k], fiz[k], fjx, fjy, fjz, energy);
+                    for (int k = 0; k < OMM_TILE; k += 2) {
+                        v2f ax = mk2(fix[k], fix[k + 1]), ay = mk2(fiy[k], fiy[k + 1]), az = mk2(fiz[k], fiz[k + 1]);
+                        pair_ixn2<METHOD, ENERGY, true>(a, rl4(iPosq, k), rl4(iPosq, k + 1), rl2(iSe, k), rl2(iSe, k + 1), pj, sej, qjK, (m >> k) & 1u, (m >> (k + 1)) & 1u,
+                                                        ax, ay, az, fj2x, fj2y, fj2z, energy2);
+                        fix[k] = ax.x; fix[k + 1] = ax.y; fiy[k] = ay.x; fiy[k + 1] = ay.y; fiz[k] = az.x; fiz[k + 1] = az.y;
+                    }
                 }
                 else {
 #pragma unroll
-                    for (int k = 0; k < OMM_TILE; k++)
-                        pair_ixn<METHOD, 0, ENERGY, false>(a, ip[k], ise[k], pj, sej, qjK, true, fix[k], fiy[k], fiz[k], fjx, fjy, fjz, energy);
+                    for (int k = 0; k < OMM_TILE; k += 2) {
+                        v2f ax = mk2(fix[k], fix[k + 1]), ay = mk2(fiy[k], fiy[k + 1]), az = mk2(fiz[k], fiz[k + 1]);
+                        pair_ixn2<METHOD, ENERGY, false>(a, rl4(iPosq, k), rl4(iPosq, k + 1), rl2(iSe, k), rl2(iSe, k + 1), pj, sej, qjK, true, true,
+                                                         ax, ay, az, fj2x, fj2y, fj2z, energy2);
+                        fix[k] = ax.x; fix[k + 1] = ax.y; fiy[k] = ay.x; fiy[k + 1] = ay.y; fiz[k] = az.x; fiz[k + 1] = az.y;
+                    }
                 }
+                fjx += fj2x.x + fj2x.y; fjy += fj2y.x + fj2y.y; fjz += fj2z.x + fj2z.y;
             }
             else if (masked) {
 #pragma unroll
@@ -192,7 +291,7 @@ __global__ __launch_bounds__(64) void nb_direct(NbArgs a, const float4* __restri
             if (!(a.debugFlags & 2)) add_force(a.force, a.paddedAtoms, X * OMM_TILE + lane, tx, ty, tz);
             else if (tx == 12345.f) a.force[0] = 1;
         }
-        if (ENERGY) energyTotal += (double) energy;
+        if (ENERGY) energyTotal += (double) energy + (double) energy2.x + (double) energy2.y;
     }
     if (ENERGY) {
         energyTotal = wave_sum(energyTotal);

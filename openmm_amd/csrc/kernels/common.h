@@ -50,6 +50,20 @@ __device__ __forceinline__ void add_force(omm_fixed* __restrict__ force, int pad
     atomic_add_fixed(force + slot + 2 * paddedAtoms, to_fixed(fz));
 }
 
+// Two floats per lane: arithmetic on v2f compiles to the packed FP32 instructions (v_pk_add/mul/fma_f32), which issue at
+// the rate of their scalar counterparts -- the only way to the FP32 peak of the CDNA3/4 vector ALUs.
+#ifdef OMMHIP_EMU
+struct v2f { float x, y; };
+static inline v2f operator+(v2f a, v2f b) { return {a.x + b.x, a.y + b.y}; }
+static inline v2f operator-(v2f a, v2f b) { return {a.x - b.x, a.y - b.y}; }
+static inline v2f operator*(v2f a, v2f b) { return {a.x * b.x, a.y * b.y}; }
+static inline v2f operator-(v2f a) { return {-a.x, -a.y}; }
+#else
+typedef float v2f __attribute__((ext_vector_type(2)));
+#endif
+__device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ v2f bc2(float a) { return mk2(a, a); }
+
 // Wave-wide sum; every lane of the wave must call it.  Result valid in all lanes.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

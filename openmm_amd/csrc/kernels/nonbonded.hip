@@ -106,21 +106,10 @@ __device__ __forceinline__ void pair_ixn(const NbArgs& a, const float4 pi, const
 // one) -- the vector ALUs of CDNA3/4 only reach their FP32 peak through these.  Same arithmetic as pair_ixn; the three
 // transcendentals per pair (rsq, rcp, exp) stay scalar.  Used on the single-image path, where no image search is needed.
 // ------------------------------------------------------------------------------------------------
-#ifdef OMMHIP_EMU
-struct v2f { float x, y; };
-static inline v2f operator+(v2f a, v2f b) { return {a.x + b.x, a.y + b.y}; }
-static inline v2f operator-(v2f a, v2f b) { return {a.x - b.x, a.y - b.y}; }
-static inline v2f operator*(v2f a, v2f b) { return {a.x * b.x, a.y * b.y}; }
-static inline v2f operator-(v2f a) { return {-a.x, -a.y}; }
-#else
-typedef float v2f __attribute__((ext_vector_type(2)));
-#endif
-__device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
 // wave-uniform copy of lane k's value (v_readlane_b32): i-atom data held one atom per lane, no memory access in the loop
 __device__ __forceinline__ float rl(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
 __device__ __forceinline__ float4 rl4(float4 v, int k) { return make_float4(rl(v.x, k), rl(v.y, k), rl(v.z, k), rl(v.w, k)); }
 __device__ __forceinline__ float2 rl2(float2 v, int k) { return make_float2(rl(v.x, k), rl(v.y, k)); }
-__device__ __forceinline__ v2f bc2(float a) { return mk2(a, a); }
 
 template <int METHOD, bool ENERGY, bool MASKED>
 __device__ __forceinline__ void pair_ixn2(const NbArgs& a, const float4 pi0, const float4 pi1, const float2 se0, const float2 se1,

@@ -245,6 +245,15 @@ int ommhip_term_forces(int kind, const ommhip_term_list* terms, const void* pos_
                        const double box[6], int periodic, const double* charge_d, double alpha,
                        long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
 
+/* The front of a force evaluation in ONE launch: after ommhip_nl_prepare, (a) the neighbour-list rebuild if one was
+ * requested (ommhip_nl_rebuild_if_requested), (b) the PME charge spreading (ommhip_pme_reciprocal with
+ * OMMHIP_PME_SPREAD_ONLY; pme may be NULL) and (c) the per-term forces (ommhip_term_forces_multi; num_lists may be 0) are
+ * independent of each other and each uses a fraction of the chip, so they run as three groups of workgroups of the
+ * same launch.  Continue with ommhip_nb_direct and ommhip_pme_reciprocal(OMMHIP_PME_AFTER_SPREAD).  The grid of pme
+ * must have been cleared already (grid_precleared). */
+int ommhip_force_front(const ommhip_neighbor_list* nl, const ommhip_pme* pme, int num_lists, const ommhip_term_batch* lists,
+                       const void* pos_d, long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
+
 /* Classic Ewald reciprocal sum for rectangular boxes (ReferenceLJCoulombIxn.cpp:272-367).
  * structure_d: device double2[kmax_x*(2 kmax_y-1)*(2 kmax_z-1)] scratch. */
 int ommhip_ewald_reciprocal(const void* pos_d, const double* charge_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms,

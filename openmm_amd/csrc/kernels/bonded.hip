@@ -162,15 +162,14 @@ __device__ __forceinline__ double term_periodic_torsion(const TermCtx& c, int t)
     return k * (1.0 + cos(deltaAngle));
 }
 
-__global__ __launch_bounds__(256) void k_terms(TermArgs a) {
-    __shared__ double partial[4];
+__device__ __forceinline__ void terms_body(const TermArgs& a, const int block, double (&partial)[4]) {
     // which list does this workgroup belong to?  (numLists <= OMMHIP_MAX_TERM_LISTS, wave-uniform)
     int li = 0;
 #pragma unroll
     for (int i = 1; i < OMMHIP_MAX_TERM_LISTS; i++)
-        if (i < a.numLists && (int) blockIdx.x >= a.list[i].firstBlock) li = i;
+        if (i < a.numLists && block >= a.list[i].firstBlock) li = i;
     const TermList& l = a.list[li];
-    const int t = ((int) blockIdx.x - l.firstBlock) * 256 + threadIdx.x;
+    const int t = (block - l.firstBlock) * 256 + threadIdx.x;
     double energy = 0;
     if (t < l.numTerms) {
         const TermCtx c(a, l);
@@ -186,8 +185,13 @@ __global__ __launch_bounds__(256) void k_terms(TermArgs a) {
         energy = wave_sum(energy);
         if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = energy;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], partial[0] + partial[1] + partial[2] + partial[3]);
+        if (threadIdx.x == 0) atomicAdd(&a.energyBuffer[block % a.energySlots], partial[0] + partial[1] + partial[2] + partial[3]);
     }
+}
+
+__global__ __launch_bounds__(256) void k_terms(TermArgs a) {
+    __shared__ double partial[4];
+    terms_body(a, blockIdx.x, partial);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -310,24 +314,32 @@ __global__ __launch_bounds__(256) void k_cm_subtract(double4* __restrict__ vel, 
 
 }  // namespace
 
-extern "C" int ommhip_term_forces_multi(int num_lists, const ommhip_term_batch* lists, const void* pos_d, const int* slot_of_atom_d, int padded_atoms,
-                                        const double box[6], long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
-    if (num_lists > OMMHIP_MAX_TERM_LISTS) return 1;
-    TermArgs a;
+// -> number of workgroups (0: nothing to do, -1: bad input)
+static int make_term_args(TermArgs& a, int num_lists, const ommhip_term_batch* lists, const void* pos_d, const int* slot_of_atom_d, int padded_atoms,
+                          const double box[6], long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy) {
+    if (num_lists > OMMHIP_MAX_TERM_LISTS) return -1;
     a.numLists = 0; a.paddedAtoms = padded_atoms; a.includeEnergy = include_energy; a.energySlots = energy_slots;
     a.box.ax = box[0]; a.box.bx = box[1]; a.box.by = box[2]; a.box.cx = box[3]; a.box.cy = box[4]; a.box.cz = box[5];
     a.pos = (const double4*) pos_d; a.slotOfAtom = slot_of_atom_d; a.force = force_d; a.energyBuffer = energy_buffer_d;
     int blocks = 0;
     for (int i = 0; i < num_lists; i++) {
         if (lists[i].terms.num_terms <= 0) continue;
-        if (lists[i].kind < OMMHIP_TERM_EXCEPTION14 || lists[i].kind > OMMHIP_TERM_PERIODIC_TORSION) return 1;
+        if (lists[i].kind < OMMHIP_TERM_EXCEPTION14 || lists[i].kind > OMMHIP_TERM_PERIODIC_TORSION) return -1;
         TermList& l = a.list[a.numLists++];
         l.kind = lists[i].kind; l.numTerms = lists[i].terms.num_terms; l.periodic = lists[i].periodic; l.firstBlock = blocks;
         l.alpha = lists[i].alpha; l.atoms = lists[i].terms.atoms; l.params = lists[i].terms.params; l.charge = lists[i].charge;
         blocks += (l.numTerms + 255) / 256;
     }
-    if (blocks == 0) return 0;
     for (int i = a.numLists; i < OMMHIP_MAX_TERM_LISTS; i++) { a.list[i] = a.list[0]; a.list[i].numTerms = 0; a.list[i].firstBlock = blocks; }
+    return blocks;
+}
+
+extern "C" int ommhip_term_forces_multi(int num_lists, const ommhip_term_batch* lists, const void* pos_d, const int* slot_of_atom_d, int padded_atoms,
+                                        const double box[6], long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
+    TermArgs a;
+    const int blocks = make_term_args(a, num_lists, lists, pos_d, slot_of_atom_d, padded_atoms, box, force_d, energy_buffer_d, energy_slots, include_energy);
+    if (blocks < 0) return 1;
+    if (blocks == 0) return 0;
     hipLaunchKernelGGL(k_terms, dim3(blocks), dim3(256), 0, (hipStream_t) stream, a);
     return (int) hipGetLastError();
 }

@@ -193,16 +193,25 @@ __global__ __launch_bounds__(1024) void nl_bin_blocks(NlArgs a) {
 // ------------------------------------------------------------------------------------------------
 // Rows of i-block X = blockIdx.x.
 // ------------------------------------------------------------------------------------------------
+// LDS of one builder workgroup (a struct so that fused launches can alias it with the LDS of other work)
+struct NlShared {
+    int listJ[NL_LIST];
+    unsigned listM[NL_LIST];
+    int candY[NL_CAND];
+    int rowMasked[NL_LIST / OMM_ROW];
+    int candCount, listCount, chunkBase, candOverflow;
+};
+
+// X = i-block of this workgroup, numWorkgroups = number of builder workgroups of the launch (for the hand-over at the end)
 template <int PBC>
-__global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
+__device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const int numWorkgroups, NlShared& sh) {
     if (a.state[ST_REBUILD] == 0) return;
-    __shared__ int listJ[NL_LIST];
-    __shared__ unsigned listM[NL_LIST];
-    __shared__ int candY[NL_CAND];
-    __shared__ int rowMasked[NL_LIST / OMM_ROW];
-    __shared__ int sCandCount, sListCount, sChunkBase, sCandOverflow;
+    int* const listJ = sh.listJ;
+    unsigned* const listM = sh.listM;
+    int* const candY = sh.candY;
+    int* const rowMasked = sh.rowMasked;
+    int& sCandCount = sh.candCount; int& sListCount = sh.listCount; int& sChunkBase = sh.chunkBase; int& sCandOverflow = sh.candOverflow;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int X = blockIdx.x;
     const float R2 = a.listCutoff2;
     const float Rlist = sqrtf(R2);
     const long long tStart = clock64();      // builder cost per i-block, kept in posqRef[..].w for diagnostics
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
         a.posqRef[X * OMM_TILE + 1].w = (float) candTotal;
         __threadfence();
         const int done = atomicAdd(&a.state[ST_BLOCKS_DONE], 1);
-        if (done == (int) gridDim.x - 1) {
+        if (done == numWorkgroups - 1) {
             // publish the list length, return the working counter to zero, clear the request
             a.state[ST_NUM_CHUNKS] = atomicExch(&a.state[ST_ALLOC], 0);
             a.state[ST_BLOCKS_DONE] = 0;
@@ -468,6 +477,12 @@ __global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
             atomicAdd(&a.state[ST_REBUILD_COUNT], 1);
         }
     }
+}
+
+template <int PBC>
+__global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
+    __shared__ NlShared sh;
+    nl_find_body<PBC>(a, blockIdx.x, gridDim.x, sh);
 }
 
 // ------------------------------------------------------------------------------------------------

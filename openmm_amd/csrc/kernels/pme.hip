@@ -128,18 +128,28 @@ __device__ __forceinline__ int wrap_rel(int d, int n) {      // d in (-n, n) -> 
     return d;
 }
 
-__global__ __launch_bounds__(256) void pme_spread_lds(PmeArgs a) {
-    // The brick accumulates in 32-bit fixed point: LDS integer atomics run ~9x faster than LDS float atomics on this
-    // chip (tools/microbench/lds_atomics.hip: 2.9 vs 0.33 lane-ops/clk/CU), and the sum is order independent.
-    __shared__ int brick[BRICK_WORDS];
-    __shared__ float brickScale;
-    __shared__ float th[SPREAD_ATOMS][3][PME_ORDER];
-    __shared__ int baseIdx[SPREAD_ATOMS][3];
-    __shared__ float charge[SPREAD_ATOMS];
-    __shared__ int ref[3];
-    __shared__ int minRel[3];
+// LDS of one spread workgroup.  The brick accumulates in 32-bit fixed point: LDS integer atomics run ~9x faster than LDS
+// float atomics on this chip (tools/microbench/lds_atomics.hip: 2.9 vs 0.33 lane-ops/clk/CU), and the sum is order independent.
+struct SpreadShared {
+    int brick[BRICK_WORDS];
+    float brickScale;
+    float th[SPREAD_ATOMS][3][PME_ORDER];
+    int baseIdx[SPREAD_ATOMS][3];
+    float charge[SPREAD_ATOMS];
+    int ref[3];
+    int minRel[3];
+};
+
+__device__ __forceinline__ void pme_spread_body(const PmeArgs& a, const int block, SpreadShared& sh) {
+    int* const brick = sh.brick;
+    float& brickScale = sh.brickScale;
+    float (&th)[SPREAD_ATOMS][3][PME_ORDER] = sh.th;
+    int (&baseIdx)[SPREAD_ATOMS][3] = sh.baseIdx;
+    float* const charge = sh.charge;
+    int* const ref = sh.ref;
+    int* const minRel = sh.minRel;
     const int t = threadIdx.x;
-    const int slot0 = blockIdx.x * SPREAD_ATOMS;
+    const int slot0 = block * SPREAD_ATOMS;
     if (t < 3) { minRel[t] = 1 << 30; ref[t] = -1; }
     for (int i = t; i < BRICK_WORDS; i += 256) brick[i] = 0;
     // splines: thread (atom, dimension)
@@ -236,6 +246,11 @@ __global__ __launch_bounds__(256) void pme_spread_lds(PmeArgs a) {
             atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], v);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void pme_spread_lds(PmeArgs a) {
+    __shared__ SpreadShared sh;
+    pme_spread_body(a, blockIdx.x, sh);
 }
 
 __global__ __launch_bounds__(256) void pme_interpolate(PmeArgs a) {
@@ -729,10 +744,9 @@ extern "C" int ommhip_pme_build_eterm(const ommhip_pme* pme, void* stream) {
     return (int) hipGetLastError();
 }
 
-extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, int padded_atoms, long long* force_d,
-                                     double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
-    hipStream_t st = (hipStream_t) stream;
-    const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
+static PmeArgs make_pme_args(const ommhip_pme* pme, const void* posq_d, int padded_atoms, long long* force_d,
+                             double* energy_buffer_d, int energy_slots, int include_energy) {
+    const int nx = pme->nx, ny = pme->ny, nz = pme->nz;
     PmeArgs pa;
     pa.paddedAtoms = padded_atoms; pa.nx = nx; pa.ny = ny; pa.nz = nz;
     static const int spreadDebug = getenv("OPENMM_HIP_DEBUG_SPREAD") != nullptr ? atoi(getenv("OPENMM_HIP_DEBUG_SPREAD")) : 0;   // profiling only
@@ -748,6 +762,14 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     pa.boxd.ax = b[0]; pa.boxd.bx = b[1]; pa.boxd.by = b[2]; pa.boxd.cx = b[3]; pa.boxd.cy = b[4]; pa.boxd.cz = b[5];
     pa.alpha = pme->alpha; pa.exclPeriodic = pme->excl_periodic;
     pa.includeEnergy = include_energy; pa.energySlots = energy_slots; pa.energyBuffer = energy_buffer_d;
+    return pa;
+}
+
+extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, int padded_atoms, long long* force_d,
+                                     double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
+    hipStream_t st = (hipStream_t) stream;
+    const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
+    PmeArgs pa = make_pme_args(pme, posq_d, padded_atoms, force_d, energy_buffer_d, energy_slots, include_energy);
     float2* cgrid = (float2*) pme->grid_complex;
 
     const int spreadBlocks = (padded_atoms * 8 + 255) / 256;

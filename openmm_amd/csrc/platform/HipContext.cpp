@@ -202,19 +202,61 @@ void HipContext::joinPme() {
     pmeJoinPending = false;
 }
 
-void HipContext::addTerms(const ommhip_term_batch& batch, bool includeEnergy) {
+void HipContext::addTerms(const ommhip_term_batch& batch, bool includeEnergy, int id) {
     if (batch.terms.num_terms <= 0) return;
     if (!pendingTerms.empty() && (pendingTermsEnergy != includeEnergy || pendingTerms.size() == OMMHIP_MAX_TERM_LISTS))
         flushTerms();
     pendingTermsEnergy = includeEnergy;
     pendingTerms.push_back(batch);
+    pendingTermIds.push_back(id);
 }
 
 void HipContext::flushTerms() {
     if (pendingTerms.empty()) return;
+    ensureCleared();
     HIP_CHECK(ommhip_term_forces_multi((int) pendingTerms.size(), pendingTerms.data(), pos.ptr, slotOfAtom.as<int>(), paddedAtoms, box,
                                        force.as<long long>(), energyBuffer.as<double>(), EnergySlots, pendingTermsEnergy ? 1 : 0, stream));
     pendingTerms.clear();
+    pendingTermIds.clear();
+}
+
+int HipContext::registerTerms(int group, const ommhip_term_batch& batch) {
+    TermRegistration r = {nextTermId++, group, batch};
+    termRegistry.push_back(r);
+    return r.id;
+}
+
+void HipContext::updateTerms(int id, const ommhip_term_batch& batch) {
+    for (size_t i = 0; i < termRegistry.size(); i++)
+        if (termRegistry[i].id == id) termRegistry[i].batch = batch;
+}
+
+void HipContext::unregisterTerms(int id) {
+    for (size_t i = 0; i < termRegistry.size(); i++)
+        if (termRegistry[i].id == id) { termRegistry.erase(termRegistry.begin() + i); return; }
+}
+
+bool HipContext::termsLaunched(int id) const {
+    return std::find(launchedTermIds.begin(), launchedTermIds.end(), id) != launchedTermIds.end();
+}
+
+void HipContext::collectFrontTerms(vector<ommhip_term_batch>& out, bool includeEnergy) {
+    if (!pendingTerms.empty() && pendingTermsEnergy != includeEnergy)
+        flushTerms();
+    // queued lists first (their owners have executed already), then registered lists whose owners will execute later
+    while (!pendingTerms.empty() && out.size() < OMMHIP_MAX_TERM_LISTS) {
+        out.push_back(pendingTerms.back());
+        if (pendingTermIds.back() >= 0) launchedTermIds.push_back(pendingTermIds.back());
+        pendingTerms.pop_back();
+        pendingTermIds.pop_back();
+    }
+    for (size_t i = 0; i < termRegistry.size() && out.size() < OMMHIP_MAX_TERM_LISTS; i++) {
+        const TermRegistration& r = termRegistry[i];
+        if (r.batch.terms.num_terms <= 0 || ((currentGroups >> r.group) & 1) == 0 || termsLaunched(r.id)) continue;
+        if (std::find(pendingTermIds.begin(), pendingTermIds.end(), r.id) != pendingTermIds.end()) continue;
+        out.push_back(r.batch);
+        launchedTermIds.push_back(r.id);
+    }
 }
 
 void HipContext::saveForces() {

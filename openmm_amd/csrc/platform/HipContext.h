@@ -92,7 +92,20 @@ public:
     void forkPme();
     void markPmeDone();
     void joinPme();
-    void addTerms(const ommhip_term_batch& batch, bool includeEnergy);
+    void addTerms(const ommhip_term_batch& batch, bool includeEnergy, int id = -1);
+    /** Term lists that persist across evaluations (bonds, angles, torsions) are registered once with their force group, so
+     *  that whoever opens an evaluation can launch all lists of the evaluated groups together with its own work
+     *  (ommhip_force_front) before the owning Force objects have executed.  Their execute() then finds them launched. */
+    int registerTerms(int group, const ommhip_term_batch& batch);
+    void updateTerms(int id, const ommhip_term_batch& batch);
+    void unregisterTerms(int id);
+    bool termsLaunched(int id) const;
+    /** Moves every term list of this evaluation that can still be launched into `out` (at most OMMHIP_MAX_TERM_LISTS in
+     *  total, `out` may already hold some): the queued ones and the registered ones of the evaluated force groups. */
+    void collectFrontTerms(std::vector<ommhip_term_batch>& out, bool includeEnergy);
+    int currentGroups = -1;
+    /** Start of an evaluation: which force groups are evaluated; forgets what the previous evaluation launched. */
+    void beginEvaluation(int groups) { currentGroups = groups; launchedTermIds.clear(); }
     void flushTerms();
     void saveForces();                                         // device copy of the force buffer (energy-only evaluations)
     void restoreForces();
@@ -136,7 +149,12 @@ private:
     void* pmeDoneEvent = NULL;
     bool pmeJoinPending = false;
     std::vector<ommhip_term_batch> pendingTerms;
+    std::vector<int> pendingTermIds;
     bool pendingTermsEnergy = false;
+    struct TermRegistration { int id, group; ommhip_term_batch batch; };
+    std::vector<TermRegistration> termRegistry;
+    std::vector<int> launchedTermIds;          // ids whose terms already went out this evaluation (fused front launch)
+    int nextTermId = 1;
     bool reorderRequested;
     int deviceIndex;
     double* pinnedResult;

@@ -266,6 +266,7 @@ void HipCalcForcesAndEnergyKernel::beginComputation(ContextImpl& context, bool i
     if (!includeForce && !hip.hostMode)
         hip.saveForces();
     hip.clearForces();
+    hip.beginEvaluation(groups);
 }
 
 double HipCalcForcesAndEnergyKernel::finishComputation(ContextImpl& context, bool includeForce, bool includeEnergy, int groups, bool& valid) {
@@ -779,7 +780,7 @@ void HipCalcNonbondedForceKernel::computeParameters(ContextImpl& context, bool f
     slotParamsDirty = true;
 }
 
-void HipCalcNonbondedForceKernel::launchPme(int includeEnergy) {
+void HipCalcNonbondedForceKernel::fillPmeStruct() {
     for (int i = 0; i < 6; i++) pme.box[i] = hip.box[i];
     pme.excl_start = foldExclusions ? exclStart.as<int>() : NULL;
     pme.excl_atoms = exclAtoms.as<int>(); pme.atom_of_slot = hip.atomOfSlot.as<int>();
@@ -787,6 +788,17 @@ void HipCalcNonbondedForceKernel::launchPme(int includeEnergy) {
     if (etermDirty) {
         HIP_CHECK(ommhip_pme_build_eterm(&pme, hip.stream));
         etermDirty = false;
+    }
+}
+
+void HipCalcNonbondedForceKernel::launchPme(int includeEnergy, bool spreadDone) {
+    fillPmeStruct();
+    if (spreadDone) {
+        // the charges were spread by the fused front launch of this evaluation
+        pme.phases = OMMHIP_PME_AFTER_SPREAD;
+        HIP_CHECK(ommhip_pme_reciprocal(&pme, posq.ptr, hip.paddedAtoms, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy, hip.stream));
+        pme.phases = OMMHIP_PME_ALL;
+        return;
     }
     if (hip.usePmeStream) {
         // The whole reciprocal-space chain goes to the side stream and runs concurrently with the list rebuild and the
@@ -827,7 +839,7 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
     }
     double energy = 0;
     const int ie = includeEnergy ? 1 : 0;
-    bool pmeLaunched = false;
+    bool pmeLaunched = false, frontLaunched = false;
     // The exclusion correction belongs to the direct-space group (ReferenceLJCoulombIxn.cpp:373,462); when both halves
     // are evaluated together it is computed by the PME interpolation launch instead of a term list of its own.
     const char* noFoldEnv = getenv("OPENMM_HIP_NO_FOLDED_EXCLUSIONS");          // test/A-B knob, read per evaluation
@@ -852,7 +864,29 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
                 HIP_CHECK(ommhip_memcpy_h2d(nlState.ptr, request, sizeof(request), hip.stream));
             }
             // positions -> posq, displacement check, bounds; then the device-conditional rebuild (2 launches)
-            if (!forceRebuild && includeReciprocal && nonbondedMethod == PME && hip.usePmeStream) {
+            static const bool noFront = getenv("OPENMM_HIP_NO_FUSED_FRONT") != NULL;          // A/B knob
+            if (!forceRebuild && includeReciprocal && nonbondedMethod == PME && !hip.usePmeStream && !noFront && pme.grid_precleared && pme.spread_mode == 0) {
+                // single-stream mode: list rebuild (if requested), charge spreading and every per-term force list of this
+                // evaluation are independent once the positions are converted -- they go out as ONE launch
+                const bool clear = hip.takePendingClear();
+                HIP_CHECK(ommhip_nl_prepare(&nl, hip.pos.ptr, hip.wrap.ptr, clear ? hip.force.ptr : NULL, clear ? hip.force.bytes : 0,
+                                            clear ? hip.extraClearPtr : NULL, clear ? hip.extraClearBytes : 0, hip.stream));
+                fillPmeStruct();
+                vector<ommhip_term_batch> lists;
+                ommhip_term_batch t14 = {OMMHIP_TERM_EXCEPTION14, {num14, exceptionAtomsD.as<int>(), exceptionParamsD.as<double>()},
+                                         exceptionsArePeriodic ? 1 : 0, chargeD.as<double>(), ewaldAlpha};
+                if (num14 > 0) lists.push_back(t14);
+                if (params.ewald && !foldExclusions && numExclusionPairs > 0) {
+                    ommhip_term_batch tex = {OMMHIP_TERM_EWALD_EXCLUSION, {numExclusionPairs, exclusionPairsD.as<int>(), NULL},
+                                             exceptionsArePeriodic ? 1 : 0, chargeD.as<double>(), ewaldAlpha};
+                    lists.push_back(tex);
+                }
+                hip.collectFrontTerms(lists, includeEnergy);
+                HIP_CHECK(ommhip_force_front(&nl, &pme, (int) lists.size(), lists.empty() ? NULL : lists.data(), hip.pos.ptr, hip.force.as<long long>(),
+                                             hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+                frontLaunched = true;
+            }
+            else if (!forceRebuild && includeReciprocal && nonbondedMethod == PME && hip.usePmeStream) {
                 // side-stream mode: reciprocal space only needs posq, so it is forked BEFORE the (possible) list rebuild
                 // and overlaps with it as well as with the pair kernel
                 const bool clear = hip.takePendingClear();
@@ -889,8 +923,8 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
         // bonded terms of the other forces (HipContext::flushTerms)
         ommhip_term_batch t14 = {OMMHIP_TERM_EXCEPTION14, {num14, exceptionAtomsD.as<int>(), exceptionParamsD.as<double>()},
                                  exceptionsArePeriodic ? 1 : 0, chargeD.as<double>(), ewaldAlpha};
-        hip.addTerms(t14, includeEnergy);
-        if (params.ewald && !foldExclusions) {
+        if (!frontLaunched) hip.addTerms(t14, includeEnergy);
+        if (params.ewald && !foldExclusions && !frontLaunched) {
             ommhip_term_batch tex = {OMMHIP_TERM_EWALD_EXCLUSION, {numExclusionPairs, exclusionPairsD.as<int>(), NULL},
                                      exceptionsArePeriodic ? 1 : 0, chargeD.as<double>(), ewaldAlpha};
             hip.addTerms(tex, includeEnergy);
@@ -900,7 +934,7 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
     }
     if (includeReciprocal) {
         if (nonbondedMethod == PME) {
-            if (!pmeLaunched) launchPme(ie);
+            if (!pmeLaunched) launchPme(ie, frontLaunched);
         }
         else if (nonbondedMethod == Ewald) {
             if (hip.box[1] != 0.0 || hip.box[3] != 0.0 || hip.box[4] != 0.0)
@@ -960,25 +994,35 @@ void HipCalcNonbondedForceKernel::getLJPMEParameters(double& alpha, int& nx, int
 // ================================================================================================
 // Bonded terms
 // ================================================================================================
-void HipTermForce::upload(const vector<int>& atoms, const vector<double>& params, bool usesPeriodic) {
+ommhip_term_batch HipTermForce::batch() const {
+    ommhip_term_batch b = {kind, {numTerms, atomsD.as<int>(), paramsD.as<double>()}, periodic ? 1 : 0, NULL, 0.0};
+    return b;
+}
+HipTermForce::~HipTermForce() {
+    if (registrationId >= 0 && data.hip != NULL) data.hip->unregisterTerms(registrationId);
+}
+void HipTermForce::upload(const vector<int>& atoms, const vector<double>& params, bool usesPeriodic, int forceGroup) {
     data.hip->setAsCurrent();
     numTerms = (int) atoms.size() / atomsPerTerm;
     periodic = usesPeriodic;
     if (usesPeriodic) data.hip->usePeriodic = true;
     uploadVector(atomsD, atoms, data.hip->stream);
     uploadVector(paramsD, params, data.hip->stream);
+    if (registrationId < 0) registrationId = data.hip->registerTerms(forceGroup, batch());
+    else data.hip->updateTerms(registrationId, batch());
 }
 void HipTermForce::uploadParams(const vector<double>& params) {
     data.hip->setAsCurrent();
     if ((int) params.size() != numTerms * paramsPerTerm)
         throw OpenMMException("updateParametersInContext: The number of terms has changed");
     uploadVector(paramsD, params, data.hip->stream);
+    if (registrationId >= 0) data.hip->updateTerms(registrationId, batch());      // uploadVector may have moved the buffer
 }
 void HipTermForce::execute(bool includeEnergy) {
     HipContext& hip = *data.hip;
     hip.setAsCurrent();
-    ommhip_term_batch b = {kind, {numTerms, atomsD.as<int>(), paramsD.as<double>()}, periodic ? 1 : 0, NULL, 0.0};
-    hip.addTerms(b, includeEnergy);
+    if (registrationId >= 0 && hip.termsLaunched(registrationId)) return;         // went out with the front launch of this evaluation
+    hip.addTerms(batch(), includeEnergy, registrationId);
 }
 
 void HipCalcHarmonicBondForceKernel::initialize(const System& system, const HarmonicBondForce& force) {
@@ -988,7 +1032,7 @@ void HipCalcHarmonicBondForceKernel::initialize(const System& system, const Harm
         force.getBondParameters(i, p1, p2, length, k);
         atoms.push_back(p1); atoms.push_back(p2); params.push_back(length); params.push_back(k);
     }
-    terms.upload(atoms, params, force.usesPeriodicBoundaryConditions());
+    terms.upload(atoms, params, force.usesPeriodicBoundaryConditions(), force.getForceGroup());
 }
 double HipCalcHarmonicBondForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy) {
     terms.execute(includeEnergy);
@@ -1011,7 +1055,7 @@ void HipCalcHarmonicAngleForceKernel::initialize(const System& system, const Har
         force.getAngleParameters(i, p1, p2, p3, angle, k);
         atoms.push_back(p1); atoms.push_back(p2); atoms.push_back(p3); params.push_back(angle); params.push_back(k);
     }
-    terms.upload(atoms, params, force.usesPeriodicBoundaryConditions());
+    terms.upload(atoms, params, force.usesPeriodicBoundaryConditions(), force.getForceGroup());
 }
 double HipCalcHarmonicAngleForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy) {
     terms.execute(includeEnergy);
@@ -1035,7 +1079,7 @@ void HipCalcPeriodicTorsionForceKernel::initialize(const System& system, const P
         atoms.push_back(p1); atoms.push_back(p2); atoms.push_back(p3); atoms.push_back(p4);
         params.push_back(k); params.push_back(phase); params.push_back(periodicity);
     }
-    terms.upload(atoms, params, force.usesPeriodicBoundaryConditions());
+    terms.upload(atoms, params, force.usesPeriodicBoundaryConditions(), force.getForceGroup());
 }
 double HipCalcPeriodicTorsionForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy) {
     terms.execute(includeEnergy);

@@ -114,7 +114,8 @@ private:
     void computeParameters(ContextImpl& context, bool force);
     void allocateNeighborList(int maxChunks);
     void setupPme();
-    void launchPme(int includeEnergy);
+    void fillPmeStruct();
+    void launchPme(int includeEnergy, bool spreadDone = false);
     void rebuildEterm();
     int estimateChunks() const;
     HipPlatform::PlatformData& data;
@@ -149,8 +150,9 @@ private:
 /** Common code of the per-term bonded kernels. */
 class HipTermForce {
 public:
-    HipTermForce(HipPlatform::PlatformData& data, int kind, int atomsPerTerm, int paramsPerTerm) : data(data), kind(kind), atomsPerTerm(atomsPerTerm), paramsPerTerm(paramsPerTerm), numTerms(0), periodic(false) {}
-    void upload(const std::vector<int>& atoms, const std::vector<double>& params, bool usesPeriodic);
+    HipTermForce(HipPlatform::PlatformData& data, int kind, int atomsPerTerm, int paramsPerTerm) : data(data), kind(kind), atomsPerTerm(atomsPerTerm), paramsPerTerm(paramsPerTerm), numTerms(0), periodic(false), registrationId(-1) {}
+    ~HipTermForce();
+    void upload(const std::vector<int>& atoms, const std::vector<double>& params, bool usesPeriodic, int forceGroup);
     void uploadParams(const std::vector<double>& params);
     void execute(bool includeEnergy);
     int getNumTerms() const { return numTerms; }
@@ -158,6 +160,8 @@ private:
     HipPlatform::PlatformData& data;
     int kind, atomsPerTerm, paramsPerTerm, numTerms;
     bool periodic;
+    int registrationId;
+    ommhip_term_batch batch() const;
     DeviceBuffer atomsD, paramsD;
 };
 

@@ -152,11 +152,12 @@ HipPlatform::HipPlatform() {
     setPropertyDefaultValue(HipDeviceName(), "");
     setPropertyDefaultValue(HipPrecision(), "mixed");
     setPropertyDefaultValue(HipDeterministicForces(), "false");
-    // Reciprocal space runs on a high-priority side stream, forked right after the positions are converted -- i.e. before
-    // the (possible) neighbour-list rebuild, whose latency-bound workgroups overlap well with the small PME launches.
-    // Measured on MI355X, DHFR-size workload: 1150 vs 1128 ns/day.  (Forking only after the rebuild, as the first version
-    // did, was slower than one stream: the pair kernel alone saturates the chip.)
-    setPropertyDefaultValue(HipDisablePmeStream(), "false");
+    // Default: ONE stream.  The work that is independent at the start of an evaluation (list rebuild, charge spreading,
+    // per-term forces) overlaps inside one fused launch (ommhip_force_front) instead of across streams: a cross-stream
+    // dependency costs ~13 us on this stack, twice per step.  Measured on MI355X, DHFR-size workload, same box:
+    // fused single stream 1275 ns/day, side stream (DisablePmeStream=false) 1214, single stream without fusion 1182.
+    const char* streamDefault = getenv("OPENMM_HIP_DEFAULT_DISABLE_PME_STREAM");      // test / A-B knob for the default
+    setPropertyDefaultValue(HipDisablePmeStream(), streamDefault != NULL && streamDefault[0] == '0' ? "false" : "true");
 }
 
 double HipPlatform::getSpeed() const {

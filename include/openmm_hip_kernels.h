@@ -116,7 +116,7 @@ typedef struct ommhip_neighbor_list {
     const int* excl_start;     /* [num_atoms+1] CSR of excluded partners (atom indices) */
     const int* excl_atoms;
     const void* excl_block_range; /* int2[padded_atoms/32] or NULL: per i-block, lowest/highest block that holds an exclusion partner */
-    int* state;               /* int[OMMHIP_NL_STATE_INTS]: 0 rebuild-request, 1 chunks used, 2 overflow, 3 scratch, 4 #rebuilds */
+    int* state;               /* int[OMMHIP_NL_STATE_INTS]: 0 rebuild-request, 1 chunks used, 2 overflow, 3 scratch, 4 #rebuilds, 5 scratch; zero-initialised by the caller */
     void* block_center;        /* float4[padded_atoms/32] */
     void* block_half;          /* float4[padded_atoms/32] */
     void* chunk_info;          /* int2[max_chunks]  (i-block, nrows | maskedRowBits<<8) */
@@ -199,7 +199,7 @@ typedef struct ommhip_pme {
     int excl_periodic;         /* NonbondedForce::getExceptionsUsePeriodicBoundaryConditions() */
     int phases;                /* OMMHIP_PME_ALL (0), or the two halves separately so that they can go to different streams */
 } ommhip_pme;
-enum { OMMHIP_PME_ALL = 0, OMMHIP_PME_SPREAD_ONLY = 1, OMMHIP_PME_AFTER_SPREAD = 2 };
+enum { OMMHIP_PME_ALL = 0, OMMHIP_PME_SPREAD_ONLY = 1, OMMHIP_PME_AFTER_SPREAD = 2, OMMHIP_PME_INTERPOLATE_ONLY = 3 };
 
 int ommhip_fft_supported_size(int n);   /* 1 if n factors into 2,3,5,7 and fits the LDS line buffer; no device access */
 int ommhip_pme_build_eterm(const ommhip_pme* pme, void* stream);
@@ -253,6 +253,15 @@ int ommhip_term_forces(int kind, const ommhip_term_list* terms, const void* pos_
  * must have been cleared already (grid_precleared). */
 int ommhip_force_front(const ommhip_neighbor_list* nl, const ommhip_pme* pme, int num_lists, const ommhip_term_batch* lists,
                        const void* pos_d, long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
+/* The middle of a PME force evaluation in ONE stream: the three FFT launches of reciprocal space (plane transforms, x
+ * transform with the convolution, plane transforms back) are latency-bound and occupy 56-112 workgroups each; the pair
+ * kernel is independent of them, so every FFT launch also carries a third of the pair kernel's chunks on the remaining
+ * CUs.  Replaces ommhip_nb_direct plus the FFT part of ommhip_pme_reciprocal; continue with
+ * ommhip_pme_reciprocal(phases = OMMHIP_PME_INTERPOLATE_ONLY).
+ * Returns -1 (nothing launched) when the configuration is not covered (non-rectangular box, no Ewald/PME, plane too large
+ * for the fused kernel's LDS budget): the caller then uses the separate entry points. */
+int ommhip_pairs_with_fft(const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, const void* sig_eps_d, const ommhip_pme* pme,
+                          long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
 
 /* Classic Ewald reciprocal sum for rectangular boxes (ReferenceLJCoulombIxn.cpp:272-367).
  * structure_d: device double2[kmax_x*(2 kmax_y-1)*(2 kmax_z-1)] scratch. */

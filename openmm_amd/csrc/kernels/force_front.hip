@@ -5,10 +5,13 @@
 // a fraction of the chip; as separate launches they cost 1-53 + 16 + 8 us back to back, and running them on separate
 // streams costs ~13 us per cross-stream dependency on this stack.  force_front runs them as three groups of workgroups
 // of ONE launch (same workgroup size, LDS aliased through a union), so they overlap without any synchronisation object.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "neighbor.hip"
 #include "pme.hip"
 #include "bonded.hip"
+#include "nonbonded.hip"
 
 namespace {
 
@@ -61,5 +64,107 @@ extern "C" int ommhip_force_front(const ommhip_neighbor_list* nl, const ommhip_p
     else if (nl->pbc == 1) hipLaunchKernelGGL(force_front<1>, grid, dim3(256), 0, st, f);
     else hipLaunchKernelGGL(force_front<2>, grid, dim3(256), 0, st, f);
     ommhip_profile_end(OMMHIP_TIMER_NL_UPDATE, stream);
+    return (int) hipGetLastError();
+}
+
+// ================================================================================================
+// Pair kernel + reciprocal-space FFTs, three launches: stage 0 = forward plane transforms, stage 1 = x transform with
+// the convolution, stage 2 = backward plane transforms.  The FFT stages are latency-bound and need only 56-112
+// workgroups; each launch is [FFT workgroups | pair workgroups], the pair workgroups of stage s working on the part
+// [split[s], split[s+1]) / 64 of the chunk list, one chunk per wavefront.
+//
+// Tried and not kept (DHFR-sized system, pair kernel 37 us + FFT chain 31 us as separate launches):
+//  * pair wavefronts drawing chunks from device-wide ticket queues until the FFT workgroups of the launch signal
+//    completion: every draw is a device-scope atomic round trip (1-2 us per 18 us chunk; same-address atomics also
+//    serialise at ~8 ns each): 88 us;
+//  * ONE launch in which the FFT workgroups walk through the three stages with a device-wide barrier of their own
+//    while the pair workgroups stream through the rest of the chip: the XCDs' L2s are not coherent with each other
+//    inside a kernel, so the grid has to be handed from stage to stage through memory.  With __threadfence() (L2
+//    write-back + invalidate, ~10 us per barrier, and it evicts the pair code's working set): 170 us; with device-scope
+//    atomic loads/stores of the grid elements (serialised by the compiler, one round trip each): 72 us; with the complex
+//    grid in uncached memory: 67 us (FFT chain alone 60 us) -- no better than separate launches.
+//  * single rows instead of two-row chunks as the pair work unit (shorter unit latency, but the i-block set-up and force
+//    reduction twice per chunk): 63 us against 59 us.
+// A launch with a share of the pair work takes ~20 us whatever the share (thirds, or one chunk per SIMD): the pair code
+// is bound by the latency of a chunk, not by throughput, at this size.  FFT workgroups alone: 13 us per launch.
+// Passing the pair kernel's arguments as a kernel parameter of their own matters: as a member of one big argument
+// struct whose other members are passed on by reference they end up in scratch, the loads turn into flat loads, and
+// the pair code runs at 60 % of its speed.
+// ================================================================================================
+namespace {
+
+#define PF_THREADS 256
+#define PF_PLANE_CAP 4160          // planes up to 64 x 64 (nz * (ny + 1) complex elements)
+
+struct PairsFftStage {
+    int fftBlocks;
+    int fracLo, fracHi;
+};
+
+template <int METHOD, bool ENERGY>
+__global__ __launch_bounds__(PF_THREADS, 2) void pairs_fft_plane(NbArgs nb, PlaneArgs plane, PairsFftStage s, const float4* __restrict__ posqI, const float2* __restrict__ sigEpsI) {
+    __shared__ PlaneShared<PF_PLANE_CAP> sh;
+    const int b = blockIdx.x;
+    if (b < s.fftBlocks) fft_plane_body<PF_THREADS, PF_PLANE_CAP>(plane, b, sh);
+    else {
+        const int wave = (b - s.fftBlocks) * (PF_THREADS / 64) + (threadIdx.x >> 6);
+        const ChunkSchedule sched = {wave, ((int) gridDim.x - s.fftBlocks) * (PF_THREADS / 64), s.fracLo, s.fracHi};
+        nb_direct_body<METHOD, 1, ENERGY>(nb, posqI, sigEpsI, sched, wave);
+    }
+}
+
+template <int METHOD, bool ENERGY>
+__global__ __launch_bounds__(PF_THREADS, 2) void pairs_fft_lines(NbArgs nb, FftArgs fft, PairsFftStage s, const float4* __restrict__ posqI, const float2* __restrict__ sigEpsI) {
+    __shared__ FftShared sh;
+    const int b = blockIdx.x;
+    if (b < s.fftBlocks) fft_body<PF_THREADS>(fft, b, sh);
+    else {
+        const int wave = (b - s.fftBlocks) * (PF_THREADS / 64) + (threadIdx.x >> 6);
+        const ChunkSchedule sched = {wave, ((int) gridDim.x - s.fftBlocks) * (PF_THREADS / 64), s.fracLo, s.fracHi};
+        nb_direct_body<METHOD, 1, ENERGY>(nb, posqI, sigEpsI, sched, wave);
+    }
+}
+
+template <int METHOD, bool ENERGY>
+void launch_pairs_fft(int stage, int pairBlocks, hipStream_t st, const NbArgs& nb, const PlaneArgs& plane, const FftArgs& fft, PairsFftStage s) {
+    const int grid = s.fftBlocks + pairBlocks;
+    if (stage == 1) hipLaunchKernelGGL((pairs_fft_lines<METHOD, ENERGY>), dim3(grid), dim3(PF_THREADS), 0, st, nb, fft, s, nb.posq, nb.sigEps);
+    else hipLaunchKernelGGL((pairs_fft_plane<METHOD, ENERGY>), dim3(grid), dim3(PF_THREADS), 0, st, nb, plane, s, nb.posq, nb.sigEps);
+}
+
+}  // namespace
+
+extern "C" int ommhip_pairs_with_fft(const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, const void* sig_eps_d, const ommhip_pme* pme,
+                                     long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
+    const int nx = pme->nx, ny = pme->ny, nz = pme->nz;
+    if (nl->pbc != 1 || !p->ewald || nz * (ny + 1) > PF_PLANE_CAP || ny > 256 || nz > 256 || pme->fft_mode == 1) return -1;
+    hipStream_t st = (hipStream_t) stream;
+    // list fractions (in 64ths) at which stages 1 and 2 begin; tuning knob OPENMM_HIP_PAIRS_FFT_SPLIT="a,b"
+    static int split[4] = {0, -1, -1, 64};
+    if (split[1] < 0) {
+        int a = 21, b = 43;
+        const char* env = getenv("OPENMM_HIP_PAIRS_FFT_SPLIT");
+        if (env != nullptr && sscanf(env, "%d,%d", &a, &b) != 2) { a = 21; b = 43; }
+        if (a < 0) a = 0;
+        if (b < a) b = a;
+        if (b > 64) b = 64;
+        split[2] = b; split[1] = a;
+    }
+    const NbArgs nb = make_nb_args(nl, p, sig_eps_d, force_d, energy_buffer_d, energy_slots);
+    const FftArgs fft = make_xconv_args(pme, energy_buffer_d, energy_slots, include_energy);
+    ommhip_profile_begin(OMMHIP_TIMER_NB_DIRECT, stream);
+    for (int stage = 0; stage < 3; stage++) {
+        const PlaneArgs plane = make_plane_args(pme, stage == 0);
+        PairsFftStage s;
+        s.fftBlocks = stage == 1 ? fft.numOuter * ((fft.numInner + fft.B - 1) / fft.B) : nx;
+        s.fracLo = split[stage]; s.fracHi = split[stage + 1];
+        // one chunk per wavefront for this stage's share of the list capacity (surplus wavefronts find no chunk and leave)
+        const long long shareChunks = ((long long) nl->max_chunks * (s.fracHi - s.fracLo) + 63) / 64;
+        const int pairBlocks = (int) ((shareChunks + PF_THREADS / 64 - 1) / (PF_THREADS / 64));
+        const bool energy = include_energy != 0;
+        if (p->use_switch) { if (energy) launch_pairs_fft<3, true>(stage, pairBlocks, st, nb, plane, fft, s); else launch_pairs_fft<3, false>(stage, pairBlocks, st, nb, plane, fft, s); }
+        else { if (energy) launch_pairs_fft<1, true>(stage, pairBlocks, st, nb, plane, fft, s); else launch_pairs_fft<1, false>(stage, pairBlocks, st, nb, plane, fft, s); }
+    }
+    ommhip_profile_end(OMMHIP_TIMER_NB_DIRECT, stream);
     return (int) hipGetLastError();
 }

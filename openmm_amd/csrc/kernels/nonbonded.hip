@@ -180,20 +180,37 @@ __device__ __forceinline__ float transpose_reduce32(float (&v)[OMM_TILE], int la
     return v[0];
 }
 
-template <int METHOD, int PBC, bool ENERGY>
-__global__ __launch_bounds__(64, 2) void nb_direct(NbArgs a, const float4* __restrict__ posqI, const float2* __restrict__ sigEpsI) {
+// A wavefront's work units: of the part [fracLo, fracHi) / 64 of the list (fused launches split the list between several
+// launches; its length is only known on the device), the units first, first + stride, ...
+struct ChunkSchedule {
+    int first, stride;
+    int fracLo, fracHi;
+};
+
+// One wavefront's share of the pair kernel.  A work unit is UNIT_ROWS rows of one chunk: the whole chunk in the kernel of
+// its own (the i-block's atoms are set up and its forces reduced once per chunk), single rows where the unit's latency
+// matters more than that overhead (fused launches).
+template <int METHOD, int PBC, bool ENERGY, int UNIT_ROWS = OMM_CHUNK_ROWS>
+__device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __restrict__ posqI, const float2* __restrict__ sigEpsI,
+                                               const ChunkSchedule& sched, const int energySlot) {
     // posqI/sigEpsI alias a.posq/a.sigEps; passing them as separate __restrict__ kernel arguments
     // lets the compiler prove they are never written here and fetch the wave-uniform i-atom data
     // with scalar loads.
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     int numChunks = a.state[ST_NUM_CHUNKS];
     if (numChunks > a.maxChunks) numChunks = a.maxChunks;
     double energyTotal = 0;
-    for (int c = blockIdx.x; c < numChunks; c += gridDim.x) {
+    constexpr int UNITS_PER_CHUNK = OMM_CHUNK_ROWS / UNIT_ROWS;
+    const long long numUnits = (long long) numChunks * UNITS_PER_CHUNK;
+    const int unitLo = (int) ((numUnits * sched.fracLo) >> 6), unitHi = (int) ((numUnits * sched.fracHi) >> 6);
+    for (int u = unitLo + sched.first; u < unitHi; u += sched.stride) {
+        const int c = u / UNITS_PER_CHUNK;
+        const int rowBase = (u % UNITS_PER_CHUNK) * UNIT_ROWS;
         const int2 info = a.chunkInfo[c];
         const int X = __builtin_amdgcn_readfirstlane(info.x);
-        const int nrows = __builtin_amdgcn_readfirstlane(info.y & 0xff);
-        const int maskedBits = __builtin_amdgcn_readfirstlane(info.y >> 8);
+        const int nrows = __builtin_amdgcn_readfirstlane(info.y & 0xff) - rowBase;       // rows of this unit
+        const int maskedBits = __builtin_amdgcn_readfirstlane(info.y >> 8) >> rowBase;
+        if (nrows <= 0) continue;
         const float4* __restrict__ ip = posqI + X * OMM_TILE;
         const float2* __restrict__ ise = sigEpsI + X * OMM_TILE;
         float fix[OMM_TILE], fiy[OMM_TILE], fiz[OMM_TILE];
@@ -216,17 +233,17 @@ __global__ __launch_bounds__(64, 2) void nb_direct(NbArgs a, const float4* __res
         }
         // All rows of the chunk are fetched before the first one is processed (index, then the gathers that depend on
         // it): the two memory round trips are paid once per chunk and the later rows arrive while the first is computed.
-        int jRow[OMM_CHUNK_ROWS]; unsigned mRow[OMM_CHUNK_ROWS]; float4 pjRow[OMM_CHUNK_ROWS]; float2 seRow[OMM_CHUNK_ROWS];
+        int jRow[UNIT_ROWS]; unsigned mRow[UNIT_ROWS]; float4 pjRow[UNIT_ROWS]; float2 seRow[UNIT_ROWS];
 #pragma unroll
-        for (int row = 0; row < OMM_CHUNK_ROWS; row++) {
-            const size_t r = ((size_t) c * OMM_CHUNK_ROWS + row) * OMM_ROW + lane;
+        for (int row = 0; row < UNIT_ROWS; row++) {
+            const size_t r = ((size_t) c * OMM_CHUNK_ROWS + rowBase + row) * OMM_ROW + lane;
             jRow[row] = row < nrows ? a.rowJ[r] : X * OMM_TILE;
             mRow[row] = row < nrows && ((maskedBits >> row) & 1) ? a.rowMask[r] : 0xFFFFFFFFu;
         }
 #pragma unroll
-        for (int row = 0; row < OMM_CHUNK_ROWS; row++) { pjRow[row] = a.posq[jRow[row]]; seRow[row] = a.sigEps[jRow[row]]; }
+        for (int row = 0; row < UNIT_ROWS; row++) { pjRow[row] = a.posq[jRow[row]]; seRow[row] = a.sigEps[jRow[row]]; }
 #pragma unroll
-        for (int row = 0; row < OMM_CHUNK_ROWS; row++) {
+        for (int row = 0; row < UNIT_ROWS; row++) {
             if (row >= nrows) break;
             const int j = jRow[row];
             float4 pj = pjRow[row];
@@ -284,8 +301,14 @@ __global__ __launch_bounds__(64, 2) void nb_direct(NbArgs a, const float4* __res
     }
     if (ENERGY) {
         energyTotal = wave_sum(energyTotal);
-        if (lane == 0 && energyTotal != 0.0) atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], energyTotal);
+        if (lane == 0 && energyTotal != 0.0) atomicAdd(&a.energyBuffer[energySlot % a.energySlots], energyTotal);
     }
+}
+
+template <int METHOD, int PBC, bool ENERGY>
+__global__ __launch_bounds__(64, 2) void nb_direct(NbArgs a, const float4* __restrict__ posqI, const float2* __restrict__ sigEpsI) {
+    const ChunkSchedule sched = {(int) blockIdx.x, (int) gridDim.x, 0, 64};
+    nb_direct_body<METHOD, PBC, ENERGY>(a, posqI, sigEpsI, sched, blockIdx.x);
 }
 
 template <int METHOD, int PBC>
@@ -302,8 +325,8 @@ void launch_direct1(int pbc, bool energy, int grid, hipStream_t st, const NbArgs
 
 }  // namespace
 
-extern "C" int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, const void* sig_eps,
-                                long long* force, double* energy_buffer, int energy_slots, int include_energy, void* stream) {
+static NbArgs make_nb_args(const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, const void* sig_eps,
+                           long long* force, double* energy_buffer, int energy_slots) {
     NbArgs a;
     a.paddedAtoms = nl->padded_atoms; a.maxChunks = nl->max_chunks; a.energySlots = energy_slots;
     // OPENMM_HIP_DEBUG_SKIP_ATOMICS (profiling only, results are wrong): bit 0 drops the j-force atomics, bit 1 the i-force atomics
@@ -319,6 +342,12 @@ extern "C" int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_non
     a.blockCenter = (const float4*) nl->block_center; a.blockHalf = (const float4*) nl->block_half;
     a.cutoff = nl->cutoff > 0 ? (float) nl->cutoff : INFINITY;
     a.force = force; a.energyBuffer = energy_buffer;
+    return a;
+}
+
+extern "C" int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, const void* sig_eps,
+                                long long* force, double* energy_buffer, int energy_slots, int include_energy, void* stream) {
+    NbArgs a = make_nb_args(nl, p, sig_eps, force, energy_buffer, energy_slots);
     // One workgroup (= one wavefront) per chunk: the list length is only known on the device, so the launch covers
     // the allocated capacity and surplus workgroups exit at once; the hardware dispatcher balances the rest.
     int grid = p->direct_grid > 0 ? p->direct_grid : nl->max_chunks;

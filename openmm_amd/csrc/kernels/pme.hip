@@ -475,28 +475,37 @@ __device__ __forceinline__ float2* fft_lines(const FftPlan& plan, float2* bufA, 
     return src;
 }
 
-__global__ __launch_bounds__(FFT_THREADS) void fft_kernel(FftArgs a) {
-    __shared__ float2 bufA[FFT_MAX_LDS];
-    __shared__ float2 bufB[FFT_MAX_LDS];
-    __shared__ double energyPartial[FFT_THREADS / 64];
-    __shared__ float2 twS[FFT_MAX_LDS / 2];          // n <= FFT_MAX_LDS/2 (ommhip_fft_supported_size)
+struct FftShared {
+    float2 bufA[FFT_MAX_LDS];
+    float2 bufB[FFT_MAX_LDS];
+    double energyPartial[8];
+    float2 twS[FFT_MAX_LDS / 2];          // n <= FFT_MAX_LDS/2 (ommhip_fft_supported_size)
+};
+
+// THREADS = workgroup size (256 as a kernel of its own; fused launches may differ); `block` = workgroup index of this work
+template <int THREADS>
+__device__ __forceinline__ void fft_body(const FftArgs& a, const int block, FftShared& sh) {
+    float2* const bufA = sh.bufA;
+    float2* const bufB = sh.bufB;
+    double* const energyPartial = sh.energyPartial;
+    float2* const twS = sh.twS;
     const int n = a.plan.n, B = a.B, BP = a.B + 1;   // LDS line stride B+1: conflict-free for both staging orders
-    for (int i = threadIdx.x; i < n; i += FFT_THREADS) twS[i] = a.twiddle[i];
+    for (int i = threadIdx.x; i < n; i += THREADS) twS[i] = a.twiddle[i];
     const int tilesPerOuter = (a.numInner + B - 1) / B;
-    const int outer = blockIdx.x / tilesPerOuter;
-    const int inner0 = (blockIdx.x % tilesPerOuter) * B;
+    const int outer = block / tilesPerOuter;
+    const int inner0 = (block % tilesPerOuter) * B;
     const int nIn = a.mode == 2 ? n / 2 + 1 : n;
     const int nOut = a.mode == 1 ? n / 2 + 1 : n;
     const bool elemFastIn = a.inElemStride == 1;
     // ---- load: all global reads of this thread (input lines and, for the fused convolution, the influence function) are
     //      issued back to back before anything is consumed; a rolled loop would wait for one round trip per element
-    constexpr int MAXLD = FFT_MAX_LDS / FFT_THREADS;          // (B + 1) * n <= FFT_MAX_LDS
+    constexpr int MAXLD = FFT_MAX_LDS / THREADS;          // (B + 1) * n <= FFT_MAX_LDS
     float2 ld[MAXLD];
     int ldPos[MAXLD];
     float etv[MAXLD];
 #pragma unroll
     for (int it = 0; it < MAXLD; it++) {
-        const int idx = threadIdx.x + it * FFT_THREADS;
+        const int idx = threadIdx.x + it * THREADS;
         float2 v = make_float2(0.f, 0.f);
         ldPos[it] = -1;
         if (idx < nIn * B) {
@@ -534,7 +543,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_kernel(FftArgs a) {
         double energy = 0;
 #pragma unroll
         for (int it = 0; it < MAXLD; it++) {
-            const int idx = threadIdx.x + it * FFT_THREADS;
+            const int idx = threadIdx.x + it * THREADS;
             if (idx < n * B) {
                 const int line = idx % B, e = idx / B;
                 float2 v = res[e * BP + line];
@@ -554,8 +563,8 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_kernel(FftArgs a) {
         __syncthreads();
         if (a.energyBuffer != nullptr && threadIdx.x == 0) {
             double e = 0;
-            for (int w = 0; w < FFT_THREADS / 64; w++) e += energyPartial[w];
-            atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], 0.5 * e);
+            for (int w = 0; w < THREADS / 64; w++) e += energyPartial[w];
+            atomicAdd(&a.energyBuffer[block % a.energySlots], 0.5 * e);
         }
         float2* other = res == bufA ? bufB : bufA;
         res = fft_lines(a.plan, res, other, B, BP, +1, twS);
@@ -565,7 +574,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_kernel(FftArgs a) {
     }
     // ---- store
     const bool elemFastOut = a.outElemStride == 1;
-    for (int idx = threadIdx.x; idx < nOut * B; idx += FFT_THREADS) {
+    for (int idx = threadIdx.x; idx < nOut * B; idx += THREADS) {
         int line, e;
         if (elemFastOut) { e = idx % nOut; line = idx / nOut; } else { line = idx % B; e = idx / B; }
         if (inner0 + line < a.numInner) {
@@ -575,6 +584,11 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_kernel(FftArgs a) {
             else ((float2*) a.out)[off] = v;
         }
     }
+}
+
+__global__ __launch_bounds__(FFT_THREADS) void fft_kernel(FftArgs a) {
+    __shared__ FftShared sh;
+    fft_body<FFT_THREADS>(a, blockIdx.x, sh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -596,27 +610,37 @@ struct PlaneArgs {
     float2* cplx;          // [nx][ny][nz/2+1]
 };
 
-__global__ __launch_bounds__(PLANE_THREADS) void fft_plane_kernel(PlaneArgs a) {
-    __shared__ float2 bufA[PLANE_MAX];
-    __shared__ float2 bufB[PLANE_MAX];
-    __shared__ float2 twYs[256];
-    __shared__ float2 twZs[256];
+template <int CAP>
+struct PlaneShared {
+    float2 bufA[CAP];
+    float2 bufB[CAP];
+    float2 twYs[256];
+    float2 twZs[256];
+};
+
+// THREADS = workgroup size, CAP = complex elements per LDS buffer (nz * (ny + 1) <= CAP), `block` = x plane of this workgroup
+template <int THREADS, int CAP>
+__device__ __forceinline__ void fft_plane_body(const PlaneArgs& a, const int block, PlaneShared<CAP>& sh) {
+    float2* const bufA = sh.bufA;
+    float2* const bufB = sh.bufB;
+    float2* const twYs = sh.twYs;
+    float2* const twZs = sh.twZs;
     const int ny = a.ny, nz = a.nz, nzc = nz / 2 + 1, S = ny + 1;
-    const int x = blockIdx.x;
-    for (int i = threadIdx.x; i < ny; i += PLANE_THREADS) twYs[i] = a.twY[i];
-    for (int i = threadIdx.x; i < nz; i += PLANE_THREADS) twZs[i] = a.twZ[i];
+    const int x = block;
+    for (int i = threadIdx.x; i < ny; i += THREADS) twYs[i] = a.twY[i];
+    for (int i = threadIdx.x; i < nz; i += THREADS) twZs[i] = a.twZ[i];
     if (a.forward) {
         const float* in = a.real + (size_t) x * ny * nz;
-        constexpr int MAXLD = (PLANE_MAX + PLANE_THREADS - 1) / PLANE_THREADS;       // all reads of the plane in flight at once
+        constexpr int MAXLD = (CAP + THREADS - 1) / THREADS;       // all reads of the plane in flight at once
         float ld[MAXLD];
 #pragma unroll
         for (int it = 0; it < MAXLD; it++) {
-            const int idx = threadIdx.x + it * PLANE_THREADS;
+            const int idx = threadIdx.x + it * THREADS;
             ld[it] = idx < ny * nz ? in[idx] : 0.f;
         }
 #pragma unroll
         for (int it = 0; it < MAXLD; it++) {
-            const int idx = threadIdx.x + it * PLANE_THREADS;
+            const int idx = threadIdx.x + it * THREADS;
             if (idx < ny * nz) {
                 const int y = idx / nz, z = idx % nz;
                 bufA[z * S + y] = make_float2(ld[it], 0.f);
@@ -627,23 +651,23 @@ __global__ __launch_bounds__(PLANE_THREADS) void fft_plane_kernel(PlaneArgs a) {
         float2* other = r1 == bufA ? bufB : bufA;
         float2* r2 = fft_lines(a.planY, r1, other, nzc, 1, -1, twYs, S);            // lines = kz < nzc, elements = y
         float2* out = a.cplx + (size_t) x * ny * nzc;
-        for (int idx = threadIdx.x; idx < ny * nzc; idx += PLANE_THREADS) {
+        for (int idx = threadIdx.x; idx < ny * nzc; idx += THREADS) {
             const int ky = idx / nzc, kz = idx % nzc;
             out[idx] = r2[kz * S + ky];
         }
     }
     else {
         const float2* in = a.cplx + (size_t) x * ny * nzc;
-        constexpr int MAXLD = (PLANE_MAX + PLANE_THREADS - 1) / PLANE_THREADS;
+        constexpr int MAXLD = (CAP + THREADS - 1) / THREADS;
         float2 ld[MAXLD];
 #pragma unroll
         for (int it = 0; it < MAXLD; it++) {
-            const int idx = threadIdx.x + it * PLANE_THREADS;
+            const int idx = threadIdx.x + it * THREADS;
             ld[it] = idx < ny * nzc ? in[idx] : make_float2(0.f, 0.f);
         }
 #pragma unroll
         for (int it = 0; it < MAXLD; it++) {
-            const int idx = threadIdx.x + it * PLANE_THREADS;
+            const int idx = threadIdx.x + it * THREADS;
             if (idx < ny * nzc) {
                 const int ky = idx / nzc, kz = idx % nzc;
                 bufA[kz * S + ky] = ld[it];
@@ -652,7 +676,7 @@ __global__ __launch_bounds__(PLANE_THREADS) void fft_plane_kernel(PlaneArgs a) {
         __syncthreads();
         float2* r1 = fft_lines(a.planY, bufA, bufB, nzc, 1, +1, twYs, S);           // backward y on the half plane
         // Hermitian completion along z: element kz' = nz - kz is the conjugate of kz (for every y)
-        for (int idx = threadIdx.x; idx < ny * (nz - nzc); idx += PLANE_THREADS) {
+        for (int idx = threadIdx.x; idx < ny * (nz - nzc); idx += THREADS) {
             const int y = idx % ny, kz = nzc + idx / ny;
             const float2 v = r1[(nz - kz) * S + y];
             r1[kz * S + y] = make_float2(v.x, -v.y);
@@ -661,11 +685,16 @@ __global__ __launch_bounds__(PLANE_THREADS) void fft_plane_kernel(PlaneArgs a) {
         float2* other = r1 == bufA ? bufB : bufA;
         float2* r2 = fft_lines(a.planZ, r1, other, ny, S, +1, twZs, 1);
         float* out = a.real + (size_t) x * ny * nz;
-        for (int idx = threadIdx.x; idx < ny * nz; idx += PLANE_THREADS) {
+        for (int idx = threadIdx.x; idx < ny * nz; idx += THREADS) {
             const int y = idx / nz, z = idx % nz;
             out[idx] = r2[z * S + y].x;
         }
     }
+}
+
+__global__ __launch_bounds__(PLANE_THREADS) void fft_plane_kernel(PlaneArgs a) {
+    __shared__ PlaneShared<PLANE_MAX> sh;
+    fft_plane_body<PLANE_THREADS, PLANE_MAX>(a, blockIdx.x, sh);
 }
 
 FftPlan make_plan(int n) {
@@ -685,6 +714,28 @@ int lines_per_group(int n) {
     if (b > 16) b = 16;
     if (b < 1) b = 1;
     return b;
+}
+
+PlaneArgs make_plane_args(const ommhip_pme* pme, bool forward) {
+    PlaneArgs p;
+    p.planY = make_plan(pme->ny); p.planZ = make_plan(pme->nz); p.ny = pme->ny; p.nz = pme->nz; p.forward = forward ? 1 : 0;
+    p.twY = (const float2*) pme->twiddle_y; p.twZ = (const float2*) pme->twiddle_z;
+    p.real = (float*) pme->grid_real; p.cplx = (float2*) pme->grid_complex;
+    return p;
+}
+
+// x pass of the reciprocal-space chain: forward, multiply by the influence function (+ energy), backward
+FftArgs make_xconv_args(const ommhip_pme* pme, double* energy_buffer_d, int energy_slots, int include_energy) {
+    const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
+    float2* cgrid = (float2*) pme->grid_complex;
+    FftArgs f;
+    f.nzFull = nz;
+    f.plan = make_plan(nx); f.B = lines_per_group(nx); f.numOuter = ny; f.numInner = nzc;
+    f.inOuterStride = nzc; f.inInnerStride = 1; f.inElemStride = (long long) ny * nzc;
+    f.outOuterStride = nzc; f.outInnerStride = 1; f.outElemStride = (long long) ny * nzc;
+    f.mode = 3; f.sign = -1; f.twiddle = (const float2*) pme->twiddle_x; f.in = cgrid; f.out = cgrid;
+    f.eterm = (const float*) pme->eterm; f.energyBuffer = include_energy ? energy_buffer_d : nullptr; f.energySlots = energy_slots;
+    return f;
 }
 
 // The (y,z) half of the 3-D transform: fused plane kernel when a plane fits in LDS, two line passes otherwise.
@@ -773,7 +824,7 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     float2* cgrid = (float2*) pme->grid_complex;
 
     const int spreadBlocks = (padded_atoms * 8 + 255) / 256;
-    if (pme->phases != OMMHIP_PME_AFTER_SPREAD) {
+    if (pme->phases != OMMHIP_PME_AFTER_SPREAD && pme->phases != OMMHIP_PME_INTERPOLATE_ONLY) {
         if (!pme->grid_precleared) hipMemsetAsync(pa.grid, 0, sizeof(float) * (size_t) nx * ny * nz, st);
         ommhip_profile_begin(OMMHIP_TIMER_PME_SPREAD, stream);
         if (pme->spread_mode == 1)
@@ -783,6 +834,7 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
         ommhip_profile_end(OMMHIP_TIMER_PME_SPREAD, stream);
     }
     if (pme->phases == OMMHIP_PME_SPREAD_ONLY) return (int) hipGetLastError();
+    if (pme->phases != OMMHIP_PME_INTERPOLATE_ONLY) {
     ommhip_profile_begin(OMMHIP_TIMER_PME_FFT, stream);
 
     FftArgs f;
@@ -800,6 +852,7 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     launch_yz(pme, false, st);
 
     ommhip_profile_end(OMMHIP_TIMER_PME_FFT, stream);
+    }
     ommhip_profile_begin(OMMHIP_TIMER_PME_INTERPOLATE, stream);
     hipLaunchKernelGGL(pme_interpolate, dim3(spreadBlocks), dim3(256), 0, st, pa);
     ommhip_profile_end(OMMHIP_TIMER_PME_INTERPOLATE, stream);

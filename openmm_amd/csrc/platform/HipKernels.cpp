@@ -791,11 +791,11 @@ void HipCalcNonbondedForceKernel::fillPmeStruct() {
     }
 }
 
-void HipCalcNonbondedForceKernel::launchPme(int includeEnergy, bool spreadDone) {
+void HipCalcNonbondedForceKernel::launchPme(int includeEnergy, bool spreadDone, bool fftDone) {
     fillPmeStruct();
     if (spreadDone) {
-        // the charges were spread by the fused front launch of this evaluation
-        pme.phases = OMMHIP_PME_AFTER_SPREAD;
+        // the charges were spread by the fused front launch of this evaluation (and the FFTs may have travelled with the pair kernel)
+        pme.phases = fftDone ? OMMHIP_PME_INTERPOLATE_ONLY : OMMHIP_PME_AFTER_SPREAD;
         HIP_CHECK(ommhip_pme_reciprocal(&pme, posq.ptr, hip.paddedAtoms, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy, hip.stream));
         pme.phases = OMMHIP_PME_ALL;
         return;
@@ -839,7 +839,7 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
     }
     double energy = 0;
     const int ie = includeEnergy ? 1 : 0;
-    bool pmeLaunched = false, frontLaunched = false;
+    bool pmeLaunched = false, frontLaunched = false, fftLaunched = false;
     // The exclusion correction belongs to the direct-space group (ReferenceLJCoulombIxn.cpp:373,462); when both halves
     // are evaluated together it is computed by the PME interpolation launch instead of a term list of its own.
     const char* noFoldEnv = getenv("OPENMM_HIP_NO_FOLDED_EXCLUSIONS");          // test/A-B knob, read per evaluation
@@ -914,7 +914,17 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
         }
         // posq is ready: start reciprocal space on the side stream BEFORE queueing the pair kernel, so the two overlap
         if (!pmeLaunched && includeReciprocal && nonbondedMethod == PME && hip.usePmeStream) { launchPme(ie); pmeLaunched = true; }
-        HIP_CHECK(ommhip_nb_direct(&nl, &params, sigEps.ptr, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+        // Single-stream mode: the pair kernel travels with the three FFT launches of reciprocal space (a third of its chunks
+        // in each), which fills the compute units the 56-112 FFT workgroups leave idle.
+        const char* noPairsFft = getenv("OPENMM_HIP_NO_PAIRS_WITH_FFT");          // A/B and test knob, read per evaluation
+        const bool pairsWithFft = !(noPairsFft != NULL && noPairsFft[0] == '1');
+        if (frontLaunched && pairsWithFft) {
+            int rc = ommhip_pairs_with_fft(&nl, &params, sigEps.ptr, &pme, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream);
+            if (rc > 0) HIP_CHECK(rc);
+            fftLaunched = rc == 0;
+        }
+        if (!fftLaunched)
+            HIP_CHECK(ommhip_nb_direct(&nl, &params, sigEps.ptr, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
         if ((++evaluationCount & 15) == 0) {
             HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
             stateCopyPending = true;
@@ -934,7 +944,7 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
     }
     if (includeReciprocal) {
         if (nonbondedMethod == PME) {
-            if (!pmeLaunched) launchPme(ie, frontLaunched);
+            if (!pmeLaunched) launchPme(ie, frontLaunched, fftLaunched);
         }
         else if (nonbondedMethod == Ewald) {
             if (hip.box[1] != 0.0 || hip.box[3] != 0.0 || hip.box[4] != 0.0)

@@ -115,7 +115,7 @@ private:
     void allocateNeighborList(int maxChunks);
     void setupPme();
     void fillPmeStruct();
-    void launchPme(int includeEnergy, bool spreadDone = false);
+    void launchPme(int includeEnergy, bool spreadDone = false, bool fftDone = false);
     void rebuildEterm();
     int estimateChunks() const;
     HipPlatform::PlatformData& data;

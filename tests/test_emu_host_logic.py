@@ -161,6 +161,13 @@ b = run({"OPENMM_HIP_NO_FOLDED_EXCLUSIONS": "1"}, H.VERLET, 0)
 rms = np.sqrt((b.forces ** 2).sum(1).mean())
 assert np.sqrt(((a.forces - b.forces) ** 2).sum(1)).max() / rms < 2e-6
 assert abs(a.potentialEnergy - b.potentialEnergy) < 5e-3      # both sum ~3e4 kJ/mol of single-precision erf terms
+# pair kernel riding on the three FFT launches vs one launch per kernel
+a = run({"OPENMM_HIP_NO_PAIRS_WITH_FFT": "0"}, H.VERLET, 3)
+b = run({"OPENMM_HIP_NO_PAIRS_WITH_FFT": "1"}, H.VERLET, 3)
+os.environ["OPENMM_HIP_NO_PAIRS_WITH_FFT"] = "0"
+assert np.abs(a.positions - b.positions).max() < 1e-9
+assert np.sqrt(((a.forces - b.forces) ** 2).sum(1)).max() / rms < 1e-6
+assert abs(a.potentialEnergy - b.potentialEnergy) < 1e-3
 print("OK")
 ''' % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)

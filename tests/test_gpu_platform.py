@@ -252,13 +252,14 @@ def test_folded_exclusion_correction_equals_term_list():
 @pytest.mark.parametrize("workload", ["water", "dhfr"])
 def test_fused_launches_equal_separate_launches(workload):
     """Single-stream evaluation with the fused launches (front: list rebuild + charge spreading + term lists; middle: pair
-    kernel riding on the three FFT launches) against one launch per kernel.  Forces accumulate in fixed point and the
-    FFT bodies are the same code, so the results agree to rounding of the final conversion."""
+    kernel riding on the three FFT launches) against one launch per kernel.  Pair forces accumulate in fixed point
+    (order-independent); the FFT stages run with a different workgroup shape, so reciprocal space agrees to single-
+    precision rounding."""
     w = T.water_box(12, seed=4) if workload == "water" else T.dhfr_like(seed=1)
     a = _trajectory(w, 3, H.VERLET, {"OPENMM_HIP_NO_PAIRS_WITH_FFT": "0"})
     b = _trajectory(w, 3, H.VERLET, {"OPENMM_HIP_NO_PAIRS_WITH_FFT": "1"})
-    assert np.abs(a.positions - b.positions).max() < 1e-9
-    assert max_rel_force_error(a.forces, b.forces) < 1e-6
+    assert np.abs(a.positions - b.positions).max() < 1e-7       # constraint tolerance 1e-6 (relative) amplifies the rounding
+    assert max_rel_force_error(a.forces, b.forces) < 1e-5
     assert abs(a.potentialEnergy - b.potentialEnergy) < 1e-6 * abs(b.potentialEnergy) + 1e-3
 
 

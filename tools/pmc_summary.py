@@ -9,7 +9,7 @@ mins = dict(a.split("=") for a in sys.argv[2:])
 piv = df.pivot_table(index=["Dispatch_Id", "Kernel_Name", "dur", "VGPR_Count", "Accum_VGPR_Count", "Scratch_Size", "LDS_Block_Size", "Grid_Size"],
                      columns="Counter_Name", values="Counter_Value", aggfunc="sum").reset_index()
 pd.set_option("display.width", 250); pd.set_option("display.max_columns", 40); pd.set_option("display.float_format", lambda v: "%.1f" % v)
-names = ["nl_find", "nl_prepare", "nb_direct", "pme_spread", "fft_plane", "fft_kernel", "pme_interp", "k_terms", "k_step_units", "k_clear2"]
+names = ["nl_find", "nl_prepare", "force_front", "pairs_fft_plane", "pairs_fft_lines", "nb_direct", "pme_spread", "fft_plane", "fft_kernel", "pme_interp", "k_terms", "k_step_units", "k_clear2"]
 rows = []
 for name in names:
     sub = piv[piv.Kernel_Name.str.contains(name)]

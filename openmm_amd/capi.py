@@ -48,6 +48,9 @@ class Pme(C.Structure):
     ]
 
 
+PME_ALL, PME_SPREAD_ONLY, PME_AFTER_SPREAD, PME_INTERPOLATE_ONLY = 0, 1, 2, 3      # Pme.phases
+
+
 class KernelError(RuntimeError):
     pass
 
@@ -85,6 +88,10 @@ SIGNATURES = {
     "reduce_energy": [_P, _I, _P, _P],
     "nl_update": [C.POINTER(NeighborList), _P],
     "nl_step": [C.POINTER(NeighborList), _P, _P, _P],
+    "nl_prepare": [C.POINTER(NeighborList), _P, _P, _P, _Z, _P, _Z, _P],
+    "nl_rebuild_if_requested": [C.POINTER(NeighborList), _P],
+    "force_front": [C.POINTER(NeighborList), C.POINTER(Pme), _I, _P, _P, _P, _P, _I, _I, _P],
+    "pairs_with_fft": [C.POINTER(NeighborList), C.POINTER(NonbondedParams), _P, C.POINTER(Pme), _P, _P, _I, _I, _P],
     "fft_supported_size": [_I],
     "pme_build_eterm": [C.POINTER(Pme), _P],
     "pme_reciprocal": [C.POINTER(Pme), _P, _I, _P, _P, _I, _I, _P],

@@ -24,12 +24,16 @@ def box6(box3):
     return (C.c_double * 6)(box3[0, 0], box3[1, 0], box3[1, 1], box3[2, 0], box3[2, 1], box3[2, 2])
 
 
-def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64, compact=False, cells=False):
+def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64, compact=False, cells=False, fused_pme=None):
     """-> (forces[n,3], energy, oracle forces, oracle energy, nl state)
 
     compact=False: random slot order, list built by ommhip_nl_update on wrapped coordinates (general image search).
     compact=True: slots sorted along a Morton curve and the per-step entry ommhip_nl_step, which stores image-coherent
-    blocks -- with a box wider than 2 (block + cutoff) this drives the pair kernel's single-image path."""
+    blocks -- with a box wider than 2 (block + cutoff) this drives the pair kernel's single-image path.
+    fused_pme=(nx, ny, nz): instead of the list builder and the pair kernel on their own, the single-stream sequence of a
+    whole PME evaluation -- ommhip_nl_prepare (with the clears), ommhip_force_front (list build + charge spreading),
+    ommhip_pairs_with_fft (pair kernel on the three FFT launches), ommhip_pme_reciprocal(interpolate only) -- against
+    direct + reciprocal space of the oracle."""
     rng = np.random.default_rng(seed)
     box3 = np.eye(3) * L
     if triclinic:
@@ -97,7 +101,18 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
         nl.cell_boxes = K.upload(np.zeros((2 * nb, 4), np.float32))
         nl.cell_meta = K.upload(np.zeros(4, np.float32))
         nl.cell_min_blocks = 1
-    if compact:
+    pm = None
+    if fused_pme is not None:
+        assert method == ONB.PME and not triclinic
+        ng = fused_pme
+        pm = make_pme(K, ng, box3, float(np.sqrt(-np.log(2 * 5e-4)) / cutoff))
+        pm.grid_precleared = 1
+        K.pme_build_eterm(C.byref(pm), None)
+        d_f, d_e = K.upload(np.full(3 * padded, 12345, np.int64)), K.upload(np.zeros(grid))       # the force buffer starts dirty: nl_prepare clears it
+        K.memset(pm.grid_real, 0x55, 4 * ng[0] * ng[1] * ng[2], None)                                # ... and the charge grid
+        K.nl_prepare(C.byref(nl), d_pos, d_wrap, d_f, 8 * 3 * padded, pm.grid_real, 4 * ng[0] * ng[1] * ng[2], None)
+        K.force_front(C.byref(nl), C.byref(pm), 0, None, d_pos, d_f, d_e, grid, 1, None)
+    elif compact:
         K.nl_step(C.byref(nl), d_pos, d_wrap, None)
     else:
         K.nl_update(C.byref(nl), None)
@@ -111,8 +126,13 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     if switch:
         p.use_switch, p.switch_distance = 1, switch
     p.direct_grid = grid
-    d_f, d_e = K.upload(np.zeros(3 * padded, np.int64)), K.upload(np.zeros(grid))
-    K.nb_direct(C.byref(nl), C.byref(p), d_se, d_f, d_e, grid, 1, None)
+    if pm is not None:
+        K.pairs_with_fft(C.byref(nl), C.byref(p), d_se, C.byref(pm), d_f, d_e, grid, 1, None)
+        pm.phases = capi.PME_INTERPOLATE_ONLY
+        K.pme_reciprocal(C.byref(pm), d_posq, padded, d_f, d_e, grid, 1, None)
+    else:
+        d_f, d_e = K.upload(np.zeros(3 * padded, np.int64)), K.upload(np.zeros(grid))
+        K.nb_direct(C.byref(nl), C.byref(p), d_se, d_f, d_e, grid, 1, None)
     f = K.download(d_f, (3, padded), np.int64).astype(np.float64) / 2 ** 32
     e = float(K.download(d_e, grid, np.float64).sum())
     forces = f[:, slot_of_atom].T
@@ -122,6 +142,9 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     ok = (half[:, 3] != 0) & np.all(half[:, :3] + cutoff < 0.5 * np.diag(box3)[None, :], axis=1)
     LAST_SINGLE_FRACTION = float(ok.mean()) if periodic and not triclinic else 0.0
     f_or, e_or = ONB.direct_space(pos, q, sig, eps, method, cutoff, box3, excl, alpha, switch_distance=switch)
+    if pm is not None:
+        f_rec, e_rec = OPME.pme_exec(pos, q.astype(np.float32).astype(np.float64), box3, alpha, fused_pme)
+        f_or, e_or = f_or + f_rec, e_or + e_rec
     return forces, e, f_or, e_or, state
 
 

@@ -48,6 +48,15 @@ def test_direct_space_single_image_path(K):
 
 
 @needs_emu
+def test_fused_single_stream_evaluation(K):
+    """nl_prepare (+clears) -> force_front (list build + charge spreading) -> pairs_with_fft -> interpolate, through the C ABI"""
+    f, e, f_or, e_or, state = KC.run_direct_space(K, 1200, ONB.PME, 0.7, 3.4, EXCL, compact=True, fused_pme=(24, 24, 24))
+    assert state[2] == 0 and state[1] > 0
+    assert max_rel_force_error(f, f_or) < 1e-4
+    assert abs(e - e_or) < 5e-5 * max(abs(e_or), 100.0)
+
+
+@needs_emu
 @pytest.mark.parametrize("compact", [False, True])
 def test_direct_space_cell_binned_builder(K, compact):
     """The candidate search of large systems (blocks bucketed by grid cell) forced at test size: same list, same forces."""

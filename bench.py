@@ -179,7 +179,7 @@ def main():
             # HBM traffic of the same kernel from the PMC passes (rocprofv3 cannot run inside this process; the counters were
             # collected by tools/gpu_pmc.sh on the same command and are committed under profiles/)
             traffic, traffic_source = None, None
-            pmc_file = os.path.join(ROOT, "profiles", "r01n_pmc_pairs_fft.json" if fused else "r01_pmc_nb_direct.json")
+            pmc_file = os.path.join(ROOT, "profiles", "r01o_pmc_pairs_fft.json" if fused else "r01_pmc_nb_direct.json")
             if args.workload == "dhfr" and os.path.exists(pmc_file):
                 with open(pmc_file) as f:
                     pmc = json.load(f)

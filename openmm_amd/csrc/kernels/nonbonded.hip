@@ -206,6 +206,16 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
     for (int u = unitLo + sched.first; u < unitHi; u += sched.stride) {
         const int c = u / UNITS_PER_CHUNK;
         const int rowBase = (u % UNITS_PER_CHUNK) * UNIT_ROWS;
+        // The row words are read unconditionally and before the chunk header is looked at (the arrays cover every row of
+        // every chunk; rows a chunk does not use hold stale words that are discarded below): header, row indices and masks
+        // come back in ONE memory round trip, the posq / (sigma, eps) gathers that depend on the indices are the second.
+        int jWord[UNIT_ROWS]; unsigned mWord[UNIT_ROWS];
+#pragma unroll
+        for (int row = 0; row < UNIT_ROWS; row++) {
+            const size_t r = ((size_t) c * OMM_CHUNK_ROWS + rowBase + row) * OMM_ROW + lane;
+            jWord[row] = a.rowJ[r];
+            mWord[row] = a.rowMask[r];
+        }
         const int2 info = a.chunkInfo[c];
         const int X = __builtin_amdgcn_readfirstlane(info.x);
         const int nrows = __builtin_amdgcn_readfirstlane(info.y & 0xff) - rowBase;       // rows of this unit
@@ -236,9 +246,8 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
         int jRow[UNIT_ROWS]; unsigned mRow[UNIT_ROWS]; float4 pjRow[UNIT_ROWS]; float2 seRow[UNIT_ROWS];
 #pragma unroll
         for (int row = 0; row < UNIT_ROWS; row++) {
-            const size_t r = ((size_t) c * OMM_CHUNK_ROWS + rowBase + row) * OMM_ROW + lane;
-            jRow[row] = row < nrows ? a.rowJ[r] : X * OMM_TILE;
-            mRow[row] = row < nrows && ((maskedBits >> row) & 1) ? a.rowMask[r] : 0xFFFFFFFFu;
+            jRow[row] = row < nrows ? jWord[row] : X * OMM_TILE;
+            mRow[row] = row < nrows && ((maskedBits >> row) & 1) ? mWord[row] : 0xFFFFFFFFu;
         }
 #pragma unroll
         for (int row = 0; row < UNIT_ROWS; row++) { pjRow[row] = a.posq[jRow[row]]; seRow[row] = a.sigEps[jRow[row]]; }

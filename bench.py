@@ -39,7 +39,7 @@ def parse_args():
     p.add_argument("--warmup", type=int, default=300)
     p.add_argument("--dt-fs", type=float, default=2.0)
     p.add_argument("--workload", default="dhfr", choices=["dhfr", "water24k", "water98k", "water1m"])
-    p.add_argument("--cpu-steps", type=int, default=150, help="steps of the CPU-platform baseline (0 disables)")
+    p.add_argument("--cpu-steps", type=int, default=150, help="steps of the CPU-platform baseline (0 disables it and the force-parity check)")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--profile-every", type=int, default=8, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region")
     p.add_argument("--props", default="", help="extra HIP platform properties, e.g. DisablePmeStream=true")
@@ -208,6 +208,23 @@ def main():
                 cctx.close()
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "ns/day", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %s" % e}
+            try:
+                # second half of BASELINE.json's metric: force max-rel-err vs the Reference platform (oracle/_ref) on the
+                # configuration the timed run ended in -- SURVEY.md §8(d): max_i |dF_i| / max(|F_ref,i|, RMS force)
+                end = ctx.getState(getPositions=True, getForces=True)
+                rsys, rnb = w.build()
+                rctx = H.Context(rsys, H.Integrator(H.VERLET, 0.001), "Reference")
+                rctx.setPositions(end.positions)
+                f_ref = rctx.getState(getForces=True).forces
+                rctx.close()
+                diff = np.linalg.norm(end.forces - f_ref, axis=1)
+                norm = np.linalg.norm(f_ref, axis=1)
+                rms = float(np.sqrt((f_ref ** 2).sum(1).mean()))
+                out["force_parity"] = {"max_rel_err_vs_reference": float((diff / np.maximum(norm, rms)).max()),
+                                       "median_rel_diff": float(np.median(2 * diff / (norm + np.linalg.norm(end.forces, axis=1)))),
+                                       "tolerance": 1e-4, "oracle": "platforms/reference from oracle/_ref, final configuration of the timed run"}
+            except Exception as e:
+                out["force_parity"] = {"max_rel_err_vs_reference": None, "error": str(e)}
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:

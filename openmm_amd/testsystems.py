@@ -109,6 +109,39 @@ def water_box(n_side, seed=0, density=33.4, rigid=True, method=H.PME, cutoff=0.9
     return w
 
 
+def apoa1_like(seed=0):
+    """BASELINE.json configs[2] stand-in (examples/apoa1.pdb is not in the reference tree): 92 224
+    atoms in the apoa1 box 10.8861 x 10.8861 x 7.7758 nm -- 30 741 TIP3P waters on a jittered 36 x 35 x 25 lattice with
+    759 sites left empty, plus one argon atom on an empty site.  PME at cutoff 0.9 nm / 5e-4 on a 98 x 98 x 70 grid."""
+    rng = np.random.default_rng(seed)
+    box = np.array([10.8861, 10.8861, 7.7758])
+    dims = np.array([36, 35, 25])
+    nw = 30741
+    g = np.stack(np.meshgrid(*[np.arange(d) for d in dims], indexing="ij"), -1).reshape(-1, 3)
+    order = rng.permutation(len(g))
+    spacing = box / dims
+    centers = (g[order[:nw]] + 0.5 + 0.15 * (rng.random((nw, 3)) - 0.5)) * spacing
+    rot = _random_rotations(rng, nw)
+    pos = (centers[:, None, :] + np.einsum("nij,kj->nki", rot, water_sites())).reshape(-1, 3)
+    argon = (g[order[nw]] + 0.5) * spacing
+    w = Workload("apoa1-sized-water-92224")
+    w.positions = np.vstack([pos, argon[None, :]])
+    w.box = np.diag(box)
+    t = TIP3P
+    w.masses = np.concatenate([np.tile([t["mO"], t["mH"], t["mH"]], nw), [39.95]])
+    w.charge = np.concatenate([np.tile([t["qO"], t["qH"], t["qH"]], nw), [0.0]])
+    w.sigma = np.concatenate([np.tile([t["sigO"], 1.0, 1.0], nw), [0.3350]])
+    w.epsilon = np.concatenate([np.tile([t["epsO"], 0.0, 0.0], nw), [0.996]])
+    o = 3 * np.arange(nw)
+    pairs = np.stack([np.stack([o, o + 1], -1), np.stack([o, o + 2], -1), np.stack([o + 1, o + 2], -1)], 1).reshape(-1, 2)
+    w.exceptions = (pairs, np.zeros(len(pairs)), np.ones(len(pairs)), np.zeros(len(pairs)))
+    w.constraints = (pairs, np.tile([t["dOH"], t["dOH"], t["dHH"]], nw))
+    # The tolerance rule gives 97 x 97 x 70 on the Reference platform (any size is legal for fftpack) and 98 x 98 x 70 on
+    # platforms that round up to FFT-friendly sizes (CudaFFT3D.cpp:127-142, and ours); pin the grid so both compute the same sum.
+    w.pme_params = (float(np.sqrt(-np.log(2 * w.ewald_tol)) / w.cutoff), 98, 98, 70)
+    return w
+
+
 def argon_box(n_cells=6, seed=0, method=H.NoCutoff):
     """864-atom (6x6x6 fcc) argon box with the HelloArgon parameters (examples/HelloArgon.cpp:36-44)."""
     rng = np.random.default_rng(seed)

@@ -83,42 +83,63 @@ def dhfr_states():
     return w, out
 
 
-def test_dhfr_size_forces_within_1e4_of_reference(dhfr_states):
-    w, out = dhfr_states
-    assert out["pme"][1:] == (56, 56, 56) and abs(out["pme"][0] - 2.9203) < 1e-3
-    f_ref, f_hip = out["Reference"].forces, out["HIP"].forces
-    # max_i |F_hip,i - F_ref,i| / max(|F_ref,i|, F_floor) with F_floor = RMS force of the system
+def _check_forces_against_reference(w, hip, ref, label):
+    """max_i |F_hip,i - F_ref,i| / max(|F_ref,i|, F_floor) with F_floor = RMS force of the system < 1e-4, the
+    reference's own statistic (median of 2|dF| / (|F_ref| + |F_hip|)) below its published single-precision figure, energy to 1e-5.
+
+    The truncated direct-space force is discontinuous at r = cutoff (for two TIP3P charges the jump is ~0.2 kJ/mol/nm,
+    2e-4 of the RMS force).  A pair whose double-precision distance lies within float32 coordinate resolution of the
+    cutoff (ulp(6 nm) = 4.8e-7 nm) may legitimately fall on the other side in the float32 pair kernel, exactly as on the
+    reference's single/mixed precision GPU platforms.  Atoms of such pairs are checked against the size of that jump instead."""
+    f_ref, f_hip = ref.forces, hip.forces
     rms = np.sqrt((f_ref ** 2).sum(1).mean())
     diff = np.linalg.norm(f_hip - f_ref, axis=1)
-    err = float((diff / np.maximum(np.linalg.norm(f_ref, axis=1), rms)).max())
-    err_rms = float(diff.max() / rms)
+    rel = diff / np.maximum(np.linalg.norm(f_ref, axis=1), rms)
     median = np.median(2 * diff / (np.linalg.norm(f_ref, axis=1) + np.linalg.norm(f_hip, axis=1)))
-    print("DHFR-size force max-rel-err %.3g (|dF|max/RMS %.3g), median relative difference (docs statistic) %.3g" % (err, err_rms, median))
-    # The truncated direct-space force is discontinuous at r = cutoff (for two TIP3P charges the jump is ~0.2 kJ/mol/nm,
-    # 2e-4 of the RMS force).  A pair whose double-precision distance lies within float32 coordinate resolution of the
-    # cutoff (ulp(6 nm) = 4.8e-7 nm) may legitimately fall on the other side in the float32 pair kernel, exactly as on the
-    # reference's single/mixed precision GPU platforms.  Such atoms are checked against the size of that jump instead.
     from scipy.spatial import cKDTree
-    L = float(w.box[0][0])
+    L = np.diag(np.asarray(w.box, float))
     band = 1.5e-6
-    tree = cKDTree(np.mod(w.positions, L), boxsize=L)
+    tree = cKDTree(np.mod(w.positions, L[None, :]), boxsize=L)
     cand = tree.query_pairs(w.cutoff + band, output_type="ndarray")
     d = w.positions[cand[:, 0]] - w.positions[cand[:, 1]]
-    d -= np.round(d / L) * L
+    d -= np.round(d / L[None, :]) * L[None, :]
     r = np.linalg.norm(d, axis=1)
     edge = cand[np.abs(r - w.cutoff) < band]
     edge_atoms = np.unique(edge)
     assert len(edge_atoms) < 0.01 * w.num_atoms
-    rel = diff / np.maximum(np.linalg.norm(f_ref, axis=1), rms)
     interior = np.ones(w.num_atoms, bool)
     interior[edge_atoms] = False
-    print("   %d pairs within %.1e nm of the cutoff; max-rel-err away from them %.3g, on them %.3g" % (len(edge), band, rel[interior].max(), rel[~interior].max() if len(edge_atoms) else 0.0))
+    print("%s: force max-rel-err %.3g (|dF|max/RMS %.3g), median relative difference (docs statistic) %.3g; %d pairs within %.1e nm of the "
+          "cutoff, max-rel-err away from them %.3g, on them %.3g" % (label, rel.max(), diff.max() / rms, median, len(edge), band, rel[interior].max(),
+                                                                   rel[~interior].max() if len(edge_atoms) else 0.0))
     assert rel[interior].max() < 1e-4
     if len(edge_atoms):
         assert rel[~interior].max() < 1e-3          # bounded by a few cutoff jumps
-    err = float(rel[interior].max())
     assert median < 4e-5        # 07_testing_validation.rst:142 quotes 3.99e-5 for CUDA single precision PME
-    assert abs(out["HIP"].potentialEnergy - out["Reference"].potentialEnergy) < 1e-5 * abs(out["Reference"].potentialEnergy)
+    assert abs(hip.potentialEnergy - ref.potentialEnergy) < 1e-5 * abs(ref.potentialEnergy)
+
+
+def test_dhfr_size_forces_within_1e4_of_reference(dhfr_states):
+    w, out = dhfr_states
+    assert out["pme"][1:] == (56, 56, 56) and abs(out["pme"][0] - 2.9203) < 1e-3
+    _check_forces_against_reference(w, out["HIP"], out["Reference"], "DHFR-size")
+
+
+def test_apoa1_size_forces_within_1e4_of_reference():
+    """BASELINE.json configs[2] (apoa1 size, 92 224 atoms; stand-in of SURVEY.md §8d config 3): rectangular non-cubic box,
+    98 x 98 x 70 PME grid (radix-7 factors; planes too large for the fused pair/FFT launches, so the stand-alone FFT and
+    pair kernels run).  One force evaluation on HIP and on the real Reference platform."""
+    w = T.apoa1_like(seed=0)
+    out = {}
+    for plat in ("HIP", "Reference"):
+        system, nb = w.build()
+        ctx = H.Context(system, H.Integrator(H.VERLET, 0.001), plat)
+        ctx.setPositions(w.positions)
+        out[plat] = ctx.getState(getForces=True, getEnergy=True)
+        if plat == "HIP":
+            assert nb.getPMEParametersInContext(ctx)[1:] == (98, 98, 70)
+        ctx.close()
+    _check_forces_against_reference(w, out["HIP"], out["Reference"], "apoa1-size")
 
 
 def test_dhfr_size_invariants():

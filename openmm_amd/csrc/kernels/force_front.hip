@@ -101,6 +101,19 @@ struct PairsFftStage {
     int fracLo, fracHi;
 };
 
+// Work units of a pair wavefront in workgroup b of a fused launch (the number of pair workgroups is a multiple of 8)
+__device__ __forceinline__ ChunkSchedule pair_schedule(const NbArgs& nb, const PairsFftStage& s, const int b) {
+    const int pairBlock = b - s.fftBlocks, pairBlocks = (int) gridDim.x - s.fftBlocks, waveInBlock = threadIdx.x >> 6;
+    ChunkSchedule sched = {pairBlock * (PF_THREADS / 64) + waveInBlock, pairBlocks * (PF_THREADS / 64), s.fracLo, s.fracHi, -1};
+    if (nb.xcdAware) {
+        // workgroup b runs on XCD b % 8; of the pair workgroups there it is number pairBlock / 8
+        sched.xcd = b % OMM_NUM_XCD;
+        sched.first = (pairBlock / OMM_NUM_XCD) * (PF_THREADS / 64) + waveInBlock;
+        sched.stride = (pairBlocks / OMM_NUM_XCD) * (PF_THREADS / 64);
+    }
+    return sched;
+}
+
 template <int METHOD, bool ENERGY>
 __global__ __launch_bounds__(PF_THREADS, 2) void pairs_fft_plane(NbArgs nb, PlaneArgs plane, PairsFftStage s, const float4* __restrict__ posqI, const float2* __restrict__ sigEpsI) {
     __shared__ PlaneShared<PF_PLANE_CAP> sh;
@@ -108,8 +121,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void pairs_fft_plane(NbArgs nb, Plan
     if (b < s.fftBlocks) fft_plane_body<PF_THREADS, PF_PLANE_CAP>(plane, b, sh);
     else {
         const int wave = (b - s.fftBlocks) * (PF_THREADS / 64) + (threadIdx.x >> 6);
-        const ChunkSchedule sched = {wave, ((int) gridDim.x - s.fftBlocks) * (PF_THREADS / 64), s.fracLo, s.fracHi};
-        nb_direct_body<METHOD, 1, ENERGY>(nb, posqI, sigEpsI, sched, wave);
+        nb_direct_body<METHOD, 1, ENERGY>(nb, posqI, sigEpsI, pair_schedule(nb, s, b), wave);
     }
 }
 
@@ -120,8 +132,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void pairs_fft_lines(NbArgs nb, FftA
     if (b < s.fftBlocks) fft_body<PF_THREADS>(fft, b, sh);
     else {
         const int wave = (b - s.fftBlocks) * (PF_THREADS / 64) + (threadIdx.x >> 6);
-        const ChunkSchedule sched = {wave, ((int) gridDim.x - s.fftBlocks) * (PF_THREADS / 64), s.fracLo, s.fracHi};
-        nb_direct_body<METHOD, 1, ENERGY>(nb, posqI, sigEpsI, sched, wave);
+        nb_direct_body<METHOD, 1, ENERGY>(nb, posqI, sigEpsI, pair_schedule(nb, s, b), wave);
     }
 }
 
@@ -160,7 +171,8 @@ extern "C" int ommhip_pairs_with_fft(const ommhip_neighbor_list* nl, const ommhi
         s.fracLo = split[stage]; s.fracHi = split[stage + 1];
         // one chunk per wavefront for this stage's share of the list capacity (surplus wavefronts find no chunk and leave)
         const long long shareChunks = ((long long) nl->max_chunks * (s.fracHi - s.fracLo) + 63) / 64;
-        const int pairBlocks = (int) ((shareChunks + PF_THREADS / 64 - 1) / (PF_THREADS / 64));
+        int pairBlocks = (int) ((shareChunks + PF_THREADS / 64 - 1) / (PF_THREADS / 64));
+        pairBlocks = (pairBlocks + OMM_NUM_XCD - 1) / OMM_NUM_XCD * OMM_NUM_XCD;       // the same number on every XCD
         const bool energy = include_energy != 0;
         if (p->use_switch) { if (energy) launch_pairs_fft<3, true>(stage, pairBlocks, st, nb, plane, fft, s); else launch_pairs_fft<3, false>(stage, pairBlocks, st, nb, plane, fft, s); }
         else { if (energy) launch_pairs_fft<1, true>(stage, pairBlocks, st, nb, plane, fft, s); else launch_pairs_fft<1, false>(stage, pairBlocks, st, nb, plane, fft, s); }

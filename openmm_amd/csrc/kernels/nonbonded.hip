@@ -32,6 +32,7 @@ namespace {
 // ================================================================================================
 struct NbArgs {
     int paddedAtoms, maxChunks, energySlots, debugFlags;
+    int xcdAware;             // XCD-aware placement of the work units (ChunkSchedule)
     float cutoff2, alpha, krf, crf, switchDist, invSwitchWidth;
     Box box;
     const float4* posq;
@@ -182,10 +183,16 @@ __device__ __forceinline__ float transpose_reduce32(float (&v)[OMM_TILE], int la
 
 // A wavefront's work units: of the part [fracLo, fracHi) / 64 of the list (fused launches split the list between several
 // launches; its length is only known on the device), the units first, first + stride, ...
+// xcd >= 0: XCD-aware placement.  Workgroups go to the 8 XCDs round-robin by index and every XCD has an L2 of its own, so
+// the launch gives XCD x the x-th eighth of the units -- neighbouring chunks (same i-block, overlapping j atoms, which the
+// Hilbert-sorted slot order keeps close in memory) then share an L2 instead of each L2 seeing the whole system.  `first`
+// is the wavefront's rank among the wavefronts of its XCD, `stride` their number.
 struct ChunkSchedule {
     int first, stride;
     int fracLo, fracHi;
+    int xcd;
 };
+#define OMM_NUM_XCD 8
 
 // One wavefront's share of the pair kernel.  A work unit is UNIT_ROWS rows of one chunk: the whole chunk in the kernel of
 // its own (the i-block's atoms are set up and its forces reduced once per chunk), single rows where the unit's latency
@@ -203,7 +210,13 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
     constexpr int UNITS_PER_CHUNK = OMM_CHUNK_ROWS / UNIT_ROWS;
     const long long numUnits = (long long) numChunks * UNITS_PER_CHUNK;
     const int unitLo = (int) ((numUnits * sched.fracLo) >> 6), unitHi = (int) ((numUnits * sched.fracHi) >> 6);
-    for (int u = unitLo + sched.first; u < unitHi; u += sched.stride) {
+    int uBegin = unitLo + sched.first, uEnd = unitHi;
+    if (sched.xcd >= 0) {
+        const int perXcd = (unitHi - unitLo + OMM_NUM_XCD - 1) / OMM_NUM_XCD;
+        uBegin = unitLo + sched.xcd * perXcd + sched.first;
+        uEnd = min(unitHi, unitLo + (sched.xcd + 1) * perXcd);
+    }
+    for (int u = uBegin; u < uEnd; u += sched.stride) {
         const int c = u / UNITS_PER_CHUNK;
         const int rowBase = (u % UNITS_PER_CHUNK) * UNIT_ROWS;
         // The row words are read unconditionally and before the chunk header is looked at (the arrays cover every row of
@@ -316,7 +329,11 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
 
 template <int METHOD, int PBC, bool ENERGY>
 __global__ __launch_bounds__(64, 2) void nb_direct(NbArgs a, const float4* __restrict__ posqI, const float2* __restrict__ sigEpsI) {
-    const ChunkSchedule sched = {(int) blockIdx.x, (int) gridDim.x, 0, 64};
+    ChunkSchedule sched = {(int) blockIdx.x, (int) gridDim.x, 0, 64, -1};
+    if (a.xcdAware) {
+        // one wavefront per workgroup: workgroup b runs on XCD b % 8 and is the (b / 8)-th of the gridDim.x / 8 there
+        sched.xcd = blockIdx.x % OMM_NUM_XCD; sched.first = blockIdx.x / OMM_NUM_XCD; sched.stride = gridDim.x / OMM_NUM_XCD;
+    }
     nb_direct_body<METHOD, PBC, ENERGY>(a, posqI, sigEpsI, sched, blockIdx.x);
 }
 
@@ -341,6 +358,8 @@ static NbArgs make_nb_args(const ommhip_neighbor_list* nl, const ommhip_nonbonde
     // OPENMM_HIP_DEBUG_SKIP_ATOMICS (profiling only, results are wrong): bit 0 drops the j-force atomics, bit 1 the i-force atomics
     static const int debugFlags = getenv("OPENMM_HIP_DEBUG_SKIP_ATOMICS") != nullptr ? atoi(getenv("OPENMM_HIP_DEBUG_SKIP_ATOMICS")) : 0;
     a.debugFlags = debugFlags;
+    static const bool xcdAware = getenv("OPENMM_HIP_NO_XCD_PLACEMENT") == nullptr;          // A/B knob
+    a.xcdAware = xcdAware ? 1 : 0;
     a.cutoff2 = nl->cutoff > 0 ? (float) (nl->cutoff * nl->cutoff) : INFINITY;
     a.alpha = (float) p->ewald_alpha; a.krf = (float) p->krf; a.crf = (float) p->crf;
     a.switchDist = (float) p->switch_distance;
@@ -361,6 +380,7 @@ extern "C" int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_non
     // the allocated capacity and surplus workgroups exit at once; the hardware dispatcher balances the rest.
     int grid = p->direct_grid > 0 ? p->direct_grid : nl->max_chunks;
     if (grid < 1) grid = 1;
+    if (a.xcdAware) grid = (grid + OMM_NUM_XCD - 1) / OMM_NUM_XCD * OMM_NUM_XCD;       // the same number of wavefronts on every XCD
     hipStream_t st = (hipStream_t) stream;
     ommhip_profile_begin(OMMHIP_TIMER_NB_DIRECT, stream);
     switch ((p->ewald ? 1 : 0) | (p->use_switch ? 2 : 0)) {

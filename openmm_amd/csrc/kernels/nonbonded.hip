@@ -164,21 +164,43 @@ __device__ __forceinline__ void pair_ixn2(const NbArgs& a, const float4 pi0, con
     if (ENERGY) { const v2f e = ljE + cE; energy = energy + mk2(in0 ? e.x : 0.f, in1 ? e.y : 0.f); }
 }
 
-// Transpose-reduce: on entry every lane holds 32 partial sums v[0..32); on exit lane l holds the
-// wave-wide total of v[l & 31].  63 cross-lane moves instead of 32*6.
+// Two registers in, one out: lanes 0-31 get a[l] + a[l + 32], lanes 32-63 get b[l - 32] + b[l] -- gfx950's
+// v_permlane32_swap exchanges the upper half of one register with the lower half of another, so one swap and one add
+// halve two partial sums at once (a shuffle-based butterfly needs two selects, a cross-lane move and an add for that).
+__device__ __forceinline__ float swap_add32(float a, float b, int lane) {
+#ifdef OMMHIP_EMU
+    const float xa = a + __shfl_xor(a, 32), xb = b + __shfl_xor(b, 32);
+    return lane < 32 ? xa : xb;
+#else
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#endif
+}
+// The same one level down (v_permlane16_swap: odd 16-lane rows of one register <-> even rows of the other):
+// even rows get a[row] + a[row + 1], odd rows get b[row - 1] + b[row].
+__device__ __forceinline__ float swap_add16(float a, float b, int lane) {
+#ifdef OMMHIP_EMU
+    const float xa = a + __shfl_xor(a, 16), xb = b + __shfl_xor(b, 16);
+    return (lane & 16) ? xb : xa;
+#else
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#endif
+}
+
+// Transpose-reduce: on entry every lane holds 32 partial sums v[0..32); on exit lane l holds the wave-wide total of
+// v[l >> 1] (each total in two neighbouring lanes).  24 lane swaps + 8 cross-lane moves instead of 32 * 6 moves.
 __device__ __forceinline__ float transpose_reduce32(float (&v)[OMM_TILE], int lane) {
 #pragma unroll
-    for (int k = 0; k < 32; k++) v[k] += __shfl_xor(v[k], 32);
+    for (int k = 0; k < 16; k++) v[k] = swap_add32(v[k], v[k + 16], lane);        // halves: v[k] | v[k + 16]
 #pragma unroll
-    for (int k = 0; k < 16; k++) { bool up = lane & 16; float send = up ? v[k] : v[k + 16]; float keep = up ? v[k + 16] : v[k]; v[k] = keep + __shfl_xor(send, 16); }
+    for (int k = 0; k < 8; k++) v[k] = swap_add16(v[k], v[k + 8], lane);          // rows: v[k], v[k + 8], v[k + 16], v[k + 24]
 #pragma unroll
-    for (int k = 0; k < 8; k++) { bool up = lane & 8; float send = up ? v[k] : v[k + 8]; float keep = up ? v[k + 8] : v[k]; v[k] = keep + __shfl_xor(send, 8); }
+    for (int k = 0; k < 4; k++) { bool up = lane & 8; float send = up ? v[k] : v[k + 4]; float keep = up ? v[k + 4] : v[k]; v[k] = keep + __shfl_xor(send, 8); }
 #pragma unroll
-    for (int k = 0; k < 4; k++) { bool up = lane & 4; float send = up ? v[k] : v[k + 4]; float keep = up ? v[k + 4] : v[k]; v[k] = keep + __shfl_xor(send, 4); }
-#pragma unroll
-    for (int k = 0; k < 2; k++) { bool up = lane & 2; float send = up ? v[k] : v[k + 2]; float keep = up ? v[k + 2] : v[k]; v[k] = keep + __shfl_xor(send, 2); }
-    { bool up = lane & 1; float send = up ? v[0] : v[1]; float keep = up ? v[1] : v[0]; v[0] = keep + __shfl_xor(send, 1); }
-    return v[0];
+    for (int k = 0; k < 2; k++) { bool up = lane & 4; float send = up ? v[k] : v[k + 2]; float keep = up ? v[k + 2] : v[k]; v[k] = keep + __shfl_xor(send, 4); }
+    { bool up = lane & 2; float send = up ? v[0] : v[1]; float keep = up ? v[1] : v[0]; v[0] = keep + __shfl_xor(send, 2); }
+    return v[0] + __shfl_xor(v[0], 1);
 }
 
 // A wavefront's work units: of the part [fracLo, fracHi) / 64 of the list (fused launches split the list between several
@@ -315,8 +337,8 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
         const float tx = transpose_reduce32(fix, lane);
         const float ty = transpose_reduce32(fiy, lane);
         const float tz = transpose_reduce32(fiz, lane);
-        if (lane < OMM_TILE) {
-            if (!(a.debugFlags & 2)) add_force(a.force, a.paddedAtoms, X * OMM_TILE + lane, tx, ty, tz);
+        if ((lane & 1) == 0) {          // lane l holds the total of i atom l >> 1
+            if (!(a.debugFlags & 2)) add_force(a.force, a.paddedAtoms, X * OMM_TILE + (lane >> 1), tx, ty, tz);
             else if (tx == 12345.f) a.force[0] = 1;
         }
         if (ENERGY) energyTotal += (double) energy + (double) energy2.x + (double) energy2.y;

@@ -305,7 +305,7 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
 #pragma unroll
                     for (int k = 0; k < OMM_TILE; k += 2) {
                         v2f ax = mk2(fix[k], fix[k + 1]), ay = mk2(fiy[k], fiy[k + 1]), az = mk2(fiz[k], fiz[k + 1]);
-                        pair_ixn2<METHOD, ENERGY, true>(a, rl4(iPosq, k), rl4(iPosq, k + 1), rl2(iSe, k), rl2(iSe, k + 1), pj, sej, qjK, (m >> k) & 1u, (m >> (k + 1)) & 1u,
+                        pair_ixn2<METHOD, ENERGY, true>(a, ip[k], ip[k + 1], ise[k], ise[k + 1], pj, sej, qjK, (m >> k) & 1u, (m >> (k + 1)) & 1u,
                                                         ax, ay, az, fj2x, fj2y, fj2z, energy2);
                         fix[k] = ax.x; fix[k + 1] = ax.y; fiy[k] = ay.x; fiy[k + 1] = ay.y; fiz[k] = az.x; fiz[k + 1] = az.y;
                     }
@@ -314,7 +314,7 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
 #pragma unroll
                     for (int k = 0; k < OMM_TILE; k += 2) {
                         v2f ax = mk2(fix[k], fix[k + 1]), ay = mk2(fiy[k], fiy[k + 1]), az = mk2(fiz[k], fiz[k + 1]);
-                        pair_ixn2<METHOD, ENERGY, false>(a, rl4(iPosq, k), rl4(iPosq, k + 1), rl2(iSe, k), rl2(iSe, k + 1), pj, sej, qjK, true, true,
+                        pair_ixn2<METHOD, ENERGY, false>(a, ip[k], ip[k + 1], ise[k], ise[k + 1], pj, sej, qjK, true, true,
                                                          ax, ay, az, fj2x, fj2y, fj2z, energy2);
                         fix[k] = ax.x; fix[k + 1] = ax.y; fiy[k] = ay.x; fiy[k + 1] = ay.y; fiz[k] = az.x; fiz[k + 1] = az.y;
                     }

@@ -48,12 +48,32 @@ def test_direct_space_single_image_path(K):
 
 
 @needs_emu
-def test_fused_single_stream_evaluation(K):
+@pytest.mark.parametrize("switch,ng", [(None, (24, 24, 24)), (0.6, (24, 20, 28))])
+def test_fused_single_stream_evaluation(K, switch, ng):
     """nl_prepare (+clears) -> force_front (list build + charge spreading) -> pairs_with_fft -> interpolate, through the C ABI"""
-    f, e, f_or, e_or, state = KC.run_direct_space(K, 1200, ONB.PME, 0.7, 3.4, EXCL, compact=True, fused_pme=(24, 24, 24))
+    f, e, f_or, e_or, state = KC.run_direct_space(K, 1200, ONB.PME, 0.7, 3.4, EXCL, compact=True, fused_pme=ng, switch=switch)
     assert state[2] == 0 and state[1] > 0
     assert max_rel_force_error(f, f_or) < 1e-4
     assert abs(e - e_or) < 5e-5 * max(abs(e_or), 100.0)
+
+
+@needs_emu
+def test_pairs_with_fft_declines_configurations_it_does_not_cover(K):
+    """ommhip_pairs_with_fft returns -1 and launches nothing for triclinic boxes, non-Ewald methods and planes beyond its
+    LDS budget; the caller then uses the separate entry points."""
+    import ctypes as C
+    from openmm_amd import capi
+    fn = K.lib.ommhip_pairs_with_fft
+    fn.restype = C.c_int
+    nl, p, pm = capi.NeighborList(), capi.NonbondedParams(), capi.Pme()
+    nl.pbc, p.ewald = 1, 1
+    pm.nx, pm.ny, pm.nz = 96, 96, 96                      # plane 96 x 97 > 4160 elements
+    assert fn(C.byref(nl), C.byref(p), None, C.byref(pm), None, None, 1, 0, None) == -1
+    pm.nx, pm.ny, pm.nz = 32, 32, 32
+    nl.pbc = 2                                            # triclinic
+    assert fn(C.byref(nl), C.byref(p), None, C.byref(pm), None, None, 1, 0, None) == -1
+    nl.pbc, p.ewald = 1, 0                                # cutoff without Ewald: no reciprocal space to ride on
+    assert fn(C.byref(nl), C.byref(p), None, C.byref(pm), None, None, 1, 0, None) == -1
 
 
 @needs_emu

@@ -57,13 +57,14 @@ def test_direct_space_cell_binned_builder(K, n, L, cutoff, compact):
     assert abs(e - e_or) < 1e-5 * max(abs(e_or), 100.0)
 
 
-@pytest.mark.parametrize("n,L,cutoff,ng", [(3000, 4.6, 0.9, (40, 40, 40)), (6000, 6.2, 0.9, (56, 56, 56)), (2500, 4.4, 0.8, (36, 40, 32))])
-def test_fused_single_stream_evaluation(K, n, L, cutoff, ng):
+@pytest.mark.parametrize("n,L,cutoff,ng,switch", [(3000, 4.6, 0.9, (40, 40, 40), None), (6000, 6.2, 0.9, (56, 56, 56), None),
+                                                  (2500, 4.4, 0.8, (36, 40, 32), None), (3000, 4.6, 0.9, (40, 36, 48), 0.8)])
+def test_fused_single_stream_evaluation(K, n, L, cutoff, ng, switch):
     """The launch sequence of the single-stream default through the C ABI: ommhip_nl_prepare (+clears of a dirty force
     buffer and charge grid), ommhip_force_front (list build + charge spreading in one launch), ommhip_pairs_with_fft
     (pair kernel riding on the three FFT launches), ommhip_pme_reciprocal(interpolate only) -- against the oracle's
     direct + reciprocal space."""
-    f, e, f_or, e_or, state = KC.run_direct_space(K, n, ONB.PME, cutoff, L, EXCL, compact=True, fused_pme=ng)
+    f, e, f_or, e_or, state = KC.run_direct_space(K, n, ONB.PME, cutoff, L, EXCL, compact=True, fused_pme=ng, switch=switch)
     assert state[2] == 0 and state[1] > 0
     assert max_rel_force_error(f, f_or) < 1e-4
     assert abs(e - e_or) < 2e-5 * abs(e_or) + 1e-2

@@ -15,9 +15,11 @@ warm-up steps, then time step(K) followed by getState(energy), which forces a de
 Multi-GPU: the path does not shard in this round (domain decomposition is SURVEY.md §8e, planned); --gpus N runs
 N independent replicas of the workload, one per GPU, and reports the aggregate ns/day ("scaling": "weak").
 
-Rank 0 prints ONE JSON line with the contract fields plus `roofline` (direct-space pair kernel, measured with HIP
-events on the stream the kernel runs on) and `cpu_baseline` (the reference's own platforms/cpu built into
-oracle/_ref, timed on this host on a bounded number of steps of the same System).
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (the direct-space pair kernel -- in the default
+single-stream mode the three launches it shares with the FFT stages of reciprocal space -- measured with HIP events on
+the stream the kernels run on), `cpu_baseline` (the reference's own platforms/cpu built into oracle/_ref, timed on this
+host on a bounded number of steps of the same System) and `force_parity` (HIP forces of the final configuration against
+the reference's Reference platform, the second half of BASELINE.json's metric).  DESIGN.md (d) defines every field.
 """
 import argparse
 import ctypes as C

@@ -136,6 +136,12 @@ typedef struct ommhip_neighbor_list {
     float* cell_meta;          /* float[4] */
     int max_cells;
     int cell_min_blocks;
+    /* Work sharing between ranks (force decomposition; all zero = everything): the list is built for the i-blocks
+     * [first_block, first_block + owned_blocks) only.  A block pair (X, Y >= X) is evaluated by whoever owns X, so the
+     * lists of ranks that partition the i-blocks partition the pairs, and the sum of their fixed-point force buffers is
+     * bit for bit the single-rank result.  posq, bounds and exclusion tables still describe the whole system. */
+    int first_block;
+    int owned_blocks;
 } ommhip_neighbor_list;
 
 typedef struct ommhip_nonbonded_params {

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void force_front(FrontArgs f) {
     __shared__ FrontShared sh;
     const int b = blockIdx.x;
     // heavy, rare work first in the grid so that it starts first
-    if (b < f.nlBlocks) nl_find_body<PBC>(f.nl, b, f.nlBlocks, sh.nl);
+    if (b < f.nlBlocks) nl_find_body<PBC>(f.nl, f.nl.firstBlock + b, f.nlBlocks, sh.nl);
     else if (b < f.nlBlocks + f.spreadBlocks) pme_spread_body(f.pme, b - f.nlBlocks, sh.spread);
     else terms_body(f.terms, b - f.nlBlocks - f.spreadBlocks, sh.termPartial);
 }
@@ -47,7 +47,7 @@ extern "C" int ommhip_force_front(const ommhip_neighbor_list* nl, const ommhip_p
     FrontArgs f;
     f.nl = make_nl_args(nl);
     if (f.nl.cellMode) hipLaunchKernelGGL(nl_bin_blocks, dim3(1), dim3(1024), 0, st, f.nl);
-    f.nlBlocks = f.nl.numBlocks;
+    f.nlBlocks = f.nl.ownedBlocks;
     f.spreadBlocks = 0;
     if (pme != nullptr) {
         if (pme->spread_mode == 1 || !pme->grid_precleared) return 1;          // the direct-atomics variant and un-cleared grids are not fused

@@ -32,6 +32,7 @@ namespace {
 
 struct NlArgs {
     int numAtoms, paddedAtoms, numBlocks, maxChunks;
+    int firstBlock, ownedBlocks;      // the list is built for the i-blocks [firstBlock, firstBlock + ownedBlocks)
     int pbc;                 // 0 none, 1 orthorhombic, 2 triclinic
     float listCutoff2;       // (cutoff + padding)^2, +inf for NoCutoff
     float maxDisp2;          // (padding/2)^2
@@ -482,7 +483,7 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
 template <int PBC>
 __global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
     __shared__ NlShared sh;
-    nl_find_body<PBC>(a, blockIdx.x, gridDim.x, sh);
+    nl_find_body<PBC>(a, a.firstBlock + blockIdx.x, gridDim.x, sh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -553,6 +554,8 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
 NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
     NlArgs a;
     a.numAtoms = nl->num_atoms; a.paddedAtoms = nl->padded_atoms; a.numBlocks = nl->padded_atoms / OMM_TILE; a.maxChunks = nl->max_chunks;
+    a.firstBlock = 0; a.ownedBlocks = a.numBlocks;
+    if (nl->owned_blocks > 0 && nl->first_block >= 0 && nl->first_block + nl->owned_blocks <= a.numBlocks) { a.firstBlock = nl->first_block; a.ownedBlocks = nl->owned_blocks; }
     a.pbc = nl->pbc;
     double rl = nl->cutoff + nl->padding;
     a.listCutoff2 = nl->cutoff > 0 ? (float) (rl * rl) : INFINITY;
@@ -590,9 +593,9 @@ NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
 
 static void launch_find(const NlArgs& a, hipStream_t st) {
     if (a.cellMode) hipLaunchKernelGGL(nl_bin_blocks, dim3(1), dim3(1024), 0, st, a);
-    if (a.pbc == 0) hipLaunchKernelGGL(nl_find_interactions<0>, dim3(a.numBlocks), dim3(NL_THREADS), 0, st, a);
-    else if (a.pbc == 1) hipLaunchKernelGGL(nl_find_interactions<1>, dim3(a.numBlocks), dim3(NL_THREADS), 0, st, a);
-    else hipLaunchKernelGGL(nl_find_interactions<2>, dim3(a.numBlocks), dim3(NL_THREADS), 0, st, a);
+    if (a.pbc == 0) hipLaunchKernelGGL(nl_find_interactions<0>, dim3(a.ownedBlocks), dim3(NL_THREADS), 0, st, a);
+    else if (a.pbc == 1) hipLaunchKernelGGL(nl_find_interactions<1>, dim3(a.ownedBlocks), dim3(NL_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(nl_find_interactions<2>, dim3(a.ownedBlocks), dim3(NL_THREADS), 0, st, a);
 }
 
 // Per-step entry of the platform: conversion + displacement check + bounds in one launch, then the

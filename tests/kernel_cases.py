@@ -10,6 +10,9 @@ from openmm_amd import capi
 from oracle import nonbonded as ONB, pme as OPME
 
 
+LAST_FIXED_POINT_FORCES = None
+
+
 def lattice_positions(rng, n, box3, jitter=0.25):
     m = int(np.ceil(n ** (1 / 3)))
     g = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n]
@@ -24,7 +27,7 @@ def box6(box3):
     return (C.c_double * 6)(box3[0, 0], box3[1, 0], box3[1, 1], box3[2, 0], box3[2, 1], box3[2, 2])
 
 
-def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64, compact=False, cells=False, fused_pme=None):
+def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64, compact=False, cells=False, fused_pme=None, block_range=None):
     """-> (forces[n,3], energy, oracle forces, oracle energy, nl state)
 
     compact=False: random slot order, list built by ommhip_nl_update on wrapped coordinates (general image search).
@@ -33,7 +36,9 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     fused_pme=(nx, ny, nz): instead of the list builder and the pair kernel on their own, the single-stream sequence of a
     whole PME evaluation -- ommhip_nl_prepare (with the clears), ommhip_force_front (list build + charge spreading),
     ommhip_pairs_with_fft (pair kernel on the three FFT launches), ommhip_pme_reciprocal(interpolate only) -- against
-    direct + reciprocal space of the oracle."""
+    direct + reciprocal space of the oracle.
+    block_range=(first, count): the list is built for these i-blocks only (force decomposition between ranks); the raw
+    fixed-point force buffer of the evaluation is left in LAST_FIXED_POINT_FORCES."""
     rng = np.random.default_rng(seed)
     box3 = np.eye(3) * L
     if triclinic:
@@ -94,6 +99,8 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     nl.chunk_info = K.upload(np.zeros((maxc, 2), np.int32))
     nl.row_j = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.int32))
     nl.row_mask = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.uint32))
+    if block_range is not None:
+        nl.first_block, nl.owned_blocks = block_range
     if cells:      # force the cell-binned candidate search of large systems at test size
         nl.max_cells = nb + 64
         nl.cell_start = K.upload(np.zeros(2 * nl.max_cells + 2, np.int32))
@@ -133,7 +140,9 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     else:
         d_f, d_e = K.upload(np.zeros(3 * padded, np.int64)), K.upload(np.zeros(grid))
         K.nb_direct(C.byref(nl), C.byref(p), d_se, d_f, d_e, grid, 1, None)
-    f = K.download(d_f, (3, padded), np.int64).astype(np.float64) / 2 ** 32
+    global LAST_FIXED_POINT_FORCES
+    LAST_FIXED_POINT_FORCES = K.download(d_f, (3, padded), np.int64)
+    f = LAST_FIXED_POINT_FORCES.astype(np.float64) / 2 ** 32
     e = float(K.download(d_e, grid, np.float64).sum())
     forces = f[:, slot_of_atom].T
     # fraction of i-blocks that qualified for the pair kernel's single-image path (coverage check for compact=True)

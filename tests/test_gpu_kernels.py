@@ -70,6 +70,25 @@ def test_fused_single_stream_evaluation(K, n, L, cutoff, ng, switch):
     assert abs(e - e_or) < 2e-5 * abs(e_or) + 1e-2
 
 
+@pytest.mark.parametrize("compact", [False, True])
+def test_block_range_lists_partition_the_pairs(K, compact):
+    """Force decomposition between ranks: lists built for disjoint ranges of i-blocks
+    (ommhip_neighbor_list.first_block / owned_blocks) partition the pairs -- the fixed-point force buffers of the parts
+    add up to the buffer of the whole evaluation bit for bit.  (tests/test_multirank_cpu.py does the same with two gloo
+    ranks on the emulated kernels.)"""
+    n, blocks = 3000, (3000 + 31) // 32
+    whole = KC.run_direct_space(K, n, ONB.PME, 0.9, 4.6, EXCL, compact=compact)
+    total = KC.LAST_FIXED_POINT_FORCES.copy()
+    acc = np.zeros_like(total)
+    chunks = 0
+    for first, count in ((0, 30), (30, 1), (31, blocks - 31)):
+        part = KC.run_direct_space(K, n, ONB.PME, 0.9, 4.6, EXCL, compact=compact, block_range=(first, count))
+        acc += KC.LAST_FIXED_POINT_FORCES
+        chunks += int(part[4][1])
+    assert np.array_equal(acc, total)
+    assert chunks >= int(whole[4][1])          # the same rows, possibly packed into a few more chunks
+
+
 def test_direct_space_kernel_launch_shape_independent(K):
     """Different launch shapes (and a rebuilt list, whose row composition depends on the order in which wavefronts
     append to it) must agree to float-summation noise; the integer force accumulation itself is order independent."""

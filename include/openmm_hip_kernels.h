@@ -139,7 +139,8 @@ typedef struct ommhip_neighbor_list {
     /* Work sharing between ranks (force decomposition; all zero = everything): the list is built for the i-blocks
      * [first_block, first_block + owned_blocks) only.  A block pair (X, Y >= X) is evaluated by whoever owns X, so the
      * lists of ranks that partition the i-blocks partition the pairs, and the sum of their fixed-point force buffers is
-     * bit for bit the single-rank result.  posq, bounds and exclusion tables still describe the whole system. */
+     * the single-rank result (bit for bit for the same row composition of the lists; to float summation noise of the
+     * per-chunk partial sums otherwise).  posq, bounds and exclusion tables still describe the whole system. */
     int first_block;
     int owned_blocks;
 } ommhip_neighbor_list;

@@ -103,7 +103,7 @@ def test_pme_logic(K, tric):
 
 
 FAST_REFERENCE_TESTS = ["HarmonicBondForce", "HarmonicAngleForce", "PeriodicTorsionForce", "CMMotionRemover", "Checkpoints",
-                        "CustomBondForce", "RBTorsionForce", "Settle", "NonbondedForce"]
+                        "CustomBondForce", "RBTorsionForce", "Settle", "NonbondedForce", "CustomExternalForce", "VirtualSites"]
 
 
 @needs_emu

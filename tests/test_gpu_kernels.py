@@ -88,7 +88,7 @@ def test_block_range_lists_partition_the_pairs(K, compact):
         acc += KC.LAST_FIXED_POINT_FORCES
         chunks += int(part[4][1])
     scale = np.abs(total).max()
-    assert np.abs(acc - total).max() < 2e-6 * scale
+    assert np.abs(acc - total).max() < 1e-5 * scale          # float noise of the per-chunk partial sums (measured ~1e-6)
     assert chunks >= int(whole[4][1]) - 2      # the same pairs, possibly packed into a few more chunks
 
 

@@ -221,11 +221,13 @@ def main():
                 rctx.close()
                 from openmm_amd.parity import force_parity
                 fp = force_parity(end.positions, w.box, w.cutoff, end.forces, f_ref)
-                out["force_parity"] = {"max_rel_err_vs_reference": fp["max_rel_err"], "tolerance": 1e-4, "median_rel_diff": fp["median_rel_diff"],
-                                       "cutoff_edge_pairs": fp["cutoff_edge_pairs"], "max_rel_err_cutoff_edge_atoms": fp["max_rel_err_cutoff_edge_atoms"],
+                out["force_parity"] = {"max_rel_err_vs_reference": fp["max_rel_err_all_atoms"], "tolerance": 1e-4,
+                                       "max_rel_err_all_atoms": fp["max_rel_err_all_atoms"], "median_rel_diff": fp["median_rel_diff"],
+                                       "atoms_above_tolerance": fp["atoms_above_tolerance"], "cutoff_edge_pairs": fp["cutoff_edge_pairs"],
+                                       "max_rel_err_away_from_cutoff_edge_pairs": fp["max_rel_err"], "edge_band_nm": fp["edge_band_nm"],
                                        "oracle": "platforms/reference from oracle/_ref, final configuration of the timed run",
-                                       "note": "atoms of pairs within %.1e nm of the cutoff are reported separately: the truncated force jumps there and "
-                                               "float32 coordinates decide the side (openmm_amd/parity.py)" % fp["edge_band_nm"]}
+                                       "note": "headline = maximum over ALL atoms; the pair kernel works on block-relative coordinates, so only pairs within "
+                                               "%.0e nm of the cutoff (where the truncated force jumps) can differ from the reference's side of it" % fp["edge_band_nm"]}
             except Exception as e:
                 out["force_parity"] = {"max_rel_err_vs_reference": None, "error": str(e)}
         print(json.dumps(out), flush=True)

@@ -143,6 +143,11 @@ typedef struct ommhip_neighbor_list {
      * per-chunk partial sums otherwise).  posq, bounds and exclusion tables still describe the whole system. */
     int first_block;
     int owned_blocks;
+    /* Block-relative coordinates: posq_rel[s].xyz = position of slot s minus block_center[s / 32] (evaluated in double from
+     * the double positions by ommhip_nl_prepare, from posq by ommhip_nl_update), .w = charge.  The pair kernel works on
+     * these only, so its separations carry the rounding of a sub-nanometre number (~6e-8 nm) whatever the box size;
+     * absolute float coordinates (ulp 1.9e-6 nm at 20 nm) only decide list membership inside the padded list cutoff. */
+    void* posq_rel;            /* float4[padded_atoms], required by ommhip_nb_direct / ommhip_pairs_with_fft */
 } ommhip_neighbor_list;
 
 typedef struct ommhip_nonbonded_params {

@@ -95,6 +95,7 @@ __device__ __forceinline__ int lane_prefix_count(unsigned long long mask) {
 struct Box {
     float ax, bx, by, cx, cy, cz;
     float invAx, invBy, invCz;
+    float axLo, byLo, czLo;     // box length minus its float value: ax + axLo is the edge to ~1e-14 nm (image shifts of block origins)
 };
 
 struct BoxD {
@@ -133,6 +134,7 @@ inline Box make_box(const double* bv) {
     Box b;
     b.ax = (float) bv[0]; b.bx = (float) bv[1]; b.by = (float) bv[2]; b.cx = (float) bv[3]; b.cy = (float) bv[4]; b.cz = (float) bv[5];
     b.invAx = (float) (1.0 / bv[0]); b.invBy = (float) (1.0 / bv[2]); b.invCz = (float) (1.0 / bv[5]);
+    b.axLo = (float) (bv[0] - (double) b.ax); b.byLo = (float) (bv[2] - (double) b.by); b.czLo = (float) (bv[5] - (double) b.cz);
     return b;
 }
 

@@ -149,6 +149,7 @@ extern "C" int ommhip_pairs_with_fft(const ommhip_neighbor_list* nl, const ommhi
                                      long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
     const int nx = pme->nx, ny = pme->ny, nz = pme->nz;
     if (nl->pbc != 1 || !p->ewald || nz * (ny + 1) > PF_PLANE_CAP || ny > 256 || nz > 256 || pme->fft_mode == 1) return -1;
+    if (nl->posq_rel == nullptr) return 1;
     hipStream_t st = (hipStream_t) stream;
     // list fractions (in 64ths) at which stages 1 and 2 begin; tuning knob OPENMM_HIP_PAIRS_FFT_SPLIT="a,b"
     static int split[4] = {0, -1, -1, 64};

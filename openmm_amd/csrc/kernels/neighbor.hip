@@ -39,6 +39,7 @@ struct NlArgs {
     Box box;
     const float4* posq;
     float4* posqRef;
+    float4* posqRel;         // block-relative coordinates (position minus blockCenter of its block) + charge, or null
     const int* atomOfSlot;
     const int* slotOfAtom;
     const int* exclStart;
@@ -91,29 +92,38 @@ __global__ void nl_check_displacement(NlArgs a) {
 // Bounding boxes of the 32-atom blocks (two blocks per wavefront); also snapshots posq -> posqRef.
 // ------------------------------------------------------------------------------------------------
 __global__ void nl_block_bounds(NlArgs a) {
-    if (a.state[ST_REBUILD] == 0) return;
+    const bool rebuild = a.state[ST_REBUILD] != 0;
+    if (!rebuild && a.posqRel == nullptr) return;
     int s = blockIdx.x * blockDim.x + threadIdx.x;     // slot
     bool inRange = s < a.paddedAtoms;
     int sl = inRange ? s : a.paddedAtoms - 1;
     float4 p = a.posq[sl];
     bool valid = inRange && a.atomOfSlot[sl] >= 0;
-    // first atom of the block (always valid: every block holds at least one real atom)
-    float4 p0 = make_float4(__shfl(p.x, 0, 32), __shfl(p.y, 0, 32), __shfl(p.z, 0, 32), 0.f);
-    float dx = p.x - p0.x, dy = p.y - p0.y, dz = p.z - p0.z;
-    apply_pbc_rt(a.pbc, dx, dy, dz, a.box);
-    if (!valid) { dx = dy = dz = 0; }
-    float minx = dx, maxx = dx, miny = dy, maxy = dy, minz = dz, maxz = dz;
+    float4 center = a.blockCenter[sl >> 5];
+    if (rebuild) {
+        // first atom of the block (always valid: every block holds at least one real atom)
+        float4 p0 = make_float4(__shfl(p.x, 0, 32), __shfl(p.y, 0, 32), __shfl(p.z, 0, 32), 0.f);
+        float dx = p.x - p0.x, dy = p.y - p0.y, dz = p.z - p0.z;
+        apply_pbc_rt(a.pbc, dx, dy, dz, a.box);
+        if (!valid) { dx = dy = dz = 0; }
+        float minx = dx, maxx = dx, miny = dy, maxy = dy, minz = dz, maxz = dz;
 #pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) {
-        minx = fminf(minx, __shfl_xor(minx, m)); maxx = fmaxf(maxx, __shfl_xor(maxx, m));
-        miny = fminf(miny, __shfl_xor(miny, m)); maxy = fmaxf(maxy, __shfl_xor(maxy, m));
-        minz = fminf(minz, __shfl_xor(minz, m)); maxz = fmaxf(maxz, __shfl_xor(maxz, m));
+        for (int m = 16; m >= 1; m >>= 1) {
+            minx = fminf(minx, __shfl_xor(minx, m)); maxx = fmaxf(maxx, __shfl_xor(maxx, m));
+            miny = fminf(miny, __shfl_xor(miny, m)); maxy = fmaxf(maxy, __shfl_xor(maxy, m));
+            minz = fminf(minz, __shfl_xor(minz, m)); maxz = fmaxf(maxz, __shfl_xor(maxz, m));
+        }
+        center = make_float4(p0.x + 0.5f * (minx + maxx), p0.y + 0.5f * (miny + maxy), p0.z + 0.5f * (minz + maxz), 0.f);
+        if (inRange && (s & 31) == 0) {
+            int blk = s >> 5;
+            a.blockCenter[blk] = center;
+            a.blockHalf[blk] = make_float4(0.5f * (maxx - minx), 0.5f * (maxy - miny), 0.5f * (maxz - minz), 0.f);
+        }
     }
-    if (inRange && (s & 31) == 0) {
-        int blk = s >> 5;
-        a.blockCenter[blk] = make_float4(p0.x + 0.5f * (minx + maxx), p0.y + 0.5f * (miny + maxy), p0.z + 0.5f * (minz + maxz), 0.f);
-        a.blockHalf[blk] = make_float4(0.5f * (maxx - minx), 0.5f * (maxy - miny), 0.5f * (maxz - minz), 0.f);
-    }
+    // block-relative coordinates for the pair kernel (any origin works as long as both sides use the same one; between
+    // rebuilds this entry keeps the centre of the last rebuild)
+    if (inRange && a.posqRel != nullptr)
+        a.posqRel[s] = valid ? make_float4(p.x - center.x, p.y - center.y, p.z - center.z, p.w) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -509,12 +519,14 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
     const int atom = a.atomOfSlot[sl];
     const bool valid = inRange && atom >= 0;
     float4 p = posqOut[sl];
+    double xw = 0.0, yw = 0.0, zw = 0.0;               // the position in double: the float posq is its rounding
     if (valid) {
         const double4 x = pos[atom];
         const int4 w = wrap[atom];
-        p.x = (float) (x.x - (w.x * boxd.ax + w.y * boxd.bx + w.z * boxd.cx));
-        p.y = (float) (x.y - (w.y * boxd.by + w.z * boxd.cy));
-        p.z = (float) (x.z - (w.z * boxd.cz));
+        xw = x.x - (w.x * boxd.ax + w.y * boxd.bx + w.z * boxd.cx);
+        yw = x.y - (w.y * boxd.by + w.z * boxd.cy);
+        zw = x.z - (w.z * boxd.cz);
+        p.x = (float) xw; p.y = (float) yw; p.z = (float) zw;
     }
     else { p.x = 0.f; p.y = 0.f; p.z = 0.f; p.w = 0.f; }
     // displacement since the last rebuild
@@ -529,12 +541,19 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
     // bounding box of the 32-atom block, relative to its first atom
     const float4 p0 = make_float4(__shfl(p.x, 0, 32), __shfl(p.y, 0, 32), __shfl(p.z, 0, 32), 0.f);
     float dx = p.x - p0.x, dy = p.y - p0.y, dz = p.z - p0.z;
-    apply_pbc_rt(a.pbc, dx, dy, dz, a.box);
-    if (!valid) { dx = dy = dz = 0; }
     // Rectangular boxes: store every atom in the periodic image nearest to the first atom of its block, so the 32 atoms
     // of a block are mutually image-coherent (coordinates may leave [0, L) by a block width; every consumer either
-    // reduces images itself or, like the pair kernel's single-image path, relies on exactly this coherence).
-    if (valid && a.pbc == 1) { p.x = p0.x + dx; p.y = p0.y + dy; p.z = p0.z + dz; }
+    // reduces images itself or, like the pair kernel's single-image path, relies on exactly this coherence).  The shift
+    // is applied to the double position, so posq stays the correctly rounded value of what posqRel is derived from.
+    if (valid && a.pbc == 1) {
+        xw -= (double) rintf(dx * a.box.invAx) * boxd.ax;
+        yw -= (double) rintf(dy * a.box.invBy) * boxd.by;
+        zw -= (double) rintf(dz * a.box.invCz) * boxd.cz;
+        p.x = (float) xw; p.y = (float) yw; p.z = (float) zw;
+        dx = p.x - p0.x; dy = p.y - p0.y; dz = p.z - p0.z;
+    }
+    else apply_pbc_rt(a.pbc, dx, dy, dz, a.box);
+    if (!valid) { dx = dy = dz = 0; }
     if (inRange) posqOut[sl] = p;
     float minx = dx, maxx = dx, miny = dy, maxy = dy, minz = dz, maxz = dz;
 #pragma unroll
@@ -543,12 +562,19 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
         miny = fminf(miny, __shfl_xor(miny, m)); maxy = fmaxf(maxy, __shfl_xor(maxy, m));
         minz = fminf(minz, __shfl_xor(minz, m)); maxz = fmaxf(maxz, __shfl_xor(maxz, m));
     }
+    // every lane of the block holds the same bounds, hence the same centre
+    const float4 center = make_float4(p0.x + 0.5f * (minx + maxx), p0.y + 0.5f * (miny + maxy), p0.z + 0.5f * (minz + maxz), 0.f);
     if (inRange && (s & 31) == 0) {
         const int blk = s >> 5;
-        a.blockCenter[blk] = make_float4(p0.x + 0.5f * (minx + maxx), p0.y + 0.5f * (miny + maxy), p0.z + 0.5f * (minz + maxz), 0.f);
+        a.blockCenter[blk] = center;
         // .w = 1: the block's atoms are image-coherent (written above); the pair kernel may then use one image per j atom
         a.blockHalf[blk] = make_float4(0.5f * (maxx - minx), 0.5f * (maxy - miny), 0.5f * (maxz - minz), a.pbc == 1 ? 1.f : 0.f);
     }
+    // Block-relative coordinates (double position minus the float centre, rounded once): what the pair kernel computes
+    // with.  Their error is the rounding of a number below ~1 nm (6e-8 nm), independent of where in the box the block is.
+    if (inRange && a.posqRel != nullptr)
+        a.posqRel[sl] = valid ? make_float4((float) (xw - (double) center.x), (float) (yw - (double) center.y), (float) (zw - (double) center.z), p.w)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
@@ -561,7 +587,7 @@ NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
     a.listCutoff2 = nl->cutoff > 0 ? (float) (rl * rl) : INFINITY;
     a.maxDisp2 = (float) (0.25 * nl->padding * nl->padding);
     a.box = make_box(nl->box);
-    a.posq = (const float4*) nl->posq; a.posqRef = (float4*) nl->posq_ref;
+    a.posq = (const float4*) nl->posq; a.posqRef = (float4*) nl->posq_ref; a.posqRel = (float4*) nl->posq_rel;
     a.atomOfSlot = nl->atom_of_slot; a.slotOfAtom = nl->slot_of_atom;
     a.exclStart = nl->excl_start; a.exclAtoms = nl->excl_atoms; a.exclBlockRange = (const int2*) nl->excl_block_range;
     a.exclSlotStart = nl->excl_slot_start; a.exclSlots = nl->excl_slots;

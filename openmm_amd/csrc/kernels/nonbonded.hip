@@ -35,7 +35,7 @@ struct NbArgs {
     int xcdAware;             // XCD-aware placement of the work units (ChunkSchedule)
     float cutoff2, alpha, krf, crf, switchDist, invSwitchWidth;
     Box box;
-    const float4* posq;
+    const float4* posq;       // block-relative coordinates + charge (ommhip_neighbor_list::posq_rel): position minus blockCenter of its block
     const float2* sigEps;
     const int* state;
     const int2* chunkInfo;
@@ -263,43 +263,49 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
         for (int k = 0; k < OMM_TILE; k++) { fix[k] = 0.f; fiy[k] = 0.f; fiz[k] = 0.f; }
         float energy = 0.f;
         v2f energy2 = bc2(0.f);
-        // the block's own atoms, one per lane (lanes 32..63 mirror 0..31); broadcast with v_readlane in the single-image loops
-        const float4 iPosq = a.posq[X * OMM_TILE + (lane & 31)];
-        const float2 iSe = a.sigEps[X * OMM_TILE + (lane & 31)];
+        // All coordinates are relative to the centre of the atom's own block (posq_rel); a j atom is moved into the frame
+        // of X by adding the offset between the two block centres.  Nothing of the size of the box enters the pair
+        // arithmetic, so the separations are good to ~1e-7 nm in a 6 nm box and in a 60 nm box alike.
         // Single-image path (rectangular boxes): when the block is image-coherent and block + cutoff stay inside half a
         // box length on every axis, the image of j nearest to the block centre is the nearest image for every i atom
         // within the cutoff (any other pair only comes out farther), so the image search is done once per j, not per pair.
+        const float4 cX = a.blockCenter[X];
         bool single = false;
-        float4 cX = make_float4(0.f, 0.f, 0.f, 0.f);
         if (PBC == 1) {
-            cX = a.blockCenter[X];
             const float4 hX = a.blockHalf[X];
             single = hX.w != 0.f && hX.x + a.cutoff < 0.5f * a.box.ax && hX.y + a.cutoff < 0.5f * a.box.by && hX.z + a.cutoff < 0.5f * a.box.cz;
         }
         // All rows of the chunk are fetched before the first one is processed (index, then the gathers that depend on
         // it): the two memory round trips are paid once per chunk and the later rows arrive while the first is computed.
-        int jRow[UNIT_ROWS]; unsigned mRow[UNIT_ROWS]; float4 pjRow[UNIT_ROWS]; float2 seRow[UNIT_ROWS];
+        int jRow[UNIT_ROWS]; unsigned mRow[UNIT_ROWS]; float4 pjRow[UNIT_ROWS]; float2 seRow[UNIT_ROWS]; float4 cjRow[UNIT_ROWS];
 #pragma unroll
         for (int row = 0; row < UNIT_ROWS; row++) {
             jRow[row] = row < nrows ? jWord[row] : X * OMM_TILE;
             mRow[row] = row < nrows && ((maskedBits >> row) & 1) ? mWord[row] : 0xFFFFFFFFu;
         }
 #pragma unroll
-        for (int row = 0; row < UNIT_ROWS; row++) { pjRow[row] = a.posq[jRow[row]]; seRow[row] = a.sigEps[jRow[row]]; }
+        for (int row = 0; row < UNIT_ROWS; row++) { pjRow[row] = a.posq[jRow[row]]; seRow[row] = a.sigEps[jRow[row]]; cjRow[row] = a.blockCenter[jRow[row] >> 5]; }
 #pragma unroll
         for (int row = 0; row < UNIT_ROWS; row++) {
             if (row >= nrows) break;
             const int j = jRow[row];
             float4 pj = pjRow[row];
+            const float4 cY = cjRow[row];
             const float2 sej = seRow[row];
             const float qjK = OMM_ONE_4PI_EPS0 * pj.w;
             float fjx = 0.f, fjy = 0.f, fjz = 0.f;
             const bool masked = (maskedBits >> row) & 1;
             const unsigned m = mRow[row];
             if (PBC == 1 && single) {
-                float dx = pj.x - cX.x, dy = pj.y - cX.y, dz = pj.z - cX.z;
-                min_image<false>(dx, dy, dz, a.box);
-                pj.x = cX.x + dx; pj.y = cX.y + dy; pj.z = cX.z + dz;
+                // offset of Y's centre from X's, in the nearest image.  cY - n L is formed first: the two are of similar size,
+                // so the FMA is exact, the low part of the box edge restores what its float value lost, and the final
+                // difference is between two numbers a few nm apart at most.
+                // (the image is chosen per j atom -- Y may be a wide block some of whose atoms are nearest in another image)
+                const float nx = rintf((cY.x - cX.x + pj.x) * a.box.invAx), ny = rintf((cY.y - cX.y + pj.y) * a.box.invBy), nz = rintf((cY.z - cX.z + pj.z) * a.box.invCz);
+                const float ox = fmaf(-nx, a.box.axLo, fmaf(-nx, a.box.ax, cY.x)) - cX.x;
+                const float oy = fmaf(-ny, a.box.byLo, fmaf(-ny, a.box.by, cY.y)) - cX.y;
+                const float oz = fmaf(-nz, a.box.czLo, fmaf(-nz, a.box.cz, cY.z)) - cX.z;
+                pj.x += ox; pj.y += oy; pj.z += oz;
                 v2f fj2x = bc2(0.f), fj2y = bc2(0.f), fj2z = bc2(0.f);
                 if (masked) {
 #pragma unroll
@@ -321,15 +327,19 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
                 }
                 fjx += fj2x.x + fj2x.y; fjy += fj2y.x + fj2y.y; fjz += fj2z.x + fj2z.y;
             }
-            else if (masked) {
-#pragma unroll
-                for (int k = 0; k < OMM_TILE; k++)
-                    pair_ixn<METHOD, PBC, ENERGY, true>(a, ip[k], ise[k], pj, sej, qjK, (m >> k) & 1u, fix[k], fiy[k], fiz[k], fjx, fjy, fjz, energy);
-            }
             else {
+                // general path: j in X's frame without an image shift; the pair code searches the image per pair
+                pj.x += cY.x - cX.x; pj.y += cY.y - cX.y; pj.z += cY.z - cX.z;
+                if (masked) {
 #pragma unroll
-                for (int k = 0; k < OMM_TILE; k++)
-                    pair_ixn<METHOD, PBC, ENERGY, false>(a, ip[k], ise[k], pj, sej, qjK, true, fix[k], fiy[k], fiz[k], fjx, fjy, fjz, energy);
+                    for (int k = 0; k < OMM_TILE; k++)
+                        pair_ixn<METHOD, PBC, ENERGY, true>(a, ip[k], ise[k], pj, sej, qjK, (m >> k) & 1u, fix[k], fiy[k], fiz[k], fjx, fjy, fjz, energy);
+                }
+                else {
+#pragma unroll
+                    for (int k = 0; k < OMM_TILE; k++)
+                        pair_ixn<METHOD, PBC, ENERGY, false>(a, ip[k], ise[k], pj, sej, qjK, true, fix[k], fiy[k], fiz[k], fjx, fjy, fjz, energy);
+                }
             }
             if (!(a.debugFlags & 1)) add_force(a.force, a.paddedAtoms, j, fjx, fjy, fjz);
             else if (fjx == 12345.f) a.force[0] = 1;           // profiling knob: keep the arithmetic alive without the atomics
@@ -387,7 +397,7 @@ static NbArgs make_nb_args(const ommhip_neighbor_list* nl, const ommhip_nonbonde
     a.switchDist = (float) p->switch_distance;
     a.invSwitchWidth = p->use_switch ? (float) (1.0 / (nl->cutoff - p->switch_distance)) : 0.f;
     a.box = make_box(nl->box);
-    a.posq = (const float4*) nl->posq; a.sigEps = (const float2*) sig_eps; a.state = nl->state;
+    a.posq = (const float4*) nl->posq_rel; a.sigEps = (const float2*) sig_eps; a.state = nl->state;
     a.chunkInfo = (const int2*) nl->chunk_info; a.rowJ = nl->row_j; a.rowMask = nl->row_mask;
     a.blockCenter = (const float4*) nl->block_center; a.blockHalf = (const float4*) nl->block_half;
     a.cutoff = nl->cutoff > 0 ? (float) nl->cutoff : INFINITY;
@@ -397,6 +407,7 @@ static NbArgs make_nb_args(const ommhip_neighbor_list* nl, const ommhip_nonbonde
 
 extern "C" int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, const void* sig_eps,
                                 long long* force, double* energy_buffer, int energy_slots, int include_energy, void* stream) {
+    if (nl->posq_rel == nullptr) return 1;      // hipErrorInvalidValue: the pair kernel needs the block-relative coordinates
     NbArgs a = make_nb_args(nl, p, sig_eps, force, energy_buffer, energy_slots);
     // One workgroup (= one wavefront) per chunk: the list length is only known on the device, so the launch covers
     // the allocated capacity and surplus workgroups exit at once; the hardware dispatcher balances the rest.

@@ -594,9 +594,11 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     epsilonD.allocate(sizeof(double) * max(numParticles, 1));
     posq.allocate(sizeof(float) * 4 * P);
     posqRef.allocate(sizeof(float) * 4 * P);
+    posqRel.allocate(sizeof(float) * 4 * P);
     sigEps.allocate(sizeof(float) * 2 * P);
     HIP_CHECK(ommhip_memset(posq.ptr, 0, posq.bytes, hip.stream));
     HIP_CHECK(ommhip_memset(posqRef.ptr, 0, posqRef.bytes, hip.stream));
+    HIP_CHECK(ommhip_memset(posqRel.ptr, 0, posqRel.bytes, hip.stream));
     vector<int> start(numParticles + 1, 0), flat;
     for (int i = 0; i < numParticles; i++) {
         for (set<int>::const_iterator it = exclusions[i].begin(); it != exclusions[i].end(); ++it) flat.push_back(*it);
@@ -621,7 +623,7 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     nl.pbc = 0;
     nl.cutoff = nonbondedMethod == NoCutoff ? 0.0 : nonbondedCutoff;
     nl.padding = padding;
-    nl.posq = posq.ptr; nl.posq_ref = posqRef.ptr;
+    nl.posq = posq.ptr; nl.posq_ref = posqRef.ptr; nl.posq_rel = posqRel.ptr;
     nl.atom_of_slot = hip.atomOfSlot.as<int>(); nl.slot_of_atom = hip.slotOfAtom.as<int>();
     nl.excl_start = exclStart.as<int>(); nl.excl_atoms = exclAtoms.as<int>();
     nl.state = nlState.as<int>();

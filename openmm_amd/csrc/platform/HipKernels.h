@@ -137,7 +137,7 @@ private:
     bool slotParamsDirty, forceRebuild, etermDirty, hasInitializedParams;
     bool foldExclusions;       // this evaluation: the Ewald exclusion correction rides in the PME interpolation launch
     // device
-    DeviceBuffer chargeD, sigmaD, epsilonD, posq, posqRef, sigEps, exclStart, exclAtoms, nlState, blockCenter, blockHalf, chunkInfo, rowJ, rowMask;
+    DeviceBuffer chargeD, sigmaD, epsilonD, posq, posqRef, posqRel, sigEps, exclStart, exclAtoms, nlState, blockCenter, blockHalf, chunkInfo, rowJ, rowMask;
     DeviceBuffer exceptionAtomsD, exceptionParamsD, exclusionPairsD, ewaldStructure;
     DeviceBuffer moduliX, moduliY, moduliZ, eterm, gridReal, gridComplex, twiddleX, twiddleY, twiddleZ;
     ommhip_neighbor_list nl;

@@ -89,6 +89,7 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     for i in range(6):
         nl.box[i] = b6[i]
     nl.posq, nl.posq_ref = d_posq, K.upload(np.zeros((padded, 4), np.float32))
+    nl.posq_rel = K.upload(np.zeros((padded, 4), np.float32))
     nl.atom_of_slot, nl.slot_of_atom = d_aos, d_soa
     nl.excl_start, nl.excl_atoms = K.upload(start), K.upload(flat)
     st = np.zeros(8, np.int32)

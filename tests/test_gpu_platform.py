@@ -84,16 +84,17 @@ def dhfr_states():
 
 
 def _check_forces_against_reference(w, hip, ref, label):
-    """SURVEY.md §8(d) force parity (openmm_amd/parity.py): atoms away from cutoff-edge pairs within 1e-4, atoms of such pairs
-    within the size of the truncation jump, the reference's own median statistic below its published single-precision figure."""
+    """SURVEY.md §8(d) force parity (openmm_amd/parity.py): EVERY atom within 1e-4 (relative to max(|F_ref,i|, RMS force)), except
+    atoms of a pair whose separation lies within 2e-7 nm of the cutoff (the truncated force jumps there; typically none), which
+    are held to the size of that jump; the reference's own median statistic below its published single-precision figure."""
     from openmm_amd.parity import force_parity
     p = force_parity(w.positions, w.box, w.cutoff, hip.forces, ref.forces)
-    print("%s: force max-rel-err %.3g, median relative difference (docs statistic) %.3g; %d pairs within %.1e nm of the cutoff, "
-          "max-rel-err on their atoms %.3g" % (label, p["max_rel_err"], p["median_rel_diff"], p["cutoff_edge_pairs"], p["edge_band_nm"],
-                                               p["max_rel_err_cutoff_edge_atoms"]))
-    assert p["cutoff_edge_atoms"] < 0.01 * w.num_atoms
+    print("%s: force max-rel-err over all atoms %.3g (away from cutoff-edge pairs %.3g), median relative difference (docs statistic) %.3g; "
+          "%d pairs within %.1e nm of the cutoff, max-rel-err on their atoms %.3g" % (label, p["max_rel_err_all_atoms"], p["max_rel_err"],
+          p["median_rel_diff"], p["cutoff_edge_pairs"], p["edge_band_nm"], p["max_rel_err_cutoff_edge_atoms"]))
+    assert p["cutoff_edge_pairs"] <= max(4, w.num_atoms // 50000)      # a 2e-7 nm band holds ~1e-6 of the pairs in the last 0.1 nm
     assert p["max_rel_err"] < 1e-4
-    assert p["max_rel_err_cutoff_edge_atoms"] < 1e-3          # bounded by a few cutoff jumps
+    assert p["max_rel_err_all_atoms"] < (1e-4 if p["cutoff_edge_pairs"] == 0 else 1e-3)
     assert p["median_rel_diff"] < 4e-5        # 07_testing_validation.rst:142 quotes 3.99e-5 for CUDA single precision PME
     # energies: 1e-5 of the magnitude, with a floor for configurations whose terms nearly cancel (lattice starts)
     assert abs(hip.potentialEnergy - ref.potentialEnergy) < 1e-5 * max(abs(ref.potentialEnergy), 5.0 * w.num_atoms)
@@ -120,6 +121,37 @@ def test_apoa1_size_forces_within_1e4_of_reference():
             assert nb.getPMEParametersInContext(ctx)[1:] == (98, 98, 70)
         ctx.close()
     _check_forces_against_reference(w, out["HIP"], out["Reference"], "apoa1-size")
+
+
+def test_water1m_forces_within_1e4_of_reference():
+    """BASELINE.json configs[3]: the 985 527-atom TIP3P box (21.4 nm, PME grid 192^3).  The Reference platform needs minutes and
+    several GB for one evaluation at this size, so its forces were computed once in the build container
+    (tools/make_golden_water1m.py, oracle/_ref) and a seeded sample of 40 000 atoms is committed under tests/golden/;
+    the positions are regenerated from the seed and verified against the stored checksums.  Same capacity question as
+    tests/TestNonbondedForce.h:539-594 (testHugeSystem), with the parity bar of SURVEY.md §8(d)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_forces_water985527_sample.npz")
+    g = np.load(path)
+    w = T.water_box(int(g["n_side"]), seed=int(g["seed"]))
+    idx = g["indices"]
+    assert np.array_equal(w.positions[idx[:64]], g["position_sample"]) and np.allclose(w.positions.sum(0), g["position_sum"], rtol=0, atol=1e-6)
+    system, nb = w.build()
+    ctx = H.Context(system, H.Integrator(H.VERLET, 0.001), "HIP")
+    ctx.setPositions(w.positions)
+    st = ctx.getState(getForces=True, getEnergy=True)
+    pme = nb.getPMEParametersInContext(ctx)
+    ctx.close()
+    assert tuple(pme[1:]) == tuple(int(v) for v in g["pme"][1:])
+    from openmm_amd.parity import force_parity
+    p = force_parity(w.positions, w.box, w.cutoff, st.forces[idx], g["forces"], subset=idx, rms=float(g["rms_force"]))
+    print("water-1M: force max-rel-err over the %d sampled atoms %.3g (away from the %d cutoff-edge pairs within %.0e nm: %.3g), median %.3g, "
+          "E_hip %.3f E_ref %.3f" % (len(idx), p["max_rel_err_all_atoms"], p["cutoff_edge_pairs"], p["edge_band_nm"], p["max_rel_err"],
+                                     p["median_rel_diff"], st.potentialEnergy, float(g["energy"])))
+    # 1.5e8 pairs lie inside the cutoff here, ~100 of them within 1e-7 nm of it: a few sampled atoms sit on such a pair and
+    # carry the truncation jump (1.8e-4 of the RMS force for an O-H pair); every other atom is inside 1e-4
+    assert p["max_rel_err"] < 1e-4
+    assert p["max_rel_err_all_atoms"] < 1e-3 and p["cutoff_edge_atoms"] <= 40
+    assert p["median_rel_diff"] < 4e-5
+    assert abs(st.potentialEnergy - float(g["energy"])) < 1e-5 * max(abs(float(g["energy"])), 5.0 * w.num_atoms)
 
 
 def test_dhfr_size_invariants():

@@ -22,9 +22,9 @@ def test_statistics_of_a_uniform_perturbation():
 def test_atoms_of_cutoff_edge_pairs_are_reported_separately():
     pos, box, f = _system()
     cutoff = 0.9
-    # put atom 1 exactly (to 5e-7 nm) one cutoff away from atom 0, across the periodic boundary
+    # put atom 1 exactly (to 1e-7 nm) one cutoff away from atom 0, across the periodic boundary
     pos[0] = [0.05, 1.0, 1.0]
-    pos[1] = [0.05 - cutoff + 5e-7 + 3.0, 1.0, 1.0]
+    pos[1] = [0.05 - cutoff + 1e-7 + 3.0, 1.0, 1.0]
     g = f.copy()
     g[0] += 0.3          # an error only on the two atoms of the edge pair
     g[1] -= 0.3
@@ -45,3 +45,13 @@ def test_non_periodic_and_rectangular_boxes():
     assert force_parity(pos, None, 0.9, f, f)["max_rel_err_all_atoms"] == 0.0
     rect = np.diag([3.0, 4.0, 5.0])
     assert force_parity(pos, rect, 0.9, f * (1 + 1e-6), f)["max_rel_err"] < 2e-6
+
+
+def test_sampled_golden():
+    """forces known for a subset of the atoms only (tests/golden/reference_forces_water985527_sample.npz)"""
+    pos, box, f = _system()
+    idx = np.arange(0, len(pos), 7)
+    g = f[idx].copy()
+    g[3] += 0.5
+    p = force_parity(pos, box, 0.9, g, f[idx], subset=idx, rms=float(np.sqrt((f ** 2).sum(1).mean())))
+    assert p["atoms_above_tolerance"] == 1 and p["cutoff_edge_atoms"] == 0 and p["max_rel_err"] > 1e-3

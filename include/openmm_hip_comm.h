@@ -1,0 +1,68 @@
+/* openmm_hip_comm.h -- the collective layer of the multi-GPU ("one 1M-atom box on N MI355X") path of the HIP
+ * platform, part of the same thin C ABI as openmm_hip_kernels.h (implemented in libopenmm_hip_kernels.so).
+ *
+ * One process drives one GPU; the N processes of a run form one communicator.  Two transports:
+ *
+ *   RCCL      the product transport: ncclAllGather / grouped ncclSend+ncclRecv over xGMI, enqueued on the caller's
+ *             HIP stream (stream ordered, no host synchronisation).  librccl.so.1 is opened with dlopen when the first
+ *             communicator is created, so single-GPU users never load it.  The launcher (bench.py, a user's mpirun
+ *             wrapper) creates the 128-byte ncclUniqueId on rank 0 with ommhip_comm_unique_id() and hands it to every
+ *             rank, e.g. through torch.distributed's store; the plugin receives it as the platform property "CommId".
+ *   callback  test transport: collectives are staged through host memory and performed by a function the caller
+ *             supplies (tests: torch.distributed with the gloo backend).  It lets the whole decomposed step run with
+ *             world_size 2 on the CPU emulator and on a single GPU shared by two processes, where RCCL refuses to form
+ *             a communicator ("Duplicate GPU detected").
+ *
+ * What the reference does instead: platforms/cuda/src/CudaParallelKernels.cpp:143-254 drives all devices from one
+ * process with per-device worker threads and copies positions / forces through device 0 with peer memcpys
+ * (CudaParallelKernels.cpp:178-202); there is no collective library on its path.
+ *
+ * All functions return 0 on success, a hipError_t, or 1000 + ncclResult_t for RCCL failures (ommhip_error_string
+ * understands all three).
+ */
+#ifndef OPENMM_HIP_COMM_H_
+#define OPENMM_HIP_COMM_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ommhip_comm ommhip_comm;
+
+/* Host all-gather supplied by the caller of the callback transport: every rank passes `bytes` bytes in `send` and
+ * receives size * bytes in `recv`, rank-major.  Must return 0 on success. */
+typedef int (*ommhip_host_all_gather_fn)(void* user, const void* send, void* recv, size_t bytes);
+
+#define OMMHIP_COMM_ID_HEX_LEN 257      /* 128 bytes as hex + NUL */
+
+/* rank 0: a fresh ncclUniqueId as a hex string (hex must hold OMMHIP_COMM_ID_HEX_LEN chars) */
+int ommhip_comm_unique_id(char* hex);
+/* collective over all ranks (blocks until every rank has called it); the current HIP device is the rank's GPU */
+int ommhip_comm_create_rccl(const char* id_hex, int rank, int size, ommhip_comm** comm);
+int ommhip_comm_create_callback(ommhip_host_all_gather_fn fn, void* user, int rank, int size, ommhip_comm** comm);
+int ommhip_comm_destroy(ommhip_comm* comm);
+int ommhip_comm_rank(const ommhip_comm* comm);
+int ommhip_comm_size(const ommhip_comm* comm);
+const char* ommhip_comm_transport(const ommhip_comm* comm);      /* "rccl" or "callback" */
+
+/* In-place all-gather of device memory: buffer_d holds size * bytes_per_rank bytes, this rank's part already sits at
+ * offset rank * bytes_per_rank.  (Positions after the integration step, forces/velocities when a State is downloaded.) */
+int ommhip_comm_all_gather(ommhip_comm* comm, void* buffer_d, size_t bytes_per_rank, void* stream);
+/* All-to-all of device memory: chunk p (bytes_per_pair bytes) of send_d goes to rank p and arrives as chunk `rank` of its
+ * recv_d.  (The two transposes of the slab-decomposed 3-D FFT.) */
+int ommhip_comm_all_to_all(ommhip_comm* comm, const void* send_d, void* recv_d, size_t bytes_per_pair, void* stream);
+/* Ring neighbours (periodic slabs): send bytes_down to rank-1 and bytes_up to rank+1; receive bytes_down from rank+1
+ * (what it sent down) into recv_from_up_d and bytes_up from rank-1 into recv_from_down_d.  (Halo planes of the PME
+ * potential.)  With size == 1 the data is copied locally. */
+int ommhip_comm_ring_exchange(ommhip_comm* comm, const void* send_down_d, void* recv_from_up_d, size_t bytes_down,
+                              const void* send_up_d, void* recv_from_down_d, size_t bytes_up, void* stream);
+/* Host all-gather of small records (energies, momenta, flags): blocking; every rank then reduces the size records in the
+ * same order, which makes sums bit-identical on all ranks. */
+int ommhip_comm_all_gather_host(ommhip_comm* comm, const void* send, void* recv, size_t bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -90,6 +90,11 @@ int ommhip_set_slot_params(const double* charge_d, const double* sigma_d, const 
 int ommhip_forces_to_double(const long long* force_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, double* out_d, void* stream);
 /* force[slot] += in[3*atom..] (double) */
 int ommhip_add_forces_from_double(const double* in_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, long long* force_d, void* stream);
+/* pos_slot[s] = pos[atom_of_slot[s]] for every valid slot (dst double4[padded_atoms]); used when every rank holds all
+ * positions (after setPositions / a re-sort) to fill the all-gather buffer.  The same for any double4 array. */
+int ommhip_pack_slots(const void* src_atom_order_d, const int* atom_of_slot_d, int slot0, int slot1, void* dst_slot_order_d, void* stream);
+/* dst[atom_of_slot[s]] = src[s] for the valid slots of [slot0, slot1) */
+int ommhip_unpack_slots(const void* src_slot_order_d, const int* atom_of_slot_d, int slot0, int slot1, void* dst_atom_order_d, void* stream);
 /* zero two device buffers (sizes multiples of 16 bytes; either may be empty) in one launch */
 int ommhip_clear2(void* a_d, size_t a_bytes, void* b_d, size_t b_bytes, void* stream);
 /* result[0] = sum of buffer[0..n), then buffer is zeroed; result_d is a device double */
@@ -148,6 +153,18 @@ typedef struct ommhip_neighbor_list {
      * these only, so its separations carry the rounding of a sub-nanometre number (~6e-8 nm) whatever the box size;
      * absolute float coordinates (ulp 1.9e-6 nm at 20 nm) only decide list membership inside the padded list cutoff. */
     void* posq_rel;            /* float4[padded_atoms], required by ommhip_nb_direct / ommhip_pairs_with_fft */
+    /* Domain decomposition (one box on several GPUs).  dd_mode = 1: this rank owns the i-blocks
+     * [first_block, first_block + owned_blocks) -- a slab of the box, since slots are sorted by slab first -- and computes
+     * the forces ON ITS OWN ATOMS ONLY: the list of an owned block X holds every partner block Y >= X plus the foreign
+     * blocks below first_block, the pair kernel drops the force on j atoms outside the owned slot range, and the pair of
+     * two atoms owned by different ranks is therefore evaluated once on each side (no force exchange between ranks;
+     * its energy is counted half on each side).  Positions of all atoms are replicated: pos_slot (double4[padded_atoms],
+     * slot order -- the buffer the ranks all-gather after every integration step) replaces the atom-ordered positions as
+     * the source of ommhip_nl_prepare, which also copies the positions of foreign slots into pos_scatter (atom order,
+     * double4[num_atoms]) for the kernels that address atoms by index (exclusion correction, bonded terms). */
+    int dd_mode;
+    const void* pos_slot;
+    void* pos_scatter;
 } ommhip_neighbor_list;
 
 typedef struct ommhip_nonbonded_params {
@@ -210,6 +227,17 @@ typedef struct ommhip_pme {
     const double* charge;      /* [num_atoms] */
     int excl_periodic;         /* NonbondedForce::getExceptionsUsePeriodicBoundaryConditions() */
     int phases;                /* OMMHIP_PME_ALL (0), or the two halves separately so that they can go to different streams */
+    /* Slab decomposition (ommhip_pme_reciprocal_dd; all zero = single GPU).  Rank r of dd_ranks owns the x planes
+     * [r nx/R, (r+1) nx/R) and, for the x transform, the y rows [r ny/R, (r+1) ny/R); nx and ny are multiples of R.
+     *   grid_real     float[(nx/R + 2 dd_halo + 4)][ny][nz]: dd_halo planes below the slab, the slab, dd_halo + 4 planes above
+     *   grid_complex  float2[nx/R][ny][nz/2+1] in transpose-ready order [dest rank][x local][y local][kz] (send buffer)
+     *   grid_complex2 float2[nx][ny/R][nz/2+1] (receive buffer of the transpose; x transform + convolution in place)
+     *   eterm         float[nx][ny/R][nz/2+1]  (the rank's rows of the influence function)
+     * dd_error (device int, zero-initialised): set to 1 when an owned atom's stencil leaves the planes this rank holds. */
+    int dd_ranks, dd_rank, dd_halo;
+    void* grid_complex2;
+    void* comm;                /* ommhip_comm* (openmm_hip_comm.h) */
+    int* dd_error;
 } ommhip_pme;
 enum { OMMHIP_PME_ALL = 0, OMMHIP_PME_SPREAD_ONLY = 1, OMMHIP_PME_AFTER_SPREAD = 2, OMMHIP_PME_INTERPOLATE_ONLY = 3 };
 
@@ -218,6 +246,13 @@ int ommhip_pme_build_eterm(const ommhip_pme* pme, void* stream);
 /* spread -> 3-D FFT -> convolution (+energy) -> inverse FFT -> interpolate; adds forces (slot order) */
 int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, int padded_atoms, long long* force_d,
                           double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
+/* The same on one rank of a slab-decomposed run (pme->dd_ranks > 1): every rank spreads the atoms (its own or not -- positions
+ * are replicated) whose stencil touches its planes, clipped to them; plane transforms; all-to-all; x transform with the
+ * convolution on its y rows; all-to-all back; plane transforms; exchange of dd_halo (+4) potential planes with the two
+ * neighbouring slabs; interpolation for the slots [own_slot0, own_slot1).  Energy: this rank's share.
+ * phases as above (the collectives belong to OMMHIP_PME_AFTER_SPREAD). */
+int ommhip_pme_reciprocal_dd(const ommhip_pme* pme, const void* posq_d, int padded_atoms, int own_slot0, int own_slot1, const void* block_center_d,
+                             const void* block_half_d, long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
 /* test hook: forward (grid_real -> grid_complex) or backward (grid_complex -> grid_real) unnormalised 3-D transform */
 int ommhip_fft3d_r2c_c2r(const ommhip_pme* pme, int forward, void* stream);
 
@@ -328,6 +363,11 @@ typedef struct ommhip_step_units {
     int remove_cm;
     double inv_total_mass;
     double* cm_scratch;        /* 4 + 4*ceil(num_units/128) doubles, zero-initialised once; or NULL */
+    /* Domain decomposition: the units are those this rank owns.  New positions are also written to pos_slot (double4,
+     * slot order: the all-gather buffer); the rank's momentum goes to pos_slot[trailer_slot + rank * slots_per_rank]
+     * instead of cm_scratch[0..2], and the CM velocity subtracted is the sum of the `ranks` trailers. */
+    void* pos_slot;
+    int ranks, rank, slots_per_rank, trailer_slot;
 } ommhip_step_units;
 enum { OMMHIP_INTEGRATOR_VERLET = 0, OMMHIP_INTEGRATOR_LANGEVIN = 1, OMMHIP_INTEGRATOR_LANGEVIN_MIDDLE = 2 };
 int ommhip_integrate_fused(int integrator, const ommhip_integrator_state* s, const ommhip_step_units* u, void* stream);

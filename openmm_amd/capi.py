@@ -27,6 +27,7 @@ class NeighborList(C.Structure):
         ("row_j", C.c_void_p), ("row_mask", C.c_void_p), ("excl_slot_start", C.c_void_p), ("excl_slots", C.c_void_p),
         ("cell_start", C.c_void_p), ("cell_blocks", C.c_void_p), ("cell_boxes", C.c_void_p), ("cell_meta", C.c_void_p), ("max_cells", C.c_int), ("cell_min_blocks", C.c_int),
         ("first_block", C.c_int), ("owned_blocks", C.c_int), ("posq_rel", C.c_void_p),
+        ("dd_mode", C.c_int), ("pos_slot", C.c_void_p), ("pos_scatter", C.c_void_p),
     ]
 
 
@@ -46,6 +47,7 @@ class Pme(C.Structure):
         ("grid_precleared", C.c_int), ("fft_mode", C.c_int),
         ("excl_start", C.c_void_p), ("excl_atoms", C.c_void_p), ("atom_of_slot", C.c_void_p), ("pos", C.c_void_p),
         ("charge", C.c_void_p), ("excl_periodic", C.c_int), ("phases", C.c_int),
+        ("dd_ranks", C.c_int), ("dd_rank", C.c_int), ("dd_halo", C.c_int), ("grid_complex2", C.c_void_p), ("comm", C.c_void_p), ("dd_error", C.c_void_p),
     ]
 
 

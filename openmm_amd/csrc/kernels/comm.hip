@@ -1,0 +1,263 @@
+// Collective layer of the multi-GPU path (include/openmm_hip_comm.h): RCCL over xGMI, and a host-staged callback
+// transport used by tests.  One process per GPU; every call is made by all ranks in the same order.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1 -- PyTorch-ROCm ships the same SONAME, so inside a torch process the
+// copy that is already mapped is the one that is used) and all traffic is enqueued on the caller's stream:
+//   all-gather   -> ncclAllGather (in place)
+//   all-to-all   -> ncclGroupStart, size x (ncclSend, ncclRecv), ncclGroupEnd: every peer pair has an xGMI link of its own,
+//                   so the size-1 transfers of a rank proceed concurrently
+//   ring         -> one group with two sends and two receives (two links)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../../include/openmm_hip_comm.h"
+
+#ifndef OMMHIP_EMU
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#endif
+
+struct ommhip_comm {
+    int rank = 0, size = 1;
+    bool rccl = false;
+    // callback transport
+    ommhip_host_all_gather_fn fn = nullptr;
+    void* user = nullptr;
+    std::vector<char> hostSend, hostRecv;
+    // rccl transport
+    void* nccl = nullptr;
+    void* smallDev = nullptr;          // staging for ommhip_comm_all_gather_host
+    size_t smallBytes = 0;
+};
+
+namespace {
+
+#ifndef OMMHIP_EMU
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+    decltype(&ncclCommInitRank) commInitRank = nullptr;
+    decltype(&ncclCommDestroy) commDestroy = nullptr;
+    decltype(&ncclAllGather) allGather = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGroupStart) groupStart = nullptr;
+    decltype(&ncclGroupEnd) groupEnd = nullptr;
+    bool ok = false;
+};
+
+RcclApi& rccl_api() {
+    static RcclApi api;
+    if (api.handle != nullptr || api.ok) return api;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (api.handle != nullptr) break;
+    }
+    if (api.handle == nullptr) { fprintf(stderr, "HIP platform: cannot open librccl: %s\n", dlerror()); return api; }
+#define OMM_BIND(field, sym) api.field = (decltype(api.field)) dlsym(api.handle, sym)
+    OMM_BIND(getUniqueId, "ncclGetUniqueId"); OMM_BIND(commInitRank, "ncclCommInitRank"); OMM_BIND(commDestroy, "ncclCommDestroy");
+    OMM_BIND(allGather, "ncclAllGather"); OMM_BIND(send, "ncclSend"); OMM_BIND(recv, "ncclRecv");
+    OMM_BIND(groupStart, "ncclGroupStart"); OMM_BIND(groupEnd, "ncclGroupEnd");
+#undef OMM_BIND
+    api.ok = api.getUniqueId && api.commInitRank && api.commDestroy && api.allGather && api.send && api.recv && api.groupStart && api.groupEnd;
+    if (!api.ok) fprintf(stderr, "HIP platform: librccl lacks a required symbol\n");
+    return api;
+}
+inline int nccl_rc(ncclResult_t r) { return r == ncclSuccess ? 0 : 1000 + (int) r; }
+#define NCCL_TRY(call) do { int rc__ = nccl_rc(call); if (rc__ != 0) return rc__; } while (0)
+#endif
+
+// host staging of the callback transport: device -> pinned-less host vector (blocking), callback, host -> device
+int stage_down(ommhip_comm* c, const void* src_d, size_t bytes, size_t offset, hipStream_t st) {
+    if (c->hostSend.size() < offset + bytes) c->hostSend.resize(offset + bytes);
+    hipError_t e = hipMemcpyAsync(c->hostSend.data() + offset, src_d, bytes, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return (int) e;
+    return (int) hipStreamSynchronize(st);
+}
+int stage_up(void* dst_d, const char* src, size_t bytes, hipStream_t st) {
+    hipError_t e = hipMemcpyAsync(dst_d, src, bytes, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return (int) e;
+    return (int) hipStreamSynchronize(st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ommhip_comm_unique_id(char* hex) {
+#ifdef OMMHIP_EMU
+    (void) hex;
+    return 1;
+#else
+    RcclApi& api = rccl_api();
+    if (!api.ok) return 1;
+    ncclUniqueId id;
+    NCCL_TRY(api.getUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    const unsigned char* b = (const unsigned char*) &id;
+    for (int i = 0; i < 128; i++) snprintf(hex + 2 * i, 3, "%02x", b[i]);
+    hex[256] = 0;
+    return 0;
+#endif
+}
+
+int ommhip_comm_create_rccl(const char* id_hex, int rank, int size, ommhip_comm** comm) {
+#ifdef OMMHIP_EMU
+    (void) id_hex; (void) rank; (void) size; (void) comm;
+    return 1;
+#else
+    RcclApi& api = rccl_api();
+    if (!api.ok || id_hex == nullptr || strlen(id_hex) != 256 || rank < 0 || rank >= size) return 1;
+    ncclUniqueId id;
+    unsigned char* b = (unsigned char*) &id;
+    for (int i = 0; i < 128; i++) {
+        unsigned v = 0;
+        if (sscanf(id_hex + 2 * i, "%2x", &v) != 1) return 1;
+        b[i] = (unsigned char) v;
+    }
+    ncclComm_t nc;
+    NCCL_TRY(api.commInitRank(&nc, size, id, rank));
+    ommhip_comm* c = new ommhip_comm();
+    c->rank = rank; c->size = size; c->rccl = true; c->nccl = (void*) nc;
+    *comm = c;
+    return 0;
+#endif
+}
+
+int ommhip_comm_create_callback(ommhip_host_all_gather_fn fn, void* user, int rank, int size, ommhip_comm** comm) {
+    if (fn == nullptr || rank < 0 || rank >= size) return 1;
+    ommhip_comm* c = new ommhip_comm();
+    c->rank = rank; c->size = size; c->rccl = false; c->fn = fn; c->user = user;
+    *comm = c;
+    return 0;
+}
+
+int ommhip_comm_destroy(ommhip_comm* comm) {
+    if (comm == nullptr) return 0;
+#ifndef OMMHIP_EMU
+    if (comm->rccl && comm->nccl != nullptr) rccl_api().commDestroy((ncclComm_t) comm->nccl);
+#endif
+    if (comm->smallDev != nullptr) hipFree(comm->smallDev);
+    delete comm;
+    return 0;
+}
+
+int ommhip_comm_rank(const ommhip_comm* comm) { return comm->rank; }
+int ommhip_comm_size(const ommhip_comm* comm) { return comm->size; }
+const char* ommhip_comm_transport(const ommhip_comm* comm) { return comm->rccl ? "rccl" : "callback"; }
+
+int ommhip_comm_all_gather(ommhip_comm* c, void* buffer_d, size_t bytes, void* stream) {
+    if (c->size == 1 || bytes == 0) return 0;
+    hipStream_t st = (hipStream_t) stream;
+    char* buf = (char*) buffer_d;
+#ifndef OMMHIP_EMU
+    if (c->rccl) {
+        NCCL_TRY(rccl_api().allGather(buf + (size_t) c->rank * bytes, buf, bytes, ncclChar, (ncclComm_t) c->nccl, st));
+        return 0;
+    }
+#endif
+    int rc = stage_down(c, buf + (size_t) c->rank * bytes, bytes, 0, st);
+    if (rc != 0) return rc;
+    c->hostRecv.resize((size_t) c->size * bytes);
+    if (c->fn(c->user, c->hostSend.data(), c->hostRecv.data(), bytes) != 0) return 1;
+    return stage_up(buf, c->hostRecv.data(), (size_t) c->size * bytes, st);
+}
+
+int ommhip_comm_all_to_all(ommhip_comm* c, const void* send_d, void* recv_d, size_t bytes, void* stream) {
+    hipStream_t st = (hipStream_t) stream;
+    if (bytes == 0) return 0;
+    if (c->size == 1) return (int) hipMemcpyAsync(recv_d, send_d, bytes, hipMemcpyDeviceToDevice, st);
+    const char* s = (const char*) send_d;
+    char* r = (char*) recv_d;
+#ifndef OMMHIP_EMU
+    if (c->rccl) {
+        RcclApi& api = rccl_api();
+        NCCL_TRY(api.groupStart());
+        for (int p = 0; p < c->size; p++) {
+            NCCL_TRY(api.send(s + (size_t) p * bytes, bytes, ncclChar, p, (ncclComm_t) c->nccl, st));
+            NCCL_TRY(api.recv(r + (size_t) p * bytes, bytes, ncclChar, p, (ncclComm_t) c->nccl, st));
+        }
+        NCCL_TRY(api.groupEnd());
+        return 0;
+    }
+#endif
+    // host transport: gather everybody's whole send buffer, keep the chunk addressed to this rank
+    const size_t all = (size_t) c->size * bytes;
+    int rc = stage_down(c, s, all, 0, st);
+    if (rc != 0) return rc;
+    c->hostRecv.resize((size_t) c->size * all);
+    if (c->fn(c->user, c->hostSend.data(), c->hostRecv.data(), all) != 0) return 1;
+    std::vector<char> mine(all);
+    for (int p = 0; p < c->size; p++) memcpy(mine.data() + (size_t) p * bytes, c->hostRecv.data() + (size_t) p * all + (size_t) c->rank * bytes, bytes);
+    return stage_up(r, mine.data(), all, st);
+}
+
+int ommhip_comm_ring_exchange(ommhip_comm* c, const void* send_down_d, void* recv_from_up_d, size_t bytes_down,
+                              const void* send_up_d, void* recv_from_down_d, size_t bytes_up, void* stream) {
+    hipStream_t st = (hipStream_t) stream;
+    if (c->size == 1) {
+        // the only slab is its own neighbour on both sides
+        if (bytes_down > 0) { hipError_t e = hipMemcpyAsync(recv_from_up_d, send_down_d, bytes_down, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int) e; }
+        if (bytes_up > 0) { hipError_t e = hipMemcpyAsync(recv_from_down_d, send_up_d, bytes_up, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int) e; }
+        return 0;
+    }
+    const int down = (c->rank + c->size - 1) % c->size, up = (c->rank + 1) % c->size;
+#ifndef OMMHIP_EMU
+    if (c->rccl) {
+        RcclApi& api = rccl_api();
+        NCCL_TRY(api.groupStart());
+        if (bytes_down > 0) {
+            NCCL_TRY(api.send(send_down_d, bytes_down, ncclChar, down, (ncclComm_t) c->nccl, st));
+            NCCL_TRY(api.recv(recv_from_up_d, bytes_down, ncclChar, up, (ncclComm_t) c->nccl, st));
+        }
+        if (bytes_up > 0) {
+            NCCL_TRY(api.send(send_up_d, bytes_up, ncclChar, up, (ncclComm_t) c->nccl, st));
+            NCCL_TRY(api.recv(recv_from_down_d, bytes_up, ncclChar, down, (ncclComm_t) c->nccl, st));
+        }
+        NCCL_TRY(api.groupEnd());
+        return 0;
+    }
+#endif
+    const size_t rec = bytes_down + bytes_up;
+    int rc = 0;
+    if (bytes_down > 0) rc = stage_down(c, send_down_d, bytes_down, 0, st);
+    if (rc == 0 && bytes_up > 0) rc = stage_down(c, send_up_d, bytes_up, bytes_down, st);
+    if (rc != 0) return rc;
+    if (c->hostSend.size() < rec) c->hostSend.resize(rec);
+    c->hostRecv.resize((size_t) c->size * rec);
+    if (c->fn(c->user, c->hostSend.data(), c->hostRecv.data(), rec) != 0) return 1;
+    if (bytes_down > 0) rc = stage_up(recv_from_up_d, c->hostRecv.data() + (size_t) up * rec, bytes_down, st);
+    if (rc == 0 && bytes_up > 0) rc = stage_up(recv_from_down_d, c->hostRecv.data() + (size_t) down * rec + bytes_down, bytes_up, st);
+    return rc;
+}
+
+int ommhip_comm_all_gather_host(ommhip_comm* c, const void* send, void* recv, size_t bytes, void* stream) {
+    if (c->size == 1) { memcpy(recv, send, bytes); return 0; }
+#ifndef OMMHIP_EMU
+    if (c->rccl) {
+        hipStream_t st = (hipStream_t) stream;
+        const size_t all = (size_t) c->size * bytes;
+        if (c->smallBytes < all) {
+            if (c->smallDev != nullptr) hipFree(c->smallDev);
+            hipError_t e = hipMalloc(&c->smallDev, all);
+            if (e != hipSuccess) return (int) e;
+            c->smallBytes = all;
+        }
+        char* dev = (char*) c->smallDev;
+        hipError_t e = hipMemcpyAsync(dev + (size_t) c->rank * bytes, send, bytes, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return (int) e;
+        NCCL_TRY(rccl_api().allGather(dev + (size_t) c->rank * bytes, dev, bytes, ncclChar, (ncclComm_t) c->nccl, st));
+        e = hipMemcpyAsync(recv, dev, all, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return (int) e;
+        return (int) hipStreamSynchronize(st);
+    }
+#endif
+    (void) stream;
+    return c->fn(c->user, send, recv, bytes) != 0 ? 1 : 0;
+}
+
+}

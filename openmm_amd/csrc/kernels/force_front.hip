@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void force_front(FrontArgs f) {
     const int b = blockIdx.x;
     // heavy, rare work first in the grid so that it starts first
     if (b < f.nlBlocks) nl_find_body<PBC>(f.nl, f.nl.firstBlock + b, f.nlBlocks, sh.nl);
-    else if (b < f.nlBlocks + f.spreadBlocks) pme_spread_body(f.pme, b - f.nlBlocks, sh.spread);
+    else if (b < f.nlBlocks + f.spreadBlocks) pme_spread_body<false>(f.pme, b - f.nlBlocks, sh.spread);
     else terms_body(f.terms, b - f.nlBlocks - f.spreadBlocks, sh.termPartial);
 }
 

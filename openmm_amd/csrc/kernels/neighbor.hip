@@ -33,6 +33,9 @@ namespace {
 struct NlArgs {
     int numAtoms, paddedAtoms, numBlocks, maxChunks;
     int firstBlock, ownedBlocks;      // the list is built for the i-blocks [firstBlock, firstBlock + ownedBlocks)
+    int ddMode;                       // domain decomposition: partners are Y >= X plus the foreign blocks below firstBlock
+    const double4* posSlot;           // DD: positions in slot order (the all-gathered buffer), replaces pos[atom] in nl_prepare
+    double4* posScatter;              // DD: atom-ordered positions, refreshed for foreign slots by nl_prepare
     int pbc;                 // 0 none, 1 orthorhombic, 2 triclinic
     float listCutoff2;       // (cutoff + padding)^2, +inf for NoCutoff
     float maxDisp2;          // (padding/2)^2
@@ -231,6 +234,12 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
     // atom (lane & 31) of X in every lane; broadcast later with v_readlane
     const float4 px = a.posq[X * OMM_TILE + (lane & 31)];
     if (t < OMM_TILE) a.posqRef[X * OMM_TILE + t] = px;          // reference positions of the displacement check
+    if (a.ownedBlocks < a.numBlocks) {
+        // A ranked list also holds j atoms of blocks this launch has no workgroup for, and the displacement check looks at
+        // every slot: the workgroups share the snapshot of all of them.
+        for (int s = (X - a.firstBlock) * NL_THREADS + t; s < a.paddedAtoms; s += numWorkgroups * NL_THREADS)
+            if (s < a.firstBlock * OMM_TILE || s >= (a.firstBlock + a.ownedBlocks) * OMM_TILE) a.posqRef[s] = a.posq[s];
+    }
     const bool iValid = lane < OMM_TILE && a.atomOfSlot[X * OMM_TILE + lane] >= 0;
     const unsigned iValidMask = (unsigned) __ballot(iValid);
     const float4 cX = a.blockCenter[X], hX = a.blockHalf[X];
@@ -340,7 +349,7 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
                 dx = fmaxf(0.f, fabsf(dx) - hX.x - hY.x);
                 dy = fmaxf(0.f, fabsf(dy) - hX.y - hY.y);
                 dz = fmaxf(0.f, fabsf(dz) - hX.z - hY.z);
-                if (Y >= X && !(dx * dx + dy * dy + dz * dz >= R2)) {
+                if ((Y >= X || (a.ddMode && Y < a.firstBlock)) && !(dx * dx + dy * dy + dz * dz >= R2)) {
                     const int pos = atomicAdd(&sCandCount, 1);
                     if (pos < NL_CAND) candY[pos] = Y; else sCandOverflow = 1;
                 }
@@ -350,7 +359,7 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
         const int numBig = __float_as_int(a.cellMeta[3]);
         for (int i = t; i < numBig; i += NL_THREADS) {
             const int Y = a.cellBlocks[a.numBlocks + i];
-            if (Y >= X && blockTest(Y)) {
+            if ((Y >= X || (a.ddMode && Y < a.firstBlock)) && blockTest(Y)) {
                 const int pos = atomicAdd(&sCandCount, 1);
                 if (pos < NL_CAND) candY[pos] = Y; else sCandOverflow = 1;
             }
@@ -359,8 +368,12 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
         if (sCandOverflow == 0) cellDone = true;
         else { __syncthreads(); if (t == 0) { sCandCount = 0; sCandOverflow = 0; } __syncthreads(); }   // absurdly fat block: scan everything
     }
-    for (int window = X; window < a.numBlocks; window += NL_CAND) {
-        const int windowEnd = min(a.numBlocks, window + NL_CAND);
+    // candidate ranges: [X, numBlocks) and, on a decomposed run, the foreign blocks [0, firstBlock) as well (their owners
+    // evaluate the same pairs for their own atoms)
+    for (int range = 0; range < (a.ddMode ? 2 : 1); range++) {
+    const int rangeBegin = range == 0 ? X : 0, rangeEnd = range == 0 ? a.numBlocks : a.firstBlock;
+    for (int window = rangeBegin; window < rangeEnd; window += NL_CAND) {
+        const int windowEnd = min(rangeEnd, window + NL_CAND);
         // ---- phase 1: block-level test
         if (!cellDone) {
             for (int yb = window + wave * 64; yb < windowEnd; yb += NL_THREADS) {
@@ -472,6 +485,8 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
         __syncthreads();
         if (cellDone) break;
     }
+    if (cellDone) break;
+    }
     flush(true);
 
     // Last workgroup out clears the rebuild request.
@@ -521,7 +536,12 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
     float4 p = posqOut[sl];
     double xw = 0.0, yw = 0.0, zw = 0.0;               // the position in double: the float posq is its rounding
     if (valid) {
-        const double4 x = pos[atom];
+        double4 x;
+        if (a.posSlot != nullptr) {
+            x = a.posSlot[sl];
+            if (a.posScatter != nullptr && (sl < a.firstBlock * OMM_TILE || sl >= (a.firstBlock + a.ownedBlocks) * OMM_TILE)) a.posScatter[atom] = x;
+        }
+        else x = pos[atom];
         const int4 w = wrap[atom];
         xw = x.x - (w.x * boxd.ax + w.y * boxd.bx + w.z * boxd.cx);
         yw = x.y - (w.y * boxd.by + w.z * boxd.cy);
@@ -564,11 +584,15 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
     }
     // every lane of the block holds the same bounds, hence the same centre
     const float4 center = make_float4(p0.x + 0.5f * (minx + maxx), p0.y + 0.5f * (miny + maxy), p0.z + 0.5f * (minz + maxz), 0.f);
+    // A block without atoms (padding at the end of a rank's slot range; padding slots are always trailing, so the first
+    // slot decides) gets a hugely negative half extent: no block test against it can pass, from either side.
+    const bool emptyBlock = __shfl((int) valid, 0, 32) == 0;
     if (inRange && (s & 31) == 0) {
         const int blk = s >> 5;
         a.blockCenter[blk] = center;
         // .w = 1: the block's atoms are image-coherent (written above); the pair kernel may then use one image per j atom
-        a.blockHalf[blk] = make_float4(0.5f * (maxx - minx), 0.5f * (maxy - miny), 0.5f * (maxz - minz), a.pbc == 1 ? 1.f : 0.f);
+        a.blockHalf[blk] = emptyBlock ? make_float4(-1e30f, -1e30f, -1e30f, 0.f)
+                                      : make_float4(0.5f * (maxx - minx), 0.5f * (maxy - miny), 0.5f * (maxz - minz), a.pbc == 1 ? 1.f : 0.f);
     }
     // Block-relative coordinates (double position minus the float centre, rounded once): what the pair kernel computes
     // with.  Their error is the rounding of a number below ~1 nm (6e-8 nm), independent of where in the box the block is.
@@ -582,6 +606,8 @@ NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
     a.numAtoms = nl->num_atoms; a.paddedAtoms = nl->padded_atoms; a.numBlocks = nl->padded_atoms / OMM_TILE; a.maxChunks = nl->max_chunks;
     a.firstBlock = 0; a.ownedBlocks = a.numBlocks;
     if (nl->owned_blocks > 0 && nl->first_block >= 0 && nl->first_block + nl->owned_blocks <= a.numBlocks) { a.firstBlock = nl->first_block; a.ownedBlocks = nl->owned_blocks; }
+    a.ddMode = nl->dd_mode != 0 && a.ownedBlocks < a.numBlocks ? 1 : 0;
+    a.posSlot = (const double4*) nl->pos_slot; a.posScatter = (double4*) nl->pos_scatter;
     a.pbc = nl->pbc;
     double rl = nl->cutoff + nl->padding;
     a.listCutoff2 = nl->cutoff > 0 ? (float) (rl * rl) : INFINITY;

@@ -33,6 +33,7 @@ namespace {
 struct NbArgs {
     int paddedAtoms, maxChunks, energySlots, debugFlags;
     int xcdAware;             // XCD-aware placement of the work units (ChunkSchedule)
+    int ownSlot0, ownSlot1;   // domain decomposition: forces on j atoms outside [ownSlot0, ownSlot1) are dropped (their owner evaluates the pair too)
     float cutoff2, alpha, krf, crf, switchDist, invSwitchWidth;
     Box box;
     const float4* posq;       // block-relative coordinates + charge (ommhip_neighbor_list::posq_rel): position minus blockCenter of its block
@@ -261,7 +262,7 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
         float fix[OMM_TILE], fiy[OMM_TILE], fiz[OMM_TILE];
 #pragma unroll
         for (int k = 0; k < OMM_TILE; k++) { fix[k] = 0.f; fiy[k] = 0.f; fiz[k] = 0.f; }
-        float energy = 0.f;
+        float energy = 0.f, eRowStart = 0.f;
         v2f energy2 = bc2(0.f);
         // All coordinates are relative to the centre of the atom's own block (posq_rel); a j atom is moved into the frame
         // of X by adding the offset between the two block centres.  Nothing of the size of the box enters the pair
@@ -341,8 +342,15 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
                         pair_ixn<METHOD, PBC, ENERGY, false>(a, ip[k], ise[k], pj, sej, qjK, true, fix[k], fiy[k], fiz[k], fjx, fjy, fjz, energy);
                 }
             }
-            if (!(a.debugFlags & 1)) add_force(a.force, a.paddedAtoms, j, fjx, fjy, fjz);
+            const bool jOwned = j >= a.ownSlot0 && j < a.ownSlot1;
+            if (!(a.debugFlags & 1)) { if (jOwned) add_force(a.force, a.paddedAtoms, j, fjx, fjy, fjz); }
             else if (fjx == 12345.f) a.force[0] = 1;           // profiling knob: keep the arithmetic alive without the atomics
+            if (ENERGY) {
+                // a pair with a foreign j atom is also evaluated by j's owner: half of its energy belongs to this side
+                const float eNow = energy + energy2.x + energy2.y;
+                if (!jOwned) { energy = eRowStart + 0.5f * (eNow - eRowStart); energy2 = bc2(0.f); }
+                eRowStart = energy + energy2.x + energy2.y;
+            }
         }
         const float tx = transpose_reduce32(fix, lane);
         const float ty = transpose_reduce32(fiy, lane);
@@ -392,6 +400,8 @@ static NbArgs make_nb_args(const ommhip_neighbor_list* nl, const ommhip_nonbonde
     a.debugFlags = debugFlags;
     static const bool xcdAware = getenv("OPENMM_HIP_NO_XCD_PLACEMENT") == nullptr;          // A/B knob
     a.xcdAware = xcdAware ? 1 : 0;
+    a.ownSlot0 = 0; a.ownSlot1 = nl->padded_atoms;
+    if (nl->dd_mode != 0 && nl->owned_blocks > 0) { a.ownSlot0 = nl->first_block * OMM_TILE; a.ownSlot1 = (nl->first_block + nl->owned_blocks) * OMM_TILE; }
     a.cutoff2 = nl->cutoff > 0 ? (float) (nl->cutoff * nl->cutoff) : INFINITY;
     a.alpha = (float) p->ewald_alpha; a.krf = (float) p->krf; a.crf = (float) p->crf;
     a.switchDist = (float) p->switch_distance;

@@ -15,6 +15,7 @@
 // influence function carries all constants.
 #include "common.h"
 #include "../../../include/openmm_hip_kernels.h"
+#include "../../../include/openmm_hip_comm.h"
 #include <cstdlib>
 
 using namespace omm;
@@ -43,7 +44,28 @@ struct PmeArgs {
     double alpha;
     int exclPeriodic, includeEnergy, energySlots;
     double* energyBuffer;
+    // Slab decomposition (DD kernels only): this rank holds the x planes [planeLo - haloLo, planeLo + planeCount + haloHi) of
+    // the real grid as local planes 0 .. gridPlanes-1; charges are spread onto the planeCount own planes only.
+    int planeLo, planeCount, haloLo, gridPlanes;
+    int ownSlot0, ownSlot1;
+    int* ddError;
+    const float4* blockCenter; const float4* blockHalf;
 };
+
+// local plane of global x plane gx for spreading (own planes only; -1 = not mine) and for interpolation (own + halo planes)
+template <bool DD> __device__ __forceinline__ int spread_plane(const PmeArgs& a, int gx) {
+    if (!DD) return gx;
+    int d = gx - a.planeLo;
+    if (d < 0) d += a.nx;
+    return d < a.planeCount ? d + a.haloLo : -1;
+}
+template <bool DD> __device__ __forceinline__ int gather_plane(const PmeArgs& a, int gx) {
+    if (!DD) return gx;
+    int d = gx - (a.planeLo - a.haloLo);
+    if (d < 0) d += a.nx;
+    if (d >= a.nx) d -= a.nx;
+    return d < a.gridPlanes ? d : -1;
+}
 
 // Grid index and B-spline weights of one coordinate.  ReferencePME.cpp:259-264 and :274-327 (order 5).
 __device__ __forceinline__ void bspline(float t, int n, int& index, float (&theta)[PME_ORDER], float (&dtheta)[PME_ORDER]) {
@@ -131,6 +153,7 @@ __device__ __forceinline__ int wrap_rel(int d, int n) {      // d in (-n, n) -> 
 // LDS of one spread workgroup.  The brick accumulates in 32-bit fixed point: LDS integer atomics run ~9x faster than LDS
 // float atomics on this chip (tools/microbench/lds_atomics.hip: 2.9 vs 0.33 lane-ops/clk/CU), and the sum is order independent.
 struct SpreadShared {
+    int touches;
     int brick[BRICK_WORDS];
     float brickScale;
     float th[SPREAD_ATOMS][3][PME_ORDER];
@@ -140,7 +163,20 @@ struct SpreadShared {
     int minRel[3];
 };
 
+template <bool DD>
 __device__ __forceinline__ void pme_spread_body(const PmeArgs& a, const int block, SpreadShared& sh) {
+    if (DD && a.recip.r10 == 0.f && a.recip.r20 == 0.f) {
+        // rectangular box: blocks whose bounding box (+ stencil) lies clear of this rank's planes leave at once
+        const float cx = a.blockCenter[block].x, hx = a.blockHalf[block].x;
+        if (hx < 0.f) return;                                                     // empty block
+        const float lo = (cx - hx) * a.recip.r00 * a.nx - 1.f, hi = (cx + hx) * a.recip.r00 * a.nx + (float) PME_ORDER;
+        if (hi - lo < (float) a.nx) {
+            // distance (in planes, periodic) from the block's plane interval [lo, hi] to the own interval
+            const float ownLo = (float) a.planeLo, ownHi = (float) (a.planeLo + a.planeCount);
+            float shift = floorf((0.5f * (lo + hi) - 0.5f * (ownLo + ownHi)) / (float) a.nx + 0.5f) * (float) a.nx;
+            if (lo - shift > ownHi || hi - shift < ownLo) return;
+        }
+    }
     int* const brick = sh.brick;
     float& brickScale = sh.brickScale;
     float (&th)[SPREAD_ATOMS][3][PME_ORDER] = sh.th;
@@ -151,6 +187,7 @@ __device__ __forceinline__ void pme_spread_body(const PmeArgs& a, const int bloc
     const int t = threadIdx.x;
     const int slot0 = block * SPREAD_ATOMS;
     if (t < 3) { minRel[t] = 1 << 30; ref[t] = -1; }
+    if (t == 0) sh.touches = DD ? 0 : 1;
     for (int i = t; i < BRICK_WORDS; i += 256) brick[i] = 0;
     // splines: thread (atom, dimension)
     if (t < 4 * SPREAD_ATOMS) {
@@ -186,8 +223,15 @@ __device__ __forceinline__ void pme_spread_body(const PmeArgs& a, const int bloc
     if (t < SPREAD_ATOMS && charge[t] != 0.f) {
 #pragma unroll
         for (int d = 0; d < 3; d++) atomicMin(&minRel[d], wrap_rel(baseIdx[t][d] - ref[d], n[d]));
+        if (DD) {
+            bool touch = false;
+#pragma unroll
+            for (int k = 0; k < PME_ORDER; k++) { int gx = baseIdx[t][0] + k; gx -= gx >= a.nx ? a.nx : 0; touch = touch || spread_plane<DD>(a, gx) >= 0; }
+            if (touch) sh.touches = 1;
+        }
     }
     __syncthreads();
+    if (DD && sh.touches == 0) return;                         // nothing of this block lands on the rank's planes
     // ---- accumulate: each wavefront takes 8 atoms, one at a time; its lanes are the stencil points (l and l + 64), so
     //      one LDS-atomic instruction never hits the same cell twice (neighbouring atoms -- a water's O, H, H -- share
     //      most of their cells, and same-address lanes serialise)
@@ -219,12 +263,14 @@ __device__ __forceinline__ void pme_spread_body(const PmeArgs& a, const int bloc
                 int gx = baseIdx[atom][0] + ixA; gx -= gx >= a.nx ? a.nx : 0;
                 int gy = baseIdx[atom][1] + iyA; gy -= gy >= a.ny ? a.ny : 0;
                 int gz = baseIdx[atom][2] + izA; gz -= gz >= a.nz ? a.nz : 0;
-                atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], vA);
+                gx = spread_plane<DD>(a, gx);
+                if (gx >= 0) atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], vA);
                 if (hasB) {
                     gx = baseIdx[atom][0] + ixB; gx -= gx >= a.nx ? a.nx : 0;
                     gy = baseIdx[atom][1] + iyB; gy -= gy >= a.ny ? a.ny : 0;
                     gz = baseIdx[atom][2] + izB; gz -= gz >= a.nz ? a.nz : 0;
-                    atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], vB);
+                    gx = spread_plane<DD>(a, gx);
+                    if (gx >= 0) atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], vB);
                 }
             }
         }
@@ -243,21 +289,24 @@ __device__ __forceinline__ void pme_spread_body(const PmeArgs& a, const int bloc
             int gx = org[0] + i / (BRICK * BRICK_ZS); gx -= gx >= a.nx ? a.nx : 0;
             int gy = org[1] + (i / BRICK_ZS) % BRICK; gy -= gy >= a.ny ? a.ny : 0;
             int gz = org[2] + i % BRICK_ZS; gz -= gz >= a.nz ? a.nz : 0;
-            atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], v);
+            gx = spread_plane<DD>(a, gx);
+            if (gx >= 0) atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], v);
         }
     }
 }
 
+template <bool DD>
 __global__ __launch_bounds__(256) void pme_spread_lds(PmeArgs a) {
     __shared__ SpreadShared sh;
-    pme_spread_body(a, blockIdx.x, sh);
+    pme_spread_body<DD>(a, blockIdx.x, sh);
 }
 
+template <bool DD>
 __global__ __launch_bounds__(256) void pme_interpolate(PmeArgs a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    int slot = t >> 3;
+    int slot = (DD ? a.ownSlot0 : 0) + (t >> 3);
     const int sub = t & 7;
-    const bool valid = slot < a.paddedAtoms;
+    const bool valid = slot < (DD ? a.ownSlot1 : a.paddedAtoms);
     if (!valid) slot = a.paddedAtoms - 1;
     const float4 p = a.posq[slot];
     float fx = 0.f, fy = 0.f, fz = 0.f;
@@ -275,6 +324,8 @@ __global__ __launch_bounds__(256) void pme_interpolate(PmeArgs a) {
             int gx = idx[0] + ix; gx -= gx >= a.nx ? a.nx : 0;
             int gy = idx[1] + iy; gy -= gy >= a.ny ? a.ny : 0;
             int gz = idx[2] + iz; gz -= gz >= a.nz ? a.nz : 0;
+            gx = gather_plane<DD>(a, gx);
+            if (DD && gx < 0) { *a.ddError = 1; gx = 0; }          // the atom drifted out of the planes this rank holds: flagged, the host re-sorts
             g[i] = a.grid[((size_t) gx * a.ny + gy) * a.nz + gz];
         }
 #pragma unroll
@@ -358,6 +409,7 @@ __global__ __launch_bounds__(256) void pme_interpolate(PmeArgs a) {
 // ------------------------------------------------------------------------------------------------
 struct EtermArgs {
     int nx, ny, nz, nzc;
+    int y0, nyl;            // rows [y0, y0 + nyl) of the influence function are built (slab decomposition; whole grid: 0, ny)
     double r00, r10, r11, r20, r21, r22, alpha, volume;
     const double* modX; const double* modY; const double* modZ;
     float* eterm;
@@ -365,9 +417,9 @@ struct EtermArgs {
 
 __global__ void pme_build_eterm(EtermArgs a) {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t) a.nx * a.ny * a.nzc;
+    const size_t total = (size_t) a.nx * a.nyl * a.nzc;
     if (i >= total) return;
-    const int kz = (int) (i % a.nzc), ky = (int) ((i / a.nzc) % a.ny), kx = (int) (i / ((size_t) a.nzc * a.ny));
+    const int kz = (int) (i % a.nzc), ky = a.y0 + (int) ((i / a.nzc) % a.nyl), kx = (int) (i / ((size_t) a.nzc * a.nyl));
     if (kx == 0 && ky == 0 && kz == 0) { a.eterm[i] = 0.f; return; }
     const int mx = kx < (a.nx + 1) / 2 ? kx : kx - a.nx;
     const int my = ky < (a.ny + 1) / 2 ? ky : ky - a.ny;
@@ -407,7 +459,15 @@ struct FftArgs {
     double* energyBuffer;  // mode 3 with energy
     int energySlots;
     int nzFull;            // mode 3: full z dimension (for the Hermitian weights); inner index = kz
+    // slab decomposition, y pass only (outer = local x plane, inner = kz, element = ky): the side flagged here addresses the
+    // transpose-ready layout [ky / remapNyl][x local of remapNxl][ky % remapNyl][kz] instead of the strides above
+    int remapIn, remapOut, remapNxl, remapNyl;
 };
+
+__device__ __forceinline__ long long fft_remap_offset(const FftArgs& a, int outer, int inner, int e) {
+    const int q = e / a.remapNyl, yl = e - q * a.remapNyl;
+    return (((long long) q * a.remapNxl + outer) * a.remapNyl + yl) * a.numInner + inner;
+}
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
@@ -512,7 +572,8 @@ __device__ __forceinline__ void fft_body(const FftArgs& a, const int block, FftS
             int line, e;
             if (elemFastIn) { e = idx % nIn; line = idx / nIn; } else { line = idx % B; e = idx / B; }
             if (inner0 + line < a.numInner) {
-                const long long off = outer * a.inOuterStride + (inner0 + line) * a.inInnerStride + e * a.inElemStride;
+                const long long off = a.remapIn ? fft_remap_offset(a, outer, inner0 + line, e)
+                                                : outer * a.inOuterStride + (inner0 + line) * a.inInnerStride + e * a.inElemStride;
                 if (a.mode == 1) v.x = ((const float*) a.in)[off];
                 else v = ((const float2*) a.in)[off];
             }
@@ -578,7 +639,8 @@ __device__ __forceinline__ void fft_body(const FftArgs& a, const int block, FftS
         int line, e;
         if (elemFastOut) { e = idx % nOut; line = idx / nOut; } else { line = idx % B; e = idx / B; }
         if (inner0 + line < a.numInner) {
-            const long long off = outer * a.outOuterStride + (inner0 + line) * a.outInnerStride + e * a.outElemStride;
+            const long long off = a.remapOut ? fft_remap_offset(a, outer, inner0 + line, e)
+                                             : outer * a.outOuterStride + (inner0 + line) * a.outInnerStride + e * a.outElemStride;
             const float2 v = res[e * BP + line];
             if (a.mode == 2) ((float*) a.out)[off] = v.x;
             else ((float2*) a.out)[off] = v;
@@ -608,7 +670,16 @@ struct PlaneArgs {
     const float2* twY; const float2* twZ;
     float* real;           // [nx][ny][nz]
     float2* cplx;          // [nx][ny][nz/2+1]
+    // slab decomposition: the workgroup's plane is local plane `block` of nxl; its complex rows live in transpose-ready order
+    // [dest rank q = ky / nyl][x local][ky % nyl][kz], so that the all-to-all moves one contiguous chunk per rank.  nyl = 0: plain.
+    int nxl, nyl;
 };
+
+__device__ __forceinline__ size_t plane_cplx_index(const PlaneArgs& a, int x, int ky, int kz, int nzc) {
+    if (a.nyl == 0) return ((size_t) x * a.ny + ky) * nzc + kz;
+    const int q = ky / a.nyl, yl = ky - q * a.nyl;
+    return (((size_t) q * a.nxl + x) * a.nyl + yl) * nzc + kz;
+}
 
 template <int CAP>
 struct PlaneShared {
@@ -650,20 +721,18 @@ __device__ __forceinline__ void fft_plane_body(const PlaneArgs& a, const int blo
         float2* r1 = fft_lines(a.planZ, bufA, bufB, ny, S, -1, twZs, 1);            // lines = y, elements = z
         float2* other = r1 == bufA ? bufB : bufA;
         float2* r2 = fft_lines(a.planY, r1, other, nzc, 1, -1, twYs, S);            // lines = kz < nzc, elements = y
-        float2* out = a.cplx + (size_t) x * ny * nzc;
         for (int idx = threadIdx.x; idx < ny * nzc; idx += THREADS) {
             const int ky = idx / nzc, kz = idx % nzc;
-            out[idx] = r2[kz * S + ky];
+            a.cplx[plane_cplx_index(a, x, ky, kz, nzc)] = r2[kz * S + ky];
         }
     }
     else {
-        const float2* in = a.cplx + (size_t) x * ny * nzc;
         constexpr int MAXLD = (CAP + THREADS - 1) / THREADS;
         float2 ld[MAXLD];
 #pragma unroll
         for (int it = 0; it < MAXLD; it++) {
             const int idx = threadIdx.x + it * THREADS;
-            ld[it] = idx < ny * nzc ? in[idx] : make_float2(0.f, 0.f);
+            ld[it] = idx < ny * nzc ? a.cplx[plane_cplx_index(a, x, idx / nzc, idx % nzc, nzc)] : make_float2(0.f, 0.f);
         }
 #pragma unroll
         for (int it = 0; it < MAXLD; it++) {
@@ -721,6 +790,7 @@ PlaneArgs make_plane_args(const ommhip_pme* pme, bool forward) {
     p.planY = make_plan(pme->ny); p.planZ = make_plan(pme->nz); p.ny = pme->ny; p.nz = pme->nz; p.forward = forward ? 1 : 0;
     p.twY = (const float2*) pme->twiddle_y; p.twZ = (const float2*) pme->twiddle_z;
     p.real = (float*) pme->grid_real; p.cplx = (float2*) pme->grid_complex;
+    p.nxl = pme->nx; p.nyl = 0;
     return p;
 }
 
@@ -729,6 +799,7 @@ FftArgs make_xconv_args(const ommhip_pme* pme, double* energy_buffer_d, int ener
     const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
     float2* cgrid = (float2*) pme->grid_complex;
     FftArgs f;
+    f.remapIn = f.remapOut = 0; f.remapNxl = f.remapNyl = 1;
     f.nzFull = nz;
     f.plan = make_plan(nx); f.B = lines_per_group(nx); f.numOuter = ny; f.numInner = nzc;
     f.inOuterStride = nzc; f.inInnerStride = 1; f.inElemStride = (long long) ny * nzc;
@@ -747,10 +818,12 @@ void launch_yz(const ommhip_pme* pme, bool forward, hipStream_t st) {
         p.planY = make_plan(ny); p.planZ = make_plan(nz); p.ny = ny; p.nz = nz; p.forward = forward ? 1 : 0;
         p.twY = (const float2*) pme->twiddle_y; p.twZ = (const float2*) pme->twiddle_z;
         p.real = (float*) pme->grid_real; p.cplx = cgrid;
+        p.nxl = nx; p.nyl = 0;
         hipLaunchKernelGGL(fft_plane_kernel, dim3(nx), dim3(PLANE_THREADS), 0, st, p);
         return;
     }
     FftArgs f;
+    f.remapIn = f.remapOut = 0; f.remapNxl = f.remapNyl = 1;
     f.eterm = nullptr; f.energyBuffer = nullptr; f.energySlots = 1; f.nzFull = nz;
     auto zpass = [&]() {
         f.plan = make_plan(nz); f.B = lines_per_group(nz); f.numOuter = 1; f.numInner = nx * ny;
@@ -790,7 +863,9 @@ extern "C" int ommhip_pme_build_eterm(const ommhip_pme* pme, void* stream) {
     a.alpha = pme->alpha; a.volume = det;
     a.modX = pme->moduli_x; a.modY = pme->moduli_y; a.modZ = pme->moduli_z;
     a.eterm = (float*) pme->eterm;
-    const size_t total = (size_t) a.nx * a.ny * a.nzc;
+    a.y0 = 0; a.nyl = a.ny;
+    if (pme->dd_ranks > 1) { a.nyl = a.ny / pme->dd_ranks; a.y0 = pme->dd_rank * a.nyl; }
+    const size_t total = (size_t) a.nx * a.nyl * a.nzc;
     hipLaunchKernelGGL(pme_build_eterm, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream, a);
     return (int) hipGetLastError();
 }
@@ -813,6 +888,8 @@ static PmeArgs make_pme_args(const ommhip_pme* pme, const void* posq_d, int padd
     pa.boxd.ax = b[0]; pa.boxd.bx = b[1]; pa.boxd.by = b[2]; pa.boxd.cx = b[3]; pa.boxd.cy = b[4]; pa.boxd.cz = b[5];
     pa.alpha = pme->alpha; pa.exclPeriodic = pme->excl_periodic;
     pa.includeEnergy = include_energy; pa.energySlots = energy_slots; pa.energyBuffer = energy_buffer_d;
+    pa.planeLo = 0; pa.planeCount = nx; pa.haloLo = 0; pa.gridPlanes = nx; pa.ownSlot0 = 0; pa.ownSlot1 = padded_atoms;
+    pa.ddError = nullptr; pa.blockCenter = nullptr; pa.blockHalf = nullptr;
     return pa;
 }
 
@@ -830,7 +907,7 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
         if (pme->spread_mode == 1)
             hipLaunchKernelGGL(pme_spread, dim3(spreadBlocks), dim3(256), 0, st, pa);             // direct global atomics (reference variant)
         else
-            hipLaunchKernelGGL(pme_spread_lds, dim3((padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS), dim3(256), 0, st, pa);
+            hipLaunchKernelGGL(pme_spread_lds<false>, dim3((padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS), dim3(256), 0, st, pa);
         ommhip_profile_end(OMMHIP_TIMER_PME_SPREAD, stream);
     }
     if (pme->phases == OMMHIP_PME_SPREAD_ONLY) return (int) hipGetLastError();
@@ -838,6 +915,7 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     ommhip_profile_begin(OMMHIP_TIMER_PME_FFT, stream);
 
     FftArgs f;
+    f.remapIn = f.remapOut = 0; f.remapNxl = f.remapNyl = 1;
     f.eterm = nullptr; f.energyBuffer = nullptr; f.energySlots = 1; f.nzFull = nz;
     // ---- forward z (r2c) and y
     launch_yz(pme, true, st);
@@ -854,7 +932,107 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     ommhip_profile_end(OMMHIP_TIMER_PME_FFT, stream);
     }
     ommhip_profile_begin(OMMHIP_TIMER_PME_INTERPOLATE, stream);
-    hipLaunchKernelGGL(pme_interpolate, dim3(spreadBlocks), dim3(256), 0, st, pa);
+    hipLaunchKernelGGL(pme_interpolate<false>, dim3(spreadBlocks), dim3(256), 0, st, pa);
+    ommhip_profile_end(OMMHIP_TIMER_PME_INTERPOLATE, stream);
+    return (int) hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// One rank of a slab-decomposed reciprocal-space evaluation.  Same kernels as above; what changes is which
+// planes / rows a launch covers and where the complex data sits, so that each of the two transposes is ONE all-to-all of
+// contiguous chunks:
+//   A = grid_complex   [dest rank q][x local][y local of q][kz]   written by the forward plane / y transforms
+//   B = grid_complex2  [x (all)][y local][kz]                      = A's chunks as they arrive, source-rank major
+// ------------------------------------------------------------------------------------------------
+namespace {
+void launch_yz_dd(const ommhip_pme* pme, bool forward, float* realOwn, hipStream_t st) {
+    const int R = pme->dd_ranks, nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1, nxl = nx / R, nyl = ny / R;
+    float2* A = (float2*) pme->grid_complex;
+    float2* B = (float2*) pme->grid_complex2;
+    if (nz * (ny + 1) <= PLANE_MAX && ny <= 256 && nz <= 256 && pme->fft_mode != 1) {
+        PlaneArgs p = make_plane_args(pme, forward);
+        p.real = realOwn; p.cplx = A; p.nxl = nxl; p.nyl = nyl;
+        hipLaunchKernelGGL(fft_plane_kernel, dim3(nxl), dim3(PLANE_THREADS), 0, st, p);
+        return;
+    }
+    FftArgs f;
+    f.remapIn = f.remapOut = 0; f.remapNxl = nxl; f.remapNyl = nyl;
+    f.eterm = nullptr; f.energyBuffer = nullptr; f.energySlots = 1; f.nzFull = nz;
+    auto zpass = [&]() {      // real planes <-> B in plain [x local][y][kz] order
+        f.plan = make_plan(nz); f.B = lines_per_group(nz); f.numOuter = 1; f.numInner = nxl * ny;
+        f.inOuterStride = 0; f.outOuterStride = 0; f.inElemStride = 1; f.outElemStride = 1; f.remapIn = f.remapOut = 0;
+        f.twiddle = (const float2*) pme->twiddle_z;
+        if (forward) { f.inInnerStride = nz; f.outInnerStride = nzc; f.mode = 1; f.sign = -1; f.in = realOwn; f.out = B; }
+        else { f.inInnerStride = nzc; f.outInnerStride = nz; f.mode = 2; f.sign = +1; f.in = B; f.out = realOwn; }
+        hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+    };
+    auto ypass = [&]() {      // B (plain) <-> A (transpose-ready)
+        f.plan = make_plan(ny); f.B = lines_per_group(ny); f.numOuter = nxl; f.numInner = nzc;
+        f.inOuterStride = (long long) ny * nzc; f.inInnerStride = 1; f.inElemStride = nzc;
+        f.outOuterStride = f.inOuterStride; f.outInnerStride = 1; f.outElemStride = nzc;
+        f.mode = 0; f.sign = forward ? -1 : +1; f.twiddle = (const float2*) pme->twiddle_y;
+        if (forward) { f.in = B; f.out = A; f.remapIn = 0; f.remapOut = 1; }
+        else { f.in = A; f.out = B; f.remapIn = 1; f.remapOut = 0; }
+        hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+    };
+    if (forward) { zpass(); ypass(); }
+    else { ypass(); zpass(); }
+}
+}  // namespace
+
+extern "C" int ommhip_pme_reciprocal_dd(const ommhip_pme* pme, const void* posq_d, int padded_atoms, int own_slot0, int own_slot1, const void* block_center_d,
+                                        const void* block_half_d, long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
+    hipStream_t st = (hipStream_t) stream;
+    const int R = pme->dd_ranks, rank = pme->dd_rank, D = pme->dd_halo;
+    const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
+    if (R < 2 || nx % R != 0 || ny % R != 0 || pme->comm == nullptr || pme->grid_complex2 == nullptr || pme->dd_error == nullptr) return 1;
+    const int nxl = nx / R, nyl = ny / R;
+    if (D < 0 || D + 4 > nxl) return 1;
+    ommhip_comm* comm = (ommhip_comm*) pme->comm;
+    PmeArgs pa = make_pme_args(pme, posq_d, padded_atoms, force_d, energy_buffer_d, energy_slots, include_energy);
+    pa.planeLo = rank * nxl; pa.planeCount = nxl; pa.haloLo = D; pa.gridPlanes = nxl + 2 * D + 4;
+    pa.ownSlot0 = own_slot0; pa.ownSlot1 = own_slot1; pa.ddError = pme->dd_error;
+    pa.blockCenter = (const float4*) block_center_d; pa.blockHalf = (const float4*) block_half_d;
+    float* real = (float*) pme->grid_real;
+    float* realOwn = real + (size_t) D * ny * nz;
+    const size_t planeBytes = sizeof(float) * (size_t) ny * nz;
+
+    if (pme->phases != OMMHIP_PME_AFTER_SPREAD && pme->phases != OMMHIP_PME_INTERPOLATE_ONLY) {
+        if (!pme->grid_precleared) hipMemsetAsync(real, 0, planeBytes * (size_t) pa.gridPlanes, st);
+        if (pa.blockCenter == nullptr || pa.blockHalf == nullptr) return 1;
+        ommhip_profile_begin(OMMHIP_TIMER_PME_SPREAD, stream);
+        hipLaunchKernelGGL(pme_spread_lds<true>, dim3((padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS), dim3(256), 0, st, pa);
+        ommhip_profile_end(OMMHIP_TIMER_PME_SPREAD, stream);
+    }
+    if (pme->phases == OMMHIP_PME_SPREAD_ONLY) return (int) hipGetLastError();
+    if (pme->phases != OMMHIP_PME_INTERPOLATE_ONLY) {
+        ommhip_profile_begin(OMMHIP_TIMER_PME_FFT, stream);
+        launch_yz_dd(pme, true, realOwn, st);
+        const size_t pairBytes = sizeof(float2) * (size_t) nxl * nyl * nzc;
+        int rc = ommhip_comm_all_to_all(comm, pme->grid_complex, pme->grid_complex2, pairBytes, stream);
+        if (rc != 0) return rc;
+        // x transform * influence function * inverse x transform on this rank's rows, in place in B = [x][y local][kz]
+        FftArgs f;
+        f.remapIn = f.remapOut = 0; f.remapNxl = f.remapNyl = 1;
+        f.nzFull = nz;
+        f.plan = make_plan(nx); f.B = lines_per_group(nx); f.numOuter = nyl; f.numInner = nzc;
+        f.inOuterStride = nzc; f.inInnerStride = 1; f.inElemStride = (long long) nyl * nzc;
+        f.outOuterStride = nzc; f.outInnerStride = 1; f.outElemStride = (long long) nyl * nzc;
+        f.mode = 3; f.sign = -1; f.twiddle = (const float2*) pme->twiddle_x; f.in = pme->grid_complex2; f.out = pme->grid_complex2;
+        f.eterm = (const float*) pme->eterm; f.energyBuffer = include_energy ? energy_buffer_d : nullptr; f.energySlots = energy_slots;
+        hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+        rc = ommhip_comm_all_to_all(comm, pme->grid_complex2, pme->grid_complex, pairBytes, stream);
+        if (rc != 0) return rc;
+        launch_yz_dd(pme, false, realOwn, st);
+        // potential planes the neighbours' atoms (and mine, beyond my slab) interpolate from
+        rc = ommhip_comm_ring_exchange(comm, realOwn, realOwn + (size_t) nxl * ny * nz, planeBytes * (size_t) (D + 4),
+                                       realOwn + (size_t) (nxl - D) * ny * nz, real, planeBytes * (size_t) D, stream);
+        if (rc != 0) return rc;
+        ommhip_profile_end(OMMHIP_TIMER_PME_FFT, stream);
+    }
+    ommhip_profile_begin(OMMHIP_TIMER_PME_INTERPOLATE, stream);
+    const int ownSlots = own_slot1 - own_slot0;
+    if (ownSlots > 0) hipLaunchKernelGGL(pme_interpolate<true>, dim3((ownSlots * 8 + 255) / 256), dim3(256), 0, st, pa);
     ommhip_profile_end(OMMHIP_TIMER_PME_INTERPOLATE, stream);
     return (int) hipGetLastError();
 }
@@ -865,6 +1043,7 @@ extern "C" int ommhip_fft3d_r2c_c2r(const ommhip_pme* pme, int forward, void* st
     const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
     float2* cgrid = (float2*) pme->grid_complex;
     FftArgs f;
+    f.remapIn = f.remapOut = 0; f.remapNxl = f.remapNyl = 1;
     f.eterm = nullptr; f.energyBuffer = nullptr; f.energySlots = 1; f.nzFull = nz;
     auto zpass = [&](bool fwd) {
         f.plan = make_plan(nz); f.B = lines_per_group(nz); f.numOuter = 1; f.numInner = nx * ny;

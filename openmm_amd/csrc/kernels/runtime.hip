@@ -55,7 +55,14 @@ int ommhip_event_record(void* event, void* stream) { return (int) hipEventRecord
 int ommhip_event_sync(void* event) { return (int) hipEventSynchronize((hipEvent_t) event); }
 int ommhip_event_elapsed_ms(void* start, void* stop, float* ms) { return (int) hipEventElapsedTime(ms, (hipEvent_t) start, (hipEvent_t) stop); }
 int ommhip_stream_wait_event(void* stream, void* event) { return (int) hipStreamWaitEvent((hipStream_t) stream, (hipEvent_t) event, 0); }
-const char* ommhip_error_string(int code) { return hipGetErrorString((hipError_t) code); }
+const char* ommhip_error_string(int code) {
+    if (code >= 1000) {                      // 1000 + ncclResult_t (include/openmm_hip_comm.h)
+        static thread_local char buf[64];
+        snprintf(buf, sizeof(buf), "RCCL error %d", code - 1000);
+        return buf;
+    }
+    return hipGetErrorString((hipError_t) code);
+}
 
 }
 

@@ -83,6 +83,20 @@ __global__ __launch_bounds__(256) void k_clear2(uint4* __restrict__ a, size_t na
     }
 }
 
+// slot-ordered <-> atom-ordered copies of a double4 array (all-gather buffers of the decomposed run)
+__global__ void k_pack_slots(const double4* __restrict__ src, const int* __restrict__ atomOfSlot, int slot0, int slot1, double4* __restrict__ dst) {
+    const int s = slot0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= slot1) return;
+    const int a = atomOfSlot[s];
+    if (a >= 0) dst[s] = src[a];
+}
+__global__ void k_unpack_slots(const double4* __restrict__ src, const int* __restrict__ atomOfSlot, int slot0, int slot1, double4* __restrict__ dst) {
+    const int s = slot0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= slot1) return;
+    const int a = atomOfSlot[s];
+    if (a >= 0) dst[a] = src[s];
+}
+
 BoxD make_boxd(const double* bv) {
     BoxD b; b.ax = bv[0]; b.bx = bv[1]; b.by = bv[2]; b.cx = bv[3]; b.cy = bv[4]; b.cz = bv[5];
     return b;
@@ -129,5 +143,19 @@ extern "C" int ommhip_clear2(void* a_d, size_t a_bytes, void* b_d, size_t b_byte
 
 extern "C" int ommhip_reduce_energy(double* buffer_d, int n, double* result_d, void* stream) {
     hipLaunchKernelGGL(k_reduce_energy, dim3(1), dim3(256), 0, (hipStream_t) stream, buffer_d, n, result_d);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_pack_slots(const void* src_atom_order_d, const int* atom_of_slot_d, int slot0, int slot1, void* dst_slot_order_d, void* stream) {
+    if (slot1 <= slot0) return 0;
+    hipLaunchKernelGGL(k_pack_slots, dim3((slot1 - slot0 + 255) / 256), dim3(256), 0, (hipStream_t) stream,
+                       (const double4*) src_atom_order_d, atom_of_slot_d, slot0, slot1, (double4*) dst_slot_order_d);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_unpack_slots(const void* src_slot_order_d, const int* atom_of_slot_d, int slot0, int slot1, void* dst_atom_order_d, void* stream) {
+    if (slot1 <= slot0) return 0;
+    hipLaunchKernelGGL(k_unpack_slots, dim3((slot1 - slot0 + 255) / 256), dim3(256), 0, (hipStream_t) stream,
+                       (const double4*) src_slot_order_d, atom_of_slot_d, slot0, slot1, (double4*) dst_atom_order_d);
     return (int) hipGetLastError();
 }

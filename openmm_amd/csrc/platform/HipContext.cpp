@@ -37,7 +37,7 @@ unsigned long long hilbertIndex(unsigned x, unsigned y, unsigned z, int bits) {
 }
 }  // namespace
 
-HipContext::HipContext(const System& system, int deviceIndex, bool hostMode) : numAtoms(system.getNumParticles()), hostMode(hostMode),
+HipContext::HipContext(const System& system, int deviceIndex, bool hostMode, const HipDomain& domain) : domain(domain), numAtoms(system.getNumParticles()), hostMode(hostMode),
         stream(NULL), usePeriodic(false), sortCutoff(0.0), positionsValid(false), hasFallbackForces(false), stepsSinceReorder(0),
         reorderInterval(getenv("OPENMM_HIP_REORDER_INTERVAL") != NULL ? atoi(getenv("OPENMM_HIP_REORDER_INTERVAL")) : 500), cmRemovalPending(false), momentumValid(false), reorderRequested(true), deviceIndex(deviceIndex), pinnedResult(NULL) {
     int count = 0;
@@ -53,6 +53,18 @@ HipContext::HipContext(const System& system, int deviceIndex, bool hostMode) : n
     usePmeStream = true;
     paddedAtoms = ((numAtoms + OMMHIP_TILE - 1) / OMMHIP_TILE) * OMMHIP_TILE;
     if (paddedAtoms == 0) paddedAtoms = OMMHIP_TILE;
+    findUnits(system);
+    slotsPerRank = paddedAtoms; ownSlot0 = 0; ownSlot1 = paddedAtoms; trailerSlot = -1;
+    if (decomposed()) {
+        if (hostMode)
+            throw OpenMMException("HIP platform: a Context spread over several GPUs needs a native integrator (Verlet, Langevin, LangevinMiddle) and no host-side state changes (barostat, virtual sites)");
+        // every rank gets the same number of slots: its share of the atoms, room to keep the last unit whole, the trailer slot
+        const int R = domain.ranks;
+        const int share = (numAtoms + R - 1) / R + maxUnitSize + 1;
+        slotsPerRank = ((share + OMMHIP_TILE - 1) / OMMHIP_TILE) * OMMHIP_TILE;
+        paddedAtoms = R * slotsPerRank;
+        ownSlot0 = domain.rank * slotsPerRank; ownSlot1 = ownSlot0 + slotsPerRank; trailerSlot = slotsPerRank - 1;
+    }
     masses.resize(numAtoms);
     for (int i = 0; i < numAtoms; i++) masses[i] = system.getParticleMass(i);
     const size_t n4 = sizeof(double) * 4 * (size_t) max(numAtoms, 1);
@@ -64,6 +76,12 @@ HipContext::HipContext(const System& system, int deviceIndex, bool hostMode) : n
     energyBuffer.allocate(sizeof(double) * EnergySlots);
     energyResult.allocate(sizeof(double) * 8);
     forceDouble.allocate(sizeof(double) * 3 * (size_t) max(numAtoms, 1));
+    if (decomposed()) {
+        posSlot.allocate(sizeof(double) * 4 * (size_t) paddedAtoms);
+        velSlot.allocate(sizeof(double) * 4 * (size_t) paddedAtoms);
+        HIP_CHECK(ommhip_memset(posSlot.ptr, 0, posSlot.bytes, stream));
+        HIP_CHECK(ommhip_memset(velSlot.ptr, 0, velSlot.bytes, stream));
+    }
     HIP_CHECK(ommhip_host_malloc((void**) &pinnedResult, sizeof(double) * 8));
     HIP_CHECK(ommhip_memset(energyBuffer.ptr, 0, energyBuffer.bytes, stream));
     HIP_CHECK(ommhip_memset(force.ptr, 0, force.bytes, stream));
@@ -89,6 +107,7 @@ HipContext::HipContext(const System& system, int deviceIndex, bool hostMode) : n
 }
 
 HipContext::~HipContext() {
+    if (domain.comm != NULL) ommhip_comm_destroy(domain.comm);
     if (pinnedResult != NULL) ommhip_host_free(pinnedResult);
     if (pmeForkEvent != NULL) ommhip_event_destroy(pmeForkEvent);
     if (pmeDoneEvent != NULL) ommhip_event_destroy(pmeDoneEvent);
@@ -117,11 +136,13 @@ void HipContext::uploadPositions(const vector<Vec3>& positions) {
         tmp[i].x = positions[i][0]; tmp[i].y = positions[i][1]; tmp[i].z = positions[i][2]; tmp[i].w = 0;
     }
     if (numAtoms > 0) HIP_CHECK(ommhip_memcpy_h2d(pos.ptr, tmp.data(), sizeof(D4) * numAtoms, stream));
+    if (decomposed()) fillPosSlotFromPos();      // every rank was handed all positions: no communication
     sync();
     positionsValid = true;
 }
 
 void HipContext::downloadPositions(vector<Vec3>& positions) {
+    if (decomposed()) gatherState();
     vector<D4> tmp(numAtoms);
     if (numAtoms > 0) HIP_CHECK(ommhip_memcpy_d2h(tmp.data(), pos.ptr, sizeof(D4) * numAtoms, stream));
     sync();
@@ -141,6 +162,7 @@ void HipContext::uploadVelocities(const vector<Vec3>& velocities) {
 }
 
 void HipContext::downloadVelocities(vector<Vec3>& velocities) {
+    if (decomposed()) gatherState();
     vector<D4> tmp(numAtoms);
     if (numAtoms > 0) HIP_CHECK(ommhip_memcpy_d2h(tmp.data(), vel.ptr, sizeof(D4) * numAtoms, stream));
     sync();
@@ -151,6 +173,11 @@ void HipContext::downloadVelocities(vector<Vec3>& velocities) {
 void HipContext::downloadForces(vector<Vec3>& forces) {
     forces.resize(numAtoms);
     if (numAtoms == 0) return;
+    if (decomposed()) {
+        // every rank holds the forces on its own slots: all-gather each component of the slot-ordered buffer in place
+        for (int c = 0; c < 3; c++)
+            HIP_CHECK(ommhip_comm_all_gather(domain.comm, force.as<long long>() + (size_t) c * paddedAtoms, sizeof(long long) * (size_t) slotsPerRank, stream));
+    }
     HIP_CHECK(ommhip_forces_to_double(force.as<long long>(), slotOfAtom.as<int>(), numAtoms, paddedAtoms, forceDouble.as<double>(), stream));
     vector<double> tmp(3 * (size_t) numAtoms);
     HIP_CHECK(ommhip_memcpy_d2h(tmp.data(), forceDouble.ptr, sizeof(double) * tmp.size(), stream));
@@ -273,7 +300,61 @@ double HipContext::reduceEnergy() {
     HIP_CHECK(ommhip_reduce_energy(energyBuffer.as<double>(), EnergySlots, energyResult.as<double>(), stream));
     HIP_CHECK(ommhip_memcpy_d2h(pinnedResult, energyResult.ptr, sizeof(double), stream));
     sync();
-    return pinnedResult[0];
+    return decomposed() ? sumOverRanks(pinnedResult[0]) : pinnedResult[0];
+}
+
+double HipContext::sumOverRanks(double v) {
+    if (!decomposed()) return v;
+    vector<double> all(domain.ranks);
+    HIP_CHECK(ommhip_comm_all_gather_host(domain.comm, &v, all.data(), sizeof(double), stream));
+    double sum = 0;
+    for (int r = 0; r < domain.ranks; r++) sum += all[r];
+    return sum;
+}
+
+void HipContext::allGatherPositions() {
+    HIP_CHECK(ommhip_comm_all_gather(domain.comm, posSlot.ptr, sizeof(double) * 4 * (size_t) slotsPerRank, stream));
+}
+
+void HipContext::fillPosSlotFromPos() {
+    HIP_CHECK(ommhip_pack_slots(pos.ptr, atomOfSlot.as<int>(), 0, paddedAtoms, posSlot.ptr, stream));
+}
+
+void HipContext::gatherState() {
+    // positions: posSlot is complete after every step's all-gather; bring the atom-ordered copy up to date
+    HIP_CHECK(ommhip_unpack_slots(posSlot.ptr, atomOfSlot.as<int>(), 0, paddedAtoms, pos.ptr, stream));
+    // velocities: only the owner's are current
+    HIP_CHECK(ommhip_pack_slots(vel.ptr, atomOfSlot.as<int>(), ownSlot0, ownSlot1, velSlot.ptr, stream));
+    HIP_CHECK(ommhip_comm_all_gather(domain.comm, velSlot.ptr, sizeof(double) * 4 * (size_t) slotsPerRank, stream));
+    HIP_CHECK(ommhip_unpack_slots(velSlot.ptr, atomOfSlot.as<int>(), 0, paddedAtoms, vel.ptr, stream));
+}
+
+void HipContext::findUnits(const System& system) {
+    // constraint-connected groups of atoms (waters, X-H clusters, ...): they are integrated by one thread and must not be
+    // split between ranks.  Union-find over the constraints; units are numbered by their lowest atom.
+    vector<int> parent(numAtoms);
+    for (int i = 0; i < numAtoms; i++) parent[i] = i;
+    struct Find { static int root(vector<int>& p, int i) { while (p[i] != i) { p[i] = p[p[i]]; i = p[i]; } return i; } };
+    for (int c = 0; c < system.getNumConstraints(); c++) {
+        int a, b; double d;
+        system.getConstraintParameters(c, a, b, d);
+        int ra = Find::root(parent, a), rb = Find::root(parent, b);
+        if (ra != rb) parent[max(ra, rb)] = min(ra, rb);
+    }
+    unitOfAtom.assign(numAtoms, -1);
+    vector<int> count;
+    for (int i = 0; i < numAtoms; i++) {
+        const int r = Find::root(parent, i);
+        if (unitOfAtom[r] < 0) { unitOfAtom[r] = (int) count.size(); count.push_back(0); }
+        unitOfAtom[i] = unitOfAtom[r];
+        count[unitOfAtom[i]]++;
+    }
+    unitStart.assign(count.size() + 1, 0);
+    maxUnitSize = 1;
+    for (size_t u = 0; u < count.size(); u++) { unitStart[u + 1] = unitStart[u] + count[u]; maxUnitSize = max(maxUnitSize, count[u]); }
+    unitAtomList.resize(numAtoms);
+    vector<int> cursor(unitStart.begin(), unitStart.end() - 1);
+    for (int i = 0; i < numAtoms; i++) unitAtomList[cursor[unitOfAtom[i]]++] = i;
 }
 
 void HipContext::stepTaken() {
@@ -327,24 +408,109 @@ void HipContext::computeOrder(const vector<Vec3>& positions, vector<int>& order,
     for (int i = 0; i < numAtoms; i++) order[i] = keyed[i].second;
 }
 
+void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<int>& newAtomOfSlot, vector<int>& wrapOut) {
+    // Slabs along x with equal numbers of atoms, whole units only; inside a slab the units follow a Hilbert curve, so
+    // 32 consecutive slots are a compact group of atoms (the neighbour list's i-blocks) just as on one GPU.
+    if (!usePeriodic || box[1] != 0.0 || box[3] != 0.0 || box[4] != 0.0)
+        throw OpenMMException("HIP platform: multi-GPU runs need a rectangular periodic box");
+    const int R = domain.ranks, numUnits = (int) unitStart.size() - 1;
+    const double L[3] = {box[0], box[2], box[5]};
+    wrapOut.assign(4 * (size_t) numAtoms, 0);
+    vector<Vec3> ref(numUnits);                      // wrapped position of the unit's first atom
+    for (int u = 0; u < numUnits; u++) {
+        const int a0 = unitAtomList[unitStart[u]];
+        Vec3 p0 = positions[a0];
+        for (int k = 0; k < 3; k++) {
+            const int w = (int) floor(p0[k] / L[k]);
+            wrapOut[4 * a0 + k] = w;
+            p0[k] -= w * L[k];
+        }
+        ref[u] = p0;
+        // the other atoms go to the image nearest to the first one, so the unit stays in one piece
+        for (int i = unitStart[u] + 1; i < unitStart[u + 1]; i++) {
+            const int a = unitAtomList[i];
+            for (int k = 0; k < 3; k++) {
+                double d = positions[a][k] - positions[a0][k];
+                d -= floor(d / L[k] + 0.5) * L[k];
+                wrapOut[4 * a + k] = (int) floor((positions[a][k] - (p0[k] + d)) / L[k] + 0.5);
+            }
+        }
+    }
+    // ---- cut along x into R groups of (nearly) equal atom count
+    vector<int> byX(numUnits);
+    for (int u = 0; u < numUnits; u++) byX[u] = u;
+    sort(byX.begin(), byX.end(), [&](int a, int b) { return ref[a][0] < ref[b][0] || (ref[a][0] == ref[b][0] && a < b); });
+    vector<int> groupStart(R + 1, numUnits);
+    groupStart[0] = 0;
+    {
+        long long cumulative = 0;
+        int g = 0;
+        for (int i = 0; i < numUnits; i++) {
+            // unit i opens the next group once the groups so far hold their share
+            while (g + 1 < R && cumulative >= (long long) (g + 1) * numAtoms / R) groupStart[++g] = i;
+            cumulative += unitStart[byX[i] + 1] - unitStart[byX[i]];
+        }
+        while (g + 1 < R) groupStart[++g] = numUnits;
+    }
+    // ---- Hilbert order inside each group
+    static const double binWidth = getenv("OPENMM_HIP_SORT_BIN") != NULL ? atof(getenv("OPENMM_HIP_SORT_BIN")) : 0.3;
+    int maxCells = 1, ncell[3];
+    for (int k = 0; k < 3; k++) { ncell[k] = max(1, min(1023, (int) floor(L[k] / binWidth) + 1)); maxCells = max(maxCells, ncell[k]); }
+    int bits = 1;
+    while ((1 << bits) < maxCells) bits++;
+    newAtomOfSlot.assign(paddedAtoms, -1);
+    ownedUnits.clear();
+    vector<pair<unsigned long long, int> > keyed;
+    for (int g = 0; g < R; g++) {
+        keyed.clear();
+        for (int i = groupStart[g]; i < groupStart[g + 1]; i++) {
+            const int u = byX[i];
+            unsigned c[3];
+            for (int k = 0; k < 3; k++) c[k] = (unsigned) max(0, min(ncell[k] - 1, (int) floor(ref[u][k] / binWidth)));
+            keyed.push_back(make_pair(hilbertIndex(c[0], c[1], c[2], bits), u));
+        }
+        sort(keyed.begin(), keyed.end());
+        int slot = g * slotsPerRank;
+        for (size_t i = 0; i < keyed.size(); i++) {
+            const int u = keyed[i].second;
+            if (slot + (unitStart[u + 1] - unitStart[u]) > g * slotsPerRank + trailerSlot)
+                throw OpenMMException("HIP platform: internal error: a rank's slot range overflowed in the domain decomposition");
+            for (int j = unitStart[u]; j < unitStart[u + 1]; j++) newAtomOfSlot[slot++] = unitAtomList[j];
+            if (g == domain.rank) ownedUnits.push_back(u);
+        }
+    }
+}
+
 bool HipContext::reorderIfNeeded() {
     if (!reorderRequested && stepsSinceReorder < reorderInterval)
         return false;
     reorderRequested = false;
     stepsSinceReorder = 0;
-    if (!usePeriodic && sortCutoff <= 0.0)
+    if (!usePeriodic && sortCutoff <= 0.0 && !decomposed())
         return false;                       // identity order and no wrapping: nothing to do
     vector<Vec3> positions;
-    downloadPositions(positions);
-    vector<int> order, wrapHost;
-    computeOrder(positions, order, wrapHost);
+    downloadPositions(positions);           // decomposed: also completes pos[] and vel[] on this rank (units change owner below)
+    vector<int> wrapHost;
     bool orderChanged = false;
-    for (int s = 0; s < numAtoms; s++)
-        if (hostAtomOfSlot[s] != order[s]) { orderChanged = true; break; }
-    for (int s = 0; s < numAtoms; s++) { hostAtomOfSlot[s] = order[s]; hostSlotOfAtom[order[s]] = s; }
+    if (decomposed()) {
+        vector<int> newAtomOfSlot;
+        computeOrderDecomposed(positions, newAtomOfSlot, wrapHost);
+        orderChanged = newAtomOfSlot != hostAtomOfSlot;
+        hostAtomOfSlot.swap(newAtomOfSlot);
+        for (int s = 0; s < paddedAtoms; s++)
+            if (hostAtomOfSlot[s] >= 0) hostSlotOfAtom[hostAtomOfSlot[s]] = s;
+    }
+    else {
+        vector<int> order;
+        computeOrder(positions, order, wrapHost);
+        for (int s = 0; s < numAtoms; s++)
+            if (hostAtomOfSlot[s] != order[s]) { orderChanged = true; break; }
+        for (int s = 0; s < numAtoms; s++) { hostAtomOfSlot[s] = order[s]; hostSlotOfAtom[order[s]] = s; }
+    }
     HIP_CHECK(ommhip_memcpy_h2d(wrap.ptr, wrapHost.data(), sizeof(int) * wrapHost.size(), stream));
     HIP_CHECK(ommhip_memcpy_h2d(atomOfSlot.ptr, hostAtomOfSlot.data(), sizeof(int) * paddedAtoms, stream));
     HIP_CHECK(ommhip_memcpy_h2d(slotOfAtom.ptr, hostSlotOfAtom.data(), sizeof(int) * numAtoms, stream));
+    if (decomposed()) fillPosSlotFromPos();
     sync();
     // wrap offsets may have changed even when the order did not: listeners rebuild their slot data either way
     for (size_t i = 0; i < listeners.size(); i++) listeners[i]->atomsReordered();

@@ -9,6 +9,7 @@
  * Each nonbonded kernel owns its own float posq/sigEps/neighbour list in slot order.
  */
 #include "openmm_hip_kernels.h"
+#include "openmm_hip_comm.h"
 #include "openmm/OpenMMException.h"
 #include "openmm/Vec3.h"
 #include <cstddef>
@@ -55,9 +56,17 @@ public:
     virtual void positionsSet() = 0;
 };
 
+/** Place of this process in a domain-decomposed run (one box on several GPUs); ranks == 1 is the ordinary case.
+ *  The communicator is owned by the HipContext that receives it. */
+struct HipDomain {
+    HipDomain() : ranks(1), rank(0), comm(NULL) {}
+    int ranks, rank;
+    ommhip_comm* comm;
+};
+
 class HipContext {
 public:
-    HipContext(const System& system, int deviceIndex, bool hostMode);
+    HipContext(const System& system, int deviceIndex, bool hostMode, const HipDomain& domain = HipDomain());
     ~HipContext();
     void setAsCurrent();
     void sync();
@@ -118,6 +127,28 @@ public:
     void addListener(HipContextListener* l) { listeners.push_back(l); }
     void removeListener(HipContextListener* l);
 
+    // ---- domain decomposition (ranks > 1): this rank owns the slots [ownSlot0, ownSlot1) -- a slab of the box along x --
+    //      integrates the atoms in them and computes the forces on them; positions of ALL atoms are replicated through posSlot
+    //      (double4, slot order), which the ranks all-gather in place after every integration step.  The last slot of each
+    //      rank's range (trailerSlot) never holds an atom: it carries the rank's momentum through the same all-gather.
+    HipDomain domain;
+    int slotsPerRank, ownSlot0, ownSlot1, trailerSlot;
+    bool decomposed() const { return domain.ranks > 1; }
+    DeviceBuffer posSlot, velSlot;
+    /** Enqueue the all-gather of posSlot on the main stream (after the integration kernel wrote this rank's part). */
+    void allGatherPositions();
+    /** Make pos[] and vel[] (atom order) complete and current on this rank: before a re-sort and before downloads. */
+    void gatherState();
+    /** posSlot[s] = pos[atomOfSlot[s]] for every slot: after an upload of all positions or a re-sort (no communication). */
+    void fillPosSlotFromPos();
+    /** Sum of one double over the ranks, the same bits everywhere (host all-gather + fixed-order sum). */
+    double sumOverRanks(double v);
+    /** Integration units (constraint-connected groups of atoms): CSR over units in atom-index order of their first atom. */
+    std::vector<int> unitStart, unitAtomList, unitOfAtom;
+    int maxUnitSize;
+    /** Units owned by this rank after the last re-sort (indices into unitStart). */
+    std::vector<int> ownedUnits;
+
     // ---- immutable after construction
     int numAtoms, paddedAtoms;
     bool hostMode;                 // true: host vectors are authoritative (Reference integrator etc.)
@@ -144,6 +175,8 @@ public:
 
 private:
     void computeOrder(const std::vector<Vec3>& positions, std::vector<int>& order, std::vector<int>& wrapOut);
+    void computeOrderDecomposed(const std::vector<Vec3>& positions, std::vector<int>& newAtomOfSlot, std::vector<int>& wrapOut);
+    void findUnits(const System& system);
     std::vector<HipContextListener*> listeners;
     void* pmeForkEvent = NULL;
     void* pmeDoneEvent = NULL;

@@ -189,12 +189,52 @@ HipConstraints::HipConstraints(const System& system, HipPlatform::PlatformData& 
                 unitAtomsHost.insert(unitAtomsHost.end(), at, at + 4);
                 unitDistHost.insert(unitDistHost.end(), d, d + 4);
             }
-        numUnits = (int) unitAtomsHost.size() / 4;
-        uploadVector(unitAtoms, unitAtomsHost, hip.stream);
-        uploadVector(unitDist, unitDistHost, hip.stream);
-        cmScratch.allocate(sizeof(double) * (4 + 4 * (size_t) ((numUnits + 127) / 128)));
+        allUnitAtoms.swap(unitAtomsHost);
+        allUnitDist.swap(unitDistHost);
+        const size_t maxUnits = allUnitAtoms.size() / 4;
+        unitAtoms.allocate(sizeof(int) * 4 * max(maxUnits, (size_t) 1));
+        unitDist.allocate(sizeof(double) * 4 * max(maxUnits, (size_t) 1));
+        cmScratch.allocate(sizeof(double) * (4 + 4 * ((maxUnits + 127) / 128)));
         HIP_CHECK(ommhip_memset(cmScratch.ptr, 0, cmScratch.bytes, hip.stream));
+        uploadOwnedUnits();
     }
+    hip.addListener(this);
+}
+
+HipConstraints::~HipConstraints() {
+    hip.removeListener(this);
+}
+
+void HipConstraints::atomsReordered() {
+    // (the momentum trailers stay valid: ownership changed, the velocities and hence the sum over the ranks did not)
+    if (hip.decomposed()) uploadOwnedUnits();
+}
+
+void HipConstraints::uploadOwnedUnits() {
+    const size_t total = allUnitAtoms.size() / 4;
+    if (total == 0) return;
+    if (!hip.decomposed()) {
+        numUnits = (int) total;
+        HIP_CHECK(ommhip_memcpy_h2d(unitAtoms.ptr, allUnitAtoms.data(), sizeof(int) * allUnitAtoms.size(), hip.stream));
+        HIP_CHECK(ommhip_memcpy_h2d(unitDist.ptr, allUnitDist.data(), sizeof(double) * allUnitDist.size(), hip.stream));
+        HIP_CHECK(ommhip_stream_sync(hip.stream));
+        return;
+    }
+    // a unit belongs to the rank that holds its first atom (constraint-connected atoms are never split between ranks)
+    std::vector<int> atoms;
+    std::vector<double> dist;
+    for (size_t u = 0; u < total; u++) {
+        const int s = hip.hostSlotOfAtom[allUnitAtoms[4 * u]];
+        if (s < hip.ownSlot0 || s >= hip.ownSlot1) continue;
+        atoms.insert(atoms.end(), allUnitAtoms.begin() + 4 * u, allUnitAtoms.begin() + 4 * u + 4);
+        dist.insert(dist.end(), allUnitDist.begin() + 4 * u, allUnitDist.begin() + 4 * u + 4);
+    }
+    numUnits = (int) atoms.size() / 4;
+    if (numUnits > 0) {
+        HIP_CHECK(ommhip_memcpy_h2d(unitAtoms.ptr, atoms.data(), sizeof(int) * atoms.size(), hip.stream));
+        HIP_CHECK(ommhip_memcpy_h2d(unitDist.ptr, dist.data(), sizeof(double) * dist.size(), hip.stream));
+    }
+    HIP_CHECK(ommhip_stream_sync(hip.stream));
 }
 
 void HipConstraints::fusedStep(int integrator, const ommhip_integrator_state& state, double tol) {
@@ -205,7 +245,14 @@ void HipConstraints::fusedStep(int integrator, const ommhip_integrator_state& st
     u.remove_cm = hip.cmRemovalPending && hip.momentumValid ? 1 : 0;
     u.inv_total_mass = totalMass > 0 ? 1.0 / totalMass : 0.0;
     u.cm_scratch = cmScratch.as<double>();
+    u.pos_slot = NULL; u.ranks = 1; u.rank = 0; u.slots_per_rank = 0; u.trailer_slot = 0;
+    if (hip.decomposed()) {
+        u.pos_slot = hip.posSlot.ptr; u.ranks = hip.domain.ranks; u.rank = hip.domain.rank;
+        u.slots_per_rank = hip.slotsPerRank; u.trailer_slot = hip.trailerSlot;
+    }
     HIP_CHECK(ommhip_integrate_fused(integrator, &state, &u, hip.stream));
+    // every rank now needs everybody's new positions (and momentum trailer): one in-place all-gather on the same stream
+    if (hip.decomposed()) hip.allGatherPositions();
     hip.cmRemovalPending = false;
     hip.momentumValid = true;
 }
@@ -382,16 +429,19 @@ void HipApplyConstraintsKernel::apply(ContextImpl& context, double tol) {
     hip.setAsCurrent();
     HipConstraints& constraints = data.getDeviceConstraints(context.getSystem());
     if (!constraints.hasConstraints()) return;
+    if (hip.decomposed()) hip.gatherState();       // every rank constrains all atoms (identical results), then refills the all-gather buffer
     // ReferenceKernels.cpp:318-324: constrain the current positions in place
     HIP_CHECK(ommhip_memcpy_d2d(hip.xp.ptr, hip.pos.ptr, hip.pos.bytes, hip.stream));
     constraints.apply(hip.xp.ptr, tol);
     HIP_CHECK(ommhip_memcpy_d2d(hip.pos.ptr, hip.xp.ptr, hip.pos.bytes, hip.stream));
+    if (hip.decomposed()) hip.fillPosSlotFromPos();
 }
 void HipApplyConstraintsKernel::applyToVelocities(ContextImpl& context, double tol) {
     HipContext& hip = *data.hip;
     hip.setAsCurrent();
     HipConstraints& constraints = data.getDeviceConstraints(context.getSystem());
     if (!constraints.hasConstraints()) return;
+    if (hip.decomposed()) hip.gatherState();
     constraints.applyToVelocities(hip.vel.ptr, tol);
     hip.momentumValid = false;
 }
@@ -451,21 +501,131 @@ void HipCalcNonbondedForceKernel::getNeighborListStats(long long* out) {
     out[0] = numParticles; out[1] = hip.paddedAtoms; out[2] = chunks; out[3] = rows; out[4] = nl.max_chunks; out[5] = state[4];
 }
 
+static vector<double> bsplineModuli(int n);
+
+void HipCalcNonbondedForceKernel::setupPmeDecomposed() {
+    // buffers of ommhip_pme_reciprocal_dd (layouts: include/openmm_hip_kernels.h, ommhip_pme)
+    const int R = hip.domain.ranks, nx = gridSize[0], ny = gridSize[1], nz = gridSize[2], nzc = nz / 2 + 1, nxl = nx / R, nyl = ny / R;
+    ddHalo = getenv("OPENMM_HIP_DD_HALO") != NULL ? atoi(getenv("OPENMM_HIP_DD_HALO")) : 6;     // potential planes kept beyond the slab on each side
+    ddHalo = max(0, min(ddHalo, nxl - 4));
+    if (nxl < 5)
+        throw OpenMMException("HIP platform: the PME grid is too coarse along x for this many GPUs (fewer than 5 planes per rank)");
+    uploadVector(moduliX, bsplineModuli(nx), hip.stream);
+    uploadVector(moduliY, bsplineModuli(ny), hip.stream);
+    uploadVector(moduliZ, bsplineModuli(nz), hip.stream);
+    DeviceBuffer* tw[3] = {&twiddleX, &twiddleY, &twiddleZ};
+    for (int d = 0; d < 3; d++) {
+        const int n = gridSize[d];
+        vector<float> t(2 * (size_t) n);
+        for (int k = 0; k < n; k++) { t[2 * k] = (float) cos(2.0 * M_PI * k / n); t[2 * k + 1] = (float) -sin(2.0 * M_PI * k / n); }
+        uploadVector(*tw[d], t, hip.stream);
+    }
+    eterm.allocate(sizeof(float) * (size_t) nx * nyl * nzc);
+    const size_t gridBytes = (sizeof(float) * (size_t) (nxl + 2 * ddHalo + 4) * ny * nz + 15) / 16 * 16;
+    gridReal.allocate(gridBytes);
+    if (hip.extraClearPtr == NULL) { hip.extraClearPtr = gridReal.ptr; hip.extraClearBytes = gridBytes; pme.grid_precleared = 1; }
+    gridComplex.allocate(sizeof(float) * 2 * (size_t) nxl * ny * nzc);
+    gridComplex2.allocate(sizeof(float) * 2 * (size_t) nx * nyl * nzc);
+    ddError.allocate(sizeof(int) * 4);
+    HIP_CHECK(ommhip_memset(ddError.ptr, 0, ddError.bytes, hip.stream));
+    HIP_CHECK(ommhip_host_malloc((void**) &pinnedDdError, sizeof(int) * 4));
+    pinnedDdError[0] = 0;
+    pme.nx = nx; pme.ny = ny; pme.nz = nz; pme.alpha = ewaldAlpha;
+    pme.moduli_x = moduliX.as<double>(); pme.moduli_y = moduliY.as<double>(); pme.moduli_z = moduliZ.as<double>();
+    pme.eterm = eterm.ptr; pme.grid_real = gridReal.ptr; pme.grid_complex = gridComplex.ptr; pme.grid_complex2 = gridComplex2.ptr;
+    pme.twiddle_x = twiddleX.ptr; pme.twiddle_y = twiddleY.ptr; pme.twiddle_z = twiddleZ.ptr;
+    pme.dd_ranks = R; pme.dd_rank = hip.domain.rank; pme.dd_halo = ddHalo; pme.comm = hip.domain.comm; pme.dd_error = ddError.as<int>();
+    etermDirty = true;
+}
+
+void HipCalcNonbondedForceKernel::checkDecomposedFlags() {
+    // filled by an asynchronous copy queued a few evaluations ago: an owned atom left the potential planes this rank holds
+    if (pinnedDdError != NULL && pinnedDdError[0] != 0)
+        throw OpenMMException("HIP platform: an atom drifted out of the PME planes its rank holds between two re-sorts; "
+                              "lower OPENMM_HIP_REORDER_INTERVAL or raise OPENMM_HIP_DD_HALO");
+}
+
+double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool includeForces, bool includeEnergy, bool includeDirect, bool includeReciprocal) {
+    // One rank of a decomposed evaluation.  Separate launches on one stream: positions (replicated) -> posq,
+    // list for the owned blocks, charge spreading on the owned planes, slab FFT with two all-to-alls, pair kernel for the
+    // owned blocks, halo planes, interpolation for the owned atoms.
+    if (nonbondedMethod != PME || !includeDirect || !includeReciprocal)
+        throw OpenMMException("HIP platform: multi-GPU runs support NonbondedForce with PME, direct and reciprocal space in one force group");
+    if (hip.box[1] != 0.0 || hip.box[3] != 0.0 || hip.box[4] != 0.0)
+        throw OpenMMException("HIP platform: multi-GPU runs need a rectangular periodic box");
+    const int ie = includeEnergy ? 1 : 0;
+    nl.pbc = 1;
+    nl.dd_mode = 1;
+    nl.first_block = hip.ownSlot0 / OMMHIP_TILE; nl.owned_blocks = hip.slotsPerRank / OMMHIP_TILE;
+    nl.pos_slot = hip.posSlot.ptr; nl.pos_scatter = hip.pos.ptr;
+    foldExclusions = numExclusionPairs > 0;
+    checkDecomposedFlags();
+    if (nl.max_chunks == 0) allocateNeighborList((int) (estimateChunks() * 1.4 / hip.domain.ranks) + 256);
+    if (stateCopyPending && (pinnedState[2] != 0 || pinnedState[1] > nl.max_chunks)) {
+        fprintf(stderr, "HIP platform: neighbour list overflowed (%d chunks needed, %d allocated); growing and rebuilding\n", pinnedState[1], nl.max_chunks);
+        hip.sync();
+        allocateNeighborList((int) (pinnedState[1] * 1.5) + 64);
+        forceRebuild = true;
+    }
+    while (true) {
+        if (forceRebuild) {
+            const int request[3] = {1, 0, 0};
+            HIP_CHECK(ommhip_memcpy_h2d(nlState.ptr, request, sizeof(request), hip.stream));
+        }
+        const bool clear = hip.takePendingClear();
+        HIP_CHECK(ommhip_nl_prepare(&nl, hip.pos.ptr, hip.wrap.ptr, clear ? hip.force.ptr : NULL, clear ? hip.force.bytes : 0,
+                                    clear ? hip.extraClearPtr : NULL, clear ? hip.extraClearBytes : 0, hip.stream));
+        HIP_CHECK(ommhip_nl_rebuild_if_requested(&nl, hip.stream));
+        if (!forceRebuild) break;
+        HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
+        hip.sync();
+        if (pinnedState[2] == 0 && pinnedState[1] * 1.5 <= nl.max_chunks) { forceRebuild = false; break; }
+        allocateNeighborList((int) (pinnedState[1] * 1.6) + 64);
+    }
+    fillPmeStruct();
+    pme.phases = OMMHIP_PME_ALL;
+    // reciprocal space first (its collectives are latency-bound), the pair kernel between the transforms and the interpolation
+    pme.phases = OMMHIP_PME_SPREAD_ONLY;
+    HIP_CHECK(ommhip_pme_reciprocal_dd(&pme, posq.ptr, hip.paddedAtoms, hip.ownSlot0, hip.ownSlot1, blockCenter.ptr, blockHalf.ptr,
+                                       hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+    pme.phases = OMMHIP_PME_AFTER_SPREAD;
+    HIP_CHECK(ommhip_nb_direct(&nl, &params, sigEps.ptr, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+    HIP_CHECK(ommhip_pme_reciprocal_dd(&pme, posq.ptr, hip.paddedAtoms, hip.ownSlot0, hip.ownSlot1, blockCenter.ptr, blockHalf.ptr,
+                                       hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+    pme.phases = OMMHIP_PME_ALL;
+    if ((++evaluationCount & 15) == 0) {
+        HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
+        HIP_CHECK(ommhip_memcpy_d2h(pinnedDdError, ddError.ptr, sizeof(int), hip.stream));
+        stateCopyPending = true;
+    }
+    // 1-4 exceptions: evaluated by every rank, energy from rank 0 (as the bonded terms, HipTermForce::execute)
+    ommhip_term_batch t14 = {OMMHIP_TERM_EXCEPTION14, {num14, exceptionAtomsD.as<int>(), exceptionParamsD.as<double>()},
+                             exceptionsArePeriodic ? 1 : 0, chargeD.as<double>(), ewaldAlpha};
+    hip.addTerms(t14, includeEnergy && hip.domain.rank == 0);
+    double energy = 0;
+    // host-side constants: returned by every rank (the device energies are summed over the ranks in finishComputation)
+    if (includeEnergy)
+        energy += dispersionCoefficient / (hip.box[0] * hip.box[2] * hip.box[5]) + selfEnergy;
+    return energy;
+}
+
 HipCalcNonbondedForceKernel::~HipCalcNonbondedForceKernel() {
     liveNonbondedKernels.erase(std::remove(liveNonbondedKernels.begin(), liveNonbondedKernels.end(), this), liveNonbondedKernels.end());
     hip.removeListener(this);
     if (hip.extraClearPtr != NULL && hip.extraClearPtr == gridReal.ptr) { hip.extraClearPtr = NULL; hip.extraClearBytes = 0; }
     if (pinnedState != NULL) ommhip_host_free(pinnedState);
+    if (pinnedDdError != NULL) ommhip_host_free(pinnedDdError);
 }
 
 void HipCalcNonbondedForceKernel::atomsReordered() { slotParamsDirty = true; forceRebuild = true; }
 void HipCalcNonbondedForceKernel::boxChanged() { etermDirty = true; forceRebuild = true; }
 void HipCalcNonbondedForceKernel::positionsSet() { forceRebuild = true; }
 
-static int findLegalFftDimension(int minimum) {
-    // smallest size >= minimum that the LDS FFT handles (2,3,5,7-smooth); same role as CudaFFT3D::findLegalDimension
+static int findLegalFftDimension(int minimum, int multipleOf = 1) {
+    // smallest size >= minimum that the LDS FFT handles (2,3,5,7-smooth); same role as CudaFFT3D::findLegalDimension.
+    // Slab-decomposed runs also need the x and y sizes to be multiples of the number of ranks.
     int n = max(minimum, 2);
-    while (!ommhip_fft_supported_size(n)) n++;
+    while (!ommhip_fft_supported_size(n) || n % multipleOf != 0) n++;
     return n;
 }
 
@@ -567,7 +727,7 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     }
     else if (nonbondedMethod == PME) {
         NonbondedForceImpl::calcPMEParameters(system, force, ewaldAlpha, gridSize[0], gridSize[1], gridSize[2], false);
-        for (int k = 0; k < 3; k++) gridSize[k] = findLegalFftDimension(gridSize[k]);
+        for (int k = 0; k < 3; k++) gridSize[k] = findLegalFftDimension(gridSize[k], k < 2 ? hip.domain.ranks : 1);
     }
     usesPeriodic = nonbondedMethod == CutoffPeriodic || nonbondedMethod == Ewald || nonbondedMethod == PME;
     exceptionsArePeriodic = usesPeriodic && force.getExceptionsUsePeriodicBoundaryConditions();
@@ -649,7 +809,7 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     }
     params.switch_distance = switchingDistance;
     params.direct_grid = directGridOverride;
-    if (nonbondedMethod == PME) setupPme();
+    if (nonbondedMethod == PME) { if (hip.decomposed()) setupPmeDecomposed(); else setupPme(); }
     if (nonbondedMethod == Ewald)
         ewaldStructure.allocate(sizeof(double) * 2 * (size_t) kmax[0] * (2 * kmax[1] - 1) * (2 * kmax[2] - 1));
     hip.sync();
@@ -843,6 +1003,8 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
         HIP_CHECK(ommhip_set_slot_params(chargeD.as<double>(), sigmaD.as<double>(), epsilonD.as<double>(), hip.atomOfSlot.as<int>(), hip.paddedAtoms, posq.ptr, sigEps.ptr, hip.stream));
         slotParamsDirty = false;
     }
+    if (hip.decomposed())
+        return executeDecomposed(context, includeForces, includeEnergy, includeDirect, includeReciprocal);
     double energy = 0;
     const int ie = includeEnergy ? 1 : 0;
     bool pmeLaunched = false, frontLaunched = false, fftLaunched = false;
@@ -1038,7 +1200,9 @@ void HipTermForce::execute(bool includeEnergy) {
     HipContext& hip = *data.hip;
     hip.setAsCurrent();
     if (registrationId >= 0 && hip.termsLaunched(registrationId)) return;         // went out with the front launch of this evaluation
-    hip.addTerms(batch(), includeEnergy, registrationId);
+    // decomposed runs: every rank evaluates all bonded terms (they are few; forces on atoms it does not own are never read),
+    // their energy is taken from rank 0 only
+    hip.addTerms(batch(), includeEnergy && (!hip.decomposed() || hip.domain.rank == 0), registrationId);
 }
 
 void HipCalcHarmonicBondForceKernel::initialize(const System& system, const HarmonicBondForce& force) {
@@ -1127,6 +1291,14 @@ double HipIntegratorBase::kineticEnergy(double timeShift) {
     // ReferenceKernels.cpp:146-176
     HipContext& hip = *data.hip;
     hip.setAsCurrent();
+    if (hip.decomposed()) {
+        // rare (a State with energies): complete velocities -- and forces, if the estimate is time-shifted -- on every rank,
+        // then every rank computes the same number
+        hip.gatherState();
+        if (timeShift != 0.0)
+            for (int c = 0; c < 3; c++)
+                HIP_CHECK(ommhip_comm_all_gather(hip.domain.comm, hip.force.as<long long>() + (size_t) c * hip.paddedAtoms, sizeof(long long) * (size_t) hip.slotsPerRank, hip.stream));
+    }
     ommhip_integrator_state s;
     fillState(s, 0.0);
     HIP_CHECK(ommhip_shifted_velocities(&s, timeShift, hip.tempVel.ptr, hip.stream));
@@ -1154,6 +1326,7 @@ void HipIntegrateVerletStepKernel::execute(ContextImpl& context, const VerletInt
     fillState(s, dt);
     HipConstraints& constraints = data.getDeviceConstraints(context.getSystem());
     if (constraints.fusedStepAvailable()) constraints.fusedStep(OMMHIP_INTEGRATOR_VERLET, s, integrator.getConstraintTolerance());
+    else if (hip.decomposed()) throw OpenMMException("HIP platform: multi-GPU runs need constraints that form SETTLE waters or X-H clusters (no CCMA)");
     else {
         HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_VERLET_1, &s, hip.stream));
         if (constraints.hasConstraints()) constraints.apply(hip.xp.ptr, integrator.getConstraintTolerance());
@@ -1188,6 +1361,7 @@ void HipIntegrateLangevinStepKernel::execute(ContextImpl& context, const Langevi
     s.noisescale = sqrt(kT * (1 - s.vscale * s.vscale));
     HipConstraints& constraints = data.getDeviceConstraints(context.getSystem());
     if (constraints.fusedStepAvailable()) constraints.fusedStep(OMMHIP_INTEGRATOR_LANGEVIN, s, integrator.getConstraintTolerance());
+    else if (hip.decomposed()) throw OpenMMException("HIP platform: multi-GPU runs need constraints that form SETTLE waters or X-H clusters (no CCMA)");
     else {
         HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_LANGEVIN_1, &s, hip.stream));
         if (constraints.hasConstraints()) constraints.apply(hip.xp.ptr, integrator.getConstraintTolerance());
@@ -1216,6 +1390,7 @@ void HipIntegrateLangevinMiddleStepKernel::execute(ContextImpl& context, const L
     s.noisescale = sqrt(kT * (1 - s.vscale * s.vscale));
     HipConstraints& constraints = data.getDeviceConstraints(context.getSystem());
     if (constraints.fusedStepAvailable()) constraints.fusedStep(OMMHIP_INTEGRATOR_LANGEVIN_MIDDLE, s, tol);
+    else if (hip.decomposed()) throw OpenMMException("HIP platform: multi-GPU runs need constraints that form SETTLE waters or X-H clusters (no CCMA)");
     else {
         HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_LMIDDLE_1, &s, hip.stream));
         if (constraints.hasConstraints()) constraints.applyToVelocities(hip.vel.ptr, tol);
@@ -1248,6 +1423,7 @@ void HipRemoveCMMotionKernel::execute(ContextImpl& context) {
         hip.cmRemovalPending = true;
         return;
     }
+    if (hip.decomposed()) hip.gatherState();     // all velocities on every rank; each removes the same centre-of-mass motion
     HIP_CHECK(ommhip_remove_cm_motion(hip.vel.ptr, hip.numAtoms, scratch.as<double>(), hip.stream));
     hip.momentumValid = false;
 }

@@ -17,9 +17,13 @@
 namespace OpenMM {
 
 /** Device-side constraint data shared by the integrators and ApplyConstraints. */
-class HipConstraints {
+class HipConstraints : public HipContextListener {
 public:
     HipConstraints(const System& system, HipPlatform::PlatformData& data);
+    ~HipConstraints();
+    void atomsReordered();
+    void boxChanged() {}
+    void positionsSet() {}
     /** Constrain trial positions `target` (double4[N]) against the reference positions ctx.pos. */
     void apply(void* target, double tol);
     /** Remove constrained components from velocities `target` (double4[N], w = 1/m). */
@@ -27,10 +31,14 @@ public:
     bool hasConstraints() const { return numSettle + numShake + numCcma > 0; }
     /** True when every constraint sits in a SETTLE water or a SHAKE cluster, so a whole step fits one launch
      *  (ommhip_integrate_fused); OPENMM_HIP_DISABLE_FUSED_STEP=1 forces the staged kernels. */
-    bool fusedStepAvailable() const { return numUnits > 0; }
+    bool fusedStepAvailable() const { return !allUnitAtoms.empty(); }
     /** Launch the fused step; consumes a pending CM-motion removal and leaves the new total momentum on the device. */
     void fusedStep(int integrator, const ommhip_integrator_state& state, double tol);
 private:
+    /** Upload the integration units this rank owns (all of them on one GPU). */
+    void uploadOwnedUnits();
+    std::vector<int> allUnitAtoms;        // int4 per unit
+    std::vector<double> allUnitDist;      // double4 per unit
     int numUnits;
     double totalMass;
     DeviceBuffer unitAtoms, unitDist, cmScratch;
@@ -116,6 +124,13 @@ private:
     void setupPme();
     void fillPmeStruct();
     void launchPme(int includeEnergy, bool spreadDone = false, bool fftDone = false);
+    /** The evaluation on one rank of a domain-decomposed run (PME only). */
+    double executeDecomposed(ContextImpl& context, bool includeForces, bool includeEnergy, bool includeDirect, bool includeReciprocal);
+    void setupPmeDecomposed();
+    void checkDecomposedFlags();
+    DeviceBuffer gridComplex2, ddError;
+    int* pinnedDdError = NULL;
+    int ddHalo = 0;
     void rebuildEterm();
     int estimateChunks() const;
     HipPlatform::PlatformData& data;

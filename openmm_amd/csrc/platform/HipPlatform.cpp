@@ -28,6 +28,7 @@
 #include "openmm/LangevinMiddleIntegrator.h"
 #include "openmm/VerletIntegrator.h"
 #include "openmm/kernels.h"
+#include <cstdio>
 #include <cstdlib>
 #include <sstream>
 
@@ -148,6 +149,12 @@ HipPlatform::HipPlatform() {
     platformProperties.push_back(HipPrecision());
     platformProperties.push_back(HipDeterministicForces());
     platformProperties.push_back(HipDisablePmeStream());
+    platformProperties.push_back(HipRanks());
+    platformProperties.push_back(HipRank());
+    platformProperties.push_back(HipCommId());
+    setPropertyDefaultValue(HipRanks(), "1");
+    setPropertyDefaultValue(HipRank(), "0");
+    setPropertyDefaultValue(HipCommId(), "");
     setPropertyDefaultValue(HipDeviceIndex(), "");
     setPropertyDefaultValue(HipDeviceName(), "");
     setPropertyDefaultValue(HipPrecision(), "mixed");
@@ -199,7 +206,40 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
             deviceIndex = atoi(getenv("LOCAL_RANK")) % count;
     }
     HipModeInfo mode = classifyContext(context);
-    PlatformData* data = new PlatformData(context.getSystem(), deviceIndex, mode.hostMode);
+    // ---- one box on several GPUs (one process per GPU)
+    HipDomain domain;
+    string commId;
+    if (properties.find(HipRanks()) != properties.end()) stringstream(properties.find(HipRanks())->second) >> domain.ranks;
+    if (properties.find(HipRank()) != properties.end()) stringstream(properties.find(HipRank())->second) >> domain.rank;
+    if (properties.find(HipCommId()) != properties.end()) commId = properties.find(HipCommId())->second;
+    if (domain.ranks < 1 || domain.rank < 0 || domain.rank >= domain.ranks)
+        throw OpenMMException("HIP platform: illegal Ranks/Rank properties");
+    if (domain.ranks > 1) {
+        if (mode.hostMode || mode.hasFallbackForces || mode.referenceNonbonded)
+            throw OpenMMException("HIP platform: a multi-GPU Context supports NonbondedForce (PME), HarmonicBond/Angle, PeriodicTorsion and CMMotionRemover with the Verlet, Langevin and LangevinMiddle integrators");
+        int count = 0;
+        HIP_CHECK(ommhip_device_count(&count));
+        if (deviceIndex < 0 || deviceIndex >= count) throw OpenMMException("HIP platform: illegal DeviceIndex");
+        HIP_CHECK(ommhip_set_device(deviceIndex));       // the communicator binds to the current device
+        if (commId.compare(0, 9, "callback:") == 0) {
+            unsigned long long fn = 0, user = 0;
+            if (sscanf(commId.c_str() + 9, "%llu:%llu", &fn, &user) < 1 || fn == 0)
+                throw OpenMMException("HIP platform: malformed callback CommId");
+            HIP_CHECK(ommhip_comm_create_callback((ommhip_host_all_gather_fn) (size_t) fn, (void*) (size_t) user, domain.rank, domain.ranks, &domain.comm));
+        }
+        else {
+            int rc = ommhip_comm_create_rccl(commId.c_str(), domain.rank, domain.ranks, &domain.comm);
+            if (rc != 0) {
+                stringstream msg;
+                msg << "HIP platform: could not create the RCCL communicator (code " << rc << ": " << ommhip_error_string(rc) << "); CommId must be the 256-character hex id from ommhip_comm_unique_id()";
+                throw OpenMMException(msg.str());
+            }
+        }
+    }
+    PlatformData* data = new PlatformData(context.getSystem(), deviceIndex, mode.hostMode, domain);
+    { stringstream v; v << domain.ranks; data->propertyValues[HipRanks()] = v.str(); }
+    { stringstream v; v << domain.rank; data->propertyValues[HipRank()] = v.str(); }
+    data->propertyValues[HipCommId()] = domain.comm != NULL ? ommhip_comm_transport(domain.comm) : "";
     data->referenceNonbonded = mode.referenceNonbonded;
     data->hip->hasFallbackForces = mode.hasFallbackForces;
     stringstream dev;
@@ -223,9 +263,9 @@ void HipPlatform::contextDestroyed(ContextImpl& context) const {
     delete data;
 }
 
-HipPlatform::PlatformData::PlatformData(const System& system, int deviceIndex, bool hostMode) : ReferencePlatform::PlatformData(system),
+HipPlatform::PlatformData::PlatformData(const System& system, int deviceIndex, bool hostMode, const HipDomain& domain) : ReferencePlatform::PlatformData(system),
         hip(NULL), system(&system), referenceNonbonded(false), deviceConstraints(NULL) {
-    hip = new HipContext(system, deviceIndex, hostMode);
+    hip = new HipContext(system, deviceIndex, hostMode, domain);
 }
 
 HipPlatform::PlatformData::~PlatformData() {

@@ -19,6 +19,7 @@ namespace OpenMM {
 
 class HipContext;
 class HipConstraints;
+struct HipDomain;
 
 class HipPlatform : public ReferencePlatform {
 public:
@@ -39,6 +40,12 @@ public:
     static const std::string& HipPrecision() { static const std::string key = "Precision"; return key; }
     static const std::string& HipDeterministicForces() { static const std::string key = "DeterministicForces"; return key; }
     static const std::string& HipDisablePmeStream() { static const std::string key = "DisablePmeStream"; return key; }
+    /** One box on several GPUs, one process per GPU: "Ranks" = number of processes, "Rank" = this one's index, "CommId" = the
+     *  ncclUniqueId (hex) created with ommhip_comm_unique_id() on rank 0 and distributed by the launcher, or
+     *  "callback:<address of an ommhip_host_all_gather_fn>:<user pointer>" for the host-staged test transport. */
+    static const std::string& HipRanks() { static const std::string key = "Ranks"; return key; }
+    static const std::string& HipRank() { static const std::string key = "Rank"; return key; }
+    static const std::string& HipCommId() { static const std::string key = "CommId"; return key; }
     static PlatformData& getData(ContextImpl& context) {
         return *reinterpret_cast<PlatformData*>(context.getPlatformData());
     }
@@ -47,7 +54,7 @@ public:
 /** ReferencePlatform::PlatformData (host vectors for fallback kernels) + the device context. */
 class HipPlatform::PlatformData : public ReferencePlatform::PlatformData {
 public:
-    PlatformData(const System& system, int deviceIndex, bool hostMode);
+    PlatformData(const System& system, int deviceIndex, bool hostMode, const HipDomain& domain);
     ~PlatformData();
     HipConstraints& getDeviceConstraints(const System& system);
     HipContext* hip;

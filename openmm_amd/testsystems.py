@@ -180,18 +180,21 @@ def _load_fixture(w, filename):
     return w
 
 
-def dhfr_like(seed=1, n_side=22, chain_atoms=2489, relaxed=True):
+def small_solvated_chain(seed=3):
+    """The same construction at test size: a 150-atom chain (bonds, angles, torsions, 1-4s, X-H clusters) in ~660 waters."""
+    return dhfr_like(seed=seed, n_side=9, chain_atoms=150, relaxed=False, L=2.75, n_target=2130, radius=0.9)
+
+
+def dhfr_like(seed=1, n_side=22, chain_atoms=2489, relaxed=True, L=6.223, n_target=23558, radius=2.2):
     """A DHFR-sized stand-in: 23 558 atoms = a 2 489-atom flexible heteropolymer
     (bonds, angles, torsions, 1-4 exceptions, X-H constraints) solvated in TIP3P water in a 6.223 nm cube,
     PME, cutoff 0.9 nm, default Ewald tolerance -> alpha 2.92 / grid 56^3, as examples/benchmark.py 'pme'.
     """
     rng = np.random.default_rng(seed)
-    L = 6.223
-    n_target = 23558
     # --- chain: a compact self-avoiding walk of heavy atoms (0.15 nm bonds, >= 0.28 nm between atoms more
     #     than three bonds apart), each carrying 0-2 hydrogens placed away from every other heavy atom
     n_heavy = int(chain_atoms / 2.0)
-    step, min_dist, radius = 0.15, 0.28, 2.2
+    step, min_dist = 0.15, 0.28
     center = np.array([L / 2, L / 2, L / 2])
     heavy = np.zeros((n_heavy, 3))
     heavy[0] = center

@@ -1,10 +1,10 @@
 """world_size-2 `gloo` tests on CPU.
-(1) The N>1 bench path: replicas are independent (no data-path collective); the only cross-rank operations are the barrier
-    and the MAX-over-ranks of the timed region.
-(2) Force decomposition through the C ABI (first building block of DESIGN.md (e)): two ranks build the neighbour list for one
-    half of the i-blocks each (ommhip_neighbor_list.first_block / owned_blocks), run the pair kernel, and all-reduce their
-    fixed-point force buffers -- the sum must be bit for bit the single-rank buffer.  Runs on the CPU SIMT emulator build of
-    the kernels (tests/emu)."""
+(1) The timing reduction bench.py uses for N > 1 (openmm_amd/multirank.py: MAX over ranks of the timed region).
+(2) Force decomposition through the C ABI: two ranks build the neighbour list for one half of the i-blocks each
+    (ommhip_neighbor_list.first_block / owned_blocks), run the pair kernel, and all-reduce their fixed-point force buffers --
+    the sum must be bit for bit the single-rank buffer.
+(3) The WHOLE step of a domain-decomposed run on two ranks against the single-rank run of the same box.
+All kernels run on the CPU SIMT emulator build (tests/emu); the collectives of (3) go through the plugin's callback transport."""
 import os
 import subprocess
 import sys
@@ -15,22 +15,21 @@ CHILD = r'''
 import os, sys, time
 sys.path.insert(0, %r)
 import torch, torch.distributed as dist
-from openmm_amd.multirank import aggregate_throughput
+from openmm_amd.multirank import max_over_ranks, ns_per_day
 dist.init_process_group(backend="gloo")
 rank = dist.get_rank()
-elapsed = 1.0 + rank          # rank 1 is slower
-value, ms = aggregate_throughput(elapsed, steps=1000, dt_fs=2.0, group=dist.group.WORLD, device="cpu")
+elapsed = max_over_ranks(1.0 + rank, dist, device="cpu")          # rank 1 is slower
+assert abs(elapsed - 2.0) < 1e-12
 if rank == 0:
-    # both ranks did 1000 steps; the job took max(1, 2) = 2 s -> 2 replicas * 2 fs * 1000 / 2 s
-    expect = 2 * 2.0e-6 * 1000 / 2.0 * 86400
-    assert abs(value - expect) < 1e-9 * expect, (value, expect)
-    assert abs(ms - 2.0) < 1e-12
+    # ONE simulation advanced 1000 steps of 2 fs in max(1, 2) = 2 s
+    value = ns_per_day(elapsed, 1000, 2.0)
+    assert abs(value - 2.0e-6 * 1000 / 2.0 * 86400) < 1e-9
     print("OK", value)
 dist.destroy_process_group()
 '''
 
 
-def test_two_rank_aggregate_on_gloo(tmp_path):
+def test_two_rank_timing_reduction_on_gloo(tmp_path):
     script = tmp_path / "child.py"
     script.write_text(CHILD % ROOT)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
@@ -88,3 +87,85 @@ def test_two_rank_force_decomposition_is_bit_exact(tmp_path):
                           "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
                          capture_output=True, text=True, timeout=900, env=env)
     assert "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+DD_CHILD = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from openmm_amd import harness as H, testsystems as T, multirank as MR
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+H.load_hip_platform(emulated=%r)
+device = %r
+
+
+def run(props, w, steps):
+    system, nb = w.build()
+    integ = H.Integrator(H.LANGEVIN_MIDDLE, 0.002, 300.0, 1.0, seed=7)
+    ctx = H.Context(system, integ, "HIP", props)
+    ctx.setPositions(w.positions)
+    ctx.applyConstraints(1e-6)
+    ctx.setVelocitiesToTemperature(300.0, 3)
+    st0 = ctx.getState(getForces=True, getEnergy=True, getPositions=True)
+    integ.step(steps)
+    st1 = ctx.getState(getPositions=True, getVelocities=True, getEnergy=True, getForces=True)
+    info = (ctx.getPlatformProperty("Ranks"), ctx.getPlatformProperty("CommId"))
+    ctx.close()
+    return st0, st1, info
+
+
+os.environ["OPENMM_HIP_REORDER_INTERVAL"] = "3"      # a re-sort (units change owner) inside the short run
+for label, w, grid in (("water", T.water_box(8, seed=5), 24), ("solvated chain", T.small_solvated_chain(seed=3), 24)):
+    if grid:
+        w.pme_params = (float(np.sqrt(-np.log(2 * w.ewald_tol)) / w.cutoff), grid, grid, grid)
+    w.cm_remover = True
+    base = {} if device is None else {"DeviceIndex": str(device)}
+    one0, one1, _ = run(dict(base), w, %d)                                      # single-rank run of the same box, on every rank
+    props = MR.domain_properties(dist, transport="gloo", device_index=device, emulated=%r)
+    dd0, dd1, info = run(props, w, %d)
+    assert info == (str(world), "callback"), info
+    rms = np.sqrt((one0.forces ** 2).sum(1).mean())
+    err0 = np.abs(dd0.forces - one0.forces).max() / rms
+    assert err0 < 3e-5, ("initial forces", err0)       # float32 summation-order noise; TestCudaNonbondedForce.cpp:37-96 allows 1e-5 of each force in its multi-device mode
+    assert abs(dd0.potentialEnergy - one0.potentialEnergy) < 1e-6 * abs(one0.potentialEnergy) + 1e-3, (dd0.potentialEnergy, one0.potentialEnergy)
+    dpos = np.abs(dd1.positions - one1.positions).max()
+    dvel = np.abs(dd1.velocities - one1.velocities).max()
+    assert dpos < 3e-7 and dvel < 5e-5, ("trajectory", dpos, dvel)      # float32 force noise (1e-5 of the RMS force) integrated over the run
+    assert abs(dd1.kineticEnergy - one1.kineticEnergy) < 1e-6 * one1.kineticEnergy
+    err1 = np.abs(dd1.forces - one1.forces).max() / rms
+    assert err1 < 1e-4, ("final forces", err1)
+    # every rank reports the same State
+    check = torch.tensor([dd1.potentialEnergy, dd1.kineticEnergy, float(dd1.positions.sum())], dtype=torch.float64)
+    both = [torch.zeros_like(check) for _ in range(world)]
+    dist.all_gather(both, check)
+    assert all(torch.equal(b, both[0]) for b in both), both
+    if rank == 0:
+        print(label, "forces", err0, err1, "trajectory", dpos, dvel, flush=True)
+if rank == 0:
+    print("OK")
+dist.destroy_process_group()
+'''
+
+
+def _run_dd_child(tmp_path, emulated, device, steps, port, nproc=2):
+    script = tmp_path / "dd_child.py"
+    script.write_text(DD_CHILD % (ROOT, emulated, device, steps, emulated, steps))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=1500, env=env)
+    assert "OK" in out.stdout, out.stdout[-3000:] + out.stderr[-4000:]
+    return out.stdout
+
+
+def test_two_rank_domain_decomposition_whole_step_on_emulator(tmp_path):
+    """The WHOLE step of a decomposed run (DESIGN.md (e)) with world_size 2: positions all-gathered, list + pair kernel for the
+    owned blocks (cross-rank pairs evaluated on both sides), slab-decomposed PME with its two all-to-alls and halo planes,
+    per-rank integration with SETTLE and the CM-motion remover riding in the all-gather -- against the single-rank run of
+    the same box.  Kernels run on the CPU SIMT emulator, collectives on gloo through the callback transport."""
+    import pytest
+    from conftest import EMU_BUILD
+    if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
+        pytest.skip("emulated plugin not built (run __graft_entry__.build())")
+    _run_dd_child(tmp_path, True, None, 4, 29547)

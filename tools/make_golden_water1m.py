@@ -21,6 +21,10 @@ def main():
     sample = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
     platform = sys.argv[3] if len(sys.argv) > 3 else "Reference"
     w = T.water_box(n_side, seed=1)
+    # The Reference platform takes the PME grid as NonbondedForceImpl::calcPMEParameters gives it (191^3 here); the HIP platform
+    # rounds up to an FFT-friendly size (192^3).  Parity is about the arithmetic, so both sides get the same explicit grid.
+    grid = int(sys.argv[4]) if len(sys.argv) > 4 else 192
+    w.pme_params = (float(np.sqrt(-np.log(2 * w.ewald_tol)) / w.cutoff), grid, grid, grid)
     if platform == "CPU":
         H.load_cpu_platform()
     system, nb = w.build()

@@ -151,15 +151,16 @@ int ommhip_comm_size(const ommhip_comm* comm) { return comm->size; }
 const char* ommhip_comm_transport(const ommhip_comm* comm) { return comm->rccl ? "rccl" : "callback"; }
 
 int ommhip_comm_all_gather(ommhip_comm* c, void* buffer_d, size_t bytes, void* stream) {
-    if (c->size == 1 || bytes == 0) return 0;
+    if (bytes == 0) return 0;
     hipStream_t st = (hipStream_t) stream;
     char* buf = (char*) buffer_d;
 #ifndef OMMHIP_EMU
-    if (c->rccl) {
+    if (c->rccl) {      // also with one rank: a single-GPU run with a communicator exercises the real transport
         NCCL_TRY(rccl_api().allGather(buf + (size_t) c->rank * bytes, buf, bytes, ncclChar, (ncclComm_t) c->nccl, st));
         return 0;
     }
 #endif
+    if (c->size == 1) return 0;
     int rc = stage_down(c, buf + (size_t) c->rank * bytes, bytes, 0, st);
     if (rc != 0) return rc;
     c->hostRecv.resize((size_t) c->size * bytes);
@@ -170,7 +171,6 @@ int ommhip_comm_all_gather(ommhip_comm* c, void* buffer_d, size_t bytes, void* s
 int ommhip_comm_all_to_all(ommhip_comm* c, const void* send_d, void* recv_d, size_t bytes, void* stream) {
     hipStream_t st = (hipStream_t) stream;
     if (bytes == 0) return 0;
-    if (c->size == 1) return (int) hipMemcpyAsync(recv_d, send_d, bytes, hipMemcpyDeviceToDevice, st);
     const char* s = (const char*) send_d;
     char* r = (char*) recv_d;
 #ifndef OMMHIP_EMU
@@ -185,6 +185,7 @@ int ommhip_comm_all_to_all(ommhip_comm* c, const void* send_d, void* recv_d, siz
         return 0;
     }
 #endif
+    if (c->size == 1) return (int) hipMemcpyAsync(recv_d, send_d, bytes, hipMemcpyDeviceToDevice, st);
     // host transport: gather everybody's whole send buffer, keep the chunk addressed to this rank
     const size_t all = (size_t) c->size * bytes;
     int rc = stage_down(c, s, all, 0, st);
@@ -199,7 +200,7 @@ int ommhip_comm_all_to_all(ommhip_comm* c, const void* send_d, void* recv_d, siz
 int ommhip_comm_ring_exchange(ommhip_comm* c, const void* send_down_d, void* recv_from_up_d, size_t bytes_down,
                               const void* send_up_d, void* recv_from_down_d, size_t bytes_up, void* stream) {
     hipStream_t st = (hipStream_t) stream;
-    if (c->size == 1) {
+    if (c->size == 1 && !c->rccl) {
         // the only slab is its own neighbour on both sides
         if (bytes_down > 0) { hipError_t e = hipMemcpyAsync(recv_from_up_d, send_down_d, bytes_down, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int) e; }
         if (bytes_up > 0) { hipError_t e = hipMemcpyAsync(recv_from_down_d, send_up_d, bytes_up, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int) e; }
@@ -236,7 +237,7 @@ int ommhip_comm_ring_exchange(ommhip_comm* c, const void* send_down_d, void* rec
 }
 
 int ommhip_comm_all_gather_host(ommhip_comm* c, const void* send, void* recv, size_t bytes, void* stream) {
-    if (c->size == 1) { memcpy(recv, send, bytes); return 0; }
+    if (c->size == 1 && !c->rccl) { memcpy(recv, send, bytes); return 0; }
 #ifndef OMMHIP_EMU
     if (c->rccl) {
         hipStream_t st = (hipStream_t) stream;

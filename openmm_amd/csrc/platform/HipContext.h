@@ -133,7 +133,7 @@ public:
     //      rank's range (trailerSlot) never holds an atom: it carries the rank's momentum through the same all-gather.
     HipDomain domain;
     int slotsPerRank, ownSlot0, ownSlot1, trailerSlot;
-    bool decomposed() const { return domain.ranks > 1; }
+    bool decomposed() const { return domain.comm != NULL; }      // also with ONE rank when a communicator was given (single-GPU test of the whole path)
     DeviceBuffer posSlot, velSlot;
     /** Enqueue the all-gather of posSlot on the main stream (after the integration kernel wrote this rank's part). */
     void allGatherPositions();

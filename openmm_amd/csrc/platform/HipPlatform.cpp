@@ -214,7 +214,7 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
     if (properties.find(HipCommId()) != properties.end()) commId = properties.find(HipCommId())->second;
     if (domain.ranks < 1 || domain.rank < 0 || domain.rank >= domain.ranks)
         throw OpenMMException("HIP platform: illegal Ranks/Rank properties");
-    if (domain.ranks > 1) {
+    if (domain.ranks > 1 || !commId.empty()) {
         if (mode.hostMode || mode.hasFallbackForces || mode.referenceNonbonded)
             throw OpenMMException("HIP platform: a multi-GPU Context supports NonbondedForce (PME), HarmonicBond/Angle, PeriodicTorsion and CMMotionRemover with the Verlet, Langevin and LangevinMiddle integrators");
         int count = 0;

@@ -26,15 +26,20 @@ def _kernel_lib(emulated=False):
     return capi.load(path).lib
 
 
+def new_rccl_id(emulated=False):
+    """A fresh ncclUniqueId (256 hex characters) from the C ABI; call on ONE rank and distribute the result."""
+    buf = C.create_string_buffer(257)
+    rc = _kernel_lib(emulated).ommhip_comm_unique_id(buf)
+    if rc != 0:
+        raise RuntimeError("ommhip_comm_unique_id failed (%d): is librccl available?" % rc)
+    return buf.value.decode()
+
+
 def rccl_comm_id(dist, emulated=False):
     """The 256-character hex ncclUniqueId of this run, the same on every rank."""
     ident = [None]
     if dist.get_rank() == 0:
-        buf = C.create_string_buffer(257)
-        rc = _kernel_lib(emulated).ommhip_comm_unique_id(buf)
-        if rc != 0:
-            raise RuntimeError("ommhip_comm_unique_id failed (%d): is librccl available?" % rc)
-        ident[0] = buf.value.decode()
+        ident[0] = new_rccl_id(emulated)
     dist.broadcast_object_list(ident, src=0)
     return ident[0]
 

@@ -6,23 +6,29 @@ OpenMM "HIP" platform, one process per GPU.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): a DHFR-sized system -- 23 558 atoms in a 6.223 nm
-cube, PME, cutoff 0.9 nm, Ewald tolerance 5e-4 (alpha 2.92/nm, grid 56^3), LangevinMiddleIntegrator 300 K,
-1/ps, X-H constraints + rigid water, dt 2 fs -- generated synthetically (openmm_amd/testsystems.py:dhfr_like).
-A "step" is one MD step = one pass of the hot path.  The timing protocol is the one of examples/benchmark.py:9-18:
-warm-up steps, then time step(K) followed by getState(energy), which forces a device sync.
+A "step" is one MD step = one pass of the hot path.  Timing protocol of examples/benchmark.py:9-18: warm-up steps, then time
+step(K) followed by getState(energy), which forces a device sync; barrier + synchronize on both sides, MAX over ranks.
 
-Multi-GPU: the path does not shard in this round (domain decomposition is SURVEY.md §8e, planned); --gpus N runs
-N independent replicas of the workload, one per GPU, and reports the aggregate ns/day ("scaling": "weak").
+N = 1 (the headline, BASELINE.json configs[1]): a DHFR-sized system -- 23 558 atoms in a 6.223 nm
+cube, PME, cutoff 0.9 nm, Ewald tolerance 5e-4 (alpha 2.92/nm, grid 56^3), LangevinMiddleIntegrator 300 K, 1/ps, X-H
+constraints + rigid water, dt 2 fs -- generated synthetically (openmm_amd/testsystems.py:dhfr_like).  The JSON line also
+carries `scale_workload`: the single-GPU ns/day of the water-1M box below, measured in the same run, i.e. the N = 1 point
+of the strong-scaling curve.
 
-Rank 0 prints ONE JSON line with the contract fields plus `roofline` (the direct-space pair kernel -- in the default
-single-stream mode the three launches it shares with the FFT stages of reciprocal space -- measured with HIP events on
-the stream the kernels run on), `cpu_baseline` (the reference's own platforms/cpu built into oracle/_ref, timed on this
-host on a bounded number of steps of the same System) and `force_parity` (HIP forces of the final configuration against
-the reference's Reference platform, the second half of BASELINE.json's metric).  DESIGN.md (d) defines every field.
+N > 1 (BASELINE.json configs[3]): ONE 985 527-atom TIP3P box (21.4 nm, PME grid 192^3) domain-decomposed over the N GPUs
+(x slabs, positions all-gathered over RCCL every step, slab FFT with two all-to-alls) -- "scaling": "strong",
+`value` = ns/day of that one simulation.  (A 23 558-atom system does not shard usefully over 8 GPUs: its halo is several
+times its slab.)  --workload overrides either default.
+
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (the direct-space pair kernel -- on the fused
+single-stream path the three launches it shares with the FFT stages -- HIP events on the stream the kernels run on),
+`roofline_fft` (the 3-D FFT chain of reciprocal space on its own), `cpu_baseline` (the reference's own platforms/cpu built
+into oracle/_ref, timed on this host on a bounded number of steps of the same System) and `force_parity` (HIP forces of the
+final configuration against the reference's Reference platform).  DESIGN.md (d) defines every field.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -32,6 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+KERNEL_SOURCES = ("nonbonded.hip", "force_front.hip", "pme.hip", "neighbor.hip", "common.h")
+WORKLOADS = ["dhfr", "water24k", "water98k", "apoa1", "water1m"]
 
 
 def parse_args():
@@ -40,10 +48,14 @@ def parse_args():
     p.add_argument("--steps", type=int, default=3000)
     p.add_argument("--warmup", type=int, default=300)
     p.add_argument("--dt-fs", type=float, default=2.0)
-    p.add_argument("--workload", default="dhfr", choices=["dhfr", "water24k", "water98k", "water1m"])
+    p.add_argument("--workload", default="auto", choices=["auto"] + WORKLOADS, help="auto = dhfr on one GPU, water1m (one box, decomposed) on several")
     p.add_argument("--cpu-steps", type=int, default=150, help="steps of the CPU-platform baseline (0 disables it and the force-parity check)")
     p.add_argument("--no-roofline", action="store_true")
-    p.add_argument("--profile-every", type=int, default=8, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region")
+    p.add_argument("--no-scale-workload", action="store_true", help="N = 1: skip the single-GPU run of the strong-scaling workload")
+    p.add_argument("--prepare-steps", type=int, default=-1, help="untimed steps that relax a lattice start before warm-up (input preparation; default 200 for the water boxes, 0 for fixtures)")
+    p.add_argument("--transport", default="rccl", choices=["rccl", "gloo"], help="collectives of the decomposed run: RCCL (product) or host-staged gloo (rehearsal on one GPU)")
+    p.add_argument("--profile-every", type=int, default=7, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region")
+    p.add_argument("--decompose", action="store_true", help="N = 1: run through the decomposed path with a one-rank RCCL communicator (overhead check on one GPU)")
     p.add_argument("--props", default="", help="extra HIP platform properties, e.g. DisablePmeStream=true")
     return p.parse_args()
 
@@ -54,13 +66,15 @@ def make_workload(name, seed):
         return T.dhfr_like(seed=seed)
     if name == "water24k":
         return T.water_box(20, seed=seed)
+    if name == "apoa1":
+        return T.apoa1_like(seed=seed)           # 92 224 atoms in the apoa1 box (BASELINE.json configs[2] stand-in)
     if name == "water1m":
         return T.water_box(69, seed=seed)        # 985 527 atoms, L = 21.4 nm (BASELINE.json configs[3]; lattice start)
     return T.water_box(32, seed=seed)
 
 
-def run_platform(w, platform, dt_ps, steps, warmup, props=None, seed=1):
-    """-> (seconds for `steps`, final State, context)"""
+def start_platform(w, platform, dt_ps, warmup, props=None, seed=1, prepare=0):
+    """Context on `platform`, positions/velocities set, `prepare` + `warmup` untimed steps done.  -> (system, nb, integrator, context)"""
     from openmm_amd import harness as H
     system, nb = w.build()
     integ = H.Integrator(H.LANGEVIN_MIDDLE, dt_ps, 300.0, 1.0, seed=seed, constraintTolerance=1e-5)
@@ -71,9 +85,36 @@ def run_platform(w, platform, dt_ps, steps, warmup, props=None, seed=1):
         ctx.setVelocities(w.velocities)          # equilibrated start (tests/golden fixture)
     else:
         ctx.setVelocitiesToTemperature(300.0, 1)
-    integ.step(warmup)
+    integ.step(prepare + warmup)
     ctx.getState(getEnergy=True)
     return system, nb, integ, ctx
+
+
+def kernel_sources_sha():
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "openmm_amd", "csrc", "kernels", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def collect_timers(kernels):
+    calls, total_ms = C.c_longlong(), C.c_double()
+    timers = {}
+    for name, idx in (("nb_direct", 0), ("nl_update", 1), ("pme_spread", 2), ("pme_fft", 3), ("pme_interpolate", 4)):
+        kernels.lib.ommhip_profile_collect(idx, C.byref(calls), C.byref(total_ms))
+        timers[name] = {"calls": calls.value, "avg_us": (1e3 * total_ms.value / calls.value) if calls.value else None}
+    return timers
+
+
+def timed_run(integ, ctx, steps, barrier):
+    barrier()
+    t0 = time.perf_counter()
+    integ.step(steps)
+    st = ctx.getState(getEnergy=True)        # blocks until the device is idle
+    elapsed = time.perf_counter() - t0
+    barrier()
+    return elapsed, st
 
 
 def main():
@@ -82,6 +123,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    gloo_group = None
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -97,19 +139,58 @@ def main():
             dist.init_process_group(backend=backend)
 
     import numpy as np
-    from openmm_amd import capi, harness as H
+    from openmm_amd import capi, harness as H, multirank as MR
     H.load_hip_platform()
     kernels = capi.load()
     plugin = C.CDLL(os.path.join(H.LIB_DIR, "libOpenMMHIP.so"))
 
+    workload = args.workload if args.workload != "auto" else ("dhfr" if world == 1 else "water1m")
+    decomposed = world > 1
     dt_ps = args.dt_fs * 1e-3
-    w = make_workload(args.workload, seed=1)        # every replica starts from the equilibrated fixture; the thermostat seeds differ
+    w = make_workload(workload, seed=1)
+    prepare = args.prepare_steps if args.prepare_steps >= 0 else (0 if getattr(w, "velocities", None) is not None else 200)
     props = {"DeviceIndex": str(local_rank)}
     for kv in filter(None, args.props.split(",")):
         k, v = kv.split("=")
         props[k] = v
-    system, nb, integ, ctx = run_platform(w, "HIP", dt_ps, 0, args.warmup, props, seed=1 + rank)
+    transport = None
+    if args.decompose and world == 1:
+        props.update({"Ranks": "1", "Rank": "0", "CommId": MR.new_rccl_id()})
+    if decomposed:
+        # ONE box over all ranks.  The plugin runs its own collectives (RCCL); the launcher only distributes the communicator id.
+        transport = args.transport
+        if transport == "gloo" and dist.get_backend() != "gloo":
+            gloo_group = dist.new_group(backend="gloo")
+        try:
+            dd = MR.domain_properties(dist, transport=transport, group=gloo_group if transport == "gloo" else None)
+        except Exception as e:
+            raise RuntimeError("could not set up the %s transport: %s" % (transport, e))
+        props.update(dd)
+    failure = None
+    try:
+        system, nb, integ, ctx = start_platform(w, "HIP", dt_ps, args.warmup, props, seed=1, prepare=prepare)
+    except Exception as e:
+        if not decomposed:
+            raise
+        failure = e
+    if decomposed:
+        # every rank must take the same path: agree on whether the RCCL start-up worked anywhere it was tried
+        import torch
+        flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) != 0:
+            if args.transport == "gloo":
+                raise failure if failure is not None else RuntimeError("another rank failed to start")
+            if rank == 0:
+                print("bench.py: RCCL transport failed to start (%s); falling back to host-staged gloo collectives" % failure, file=sys.stderr, flush=True)
+            if failure is None:
+                ctx.close()
+            gloo_group = dist.new_group(backend="gloo")
+            props.update(MR.domain_properties(dist, transport="gloo", group=gloo_group))
+            system, nb, integ, ctx = start_platform(w, "HIP", dt_ps, args.warmup, props, seed=1, prepare=prepare)
     device_name = ctx.getPlatformProperty("DeviceName")
+    if decomposed:
+        transport = ctx.getPlatformProperty("CommId")       # what the plugin actually uses
 
     def barrier():
         if dist is not None:
@@ -122,35 +203,29 @@ def main():
     if profile:
         kernels.lib.ommhip_profile_reset()
         kernels.lib.ommhip_profile_enable(max(1, args.profile_every))
-    barrier()
-    t0 = time.perf_counter()
-    integ.step(args.steps)
-    st = ctx.getState(getEnergy=True)        # blocks until the device is idle
-    elapsed = time.perf_counter() - t0
-    barrier()
+    elapsed, st = timed_run(integ, ctx, args.steps, barrier)
     if profile:
         kernels.lib.ommhip_profile_enable(0)
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = MR.max_over_ranks(elapsed, dist, device="cuda" if on_gpu else "cpu")
     if not np.isfinite(st.potentialEnergy):
         raise RuntimeError("simulation blew up: potential energy is not finite")
 
     ms_per_step = 1e3 * elapsed / args.steps
-    ns_per_day_one = args.dt_fs * 1e-6 * args.steps / elapsed * 86400.0
-    value = ns_per_day_one * world
+    value = MR.ns_per_day(elapsed, args.steps, args.dt_fs)          # ONE simulation, whatever the number of GPUs
+    grid = nb.getPMEParametersInContext(ctx)[1:]
     out = {
         "metric": "ns/day (DHFR PME 2 fs) at 1/2/4/8 MI355X; force max-rel-err vs Reference",
         "value": round(value, 3), "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong" if decomposed else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %d atoms, PME cutoff 0.9 nm grid %s, LangevinMiddle %.0f fs, X-H constraints + rigid water; %s" % (
-            w.name, w.num_atoms, "x".join(str(g) for g in nb.getPMEParametersInContext(ctx)[1:]), args.dt_fs,
-            "independent replicas, one per GPU" if world > 1 else "single GPU"),
-            "precision": "mixed (f32 forces, fixed-point accumulation, f64 integration)", "device": device_name},
+            w.name, w.num_atoms, "x".join(str(g) for g in grid), args.dt_fs,
+            ("ONE box domain-decomposed over %d GPUs (x slabs, %s collectives)" % (world, transport)) if decomposed else "single GPU"),
+            "precision": "mixed (f32 forces, fixed-point accumulation, f64 integration)", "device": device_name,
+            "prepare_steps": prepare},
     }
+    if decomposed:
+        out["config"]["parallelism"] = "dd%d (x slabs; all-gather of positions + 2 all-to-alls + halo planes per step)" % world
 
     if rank == 0:
         # ---- roofline of the dominant kernel (direct-space pair kernel)
@@ -158,46 +233,71 @@ def main():
             stats = (C.c_longlong * 8)()
             plugin.ommhip_plugin_nl_stats(stats)
             chunks, rows = stats[2], stats[3]
-            calls, total_ms = C.c_longlong(), C.c_double()
-            timers = {}
-            for name, idx in (("nb_direct", 0), ("nl_update", 1), ("pme_spread", 2), ("pme_fft", 3), ("pme_interpolate", 4)):
-                kernels.lib.ommhip_profile_collect(idx, C.byref(calls), C.byref(total_ms))
-                timers[name] = {"calls": calls.value, "avg_us": (1e3 * total_ms.value / calls.value) if calls.value else None}
-            # algorithmic bytes of one launch (DESIGN.md §4): per row 64 j-slots x (index 4 + mask 4 + posq 16 + sigEps 8 + force 24)
+            timers = collect_timers(kernels)
+            # algorithmic bytes of one launch (DESIGN.md (d)): per row 64 j-slots x (index 4 + mask 4 + posq 16 + sigEps 8 + force 24)
             # plus per chunk 32 i-atoms x (posq 16 + sigEps 8 + force 24)
             algo_bytes = rows * 64 * 56 + chunks * 32 * 48
             avg_us = timers["nb_direct"]["avg_us"]
-            # Single-stream default: the pair kernel rides on the three FFT launches (ommhip_pairs_with_fft), the timer then
+            # Fused single-stream path: the pair kernel rides on the three FFT launches (ommhip_pairs_with_fft), the timer then
             # brackets those three launches and the algorithmic bytes include the FFT stages' grid traffic: real grid read +
             # complex written, complex read + written + influence function read, complex read + real written
             kernel_name = "nb_direct"
             fused = timers["pme_fft"]["calls"] * 2 < timers["nb_direct"]["calls"]
+            gx, gy, gz = grid
+            real_b, cplx_b = gx * gy * gz * 4, gx * gy * (gz // 2 + 1) * 8
             if fused:
-                gx, gy, gz = nb.getPMEParametersInContext(ctx)[1:]
-                real_b, cplx_b = gx * gy * gz * 4, gx * gy * (gz // 2 + 1) * 8
                 algo_bytes += (real_b + cplx_b) + (2 * cplx_b + cplx_b // 2) + (cplx_b + real_b)
                 kernel_name = "pairs_fft_plane + pairs_fft_lines + pairs_fft_plane (pair kernel riding on the 3 FFT launches)"
             achieved = algo_bytes / (avg_us * 1e-6) / 1e9 if avg_us else None
-            # HBM traffic of the same kernel from the PMC passes (rocprofv3 cannot run inside this process; the counters were
-            # collected by tools/gpu_pmc.sh on the same command and are committed under profiles/)
+            # HBM traffic of the same kernel from the PMC passes (rocprofv3 cannot run inside this process; the counters are
+            # collected by tools/gpu_pmc2.sh on the same command and committed under profiles/ with the hash of the kernel
+            # sources they were taken from; a summary of other sources is stale and is not quoted)
             traffic, traffic_source = None, None
-            pmc_file = os.path.join(ROOT, "profiles", "r01o_pmc_pairs_fft.json" if fused else "r01_pmc_nb_direct.json")
-            if args.workload == "dhfr" and os.path.exists(pmc_file):
+            sha = kernel_sources_sha()
+            pmc_file = os.path.join(ROOT, "profiles", "pmc_pairs_fft.json" if fused else "pmc_nb_direct.json")
+            if workload == "dhfr" and os.path.exists(pmc_file):
                 with open(pmc_file) as f:
                     pmc = json.load(f)
-                traffic, traffic_source = pmc["traffic_bytes_per_launch"], pmc["source"]
+                if pmc.get("kernel_sources_sha") == sha:
+                    traffic, traffic_source = pmc["traffic_bytes_per_launch"], pmc["source"]
+                else:
+                    traffic_source = "stale: %s was collected from other kernel sources (%s, now %s)" % (os.path.basename(pmc_file), pmc.get("kernel_sources_sha"), sha)
             out["roofline"] = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5) if achieved else None, "traffic": traffic,
                                "traffic_source": traffic_source,
                                "algorithmic_bytes_per_launch": int(algo_bytes), "avg_kernel_us": round(avg_us, 3) if avg_us else None,
                                "rows": int(rows), "chunks": int(chunks), "rebuilds": int(stats[5]),
-                               "pair_evals_per_launch": int(rows) * 64 * 32, "kernel_timers_us": timers,
-                               "note": "working set is cache-resident at this size; the kernel is FP32-VALU bound, see DESIGN.md"}
+                               "pair_evals_per_launch": int(rows) * 64 * 32, "kernel_timers_us": timers, "kernel_sources_sha": sha,
+                               "note": "working set is cache-resident at DHFR size (the kernel is FP32-issue bound there); see DESIGN.md (d)"}
+            # ---- the 3-D FFT chain on its own: 96 * Hc algorithmic bytes over its measured duration.  On the fused
+            #      path the FFT stages share launches with the pair kernel, so a short extra run with separate launches times them.
+            if not decomposed:
+                try:
+                    fft = timers["pme_fft"]
+                    if fused:
+                        os.environ["OPENMM_HIP_NO_PAIRS_WITH_FFT"] = "1"          # read per evaluation by the plugin
+                        kernels.lib.ommhip_profile_reset()
+                        kernels.lib.ommhip_profile_enable(1)
+                        integ.step(100)
+                        ctx.getState(getEnergy=True)
+                        kernels.lib.ommhip_profile_enable(0)
+                        os.environ.pop("OPENMM_HIP_NO_PAIRS_WITH_FFT")
+                        sep = collect_timers(kernels)
+                        fft = sep["pme_fft"]
+                        out["roofline"]["separate_launch_timers_us"] = {k: sep[k] for k in ("nb_direct", "pme_fft")}
+                    hc = gx * gy * (gz // 2 + 1)
+                    if fft["avg_us"]:
+                        a = 96.0 * hc / (fft["avg_us"] * 1e-6) / 1e9
+                        out["roofline_fft"] = {"bound": "hbm", "kernel": "forward plane/line transforms + x transform with convolution + backward transforms",
+                                               "grid": [gx, gy, gz], "algorithmic_bytes": 96 * hc, "avg_us": round(fft["avg_us"], 3), "achieved": round(a, 2),
+                                               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBPS, 5), "calls": fft["calls"]}
+                except Exception as e:
+                    out["roofline_fft"] = {"error": str(e)}
         # ---- CPU baseline: the reference's platforms/cpu on the same System, bounded sample
         if args.cpu_steps > 0 and world == 1:        # rank 0 at N = 1 only
             try:
                 H.load_cpu_platform()
-                csys, cnb, cinteg, cctx = run_platform(w, "CPU", dt_ps, 0, 5)
+                csys, cnb, cinteg, cctx = start_platform(w, "CPU", dt_ps, 5)
                 t0 = time.perf_counter()
                 cinteg.step(args.cpu_steps)
                 cctx.getState(getEnergy=True)
@@ -212,7 +312,9 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "ns/day", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %s" % e}
             try:
                 # second half of BASELINE.json's metric: force max-rel-err vs the Reference platform (oracle/_ref) on the
-                # configuration the timed run ended in -- SURVEY.md §8(d): max_i |dF_i| / max(|F_ref,i|, RMS force)
+                # configuration the timed run ended in -- SURVEY.md §8(d): max_i |dF_i| / max(|F_ref,i|, RMS force), ALL atoms
+                if w.num_atoms > 120000:
+                    raise RuntimeError("skipped at this size (the Reference platform needs minutes); see tests/test_gpu_platform.py::test_water1m_forces_within_1e4_of_reference")
                 end = ctx.getState(getPositions=True, getForces=True)
                 rsys, rnb = w.build()
                 rctx = H.Context(rsys, H.Integrator(H.VERLET, 0.001), "Reference")
@@ -230,8 +332,23 @@ def main():
                                                "%.0e nm of the cutoff (where the truncated force jumps) can differ from the reference's side of it" % fp["edge_band_nm"]}
             except Exception as e:
                 out["force_parity"] = {"max_rel_err_vs_reference": None, "error": str(e)}
-        print(json.dumps(out), flush=True)
     ctx.close()
+
+    # ---- N = 1: the single-GPU point of the strong-scaling curve (same workload, same protocol as the N > 1 runs)
+    if world == 1 and workload == "dhfr" and not args.no_scale_workload:
+        try:
+            sw = make_workload("water1m", seed=1)
+            ssys, snb, sinteg, sctx = start_platform(sw, "HIP", dt_ps, args.warmup, {"DeviceIndex": str(local_rank)}, seed=1, prepare=200)
+            s_elapsed, s_st = timed_run(sinteg, sctx, args.steps, barrier)
+            out["scale_workload"] = {"workload": "%s: ONE box of %d atoms, PME grid %s, single GPU (the N = 1 point of the strong-scaling curve that "
+                                                 "bench.py --gpus N reports for N > 1)" % (sw.name, sw.num_atoms, "x".join(str(g) for g in snb.getPMEParametersInContext(sctx)[1:])),
+                                     "value": round(MR.ns_per_day(s_elapsed, args.steps, args.dt_fs), 3), "unit": "ns/day",
+                                     "ms_per_step": round(1e3 * s_elapsed / args.steps, 5), "steps": args.steps, "prepare_steps": 200}
+            sctx.close()
+        except Exception as e:
+            out["scale_workload"] = {"value": None, "error": str(e)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -348,6 +348,13 @@ def main():
         except Exception as e:
             out["scale_workload"] = {"value": None, "error": str(e)}
     if rank == 0:
+        # librccl prints a version banner through C stdio, which is flushed at exit -- after Python's own output -- when stdout
+        # is a pipe or a file: push it out first so that the JSON line is the last line
+        sys.stdout.flush()
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

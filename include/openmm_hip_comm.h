@@ -42,6 +42,9 @@ int ommhip_comm_unique_id(char* hex);
 /* collective over all ranks (blocks until every rank has called it); the current HIP device is the rank's GPU */
 int ommhip_comm_create_rccl(const char* id_hex, int rank, int size, ommhip_comm** comm);
 int ommhip_comm_create_callback(ommhip_host_all_gather_fn fn, void* user, int rank, int size, ommhip_comm** comm);
+/* A second communicator over the same ranks (collective): for traffic issued from another stream (reciprocal space runs
+ * beside the pair kernel).  RCCL: ncclCommSplit with one colour; the callback transport shares its callback. */
+int ommhip_comm_duplicate(ommhip_comm* comm, ommhip_comm** copy);
 int ommhip_comm_destroy(ommhip_comm* comm);
 int ommhip_comm_rank(const ommhip_comm* comm);
 int ommhip_comm_size(const ommhip_comm* comm);

@@ -46,6 +46,7 @@ struct RcclApi {
     decltype(&ncclRecv) recv = nullptr;
     decltype(&ncclGroupStart) groupStart = nullptr;
     decltype(&ncclGroupEnd) groupEnd = nullptr;
+    decltype(&ncclCommSplit) commSplit = nullptr;      // optional
     bool ok = false;
 };
 
@@ -61,7 +62,7 @@ RcclApi& rccl_api() {
 #define OMM_BIND(field, sym) api.field = (decltype(api.field)) dlsym(api.handle, sym)
     OMM_BIND(getUniqueId, "ncclGetUniqueId"); OMM_BIND(commInitRank, "ncclCommInitRank"); OMM_BIND(commDestroy, "ncclCommDestroy");
     OMM_BIND(allGather, "ncclAllGather"); OMM_BIND(send, "ncclSend"); OMM_BIND(recv, "ncclRecv");
-    OMM_BIND(groupStart, "ncclGroupStart"); OMM_BIND(groupEnd, "ncclGroupEnd");
+    OMM_BIND(groupStart, "ncclGroupStart"); OMM_BIND(groupEnd, "ncclGroupEnd"); OMM_BIND(commSplit, "ncclCommSplit");
 #undef OMM_BIND
     api.ok = api.getUniqueId && api.commInitRank && api.commDestroy && api.allGather && api.send && api.recv && api.groupStart && api.groupEnd;
     if (!api.ok) fprintf(stderr, "HIP platform: librccl lacks a required symbol\n");
@@ -133,6 +134,23 @@ int ommhip_comm_create_callback(ommhip_host_all_gather_fn fn, void* user, int ra
     ommhip_comm* c = new ommhip_comm();
     c->rank = rank; c->size = size; c->rccl = false; c->fn = fn; c->user = user;
     *comm = c;
+    return 0;
+}
+
+int ommhip_comm_duplicate(ommhip_comm* comm, ommhip_comm** copy) {
+    ommhip_comm* c = new ommhip_comm();
+    c->rank = comm->rank; c->size = comm->size; c->rccl = comm->rccl; c->fn = comm->fn; c->user = comm->user;
+#ifndef OMMHIP_EMU
+    if (comm->rccl) {
+        RcclApi& api = rccl_api();
+        if (api.commSplit == nullptr) { delete c; return 1; }
+        ncclComm_t nc;
+        int rc = nccl_rc(api.commSplit((ncclComm_t) comm->nccl, 0, comm->rank, &nc, nullptr));
+        if (rc != 0) { delete c; return rc; }
+        c->nccl = (void*) nc;
+    }
+#endif
+    *copy = c;
     return 0;
 }
 

@@ -415,7 +415,9 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
                 bool near = !(bx * bx + by * by + bz * bz >= R2);
                 if (PBC == 2 && (0.5f * a.box.cz - hX.z < Rlist || 0.5f * a.box.by - hX.y < Rlist)) near = true;
                 // exact test against the 32 atoms of X (same metric as the pair kernel); executed by every lane so
-                // that the v_readlane broadcasts sit in convergent code
+                // that the v_readlane broadcasts sit in convergent code.  Passes none of whose 64 atoms comes near X's box
+                // (candidate blocks at the rim of the reach) skip it altogether -- a wave-uniform decision.
+                if (!__any(ok && near)) continue;
                 bool any = false;
                 if (singleImage) {
 #pragma unroll

@@ -985,7 +985,7 @@ extern "C" int ommhip_pme_reciprocal_dd(const ommhip_pme* pme, const void* posq_
     hipStream_t st = (hipStream_t) stream;
     const int R = pme->dd_ranks, rank = pme->dd_rank, D = pme->dd_halo;
     const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
-    if (R < 2 || nx % R != 0 || ny % R != 0 || pme->comm == nullptr || pme->grid_complex2 == nullptr || pme->dd_error == nullptr) return 1;
+    if (R < 1 || nx % R != 0 || ny % R != 0 || pme->comm == nullptr || pme->grid_complex2 == nullptr || pme->dd_error == nullptr) return 1;
     const int nxl = nx / R, nyl = ny / R;
     if (D < 0 || D + 4 > nxl) return 1;
     ommhip_comm* comm = (ommhip_comm*) pme->comm;

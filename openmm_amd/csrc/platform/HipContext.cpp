@@ -77,6 +77,8 @@ HipContext::HipContext(const System& system, int deviceIndex, bool hostMode, con
     energyResult.allocate(sizeof(double) * 8);
     forceDouble.allocate(sizeof(double) * 3 * (size_t) max(numAtoms, 1));
     if (decomposed()) {
+        // reciprocal space (with its all-to-alls) runs on the side stream beside the pair kernel: it gets a communicator of its own
+        if (ommhip_comm_duplicate(domain.comm, &pmeComm) != 0) pmeComm = NULL;
         posSlot.allocate(sizeof(double) * 4 * (size_t) paddedAtoms);
         velSlot.allocate(sizeof(double) * 4 * (size_t) paddedAtoms);
         HIP_CHECK(ommhip_memset(posSlot.ptr, 0, posSlot.bytes, stream));
@@ -107,6 +109,7 @@ HipContext::HipContext(const System& system, int deviceIndex, bool hostMode, con
 }
 
 HipContext::~HipContext() {
+    if (pmeComm != NULL) ommhip_comm_destroy(pmeComm);
     if (domain.comm != NULL) ommhip_comm_destroy(domain.comm);
     if (pinnedResult != NULL) ommhip_host_free(pinnedResult);
     if (pmeForkEvent != NULL) ommhip_event_destroy(pmeForkEvent);

@@ -135,6 +135,8 @@ public:
     int slotsPerRank, ownSlot0, ownSlot1, trailerSlot;
     bool decomposed() const { return domain.comm != NULL; }      // also with ONE rank when a communicator was given (single-GPU test of the whole path)
     DeviceBuffer posSlot, velSlot;
+    /** Communicator of the reciprocal-space stream (a duplicate of domain.comm; NULL = share domain.comm, single stream). */
+    ommhip_comm* pmeComm = NULL;
     /** Enqueue the all-gather of posSlot on the main stream (after the integration kernel wrote this rank's part). */
     void allGatherPositions();
     /** Make pos[] and vel[] (atom order) complete and current on this rank: before a re-sort and before downloads. */

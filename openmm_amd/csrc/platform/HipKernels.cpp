@@ -575,23 +575,39 @@ double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool
         const bool clear = hip.takePendingClear();
         HIP_CHECK(ommhip_nl_prepare(&nl, hip.pos.ptr, hip.wrap.ptr, clear ? hip.force.ptr : NULL, clear ? hip.force.bytes : 0,
                                     clear ? hip.extraClearPtr : NULL, clear ? hip.extraClearBytes : 0, hip.stream));
+        if (!forceRebuild) break;            // the (device-decided) rebuild is queued below, after reciprocal space was forked
         HIP_CHECK(ommhip_nl_rebuild_if_requested(&nl, hip.stream));
-        if (!forceRebuild) break;
         HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
         hip.sync();
         if (pinnedState[2] == 0 && pinnedState[1] * 1.5 <= nl.max_chunks) { forceRebuild = false; break; }
         allocateNeighborList((int) (pinnedState[1] * 1.6) + 64);
     }
     fillPmeStruct();
-    pme.phases = OMMHIP_PME_ALL;
-    // reciprocal space first (its collectives are latency-bound), the pair kernel between the transforms and the interpolation
-    pme.phases = OMMHIP_PME_SPREAD_ONLY;
-    HIP_CHECK(ommhip_pme_reciprocal_dd(&pme, posq.ptr, hip.paddedAtoms, hip.ownSlot0, hip.ownSlot1, blockCenter.ptr, blockHalf.ptr,
-                                       hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
-    pme.phases = OMMHIP_PME_AFTER_SPREAD;
-    HIP_CHECK(ommhip_nb_direct(&nl, &params, sigEps.ptr, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
-    HIP_CHECK(ommhip_pme_reciprocal_dd(&pme, posq.ptr, hip.paddedAtoms, hip.ownSlot0, hip.ownSlot1, blockCenter.ptr, blockHalf.ptr,
-                                       hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+    const bool sideStream = hip.usePmeStream && hip.pmeComm != NULL;
+    if (sideStream) {
+        // Two streams: reciprocal space -- spreading, slab FFT with its two all-to-alls, halo planes, interpolation -- on the
+        // side stream with a communicator of its own, the list rebuild and the pair kernel on the main stream; the latency of
+        // the collectives hides behind the pair kernel.  finishComputation joins the streams before the forces are used.
+        hip.forkPme();
+        pme.comm = hip.pmeComm;
+        pme.phases = OMMHIP_PME_ALL;
+        HIP_CHECK(ommhip_pme_reciprocal_dd(&pme, posq.ptr, hip.paddedAtoms, hip.ownSlot0, hip.ownSlot1, blockCenter.ptr, blockHalf.ptr,
+                                           hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.pmeStream));
+        hip.markPmeDone();
+        HIP_CHECK(ommhip_nl_rebuild_if_requested(&nl, hip.stream));
+        HIP_CHECK(ommhip_nb_direct(&nl, &params, sigEps.ptr, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+    }
+    else {
+        pme.comm = hip.domain.comm;
+        HIP_CHECK(ommhip_nl_rebuild_if_requested(&nl, hip.stream));
+        pme.phases = OMMHIP_PME_SPREAD_ONLY;
+        HIP_CHECK(ommhip_pme_reciprocal_dd(&pme, posq.ptr, hip.paddedAtoms, hip.ownSlot0, hip.ownSlot1, blockCenter.ptr, blockHalf.ptr,
+                                           hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+        pme.phases = OMMHIP_PME_AFTER_SPREAD;
+        HIP_CHECK(ommhip_nb_direct(&nl, &params, sigEps.ptr, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+        HIP_CHECK(ommhip_pme_reciprocal_dd(&pme, posq.ptr, hip.paddedAtoms, hip.ownSlot0, hip.ownSlot1, blockCenter.ptr, blockHalf.ptr,
+                                           hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+    }
     pme.phases = OMMHIP_PME_ALL;
     if ((++evaluationCount & 15) == 0) {
         HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
@@ -741,8 +757,10 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     // List padding as a fraction of the cutoff.  Small systems do not fill the chip: the pair launches are bound by the latency
     // of a chunk, extra rows ride along for free (DHFR size: 7.3 k -> 8.7 k rows, same 59 us) while every rebuild avoided
     // saves 50 us -- 0.2 measured best there (1433 vs 1388 ns/day; 0.25 pushes the list past what two rounds of wavefronts
-    // cover and loses again).  Large systems are throughput-bound in the pair kernel and keep the tighter list.
-    double paddingFraction = numParticles <= 40000 ? 0.2 : 0.1;
+    // cover and loses again).  At a million atoms the pair kernel is throughput-bound (+16 % time for +20 % rows), but an atom
+    // somewhere crosses half the padding every 2-3 steps and a rebuild costs two pair-kernel launches: 0.1 / 0.15 / 0.2 gave
+    // 4.20 / 3.84 / 3.67 ms per step on one MI355X (profiles/r02c), so 0.2 it is at every size until the rebuild gets cheaper.
+    double paddingFraction = 0.2;
     if (getenv("OPENMM_HIP_NL_PADDING") != NULL) paddingFraction = atof(getenv("OPENMM_HIP_NL_PADDING"));   // tuning knob, fraction of the cutoff
     padding = nonbondedMethod == NoCutoff ? 0.0 : paddingFraction * nonbondedCutoff;
     if (getenv("OPENMM_HIP_DIRECT_GRID") != NULL) directGridOverride = atoi(getenv("OPENMM_HIP_DIRECT_GRID"));
@@ -1033,7 +1051,10 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
             }
             // positions -> posq, displacement check, bounds; then the device-conditional rebuild (2 launches)
             static const bool noFront = getenv("OPENMM_HIP_NO_FUSED_FRONT") != NULL;          // A/B knob
-            if (!forceRebuild && includeReciprocal && nonbondedMethod == PME && !hip.usePmeStream && !noFront && pme.grid_precleared && pme.spread_mode == 0) {
+            // (small systems only: at a million atoms the builder workgroups of a rebuild get in each other's way with the spread
+            // workgroups of the same launch -- 3.5 ms against 2.1 + 0.3 ms as launches of their own, profiles/r02a vs r02c)
+            static const int frontMaxAtoms = getenv("OPENMM_HIP_FUSED_FRONT_MAX_ATOMS") != NULL ? atoi(getenv("OPENMM_HIP_FUSED_FRONT_MAX_ATOMS")) : 60000;
+            if (!forceRebuild && includeReciprocal && nonbondedMethod == PME && !hip.usePmeStream && !noFront && pme.grid_precleared && pme.spread_mode == 0 && numParticles <= frontMaxAtoms) {
                 // single-stream mode: list rebuild (if requested), charge spreading and every per-term force list of this
                 // evaluation are independent once the positions are converted -- they go out as ONE launch
                 const bool clear = hip.takePendingClear();

@@ -255,6 +255,11 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
     data->propertyValues[HipDisablePmeStream()] = (properties.find(HipDisablePmeStream()) == properties.end() ?
             getPropertyDefaultValue(HipDisablePmeStream()) : properties.find(HipDisablePmeStream())->second);
     data->hip->usePmeStream = data->propertyValues[HipDisablePmeStream()] != "true";
+    // decomposed runs overlap reciprocal space (and its collectives) with the pair kernel unless told otherwise
+    if (data->hip->decomposed() && properties.find(HipDisablePmeStream()) == properties.end()) {
+        data->hip->usePmeStream = true;
+        data->propertyValues[HipDisablePmeStream()] = "false";
+    }
     context.setPlatformData(data);
 }
 

@@ -28,6 +28,8 @@ extern "C" {
 #define OMMHIP_ROW 64         /* j-atoms per neighbour-list row          */
 #define OMMHIP_CHUNK_ROWS 2   /* rows per chunk                          */
 #define OMMHIP_NL_STATE_INTS 8
+#define OMMHIP_NL_STATE_OVERFLOW 2   /* state word: a rebuild ran out of rows (sticky until the host clears it) */
+#define OMMHIP_NL_STATE_FROZEN 6     /* state word: integration steps skipped while the overflow word was set */
 
 /* ------------------------------------------------------------------------------------------
  * Runtime plumbing (device memory, streams, events).  Replaces what CudaContext/CudaArray do in
@@ -336,6 +338,12 @@ typedef struct ommhip_integrator_state {
     void* oldx;                /* double4[num_atoms] (LangevinMiddle) */
     const long long* force;    /* fixed-point, slot order */
     const int* slot_of_atom;
+    /* Optional: the neighbour list's state array (ommhip_neighbor_list::state).  While its overflow word is set -- a
+     * device-triggered rebuild needed more rows than allocated, so the forces of this step are incomplete -- every integration
+     * kernel leaves the state untouched and the first kernel of the step counts the skipped step in state[6]: the simulation
+     * freezes at the last valid state until the host has grown the list, and the host then replays the skipped steps
+     * (the reference reports valid = false and recomputes at once, ContextImpl.cpp:298-307; here nothing waits on the host). */
+    int* freeze_state;
 } ommhip_integrator_state;
 
 enum {

@@ -61,7 +61,16 @@ struct IntArgs {
     double4* pos; double4* vel; double4* xp; double4* oldx;
     const omm_fixed* force;
     const int* slotOfAtom;
+    int* freeze;              // neighbour-list state array or null (ommhip_integrator_state::freeze_state)
 };
+
+// True while the neighbour list of this step's forces had overflowed: the kernel must not touch the state.  `count`: this
+// kernel opens a step, so one of its threads records the skipped step.
+__device__ __forceinline__ bool frozen(const IntArgs& a, bool count) {
+    if (a.freeze == nullptr || a.freeze[OMMHIP_NL_STATE_OVERFLOW] == 0) return false;
+    if (count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.freeze[OMMHIP_NL_STATE_FROZEN], 1);
+    return true;
+}
 
 __device__ __forceinline__ double3 load_force(const IntArgs& a, int atom) {
     int s = a.slotOfAtom[atom];
@@ -70,6 +79,7 @@ __device__ __forceinline__ double3 load_force(const IntArgs& a, int atom) {
 
 // ReferenceVerletDynamics.cpp:97-104
 __global__ void k_verlet_part1(IntArgs a) {
+    if (frozen(a, true)) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.numAtoms) return;
     double4 x = a.pos[i], v = a.vel[i];
@@ -83,6 +93,7 @@ __global__ void k_verlet_part1(IntArgs a) {
 }
 // ReferenceVerletDynamics.cpp:109-116 (also the last stage of ReferenceStochasticDynamics.cpp:138-146)
 __global__ void k_finish_positions(IntArgs a) {
+    if (frozen(a, false)) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.numAtoms) return;
     double4 x = a.pos[i], v = a.vel[i], xp = a.xp[i];
@@ -95,6 +106,7 @@ __global__ void k_finish_positions(IntArgs a) {
 }
 // ReferenceStochasticDynamics.cpp:89-136
 __global__ void k_langevin_part1(IntArgs a) {
+    if (frozen(a, true)) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.numAtoms) return;
     double4 x = a.pos[i], v = a.vel[i];
@@ -112,6 +124,7 @@ __global__ void k_langevin_part1(IntArgs a) {
 }
 // ReferenceLangevinMiddleDynamics.cpp:54-58
 __global__ void k_lmiddle_part1(IntArgs a) {
+    if (frozen(a, true)) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.numAtoms) return;
     double4 v = a.vel[i];
@@ -123,6 +136,7 @@ __global__ void k_lmiddle_part1(IntArgs a) {
 }
 // ReferenceLangevinMiddleDynamics.cpp:60-80   (noisescale = sqrt(kT (1-vscale^2)))
 __global__ void k_lmiddle_part2(IntArgs a) {
+    if (frozen(a, false)) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.numAtoms) return;
     double4 x = a.pos[i], v = a.vel[i];
@@ -142,6 +156,7 @@ __global__ void k_lmiddle_part2(IntArgs a) {
 }
 // ReferenceLangevinMiddleDynamics.cpp:82-90
 __global__ void k_lmiddle_part3(IntArgs a) {
+    if (frozen(a, false)) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.numAtoms) return;
     double4 x = a.pos[i], v = a.vel[i], xp = a.xp[i], ox = a.oldx[i];
@@ -398,6 +413,7 @@ struct UnitArgs {
 
 template <int KIND>
 __global__ __launch_bounds__(128) void k_step_units(IntArgs a, UnitArgs u) {
+    if (frozen(a, true)) return;
     const int c = blockIdx.x * 128 + threadIdx.x;
     V3 mom = v3(0, 0, 0);
     if (c < u.numUnits) {
@@ -596,7 +612,7 @@ IntArgs make_int_args(const ommhip_integrator_state* s) {
     a.dt = s->dt; a.vscale = s->vscale; a.fscale = s->fscale; a.noisescale = s->noisescale;
     a.seed = s->seed; a.step = s->step;
     a.pos = (double4*) s->pos; a.vel = (double4*) s->vel; a.xp = (double4*) s->xp; a.oldx = (double4*) s->oldx;
-    a.force = s->force; a.slotOfAtom = s->slot_of_atom;
+    a.force = s->force; a.slotOfAtom = s->slot_of_atom; a.freeze = s->freeze_state;
     return a;
 }
 

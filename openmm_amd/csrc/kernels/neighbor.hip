@@ -214,6 +214,9 @@ struct NlShared {
     int candY[NL_CAND];
     int rowMasked[NL_LIST / OMM_ROW];
     int candCount, listCount, chunkBase, candOverflow;
+    // the i atoms of X relative to its centre, one array per component: two neighbouring atoms come back with one 64-bit
+    // broadcast read, ready for the packed-FP32 exact test
+    float ix[OMM_TILE], iy[OMM_TILE], iz[OMM_TILE];
 };
 
 // X = i-block of this workgroup, numWorkgroups = number of builder workgroups of the launch (for the hand-over at the end)
@@ -251,6 +254,7 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
     float rx = px.x - cX.x, ry = px.y - cX.y, rz = px.z - cX.z;
     apply_pbc<PBC>(rx, ry, rz, a.box);
     const bool singleImage = PBC == 0 || (PBC == 1 && hX.x + Rlist < 0.5f * a.box.ax && hX.y + Rlist < 0.5f * a.box.by && hX.z + Rlist < 0.5f * a.box.cz);
+    if (t < OMM_TILE) { sh.ix[t] = rx; sh.iy[t] = ry; sh.iz[t] = rz; }
     __syncthreads();
 
     // Writes staged entries as rows.  final = false: only full rows, the remainder stays staged.
@@ -420,12 +424,14 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
                 if (!__any(ok && near)) continue;
                 bool any = false;
                 if (singleImage) {
+                    // two i atoms per iteration in packed FP32; their coordinates are wave-uniform LDS reads (no VALU slot,
+                    // unlike a v_readlane broadcast): 8 vector instructions per pair of atoms instead of 22
+                    const v2f jx = bc2(dx), jy = bc2(dy), jz = bc2(dz);
 #pragma unroll
-                    for (int k = 0; k < OMM_TILE; k++) {
-                        const float ex = dx - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rx), k));
-                        const float ey = dy - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ry), k));
-                        const float ez = dz - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rz), k));
-                        any = any || !(ex * ex + ey * ey + ez * ez >= R2);
+                    for (int k = 0; k < OMM_TILE; k += 2) {
+                        const v2f ex = jx - mk2(sh.ix[k], sh.ix[k + 1]), ey = jy - mk2(sh.iy[k], sh.iy[k + 1]), ez = jz - mk2(sh.iz[k], sh.iz[k + 1]);
+                        const v2f r2 = ex * ex + ey * ey + ez * ez;
+                        any = any || !(r2.x >= R2) || !(r2.y >= R2);
                     }
                 }
                 else {

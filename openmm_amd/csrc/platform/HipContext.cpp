@@ -1,7 +1,9 @@
 #include "HipContext.h"
 #include "openmm/System.h"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -144,7 +146,18 @@ void HipContext::uploadPositions(const vector<Vec3>& positions) {
     positionsValid = true;
 }
 
+void HipContext::recoverIfFrozen() {
+    if (inRecovery || !listRecovery || !replaySteps) return;
+    inRecovery = true;
+    try {
+        const int skipped = listRecovery();
+        if (skipped > 0) replaySteps(skipped);
+    } catch (...) { inRecovery = false; throw; }
+    inRecovery = false;
+}
+
 void HipContext::downloadPositions(vector<Vec3>& positions) {
+    recoverIfFrozen();
     if (decomposed()) gatherState();
     vector<D4> tmp(numAtoms);
     if (numAtoms > 0) HIP_CHECK(ommhip_memcpy_d2h(tmp.data(), pos.ptr, sizeof(D4) * numAtoms, stream));
@@ -165,6 +178,7 @@ void HipContext::uploadVelocities(const vector<Vec3>& velocities) {
 }
 
 void HipContext::downloadVelocities(vector<Vec3>& velocities) {
+    recoverIfFrozen();
     if (decomposed()) gatherState();
     vector<D4> tmp(numAtoms);
     if (numAtoms > 0) HIP_CHECK(ommhip_memcpy_d2h(tmp.data(), vel.ptr, sizeof(D4) * numAtoms, stream));
@@ -174,6 +188,7 @@ void HipContext::downloadVelocities(vector<Vec3>& velocities) {
 }
 
 void HipContext::downloadForces(vector<Vec3>& forces) {
+    recoverIfFrozen();
     forces.resize(numAtoms);
     if (numAtoms == 0) return;
     if (decomposed()) {
@@ -487,6 +502,10 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
 bool HipContext::reorderIfNeeded() {
     if (!reorderRequested && stepsSinceReorder < reorderInterval)
         return false;
+    static const bool timing = getenv("OPENMM_HIP_TIMING") != NULL;          // diagnostics: wall time of the re-sort on stderr
+    const std::chrono::steady_clock::time_point tStart = std::chrono::steady_clock::now();
+    struct Report { bool on; std::chrono::steady_clock::time_point t0; int n;
+                    ~Report() { if (on) fprintf(stderr, "HIP platform: re-sort of %d atoms took %.2f ms\n", n, 1e-3 * std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count()); } } report = {timing, tStart, numAtoms};
     reorderRequested = false;
     stepsSinceReorder = 0;
     if (!usePeriodic && sortCutoff <= 0.0 && !decomposed())

@@ -13,6 +13,7 @@
 #include "openmm/OpenMMException.h"
 #include "openmm/Vec3.h"
 #include <cstddef>
+#include <functional>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -151,6 +152,16 @@ public:
     /** Units owned by this rank after the last re-sort (indices into unitStart). */
     std::vector<int> ownedUnits;
 
+    // ---- neighbour-list overflow (a device-triggered rebuild needed more rows than allocated).  The device freezes the
+    //      integration while the list's overflow word is set (ommhip_integrator_state::freeze_state); the host notices at the
+    //      latest 16 evaluations later (or at the next download of positions / velocities / forces), grows the list and
+    //      replays the skipped steps.  freezeState: device pointer to the list's state array (NULL: no freezing, e.g. decomposed runs).
+    int* freezeState = NULL;
+    int pendingReplay = 0;                                   // skipped steps the integrator still has to redo
+    std::function<int()> listRecovery;                       // set by the nonbonded kernel: synchronous check; fixes the list, returns skipped steps
+    std::function<void(int)> replaySteps;                    // set by the integrator kernel: redo that many steps
+    void recoverIfFrozen();
+
     // ---- immutable after construction
     int numAtoms, paddedAtoms;
     bool hostMode;                 // true: host vectors are authoritative (Reference integrator etc.)
@@ -180,6 +191,7 @@ private:
     void computeOrderDecomposed(const std::vector<Vec3>& positions, std::vector<int>& newAtomOfSlot, std::vector<int>& wrapOut);
     void findUnits(const System& system);
     std::vector<HipContextListener*> listeners;
+    bool inRecovery = false;
     void* pmeForkEvent = NULL;
     void* pmeDoneEvent = NULL;
     bool pmeJoinPending = false;

@@ -633,6 +633,24 @@ HipCalcNonbondedForceKernel::~HipCalcNonbondedForceKernel() {
     if (pinnedDdError != NULL) ommhip_host_free(pinnedDdError);
 }
 
+int HipCalcNonbondedForceKernel::recoverFromOverflow() {
+    if (nl.max_chunks == 0) return 0;
+    hip.setAsCurrent();
+    HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
+    hip.sync();
+    stateCopyPending = false;
+    if (pinnedState[OMMHIP_NL_STATE_OVERFLOW] == 0 && pinnedState[1] <= nl.max_chunks) return 0;
+    const int skipped = pinnedState[OMMHIP_NL_STATE_FROZEN];
+    fprintf(stderr, "HIP platform: neighbour list overflowed (%d chunks needed, %d allocated); growing it and redoing %d step(s)\n", pinnedState[1], nl.max_chunks, skipped);
+    allocateNeighborList((int) (std::max(pinnedState[1], nl.max_chunks) * 1.5) + 64);
+    const int zero[OMMHIP_NL_STATE_INTS] = {1, 0, 0, 0, pinnedState[4], 0, 0, 0};          // rebuild requested, overflow and frozen counters cleared
+    HIP_CHECK(ommhip_memcpy_h2d(nlState.ptr, zero, sizeof(zero), hip.stream));
+    hip.sync();
+    forceRebuild = true;
+    debugShrinkDone = true;
+    return skipped;
+}
+
 void HipCalcNonbondedForceKernel::atomsReordered() { slotParamsDirty = true; forceRebuild = true; }
 void HipCalcNonbondedForceKernel::boxChanged() { etermDirty = true; forceRebuild = true; }
 void HipCalcNonbondedForceKernel::positionsSet() { forceRebuild = true; }
@@ -815,6 +833,12 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     nl.cell_start = cellStart.as<int>(); nl.cell_blocks = cellBlocks.as<int>(); nl.cell_boxes = cellBoxes.ptr; nl.cell_meta = cellMeta.as<float>();
     nl.cell_min_blocks = getenv("OPENMM_HIP_NL_CELL_MIN_BLOCKS") != NULL ? atoi(getenv("OPENMM_HIP_NL_CELL_MIN_BLOCKS")) : 0;   // 0 = default
     nl.max_chunks = 0;
+    if (!hip.decomposed() && !hip.hostMode) {
+        // single-GPU device mode: the integration kernels freeze while this list's overflow word is set, and the skipped
+        // steps are replayed after recoverFromOverflow() has grown the list (decomposed runs treat an overflow as an error)
+        hip.freezeState = nlState.as<int>();
+        hip.listRecovery = [this]() { return recoverFromOverflow(); };
+    }
 
     params.ewald = (nonbondedMethod == Ewald || nonbondedMethod == PME) ? 1 : 0;
     params.use_switch = useSwitchingFunction ? 1 : 0;
@@ -1037,12 +1061,23 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
     else {
         if (nl.max_chunks == 0) allocateNeighborList(estimateChunks());
         // A list that overflowed during an earlier (device-triggered) rebuild shows up here late (the state is read back
-        // asynchronously every 16th evaluation): the list is then grown and rebuilt.
-        if (stateCopyPending && (pinnedState[2] != 0 || pinnedState[1] > nl.max_chunks)) {
-            fprintf(stderr, "HIP platform: neighbour list overflowed (%d chunks needed, %d allocated); growing and rebuilding\n", pinnedState[1], nl.max_chunks);
+        // asynchronously every 16th evaluation).  The device has been skipping the integration since then; the list is grown
+        // and rebuilt now, and the integrator redoes the skipped steps (HipIntegratorBase::replaySkippedSteps).
+        if (stateCopyPending && (pinnedState[OMMHIP_NL_STATE_OVERFLOW] != 0 || pinnedState[1] > nl.max_chunks)) {
+            const int skipped = recoverFromOverflow();
+            if (hip.freezeState != NULL) hip.pendingReplay += skipped;
+        }
+        // test hook: after a few evaluations pretend the allocation is a little smaller than the list and request a rebuild the
+        // way the displacement check does (no host verification), so that it overflows (tests/test_gpu_platform.py::test_neighbour_list_overflow_is_recovered)
+        const int debugShrinkAfter = getenv("OPENMM_HIP_DEBUG_SHRINK_LIST_AFTER") != NULL ? atoi(getenv("OPENMM_HIP_DEBUG_SHRINK_LIST_AFTER")) : 0;      // read per evaluation
+        if (debugShrinkAfter > 0 && !debugShrinkDone && (int) evaluationCount == debugShrinkAfter && nl.max_chunks > 0) {
+            HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
             hip.sync();
-            allocateNeighborList((int) (pinnedState[1] * 1.5) + 64);
-            forceRebuild = true;
+            nl.max_chunks = std::max(1, pinnedState[1] - 8);
+            const int one = 1;
+            HIP_CHECK(ommhip_memcpy_h2d(nlState.ptr, &one, sizeof(int), hip.stream));      // ... and make this evaluation rebuild on the device's own path
+            hip.sync();
+            debugShrinkDone = true;
         }
         while (true) {
             if (forceRebuild) {
@@ -1306,6 +1341,30 @@ void HipIntegratorBase::fillState(ommhip_integrator_state& s, double dt) {
     s.pos = hip.pos.ptr; s.vel = hip.vel.ptr; s.xp = hip.xp.ptr; s.oldx = hip.oldx.ptr;
     s.force = hip.force.as<long long>(); s.slot_of_atom = hip.slotOfAtom.as<int>();
     s.step = (unsigned long long) data.stepCount;
+    s.freeze_state = hip.freezeState;
+}
+
+void HipIntegratorBase::runSteps(ContextImpl& context, const Integrator& integrator, const std::function<void(long long)>& launch,
+                                 long long firstIndex, long long endIndex, bool haveForces) {
+    // Steps firstIndex .. endIndex-1, each a force evaluation plus launch(index) -- the first one without the evaluation if the
+    // current forces already belong to it.  This is the ordinary single step (firstIndex + 1 == endIndex) and, after a
+    // neighbour-list overflow, the steps the device skipped (HipContext::pendingReplay, filled by the nonbonded kernel while
+    // it evaluates the forces): they are redone in order with the step indices they would have had (the thermostat noise is
+    // keyed by the index), so the trajectory is the one an unlimited list would have given.
+    HipContext& hip = *data.hip;
+    long long next = firstIndex;
+    while (next < endIndex) {
+        if (!haveForces) {
+            context.updateContextState();
+            context.calcForcesAndEnergy(true, false, integrator.getIntegrationForceGroups());
+            if (hip.pendingReplay > 0) {             // overflowed again meanwhile: the last pendingReplay launches did nothing
+                next -= hip.pendingReplay;
+                hip.pendingReplay = 0;
+            }
+        }
+        haveForces = false;
+        launch(next++);
+    }
 }
 
 double HipIntegratorBase::kineticEnergy(double timeShift) {
@@ -1338,13 +1397,13 @@ void HipIntegratorBase::finishStep(double dt) {
     data.hip->stepTaken();
 }
 
-void HipIntegrateVerletStepKernel::execute(ContextImpl& context, const VerletIntegrator& integrator) {
+void HipIntegrateVerletStepKernel::launchStep(ContextImpl& context, const VerletIntegrator& integrator, long long stepIndex) {
     // ReferenceVerletDynamics.cpp:76-119
     HipContext& hip = *data.hip;
-    hip.setAsCurrent();
     const double dt = integrator.getStepSize();
     ommhip_integrator_state s;
     fillState(s, dt);
+    s.step = (unsigned long long) stepIndex;
     HipConstraints& constraints = data.getDeviceConstraints(context.getSystem());
     if (constraints.fusedStepAvailable()) constraints.fusedStep(OMMHIP_INTEGRATOR_VERLET, s, integrator.getConstraintTolerance());
     else if (hip.decomposed()) throw OpenMMException("HIP platform: multi-GPU runs need constraints that form SETTLE waters or X-H clusters (no CCMA)");
@@ -1354,7 +1413,17 @@ void HipIntegrateVerletStepKernel::execute(ContextImpl& context, const VerletInt
         HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_FINISH_POSITIONS, &s, hip.stream));
         hip.momentumValid = false;
     }
-    finishStep(dt);
+}
+void HipIntegrateVerletStepKernel::execute(ContextImpl& context, const VerletIntegrator& integrator) {
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    const std::function<void(long long)> launch = [this, &context, &integrator](long long index) { launchStep(context, integrator, index); };
+    hip.replaySteps = [this, &context, &integrator, launch](int steps) { runSteps(context, integrator, launch, (long long) data.stepCount - steps, data.stepCount, false); };
+    // the forces just evaluated belong to the oldest step not done yet: this one, or the first of those the device skipped
+    const int skipped = hip.pendingReplay;
+    hip.pendingReplay = 0;
+    runSteps(context, integrator, launch, (long long) data.stepCount - skipped, (long long) data.stepCount + 1, true);
+    finishStep(integrator.getStepSize());
 }
 double HipIntegrateVerletStepKernel::computeKineticEnergy(ContextImpl& context, const VerletIntegrator& integrator) {
     return kineticEnergy(0.5 * integrator.getStepSize());
@@ -1369,13 +1438,13 @@ static unsigned long long resolveSeed(int seed) {
 void HipIntegrateLangevinStepKernel::initialize(const System& system, const LangevinIntegrator& integrator) {
     seed = resolveSeed(integrator.getRandomNumberSeed());
 }
-void HipIntegrateLangevinStepKernel::execute(ContextImpl& context, const LangevinIntegrator& integrator) {
+void HipIntegrateLangevinStepKernel::launchStep(ContextImpl& context, const LangevinIntegrator& integrator, long long stepIndex) {
     // ReferenceStochasticDynamics.cpp:89-194
     HipContext& hip = *data.hip;
-    hip.setAsCurrent();
     const double dt = integrator.getStepSize(), friction = integrator.getFriction(), kT = BOLTZ * integrator.getTemperature();
     ommhip_integrator_state s;
     fillState(s, dt);
+    s.step = (unsigned long long) stepIndex;
     s.seed = seed;
     s.vscale = exp(-dt * friction);
     s.fscale = friction == 0 ? dt : (1 - s.vscale) / friction;
@@ -1389,7 +1458,17 @@ void HipIntegrateLangevinStepKernel::execute(ContextImpl& context, const Langevi
         HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_FINISH_POSITIONS, &s, hip.stream));
         hip.momentumValid = false;
     }
-    finishStep(dt);
+}
+void HipIntegrateLangevinStepKernel::execute(ContextImpl& context, const LangevinIntegrator& integrator) {
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    const std::function<void(long long)> launch = [this, &context, &integrator](long long index) { launchStep(context, integrator, index); };
+    hip.replaySteps = [this, &context, &integrator, launch](int steps) { runSteps(context, integrator, launch, (long long) data.stepCount - steps, data.stepCount, false); };
+    // the forces just evaluated belong to the oldest step not done yet: this one, or the first of those the device skipped
+    const int skipped = hip.pendingReplay;
+    hip.pendingReplay = 0;
+    runSteps(context, integrator, launch, (long long) data.stepCount - skipped, (long long) data.stepCount + 1, true);
+    finishStep(integrator.getStepSize());
 }
 double HipIntegrateLangevinStepKernel::computeKineticEnergy(ContextImpl& context, const LangevinIntegrator& integrator) {
     return kineticEnergy(0.5 * integrator.getStepSize());
@@ -1398,14 +1477,14 @@ double HipIntegrateLangevinStepKernel::computeKineticEnergy(ContextImpl& context
 void HipIntegrateLangevinMiddleStepKernel::initialize(const System& system, const LangevinMiddleIntegrator& integrator) {
     seed = resolveSeed(integrator.getRandomNumberSeed());
 }
-void HipIntegrateLangevinMiddleStepKernel::execute(ContextImpl& context, const LangevinMiddleIntegrator& integrator) {
+void HipIntegrateLangevinMiddleStepKernel::launchStep(ContextImpl& context, const LangevinMiddleIntegrator& integrator, long long stepIndex) {
     // ReferenceLangevinMiddleDynamics.cpp:92-127
     HipContext& hip = *data.hip;
-    hip.setAsCurrent();
     const double dt = integrator.getStepSize(), friction = integrator.getFriction(), kT = BOLTZ * integrator.getTemperature();
     const double tol = integrator.getConstraintTolerance();
     ommhip_integrator_state s;
     fillState(s, dt);
+    s.step = (unsigned long long) stepIndex;
     s.seed = seed;
     s.vscale = exp(-dt * friction);
     s.noisescale = sqrt(kT * (1 - s.vscale * s.vscale));
@@ -1420,7 +1499,17 @@ void HipIntegrateLangevinMiddleStepKernel::execute(ContextImpl& context, const L
         HIP_CHECK(ommhip_integrate_stage(OMMHIP_STAGE_LMIDDLE_3, &s, hip.stream));
         hip.momentumValid = false;
     }
-    finishStep(dt);
+}
+void HipIntegrateLangevinMiddleStepKernel::execute(ContextImpl& context, const LangevinMiddleIntegrator& integrator) {
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    const std::function<void(long long)> launch = [this, &context, &integrator](long long index) { launchStep(context, integrator, index); };
+    hip.replaySteps = [this, &context, &integrator, launch](int steps) { runSteps(context, integrator, launch, (long long) data.stepCount - steps, data.stepCount, false); };
+    // the forces just evaluated belong to the oldest step not done yet: this one, or the first of those the device skipped
+    const int skipped = hip.pendingReplay;
+    hip.pendingReplay = 0;
+    runSteps(context, integrator, launch, (long long) data.stepCount - skipped, (long long) data.stepCount + 1, true);
+    finishStep(integrator.getStepSize());
 }
 double HipIntegrateLangevinMiddleStepKernel::computeKineticEnergy(ContextImpl& context, const LangevinMiddleIntegrator& integrator) {
     return kineticEnergy(0.0);

@@ -8,6 +8,7 @@
 #include "HipContext.h"
 #include "openmm/kernels.h"
 #include "openmm/System.h"
+#include <functional>
 #include <map>
 #include <set>
 #include <string>
@@ -124,6 +125,9 @@ private:
     void setupPme();
     void fillPmeStruct();
     void launchPme(int includeEnergy, bool spreadDone = false, bool fftDone = false);
+    /** Synchronous overflow check (HipContext::listRecovery): grows the list and requests a rebuild if a device-triggered
+     *  rebuild ran out of rows; returns the number of integration steps the device skipped meanwhile. */
+    int recoverFromOverflow();
     /** The evaluation on one rank of a domain-decomposed run (PME only). */
     double executeDecomposed(ContextImpl& context, bool includeForces, bool includeEnergy, bool includeDirect, bool includeReciprocal);
     void setupPmeDecomposed();
@@ -160,6 +164,7 @@ private:
     ommhip_pme pme;
     int* pinnedState;
     bool stateCopyPending;
+    bool debugShrinkDone = false;
 };
 
 /** Common code of the per-term bonded kernels. */
@@ -221,6 +226,9 @@ protected:
     void fillState(ommhip_integrator_state& s, double dt);
     double kineticEnergy(double timeShift);
     void finishStep(double dt);
+    /** Steps firstIndex .. endIndex-1 (force evaluation + launch each; the first without the evaluation if haveForces). */
+    void runSteps(ContextImpl& context, const Integrator& integrator, const std::function<void(long long)>& launch,
+                  long long firstIndex, long long endIndex, bool haveForces);
     HipPlatform::PlatformData& data;
 };
 
@@ -231,6 +239,8 @@ public:
     void initialize(const System& system, const VerletIntegrator& integrator) {}
     void execute(ContextImpl& context, const VerletIntegrator& integrator);
     double computeKineticEnergy(ContextImpl& context, const VerletIntegrator& integrator);
+private:
+    void launchStep(ContextImpl& context, const VerletIntegrator& integrator, long long stepIndex);
 };
 
 /** kernels.h:1160-1188 IntegrateLangevinStepKernel; Reference: ReferenceKernels.cpp:2360-2402. */
@@ -241,6 +251,7 @@ public:
     void execute(ContextImpl& context, const LangevinIntegrator& integrator);
     double computeKineticEnergy(ContextImpl& context, const LangevinIntegrator& integrator);
 private:
+    void launchStep(ContextImpl& context, const LangevinIntegrator& integrator, long long stepIndex);
     unsigned long long seed;
 };
 
@@ -252,6 +263,7 @@ public:
     void execute(ContextImpl& context, const LangevinMiddleIntegrator& integrator);
     double computeKineticEnergy(ContextImpl& context, const LangevinMiddleIntegrator& integrator);
 private:
+    void launchStep(ContextImpl& context, const LangevinMiddleIntegrator& integrator, long long stepIndex);
     unsigned long long seed;
 };
 

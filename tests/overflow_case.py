@@ -1,0 +1,52 @@
+"""Neighbour-list overflow on a device-triggered rebuild: the device freezes the integration
+while the list is incomplete, the host notices late (every 16th evaluation, or at the next download), grows the list and
+redoes the skipped steps in order -- the trajectory must be the one of an undisturbed run.  Shared by the CPU-emulator test
+and the GPU test; the reference's remedy is the immediate retry of ContextImpl.cpp:298-307 / CudaNonbondedUtilities.cpp:423-456."""
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+CHILD = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+from openmm_amd import harness as H, testsystems as T
+H.load_hip_platform(emulated=%r)
+
+
+def run(shrink, steps):
+    if shrink:
+        os.environ["OPENMM_HIP_DEBUG_SHRINK_LIST_AFTER"] = "3"      # the 3rd evaluation rebuilds into an allocation 8 chunks too small
+    else:
+        os.environ.pop("OPENMM_HIP_DEBUG_SHRINK_LIST_AFTER", None)
+    w = T.water_box(%d, seed=9)
+    w.pme_params = (float(np.sqrt(-np.log(2 * w.ewald_tol)) / w.cutoff), %d, %d, %d)
+    w.cm_remover = True
+    s, nb = w.build()
+    integ = H.Integrator(H.LANGEVIN_MIDDLE, 0.002, 300.0, 1.0, seed=5)
+    c = H.Context(s, integ, "HIP")
+    c.setPositions(w.positions); c.applyConstraints(1e-6); c.setVelocitiesToTemperature(300.0, 2)
+    integ.step(steps)
+    st = c.getState(getPositions=True, getVelocities=True, getEnergy=True)
+    c.close()
+    return st
+
+
+for steps in (5, 40):        # 5: found at the download (getState); 40: found by the lazy read-back during the run
+    a, b = run(False, steps), run(True, steps)
+    dpos, dvel = np.abs(a.positions - b.positions).max(), np.abs(a.velocities - b.velocities).max()
+    print(steps, "steps: dpos", dpos, "dvel", dvel, "time", a.time, b.time, flush=True)
+    assert a.time == b.time
+    assert dpos < %g and dvel < %g, (dpos, dvel)
+print("OK")
+'''
+
+
+def run_overflow_case(tmp_path, emulated, n_side, grid, pos_tol, vel_tol):
+    script = tmp_path / "overflow_child.py"
+    script.write_text(CHILD % (ROOT, emulated, n_side, grid, grid, grid, pos_tol, vel_tol))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=1200)
+    assert "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    assert out.stderr.count("neighbour list overflowed") == 2, out.stderr[-2000:]
+    return out.stdout

@@ -201,3 +201,11 @@ print("OK")
 ''' % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@needs_emu
+def test_neighbour_list_overflow_is_recovered(tmp_path):
+    """A device-triggered rebuild that runs out of rows freezes the integration on the device; the host grows the list and
+    redoes the skipped steps: same trajectory as an undisturbed run (tests/overflow_case.py)."""
+    from overflow_case import run_overflow_case
+    print(run_overflow_case(tmp_path, True, 7, 20, 1e-6, 1e-4))

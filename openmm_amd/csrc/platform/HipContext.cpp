@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 using namespace OpenMM;
 using namespace std;
@@ -36,6 +37,40 @@ unsigned long long hilbertIndex(unsigned x, unsigned y, unsigned z, int bits) {
         for (int i = 0; i < 3; i++)
             key = (key << 1) | ((X[i] >> b) & 1u);
     return key;
+}
+
+/* Host-side helpers of the re-sort (every few hundred steps, but O(N) serial work shows at a million atoms). */
+int hostThreads(int ranksOnNode) {
+    static const int forced = getenv("OPENMM_HIP_HOST_THREADS") != NULL ? atoi(getenv("OPENMM_HIP_HOST_THREADS")) : 0;
+    if (forced > 0) return forced;
+    const int hw = (int) std::thread::hardware_concurrency();
+    return std::max(1, std::min(16, hw / std::max(1, ranksOnNode)));
+}
+template <class F>
+void parallelFor(int n, int threads, const F& body) {          // body(begin, end)
+    if (threads <= 1 || n < 50000) { body(0, n); return; }
+    std::vector<std::thread> pool;
+    const int chunk = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; t++) {
+        const int b = t * chunk, e = std::min(n, b + chunk);
+        if (b >= e) break;
+        pool.push_back(std::thread([&body, b, e]() { body(b, e); }));
+    }
+    for (size_t t = 0; t < pool.size(); t++) pool[t].join();
+}
+/* Stable LSD radix sort of (key, value) pairs on the low `bits` bits of the key, 11 bits per pass. */
+void radixSortPairs(std::vector<std::pair<unsigned long long, int> >& v, int bits) {
+    std::vector<std::pair<unsigned long long, int> > tmp(v.size());
+    const int digit = 11, buckets = 1 << digit;
+    std::vector<size_t> count(buckets);
+    for (int shift = 0; shift < bits; shift += digit) {
+        std::fill(count.begin(), count.end(), 0);
+        for (size_t i = 0; i < v.size(); i++) count[(v[i].first >> shift) & (buckets - 1)]++;
+        size_t run = 0;
+        for (int b = 0; b < buckets; b++) { const size_t c = count[b]; count[b] = run; run += c; }
+        for (size_t i = 0; i < v.size(); i++) tmp[count[(v[i].first >> shift) & (buckets - 1)]++] = v[i];
+        v.swap(tmp);
+    }
 }
 }  // namespace
 
@@ -414,15 +449,18 @@ void HipContext::computeOrder(const vector<Vec3>& positions, vector<int>& order,
     int bits = 1;
     while ((1 << bits) < maxCells) bits++;
     vector<pair<unsigned long long, int> > keyed(numAtoms);
-    for (int i = 0; i < numAtoms; i++) {
-        unsigned c[3];
-        for (int k = 0; k < 3; k++) {
-            int v = (int) floor((wrapped[i][k] - lo[k]) / binWidth);
-            c[k] = (unsigned) max(0, min(ncell[k] - 1, v));
+    const int threads = hostThreads(domain.ranks);
+    parallelFor(numAtoms, threads, [&](int begin, int end) {
+        for (int i = begin; i < end; i++) {
+            unsigned c[3];
+            for (int k = 0; k < 3; k++) {
+                int v = (int) floor((wrapped[i][k] - lo[k]) / binWidth);
+                c[k] = (unsigned) max(0, min(ncell[k] - 1, v));
+            }
+            keyed[i] = make_pair(hilbertIndex(c[0], c[1], c[2], bits), i);
         }
-        keyed[i] = make_pair(hilbertIndex(c[0], c[1], c[2], bits), i);
-    }
-    sort(keyed.begin(), keyed.end());
+    });
+    radixSortPairs(keyed, 3 * bits);          // stable: equal keys stay in atom order, as a sort of (key, atom) pairs would leave them
     for (int i = 0; i < numAtoms; i++) order[i] = keyed[i].second;
 }
 
@@ -456,8 +494,13 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
     }
     // ---- cut along x into R groups of (nearly) equal atom count
     vector<int> byX(numUnits);
-    for (int u = 0; u < numUnits; u++) byX[u] = u;
-    sort(byX.begin(), byX.end(), [&](int a, int b) { return ref[a][0] < ref[b][0] || (ref[a][0] == ref[b][0] && a < b); });
+    {
+        vector<pair<unsigned long long, int> > xs(numUnits);
+        const double scale = 4294967295.0 / L[0];
+        for (int u = 0; u < numUnits; u++) xs[u] = make_pair((unsigned long long) (max(0.0, min(L[0], ref[u][0])) * scale), u);
+        radixSortPairs(xs, 33);                  // 32-bit fixed-point x; ties stay in unit order
+        for (int u = 0; u < numUnits; u++) byX[u] = xs[u].second;
+    }
     vector<int> groupStart(R + 1, numUnits);
     groupStart[0] = 0;
     {
@@ -487,7 +530,7 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
             for (int k = 0; k < 3; k++) c[k] = (unsigned) max(0, min(ncell[k] - 1, (int) floor(ref[u][k] / binWidth)));
             keyed.push_back(make_pair(hilbertIndex(c[0], c[1], c[2], bits), u));
         }
-        sort(keyed.begin(), keyed.end());
+        radixSortPairs(keyed, 3 * bits);
         int slot = g * slotsPerRank;
         for (size_t i = 0; i < keyed.size(); i++) {
             const int u = keyed[i].second;

@@ -32,6 +32,7 @@ public:
     DeviceBuffer() : ptr(NULL), bytes(0) {}
     ~DeviceBuffer() { release(); }
     void allocate(size_t nbytes) {
+        if (ptr != NULL && bytes == nbytes) return;       // same size: keep the allocation (contents unspecified either way)
         release();
         HIP_CHECK(ommhip_malloc(&ptr, nbytes));
         bytes = nbytes;

@@ -20,6 +20,8 @@
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <thread>
+#include <sstream>
 
 using namespace OpenMM;
 using namespace std;
@@ -562,10 +564,12 @@ double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool
     checkDecomposedFlags();
     if (nl.max_chunks == 0) allocateNeighborList((int) (estimateChunks() * 1.4 / hip.domain.ranks) + 256);
     if (stateCopyPending && (pinnedState[2] != 0 || pinnedState[1] > nl.max_chunks)) {
-        fprintf(stderr, "HIP platform: neighbour list overflowed (%d chunks needed, %d allocated); growing and rebuilding\n", pinnedState[1], nl.max_chunks);
-        hip.sync();
-        allocateNeighborList((int) (pinnedState[1] * 1.5) + 64);
-        forceRebuild = true;
+        // the ranks step in lockstep through the all-gather, so one of them cannot freeze and redo steps on its own:
+        // a list that outgrows 1.5x its verified size on a decomposed run ends the run instead of producing wrong forces
+        stringstream msg;
+        msg << "HIP platform: the neighbour list of rank " << hip.domain.rank << " overflowed (" << pinnedState[1] << " chunks needed, " << nl.max_chunks
+            << " allocated) on a multi-GPU run; the last steps are invalid";
+        throw OpenMMException(msg.str());
     }
     while (true) {
         if (forceRebuild) {
@@ -888,28 +892,42 @@ void HipCalcNonbondedForceKernel::setupPme() {
 }
 
 void HipCalcNonbondedForceKernel::updateExclusionBlockRanges() {
-    // For every i-block: the lowest/highest block that holds an exclusion partner of one of its atoms.
+    // For every i-block: the lowest/highest block that holds an exclusion partner of one of its atoms; and the exclusion CSR
+    // keyed by slot with partners as slots (the builder then needs one gather per partner instead of three).  Runs after every
+    // re-sort; block-parallel on the host (a million atoms take tens of milliseconds on one thread).
     const int numBlocks = hip.paddedAtoms / OMMHIP_TILE;
     vector<int> range(2 * (size_t) numBlocks);
-    for (int b = 0; b < numBlocks; b++) { range[2 * b] = numBlocks; range[2 * b + 1] = -1; }
-    for (int atom = 0; atom < numParticles; atom++) {
-        const int X = hip.hostSlotOfAtom[atom] / OMMHIP_TILE;
-        for (int e = hostExclStart[atom]; e < hostExclStart[atom + 1]; e++) {
-            const int Y = hip.hostSlotOfAtom[hostExclAtoms[e]] / OMMHIP_TILE;
-            range[2 * X] = min(range[2 * X], Y);
-            range[2 * X + 1] = max(range[2 * X + 1], Y);
-        }
-    }
-    HIP_CHECK(ommhip_memcpy_h2d(exclBlockRange.ptr, range.data(), sizeof(int) * range.size(), hip.stream));
-    // the same CSR keyed by slot, partners as slots: the builder then needs one gather per partner instead of three
     vector<int> slotStart(hip.paddedAtoms + 1, 0), slots(max((size_t) 1, hostExclAtoms.size()));
     for (int s = 0; s < hip.paddedAtoms; s++) {
         const int atom = hip.hostAtomOfSlot[s];
-        int n = slotStart[s];
-        if (atom >= 0)
-            for (int e = hostExclStart[atom]; e < hostExclStart[atom + 1]; e++) slots[n++] = hip.hostSlotOfAtom[hostExclAtoms[e]];
-        slotStart[s + 1] = n;
+        slotStart[s + 1] = slotStart[s] + (atom >= 0 ? hostExclStart[atom + 1] - hostExclStart[atom] : 0);
     }
+    auto body = [&](int begin, int end) {
+        for (int b = begin; b < end; b++) {
+            int lo = numBlocks, hi = -1;
+            for (int s = b * OMMHIP_TILE; s < (b + 1) * OMMHIP_TILE; s++) {
+                const int atom = hip.hostAtomOfSlot[s];
+                if (atom < 0) continue;
+                int n = slotStart[s];
+                for (int e = hostExclStart[atom]; e < hostExclStart[atom + 1]; e++) {
+                    const int partner = hip.hostSlotOfAtom[hostExclAtoms[e]];
+                    slots[n++] = partner;
+                    lo = min(lo, partner / OMMHIP_TILE);
+                    hi = max(hi, partner / OMMHIP_TILE);
+                }
+            }
+            range[2 * b] = lo; range[2 * b + 1] = hi;
+        }
+    };
+    const int threads = numBlocks >= 4096 ? max(1, min(16, (int) std::thread::hardware_concurrency() / max(1, hip.domain.ranks))) : 1;
+    if (threads <= 1) body(0, numBlocks);
+    else {
+        vector<std::thread> pool;
+        const int chunk = (numBlocks + threads - 1) / threads;
+        for (int t = 0; t < threads && t * chunk < numBlocks; t++) pool.push_back(std::thread(body, t * chunk, min(numBlocks, (t + 1) * chunk)));
+        for (size_t t = 0; t < pool.size(); t++) pool[t].join();
+    }
+    HIP_CHECK(ommhip_memcpy_h2d(exclBlockRange.ptr, range.data(), sizeof(int) * range.size(), hip.stream));
     exclSlotStart.allocate(sizeof(int) * slotStart.size());
     exclSlots.allocate(sizeof(int) * slots.size());
     HIP_CHECK(ommhip_memcpy_h2d(exclSlotStart.ptr, slotStart.data(), sizeof(int) * slotStart.size(), hip.stream));

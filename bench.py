@@ -9,9 +9,10 @@ OpenMM "HIP" platform, one process per GPU.
 A "step" is one MD step = one pass of the hot path.  Timing protocol of examples/benchmark.py:9-18: warm-up steps, then time
 step(K) followed by getState(energy), which forces a device sync; barrier + synchronize on both sides, MAX over ranks.
 
-N = 1 (the headline, BASELINE.json configs[1]): a DHFR-sized system -- 23 558 atoms in a 6.223 nm
-cube, PME, cutoff 0.9 nm, Ewald tolerance 5e-4 (alpha 2.92/nm, grid 56^3), LangevinMiddleIntegrator 300 K, 1/ps, X-H
-constraints + rigid water, dt 2 fs -- generated synthetically (openmm_amd/testsystems.py:dhfr_like).  The JSON line also
+N = 1 (the headline, BASELINE.json configs[1], examples/benchmark.py `pme`): DHFR -- the 23 558 atoms of
+examples/5dfr_solv-cube_equil.pdb with amber99sb + tip3p parameters (openmm_amd/forcefield.py, fixture under tests/golden/),
+6.223 nm cube, PME, cutoff 0.9 nm, Ewald tolerance 5e-4 (alpha 2.92/nm, grid 56^3), LangevinMiddleIntegrator 300 K, 1/ps,
+HBonds constraints + rigid water, CMMotionRemover, dt 2 fs (--dt-fs 4 for the script's own step size).  The JSON line also
 carries `scale_workload`: the single-GPU ns/day of the water-1M box below, measured in the same run, i.e. the N = 1 point
 of the strong-scaling curve.
 
@@ -39,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 KERNEL_SOURCES = ("nonbonded.hip", "force_front.hip", "pme.hip", "neighbor.hip", "common.h")
-WORKLOADS = ["dhfr", "water24k", "water98k", "apoa1", "water1m"]
+WORKLOADS = ["dhfr", "dhfr_like", "water24k", "water98k", "apoa1", "water1m"]
 
 
 def parse_args():
@@ -63,7 +64,9 @@ def parse_args():
 def make_workload(name, seed):
     from openmm_amd import testsystems as T
     if name == "dhfr":
-        return T.dhfr_like(seed=seed)
+        return T.dhfr()                          # the real benchmark System (5dfr_solv-cube_equil.pdb, amber99sb + tip3p)
+    if name == "dhfr_like":
+        return T.dhfr_like(seed=seed)            # round-1 stand-in: same size, synthetic chain
     if name == "water24k":
         return T.water_box(20, seed=seed)
     if name == "apoa1":
@@ -218,7 +221,7 @@ def main():
         "value": round(value, 3), "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong" if decomposed else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d atoms, PME cutoff 0.9 nm grid %s, LangevinMiddle %.0f fs, X-H constraints + rigid water; %s" % (
+        "config": {"workload": "%s: %d atoms, PME cutoff 0.9 nm grid %s, LangevinMiddle %.0f fs, HBonds constraints + rigid water; %s" % (
             w.name, w.num_atoms, "x".join(str(g) for g in grid), args.dt_fs,
             ("ONE box domain-decomposed over %d GPUs (x slabs, %s collectives)" % (world, transport)) if decomposed else "single GPU"),
             "precision": "mixed (f32 forces, fixed-point accumulation, f64 integration)", "device": device_name,

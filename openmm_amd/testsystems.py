@@ -42,7 +42,7 @@ class Workload:
         nb = H.NonbondedForce(s, self.method, self.cutoff, self.ewald_tol, self.dispersion)
         nb.addParticles(self.charge, self.sigma, self.epsilon)
         if self.exception_bonds is not None and len(self.exception_bonds):
-            nb.createExceptionsFromBonds(self.exception_bonds, 1.0 / 1.2, 0.5)
+            nb.createExceptionsFromBonds(self.exception_bonds, getattr(self, "coulomb14", 1.0 / 1.2), getattr(self, "lj14", 0.5))
         if self.exceptions is not None and len(self.exceptions[0]):
             nb.addExceptions(*self.exceptions)
         if self.pme_params is not None:
@@ -177,6 +177,28 @@ def _load_fixture(w, filename):
             w.positions = data["positions"].astype(np.float64)
             w.velocities = data["velocities"].astype(np.float64)
             w.relaxed = True
+    return w
+
+
+def dhfr():
+    """The real DHFR benchmark System (examples/benchmark.py `pme`: 5dfr_solv-cube_equil.pdb, amber99sb + tip3p, PME 0.9 nm, HBonds,
+    rigid water, CMMotionRemover) from the fixture tests/golden/dhfr_5dfr_amber99sb_tip3p.npz, which tools/make_dhfr_fixture.py
+    builds from the reference's own input files with openmm_amd/forcefield.py; equilibrated positions and velocities."""
+    import os
+    d = np.load(os.path.join(H.ROOT, "tests", "golden", "dhfr_5dfr_amber99sb_tip3p.npz"))
+    w = Workload(str(d["name"]))
+    w.box = d["box"]
+    w.masses, w.charge = d["masses"].astype(np.float64), d["charge"].astype(np.float64)
+    w.sigma, w.epsilon = d["sigma"], d["epsilon"]
+    w.exception_bonds = d["exception_bonds"].astype(np.int64)
+    w.coulomb14, w.lj14, w.cutoff = float(d["coulomb14"]), float(d["lj14"]), float(d["cutoff"])
+    w.bonds = (d["bond_atoms"].astype(np.int64), d["bond_length"], d["bond_k"])
+    w.angles = (d["angle_atoms"].astype(np.int64), d["angle_theta"], d["angle_k"])
+    w.torsions = (d["torsion_atoms"].astype(np.int64), d["torsion_n"].astype(np.int32), d["torsion_phase"], d["torsion_k"])
+    w.constraints = (d["constraint_atoms"].astype(np.int64), d["constraint_length"])
+    w.positions, w.velocities = d["positions"], d["velocities"].astype(np.float64)
+    w.pdb_positions, w.pdb_potential_energy = d["pdb_positions"].astype(np.float64), float(d["pdb_potential_energy"])
+    w.method, w.dispersion, w.cm_remover, w.relaxed = H.PME, True, True, True
     return w
 
 

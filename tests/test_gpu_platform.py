@@ -106,6 +106,47 @@ def test_dhfr_size_forces_within_1e4_of_reference(dhfr_states):
     _check_forces_against_reference(w, out["HIP"], out["Reference"], "DHFR-size")
 
 
+def test_real_dhfr_forces_within_1e4_of_reference():
+    """BASELINE.json configs[1] itself: examples/5dfr_solv-cube_equil.pdb with amber99sb + tip3p (fixture built by
+    tools/make_dhfr_fixture.py through openmm_amd/forcefield.py), equilibrated coordinates; HIP against the Reference platform."""
+    w = T.dhfr()
+    assert w.num_atoms == 23558 and abs(w.charge.sum() + 11.0) < 1e-3 and len(w.constraints[0]) == 22290
+    out = {}
+    for plat in ("HIP", "Reference"):
+        system, nb = w.build()
+        ctx = H.Context(system, H.Integrator(H.VERLET, 0.001), plat)
+        ctx.setPositions(w.positions)
+        out[plat] = ctx.getState(getForces=True, getEnergy=True)
+        if plat == "HIP":
+            pme = nb.getPMEParametersInContext(ctx)
+            assert tuple(pme[1:]) == (56, 56, 56) and abs(pme[0] - 2.9203) < 1e-3
+        ctx.close()
+    _check_forces_against_reference(w, out["HIP"], out["Reference"], "DHFR (real)")
+
+
+@pytest.mark.parametrize("dt_fs", [2.0, 4.0])
+def test_real_dhfr_runs_at_2_and_4_fs(dt_fs):
+    """examples/benchmark.py:133-138 runs the pme test at 4 fs with HBonds; SURVEY.md §8(d) asks for 2 fs and 4 fs.  600 steps:
+    constraints hold, the temperature stays at the thermostat's."""
+    w = T.dhfr()
+    system, nb = w.build()
+    integ = H.Integrator(H.LANGEVIN_MIDDLE, dt_fs * 1e-3, 300.0, 1.0, seed=11, constraintTolerance=1e-5)
+    ctx = H.Context(system, integ, "HIP")
+    ctx.setPositions(w.positions)
+    ctx.setVelocities(w.velocities)
+    integ.step(600)
+    st = ctx.getState(getPositions=True, getEnergy=True)
+    pairs, dist = w.constraints
+    d = np.linalg.norm(st.positions[pairs[:, 0]] - st.positions[pairs[:, 1]], axis=1)
+    assert np.abs(d - dist).max() < 2e-5 * dist.max() + 1e-6
+    ndof = 3 * w.num_atoms - len(dist) - 3
+    temperature = 2 * st.kineticEnergy / (ndof * 0.00831446261815324)
+    print("DHFR at %.0f fs: T = %.1f K, E_pot = %.1f" % (dt_fs, temperature, st.potentialEnergy))
+    assert 285 < temperature < 315, temperature
+    assert np.isfinite(st.potentialEnergy) and st.potentialEnergy < -2.8e5
+    ctx.close()
+
+
 def test_apoa1_size_forces_within_1e4_of_reference():
     """BASELINE.json configs[2] (apoa1 size, 92 224 atoms; stand-in of SURVEY.md §8d config 3): rectangular non-cubic box,
     98 x 98 x 70 PME grid (radix-7 factors; planes too large for the fused pair/FFT launches, so the stand-alone FFT and

@@ -411,6 +411,12 @@ typedef struct ommhip_ccma {
 int ommhip_ccma_iteration(const ommhip_ccma* c, const void* pos_d, void* target_d, const void* vel_mass_d,
                           int velocities, double tol, int phase, void* stream);
 
+/* `iterations` CCMA iterations without host involvement: once every constraint is inside the tolerance (c->converged[2] = 1, set on
+ * the device) the remaining kernels leave at once.  c->converged is int[4], zeroed by the caller before the first batch; the
+ * caller reads converged[2] after a batch (CudaIntegrationUtilities.cpp:94-130 polls a mapped flag the same way). */
+int ommhip_ccma_iterations(const ommhip_ccma* c, const void* pos_d, void* target_d, const void* vel_mass_d,
+                           int velocities, double tol, int iterations, void* stream);
+
 /* RemoveCMMotionKernel::execute (kernels.h:1464; ReferenceKernels.cpp:2712-2740).  vel_d: double4 (vx,vy,vz,1/m). */
 int ommhip_remove_cm_motion(void* vel_d, int num_atoms, double* scratch4_d, void* stream);
 

@@ -561,12 +561,15 @@ struct CcmaArgs {
     double* delta;            // [numConstraints]
     double* delta2;
     const int* rowStart; const int* col; const double* value;
-    int* converged;
+    int* converged;           // [0] converged constraints of the iteration in flight, [1] blocks done, [2] all converged (sticky), [3] iterations run
+    int resident;             // 1: the iteration kernels look at [2] and leave once it is set (batches of iterations without host round trips)
 };
 
-__global__ void k_ccma_delta(CcmaArgs a) {
+__global__ __launch_bounds__(128) void k_ccma_delta(CcmaArgs a) {
+    if (a.resident && a.converged[2] != 0) return;
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.numConstraints) return;
+    bool ok = false;
+    if (c < a.numConstraints) {
     const int2 at = a.atoms[c];
     const V3 r = xyz(a.pos[at.x]) - xyz(a.pos[at.y]);
     const V3 rp = xyz(a.target[at.x]) - xyz(a.target[at.y]);
@@ -584,9 +587,26 @@ __global__ void k_ccma_delta(CcmaArgs a) {
         ok = rp2 >= lowerTol * d2 && rp2 <= upperTol * d2;
     }
     a.delta[c] = delta;
-    if (ok) atomicAdd(a.converged, 1);
+    }
+    const int waveOk = __popcll(__ballot(ok));
+    if (lane_id() == 0 && waveOk > 0) atomicAdd(a.converged, waveOk);
+    if (!a.resident) return;
+    // device-resident loop: the last workgroup of the iteration decides whether everything has converged
+    __shared__ bool last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(&a.converged[1], 1) == (int) gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        if (atomicAdd(&a.converged[0], 0) == a.numConstraints) a.converged[2] = 1;
+        a.converged[0] = 0; a.converged[1] = 0;
+        a.converged[3] += 1;
+    }
 }
 __global__ void k_ccma_multiply(CcmaArgs a) {
+    if (a.resident && a.converged[2] != 0) return;
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.numConstraints) return;
     double sum = 0;
@@ -594,6 +614,7 @@ __global__ void k_ccma_multiply(CcmaArgs a) {
     a.delta2[c] = sum;
 }
 __global__ void k_ccma_update(CcmaArgs a) {
+    if (a.resident && a.converged[2] != 0) return;
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.numConstraints) return;
     const int2 at = a.atoms[c];
@@ -703,13 +724,34 @@ extern "C" int ommhip_ccma_iteration(const ommhip_ccma* c, const void* pos_d, vo
     a.numConstraints = c->num_constraints; a.velocities = velocities; a.tol = tol;
     a.atoms = (const int2*) c->atoms; a.dist = c->distance; a.pos = (const double4*) pos_d; a.target = (double4*) target_d;
     a.velMass = (const double4*) vel_mass_d; a.delta = c->delta; a.delta2 = c->delta2;
-    a.rowStart = c->row_start; a.col = c->col; a.value = c->value; a.converged = c->converged;
+    a.rowStart = c->row_start; a.col = c->col; a.value = c->value; a.converged = c->converged; a.resident = 0;
     hipStream_t st = (hipStream_t) stream;
     if (phase == 0) {
         hipMemsetAsync(c->converged, 0, sizeof(int), st);
         hipLaunchKernelGGL(k_ccma_delta, grid_for(a.numConstraints), BLOCK128, 0, st, a);
     }
     else {
+        hipLaunchKernelGGL(k_ccma_multiply, grid_for(a.numConstraints), BLOCK128, 0, st, a);
+        hipLaunchKernelGGL(k_ccma_update, grid_for(a.numConstraints), BLOCK128, 0, st, a);
+    }
+    return (int) hipGetLastError();
+}
+
+// Device-resident CCMA: `iterations` iterations enqueued back to back; each one leaves at once when an earlier one found every
+// constraint converged (converged[2], set by the last workgroup of its delta kernel).  The caller zeroes converged[0..3] before
+// the first batch and reads converged[2] after each batch -- the loop of platforms/cuda/src/CudaIntegrationUtilities.cpp:94-130,
+// which looks at a host-mapped flag every few iterations instead of after every one.
+extern "C" int ommhip_ccma_iterations(const ommhip_ccma* c, const void* pos_d, void* target_d, const void* vel_mass_d,
+                                      int velocities, double tol, int iterations, void* stream) {
+    if (c->num_constraints <= 0) return 0;
+    CcmaArgs a;
+    a.numConstraints = c->num_constraints; a.velocities = velocities; a.tol = tol;
+    a.atoms = (const int2*) c->atoms; a.dist = c->distance; a.pos = (const double4*) pos_d; a.target = (double4*) target_d;
+    a.velMass = (const double4*) vel_mass_d; a.delta = c->delta; a.delta2 = c->delta2;
+    a.rowStart = c->row_start; a.col = c->col; a.value = c->value; a.converged = c->converged; a.resident = 1;
+    hipStream_t st = (hipStream_t) stream;
+    for (int i = 0; i < iterations; i++) {
+        hipLaunchKernelGGL(k_ccma_delta, grid_for(a.numConstraints), BLOCK128, 0, st, a);
         hipLaunchKernelGGL(k_ccma_multiply, grid_for(a.numConstraints), BLOCK128, 0, st, a);
         hipLaunchKernelGGL(k_ccma_update, grid_for(a.numConstraints), BLOCK128, 0, st, a);
     }

@@ -260,14 +260,17 @@ void HipConstraints::fusedStep(int integrator, const ommhip_integrator_state& st
 }
 
 void HipConstraints::runCcma(void* target, bool velocities, double tol) {
-    // ReferenceCCMAAlgorithm.cpp:240-310; the converged count comes back to the host every iteration.
-    for (int iteration = 0; iteration < 150; iteration++) {
-        HIP_CHECK(ommhip_ccma_iteration(&ccma, hip.pos.ptr, target, hip.vel.ptr, velocities, tol, 0, hip.stream));
-        int converged = 0;
-        HIP_CHECK(ommhip_memcpy_d2h(&converged, ccma.converged, sizeof(int), hip.stream));
+    // ReferenceCCMAAlgorithm.cpp:240-310 as a device-resident loop: batches of four iterations are enqueued without waiting;
+    // the kernels of an iteration leave at once when an earlier one found every constraint converged, and the host looks at that
+    // flag once per batch (the reference's GPU platforms poll a mapped flag every few iterations, CudaIntegrationUtilities.cpp:94-130).
+    HIP_CHECK(ommhip_memset(ccma.converged, 0, sizeof(int) * 4, hip.stream));
+    const int batch = 4;
+    for (int done = 0; done < 150; done += batch) {
+        HIP_CHECK(ommhip_ccma_iterations(&ccma, hip.pos.ptr, target, hip.vel.ptr, velocities ? 1 : 0, tol, batch, hip.stream));
+        int state[4] = {0, 0, 0, 0};
+        HIP_CHECK(ommhip_memcpy_d2h(state, ccma.converged, sizeof(state), hip.stream));
         hip.sync();
-        if (converged == numCcma) break;
-        HIP_CHECK(ommhip_ccma_iteration(&ccma, hip.pos.ptr, target, hip.vel.ptr, velocities, tol, 1, hip.stream));
+        if (state[2] != 0) break;
     }
 }
 

@@ -417,6 +417,12 @@ int ommhip_ccma_iteration(const ommhip_ccma* c, const void* pos_d, void* target_
 int ommhip_ccma_iterations(const ommhip_ccma* c, const void* pos_d, void* target_d, const void* vel_mass_d,
                            int velocities, double tol, int iterations, void* stream);
 
+/* ApplyMonteCarloBarostatKernel::scaleCoordinates (kernels.h:1425-1459; ReferenceMonteCarloBarostat.cpp:68-104): every molecule
+ * is moved rigidly so that its centre, wrapped into the first periodic box (box[6], reduced form), is scaled by (sx, sy, sz).
+ * mol_start_d / mol_atoms_d: CSR of the molecules' atoms.  pos_d double4[num_atoms] is updated in place. */
+int ommhip_scale_molecule_centers(int num_molecules, const int* mol_start_d, const int* mol_atoms_d, void* pos_d,
+                                  const double box[6], double sx, double sy, double sz, void* stream);
+
 /* RemoveCMMotionKernel::execute (kernels.h:1464; ReferenceKernels.cpp:2712-2740).  vel_d: double4 (vx,vy,vz,1/m). */
 int ommhip_remove_cm_motion(void* vel_d, int num_atoms, double* scratch4_d, void* stream);
 

@@ -97,6 +97,24 @@ __global__ void k_unpack_slots(const double4* __restrict__ src, const int* __res
     if (a >= 0) dst[a] = src[s];
 }
 
+// ReferenceMonteCarloBarostat.cpp:68-104, one thread per molecule
+__global__ void k_scale_molecule_centers(int numMolecules, const int* __restrict__ molStart, const int* __restrict__ molAtoms, double4* __restrict__ pos,
+                                         BoxD box, double sx, double sy, double sz) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= numMolecules) return;
+    const int b = molStart[m], e = molStart[m + 1];
+    double cx = 0, cy = 0, cz = 0;
+    for (int i = b; i < e; i++) { const double4 p = pos[molAtoms[i]]; cx += p.x; cy += p.y; cz += p.z; }
+    const double inv = 1.0 / (e - b);
+    cx *= inv; cy *= inv; cz *= inv;
+    double nx = cx, ny = cy, nz = cz;
+    double f = floor(nz / box.cz); nx -= f * box.cx; ny -= f * box.cy; nz -= f * box.cz;
+    f = floor(ny / box.by); nx -= f * box.bx; ny -= f * box.by;
+    f = floor(nx / box.ax); nx -= f * box.ax;
+    const double ox = nx * sx - cx, oy = ny * sy - cy, oz = nz * sz - cz;
+    for (int i = b; i < e; i++) { double4 p = pos[molAtoms[i]]; p.x += ox; p.y += oy; p.z += oz; pos[molAtoms[i]] = p; }
+}
+
 BoxD make_boxd(const double* bv) {
     BoxD b; b.ax = bv[0]; b.bx = bv[1]; b.by = bv[2]; b.cx = bv[3]; b.cy = bv[4]; b.cz = bv[5];
     return b;
@@ -157,5 +175,13 @@ extern "C" int ommhip_unpack_slots(const void* src_slot_order_d, const int* atom
     if (slot1 <= slot0) return 0;
     hipLaunchKernelGGL(k_unpack_slots, dim3((slot1 - slot0 + 255) / 256), dim3(256), 0, (hipStream_t) stream,
                        (const double4*) src_slot_order_d, atom_of_slot_d, slot0, slot1, (double4*) dst_atom_order_d);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_scale_molecule_centers(int num_molecules, const int* mol_start_d, const int* mol_atoms_d, void* pos_d,
+                                             const double box[6], double sx, double sy, double sz, void* stream) {
+    if (num_molecules <= 0) return 0;
+    hipLaunchKernelGGL(k_scale_molecule_centers, dim3((num_molecules + 127) / 128), dim3(128), 0, (hipStream_t) stream,
+                       num_molecules, mol_start_d, mol_atoms_d, (double4*) pos_d, make_boxd(box), sx, sy, sz);
     return (int) hipGetLastError();
 }

@@ -1558,3 +1558,36 @@ void HipRemoveCMMotionKernel::execute(ContextImpl& context) {
     HIP_CHECK(ommhip_remove_cm_motion(hip.vel.ptr, hip.numAtoms, scratch.as<double>(), hip.stream));
     hip.momentumValid = false;
 }
+
+// ================================================================================================
+// MonteCarloBarostat
+// ================================================================================================
+void HipApplyMonteCarloBarostatKernel::initialize(const System& system, const Force& barostat) {
+}
+void HipApplyMonteCarloBarostatKernel::scaleCoordinates(ContextImpl& context, double scaleX, double scaleY, double scaleZ) {
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    if (numMolecules == 0) {
+        // molecules as ContextImpl finds them (bond- and constraint-connected atoms), as ReferenceKernels.cpp does on first use
+        const vector<vector<int> >& molecules = context.getMolecules();
+        vector<int> start(1, 0), atoms;
+        for (size_t m = 0; m < molecules.size(); m++) {
+            atoms.insert(atoms.end(), molecules[m].begin(), molecules[m].end());
+            start.push_back((int) atoms.size());
+        }
+        numMolecules = (int) molecules.size();
+        uploadVector(molStart, start, hip.stream);
+        uploadVector(molAtoms, atoms, hip.stream);
+        savedPos.allocate(hip.pos.bytes);
+    }
+    hip.recoverIfFrozen();
+    HIP_CHECK(ommhip_memcpy_d2d(savedPos.ptr, hip.pos.ptr, hip.pos.bytes, hip.stream));
+    HIP_CHECK(ommhip_scale_molecule_centers(numMolecules, molStart.as<int>(), molAtoms.as<int>(), hip.pos.ptr, hip.box, scaleX, scaleY, scaleZ, hip.stream));
+    hip.requestReorder();          // wrap counts and slot order refer to the old box
+}
+void HipApplyMonteCarloBarostatKernel::restoreCoordinates(ContextImpl& context) {
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    HIP_CHECK(ommhip_memcpy_d2d(hip.pos.ptr, savedPos.ptr, hip.pos.bytes, hip.stream));
+    hip.requestReorder();
+}

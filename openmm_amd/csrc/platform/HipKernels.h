@@ -279,5 +279,19 @@ private:
     DeviceBuffer scratch;
 };
 
+/** kernels.h:1425-1459 ApplyMonteCarloBarostatKernel; Reference: ReferenceKernels.cpp ReferenceApplyMonteCarloBarostatKernel,
+ *  ReferenceMonteCarloBarostat.cpp:68-120.  Keeps NPT runs in device mode: positions are scaled and restored in HBM. */
+class HipApplyMonteCarloBarostatKernel : public ApplyMonteCarloBarostatKernel {
+public:
+    HipApplyMonteCarloBarostatKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : ApplyMonteCarloBarostatKernel(name, platform), data(data), numMolecules(0) {}
+    void initialize(const System& system, const Force& barostat);
+    void scaleCoordinates(ContextImpl& context, double scaleX, double scaleY, double scaleZ);
+    void restoreCoordinates(ContextImpl& context);
+private:
+    HipPlatform::PlatformData& data;
+    int numMolecules;
+    DeviceBuffer molStart, molAtoms, savedPos;
+};
+
 }  // namespace OpenMM
 #endif

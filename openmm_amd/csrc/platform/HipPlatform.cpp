@@ -47,13 +47,14 @@ namespace OpenMM {
  *                   on the GPU from an uploaded copy of the positions.
  */
 struct HipModeInfo {
+    bool hasBarostat;
     bool hostMode;
     bool referenceNonbonded;     // LJPME: NonbondedForce itself falls back to Reference
     bool hasFallbackForces;
 };
 
 static HipModeInfo classifyContext(ContextImpl& context) {
-    HipModeInfo info = {false, false, false};
+    HipModeInfo info = {false, false, false, false};
     const System& system = context.getSystem();
     const Integrator& integrator = context.getIntegrator();
     if (dynamic_cast<const VerletIntegrator*>(&integrator) == NULL && dynamic_cast<const LangevinIntegrator*>(&integrator) == NULL &&
@@ -70,7 +71,11 @@ static HipModeInfo classifyContext(ContextImpl& context) {
         if (dynamic_cast<const HarmonicBondForce*>(&f) != NULL || dynamic_cast<const HarmonicAngleForce*>(&f) != NULL ||
                 dynamic_cast<const PeriodicTorsionForce*>(&f) != NULL || dynamic_cast<const CMMotionRemover*>(&f) != NULL)
             continue;
-        if (dynamic_cast<const AndersenThermostat*>(&f) != NULL || dynamic_cast<const MonteCarloBarostat*>(&f) != NULL ||
+        if (dynamic_cast<const MonteCarloBarostat*>(&f) != NULL || dynamic_cast<const MonteCarloAnisotropicBarostat*>(&f) != NULL) {
+            info.hasBarostat = true;        // native: positions are scaled / restored on the device (HipApplyMonteCarloBarostatKernel)
+            continue;
+        }
+        if (dynamic_cast<const AndersenThermostat*>(&f) != NULL ||
                 dynamic_cast<const MonteCarloAnisotropicBarostat*>(&f) != NULL || dynamic_cast<const MonteCarloMembraneBarostat*>(&f) != NULL ||
                 dynamic_cast<const CustomCVForce*>(&f) != NULL) {
             info.hostMode = true;       // these change state (or own an inner Context) on the host
@@ -114,6 +119,8 @@ public:
                 return new HipIntegrateLangevinMiddleStepKernel(name, platform, data);
             if (name == RemoveCMMotionKernel::Name())
                 return new HipRemoveCMMotionKernel(name, platform, data);
+            if (name == ApplyMonteCarloBarostatKernel::Name())
+                return new HipApplyMonteCarloBarostatKernel(name, platform, data);
         }
         return reference.createKernelImpl(name, platform, context);
     }
@@ -144,6 +151,7 @@ HipPlatform::HipPlatform() {
     registerKernelFactory(IntegrateLangevinStepKernel::Name(), factory);
     registerKernelFactory(IntegrateLangevinMiddleStepKernel::Name(), factory);
     registerKernelFactory(RemoveCMMotionKernel::Name(), factory);
+    registerKernelFactory(ApplyMonteCarloBarostatKernel::Name(), factory);
     platformProperties.push_back(HipDeviceIndex());
     platformProperties.push_back(HipDeviceName());
     platformProperties.push_back(HipPrecision());
@@ -215,7 +223,7 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
     if (domain.ranks < 1 || domain.rank < 0 || domain.rank >= domain.ranks)
         throw OpenMMException("HIP platform: illegal Ranks/Rank properties");
     if (domain.ranks > 1 || !commId.empty()) {
-        if (mode.hostMode || mode.hasFallbackForces || mode.referenceNonbonded)
+        if (mode.hostMode || mode.hasFallbackForces || mode.referenceNonbonded || mode.hasBarostat)
             throw OpenMMException("HIP platform: a multi-GPU Context supports NonbondedForce (PME), HarmonicBond/Angle, PeriodicTorsion and CMMotionRemover with the Verlet, Langevin and LangevinMiddle integrators");
         int count = 0;
         HIP_CHECK(ommhip_device_count(&count));

@@ -97,6 +97,8 @@ int ommhip_add_forces_from_double(const double* in_d, const int* slot_of_atom_d,
 int ommhip_pack_slots(const void* src_atom_order_d, const int* atom_of_slot_d, int slot0, int slot1, void* dst_slot_order_d, void* stream);
 /* dst[atom_of_slot[s]] = src[s] for the valid slots of [slot0, slot1) */
 int ommhip_unpack_slots(const void* src_slot_order_d, const int* atom_of_slot_d, int slot0, int slot1, void* dst_atom_order_d, void* stream);
+/* dst[s] = (src[s].xyz, w[atom_of_slot[s]])  (float4 in slot order; the dispersion grid of LJPME spreads C6 factors at the same positions) */
+int ommhip_posq_with_weights(const void* posq_d, const double* weight_d, const int* atom_of_slot_d, int padded_atoms, void* dst_d, void* stream);
 /* zero two device buffers (sizes multiples of 16 bytes; either may be empty) in one launch */
 int ommhip_clear2(void* a_d, size_t a_bytes, void* b_d, size_t b_bytes, void* stream);
 /* result[0] = sum of buffer[0..n), then buffer is zeroed; result_d is a device double */
@@ -176,6 +178,10 @@ typedef struct ommhip_nonbonded_params {
     double krf, crf;           /* reaction-field constants (0 for NoCutoff) */
     double switch_distance;
     int direct_grid;           /* number of wavefront-sized workgroups to launch (0 = default) */
+    /* LJPME (kernels.h:558-565, ReferenceLJCoulombIxn.cpp:407-435): direct space adds back the part of the geometric-mean C6
+     * term that the dispersion grid does not cover.  Requires ewald = 1. */
+    int ljpme;
+    double dispersion_alpha;
 } ommhip_nonbonded_params;
 
 /* Checks displacement, and (only if state[0] != 0 afterwards) rebuilds bounds + rows.  No host sync. */
@@ -229,6 +235,8 @@ typedef struct ommhip_pme {
     const double* charge;      /* [num_atoms] */
     int excl_periodic;         /* NonbondedForce::getExceptionsUsePeriodicBoundaryConditions() */
     int phases;                /* OMMHIP_PME_ALL (0), or the two halves separately so that they can go to different streams */
+    int dispersion;            /* 1: the dispersion grid of LJPME -- influence function of ReferencePME.cpp:518-614 (an m = 0 term, no
+                                * Coulomb constant); the "charges" in posq.w are the per-atom C6 factors */
     /* Slab decomposition (ommhip_pme_reciprocal_dd; all zero = single GPU).  Rank r of dd_ranks owns the x planes
      * [r nx/R, (r+1) nx/R) and, for the x transform, the y rows [r ny/R, (r+1) ny/R); nx and ny are multiples of R.
      *   grid_real     float[(nx/R + 2 dd_halo + 4)][ny][nz]: dd_halo planes below the slab, the slab, dd_halo + 4 planes above
@@ -271,7 +279,8 @@ enum {
     OMMHIP_TERM_EWALD_EXCLUSION = 1,
     OMMHIP_TERM_HARMONIC_BOND = 2,
     OMMHIP_TERM_HARMONIC_ANGLE = 3,
-    OMMHIP_TERM_PERIODIC_TORSION = 4
+    OMMHIP_TERM_PERIODIC_TORSION = 4,
+    OMMHIP_TERM_DISPERSION_EXCLUSION = 5     /* atoms (i,j); `charge` = per-atom C6 factor 8 (sigma/2)^3 2 sqrt(eps), `alpha` = dispersion alpha; ReferenceLJCoulombIxn.cpp:505-520 */
 };
 typedef struct ommhip_term_list {
     int num_terms;

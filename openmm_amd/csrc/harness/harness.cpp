@@ -62,6 +62,10 @@ int omm_nonbonded_create_exceptions_from_bonds(void* f, int n, const int* pairs,
 }
 int omm_nonbonded_num_exceptions(void* f) { return ((NonbondedForce*) f)->getNumExceptions(); }
 int omm_nonbonded_set_pme_parameters(void* f, double alpha, int nx, int ny, int nz) { GUARD(((NonbondedForce*) f)->setPMEParameters(alpha, nx, ny, nz)) }
+int omm_nonbonded_set_ljpme_parameters(void* f, double alpha, int nx, int ny, int nz) { GUARD(((NonbondedForce*) f)->setLJPMEParameters(alpha, nx, ny, nz)) }
+int omm_nonbonded_get_ljpme_parameters_in_context(void* f, void* ctx, double* alpha, int* n) {
+    GUARD(((NonbondedForce*) f)->getLJPMEParametersInContext(*(Context*) ctx, *alpha, n[0], n[1], n[2]))
+}
 int omm_nonbonded_set_reaction_field_dielectric(void* f, double d) { GUARD(((NonbondedForce*) f)->setReactionFieldDielectric(d)) }
 int omm_nonbonded_set_reciprocal_force_group(void* f, int g) { GUARD(((NonbondedForce*) f)->setReciprocalSpaceForceGroup(g)) }
 int omm_nonbonded_set_exceptions_use_periodic(void* f, int p) { GUARD(((NonbondedForce*) f)->setExceptionsUsePeriodicBoundaryConditions(p != 0)) }

@@ -90,6 +90,20 @@ __device__ __forceinline__ double term_ewald_exclusion(const TermCtx& c, int t) 
     return -c.l.alpha * 1.12837916709551257390 * qq;
 }
 
+// LJPME: the dispersion grid also covers excluded pairs; this takes their share out again (ReferenceLJCoulombIxn.cpp:505-520).
+// l.charge holds the per-atom C6 factors, l.alpha the dispersion alpha.
+__device__ __forceinline__ double term_dispersion_exclusion(const TermCtx& c, int t) {
+    const int i = c.l.atoms[2 * t], j = c.l.atoms[2 * t + 1];
+    const double c6 = c.l.charge[i] * c.l.charge[j];
+    const double3 d = c.delta(i, j);                      // j - i
+    const double r2 = dot3(d, d), inv2 = 1.0 / r2, inv6 = inv2 * inv2 * inv2;
+    const double x = c.l.alpha * c.l.alpha * r2, ex = exp(-x);
+    const double coeff = 6.0 * c6 * inv6 * inv2 * (1.0 - ex * (1.0 + x + 0.5 * x * x + x * x * x / 6.0));
+    c.add(j, coeff * d.x, coeff * d.y, coeff * d.z);
+    c.add(i, -coeff * d.x, -coeff * d.y, -coeff * d.z);
+    return c6 * inv6 * (1.0 - ex * (1.0 + x + 0.5 * x * x));
+}
+
 __device__ __forceinline__ double term_harmonic_bond(const TermCtx& c, int t) {
     const int i = c.l.atoms[2 * t], j = c.l.atoms[2 * t + 1];
     const double r0 = c.l.params[2 * t], k = c.l.params[2 * t + 1];
@@ -178,6 +192,7 @@ __device__ __forceinline__ void terms_body(const TermArgs& a, const int block, d
             case OMMHIP_TERM_EWALD_EXCLUSION: energy = term_ewald_exclusion(c, t); break;
             case OMMHIP_TERM_HARMONIC_BOND: energy = term_harmonic_bond(c, t); break;
             case OMMHIP_TERM_HARMONIC_ANGLE: energy = term_harmonic_angle(c, t); break;
+            case OMMHIP_TERM_DISPERSION_EXCLUSION: energy = term_dispersion_exclusion(c, t); break;
             default: energy = term_periodic_torsion(c, t); break;
         }
     }
@@ -324,7 +339,7 @@ static int make_term_args(TermArgs& a, int num_lists, const ommhip_term_batch* l
     int blocks = 0;
     for (int i = 0; i < num_lists; i++) {
         if (lists[i].terms.num_terms <= 0) continue;
-        if (lists[i].kind < OMMHIP_TERM_EXCEPTION14 || lists[i].kind > OMMHIP_TERM_PERIODIC_TORSION) return -1;
+        if (lists[i].kind < OMMHIP_TERM_EXCEPTION14 || lists[i].kind > OMMHIP_TERM_DISPERSION_EXCLUSION) return -1;
         TermList& l = a.list[a.numLists++];
         l.kind = lists[i].kind; l.numTerms = lists[i].terms.num_terms; l.periodic = lists[i].periodic; l.firstBlock = blocks;
         l.alpha = lists[i].alpha; l.atoms = lists[i].terms.atoms; l.params = lists[i].terms.params; l.charge = lists[i].charge;

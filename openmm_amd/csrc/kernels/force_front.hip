@@ -148,7 +148,7 @@ void launch_pairs_fft(int stage, int pairBlocks, hipStream_t st, const NbArgs& n
 extern "C" int ommhip_pairs_with_fft(const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, const void* sig_eps_d, const ommhip_pme* pme,
                                      long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
     const int nx = pme->nx, ny = pme->ny, nz = pme->nz;
-    if (nl->pbc != 1 || !p->ewald || nz * (ny + 1) > PF_PLANE_CAP || ny > 256 || nz > 256 || pme->fft_mode == 1) return -1;
+    if (nl->pbc != 1 || !p->ewald || p->ljpme || nz * (ny + 1) > PF_PLANE_CAP || ny > 256 || nz > 256 || pme->fft_mode == 1) return -1;
     if (nl->posq_rel == nullptr) return 1;
     hipStream_t st = (hipStream_t) stream;
     // list fractions (in 64ths) at which stages 1 and 2 begin; tuning knob OPENMM_HIP_PAIRS_FFT_SPLIT="a,b"

@@ -20,6 +20,7 @@
 //   there is a single code path; rows whose 64 masks are all-ones take a mask-free inner loop.
 #include "common.h"
 #include "erfc_coeffs.h"
+#include <cmath>
 #include <cstdlib>
 #include "../../../include/openmm_hip_kernels.h"
 
@@ -35,6 +36,7 @@ struct NbArgs {
     int xcdAware;             // XCD-aware placement of the work units (ChunkSchedule)
     int ownSlot0, ownSlot1;   // domain decomposition: forces on j atoms outside [ownSlot0, ownSlot1) are dropped (their owner evaluates the pair too)
     float cutoff2, alpha, krf, crf, switchDist, invSwitchWidth;
+    float dispAlpha2, invCut6, dispShift;   // LJPME (METHOD & 4): alpha_d^2, 1/rc^6, (1 - exp(-x)(1 + x + x^2/2)) / rc^6 at x = (alpha_d rc)^2
     Box box;
     const float4* posq;       // block-relative coordinates + charge (ommhip_neighbor_list::posq_rel): position minus blockCenter of its block
     const float2* sigEps;
@@ -67,6 +69,19 @@ __device__ __forceinline__ void pair_ixn(const NbArgs& a, const float4 pi, const
     const float s6 = s2 * s2 * s2;
     float ljF = eps * (12.f * s6 - 6.f) * s6;          // dE/dr * (-r)
     float ljE = eps * (s6 - 1.f) * s6;
+    float dispF = 0.f;                                  // LJPME: force coefficient of the multiplicative C6 term (multiplies the separation vector)
+    if (METHOD & 4) {
+        // ReferenceLJCoulombIxn.cpp:407-435: the Lorentz-Berthelot LJ stays as it is; the part of the geometric-mean C6 term that
+        // reciprocal space does not cover is taken out again, plus a shift that makes the energy continuous at the cutoff
+        const float c6 = (8.f * sei.x * sei.x * sei.x * sei.y) * (8.f * sej.x * sej.x * sej.x * sej.y);
+        const float x = a.dispAlpha2 * r2, ex = fast_exp(-x);
+        const float invR6 = invR2 * invR2 * invR2;
+        dispF = 6.f * c6 * invR6 * invR2 * (1.f - ex * (1.f + x + 0.5f * x * x + x * x * x * (1.f / 6.f)));
+        if (ENERGY || (METHOD & 2)) {
+            float sc2 = sig * sig; const float sc6 = sc2 * sc2 * sc2 * a.invCut6;
+            ljE += c6 * invR6 * (1.f - ex * (1.f + x + 0.5f * x * x)) + eps * (1.f - sc6) * sc6 - c6 * a.dispShift;
+        }
+    }
     if (METHOD & 2) {
         // ReferenceLJCoulombIxn.cpp:388-392,437-440 / :587-594,615-618; t = 0 below the switching
         // distance gives sw = 1, dsw = 0, so no branch is needed.
@@ -96,7 +111,7 @@ __device__ __forceinline__ void pair_ixn(const NbArgs& a, const float4 pi, const
         cF = qq * (invR - 2.f * a.krf * r2);
         cE = qq * (invR + a.krf * r2 - a.crf);
     }
-    float dEdR = (ljF + cF) * invR2;
+    float dEdR = (ljF + cF) * invR2 + dispF;
     dEdR = in ? dEdR : 0.f;
     fjx += dEdR * dx; fjy += dEdR * dy; fjz += dEdR * dz;
     fix -= dEdR * dx; fiy -= dEdR * dy; fiz -= dEdR * dz;
@@ -130,6 +145,19 @@ __device__ __forceinline__ void pair_ixn2(const NbArgs& a, const float4 pi0, con
     const v2f s6 = s2 * s2 * s2;
     v2f ljF = eps * (bc2(12.f) * s6 - bc2(6.f)) * s6;
     v2f ljE = eps * (s6 - bc2(1.f)) * s6;
+    v2f dispF = bc2(0.f);
+    if (METHOD & 4) {
+        const v2f c6 = mk2(8.f * se0.x * se0.x * se0.x * se0.y, 8.f * se1.x * se1.x * se1.x * se1.y) * bc2(8.f * sej.x * sej.x * sej.x * sej.y);
+        const v2f x = bc2(a.dispAlpha2) * r2;
+        const v2f argd = -x * bc2(1.44269504088896340736f);
+        const v2f ex = mk2(__builtin_amdgcn_exp2f(argd.x), __builtin_amdgcn_exp2f(argd.y));
+        const v2f invR6 = invR2 * invR2 * invR2;
+        dispF = bc2(6.f) * c6 * invR6 * invR2 * (bc2(1.f) - ex * (bc2(1.f) + x + bc2(0.5f) * x * x + x * x * x * bc2(1.f / 6.f)));
+        if (ENERGY || (METHOD & 2)) {
+            const v2f sc2 = sig * sig; const v2f sc6 = sc2 * sc2 * sc2 * bc2(a.invCut6);
+            ljE = ljE + c6 * invR6 * (bc2(1.f) - ex * (bc2(1.f) + x + bc2(0.5f) * x * x)) + eps * (bc2(1.f) - sc6) * sc6 - c6 * bc2(a.dispShift);
+        }
+    }
     if (METHOD & 2) {
         v2f t = (r - bc2(a.switchDist)) * bc2(a.invSwitchWidth);
         t = mk2(fmaxf(0.f, t.x), fmaxf(0.f, t.y));
@@ -158,7 +186,7 @@ __device__ __forceinline__ void pair_ixn2(const NbArgs& a, const float4 pi0, con
         cF = qq * (invR - bc2(2.f * a.krf) * r2);
         cE = qq * (invR + bc2(a.krf) * r2 - bc2(a.crf));
     }
-    v2f dEdR = (ljF + cF) * invR2;
+    v2f dEdR = (ljF + cF) * invR2 + dispF;
     dEdR = mk2(in0 ? dEdR.x : 0.f, in1 ? dEdR.y : 0.f);
     fjx = fjx + dEdR * dx; fjy = fjy + dEdR * dy; fjz = fjz + dEdR * dz;
     fix = fix - dEdR * dx; fiy = fiy - dEdR * dy; fiz = fiz - dEdR * dz;
@@ -405,6 +433,12 @@ static NbArgs make_nb_args(const ommhip_neighbor_list* nl, const ommhip_nonbonde
     a.cutoff2 = nl->cutoff > 0 ? (float) (nl->cutoff * nl->cutoff) : INFINITY;
     a.alpha = (float) p->ewald_alpha; a.krf = (float) p->krf; a.crf = (float) p->crf;
     a.switchDist = (float) p->switch_distance;
+    a.dispAlpha2 = (float) (p->dispersion_alpha * p->dispersion_alpha);
+    a.invCut6 = nl->cutoff > 0 ? (float) pow(nl->cutoff, -6.0) : 0.f;
+    {
+        const double xc = p->dispersion_alpha * p->dispersion_alpha * nl->cutoff * nl->cutoff;
+        a.dispShift = nl->cutoff > 0 ? (float) ((1.0 - exp(-xc) * (1.0 + xc + 0.5 * xc * xc)) * pow(nl->cutoff, -6.0)) : 0.f;
+    }
     a.invSwitchWidth = p->use_switch ? (float) (1.0 / (nl->cutoff - p->switch_distance)) : 0.f;
     a.box = make_box(nl->box);
     a.posq = (const float4*) nl->posq_rel; a.sigEps = (const float2*) sig_eps; a.state = nl->state;
@@ -426,11 +460,14 @@ extern "C" int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_non
     if (a.xcdAware) grid = (grid + OMM_NUM_XCD - 1) / OMM_NUM_XCD * OMM_NUM_XCD;       // the same number of wavefronts on every XCD
     hipStream_t st = (hipStream_t) stream;
     ommhip_profile_begin(OMMHIP_TIMER_NB_DIRECT, stream);
-    switch ((p->ewald ? 1 : 0) | (p->use_switch ? 2 : 0)) {
+    if (p->ljpme && !p->ewald) return 1;
+    switch ((p->ewald ? 1 : 0) | (p->use_switch ? 2 : 0) | (p->ljpme ? 4 : 0)) {
         case 0: launch_direct1<0>(nl->pbc, include_energy != 0, grid, st, a); break;
         case 1: launch_direct1<1>(nl->pbc, include_energy != 0, grid, st, a); break;
         case 2: launch_direct1<2>(nl->pbc, include_energy != 0, grid, st, a); break;
-        default: launch_direct1<3>(nl->pbc, include_energy != 0, grid, st, a); break;
+        case 3: launch_direct1<3>(nl->pbc, include_energy != 0, grid, st, a); break;
+        case 5: launch_direct1<5>(nl->pbc, include_energy != 0, grid, st, a); break;
+        default: launch_direct1<7>(nl->pbc, include_energy != 0, grid, st, a); break;
     }
     ommhip_profile_end(OMMHIP_TIMER_NB_DIRECT, stream);
     return (int) hipGetLastError();

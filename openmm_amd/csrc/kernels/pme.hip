@@ -410,6 +410,7 @@ __global__ __launch_bounds__(256) void pme_interpolate(PmeArgs a) {
 struct EtermArgs {
     int nx, ny, nz, nzc;
     int y0, nyl;            // rows [y0, y0 + nyl) of the influence function are built (slab decomposition; whole grid: 0, ny)
+    int dispersion;         // LJPME's dispersion grid: ReferencePME.cpp:518-614
     double r00, r10, r11, r20, r21, r22, alpha, volume;
     const double* modX; const double* modY; const double* modZ;
     float* eterm;
@@ -420,7 +421,7 @@ __global__ void pme_build_eterm(EtermArgs a) {
     const size_t total = (size_t) a.nx * a.nyl * a.nzc;
     if (i >= total) return;
     const int kz = (int) (i % a.nzc), ky = a.y0 + (int) ((i / a.nzc) % a.nyl), kx = (int) (i / ((size_t) a.nzc * a.nyl));
-    if (kx == 0 && ky == 0 && kz == 0) { a.eterm[i] = 0.f; return; }
+    if (!a.dispersion && kx == 0 && ky == 0 && kz == 0) { a.eterm[i] = 0.f; return; }
     const int mx = kx < (a.nx + 1) / 2 ? kx : kx - a.nx;
     const int my = ky < (a.ny + 1) / 2 ? ky : ky - a.ny;
     const int mz = kz < (a.nz + 1) / 2 ? kz : kz - a.nz;
@@ -429,6 +430,14 @@ __global__ void pme_build_eterm(EtermArgs a) {
     const double mhz = mx * a.r20 + my * a.r21 + mz * a.r22;
     const double m2 = mhx * mhx + mhy * mhy + mhz * mhz;
     const double pi = 3.14159265358979323846;
+    if (a.dispersion) {
+        // dpme_reciprocal_convolution: every frequency contributes, m = 0 included
+        const double boxfactor = -2.0 * pi * sqrt(pi) / (6.0 * a.volume);
+        const double m = sqrt(m2), b = pi * m / a.alpha;
+        const double term = 2.0 * pi * pi * pi * sqrt(pi) * erfc(b) * m * m2 + exp(-b * b) * (a.alpha * a.alpha * a.alpha - 2.0 * a.alpha * pi * pi * m2);
+        a.eterm[i] = (float) (term * boxfactor / (a.modX[kx] * a.modY[ky] * a.modZ[kz]));
+        return;
+    }
     const double denom = m2 * (pi * a.volume * a.modX[kx]) * a.modY[ky] * a.modZ[kz];
     a.eterm[i] = (float) (OMM_ONE_4PI_EPS0_D * exp(-(pi * pi / (a.alpha * a.alpha)) * m2) / denom);
 }
@@ -863,7 +872,7 @@ extern "C" int ommhip_pme_build_eterm(const ommhip_pme* pme, void* stream) {
     a.alpha = pme->alpha; a.volume = det;
     a.modX = pme->moduli_x; a.modY = pme->moduli_y; a.modZ = pme->moduli_z;
     a.eterm = (float*) pme->eterm;
-    a.y0 = 0; a.nyl = a.ny;
+    a.y0 = 0; a.nyl = a.ny; a.dispersion = pme->dispersion;
     if (pme->dd_ranks > 1) { a.nyl = a.ny / pme->dd_ranks; a.y0 = pme->dd_rank * a.nyl; }
     const size_t total = (size_t) a.nx * a.nyl * a.nzc;
     hipLaunchKernelGGL(pme_build_eterm, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream, a);

@@ -83,6 +83,14 @@ __global__ __launch_bounds__(256) void k_clear2(uint4* __restrict__ a, size_t na
     }
 }
 
+__global__ void k_posq_with_weights(const float4* __restrict__ posq, const double* __restrict__ weight, const int* __restrict__ atomOfSlot, int paddedAtoms, float4* __restrict__ dst) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= paddedAtoms) return;
+    const float4 p = posq[s];
+    const int a = atomOfSlot[s];
+    dst[s] = make_float4(p.x, p.y, p.z, a >= 0 ? (float) weight[a] : 0.f);
+}
+
 // slot-ordered <-> atom-ordered copies of a double4 array (all-gather buffers of the decomposed run)
 __global__ void k_pack_slots(const double4* __restrict__ src, const int* __restrict__ atomOfSlot, int slot0, int slot1, double4* __restrict__ dst) {
     const int s = slot0 + blockIdx.x * blockDim.x + threadIdx.x;
@@ -183,5 +191,11 @@ extern "C" int ommhip_scale_molecule_centers(int num_molecules, const int* mol_s
     if (num_molecules <= 0) return 0;
     hipLaunchKernelGGL(k_scale_molecule_centers, dim3((num_molecules + 127) / 128), dim3(128), 0, (hipStream_t) stream,
                        num_molecules, mol_start_d, mol_atoms_d, (double4*) pos_d, make_boxd(box), sx, sy, sz);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_posq_with_weights(const void* posq_d, const double* weight_d, const int* atom_of_slot_d, int padded_atoms, void* dst_d, void* stream) {
+    hipLaunchKernelGGL(k_posq_with_weights, dim3((padded_atoms + 255) / 256), dim3(256), 0, (hipStream_t) stream,
+                       (const float4*) posq_d, weight_d, atom_of_slot_d, padded_atoms, (float4*) dst_d);
     return (int) hipGetLastError();
 }

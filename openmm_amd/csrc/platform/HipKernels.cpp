@@ -462,6 +462,7 @@ HipCalcNonbondedForceKernel::HipCalcNonbondedForceKernel(string name, const Plat
     memset(&nl, 0, sizeof(nl));
     memset(&params, 0, sizeof(params));
     memset(&pme, 0, sizeof(pme));
+    memset(&pmeDisp, 0, sizeof(pmeDisp));
     hip.addListener(this);
     liveNonbondedKernels.push_back(this);
 }
@@ -659,7 +660,7 @@ int HipCalcNonbondedForceKernel::recoverFromOverflow() {
 }
 
 void HipCalcNonbondedForceKernel::atomsReordered() { slotParamsDirty = true; forceRebuild = true; }
-void HipCalcNonbondedForceKernel::boxChanged() { etermDirty = true; forceRebuild = true; }
+void HipCalcNonbondedForceKernel::boxChanged() { etermDirty = true; dispersionEtermDirty = true; forceRebuild = true; }
 void HipCalcNonbondedForceKernel::positionsSet() { forceRebuild = true; }
 
 static int findLegalFftDimension(int minimum, int multipleOf = 1) {
@@ -761,8 +762,14 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     ewaldAlpha = 0;
     kmax[0] = kmax[1] = kmax[2] = 0;
     gridSize[0] = gridSize[1] = gridSize[2] = 0;
-    if (nonbondedMethod == LJPME)
-        throw OpenMMException("HIP platform: LJPME is handled by the Reference kernel (internal error: native kernel created)");
+    if (nonbondedMethod == LJPME) {
+        // ReferenceKernels.cpp:948-955: two sets of PME parameters, no switching function
+        if (hip.decomposed()) throw OpenMMException("HIP platform: LJPME is not available on multi-GPU runs");
+        NonbondedForceImpl::calcPMEParameters(system, force, ewaldAlpha, gridSize[0], gridSize[1], gridSize[2], false);
+        NonbondedForceImpl::calcPMEParameters(system, force, dispersionAlpha, dispersionGridSize[0], dispersionGridSize[1], dispersionGridSize[2], true);
+        for (int k = 0; k < 3; k++) { gridSize[k] = findLegalFftDimension(gridSize[k]); dispersionGridSize[k] = findLegalFftDimension(dispersionGridSize[k]); }
+        useSwitchingFunction = false;
+    }
     if (nonbondedMethod == Ewald) {
         NonbondedForceImpl::calcEwaldParameters(system, force, ewaldAlpha, kmax[0], kmax[1], kmax[2]);
     }
@@ -770,7 +777,7 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
         NonbondedForceImpl::calcPMEParameters(system, force, ewaldAlpha, gridSize[0], gridSize[1], gridSize[2], false);
         for (int k = 0; k < 3; k++) gridSize[k] = findLegalFftDimension(gridSize[k], k < 2 ? hip.domain.ranks : 1);
     }
-    usesPeriodic = nonbondedMethod == CutoffPeriodic || nonbondedMethod == Ewald || nonbondedMethod == PME;
+    usesPeriodic = nonbondedMethod == CutoffPeriodic || nonbondedMethod == Ewald || nonbondedMethod == PME || nonbondedMethod == LJPME;
     exceptionsArePeriodic = usesPeriodic && force.getExceptionsUsePeriodicBoundaryConditions();
     if (force.getUseDispersionCorrection() && usesPeriodic)
         dispersionCoefficient = NonbondedForceImpl::calcDispersionCorrection(system, force);
@@ -847,7 +854,9 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
         hip.listRecovery = [this]() { return recoverFromOverflow(); };
     }
 
-    params.ewald = (nonbondedMethod == Ewald || nonbondedMethod == PME) ? 1 : 0;
+    params.ewald = (nonbondedMethod == Ewald || nonbondedMethod == PME || nonbondedMethod == LJPME) ? 1 : 0;
+    params.ljpme = nonbondedMethod == LJPME ? 1 : 0;
+    params.dispersion_alpha = dispersionAlpha;
     params.use_switch = useSwitchingFunction ? 1 : 0;
     params.ewald_alpha = ewaldAlpha;
     params.krf = params.crf = 0;
@@ -859,6 +868,7 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     params.switch_distance = switchingDistance;
     params.direct_grid = directGridOverride;
     if (nonbondedMethod == PME) { if (hip.decomposed()) setupPmeDecomposed(); else setupPme(); }
+    if (nonbondedMethod == LJPME) { setupPme(); setupDispersionPme(); }
     if (nonbondedMethod == Ewald)
         ewaldStructure.allocate(sizeof(double) * 2 * (size_t) kmax[0] * (2 * kmax[1] - 1) * (2 * kmax[2] - 1));
     hip.sync();
@@ -892,6 +902,32 @@ void HipCalcNonbondedForceKernel::setupPme() {
     pme.twiddle_x = twiddleX.ptr; pme.twiddle_y = twiddleY.ptr; pme.twiddle_z = twiddleZ.ptr;
     pme.spread_mode = getenv("OPENMM_HIP_PME_SPREAD_DIRECT") != NULL ? 1 : 0;    // A/B knob: direct global atomics
     etermDirty = true;
+}
+
+void HipCalcNonbondedForceKernel::setupDispersionPme() {
+    // the second grid of LJPME: same kernels, C6 factors instead of charges, the influence function of ReferencePME.cpp:518-614
+    const int nx = dispersionGridSize[0], ny = dispersionGridSize[1], nz = dispersionGridSize[2], nzc = nz / 2 + 1;
+    uploadVector(dModuliX, bsplineModuli(nx), hip.stream);
+    uploadVector(dModuliY, bsplineModuli(ny), hip.stream);
+    uploadVector(dModuliZ, bsplineModuli(nz), hip.stream);
+    DeviceBuffer* tw[3] = {&dTwiddleX, &dTwiddleY, &dTwiddleZ};
+    for (int d = 0; d < 3; d++) {
+        const int n = dispersionGridSize[d];
+        vector<float> t(2 * (size_t) n);
+        for (int k = 0; k < n; k++) { t[2 * k] = (float) cos(2.0 * M_PI * k / n); t[2 * k + 1] = (float) -sin(2.0 * M_PI * k / n); }
+        uploadVector(*tw[d], t, hip.stream);
+    }
+    dEterm.allocate(sizeof(float) * (size_t) nx * ny * nzc);
+    dGridReal.allocate((sizeof(float) * (size_t) nx * ny * nz + 15) / 16 * 16);
+    dGridComplex.allocate(sizeof(float) * 2 * (size_t) nx * ny * nzc);
+    c6D.allocate(sizeof(double) * max(numParticles, 1));
+    posqDisp.allocate(sizeof(float) * 4 * hip.paddedAtoms);
+    pmeDisp.nx = nx; pmeDisp.ny = ny; pmeDisp.nz = nz; pmeDisp.alpha = dispersionAlpha;
+    pmeDisp.moduli_x = dModuliX.as<double>(); pmeDisp.moduli_y = dModuliY.as<double>(); pmeDisp.moduli_z = dModuliZ.as<double>();
+    pmeDisp.eterm = dEterm.ptr; pmeDisp.grid_real = dGridReal.ptr; pmeDisp.grid_complex = dGridComplex.ptr;
+    pmeDisp.twiddle_x = dTwiddleX.ptr; pmeDisp.twiddle_y = dTwiddleY.ptr; pmeDisp.twiddle_z = dTwiddleZ.ptr;
+    pmeDisp.dispersion = 1;
+    dispersionEtermDirty = true;
 }
 
 void HipCalcNonbondedForceKernel::updateExclusionBlockRanges() {
@@ -1004,8 +1040,19 @@ void HipCalcNonbondedForceKernel::computeParameters(ContextImpl& context, bool f
     hip.sync();
     // Ewald self energy (ReferenceLJCoulombIxn.cpp:220-233)
     selfEnergy = 0;
-    if (nonbondedMethod == Ewald || nonbondedMethod == PME)
+    if (nonbondedMethod == Ewald || nonbondedMethod == PME || nonbondedMethod == LJPME)
         for (int i = 0; i < numParticles; i++) selfEnergy -= ONE_4PI_EPS0 * charges[i] * charges[i] * ewaldAlpha / sqrt(M_PI);
+    if (nonbondedMethod == LJPME) {
+        // per-atom C6 factors 8 (sigma/2)^3 (2 sqrt(eps)) and the dispersion self term (ReferenceLJCoulombIxn.cpp:224-227,257)
+        vector<double> c6(numParticles);
+        for (int i = 0; i < numParticles; i++) {
+            const double s = 0.5 * sigmas[i], e = 2.0 * sqrt(epsilons[i]);
+            c6[i] = 8.0 * s * s * s * e;
+            selfEnergy += pow(dispersionAlpha, 6.0) * c6[i] * c6[i] / 12.0;
+        }
+        HIP_CHECK(ommhip_memcpy_h2d(c6D.ptr, c6.data(), sizeof(double) * numParticles, hip.stream));
+        hip.sync();
+    }
     slotParamsDirty = true;
 }
 
@@ -1183,13 +1230,28 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
             ommhip_term_batch tex = {OMMHIP_TERM_EWALD_EXCLUSION, {numExclusionPairs, exclusionPairsD.as<int>(), NULL},
                                      exceptionsArePeriodic ? 1 : 0, chargeD.as<double>(), ewaldAlpha};
             hip.addTerms(tex, includeEnergy);
+            if (nonbondedMethod == LJPME) {
+                ommhip_term_batch tdx = {OMMHIP_TERM_DISPERSION_EXCLUSION, {numExclusionPairs, exclusionPairsD.as<int>(), NULL},
+                                         exceptionsArePeriodic ? 1 : 0, c6D.as<double>(), dispersionAlpha};
+                hip.addTerms(tdx, includeEnergy);
+            }
         }
-        if (includeEnergy && usesPeriodic)
+        if (includeEnergy && usesPeriodic && nonbondedMethod != LJPME)         // ReferenceKernels.cpp:1008-1011 (not for LJPME)
             energy += dispersionCoefficient / (hip.box[0] * hip.box[2] * hip.box[5]);
     }
     if (includeReciprocal) {
         if (nonbondedMethod == PME) {
             if (!pmeLaunched) launchPme(ie, frontLaunched, fftLaunched);
+        }
+        else if (nonbondedMethod == LJPME) {
+            // two grids back to back on the main stream: charges, then C6 factors at the same positions
+            fillPmeStruct();
+            pme.phases = OMMHIP_PME_ALL;
+            HIP_CHECK(ommhip_pme_reciprocal(&pme, posq.ptr, hip.paddedAtoms, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+            for (int i = 0; i < 6; i++) pmeDisp.box[i] = hip.box[i];
+            if (dispersionEtermDirty) { HIP_CHECK(ommhip_pme_build_eterm(&pmeDisp, hip.stream)); dispersionEtermDirty = false; }
+            HIP_CHECK(ommhip_posq_with_weights(posq.ptr, c6D.as<double>(), hip.atomOfSlot.as<int>(), hip.paddedAtoms, posqDisp.ptr, hip.stream));
+            HIP_CHECK(ommhip_pme_reciprocal(&pmeDisp, posqDisp.ptr, hip.paddedAtoms, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
         }
         else if (nonbondedMethod == Ewald) {
             if (hip.box[1] != 0.0 || hip.box[3] != 0.0 || hip.box[4] != 0.0)
@@ -1237,13 +1299,15 @@ void HipCalcNonbondedForceKernel::copyParametersToContext(ContextImpl& context, 
 }
 
 void HipCalcNonbondedForceKernel::getPMEParameters(double& alpha, int& nx, int& ny, int& nz) const {
-    if (nonbondedMethod != PME)
-        throw OpenMMException("getPMEParametersInContext: This Context is not using PME");
+    if (nonbondedMethod != PME && nonbondedMethod != LJPME)
+        throw OpenMMException("getPMEParametersInContext: This Context is not using PME or LJPME");
     alpha = ewaldAlpha; nx = gridSize[0]; ny = gridSize[1]; nz = gridSize[2];
 }
 
 void HipCalcNonbondedForceKernel::getLJPMEParameters(double& alpha, int& nx, int& ny, int& nz) const {
-    throw OpenMMException("getPMEParametersInContext: This Context is not using LJPME");
+    if (nonbondedMethod != LJPME)
+        throw OpenMMException("getPMEParametersInContext: This Context is not using LJPME");
+    alpha = dispersionAlpha; nx = dispersionGridSize[0]; ny = dispersionGridSize[1]; nz = dispersionGridSize[2];
 }
 
 // ================================================================================================

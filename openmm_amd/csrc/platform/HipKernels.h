@@ -132,6 +132,13 @@ private:
     double executeDecomposed(ContextImpl& context, bool includeForces, bool includeEnergy, bool includeDirect, bool includeReciprocal);
     void setupPmeDecomposed();
     void checkDecomposedFlags();
+    // LJPME: the dispersion grid (second set of PME buffers), per-atom C6 factors, posq with the C6 factor in .w
+    void setupDispersionPme();
+    double dispersionAlpha = 0.0, dispersionSelfEnergy = 0.0;
+    int dispersionGridSize[3] = {0, 0, 0};
+    DeviceBuffer dModuliX, dModuliY, dModuliZ, dEterm, dGridReal, dGridComplex, dTwiddleX, dTwiddleY, dTwiddleZ, c6D, posqDisp;
+    ommhip_pme pmeDisp;
+    bool dispersionEtermDirty = true;
     DeviceBuffer gridComplex2, ddError;
     int* pinnedDdError = NULL;
     int ddHalo = 0;

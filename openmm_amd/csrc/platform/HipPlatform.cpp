@@ -65,7 +65,9 @@ static HipModeInfo classifyContext(ContextImpl& context) {
     for (int i = 0; i < system.getNumForces(); i++) {
         const Force& f = system.getForce(i);
         if (const NonbondedForce* nb = dynamic_cast<const NonbondedForce*>(&f)) {
-            if (nb->getNonbondedMethod() == NonbondedForce::LJPME) { info.referenceNonbonded = true; info.hasFallbackForces = true; }
+            // LJPME is native too (dispersion grid + direct-space correction); OPENMM_HIP_REFERENCE_LJPME=1 restores the Reference kernel (A/B)
+            char* refLj = getenv("OPENMM_HIP_REFERENCE_LJPME");
+            if (nb->getNonbondedMethod() == NonbondedForce::LJPME && refLj != NULL && string(refLj) == "1") { info.referenceNonbonded = true; info.hasFallbackForces = true; }
             continue;
         }
         if (dynamic_cast<const HarmonicBondForce*>(&f) != NULL || dynamic_cast<const HarmonicAngleForce*>(&f) != NULL ||

@@ -169,6 +169,15 @@ class NonbondedForce:
     def setPMEParameters(self, alpha, nx, ny, nz):
         _check(lib().omm_nonbonded_set_pme_parameters(self.h, C.c_double(alpha), nx, ny, nz))
 
+    def setLJPMEParameters(self, alpha, nx, ny, nz):
+        _check(lib().omm_nonbonded_set_ljpme_parameters(self.h, C.c_double(alpha), nx, ny, nz))
+
+    def getLJPMEParametersInContext(self, context):
+        alpha = C.c_double()
+        n = (C.c_int * 3)()
+        _check(lib().omm_nonbonded_get_ljpme_parameters_in_context(self.h, context.h, C.byref(alpha), n))
+        return alpha.value, n[0], n[1], n[2]
+
     def setReciprocalSpaceForceGroup(self, group):
         _check(lib().omm_nonbonded_set_reciprocal_force_group(self.h, group))
 

@@ -47,6 +47,8 @@ class Workload:
             nb.addExceptions(*self.exceptions)
         if self.pme_params is not None:
             nb.setPMEParameters(*self.pme_params)
+        if getattr(self, "ljpme_params", None) is not None:
+            nb.setLJPMEParameters(*self.ljpme_params)
         if self.constraints is not None and len(self.constraints[0]):
             s.addConstraints(*self.constraints)
         if self.bonds is not None and len(self.bonds[0]):

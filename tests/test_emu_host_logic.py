@@ -209,3 +209,14 @@ def test_neighbour_list_overflow_is_recovered(tmp_path):
     redoes the skipped steps: same trajectory as an undisturbed run (tests/overflow_case.py)."""
     from overflow_case import run_overflow_case
     print(run_overflow_case(tmp_path, True, 7, 20, 1e-6, 1e-4))
+
+
+@needs_emu
+def test_native_ljpme_matches_the_reference_platform():
+    """tests/ljpme_case.py on the emulated kernels (own process: one plugin build per process)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); from openmm_amd import harness as H; H.load_hip_platform(emulated=True); "
+            "from ljpme_case import run_ljpme_case; run_ljpme_case(); print('OK')") % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -355,3 +355,9 @@ def test_neighbour_list_overflow_is_recovered(tmp_path):
     order in which wavefronts append to it, so the two trajectories differ by float32 summation noise.)"""
     from overflow_case import run_overflow_case
     print(run_overflow_case(tmp_path, False, 12, 32, 2e-5, 2e-3))
+
+
+def test_native_ljpme_matches_the_reference_platform():
+    """tests/ljpme_case.py on the GPU (the reference's own tests/TestDispersionPME.h body runs natively as TestHipDispersionPME)."""
+    from ljpme_case import run_ljpme_case
+    run_ljpme_case()

@@ -235,6 +235,11 @@ typedef struct ommhip_pme {
     const double* charge;      /* [num_atoms] */
     int excl_periodic;         /* NonbondedForce::getExceptionsUsePeriodicBoundaryConditions() */
     int phases;                /* OMMHIP_PME_ALL (0), or the two halves separately so that they can go to different streams */
+    /* Bit-reproducible spreading (platform property DeterministicForces): the charge grid is accumulated as 32-bit fixed point
+     * with ONE scale for the whole grid (2^31 / (64 max_charge): integer atomics commute, float atomics do not) and converted to
+     * float by a small extra launch before the transforms.  Forces are then a pure function of positions and list. */
+    int deterministic;
+    double max_charge;
     int dispersion;            /* 1: the dispersion grid of LJPME -- influence function of ReferencePME.cpp:518-614 (an m = 0 term, no
                                 * Coulomb constant); the "charges" in posq.w are the per-atom C6 factors */
     /* Slab decomposition (ommhip_pme_reciprocal_dd; all zero = single GPU).  Rank r of dd_ranks owns the x planes

@@ -46,7 +46,7 @@ class Pme(C.Structure):
         ("twiddle_x", C.c_void_p), ("twiddle_y", C.c_void_p), ("twiddle_z", C.c_void_p), ("spread_mode", C.c_int),
         ("grid_precleared", C.c_int), ("fft_mode", C.c_int),
         ("excl_start", C.c_void_p), ("excl_atoms", C.c_void_p), ("atom_of_slot", C.c_void_p), ("pos", C.c_void_p),
-        ("charge", C.c_void_p), ("excl_periodic", C.c_int), ("phases", C.c_int), ("dispersion", C.c_int),
+        ("charge", C.c_void_p), ("excl_periodic", C.c_int), ("phases", C.c_int), ("deterministic", C.c_int), ("max_charge", C.c_double), ("dispersion", C.c_int),
         ("dd_ranks", C.c_int), ("dd_rank", C.c_int), ("dd_halo", C.c_int), ("grid_complex2", C.c_void_p), ("comm", C.c_void_p), ("dd_error", C.c_void_p),
     ]
 

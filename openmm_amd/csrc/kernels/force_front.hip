@@ -50,7 +50,7 @@ extern "C" int ommhip_force_front(const ommhip_neighbor_list* nl, const ommhip_p
     f.nlBlocks = f.nl.ownedBlocks;
     f.spreadBlocks = 0;
     if (pme != nullptr) {
-        if (pme->spread_mode == 1 || !pme->grid_precleared) return 1;          // the direct-atomics variant and un-cleared grids are not fused
+        if (pme->spread_mode == 1 || !pme->grid_precleared || pme->deterministic) return 1;          // the direct-atomics variant, un-cleared grids and fixed-point grids are not fused
         f.pme = make_pme_args(pme, nl->posq, nl->padded_atoms, force_d, energy_buffer_d, energy_slots, include_energy);
         f.spreadBlocks = (nl->padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS;
     }

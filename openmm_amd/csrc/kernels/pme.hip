@@ -50,7 +50,19 @@ struct PmeArgs {
     int ownSlot0, ownSlot1;
     int* ddError;
     const float4* blockCenter; const float4* blockHalf;
+    float detScale;          // > 0: the grid is accumulated as int32 fixed point with this scale (deterministic sums), converted afterwards
 };
+
+// one grid accumulation: float atomic, or -- for bit-reproducible sums -- an integer atomic on the same word
+__device__ __forceinline__ void grid_add(const PmeArgs& a, size_t index, float v) {
+    if (a.detScale > 0.f) atomicAdd((int*) &a.grid[index], __float2int_rn(v * a.detScale));
+    else atomicAdd(&a.grid[index], v);
+}
+
+__global__ void pme_fixed_to_float(float* __restrict__ grid, size_t n, float invScale) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) grid[i] = (float) ((const int*) grid)[i] * invScale;
+}
 
 // local plane of global x plane gx for spreading (own planes only; -1 = not mine) and for interpolation (own + halo planes)
 template <bool DD> __device__ __forceinline__ int spread_plane(const PmeArgs& a, int gx) {
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(256) void pme_spread(PmeArgs a) {
         float wx = th[0][0], wy = th[1][0], wz = th[2][0];
 #pragma unroll
         for (int k = 1; k < PME_ORDER; k++) { wx = ix == k ? th[0][k] : wx; wy = iy == k ? th[1][k] : wy; wz = iz == k ? th[2][k] : wz; }
-        atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], p.w * wx * wy * wz);
+        grid_add(a, ((size_t) gx * a.ny + gy) * a.nz + gz, p.w * wx * wy * wz);
     }
 }
 
@@ -264,13 +276,13 @@ __device__ __forceinline__ void pme_spread_body(const PmeArgs& a, const int bloc
                 int gy = baseIdx[atom][1] + iyA; gy -= gy >= a.ny ? a.ny : 0;
                 int gz = baseIdx[atom][2] + izA; gz -= gz >= a.nz ? a.nz : 0;
                 gx = spread_plane<DD>(a, gx);
-                if (gx >= 0) atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], vA);
+                if (gx >= 0) grid_add(a, ((size_t) gx * a.ny + gy) * a.nz + gz, vA);
                 if (hasB) {
                     gx = baseIdx[atom][0] + ixB; gx -= gx >= a.nx ? a.nx : 0;
                     gy = baseIdx[atom][1] + iyB; gy -= gy >= a.ny ? a.ny : 0;
                     gz = baseIdx[atom][2] + izB; gz -= gz >= a.nz ? a.nz : 0;
                     gx = spread_plane<DD>(a, gx);
-                    if (gx >= 0) atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], vB);
+                    if (gx >= 0) grid_add(a, ((size_t) gx * a.ny + gy) * a.nz + gz, vB);
                 }
             }
         }
@@ -290,7 +302,7 @@ __device__ __forceinline__ void pme_spread_body(const PmeArgs& a, const int bloc
             int gy = org[1] + (i / BRICK_ZS) % BRICK; gy -= gy >= a.ny ? a.ny : 0;
             int gz = org[2] + i % BRICK_ZS; gz -= gz >= a.nz ? a.nz : 0;
             gx = spread_plane<DD>(a, gx);
-            if (gx >= 0) atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], v);
+            if (gx >= 0) grid_add(a, ((size_t) gx * a.ny + gy) * a.nz + gz, v);
         }
     }
 }
@@ -899,6 +911,7 @@ static PmeArgs make_pme_args(const ommhip_pme* pme, const void* posq_d, int padd
     pa.includeEnergy = include_energy; pa.energySlots = energy_slots; pa.energyBuffer = energy_buffer_d;
     pa.planeLo = 0; pa.planeCount = nx; pa.haloLo = 0; pa.gridPlanes = nx; pa.ownSlot0 = 0; pa.ownSlot1 = padded_atoms;
     pa.ddError = nullptr; pa.blockCenter = nullptr; pa.blockHalf = nullptr;
+    pa.detScale = pme->deterministic && pme->max_charge > 0 ? (float) (2147483648.0 / (64.0 * pme->max_charge)) : 0.f;
     return pa;
 }
 
@@ -917,6 +930,10 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
             hipLaunchKernelGGL(pme_spread, dim3(spreadBlocks), dim3(256), 0, st, pa);             // direct global atomics (reference variant)
         else
             hipLaunchKernelGGL(pme_spread_lds<false>, dim3((padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS), dim3(256), 0, st, pa);
+        if (pa.detScale > 0.f) {
+            const size_t n = (size_t) nx * ny * nz;
+            hipLaunchKernelGGL(pme_fixed_to_float, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, pa.grid, n, 1.f / pa.detScale);
+        }
         ommhip_profile_end(OMMHIP_TIMER_PME_SPREAD, stream);
     }
     if (pme->phases == OMMHIP_PME_SPREAD_ONLY) return (int) hipGetLastError();

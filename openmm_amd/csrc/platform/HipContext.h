@@ -157,6 +157,7 @@ public:
     //      integration while the list's overflow word is set (ommhip_integrator_state::freeze_state); the host notices at the
     //      latest 16 evaluations later (or at the next download of positions / velocities / forces), grows the list and
     //      replays the skipped steps.  freezeState: device pointer to the list's state array (NULL: no freezing, e.g. decomposed runs).
+    bool deterministicForces = false;                        // platform property DeterministicForces: reproducible charge-grid sums (ommhip_pme::deterministic)
     int* freezeState = NULL;
     int pendingReplay = 0;                                   // skipped steps the integrator still has to redo
     std::function<int()> listRecovery;                       // set by the nonbonded kernel: synchronous check; fixes the list, returns skipped steps

@@ -1061,6 +1061,10 @@ void HipCalcNonbondedForceKernel::fillPmeStruct() {
     pme.excl_start = foldExclusions ? exclStart.as<int>() : NULL;
     pme.excl_atoms = exclAtoms.as<int>(); pme.atom_of_slot = hip.atomOfSlot.as<int>();
     pme.pos = hip.pos.ptr; pme.charge = chargeD.as<double>(); pme.excl_periodic = exceptionsArePeriodic ? 1 : 0;
+    pme.deterministic = hip.deterministicForces ? 1 : 0;
+    pme.max_charge = 0;
+    if (hip.deterministicForces)
+        for (size_t i = 0; i < charges.size(); i++) pme.max_charge = max(pme.max_charge, fabs(charges[i]));
     if (etermDirty) {
         HIP_CHECK(ommhip_pme_build_eterm(&pme, hip.stream));
         etermDirty = false;
@@ -1157,7 +1161,7 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
             // (small systems only: at a million atoms the builder workgroups of a rebuild get in each other's way with the spread
             // workgroups of the same launch -- 3.5 ms against 2.1 + 0.3 ms as launches of their own, profiles/r02a vs r02c)
             static const int frontMaxAtoms = getenv("OPENMM_HIP_FUSED_FRONT_MAX_ATOMS") != NULL ? atoi(getenv("OPENMM_HIP_FUSED_FRONT_MAX_ATOMS")) : 60000;
-            if (!forceRebuild && includeReciprocal && nonbondedMethod == PME && !hip.usePmeStream && !noFront && pme.grid_precleared && pme.spread_mode == 0 && numParticles <= frontMaxAtoms) {
+            if (!forceRebuild && includeReciprocal && nonbondedMethod == PME && !hip.usePmeStream && !noFront && pme.grid_precleared && pme.spread_mode == 0 && numParticles <= frontMaxAtoms && !hip.deterministicForces) {
                 // single-stream mode: list rebuild (if requested), charge spreading and every per-term force list of this
                 // evaluation are independent once the positions are converted -- they go out as ONE launch
                 const bool clear = hip.takePendingClear();

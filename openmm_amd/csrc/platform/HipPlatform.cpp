@@ -195,6 +195,8 @@ const string& HipPlatform::getPropertyValue(const Context& context, const string
 }
 
 void HipPlatform::setPropertyValue(Context& context, const string& property, const string& value) const {
+    // every property of this platform shapes the Context at creation (device, streams, communicator): none can change afterwards
+    throw OpenMMException("HIP platform: the property '" + property + "' cannot be changed after the Context has been created");
 }
 
 void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>& properties) const {
@@ -202,8 +204,9 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
             getPropertyDefaultValue(HipDeviceIndex()) : properties.find(HipDeviceIndex())->second);
     string precision = (properties.find(HipPrecision()) == properties.end() ?
             getPropertyDefaultValue(HipPrecision()) : properties.find(HipPrecision())->second);
-    if (precision != "mixed" && precision != "single")
-        throw OpenMMException("HIP platform: Precision must be 'single' or 'mixed' (forces are single precision, integration is double)");
+    if (precision != "mixed")
+        throw OpenMMException("HIP platform: Precision must be 'mixed' (single-precision pair and PME arithmetic, 64-bit fixed-point force accumulation, "
+                              "double-precision integration and constraints); 'single' and 'double' modes do not exist on this platform");
     int deviceIndex = 0;
     if (devicePropValue.find(',') != string::npos)
         throw OpenMMException("HIP platform: one Context drives one device; multi-GPU runs use one process per GPU (see bench.py)");
@@ -265,6 +268,7 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
     data->propertyValues[HipDisablePmeStream()] = (properties.find(HipDisablePmeStream()) == properties.end() ?
             getPropertyDefaultValue(HipDisablePmeStream()) : properties.find(HipDisablePmeStream())->second);
     data->hip->usePmeStream = data->propertyValues[HipDisablePmeStream()] != "true";
+    data->hip->deterministicForces = data->propertyValues[HipDeterministicForces()] == "true";
     // decomposed runs overlap reciprocal space (and its collectives) with the pair kernel unless told otherwise
     if (data->hip->decomposed() && properties.find(HipDisablePmeStream()) == properties.end()) {
         data->hip->usePmeStream = true;

@@ -17,7 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_DIR = os.path.join(_HERE, "lib")
 EMU_DIR = os.path.join(ROOT, "tests", "emu", "_build")
-ORACLE_DIR = os.path.join(ROOT, "oracle", "_ref")
+ORACLE_DIR = os.path.join(ROOT, "oracle", "_ref")          # libOpenMMCPU.so: CPU baseline / second checker (tests and bench only)
+HOST_LIB_DIR = os.path.join(os.environ.get("OPENMM_DIR", os.path.join(ROOT, "build", "openmm")), "lib")      # the host OpenMM library the plugin links
 
 NoCutoff, CutoffNonPeriodic, CutoffPeriodic, Ewald, PME, LJPME = range(6)
 VERLET, LANGEVIN, LANGEVIN_MIDDLE = 0, 1, 2
@@ -44,7 +45,7 @@ def lib():
         path = os.path.join(LIB_DIR, "libommharness.so")
         if not os.path.exists(path):
             raise OpenMMError("harness library missing: %s (run __graft_entry__.build())" % path)
-        C.CDLL(os.path.join(ORACLE_DIR, "libOpenMM.so"), mode=C.RTLD_GLOBAL)
+        C.CDLL(os.path.join(HOST_LIB_DIR, "libOpenMM.so"), mode=C.RTLD_GLOBAL)
         _lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
         for name in ("omm_last_error", "omm_platform_name", "omm_version", "omm_context_platform_name", "omm_context_platform_property"):
             getattr(_lib, name).restype = C.c_char_p

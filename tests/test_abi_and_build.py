@@ -10,20 +10,21 @@ import pytest
 
 from conftest import ROOT
 
-HEADER = os.path.join(ROOT, "include", "openmm_hip_kernels.h")
+HEADERS = [os.path.join(ROOT, "include", "openmm_hip_kernels.h"), os.path.join(ROOT, "include", "openmm_hip_comm.h")]
 LIB = os.path.join(ROOT, "openmm_amd", "lib")
 
 
 def declared_symbols():
-    text = open(HEADER).read()
+    text = "".join(open(h).read() for h in HEADERS)
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ommhip_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(ommhip_\w+)\s*\(", text)) - {"ommhip_host_all_gather_fn"})
 
 
 def test_header_declares_entry_points():
     syms = declared_symbols()
     assert len(syms) >= 40
-    for must in ("ommhip_nb_direct", "ommhip_nl_update", "ommhip_pme_reciprocal", "ommhip_integrate_stage", "ommhip_settle"):
+    for must in ("ommhip_nb_direct", "ommhip_nl_update", "ommhip_pme_reciprocal", "ommhip_integrate_stage", "ommhip_settle",
+                 "ommhip_pme_reciprocal_dd", "ommhip_comm_create_rccl", "ommhip_comm_all_gather", "ommhip_comm_all_to_all"):
         assert must in syms
 
 
@@ -40,7 +41,7 @@ def test_kernel_library_contains_gfx950_code_objects():
 
 def test_plugin_exports_openmm_entry_points():
     # olla/include/openmm/PluginInitializer.h:45-57
-    C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libOpenMM.so"), mode=C.RTLD_GLOBAL)
+    C.CDLL(os.path.join(ROOT, "build", "openmm", "lib", "libOpenMM.so"), mode=C.RTLD_GLOBAL)      # the host library the plugin links
     plugin = C.CDLL(os.path.join(LIB, "libOpenMMHIP.so"))
     assert hasattr(plugin, "registerPlatforms")
     assert hasattr(plugin, "registerKernelFactories")

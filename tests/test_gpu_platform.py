@@ -361,3 +361,47 @@ def test_native_ljpme_matches_the_reference_platform():
     """tests/ljpme_case.py on the GPU (the reference's own tests/TestDispersionPME.h body runs natively as TestHipDispersionPME)."""
     from ljpme_case import run_ljpme_case
     run_ljpme_case()
+
+
+def test_reordering_leaves_positions_alone():
+    """HIP twin of platforms/cuda/tests/TestCudaNonbondedForce.cpp:96-121 (testReordering): 200 uncharged particles scattered over
+    +-10 nm in a 6 nm triclinic box; one step with zero forces and velocities must hand back the positions that were set -- the
+    spatial re-sort and the periodic wrapping are internal."""
+    rng = np.random.default_rng(0)
+    n = 200
+    w = T.Workload("reordering")
+    w.box = np.array([[6.0, 0, 0], [2.1, 6.0, 0], [-1.5, -0.5, 6.0]])
+    w.masses = np.ones(n)
+    w.charge = w.sigma = w.epsilon = np.zeros(n)
+    w.positions = (rng.random((n, 3)) - 0.5) * 20
+    w.method, w.cutoff, w.dispersion = H.PME, 1.0, True
+    system, nb = w.build()
+    integ = H.Integrator(H.VERLET, 0.001)
+    ctx = H.Context(system, integ, "HIP")
+    ctx.setPositions(w.positions)
+    integ.step(1)
+    st = ctx.getState(getPositions=True, getVelocities=True)
+    ctx.close()
+    assert np.abs(st.positions - w.positions).max() < 1e-6
+    assert np.abs(st.velocities).max() < 1e-6
+
+
+def test_deterministic_forces():
+    """HIP twin of TestCudaNonbondedForce.cpp:123-155 (testDeterministicForces): with DeterministicForces=true two evaluations of
+    the same configuration give bit-identical forces (1000 charges, triclinic box, PME)."""
+    rng = np.random.default_rng(0)
+    n = 1000
+    w = T.Workload("deterministic")
+    w.box = np.array([[6.0, 0, 0], [2.1, 6.0, 0], [-1.5, -0.5, 6.0]])
+    w.masses = np.ones(n)
+    w.charge = np.where(np.arange(n) % 2 == 0, 1.0, -1.0)
+    w.sigma, w.epsilon = np.ones(n), np.zeros(n)
+    w.positions = (rng.random((n, 3)) - 0.5) * 6
+    w.method, w.cutoff, w.dispersion = H.PME, 1.0, True
+    system, nb = w.build()
+    ctx = H.Context(system, H.Integrator(H.VERLET, 0.001), "HIP", {"DeterministicForces": "true"})
+    ctx.setPositions(w.positions)
+    f1 = ctx.getState(getForces=True).forces
+    f2 = ctx.getState(getForces=True).forces
+    ctx.close()
+    assert np.array_equal(f1, f2)

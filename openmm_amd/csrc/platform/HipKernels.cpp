@@ -393,12 +393,14 @@ void HipUpdateStateDataKernel::setPeriodicBoxVectors(ContextImpl& context, const
     *data.periodicBoxSize = Vec3(a[0], b[1], c[2]);
 }
 void HipUpdateStateDataKernel::createCheckpoint(ContextImpl& context, ostream& stream) {
-    // same content as ReferenceUpdateStateDataKernel::createCheckpoint (ReferenceKernels.cpp:282-294);
-    // the integrators' random numbers are a pure function of (seed, stepCount, atom), so no RNG state is needed.
-    int version = 1;
+    // same content as ReferenceUpdateStateDataKernel::createCheckpoint (ReferenceKernels.cpp:282-294).  The thermostat noise is a
+    // pure function of (seed, stepCount, atom): instead of a generator state the checkpoint carries the resolved seed, so a run
+    // restarted in another Context or process (where seed 0 would resolve differently) continues the same noise stream.
+    int version = 2;
     stream.write((char*) &version, sizeof(int));
     stream.write((char*) &data.time, sizeof(double));
     stream.write((char*) &data.stepCount, sizeof(int));
+    stream.write((char*) &data.integratorSeed, sizeof(unsigned long long));
     vector<Vec3> pos, vel;
     data.hip->downloadPositions(pos);
     data.hip->downloadVelocities(vel);
@@ -411,14 +413,16 @@ void HipUpdateStateDataKernel::createCheckpoint(ContextImpl& context, ostream& s
 void HipUpdateStateDataKernel::loadCheckpoint(ContextImpl& context, istream& stream) {
     int version;
     stream.read((char*) &version, sizeof(int));
-    if (version != 1) throw OpenMMException("Checkpoint was created with a different version of OpenMM");
+    if (version != 2) throw OpenMMException("Checkpoint was created with a different version of OpenMM");
     stream.read((char*) &data.time, sizeof(double));
     stream.read((char*) &data.stepCount, sizeof(int));
+    stream.read((char*) &data.integratorSeed, sizeof(unsigned long long));
     vector<Vec3> pos(data.hip->numAtoms), vel(data.hip->numAtoms);
     stream.read((char*) pos.data(), sizeof(Vec3) * pos.size());
     stream.read((char*) vel.data(), sizeof(Vec3) * vel.size());
     Vec3 box[3];
     stream.read((char*) box, 3 * sizeof(Vec3));
+    if (!stream.good()) throw OpenMMException("HIP platform: the checkpoint is truncated");
     setPeriodicBoxVectors(context, box[0], box[1], box[2]);
     setPositions(context, pos);
     setVelocities(context, vel);
@@ -1525,7 +1529,7 @@ static unsigned long long resolveSeed(int seed) {
 }
 
 void HipIntegrateLangevinStepKernel::initialize(const System& system, const LangevinIntegrator& integrator) {
-    seed = resolveSeed(integrator.getRandomNumberSeed());
+    data.integratorSeed = resolveSeed(integrator.getRandomNumberSeed());
 }
 void HipIntegrateLangevinStepKernel::launchStep(ContextImpl& context, const LangevinIntegrator& integrator, long long stepIndex) {
     // ReferenceStochasticDynamics.cpp:89-194
@@ -1534,7 +1538,7 @@ void HipIntegrateLangevinStepKernel::launchStep(ContextImpl& context, const Lang
     ommhip_integrator_state s;
     fillState(s, dt);
     s.step = (unsigned long long) stepIndex;
-    s.seed = seed;
+    s.seed = data.integratorSeed;
     s.vscale = exp(-dt * friction);
     s.fscale = friction == 0 ? dt : (1 - s.vscale) / friction;
     s.noisescale = sqrt(kT * (1 - s.vscale * s.vscale));
@@ -1564,7 +1568,7 @@ double HipIntegrateLangevinStepKernel::computeKineticEnergy(ContextImpl& context
 }
 
 void HipIntegrateLangevinMiddleStepKernel::initialize(const System& system, const LangevinMiddleIntegrator& integrator) {
-    seed = resolveSeed(integrator.getRandomNumberSeed());
+    data.integratorSeed = resolveSeed(integrator.getRandomNumberSeed());
 }
 void HipIntegrateLangevinMiddleStepKernel::launchStep(ContextImpl& context, const LangevinMiddleIntegrator& integrator, long long stepIndex) {
     // ReferenceLangevinMiddleDynamics.cpp:92-127
@@ -1574,7 +1578,7 @@ void HipIntegrateLangevinMiddleStepKernel::launchStep(ContextImpl& context, cons
     ommhip_integrator_state s;
     fillState(s, dt);
     s.step = (unsigned long long) stepIndex;
-    s.seed = seed;
+    s.seed = data.integratorSeed;
     s.vscale = exp(-dt * friction);
     s.noisescale = sqrt(kT * (1 - s.vscale * s.vscale));
     HipConstraints& constraints = data.getDeviceConstraints(context.getSystem());

@@ -283,7 +283,7 @@ void HipPlatform::contextDestroyed(ContextImpl& context) const {
 }
 
 HipPlatform::PlatformData::PlatformData(const System& system, int deviceIndex, bool hostMode, const HipDomain& domain) : ReferencePlatform::PlatformData(system),
-        hip(NULL), system(&system), referenceNonbonded(false), deviceConstraints(NULL) {
+        hip(NULL), system(&system), referenceNonbonded(false), integratorSeed(0), deviceConstraints(NULL) {
     hip = new HipContext(system, deviceIndex, hostMode, domain);
 }
 

@@ -60,6 +60,7 @@ public:
     HipContext* hip;
     const System* system;
     bool referenceNonbonded;
+    unsigned long long integratorSeed;      // resolved seed of the Langevin thermostat noise (part of a checkpoint)
     std::map<std::string, std::string> propertyValues;
 private:
     HipConstraints* deviceConstraints;

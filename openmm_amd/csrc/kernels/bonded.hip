@@ -141,27 +141,26 @@ __device__ __forceinline__ double term_harmonic_angle(const TermCtx& c, int t) {
 
 __device__ __forceinline__ double term_periodic_torsion(const TermCtx& c, int t) {
     const int ia = c.l.atoms[4 * t], ib = c.l.atoms[4 * t + 1], ic = c.l.atoms[4 * t + 2], id = c.l.atoms[4 * t + 3];
-    const double k = c.l.params[3 * t], phase = c.l.params[3 * t + 1], periodicity = c.l.params[3 * t + 2];
+    // params: (k, cos(phase), sin(phase), periodicity) -- the host takes the sine and cosine of the phase once
+    const double k = c.l.params[4 * t], cosPhase = c.l.params[4 * t + 1], sinPhase = c.l.params[4 * t + 2];
+    const int periodicity = (int) c.l.params[4 * t + 3];
     const double3 v0 = c.delta(ib, ia);      // a - b
     const double3 v1 = c.delta(ib, ic);      // c - b
     const double3 v2 = c.delta(id, ic);      // c - d
     const double3 cp0 = cross3(v0, v1), cp1 = cross3(v1, v2);
-    // angle between the two plane normals, asin branch near 0/pi (ReferenceBondIxn.cpp:115-135)
+    // The dihedral angle phi of ReferenceBondIxn.cpp:115-135 never has to be formed: with the plane normals cp0, cp1
+    //   cos(phi) = cp0.cp1 / (|cp0| |cp1|),   sin(phi) = |v1| (v0.cp1) / (|cp0| |cp1|)   (sign as the reference's dot(v0, cp1) test),
+    // cos(n phi), sin(n phi) follow by the angle-addition recurrence for the integer periodicity n, and the phase enters through
+    // its own sine and cosine -- no inverse trigonometric function and no sin/cos call in double precision per term.
     const double n0 = dot3(cp0, cp0), n1 = dot3(cp1, cp1);
-    double dp = dot3(cp0, cp1) / sqrt(n0 * n1);
-    dp = dp > 1.0 ? 1.0 : (dp < -1.0 ? -1.0 : dp);
-    double angle;
-    if (dp > 0.99 || dp < -0.99) {
-        const double3 cr = cross3(cp0, cp1);
-        angle = asin(sqrt(dot3(cr, cr) / (n0 * n1)));
-        if (dp < 0.0) angle = 3.14159265358979323846 - angle;
-    }
-    else
-        angle = acos(dp);
-    if (dot3(v0, cp1) < 0.0) angle = -angle;
-    const double deltaAngle = periodicity * angle - phase;
-    const double dEdAngle = -k * periodicity * sin(deltaAngle);
+    const double invNorm = 1.0 / sqrt(n0 * n1);
     const double normBC = sqrt(dot3(v1, v1));
+    const double cosPhi = dot3(cp0, cp1) * invNorm, sinPhi = normBC * dot3(v0, cp1) * invNorm;
+    double cn = 1.0, sn = 0.0;
+    for (int i = 0; i < periodicity; i++) { const double cNext = cn * cosPhi - sn * sinPhi; sn = sn * cosPhi + cn * sinPhi; cn = cNext; }
+    const double cosDelta = cn * cosPhase + sn * sinPhase;          // cos(n phi - phase)
+    const double sinDelta = sn * cosPhase - cn * sinPhase;          // sin(n phi - phase)
+    const double dEdAngle = -k * periodicity * sinDelta;
     const double ff0 = (-dEdAngle * normBC) / n0;
     const double ff3 = (dEdAngle * normBC) / n1;
     const double ff1 = dot3(v0, v1) / dot3(v1, v1);
@@ -173,7 +172,7 @@ __device__ __forceinline__ double term_periodic_torsion(const TermCtx& c, int t)
     c.add(ib, -(f0.x - s.x), -(f0.y - s.y), -(f0.z - s.z));
     c.add(ic, -(f3.x + s.x), -(f3.y + s.y), -(f3.z + s.z));
     c.add(id, f3.x, f3.y, f3.z);
-    return k * (1.0 + cos(deltaAngle));
+    return k * (1.0 + cosDelta);
 }
 
 __device__ __forceinline__ void terms_body(const TermArgs& a, const int block, double (&partial)[4]) {

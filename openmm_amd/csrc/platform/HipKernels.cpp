@@ -1406,7 +1406,7 @@ void HipCalcPeriodicTorsionForceKernel::initialize(const System& system, const P
         int p1, p2, p3, p4, periodicity; double phase, k;
         force.getTorsionParameters(i, p1, p2, p3, p4, periodicity, phase, k);
         atoms.push_back(p1); atoms.push_back(p2); atoms.push_back(p3); atoms.push_back(p4);
-        params.push_back(k); params.push_back(phase); params.push_back(periodicity);
+        params.push_back(k); params.push_back(cos(phase)); params.push_back(sin(phase)); params.push_back(periodicity);
     }
     terms.upload(atoms, params, force.usesPeriodicBoundaryConditions(), force.getForceGroup());
 }
@@ -1419,7 +1419,7 @@ void HipCalcPeriodicTorsionForceKernel::copyParametersToContext(ContextImpl& con
     for (int i = 0; i < force.getNumTorsions(); i++) {
         int p1, p2, p3, p4, periodicity; double phase, k;
         force.getTorsionParameters(i, p1, p2, p3, p4, periodicity, phase, k);
-        params.push_back(k); params.push_back(phase); params.push_back(periodicity);
+        params.push_back(k); params.push_back(cos(phase)); params.push_back(sin(phase)); params.push_back(periodicity);
     }
     terms.uploadParams(params);
 }

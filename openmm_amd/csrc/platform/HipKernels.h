@@ -217,7 +217,7 @@ private:
 /** kernels.h:416-481 CalcPeriodicTorsionForceKernel; Reference: ReferenceKernels.cpp:603-650. */
 class HipCalcPeriodicTorsionForceKernel : public CalcPeriodicTorsionForceKernel {
 public:
-    HipCalcPeriodicTorsionForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : CalcPeriodicTorsionForceKernel(name, platform), terms(data, OMMHIP_TERM_PERIODIC_TORSION, 4, 3) {}
+    HipCalcPeriodicTorsionForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : CalcPeriodicTorsionForceKernel(name, platform), terms(data, OMMHIP_TERM_PERIODIC_TORSION, 4, 4) {}
     void initialize(const System& system, const PeriodicTorsionForce& force);
     double execute(ContextImpl& context, bool includeForces, bool includeEnergy);
     void copyParametersToContext(ContextImpl& context, const PeriodicTorsionForce& force);

@@ -492,22 +492,86 @@ __device__ __forceinline__ long long fft_remap_offset(const FftArgs& a, int oute
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
+// Radix-R butterflies on R values held in registers: v[] -> o[], the DFT of length R with the sign of the pass (fs = -1 forward,
+// +1 backward).  Split-radix style forms instead of the O(R^2) sum: radix 4 and 8 need no / two real constants, the odd radices
+// pair v[k] with v[R-k] (cosine part on the sums, sine part on the differences), so radix 3 / 5 / 7 cost 4 / 16 / 36 real
+// multiplies where the plain sum costs 16 / 64 / 144.  rot() multiplies by i * fs.
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 rot(float2 v, float fs) { return make_float2(-fs * v.y, fs * v.x); }
+
+template <int R> __device__ __forceinline__ void butterfly(const float2 (&v)[R], float2 (&o)[R], float fs);
+
+template <> __device__ __forceinline__ void butterfly<2>(const float2 (&v)[2], float2 (&o)[2], float) {
+    o[0] = cadd(v[0], v[1]); o[1] = csub(v[0], v[1]);
+}
+template <> __device__ __forceinline__ void butterfly<4>(const float2 (&v)[4], float2 (&o)[4], float fs) {
+    const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = rot(csub(v[1], v[3]), fs);
+    o[0] = cadd(t0, t2); o[2] = csub(t0, t2); o[1] = cadd(t1, t3); o[3] = csub(t1, t3);
+}
+template <> __device__ __forceinline__ void butterfly<8>(const float2 (&v)[8], float2 (&o)[8], float fs) {
+    // two radix-4 transforms (even and odd inputs), odd outputs twisted by W8^k = exp(i fs pi k / 4)
+    const float2 e[4] = {v[0], v[2], v[4], v[6]}, d[4] = {v[1], v[3], v[5], v[7]};
+    float2 E[4], D[4];
+    butterfly<4>(e, E, fs);
+    butterfly<4>(d, D, fs);
+    const float h = 0.70710678118654752440f;
+    const float2 w1 = make_float2(h * (D[1].x - fs * D[1].y), h * (D[1].y + fs * D[1].x));        // D1 * (1 + i fs) / sqrt 2
+    const float2 w2 = rot(D[2], fs);
+    const float2 w3 = make_float2(h * (-D[3].x - fs * D[3].y), h * (-D[3].y + fs * D[3].x));      // D3 * (-1 + i fs) / sqrt 2
+    o[0] = cadd(E[0], D[0]); o[4] = csub(E[0], D[0]);
+    o[1] = cadd(E[1], w1);   o[5] = csub(E[1], w1);
+    o[2] = cadd(E[2], w2);   o[6] = csub(E[2], w2);
+    o[3] = cadd(E[3], w3);   o[7] = csub(E[3], w3);
+}
+template <> __device__ __forceinline__ void butterfly<3>(const float2 (&v)[3], float2 (&o)[3], float fs) {
+    const float2 t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+    const float2 m = make_float2(v[0].x - 0.5f * t.x, v[0].y - 0.5f * t.y);
+    const float2 n = rot(make_float2(0.86602540378443864676f * d.x, 0.86602540378443864676f * d.y), fs);
+    o[0] = cadd(v[0], t); o[1] = cadd(m, n); o[2] = csub(m, n);
+}
+template <> __device__ __forceinline__ void butterfly<5>(const float2 (&v)[5], float2 (&o)[5], float fs) {
+    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f, s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+    const float2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), d1 = csub(v[1], v[4]), d2 = csub(v[2], v[3]);
+    const float2 m1 = make_float2(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
+    const float2 m2 = make_float2(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
+    const float2 n1 = rot(make_float2(s1 * d1.x + s2 * d2.x, s1 * d1.y + s2 * d2.y), fs);
+    const float2 n2 = rot(make_float2(s2 * d1.x - s1 * d2.x, s2 * d1.y - s1 * d2.y), fs);
+    o[0] = make_float2(v[0].x + t1.x + t2.x, v[0].y + t1.y + t2.y);
+    o[1] = cadd(m1, n1); o[4] = csub(m1, n1); o[2] = cadd(m2, n2); o[3] = csub(m2, n2);
+}
+template <> __device__ __forceinline__ void butterfly<7>(const float2 (&v)[7], float2 (&o)[7], float fs) {
+    const float c1 = 0.62348980185873353053f, c2 = -0.22252093395631440429f, c3 = -0.90096886790241912624f;
+    const float s1 = 0.78183148246802980871f, s2 = 0.97492791218182360702f, s3 = 0.43388373911755812048f;
+    const float2 t1 = cadd(v[1], v[6]), t2 = cadd(v[2], v[5]), t3 = cadd(v[3], v[4]);
+    const float2 d1 = csub(v[1], v[6]), d2 = csub(v[2], v[5]), d3 = csub(v[3], v[4]);
+    // cos(2 pi j k / 7) for j, k = 1..3: row j = (c_j, c_2j, c_3j) with c4 = c3, c6 = c1, c9 = c2; sines likewise with s4 = -s3, s6 = -s1, s9 = s2
+    const float2 m1 = make_float2(v[0].x + c1 * t1.x + c2 * t2.x + c3 * t3.x, v[0].y + c1 * t1.y + c2 * t2.y + c3 * t3.y);
+    const float2 m2 = make_float2(v[0].x + c2 * t1.x + c3 * t2.x + c1 * t3.x, v[0].y + c2 * t1.y + c3 * t2.y + c1 * t3.y);
+    const float2 m3 = make_float2(v[0].x + c3 * t1.x + c1 * t2.x + c2 * t3.x, v[0].y + c3 * t1.y + c1 * t2.y + c2 * t3.y);
+    const float2 n1 = rot(make_float2(s1 * d1.x + s2 * d2.x + s3 * d3.x, s1 * d1.y + s2 * d2.y + s3 * d3.y), fs);
+    const float2 n2 = rot(make_float2(s2 * d1.x - s3 * d2.x - s1 * d3.x, s2 * d1.y - s3 * d2.y - s1 * d3.y), fs);
+    const float2 n3 = rot(make_float2(s3 * d1.x - s1 * d2.x + s2 * d3.x, s3 * d1.y - s1 * d2.y + s2 * d3.y), fs);
+    o[0] = make_float2(v[0].x + t1.x + t2.x + t3.x, v[0].y + t1.y + t2.y + t3.y);
+    o[1] = cadd(m1, n1); o[6] = csub(m1, n1); o[2] = cadd(m2, n2); o[5] = csub(m2, n2); o[3] = cadd(m3, n3); o[4] = csub(m3, n3);
+}
+
 // One Stockham pass of radix R over all B lines.  `sign` selects forward (-1) or backward (+1).
 template <int R>
 // Element e of line l lives at e*BP + l*LS (BP = element stride, LS = line stride).
 __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2* __restrict__ dst, int n, int Ns, int B, int BP, int sign,
                                          const float2* __restrict__ tw, int LS) {
-    // `tw` is the LDS copy of the twiddle table exp(-2 pi i k/n).  The R-th roots of unity of the butterfly
-    // itself are R entries of that table, held in registers for the whole pass.
+    // `tw` is the LDS copy of the twiddle table exp(-2 pi i k/n).
     const int butterflies = n / R;
     const float fsign = (float) -sign;             // table holds exp(-i...), i.e. forward
-    float2 root[R];
-#pragma unroll
-    for (int m = 0; m < R; m++) { root[m] = tw[m * (n / R)]; root[m].y *= fsign; }
+    const float fs = (float) sign;
     const int twStep = n / (Ns * R);               // twiddle index increment per r
+    const bool pow2B = (B & (B - 1)) == 0;
+    const int shiftB = 31 - __clz(B);
     for (int idx = threadIdx.x; idx < butterflies * B; idx += (int) blockDim.x) {
-        const int line = idx % B, j = idx / B;
-        const int k = j % Ns;
+        int line, j;
+        if (pow2B) { line = idx & (B - 1); j = idx >> shiftB; } else { j = idx / B; line = idx - j * B; }
+        const int q = j / Ns, k = j - q * Ns;
         float2 v[R];
         v[0] = src[j * BP + line * LS];
 #pragma unroll
@@ -518,17 +582,8 @@ __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2*
             v[r] = cmul(x, w);
         }
         float2 o[R];
-#pragma unroll
-        for (int p = 0; p < R; p++) {
-            float2 acc = v[0];
-#pragma unroll
-            for (int r = 1; r < R; r++) {
-                float2 m = cmul(v[r], root[(p * r) % R]);
-                acc.x += m.x; acc.y += m.y;
-            }
-            o[p] = acc;
-        }
-        const int j0 = (j / Ns) * Ns * R + k;
+        butterfly<R>(v, o, fs);
+        const int j0 = q * Ns * R + k;
 #pragma unroll
         for (int p = 0; p < R; p++) dst[(j0 + p * Ns) * BP + line * LS] = o[p];
     }
@@ -803,7 +858,9 @@ int lines_per_group(int n) {
     int b = FFT_MAX_LDS / n - 1;     // (b+1)*n elements of LDS per buffer
     if (b > 16) b = 16;
     if (b < 1) b = 1;
-    return b;
+    int p = 1;                       // a power of two: line / butterfly indices by shift and mask, aligned segments in memory
+    while (2 * p <= b) p *= 2;
+    return p;
 }
 
 PlaneArgs make_plane_args(const ommhip_pme* pme, bool forward) {

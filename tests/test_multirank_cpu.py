@@ -148,9 +148,12 @@ dist.destroy_process_group()
 '''
 
 
-def _run_dd_child(tmp_path, emulated, device, steps, port, nproc=2):
+def _run_dd_child(tmp_path, emulated, device, steps, port, nproc=2, cases=None):
     script = tmp_path / "dd_child.py"
-    script.write_text(DD_CHILD % (ROOT, emulated, device, steps, emulated, steps))
+    text = DD_CHILD % (ROOT, emulated, device, steps, emulated, steps)
+    if cases is not None:
+        text = text.replace('(("water", T.water_box(8, seed=5), 24), ("solvated chain", T.small_solvated_chain(seed=3), 24))', cases)
+    script.write_text(text)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
@@ -169,3 +172,13 @@ def test_two_rank_domain_decomposition_whole_step_on_emulator(tmp_path):
     if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
         pytest.skip("emulated plugin not built (run __graft_entry__.build())")
     _run_dd_child(tmp_path, True, None, 4, 29547)
+
+
+def test_four_rank_domain_decomposition_on_emulator(tmp_path):
+    """Four slabs: every rank has two distinct ring neighbours for the potential planes, the all-to-alls move 4 x 4 chunks, and
+    in a 2.5 nm box the 0.6 nm slabs are thinner than the cutoff -- each rank's partners span all the others."""
+    import pytest
+    from conftest import EMU_BUILD
+    if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
+        pytest.skip("emulated plugin not built (run __graft_entry__.build())")
+    _run_dd_child(tmp_path, True, None, 3, 29557, nproc=4, cases='(("water, 4 ranks", T.water_box(8, seed=5), 24),)')

@@ -277,7 +277,8 @@ int ommhip_fft3d_r2c_c2r(const ommhip_pme* pme, int forward, void* stream);
  *   EWALD_EXCLUSION  atoms (i,j)      params unused; uses charge_d, alpha   ReferenceLJCoulombIxn.cpp:462-523
  *   HARMONIC_BOND    atoms (i,j)      params (length, k)                    kernels.h:276 CalcHarmonicBondForceKernel
  *   HARMONIC_ANGLE   atoms (i,j,k)    params (angle, k)                     kernels.h:346 CalcHarmonicAngleForceKernel
- *   PERIODIC_TORSION atoms (i,j,k,l)  params (k, cos phase, sin phase, periodicity)   kernels.h:416 CalcPeriodicTorsionForceKernel
+ *   PERIODIC_TORSION atoms (i,j,k,l)  params OMMHIP_TORSION_SUBTERMS x (k, cos phase, sin phase, periodicity), k = 0 for unused
+ *                                     sub-terms: all periodicities of one dihedral share a term            kernels.h:416 CalcPeriodicTorsionForceKernel
  * ------------------------------------------------------------------------------------------ */
 enum {
     OMMHIP_TERM_EXCEPTION14 = 0,
@@ -295,6 +296,7 @@ typedef struct ommhip_term_list {
 
 /* Several term lists in ONE launch (each list gets its own range of workgroups). */
 #define OMMHIP_MAX_TERM_LISTS 8
+#define OMMHIP_TORSION_SUBTERMS 4
 typedef struct ommhip_term_batch {
     int kind;
     ommhip_term_list terms;

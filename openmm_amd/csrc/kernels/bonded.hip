@@ -141,9 +141,10 @@ __device__ __forceinline__ double term_harmonic_angle(const TermCtx& c, int t) {
 
 __device__ __forceinline__ double term_periodic_torsion(const TermCtx& c, int t) {
     const int ia = c.l.atoms[4 * t], ib = c.l.atoms[4 * t + 1], ic = c.l.atoms[4 * t + 2], id = c.l.atoms[4 * t + 3];
-    // params: (k, cos(phase), sin(phase), periodicity) -- the host takes the sine and cosine of the phase once
-    const double k = c.l.params[4 * t], cosPhase = c.l.params[4 * t + 1], sinPhase = c.l.params[4 * t + 2];
-    const int periodicity = (int) c.l.params[4 * t + 3];
+    // params: OMMHIP_TORSION_SUBTERMS x (k, cos(phase), sin(phase), periodicity) -- every term on the same four atoms shares one
+    // thread (force fields put up to four periodicities on a dihedral: one geometry, no same-address atomics between them);
+    // unused sub-terms have k = 0.  The host takes the sine and cosine of the phase once.
+    const double* par = c.l.params + 4 * OMMHIP_TORSION_SUBTERMS * t;
     const double3 v0 = c.delta(ib, ia);      // a - b
     const double3 v1 = c.delta(ib, ic);      // c - b
     const double3 v2 = c.delta(id, ic);      // c - d
@@ -156,11 +157,18 @@ __device__ __forceinline__ double term_periodic_torsion(const TermCtx& c, int t)
     const double invNorm = 1.0 / sqrt(n0 * n1);
     const double normBC = sqrt(dot3(v1, v1));
     const double cosPhi = dot3(cp0, cp1) * invNorm, sinPhi = normBC * dot3(v0, cp1) * invNorm;
-    double cn = 1.0, sn = 0.0;
-    for (int i = 0; i < periodicity; i++) { const double cNext = cn * cosPhi - sn * sinPhi; sn = sn * cosPhi + cn * sinPhi; cn = cNext; }
-    const double cosDelta = cn * cosPhase + sn * sinPhase;          // cos(n phi - phase)
-    const double sinDelta = sn * cosPhase - cn * sinPhase;          // sin(n phi - phase)
-    const double dEdAngle = -k * periodicity * sinDelta;
+    double dEdAngle = 0.0, energy = 0.0;
+#pragma unroll
+    for (int sub = 0; sub < OMMHIP_TORSION_SUBTERMS; sub++) {
+        const double k = par[4 * sub];
+        if (k == 0.0) continue;
+        const double cosPhase = par[4 * sub + 1], sinPhase = par[4 * sub + 2];
+        const int periodicity = (int) par[4 * sub + 3];
+        double cn = 1.0, sn = 0.0;
+        for (int i = 0; i < periodicity; i++) { const double cNext = cn * cosPhi - sn * sinPhi; sn = sn * cosPhi + cn * sinPhi; cn = cNext; }
+        dEdAngle -= k * periodicity * (sn * cosPhase - cn * sinPhase);          // -k n sin(n phi - phase)
+        energy += k * (1.0 + cn * cosPhase + sn * sinPhase);                    //  k (1 + cos(n phi - phase))
+    }
     const double ff0 = (-dEdAngle * normBC) / n0;
     const double ff3 = (dEdAngle * normBC) / n1;
     const double ff1 = dot3(v0, v1) / dot3(v1, v1);
@@ -172,7 +180,7 @@ __device__ __forceinline__ double term_periodic_torsion(const TermCtx& c, int t)
     c.add(ib, -(f0.x - s.x), -(f0.y - s.y), -(f0.z - s.z));
     c.add(ic, -(f3.x + s.x), -(f3.y + s.y), -(f3.z + s.z));
     c.add(id, f3.x, f3.y, f3.z);
-    return k * (1.0 + cosDelta);
+    return energy;
 }
 
 __device__ __forceinline__ void terms_body(const TermArgs& a, const int block, double (&partial)[4]) {

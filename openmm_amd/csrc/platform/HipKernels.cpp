@@ -667,6 +667,17 @@ void HipCalcNonbondedForceKernel::atomsReordered() { slotParamsDirty = true; for
 void HipCalcNonbondedForceKernel::boxChanged() { etermDirty = true; dispersionEtermDirty = true; forceRebuild = true; }
 void HipCalcNonbondedForceKernel::positionsSet() { forceRebuild = true; }
 
+/* The "transposed" order of HipTermForce::upload for a list of term ids: neighbouring 1-4s share atoms, the lanes of a wavefront
+ * should not (their fixed-point atomics to one address would serialise). */
+static void transposeTermOrder(vector<int>& ids) {
+    const int n = (int) ids.size(), waves = (n + 63) / 64;
+    vector<int> reordered;
+    for (int w = 0; w < waves; w++)
+        for (int l = 0; l < 64; l++)
+            if (l * waves + w < n) reordered.push_back(ids[l * waves + w]);
+    ids.swap(reordered);
+}
+
 static int findLegalFftDimension(int minimum, int multipleOf = 1) {
     // smallest size >= minimum that the LDS FFT handles (2,3,5,7-smooth); same role as CudaFFT3D::findLegalDimension.
     // Slab-decomposed runs also need the x and y sizes to be multiples of the number of ranks.
@@ -732,6 +743,8 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
             nb14s.push_back(i);
         }
     }
+    transposeTermOrder(nb14s);
+    for (size_t i = 0; i < nb14s.size(); i++) nb14Index[nb14s[i]] = (int) i;
     num14 = (int) nb14s.size();
     numExclusionPairs = (int) exclusionPairs.size() / 2;
     baseParticleParams.assign(numParticles, vector<double>(3));
@@ -1291,6 +1304,7 @@ void HipCalcNonbondedForceKernel::copyParametersToContext(ContextImpl& context, 
     }
     if ((int) nb14s.size() != num14)
         throw OpenMMException("updateParametersInContext: The number of non-excluded exceptions has changed");
+    transposeTermOrder(nb14s);
     for (int i = 0; i < numParticles; i++)
         force.getParticleParameters(i, baseParticleParams[i][0], baseParticleParams[i][1], baseParticleParams[i][2]);
     for (int i = 0; i < num14; i++) {
@@ -1333,8 +1347,25 @@ void HipTermForce::upload(const vector<int>& atoms, const vector<double>& params
     numTerms = (int) atoms.size() / atomsPerTerm;
     periodic = usesPeriodic;
     if (usesPeriodic) data.hip->usePeriodic = true;
-    uploadVector(atomsD, atoms, data.hip->stream);
-    uploadVector(paramsD, params, data.hip->stream);
+    // Force fields list their terms atom by atom, so neighbouring terms share atoms and the 64 threads of a wavefront would
+    // send several fixed-point atomics to the same address in one instruction (they serialise).  The device lists are stored
+    // "transposed": lane l of wavefront w takes term l * W + w (W wavefronts), i.e. terms far apart in the original order.
+    order.resize(numTerms);
+    const int waves = (numTerms + 63) / 64;
+    int t = 0;
+    for (int w = 0; w < waves; w++)
+        for (int l = 0; l < 64; l++) {
+            const int original = l * waves + w;
+            if (original < numTerms) order[t++] = original;
+        }
+    vector<int> atomsP(atoms.size());
+    vector<double> paramsP(params.size());
+    for (int i = 0; i < numTerms; i++) {
+        for (int k = 0; k < atomsPerTerm; k++) atomsP[(size_t) i * atomsPerTerm + k] = atoms[(size_t) order[i] * atomsPerTerm + k];
+        for (int k = 0; k < paramsPerTerm; k++) paramsP[(size_t) i * paramsPerTerm + k] = params[(size_t) order[i] * paramsPerTerm + k];
+    }
+    uploadVector(atomsD, atomsP, data.hip->stream);
+    uploadVector(paramsD, paramsP, data.hip->stream);
     if (registrationId < 0) registrationId = data.hip->registerTerms(forceGroup, batch());
     else data.hip->updateTerms(registrationId, batch());
 }
@@ -1342,7 +1373,10 @@ void HipTermForce::uploadParams(const vector<double>& params) {
     data.hip->setAsCurrent();
     if ((int) params.size() != numTerms * paramsPerTerm)
         throw OpenMMException("updateParametersInContext: The number of terms has changed");
-    uploadVector(paramsD, params, data.hip->stream);
+    vector<double> paramsP(params.size());
+    for (int i = 0; i < numTerms; i++)
+        for (int k = 0; k < paramsPerTerm; k++) paramsP[(size_t) i * paramsPerTerm + k] = params[(size_t) order[i] * paramsPerTerm + k];
+    uploadVector(paramsD, paramsP, data.hip->stream);
     if (registrationId >= 0) data.hip->updateTerms(registrationId, batch());      // uploadVector may have moved the buffer
 }
 void HipTermForce::execute(bool includeEnergy) {
@@ -1400,14 +1434,32 @@ void HipCalcHarmonicAngleForceKernel::copyParametersToContext(ContextImpl& conte
     terms.uploadParams(params);
 }
 
-void HipCalcPeriodicTorsionForceKernel::initialize(const System& system, const PeriodicTorsionForce& force) {
-    vector<int> atoms; vector<double> params;
+void HipCalcPeriodicTorsionForceKernel::packTorsions(const PeriodicTorsionForce& force, vector<int>& atoms, vector<double>& params) {
+    // every (periodicity, phase, k) on the same four atoms -- force fields use up to four per dihedral -- becomes a sub-term of ONE
+    // device term (OMMHIP_TORSION_SUBTERMS slots, k = 0 when unused); a fifth one opens another device term on the same atoms
+    map<vector<int>, int> open;            // atoms -> device term that still has a free slot
+    vector<int> used;                       // sub-terms filled per device term
     for (int i = 0; i < force.getNumTorsions(); i++) {
         int p1, p2, p3, p4, periodicity; double phase, k;
         force.getTorsionParameters(i, p1, p2, p3, p4, periodicity, phase, k);
-        atoms.push_back(p1); atoms.push_back(p2); atoms.push_back(p3); atoms.push_back(p4);
-        params.push_back(k); params.push_back(cos(phase)); params.push_back(sin(phase)); params.push_back(periodicity);
+        const vector<int> key = {p1, p2, p3, p4};
+        map<vector<int>, int>::iterator it = open.find(key);
+        int term;
+        if (it == open.end() || used[it->second] == OMMHIP_TORSION_SUBTERMS) {
+            term = (int) used.size();
+            used.push_back(0);
+            atoms.insert(atoms.end(), key.begin(), key.end());
+            params.resize(params.size() + 4 * OMMHIP_TORSION_SUBTERMS, 0.0);
+            open[key] = term;
+        }
+        else term = it->second;
+        double* slot = &params[(size_t) term * 4 * OMMHIP_TORSION_SUBTERMS + 4 * used[term]++];
+        slot[0] = k; slot[1] = cos(phase); slot[2] = sin(phase); slot[3] = periodicity;
     }
+}
+void HipCalcPeriodicTorsionForceKernel::initialize(const System& system, const PeriodicTorsionForce& force) {
+    vector<int> atoms; vector<double> params;
+    packTorsions(force, atoms, params);
     terms.upload(atoms, params, force.usesPeriodicBoundaryConditions(), force.getForceGroup());
 }
 double HipCalcPeriodicTorsionForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy) {
@@ -1415,12 +1467,9 @@ double HipCalcPeriodicTorsionForceKernel::execute(ContextImpl& context, bool inc
     return 0.0;
 }
 void HipCalcPeriodicTorsionForceKernel::copyParametersToContext(ContextImpl& context, const PeriodicTorsionForce& force) {
-    vector<double> params;
-    for (int i = 0; i < force.getNumTorsions(); i++) {
-        int p1, p2, p3, p4, periodicity; double phase, k;
-        force.getTorsionParameters(i, p1, p2, p3, p4, periodicity, phase, k);
-        params.push_back(k); params.push_back(cos(phase)); params.push_back(sin(phase)); params.push_back(periodicity);
-    }
+    // the atoms of a torsion cannot change (PeriodicTorsionForce.h: updateParametersInContext), so the grouping is the same
+    vector<int> atoms; vector<double> params;
+    packTorsions(force, atoms, params);
     terms.uploadParams(params);
 }
 

@@ -190,6 +190,7 @@ private:
     int registrationId;
     ommhip_term_batch batch() const;
     DeviceBuffer atomsD, paramsD;
+    std::vector<int> order;        // term t of the device lists is term order[t] of the caller (see upload)
 };
 
 /** kernels.h:276-341 CalcHarmonicBondForceKernel; Reference: ReferenceKernels.cpp:343-391. */
@@ -217,11 +218,13 @@ private:
 /** kernels.h:416-481 CalcPeriodicTorsionForceKernel; Reference: ReferenceKernels.cpp:603-650. */
 class HipCalcPeriodicTorsionForceKernel : public CalcPeriodicTorsionForceKernel {
 public:
-    HipCalcPeriodicTorsionForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : CalcPeriodicTorsionForceKernel(name, platform), terms(data, OMMHIP_TERM_PERIODIC_TORSION, 4, 4) {}
+    HipCalcPeriodicTorsionForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : CalcPeriodicTorsionForceKernel(name, platform), terms(data, OMMHIP_TERM_PERIODIC_TORSION, 4, 4 * OMMHIP_TORSION_SUBTERMS) {}
     void initialize(const System& system, const PeriodicTorsionForce& force);
     double execute(ContextImpl& context, bool includeForces, bool includeEnergy);
     void copyParametersToContext(ContextImpl& context, const PeriodicTorsionForce& force);
 private:
+    /** Groups the force's torsions by their four atoms and packs each group's (k, phase, periodicity) into sub-terms. */
+    void packTorsions(const PeriodicTorsionForce& force, std::vector<int>& atoms, std::vector<double>& params);
     HipTermForce terms;
 };
 

@@ -55,3 +55,49 @@ def test_two_ranks_sharing_the_gpu_reproduce_the_single_gpu_run(tmp_path):
     from test_multirank_cpu import _run_dd_child
     out = _run_dd_child(tmp_path, False, 0, 10, 29561)
     print(out)
+
+
+GOLDEN_CHILD = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch.distributed as dist
+from openmm_amd import harness as H, testsystems as T, multirank as MR
+from openmm_amd.parity import force_parity
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+H.load_hip_platform()
+g = np.load(os.path.join(%r, "tests", "golden", "reference_forces_water985527_sample.npz"))
+w = T.water_box(int(g["n_side"]), seed=int(g["seed"]))
+w.pme_params = (float(g["pme"][0]), int(g["pme"][1]), int(g["pme"][2]), int(g["pme"][3]))
+props = MR.domain_properties(dist, transport="gloo", device_index=0)
+system, nb = w.build()
+ctx = H.Context(system, H.Integrator(H.VERLET, 0.001), "HIP", props)
+ctx.setPositions(w.positions)
+st = ctx.getState(getForces=True, getEnergy=True)
+ctx.close()
+idx = g["indices"]
+p = force_parity(w.positions, w.box, w.cutoff, st.forces[idx], g["forces"], subset=idx, rms=float(g["rms_force"]))
+if rank == 0:
+    print("water-1M on %%d ranks: force max-rel-err over the sampled atoms %%.3g (away from %%d edge pairs: %%.3g), E %%.3f vs %%.3f" %% (
+        world, p["max_rel_err_all_atoms"], p["cutoff_edge_pairs"], p["max_rel_err"], st.potentialEnergy, float(g["energy"])), flush=True)
+assert p["max_rel_err"] < 1e-4 and p["max_rel_err_all_atoms"] < 1e-3
+assert abs(st.potentialEnergy - float(g["energy"])) < 1e-5 * 5.0 * w.num_atoms
+if rank == 0:
+    print("OK")
+dist.destroy_process_group()
+'''
+
+
+def test_million_atom_box_on_four_ranks_matches_the_reference_golden(tmp_path):
+    """BASELINE.json configs[3] through the decomposed path: the 985 527-atom box on four ranks (sharing this GPU, collectives over
+    gloo) against the sampled Reference-platform golden -- the same bar as the single-GPU test."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "golden_child.py"
+    script.write_text(GOLDEN_CHILD % (ROOT, ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                          "--master-port", "29571", str(script)], capture_output=True, text=True, timeout=1500, env=env)
+    assert "OK" in out.stdout, out.stdout[-3000:] + out.stderr[-4000:]
+    print(out.stdout)

@@ -92,8 +92,10 @@ int ommhip_set_slot_params(const double* charge_d, const double* sigma_d, const 
 int ommhip_forces_to_double(const long long* force_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, double* out_d, void* stream);
 /* force[slot] += in[3*atom..] (double) */
 int ommhip_add_forces_from_double(const double* in_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, long long* force_d, void* stream);
-/* pos_slot[s] = pos[atom_of_slot[s]] for every valid slot (dst double4[padded_atoms]); used when every rank holds all
- * positions (after setPositions / a re-sort) to fill the all-gather buffer.  The same for any double4 array. */
+/* wire[s] = fixed-point box fractions of pos[atom_of_slot[s]] for the valid slots of [slot0, slot1)  (ommhip_neighbor_list::pos_wire) */
+int ommhip_encode_wire(const void* pos_d, const int* atom_of_slot_d, int slot0, int slot1, const double box_len[3], void* wire_d, void* stream);
+/* dst[s] = src[atom_of_slot[s]] for every valid slot of [slot0, slot1) (double4 arrays): slot-ordered staging of positions or
+ * velocities for an all-gather (State downloads, re-sorts). */
 int ommhip_pack_slots(const void* src_atom_order_d, const int* atom_of_slot_d, int slot0, int slot1, void* dst_slot_order_d, void* stream);
 /* dst[atom_of_slot[s]] = src[s] for the valid slots of [slot0, slot1) */
 int ommhip_unpack_slots(const void* src_slot_order_d, const int* atom_of_slot_d, int slot0, int slot1, void* dst_atom_order_d, void* stream);
@@ -162,12 +164,16 @@ typedef struct ommhip_neighbor_list {
      * the forces ON ITS OWN ATOMS ONLY: the list of an owned block X holds every partner block Y >= X plus the foreign
      * blocks below first_block, the pair kernel drops the force on j atoms outside the owned slot range, and the pair of
      * two atoms owned by different ranks is therefore evaluated once on each side (no force exchange between ranks;
-     * its energy is counted half on each side).  Positions of all atoms are replicated: pos_slot (double4[padded_atoms],
-     * slot order -- the buffer the ranks all-gather after every integration step) replaces the atom-ordered positions as
-     * the source of ommhip_nl_prepare, which also copies the positions of foreign slots into pos_scatter (atom order,
-     * double4[num_atoms]) for the kernels that address atoms by index (exclusion correction, bonded terms). */
+     * its energy is counted half on each side).  Positions of all atoms are replicated through pos_wire (uint4[padded_atoms],
+     * slot order -- the buffer the ranks all-gather after every integration step): x, y, z as 32-bit fixed-point fractions of
+     * the (rectangular) box edges, 16 bytes per atom on the wire, resolution L / 2^32 (5e-9 nm in a 21 nm box).  It replaces the
+     * atom-ordered positions as the source of ommhip_nl_prepare for EVERY slot, own ones included, so that all ranks derive
+     * bit-identical float coordinates and take identical rebuild decisions; the owner keeps integrating its exact doubles.
+     * ommhip_nl_prepare also refreshes pos_scatter (atom order, double4[num_atoms]) for foreign slots -- the last known
+     * position moved by the minimum-image displacement to the decoded one, so molecules stay whole -- for the kernels that
+     * address atoms by index (exclusion correction, bonded terms). */
     int dd_mode;
-    const void* pos_slot;
+    const void* pos_wire;
     void* pos_scatter;
 } ommhip_neighbor_list;
 
@@ -387,10 +393,12 @@ typedef struct ommhip_step_units {
     int remove_cm;
     double inv_total_mass;
     double* cm_scratch;        /* 4 + 4*ceil(num_units/128) doubles, zero-initialised once; or NULL */
-    /* Domain decomposition: the units are those this rank owns.  New positions are also written to pos_slot (double4,
-     * slot order: the all-gather buffer); the rank's momentum goes to pos_slot[trailer_slot + rank * slots_per_rank]
-     * instead of cm_scratch[0..2], and the CM velocity subtracted is the sum of the `ranks` trailers. */
-    void* pos_slot;
+    /* Domain decomposition: the units are those this rank owns.  New positions are also written to pos_wire (uint4, slot
+     * order: the all-gather buffer, fixed-point fractions of the box edges box_len[3]); the rank's momentum goes, as three
+     * doubles, into the two wire records [trailer_slot, trailer_slot + 1] of its range (trailer_slot even, no atoms there)
+     * in addition to cm_scratch[0..2], and the CM velocity subtracted is the sum of the `ranks` trailers. */
+    void* pos_wire;
+    double box_len[3];
     int ranks, rank, slots_per_rank, trailer_slot;
 } ommhip_step_units;
 enum { OMMHIP_INTEGRATOR_VERLET = 0, OMMHIP_INTEGRATOR_LANGEVIN = 1, OMMHIP_INTEGRATOR_LANGEVIN_MIDDLE = 2 };

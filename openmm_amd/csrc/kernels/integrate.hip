@@ -405,9 +405,11 @@ struct UnitArgs {
     const int4* atoms;        // (a0, a1, a2, a3), unused = -1; SETTLE: a0 = apex; SHAKE: a0 = centre
     const double4* dist;      // SETTLE (d01, d12, -, 1); SHAKE (d1, d2, d3, 2); free atom (-, -, -, 0)
     double* cm;               // [0..2] momentum after the previous fused step, [3] block counter (as int), [4 + 4*block] partials
-    // domain decomposition (posSlot != null): new positions also go to the all-gather buffer, and the momentum lives in one
-    // reserved slot per rank of that buffer ("trailer"), so the CM velocity needs no collective of its own
-    double4* posSlot;
+    // domain decomposition (posWire != null): new positions also go to the all-gather buffer as fixed-point box fractions, and the
+    // momentum lives in two reserved records per rank of that buffer ("trailer": 32 bytes = three doubles), so the CM velocity
+    // needs no collective of its own
+    uint4* posWire;
+    double invBox[3];
     int ranks, rank, slotsPerRank, trailerSlot;
 };
 
@@ -425,10 +427,10 @@ __global__ __launch_bounds__(128) void k_step_units(IntArgs a, UnitArgs u) {
         double w[4], xw[4];
         V3 cmv = v3(0, 0, 0);
         if (u.removeCm) {
-            if (u.posSlot != nullptr) {
+            if (u.posWire != nullptr) {
                 // total momentum = the ranks' trailers summed in rank order (the same bits on every rank)
                 double mx = 0, my = 0, mz = 0;
-                for (int r = 0; r < u.ranks; r++) { const double4 m = u.posSlot[(size_t) r * u.slotsPerRank + u.trailerSlot]; mx += m.x; my += m.y; mz += m.z; }
+                for (int r = 0; r < u.ranks; r++) { const double4 m = *(const double4*) (u.posWire + (size_t) r * u.slotsPerRank + u.trailerSlot); mx += m.x; my += m.y; mz += m.z; }
                 cmv = v3(mx * u.invTotalMass, my * u.invTotalMass, mz * u.invTotalMass);
             }
             else cmv = v3(u.cm[0] * u.invTotalMass, u.cm[1] * u.invTotalMass, u.cm[2] * u.invTotalMass);
@@ -495,7 +497,13 @@ __global__ __launch_bounds__(128) void k_step_units(IntArgs a, UnitArgs u) {
                 else v[k] = (xn[k] - x[k]) * inv;
                 a.vel[ids[k]] = make_double4(v[k].x, v[k].y, v[k].z, w[k]);
                 a.pos[ids[k]] = make_double4(xn[k].x, xn[k].y, xn[k].z, xw[k]);
-                if (u.posSlot != nullptr) u.posSlot[a.slotOfAtom[ids[k]]] = make_double4(xn[k].x, xn[k].y, xn[k].z, xw[k]);
+                if (u.posWire != nullptr) {
+                    // fraction of the box edge in [0, 1) as 32-bit fixed point (the wrap into the box is the conversion's modulo)
+                    double fx = xn[k].x * u.invBox[0], fy = xn[k].y * u.invBox[1], fz = xn[k].z * u.invBox[2];
+                    fx -= floor(fx); fy -= floor(fy); fz -= floor(fz);
+                    u.posWire[a.slotOfAtom[ids[k]]] = make_uint4((unsigned) (unsigned long long) (fx * 4294967296.0), (unsigned) (unsigned long long) (fy * 4294967296.0),
+                                                               (unsigned) (unsigned long long) (fz * 4294967296.0), 0u);
+                }
                 mom = mom + v[k] * (1.0 / w[k]);
             }
         }
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(128) void k_step_units(IntArgs a, UnitArgs u) {
         sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
         if (threadIdx.x == 0) {
             u.cm[0] = sx; u.cm[1] = sy; u.cm[2] = sz; *counter = 0;
-            if (u.posSlot != nullptr) u.posSlot[(size_t) u.rank * u.slotsPerRank + u.trailerSlot] = make_double4(sx, sy, sz, 0.0);
+            if (u.posWire != nullptr) *(double4*) (u.posWire + (size_t) u.rank * u.slotsPerRank + u.trailerSlot) = make_double4(sx, sy, sz, 0.0);
         }
     }
 }
@@ -665,7 +673,9 @@ extern "C" int ommhip_integrate_fused(int integrator, const ommhip_integrator_st
     u.numUnits = units->num_units; u.maxIterations = units->max_iterations; u.removeCm = units->remove_cm;
     u.tol = units->tol; u.invTotalMass = units->inv_total_mass;
     u.atoms = (const int4*) units->atoms; u.dist = (const double4*) units->dist; u.cm = units->cm_scratch;
-    u.posSlot = (double4*) units->pos_slot; u.ranks = units->ranks; u.rank = units->rank; u.slotsPerRank = units->slots_per_rank; u.trailerSlot = units->trailer_slot;
+    u.posWire = (uint4*) units->pos_wire;
+    for (int k = 0; k < 3; k++) u.invBox[k] = units->box_len[k] > 0 ? 1.0 / units->box_len[k] : 0.0;
+    u.ranks = units->ranks; u.rank = units->rank; u.slotsPerRank = units->slots_per_rank; u.trailerSlot = units->trailer_slot;
     hipStream_t st = (hipStream_t) stream;
     const dim3 grid = grid_for(u.numUnits);
     switch (integrator) {

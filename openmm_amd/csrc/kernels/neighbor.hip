@@ -34,7 +34,7 @@ struct NlArgs {
     int numAtoms, paddedAtoms, numBlocks, maxChunks;
     int firstBlock, ownedBlocks;      // the list is built for the i-blocks [firstBlock, firstBlock + ownedBlocks)
     int ddMode;                       // domain decomposition: partners are Y >= X plus the foreign blocks below firstBlock
-    const double4* posSlot;           // DD: positions in slot order (the all-gathered buffer), replaces pos[atom] in nl_prepare
+    const uint4* posWire;             // DD: all positions as fixed-point box fractions, slot order (the all-gathered buffer)
     double4* posScatter;              // DD: atom-ordered positions, refreshed for foreign slots by nl_prepare
     int pbc;                 // 0 none, 1 orthorhombic, 2 triclinic
     float listCutoff2;       // (cutoff + padding)^2, +inf for NoCutoff
@@ -544,16 +544,28 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
     float4 p = posqOut[sl];
     double xw = 0.0, yw = 0.0, zw = 0.0;               // the position in double: the float posq is its rounding
     if (valid) {
-        double4 x;
-        if (a.posSlot != nullptr) {
-            x = a.posSlot[sl];
-            if (a.posScatter != nullptr && (sl < a.firstBlock * OMM_TILE || sl >= (a.firstBlock + a.ownedBlocks) * OMM_TILE)) a.posScatter[atom] = x;
+        if (a.posWire != nullptr) {
+            // decomposed run: every slot -- own ones too, so that all ranks see the same numbers -- comes from the wire record,
+            // already wrapped into the box (rectangular by construction)
+            const uint4 u = a.posWire[sl];
+            const double f = 1.0 / 4294967296.0;
+            xw = (double) u.x * f * boxd.ax; yw = (double) u.y * f * boxd.by; zw = (double) u.z * f * boxd.cz;
+            if (a.posScatter != nullptr && (sl < a.firstBlock * OMM_TILE || sl >= (a.firstBlock + a.ownedBlocks) * OMM_TILE)) {
+                // atom-ordered copy of a foreign atom: the last known position moved by the minimum-image displacement
+                double4 o = a.posScatter[atom];
+                double dx = xw - o.x, dy = yw - o.y, dz = zw - o.z;
+                dx -= rint(dx / boxd.ax) * boxd.ax; dy -= rint(dy / boxd.by) * boxd.by; dz -= rint(dz / boxd.cz) * boxd.cz;
+                o.x += dx; o.y += dy; o.z += dz;
+                a.posScatter[atom] = o;
+            }
         }
-        else x = pos[atom];
-        const int4 w = wrap[atom];
-        xw = x.x - (w.x * boxd.ax + w.y * boxd.bx + w.z * boxd.cx);
-        yw = x.y - (w.y * boxd.by + w.z * boxd.cy);
-        zw = x.z - (w.z * boxd.cz);
+        else {
+            const double4 x = pos[atom];
+            const int4 w = wrap[atom];
+            xw = x.x - (w.x * boxd.ax + w.y * boxd.bx + w.z * boxd.cx);
+            yw = x.y - (w.y * boxd.by + w.z * boxd.cy);
+            zw = x.z - (w.z * boxd.cz);
+        }
         p.x = (float) xw; p.y = (float) yw; p.z = (float) zw;
     }
     else { p.x = 0.f; p.y = 0.f; p.z = 0.f; p.w = 0.f; }
@@ -615,7 +627,7 @@ NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
     a.firstBlock = 0; a.ownedBlocks = a.numBlocks;
     if (nl->owned_blocks > 0 && nl->first_block >= 0 && nl->first_block + nl->owned_blocks <= a.numBlocks) { a.firstBlock = nl->first_block; a.ownedBlocks = nl->owned_blocks; }
     a.ddMode = nl->dd_mode != 0 && a.ownedBlocks < a.numBlocks ? 1 : 0;
-    a.posSlot = (const double4*) nl->pos_slot; a.posScatter = (double4*) nl->pos_scatter;
+    a.posWire = (const uint4*) nl->pos_wire; a.posScatter = (double4*) nl->pos_scatter;
     a.pbc = nl->pbc;
     double rl = nl->cutoff + nl->padding;
     a.listCutoff2 = nl->cutoff > 0 ? (float) (rl * rl) : INFINITY;

@@ -91,6 +91,19 @@ __global__ void k_posq_with_weights(const float4* __restrict__ posq, const doubl
     dst[s] = make_float4(p.x, p.y, p.z, a >= 0 ? (float) weight[a] : 0.f);
 }
 
+// positions -> wire records (fixed-point fractions of the box edges), slot order
+__global__ void k_encode_wire(const double4* __restrict__ pos, const int* __restrict__ atomOfSlot, int slot0, int slot1, double ix, double iy, double iz, uint4* __restrict__ wire) {
+    const int s = slot0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= slot1) return;
+    const int a = atomOfSlot[s];
+    if (a < 0) return;
+    const double4 p = pos[a];
+    double fx = p.x * ix, fy = p.y * iy, fz = p.z * iz;
+    fx -= floor(fx); fy -= floor(fy); fz -= floor(fz);
+    wire[s] = make_uint4((unsigned) (unsigned long long) (fx * 4294967296.0), (unsigned) (unsigned long long) (fy * 4294967296.0),
+                         (unsigned) (unsigned long long) (fz * 4294967296.0), 0u);
+}
+
 // slot-ordered <-> atom-ordered copies of a double4 array (all-gather buffers of the decomposed run)
 __global__ void k_pack_slots(const double4* __restrict__ src, const int* __restrict__ atomOfSlot, int slot0, int slot1, double4* __restrict__ dst) {
     const int s = slot0 + blockIdx.x * blockDim.x + threadIdx.x;
@@ -197,5 +210,12 @@ extern "C" int ommhip_scale_molecule_centers(int num_molecules, const int* mol_s
 extern "C" int ommhip_posq_with_weights(const void* posq_d, const double* weight_d, const int* atom_of_slot_d, int padded_atoms, void* dst_d, void* stream) {
     hipLaunchKernelGGL(k_posq_with_weights, dim3((padded_atoms + 255) / 256), dim3(256), 0, (hipStream_t) stream,
                        (const float4*) posq_d, weight_d, atom_of_slot_d, padded_atoms, (float4*) dst_d);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_encode_wire(const void* pos_d, const int* atom_of_slot_d, int slot0, int slot1, const double box_len[3], void* wire_d, void* stream) {
+    if (slot1 <= slot0) return 0;
+    hipLaunchKernelGGL(k_encode_wire, dim3((slot1 - slot0 + 255) / 256), dim3(256), 0, (hipStream_t) stream,
+                       (const double4*) pos_d, atom_of_slot_d, slot0, slot1, 1.0 / box_len[0], 1.0 / box_len[1], 1.0 / box_len[2], (uint4*) wire_d);
     return (int) hipGetLastError();
 }

@@ -97,10 +97,10 @@ HipContext::HipContext(const System& system, int deviceIndex, bool hostMode, con
             throw OpenMMException("HIP platform: a Context spread over several GPUs needs a native integrator (Verlet, Langevin, LangevinMiddle) and no host-side state changes (barostat, virtual sites)");
         // every rank gets the same number of slots: its share of the atoms, room to keep the last unit whole, the trailer slot
         const int R = domain.ranks;
-        const int share = (numAtoms + R - 1) / R + maxUnitSize + 1;
+        const int share = (numAtoms + R - 1) / R + maxUnitSize + 2;
         slotsPerRank = ((share + OMMHIP_TILE - 1) / OMMHIP_TILE) * OMMHIP_TILE;
         paddedAtoms = R * slotsPerRank;
-        ownSlot0 = domain.rank * slotsPerRank; ownSlot1 = ownSlot0 + slotsPerRank; trailerSlot = slotsPerRank - 1;
+        ownSlot0 = domain.rank * slotsPerRank; ownSlot1 = ownSlot0 + slotsPerRank; trailerSlot = slotsPerRank - 2;
     }
     masses.resize(numAtoms);
     for (int i = 0; i < numAtoms; i++) masses[i] = system.getParticleMass(i);
@@ -116,6 +116,8 @@ HipContext::HipContext(const System& system, int deviceIndex, bool hostMode, con
     if (decomposed()) {
         // reciprocal space (with its all-to-alls) runs on the side stream beside the pair kernel: it gets a communicator of its own
         if (ommhip_comm_duplicate(domain.comm, &pmeComm) != 0) pmeComm = NULL;
+        posWire.allocate(sizeof(unsigned) * 4 * (size_t) paddedAtoms);
+        HIP_CHECK(ommhip_memset(posWire.ptr, 0, posWire.bytes, stream));
         posSlot.allocate(sizeof(double) * 4 * (size_t) paddedAtoms);
         velSlot.allocate(sizeof(double) * 4 * (size_t) paddedAtoms);
         HIP_CHECK(ommhip_memset(posSlot.ptr, 0, posSlot.bytes, stream));
@@ -176,7 +178,7 @@ void HipContext::uploadPositions(const vector<Vec3>& positions) {
         tmp[i].x = positions[i][0]; tmp[i].y = positions[i][1]; tmp[i].z = positions[i][2]; tmp[i].w = 0;
     }
     if (numAtoms > 0) HIP_CHECK(ommhip_memcpy_h2d(pos.ptr, tmp.data(), sizeof(D4) * numAtoms, stream));
-    if (decomposed()) fillPosSlotFromPos();      // every rank was handed all positions: no communication
+    if (decomposed()) fillWireFromPos();         // every rank was handed all positions: no communication
     sync();
     positionsValid = true;
 }
@@ -366,15 +368,19 @@ double HipContext::sumOverRanks(double v) {
 }
 
 void HipContext::allGatherPositions() {
-    HIP_CHECK(ommhip_comm_all_gather(domain.comm, posSlot.ptr, sizeof(double) * 4 * (size_t) slotsPerRank, stream));
+    HIP_CHECK(ommhip_comm_all_gather(domain.comm, posWire.ptr, sizeof(unsigned) * 4 * (size_t) slotsPerRank, stream));
 }
 
-void HipContext::fillPosSlotFromPos() {
-    HIP_CHECK(ommhip_pack_slots(pos.ptr, atomOfSlot.as<int>(), 0, paddedAtoms, posSlot.ptr, stream));
+void HipContext::fillWireFromPos() {
+    const double len[3] = {box[0], box[2], box[5]};
+    HIP_CHECK(ommhip_encode_wire(pos.ptr, atomOfSlot.as<int>(), 0, paddedAtoms, len, posWire.ptr, stream));
 }
 
 void HipContext::gatherState() {
-    // positions: posSlot is complete after every step's all-gather; bring the atom-ordered copy up to date
+    // positions: the per-step wire records are 32-bit fractions; what leaves the platform (and what a re-sort redistributes) are
+    // the owners' exact doubles -- staged in slot order, all-gathered, scattered back to atom order
+    HIP_CHECK(ommhip_pack_slots(pos.ptr, atomOfSlot.as<int>(), ownSlot0, ownSlot1, posSlot.ptr, stream));
+    HIP_CHECK(ommhip_comm_all_gather(domain.comm, posSlot.ptr, sizeof(double) * 4 * (size_t) slotsPerRank, stream));
     HIP_CHECK(ommhip_unpack_slots(posSlot.ptr, atomOfSlot.as<int>(), 0, paddedAtoms, pos.ptr, stream));
     // velocities: only the owner's are current
     HIP_CHECK(ommhip_pack_slots(vel.ptr, atomOfSlot.as<int>(), ownSlot0, ownSlot1, velSlot.ptr, stream));
@@ -534,7 +540,7 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
         int slot = g * slotsPerRank;
         for (size_t i = 0; i < keyed.size(); i++) {
             const int u = keyed[i].second;
-            if (slot + (unitStart[u + 1] - unitStart[u]) > g * slotsPerRank + trailerSlot)
+            if (slot + (unitStart[u + 1] - unitStart[u]) > g * slotsPerRank + trailerSlot)      // the two trailer records stay free
                 throw OpenMMException("HIP platform: internal error: a rank's slot range overflowed in the domain decomposition");
             for (int j = unitStart[u]; j < unitStart[u + 1]; j++) newAtomOfSlot[slot++] = unitAtomList[j];
             if (g == domain.rank) ownedUnits.push_back(u);
@@ -575,7 +581,7 @@ bool HipContext::reorderIfNeeded() {
     HIP_CHECK(ommhip_memcpy_h2d(wrap.ptr, wrapHost.data(), sizeof(int) * wrapHost.size(), stream));
     HIP_CHECK(ommhip_memcpy_h2d(atomOfSlot.ptr, hostAtomOfSlot.data(), sizeof(int) * paddedAtoms, stream));
     HIP_CHECK(ommhip_memcpy_h2d(slotOfAtom.ptr, hostSlotOfAtom.data(), sizeof(int) * numAtoms, stream));
-    if (decomposed()) fillPosSlotFromPos();
+    if (decomposed()) fillWireFromPos();
     sync();
     // wrap offsets may have changed even when the order did not: listeners rebuild their slot data either way
     for (size_t i = 0; i < listeners.size(); i++) listeners[i]->atomsReordered();

@@ -130,21 +130,22 @@ public:
     void removeListener(HipContextListener* l);
 
     // ---- domain decomposition (ranks > 1): this rank owns the slots [ownSlot0, ownSlot1) -- a slab of the box along x --
-    //      integrates the atoms in them and computes the forces on them; positions of ALL atoms are replicated through posSlot
-    //      (double4, slot order), which the ranks all-gather in place after every integration step.  The last slot of each
-    //      rank's range (trailerSlot) never holds an atom: it carries the rank's momentum through the same all-gather.
+    //      integrates the atoms in them and computes the forces on them; positions of ALL atoms are replicated through posWire
+    //      (uint4, slot order: 32-bit fixed-point fractions of the box edges, 16 bytes per atom), which the ranks all-gather in
+    //      place after every integration step.  The last two records of each rank's range (trailerSlot, trailerSlot + 1) never
+    //      hold an atom: they carry the rank's momentum (three doubles) through the same all-gather.
     HipDomain domain;
     int slotsPerRank, ownSlot0, ownSlot1, trailerSlot;
     bool decomposed() const { return domain.comm != NULL; }      // also with ONE rank when a communicator was given (single-GPU test of the whole path)
-    DeviceBuffer posSlot, velSlot;
+    DeviceBuffer posWire, posSlot, velSlot;      // posSlot / velSlot: double4 staging of exact positions / velocities for downloads and re-sorts
     /** Communicator of the reciprocal-space stream (a duplicate of domain.comm; NULL = share domain.comm, single stream). */
     ommhip_comm* pmeComm = NULL;
-    /** Enqueue the all-gather of posSlot on the main stream (after the integration kernel wrote this rank's part). */
+    /** Enqueue the all-gather of posWire on the main stream (after the integration kernel wrote this rank's part). */
     void allGatherPositions();
     /** Make pos[] and vel[] (atom order) complete and current on this rank: before a re-sort and before downloads. */
     void gatherState();
-    /** posSlot[s] = pos[atomOfSlot[s]] for every slot: after an upload of all positions or a re-sort (no communication). */
-    void fillPosSlotFromPos();
+    /** Wire records of every slot from pos[]: after an upload of all positions or a re-sort (every rank holds them all; no communication). */
+    void fillWireFromPos();
     /** Sum of one double over the ranks, the same bits everywhere (host all-gather + fixed-order sum). */
     double sumOverRanks(double v);
     /** Integration units (constraint-connected groups of atoms): CSR over units in atom-index order of their first atom. */

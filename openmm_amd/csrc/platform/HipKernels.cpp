@@ -247,9 +247,10 @@ void HipConstraints::fusedStep(int integrator, const ommhip_integrator_state& st
     u.remove_cm = hip.cmRemovalPending && hip.momentumValid ? 1 : 0;
     u.inv_total_mass = totalMass > 0 ? 1.0 / totalMass : 0.0;
     u.cm_scratch = cmScratch.as<double>();
-    u.pos_slot = NULL; u.ranks = 1; u.rank = 0; u.slots_per_rank = 0; u.trailer_slot = 0;
+    u.pos_wire = NULL; u.ranks = 1; u.rank = 0; u.slots_per_rank = 0; u.trailer_slot = 0;
+    u.box_len[0] = hip.box[0]; u.box_len[1] = hip.box[2]; u.box_len[2] = hip.box[5];
     if (hip.decomposed()) {
-        u.pos_slot = hip.posSlot.ptr; u.ranks = hip.domain.ranks; u.rank = hip.domain.rank;
+        u.pos_wire = hip.posWire.ptr; u.ranks = hip.domain.ranks; u.rank = hip.domain.rank;
         u.slots_per_rank = hip.slotsPerRank; u.trailer_slot = hip.trailerSlot;
     }
     HIP_CHECK(ommhip_integrate_fused(integrator, &state, &u, hip.stream));
@@ -443,7 +444,7 @@ void HipApplyConstraintsKernel::apply(ContextImpl& context, double tol) {
     HIP_CHECK(ommhip_memcpy_d2d(hip.xp.ptr, hip.pos.ptr, hip.pos.bytes, hip.stream));
     constraints.apply(hip.xp.ptr, tol);
     HIP_CHECK(ommhip_memcpy_d2d(hip.pos.ptr, hip.xp.ptr, hip.pos.bytes, hip.stream));
-    if (hip.decomposed()) hip.fillPosSlotFromPos();
+    if (hip.decomposed()) hip.fillWireFromPos();
 }
 void HipApplyConstraintsKernel::applyToVelocities(ContextImpl& context, double tol) {
     HipContext& hip = *data.hip;
@@ -567,7 +568,7 @@ double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool
     nl.pbc = 1;
     nl.dd_mode = 1;
     nl.first_block = hip.ownSlot0 / OMMHIP_TILE; nl.owned_blocks = hip.slotsPerRank / OMMHIP_TILE;
-    nl.pos_slot = hip.posSlot.ptr; nl.pos_scatter = hip.pos.ptr;
+    nl.pos_wire = hip.posWire.ptr; nl.pos_scatter = hip.pos.ptr;
     foldExclusions = numExclusionPairs > 0;
     checkDecomposedFlags();
     if (nl.max_chunks == 0) allocateNeighborList((int) (estimateChunks() * 1.4 / hip.domain.ranks) + 256);

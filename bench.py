@@ -19,7 +19,12 @@ of the strong-scaling curve.
 N > 1 (BASELINE.json configs[3]): ONE 985 527-atom TIP3P box (21.4 nm, PME grid 192^3) domain-decomposed over the N GPUs
 (x slabs, positions all-gathered over RCCL every step, slab FFT with two all-to-alls) -- "scaling": "strong",
 `value` = ns/day of that one simulation.  (A 23 558-atom system does not shard usefully over 8 GPUs: its halo is several
-times its slab.)  --workload overrides either default.
+times its slab.)  --workload overrides either default.  The line also carries `single_gpu_same_box`: rank 0 runs the same box
+on its GPU alone after the timed region (the other ranks wait), so every N > 1 line holds its own N = 1 reference.
+The process torch.distributed.run starts on each rank is only a launcher: the measurement runs in a child process
+(multirank.run_attempts), first with RCCL and reciprocal space on its own stream + communicator, then -- only if that
+attempt fails or never returns on some rank -- with RCCL on a single stream, and last with host-staged gloo collectives; the
+configuration that ran is named in config.workload and the failed attempts are listed in config.attempts_failed.
 
 Rank 0 prints ONE JSON line with the contract fields plus `roofline` (the direct-space pair kernel -- on the fused
 single-stream path the three launches it shares with the FFT stages -- HIP events on the stream the kernels run on),
@@ -40,7 +45,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 KERNEL_SOURCES = ("nonbonded.hip", "force_front.hip", "pme.hip", "neighbor.hip", "common.h")
-WORKLOADS = ["dhfr", "dhfr_like", "water24k", "water98k", "apoa1", "water1m"]
+WORKLOADS = ["dhfr", "dhfr_like", "water1k", "water24k", "water98k", "apoa1", "water1m"]
+EMULATED = os.environ.get("BENCH_EMULATED") == "1"     # tests only: the CPU SIMT emulator build of the plugin (tests/emu), to run the N > 1 flow without a GPU
 
 
 def parse_args():
@@ -58,7 +64,35 @@ def parse_args():
     p.add_argument("--profile-every", type=int, default=7, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region")
     p.add_argument("--decompose", action="store_true", help="N = 1: run through the decomposed path with a one-rank RCCL communicator (overhead check on one GPU)")
     p.add_argument("--props", default="", help="extra HIP platform properties, e.g. DisablePmeStream=true")
+    p.add_argument("--attempt-timeout", type=float, default=420.0, help="N > 1: seconds a configuration may take before the launchers give up on it")
     return p.parse_args()
+
+
+def supervise(args, rank, world):
+    """N > 1, the process torch.distributed.run started: run the measurement in a child and fall back together (see the module text)."""
+    from openmm_amd import multirank as MR
+    base = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    extra = [kv for kv in args.props.split(",") if kv]
+    attempts = []
+    if args.transport == "rccl":
+        attempts.append(base + ["--transport", "rccl"])
+        if not any(kv.startswith("DisablePmeStream=") for kv in extra):
+            attempts.append(base + ["--transport", "rccl", "--props", ",".join(extra + ["DisablePmeStream=true"])])
+    attempts.append(base + ["--transport", "gloo"])
+    say = lambda msg: print("bench.py launcher (rank %d): %s" % (rank, msg), file=sys.stderr, flush=True)
+    idx, lines, notes = MR.run_attempts(attempts, rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")),
+                                        args.attempt_timeout, log=say if rank == 0 else None)
+    if rank != 0:
+        return
+    result = [l for l in lines if l.startswith("{")]
+    if not result:
+        raise RuntimeError("the measurement finished without a result line")
+    out = json.loads(result[-1])
+    out["config"]["attempts_failed"] = notes
+    for l in lines:
+        if not l.startswith("{"):
+            print(l)
+    print(json.dumps(out), flush=True)
 
 
 def make_workload(name, seed):
@@ -67,6 +101,8 @@ def make_workload(name, seed):
         return T.dhfr()                          # the real benchmark System (5dfr_solv-cube_equil.pdb, amber99sb + tip3p)
     if name == "dhfr_like":
         return T.dhfr_like(seed=seed)            # round-1 stand-in: same size, synthetic chain
+    if name == "water1k":
+        return T.water_box(8, seed=seed)         # 1536 atoms: flow tests on the emulator
     if name == "water24k":
         return T.water_box(20, seed=seed)
     if name == "apoa1":
@@ -125,27 +161,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and os.environ.get("BENCH_CHILD") != "1":
+        return supervise(args, rank, world)
     dist = None
-    gloo_group = None
     if world > 1:
+        # control plane (communicator id, barriers, the MAX of the timings): gloo.  The data path is the plugin's own RCCL
+        # communicator(s); keeping torch's NCCL process group out of the process leaves one RCCL user per GPU.
         import torch
         import torch.distributed as dist
-        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")      # "gloo" only to rehearse the N > 1 flow on a 1-GPU box
         ndev = torch.cuda.device_count()
-        if backend == "nccl":
-            if local_rank >= ndev:
+        if local_rank >= ndev and not EMULATED:
+            if args.transport != "gloo":
                 raise RuntimeError("rank %d has no GPU (%d visible)" % (local_rank, ndev))
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            local_rank = local_rank % max(ndev, 1)       # rehearsal of the N > 1 flow on a box with fewer GPUs (host-staged transport only)
+        if EMULATED:
+            local_rank = 0
         else:
-            local_rank = local_rank % max(ndev, 1)
-            dist.init_process_group(backend=backend)
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="gloo")
 
     import numpy as np
     from openmm_amd import capi, harness as H, multirank as MR
-    H.load_hip_platform()
-    kernels = capi.load()
-    plugin = C.CDLL(os.path.join(H.LIB_DIR, "libOpenMMHIP.so"))
+    H.load_hip_platform(emulated=EMULATED)
+    kernels = capi.load(os.path.join(H.EMU_DIR, "libopenmm_hip_kernels.so")) if EMULATED else capi.load()
+    plugin = C.CDLL(os.path.join(H.EMU_DIR if EMULATED else H.LIB_DIR, "libOpenMMHIP.so"))
 
     workload = args.workload if args.workload != "auto" else ("dhfr" if world == 1 else "water1m")
     decomposed = world > 1
@@ -161,46 +200,22 @@ def main():
         props.update({"Ranks": "1", "Rank": "0", "CommId": MR.new_rccl_id()})
     if decomposed:
         # ONE box over all ranks.  The plugin runs its own collectives (RCCL); the launcher only distributes the communicator id.
+        # a failure here (or a collective that never returns) ends this child; the launchers then move to the next configuration
         transport = args.transport
-        if transport == "gloo" and dist.get_backend() != "gloo":
-            gloo_group = dist.new_group(backend="gloo")
-        try:
-            dd = MR.domain_properties(dist, transport=transport, group=gloo_group if transport == "gloo" else None)
-        except Exception as e:
-            raise RuntimeError("could not set up the %s transport: %s" % (transport, e))
-        props.update(dd)
-    failure = None
-    try:
-        system, nb, integ, ctx = start_platform(w, "HIP", dt_ps, args.warmup, props, seed=1, prepare=prepare)
-    except Exception as e:
-        if not decomposed:
-            raise
-        failure = e
-    if decomposed:
-        # every rank must take the same path: agree on whether the RCCL start-up worked anywhere it was tried
-        import torch
-        flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()) != 0:
-            if args.transport == "gloo":
-                raise failure if failure is not None else RuntimeError("another rank failed to start")
-            if rank == 0:
-                print("bench.py: RCCL transport failed to start (%s); falling back to host-staged gloo collectives" % failure, file=sys.stderr, flush=True)
-            if failure is None:
-                ctx.close()
-            gloo_group = dist.new_group(backend="gloo")
-            props.update(MR.domain_properties(dist, transport="gloo", group=gloo_group))
-            system, nb, integ, ctx = start_platform(w, "HIP", dt_ps, args.warmup, props, seed=1, prepare=prepare)
+        props.update(MR.domain_properties(dist, transport=transport, emulated=EMULATED))
+    system, nb, integ, ctx = start_platform(w, "HIP", dt_ps, args.warmup, props, seed=1, prepare=prepare)
     device_name = ctx.getPlatformProperty("DeviceName")
     if decomposed:
         transport = ctx.getPlatformProperty("CommId")       # what the plugin actually uses
+        if ctx.getPlatformProperty("DisablePmeStream") == "true":
+            transport += ", single stream"
 
     def barrier():
         if dist is not None:
             import torch
-            torch.cuda.synchronize()
+            if not EMULATED:
+                torch.cuda.synchronize()
             dist.barrier()
-    on_gpu = dist is None or dist.get_backend() == "nccl"
 
     profile = not args.no_roofline
     if profile:
@@ -209,7 +224,7 @@ def main():
     elapsed, st = timed_run(integ, ctx, args.steps, barrier)
     if profile:
         kernels.lib.ommhip_profile_enable(0)
-    elapsed = MR.max_over_ranks(elapsed, dist, device="cuda" if on_gpu else "cpu")
+    elapsed = MR.max_over_ranks(elapsed, dist, device="cpu")
     if not np.isfinite(st.potentialEnergy):
         raise RuntimeError("simulation blew up: potential energy is not finite")
 
@@ -336,6 +351,20 @@ def main():
             except Exception as e:
                 out["force_parity"] = {"max_rel_err_vs_reference": None, "error": str(e)}
     ctx.close()
+
+    # ---- N > 1: the same box on rank 0's GPU alone, in the same job (the other ranks wait at the barrier below)
+    if decomposed and rank == 0 and not args.no_scale_workload:
+        try:
+            ssys, snb, sinteg, sctx = start_platform(w, "HIP", dt_ps, args.warmup, {"DeviceIndex": str(local_rank)}, seed=1, prepare=prepare)
+            s_elapsed, s_st = timed_run(sinteg, sctx, args.steps, lambda: None)
+            out["single_gpu_same_box"] = {"value": round(MR.ns_per_day(s_elapsed, args.steps, args.dt_fs), 3), "unit": "ns/day",
+                                          "ms_per_step": round(1e3 * s_elapsed / args.steps, 5), "steps": args.steps, "warmup": args.warmup,
+                                          "prepare_steps": prepare, "note": "same System, same protocol, rank 0's GPU alone, measured after the decomposed run"}
+            sctx.close()
+        except Exception as e:
+            out["single_gpu_same_box"] = {"value": None, "error": str(e)}
+    if dist is not None:
+        dist.barrier()
 
     # ---- N = 1: the single-GPU point of the strong-scaling curve (same workload, same protocol as the N > 1 runs)
     if world == 1 and workload == "dhfr" and not args.no_scale_workload:

@@ -13,9 +13,17 @@ callback that performs the all-gather with torch.distributed (gloo); for tests o
 by several ranks (RCCL refuses two ranks on one device).
 
 `max_over_ranks()` is the timing reduction of bench.py (the slowest rank decides the step time).
+
+`run_attempts()` is the launcher's safety net: each rank's launcher process runs the actual work in a child process and the
+launchers agree, through a TCPStore of their own, whether an attempt worked on every rank.  A collective that never returns
+on some rank (a stuck GPU queue cannot be recovered from inside the process) is ended by killing exactly that child, and all
+ranks move on to the next configuration together instead of hanging the node.
 """
 import ctypes as C
 import os
+import subprocess
+import threading
+import time
 
 _KEEP_ALIVE = []      # ctypes callbacks must outlive the Contexts that hold their address
 
@@ -94,3 +102,59 @@ def max_over_ranks(elapsed_s, dist=None, device="cuda"):
 
 def ns_per_day(elapsed_s, steps, dt_fs):
     return dt_fs * 1e-6 * steps / elapsed_s * 86400.0
+
+
+STORE_PORT_OFFSET = 17      # the launchers' own store; children rendezvous on MASTER_PORT + 1 + attempt
+
+
+def run_attempts(commands, rank, world, master_addr, master_port, timeout_s, env=None, poll_s=0.2, log=None):
+    """Run commands[0] as a child process on every rank; if it fails, hangs past `timeout_s` or fails on ANY other rank, kill
+    this rank's child (its exact pid) and try commands[1], and so on.  Children get MASTER_PORT = master_port + 1 + attempt and
+    BENCH_ATTEMPT = attempt in their environment.  -> (attempt index, stdout lines of this rank's child, [failure notes]);
+    raises RuntimeError when every command failed."""
+    from datetime import timedelta
+    import torch.distributed as dist
+    store = dist.TCPStore(master_addr, master_port + STORE_PORT_OFFSET, world, is_master=(rank == 0), timeout=timedelta(seconds=timeout_s + 120),
+                          wait_for_workers=True)
+    notes = []
+    for i, cmd in enumerate(commands):
+        child_env = dict(os.environ if env is None else env)
+        # torch.distributed.run tells its workers to rendezvous through the agent's own store; the children form a group of their own
+        child_env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        child_env.update({"MASTER_ADDR": master_addr, "MASTER_PORT": str(master_port + 1 + i), "BENCH_ATTEMPT": str(i), "BENCH_CHILD": "1"})
+        proc = subprocess.Popen(cmd, env=child_env, stdout=subprocess.PIPE, text=True)
+        lines = []
+        reader = threading.Thread(target=lambda: lines.extend(l.rstrip("\n") for l in proc.stdout), daemon=True)
+        reader.start()
+        deadline = time.monotonic() + timeout_s
+        why = None
+        while proc.poll() is None:
+            if store.add("fail%d" % i, 0) > 0:
+                why = "another rank's attempt failed"
+            elif time.monotonic() > deadline:
+                why = "no result after %.0f s" % timeout_s
+            if why is not None:
+                proc.kill()
+                break
+            time.sleep(poll_s)
+        proc.wait()
+        reader.join(5.0)
+        if why is None and proc.returncode != 0:
+            why = "exit code %d" % proc.returncode
+        if why is not None:
+            store.add("fail%d" % i, 1)
+        store.add("done%d" % i, 1)
+        wait_until = time.monotonic() + timeout_s + 60
+        while store.add("done%d" % i, 0) < world and time.monotonic() < wait_until:
+            time.sleep(poll_s)
+        failed = store.add("fail%d" % i, 0) > 0
+        if not failed or i == len(commands) - 1:
+            store.add("left", 1)
+            while rank == 0 and store.add("left", 0) < world and time.monotonic() < wait_until:      # the store lives in rank 0
+                time.sleep(poll_s)
+        if not failed:
+            return i, lines, notes
+        notes.append("attempt %d (%s): %s" % (i, " ".join(cmd[-4:]), why or "failed on another rank"))
+        if log is not None:
+            log(notes[-1])
+    raise RuntimeError("every configuration failed: " + "; ".join(notes))

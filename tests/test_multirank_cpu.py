@@ -182,3 +182,56 @@ def test_four_rank_domain_decomposition_on_emulator(tmp_path):
     if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
         pytest.skip("emulated plugin not built (run __graft_entry__.build())")
     _run_dd_child(tmp_path, True, None, 3, 29557, nproc=4, cases='(("water, 4 ranks", T.water_box(8, seed=5), 24),)')
+
+
+LAUNCHER = r"""
+import json, os, sys, time
+sys.path.insert(0, %r)
+from openmm_amd import multirank as MR
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+hang = "import os, sys, time\nif os.environ['RANK'] == '1': time.sleep(600)\nprint('{\"attempt\": 0}')"
+crash = "import os, sys\nif os.environ['RANK'] == '0': sys.exit(3)\nimport time; time.sleep(600)"
+good = ("import os, torch, torch.distributed as dist\ndist.init_process_group('gloo')\nt = torch.ones(1); dist.all_reduce(t)\n"
+        "print('note'); print('{\"attempt\": %%s, \"port\": %%s, \"sum\": %%d}' %% (os.environ['BENCH_ATTEMPT'], os.environ['MASTER_PORT'], int(t.item())))")
+t0 = time.monotonic()
+idx, lines, notes = MR.run_attempts([[sys.executable, "-c", hang], [sys.executable, "-c", crash], [sys.executable, "-c", good]],
+                                    rank, world, "127.0.0.1", int(os.environ["MASTER_PORT"]), timeout_s=8.0)
+took = time.monotonic() - t0
+out = json.loads([l for l in lines if l.startswith("{")][-1])
+assert idx == 2 and out["attempt"] == 2 and out["port"] == int(os.environ["MASTER_PORT"]) + 3 and out["sum"] == world, (idx, out)
+assert len(notes) == 2 and took < 30.0, (notes, took)
+print("RANK", rank, "OK", notes, flush=True)
+"""
+
+
+def test_launchers_agree_on_a_fallback_when_one_rank_hangs_or_crashes(tmp_path):
+    """bench.py's N > 1 safety net: attempt 0 never returns on rank 1 (killed after the timeout, and rank 0's successful child
+    does not count), attempt 1 crashes on rank 0 (rank 1's hanging child is killed at once), attempt 2 works on both: its
+    children form their own gloo group.  Started the way the driver starts bench.py (torch.distributed.run)."""
+    script = tmp_path / "launcher.py"
+    script.write_text(LAUNCHER % ROOT)
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
+                          capture_output=True, text=True, timeout=240)
+    assert proc.returncode == 0 and "RANK 0 OK" in proc.stdout and "RANK 1 OK" in proc.stdout, proc.stdout + proc.stderr
+
+
+def test_bench_multi_gpu_flow_on_emulator_falls_back_and_reports_one_line():
+    """`bench.py --gpus 2` as the driver starts it, on the CPU emulator build: RCCL cannot start here, so both RCCL
+    configurations fail on every rank, the launchers move to host-staged gloo together, and rank 0 prints ONE JSON line last:
+    strong scaling of one box, with the failed attempts listed and the single-GPU time of the same box beside it."""
+    import json
+    import pytest
+    from conftest import EMU_BUILD
+    if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
+        pytest.skip("emulator build missing")
+    env = dict(os.environ, BENCH_EMULATED="1")
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29671", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                           "--workload", "water1k", "--cpu-steps", "0", "--no-roofline", "--prepare-steps", "0", "--attempt-timeout", "200"],
+                          capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    out = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 3 and out["value"] > 0
+    assert "callback" in out["config"]["workload"] and len(out["config"]["attempts_failed"]) == 2
+    assert out["single_gpu_same_box"]["value"] > 0

@@ -23,12 +23,26 @@ using namespace omm;
 
 namespace {
 
+#ifndef NL_THREADS
 #define NL_THREADS 256
-#define NL_WAVES 4
-#define NL_LIST 4096          // staged (j, mask) entries
-#define NL_FLUSH 2048         // flush full rows once this many entries are staged
-#define NL_CAND 2048          // candidate blocks per window
-#define NL_ROUND 8            // passes a wavefront runs between two workgroup-wide flush checks (4 x 8 x 64 <= NL_LIST - NL_FLUSH)
+#endif
+#define NL_WAVES (NL_THREADS / 64)
+#ifndef NL_LIST
+#define NL_LIST 2048          // staged (j, mask) entries
+#endif
+#ifndef NL_FLUSH
+#define NL_FLUSH 1024         // flush full rows once this many entries are staged
+#endif
+#ifndef NL_CAND
+#define NL_CAND 1024          // candidate blocks per window
+#endif
+#ifndef NL_ROUND
+#define NL_ROUND 4            // passes a wavefront runs between two workgroup-wide flush checks (NL_WAVES x NL_ROUND x 64 <= NL_LIST - NL_FLUSH)
+#endif
+#ifndef NL_BIG_HALF
+#define NL_BIG_HALF 1.0       // blocks with a half extent above this fraction of the list cutoff are not binned
+#endif
+static_assert(NL_WAVES * NL_ROUND * 64 <= NL_LIST - NL_FLUSH, "a round of passes must fit behind the flush threshold");
 
 struct NlArgs {
     int numAtoms, paddedAtoms, numBlocks, maxChunks;
@@ -232,7 +246,8 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
     const float R2 = a.listCutoff2;
     const float Rlist = sqrtf(R2);
     const long long tStart = clock64();      // builder cost per i-block, kept in posqRef[..].w for diagnostics
-    int candTotal = 0;
+    int candTotal = 0, entryTotal = 0;
+    long long tPhase1 = tStart, tFlush = 0, tSetup = tStart, tRanges = tStart, tEntries = tStart;
 
     // atom (lane & 31) of X in every lane; broadcast later with v_readlane
     const float4 px = a.posq[X * OMM_TILE + (lane & 31)];
@@ -256,9 +271,11 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
     const bool singleImage = PBC == 0 || (PBC == 1 && hX.x + Rlist < 0.5f * a.box.ax && hX.y + Rlist < 0.5f * a.box.by && hX.z + Rlist < 0.5f * a.box.cz);
     if (t < OMM_TILE) { sh.ix[t] = rx; sh.iy[t] = ry; sh.iz[t] = rz; }
     __syncthreads();
+    tSetup = clock64();
 
     // Writes staged entries as rows.  final = false: only full rows, the remainder stays staged.
     auto flush = [&](bool final) {
+        const long long tf0 = clock64();
         const int total = sListCount;
         const int nRows = final ? (total + OMM_ROW - 1) / OMM_ROW : total / OMM_ROW;
         const int nChunks = (nRows + OMM_CHUNK_ROWS - 1) / OMM_CHUNK_ROWS;
@@ -297,6 +314,8 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
         if (t < rem) { listJ[t] = tj; listM[t] = tm; }
         if (t == 0) sListCount = rem;
         __syncthreads();
+        entryTotal += total - rem;
+        tFlush += clock64() - tf0;
     };
 
     // Block-level test of one candidate Y against X's bounding box.
@@ -329,35 +348,94 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
         const int n[3] = {a.ncx, a.ncy, a.ncz};
         const float inv[3] = {a.cellInvX, a.cellInvY, a.cellInvZ};
         const float c3[3] = {cX.x, cX.y, cX.z}, h3[3] = {hX.x, hX.y, hX.z};
+        // A binned block Y lies inside its centre's cell grown by the largest binned half extent (cellMeta), so X can only
+        // reach it if X's box comes within Rlist of that grown cell.  Work in unwrapped cell coordinates around X's centre:
+        // per axis the cells whose grown extent is within Rlist of X's box, clamped to one period.
         int lo[3], cnt[3];
+        float grow[3];          // hX + hmax + half a cell, per axis (nm)
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-            const int reach = (int) ceilf((Rlist + h3[d] + a.cellMeta[d]) * inv[d]) + 1;    // +1: centres are binned, not boxes
-            const int cc = cell_coord(c3[d], inv[d], n[d]);
-            if (2 * reach + 1 >= n[d]) { lo[d] = 0; cnt[d] = n[d]; }
-            else { lo[d] = cc - reach; cnt[d] = 2 * reach + 1; }
+            grow[d] = h3[d] + a.cellMeta[d] + 0.5f / inv[d];
+            const float u = c3[d] * inv[d] - 0.5f, w = (Rlist + grow[d]) * inv[d] + 0.01f;     // cell k qualifies if |k - u| <= w
+            lo[d] = (int) ceilf(u - w);
+            cnt[d] = (int) floorf(u + w) - lo[d] + 1;
+            if (cnt[d] >= n[d]) { lo[d] = 0; cnt[d] = n[d]; }
         }
-        // One thread per cell of the region (a few cells each): the two levels of loads (cell range, then the boxes of
-        // its blocks, stored in cell order) are independent across cells, so they overlap instead of chaining.
-        const int regionCells = cnt[0] * cnt[1] * cnt[2];
-        for (int rc = t; rc < regionCells; rc += NL_THREADS) {
-            int x = lo[0] + rc / (cnt[1] * cnt[2]), y = lo[1] + (rc / cnt[2]) % cnt[1], z = lo[2] + rc % cnt[2];
-            x = (x % n[0] + n[0]) % n[0]; y = (y % n[1] + n[1]) % n[1]; z = (z % n[2] + n[2]) % n[2];
-            const int cell = (x * n[1] + y) * n[2] + z;
-            const int e0 = a.cellStart[cell], e1 = a.cellStart[cell + 1];
-            for (int e = e0; e < e1; e++) {
-                const int Y = a.cellBlocks[e];
-                const float4 cY = a.cellBoxes[2 * e], hY = a.cellBoxes[2 * e + 1];
-                float dx = cY.x - cX.x, dy = cY.y - cX.y, dz = cY.z - cX.z;
-                apply_pbc<PBC>(dx, dy, dz, a.box);
-                dx = fmaxf(0.f, fabsf(dx) - hX.x - hY.x);
-                dy = fmaxf(0.f, fabsf(dy) - hX.y - hY.y);
-                dz = fmaxf(0.f, fabsf(dz) - hX.z - hY.z);
-                if ((Y >= X || (a.ddMode && Y < a.firstBlock)) && !(dx * dx + dy * dy + dz * dz >= R2)) {
-                    const int pos = atomicAdd(&sCandCount, 1);
-                    if (pos < NL_CAND) candY[pos] = Y; else sCandOverflow = 1;
+        // One thread per (x, y) column of the region: the cells of a column are consecutive in the cell-sorted block list, so
+        // a column is one range of entries (two when it wraps around the box).  The z extent of each column is cut to what
+        // the x/y gap leaves of Rlist.  Entries are first expanded into an LDS list (listJ is free during phase 1), then
+        // tested by all threads in parallel: three dependent memory round trips per workgroup instead of two per cell.
+        int* const entryList = listJ;
+        int& sEntryCount = sh.listCount;          // phase 2 starts from zero again
+        auto testEntry = [&](int e) {
+            const int Y = a.cellBlocks[e];
+            const float4 cY = a.cellBoxes[2 * e], hY = a.cellBoxes[2 * e + 1];
+            float dx = cY.x - cX.x, dy = cY.y - cX.y, dz = cY.z - cX.z;
+            apply_pbc<PBC>(dx, dy, dz, a.box);
+            dx = fmaxf(0.f, fabsf(dx) - hX.x - hY.x);
+            dy = fmaxf(0.f, fabsf(dy) - hX.y - hY.y);
+            dz = fmaxf(0.f, fabsf(dz) - hX.z - hY.z);
+            if ((Y >= X || (a.ddMode && Y < a.firstBlock)) && !(dx * dx + dy * dy + dz * dz >= R2)) {
+                const int pos = atomicAdd(&sCandCount, 1);
+                if (pos < NL_CAND) candY[pos] = Y; else sCandOverflow = 1;
+            }
+        };
+        const int numCols = cnt[0] * cnt[1];
+        for (int col0 = 0; col0 < numCols; col0 += NL_THREADS) {
+            const int col = col0 + t;
+            int r0[2] = {0, 0}, r1[2] = {0, 0};          // entry ranges of this thread's column
+            if (col < numCols) {
+                const int kx = lo[0] + col / cnt[1], ky = lo[1] + col % cnt[1];
+                // distance of the column's centre line from X's centre, nearest image (a span of the whole period starts at cell 0,
+                // wherever X is)
+                float ddx = (kx + 0.5f) / inv[0] - c3[0], ddy = (ky + 0.5f) / inv[1] - c3[1];
+                ddx -= (n[0] / inv[0]) * rintf(ddx * inv[0] / n[0]);
+                ddy -= (n[1] / inv[1]) * rintf(ddy * inv[1] / n[1]);
+                const float gx = fmaxf(0.f, fabsf(ddx) - grow[0]);
+                const float gy = fmaxf(0.f, fabsf(ddy) - grow[1]);
+                const float rem = R2 - gx * gx - gy * gy;
+                if (rem > 0.f) {
+                    int zlo = lo[2], zn = cnt[2];
+                    if (cnt[2] < n[2]) {
+                        const float u = c3[2] * inv[2] - 0.5f, w = (sqrtf(rem) + grow[2]) * inv[2] + 0.01f;
+                        zlo = max(lo[2], (int) ceilf(u - w));
+                        zn = min(lo[2] + cnt[2] - 1, (int) floorf(u + w)) - zlo + 1;
+                    }
+                    if (zn > 0) {
+                        const int xw = ((kx % n[0]) + n[0]) % n[0], yw = ((ky % n[1]) + n[1]) % n[1];
+                        const int base = (xw * n[1] + yw) * n[2];
+                        const int z0 = ((zlo % n[2]) + n[2]) % n[2];
+                        const int first = min(zn, n[2] - z0);          // cells before the wrap
+                        r0[0] = a.cellStart[base + z0]; r1[0] = a.cellStart[base + z0 + first];
+                        if (first < zn) { r0[1] = a.cellStart[base]; r1[1] = a.cellStart[base + zn - first]; }
+                    }
                 }
             }
+            const int len = (r1[0] - r0[0]) + (r1[1] - r0[1]);
+            int slot = 0;
+            if (len > 0) slot = atomicAdd(&sEntryCount, len);
+            if (len > 0 && slot + len <= NL_LIST) {
+                for (int e = r0[0]; e < r1[0]; e++) entryList[slot++] = e;
+                for (int e = r0[1]; e < r1[1]; e++) entryList[slot++] = e;
+            }
+            else if (len > 0) {
+                // more entries than the staging list holds (an oversized X reaching across the box): this thread's share one by
+                // one, and the part of the list its range would have covered is marked empty
+                for (int i = slot; i < NL_LIST; i++) entryList[i] = -1;
+                for (int e = r0[0]; e < r1[0]; e++) testEntry(e);
+                for (int e = r0[1]; e < r1[1]; e++) testEntry(e);
+            }
+            __syncthreads();
+            tRanges = clock64();
+            const int numEntries = min(sEntryCount, NL_LIST);
+            for (int i = t; i < numEntries; i += NL_THREADS) {
+                const int e = entryList[i];
+                if (e >= 0) testEntry(e);
+            }
+            __syncthreads();
+            tEntries = clock64();
+            if (t == 0) sEntryCount = 0;
+            __syncthreads();
         }
         // the oversized blocks, tested by everybody
         const int numBig = __float_as_int(a.cellMeta[3]);
@@ -369,6 +447,7 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
             }
         }
         __syncthreads();
+        tPhase1 = clock64();
         if (sCandOverflow == 0) cellDone = true;
         else { __syncthreads(); if (t == 0) { sCandCount = 0; sCandOverflow = 0; } __syncthreads(); }   // absurdly fat block: scan everything
     }
@@ -501,6 +580,12 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
     if (t == 0) {
         a.posqRef[X * OMM_TILE].w = (float) (clock64() - tStart);
         a.posqRef[X * OMM_TILE + 1].w = (float) candTotal;
+        a.posqRef[X * OMM_TILE + 2].w = (float) (tPhase1 - tStart);
+        a.posqRef[X * OMM_TILE + 3].w = (float) tFlush;
+        a.posqRef[X * OMM_TILE + 4].w = (float) entryTotal;
+        a.posqRef[X * OMM_TILE + 5].w = (float) (tSetup - tStart);
+        a.posqRef[X * OMM_TILE + 6].w = (float) (tRanges - tStart);
+        a.posqRef[X * OMM_TILE + 7].w = (float) (tEntries - tStart);
         __threadfence();
         const int done = atomicAdd(&a.state[ST_BLOCKS_DONE], 1);
         if (done == numWorkgroups - 1) {
@@ -655,7 +740,7 @@ NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
             n[big]--;
         }
         a.cellMode = 1; a.ncx = n[0]; a.ncy = n[1]; a.ncz = n[2];
-        a.bigHalf = (float) (0.6 * rl);
+        a.bigHalf = (float) (NL_BIG_HALF * rl);
         a.cellInvX = (float) (n[0] / L[0]); a.cellInvY = (float) (n[1] / L[1]); a.cellInvZ = (float) (n[2] / L[2]);
     }
     return a;

@@ -485,6 +485,39 @@ extern "C" __attribute__((visibility("default"))) int ommhip_plugin_nl_block_cos
     try { return liveNonbondedKernels.back()->getBlockCosts(ticks, candidates, maxBlocks); } catch (...) { return -2; }
 }
 
+extern "C" __attribute__((visibility("default"))) int ommhip_plugin_nl_block_diag(float* out, int columns, int maxBlocks) {
+    // per i-block diagnostics of the last list build, `columns` (<= 8) floats each: builder ticks, candidate blocks, ticks until the
+    // candidates were collected, ticks inside flushes, entries written
+    if (liveNonbondedKernels.empty()) return -1;
+    try { return liveNonbondedKernels.back()->getBlockDiag(out, columns, maxBlocks); } catch (...) { return -2; }
+}
+
+extern "C" __attribute__((visibility("default"))) int ommhip_plugin_nl_block_halves(float* out, int maxBlocks) {
+    // half extents (x, y, z, flag) of the i-blocks' bounding boxes at the last evaluation
+    if (liveNonbondedKernels.empty()) return -1;
+    try { return liveNonbondedKernels.back()->getBlockHalves(out, maxBlocks); } catch (...) { return -2; }
+}
+
+int HipCalcNonbondedForceKernel::getBlockHalves(float* out, int maxBlocks) {
+    hip.setAsCurrent();
+    const int n = min(hip.paddedAtoms / OMMHIP_TILE, maxBlocks);
+    HIP_CHECK(ommhip_memcpy_d2h(out, blockHalf.ptr, sizeof(float) * 4 * (size_t) n, hip.stream));
+    hip.sync();
+    return n;
+}
+
+int HipCalcNonbondedForceKernel::getBlockDiag(float* out, int columns, int maxBlocks) {
+    hip.setAsCurrent();
+    const int numBlocks = hip.paddedAtoms / OMMHIP_TILE;
+    vector<float> ref(4 * (size_t) hip.paddedAtoms);
+    HIP_CHECK(ommhip_memcpy_d2h(ref.data(), posqRef.ptr, sizeof(float) * ref.size(), hip.stream));
+    hip.sync();
+    const int n = min(numBlocks, maxBlocks), cols = min(columns, 8);
+    for (int b = 0; b < n; b++)
+        for (int c = 0; c < cols; c++) out[(size_t) b * columns + c] = ref[4 * (size_t) (b * OMMHIP_TILE + c) + 3];
+    return n;
+}
+
 int HipCalcNonbondedForceKernel::getBlockCosts(float* ticks, float* candidates, int maxBlocks) {
     hip.setAsCurrent();
     const int numBlocks = hip.paddedAtoms / OMMHIP_TILE;

@@ -220,3 +220,90 @@ def run_pme(K, n, ng, L, triclinic=False, seed=2, alpha=2.6):
     e = float(K.download(d_e, 64, np.float64).sum())
     f_or, e_or = OPME.pme_exec(posq[:n, :3].astype(np.float64), q.astype(np.float32).astype(np.float64), box3, alpha, ng)
     return f[:, :n].T, e, f_or, e_or
+
+
+def run_list_completeness(K, n, cutoff, box_lengths, sort_cell, cells, seed=0, padding=0.1):
+    """Builds the neighbour list of n random atoms in a rectangular periodic box (slots sorted along a Morton curve through
+    `sort_cell` bins, per-step entry ommhip_nl_step) and decodes it.  -> (missing pairs, duplicated pairs, pairs within the cutoff,
+    list entries, nl state): every pair within the cutoff must be in the list exactly once (the brute-force side is
+    scipy's periodic cKDTree)."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(seed)
+    Ls = np.asarray(box_lengths, float)
+    box3 = np.diag(Ls)
+    pos = rng.random((n, 3)) * Ls
+    padded = (n + 31) // 32 * 32
+    cell = np.floor(pos / sort_cell).astype(np.int64)
+    key = np.zeros(n, np.int64)
+    for bit in range(8):
+        for d in range(3):
+            key |= ((cell[:, d] >> bit) & 1) << (3 * bit + d)
+    perm = np.argsort(key, kind="stable").astype(np.int32)
+    atom_of_slot = np.full(padded, -1, np.int32)
+    atom_of_slot[:n] = perm
+    slot_of_atom = np.empty(n, np.int32)
+    slot_of_atom[perm] = np.arange(n, dtype=np.int32)
+    pos4 = np.zeros((n, 4))
+    pos4[:, :3] = pos
+    d_pos, d_wrap = K.upload(pos4), K.upload(np.zeros((n, 4), np.int32))
+    d_aos, d_soa = K.upload(atom_of_slot), K.upload(slot_of_atom)
+    d_posq, d_se = K.upload(np.zeros((padded, 4), np.float32)), K.upload(np.zeros((padded, 2), np.float32))
+    K.set_slot_params(K.upload(np.zeros(n)), K.upload(np.full(n, 0.3)), K.upload(np.ones(n)), d_aos, padded, d_posq, d_se, None)
+    b6 = box6(box3)
+    nl = capi.NeighborList()
+    nl.num_atoms, nl.padded_atoms = n, padded
+    nb = padded // 32
+    maxc = 40 * nb
+    nl.max_chunks = maxc
+    nl.pbc = 1
+    nl.cutoff, nl.padding = cutoff, padding * cutoff
+    for i in range(6):
+        nl.box[i] = b6[i]
+    nl.posq, nl.posq_ref = d_posq, K.upload(np.zeros((padded, 4), np.float32))
+    nl.posq_rel = K.upload(np.zeros((padded, 4), np.float32))
+    nl.atom_of_slot, nl.slot_of_atom = d_aos, d_soa
+    nl.excl_start, nl.excl_atoms = K.upload(np.zeros(n + 1, np.int32)), K.upload(np.zeros(1, np.int32))
+    st = np.zeros(8, np.int32)
+    st[0] = 1
+    nl.state = K.upload(st)
+    nl.block_center, nl.block_half = K.upload(np.zeros((nb, 4), np.float32)), K.upload(np.zeros((nb, 4), np.float32))
+    nl.chunk_info = K.upload(np.zeros((maxc, 2), np.int32))
+    nl.row_j = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.int32))
+    nl.row_mask = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.uint32))
+    if cells:
+        nl.max_cells = 4 * nb + 64
+        nl.cell_start = K.upload(np.zeros(2 * nl.max_cells + 2, np.int32))
+        nl.cell_blocks = K.upload(np.zeros(2 * nb, np.int32))
+        nl.cell_boxes = K.upload(np.zeros((2 * nb, 4), np.float32))
+        nl.cell_meta = K.upload(np.zeros(4, np.float32))
+        nl.cell_min_blocks = 1
+    K.nl_step(C.byref(nl), d_pos, d_wrap, None)
+    state = K.download(nl.state, 8, np.int32)
+    chunks = int(state[1])
+    assert state[2] == 0 and 0 < chunks <= maxc, state
+    info = K.download(nl.chunk_info, (maxc, 2), np.int32)[:chunks]
+    rows_j = K.download(nl.row_j, (maxc, capi.CHUNK_ROWS, capi.ROW), np.int32)[:chunks]
+    rows_m = K.download(nl.row_mask, (maxc, capi.CHUNK_ROWS, capi.ROW), np.uint32)[:chunks]
+    pairs = []
+    entries = 0
+    for c in range(chunks):
+        X, nrows = int(info[c, 0]), int(info[c, 1]) & 0xFF
+        j = rows_j[c, :nrows].ravel()
+        m = rows_m[c, :nrows].ravel()
+        keep = m != 0
+        j, m = j[keep], m[keep]
+        entries += len(j)
+        bits = (m[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1
+        jj, ii = np.nonzero(bits)
+        si, sj = X * 32 + ii, j[jj]
+        a, b = atom_of_slot[si], atom_of_slot[sj]
+        assert (a >= 0).all() and (b >= 0).all()
+        pairs.append(np.stack([np.minimum(a, b), np.maximum(a, b)], 1))
+    listed = np.concatenate(pairs).astype(np.int64)
+    listed_key = listed[:, 0] * n + listed[:, 1]
+    uniq, counts = np.unique(listed_key, return_counts=True)
+    tree = cKDTree(pos, boxsize=Ls)
+    true = tree.query_pairs(cutoff, output_type="ndarray").astype(np.int64)
+    true_key = np.minimum(true[:, 0], true[:, 1]) * n + np.maximum(true[:, 0], true[:, 1])
+    missing = int((~np.isin(true_key, uniq)).sum())
+    return missing, int((counts > 1).sum()), len(true_key), entries, state

@@ -87,6 +87,20 @@ def test_direct_space_cell_binned_builder(K, compact):
 
 
 @needs_emu
+@pytest.mark.parametrize("n,cutoff,box,sort_cell", [(21000, 0.5, (4.2, 5.0, 6.1), 0.12),      # 7 x 9 x 11 cells: sub-period spans on every axis, wrapped columns
+                                                    (9000, 0.5, (2.3, 5.0, 8.1), 0.12),       # whole period along x, sub-period along z
+                                                    (9000, 0.7, (3.3, 3.0, 3.1), 0.3)])       # fat blocks: most go to the oversized list
+def test_cell_binned_list_is_complete(K, n, cutoff, box, sort_cell):
+    """Every pair within the cutoff (scipy's periodic cKDTree) is in the list exactly once, with the candidate search through
+    the cell-sorted block list -- columns of cells cut to what the x/y gap leaves of the list cutoff -- and the list has the
+    same number of entries as the one built by scanning all blocks."""
+    missing, dup, true_pairs, entries, state = KC.run_list_completeness(K, n, cutoff, box, sort_cell, cells=True, seed=n % 7)
+    assert missing == 0 and dup == 0 and true_pairs > 100000
+    missing0, dup0, _, entries0, _ = KC.run_list_completeness(K, n, cutoff, box, sort_cell, cells=False, seed=n % 7)
+    assert missing0 == 0 and dup0 == 0 and entries0 == entries
+
+
+@needs_emu
 @pytest.mark.parametrize("ng", [(8, 6, 10), (28, 25, 30), (21, 20, 18)])
 @pytest.mark.parametrize("fft_mode", [0, 1])
 def test_fft_logic(K, ng, fft_mode):
@@ -113,6 +127,12 @@ def test_reference_test_bodies_on_emulated_platform(name):
     if not os.path.exists(exe):
         pytest.skip("not built")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    # Bodies that draw their seed from the clock check statistics with ASSERT_USUALLY_*: the reference's own message says such a
+    # failure "may occasionally" happen (openmmapi/include/openmm/internal/AssertionUtilities.h:59-61), so those -- and only those -- get two more draws.
+    for attempt in range(2):
+        if out.returncode == 0 or "This test is stochastic and may occasionally fail" not in out.stdout:
+            break
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "Done" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
@@ -206,9 +226,12 @@ print("OK")
 @needs_emu
 def test_neighbour_list_overflow_is_recovered(tmp_path):
     """A device-triggered rebuild that runs out of rows freezes the integration on the device; the host grows the list and
-    redoes the skipped steps: same trajectory as an undisturbed run (tests/overflow_case.py)."""
+    redoes the skipped steps: same trajectory as an undisturbed run (tests/overflow_case.py).  Tolerance: after the recovery the
+    two runs hold different lists, so their float32 force sums differ in order (1e-5 of the RMS force, the same noise the
+    multi-rank tests allow); over 40 steps that random-walks to 1e-4 nm/ps on a hydrogen.  A wrong replay (one step with
+    another step's noise) is off by 1e-2 nm/ps."""
     from overflow_case import run_overflow_case
-    print(run_overflow_case(tmp_path, True, 7, 20, 1e-6, 1e-4))
+    print(run_overflow_case(tmp_path, True, 7, 20, 5e-6, 5e-4))
 
 
 @needs_emu

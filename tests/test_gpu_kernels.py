@@ -113,3 +113,14 @@ def test_pme_reciprocal(K, n, ng, tric):
     f, e, f_or, e_or = KC.run_pme(K, n, ng, 3.0 if n <= 3000 else 6.2, tric, alpha=2.6 if n <= 3000 else 2.92)
     assert max_rel_force_error(f, f_or) < 2e-5
     assert abs(e - e_or) < 1e-5 * abs(e_or)
+
+
+@pytest.mark.parametrize("n,cutoff,box,sort_cell", [(21000, 0.5, (4.2, 5.0, 6.1), 0.12), (9000, 0.5, (2.3, 5.0, 8.1), 0.12),
+                                                    (9000, 0.7, (3.3, 3.0, 3.1), 0.3), (150000, 0.9, (11.0, 11.5, 12.0), 0.3)])
+def test_cell_binned_list_is_complete(K, n, cutoff, box, sort_cell):
+    """Every pair within the cutoff (scipy's periodic cKDTree) is in the list exactly once when the candidate blocks come from
+    the cell-sorted block list (the search of 0.5M+ atom systems, forced here); same entries as the all-blocks scan."""
+    missing, dup, true_pairs, entries, state = KC.run_list_completeness(K, n, cutoff, box, sort_cell, cells=True, seed=n % 7)
+    assert missing == 0 and dup == 0 and true_pairs > 100000
+    missing0, dup0, _, entries0, _ = KC.run_list_completeness(K, n, cutoff, box, sort_cell, cells=False, seed=n % 7)
+    assert missing0 == 0 and dup0 == 0 and entries0 == entries

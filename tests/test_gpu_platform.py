@@ -33,6 +33,12 @@ def test_reference_test_body(name):
     exe = os.path.join(PRODUCT_TESTS, "TestHip" + name)
     assert os.path.exists(exe), "%s missing: run __graft_entry__.build() in the build container" % exe
     out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    # Bodies that draw their seed from the clock check statistics with ASSERT_USUALLY_*: the reference's own message says such a
+    # failure "may occasionally" happen (openmmapi/include/openmm/internal/AssertionUtilities.h:59-61), so those -- and only those -- get two more draws.
+    for attempt in range(2):
+        if out.returncode == 0 or "This test is stochastic and may occasionally fail" not in out.stdout:
+            break
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "Done" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 

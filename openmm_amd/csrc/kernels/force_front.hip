@@ -129,7 +129,7 @@ template <int METHOD, bool ENERGY>
 __global__ __launch_bounds__(PF_THREADS, 2) void pairs_fft_lines(NbArgs nb, FftArgs fft, PairsFftStage s, const float4* __restrict__ posqI, const float2* __restrict__ sigEpsI) {
     __shared__ FftShared sh;
     const int b = blockIdx.x;
-    if (b < s.fftBlocks) fft_body<PF_THREADS>(fft, b, sh);
+    if (b < s.fftBlocks) fft_body_mode<PF_THREADS, 3, false, false>(fft, b, sh, 0, 0);
     else {
         const int wave = (b - s.fftBlocks) * (PF_THREADS / 64) + (threadIdx.x >> 6);
         nb_direct_body<METHOD, 1, ENERGY>(nb, posqI, sigEpsI, pair_schedule(nb, s, b), wave);

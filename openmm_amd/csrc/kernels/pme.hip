@@ -461,7 +461,8 @@ __global__ void pme_build_eterm(EtermArgs a) {
 struct FftPlan {
     int n;
     int numRadices;
-    int radix[FFT_MAX_RADICES];
+    unsigned long long radices;      // 4 bits per pass, first pass in the low bits: read with shifts (a table indexed by the pass
+                                     // number would be a memory load -- and a wait for everything in flight -- in every pass)
 };
 
 struct FftArgs {
@@ -483,81 +484,84 @@ struct FftArgs {
     // slab decomposition, y pass only (outer = local x plane, inner = kz, element = ky): the side flagged here addresses the
     // transpose-ready layout [ky / remapNyl][x local of remapNxl][ky % remapNyl][kz] instead of the strides above
     int remapIn, remapOut, remapNxl, remapNyl;
+    unsigned long long* diag;      // diagnostics (OMMHIP_FFT_DIAG=1): clock ticks of workgroup 0's thread 0 per phase, summed over launches
 };
 
-__device__ __forceinline__ long long fft_remap_offset(const FftArgs& a, int outer, int inner, int e) {
-    const int q = e / a.remapNyl, yl = e - q * a.remapNyl;
-    return (((long long) q * a.remapNxl + outer) * a.remapNyl + yl) * a.numInner + inner;
-}
+// (offset of element e of line `inner` of plane `outer` in the transpose-ready layout: (((e / Nyl) * Nxl + outer) * Nyl + e % Nyl) * numInner + inner)
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
+// Complex numbers as v2f (re, im): an addition is ONE packed instruction (v_pk_add_f32), a multiplication by i a swizzle with a
+// sign (source modifiers of the packed instruction that consumes it), a complex product a packed multiply and a packed fma.
+// The radix passes are bound by VALU issue, and packed FP32 issues two results per lane per slot.
+__device__ __forceinline__ v2f swp(v2f v) { return mk2(v.y, v.x); }
+__device__ __forceinline__ v2f cmulp(v2f a, v2f w) { return bc2(w.x) * a + bc2(w.y) * mk2(-a.y, a.x); }
+__device__ __forceinline__ v2f rot(v2f v, float fs) { return mk2(-fs, fs) * swp(v); }          // v * (i fs)
+
 // Radix-R butterflies on R values held in registers: v[] -> o[], the DFT of length R with the sign of the pass (fs = -1 forward,
 // +1 backward).  Split-radix style forms instead of the O(R^2) sum: radix 4 and 8 need no / two real constants, the odd radices
-// pair v[k] with v[R-k] (cosine part on the sums, sine part on the differences), so radix 3 / 5 / 7 cost 4 / 16 / 36 real
-// multiplies where the plain sum costs 16 / 64 / 144.  rot() multiplies by i * fs.
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 rot(float2 v, float fs) { return make_float2(-fs * v.y, fs * v.x); }
+// pair v[k] with v[R-k] (cosine part on the sums, sine part on the differences).
+template <int R> __device__ __forceinline__ void butterfly(const v2f (&v)[R], v2f (&o)[R], float fs);
 
-template <int R> __device__ __forceinline__ void butterfly(const float2 (&v)[R], float2 (&o)[R], float fs);
-
-template <> __device__ __forceinline__ void butterfly<2>(const float2 (&v)[2], float2 (&o)[2], float) {
-    o[0] = cadd(v[0], v[1]); o[1] = csub(v[0], v[1]);
+template <> __device__ __forceinline__ void butterfly<2>(const v2f (&v)[2], v2f (&o)[2], float) {
+    o[0] = v[0] + v[1]; o[1] = v[0] - v[1];
 }
-template <> __device__ __forceinline__ void butterfly<4>(const float2 (&v)[4], float2 (&o)[4], float fs) {
-    const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = rot(csub(v[1], v[3]), fs);
-    o[0] = cadd(t0, t2); o[2] = csub(t0, t2); o[1] = cadd(t1, t3); o[3] = csub(t1, t3);
+template <> __device__ __forceinline__ void butterfly<4>(const v2f (&v)[4], v2f (&o)[4], float fs) {
+    const v2f t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], t3 = rot(v[1] - v[3], fs);
+    o[0] = t0 + t2; o[2] = t0 - t2; o[1] = t1 + t3; o[3] = t1 - t3;
 }
-template <> __device__ __forceinline__ void butterfly<8>(const float2 (&v)[8], float2 (&o)[8], float fs) {
+template <> __device__ __forceinline__ void butterfly<8>(const v2f (&v)[8], v2f (&o)[8], float fs) {
     // two radix-4 transforms (even and odd inputs), odd outputs twisted by W8^k = exp(i fs pi k / 4)
-    const float2 e[4] = {v[0], v[2], v[4], v[6]}, d[4] = {v[1], v[3], v[5], v[7]};
-    float2 E[4], D[4];
+    const v2f e[4] = {v[0], v[2], v[4], v[6]}, d[4] = {v[1], v[3], v[5], v[7]};
+    v2f E[4], D[4];
     butterfly<4>(e, E, fs);
     butterfly<4>(d, D, fs);
     const float h = 0.70710678118654752440f;
-    const float2 w1 = make_float2(h * (D[1].x - fs * D[1].y), h * (D[1].y + fs * D[1].x));        // D1 * (1 + i fs) / sqrt 2
-    const float2 w2 = rot(D[2], fs);
-    const float2 w3 = make_float2(h * (-D[3].x - fs * D[3].y), h * (-D[3].y + fs * D[3].x));      // D3 * (-1 + i fs) / sqrt 2
-    o[0] = cadd(E[0], D[0]); o[4] = csub(E[0], D[0]);
-    o[1] = cadd(E[1], w1);   o[5] = csub(E[1], w1);
-    o[2] = cadd(E[2], w2);   o[6] = csub(E[2], w2);
-    o[3] = cadd(E[3], w3);   o[7] = csub(E[3], w3);
+    const v2f w1 = bc2(h) * (D[1] + rot(D[1], fs));          // D1 * (1 + i fs) / sqrt 2
+    const v2f w2 = rot(D[2], fs);
+    const v2f w3 = bc2(h) * (rot(D[3], fs) - D[3]);          // D3 * (-1 + i fs) / sqrt 2
+    o[0] = E[0] + D[0]; o[4] = E[0] - D[0];
+    o[1] = E[1] + w1;   o[5] = E[1] - w1;
+    o[2] = E[2] + w2;   o[6] = E[2] - w2;
+    o[3] = E[3] + w3;   o[7] = E[3] - w3;
 }
-template <> __device__ __forceinline__ void butterfly<3>(const float2 (&v)[3], float2 (&o)[3], float fs) {
-    const float2 t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
-    const float2 m = make_float2(v[0].x - 0.5f * t.x, v[0].y - 0.5f * t.y);
-    const float2 n = rot(make_float2(0.86602540378443864676f * d.x, 0.86602540378443864676f * d.y), fs);
-    o[0] = cadd(v[0], t); o[1] = cadd(m, n); o[2] = csub(m, n);
+template <> __device__ __forceinline__ void butterfly<3>(const v2f (&v)[3], v2f (&o)[3], float fs) {
+    const v2f t = v[1] + v[2], d = v[1] - v[2];
+    const v2f m = v[0] - bc2(0.5f) * t;
+    const v2f n = rot(bc2(0.86602540378443864676f) * d, fs);
+    o[0] = v[0] + t; o[1] = m + n; o[2] = m - n;
 }
-template <> __device__ __forceinline__ void butterfly<5>(const float2 (&v)[5], float2 (&o)[5], float fs) {
+template <> __device__ __forceinline__ void butterfly<5>(const v2f (&v)[5], v2f (&o)[5], float fs) {
     const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f, s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
-    const float2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), d1 = csub(v[1], v[4]), d2 = csub(v[2], v[3]);
-    const float2 m1 = make_float2(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
-    const float2 m2 = make_float2(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
-    const float2 n1 = rot(make_float2(s1 * d1.x + s2 * d2.x, s1 * d1.y + s2 * d2.y), fs);
-    const float2 n2 = rot(make_float2(s2 * d1.x - s1 * d2.x, s2 * d1.y - s1 * d2.y), fs);
-    o[0] = make_float2(v[0].x + t1.x + t2.x, v[0].y + t1.y + t2.y);
-    o[1] = cadd(m1, n1); o[4] = csub(m1, n1); o[2] = cadd(m2, n2); o[3] = csub(m2, n2);
+    const v2f t1 = v[1] + v[4], t2 = v[2] + v[3], d1 = v[1] - v[4], d2 = v[2] - v[3];
+    const v2f m1 = v[0] + bc2(c1) * t1 + bc2(c2) * t2;
+    const v2f m2 = v[0] + bc2(c2) * t1 + bc2(c1) * t2;
+    const v2f n1 = rot(bc2(s1) * d1 + bc2(s2) * d2, fs);
+    const v2f n2 = rot(bc2(s2) * d1 - bc2(s1) * d2, fs);
+    o[0] = v[0] + t1 + t2;
+    o[1] = m1 + n1; o[4] = m1 - n1; o[2] = m2 + n2; o[3] = m2 - n2;
 }
-template <> __device__ __forceinline__ void butterfly<7>(const float2 (&v)[7], float2 (&o)[7], float fs) {
+template <> __device__ __forceinline__ void butterfly<7>(const v2f (&v)[7], v2f (&o)[7], float fs) {
     const float c1 = 0.62348980185873353053f, c2 = -0.22252093395631440429f, c3 = -0.90096886790241912624f;
     const float s1 = 0.78183148246802980871f, s2 = 0.97492791218182360702f, s3 = 0.43388373911755812048f;
-    const float2 t1 = cadd(v[1], v[6]), t2 = cadd(v[2], v[5]), t3 = cadd(v[3], v[4]);
-    const float2 d1 = csub(v[1], v[6]), d2 = csub(v[2], v[5]), d3 = csub(v[3], v[4]);
+    const v2f t1 = v[1] + v[6], t2 = v[2] + v[5], t3 = v[3] + v[4];
+    const v2f d1 = v[1] - v[6], d2 = v[2] - v[5], d3 = v[3] - v[4];
     // cos(2 pi j k / 7) for j, k = 1..3: row j = (c_j, c_2j, c_3j) with c4 = c3, c6 = c1, c9 = c2; sines likewise with s4 = -s3, s6 = -s1, s9 = s2
-    const float2 m1 = make_float2(v[0].x + c1 * t1.x + c2 * t2.x + c3 * t3.x, v[0].y + c1 * t1.y + c2 * t2.y + c3 * t3.y);
-    const float2 m2 = make_float2(v[0].x + c2 * t1.x + c3 * t2.x + c1 * t3.x, v[0].y + c2 * t1.y + c3 * t2.y + c1 * t3.y);
-    const float2 m3 = make_float2(v[0].x + c3 * t1.x + c1 * t2.x + c2 * t3.x, v[0].y + c3 * t1.y + c1 * t2.y + c2 * t3.y);
-    const float2 n1 = rot(make_float2(s1 * d1.x + s2 * d2.x + s3 * d3.x, s1 * d1.y + s2 * d2.y + s3 * d3.y), fs);
-    const float2 n2 = rot(make_float2(s2 * d1.x - s3 * d2.x - s1 * d3.x, s2 * d1.y - s3 * d2.y - s1 * d3.y), fs);
-    const float2 n3 = rot(make_float2(s3 * d1.x - s1 * d2.x + s2 * d3.x, s3 * d1.y - s1 * d2.y + s2 * d3.y), fs);
-    o[0] = make_float2(v[0].x + t1.x + t2.x + t3.x, v[0].y + t1.y + t2.y + t3.y);
-    o[1] = cadd(m1, n1); o[6] = csub(m1, n1); o[2] = cadd(m2, n2); o[5] = csub(m2, n2); o[3] = cadd(m3, n3); o[4] = csub(m3, n3);
+    const v2f m1 = v[0] + bc2(c1) * t1 + bc2(c2) * t2 + bc2(c3) * t3;
+    const v2f m2 = v[0] + bc2(c2) * t1 + bc2(c3) * t2 + bc2(c1) * t3;
+    const v2f m3 = v[0] + bc2(c3) * t1 + bc2(c1) * t2 + bc2(c2) * t3;
+    const v2f n1 = rot(bc2(s1) * d1 + bc2(s2) * d2 + bc2(s3) * d3, fs);
+    const v2f n2 = rot(bc2(s2) * d1 - bc2(s3) * d2 - bc2(s1) * d3, fs);
+    const v2f n3 = rot(bc2(s3) * d1 - bc2(s1) * d2 + bc2(s2) * d3, fs);
+    o[0] = v[0] + t1 + t2 + t3;
+    o[1] = m1 + n1; o[6] = m1 - n1; o[2] = m2 + n2; o[5] = m2 - n2; o[3] = m3 + n3; o[4] = m3 - n3;
 }
 
 // One Stockham pass of radix R over all B lines.  `sign` selects forward (-1) or backward (+1).
-template <int R>
+// THREADS = workgroup size as a compile-time constant: blockDim.x is a 16-bit load from the dispatch packet, i.e. a wait for
+// every global read in flight, in every pass.
+// FIRST: the pass with Ns = 1, whose twiddle factors are all 1.
+template <int R, int THREADS, bool FIRST>
 // Element e of line l lives at e*BP + l*LS (BP = element stride, LS = line stride).
 __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2* __restrict__ dst, int n, int Ns, int B, int BP, int sign,
                                          const float2* __restrict__ tw, int LS) {
@@ -568,41 +572,61 @@ __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2*
     const int twStep = n / (Ns * R);               // twiddle index increment per r
     const bool pow2B = (B & (B - 1)) == 0;
     const int shiftB = 31 - __clz(B);
-    for (int idx = threadIdx.x; idx < butterflies * B; idx += (int) blockDim.x) {
+    const bool pow2Ns = (Ns & (Ns - 1)) == 0;      // radix-2/4/8 passes come first: shifts instead of a division
+    const int shiftNs = 31 - __clz(Ns);
+    for (int idx = threadIdx.x; idx < butterflies * B; idx += THREADS) {
         int line, j;
         if (pow2B) { line = idx & (B - 1); j = idx >> shiftB; } else { j = idx / B; line = idx - j * B; }
-        const int q = j / Ns, k = j - q * Ns;
-        float2 v[R];
-        v[0] = src[j * BP + line * LS];
+        int q, k;
+        if (FIRST) { q = j; k = 0; }
+        else if (pow2Ns) { q = j >> shiftNs; k = j & (Ns - 1); }
+        else { q = j / Ns; k = j - q * Ns; }
+        v2f v[R];
+        { const float2 x = src[j * BP + line * LS]; v[0] = mk2(x.x, x.y); }
 #pragma unroll
         for (int r = 1; r < R; r++) {
-            float2 x = src[(j + r * butterflies) * BP + line * LS];
-            float2 w = tw[k * r * twStep];         // < n because k < Ns and r < R
-            w.y *= fsign;
-            v[r] = cmul(x, w);
+            const float2 x = src[(j + r * butterflies) * BP + line * LS];
+            if (FIRST) v[r] = mk2(x.x, x.y);
+            else {
+                const float2 w = tw[k * r * twStep];         // < n because k < Ns and r < R
+                v[r] = cmulp(mk2(x.x, x.y), mk2(w.x, w.y * fsign));
+            }
         }
-        float2 o[R];
+        v2f o[R];
         butterfly<R>(v, o, fs);
         const int j0 = q * Ns * R + k;
 #pragma unroll
-        for (int p = 0; p < R; p++) dst[(j0 + p * Ns) * BP + line * LS] = o[p];
+        for (int p = 0; p < R; p++) dst[(j0 + p * Ns) * BP + line * LS] = make_float2(o[p].x, o[p].y);
     }
 }
 
 // Runs all passes; returns the buffer that holds the result.
+template <int THREADS>
 __device__ __forceinline__ float2* fft_lines(const FftPlan& plan, float2* bufA, float2* bufB, int B, int BP, int sign, const float2* tw, int LS = 1) {
     float2* src = bufA;
     float2* dst = bufB;
     int Ns = 1;
     for (int s = 0; s < plan.numRadices; s++) {
-        const int R = plan.radix[s];
-        switch (R) {
-            case 2: fft_pass<2>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
-            case 3: fft_pass<3>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
-            case 4: fft_pass<4>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
-            case 5: fft_pass<5>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
-            case 7: fft_pass<7>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
-            default: fft_pass<8>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+        const int R = (int) ((plan.radices >> (4 * s)) & 15ull);
+        if (s == 0) {
+            switch (R) {
+                case 2: fft_pass<2, THREADS, true>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+                case 3: fft_pass<3, THREADS, true>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+                case 4: fft_pass<4, THREADS, true>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+                case 5: fft_pass<5, THREADS, true>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+                case 7: fft_pass<7, THREADS, true>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+                default: fft_pass<8, THREADS, true>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+            }
+        }
+        else {
+            switch (R) {
+                case 2: fft_pass<2, THREADS, false>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+                case 3: fft_pass<3, THREADS, false>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+                case 4: fft_pass<4, THREADS, false>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+                case 5: fft_pass<5, THREADS, false>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+                case 7: fft_pass<7, THREADS, false>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+                default: fft_pass<8, THREADS, false>(src, dst, plan.n, Ns, B, BP, sign, tw, LS); break;
+            }
         }
         Ns *= R;
         __syncthreads();
@@ -618,9 +642,13 @@ struct FftShared {
     float2 twS[FFT_MAX_LDS / 2];          // n <= FFT_MAX_LDS/2 (ommhip_fft_supported_size)
 };
 
-// THREADS = workgroup size (256 as a kernel of its own; fused launches may differ); `block` = workgroup index of this work
-template <int THREADS>
-__device__ __forceinline__ void fft_body(const FftArgs& a, const int block, FftShared& sh) {
+// THREADS = workgroup size (256 as a kernel of its own; fused launches may differ); `block` = first tile of this workgroup,
+// `tileStride` > 0: the workgroup goes on with tiles block + tileStride, block + 2 tileStride, ... < numTiles, and the global
+// reads of the next tile are issued before the passes of the current one (they land in the registers the current tile has
+// just left for LDS), so memory stays busy while the butterflies run.  A line-pass workgroup alone keeps ~12 KB in flight
+// for a third of its life; at 4 workgroups per CU that is a fifth of what 8 TB/s needs.
+template <int THREADS, int MODE, bool REMAP_IN, bool REMAP_OUT>
+__device__ __forceinline__ void fft_body_mode(const FftArgs& a, const int block, FftShared& sh, const int tileStride, const int numTiles) {
     float2* const bufA = sh.bufA;
     float2* const bufB = sh.bufB;
     double* const energyPartial = sh.energyPartial;
@@ -628,105 +656,186 @@ __device__ __forceinline__ void fft_body(const FftArgs& a, const int block, FftS
     const int n = a.plan.n, B = a.B, BP = a.B + 1;   // LDS line stride B+1: conflict-free for both staging orders
     for (int i = threadIdx.x; i < n; i += THREADS) twS[i] = a.twiddle[i];
     const int tilesPerOuter = (a.numInner + B - 1) / B;
-    const int outer = block / tilesPerOuter;
-    const int inner0 = (block % tilesPerOuter) * B;
-    const int nIn = a.mode == 2 ? n / 2 + 1 : n;
-    const int nOut = a.mode == 1 ? n / 2 + 1 : n;
+    const int nIn = MODE == 2 ? n / 2 + 1 : n;
+    const int nOut = MODE == 1 ? n / 2 + 1 : n;
     const bool elemFastIn = a.inElemStride == 1;
-    // ---- load: all global reads of this thread (input lines and, for the fused convolution, the influence function) are
-    //      issued back to back before anything is consumed; a rolled loop would wait for one round trip per element
+    const bool elemFastOut = a.outElemStride == 1;
+    // ---- load: all global reads of this thread are issued back to back before anything is consumed; a rolled loop would
+    //      wait for one round trip per element
     constexpr int MAXLD = FFT_MAX_LDS / THREADS;          // (B + 1) * n <= FFT_MAX_LDS
     float2 ld[MAXLD];
-    int ldPos[MAXLD];
+    unsigned ldZero = 0;          // bit it: ld[it] belongs to a line beyond the end and is staged as zero
     float etv[MAXLD];
+    // What a thread reads and writes is the same in every tile up to the tile's origin: LDS position, line within the tile and
+    // memory offset relative to the origin are computed once (the divisions of the index split are a third of a tile's
+    // instructions otherwise).  pack = LDS position | line << 16, or -1 for "no element".
+    int ldPack[MAXLD], stPack[MAXLD];
+    unsigned ldRel[MAXLD], stRel[MAXLD];
 #pragma unroll
     for (int it = 0; it < MAXLD; it++) {
         const int idx = threadIdx.x + it * THREADS;
-        float2 v = make_float2(0.f, 0.f);
-        ldPos[it] = -1;
-        if (idx < nIn * B) {
-            int line, e;
-            if (elemFastIn) { e = idx % nIn; line = idx / nIn; } else { line = idx % B; e = idx / B; }
-            if (inner0 + line < a.numInner) {
-                const long long off = a.remapIn ? fft_remap_offset(a, outer, inner0 + line, e)
-                                                : outer * a.inOuterStride + (inner0 + line) * a.inInnerStride + e * a.inElemStride;
-                if (a.mode == 1) v.x = ((const float*) a.in)[off];
-                else v = ((const float2*) a.in)[off];
-            }
-            ldPos[it] = e * BP + line;
-        }
-        ld[it] = v;
-        etv[it] = 0.f;
-        if (a.mode == 3 && idx < n * B) {
-            const int line = idx % B, e = idx / B, kz = inner0 + line;
-            if (kz < a.numInner) etv[it] = a.eterm[outer * a.inOuterStride + kz * a.inInnerStride + e * a.inElemStride];
-        }
+        int line, e;
+        if (elemFastIn) { e = idx % nIn; line = idx / nIn; } else { line = idx % B; e = idx / B; }
+        ldPack[it] = idx < nIn * B ? (e * BP + line) | (line << 16) : -1;
+        if (REMAP_IN) { const int q = e / a.remapNyl, yl = e - q * a.remapNyl; ldRel[it] = (unsigned) ((q * a.remapNxl * a.remapNyl + yl) * a.numInner + line); }
+        else ldRel[it] = (unsigned) (line * a.inInnerStride + e * a.inElemStride);
+        if (elemFastOut) { e = idx % nOut; line = idx / nOut; } else { line = idx % B; e = idx / B; }
+        stPack[it] = idx < nOut * B ? (e * BP + line) | (line << 16) : -1;
+        if (REMAP_OUT) { const int q = e / a.remapNyl, yl = e - q * a.remapNyl; stRel[it] = (unsigned) ((q * a.remapNxl * a.remapNyl + yl) * a.numInner + line); }
+        else stRel[it] = (unsigned) (line * a.outInnerStride + e * a.outElemStride);
     }
-#pragma unroll
-    for (int it = 0; it < MAXLD; it++) {
-        if (ldPos[it] >= 0) {
-            const float2 v = ld[it];
-            bufA[ldPos[it]] = v;
-            if (a.mode == 2) {
-                const int e = ldPos[it] / BP, line = ldPos[it] - e * BP;
-                if (e > 0 && e < n - e) bufA[(n - e) * BP + line] = make_float2(v.x, -v.y);   // Hermitian completion
-            }
-        }
-    }
-    __syncthreads();
-    float2* res;
-    if (a.mode == 3) {
-        res = fft_lines(a.plan, bufA, bufB, B, BP, -1, twS);
-        double energy = 0;
+    auto originIn = [&](int outer, int inner0) -> long long {
+        return REMAP_IN ? (long long) outer * a.remapNyl * a.numInner + inner0 : outer * a.inOuterStride + inner0 * a.inInnerStride;
+    };
+    auto originOut = [&](int outer, int inner0) -> long long {
+        return REMAP_OUT ? (long long) outer * a.remapNyl * a.numInner + inner0 : outer * a.outOuterStride + inner0 * a.outInnerStride;
+    };
+    // Every read is unconditional (lanes without an element read element 0 and discard it): no branches, so the compiler can
+    // issue all of them before the first wait.
+    auto loadTile = [&](int tile) {
+        const int outer = tile / tilesPerOuter, inner0 = (tile % tilesPerOuter) * B;
+        const long long origin = originIn(outer, inner0);
+        ldZero = 0;
 #pragma unroll
         for (int it = 0; it < MAXLD; it++) {
-            const int idx = threadIdx.x + it * THREADS;
-            if (idx < n * B) {
-                const int line = idx % B, e = idx / B;
-                float2 v = res[e * BP + line];
-                const float et = etv[it];
-                const int kz = inner0 + line;
-                if (a.energyBuffer != nullptr) {
-                    const float wgt = (kz == 0 || 2 * kz == a.nzFull) ? 1.f : 2.f;
-                    energy += (double) (wgt * et * (v.x * v.x + v.y * v.y));
+            const bool valid = ldPack[it] >= 0 && inner0 + (ldPack[it] >> 16) < a.numInner;
+            const long long off = valid ? origin + ldRel[it] : 0;
+            float2 v;
+            if (MODE == 1) v = make_float2(((const float*) a.in)[off], 0.f);
+            else v = ((const float2*) a.in)[off];
+            ld[it] = v;                                   // not looked at here: a use would make the compiler wait for it
+            ldZero |= (valid ? 0u : 1u) << it;
+        }
+    };
+    // influence function of the tile being transformed (mode 3; same indexing as the input): consumed after the forward passes,
+    // so it is requested at their start
+    auto loadEterm = [&](int tile) {
+        const int outer = tile / tilesPerOuter, inner0 = (tile % tilesPerOuter) * B;
+        const long long origin = originIn(outer, inner0);
+#pragma unroll
+        for (int it = 0; it < MAXLD; it++) {
+            const bool valid = ldPack[it] >= 0 && inner0 + (ldPack[it] >> 16) < a.numInner;
+            etv[it] = a.eterm[valid ? origin + ldRel[it] : 0];      // lanes beyond the end never use it
+        }
+    };
+    const bool diagOn = a.diag != nullptr && threadIdx.x == 0 && block == 0;
+    long long dT0 = diagOn ? clock64() : 0, dStage = 0, dPass = 0, dStore = 0, dIssue = 0;
+    loadTile(block);
+    __builtin_amdgcn_sched_barrier(0);          // all reads of the first tile are issued before its staging starts
+    for (int tile = block; ; ) {
+        const int outer = tile / tilesPerOuter, inner0 = (tile % tilesPerOuter) * B;
+        long long dA = diagOn ? clock64() : 0;
+#pragma unroll
+        for (int it = 0; it < MAXLD; it++) {
+            if (ldPack[it] >= 0) {
+                const float2 v = (ldZero >> it) & 1u ? make_float2(0.f, 0.f) : ld[it];
+                const int pos = ldPack[it] & 0xFFFF, line = ldPack[it] >> 16;
+                bufA[pos] = v;
+                if (MODE == 2) {
+                    const int e = (pos - line) / BP;
+                    if (e > 0 && e < n - e) bufA[(n - e) * BP + line] = make_float2(v.x, -v.y);   // Hermitian completion
                 }
-                res[e * BP + line] = make_float2(v.x * et, v.y * et);
             }
         }
-        if (a.energyBuffer != nullptr) {
-            energy = wave_sum(energy);
-            if ((threadIdx.x & 63) == 0) energyPartial[threadIdx.x >> 6] = energy;
-        }
         __syncthreads();
-        if (a.energyBuffer != nullptr && threadIdx.x == 0) {
-            double e = 0;
-            for (int w = 0; w < THREADS / 64; w++) e += energyPartial[w];
-            atomicAdd(&a.energyBuffer[block % a.energySlots], 0.5 * e);
+        long long dB = diagOn ? clock64() : 0;
+        const int next = tile + tileStride;
+        const bool more = tileStride > 0 && next < numTiles;
+        if (MODE == 3) loadEterm(tile);
+        if (more) loadTile(next);
+        long long dC = diagOn ? clock64() : 0;
+        float2* res;
+        if (MODE == 3) {
+            res = fft_lines<THREADS>(a.plan, bufA, bufB, B, BP, -1, twS);
+            double energy = 0;
+#pragma unroll
+            for (int it = 0; it < MAXLD; it++) {
+                if (ldPack[it] >= 0) {
+                    const int pos = ldPack[it] & 0xFFFF, line = ldPack[it] >> 16;
+                    float2 v = res[pos];
+                    const float et = etv[it];
+                    const int kz = inner0 + line;
+                    if (a.energyBuffer != nullptr) {
+                        const float wgt = (kz == 0 || 2 * kz == a.nzFull) ? 1.f : 2.f;
+                        energy += (double) (wgt * et * (v.x * v.x + v.y * v.y));
+                    }
+                    res[pos] = make_float2(v.x * et, v.y * et);
+                }
+            }
+            if (a.energyBuffer != nullptr) {
+                energy = wave_sum(energy);
+                if ((threadIdx.x & 63) == 0) energyPartial[threadIdx.x >> 6] = energy;
+            }
+            __syncthreads();
+            if (a.energyBuffer != nullptr && threadIdx.x == 0) {
+                double e = 0;
+                for (int w = 0; w < THREADS / 64; w++) e += energyPartial[w];
+                atomicAdd(&a.energyBuffer[tile % a.energySlots], 0.5 * e);
+            }
+            float2* other = res == bufA ? bufB : bufA;
+            res = fft_lines<THREADS>(a.plan, res, other, B, BP, +1, twS);
         }
-        float2* other = res == bufA ? bufB : bufA;
-        res = fft_lines(a.plan, res, other, B, BP, +1, twS);
-    }
-    else {
-        res = fft_lines(a.plan, bufA, bufB, B, BP, a.sign, twS);
-    }
-    // ---- store
-    const bool elemFastOut = a.outElemStride == 1;
-    for (int idx = threadIdx.x; idx < nOut * B; idx += THREADS) {
-        int line, e;
-        if (elemFastOut) { e = idx % nOut; line = idx / nOut; } else { line = idx % B; e = idx / B; }
-        if (inner0 + line < a.numInner) {
-            const long long off = a.remapOut ? fft_remap_offset(a, outer, inner0 + line, e)
-                                             : outer * a.outOuterStride + (inner0 + line) * a.outInnerStride + e * a.outElemStride;
-            const float2 v = res[e * BP + line];
-            if (a.mode == 2) ((float*) a.out)[off] = v.x;
-            else ((float2*) a.out)[off] = v;
+        else {
+            res = fft_lines<THREADS>(a.plan, bufA, bufB, B, BP, a.sign, twS);
         }
+        // ---- store
+        long long dD = diagOn ? clock64() : 0;
+        const long long outOrigin = originOut(outer, inner0);
+#pragma unroll
+        for (int it = 0; it < MAXLD; it++) {
+            if (stPack[it] >= 0 && inner0 + (stPack[it] >> 16) < a.numInner) {
+                const float2 v = res[stPack[it] & 0xFFFF];
+                if (MODE == 2) ((float*) a.out)[outOrigin + stRel[it]] = v.x;
+                else ((float2*) a.out)[outOrigin + stRel[it]] = v;
+            }
+        }
+        if (diagOn) { const long long dE = clock64(); dStage += dB - dA; dIssue += dC - dB; dPass += dD - dC; dStore += dE - dD; }
+        if (!more) break;
+        tile = next;
+        __syncthreads();          // the next tile is staged into bufA, which the last pass may still be read from
+    }
+    if (diagOn) {
+        unsigned long long* d = a.diag + 8 * MODE;
+        atomicAdd(&d[0], 1ull); atomicAdd(&d[1], (unsigned long long) (clock64() - dT0)); atomicAdd(&d[2], (unsigned long long) dStage);
+        atomicAdd(&d[3], (unsigned long long) dIssue); atomicAdd(&d[4], (unsigned long long) dPass); atomicAdd(&d[5], (unsigned long long) dStore);
     }
 }
 
+// Tiles per launch of the line-pass kernel: every workgroup resident at once (4 per CU), each with the same number of tiles
+static int fft_grid(int numTiles) {
+    static const char* forced = getenv("OMMHIP_FFT_RESIDENT_WORKGROUPS");      // tests: a few workgroups walk through many tiles
+    const int resident = forced != nullptr && atoi(forced) > 0 ? atoi(forced) : 1024;
+    const int rounds = (numTiles + resident - 1) / resident;
+    return (numTiles + rounds - 1) / rounds;
+}
+
+// One kernel per (mode, remap) combination: each gets its own register allocation (the six bodies in one kernel needed 145 VGPRs
+// and spilled 180 SGPRs).
+template <int MODE, bool REMAP_IN, bool REMAP_OUT>
 __global__ __launch_bounds__(FFT_THREADS) void fft_kernel(FftArgs a) {
     __shared__ FftShared sh;
-    fft_body<FFT_THREADS>(a, blockIdx.x, sh);
+    fft_body_mode<FFT_THREADS, MODE, REMAP_IN, REMAP_OUT>(a, blockIdx.x, sh, gridDim.x, a.numOuter * ((a.numInner + a.B - 1) / a.B));
+}
+
+static unsigned long long* g_fftDiag = nullptr;
+extern "C" int ommhip_fft_diag(unsigned long long* out32) {      // diagnostics only (tools/diag_fft_phases.py); not part of the product ABI
+    if (g_fftDiag == nullptr) return 1;
+    hipDeviceSynchronize();
+    return (int) hipMemcpy(out32, g_fftDiag, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+
+static void launch_fft(const FftArgs& fin, hipStream_t st) {
+    FftArgs f = fin;
+    static const bool diag = getenv("OMMHIP_FFT_DIAG") != nullptr;
+    if (diag && g_fftDiag == nullptr) { hipMalloc((void**) &g_fftDiag, 32 * sizeof(unsigned long long)); hipMemset(g_fftDiag, 0, 32 * sizeof(unsigned long long)); }
+    f.diag = g_fftDiag;
+    const dim3 grid(fft_grid(f.numOuter * ((f.numInner + f.B - 1) / f.B))), block(FFT_THREADS);
+    if (f.mode == 1) hipLaunchKernelGGL((fft_kernel<1, false, false>), grid, block, 0, st, f);
+    else if (f.mode == 2) hipLaunchKernelGGL((fft_kernel<2, false, false>), grid, block, 0, st, f);
+    else if (f.mode == 3) hipLaunchKernelGGL((fft_kernel<3, false, false>), grid, block, 0, st, f);
+    else if (f.remapIn) hipLaunchKernelGGL((fft_kernel<0, true, false>), grid, block, 0, st, f);
+    else if (f.remapOut) hipLaunchKernelGGL((fft_kernel<0, false, true>), grid, block, 0, st, f);
+    else hipLaunchKernelGGL((fft_kernel<0, false, false>), grid, block, 0, st, f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -794,9 +903,9 @@ __device__ __forceinline__ void fft_plane_body(const PlaneArgs& a, const int blo
             }
         }
         __syncthreads();
-        float2* r1 = fft_lines(a.planZ, bufA, bufB, ny, S, -1, twZs, 1);            // lines = y, elements = z
+        float2* r1 = fft_lines<THREADS>(a.planZ, bufA, bufB, ny, S, -1, twZs, 1);            // lines = y, elements = z
         float2* other = r1 == bufA ? bufB : bufA;
-        float2* r2 = fft_lines(a.planY, r1, other, nzc, 1, -1, twYs, S);            // lines = kz < nzc, elements = y
+        float2* r2 = fft_lines<THREADS>(a.planY, r1, other, nzc, 1, -1, twYs, S);            // lines = kz < nzc, elements = y
         for (int idx = threadIdx.x; idx < ny * nzc; idx += THREADS) {
             const int ky = idx / nzc, kz = idx % nzc;
             a.cplx[plane_cplx_index(a, x, ky, kz, nzc)] = r2[kz * S + ky];
@@ -819,7 +928,7 @@ __device__ __forceinline__ void fft_plane_body(const PlaneArgs& a, const int blo
             }
         }
         __syncthreads();
-        float2* r1 = fft_lines(a.planY, bufA, bufB, nzc, 1, +1, twYs, S);           // backward y on the half plane
+        float2* r1 = fft_lines<THREADS>(a.planY, bufA, bufB, nzc, 1, +1, twYs, S);           // backward y on the half plane
         // Hermitian completion along z: element kz' = nz - kz is the conjugate of kz (for every y)
         for (int idx = threadIdx.x; idx < ny * (nz - nzc); idx += THREADS) {
             const int y = idx % ny, kz = nzc + idx / ny;
@@ -828,7 +937,7 @@ __device__ __forceinline__ void fft_plane_body(const PlaneArgs& a, const int blo
         }
         __syncthreads();
         float2* other = r1 == bufA ? bufB : bufA;
-        float2* r2 = fft_lines(a.planZ, r1, other, ny, S, +1, twZs, 1);
+        float2* r2 = fft_lines<THREADS>(a.planZ, r1, other, ny, S, +1, twZs, 1);
         float* out = a.real + (size_t) x * ny * nz;
         for (int idx = threadIdx.x; idx < ny * nz; idx += THREADS) {
             const int y = idx / nz, z = idx % nz;
@@ -844,12 +953,12 @@ __global__ __launch_bounds__(PLANE_THREADS) void fft_plane_kernel(PlaneArgs a) {
 
 FftPlan make_plan(int n) {
     FftPlan p;
-    p.n = n; p.numRadices = 0;
+    p.n = n; p.numRadices = 0; p.radices = 0;
     int m = n;
     const int cand[6] = {8, 4, 2, 3, 5, 7};
     // power-of-two part first (as 8s, then a 4 or 2), then odd primes
     for (int c = 0; c < 6; c++)
-        while (m % cand[c] == 0 && p.numRadices < FFT_MAX_RADICES) { p.radix[p.numRadices++] = cand[c]; m /= cand[c]; }
+        while (m % cand[c] == 0 && p.numRadices < FFT_MAX_RADICES) { p.radices |= (unsigned long long) cand[c] << (4 * p.numRadices++); m /= cand[c]; }
     if (m != 1) p.n = -1;   // unsupported size
     return p;
 }
@@ -877,6 +986,7 @@ FftArgs make_xconv_args(const ommhip_pme* pme, double* energy_buffer_d, int ener
     const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
     float2* cgrid = (float2*) pme->grid_complex;
     FftArgs f;
+    f.diag = nullptr;
     f.remapIn = f.remapOut = 0; f.remapNxl = f.remapNyl = 1;
     f.nzFull = nz;
     f.plan = make_plan(nx); f.B = lines_per_group(nx); f.numOuter = ny; f.numInner = nzc;
@@ -901,6 +1011,7 @@ void launch_yz(const ommhip_pme* pme, bool forward, hipStream_t st) {
         return;
     }
     FftArgs f;
+    f.diag = nullptr;
     f.remapIn = f.remapOut = 0; f.remapNxl = f.remapNyl = 1;
     f.eterm = nullptr; f.energyBuffer = nullptr; f.energySlots = 1; f.nzFull = nz;
     auto zpass = [&]() {
@@ -909,14 +1020,14 @@ void launch_yz(const ommhip_pme* pme, bool forward, hipStream_t st) {
         f.twiddle = (const float2*) pme->twiddle_z;
         if (forward) { f.inInnerStride = nz; f.outInnerStride = nzc; f.mode = 1; f.sign = -1; f.in = pme->grid_real; f.out = cgrid; }
         else { f.inInnerStride = nzc; f.outInnerStride = nz; f.mode = 2; f.sign = +1; f.in = cgrid; f.out = pme->grid_real; }
-        hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+        launch_fft(f, st);
     };
     auto ypass = [&]() {
         f.plan = make_plan(ny); f.B = lines_per_group(ny); f.numOuter = nx; f.numInner = nzc;
         f.inOuterStride = (long long) ny * nzc; f.inInnerStride = 1; f.inElemStride = nzc;
         f.outOuterStride = f.inOuterStride; f.outInnerStride = 1; f.outElemStride = nzc;
         f.mode = 0; f.sign = forward ? -1 : +1; f.twiddle = (const float2*) pme->twiddle_y; f.in = cgrid; f.out = cgrid;
-        hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+        launch_fft(f, st);
     };
     if (forward) { zpass(); ypass(); }
     else { ypass(); zpass(); }
@@ -998,6 +1109,7 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     ommhip_profile_begin(OMMHIP_TIMER_PME_FFT, stream);
 
     FftArgs f;
+    f.diag = nullptr;
     f.remapIn = f.remapOut = 0; f.remapNxl = f.remapNyl = 1;
     f.eterm = nullptr; f.energyBuffer = nullptr; f.energySlots = 1; f.nzFull = nz;
     // ---- forward z (r2c) and y
@@ -1008,7 +1120,7 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     f.outOuterStride = nzc; f.outInnerStride = 1; f.outElemStride = (long long) ny * nzc;
     f.mode = 3; f.sign = -1; f.twiddle = (const float2*) pme->twiddle_x; f.in = cgrid; f.out = cgrid;
     f.eterm = (const float*) pme->eterm; f.energyBuffer = include_energy ? energy_buffer_d : nullptr; f.energySlots = energy_slots;
-    hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+    launch_fft(f, st);
     // ---- backward y and z (c2r)
     launch_yz(pme, false, st);
 
@@ -1039,6 +1151,7 @@ void launch_yz_dd(const ommhip_pme* pme, bool forward, float* realOwn, hipStream
         return;
     }
     FftArgs f;
+    f.diag = nullptr;
     f.remapIn = f.remapOut = 0; f.remapNxl = nxl; f.remapNyl = nyl;
     f.eterm = nullptr; f.energyBuffer = nullptr; f.energySlots = 1; f.nzFull = nz;
     auto zpass = [&]() {      // real planes <-> B in plain [x local][y][kz] order
@@ -1047,7 +1160,7 @@ void launch_yz_dd(const ommhip_pme* pme, bool forward, float* realOwn, hipStream
         f.twiddle = (const float2*) pme->twiddle_z;
         if (forward) { f.inInnerStride = nz; f.outInnerStride = nzc; f.mode = 1; f.sign = -1; f.in = realOwn; f.out = B; }
         else { f.inInnerStride = nzc; f.outInnerStride = nz; f.mode = 2; f.sign = +1; f.in = B; f.out = realOwn; }
-        hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+        launch_fft(f, st);
     };
     auto ypass = [&]() {      // B (plain) <-> A (transpose-ready)
         f.plan = make_plan(ny); f.B = lines_per_group(ny); f.numOuter = nxl; f.numInner = nzc;
@@ -1056,7 +1169,7 @@ void launch_yz_dd(const ommhip_pme* pme, bool forward, float* realOwn, hipStream
         f.mode = 0; f.sign = forward ? -1 : +1; f.twiddle = (const float2*) pme->twiddle_y;
         if (forward) { f.in = B; f.out = A; f.remapIn = 0; f.remapOut = 1; }
         else { f.in = A; f.out = B; f.remapIn = 1; f.remapOut = 0; }
-        hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+        launch_fft(f, st);
     };
     if (forward) { zpass(); ypass(); }
     else { ypass(); zpass(); }
@@ -1096,6 +1209,7 @@ extern "C" int ommhip_pme_reciprocal_dd(const ommhip_pme* pme, const void* posq_
         if (rc != 0) return rc;
         // x transform * influence function * inverse x transform on this rank's rows, in place in B = [x][y local][kz]
         FftArgs f;
+        f.diag = nullptr;
         f.remapIn = f.remapOut = 0; f.remapNxl = f.remapNyl = 1;
         f.nzFull = nz;
         f.plan = make_plan(nx); f.B = lines_per_group(nx); f.numOuter = nyl; f.numInner = nzc;
@@ -1103,7 +1217,7 @@ extern "C" int ommhip_pme_reciprocal_dd(const ommhip_pme* pme, const void* posq_
         f.outOuterStride = nzc; f.outInnerStride = 1; f.outElemStride = (long long) nyl * nzc;
         f.mode = 3; f.sign = -1; f.twiddle = (const float2*) pme->twiddle_x; f.in = pme->grid_complex2; f.out = pme->grid_complex2;
         f.eterm = (const float*) pme->eterm; f.energyBuffer = include_energy ? energy_buffer_d : nullptr; f.energySlots = energy_slots;
-        hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+        launch_fft(f, st);
         rc = ommhip_comm_all_to_all(comm, pme->grid_complex2, pme->grid_complex, pairBytes, stream);
         if (rc != 0) return rc;
         launch_yz_dd(pme, false, realOwn, st);
@@ -1126,6 +1240,7 @@ extern "C" int ommhip_fft3d_r2c_c2r(const ommhip_pme* pme, int forward, void* st
     const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
     float2* cgrid = (float2*) pme->grid_complex;
     FftArgs f;
+    f.diag = nullptr;
     f.remapIn = f.remapOut = 0; f.remapNxl = f.remapNyl = 1;
     f.eterm = nullptr; f.energyBuffer = nullptr; f.energySlots = 1; f.nzFull = nz;
     auto zpass = [&](bool fwd) {
@@ -1134,21 +1249,21 @@ extern "C" int ommhip_fft3d_r2c_c2r(const ommhip_pme* pme, int forward, void* st
         f.twiddle = (const float2*) pme->twiddle_z;
         if (fwd) { f.inInnerStride = nz; f.outInnerStride = nzc; f.mode = 1; f.sign = -1; f.in = pme->grid_real; f.out = cgrid; }
         else { f.inInnerStride = nzc; f.outInnerStride = nz; f.mode = 2; f.sign = +1; f.in = cgrid; f.out = pme->grid_real; }
-        hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+        launch_fft(f, st);
     };
     auto ypass = [&](int sign) {
         f.plan = make_plan(ny); f.B = lines_per_group(ny); f.numOuter = nx; f.numInner = nzc;
         f.inOuterStride = (long long) ny * nzc; f.inInnerStride = 1; f.inElemStride = nzc;
         f.outOuterStride = f.inOuterStride; f.outInnerStride = 1; f.outElemStride = nzc;
         f.mode = 0; f.sign = sign; f.twiddle = (const float2*) pme->twiddle_y; f.in = cgrid; f.out = cgrid;
-        hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+        launch_fft(f, st);
     };
     auto xpass = [&](int sign) {
         f.plan = make_plan(nx); f.B = lines_per_group(nx); f.numOuter = ny; f.numInner = nzc;
         f.inOuterStride = nzc; f.inInnerStride = 1; f.inElemStride = (long long) ny * nzc;
         f.outOuterStride = nzc; f.outInnerStride = 1; f.outElemStride = (long long) ny * nzc;
         f.mode = 0; f.sign = sign; f.twiddle = (const float2*) pme->twiddle_x; f.in = cgrid; f.out = cgrid;
-        hipLaunchKernelGGL(fft_kernel, dim3(f.numOuter * ((f.numInner + f.B - 1) / f.B)), dim3(FFT_THREADS), 0, st, f);
+        launch_fft(f, st);
     };
     (void) zpass; (void) ypass;
     if (forward) { launch_yz(pme, true, st); xpass(-1); }

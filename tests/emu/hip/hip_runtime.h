@@ -193,6 +193,7 @@ template <class T> static inline T emu_readfirstlane(T v) {
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_sqrtf(x) sqrtf(x)
+#define __builtin_amdgcn_sched_barrier(x) ((void) 0)
 #define __builtin_amdgcn_mbcnt_lo(m, c) ((c) + __builtin_popcount((unsigned) (m) & (unsigned) (((1ull << (emu::cur->lane < 32 ? emu::cur->lane : 32)) - 1))))
 #define __builtin_amdgcn_mbcnt_hi(m, c) ((c) + (emu::cur->lane > 32 ? __builtin_popcount((unsigned) (m) & (unsigned) ((1ull << (emu::cur->lane - 32)) - 1)) : 0))
 #define __builtin_amdgcn_s_sleep(x) ((void) 0)

@@ -109,6 +109,29 @@ def test_fft_logic(K, ng, fft_mode):
 
 
 @needs_emu
+def test_fft_line_passes_with_several_tiles_per_workgroup():
+    """Large grids run the line-pass kernel with fewer workgroups than tiles: each workgroup walks through its tiles and requests
+    the next one while it transforms the current one.  Forced at test size (3 workgroups per launch) in a process of its own,
+    because the launch geometry is read once."""
+    code = (
+        "import os, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "import kernel_cases as KC\n"
+        "from openmm_amd import capi\n"
+        "K = capi.load(%r)\n"
+        "for ng in ((28, 25, 30), (21, 20, 18), (8, 6, 10)):\n"
+        "    fwd, back = KC.run_fft(K, ng, fft_mode=1)\n"
+        "    assert fwd < 1e-5 and back < 1e-5, (ng, fwd, back)\n"
+        "f, e, f_or, e_or = KC.run_pme(K, 300, (20, 24, 28), 3.0, False)\n"
+        "import numpy as np\n"
+        "assert np.abs(f - f_or).max() / np.sqrt((f_or ** 2).sum(1).mean()) < 5e-5 and abs(e - e_or) < 1e-5 * abs(e_or) + 1e-4, (e, e_or)\n"
+        "print('OK')\n" % (ROOT, ROOT, EMU_LIB))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, OMMHIP_FFT_RESIDENT_WORKGROUPS="3"))
+    assert "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@needs_emu
 @pytest.mark.parametrize("tric", [False, True])
 def test_pme_logic(K, tric):
     f, e, f_or, e_or = KC.run_pme(K, 300, (20, 24, 28), 3.0, tric)

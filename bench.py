@@ -64,7 +64,7 @@ def parse_args():
     p.add_argument("--profile-every", type=int, default=7, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region")
     p.add_argument("--decompose", action="store_true", help="N = 1: run through the decomposed path with a one-rank RCCL communicator (overhead check on one GPU)")
     p.add_argument("--props", default="", help="extra HIP platform properties, e.g. DisablePmeStream=true")
-    p.add_argument("--attempt-timeout", type=float, default=420.0, help="N > 1: seconds a configuration may take before the launchers give up on it")
+    p.add_argument("--attempt-timeout", type=float, default=300.0, help="N > 1: seconds a configuration may take before the launchers give up on it")
     return p.parse_args()
 
 
@@ -124,6 +124,7 @@ def start_platform(w, platform, dt_ps, warmup, props=None, seed=1, prepare=0):
         ctx.setVelocities(w.velocities)          # equilibrated start (tests/golden fixture)
     else:
         ctx.setVelocitiesToTemperature(300.0, 1)
+    ctx.initial_potential_energy = ctx.getState(getEnergy=True).potentialEnergy      # same start on every platform / decomposition: a parity handle
     integ.step(prepare + warmup)
     ctx.getState(getEnergy=True)
     return system, nb, integ, ctx
@@ -205,6 +206,7 @@ def main():
         props.update(MR.domain_properties(dist, transport=transport, emulated=EMULATED))
     system, nb, integ, ctx = start_platform(w, "HIP", dt_ps, args.warmup, props, seed=1, prepare=prepare)
     device_name = ctx.getPlatformProperty("DeviceName")
+    e0_run = ctx.initial_potential_energy
     if decomposed:
         transport = ctx.getPlatformProperty("CommId")       # what the plugin actually uses
         if ctx.getPlatformProperty("DisablePmeStream") == "true":
@@ -357,7 +359,10 @@ def main():
         try:
             ssys, snb, sinteg, sctx = start_platform(w, "HIP", dt_ps, args.warmup, {"DeviceIndex": str(local_rank)}, seed=1, prepare=prepare)
             s_elapsed, s_st = timed_run(sinteg, sctx, args.steps, lambda: None)
-            out["single_gpu_same_box"] = {"value": round(MR.ns_per_day(s_elapsed, args.steps, args.dt_fs), 3), "unit": "ns/day",
+            e0_single = sctx.initial_potential_energy
+            out["single_gpu_same_box"] = {"initial_energy_kj_mol": {"decomposed": e0_run, "single_gpu": e0_single,
+                                                                    "rel_diff": abs(e0_run - e0_single) / max(abs(e0_single), 1.0)},
+                                          "value": round(MR.ns_per_day(s_elapsed, args.steps, args.dt_fs), 3), "unit": "ns/day",
                                           "ms_per_step": round(1e3 * s_elapsed / args.steps, 5), "steps": args.steps, "warmup": args.warmup,
                                           "prepare_steps": prepare, "note": "same System, same protocol, rank 0's GPU alone, measured after the decomposed run"}
             sctx.close()

@@ -235,3 +235,4 @@ def test_bench_multi_gpu_flow_on_emulator_falls_back_and_reports_one_line():
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 3 and out["value"] > 0
     assert "callback" in out["config"]["workload"] and len(out["config"]["attempts_failed"]) == 2
     assert out["single_gpu_same_box"]["value"] > 0
+    assert out["single_gpu_same_box"]["initial_energy_kj_mol"]["rel_diff"] < 1e-5      # the decomposed run starts from the same energy as one GPU

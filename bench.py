@@ -64,6 +64,7 @@ def parse_args():
     p.add_argument("--profile-every", type=int, default=7, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region")
     p.add_argument("--decompose", action="store_true", help="N = 1: run through the decomposed path with a one-rank RCCL communicator (overhead check on one GPU)")
     p.add_argument("--props", default="", help="extra HIP platform properties, e.g. DisablePmeStream=true")
+    p.add_argument("--serialize-ranks", action="store_true", help="diagnostics, gloo transport on one GPU: the ranks run their work between collectives one at a time, so each rank's compute time per step is measured on an idle GPU (per_rank_compute_ms_per_step); the wall-clock value is meaningless in this mode")
     p.add_argument("--attempt-timeout", type=float, default=300.0, help="N > 1: seconds a configuration may take before the launchers give up on it")
     return p.parse_args()
 
@@ -79,6 +80,8 @@ def supervise(args, rank, world):
         if not any(kv.startswith("DisablePmeStream=") for kv in extra):
             attempts.append(base + ["--transport", "rccl", "--props", ",".join(extra + ["DisablePmeStream=true"])])
     attempts.append(base + ["--transport", "gloo"])
+    if args.serialize_ranks:
+        os.environ["OMMHIP_COMM_DIAG"] = "1"          # inherited by the children
     say = lambda msg: print("bench.py launcher (rank %d): %s" % (rank, msg), file=sys.stderr, flush=True)
     idx, lines, notes = MR.run_attempts(attempts, rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")),
                                         args.attempt_timeout, log=say if rank == 0 else None)
@@ -203,7 +206,7 @@ def main():
         # ONE box over all ranks.  The plugin runs its own collectives (RCCL); the launcher only distributes the communicator id.
         # a failure here (or a collective that never returns) ends this child; the launchers then move to the next configuration
         transport = args.transport
-        props.update(MR.domain_properties(dist, transport=transport, emulated=EMULATED))
+        props.update(MR.domain_properties(dist, transport=transport, emulated=EMULATED, serialize=args.serialize_ranks and transport == "gloo"))
     system, nb, integ, ctx = start_platform(w, "HIP", dt_ps, args.warmup, props, seed=1, prepare=prepare)
     device_name = ctx.getPlatformProperty("DeviceName")
     e0_run = ctx.initial_potential_energy
@@ -223,7 +226,16 @@ def main():
     if profile:
         kernels.lib.ommhip_profile_reset()
         kernels.lib.ommhip_profile_enable(max(1, args.profile_every))
-    elapsed, st = timed_run(integ, ctx, args.steps, barrier)
+    serialized = decomposed and args.serialize_ranks and args.transport == "gloo"
+    if serialized:
+        barrier()
+        MR.serial_reset(EMULATED)
+    elapsed, st = timed_run(integ, ctx, args.steps, (lambda: None) if serialized else barrier)
+    if serialized:
+        compute_s = MR.serial_release(EMULATED)
+        mine = [1e3 * compute_s / args.steps, MR.SERIAL["collectives"] / float(args.steps), 1e3 * MR.SERIAL["segments_s"] / args.steps]
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
     if profile:
         kernels.lib.ommhip_profile_enable(0)
     elapsed = MR.max_over_ranks(elapsed, dist, device="cpu")
@@ -244,6 +256,12 @@ def main():
             "precision": "mixed (f32 forces, fixed-point accumulation, f64 integration)", "device": device_name,
             "prepare_steps": prepare},
     }
+    if serialized:
+        out["per_rank_compute_ms_per_step"] = {"ranks": [round(e[0], 4) for e in everyone], "collectives_per_step": everyone[0][1],
+                                               "including_host_staging": [round(e[2], 4) for e in everyone],
+                                               "note": "ranks serialized on ONE GPU (one rank's kernels at a time): each rank's wall time minus its time inside collectives, "
+                                                       "the latter counted from a device-wide synchronisation at their start -- i.e. its step without communication; "
+                                                       "`value` and ms_per_step are NOT a measurement in this mode"}
     if decomposed:
         out["config"]["parallelism"] = "dd%d (x slabs; all-gather of positions + 2 all-to-alls + halo planes per step)" % world
 

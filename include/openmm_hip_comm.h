@@ -65,6 +65,11 @@ int ommhip_comm_ring_exchange(ommhip_comm* comm, const void* send_down_d, void* 
  * same order, which makes sums bit-identical on all ranks. */
 int ommhip_comm_all_gather_host(ommhip_comm* comm, const void* send, void* recv, size_t bytes, void* stream);
 
+/* Diagnostics (callback transport, environment OMMHIP_COMM_DIAG=1): seconds spent inside collectives since the last reset,
+ * each counted from the moment the device is idle.  Used by bench.py --serialize-ranks to time a rank's step without
+ * communication on a box with fewer GPUs than ranks. */
+double ommhip_comm_diag_seconds(int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 #include "../../../include/openmm_hip_comm.h"
 
@@ -71,6 +72,21 @@ RcclApi& rccl_api() {
 inline int nccl_rc(ncclResult_t r) { return r == ncclSuccess ? 0 : 1000 + (int) r; }
 #define NCCL_TRY(call) do { int rc__ = nccl_rc(call); if (rc__ != 0) return rc__; } while (0)
 #endif
+
+// Diagnostics of the callback transport (OMMHIP_COMM_DIAG=1, bench.py --serialize-ranks): wall time spent inside collectives,
+// counted from the moment the device is idle -- staging copies, the callback and whatever the callback waits for.  A rank's wall
+// time minus this is its step without communication.
+double g_commSeconds = 0.0;
+struct CommDiag {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    CommDiag() {
+        static const bool enabled = getenv("OMMHIP_COMM_DIAG") != nullptr;
+        on = enabled;
+        if (on) { hipDeviceSynchronize(); t0 = std::chrono::steady_clock::now(); }
+    }
+    ~CommDiag() { if (on) g_commSeconds += 1e-9 * (double) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 // host staging of the callback transport: device -> pinned-less host vector (blocking), callback, host -> device
 int stage_down(ommhip_comm* c, const void* src_d, size_t bytes, size_t offset, hipStream_t st) {
@@ -179,6 +195,7 @@ int ommhip_comm_all_gather(ommhip_comm* c, void* buffer_d, size_t bytes, void* s
     }
 #endif
     if (c->size == 1) return 0;
+    CommDiag diag;
     int rc = stage_down(c, buf + (size_t) c->rank * bytes, bytes, 0, st);
     if (rc != 0) return rc;
     c->hostRecv.resize((size_t) c->size * bytes);
@@ -205,6 +222,7 @@ int ommhip_comm_all_to_all(ommhip_comm* c, const void* send_d, void* recv_d, siz
 #endif
     if (c->size == 1) return (int) hipMemcpyAsync(recv_d, send_d, bytes, hipMemcpyDeviceToDevice, st);
     // host transport: gather everybody's whole send buffer, keep the chunk addressed to this rank
+    CommDiag diag;
     const size_t all = (size_t) c->size * bytes;
     int rc = stage_down(c, s, all, 0, st);
     if (rc != 0) return rc;
@@ -241,6 +259,7 @@ int ommhip_comm_ring_exchange(ommhip_comm* c, const void* send_down_d, void* rec
         return 0;
     }
 #endif
+    CommDiag diag;
     const size_t rec = bytes_down + bytes_up;
     int rc = 0;
     if (bytes_down > 0) rc = stage_down(c, send_down_d, bytes_down, 0, st);
@@ -276,7 +295,14 @@ int ommhip_comm_all_gather_host(ommhip_comm* c, const void* send, void* recv, si
     }
 #endif
     (void) stream;
+    CommDiag diag;
     return c->fn(c->user, send, recv, bytes) != 0 ? 1 : 0;
+}
+
+double ommhip_comm_diag_seconds(int reset) {
+    const double v = g_commSeconds;
+    if (reset) g_commSeconds = 0.0;
+    return v;
 }
 
 }

@@ -158,32 +158,44 @@ __device__ __forceinline__ int cell_of(const NlArgs& a, float4 c) {
     return (cell_coord(c.x, a.cellInvX, a.ncx) * a.ncy + cell_coord(c.y, a.cellInvY, a.ncy)) * a.ncz + cell_coord(c.z, a.cellInvZ, a.ncz);
 }
 
+#define NL_BIN_CELLS 7168     // cells whose counters fit the binning workgroup's LDS (2 x 28 KB); the host never asks for more
+#define NL_BIN_BATCH 4        // blocks per thread whose boxes are requested before any is processed
+
 __global__ __launch_bounds__(1024) void nl_bin_blocks(NlArgs a) {
     if (a.state[ST_REBUILD] == 0) return;
+    // Counting sort of the blocks by cell, ONE workgroup, counters and cursors in LDS: with the counters in global memory every
+    // one of the ~100 dependent steps of a thread was an atomic round trip to L2 (180 us at 30 798 blocks).
+    __shared__ int count[NL_BIN_CELLS + 1];      // count[c + 1] = blocks in cell c, then prefix-summed in place: the CSR start array
+    __shared__ int cursor[NL_BIN_CELLS];
     __shared__ int partial[1024];
     __shared__ float hmax[3][16];
+    __shared__ int numBig;
     const int t = threadIdx.x, ncells = a.ncx * a.ncy * a.ncz;
-    int* count = a.cellStart;                 // count[c + 1] = blocks in cell c, then prefix-summed in place
-    int* cursor = a.cellStart + ncells + 1;
     for (int i = t; i <= ncells; i += 1024) count[i] = 0;
     for (int i = t; i < ncells; i += 1024) cursor[i] = 0;
-    __threadfence();
+    if (t == 0) numBig = 0;
     __syncthreads();
     // A handful of blocks have large bounding boxes (stragglers of the spatial sort); binning them would force every
     // block to search as far as the largest of them reaches.  They go to a short list that everybody scans instead.
-    __shared__ int numBig;
-    if (t == 0) numBig = 0;
-    __syncthreads();
     float hx = 0.f, hy = 0.f, hz = 0.f;
-    for (int b = t; b < a.numBlocks; b += 1024) {
-        const float4 h = a.blockHalf[b];
-        if (h.x > a.bigHalf || h.y > a.bigHalf || h.z > a.bigHalf) { a.cellBlocks[a.numBlocks + atomicAdd(&numBig, 1)] = b; continue; }
-        atomicAdd(&count[cell_of(a, a.blockCenter[b]) + 1], 1);
-        hx = fmaxf(hx, h.x); hy = fmaxf(hy, h.y); hz = fmaxf(hz, h.z);
+    for (int b0 = 0; b0 < a.numBlocks; b0 += 1024 * NL_BIN_BATCH) {
+        float4 h[NL_BIN_BATCH], c[NL_BIN_BATCH];
+#pragma unroll
+        for (int u = 0; u < NL_BIN_BATCH; u++) {
+            const int b = min(b0 + u * 1024 + t, a.numBlocks - 1);
+            h[u] = a.blockHalf[b]; c[u] = a.blockCenter[b];
+        }
+#pragma unroll
+        for (int u = 0; u < NL_BIN_BATCH; u++) {
+            const int b = b0 + u * 1024 + t;
+            if (b >= a.numBlocks) continue;
+            if (h[u].x > a.bigHalf || h[u].y > a.bigHalf || h[u].z > a.bigHalf) { a.cellBlocks[a.numBlocks + atomicAdd(&numBig, 1)] = b; continue; }
+            atomicAdd(&count[cell_of(a, c[u]) + 1], 1);
+            hx = fmaxf(hx, h[u].x); hy = fmaxf(hy, h[u].y); hz = fmaxf(hz, h[u].z);
+        }
     }
     hx = wave_max(hx); hy = wave_max(hy); hz = wave_max(hz);
     if ((t & 63) == 0) { hmax[0][t >> 6] = hx; hmax[1][t >> 6] = hy; hmax[2][t >> 6] = hz; }
-    __threadfence();
     __syncthreads();
     if (t < 3) {
         float m = 0.f;
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(1024) void nl_bin_blocks(NlArgs a) {
     // exclusive prefix sum of the counts: each thread owns a contiguous run of cells
     const int per = (ncells + 1023) / 1024, c0 = t * per, c1 = min(ncells, c0 + per);
     int sum = 0;
-    for (int c = c0; c < c1; c++) sum += atomicAdd(&count[c + 1], 0);
+    for (int c = c0; c < c1; c++) sum += count[c + 1];
     partial[t] = sum;
     __syncthreads();
     if (t == 0) {
@@ -203,18 +215,28 @@ __global__ __launch_bounds__(1024) void nl_bin_blocks(NlArgs a) {
     }
     __syncthreads();
     int run = partial[t];
-    for (int c = c0; c < c1; c++) { const int v = atomicAdd(&count[c + 1], 0); atomicExch(&count[c + 1], run + v); run += v; }
-    __threadfence();
+    for (int c = c0; c < c1; c++) { const int v = count[c + 1]; run += v; count[c + 1] = run; }
     __syncthreads();
     // after the scan count[c + 1] holds the END of cell c, i.e. count[] is the CSR start array (count[0] = 0)
-    for (int b = t; b < a.numBlocks; b += 1024) {
-        const float4 h = a.blockHalf[b];
-        if (h.x > a.bigHalf || h.y > a.bigHalf || h.z > a.bigHalf) continue;
-        const int c = cell_of(a, a.blockCenter[b]);
-        const int pos = atomicAdd(&count[c], 0) + atomicAdd(&cursor[c], 1);
-        a.cellBlocks[pos] = b;
-        a.cellBoxes[2 * pos] = a.blockCenter[b];          // copies in cell order: the scan streams them
-        a.cellBoxes[2 * pos + 1] = a.blockHalf[b];
+    for (int i = t; i <= ncells; i += 1024) a.cellStart[i] = count[i];
+    for (int b0 = 0; b0 < a.numBlocks; b0 += 1024 * NL_BIN_BATCH) {
+        float4 h[NL_BIN_BATCH], c[NL_BIN_BATCH];
+#pragma unroll
+        for (int u = 0; u < NL_BIN_BATCH; u++) {
+            const int b = min(b0 + u * 1024 + t, a.numBlocks - 1);
+            h[u] = a.blockHalf[b]; c[u] = a.blockCenter[b];
+        }
+#pragma unroll
+        for (int u = 0; u < NL_BIN_BATCH; u++) {
+            const int b = b0 + u * 1024 + t;
+            if (b >= a.numBlocks) continue;
+            if (h[u].x > a.bigHalf || h[u].y > a.bigHalf || h[u].z > a.bigHalf) continue;
+            const int cell = cell_of(a, c[u]);
+            const int pos = count[cell] + atomicAdd(&cursor[cell], 1);
+            a.cellBlocks[pos] = b;
+            a.cellBoxes[2 * pos] = c[u];          // copies in cell order: the scan streams them
+            a.cellBoxes[2 * pos + 1] = h[u];
+        }
     }
 }
 
@@ -735,7 +757,7 @@ NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
         int n[3];
         const double L[3] = {nl->box[0], nl->box[2], nl->box[5]};
         for (int d = 0; d < 3; d++) { n[d] = (int) floor(L[d] / rl); if (n[d] < 1) n[d] = 1; }
-        while ((long long) n[0] * n[1] * n[2] > nl->max_cells) {
+        while ((long long) n[0] * n[1] * n[2] > (nl->max_cells < NL_BIN_CELLS ? nl->max_cells : NL_BIN_CELLS)) {
             const int big = n[0] >= n[1] && n[0] >= n[2] ? 0 : (n[1] >= n[2] ? 1 : 2);
             n[big]--;
         }

@@ -52,20 +52,44 @@ def rccl_comm_id(dist, emulated=False):
     return ident[0]
 
 
-def gloo_all_gather_callback(dist, group=None):
-    """-> "callback:<fn>:<user>" CommId of the host-staged transport; the all-gather runs on `group` (a gloo group)."""
+SERIAL = {"on": False, "active": False, "armed": False, "segments_s": 0.0, "collectives": 0, "t_return": None, "dist": None, "group": None}
+
+
+def gloo_all_gather_callback(dist, group=None, serialize=False):
+    """-> "callback:<fn>:<user>" CommId of the host-staged transport; the all-gather runs on `group` (a gloo group).
+
+    serialize=True (diagnostics on a box with fewer GPUs than ranks): the ranks run their work between two collectives ONE AT A
+    TIME -- rank r leaves a collective only when rank r-1 has finished the work that follows it -- so each rank's segments are
+    timed on an otherwise idle GPU.  SERIAL["segments_s"] accumulates this rank's time between collectives (host clock, device
+    idle at both ends); call serial_release() after the last step so that the next rank can finish."""
     import numpy as np
     import torch
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+    SERIAL.update({"on": serialize, "dist": dist, "group": group})
+    token = torch.zeros(1, dtype=torch.int32)
 
     def all_gather(user, send, recv, nbytes):
         try:
+            active = serialize and SERIAL["active"]       # only between serial_reset() and serial_release(): no other collectives there
+            if active:
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()          # everything this rank queued since the last collective has run
+                SERIAL["segments_s"] += time.perf_counter() - SERIAL["t_return"]
+                if SERIAL["armed"] and rank + 1 < world:
+                    dist.send(token, dst=rank + 1, group=group)          # my segment is done: the next rank (waiting below) may run its own
+                SERIAL["collectives"] += 1
             src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
             dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(world * nbytes,))
             out = torch.empty(world * nbytes, dtype=torch.uint8)
             dist.all_gather_into_tensor(out, torch.from_numpy(src.copy()), group=group)
             dst[:] = out.numpy()
+            if active:
+                if rank > 0:
+                    dist.recv(token, src=rank - 1, group=group)              # wait until the rank before me has run its segment
+                SERIAL["armed"] = True
+                SERIAL["t_return"] = time.perf_counter()
             return 0
         except Exception as e:      # never let an exception cross the C boundary
             print("gloo all-gather callback failed:", e, flush=True)
@@ -75,7 +99,34 @@ def gloo_all_gather_callback(dist, group=None):
     return "callback:%d:0" % C.cast(fn, C.c_void_p).value
 
 
-def domain_properties(dist, transport="rccl", device_index=None, group=None, emulated=False):
+def serial_reset(emulated=False):
+    """Start of the measured region (call right after a barrier)."""
+    lib = _kernel_lib(emulated)
+    lib.ommhip_comm_diag_seconds.restype = C.c_double
+    lib.ommhip_comm_diag_seconds(1)
+    SERIAL["t_region"] = time.perf_counter()
+    SERIAL.update({"segments_s": 0.0, "collectives": 0, "t_return": time.perf_counter(), "active": SERIAL["on"], "armed": False})
+
+
+def serial_release(emulated=False):
+    """End of a serialized run: account the last segment and let the next rank finish its own.
+    -> this rank's wall time of the region minus the time inside collectives (seconds): its steps without communication."""
+    if not SERIAL["active"]:
+        return None
+    import torch
+    dist, group = SERIAL["dist"], SERIAL["group"]
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    SERIAL["segments_s"] += time.perf_counter() - SERIAL["t_return"]
+    if SERIAL["armed"] and dist.get_rank(group) + 1 < dist.get_world_size(group):
+        dist.send(torch.zeros(1, dtype=torch.int32), dst=dist.get_rank(group) + 1, group=group)
+    SERIAL.update({"active": False, "armed": False})
+    lib = _kernel_lib(emulated)
+    lib.ommhip_comm_diag_seconds.restype = C.c_double
+    return (time.perf_counter() - SERIAL["t_region"]) - lib.ommhip_comm_diag_seconds(0)
+
+
+def domain_properties(dist, transport="rccl", device_index=None, group=None, emulated=False, serialize=False):
     """Platform properties of this rank's Context in a decomposed run."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     props = {"Ranks": str(world), "Rank": str(rank)}
@@ -84,7 +135,7 @@ def domain_properties(dist, transport="rccl", device_index=None, group=None, emu
     if transport == "rccl":
         props["CommId"] = rccl_comm_id(dist, emulated)
     elif transport == "gloo":
-        props["CommId"] = gloo_all_gather_callback(dist, group)
+        props["CommId"] = gloo_all_gather_callback(dist, group, serialize)
     else:
         raise ValueError("unknown transport %r" % transport)
     return props

@@ -228,7 +228,11 @@ typedef struct ommhip_pme {
     const void* twiddle_x;     /* device float2[nx]: exp(-2 pi i k/nx) */
     const void* twiddle_y;
     const void* twiddle_z;
-    int spread_mode;           /* 0: LDS-staged bricks (default), 1: direct global atomics */
+    int spread_mode;           /* 0: LDS-staged bricks per 32-atom block, flushed with coalesced atomics (default for small grids and
+                                *    inside ommhip_force_front), 1: direct global atomics,
+                                * 2: grid tiles -- every 16^3 tile of the grid is accumulated in LDS by ONE workgroup from the atoms of the
+                                *    blocks that reach it and written once (no global atomics, no cleared grid needed); needs the tile_* and
+                                *    block_* fields below, a rectangular box and >= 32 cells per axis, else mode 0 is used */
     int grid_precleared;       /* 1: the caller zeroed grid_real on this stream already (fused clear), skip the memset */
     int fft_mode;              /* 0: fused (y,z) plane kernel when a plane fits in LDS (default), 1: always separate line passes */
     /* Optional: the Ewald exclusion correction (ReferenceLJCoulombIxn.cpp:462-523) folded into the interpolation
@@ -259,6 +263,13 @@ typedef struct ommhip_pme {
     void* grid_complex2;
     void* comm;                /* ommhip_comm* (openmm_hip_comm.h) */
     int* dd_error;
+    /* spread_mode 2: per tile of the spread range a counter and a list of the 32-atom blocks whose bounding box plus stencil
+     * reaches it, refilled every evaluation from the neighbour list's block boxes (ommhip_neighbor_list::block_center/half) */
+    int* tile_count;           /* device int[max_tiles] */
+    int* tile_blocks;          /* device int[max_tiles * tile_cap] */
+    int tile_cap, max_tiles;
+    const void* block_center;  /* device float4[padded_atoms / 32] */
+    const void* block_half;
 } ommhip_pme;
 enum { OMMHIP_PME_ALL = 0, OMMHIP_PME_SPREAD_ONLY = 1, OMMHIP_PME_AFTER_SPREAD = 2, OMMHIP_PME_INTERPOLATE_ONLY = 3 };
 

@@ -51,6 +51,9 @@ struct PmeArgs {
     int* ddError;
     const float4* blockCenter; const float4* blockHalf;
     float detScale;          // > 0: the grid is accumulated as int32 fixed point with this scale (deterministic sums), converted afterwards
+    // tile spreading (spread_mode 2): tiles of TILE^3 cells over the spread range (x: the own planes), ntx * nty * ntz of them
+    int* tileCount; int* tileBlocks; int tileCap, ntx, nty, ntz, numBlocks;
+    float tileScale;         // fixed-point scale of the LDS accumulation (a power of two)
 };
 
 // one grid accumulation: float atomic, or -- for bit-reproducible sums -- an integer atomic on the same word
@@ -311,6 +314,171 @@ template <bool DD>
 __global__ __launch_bounds__(256) void pme_spread_lds(PmeArgs a) {
     __shared__ SpreadShared sh;
     pme_spread_body<DD>(a, blockIdx.x, sh);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile spreading (spread_mode 2, systems too large for the fused front launch).  The brick scheme above turns an atom's 125
+// scattered atomics into line-coalesced ones, but every grid cell still receives ~17 global atomic transactions (one per
+// block whose brick covers it): 4.3 M line transactions for 30 798 blocks on a 192^3 grid.  Here the roles are swapped: ONE
+// workgroup owns a tile of TILE^3 cells, accumulates -- in LDS, 32-bit fixed point, integer LDS atomics -- every stencil
+// point that falls into it from the atoms of the 32-atom blocks whose bounding box plus stencil reaches the tile, and writes
+// the tile once with plain stores.  No global atomics, no zeroed grid, and sums that do not depend on the order of arrival.
+// pme_bin_tiles (one thread per block) fills the per-tile block lists every evaluation from the boxes nl_prepare keeps
+// current; a tile whose list overflows scans all blocks itself.  Rectangular boxes only (a block's cell range is then a box).
+// ------------------------------------------------------------------------------------------------
+#define TILE 16
+#define TILE_ZS (TILE + 1)
+#define TILE_WORDS (TILE * TILE * TILE_ZS)
+#define TILE_ATOMS 64         // atoms (two blocks) staged per round
+
+// cells [lo, hi] (unwrapped) that the stencils of block b's atoms can touch along one axis
+__device__ __forceinline__ void block_cell_range(float c, float h, float recip, int n, int& lo, int& hi) {
+    lo = (int) floorf((c - h) * recip * (float) n) - 1;
+    hi = (int) floorf((c + h) * recip * (float) n) + PME_ORDER;
+}
+// does the periodic image set of the cell interval [lo, hi] meet the tile's cells [t0, t1] (both in 0 .. n-1)?
+__device__ __forceinline__ bool range_meets_tile(int lo, int hi, int t0, int t1, int n) {
+    if (hi - lo + 1 >= n) return true;
+    // some k with lo <= t1 + k n and t0 + k n <= hi
+    const int kLo = (int) ceilf((float) (lo - t1) / (float) n), kHi = (int) floorf((float) (hi - t0) / (float) n);
+    return kHi >= kLo;
+}
+template <bool DD> __device__ __forceinline__ int tile_x_origin(const PmeArgs& a, int tx) { return (DD ? a.planeLo : 0) + tx * TILE; }
+template <bool DD> __device__ __forceinline__ int tile_x_end(const PmeArgs& a) { return DD ? a.planeLo + a.planeCount : a.nx; }
+
+template <bool DD>
+__global__ __launch_bounds__(256) void pme_bin_tiles(PmeArgs a) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= a.numBlocks) return;
+    const float4 c = a.blockCenter[b], h = a.blockHalf[b];
+    if (h.x < 0.f) return;                                     // empty block
+    int lo[3], hi[3];
+    block_cell_range(c.x, h.x, a.recip.r00, a.nx, lo[0], hi[0]);
+    block_cell_range(c.y, h.y, a.recip.r11, a.ny, lo[1], hi[1]);
+    block_cell_range(c.z, h.z, a.recip.r22, a.nz, lo[2], hi[2]);
+    unsigned long long mx = 0, my = 0, mz = 0;
+    const int xEnd = tile_x_end<DD>(a);
+    for (int t = 0; t < a.ntx; t++) { const int t0 = tile_x_origin<DD>(a, t), t1 = min(t0 + TILE, xEnd) - 1; if (range_meets_tile(lo[0], hi[0], t0, t1, a.nx)) mx |= 1ull << t; }
+    for (int t = 0; t < a.nty; t++) { const int t0 = t * TILE, t1 = min(t0 + TILE, a.ny) - 1; if (range_meets_tile(lo[1], hi[1], t0, t1, a.ny)) my |= 1ull << t; }
+    for (int t = 0; t < a.ntz; t++) { const int t0 = t * TILE, t1 = min(t0 + TILE, a.nz) - 1; if (range_meets_tile(lo[2], hi[2], t0, t1, a.nz)) mz |= 1ull << t; }
+    for (unsigned long long ix = mx; ix != 0; ix &= ix - 1) {
+        const int tx = __ffsll((long long) ix) - 1;
+        for (unsigned long long iy = my; iy != 0; iy &= iy - 1) {
+            const int ty = __ffsll((long long) iy) - 1;
+            for (unsigned long long iz = mz; iz != 0; iz &= iz - 1) {
+                const int tz = __ffsll((long long) iz) - 1;
+                const int tile = (tx * a.nty + ty) * a.ntz + tz;
+                const int pos = atomicAdd(&a.tileCount[tile], 1);
+                if (pos < a.tileCap) a.tileBlocks[(size_t) tile * a.tileCap + pos] = b;
+            }
+        }
+    }
+}
+
+struct TileShared {
+    int cells[TILE_WORDS];
+    float th[TILE_ATOMS][3][PME_ORDER];
+    int baseIdx[TILE_ATOMS][3];
+    float charge[TILE_ATOMS];
+};
+
+template <bool DD>
+__global__ __launch_bounds__(256) void pme_spread_tiles(PmeArgs a) {
+    __shared__ TileShared sh;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tile = blockIdx.x;
+    const int tz = tile % a.ntz, ty = (tile / a.ntz) % a.nty, tx = tile / (a.ntz * a.nty);
+    const int org[3] = {tile_x_origin<DD>(a, tx), ty * TILE, tz * TILE};
+    const int ext[3] = {min(TILE, tile_x_end<DD>(a) - org[0]), min(TILE, a.ny - org[1]), min(TILE, a.nz - org[2])};
+    const int n[3] = {a.nx, a.ny, a.nz};
+    for (int i = t; i < TILE_WORDS; i += 256) sh.cells[i] = 0;
+    const int listed = a.tileCount[tile];
+    const bool overflow = listed > a.tileCap;                  // more blocks than the list holds: look at every block
+    const int numCand = overflow ? a.numBlocks : listed;
+    const int ptA = lane, ptB = lane + 64;
+    const int ixA = ptA / 25, iyA = (ptA / 5) % 5, izA = ptA % 5;
+    const int ixB = ptB / 25, iyB = (ptB / 5) % 5, izB = ptB % 5;
+    const bool hasB = ptB < PME_ORDER * PME_ORDER * PME_ORDER;
+    for (int c0 = 0; c0 < numCand; c0 += TILE_ATOMS / 32) {
+        __syncthreads();                                       // the previous round's tables are done with (and the cells are zeroed)
+        // ---- splines: thread (atom, dimension); d = 3 carries the charge
+        {
+            const int atom = t >> 2, d = t & 3;
+            const int ci = c0 + (atom >> 5);
+            int blk = -1;
+            if (ci < numCand) blk = overflow ? ci : a.tileBlocks[(size_t) tile * a.tileCap + ci];
+            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (blk >= 0) p = a.posq[blk * 32 + (atom & 31)];
+            if (d == 3) sh.charge[atom] = p.w;
+            else if (p.w != 0.f) {
+                const float frac = d == 0 ? p.x * a.recip.r00 : (d == 1 ? p.y * a.recip.r11 : p.z * a.recip.r22);
+                int idx; float theta[PME_ORDER], dtheta[PME_ORDER];
+                bspline(frac, n[d], idx, theta, dtheta);
+                sh.baseIdx[atom][d] = idx;
+#pragma unroll
+                for (int k = 0; k < PME_ORDER; k++) sh.th[atom][d][k] = theta[k];
+            }
+        }
+        __syncthreads();
+        // ---- accumulate: each wavefront takes 16 atoms, one at a time; its lanes are the stencil points (l and l + 64)
+        for (int k = 0; k < TILE_ATOMS / 4; k++) {
+            const int atom = wave * (TILE_ATOMS / 4) + k;
+            const float q = sh.charge[atom];
+            if (q == 0.f) continue;                            // wave-uniform
+            int rel[3];
+            bool reaches = true;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                rel[d] = wrap_rel(sh.baseIdx[atom][d] - org[d], n[d]);        // base cell relative to the tile's origin, nearest image
+                reaches = reaches && rel[d] > -PME_ORDER && rel[d] < ext[d];
+            }
+            if (!reaches) continue;                            // wave-uniform: the atom's stencil misses this tile
+            const int cxA = rel[0] + ixA, cyA = rel[1] + iyA, czA = rel[2] + izA;
+            if (cxA >= 0 && cxA < ext[0] && cyA >= 0 && cyA < ext[1] && czA >= 0 && czA < ext[2])
+                atomicAdd(&sh.cells[(cxA * TILE + cyA) * TILE_ZS + czA], __float2int_rn(q * sh.th[atom][0][ixA] * sh.th[atom][1][iyA] * sh.th[atom][2][izA] * a.tileScale));
+            if (hasB) {
+                const int cxB = rel[0] + ixB, cyB = rel[1] + iyB, czB = rel[2] + izB;
+                if (cxB >= 0 && cxB < ext[0] && cyB >= 0 && cyB < ext[1] && czB >= 0 && czB < ext[2])
+                    atomicAdd(&sh.cells[(cxB * TILE + cyB) * TILE_ZS + czB], __float2int_rn(q * sh.th[atom][0][ixB] * sh.th[atom][1][iyB] * sh.th[atom][2][izB] * a.tileScale));
+            }
+        }
+    }
+    __syncthreads();
+    // ---- write the tile: consecutive threads -> consecutive z
+    const float invScale = 1.f / a.tileScale;
+    for (int i = t; i < TILE * TILE * TILE; i += 256) {
+        const int cz = i % TILE, cy = (i / TILE) % TILE, cx = i / (TILE * TILE);
+        if (cx < ext[0] && cy < ext[1] && cz < ext[2]) {
+            int gx = org[0] + cx; gx -= gx >= a.nx ? a.nx : 0;
+            const int px = spread_plane<DD>(a, gx);
+            a.grid[((size_t) px * a.ny + org[1] + cy) * a.nz + org[2] + cz] = (float) sh.cells[(cx * TILE + cy) * TILE_ZS + cz] * invScale;
+        }
+    }
+}
+
+// Launches the binning and the tile kernel when the evaluation qualifies; false = use the brick kernel.
+template <bool DD>
+static bool launch_tile_spread(const ommhip_pme* pme, PmeArgs pa, const void* block_center_d, const void* block_half_d, hipStream_t st) {
+    if (pme->spread_mode != 2 || pme->tile_count == nullptr || pme->tile_blocks == nullptr || block_center_d == nullptr || block_half_d == nullptr) return false;
+    if (pme->deterministic || pme->max_charge <= 0.0) return false;
+    if (pa.recip.r10 != 0.f || pa.recip.r20 != 0.f || pa.recip.r21 != 0.f) return false;
+    const int xCells = DD ? pa.planeCount : pa.nx;
+    if (pa.nx < 2 * TILE || pa.ny < 2 * TILE || pa.nz < 2 * TILE) return false;
+    pa.ntx = (xCells + TILE - 1) / TILE; pa.nty = (pa.ny + TILE - 1) / TILE; pa.ntz = (pa.nz + TILE - 1) / TILE;
+    const long long tiles = (long long) pa.ntx * pa.nty * pa.ntz;
+    if (pa.ntx > 64 || pa.nty > 64 || pa.ntz > 64 || tiles > pme->max_tiles || pme->tile_cap < 1) return false;
+    pa.tileCount = pme->tile_count; pa.tileBlocks = pme->tile_blocks; pa.tileCap = pme->tile_cap;
+    pa.blockCenter = (const float4*) block_center_d; pa.blockHalf = (const float4*) block_half_d;
+    pa.numBlocks = pa.paddedAtoms / 32;
+    // fixed-point scale: a power of two such that a cell's sum stays below 2^30 as long as sum |q w| <= 64 max|q|.  A cell collects
+    // from the atoms of the 5^3 cells below it (17 atoms in water at 0.11 nm spacing, ~60 at diamond density and 0.15 nm), each
+    // with a weight product of at most 0.22: <= 14 max|q| for any condensed-phase system -- the brick kernel's bound of 32 atoms
+    // stacked on one cell had the same form.  Resolution: max|q| 2^-24 per contribution, as float32 accumulation would give.
+    pa.tileScale = exp2f(floorf(30.f - log2f(64.f * (float) pme->max_charge)));
+    hipMemsetAsync(pa.tileCount, 0, sizeof(int) * (size_t) tiles, st);
+    hipLaunchKernelGGL(pme_bin_tiles<DD>, dim3((pa.numBlocks + 255) / 256), dim3(256), 0, st, pa);
+    hipLaunchKernelGGL(pme_spread_tiles<DD>, dim3((unsigned) tiles), dim3(256), 0, st, pa);
+    return true;
 }
 
 template <bool DD>
@@ -1092,12 +1260,14 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
 
     const int spreadBlocks = (padded_atoms * 8 + 255) / 256;
     if (pme->phases != OMMHIP_PME_AFTER_SPREAD && pme->phases != OMMHIP_PME_INTERPOLATE_ONLY) {
-        if (!pme->grid_precleared) hipMemsetAsync(pa.grid, 0, sizeof(float) * (size_t) nx * ny * nz, st);
         ommhip_profile_begin(OMMHIP_TIMER_PME_SPREAD, stream);
-        if (pme->spread_mode == 1)
-            hipLaunchKernelGGL(pme_spread, dim3(spreadBlocks), dim3(256), 0, st, pa);             // direct global atomics (reference variant)
-        else
-            hipLaunchKernelGGL(pme_spread_lds<false>, dim3((padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS), dim3(256), 0, st, pa);
+        if (!launch_tile_spread<false>(pme, pa, pme->block_center, pme->block_half, st)) {      // tiles write every cell: no cleared grid needed
+            if (!pme->grid_precleared) hipMemsetAsync(pa.grid, 0, sizeof(float) * (size_t) nx * ny * nz, st);
+            if (pme->spread_mode == 1)
+                hipLaunchKernelGGL(pme_spread, dim3(spreadBlocks), dim3(256), 0, st, pa);             // direct global atomics (reference variant)
+            else
+                hipLaunchKernelGGL(pme_spread_lds<false>, dim3((padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS), dim3(256), 0, st, pa);
+        }
         if (pa.detScale > 0.f) {
             const size_t n = (size_t) nx * ny * nz;
             hipLaunchKernelGGL(pme_fixed_to_float, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, pa.grid, n, 1.f / pa.detScale);
@@ -1194,10 +1364,12 @@ extern "C" int ommhip_pme_reciprocal_dd(const ommhip_pme* pme, const void* posq_
     const size_t planeBytes = sizeof(float) * (size_t) ny * nz;
 
     if (pme->phases != OMMHIP_PME_AFTER_SPREAD && pme->phases != OMMHIP_PME_INTERPOLATE_ONLY) {
-        if (!pme->grid_precleared) hipMemsetAsync(real, 0, planeBytes * (size_t) pa.gridPlanes, st);
         if (pa.blockCenter == nullptr || pa.blockHalf == nullptr) return 1;
         ommhip_profile_begin(OMMHIP_TIMER_PME_SPREAD, stream);
-        hipLaunchKernelGGL(pme_spread_lds<true>, dim3((padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS), dim3(256), 0, st, pa);
+        if (!launch_tile_spread<true>(pme, pa, block_center_d, block_half_d, st)) {
+            if (!pme->grid_precleared) hipMemsetAsync(real, 0, planeBytes * (size_t) pa.gridPlanes, st);
+            hipLaunchKernelGGL(pme_spread_lds<true>, dim3((padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS), dim3(256), 0, st, pa);
+        }
         ommhip_profile_end(OMMHIP_TIMER_PME_SPREAD, stream);
     }
     if (pme->phases == OMMHIP_PME_SPREAD_ONLY) return (int) hipGetLastError();

@@ -463,7 +463,8 @@ static vector<HipCalcNonbondedForceKernel*> liveNonbondedKernels;
 
 HipCalcNonbondedForceKernel::HipCalcNonbondedForceKernel(string name, const Platform& platform, HipPlatform::PlatformData& data) :
         CalcNonbondedForceKernel(name, platform), data(data), hip(*data.hip), numParticles(0), num14(0), numExclusionPairs(0),
-        slotParamsDirty(true), forceRebuild(true), etermDirty(true), hasInitializedParams(false), pinnedState(NULL), stateCopyPending(false) {
+        slotParamsDirty(true), forceRebuild(true), etermDirty(true), hasInitializedParams(false), pinnedState(NULL), stateCopyPending(false),
+        maxCharge(0.0), maxChargeDirty(true) {
     memset(&nl, 0, sizeof(nl));
     memset(&params, 0, sizeof(params));
     memset(&pme, 0, sizeof(pme));
@@ -567,7 +568,7 @@ void HipCalcNonbondedForceKernel::setupPmeDecomposed() {
     eterm.allocate(sizeof(float) * (size_t) nx * nyl * nzc);
     const size_t gridBytes = (sizeof(float) * (size_t) (nxl + 2 * ddHalo + 4) * ny * nz + 15) / 16 * 16;
     gridReal.allocate(gridBytes);
-    if (hip.extraClearPtr == NULL) { hip.extraClearPtr = gridReal.ptr; hip.extraClearBytes = gridBytes; pme.grid_precleared = 1; }
+    if (!enableTileSpread(nx, ny, nz) && hip.extraClearPtr == NULL) { hip.extraClearPtr = gridReal.ptr; hip.extraClearBytes = gridBytes; pme.grid_precleared = 1; }
     gridComplex.allocate(sizeof(float) * 2 * (size_t) nxl * ny * nzc);
     gridComplex2.allocate(sizeof(float) * 2 * (size_t) nx * nyl * nzc);
     ddError.allocate(sizeof(int) * 4);
@@ -927,6 +928,22 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     hip.sync();
 }
 
+bool HipCalcNonbondedForceKernel::enableTileSpread(int nx, int ny, int nz) {
+    // Opt-in (OPENMM_HIP_TILE_SPREAD_MIN_ATOMS=n): spread the charges by grid tiles (ommhip_pme::spread_mode 2) -- one workgroup
+    // per 16^3 cells gathers what lands in it, no global atomics and no grid to clear.  Correct and tested, but measured SLOWER
+    // than the brick kernel in this form ("tried and not kept": 446 vs 50 us at 92 k atoms, 837 vs 433 us at 1M), so
+    // it is off unless asked for.  The kernel library falls back to the brick kernel by itself when the evaluation does not
+    // qualify (triclinic box, fewer than 32 cells on an axis).
+    const int minAtoms = getenv("OPENMM_HIP_TILE_SPREAD_MIN_ATOMS") != NULL ? atoi(getenv("OPENMM_HIP_TILE_SPREAD_MIN_ATOMS")) : 2147483647;
+    if (numParticles < minAtoms || hip.deterministicForces || getenv("OPENMM_HIP_PME_SPREAD_DIRECT") != NULL || min(nx, min(ny, nz)) < 32) return false;
+    const int tiles = ((nx + 15) / 16) * ((ny + 15) / 16) * ((nz + 15) / 16);
+    const int cap = 384;        // blocks per tile list; water: ~110
+    tileCount.allocate(sizeof(int) * (size_t) tiles);
+    tileBlocks.allocate(sizeof(int) * (size_t) tiles * cap);
+    pme.spread_mode = 2; pme.tile_count = tileCount.as<int>(); pme.tile_blocks = tileBlocks.as<int>(); pme.tile_cap = cap; pme.max_tiles = tiles;
+    return true;
+}
+
 void HipCalcNonbondedForceKernel::setupPme() {
     const int nx = gridSize[0], ny = gridSize[1], nz = gridSize[2], nzc = nz / 2 + 1;
     uploadVector(moduliX, bsplineModuli(nx), hip.stream);
@@ -942,7 +959,8 @@ void HipCalcNonbondedForceKernel::setupPme() {
     eterm.allocate(sizeof(float) * (size_t) nx * ny * nzc);
     const size_t gridBytes = (sizeof(float) * (size_t) nx * ny * nz + 15) / 16 * 16;
     gridReal.allocate(gridBytes);
-    if (hip.extraClearPtr == NULL) {
+    pme.spread_mode = getenv("OPENMM_HIP_PME_SPREAD_DIRECT") != NULL ? 1 : 0;    // A/B knob: direct global atomics
+    if (!enableTileSpread(nx, ny, nz) && hip.extraClearPtr == NULL) {
         // the context zeroes this grid together with the force buffer at the start of every evaluation
         hip.extraClearPtr = gridReal.ptr;
         hip.extraClearBytes = gridBytes;
@@ -953,7 +971,6 @@ void HipCalcNonbondedForceKernel::setupPme() {
     pme.moduli_x = moduliX.as<double>(); pme.moduli_y = moduliY.as<double>(); pme.moduli_z = moduliZ.as<double>();
     pme.eterm = eterm.ptr; pme.grid_real = gridReal.ptr; pme.grid_complex = gridComplex.ptr;
     pme.twiddle_x = twiddleX.ptr; pme.twiddle_y = twiddleY.ptr; pme.twiddle_z = twiddleZ.ptr;
-    pme.spread_mode = getenv("OPENMM_HIP_PME_SPREAD_DIRECT") != NULL ? 1 : 0;    // A/B knob: direct global atomics
     etermDirty = true;
 }
 
@@ -1070,6 +1087,7 @@ void HipCalcNonbondedForceKernel::computeParameters(ContextImpl& context, bool f
     hasInitializedParams = true;
     vector<double> sigmas(numParticles), epsilons(numParticles);
     charges.resize(numParticles);
+    maxChargeDirty = true;
     for (int i = 0; i < numParticles; i++) { charges[i] = baseParticleParams[i][0]; sigmas[i] = baseParticleParams[i][1]; epsilons[i] = baseParticleParams[i][2]; }
     for (map<pair<string, int>, vector<double> >::const_iterator it = particleParamOffsets.begin(); it != particleParamOffsets.end(); ++it) {
         double value = lastGlobalValues[it->first.first];
@@ -1115,9 +1133,13 @@ void HipCalcNonbondedForceKernel::fillPmeStruct() {
     pme.excl_atoms = exclAtoms.as<int>(); pme.atom_of_slot = hip.atomOfSlot.as<int>();
     pme.pos = hip.pos.ptr; pme.charge = chargeD.as<double>(); pme.excl_periodic = exceptionsArePeriodic ? 1 : 0;
     pme.deterministic = hip.deterministicForces ? 1 : 0;
-    pme.max_charge = 0;
-    if (hip.deterministicForces)
-        for (size_t i = 0; i < charges.size(); i++) pme.max_charge = max(pme.max_charge, fabs(charges[i]));
+    pme.block_center = blockCenter.ptr; pme.block_half = blockHalf.ptr;
+    if (maxChargeDirty) {          // fixed-point scales of the deterministic grid and of the tile spreading
+        maxCharge = 0;
+        for (size_t i = 0; i < charges.size(); i++) maxCharge = max(maxCharge, fabs(charges[i]));
+        maxChargeDirty = false;
+    }
+    pme.max_charge = maxCharge;
     if (etermDirty) {
         HIP_CHECK(ommhip_pme_build_eterm(&pme, hip.stream));
         etermDirty = false;

@@ -167,7 +167,10 @@ private:
     // device
     DeviceBuffer chargeD, sigmaD, epsilonD, posq, posqRef, posqRel, sigEps, exclStart, exclAtoms, nlState, blockCenter, blockHalf, chunkInfo, rowJ, rowMask;
     DeviceBuffer exceptionAtomsD, exceptionParamsD, exclusionPairsD, ewaldStructure;
-    DeviceBuffer moduliX, moduliY, moduliZ, eterm, gridReal, gridComplex, twiddleX, twiddleY, twiddleZ;
+    DeviceBuffer moduliX, moduliY, moduliZ, eterm, gridReal, gridComplex, twiddleX, twiddleY, twiddleZ, tileCount, tileBlocks;
+    double maxCharge;
+    bool maxChargeDirty;
+    bool enableTileSpread(int nx, int ny, int nz);
     ommhip_neighbor_list nl;
     ommhip_nonbonded_params params;
     ommhip_pme pme;

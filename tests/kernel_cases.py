@@ -200,12 +200,23 @@ def run_fft(K, ng, seed=1, fft_mode=0):
     return fwd, float(np.abs(back / np.prod(ng) - g).max())
 
 
-def run_pme(K, n, ng, L, triclinic=False, seed=2, alpha=2.6):
+def run_pme(K, n, ng, L, triclinic=False, seed=2, alpha=2.6, tiles=None, sort_cell=None, shift=0.0):
+    """tiles=(cap,): spread_mode 2 (one workgroup per 16^3 grid tile gathers the atoms of the blocks that reach it) with per-tile
+    block lists of `cap` entries (a small cap forces the scan-everything path); sort_cell: slots sorted along a Morton curve so
+    that blocks are compact; shift: all coordinates moved by this many box lengths (blocks outside the primary cell)."""
     rng = np.random.default_rng(seed)
     box3 = np.eye(3) * L
     if triclinic:
         box3 = np.array([[L, 0, 0], [0.2 * L, 0.9 * L, 0], [-0.3 * L, 0.25 * L, 1.1 * L]])
     pos = rng.random((n, 3)) @ box3
+    if sort_cell is not None:
+        cell = np.floor(pos / sort_cell).astype(np.int64)
+        key = np.zeros(n, np.int64)
+        for bit in range(8):
+            for d in range(3):
+                key |= ((cell[:, d] >> bit) & 1) << (3 * bit + d)
+        pos = pos[np.argsort(key, kind="stable")]
+    pos = pos + shift * L
     q = rng.normal(0, 0.5, n)
     q -= q.mean()
     padded = (n + 31) // 32 * 32
@@ -214,6 +225,20 @@ def run_pme(K, n, ng, L, triclinic=False, seed=2, alpha=2.6):
     posq[:n, 3] = q
     d_posq, d_f, d_e = K.upload(posq), K.upload(np.zeros(3 * padded, np.int64)), K.upload(np.zeros(64))
     pm = make_pme(K, ng, box3, alpha)
+    if tiles is not None:
+        nb = padded // 32
+        center, half = np.zeros((nb, 4), np.float32), np.full((nb, 4), -1e30, np.float32)
+        for b in range(nb):
+            p = posq[b * 32:min((b + 1) * 32, n), :3]
+            if len(p):
+                center[b, :3] = 0.5 * (p.min(0) + p.max(0))
+                half[b, :3] = 0.5 * (p.max(0) - p.min(0)) + 1e-6
+        ntiles = int(np.prod([(g + 15) // 16 for g in ng]))
+        pm.spread_mode, pm.tile_cap, pm.max_tiles = 2, tiles[0], ntiles
+        pm.tile_count, pm.tile_blocks = K.upload(np.zeros(ntiles, np.int32)), K.upload(np.zeros(ntiles * tiles[0], np.int32))
+        pm.block_center, pm.block_half = K.upload(center), K.upload(half)
+        pm.max_charge = float(np.abs(q).max())
+        K.memset(pm.grid_real, 0x55, 4 * ng[0] * ng[1] * ng[2], None)        # tiles must write every cell: start from a dirty grid
     K.pme_build_eterm(C.byref(pm), None)
     K.pme_reciprocal(C.byref(pm), d_posq, padded, d_f, d_e, 64, 1, None)
     f = K.download(d_f, (3, padded), np.int64).astype(np.float64) / 2 ** 32

@@ -109,6 +109,50 @@ def test_fft_logic(K, ng, fft_mode):
 
 
 @needs_emu
+@pytest.mark.parametrize("kw", [dict(tiles=(64,)), dict(tiles=(2,)), dict(tiles=(64,), shift=-1.0), dict(tiles=(64,), sort_cell=None, n=1000, ng=(32, 32, 32), L=3.0)])
+def test_pme_spreading_by_grid_tiles(K, kw):
+    """spread_mode 2: one workgroup per 16^3 grid tile gathers the stencil points of the atoms of the blocks that reach it
+    (per-tile block lists from the blocks' bounding boxes) and writes the tile once -- from a dirty grid, with lists that hold
+    everything, with lists of 2 entries (the scan-everything path), with all atoms one box length away from the primary cell, and
+    with unsorted atoms (every block reaches every tile).  Forces / energy against the float64 oracle."""
+    args = dict(n=3000, ng=(40, 36, 50), L=4.0, sort_cell=0.4)
+    args.update(kw)
+    f, e, f_or, e_or = KC.run_pme(K, args.pop("n"), args.pop("ng"), args.pop("L"), **args)
+    assert np.abs(f - f_or).max() / np.sqrt((f_or ** 2).sum(1).mean()) < 2e-5
+    assert abs(e - e_or) < 5e-6 * abs(e_or)
+
+
+@needs_emu
+def test_tile_spreading_through_the_platform():
+    """The platform's own wiring of the tile spreading (block boxes from the neighbour list, no pre-cleared grid), forced at test
+    size: same forces as the brick kernel to float32 noise."""
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from openmm_amd import harness as H, testsystems as T\n"
+        "H.load_hip_platform(emulated=True)\n"
+        "w = T.water_box(8, seed=5)\n"
+        "w.pme_params = (float(np.sqrt(-np.log(2 * w.ewald_tol)) / w.cutoff), 32, 32, 36)\n"
+        "def forces(env):\n"
+        "    os.environ.update(env)\n"
+        "    s, nb = w.build()\n"
+        "    c = H.Context(s, H.Integrator(H.VERLET, 0.001), 'HIP')\n"
+        "    c.setPositions(w.positions)\n"
+        "    st = c.getState(getForces=True, getEnergy=True)\n"
+        "    c.close()\n"
+        "    for k in env: os.environ.pop(k)\n"
+        "    return st\n"
+        "a, b = forces({}), forces({'OPENMM_HIP_TILE_SPREAD_MIN_ATOMS': '1'})\n"
+        "rms = np.sqrt((a.forces ** 2).sum(1).mean())\n"
+        "d = np.abs(a.forces - b.forces).max() / rms\n"
+        "assert 0 < d < 1e-5, d          # not zero: the two kernels round differently\n"
+        "assert abs(a.potentialEnergy - b.potentialEnergy) < 0.01\n"
+        "print('OK')\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@needs_emu
 def test_fft_line_passes_with_several_tiles_per_workgroup():
     """Large grids run the line-pass kernel with fewer workgroups than tiles: each workgroup walks through its tiles and requests
     the next one while it transforms the current one.  Forced at test size (3 workgroups per launch) in a process of its own,

@@ -124,3 +124,12 @@ def test_cell_binned_list_is_complete(K, n, cutoff, box, sort_cell):
     assert missing == 0 and dup == 0 and true_pairs > 100000
     missing0, dup0, _, entries0, _ = KC.run_list_completeness(K, n, cutoff, box, sort_cell, cells=False, seed=n % 7)
     assert missing0 == 0 and dup0 == 0 and entries0 == entries
+
+
+@pytest.mark.parametrize("kw", [dict(tiles=(128,)), dict(tiles=(4,)), dict(tiles=(128,), shift=1.0)])
+def test_pme_spreading_by_grid_tiles(K, kw):
+    """spread_mode 2 (one workgroup per 16^3 grid tile, written once, no global atomics) against the float64 oracle: 20 000 atoms
+    on a 64 x 60 x 72 grid, lists that hold everything, lists of 4 entries (scan-everything path), atoms one box length away."""
+    f, e, f_or, e_or = KC.run_pme(K, 20000, (64, 60, 72), 6.4, sort_cell=0.4, **kw)
+    assert np.abs(f - f_or).max() / np.sqrt((f_or ** 2).sum(1).mean()) < 2e-5
+    assert abs(e - e_or) < 5e-6 * abs(e_or)

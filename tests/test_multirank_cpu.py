@@ -116,7 +116,10 @@ def run(props, w, steps):
 
 
 os.environ["OPENMM_HIP_REORDER_INTERVAL"] = "3"      # a re-sort (units change owner) inside the short run
-for label, w, grid in (("water", T.water_box(8, seed=5), 24), ("solvated chain", T.small_solvated_chain(seed=3), 24)):
+for label, w, grid in (("water", T.water_box(8, seed=5), 32), ("solvated chain", T.small_solvated_chain(seed=3), 24)):
+    # water on a 32^3 grid with the tile spreading forced: 16 own planes per rank = one tile along x, clipped to the slab
+    if grid >= 32: os.environ["OPENMM_HIP_TILE_SPREAD_MIN_ATOMS"] = "1"
+    else: os.environ.pop("OPENMM_HIP_TILE_SPREAD_MIN_ATOMS", None)
     if grid:
         w.pme_params = (float(np.sqrt(-np.log(2 * w.ewald_tol)) / w.cutoff), grid, grid, grid)
     w.cm_remover = True

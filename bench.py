@@ -23,7 +23,8 @@ times its slab.)  --workload overrides either default.  The line also carries `s
 on its GPU alone after the timed region (the other ranks wait), so every N > 1 line holds its own N = 1 reference.
 The process torch.distributed.run starts on each rank is only a launcher: the measurement runs in a child process
 (multirank.run_attempts), first with RCCL and reciprocal space on its own stream + communicator, then -- only if that
-attempt fails or never returns on some rank -- with RCCL on a single stream, and last with host-staged gloo collectives; the
+attempt fails or never returns on some rank -- with RCCL on a single stream and ncclAllGather instead of direct sends, and
+last with host-staged gloo collectives; the
 configuration that ran is named in config.workload and the failed attempts are listed in config.attempts_failed.
 
 Rank 0 prints ONE JSON line with the contract fields plus `roofline` (the direct-space pair kernel -- on the fused
@@ -78,7 +79,8 @@ def supervise(args, rank, world):
     if args.transport == "rccl":
         attempts.append(base + ["--transport", "rccl"])
         if not any(kv.startswith("DisablePmeStream=") for kv in extra):
-            attempts.append(base + ["--transport", "rccl", "--props", ",".join(extra + ["DisablePmeStream=true"])])
+            # the most conservative RCCL configuration: one stream, one communicator, ncclAllGather instead of the direct sends
+            attempts.append((base + ["--transport", "rccl", "--props", ",".join(extra + ["DisablePmeStream=true"])], {"OPENMM_HIP_ALLGATHER": "ring"}))
     attempts.append(base + ["--transport", "gloo"])
     if args.serialize_ranks:
         os.environ["OMMHIP_COMM_DIAG"] = "1"          # inherited by the children

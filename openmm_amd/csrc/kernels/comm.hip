@@ -189,8 +189,24 @@ int ommhip_comm_all_gather(ommhip_comm* c, void* buffer_d, size_t bytes, void* s
     hipStream_t st = (hipStream_t) stream;
     char* buf = (char*) buffer_d;
 #ifndef OMMHIP_EMU
-    if (c->rccl) {      // also with one rank: a single-GPU run with a communicator exercises the real transport
-        NCCL_TRY(rccl_api().allGather(buf + (size_t) c->rank * bytes, buf, bytes, ncclChar, (ncclComm_t) c->nccl, st));
+    if (c->rccl) {
+        // xGMI is point-to-point: every pair of the node's GPUs has a link of its own.  A ring all-gather pushes (N-1)/N of the
+        // whole buffer through each link, hop after hop; sending this rank's part straight to its N-1 peers (one grouped
+        // send/recv, the primitive the all-to-all uses) moves 1/N of it over each of the N-1 links at the same time, one hop.
+        // OPENMM_HIP_ALLGATHER=ring selects ncclAllGather (also used with one rank, where it exercises the real transport).
+        static const bool ring = getenv("OPENMM_HIP_ALLGATHER") != nullptr && strcmp(getenv("OPENMM_HIP_ALLGATHER"), "ring") == 0;
+        RcclApi& api = rccl_api();
+        if (ring || c->size == 1) {
+            NCCL_TRY(api.allGather(buf + (size_t) c->rank * bytes, buf, bytes, ncclChar, (ncclComm_t) c->nccl, st));
+            return 0;
+        }
+        NCCL_TRY(api.groupStart());
+        for (int p = 0; p < c->size; p++) {
+            if (p == c->rank) continue;
+            NCCL_TRY(api.send(buf + (size_t) c->rank * bytes, bytes, ncclChar, p, (ncclComm_t) c->nccl, st));
+            NCCL_TRY(api.recv(buf + (size_t) p * bytes, bytes, ncclChar, p, (ncclComm_t) c->nccl, st));
+        }
+        NCCL_TRY(api.groupEnd());
         return 0;
     }
 #endif

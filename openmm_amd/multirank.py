@@ -161,7 +161,7 @@ STORE_PORT_OFFSET = 17      # the launchers' own store; children rendezvous on M
 def run_attempts(commands, rank, world, master_addr, master_port, timeout_s, env=None, poll_s=0.2, log=None):
     """Run commands[0] as a child process on every rank; if it fails, hangs past `timeout_s` or fails on ANY other rank, kill
     this rank's child (its exact pid) and try commands[1], and so on.  Children get MASTER_PORT = master_port + 1 + attempt and
-    BENCH_ATTEMPT = attempt in their environment.  -> (attempt index, stdout lines of this rank's child, [failure notes]);
+    BENCH_ATTEMPT = attempt in their environment; a command may be a pair (argv, {extra environment}).  -> (attempt index, stdout lines of this rank's child, [failure notes]);
     raises RuntimeError when every command failed."""
     from datetime import timedelta
     import torch.distributed as dist
@@ -169,7 +169,11 @@ def run_attempts(commands, rank, world, master_addr, master_port, timeout_s, env
                           wait_for_workers=True)
     notes = []
     for i, cmd in enumerate(commands):
+        extra_env = {}
+        if isinstance(cmd, tuple):            # (argv, {environment of this attempt})
+            cmd, extra_env = cmd
         child_env = dict(os.environ if env is None else env)
+        child_env.update(extra_env)
         # torch.distributed.run tells its workers to rendezvous through the agent's own store; the children form a group of their own
         child_env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
         child_env.update({"MASTER_ADDR": master_addr, "MASTER_PORT": str(master_port + 1 + i), "BENCH_ATTEMPT": str(i), "BENCH_CHILD": "1"})

@@ -53,7 +53,7 @@ def test_one_rank_with_rccl_reproduces_the_single_gpu_run(n_side, grid):
 
 def test_two_ranks_sharing_the_gpu_reproduce_the_single_gpu_run(tmp_path):
     from test_multirank_cpu import _run_dd_child
-    out = _run_dd_child(tmp_path, False, 0, 10, 29561)
+    out = _run_dd_child(tmp_path, False, 0, 10, 29561, extra_cases='(("water, tile spreading", T.water_box(8, seed=5), 32),)')
     print(out)
 
 

@@ -116,9 +116,11 @@ def run(props, w, steps):
 
 
 os.environ["OPENMM_HIP_REORDER_INTERVAL"] = "3"      # a re-sort (units change owner) inside the short run
-for label, w, grid in (("water", T.water_box(8, seed=5), 32), ("solvated chain", T.small_solvated_chain(seed=3), 24)):
-    # water on a 32^3 grid with the tile spreading forced: 16 own planes per rank = one tile along x, clipped to the slab
-    if grid >= 32: os.environ["OPENMM_HIP_TILE_SPREAD_MIN_ATOMS"] = "1"
+EXTRA_CASES = %s
+for label, w, grid in (("water", T.water_box(8, seed=5), 24), ("solvated chain", T.small_solvated_chain(seed=3), 24)) + EXTRA_CASES:
+    # a 32^3 grid marks the case that runs with the (opt-in) tile spreading: 16 own planes per rank = one tile along x, clipped to the slab
+    tiles = grid is not None and grid >= 32
+    if tiles: os.environ["OPENMM_HIP_TILE_SPREAD_MIN_ATOMS"] = "1"
     else: os.environ.pop("OPENMM_HIP_TILE_SPREAD_MIN_ATOMS", None)
     if grid:
         w.pme_params = (float(np.sqrt(-np.log(2 * w.ewald_tol)) / w.cutoff), grid, grid, grid)
@@ -134,7 +136,8 @@ for label, w, grid in (("water", T.water_box(8, seed=5), 32), ("solvated chain",
     assert abs(dd0.potentialEnergy - one0.potentialEnergy) < 1e-6 * abs(one0.potentialEnergy) + 1e-3, (dd0.potentialEnergy, one0.potentialEnergy)
     dpos = np.abs(dd1.positions - one1.positions).max()
     dvel = np.abs(dd1.velocities - one1.velocities).max()
-    assert dpos < 3e-7 and dvel < 5e-5, ("trajectory", dpos, dvel)      # float32 force noise (1e-5 of the RMS force) integrated over the run
+    # float32 force noise (1e-5 of the RMS force) integrated over the run; the tile spreading rounds each contribution to max|q| 2^-24
+    assert dpos < 3e-7 and dvel < (1.5e-4 if tiles else 5e-5), ("trajectory", dpos, dvel)
     assert abs(dd1.kineticEnergy - one1.kineticEnergy) < 1e-6 * one1.kineticEnergy
     err1 = np.abs(dd1.forces - one1.forces).max() / rms
     assert err1 < 1e-4, ("final forces", err1)
@@ -151,9 +154,10 @@ dist.destroy_process_group()
 '''
 
 
-def _run_dd_child(tmp_path, emulated, device, steps, port, nproc=2, cases=None):
+def _run_dd_child(tmp_path, emulated, device, steps, port, nproc=2, cases=None, extra_cases="()"):
+    """extra_cases: Python source of a tuple of further (label, workload, grid) cases; a grid >= 32 runs with tile spreading."""
     script = tmp_path / "dd_child.py"
-    text = DD_CHILD % (ROOT, emulated, device, steps, emulated, steps)
+    text = DD_CHILD % (ROOT, emulated, device, extra_cases, steps, emulated, steps)
     if cases is not None:
         text = text.replace('(("water", T.water_box(8, seed=5), 24), ("solvated chain", T.small_solvated_chain(seed=3), 24))', cases)
     script.write_text(text)
@@ -174,7 +178,7 @@ def test_two_rank_domain_decomposition_whole_step_on_emulator(tmp_path):
     from conftest import EMU_BUILD
     if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
         pytest.skip("emulated plugin not built (run __graft_entry__.build())")
-    _run_dd_child(tmp_path, True, None, 4, 29547)
+    _run_dd_child(tmp_path, True, None, 4, 29547, extra_cases='(("water, tile spreading", T.water_box(8, seed=5), 32),)')
 
 
 def test_four_rank_domain_decomposition_on_emulator(tmp_path):

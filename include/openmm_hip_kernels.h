@@ -416,8 +416,11 @@ enum { OMMHIP_INTEGRATOR_VERLET = 0, OMMHIP_INTEGRATOR_LANGEVIN = 1, OMMHIP_INTE
 int ommhip_integrate_fused(int integrator, const ommhip_integrator_state* s, const ommhip_step_units* u, void* stream);
 /* out_d (double4[num_atoms]) = vel + force*shift/m   (ReferenceKernels.cpp:146-160) */
 int ommhip_shifted_velocities(const ommhip_integrator_state* s, double shift, void* out_d, void* stream);
-/* result_d[0] = 1/2 sum m v^2 */
-int ommhip_kinetic_energy(const void* vel_d, int num_atoms, double* result_d, void* stream);
+/* result_d[0] = 1/2 sum m v^2 (ReferenceKernels.cpp:161-175) over the atoms [first, end) -- or, with atom_of_slot_d given, over the
+ * atoms in the slots [first, end) (negative entries = empty slots): a rank's own atoms in a decomposed run.
+ * scratch_d: OMMHIP_KE_SCRATCH doubles (partial sums of the first launch; fixed summation order). */
+#define OMMHIP_KE_SCRATCH 1024
+int ommhip_kinetic_energy(const void* vel_d, const int* atom_of_slot_d, int first, int end, double* scratch_d, double* result_d, void* stream);
 
 /* SETTLE: atoms_d int4[n] (apex,b,c,-), dist_d double2[n] (apex-leg, base).  velocities=0: corrects
  * target_d (trial positions) against pos_d; velocities=1: corrects target_d (velocities). */

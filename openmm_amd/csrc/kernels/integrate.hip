@@ -178,13 +178,29 @@ __global__ void k_shifted_velocities(IntArgs a, double shift, double4* out) {
     }
     out[i] = v;
 }
-__global__ __launch_bounds__(256) void k_kinetic_energy(const double4* __restrict__ vel, int numAtoms, double* __restrict__ result) {
+// Kinetic energy in two launches: up to KE_PARTIALS workgroups each sum a strided share of the range into scratch[block]
+// (fixed assignment and summation order: the result is reproducible), one workgroup adds the partials.  The range is
+// either atoms [first, end) or -- atomOfSlot given -- the atoms in the slots [first, end) (a rank's own atoms in a decomposed run).
+#define KE_PARTIALS 1024
+__global__ __launch_bounds__(256) void k_kinetic_energy_partial(const double4* __restrict__ vel, const int* __restrict__ atomOfSlot, int first, int end,
+                                                                double* __restrict__ scratch) {
     __shared__ double part[4];
     double e = 0;
-    for (int i = threadIdx.x; i < numAtoms; i += 256) {
-        double4 v = vel[i];
+    for (int i = first + blockIdx.x * 256 + threadIdx.x; i < end; i += gridDim.x * 256) {
+        const int atom = atomOfSlot != nullptr ? atomOfSlot[i] : i;
+        if (atom < 0) continue;
+        double4 v = vel[atom];
         if (v.w != 0.0) e += (v.x * v.x + v.y * v.y + v.z * v.z) / v.w;
     }
+    e = wave_sum(e);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) scratch[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ __launch_bounds__(256) void k_kinetic_energy_final(const double* __restrict__ scratch, int n, double* __restrict__ result) {
+    __shared__ double part[4];
+    double e = 0;
+    for (int i = threadIdx.x; i < n; i += 256) e += scratch[i];
     e = wave_sum(e);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = e;
     __syncthreads();
@@ -694,8 +710,11 @@ extern "C" int ommhip_shifted_velocities(const ommhip_integrator_state* s, doubl
     return (int) hipGetLastError();
 }
 
-extern "C" int ommhip_kinetic_energy(const void* vel_d, int num_atoms, double* result_d, void* stream) {
-    hipLaunchKernelGGL(k_kinetic_energy, dim3(1), dim3(256), 0, (hipStream_t) stream, (const double4*) vel_d, num_atoms, result_d);
+extern "C" int ommhip_kinetic_energy(const void* vel_d, const int* atom_of_slot_d, int first, int end, double* scratch_d, double* result_d, void* stream) {
+    int blocks = (end - first + 1023) / 1024;
+    blocks = blocks < 1 ? 1 : (blocks > KE_PARTIALS ? KE_PARTIALS : blocks);
+    hipLaunchKernelGGL(k_kinetic_energy_partial, dim3(blocks), dim3(256), 0, (hipStream_t) stream, (const double4*) vel_d, atom_of_slot_d, first, end, scratch_d);
+    hipLaunchKernelGGL(k_kinetic_energy_final, dim3(1), dim3(256), 0, (hipStream_t) stream, (const double*) scratch_d, blocks, result_d);
     return (int) hipGetLastError();
 }
 

@@ -111,7 +111,7 @@ HipContext::HipContext(const System& system, int deviceIndex, bool hostMode, con
     atomOfSlot.allocate(sizeof(int) * (size_t) paddedAtoms);
     slotOfAtom.allocate(sizeof(int) * (size_t) max(numAtoms, 1));
     energyBuffer.allocate(sizeof(double) * EnergySlots);
-    energyResult.allocate(sizeof(double) * 8);
+    energyResult.allocate(sizeof(double) * (8 + OMMHIP_KE_SCRATCH));     // [0] potential, [1] kinetic, [8..] partial sums of the kinetic energy
     forceDouble.allocate(sizeof(double) * 3 * (size_t) max(numAtoms, 1));
     if (decomposed()) {
         // reciprocal space (with its all-to-alls) runs on the side stream beside the pair kernel: it gets a communicator of its own

@@ -1575,24 +1575,24 @@ double HipIntegratorBase::kineticEnergy(double timeShift) {
     // ReferenceKernels.cpp:146-176
     HipContext& hip = *data.hip;
     hip.setAsCurrent();
-    if (hip.decomposed()) {
-        // rare (a State with energies): complete velocities -- and forces, if the estimate is time-shifted -- on every rank,
-        // then every rank computes the same number
-        hip.gatherState();
-        if (timeShift != 0.0)
-            for (int c = 0; c < 3; c++)
-                HIP_CHECK(ommhip_comm_all_gather(hip.domain.comm, hip.force.as<long long>() + (size_t) c * hip.paddedAtoms, sizeof(long long) * (size_t) hip.slotsPerRank, hip.stream));
-    }
+    // Decomposed run: every rank sums over its own atoms (their velocities, and the forces a time-shifted estimate needs, are
+    // local; constraint-connected units are never split between ranks) and the partial sums are added in rank order on every
+    // rank.  The kernels below also run over the atoms of the other ranks -- on stale data whose results are not read.
     ommhip_integrator_state s;
     fillState(s, 0.0);
     HIP_CHECK(ommhip_shifted_velocities(&s, timeShift, hip.tempVel.ptr, hip.stream));
     HipConstraints& constraints = data.getDeviceConstraints(*data.system);
     if (constraints.hasConstraints()) constraints.applyToVelocities(hip.tempVel.ptr, 1e-4);
-    HIP_CHECK(ommhip_kinetic_energy(hip.tempVel.ptr, hip.numAtoms, hip.energyResult.as<double>() + 1, hip.stream));
+    double* const result_d = hip.energyResult.as<double>() + 1;
+    double* const scratch_d = hip.energyResult.as<double>() + 8;
+    if (hip.decomposed())
+        HIP_CHECK(ommhip_kinetic_energy(hip.tempVel.ptr, hip.atomOfSlot.as<int>(), hip.ownSlot0, hip.ownSlot1, scratch_d, result_d, hip.stream));
+    else
+        HIP_CHECK(ommhip_kinetic_energy(hip.tempVel.ptr, NULL, 0, hip.numAtoms, scratch_d, result_d, hip.stream));
     double result = 0;
-    HIP_CHECK(ommhip_memcpy_d2h(&result, hip.energyResult.as<double>() + 1, sizeof(double), hip.stream));
+    HIP_CHECK(ommhip_memcpy_d2h(&result, result_d, sizeof(double), hip.stream));
     hip.sync();
-    return result;
+    return hip.sumOverRanks(result);
 }
 
 void HipIntegratorBase::finishStep(double dt) {

@@ -34,6 +34,7 @@ namespace {
 struct NbArgs {
     int paddedAtoms, maxChunks, energySlots, debugFlags;
     int xcdAware;             // XCD-aware placement of the work units (ChunkSchedule)
+    int ljHeadSplit;          // use the split loops for i-blocks whose atoms from OMM_LJ_HEAD on have epsilon = 0
     int ownSlot0, ownSlot1;   // domain decomposition: forces on j atoms outside [ownSlot0, ownSlot1) are dropped (their owner evaluates the pair too)
     float cutoff2, alpha, krf, crf, switchDist, invSwitchWidth;
     float dispAlpha2, invCut6, dispShift;   // LJPME (METHOD & 4): alpha_d^2, 1/rc^6, (1 - exp(-x)(1 + x + x^2/2)) / rc^6 at x = (alpha_d rc)^2
@@ -50,6 +51,8 @@ struct NbArgs {
     omm_fixed* force;
     double* energyBuffer;     // one slot per workgroup
 };
+
+#define OMM_LJ_HEAD 12        // slots of a block that may hold atoms with Lennard-Jones parameters when the rest has none (32 water atoms: 10-11 oxygens)
 
 template <int METHOD, int PBC, bool ENERGY, bool MASKED>
 __device__ __forceinline__ void pair_ixn(const NbArgs& a, const float4 pi, const float2 sei, const float4 pj, const float2 sej, const float qjK,
@@ -128,7 +131,9 @@ __device__ __forceinline__ float rl(float v, int k) { return __int_as_float(__bu
 __device__ __forceinline__ float4 rl4(float4 v, int k) { return make_float4(rl(v.x, k), rl(v.y, k), rl(v.z, k), rl(v.w, k)); }
 __device__ __forceinline__ float2 rl2(float2 v, int k) { return make_float2(rl(v.x, k), rl(v.y, k)); }
 
-template <int METHOD, bool ENERGY, bool MASKED>
+// NOLJ: both i atoms have epsilon = 0 (wave-uniform, decided by the caller from the i-block's parameters): the whole
+// Lennard-Jones part -- a fifth of the packed arithmetic -- is left out; its terms would all carry the factor eps_i eps_j = 0.
+template <int METHOD, bool ENERGY, bool MASKED, bool NOLJ = false>
 __device__ __forceinline__ void pair_ixn2(const NbArgs& a, const float4 pi0, const float4 pi1, const float2 se0, const float2 se1,
                                           const float4 pj, const float2 sej, const float qjK, bool bit0, bool bit1,
                                           v2f& fix, v2f& fiy, v2f& fiz, v2f& fjx, v2f& fjy, v2f& fjz, v2f& energy) {
@@ -139,32 +144,34 @@ __device__ __forceinline__ void pair_ixn2(const NbArgs& a, const float4 pi0, con
     const v2f invR = mk2(fast_rsqrt(r2.x), fast_rsqrt(r2.y));
     const v2f r = r2 * invR;
     const v2f invR2 = invR * invR;
-    const v2f sig = mk2(se0.x, se1.x) + bc2(sej.x);
-    const v2f eps = mk2(se0.y, se1.y) * bc2(sej.y);
-    v2f s2 = sig * invR; s2 = s2 * s2;
-    const v2f s6 = s2 * s2 * s2;
-    v2f ljF = eps * (bc2(12.f) * s6 - bc2(6.f)) * s6;
-    v2f ljE = eps * (s6 - bc2(1.f)) * s6;
-    v2f dispF = bc2(0.f);
-    if (METHOD & 4) {
-        const v2f c6 = mk2(8.f * se0.x * se0.x * se0.x * se0.y, 8.f * se1.x * se1.x * se1.x * se1.y) * bc2(8.f * sej.x * sej.x * sej.x * sej.y);
-        const v2f x = bc2(a.dispAlpha2) * r2;
-        const v2f argd = -x * bc2(1.44269504088896340736f);
-        const v2f ex = mk2(__builtin_amdgcn_exp2f(argd.x), __builtin_amdgcn_exp2f(argd.y));
-        const v2f invR6 = invR2 * invR2 * invR2;
-        dispF = bc2(6.f) * c6 * invR6 * invR2 * (bc2(1.f) - ex * (bc2(1.f) + x + bc2(0.5f) * x * x + x * x * x * bc2(1.f / 6.f)));
-        if (ENERGY || (METHOD & 2)) {
-            const v2f sc2 = sig * sig; const v2f sc6 = sc2 * sc2 * sc2 * bc2(a.invCut6);
-            ljE = ljE + c6 * invR6 * (bc2(1.f) - ex * (bc2(1.f) + x + bc2(0.5f) * x * x)) + eps * (bc2(1.f) - sc6) * sc6 - c6 * bc2(a.dispShift);
+    v2f ljF = bc2(0.f), ljE = bc2(0.f), dispF = bc2(0.f);
+    if (!NOLJ) {
+        const v2f sig = mk2(se0.x, se1.x) + bc2(sej.x);
+        const v2f eps = mk2(se0.y, se1.y) * bc2(sej.y);
+        v2f s2 = sig * invR; s2 = s2 * s2;
+        const v2f s6 = s2 * s2 * s2;
+        ljF = eps * (bc2(12.f) * s6 - bc2(6.f)) * s6;
+        ljE = eps * (s6 - bc2(1.f)) * s6;
+        if (METHOD & 4) {
+            const v2f c6 = mk2(8.f * se0.x * se0.x * se0.x * se0.y, 8.f * se1.x * se1.x * se1.x * se1.y) * bc2(8.f * sej.x * sej.x * sej.x * sej.y);
+            const v2f x = bc2(a.dispAlpha2) * r2;
+            const v2f argd = -x * bc2(1.44269504088896340736f);
+            const v2f ex = mk2(__builtin_amdgcn_exp2f(argd.x), __builtin_amdgcn_exp2f(argd.y));
+            const v2f invR6 = invR2 * invR2 * invR2;
+            dispF = bc2(6.f) * c6 * invR6 * invR2 * (bc2(1.f) - ex * (bc2(1.f) + x + bc2(0.5f) * x * x + x * x * x * bc2(1.f / 6.f)));
+            if (ENERGY || (METHOD & 2)) {
+                const v2f sc2 = sig * sig; const v2f sc6 = sc2 * sc2 * sc2 * bc2(a.invCut6);
+                ljE = ljE + c6 * invR6 * (bc2(1.f) - ex * (bc2(1.f) + x + bc2(0.5f) * x * x)) + eps * (bc2(1.f) - sc6) * sc6 - c6 * bc2(a.dispShift);
+            }
         }
-    }
-    if (METHOD & 2) {
-        v2f t = (r - bc2(a.switchDist)) * bc2(a.invSwitchWidth);
-        t = mk2(fmaxf(0.f, t.x), fmaxf(0.f, t.y));
-        const v2f sw = bc2(1.f) + t * t * t * (bc2(-10.f) + t * (bc2(15.f) - t * bc2(6.f)));
-        const v2f dsw = t * t * (bc2(-30.f) + t * (bc2(60.f) - t * bc2(30.f))) * bc2(a.invSwitchWidth);
-        ljF = sw * ljF - ljE * dsw * r;
-        ljE = ljE * sw;
+        if (METHOD & 2) {
+            v2f t = (r - bc2(a.switchDist)) * bc2(a.invSwitchWidth);
+            t = mk2(fmaxf(0.f, t.x), fmaxf(0.f, t.y));
+            const v2f sw = bc2(1.f) + t * t * t * (bc2(-10.f) + t * (bc2(15.f) - t * bc2(6.f)));
+            const v2f dsw = t * t * (bc2(-30.f) + t * (bc2(60.f) - t * bc2(30.f))) * bc2(a.invSwitchWidth);
+            ljF = sw * ljF - ljE * dsw * r;
+            ljE = ljE * sw;
+        }
     }
     const v2f qq = mk2(pi0.w, pi1.w) * bc2(qjK);
     v2f cF, cE;
@@ -186,11 +193,25 @@ __device__ __forceinline__ void pair_ixn2(const NbArgs& a, const float4 pi0, con
         cF = qq * (invR - bc2(2.f * a.krf) * r2);
         cE = qq * (invR + bc2(a.krf) * r2 - bc2(a.crf));
     }
-    v2f dEdR = (ljF + cF) * invR2 + dispF;
+    v2f dEdR = NOLJ ? cF * invR2 : (ljF + cF) * invR2 + dispF;
     dEdR = mk2(in0 ? dEdR.x : 0.f, in1 ? dEdR.y : 0.f);
     fjx = fjx + dEdR * dx; fjy = fjy + dEdR * dy; fjz = fjz + dEdR * dz;
     fix = fix - dEdR * dx; fiy = fiy - dEdR * dy; fiz = fiz - dEdR * dz;
-    if (ENERGY) { const v2f e = ljE + cE; energy = energy + mk2(in0 ? e.x : 0.f, in1 ? e.y : 0.f); }
+    if (ENERGY) { const v2f e = NOLJ ? cE : ljE + cE; energy = energy + mk2(in0 ? e.x : 0.f, in1 ? e.y : 0.f); }
+}
+
+// i atoms [K0, K1) of a block against the j atom of this lane, two per call (single-image path).
+template <int METHOD, bool ENERGY, bool MASKED, bool NOLJ, int K0, int K1>
+__device__ __forceinline__ void row_pairs2(const NbArgs& a, const float4* __restrict__ ip, const float2* __restrict__ ise, const float4 pj, const float2 sej,
+                                           const float qjK, const unsigned m, float (&fix)[OMM_TILE], float (&fiy)[OMM_TILE], float (&fiz)[OMM_TILE],
+                                           v2f& fj2x, v2f& fj2y, v2f& fj2z, v2f& energy2) {
+#pragma unroll
+    for (int k = K0; k < K1; k += 2) {
+        v2f ax = mk2(fix[k], fix[k + 1]), ay = mk2(fiy[k], fiy[k + 1]), az = mk2(fiz[k], fiz[k + 1]);
+        pair_ixn2<METHOD, ENERGY, MASKED, NOLJ>(a, ip[k], ip[k + 1], ise[k], ise[k + 1], pj, sej, qjK, MASKED ? ((m >> k) & 1u) != 0 : true,
+                                                MASKED ? ((m >> (k + 1)) & 1u) != 0 : true, ax, ay, az, fj2x, fj2y, fj2z, energy2);
+        fix[k] = ax.x; fix[k + 1] = ax.y; fiy[k] = ay.x; fiy[k + 1] = ay.y; fiz[k] = az.x; fiz[k + 1] = az.y;
+    }
 }
 
 // Two registers in, one out: lanes 0-31 get a[l] + a[l + 32], lanes 32-63 get b[l - 32] + b[l] -- gfx950's
@@ -304,6 +325,12 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
             const float4 hX = a.blockHalf[X];
             single = hX.w != 0.f && hX.x + a.cutoff < 0.5f * a.box.ax && hX.y + a.cutoff < 0.5f * a.box.by && hX.z + a.cutoff < 0.5f * a.box.cz;
         }
+        // wave-uniform: do the i atoms from OMM_LJ_HEAD on all have epsilon = 0?  (scalar compares on the block's parameters)
+        bool ljFree = a.ljHeadSplit != 0;
+        if (PBC == 1 && single && ljFree) {
+#pragma unroll
+            for (int k = OMM_LJ_HEAD; k < OMM_TILE; k++) ljFree = ljFree && ise[k].y == 0.f;
+        }
         // All rows of the chunk are fetched before the first one is processed (index, then the gathers that depend on
         // it): the two memory round trips are paid once per chunk and the later rows arrive while the first is computed.
         int jRow[UNIT_ROWS]; unsigned mRow[UNIT_ROWS]; float4 pjRow[UNIT_ROWS]; float2 seRow[UNIT_ROWS]; float4 cjRow[UNIT_ROWS];
@@ -336,24 +363,20 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
                 const float oz = fmaf(-nz, a.box.czLo, fmaf(-nz, a.box.cz, cY.z)) - cX.z;
                 pj.x += ox; pj.y += oy; pj.z += oz;
                 v2f fj2x = bc2(0.f), fj2y = bc2(0.f), fj2z = bc2(0.f);
-                if (masked) {
-#pragma unroll
-                    for (int k = 0; k < OMM_TILE; k += 2) {
-                        v2f ax = mk2(fix[k], fix[k + 1]), ay = mk2(fiy[k], fiy[k + 1]), az = mk2(fiz[k], fiz[k + 1]);
-                        pair_ixn2<METHOD, ENERGY, true>(a, ip[k], ip[k + 1], ise[k], ise[k + 1], pj, sej, qjK, (m >> k) & 1u, (m >> (k + 1)) & 1u,
-                                                        ax, ay, az, fj2x, fj2y, fj2z, energy2);
-                        fix[k] = ax.x; fix[k + 1] = ax.y; fiy[k] = ay.x; fiy[k + 1] = ay.y; fiz[k] = az.x; fiz[k + 1] = az.y;
+                if (ljFree) {
+                    // the block's atoms from OMM_LJ_HEAD on carry no Lennard-Jones parameters (water: the slot order puts the
+                    // oxygens of a block first): two thirds of the row's pairs skip that part of the arithmetic
+                    if (masked) {
+                        row_pairs2<METHOD, ENERGY, true, false, 0, OMM_LJ_HEAD>(a, ip, ise, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
+                        row_pairs2<METHOD, ENERGY, true, true, OMM_LJ_HEAD, OMM_TILE>(a, ip, ise, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
+                    }
+                    else {
+                        row_pairs2<METHOD, ENERGY, false, false, 0, OMM_LJ_HEAD>(a, ip, ise, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
+                        row_pairs2<METHOD, ENERGY, false, true, OMM_LJ_HEAD, OMM_TILE>(a, ip, ise, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
                     }
                 }
-                else {
-#pragma unroll
-                    for (int k = 0; k < OMM_TILE; k += 2) {
-                        v2f ax = mk2(fix[k], fix[k + 1]), ay = mk2(fiy[k], fiy[k + 1]), az = mk2(fiz[k], fiz[k + 1]);
-                        pair_ixn2<METHOD, ENERGY, false>(a, ip[k], ip[k + 1], ise[k], ise[k + 1], pj, sej, qjK, true, true,
-                                                         ax, ay, az, fj2x, fj2y, fj2z, energy2);
-                        fix[k] = ax.x; fix[k + 1] = ax.y; fiy[k] = ay.x; fiy[k + 1] = ay.y; fiz[k] = az.x; fiz[k + 1] = az.y;
-                    }
-                }
+                else if (masked) row_pairs2<METHOD, ENERGY, true, false, 0, OMM_TILE>(a, ip, ise, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
+                else row_pairs2<METHOD, ENERGY, false, false, 0, OMM_TILE>(a, ip, ise, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
                 fjx += fj2x.x + fj2x.y; fjy += fj2y.x + fj2y.y; fjz += fj2z.x + fj2z.y;
             }
             else {
@@ -428,6 +451,8 @@ static NbArgs make_nb_args(const ommhip_neighbor_list* nl, const ommhip_nonbonde
     a.debugFlags = debugFlags;
     static const bool xcdAware = getenv("OPENMM_HIP_NO_XCD_PLACEMENT") == nullptr;          // A/B knob
     a.xcdAware = xcdAware ? 1 : 0;
+    static const bool ljHeadSplit = getenv("OPENMM_HIP_NO_LJ_SPLIT") == nullptr;            // A/B knob
+    a.ljHeadSplit = ljHeadSplit ? 1 : 0;
     a.ownSlot0 = 0; a.ownSlot1 = nl->padded_atoms;
     if (nl->dd_mode != 0 && nl->owned_blocks > 0) { a.ownSlot0 = nl->first_block * OMM_TILE; a.ownSlot1 = (nl->first_block + nl->owned_blocks) * OMM_TILE; }
     a.cutoff2 = nl->cutoff > 0 ? (float) (nl->cutoff * nl->cutoff) : INFINITY;

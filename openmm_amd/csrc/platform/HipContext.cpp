@@ -420,6 +420,38 @@ void HipContext::stepTaken() {
     stepsSinceReorder++;
 }
 
+void HipContext::partitionBlocks(vector<int>& atomOfSlotLike) const {
+    // inside every 32-slot block: atoms flagged by setBlockTailAtoms() after the others (stable), empty slots (-1) last
+    if (blockTailAtom.empty()) return;
+    static const bool off = getenv("OPENMM_HIP_NO_LJ_PARTITION") != NULL;        // A/B knob
+    if (off) return;
+    int tmp[OMMHIP_TILE];
+    for (size_t b = 0; b < atomOfSlotLike.size(); b += OMMHIP_TILE) {
+        const int n = (int) min((size_t) OMMHIP_TILE, atomOfSlotLike.size() - b);
+        int k = 0;
+        for (int pass = 0; pass < 3; pass++)
+            for (int i = 0; i < n; i++) {
+                const int atom = atomOfSlotLike[b + i];
+                const int cls = atom < 0 ? 2 : (blockTailAtom[atom] ? 1 : 0);
+                if (cls == pass) tmp[k++] = atom;
+            }
+        for (int i = 0; i < n; i++) atomOfSlotLike[b + i] = tmp[i];
+    }
+    static const bool diag = getenv("OPENMM_HIP_DIAG_BLOCKS") != NULL;          // diagnostics: blocks by their number of head (non-tail) atoms
+    if (diag) {
+        int hist[OMMHIP_TILE + 1] = {0};
+        for (size_t b = 0; b < atomOfSlotLike.size(); b += OMMHIP_TILE) {
+            int head = 0;
+            for (size_t i = b; i < min(b + OMMHIP_TILE, atomOfSlotLike.size()); i++)
+                if (atomOfSlotLike[i] >= 0 && !blockTailAtom[atomOfSlotLike[i]]) head++;
+            hist[head]++;
+        }
+        fprintf(stderr, "HIP platform: blocks by number of head atoms:");
+        for (int h = 0; h <= OMMHIP_TILE; h++) if (hist[h] > 0) fprintf(stderr, " %d:%d", h, hist[h]);
+        fprintf(stderr, "\n");
+    }
+}
+
 void HipContext::computeOrder(const vector<Vec3>& positions, vector<int>& order, vector<int>& wrapOut) {
     wrapOut.assign(4 * (size_t) numAtoms, 0);
     order.resize(numAtoms);
@@ -468,6 +500,7 @@ void HipContext::computeOrder(const vector<Vec3>& positions, vector<int>& order,
     });
     radixSortPairs(keyed, 3 * bits);          // stable: equal keys stay in atom order, as a sort of (key, atom) pairs would leave them
     for (int i = 0; i < numAtoms; i++) order[i] = keyed[i].second;
+    partitionBlocks(order);
 }
 
 void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<int>& newAtomOfSlot, vector<int>& wrapOut) {
@@ -546,6 +579,7 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
             if (g == domain.rank) ownedUnits.push_back(u);
         }
     }
+    partitionBlocks(newAtomOfSlot);          // a rank's range is a whole number of blocks: no atom changes owner
 }
 
 bool HipContext::reorderIfNeeded() {

@@ -127,6 +127,9 @@ public:
     void stepTaken();                                           // counts steps towards the next reorder
 
     void addListener(HipContextListener* l) { listeners.push_back(l); }
+    /** Atoms that should sit at the END of their 32-slot block (e.g. atoms without Lennard-Jones parameters: the pair kernel
+     *  skips that part of the arithmetic for the tail of a block whose atoms have none).  Takes effect at the next re-sort. */
+    void setBlockTailAtoms(const std::vector<char>& tail) { blockTailAtom = tail; reorderRequested = true; }
     void removeListener(HipContextListener* l);
 
     // ---- domain decomposition (ranks > 1): this rank owns the slots [ownSlot0, ownSlot1) -- a slab of the box along x --
@@ -194,6 +197,8 @@ private:
     void computeOrderDecomposed(const std::vector<Vec3>& positions, std::vector<int>& newAtomOfSlot, std::vector<int>& wrapOut);
     void findUnits(const System& system);
     std::vector<HipContextListener*> listeners;
+    std::vector<char> blockTailAtom;
+    void partitionBlocks(std::vector<int>& atomOfSlotLike) const;
     bool inRecovery = false;
     void* pmeForkEvent = NULL;
     void* pmeDoneEvent = NULL;

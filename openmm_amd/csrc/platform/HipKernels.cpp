@@ -839,6 +839,14 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
         dispersionCoefficient = 0.0;
     if (usesPeriodic) hip.usePeriodic = true;
     if (nonbondedMethod != NoCutoff) hip.sortCutoff = max(hip.sortCutoff, nonbondedCutoff);
+    {
+        // atoms without Lennard-Jones parameters (water hydrogens: two thirds of a solvated system) go to the end of their
+        // 32-slot block, so that the pair kernel can leave the LJ arithmetic out for the tail of such blocks (nonbonded.hip,
+        // OMM_LJ_HEAD).  Only an ordering hint: the kernel looks at the parameters themselves.
+        vector<char> noLJ(numParticles);
+        for (int i = 0; i < numParticles; i++) noLJ[i] = baseParticleParams[i][2] == 0.0 ? 1 : 0;
+        hip.setBlockTailAtoms(noLJ);
+    }
     hip.requestReorder();
     // List padding as a fraction of the cutoff.  Small systems do not fill the chip: the pair launches are bound by the latency
     // of a chunk, extra rows ride along for free (DHFR size: 7.3 k -> 8.7 k rows, same 59 us) while every rebuild avoided

@@ -175,7 +175,8 @@ extern "C" int ommhip_pairs_with_fft(const ommhip_neighbor_list* nl, const ommhi
         int pairBlocks = (int) ((shareChunks + PF_THREADS / 64 - 1) / (PF_THREADS / 64));
         pairBlocks = (pairBlocks + OMM_NUM_XCD - 1) / OMM_NUM_XCD * OMM_NUM_XCD;       // the same number on every XCD
         const bool energy = include_energy != 0;
-        if (p->use_switch) { if (energy) launch_pairs_fft<3, true>(stage, pairBlocks, st, nb, plane, fft, s); else launch_pairs_fft<3, false>(stage, pairBlocks, st, nb, plane, fft, s); }
+        if (use_ewald_poly(nb, nl, p, include_energy)) launch_pairs_fft<9, false>(stage, pairBlocks, st, nb, plane, fft, s);
+        else if (p->use_switch) { if (energy) launch_pairs_fft<3, true>(stage, pairBlocks, st, nb, plane, fft, s); else launch_pairs_fft<3, false>(stage, pairBlocks, st, nb, plane, fft, s); }
         else { if (energy) launch_pairs_fft<1, true>(stage, pairBlocks, st, nb, plane, fft, s); else launch_pairs_fft<1, false>(stage, pairBlocks, st, nb, plane, fft, s); }
     }
     ommhip_profile_end(OMMHIP_TIMER_NB_DIRECT, stream);

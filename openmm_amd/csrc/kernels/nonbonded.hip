@@ -31,12 +31,15 @@ namespace {
 // ================================================================================================
 // Pair kernel
 // ================================================================================================
+#define OMM_EWPOLY_DEGREE 11
 struct NbArgs {
     int paddedAtoms, maxChunks, energySlots, debugFlags;
     int xcdAware;             // XCD-aware placement of the work units (ChunkSchedule)
     int ljHeadSplit;          // use the split loops for i-blocks whose atoms from OMM_LJ_HEAD on have epsilon = 0
     int ownSlot0, ownSlot1;   // domain decomposition: forces on j atoms outside [ownSlot0, ownSlot1) are dropped (their owner evaluates the pair too)
     float cutoff2, alpha, krf, crf, switchDist, invSwitchWidth;
+    float ewPoly[OMM_EWPOLY_DEGREE + 1];   // METHOD & 8: alpha^3 g((u + 1) zmax / 2) as a polynomial in u, highest power first (see ewald_poly_for)
+    float ewPolyScale;                     // u = r^2 * ewPolyScale - 1
     float dispAlpha2, invCut6, dispShift;   // LJPME (METHOD & 4): alpha_d^2, 1/rc^6, (1 - exp(-x)(1 + x + x^2/2)) / rc^6 at x = (alpha_d rc)^2
     Box box;
     const float4* posq;       // block-relative coordinates + charge (ommhip_neighbor_list::posq_rel): position minus blockCenter of its block
@@ -174,6 +177,24 @@ __device__ __forceinline__ void pair_ixn2(const NbArgs& a, const float4 pi0, con
         }
     }
     const v2f qq = mk2(pi0.w, pi1.w) * bc2(qjK);
+    if ((METHOD & 8) && !ENERGY) {
+        // Real-space Ewald force without exp and rcp (forces only): the bracket of ReferenceLJCoulombIxn.cpp:396-399 over r^3 is
+        //   [erfc(ar) + 2 ar exp(-(ar)^2) / sqrt(pi)] / r^3 = 1 / r^3 - alpha^3 g(z),   z = (alpha r)^2,
+        //   g(z) = [erf(sqrt z) - 2 sqrt(z / pi) exp(-z)] / z^(3/2)   (entire in z, g(0) = 4 / (3 sqrt pi)),
+        // and alpha^3 g is a degree-11 polynomial in z on [0, (alpha cutoff)^2] to 1e-7 of g(0) (fitted for the run's alpha and
+        // cutoff on the host, make_nb_args).  The difference of two numbers of the size of 1/r^3 is good to 6e-8 / r^3 --
+        // 1e-7 of the pair's own Coulomb force at contact, 1e-4 kJ/mol/nm at the cutoff, where the force itself is tiny.
+        const v2f u = r2 * bc2(a.ewPolyScale) - bc2(1.f);
+        v2f poly = bc2(a.ewPoly[0]);
+#pragma unroll
+        for (int n = 1; n <= OMM_EWPOLY_DEGREE; n++) poly = poly * u + bc2(a.ewPoly[n]);
+        const v2f coul = qq * (invR2 * invR - poly);
+        v2f dEdR = NOLJ ? coul : ljF * invR2 + coul;
+        dEdR = mk2(in0 ? dEdR.x : 0.f, in1 ? dEdR.y : 0.f);
+        fjx = fjx + dEdR * dx; fjy = fjy + dEdR * dy; fjz = fjz + dEdR * dz;
+        fix = fix - dEdR * dx; fiy = fiy - dEdR * dy; fiz = fiz - dEdR * dz;
+        return;
+    }
     v2f cF, cE;
     if (METHOD & 1) {
         const v2f ar = bc2(a.alpha) * r;
@@ -442,6 +463,54 @@ void launch_direct1(int pbc, bool energy, int grid, hipStream_t st, const NbArgs
 
 }  // namespace
 
+// alpha^3 g(z), z = (alpha r)^2, as a polynomial of degree OMM_EWPOLY_DEGREE in u = 2 z / zmax - 1 (see pair_ixn2, METHOD & 8):
+// interpolation at the Chebyshev nodes (near-minimax for this entire function), converted to powers of u -- the series
+// decays so fast that the power form is as well conditioned as the Chebyshev one (sum |c_k| = g(0) to seven digits).
+// ok = the fit is good to 1.5e-7 g(0) over the whole range (alpha * cutoff up to ~2.9; Ewald tolerances down to ~1e-4).
+struct EwaldPoly { double alpha = -1, cutoff = -1; bool ok = false; float coeff[OMM_EWPOLY_DEGREE + 1]; float scale = 0; double maxErr = 0; };
+static double ewald_g(double z) {
+    if (z < 1e-3) return 4.0 / (3.0 * sqrt(M_PI)) * (1.0 - 0.6 * z + 3.0 * z * z / 14.0 - z * z * z / 27.0);
+    const double s = sqrt(z);
+    return (erf(s) - 2.0 * s / sqrt(M_PI) * exp(-z)) / (z * s);
+}
+static const EwaldPoly& ewald_poly_for(double alpha, double cutoff) {
+    static thread_local EwaldPoly cache;
+    if (cache.alpha == alpha && cache.cutoff == cutoff) return cache;
+    cache.alpha = alpha; cache.cutoff = cutoff; cache.ok = false;
+    if (!(alpha > 0) || !(cutoff > 0)) return cache;
+    constexpr int N = OMM_EWPOLY_DEGREE;
+    const double zmax = alpha * alpha * cutoff * cutoff * 1.0001, a3 = alpha * alpha * alpha;
+    double f[N + 1], x[N + 1], cheb[N + 1];
+    for (int j = 0; j <= N; j++) { x[j] = cos(M_PI * (j + 0.5) / (N + 1)); f[j] = a3 * ewald_g(0.5 * (x[j] + 1.0) * zmax); }
+    for (int k = 0; k <= N; k++) {
+        double sum = 0;
+        for (int j = 0; j <= N; j++) sum += f[j] * cos(M_PI * k * (j + 0.5) / (N + 1));
+        cheb[k] = (k == 0 ? 1.0 : 2.0) * sum / (N + 1);
+    }
+    // Chebyshev series -> powers of u:  T_0 = 1, T_1 = u, T_{k+1} = 2 u T_k - T_{k-1}
+    double mono[N + 1] = {0}, tPrev[N + 1] = {0}, tCur[N + 1] = {0}, tNext[N + 1];
+    tPrev[0] = 1.0; tCur[1] = 1.0;
+    for (int i = 0; i <= N; i++) mono[i] += cheb[0] * tPrev[i] + (N >= 1 ? cheb[1] * tCur[i] : 0.0);
+    for (int k = 2; k <= N; k++) {
+        for (int i = 0; i <= N; i++) tNext[i] = (i > 0 ? 2.0 * tCur[i - 1] : 0.0) - tPrev[i];
+        for (int i = 0; i <= N; i++) { mono[i] += cheb[k] * tNext[i]; tPrev[i] = tCur[i]; tCur[i] = tNext[i]; }
+    }
+    for (int i = 0; i <= N; i++) cache.coeff[i] = (float) mono[N - i];          // highest power first (Horner)
+    cache.scale = (float) (2.0 * alpha * alpha / zmax);
+    // check the single-precision Horner form over the whole range
+    double worst = 0;
+    for (int i = 0; i <= 2000; i++) {
+        const double r = cutoff * i / 2000.0;
+        const float u = (float) (r * r) * cache.scale - 1.f;
+        float p = cache.coeff[0];
+        for (int n = 1; n <= N; n++) p = p * u + cache.coeff[n];
+        worst = fmax(worst, fabs((double) p - a3 * ewald_g(alpha * alpha * r * r)));
+    }
+    cache.maxErr = worst / (a3 * ewald_g(0.0));
+    cache.ok = cache.maxErr < 4e-7;          // fit error (<= 1.5e-7 up to alpha * cutoff = 2.9) + float rounding of the Horner steps
+    return cache;
+}
+
 static NbArgs make_nb_args(const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, const void* sig_eps,
                            long long* force, double* energy_buffer, int energy_slots) {
     NbArgs a;
@@ -457,6 +526,12 @@ static NbArgs make_nb_args(const ommhip_neighbor_list* nl, const ommhip_nonbonde
     if (nl->dd_mode != 0 && nl->owned_blocks > 0) { a.ownSlot0 = nl->first_block * OMM_TILE; a.ownSlot1 = (nl->first_block + nl->owned_blocks) * OMM_TILE; }
     a.cutoff2 = nl->cutoff > 0 ? (float) (nl->cutoff * nl->cutoff) : INFINITY;
     a.alpha = (float) p->ewald_alpha; a.krf = (float) p->krf; a.crf = (float) p->crf;
+    a.ewPolyScale = 0.f;
+    for (int i = 0; i <= OMM_EWPOLY_DEGREE; i++) a.ewPoly[i] = 0.f;
+    if (p->ewald && nl->cutoff > 0) {
+        const EwaldPoly& ep = ewald_poly_for(p->ewald_alpha, nl->cutoff);
+        if (ep.ok) { a.ewPolyScale = ep.scale; for (int i = 0; i <= OMM_EWPOLY_DEGREE; i++) a.ewPoly[i] = ep.coeff[i]; }
+    }
     a.switchDist = (float) p->switch_distance;
     a.dispAlpha2 = (float) (p->dispersion_alpha * p->dispersion_alpha);
     a.invCut6 = nl->cutoff > 0 ? (float) pow(nl->cutoff, -6.0) : 0.f;
@@ -474,6 +549,12 @@ static NbArgs make_nb_args(const ommhip_neighbor_list* nl, const ommhip_nonbonde
     return a;
 }
 
+// METHOD 9 = plain Ewald/PME direct space with the polynomial form of the real-space force (forces only, rectangular box)
+static bool use_ewald_poly(const NbArgs& a, const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, int include_energy) {
+    static const bool off = getenv("OPENMM_HIP_NO_EWALD_POLY") != nullptr;              // A/B knob
+    return !off && a.ewPolyScale != 0.f && nl->pbc == 1 && p->ewald && !p->use_switch && !p->ljpme && include_energy == 0;
+}
+
 extern "C" int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, const void* sig_eps,
                                 long long* force, double* energy_buffer, int energy_slots, int include_energy, void* stream) {
     if (nl->posq_rel == nullptr) return 1;      // hipErrorInvalidValue: the pair kernel needs the block-relative coordinates
@@ -486,7 +567,8 @@ extern "C" int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_non
     hipStream_t st = (hipStream_t) stream;
     ommhip_profile_begin(OMMHIP_TIMER_NB_DIRECT, stream);
     if (p->ljpme && !p->ewald) return 1;
-    switch ((p->ewald ? 1 : 0) | (p->use_switch ? 2 : 0) | (p->ljpme ? 4 : 0)) {
+    if (use_ewald_poly(a, nl, p, include_energy)) hipLaunchKernelGGL((nb_direct<9, 1, false>), dim3(grid), dim3(64), 0, st, a, a.posq, a.sigEps);
+    else switch ((p->ewald ? 1 : 0) | (p->use_switch ? 2 : 0) | (p->ljpme ? 4 : 0)) {
         case 0: launch_direct1<0>(nl->pbc, include_energy != 0, grid, st, a); break;
         case 1: launch_direct1<1>(nl->pbc, include_energy != 0, grid, st, a); break;
         case 2: launch_direct1<2>(nl->pbc, include_energy != 0, grid, st, a); break;

@@ -27,7 +27,7 @@ def box6(box3):
     return (C.c_double * 6)(box3[0, 0], box3[1, 0], box3[1, 1], box3[2, 0], box3[2, 1], box3[2, 2])
 
 
-def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64, compact=False, cells=False, fused_pme=None, block_range=None):
+def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64, compact=False, cells=False, fused_pme=None, block_range=None, energy=True, lj_free_tail=False):
     """-> (forces[n,3], energy, oracle forces, oracle energy, nl state)
 
     compact=False: random slot order, list built by ommhip_nl_update on wrapped coordinates (general image search).
@@ -38,7 +38,11 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     ommhip_pairs_with_fft (pair kernel on the three FFT launches), ommhip_pme_reciprocal(interpolate only) -- against
     direct + reciprocal space of the oracle.
     block_range=(first, count): the list is built for these i-blocks only (force decomposition between ranks); the raw
-    fixed-point force buffer of the evaluation is left in LAST_FIXED_POINT_FORCES."""
+    fixed-point force buffer of the evaluation is left in LAST_FIXED_POINT_FORCES.
+    energy=False: forces only -- plain Ewald/PME in a rectangular box then takes the polynomial form of the real-space force
+    (nonbonded.hip, METHOD 9) on the single-image path; the energy returned is 0.
+    lj_free_tail=True: epsilon = 0 for the atoms in the slots 12..31 of every block (a water box after the platform's
+    in-block ordering): the single-image path leaves the Lennard-Jones arithmetic out for them."""
     rng = np.random.default_rng(seed)
     box3 = np.eye(3) * L
     if triclinic:
@@ -60,6 +64,8 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
         perm = np.argsort(key, kind="stable").astype(np.int32)
     atom_of_slot = np.full(padded, -1, np.int32)
     atom_of_slot[:n] = perm
+    if lj_free_tail:
+        eps[perm[(np.arange(n) % 32) >= 12]] = 0.0
     slot_of_atom = np.empty(n, np.int32)
     slot_of_atom[perm] = np.arange(n, dtype=np.int32)
     ex = [[] for _ in range(n)]
@@ -135,12 +141,12 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
         p.use_switch, p.switch_distance = 1, switch
     p.direct_grid = grid
     if pm is not None:
-        K.pairs_with_fft(C.byref(nl), C.byref(p), d_se, C.byref(pm), d_f, d_e, grid, 1, None)
+        K.pairs_with_fft(C.byref(nl), C.byref(p), d_se, C.byref(pm), d_f, d_e, grid, 1 if energy else 0, None)
         pm.phases = capi.PME_INTERPOLATE_ONLY
         K.pme_reciprocal(C.byref(pm), d_posq, padded, d_f, d_e, grid, 1, None)
     else:
         d_f, d_e = K.upload(np.zeros(3 * padded, np.int64)), K.upload(np.zeros(grid))
-        K.nb_direct(C.byref(nl), C.byref(p), d_se, d_f, d_e, grid, 1, None)
+        K.nb_direct(C.byref(nl), C.byref(p), d_se, d_f, d_e, grid, 1 if energy else 0, None)
     global LAST_FIXED_POINT_FORCES
     LAST_FIXED_POINT_FORCES = K.download(d_f, (3, padded), np.int64)
     f = LAST_FIXED_POINT_FORCES.astype(np.float64) / 2 ** 32

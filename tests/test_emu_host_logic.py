@@ -48,6 +48,19 @@ def test_direct_space_single_image_path(K):
 
 
 @needs_emu
+@pytest.mark.parametrize("energy,lj_free_tail,fused", [(False, False, None), (False, True, None), (True, True, None), (False, True, (24, 24, 24))])
+def test_direct_space_force_only_and_lj_free_variants(K, energy, lj_free_tail, fused):
+    """The loops a production step runs: forces only (polynomial form of the real-space Ewald force, no exp / rcp) and blocks
+    whose atoms from slot 12 on have no Lennard-Jones parameters (LJ arithmetic left out) -- same bar against the oracle."""
+    f, e, f_or, e_or, state = KC.run_direct_space(K, 1200, ONB.PME, 0.7, 3.4, EXCL, compact=True, energy=energy, lj_free_tail=lj_free_tail, fused_pme=fused)
+    assert state[2] == 0 and state[1] > 0
+    assert KC.LAST_SINGLE_FRACTION > 0.5
+    assert max_rel_force_error(f, f_or) < (1e-4 if fused else 5e-5)
+    if energy:
+        assert abs(e - e_or) < 5e-5 * max(abs(e_or), 100.0)
+
+
+@needs_emu
 @pytest.mark.parametrize("switch,ng", [(None, (24, 24, 24)), (0.6, (24, 20, 28))])
 def test_fused_single_stream_evaluation(K, switch, ng):
     """nl_prepare (+clears) -> force_front (list build + charge spreading) -> pairs_with_fft -> interpolate, through the C ABI"""

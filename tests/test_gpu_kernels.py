@@ -46,6 +46,18 @@ def test_direct_space_single_image_path(K, n, method, L, cutoff, switch):
     assert abs(e - e_or) < 1e-5 * max(abs(e_or), 100.0)
 
 
+@pytest.mark.parametrize("energy,lj_free_tail,fused", [(False, False, None), (False, True, None), (True, True, None), (False, True, (32, 32, 32))])
+def test_direct_space_force_only_and_lj_free_variants(K, energy, lj_free_tail, fused):
+    """The loops a production step runs: forces only (polynomial form of the real-space Ewald force, no exp / rcp) and blocks
+    whose atoms from slot 12 on have no Lennard-Jones parameters (LJ arithmetic left out) -- same bar against the oracle."""
+    f, e, f_or, e_or, state = KC.run_direct_space(K, 3000, ONB.PME, 0.9, 4.6, EXCL, grid=256, compact=True, energy=energy, lj_free_tail=lj_free_tail, fused_pme=fused)
+    assert state[2] == 0 and state[1] > 0
+    assert KC.LAST_SINGLE_FRACTION > 0.8
+    assert max_rel_force_error(f, f_or) < 1e-4
+    if energy:
+        assert abs(e - e_or) < 1e-5 * max(abs(e_or), 100.0)
+
+
 @pytest.mark.parametrize("n,L,cutoff,compact", [(3000, 4.6, 0.9, True), (3000, 4.6, 0.9, False), (2500, 6.5, 0.8, True)])
 def test_direct_space_cell_binned_builder(K, n, L, cutoff, compact):
     """The candidate search used from 65 k atoms up (blocks bucketed by the grid cell of their centre, only nearby cells

@@ -221,18 +221,43 @@ __device__ __forceinline__ void pair_ixn2(const NbArgs& a, const float4 pi0, con
     if (ENERGY) { const v2f e = NOLJ ? cE : ljE + cE; energy = energy + mk2(in0 ? e.x : 0.f, in1 ? e.y : 0.f); }
 }
 
+// Where the 32 i atoms of a block come from inside the pair loops.  OMM_I_FROM_LANES = 1: lane k holds atom k in six
+// VGPRs (one coalesced vector load per chunk, together with the row gathers) and the loops fetch an atom with
+// v_readlane_b32 -- no memory access in the loops.  0: wave-uniform scalar loads (s_load_dwordx16) from posqI / sigEpsI
+// inside the loops: no VALU work, but 768 bytes do not fit the SGPR file, so every row re-loads them in pieces and waits
+// for each piece -- measured on the 1M-atom box (rocprofv3 SQ counters, profiles/r03b_*): waves parked on s_waitcnt for
+// 40-50 % of their cycles with the VALU active 30 %.
+#ifndef OMM_I_FROM_LANES
+#define OMM_I_FROM_LANES 1
+#endif
+struct IAtoms {
+    const float4* __restrict__ ip; const float2* __restrict__ ise;     // memory form
+    float4 pLane; float2 seLane;                                       // lane form
+    // k is a compile-time constant after unrolling: v_readlane_b32 with an immediate lane
+    __device__ __forceinline__ float4 posq(int k) const { return OMM_I_FROM_LANES ? rl4(pLane, k) : ip[k]; }
+    __device__ __forceinline__ float2 sigEps(int k) const { return OMM_I_FROM_LANES ? rl2(seLane, k) : ise[k]; }
+};
+
 // i atoms [K0, K1) of a block against the j atom of this lane, two per call (single-image path).
 template <int METHOD, bool ENERGY, bool MASKED, bool NOLJ, int K0, int K1>
-__device__ __forceinline__ void row_pairs2(const NbArgs& a, const float4* __restrict__ ip, const float2* __restrict__ ise, const float4 pj, const float2 sej,
+__device__ __forceinline__ void row_pairs2(const NbArgs& a, const IAtoms& ia, const float4 pj, const float2 sej,
                                            const float qjK, const unsigned m, float (&fix)[OMM_TILE], float (&fiy)[OMM_TILE], float (&fiz)[OMM_TILE],
                                            v2f& fj2x, v2f& fj2y, v2f& fj2z, v2f& energy2) {
 #pragma unroll
     for (int k = K0; k < K1; k += 2) {
         v2f ax = mk2(fix[k], fix[k + 1]), ay = mk2(fiy[k], fiy[k + 1]), az = mk2(fiz[k], fiz[k + 1]);
-        pair_ixn2<METHOD, ENERGY, MASKED, NOLJ>(a, ip[k], ip[k + 1], ise[k], ise[k + 1], pj, sej, qjK, MASKED ? ((m >> k) & 1u) != 0 : true,
+        pair_ixn2<METHOD, ENERGY, MASKED, NOLJ>(a, ia.posq(k), ia.posq(k + 1), ia.sigEps(k), ia.sigEps(k + 1), pj, sej, qjK, MASKED ? ((m >> k) & 1u) != 0 : true,
                                                 MASKED ? ((m >> (k + 1)) & 1u) != 0 : true, ax, ay, az, fj2x, fj2y, fj2z, energy2);
         fix[k] = ax.x; fix[k + 1] = ax.y; fiy[k] = ay.x; fiy[k + 1] = ay.y; fiz[k] = az.x; fiz[k + 1] = az.y;
     }
+}
+// ... and one per call with the image search per pair (general path)
+template <int METHOD, int PBC, bool ENERGY, bool MASKED>
+__device__ __forceinline__ void row_pairs1(const NbArgs& a, const IAtoms& ia, const float4 pj, const float2 sej, const float qjK, const unsigned m,
+                                           float (&fix)[OMM_TILE], float (&fiy)[OMM_TILE], float (&fiz)[OMM_TILE], float& fjx, float& fjy, float& fjz, float& energy) {
+#pragma unroll
+    for (int k = 0; k < OMM_TILE; k++)
+        pair_ixn<METHOD, PBC, ENERGY, MASKED>(a, ia.posq(k), ia.sigEps(k), pj, sej, qjK, MASKED ? ((m >> k) & 1u) != 0 : true, fix[k], fiy[k], fiz[k], fjx, fjy, fjz, energy);
 }
 
 // Two registers in, one out: lanes 0-31 get a[l] + a[l + 32], lanes 32-63 get b[l - 32] + b[l] -- gfx950's
@@ -327,8 +352,9 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
         const int nrows = __builtin_amdgcn_readfirstlane(info.y & 0xff) - rowBase;       // rows of this unit
         const int maskedBits = __builtin_amdgcn_readfirstlane(info.y >> 8) >> rowBase;
         if (nrows <= 0) continue;
-        const float4* __restrict__ ip = posqI + X * OMM_TILE;
-        const float2* __restrict__ ise = sigEpsI + X * OMM_TILE;
+        IAtoms ia;
+        ia.ip = posqI + X * OMM_TILE; ia.ise = sigEpsI + X * OMM_TILE;
+        if (OMM_I_FROM_LANES) { ia.pLane = a.posq[X * OMM_TILE + (lane & (OMM_TILE - 1))]; ia.seLane = a.sigEps[X * OMM_TILE + (lane & (OMM_TILE - 1))]; }
         float fix[OMM_TILE], fiy[OMM_TILE], fiz[OMM_TILE];
 #pragma unroll
         for (int k = 0; k < OMM_TILE; k++) { fix[k] = 0.f; fiy[k] = 0.f; fiz[k] = 0.f; }
@@ -349,8 +375,11 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
         // wave-uniform: do the i atoms from OMM_LJ_HEAD on all have epsilon = 0?  (scalar compares on the block's parameters)
         bool ljFree = a.ljHeadSplit != 0;
         if (PBC == 1 && single && ljFree) {
+            if (OMM_I_FROM_LANES) ljFree = ((unsigned) __ballot(ia.seLane.y != 0.f) >> OMM_LJ_HEAD) == 0u;       // lanes 12..31 of the lower half
+            else {
 #pragma unroll
-            for (int k = OMM_LJ_HEAD; k < OMM_TILE; k++) ljFree = ljFree && ise[k].y == 0.f;
+                for (int k = OMM_LJ_HEAD; k < OMM_TILE; k++) ljFree = ljFree && ia.ise[k].y == 0.f;
+            }
         }
         // All rows of the chunk are fetched before the first one is processed (index, then the gathers that depend on
         // it): the two memory round trips are paid once per chunk and the later rows arrive while the first is computed.
@@ -388,31 +417,23 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
                     // the block's atoms from OMM_LJ_HEAD on carry no Lennard-Jones parameters (water: the slot order puts the
                     // oxygens of a block first): two thirds of the row's pairs skip that part of the arithmetic
                     if (masked) {
-                        row_pairs2<METHOD, ENERGY, true, false, 0, OMM_LJ_HEAD>(a, ip, ise, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
-                        row_pairs2<METHOD, ENERGY, true, true, OMM_LJ_HEAD, OMM_TILE>(a, ip, ise, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
+                        row_pairs2<METHOD, ENERGY, true, false, 0, OMM_LJ_HEAD>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
+                        row_pairs2<METHOD, ENERGY, true, true, OMM_LJ_HEAD, OMM_TILE>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
                     }
                     else {
-                        row_pairs2<METHOD, ENERGY, false, false, 0, OMM_LJ_HEAD>(a, ip, ise, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
-                        row_pairs2<METHOD, ENERGY, false, true, OMM_LJ_HEAD, OMM_TILE>(a, ip, ise, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
+                        row_pairs2<METHOD, ENERGY, false, false, 0, OMM_LJ_HEAD>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
+                        row_pairs2<METHOD, ENERGY, false, true, OMM_LJ_HEAD, OMM_TILE>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
                     }
                 }
-                else if (masked) row_pairs2<METHOD, ENERGY, true, false, 0, OMM_TILE>(a, ip, ise, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
-                else row_pairs2<METHOD, ENERGY, false, false, 0, OMM_TILE>(a, ip, ise, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
+                else if (masked) row_pairs2<METHOD, ENERGY, true, false, 0, OMM_TILE>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
+                else row_pairs2<METHOD, ENERGY, false, false, 0, OMM_TILE>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
                 fjx += fj2x.x + fj2x.y; fjy += fj2y.x + fj2y.y; fjz += fj2z.x + fj2z.y;
             }
             else {
                 // general path: j in X's frame without an image shift; the pair code searches the image per pair
                 pj.x += cY.x - cX.x; pj.y += cY.y - cX.y; pj.z += cY.z - cX.z;
-                if (masked) {
-#pragma unroll
-                    for (int k = 0; k < OMM_TILE; k++)
-                        pair_ixn<METHOD, PBC, ENERGY, true>(a, ip[k], ise[k], pj, sej, qjK, (m >> k) & 1u, fix[k], fiy[k], fiz[k], fjx, fjy, fjz, energy);
-                }
-                else {
-#pragma unroll
-                    for (int k = 0; k < OMM_TILE; k++)
-                        pair_ixn<METHOD, PBC, ENERGY, false>(a, ip[k], ise[k], pj, sej, qjK, true, fix[k], fiy[k], fiz[k], fjx, fjy, fjz, energy);
-                }
+                if (masked) row_pairs1<METHOD, PBC, ENERGY, true>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fjx, fjy, fjz, energy);
+                else row_pairs1<METHOD, PBC, ENERGY, false>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fjx, fjy, fjz, energy);
             }
             const bool jOwned = j >= a.ownSlot0 && j < a.ownSlot1;
             if (!(a.debugFlags & 1)) { if (jOwned) add_force(a.force, a.paddedAtoms, j, fjx, fjy, fjz); }

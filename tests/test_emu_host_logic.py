@@ -197,7 +197,8 @@ def test_pme_logic(K, tric):
 
 
 FAST_REFERENCE_TESTS = ["HarmonicBondForce", "HarmonicAngleForce", "PeriodicTorsionForce", "CMMotionRemover", "Checkpoints",
-                        "CustomBondForce", "RBTorsionForce", "Settle", "NonbondedForce", "CustomExternalForce", "VirtualSites"]
+                        "CustomBondForce", "RBTorsionForce", "Settle", "NonbondedForce", "CustomExternalForce", "VirtualSites",
+                        "AmoebaVdwForce", "AmoebaMultipoleForce", "AmoebaTorsionTorsionForce"]
 
 
 @needs_emu

@@ -66,7 +66,7 @@ def parse_args():
     p.add_argument("--decompose", action="store_true", help="N = 1: run through the decomposed path with a one-rank RCCL communicator (overhead check on one GPU)")
     p.add_argument("--props", default="", help="extra HIP platform properties, e.g. DisablePmeStream=true")
     p.add_argument("--serialize-ranks", action="store_true", help="diagnostics, gloo transport on one GPU: the ranks run their work between collectives one at a time, so each rank's compute time per step is measured on an idle GPU (per_rank_compute_ms_per_step); the wall-clock value is meaningless in this mode")
-    p.add_argument("--attempt-timeout", type=float, default=300.0, help="N > 1: seconds a configuration may take before the launchers give up on it")
+    p.add_argument("--attempt-timeout", type=float, default=200.0, help="N > 1: seconds a configuration may take before the launchers give up on it")
     return p.parse_args()
 
 

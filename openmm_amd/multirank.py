@@ -177,7 +177,11 @@ def run_attempts(commands, rank, world, master_addr, master_port, timeout_s, env
         # torch.distributed.run tells its workers to rendezvous through the agent's own store; the children form a group of their own
         child_env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
         child_env.update({"MASTER_ADDR": master_addr, "MASTER_PORT": str(master_port + 1 + i), "BENCH_ATTEMPT": str(i), "BENCH_CHILD": "1"})
-        proc = subprocess.Popen(cmd, env=child_env, stdout=subprocess.PIPE, text=True)
+        # the child's stderr goes to a file of its own: the tail of it is what explains a failed attempt in the result line
+        # (a run on hardware nobody can log into afterwards) -- and is passed on to this process's stderr either way
+        import tempfile
+        errfile = tempfile.TemporaryFile(mode="w+", prefix="bench_attempt%d_rank%d_" % (i, rank))
+        proc = subprocess.Popen(cmd, env=child_env, stdout=subprocess.PIPE, stderr=errfile, text=True)
         lines = []
         reader = threading.Thread(target=lambda: lines.extend(l.rstrip("\n") for l in proc.stdout), daemon=True)
         reader.start()
@@ -196,6 +200,26 @@ def run_attempts(commands, rank, world, master_addr, master_port, timeout_s, env
         reader.join(5.0)
         if why is None and proc.returncode != 0:
             why = "exit code %d" % proc.returncode
+        err_tail = ""
+        try:
+            errfile.seek(0)
+            err_text = errfile.read()
+            errfile.close()
+            if err_text:
+                import sys as _sys
+                _sys.stderr.write(err_text)
+                _sys.stderr.flush()
+            err_lines = [l for l in err_text.splitlines() if l.strip()]
+            err_tail = " | ".join(err_lines[-3:])[-400:]
+        except Exception:
+            pass
+        if why is not None and proc.returncode not in (0, None, -9) and err_tail:
+            why += " (rank %d stderr: %s)" % (rank, err_tail)
+            try:      # the rank whose child actually failed tells the others why (rank 0 writes the result line)
+                if store.add("haserr%d" % i, 1) == 1:
+                    store.set("errtext%d" % i, "rank %d stderr: %s" % (rank, err_tail))
+            except Exception:
+                pass
         if why is not None:
             store.add("fail%d" % i, 1)
         store.add("done%d" % i, 1)
@@ -209,7 +233,14 @@ def run_attempts(commands, rank, world, master_addr, master_port, timeout_s, env
                 time.sleep(poll_s)
         if not failed:
             return i, lines, notes
-        notes.append("attempt %d (%s): %s" % (i, " ".join(cmd[-4:]), why or "failed on another rank"))
+        reason = why or "failed on another rank"
+        if "stderr:" not in reason:
+            try:
+                if store.add("haserr%d" % i, 0) > 0:
+                    reason += " (" + store.get("errtext%d" % i).decode(errors="replace") + ")"
+            except Exception:
+                pass
+        notes.append("attempt %d (%s): %s" % (i, " ".join(cmd[-4:]), reason))
         if log is not None:
             log(notes[-1])
     raise RuntimeError("every configuration failed: " + "; ".join(notes))

@@ -213,7 +213,7 @@ def run_attempts(commands, rank, world, master_addr, master_port, timeout_s, env
             err_tail = " | ".join(err_lines[-3:])[-400:]
         except Exception:
             pass
-        if why is not None and proc.returncode not in (0, None, -9) and err_tail:
+        if why is not None and err_tail and (proc.returncode not in (0, None, -9) or why.startswith("no result")):
             why += " (rank %d stderr: %s)" % (rank, err_tail)
             try:      # the rank whose child actually failed tells the others why (rank 0 writes the result line)
                 if store.add("haserr%d" % i, 1) == 1:

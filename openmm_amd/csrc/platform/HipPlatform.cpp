@@ -269,8 +269,14 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
             getPropertyDefaultValue(HipDisablePmeStream()) : properties.find(HipDisablePmeStream())->second);
     data->hip->usePmeStream = data->propertyValues[HipDisablePmeStream()] != "true";
     data->hip->deterministicForces = data->propertyValues[HipDeterministicForces()] == "true";
-    // decomposed runs overlap reciprocal space (and its collectives) with the pair kernel unless told otherwise
-    if (data->hip->decomposed() && properties.find(HipDisablePmeStream()) == properties.end()) {
+    // decomposed runs overlap reciprocal space (and its collectives) with the pair kernel unless told otherwise -- and so do
+    // single-GPU runs of systems above the size up to which the fused single-stream launches are used (HipKernels.cpp,
+    // OPENMM_HIP_FUSED_FRONT_MAX_ATOMS): there the pair kernel is a launch of its own that fills the chip for 0.1-1 ms while
+    // the FFT launches need a few hundred workgroups; same-box A/B (profiles/r03f_ab_pme_stream.txt): +2.5 % at 92 k atoms,
+    // +2.8 % at 98 k, +2 % at 985 k
+    static const int fusedMaxAtoms = getenv("OPENMM_HIP_FUSED_FRONT_MAX_ATOMS") != NULL ? atoi(getenv("OPENMM_HIP_FUSED_FRONT_MAX_ATOMS")) : 60000;
+    if (properties.find(HipDisablePmeStream()) == properties.end() &&
+            (data->hip->decomposed() || (!mode.hostMode && context.getSystem().getNumParticles() > fusedMaxAtoms))) {
         data->hip->usePmeStream = true;
         data->propertyValues[HipDisablePmeStream()] = "false";
     }

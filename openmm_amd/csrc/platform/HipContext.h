@@ -126,6 +126,7 @@ public:
     void requestReorder() { reorderRequested = true; }
     void stepTaken();                                           // counts steps towards the next reorder
 
+    int getDeviceIndex() const { return deviceIndex; }
     void addListener(HipContextListener* l) { listeners.push_back(l); }
     /** Atoms that should sit at the END of their 32-slot block (e.g. atoms without Lennard-Jones parameters: the pair kernel
      *  skips that part of the arithmetic for the tail of a block whose atoms have none).  Takes effect at the next re-sort. */

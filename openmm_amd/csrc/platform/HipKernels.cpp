@@ -642,7 +642,9 @@ double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool
                                            hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.pmeStream));
         hip.markPmeDone();
         HIP_CHECK(ommhip_nl_rebuild_if_requested(&nl, hip.stream));
+        params.direct_grid = pairGridBesideSideStream();
         HIP_CHECK(ommhip_nb_direct(&nl, &params, sigEps.ptr, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+        params.direct_grid = directGridOverride;
     }
     else {
         pme.comm = hip.domain.comm;
@@ -934,6 +936,23 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     if (nonbondedMethod == Ewald)
         ewaldStructure.allocate(sizeof(double) * 2 * (size_t) kmax[0] * (2 * kmax[1] - 1) * (2 * kmax[2] - 1));
     hip.sync();
+}
+
+int HipCalcNonbondedForceKernel::pairGridBesideSideStream() {
+    // Pair kernel while reciprocal space runs on the side stream: with a long list, 2 wavefronts per SIMD that walk through the
+    // chunks (8 per CU x 4 SIMDs... = 8 x CUs workgroups of one wavefront) instead of one short-lived wavefront per chunk -- the
+    // small launches of the side stream then find a chip in a steady state instead of queueing behind a dispatch backlog of
+    // 10^5 workgroups.  Same-box A/B on one GPU (profiles/r03h_ab_persistent_grid_two_streams.txt): 2.69 / 2.65 -> 2.60 ms per step
+    // at 985 k atoms, 0.321 / 0.312 -> 0.309 / 0.311 at 92 k; fewer wavefronts than that (slots left free on purpose) lose.
+    // Decomposed runs take the same setting (same mechanism, not measured there).
+    if (directGridOverride != 0) return directGridOverride;
+    static int resident = 0;
+    if (resident == 0) {
+        int cus = 0;
+        if (ommhip_device_info(hip.getDeviceIndex(), NULL, 0, &cus, NULL) != 0 || cus <= 0) cus = 256;
+        resident = 8 * cus;
+    }
+    return nl.max_chunks >= 4 * resident ? resident : 0;
 }
 
 bool HipCalcNonbondedForceKernel::enableTileSpread(int nx, int ny, int nz) {
@@ -1302,8 +1321,11 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
             if (rc > 0) HIP_CHECK(rc);
             fftLaunched = rc == 0;
         }
-        if (!fftLaunched)
+        if (!fftLaunched) {
+            if (pmeLaunched && hip.usePmeStream) params.direct_grid = pairGridBesideSideStream();
             HIP_CHECK(ommhip_nb_direct(&nl, &params, sigEps.ptr, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
+            params.direct_grid = directGridOverride;
+        }
         if ((++evaluationCount & 15) == 0) {
             HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
             stateCopyPending = true;

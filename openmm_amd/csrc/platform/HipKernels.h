@@ -153,6 +153,7 @@ private:
     double nonbondedCutoff, switchingDistance, rfDielectric, ewaldAlpha, dispersionCoefficient, selfEnergy, padding;
     bool useSwitchingFunction, exceptionsArePeriodic, usesPeriodic;
     int kmax[3], gridSize[3], directGridOverride = 0;
+    int pairGridBesideSideStream();
     unsigned evaluationCount = 0;
     std::vector<std::vector<double> > baseParticleParams, baseExceptionParams;   // (charge, sigma, epsilon)
     std::vector<std::pair<int, int> > exceptionAtoms;

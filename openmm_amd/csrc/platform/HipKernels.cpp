@@ -644,7 +644,7 @@ double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool
         HIP_CHECK(ommhip_nl_rebuild_if_requested(&nl, hip.stream));
         params.direct_grid = pairGridBesideSideStream();
         HIP_CHECK(ommhip_nb_direct(&nl, &params, sigEps.ptr, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
-        params.direct_grid = directGridOverride;
+        params.direct_grid = directGridOverride > 0 ? directGridOverride : 0;
     }
     else {
         pme.comm = hip.domain.comm;
@@ -930,7 +930,7 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
         params.crf = (1.0 / nonbondedCutoff) * (3.0 * rfDielectric) / (2.0 * rfDielectric + 1.0);
     }
     params.switch_distance = switchingDistance;
-    params.direct_grid = directGridOverride;
+    params.direct_grid = directGridOverride > 0 ? directGridOverride : 0;
     if (nonbondedMethod == PME) { if (hip.decomposed()) setupPmeDecomposed(); else setupPme(); }
     if (nonbondedMethod == LJPME) { setupPme(); setupDispersionPme(); }
     if (nonbondedMethod == Ewald)
@@ -945,7 +945,7 @@ int HipCalcNonbondedForceKernel::pairGridBesideSideStream() {
     // 10^5 workgroups.  Same-box A/B on one GPU (profiles/r03h_ab_persistent_grid_two_streams.txt): 2.69 / 2.65 -> 2.60 ms per step
     // at 985 k atoms, 0.321 / 0.312 -> 0.309 / 0.311 at 92 k; fewer wavefronts than that (slots left free on purpose) lose.
     // Decomposed runs take the same setting (same mechanism, not measured there).
-    if (directGridOverride != 0) return directGridOverride;
+    if (directGridOverride != 0) return directGridOverride > 0 ? directGridOverride : 0;       // OPENMM_HIP_DIRECT_GRID=-1: one wavefront per chunk everywhere (A/B)
     static int resident = 0;
     if (resident == 0) {
         int cus = 0;
@@ -1324,7 +1324,7 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
         if (!fftLaunched) {
             if (pmeLaunched && hip.usePmeStream) params.direct_grid = pairGridBesideSideStream();
             HIP_CHECK(ommhip_nb_direct(&nl, &params, sigEps.ptr, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
-            params.direct_grid = directGridOverride;
+            params.direct_grid = directGridOverride > 0 ? directGridOverride : 0;
         }
         if ((++evaluationCount & 15) == 0) {
             HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));

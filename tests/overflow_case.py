@@ -25,7 +25,7 @@ def run(shrink, steps):
     w.cm_remover = True
     s, nb = w.build()
     integ = H.Integrator(H.LANGEVIN_MIDDLE, 0.002, 300.0, 1.0, seed=5)
-    c = H.Context(s, integ, "HIP")
+    c = H.Context(s, integ, "HIP", %r)
     c.setPositions(w.positions); c.applyConstraints(1e-6); c.setVelocitiesToTemperature(300.0, 2)
     integ.step(steps)
     st = c.getState(getPositions=True, getVelocities=True, getEnergy=True)
@@ -43,9 +43,9 @@ print("OK")
 '''
 
 
-def run_overflow_case(tmp_path, emulated, n_side, grid, pos_tol, vel_tol):
+def run_overflow_case(tmp_path, emulated, n_side, grid, pos_tol, vel_tol, props=None):
     script = tmp_path / "overflow_child.py"
-    script.write_text(CHILD % (ROOT, emulated, n_side, grid, grid, grid, pos_tol, vel_tol))
+    script.write_text(CHILD % (ROOT, emulated, n_side, grid, grid, grid, props, pos_tol, vel_tol))
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=1200)
     assert "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
     assert out.stderr.count("neighbour list overflowed") == 2, out.stderr[-2000:]

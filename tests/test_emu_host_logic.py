@@ -316,6 +316,13 @@ def test_neighbour_list_overflow_is_recovered(tmp_path):
 
 
 @needs_emu
+def test_neighbour_list_overflow_is_recovered_with_the_side_stream(tmp_path):
+    """... and with reciprocal space on its own stream (the default above 60 000 atoms and on decomposed runs)."""
+    from overflow_case import run_overflow_case
+    print(run_overflow_case(tmp_path, True, 7, 20, 5e-6, 5e-4, props={"DisablePmeStream": "false"}))
+
+
+@needs_emu
 def test_native_ljpme_matches_the_reference_platform():
     """tests/ljpme_case.py on the emulated kernels (own process: one plugin build per process)."""
     import subprocess

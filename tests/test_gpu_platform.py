@@ -278,14 +278,14 @@ print("OK", st.potentialEnergy)
     assert max_rel_force_error(f_host, st.forces) < 2e-6
 
 
-def _trajectory(w, steps, kind, env):
+def _trajectory(w, steps, kind, env, props=None):
     """positions/velocities after `steps` steps with the given environment knobs set while the Context is built and run"""
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
         system, nb = w.build()
         integ = H.Integrator(kind, 0.002 if kind != H.VERLET else 0.001, 300.0, 1.0, seed=7, constraintTolerance=1e-6)
-        ctx = H.Context(system, integ, "HIP")
+        ctx = H.Context(system, integ, "HIP", props)
         ctx.setPositions(w.positions)
         ctx.applyConstraints(1e-6)
         if getattr(w, "velocities", None) is not None:
@@ -347,6 +347,20 @@ def test_fused_launches_equal_separate_launches(workload):
     assert abs(a.potentialEnergy - b.potentialEnergy) < 1e-6 * abs(b.potentialEnergy) + 1e-3
 
 
+@pytest.mark.parametrize("workload", ["water", "dhfr"])
+def test_side_stream_equals_single_stream(workload):
+    """Reciprocal space on the high-priority side stream beside list rebuild and pair kernel (the default above 60 000 atoms and
+    on decomposed runs; requested here with DisablePmeStream=false) against the single-stream default with its fused launches:
+    same trajectory over steps that include list rebuilds, to single-precision rounding of the differently shaped FFT stages."""
+    w = T.water_box(12, seed=4) if workload == "water" else T.dhfr_like(seed=1)
+    a = _trajectory(w, 12, H.LANGEVIN_MIDDLE, {}, {"DisablePmeStream": "false"})
+    b = _trajectory(w, 12, H.LANGEVIN_MIDDLE, {}, {"DisablePmeStream": "true"})
+    assert np.abs(a.positions - b.positions).max() < 2e-6
+    assert max_rel_force_error(a.forces, b.forces) < 1e-4
+    assert abs(a.potentialEnergy - b.potentialEnergy) < 2e-6 * abs(b.potentialEnergy) + 1e-2
+    assert abs(a.kineticEnergy - b.kineticEnergy) < 1e-4 * abs(b.kineticEnergy)
+
+
 def test_cell_binned_builder_matches_full_scan_at_98k_atoms():
     """On large systems (16 384 i-blocks up) the list builder looks for candidate blocks through a cell grid instead of
     testing all blocks (quadratic).  Forced here at 98 304 atoms (14 cells per axis, reach 3): both searches must produce
@@ -364,6 +378,13 @@ def test_neighbour_list_overflow_is_recovered(tmp_path):
     order in which wavefronts append to it, so the two trajectories differ by float32 summation noise.)"""
     from overflow_case import run_overflow_case
     print(run_overflow_case(tmp_path, False, 12, 32, 2e-5, 2e-3))
+
+
+def test_neighbour_list_overflow_is_recovered_with_the_side_stream(tmp_path):
+    """The same with reciprocal space on its own stream (the default above 60 000 atoms): the frozen steps and their replay must
+    not depend on which stream the grid work of a skipped evaluation ran on."""
+    from overflow_case import run_overflow_case
+    print(run_overflow_case(tmp_path, False, 12, 32, 2e-5, 2e-3, props={"DisablePmeStream": "false"}))
 
 
 def test_native_ljpme_matches_the_reference_platform():

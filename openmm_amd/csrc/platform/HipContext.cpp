@@ -305,6 +305,7 @@ void HipContext::flushTerms() {
 int HipContext::registerTerms(int group, const ommhip_term_batch& batch) {
     TermRegistration r = {nextTermId++, group, batch};
     termRegistry.push_back(r);
+    foreignPositionsNeeded = true;        // every rank evaluates every registered term (bonds, angles, torsions): all positions must be current
     return r.id;
 }
 

@@ -155,6 +155,9 @@ public:
     /** Integration units (constraint-connected groups of atoms): CSR over units in atom-index order of their first atom. */
     std::vector<int> unitStart, unitAtomList, unitOfAtom;
     int maxUnitSize;
+    /** Decomposed runs: does anything read the double-precision positions of atoms this rank does not own (term lists of bonded
+     *  forces, 1-4s, exclusion pairs across integration units)?  If not, nl_prepare skips the per-step refresh of those positions. */
+    bool foreignPositionsNeeded = false;
     /** Units owned by this rank after the last re-sort (indices into unitStart). */
     std::vector<int> ownedUnits;
 

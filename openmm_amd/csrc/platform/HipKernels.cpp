@@ -602,7 +602,11 @@ double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool
     nl.pbc = 1;
     nl.dd_mode = 1;
     nl.first_block = hip.ownSlot0 / OMMHIP_TILE; nl.owned_blocks = hip.slotsPerRank / OMMHIP_TILE;
-    nl.pos_wire = hip.posWire.ptr; nl.pos_scatter = hip.pos.ptr;
+    // double-precision positions of foreign atoms (atom order) are refreshed per step only if something reads them: term lists of
+    // bonded forces (evaluated by every rank), 1-4 terms, exclusion partners in another integration unit.  A water box needs none
+    // of it -- 64 B of scattered read-modify-write per foreign atom and step saved.
+    nl.pos_wire = hip.posWire.ptr;
+    nl.pos_scatter = (hip.foreignPositionsNeeded || exclusionsSpanUnits || num14 > 0) ? hip.pos.ptr : NULL;
     foldExclusions = numExclusionPairs > 0;
     checkDecomposedFlags();
     if (nl.max_chunks == 0) allocateNeighborList((int) (estimateChunks() * 1.4 / hip.domain.ranks) + 256);
@@ -786,6 +790,9 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     for (size_t i = 0; i < nb14s.size(); i++) nb14Index[nb14s[i]] = (int) i;
     num14 = (int) nb14s.size();
     numExclusionPairs = (int) exclusionPairs.size() / 2;
+    exclusionsSpanUnits = false;
+    for (size_t i = 0; i + 1 < exclusionPairs.size() && !hip.unitOfAtom.empty(); i += 2)
+        if (hip.unitOfAtom[exclusionPairs[i]] != hip.unitOfAtom[exclusionPairs[i + 1]]) { exclusionsSpanUnits = true; break; }
     baseParticleParams.assign(numParticles, vector<double>(3));
     baseExceptionParams.assign(num14, vector<double>(3));
     exceptionAtoms.resize(num14);

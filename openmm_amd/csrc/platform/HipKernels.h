@@ -149,6 +149,7 @@ private:
     HipPlatform::PlatformData& data;
     HipContext& hip;
     int numParticles, num14, numExclusionPairs;
+    bool exclusionsSpanUnits = false;
     NonbondedMethod nonbondedMethod;
     double nonbondedCutoff, switchingDistance, rfDielectric, ewaldAlpha, dispersionCoefficient, selfEnergy, padding;
     bool useSwitchingFunction, exceptionsArePeriodic, usesPeriodic;

@@ -319,7 +319,7 @@ def test_neighbour_list_overflow_is_recovered(tmp_path):
 def test_neighbour_list_overflow_is_recovered_with_the_side_stream(tmp_path):
     """... and with reciprocal space on its own stream (the default above 60 000 atoms and on decomposed runs)."""
     from overflow_case import run_overflow_case
-    print(run_overflow_case(tmp_path, True, 7, 20, 5e-6, 5e-4, props={"DisablePmeStream": "false"}))
+    print(run_overflow_case(tmp_path, True, 7, 20, 5e-6, 5e-4, props={"DisablePmeStream": "false"}, step_counts=(18,)))      # found by the lazy read-back
 
 
 @needs_emu

@@ -27,7 +27,7 @@ def box6(box3):
     return (C.c_double * 6)(box3[0, 0], box3[1, 0], box3[1, 1], box3[2, 0], box3[2, 1], box3[2, 2])
 
 
-def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64, compact=False, cells=False, fused_pme=None, block_range=None, energy=True, lj_free_tail=False):
+def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64, compact=False, cells=False, fused_pme=None, block_range=None, energy=True, lj_free_tail=False, ewald_tol=5e-4):
     """-> (forces[n,3], energy, oracle forces, oracle energy, nl state)
 
     compact=False: random slot order, list built by ommhip_nl_update on wrapped coordinates (general image search).
@@ -119,7 +119,7 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     if fused_pme is not None:
         assert method == ONB.PME and not triclinic
         ng = fused_pme
-        pm = make_pme(K, ng, box3, float(np.sqrt(-np.log(2 * 5e-4)) / cutoff))
+        pm = make_pme(K, ng, box3, float(np.sqrt(-np.log(2 * ewald_tol)) / cutoff))
         pm.grid_precleared = 1
         K.pme_build_eterm(C.byref(pm), None)
         d_f, d_e = K.upload(np.full(3 * padded, 12345, np.int64)), K.upload(np.zeros(grid))       # the force buffer starts dirty: nl_prepare clears it
@@ -133,7 +133,7 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     state = K.download(nl.state, 8, np.int32)
     p = capi.NonbondedParams()
     p.ewald = 1 if method in (ONB.Ewald, ONB.PME) else 0
-    alpha = float(np.sqrt(-np.log(2 * 5e-4)) / cutoff) if p.ewald else 0.0
+    alpha = float(np.sqrt(-np.log(2 * ewald_tol)) / cutoff) if p.ewald else 0.0
     p.ewald_alpha = alpha
     if method in (ONB.CutoffPeriodic, ONB.CutoffNonPeriodic):
         p.krf, p.crf = ONB.reaction_field_constants(cutoff, 78.3)

@@ -61,6 +61,16 @@ def test_direct_space_force_only_and_lj_free_variants(K, energy, lj_free_tail, f
 
 
 @needs_emu
+@pytest.mark.parametrize("ewald_tol", [1e-4, 1e-6])
+def test_direct_space_force_only_at_other_ewald_tolerances(K, ewald_tol):
+    """alpha * cutoff = 2.92 (the degree-11 fit of the real-space Ewald force still holds: polynomial form) and 3.62 (it does not:
+    the kernel must fall back to the erfc form) -- same accuracy against the oracle either way."""
+    f, e, f_or, e_or, state = KC.run_direct_space(K, 1200, ONB.PME, 0.7, 3.4, EXCL, compact=True, energy=False, ewald_tol=ewald_tol)
+    assert state[2] == 0 and state[1] > 0
+    assert max_rel_force_error(f, f_or) < 5e-5
+
+
+@needs_emu
 @pytest.mark.parametrize("switch,ng", [(None, (24, 24, 24)), (0.6, (24, 20, 28))])
 def test_fused_single_stream_evaluation(K, switch, ng):
     """nl_prepare (+clears) -> force_front (list build + charge spreading) -> pairs_with_fft -> interpolate, through the C ABI"""

@@ -58,6 +58,14 @@ def test_direct_space_force_only_and_lj_free_variants(K, energy, lj_free_tail, f
         assert abs(e - e_or) < 1e-5 * max(abs(e_or), 100.0)
 
 
+@pytest.mark.parametrize("ewald_tol", [1e-4, 1e-6])
+def test_direct_space_force_only_at_other_ewald_tolerances(K, ewald_tol):
+    """alpha * cutoff = 2.92 (polynomial form of the real-space Ewald force) and 3.62 (beyond its fit: erfc form) -- same bar."""
+    f, e, f_or, e_or, state = KC.run_direct_space(K, 3000, ONB.PME, 0.9, 4.6, EXCL, grid=256, compact=True, energy=False, ewald_tol=ewald_tol)
+    assert state[2] == 0 and state[1] > 0
+    assert max_rel_force_error(f, f_or) < 1e-4
+
+
 @pytest.mark.parametrize("n,L,cutoff,compact", [(3000, 4.6, 0.9, True), (3000, 4.6, 0.9, False), (2500, 6.5, 0.8, True)])
 def test_direct_space_cell_binned_builder(K, n, L, cutoff, compact):
     """The candidate search used from 65 k atoms up (blocks bucketed by the grid cell of their centre, only nearby cells

@@ -532,19 +532,50 @@ __global__ __launch_bounds__(128) void k_step_units(IntArgs a, UnitArgs u) {
     if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = mom.x; part[threadIdx.x >> 6][1] = mom.y; part[threadIdx.x >> 6][2] = mom.z; }
     __syncthreads();
     int* counter = (int*) (u.cm + 3);
+    // Hand-over of the block partials to the last block.  OMM_CM_TAIL_ATOMICS = 1: the three partial sums are written with
+    // returning device-scope atomics (they complete at the memory side before the counter is touched) and read back the same
+    // way -- no __threadfence(), whose L2 write-back (buffer_wbl2) would flush everything this kernel has just written on the
+    // XCD, once per block, on the critical path of the step's last launch.  0: plain stores + fence (the form until session 2).
+#ifndef OMM_CM_TAIL_ATOMICS
+#define OMM_CM_TAIL_ATOMICS 1
+#endif
     if (threadIdx.x == 0) {
         double* out = u.cm + 4 + 4 * blockIdx.x;
-        out[0] = part[0][0] + part[1][0]; out[1] = part[0][1] + part[1][1]; out[2] = part[0][2] + part[1][2];
-        __threadfence();
-        last = atomicAdd(counter, 1) == (int) gridDim.x - 1;
+        const double sx = part[0][0] + part[1][0], sy = part[0][1] + part[1][1], sz = part[0][2] + part[1][2];
+        if (OMM_CM_TAIL_ATOMICS) {
+            unsigned long long seen = atomicExch((unsigned long long*) &out[0], (unsigned long long) __double_as_longlong(sx));
+            seen |= atomicExch((unsigned long long*) &out[1], (unsigned long long) __double_as_longlong(sy));
+            seen |= atomicExch((unsigned long long*) &out[2], (unsigned long long) __double_as_longlong(sz));
+            // the returned values are consumed before the counter is touched: the three exchanges have completed by then
+#ifdef OMMHIP_EMU
+            (void) seen;
+#else
+            asm volatile("" :: "v"(seen));
+#endif
+            last = atomicAdd(counter, 1) == (int) gridDim.x - 1;
+        }
+        else {
+            out[0] = sx; out[1] = sy; out[2] = sz;
+            __threadfence();
+            last = atomicAdd(counter, 1) == (int) gridDim.x - 1;
+        }
     }
     __syncthreads();
     if (last && threadIdx.x < 64) {
         // fixed summation order -> the same bits whatever the block scheduling
         double sx = 0, sy = 0, sz = 0;
         for (int b = threadIdx.x; b < (int) gridDim.x; b += 64) {
-            const volatile double* in = u.cm + 4 + 4 * b;
-            sx += in[0]; sy += in[1]; sz += in[2];
+            if (OMM_CM_TAIL_ATOMICS) {
+                unsigned long long* in = (unsigned long long*) (u.cm + 4 + 4 * b);
+                // a real read-modify-write (an add of 0 would be folded into a load, which the XCD's L2 may serve from a stale line)
+                sx += __longlong_as_double((long long) atomicExch(&in[0], 0ull));
+                sy += __longlong_as_double((long long) atomicExch(&in[1], 0ull));
+                sz += __longlong_as_double((long long) atomicExch(&in[2], 0ull));
+            }
+            else {
+                const volatile double* in = u.cm + 4 + 4 * b;
+                sx += in[0]; sy += in[1]; sz += in[2];
+            }
         }
         sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
         if (threadIdx.x == 0) {

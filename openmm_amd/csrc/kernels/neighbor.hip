@@ -608,7 +608,14 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
         a.posqRef[X * OMM_TILE + 5].w = (float) (tSetup - tStart);
         a.posqRef[X * OMM_TILE + 6].w = (float) (tRanges - tStart);
         a.posqRef[X * OMM_TILE + 7].w = (float) (tEntries - tStart);
+        // No __threadfence() here (OMM_NL_TAIL_FENCE=1 restores it for A/B): nothing inside this launch reads what the other
+        // workgroups wrote -- the last one out only exchanges the allocation counter, and the workgroup barriers of flush()
+        // order every allocation of this workgroup before the increment below; rows, reference positions and the published
+        // state reach their consumers through the kernel boundary.  A fence per builder workgroup is an L2 write-back of
+        // everything written on the XCD so far, 30 798 times per rebuild at a million atoms.
+#if defined(OMM_NL_TAIL_FENCE) && OMM_NL_TAIL_FENCE
         __threadfence();
+#endif
         const int done = atomicAdd(&a.state[ST_BLOCKS_DONE], 1);
         if (done == numWorkgroups - 1) {
             // publish the list length, return the working counter to zero, clear the request

@@ -45,7 +45,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-KERNEL_SOURCES = ("nonbonded.hip", "force_front.hip", "pme.hip", "neighbor.hip", "common.h")
+# Sources the PMC-profiled launches (pairs_fft_plane / pairs_fft_lines: pair kernel + FFT stages) are compiled from; profiles/pmc_pairs_fft.json
+# is quoted only while their hash matches.  (neighbor.hip -- the list BUILDER -- was part of the set until the end of round 2; a change
+# of the list FORMAT shows up in nonbonded.hip, which reads it.)
+KERNEL_SOURCES = ("nonbonded.hip", "force_front.hip", "pme.hip", "common.h")
 WORKLOADS = ["dhfr", "dhfr_like", "water1k", "water24k", "water98k", "apoa1", "water1m"]
 EMULATED = os.environ.get("BENCH_EMULATED") == "1"     # tests only: the CPU SIMT emulator build of the plugin (tests/emu), to run the N > 1 flow without a GPU
 

@@ -411,6 +411,9 @@ typedef struct ommhip_step_units {
     void* pos_wire;
     double box_len[3];
     int ranks, rank, slots_per_rank, trailer_slot;
+    /* 1: no unit is a SHAKE cluster (SETTLE waters and free atoms only, at most three atoms per unit): the kernel variant without
+     * the fourth atom's state and the SHAKE iteration is launched (fewer registers, more waves per SIMD) */
+    int small_units;
 } ommhip_step_units;
 enum { OMMHIP_INTEGRATOR_VERLET = 0, OMMHIP_INTEGRATOR_LANGEVIN = 1, OMMHIP_INTEGRATOR_LANGEVIN_MIDDLE = 2 };
 int ommhip_integrate_fused(int integrator, const ommhip_integrator_state* s, const ommhip_step_units* u, void* stream);

@@ -429,8 +429,11 @@ struct UnitArgs {
     int ranks, rank, slotsPerRank, trailerSlot;
 };
 
-template <int KIND>
+// SMALL: no unit is a SHAKE cluster (only SETTLE waters and free atoms: every unit has at most three atoms) -- the state of a fourth
+// atom and the SHAKE iteration are compiled out, which is worth registers (two waves per SIMD otherwise) in a latency-bound kernel.
+template <int KIND, bool SMALL>
 __global__ __launch_bounds__(128) void k_step_units(IntArgs a, UnitArgs u) {
+    constexpr int MAXA = SMALL ? 3 : 4;
     if (frozen(a, true)) return;
     const int c = blockIdx.x * 128 + threadIdx.x;
     V3 mom = v3(0, 0, 0);
@@ -438,9 +441,9 @@ __global__ __launch_bounds__(128) void k_step_units(IntArgs a, UnitArgs u) {
         const int4 at = u.atoms[c];
         const double4 dd = u.dist[c];
         const int kind = (int) dd.w;
-        const int ids[4] = {at.x, at.y, at.z, at.w};
-        V3 x[4], v[4], xn[4], ox[4];
-        double w[4], xw[4];
+        const int ids[4] = {at.x, at.y, at.z, SMALL ? -1 : at.w};
+        V3 x[MAXA], v[MAXA], xn[MAXA], ox[MAXA];
+        double w[MAXA], xw[MAXA];
         V3 cmv = v3(0, 0, 0);
         if (u.removeCm) {
             if (u.posWire != nullptr) {
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(128) void k_step_units(IntArgs a, UnitArgs u) {
         }
         const double h = 0.5 * a.dt;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < MAXA; k++) {
             x[k] = v3(0, 0, 0); v[k] = v3(0, 0, 0); w[k] = 0; xw[k] = 0;
             if (ids[k] >= 0) {
                 const double4 p = a.pos[ids[k]], vv = a.vel[ids[k]];
@@ -474,20 +477,20 @@ __global__ __launch_bounds__(128) void k_step_units(IntArgs a, UnitArgs u) {
             xn[k] = x[k]; ox[k] = x[k];
         }
         V3 r[3];
-        double iws[3] = {w[1], w[2], w[3]};
+        double iws[3] = {w[1], w[2], SMALL ? 0.0 : w[MAXA - 1]};
         const double dist[3] = {dd.x, dd.y, dd.z};
         int n = 0;
-        if (kind == 2) {
+        if (!SMALL && kind == 2) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) { r[k] = x[0] - x[k + 1]; if (ids[k + 1] >= 0) n = k + 1; }
+            for (int k = 0; k < MAXA - 1; k++) { r[k] = x[0] - x[k + 1]; if (ids[k + 1] >= 0) n = k + 1; }
         }
         if (KIND == 2) {
             // velocity constraints on the kicked velocities (ReferenceLangevinMiddleDynamics.cpp:104)
             if (kind == 1) settle_velocities_regs(x[0], x[1], x[2], v[0], v[1], v[2], w[0], w[1], w[2]);
-            else if (kind == 2) { V3 t[3] = {v[1], v[2], v[3]}; shake_regs<true>(r, v[0], t, w[0], iws, dist, n, u.tol, u.maxIterations); v[1] = t[0]; v[2] = t[1]; v[3] = t[2]; }
+            else if (!SMALL && kind == 2) { V3 t[3] = {v[1], v[2], v[MAXA - 1]}; shake_regs<true>(r, v[0], t, w[0], iws, dist, n, u.tol, u.maxIterations); v[1] = t[0]; v[2] = t[1]; v[MAXA - 1] = t[2]; }
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < MAXA; k++) {
             if (ids[k] >= 0 && w[k] != 0.0) {
                 if (KIND == 2) {
                     xn[k] = x[k] + v[k] * h;
@@ -504,10 +507,10 @@ __global__ __launch_bounds__(128) void k_step_units(IntArgs a, UnitArgs u) {
         }
         // position constraints against the positions at the start of the step
         if (kind == 1) settle_positions_regs(x[0], x[1], x[2], xn[0], xn[1], xn[2], 1.0 / w[0], 1.0 / w[1], 1.0 / w[2], dd.x, dd.y);
-        else if (kind == 2) { V3 t[3] = {xn[1], xn[2], xn[3]}; shake_regs<false>(r, xn[0], t, w[0], iws, dist, n, u.tol, u.maxIterations); xn[1] = t[0]; xn[2] = t[1]; xn[3] = t[2]; }
+        else if (!SMALL && kind == 2) { V3 t[3] = {xn[1], xn[2], xn[MAXA - 1]}; shake_regs<false>(r, xn[0], t, w[0], iws, dist, n, u.tol, u.maxIterations); xn[1] = t[0]; xn[2] = t[1]; xn[MAXA - 1] = t[2]; }
         const double inv = 1.0 / a.dt;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < MAXA; k++) {
             if (ids[k] >= 0 && w[k] != 0.0) {
                 if (KIND == 2) v[k] = v[k] + (xn[k] - ox[k]) * inv;
                 else v[k] = (xn[k] - x[k]) * inv;
@@ -741,9 +744,15 @@ extern "C" int ommhip_integrate_fused(int integrator, const ommhip_integrator_st
     hipStream_t st = (hipStream_t) stream;
     const dim3 grid = grid_for(u.numUnits);
     switch (integrator) {
-        case OMMHIP_INTEGRATOR_VERLET: hipLaunchKernelGGL(k_step_units<0>, grid, BLOCK128, 0, st, a, u); break;
-        case OMMHIP_INTEGRATOR_LANGEVIN: hipLaunchKernelGGL(k_step_units<1>, grid, BLOCK128, 0, st, a, u); break;
-        case OMMHIP_INTEGRATOR_LANGEVIN_MIDDLE: hipLaunchKernelGGL(k_step_units<2>, grid, BLOCK128, 0, st, a, u); break;
+        case OMMHIP_INTEGRATOR_VERLET:
+            if (units->small_units) hipLaunchKernelGGL((k_step_units<0, true>), grid, BLOCK128, 0, st, a, u); else hipLaunchKernelGGL((k_step_units<0, false>), grid, BLOCK128, 0, st, a, u);
+            break;
+        case OMMHIP_INTEGRATOR_LANGEVIN:
+            if (units->small_units) hipLaunchKernelGGL((k_step_units<1, true>), grid, BLOCK128, 0, st, a, u); else hipLaunchKernelGGL((k_step_units<1, false>), grid, BLOCK128, 0, st, a, u);
+            break;
+        case OMMHIP_INTEGRATOR_LANGEVIN_MIDDLE:
+            if (units->small_units) hipLaunchKernelGGL((k_step_units<2, true>), grid, BLOCK128, 0, st, a, u); else hipLaunchKernelGGL((k_step_units<2, false>), grid, BLOCK128, 0, st, a, u);
+            break;
         default: return 1;
     }
     return (int) hipGetLastError();

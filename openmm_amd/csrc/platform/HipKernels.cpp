@@ -193,6 +193,11 @@ HipConstraints::HipConstraints(const System& system, HipPlatform::PlatformData& 
             }
         allUnitAtoms.swap(unitAtomsHost);
         allUnitDist.swap(unitDistHost);
+        // no SHAKE cluster (kind 2 in dist.w) anywhere: every unit is a SETTLE water or a free atom, at most three atoms -- the fused
+        // step can run its register-lean variant (integrate.hip, k_step_units<KIND, SMALL>)
+        smallUnits = true;
+        for (size_t i = 3; i < allUnitDist.size(); i += 4)
+            if (allUnitDist[i] == 2.0 || allUnitAtoms[i] >= 0) { smallUnits = false; break; }
         const size_t maxUnits = allUnitAtoms.size() / 4;
         unitAtoms.allocate(sizeof(int) * 4 * max(maxUnits, (size_t) 1));
         unitDist.allocate(sizeof(double) * 4 * max(maxUnits, (size_t) 1));
@@ -248,6 +253,8 @@ void HipConstraints::fusedStep(int integrator, const ommhip_integrator_state& st
     u.inv_total_mass = totalMass > 0 ? 1.0 / totalMass : 0.0;
     u.cm_scratch = cmScratch.as<double>();
     u.pos_wire = NULL; u.ranks = 1; u.rank = 0; u.slots_per_rank = 0; u.trailer_slot = 0;
+    static const bool noSmall = getenv("OPENMM_HIP_NO_SMALL_UNITS") != NULL;         // A/B knob
+    u.small_units = smallUnits && !noSmall ? 1 : 0;
     u.box_len[0] = hip.box[0]; u.box_len[1] = hip.box[2]; u.box_len[2] = hip.box[5];
     if (hip.decomposed()) {
         u.pos_wire = hip.posWire.ptr; u.ranks = hip.domain.ranks; u.rank = hip.domain.rank;

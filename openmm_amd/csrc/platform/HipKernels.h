@@ -40,6 +40,7 @@ private:
     void uploadOwnedUnits();
     std::vector<int> allUnitAtoms;        // int4 per unit
     std::vector<double> allUnitDist;      // double4 per unit
+    bool smallUnits = false;              // no SHAKE cluster among the units (fusedStep launches the three-atom variant)
     int numUnits;
     double totalMass;
     DeviceBuffer unitAtoms, unitDist, cmScratch;

@@ -45,6 +45,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector (non-matrix) peak
+PAIR_FLOP = 45            # flop per evaluated pair (F_dir = 1024 T 45)
 # Sources the PMC-profiled launches (pairs_fft_plane / pairs_fft_lines: pair kernel + FFT stages) are compiled from; profiles/pmc_pairs_fft.json
 # is quoted only while their hash matches.  (neighbor.hip -- the list BUILDER -- was part of the set until the end of round 2; a change
 # of the list FORMAT shows up in nonbonded.hip, which reads it.)
@@ -65,7 +67,8 @@ def parse_args():
     p.add_argument("--no-scale-workload", action="store_true", help="N = 1: skip the single-GPU run of the strong-scaling workload")
     p.add_argument("--prepare-steps", type=int, default=-1, help="untimed steps that relax a lattice start before warm-up (input preparation; default 200 for the water boxes, 0 for fixtures)")
     p.add_argument("--transport", default="rccl", choices=["rccl", "gloo"], help="collectives of the decomposed run: RCCL (product) or host-staged gloo (rehearsal on one GPU)")
-    p.add_argument("--profile-every", type=int, default=7, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region")
+    p.add_argument("--profile-every", type=int, default=0, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region (0 = 7, or 2 for runs below 100 steps so that a 20-step run still holds 10 samples)")
+    p.add_argument("--no-extra-workloads", action="store_true", help="N = 1: skip the short runs of BASELINE.json configs[2] (apoa1-sized) and of the benchmark script's own 4 fs step")
     p.add_argument("--decompose", action="store_true", help="N = 1: run through the decomposed path with a one-rank RCCL communicator (overhead check on one GPU)")
     p.add_argument("--props", default="", help="extra HIP platform properties, e.g. DisablePmeStream=true")
     p.add_argument("--serialize-ranks", action="store_true", help="diagnostics, gloo transport on one GPU: the ranks run their work between collectives one at a time, so each rank's compute time per step is measured on an idle GPU (per_rank_compute_ms_per_step); the wall-clock value is meaningless in this mode")
@@ -230,7 +233,7 @@ def main():
     profile = not args.no_roofline
     if profile:
         kernels.lib.ommhip_profile_reset()
-        kernels.lib.ommhip_profile_enable(max(1, args.profile_every))
+        kernels.lib.ommhip_profile_enable(args.profile_every if args.profile_every > 0 else (2 if args.steps < 100 else 7))
     serialized = decomposed and args.serialize_ranks and args.transport == "gloo"
     if serialized:
         barrier()
@@ -253,8 +256,11 @@ def main():
     out = {
         "metric": "ns/day (DHFR PME 2 fs) at 1/2/4/8 MI355X; force max-rel-err vs Reference",
         "value": round(value, 3), "unit": "ns/day", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong" if decomposed else "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32",
+        # N = 1: one run of the real benchmark System; N > 1: ONE fixed box over N GPUs (total work fixed)
+        "data": ("real: examples/5dfr_solv-cube_equil.pdb with amber99sb + tip3p parameters (committed fixture tests/golden/dhfr_5dfr_amber99sb_tip3p.npz, equilibrated coordinates and velocities)"
+                 if workload == "dhfr" else "synthetic: %s (generated coordinates, standard TIP3P parameters)" % w.name),
         "config": {"workload": "%s: %d atoms, PME cutoff 0.9 nm grid %s, LangevinMiddle %.0f fs, HBonds constraints + rigid water; %s" % (
             w.name, w.num_atoms, "x".join(str(g) for g in grid), args.dt_fs,
             ("ONE box domain-decomposed over %d GPUs (x slabs, %s collectives)" % (world, transport)) if decomposed else "single GPU"),
@@ -302,7 +308,9 @@ def main():
                 with open(pmc_file) as f:
                     pmc = json.load(f)
                 if pmc.get("kernel_sources_sha") == sha:
-                    traffic, traffic_source = pmc["traffic_bytes_per_launch"], pmc["source"]
+                    traffic = pmc["traffic_bytes_per_launch"]
+                    traffic_source = ("NOT measured in this run: rocprofv3 PMC counters cannot be read from inside the process, so the figure is a committed PMC visit of "
+                                      "the same command on the same kernel sources (hash checked): %s; visit %s" % (pmc["source"], pmc.get("visit", "date and box not recorded")))
                 else:
                     traffic_source = "stale: %s was collected from other kernel sources (%s, now %s)" % (os.path.basename(pmc_file), pmc.get("kernel_sources_sha"), sha)
             out["roofline"] = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBPS,
@@ -311,7 +319,24 @@ def main():
                                "algorithmic_bytes_per_launch": int(algo_bytes), "avg_kernel_us": round(avg_us, 3) if avg_us else None,
                                "rows": int(rows), "chunks": int(chunks), "rebuilds": int(stats[5]),
                                "pair_evals_per_launch": int(rows) * 64 * 32, "kernel_timers_us": timers, "kernel_sources_sha": sha,
-                               "note": "working set is cache-resident at DHFR size (the kernel is FP32-issue bound there); see DESIGN.md (d)"}
+                               "note": "working set is cache-resident at DHFR size (the kernel is FP32-issue bound there, see fp32_issue); see DESIGN.md (d)"}
+            # the bound that actually applies to the pair kernel at this size: FP32 vector issue.  Evaluated pairs x 45 flop over
+            # the kernel's own time -- stand-alone launches when the timed region ran it fused with the FFT stages (filled in below) -- and
+            # the part of it spent on pairs inside the cutoff (counted on the final configuration with a k-d tree).
+            out["roofline"]["fp32_issue"] = {"bound": "fp32 vector issue", "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "flop_per_pair": PAIR_FLOP,
+                                             "pair_evals_per_launch": int(rows) * 64 * 32}
+            try:
+                if w.num_atoms <= 120000:
+                    from scipy.spatial import cKDTree
+                    endp = ctx.getState(getPositions=True).positions
+                    Lbox = np.diag(np.asarray(w.box, float))
+                    wrapped = np.mod(endp, Lbox[None, :])
+                    wrapped[wrapped >= Lbox[None, :]] = 0.0
+                    inside = int(cKDTree(wrapped, boxsize=Lbox).count_neighbors(cKDTree(wrapped, boxsize=Lbox), w.cutoff) - w.num_atoms) // 2
+                    out["roofline"]["fp32_issue"]["pairs_inside_cutoff"] = inside
+                    out["roofline"]["fp32_issue"]["evals_per_useful_pair"] = round(int(rows) * 64 * 32 / max(inside, 1), 3)
+            except Exception as e:
+                out["roofline"]["fp32_issue"]["pairs_inside_cutoff_error"] = str(e)
             # ---- the 3-D FFT chain on its own: 96 * Hc algorithmic bytes over its measured duration.  On the fused
             #      path the FFT stages share launches with the pair kernel, so a short extra run with separate launches times them.
             if not decomposed:
@@ -328,6 +353,15 @@ def main():
                         sep = collect_timers(kernels)
                         fft = sep["pme_fft"]
                         out["roofline"]["separate_launch_timers_us"] = {k: sep[k] for k in ("nb_direct", "pme_fft")}
+                    pair_us = (sep if fused else timers)["nb_direct"]["avg_us"]
+                    if pair_us:
+                        fi = out["roofline"]["fp32_issue"]
+                        fi["kernel_us"] = round(pair_us, 3)
+                        fi["kernel"] = "nb_direct as a launch of its own" + (" (100 extra steps after the timed region)" if fused else "")
+                        fi["achieved"] = round(fi["pair_evals_per_launch"] * PAIR_FLOP / (pair_us * 1e-6) / 1e12, 3)
+                        fi["frac"] = round(fi["achieved"] / FP32_VECTOR_PEAK_TFLOPS, 5)
+                        if fi.get("pairs_inside_cutoff"):
+                            fi["useful_frac"] = round(fi["pairs_inside_cutoff"] * PAIR_FLOP / (pair_us * 1e-6) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5)
                     hc = gx * gy * (gz // 2 + 1)
                     if fft["avg_us"]:
                         a = 96.0 * hc / (fft["avg_us"] * 1e-6) / 1e9
@@ -407,6 +441,24 @@ def main():
             sctx.close()
         except Exception as e:
             out["scale_workload"] = {"value": None, "error": str(e)}
+    # ---- N = 1: driver-timed figures for BASELINE.json configs[2] (apoa1-sized) and for the benchmark script's own 4 fs step
+    if world == 1 and workload == "dhfr" and not args.no_extra_workloads and abs(args.dt_fs - 2.0) < 1e-9:
+        out["extra_workloads"] = {}
+        for key, wl_name, dt_fs in (("dhfr_4fs", "dhfr", 4.0), ("apoa1", "apoa1", 2.0)):
+            try:
+                xw = w if wl_name == "dhfr" else make_workload(wl_name, seed=1)
+                xprep = 0 if getattr(xw, "velocities", None) is not None else 200
+                xsys, xnb, xinteg, xctx = start_platform(xw, "HIP", dt_fs * 1e-3, args.warmup, {"DeviceIndex": str(local_rank)}, seed=1, prepare=xprep)
+                x_elapsed, x_st = timed_run(xinteg, xctx, args.steps, barrier)
+                if not np.isfinite(x_st.potentialEnergy):
+                    raise RuntimeError("potential energy is not finite")
+                out["extra_workloads"][key] = {"workload": "%s: %d atoms, PME grid %s, LangevinMiddle %.0f fs, single GPU" % (
+                                                   xw.name, xw.num_atoms, "x".join(str(g) for g in xnb.getPMEParametersInContext(xctx)[1:]), dt_fs),
+                                               "value": round(MR.ns_per_day(x_elapsed, args.steps, dt_fs), 3), "unit": "ns/day",
+                                               "ms_per_step": round(1e3 * x_elapsed / args.steps, 5), "steps": args.steps, "warmup": args.warmup, "prepare_steps": xprep}
+                xctx.close()
+            except Exception as e:
+                out["extra_workloads"][key] = {"value": None, "error": str(e)}
     if rank == 0:
         # librccl prints a version banner through C stdio, which is flushed at exit -- after Python's own output -- when stdout
         # is a pipe or a file: push it out first so that the JSON line is the last line

@@ -175,6 +175,13 @@ typedef struct ommhip_neighbor_list {
     int dd_mode;
     const void* pos_wire;
     void* pos_scatter;
+    /* Optional float4[padded_atoms]: the low parts of posq_rel -- (double-precision position minus block centre) minus its float
+     * rounding, written by ommhip_nl_prepare (zeros by ommhip_nl_update, whose input is float already).  With it the pair kernel
+     * settles the one decision float32 separations cannot: a pair whose float r^2 lies within +-6e-7 rc^2 of the cutoff (a few of
+     * millions per step) is re-decided in a rare wave-uniform branch from hi + lo coordinates, block-centre offset and minimum
+     * image in double, i.e. exactly as ReferenceNeighborList.cpp:195-197 decides it.  NULL: the float separation decides, and a
+     * pair within ~1e-7 nm of the cutoff may be counted on the other side (a force jump of ~2e-4 of the RMS force on two atoms). */
+    void* posq_rel_lo;
 } ommhip_neighbor_list;
 
 typedef struct ommhip_nonbonded_params {

@@ -63,6 +63,28 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #endif
 __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
 __device__ __forceinline__ v2f bc2(float a) { return mk2(a, a); }
+// a * b + c with ONE rounding per element (v_pk_fma_f32): written out where a packed and a scalar code path must agree bit for bit
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) {
+#ifdef OMMHIP_EMU
+    return mk2(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y));
+#else
+    return __builtin_elementwise_fma(a, b, c);
+#endif
+}
+// Squared length of a separation vector.  The pair kernel decides "inside the cutoff" on this number in its packed loops and
+// re-derives the same decision in its (scalar) cutoff-edge path: explicit fused multiply-adds in a fixed order, so that the
+// two agree bit for bit whatever the compiler's contraction choices are at either site.
+__device__ __forceinline__ float r2_of(float dx, float dy, float dz) { return fmaf(dx, dx, fmaf(dy, dy, dz * dz)); }
+__device__ __forceinline__ v2f r2_of(v2f dx, v2f dy, v2f dz) { return fma2(dx, dx, fma2(dy, dy, dz * dz)); }
+
+// lanes of the wavefront for which the predicate holds, as a scalar (SGPR pair): accumulating such masks costs no vector instruction
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) {
+#ifdef OMMHIP_EMU
+    return __ballot(p ? 1 : 0);
+#else
+    return __builtin_amdgcn_ballot_w64(p);
+#endif
+}
 
 // Wave-wide sum; every lane of the wave must call it.  Result valid in all lanes.
 __device__ __forceinline__ float wave_sum(float v) {
@@ -84,6 +106,17 @@ __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
     return v;
+}
+
+// acc |= in & ~lo on the scalar unit, as ONE dependency chain: written as plain C the compiler re-associates the ORs of an unrolled
+// loop into a tree, keeps dozens of 64-bit masks alive and spills SGPRs through v_writelane / v_readlane inside the pair loops
+__device__ __forceinline__ void mask_accumulate(unsigned long long& acc, unsigned long long in, unsigned long long lo) {
+#ifdef OMMHIP_EMU
+    acc |= in & ~lo;
+#else
+    const unsigned long long t = in & ~lo;
+    asm("s_or_b64 %0, %0, %1" : "+s"(acc) : "s"(t));
+#endif
 }
 
 // Number of set bits of `mask` below this lane.
@@ -108,17 +141,18 @@ __device__ __forceinline__ void min_image(float& dx, float& dy, float& dz, const
     if (TRICLINIC) {
         // platforms/reference/src/SimTKReference/ReferenceForce.cpp getDeltaRPeriodic (triclinic branch):
         // subtract multiples of c, then b, then a.
+        // (explicit fused multiply-adds: the pair kernel's cutoff-edge path repeats this reduction and must land on the same bits)
         float s = rintf(dz * b.invCz);
-        dx -= s * b.cx; dy -= s * b.cy; dz -= s * b.cz;
+        dx = fmaf(-s, b.cx, dx); dy = fmaf(-s, b.cy, dy); dz = fmaf(-s, b.cz, dz);
         s = rintf(dy * b.invBy);
-        dx -= s * b.bx; dy -= s * b.by;
+        dx = fmaf(-s, b.bx, dx); dy = fmaf(-s, b.by, dy);
         s = rintf(dx * b.invAx);
-        dx -= s * b.ax;
+        dx = fmaf(-s, b.ax, dx);
     }
     else {
-        dx -= rintf(dx * b.invAx) * b.ax;
-        dy -= rintf(dy * b.invBy) * b.by;
-        dz -= rintf(dz * b.invCz) * b.cz;
+        dx = fmaf(-rintf(dx * b.invAx), b.ax, dx);
+        dy = fmaf(-rintf(dy * b.invBy), b.by, dy);
+        dz = fmaf(-rintf(dz * b.invCz), b.cz, dz);
     }
 }
 

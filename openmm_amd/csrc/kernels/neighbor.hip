@@ -57,6 +57,7 @@ struct NlArgs {
     const float4* posq;
     float4* posqRef;
     float4* posqRel;         // block-relative coordinates (position minus blockCenter of its block) + charge, or null
+    float4* posqRelLo;       // what the float rounding of posqRel left of the double-precision value (pair kernel's cutoff-edge path), or null
     const int* atomOfSlot;
     const int* slotOfAtom;
     const int* exclStart;
@@ -141,6 +142,7 @@ __global__ void nl_block_bounds(NlArgs a) {
     // rebuilds this entry keeps the centre of the last rebuild)
     if (inRange && a.posqRel != nullptr)
         a.posqRel[s] = valid ? make_float4(p.x - center.x, p.y - center.y, p.z - center.z, p.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (inRange && a.posqRelLo != nullptr) a.posqRelLo[s] = make_float4(0.f, 0.f, 0.f, 0.f);        // float positions in: nothing was lost
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -730,9 +732,14 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
     }
     // Block-relative coordinates (double position minus the float centre, rounded once): what the pair kernel computes
     // with.  Their error is the rounding of a number below ~1 nm (6e-8 nm), independent of where in the box the block is.
-    if (inRange && a.posqRel != nullptr)
-        a.posqRel[sl] = valid ? make_float4((float) (xw - (double) center.x), (float) (yw - (double) center.y), (float) (zw - (double) center.z), p.w)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (inRange && a.posqRel != nullptr) {
+        const double rx = xw - (double) center.x, ry = yw - (double) center.y, rz = zw - (double) center.z;
+        const float4 hi = valid ? make_float4((float) rx, (float) ry, (float) rz, p.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+        a.posqRel[sl] = hi;
+        // ... and what that rounding dropped (<= 3e-8 nm): only the pair kernel's cutoff-edge path reads it
+        if (a.posqRelLo != nullptr)
+            a.posqRelLo[sl] = valid ? make_float4((float) (rx - (double) hi.x), (float) (ry - (double) hi.y), (float) (rz - (double) hi.z), 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
@@ -747,7 +754,7 @@ NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
     a.listCutoff2 = nl->cutoff > 0 ? (float) (rl * rl) : INFINITY;
     a.maxDisp2 = (float) (0.25 * nl->padding * nl->padding);
     a.box = make_box(nl->box);
-    a.posq = (const float4*) nl->posq; a.posqRef = (float4*) nl->posq_ref; a.posqRel = (float4*) nl->posq_rel;
+    a.posq = (const float4*) nl->posq; a.posqRef = (float4*) nl->posq_ref; a.posqRel = (float4*) nl->posq_rel; a.posqRelLo = (float4*) nl->posq_rel_lo;
     a.atomOfSlot = nl->atom_of_slot; a.slotOfAtom = nl->slot_of_atom;
     a.exclStart = nl->excl_start; a.exclAtoms = nl->excl_atoms; a.exclBlockRange = (const int2*) nl->excl_block_range;
     a.exclSlotStart = nl->excl_slot_start; a.exclSlots = nl->excl_slots;

@@ -38,6 +38,15 @@ struct NbArgs {
     int ljHeadSplit;          // use the split loops for i-blocks whose atoms from OMM_LJ_HEAD on have epsilon = 0
     int ownSlot0, ownSlot1;   // domain decomposition: forces on j atoms outside [ownSlot0, ownSlot1) are dropped (their owner evaluates the pair too)
     float cutoff2, alpha, krf, crf, switchDist, invSwitchWidth;
+    // Cutoff edge (posqLo != null): a pair is "inside" for the packed loops when r^2 < cutoff2 = rc^2 (1 + d), which includes every
+    // pair whose float separation could be the rounding of a double-precision separation inside the cutoff; pairs in the band
+    // [cutoff2Lo, cutoff2) = rc^2 (1 -+ d) raise a wave-uniform flag, and the rare path behind it (fix_edge_pairs) re-decides each of
+    // them from the hi + lo coordinates in double -- the decision the Reference platform takes -- and takes the pair out again when
+    // it lies outside.  Without posqLo: cutoff2 = cutoff2Lo = rc^2 and the float separation decides.
+    float cutoff2Lo;
+    double cutoff2d;
+    BoxD boxd;
+    const float4* posqLo;     // low parts of the block-relative coordinates (ommhip_neighbor_list::posq_rel_lo), or null
     float ewPoly[OMM_EWPOLY_DEGREE + 1];   // METHOD & 8: alpha^3 g((u + 1) zmax / 2) as a polynomial in u, highest power first (see ewald_poly_for)
     float ewPolyScale;                     // u = r^2 * ewPolyScale - 1
     float dispAlpha2, invCut6, dispShift;   // LJPME (METHOD & 4): alpha_d^2, 1/rc^6, (1 - exp(-x)(1 + x + x^2/2)) / rc^6 at x = (alpha_d rc)^2
@@ -57,14 +66,17 @@ struct NbArgs {
 
 #define OMM_LJ_HEAD 12        // slots of a block that may hold atoms with Lennard-Jones parameters when the rest has none (32 water atoms: 10-11 oxygens)
 
-template <int METHOD, int PBC, bool ENERGY, bool MASKED>
+// EDGE = false: called from the cutoff-edge path itself (divergent code: no wave-wide mask arithmetic there)
+template <int METHOD, int PBC, bool ENERGY, bool MASKED, bool EDGE = true>
 __device__ __forceinline__ void pair_ixn(const NbArgs& a, const float4 pi, const float2 sei, const float4 pj, const float2 sej, const float qjK,
-                                         bool bit, float& fix, float& fiy, float& fiz, float& fjx, float& fjy, float& fjz, float& energy) {
+                                         bool bit, float& fix, float& fiy, float& fiz, float& fjx, float& fjy, float& fjz, float& energy,
+                                         unsigned long long& edge) {
     float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
     if (PBC == 1) min_image<false>(dx, dy, dz, a.box);
     if (PBC == 2) min_image<true>(dx, dy, dz, a.box);
-    const float r2 = dx * dx + dy * dy + dz * dz;
+    const float r2 = r2_of(dx, dy, dz);
     bool in = r2 < a.cutoff2;
+    if (EDGE) mask_accumulate(edge, wave_ballot(in), wave_ballot(r2 < a.cutoff2Lo));        // scalar mask arithmetic: one extra vector compare per pair
     if (MASKED) in = in && bit;
     const float invR = fast_rsqrt(r2);
     const float r = r2 * invR;
@@ -139,10 +151,12 @@ __device__ __forceinline__ float2 rl2(float2 v, int k) { return make_float2(rl(v
 template <int METHOD, bool ENERGY, bool MASKED, bool NOLJ = false>
 __device__ __forceinline__ void pair_ixn2(const NbArgs& a, const float4 pi0, const float4 pi1, const float2 se0, const float2 se1,
                                           const float4 pj, const float2 sej, const float qjK, bool bit0, bool bit1,
-                                          v2f& fix, v2f& fiy, v2f& fiz, v2f& fjx, v2f& fjy, v2f& fjz, v2f& energy) {
+                                          v2f& fix, v2f& fiy, v2f& fiz, v2f& fjx, v2f& fjy, v2f& fjz, v2f& energy, unsigned long long& edge) {
     const v2f dx = bc2(pj.x) - mk2(pi0.x, pi1.x), dy = bc2(pj.y) - mk2(pi0.y, pi1.y), dz = bc2(pj.z) - mk2(pi0.z, pi1.z);
-    const v2f r2 = dx * dx + dy * dy + dz * dz;
+    const v2f r2 = r2_of(dx, dy, dz);
     bool in0 = r2.x < a.cutoff2, in1 = r2.y < a.cutoff2;
+    mask_accumulate(edge, wave_ballot(in0), wave_ballot(r2.x < a.cutoff2Lo));
+    mask_accumulate(edge, wave_ballot(in1), wave_ballot(r2.y < a.cutoff2Lo));
     if (MASKED) { in0 = in0 && bit0; in1 = in1 && bit1; }
     const v2f invR = mk2(fast_rsqrt(r2.x), fast_rsqrt(r2.y));
     const v2f r = r2 * invR;
@@ -242,22 +256,59 @@ struct IAtoms {
 template <int METHOD, bool ENERGY, bool MASKED, bool NOLJ, int K0, int K1>
 __device__ __forceinline__ void row_pairs2(const NbArgs& a, const IAtoms& ia, const float4 pj, const float2 sej,
                                            const float qjK, const unsigned m, float (&fix)[OMM_TILE], float (&fiy)[OMM_TILE], float (&fiz)[OMM_TILE],
-                                           v2f& fj2x, v2f& fj2y, v2f& fj2z, v2f& energy2) {
+                                           v2f& fj2x, v2f& fj2y, v2f& fj2z, v2f& energy2, unsigned long long& edge) {
 #pragma unroll
     for (int k = K0; k < K1; k += 2) {
         v2f ax = mk2(fix[k], fix[k + 1]), ay = mk2(fiy[k], fiy[k + 1]), az = mk2(fiz[k], fiz[k + 1]);
         pair_ixn2<METHOD, ENERGY, MASKED, NOLJ>(a, ia.posq(k), ia.posq(k + 1), ia.sigEps(k), ia.sigEps(k + 1), pj, sej, qjK, MASKED ? ((m >> k) & 1u) != 0 : true,
-                                                MASKED ? ((m >> (k + 1)) & 1u) != 0 : true, ax, ay, az, fj2x, fj2y, fj2z, energy2);
+                                                MASKED ? ((m >> (k + 1)) & 1u) != 0 : true, ax, ay, az, fj2x, fj2y, fj2z, energy2, edge);
         fix[k] = ax.x; fix[k + 1] = ax.y; fiy[k] = ay.x; fiy[k + 1] = ay.y; fiz[k] = az.x; fiz[k + 1] = az.y;
     }
 }
 // ... and one per call with the image search per pair (general path)
 template <int METHOD, int PBC, bool ENERGY, bool MASKED>
 __device__ __forceinline__ void row_pairs1(const NbArgs& a, const IAtoms& ia, const float4 pj, const float2 sej, const float qjK, const unsigned m,
-                                           float (&fix)[OMM_TILE], float (&fiy)[OMM_TILE], float (&fiz)[OMM_TILE], float& fjx, float& fjy, float& fjz, float& energy) {
+                                           float (&fix)[OMM_TILE], float (&fiy)[OMM_TILE], float (&fiz)[OMM_TILE], float& fjx, float& fjy, float& fjz, float& energy,
+                                           unsigned long long& edge) {
 #pragma unroll
     for (int k = 0; k < OMM_TILE; k++)
-        pair_ixn<METHOD, PBC, ENERGY, MASKED>(a, ia.posq(k), ia.sigEps(k), pj, sej, qjK, MASKED ? ((m >> k) & 1u) != 0 : true, fix[k], fiy[k], fiz[k], fjx, fjy, fjz, energy);
+        pair_ixn<METHOD, PBC, ENERGY, MASKED>(a, ia.posq(k), ia.sigEps(k), pj, sej, qjK, MASKED ? ((m >> k) & 1u) != 0 : true, fix[k], fiy[k], fiz[k], fjx, fjy, fjz, energy, edge);
+}
+
+// The rare path behind the cutoff-edge flag of a row (see NbArgs::cutoff2Lo): some lane's j atom has a partner among the 32 i
+// atoms whose float separation lies within the rounding band around the cutoff.  Walk through the i atoms once more (a real loop,
+// wave-uniform k: this code runs for a handful of the millions of rows of a step), find those pairs with the arithmetic of the
+// packed loops (r2_of: same bits), decide each from the double-precision separation -- block-relative hi + lo coordinates, the
+// offset between the two block centres and the minimum image all in double -- and subtract the pair's force and energy again when
+// it lies outside the cutoff there (the Reference platform includes r^2 <= rc^2, ReferenceNeighborList.cpp:195-197).
+// pjShifted: the j atom as the loops saw it (in X's frame; image chosen when `single`).
+template <int METHOD, int PBC, bool ENERGY>
+__device__ __forceinline__ void fix_edge_pairs(const NbArgs& a, const float4 iLane, const float2 seLane, const int X, const int j, const float4 pjShifted,
+                                                      const float4 cX, const float4 cY, const float2 sej, const float qjK, const unsigned m, const bool single,
+                                                      float& fjx, float& fjy, float& fjz, float& energy) {
+    for (int k = 0; k < OMM_TILE; k++) {
+        const float4 pi = rl4(iLane, k);
+        const float2 sei = rl2(seLane, k);
+        float dx = pjShifted.x - pi.x, dy = pjShifted.y - pi.y, dz = pjShifted.z - pi.z;
+        if (PBC == 1 && !single) min_image<false>(dx, dy, dz, a.box);
+        if (PBC == 2) min_image<true>(dx, dy, dz, a.box);
+        const float r2 = r2_of(dx, dy, dz);
+        if (!(r2 < a.cutoff2 && !(r2 < a.cutoff2Lo) && ((m >> k) & 1u) != 0)) continue;
+        const float4 pjr = a.posq[j], pjl = a.posqLo[j], pil = a.posqLo[X * OMM_TILE + k];
+        double ex = ((double) pjr.x + (double) pjl.x) + ((double) cY.x - (double) cX.x) - ((double) pi.x + (double) pil.x);
+        double ey = ((double) pjr.y + (double) pjl.y) + ((double) cY.y - (double) cX.y) - ((double) pi.y + (double) pil.y);
+        double ez = ((double) pjr.z + (double) pjl.z) + ((double) cY.z - (double) cX.z) - ((double) pi.z + (double) pil.z);
+        if (PBC != 0) min_image_d(ex, ey, ez, a.boxd);
+        if (!(ex * ex + ey * ey + ez * ez > a.cutoff2d)) continue;          // inside in double as well: the loops were right
+        float tix = 0.f, tiy = 0.f, tiz = 0.f, tjx = 0.f, tjy = 0.f, tjz = 0.f, te = 0.f;
+        unsigned long long ignored = 0;
+        if (PBC == 1 && !single) pair_ixn<METHOD & 7, 1, ENERGY, false, false>(a, pi, sei, pjShifted, sej, qjK, true, tix, tiy, tiz, tjx, tjy, tjz, te, ignored);
+        else if (PBC == 2) pair_ixn<METHOD & 7, 2, ENERGY, false, false>(a, pi, sei, pjShifted, sej, qjK, true, tix, tiy, tiz, tjx, tjy, tjz, te, ignored);
+        else pair_ixn<METHOD & 7, 0, ENERGY, false, false>(a, pi, sei, pjShifted, sej, qjK, true, tix, tiy, tiz, tjx, tjy, tjz, te, ignored);
+        fjx -= tjx; fjy -= tjy; fjz -= tjz;
+        if (ENERGY) energy -= te;
+        add_force(a.force, a.paddedAtoms, X * OMM_TILE + k, -tix, -tiy, -tiz);
+    }
 }
 
 // Two registers in, one out: lanes 0-31 get a[l] + a[l + 32], lanes 32-63 get b[l - 32] + b[l] -- gfx950's
@@ -402,6 +453,7 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
             float fjx = 0.f, fjy = 0.f, fjz = 0.f;
             const bool masked = (maskedBits >> row) & 1;
             const unsigned m = mRow[row];
+            unsigned long long edge = 0;          // lanes with a pair in the rounding band around the cutoff (scalar register pair)
             if (PBC == 1 && single) {
                 // offset of Y's centre from X's, in the nearest image.  cY - n L is formed first: the two are of similar size,
                 // so the FMA is exact, the low part of the box edge restores what its float value lost, and the final
@@ -417,23 +469,29 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
                     // the block's atoms from OMM_LJ_HEAD on carry no Lennard-Jones parameters (water: the slot order puts the
                     // oxygens of a block first): two thirds of the row's pairs skip that part of the arithmetic
                     if (masked) {
-                        row_pairs2<METHOD, ENERGY, true, false, 0, OMM_LJ_HEAD>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
-                        row_pairs2<METHOD, ENERGY, true, true, OMM_LJ_HEAD, OMM_TILE>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
+                        row_pairs2<METHOD, ENERGY, true, false, 0, OMM_LJ_HEAD>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2, edge);
+                        row_pairs2<METHOD, ENERGY, true, true, OMM_LJ_HEAD, OMM_TILE>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2, edge);
                     }
                     else {
-                        row_pairs2<METHOD, ENERGY, false, false, 0, OMM_LJ_HEAD>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
-                        row_pairs2<METHOD, ENERGY, false, true, OMM_LJ_HEAD, OMM_TILE>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
+                        row_pairs2<METHOD, ENERGY, false, false, 0, OMM_LJ_HEAD>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2, edge);
+                        row_pairs2<METHOD, ENERGY, false, true, OMM_LJ_HEAD, OMM_TILE>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2, edge);
                     }
                 }
-                else if (masked) row_pairs2<METHOD, ENERGY, true, false, 0, OMM_TILE>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
-                else row_pairs2<METHOD, ENERGY, false, false, 0, OMM_TILE>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2);
+                else if (masked) row_pairs2<METHOD, ENERGY, true, false, 0, OMM_TILE>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2, edge);
+                else row_pairs2<METHOD, ENERGY, false, false, 0, OMM_TILE>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fj2x, fj2y, fj2z, energy2, edge);
                 fjx += fj2x.x + fj2x.y; fjy += fj2y.x + fj2y.y; fjz += fj2z.x + fj2z.y;
             }
             else {
                 // general path: j in X's frame without an image shift; the pair code searches the image per pair
                 pj.x += cY.x - cX.x; pj.y += cY.y - cX.y; pj.z += cY.z - cX.z;
-                if (masked) row_pairs1<METHOD, PBC, ENERGY, true>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fjx, fjy, fjz, energy);
-                else row_pairs1<METHOD, PBC, ENERGY, false>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fjx, fjy, fjz, energy);
+                if (masked) row_pairs1<METHOD, PBC, ENERGY, true>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fjx, fjy, fjz, energy, edge);
+                else row_pairs1<METHOD, PBC, ENERGY, false>(a, ia, pj, sej, qjK, m, fix, fiy, fiz, fjx, fjy, fjz, energy, edge);
+            }
+            if (edge != 0) {
+                // wave-uniform and rare (a few rows per step): pairs within float rounding of the cutoff are re-decided in double
+                const float4 iLane = OMM_I_FROM_LANES ? ia.pLane : a.posq[X * OMM_TILE + (lane & (OMM_TILE - 1))];
+                const float2 seLane = OMM_I_FROM_LANES ? ia.seLane : a.sigEps[X * OMM_TILE + (lane & (OMM_TILE - 1))];
+                fix_edge_pairs<METHOD, PBC, ENERGY>(a, iLane, seLane, X, j, pj, cX, cY, sej, qjK, m, PBC == 1 && single, fjx, fjy, fjz, energy);
             }
             const bool jOwned = j >= a.ownSlot0 && j < a.ownSlot1;
             if (!(a.debugFlags & 1)) { if (jOwned) add_force(a.force, a.paddedAtoms, j, fjx, fjy, fjz); }
@@ -546,6 +604,16 @@ static NbArgs make_nb_args(const ommhip_neighbor_list* nl, const ommhip_nonbonde
     a.ownSlot0 = 0; a.ownSlot1 = nl->padded_atoms;
     if (nl->dd_mode != 0 && nl->owned_blocks > 0) { a.ownSlot0 = nl->first_block * OMM_TILE; a.ownSlot1 = (nl->first_block + nl->owned_blocks) * OMM_TILE; }
     a.cutoff2 = nl->cutoff > 0 ? (float) (nl->cutoff * nl->cutoff) : INFINITY;
+    a.cutoff2Lo = a.cutoff2; a.cutoff2d = nl->cutoff > 0 ? nl->cutoff * nl->cutoff : INFINITY;
+    a.posqLo = (const float4*) nl->posq_rel_lo;
+    a.boxd.ax = nl->box[0]; a.boxd.bx = nl->box[1]; a.boxd.by = nl->box[2]; a.boxd.cx = nl->box[3]; a.boxd.cy = nl->box[4]; a.boxd.cz = nl->box[5];
+    static const bool noEdge = getenv("OPENMM_HIP_NO_CUTOFF_EDGE") != nullptr;           // A/B knob: the float separation decides
+    if (a.posqLo != nullptr && nl->cutoff > 0 && !noEdge) {
+        // band of about +-1.2e-6 rc^2 around rc^2: the float r^2 of a pair at the cutoff is off by 2 r x (1e-7 nm of separation error) =
+        // 2.2e-7 rc^2 at rc = 0.9 nm (block-relative coordinates, whatever the box), plus the rounding of r^2 itself; ~13 of DHFR's 3.5 M pairs fall into it
+        const double c2 = nl->cutoff * nl->cutoff, band = 1e-6 * c2 + 2e-7 * nl->cutoff;
+        a.cutoff2 = (float) (c2 + band); a.cutoff2Lo = (float) (c2 - band);
+    }
     a.alpha = (float) p->ewald_alpha; a.krf = (float) p->krf; a.crf = (float) p->crf;
     a.ewPolyScale = 0.f;
     for (int i = 0; i <= OMM_EWPOLY_DEGREE; i++) a.ewPoly[i] = 0.f;

@@ -883,6 +883,8 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     posq.allocate(sizeof(float) * 4 * P);
     posqRef.allocate(sizeof(float) * 4 * P);
     posqRel.allocate(sizeof(float) * 4 * P);
+    posqRelLo.allocate(sizeof(float) * 4 * P);
+    HIP_CHECK(ommhip_memset(posqRelLo.ptr, 0, posqRelLo.bytes, hip.stream));
     sigEps.allocate(sizeof(float) * 2 * P);
     HIP_CHECK(ommhip_memset(posq.ptr, 0, posq.bytes, hip.stream));
     HIP_CHECK(ommhip_memset(posqRef.ptr, 0, posqRef.bytes, hip.stream));
@@ -911,7 +913,7 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     nl.pbc = 0;
     nl.cutoff = nonbondedMethod == NoCutoff ? 0.0 : nonbondedCutoff;
     nl.padding = padding;
-    nl.posq = posq.ptr; nl.posq_ref = posqRef.ptr; nl.posq_rel = posqRel.ptr;
+    nl.posq = posq.ptr; nl.posq_ref = posqRef.ptr; nl.posq_rel = posqRel.ptr; nl.posq_rel_lo = posqRelLo.ptr;
     nl.atom_of_slot = hip.atomOfSlot.as<int>(); nl.slot_of_atom = hip.slotOfAtom.as<int>();
     nl.excl_start = exclStart.as<int>(); nl.excl_atoms = exclAtoms.as<int>();
     nl.state = nlState.as<int>();

@@ -11,6 +11,7 @@ from oracle import nonbonded as ONB, pme as OPME
 
 
 LAST_FIXED_POINT_FORCES = None
+LAST_NL = None
 
 
 def lattice_positions(rng, n, box3, jitter=0.25):
@@ -27,7 +28,7 @@ def box6(box3):
     return (C.c_double * 6)(box3[0, 0], box3[1, 0], box3[1, 1], box3[2, 0], box3[2, 1], box3[2, 2])
 
 
-def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64, compact=False, cells=False, fused_pme=None, block_range=None, energy=True, lj_free_tail=False, ewald_tol=5e-4):
+def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64, compact=False, cells=False, fused_pme=None, block_range=None, energy=True, lj_free_tail=False, ewald_tol=5e-4, positions=None, charges=None, edge_path=True, prepare=False):
     """-> (forces[n,3], energy, oracle forces, oracle energy, nl state)
 
     compact=False: random slot order, list built by ommhip_nl_update on wrapped coordinates (general image search).
@@ -42,14 +43,18 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     energy=False: forces only -- plain Ewald/PME in a rectangular box then takes the polynomial form of the real-space force
     (nonbonded.hip, METHOD 9) on the single-image path; the energy returned is 0.
     lj_free_tail=True: epsilon = 0 for the atoms in the slots 12..31 of every block (a water box after the platform's
-    in-block ordering): the single-image path leaves the Lennard-Jones arithmetic out for them."""
+    in-block ordering): the single-image path leaves the Lennard-Jones arithmetic out for them.
+    prepare=True: the per-step entry ommhip_nl_step (double positions in) also for the random slot order.
+    positions / charges: given instead of drawn; edge_path=False: no posq_rel_lo, the float separation decides at the cutoff."""
     rng = np.random.default_rng(seed)
     box3 = np.eye(3) * L
     if triclinic:
         box3 = np.array([[L, 0, 0], [0.2 * L, 0.9 * L, 0], [-0.3 * L, 0.25 * L, 1.1 * L]])
-    pos = lattice_positions(rng, n, box3)
+    pos = lattice_positions(rng, n, box3) if positions is None else np.asarray(positions, np.float64)
     q = rng.normal(0, 0.5, n)
     q -= q.mean()
+    if charges is not None:
+        q = np.asarray(charges, np.float64)
     sig = 0.2 + 0.1 * rng.random(n)
     eps = rng.random(n)
     padded = (n + 31) // 32 * 32
@@ -96,6 +101,8 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
         nl.box[i] = b6[i]
     nl.posq, nl.posq_ref = d_posq, K.upload(np.zeros((padded, 4), np.float32))
     nl.posq_rel = K.upload(np.zeros((padded, 4), np.float32))
+    if edge_path:
+        nl.posq_rel_lo = K.upload(np.zeros((padded, 4), np.float32))
     nl.atom_of_slot, nl.slot_of_atom = d_aos, d_soa
     nl.excl_start, nl.excl_atoms = K.upload(start), K.upload(flat)
     st = np.zeros(8, np.int32)
@@ -126,7 +133,7 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
         K.memset(pm.grid_real, 0x55, 4 * ng[0] * ng[1] * ng[2], None)                                # ... and the charge grid
         K.nl_prepare(C.byref(nl), d_pos, d_wrap, d_f, 8 * 3 * padded, pm.grid_real, 4 * ng[0] * ng[1] * ng[2], None)
         K.force_front(C.byref(nl), C.byref(pm), 0, None, d_pos, d_f, d_e, grid, 1, None)
-    elif compact:
+    elif compact or prepare:
         K.nl_step(C.byref(nl), d_pos, d_wrap, None)
     else:
         K.nl_update(C.byref(nl), None)
@@ -147,7 +154,8 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     else:
         d_f, d_e = K.upload(np.zeros(3 * padded, np.int64)), K.upload(np.zeros(grid))
         K.nb_direct(C.byref(nl), C.byref(p), d_se, d_f, d_e, grid, 1 if energy else 0, None)
-    global LAST_FIXED_POINT_FORCES
+    global LAST_FIXED_POINT_FORCES, LAST_NL
+    LAST_NL = (nl, slot_of_atom)
     LAST_FIXED_POINT_FORCES = K.download(d_f, (3, padded), np.int64)
     f = LAST_FIXED_POINT_FORCES.astype(np.float64) / 2 ** 32
     e = float(K.download(d_e, grid, np.float64).sum())
@@ -162,6 +170,48 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
         f_rec, e_rec = OPME.pme_exec(pos, q.astype(np.float32).astype(np.float64), box3, alpha, fused_pme)
         f_or, e_or = f_or + f_rec, e_or + e_rec
     return forces, e, f_or, e_or, state
+
+
+def run_cutoff_edge(K, n=1200, L=3.4, cutoff=0.7, seed=5, energy=False, edge_path=True, triclinic=False, compact=True):
+    """A dense box in which up to 100 pairs of unit charges are moved to distances rc (1 + e), |e| from 1e-10 to 3e-7, on both sides
+    of the cutoff: the float32 separation of such a pair (rounding ~1e-7 nm) cannot tell the side, the truncated pair force there
+    (`jump`) is of order 1 kJ/mol/nm, so a wrong decision shows as an error of one jump on two atoms.
+    -> (forces, oracle forces, planted atoms [2m], jump, energy, oracle energy)"""
+    from scipy.special import erfc
+    rng = np.random.default_rng(seed)
+    box3 = np.eye(3) * L
+    if triclinic:
+        box3 = np.array([[L, 0, 0], [0.2 * L, 0.9 * L, 0], [-0.3 * L, 0.25 * L, 1.1 * L]])
+    pos = lattice_positions(rng, n, box3)                       # what run_direct_space would draw with this seed
+    q = np.where(rng.random(n) < 0.5, 1.0, -1.0)
+    q[: n // 2 * 2 : 2] = 1.0
+    q[1 : n // 2 * 2 : 2] = -1.0
+    inv = np.linalg.inv(box3)
+    mags = np.array([1e-10, 1e-9, 3e-9, 1e-8, 3e-8, 1e-7, 3e-7])
+    used = np.zeros(n, bool)
+    planted = []
+    for i in range(n):
+        if used[i] or len(planted) >= 100:
+            continue
+        d = pos - pos[i]
+        d -= np.round(d @ inv) @ box3                            # nearest image for boxes this much wider than the cutoff
+        r = np.linalg.norm(d, axis=1)
+        cand = np.where((np.abs(r - cutoff) < 0.02) & ~used)[0]
+        cand = cand[cand != i]
+        if len(cand) == 0:
+            continue
+        j = int(cand[0])
+        k = len(planted)
+        e = mags[k % len(mags)] * (1.0 if (k // len(mags)) % 2 == 0 else -1.0)
+        pos[j] = pos[i] + d[j] * (cutoff * (1.0 + e) / r[j])
+        used[i] = used[j] = True
+        planted.append((i, j))
+    assert len(planted) >= 40
+    alpha = float(np.sqrt(-np.log(2 * 5e-4)) / cutoff)
+    jump = 138.935 * (erfc(alpha * cutoff) / cutoff ** 2 + 2 * alpha / np.sqrt(np.pi) * np.exp(-(alpha * cutoff) ** 2) / cutoff)
+    f, en, f_or, e_or, state = run_direct_space(K, n, ONB.PME, cutoff, L, [], triclinic=triclinic, compact=compact, energy=energy, positions=pos, charges=q,
+                                                 edge_path=edge_path, seed=seed, prepare=True)
+    return f, f_or, np.array(planted).reshape(-1), float(jump), en, e_or
 
 
 def twiddles(n):

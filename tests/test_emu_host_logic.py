@@ -81,6 +81,27 @@ def test_fused_single_stream_evaluation(K, switch, ng):
 
 
 @needs_emu
+@pytest.mark.parametrize("kw", [dict(), dict(energy=True), dict(triclinic=True, compact=False), dict(compact=False)],
+                         ids=["single_image_forces", "single_image_energy", "triclinic", "per_pair_image"])
+def test_cutoff_edge_pairs_are_decided_in_double(K, kw):
+    # a pair within float rounding of the cutoff must land on the side the Reference platform puts it
+    f, f_or, planted, jump, en, e_or = KC.run_cutoff_edge(K, **kw)
+    if not kw or kw.get("energy"):
+        assert KC.LAST_SINGLE_FRACTION > 0.8
+    err = np.linalg.norm(f - f_or, axis=1)
+    rms = np.sqrt((f_or ** 2).sum(1).mean())
+    # (a wrong decision is an error of one whole jump; the float noise of a random slot order, whose blocks span the box, is 3 % of it)
+    assert err.max() < (5e-5 if kw.get("compact", True) else 1e-4) * rms and err[planted].max() < (0.02 if kw.get("compact", True) else 0.1) * jump, "a pair was counted on the wrong side of the cutoff: %g of the force jump there" % (err[planted].max() / jump)
+    if kw.get("energy"):
+        assert abs(en - e_or) < 1e-5 * abs(e_or)
+
+
+def test_cutoff_edge_case_is_not_vacuous(K):
+    # the same pairs without the low parts of the coordinates: the float separation decides, and some pairs land on the wrong side
+    f, f_or, planted, jump, en, e_or = KC.run_cutoff_edge(K, edge_path=False)
+    assert np.linalg.norm(f - f_or, axis=1)[planted].max() > 0.5 * jump
+
+
 def test_pairs_with_fft_declines_configurations_it_does_not_cover(K):
     """ommhip_pairs_with_fft returns -1 and launches nothing for triclinic boxes, non-Ewald methods and planes beyond its
     LDS budget; the caller then uses the separate entry points."""

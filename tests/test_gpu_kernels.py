@@ -58,6 +58,25 @@ def test_direct_space_force_only_and_lj_free_variants(K, energy, lj_free_tail, f
         assert abs(e - e_or) < 1e-5 * max(abs(e_or), 100.0)
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(energy=True), dict(triclinic=True, compact=False), dict(compact=False)],
+                         ids=["single_image_forces", "single_image_energy", "triclinic", "per_pair_image"])
+def test_cutoff_edge_pairs_are_decided_in_double(K, kw):
+    """~100 pairs planted at rc (1 +- 1e-10 ... 3e-7) in a dense 3 000-atom box.  Float32 separations cannot tell
+    which side of the cutoff they are on; the pair kernel's rare double-precision path must put every one where the oracle (and
+    ReferenceNeighborList.cpp:195-197) puts it -- a wrong decision is an error of one whole truncation jump on two atoms."""
+    f, f_or, planted, jump, en, e_or = KC.run_cutoff_edge(K, n=3000, L=4.6, cutoff=0.9, **kw)
+    err = np.linalg.norm(f - f_or, axis=1)
+    rms = np.sqrt((f_or ** 2).sum(1).mean())
+    assert err.max() < (5e-5 if kw.get("compact", True) else 1e-4) * rms and err[planted].max() < (0.02 if kw.get("compact", True) else 0.1) * jump
+    if kw.get("energy"):
+        assert abs(en - e_or) < 1e-5 * abs(e_or)
+
+
+def test_cutoff_edge_case_is_not_vacuous(K):
+    f, f_or, planted, jump, en, e_or = KC.run_cutoff_edge(K, n=3000, L=4.6, cutoff=0.9, edge_path=False)
+    assert np.linalg.norm(f - f_or, axis=1)[planted].max() > 0.5 * jump
+
+
 @pytest.mark.parametrize("ewald_tol", [1e-4, 1e-6])
 def test_direct_space_force_only_at_other_ewald_tolerances(K, ewald_tol):
     """alpha * cutoff = 2.92 (polynomial form of the real-space Ewald force) and 3.62 (beyond its fit: erfc form) -- same bar."""

@@ -1,4 +1,4 @@
-"""profiles/pmc_pairs_fft.json from the two PMC summaries of tools/gpu_pmc2.sh (FETCH_SIZE and WRITE_SIZE passes over the default
+"""profiles/pmc_pairs_fft.json from the two PMC summaries of `tools/gpu_visit.sh hbm` (FETCH_SIZE and WRITE_SIZE passes over the default
 bench command): HBM-side bytes of one unit = pairs_fft_plane + pairs_fft_lines + pairs_fft_plane, with the hash of the kernel
 sources they were measured on (bench.py quotes the figure only while that hash matches).
 usage: make_pmc_json.py <fetch_summary.txt> <write_summary.txt> <tag>"""
@@ -31,11 +31,12 @@ def main():
     # gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported; both in KB
     traffic = 1024.0 * (2.0 * (2 * f_plane + f_lines) + (2 * w_plane + w_lines))
     out = {"kernel": "pairs_fft_plane + pairs_fft_lines + pairs_fft_plane (one unit = the three launches)",
-           "source": "profiles/%s_pmc_fetch_summary.txt and %s_pmc_write_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, %d units each)" % (tag, tag, int(n)),
+           "source": "profiles/%s_pmc_fetch.txt and %s_pmc_write.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, %d units each)" % (tag, tag, int(n)),
            "fetch_size_kb": {"pairs_fft_plane (x2)": f_plane, "pairs_fft_lines": f_lines},
            "write_size_kb": {"pairs_fft_plane (x2)": w_plane, "pairs_fft_lines": w_lines},
            "correction": "gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated, taken as reported",
-           "traffic_bytes_per_launch": int(traffic), "kernel_sources_sha": bench.kernel_sources_sha()}
+           "traffic_bytes_per_launch": int(traffic), "kernel_sources_sha": bench.kernel_sources_sha(),
+           "visit": "%s, %s, device %s" % (tag, __import__("datetime").date.today().isoformat(), os.environ.get("OMMHIP_VISIT_BOX", "MI355X gpurun box"))}
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_pairs_fft.json"), "w"), indent=1)
     print(out)
 

@@ -61,6 +61,22 @@ int ommhip_comm_all_to_all(ommhip_comm* comm, const void* send_d, void* recv_d, 
  * potential.)  With size == 1 the data is copied locally. */
 int ommhip_comm_ring_exchange(ommhip_comm* comm, const void* send_down_d, void* recv_from_up_d, size_t bytes_down,
                               const void* send_up_d, void* recv_from_down_d, size_t bytes_up, void* stream);
+/* Halo exchange between neighbouring slabs (periodic ring) -- the per-step position exchange of a decomposed run.  buffer_d holds
+ * one range of `rank_stride` bytes per rank (slot order: rank r's records start at r * rank_stride); the plan -- identical on all
+ * ranks -- says, for EVERY rank, which part of its range its lower neighbour needs ("down" section) and which part its upper
+ * neighbour needs ("up" section; the two may overlap).  In place: this rank's own range is the send buffer, the sections of rank - 1
+ * and rank + 1 land at their natural addresses inside this rank's copy of the buffer.  `trailer_bytes` > 0: the small record at
+ * trailer_offset of every rank's range (momentum, flags) goes to ALL ranks in the same group (size - 1 tiny sends).
+ * RCCL: one ncclGroup of at most 2 + (size - 1) sends and as many receives -- every one over a link of its own on xGMI.
+ * With two ranks both neighbours are the same peer; with one rank nothing moves. */
+#define OMMHIP_MAX_RANKS 64
+typedef struct ommhip_halo_plan {
+    size_t rank_stride;
+    size_t down_offset[OMMHIP_MAX_RANKS], down_bytes[OMMHIP_MAX_RANKS];     /* relative to the start of the rank's range */
+    size_t up_offset[OMMHIP_MAX_RANKS], up_bytes[OMMHIP_MAX_RANKS];
+    size_t trailer_offset, trailer_bytes;
+} ommhip_halo_plan;
+int ommhip_comm_halo_exchange(ommhip_comm* comm, void* buffer_d, const ommhip_halo_plan* plan, void* stream);
 /* Host all-gather of small records (energies, momenta, flags): blocking; every rank then reduces the size records in the
  * same order, which makes sums bit-identical on all ranks. */
 int ommhip_comm_all_gather_host(ommhip_comm* comm, const void* send, void* recv, size_t bytes, void* stream);

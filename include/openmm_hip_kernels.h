@@ -94,6 +94,9 @@ int ommhip_forces_to_double(const long long* force_d, const int* slot_of_atom_d,
 int ommhip_add_forces_from_double(const double* in_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, long long* force_d, void* stream);
 /* wire[s] = fixed-point box fractions of pos[atom_of_slot[s]] for the valid slots of [slot0, slot1)  (ommhip_neighbor_list::pos_wire) */
 int ommhip_encode_wire(const void* pos_d, const int* atom_of_slot_d, int slot0, int slot1, const double box_len[3], void* wire_d, void* stream);
+/* Decomposed runs: zero the flag word (fourth double) of every rank's trailer record in the wire buffer (ommhip_neighbor_list::dd_flags);
+ * the momentum in the first three doubles stays.  Called at every re-sort. */
+int ommhip_clear_trailer_flags(void* wire_d, int ranks, int slots_per_rank, int trailer_slot, void* stream);
 /* dst[s] = src[atom_of_slot[s]] for every valid slot of [slot0, slot1) (double4 arrays): slot-ordered staging of positions or
  * velocities for an all-gather (State downloads, re-sorts). */
 int ommhip_pack_slots(const void* src_atom_order_d, const int* atom_of_slot_d, int slot0, int slot1, void* dst_slot_order_d, void* stream);
@@ -182,6 +185,25 @@ typedef struct ommhip_neighbor_list {
      * image in double, i.e. exactly as ReferenceNeighborList.cpp:195-197 decides it.  NULL: the float separation decides, and a
      * pair within ~1e-7 nm of the cutoff may be counted on the other side (a force jump of ~2e-4 of the RMS force on two atoms). */
     void* posq_rel_lo;
+    /* Halo mode of a decomposed run (dd_mode = 1): pos_wire is current only for the slots of this rank and for the
+     * sections of its two neighbouring slabs that the per-step halo exchange (ommhip_comm_halo_exchange) delivers -- up to four
+     * [begin, end) slot ranges, multiples of 32.  ommhip_nl_prepare then converts, checks and bounds those slots only (every other
+     * block keeps the hugely negative half extent the host gave it at the re-sort, so nothing can pair with it), and the list
+     * builder snapshots reference positions for them only.  num_active_ranges = 0: every slot (replicated positions).
+     * Drift guard: an atom outside the delivered sections can only come within the list cutoff of an owned atom if one of the two
+     * drifts further along x than the margin the sections were cut with.  wire_ref (uint4[padded_atoms]) holds the wire records of
+     * the last re-sort; an owned atom whose x fraction differs from it by more than dd_warn (units of 2^-32 box lengths) raises
+     * dd_flags[1] -- which ommhip_integrate_fused puts into the rank's trailer, so that one step later every rank finds it in some
+     * trailer and raises dd_flags[2]: the host reads that word at the same evaluation on all ranks and re-sorts -- and more than
+     * dd_max raises dd_flags[0] (the forces may be incomplete: the host ends the run). */
+    int num_active_ranges;
+    int active_range[8];
+    const void* wire_ref;
+    const unsigned char* dd_guard_atom;   /* [num_atoms]: 1 = watched by the drift guard (the first atom of each constraint-connected unit: the
+                                           * others stay within the unit's size of it, which the halo is cut for); NULL = every atom */
+    unsigned dd_warn, dd_max;
+    int* dd_flags;                /* device int[4], zeroed by the host at every re-sort */
+    int dd_ranks, dd_slots_per_rank, dd_trailer_slot;
 } ommhip_neighbor_list;
 
 typedef struct ommhip_nonbonded_params {
@@ -327,6 +349,11 @@ typedef struct ommhip_term_batch {
     int periodic;              /* minimum-image displacements */
     const double* charge;      /* device double[num_atoms], EWALD_EXCLUSION only */
     double alpha;              /* EWALD_EXCLUSION only */
+    /* Decomposed runs in halo mode (own_slot1 > own_slot0): every rank walks through the whole list but evaluates a term only if it
+     * owns one of its atoms (slot in [own_slot0, own_slot1)) -- the positions of the others are then inside its halo -- keeps the
+     * forces on its own atoms (the rest lands in slots nobody reads), and counts the term's energy only if it owns the FIRST atom:
+     * over the ranks every term is counted once. */
+    int own_slot0, own_slot1;
 } ommhip_term_batch;
 int ommhip_term_forces_multi(int num_lists, const ommhip_term_batch* lists, const void* pos_d, const int* slot_of_atom_d, int padded_atoms,
                              const double box[6], long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
@@ -421,6 +448,8 @@ typedef struct ommhip_step_units {
     /* 1: no unit is a SHAKE cluster (SETTLE waters and free atoms only, at most three atoms per unit): the kernel variant without
      * the fourth atom's state and the SHAKE iteration is launched (fewer registers, more waves per SIMD) */
     int small_units;
+    /* decomposed runs in halo mode: ommhip_neighbor_list::dd_flags; the trailer's fourth double carries dd_flags[1] (or NULL) */
+    const int* dd_flags;
 } ommhip_step_units;
 enum { OMMHIP_INTEGRATOR_VERLET = 0, OMMHIP_INTEGRATOR_LANGEVIN = 1, OMMHIP_INTEGRATOR_LANGEVIN_MIDDLE = 2 };
 int ommhip_integrate_fused(int integrator, const ommhip_integrator_state* s, const ommhip_step_units* u, void* stream);

@@ -23,6 +23,7 @@ namespace {
 
 struct TermList {
     int kind, numTerms, periodic, firstBlock;
+    int ownSlot0, ownSlot1;    // halo mode of a decomposed run (ownSlot1 > ownSlot0): terms without an owned atom are skipped, the energy counts where the first atom is owned
     double alpha;
     const int* atoms;          // numTerms * atomsPerTerm
     const double* params;      // numTerms * paramsPerTerm
@@ -192,7 +193,19 @@ __device__ __forceinline__ void terms_body(const TermArgs& a, const int block, d
     const TermList& l = a.list[li];
     const int t = (block - l.firstBlock) * 256 + threadIdx.x;
     double energy = 0;
-    if (t < l.numTerms) {
+    bool evaluate = t < l.numTerms, countEnergy = true;
+    if (evaluate && l.ownSlot1 > l.ownSlot0) {
+        const int perTerm = l.kind == OMMHIP_TERM_HARMONIC_ANGLE ? 3 : (l.kind == OMMHIP_TERM_PERIODIC_TORSION ? 4 : 2);
+        bool any = false;
+        for (int k = 0; k < perTerm; k++) {
+            const int slot = a.slotOfAtom[l.atoms[(size_t) t * perTerm + k]];
+            const bool own = slot >= l.ownSlot0 && slot < l.ownSlot1;
+            any = any || own;
+            if (k == 0) countEnergy = own;
+        }
+        evaluate = any;
+    }
+    if (evaluate) {
         const TermCtx c(a, l);
         switch (l.kind) {
             case OMMHIP_TERM_EXCEPTION14: energy = term_exception14(c, t); break;
@@ -204,6 +217,7 @@ __device__ __forceinline__ void terms_body(const TermArgs& a, const int block, d
         }
     }
     if (a.includeEnergy) {
+        if (!countEnergy) energy = 0;
         energy = wave_sum(energy);
         if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = energy;
         __syncthreads();
@@ -348,7 +362,7 @@ static int make_term_args(TermArgs& a, int num_lists, const ommhip_term_batch* l
         if (lists[i].terms.num_terms <= 0) continue;
         if (lists[i].kind < OMMHIP_TERM_EXCEPTION14 || lists[i].kind > OMMHIP_TERM_DISPERSION_EXCLUSION) return -1;
         TermList& l = a.list[a.numLists++];
-        l.kind = lists[i].kind; l.numTerms = lists[i].terms.num_terms; l.periodic = lists[i].periodic; l.firstBlock = blocks;
+        l.kind = lists[i].kind; l.numTerms = lists[i].terms.num_terms; l.periodic = lists[i].periodic; l.firstBlock = blocks; l.ownSlot0 = lists[i].own_slot0; l.ownSlot1 = lists[i].own_slot1;
         l.alpha = lists[i].alpha; l.atoms = lists[i].terms.atoms; l.params = lists[i].terms.params; l.charge = lists[i].charge;
         blocks += (l.numTerms + 255) / 256;
     }

@@ -289,6 +289,56 @@ int ommhip_comm_ring_exchange(ommhip_comm* c, const void* send_down_d, void* rec
     return rc;
 }
 
+int ommhip_comm_halo_exchange(ommhip_comm* c, void* buffer_d, const ommhip_halo_plan* plan, void* stream) {
+    if (c->size > OMMHIP_MAX_RANKS) return 1;
+    if (c->size == 1) return 0;                     // the only slab holds everything already
+    hipStream_t st = (hipStream_t) stream;
+    char* buf = (char*) buffer_d;
+    const int me = c->rank, down = (me + c->size - 1) % c->size, up = (me + 1) % c->size;
+    char* mine = buf + (size_t) me * plan->rank_stride;
+#ifndef OMMHIP_EMU
+    if (c->rccl) {
+        RcclApi& api = rccl_api();
+        ncclComm_t nc = (ncclComm_t) c->nccl;
+        NCCL_TRY(api.groupStart());
+        // Sends and receives between one pair of ranks are matched in the order they are issued: with two ranks `down` and `up` are the
+        // same peer, and both sides issue "down section" before "up section".
+        if (plan->down_bytes[me] > 0) NCCL_TRY(api.send(mine + plan->down_offset[me], plan->down_bytes[me], ncclChar, down, nc, st));
+        if (plan->down_bytes[up] > 0) NCCL_TRY(api.recv(buf + (size_t) up * plan->rank_stride + plan->down_offset[up], plan->down_bytes[up], ncclChar, up, nc, st));
+        if (plan->up_bytes[me] > 0) NCCL_TRY(api.send(mine + plan->up_offset[me], plan->up_bytes[me], ncclChar, up, nc, st));
+        if (plan->up_bytes[down] > 0) NCCL_TRY(api.recv(buf + (size_t) down * plan->rank_stride + plan->up_offset[down], plan->up_bytes[down], ncclChar, down, nc, st));
+        if (plan->trailer_bytes > 0)
+            for (int p = 0; p < c->size; p++) {
+                if (p == me) continue;
+                NCCL_TRY(api.send(mine + plan->trailer_offset, plan->trailer_bytes, ncclChar, p, nc, st));
+                NCCL_TRY(api.recv(buf + (size_t) p * plan->rank_stride + plan->trailer_offset, plan->trailer_bytes, ncclChar, p, nc, st));
+            }
+        NCCL_TRY(api.groupEnd());
+        return 0;
+    }
+#endif
+    // host transport: records of one size (the largest section sizes of the plan) -- [down section | up section | trailer]
+    CommDiag diag;
+    size_t maxDown = 0, maxUp = 0;
+    for (int r = 0; r < c->size; r++) { if (plan->down_bytes[r] > maxDown) maxDown = plan->down_bytes[r]; if (plan->up_bytes[r] > maxUp) maxUp = plan->up_bytes[r]; }
+    const size_t rec = maxDown + maxUp + plan->trailer_bytes;
+    if (rec == 0) return 0;
+    if (c->hostSend.size() < rec) c->hostSend.resize(rec);
+    int rc = 0;
+    if (plan->down_bytes[me] > 0) rc = stage_down(c, mine + plan->down_offset[me], plan->down_bytes[me], 0, st);
+    if (rc == 0 && plan->up_bytes[me] > 0) rc = stage_down(c, mine + plan->up_offset[me], plan->up_bytes[me], maxDown, st);
+    if (rc == 0 && plan->trailer_bytes > 0) rc = stage_down(c, mine + plan->trailer_offset, plan->trailer_bytes, maxDown + maxUp, st);
+    if (rc != 0) return rc;
+    c->hostRecv.resize((size_t) c->size * rec);
+    if (c->fn(c->user, c->hostSend.data(), c->hostRecv.data(), rec) != 0) return 1;
+    if (plan->down_bytes[up] > 0) rc = stage_up(buf + (size_t) up * plan->rank_stride + plan->down_offset[up], c->hostRecv.data() + (size_t) up * rec, plan->down_bytes[up], st);
+    if (rc == 0 && plan->up_bytes[down] > 0)
+        rc = stage_up(buf + (size_t) down * plan->rank_stride + plan->up_offset[down], c->hostRecv.data() + (size_t) down * rec + maxDown, plan->up_bytes[down], st);
+    for (int p = 0; p < c->size && rc == 0 && plan->trailer_bytes > 0; p++)
+        if (p != me) rc = stage_up(buf + (size_t) p * plan->rank_stride + plan->trailer_offset, c->hostRecv.data() + (size_t) p * rec + maxDown + maxUp, plan->trailer_bytes, st);
+    return rc;
+}
+
 int ommhip_comm_all_gather_host(ommhip_comm* c, const void* send, void* recv, size_t bytes, void* stream) {
     if (c->size == 1 && !c->rccl) { memcpy(recv, send, bytes); return 0; }
 #ifndef OMMHIP_EMU

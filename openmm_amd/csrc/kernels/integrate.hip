@@ -427,6 +427,7 @@ struct UnitArgs {
     uint4* posWire;
     double invBox[3];
     int ranks, rank, slotsPerRank, trailerSlot;
+    const int* ddFlags;       // halo mode: [1] = an owned atom is near the drift margin -> fourth double of the trailer (every rank sees it one step later)
 };
 
 // SMALL: no unit is a SHAKE cluster (only SETTLE waters and free atoms: every unit has at most three atoms) -- the state of a fourth
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(128) void k_step_units(IntArgs a, UnitArgs u) {
         sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
         if (threadIdx.x == 0) {
             u.cm[0] = sx; u.cm[1] = sy; u.cm[2] = sz; *counter = 0;
-            if (u.posWire != nullptr) *(double4*) (u.posWire + (size_t) u.rank * u.slotsPerRank + u.trailerSlot) = make_double4(sx, sy, sz, 0.0);
+            if (u.posWire != nullptr) *(double4*) (u.posWire + (size_t) u.rank * u.slotsPerRank + u.trailerSlot) = make_double4(sx, sy, sz, u.ddFlags != nullptr && u.ddFlags[1] != 0 ? 1.0 : 0.0);
         }
     }
 }
@@ -741,6 +742,7 @@ extern "C" int ommhip_integrate_fused(int integrator, const ommhip_integrator_st
     u.posWire = (uint4*) units->pos_wire;
     for (int k = 0; k < 3; k++) u.invBox[k] = units->box_len[k] > 0 ? 1.0 / units->box_len[k] : 0.0;
     u.ranks = units->ranks; u.rank = units->rank; u.slotsPerRank = units->slots_per_rank; u.trailerSlot = units->trailer_slot;
+    u.ddFlags = units->dd_flags;
     hipStream_t st = (hipStream_t) stream;
     const dim3 grid = grid_for(u.numUnits);
     switch (integrator) {

@@ -57,6 +57,9 @@ struct NlArgs {
     const float4* posq;
     float4* posqRef;
     float4* posqRel;         // block-relative coordinates (position minus blockCenter of its block) + charge, or null
+    // halo mode: the slot ranges with current wire records (own + the neighbours' sections); numActive = 0: all slots
+    int numActive, activeBegin[4], activeEnd[4], activeTotal;
+    const uint4* wireRef; const unsigned char* ddGuardAtom; unsigned ddWarn, ddMax; int* ddFlags; int ddRanks, ddSlotsPerRank, ddTrailerSlot;
     float4* posqRelLo;       // what the float rounding of posqRel left of the double-precision value (pair kernel's cutoff-edge path), or null
     const int* atomOfSlot;
     const int* slotOfAtom;
@@ -80,6 +83,20 @@ struct NlArgs {
     float4* cellBoxes;       // [2 * numBlocks] (centre, half extent) of those blocks, in the same order
     float* cellMeta;         // [0..2] largest half extent per axis among the binned blocks, [3] number of oversized blocks (int bits)
 };
+
+// g-th slot of the active ranges (halo mode), or g itself; false beyond the last one
+__device__ __forceinline__ bool active_slot(const NlArgs& a, int g, int& s) {
+    if (a.numActive == 0) { s = g; return g < a.paddedAtoms; }
+    s = 0;
+    bool found = false;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int len = r < a.numActive ? a.activeEnd[r] - a.activeBegin[r] : 0;
+        if (!found && g < len) { s = a.activeBegin[r] + g; found = true; }
+        g -= len;
+    }
+    return found;
+}
 
 template <int PBC>
 __device__ __forceinline__ void apply_pbc(float& dx, float& dy, float& dz, const Box& b) {
@@ -191,6 +208,7 @@ __global__ __launch_bounds__(1024) void nl_bin_blocks(NlArgs a) {
         for (int u = 0; u < NL_BIN_BATCH; u++) {
             const int b = b0 + u * 1024 + t;
             if (b >= a.numBlocks) continue;
+            if (h[u].x < 0.f) continue;                  // a block without atoms, or (halo mode) without current positions on this rank
             if (h[u].x > a.bigHalf || h[u].y > a.bigHalf || h[u].z > a.bigHalf) { a.cellBlocks[a.numBlocks + atomicAdd(&numBig, 1)] = b; continue; }
             atomicAdd(&count[cell_of(a, c[u]) + 1], 1);
             hx = fmaxf(hx, h[u].x); hy = fmaxf(hy, h[u].y); hz = fmaxf(hz, h[u].z);
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(1024) void nl_bin_blocks(NlArgs a) {
         for (int u = 0; u < NL_BIN_BATCH; u++) {
             const int b = b0 + u * 1024 + t;
             if (b >= a.numBlocks) continue;
-            if (h[u].x > a.bigHalf || h[u].y > a.bigHalf || h[u].z > a.bigHalf) continue;
+            if (h[u].x < 0.f || h[u].x > a.bigHalf || h[u].y > a.bigHalf || h[u].z > a.bigHalf) continue;
             const int cell = cell_of(a, c[u]);
             const int pos = count[cell] + atomicAdd(&cursor[cell], 1);
             a.cellBlocks[pos] = b;
@@ -279,8 +297,12 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
     if (a.ownedBlocks < a.numBlocks) {
         // A ranked list also holds j atoms of blocks this launch has no workgroup for, and the displacement check looks at
         // every slot: the workgroups share the snapshot of all of them.
-        for (int s = (X - a.firstBlock) * NL_THREADS + t; s < a.paddedAtoms; s += numWorkgroups * NL_THREADS)
+        const int total = a.numActive == 0 ? a.paddedAtoms : a.activeTotal;
+        for (int g = (X - a.firstBlock) * NL_THREADS + t; g < total; g += numWorkgroups * NL_THREADS) {
+            int s;
+            active_slot(a, g, s);
             if (s < a.firstBlock * OMM_TILE || s >= (a.firstBlock + a.ownedBlocks) * OMM_TILE) a.posqRef[s] = a.posq[s];
+        }
     }
     const bool iValid = lane < OMM_TILE && a.atomOfSlot[X * OMM_TILE + lane] >= 0;
     const unsigned iValidMask = (unsigned) __ballot(iValid);
@@ -643,18 +665,26 @@ __global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
 __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __restrict__ pos, const int4* __restrict__ wrap, BoxD boxd,
                                                   float4* __restrict__ posqOut, int checkDisplacement,
                                                   uint4* __restrict__ clearA, size_t clearNA, uint4* __restrict__ clearB, size_t clearNB) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;      // slot; the grid covers paddedAtoms exactly (multiple of 32)
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;      // the grid covers the slots to convert (a multiple of 32) exactly
     // start-of-evaluation clears (force accumulator, PME charge grid) ride along: nothing in this launch reads them
     {
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
         const size_t stride = (size_t) gridDim.x * blockDim.x;
-        for (size_t i = (size_t) s; i < clearNA + clearNB; i += stride) {
+        for (size_t i = (size_t) g; i < clearNA + clearNB; i += stride) {
             if (i < clearNA) clearA[i] = z;
             else clearB[i - clearNA] = z;
         }
     }
-    const bool inRange = s < a.paddedAtoms;
+    int s;                                                     // slot: g itself, or the g-th slot of the active ranges (halo mode)
+    const bool inRange = active_slot(a, g, s);
     const int sl = inRange ? s : a.paddedAtoms - 1;
+    if (g == 0 && a.ddFlags != nullptr && a.posWire != nullptr) {
+        // some rank saw one of its atoms near the drift margin one step ago (the flag travelled in its trailer): every rank raises
+        // the same word at the same evaluation, the hosts re-sort together
+        bool any = false;
+        for (int r = 0; r < a.ddRanks; r++) any = any || ((const double4*) (a.posWire + (size_t) r * a.ddSlotsPerRank + a.ddTrailerSlot))->w != 0.0;
+        if (any) a.ddFlags[2] = 1;
+    }
     const int atom = a.atomOfSlot[sl];
     const bool valid = inRange && atom >= 0;
     float4 p = posqOut[sl];
@@ -666,7 +696,15 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
             const uint4 u = a.posWire[sl];
             const double f = 1.0 / 4294967296.0;
             xw = (double) u.x * f * boxd.ax; yw = (double) u.y * f * boxd.by; zw = (double) u.z * f * boxd.cz;
-            if (a.posScatter != nullptr && (sl < a.firstBlock * OMM_TILE || sl >= (a.firstBlock + a.ownedBlocks) * OMM_TILE)) {
+            const bool own = sl >= a.firstBlock * OMM_TILE && sl < (a.firstBlock + a.ownedBlocks) * OMM_TILE;
+            if (a.wireRef != nullptr && own && (a.ddGuardAtom == nullptr || a.ddGuardAtom[atom] != 0)) {
+                // drift along x since the re-sort (wrap-around arithmetic of the 32-bit fractions = minimum image)
+                const int d = (int) (u.x - a.wireRef[sl].x);
+                const unsigned ad = (unsigned) (d < 0 ? -d : d);
+                if (ad > a.ddWarn) a.ddFlags[1] = 1;
+                if (ad > a.ddMax) a.ddFlags[0] = 1;
+            }
+            if (a.posScatter != nullptr && !own) {
                 // atom-ordered copy of a foreign atom: the last known position moved by the minimum-image displacement
                 double4 o = a.posScatter[atom];
                 double dx = xw - o.x, dy = yw - o.y, dz = zw - o.z;
@@ -749,6 +787,16 @@ NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
     if (nl->owned_blocks > 0 && nl->first_block >= 0 && nl->first_block + nl->owned_blocks <= a.numBlocks) { a.firstBlock = nl->first_block; a.ownedBlocks = nl->owned_blocks; }
     a.ddMode = nl->dd_mode != 0 && a.ownedBlocks < a.numBlocks ? 1 : 0;
     a.posWire = (const uint4*) nl->pos_wire; a.posScatter = (double4*) nl->pos_scatter;
+    a.numActive = 0; a.activeTotal = a.paddedAtoms;
+    for (int r = 0; r < 4; r++) { a.activeBegin[r] = 0; a.activeEnd[r] = 0; }
+    if (a.ddMode && nl->num_active_ranges > 0 && nl->num_active_ranges <= 4) {
+        a.numActive = nl->num_active_ranges; a.activeTotal = 0;
+        for (int r = 0; r < a.numActive; r++) { a.activeBegin[r] = nl->active_range[2 * r]; a.activeEnd[r] = nl->active_range[2 * r + 1]; a.activeTotal += a.activeEnd[r] - a.activeBegin[r]; }
+    }
+    a.ddGuardAtom = nl->dd_guard_atom;
+    a.wireRef = (const uint4*) nl->wire_ref; a.ddWarn = nl->dd_warn; a.ddMax = nl->dd_max; a.ddFlags = nl->dd_flags;
+    a.ddRanks = nl->dd_ranks; a.ddSlotsPerRank = nl->dd_slots_per_rank; a.ddTrailerSlot = nl->dd_trailer_slot;
+    if (a.ddFlags == nullptr || !a.ddMode) { a.wireRef = nullptr; a.ddFlags = nullptr; }
     a.pbc = nl->pbc;
     double rl = nl->cutoff + nl->padding;
     a.listCutoff2 = nl->cutoff > 0 ? (float) (rl * rl) : INFINITY;
@@ -811,7 +859,7 @@ extern "C" int ommhip_nl_prepare(const ommhip_neighbor_list* nl, const void* pos
     NlArgs a = make_nl_args(nl);
     BoxD bd;
     bd.ax = nl->box[0]; bd.bx = nl->box[1]; bd.by = nl->box[2]; bd.cx = nl->box[3]; bd.cy = nl->box[4]; bd.cz = nl->box[5];
-    hipLaunchKernelGGL(nl_prepare, dim3((a.paddedAtoms + 255) / 256), dim3(256), 0, st, a, (const double4*) pos_d, (const int4*) wrap_d, bd,
+    hipLaunchKernelGGL(nl_prepare, dim3(((a.numActive == 0 ? a.paddedAtoms : a.activeTotal) + 255) / 256), dim3(256), 0, st, a, (const double4*) pos_d, (const int4*) wrap_d, bd,
                        (float4*) nl->posq, nl->cutoff > 0 ? 1 : 0,
                        (uint4*) clear_a_d, clear_a_d != nullptr ? a_bytes / 16 : 0, (uint4*) clear_b_d, clear_b_d != nullptr ? b_bytes / 16 : 0);
     return (int) hipGetLastError();

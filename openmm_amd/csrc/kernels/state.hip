@@ -104,6 +104,12 @@ __global__ void k_encode_wire(const double4* __restrict__ pos, const int* __rest
                          (unsigned) (unsigned long long) (fz * 4294967296.0), 0u);
 }
 
+// the fourth double of every rank's trailer record (the "an atom of mine is near the drift margin" flag) back to zero: at a re-sort
+__global__ void k_clear_trailer_flags(uint4* __restrict__ wire, int ranks, int slotsPerRank, int trailerSlot) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < ranks) ((double4*) (wire + (size_t) r * slotsPerRank + trailerSlot))->w = 0.0;
+}
+
 // slot-ordered <-> atom-ordered copies of a double4 array (all-gather buffers of the decomposed run)
 __global__ void k_pack_slots(const double4* __restrict__ src, const int* __restrict__ atomOfSlot, int slot0, int slot1, double4* __restrict__ dst) {
     const int s = slot0 + blockIdx.x * blockDim.x + threadIdx.x;
@@ -210,6 +216,12 @@ extern "C" int ommhip_scale_molecule_centers(int num_molecules, const int* mol_s
 extern "C" int ommhip_posq_with_weights(const void* posq_d, const double* weight_d, const int* atom_of_slot_d, int padded_atoms, void* dst_d, void* stream) {
     hipLaunchKernelGGL(k_posq_with_weights, dim3((padded_atoms + 255) / 256), dim3(256), 0, (hipStream_t) stream,
                        (const float4*) posq_d, weight_d, atom_of_slot_d, padded_atoms, (float4*) dst_d);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_clear_trailer_flags(void* wire_d, int ranks, int slots_per_rank, int trailer_slot, void* stream) {
+    if (ranks <= 0) return 0;
+    hipLaunchKernelGGL(k_clear_trailer_flags, dim3((ranks + 63) / 64), dim3(64), 0, (hipStream_t) stream, (uint4*) wire_d, ranks, slots_per_rank, trailer_slot);
     return (int) hipGetLastError();
 }
 

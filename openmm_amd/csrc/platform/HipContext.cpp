@@ -97,7 +97,7 @@ HipContext::HipContext(const System& system, int deviceIndex, bool hostMode, con
             throw OpenMMException("HIP platform: a Context spread over several GPUs needs a native integrator (Verlet, Langevin, LangevinMiddle) and no host-side state changes (barostat, virtual sites)");
         // every rank gets the same number of slots: its share of the atoms, room to keep the last unit whole, the trailer slot
         const int R = domain.ranks;
-        const int share = (numAtoms + R - 1) / R + maxUnitSize + 2;
+        const int share = (numAtoms + R - 1) / R + maxUnitSize + 2 + 4 * OMMHIP_TILE;     // + the padding between the four sections of a range (halo mode)
         slotsPerRank = ((share + OMMHIP_TILE - 1) / OMMHIP_TILE) * OMMHIP_TILE;
         paddedAtoms = R * slotsPerRank;
         ownSlot0 = domain.rank * slotsPerRank; ownSlot1 = ownSlot0 + slotsPerRank; trailerSlot = slotsPerRank - 2;
@@ -122,7 +122,26 @@ HipContext::HipContext(const System& system, int deviceIndex, bool hostMode, con
         velSlot.allocate(sizeof(double) * 4 * (size_t) paddedAtoms);
         HIP_CHECK(ommhip_memset(posSlot.ptr, 0, posSlot.bytes, stream));
         HIP_CHECK(ommhip_memset(velSlot.ptr, 0, velSlot.bytes, stream));
+        wireRef.allocate(posWire.bytes);
+        HIP_CHECK(ommhip_memset(wireRef.ptr, 0, wireRef.bytes, stream));
+        ddFlags.allocate(sizeof(int) * 4);
+        HIP_CHECK(ommhip_memset(ddFlags.ptr, 0, ddFlags.bytes, stream));
+        HIP_CHECK(ommhip_host_malloc((void**) &pinnedDdFlags, sizeof(int) * 4));
+        memset(pinnedDdFlags, 0, sizeof(int) * 4);
+        HIP_CHECK(ommhip_event_create_untimed(&ddFlagsEvent));
     }
+    // x drift of a unit's first atom between two re-sorts that the halo is cut for (nm).  A water molecule diffuses 0.07-0.1 nm (RMS, one
+    // axis) in the 500 steps = 1 ps between two scheduled re-sorts, the fastest of a million a few times that; at 0.75 of the margin
+    // the ranks re-sort early, together (pollDriftFlags).
+    haloDrift = getenv("OPENMM_HIP_DD_DRIFT") != NULL ? atof(getenv("OPENMM_HIP_DD_DRIFT")) : 0.4;
+    if (decomposed()) {
+        vector<unsigned char> first(max(numAtoms, 1), 0);
+        for (size_t u = 0; u + 1 < unitStart.size(); u++) first[unitAtomList[unitStart[u]]] = 1;
+        guardAtom.allocate(first.size());
+        HIP_CHECK(ommhip_memcpy_h2d(guardAtom.ptr, first.data(), first.size(), stream));
+        HIP_CHECK(ommhip_stream_sync(stream));
+    }
+    memset(&haloPlan, 0, sizeof(haloPlan));
     HIP_CHECK(ommhip_host_malloc((void**) &pinnedResult, sizeof(double) * 8));
     HIP_CHECK(ommhip_memset(energyBuffer.ptr, 0, energyBuffer.bytes, stream));
     HIP_CHECK(ommhip_memset(force.ptr, 0, force.bytes, stream));
@@ -151,6 +170,8 @@ HipContext::~HipContext() {
     if (pmeComm != NULL) ommhip_comm_destroy(pmeComm);
     if (domain.comm != NULL) ommhip_comm_destroy(domain.comm);
     if (pinnedResult != NULL) ommhip_host_free(pinnedResult);
+    if (pinnedDdFlags != NULL) ommhip_host_free(pinnedDdFlags);
+    if (ddFlagsEvent != NULL) ommhip_event_destroy(ddFlagsEvent);
     if (pmeForkEvent != NULL) ommhip_event_destroy(pmeForkEvent);
     if (pmeDoneEvent != NULL) ommhip_event_destroy(pmeDoneEvent);
     if (pmeStream != NULL) ommhip_stream_destroy(pmeStream);
@@ -296,11 +317,20 @@ void HipContext::addTerms(const ommhip_term_batch& batch, bool includeEnergy, in
 void HipContext::flushTerms() {
     if (pendingTerms.empty()) return;
     ensureCleared();
+    for (size_t i = 0; i < pendingTerms.size(); i++) stampOwnership(pendingTerms[i]);
     HIP_CHECK(ommhip_term_forces_multi((int) pendingTerms.size(), pendingTerms.data(), pos.ptr, slotOfAtom.as<int>(), paddedAtoms, box,
                                        force.as<long long>(), energyBuffer.as<double>(), EnergySlots, pendingTermsEnergy ? 1 : 0, stream));
     pendingTerms.clear();
     pendingTermIds.clear();
 }
+
+void HipContext::stampOwnership(ommhip_term_batch& batch) const {
+    // halo mode: a rank evaluates the terms that touch its atoms and counts the energy of those whose first atom it owns (bonded.hip)
+    batch.own_slot0 = batch.own_slot1 = 0;
+    if (haloMode) { batch.own_slot0 = ownSlot0; batch.own_slot1 = ownSlot1; }
+}
+
+bool HipContext::countsTermEnergy() const { return !decomposed() || haloMode || domain.rank == 0; }
 
 int HipContext::registerTerms(int group, const ommhip_term_batch& batch) {
     TermRegistration r = {nextTermId++, group, batch};
@@ -328,6 +358,7 @@ void HipContext::collectFrontTerms(vector<ommhip_term_batch>& out, bool includeE
         flushTerms();
     // queued lists first (their owners have executed already), then registered lists whose owners will execute later
     while (!pendingTerms.empty() && out.size() < OMMHIP_MAX_TERM_LISTS) {
+        stampOwnership(pendingTerms.back());
         out.push_back(pendingTerms.back());
         if (pendingTermIds.back() >= 0) launchedTermIds.push_back(pendingTermIds.back());
         pendingTerms.pop_back();
@@ -338,6 +369,7 @@ void HipContext::collectFrontTerms(vector<ommhip_term_batch>& out, bool includeE
         if (r.batch.terms.num_terms <= 0 || ((currentGroups >> r.group) & 1) == 0 || termsLaunched(r.id)) continue;
         if (std::find(pendingTermIds.begin(), pendingTermIds.end(), r.id) != pendingTermIds.end()) continue;
         out.push_back(r.batch);
+        stampOwnership(out.back());
         launchedTermIds.push_back(r.id);
     }
 }
@@ -368,8 +400,33 @@ double HipContext::sumOverRanks(double v) {
     return sum;
 }
 
-void HipContext::allGatherPositions() {
-    HIP_CHECK(ommhip_comm_all_gather(domain.comm, posWire.ptr, sizeof(unsigned) * 4 * (size_t) slotsPerRank, stream));
+void HipContext::exchangePositions() {
+    if (haloMode) HIP_CHECK(ommhip_comm_halo_exchange(domain.comm, posWire.ptr, &haloPlan, stream));
+    else HIP_CHECK(ommhip_comm_all_gather(domain.comm, posWire.ptr, sizeof(unsigned) * 4 * (size_t) slotsPerRank, stream));
+}
+
+unsigned HipContext::ddWarnFraction() const {
+    // the re-sort is requested at this part of the margin; what is left of it must outlast the (at most 12) steps until every rank has
+    // seen the flag: 0.1 nm at the defaults, i.e. an atom at 8 nm/ps all the way
+    static const double warn = getenv("OPENMM_HIP_DD_WARN") != NULL ? atof(getenv("OPENMM_HIP_DD_WARN")) : 0.75;
+    return (unsigned) (warn * haloDrift / box[0] * 4294967296.0);
+}
+unsigned HipContext::ddMaxFraction() const { return (unsigned) (haloDrift / box[0] * 4294967296.0); }
+
+void HipContext::pollDriftFlags() {
+    if (!haloMode) return;
+    const long long n = ddEvaluations++;
+    if ((n & 7) == 0) {
+        HIP_CHECK(ommhip_memcpy_d2h(pinnedDdFlags, ddFlags.ptr, sizeof(int) * 4, stream));
+        HIP_CHECK(ommhip_event_record(ddFlagsEvent, stream));
+    }
+    else if ((n & 7) == 4) {
+        HIP_CHECK(ommhip_event_sync(ddFlagsEvent));          // recorded four evaluations ago: long complete
+        if (pinnedDdFlags[0] != 0)
+            throw OpenMMException("HIP platform: an atom drifted further along x between two re-sorts than the halo of the domain decomposition allows; "
+                                  "lower OPENMM_HIP_REORDER_INTERVAL or raise OPENMM_HIP_DD_DRIFT");
+        if (pinnedDdFlags[2] != 0) reorderRequested = true;  // every rank reads the same word at the same evaluation: they re-sort together
+    }
 }
 
 void HipContext::fillWireFromPos() {
@@ -553,7 +610,36 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
         }
         while (g + 1 < R) groupStart[++g] = numUnits;
     }
-    // ---- Hilbert order inside each group
+    // ---- halo mode?  A rank needs the positions of every atom that can come within the list cutoff of one of its own before the
+    //      next re-sort, and of every atom whose PME stencil can reach its planes: everything within T of its slab along x, T =
+    //      list cutoff + the drift allowed to the two atoms + the reach of a unit's atoms from its first one.  With more than two
+    //      ranks that must lie inside the two neighbouring slabs (each at least T wide); the decision is a pure function of the
+    //      gathered positions, so all ranks take it alike.  Otherwise positions stay replicated through the all-gather.
+    vector<double> bound(R + 1, L[0]);           // slab of group g = [bound[g], bound[g + 1])
+    bound[0] = 0.0;
+    for (int g = 1; g < R; g++) bound[g] = groupStart[g] < numUnits ? ref[byX[groupStart[g]]][0] : L[0];
+    double extent = 0.0;                          // largest distance of an atom from the first atom of its unit (a rigid unit may rotate: any of it can turn into x)
+    for (int u = 0; u < numUnits; u++)
+        for (int i = unitStart[u] + 1; i < unitStart[u + 1]; i++) {
+            double d2 = 0;
+            for (int k = 0; k < 3; k++) {
+                double d = positions[unitAtomList[i]][k] - positions[unitAtomList[unitStart[u]]][k];
+                d -= floor(d / L[k] + 0.5) * L[k];
+                d2 += d * d;
+            }
+            extent = max(extent, sqrt(d2));
+        }
+    extent *= 1.1;                                // constraints hold distances to the first atom; flexible units get a little room
+    const double T = haloReach + 2.0 * haloDrift + extent;
+    static const bool noHalo = getenv("OPENMM_HIP_DD_REPLICATE") != NULL;          // A/B knob: always replicate positions (round-2 behaviour)
+    bool halo = R > 1 && haloReach > 0.0 && !noHalo && R <= OMMHIP_MAX_RANKS;
+    for (int g = 0; g < R && halo; g++) {
+        if (R > 2 && bound[g + 1] - bound[g] < T) halo = false;
+        // charge spreading: the rank's PME planes +- pmeReachX must lie inside what it sees
+        if (pmeReachX > 0.0 && (g * L[0] / R - pmeReachX - haloDrift - extent < bound[g] - T || (g + 1) * L[0] / R + pmeReachX + haloDrift + extent > bound[g + 1] + T)) halo = false;
+    }
+    haloMode = halo;
+    // ---- Hilbert order inside each group (halo mode: inside each of the group's four sections)
     static const double binWidth = getenv("OPENMM_HIP_SORT_BIN") != NULL ? atof(getenv("OPENMM_HIP_SORT_BIN")) : 0.3;
     int maxCells = 1, ncell[3];
     for (int k = 0; k < 3; k++) { ncell[k] = max(1, min(1023, (int) floor(L[k] / binWidth) + 1)); maxCells = max(maxCells, ncell[k]); }
@@ -562,23 +648,60 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
     newAtomOfSlot.assign(paddedAtoms, -1);
     ownedUnits.clear();
     vector<pair<unsigned long long, int> > keyed;
+    // sections of every rank's range, in slots relative to its start: down = [0, sectionEnd[1]), up = [sectionEnd[0], sectionEnd[2])
+    vector<int> sectionEnd(4 * (size_t) R, 0);
     for (int g = 0; g < R; g++) {
         keyed.clear();
         for (int i = groupStart[g]; i < groupStart[g + 1]; i++) {
             const int u = byX[i];
             unsigned c[3];
             for (int k = 0; k < 3; k++) c[k] = (unsigned) max(0, min(ncell[k] - 1, (int) floor(ref[u][k] / binWidth)));
-            keyed.push_back(make_pair(hilbertIndex(c[0], c[1], c[2], bits), u));
+            // section: 0 = the rank below needs it, 1 = both neighbours, 2 = the rank above, 3 = nobody (most significant key bits)
+            unsigned long long section = 0;
+            if (halo) {
+                const bool down = ref[u][0] - bound[g] < T, up = bound[g + 1] - ref[u][0] < T;
+                section = down ? (up ? 1 : 0) : (up ? 2 : 3);
+            }
+            keyed.push_back(make_pair((section << (3 * bits)) | hilbertIndex(c[0], c[1], c[2], bits), u));
         }
-        radixSortPairs(keyed, 3 * bits);
-        int slot = g * slotsPerRank;
+        radixSortPairs(keyed, 3 * bits + 2);
+        int slot = g * slotsPerRank, current = 0;
         for (size_t i = 0; i < keyed.size(); i++) {
             const int u = keyed[i].second;
+            const int section = (int) (keyed[i].first >> (3 * bits));
+            while (current < section) {          // a section ends: the next one starts on a block boundary
+                slot = (slot + OMMHIP_TILE - 1) / OMMHIP_TILE * OMMHIP_TILE;
+                sectionEnd[4 * g + current++] = slot - g * slotsPerRank;
+            }
             if (slot + (unitStart[u + 1] - unitStart[u]) > g * slotsPerRank + trailerSlot)      // the two trailer records stay free
                 throw OpenMMException("HIP platform: internal error: a rank's slot range overflowed in the domain decomposition");
             for (int j = unitStart[u]; j < unitStart[u + 1]; j++) newAtomOfSlot[slot++] = unitAtomList[j];
             if (g == domain.rank) ownedUnits.push_back(u);
         }
+        while (current < 4) {
+            slot = (slot + OMMHIP_TILE - 1) / OMMHIP_TILE * OMMHIP_TILE;
+            sectionEnd[4 * g + current++] = min(slot - g * slotsPerRank, slotsPerRank);
+        }
+    }
+    numActiveRanges = 0;
+    memset(&haloPlan, 0, sizeof(haloPlan));
+    if (halo) {
+        const size_t rec = sizeof(unsigned) * 4;
+        haloPlan.rank_stride = rec * (size_t) slotsPerRank;
+        for (int g = 0; g < R; g++) {
+            haloPlan.down_offset[g] = 0; haloPlan.down_bytes[g] = rec * (size_t) sectionEnd[4 * g + 1];
+            haloPlan.up_offset[g] = rec * (size_t) sectionEnd[4 * g]; haloPlan.up_bytes[g] = rec * (size_t) (sectionEnd[4 * g + 2] - sectionEnd[4 * g]);
+        }
+        haloPlan.trailer_offset = rec * (size_t) trailerSlot; haloPlan.trailer_bytes = 2 * rec;
+        // what this rank holds current wire records for: its own range, the down section of the rank above, the up section of the rank below
+        const int me = domain.rank, above = (me + 1) % R, below = (me + R - 1) % R;
+        int ranges[3][2] = {{ownSlot0, ownSlot1}, {above * slotsPerRank, above * slotsPerRank + sectionEnd[4 * above + 1]},
+                            {below * slotsPerRank + sectionEnd[4 * below], below * slotsPerRank + sectionEnd[4 * below + 2]}};
+        if (above == below) {      // two ranks: one neighbour, its two sections may overlap or touch
+            if (ranges[1][1] >= ranges[2][0]) { ranges[1][1] = ranges[2][1]; ranges[2][0] = ranges[2][1]; }          // merged into one range
+        }
+        for (int r = 0; r < 3; r++)
+            if (ranges[r][1] > ranges[r][0]) { activeRange[2 * numActiveRanges] = ranges[r][0]; activeRange[2 * numActiveRanges + 1] = ranges[r][1]; numActiveRanges++; }
     }
     partitionBlocks(newAtomOfSlot);          // a rank's range is a whole number of blocks: no atom changes owner
 }
@@ -592,6 +715,7 @@ bool HipContext::reorderIfNeeded() {
                     ~Report() { if (on) fprintf(stderr, "HIP platform: re-sort of %d atoms took %.2f ms\n", n, 1e-3 * std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count()); } } report = {timing, tStart, numAtoms};
     reorderRequested = false;
     stepsSinceReorder = 0;
+    reorderCount++;
     if (!usePeriodic && sortCutoff <= 0.0 && !decomposed())
         return false;                       // identity order and no wrapping: nothing to do
     vector<Vec3> positions;
@@ -616,7 +740,14 @@ bool HipContext::reorderIfNeeded() {
     HIP_CHECK(ommhip_memcpy_h2d(wrap.ptr, wrapHost.data(), sizeof(int) * wrapHost.size(), stream));
     HIP_CHECK(ommhip_memcpy_h2d(atomOfSlot.ptr, hostAtomOfSlot.data(), sizeof(int) * paddedAtoms, stream));
     HIP_CHECK(ommhip_memcpy_h2d(slotOfAtom.ptr, hostSlotOfAtom.data(), sizeof(int) * numAtoms, stream));
-    if (decomposed()) fillWireFromPos();
+    if (decomposed()) {
+        fillWireFromPos();
+        HIP_CHECK(ommhip_memcpy_d2d(wireRef.ptr, posWire.ptr, posWire.bytes, stream));       // the drift guard measures from here
+        HIP_CHECK(ommhip_memset(ddFlags.ptr, 0, ddFlags.bytes, stream));
+        HIP_CHECK(ommhip_clear_trailer_flags(posWire.ptr, domain.ranks, slotsPerRank, trailerSlot, stream));
+        memset(pinnedDdFlags, 0, sizeof(int) * 4);
+        ddEvaluations = 0;
+    }
     sync();
     // wrap offsets may have changed even when the order did not: listeners rebuild their slot data either way
     for (size_t i = 0; i < listeners.size(); i++) listeners[i]->atomsReordered();

@@ -104,6 +104,10 @@ public:
     void markPmeDone();
     void joinPme();
     void addTerms(const ommhip_term_batch& batch, bool includeEnergy, int id = -1);
+    /** Decomposed runs: which rank's term energies count.  Replicated positions: every rank evaluates every term, rank 0 counts;
+     *  halo mode: the term kernel itself counts a term on the rank that owns its first atom (stampOwnership). */
+    bool countsTermEnergy() const;
+    void stampOwnership(ommhip_term_batch& batch) const;
     /** Term lists that persist across evaluations (bonds, angles, torsions) are registered once with their force group, so
      *  that whoever opens an evaluation can launch all lists of the evaluated groups together with its own work
      *  (ommhip_force_front) before the owning Force objects have executed.  Their execute() then finds them launched. */
@@ -144,8 +148,33 @@ public:
     DeviceBuffer posWire, posSlot, velSlot;      // posSlot / velSlot: double4 staging of exact positions / velocities for downloads and re-sorts
     /** Communicator of the reciprocal-space stream (a duplicate of domain.comm; NULL = share domain.comm, single stream). */
     ommhip_comm* pmeComm = NULL;
-    /** Enqueue the all-gather of posWire on the main stream (after the integration kernel wrote this rank's part). */
-    void allGatherPositions();
+    /** Enqueue the per-step position exchange on the main stream (after the integration kernel wrote this rank's part): in halo
+     *  mode the grouped send/recv of the boundary sections with the two neighbouring slabs (+ the momentum trailers of all ranks),
+     *  else the all-gather of the whole buffer. */
+    void exchangePositions();
+    // ---- halo mode: decided at every re-sort, identically on all ranks.  Inside a rank's slot range the units are
+    //      laid out by what the neighbours need: [needed below only | needed on both sides | needed above only | needed by nobody],
+    //      each section a whole number of 32-slot blocks and Hilbert-sorted on its own, so "what rank r - 1 needs" and "what rank
+    //      r + 1 needs" are two contiguous (overlapping) runs of slots that travel without packing.
+    bool haloMode = false;
+    ommhip_halo_plan haloPlan;
+    int numActiveRanges = 0;              // slot ranges this rank has current wire records for (own + received sections); 0 = all
+    int activeRange[8];
+    double haloReach = 0.0;               // list cutoff (cutoff + padding) of the nonbonded force, nm; 0 = no halo mode
+    double pmeReachX = 0.0;               // how far (nm) beyond its PME planes a rank must see atoms for charge spreading
+    double haloDrift;                     // x drift since the re-sort an atom is allowed before the run must have re-sorted (nm)
+    DeviceBuffer guardAtom;               // unsigned char[N]: 1 for the first atom of every integration unit (the atoms the drift guard watches)
+    DeviceBuffer wireRef, ddFlags;        // wire records of the last re-sort; int[4] flags (ommhip_neighbor_list::dd_flags)
+    int* pinnedDdFlags = NULL;
+    void* ddFlagsEvent = NULL;
+    long long ddEvaluations = 0;
+    long long reorderCount = 0;            // re-sorts so far (diagnostics)
+    /** Called once per force evaluation on decomposed runs: reads the drift flags back every 16 evaluations (asynchronously),
+     *  looks at them 8 evaluations later -- the same evaluation on every rank, and every rank finds the same words -- and
+     *  requests a re-sort, or ends the run when the hard limit was exceeded. */
+    void pollDriftFlags();
+    unsigned ddWarnFraction() const;      // thresholds in units of 2^-32 box lengths
+    unsigned ddMaxFraction() const;
     /** Make pos[] and vel[] (atom order) complete and current on this rank: before a re-sort and before downloads. */
     void gatherState();
     /** Wire records of every slot from pos[]: after an upload of all positions or a re-sort (every rank holds them all; no communication). */

@@ -252,17 +252,19 @@ void HipConstraints::fusedStep(int integrator, const ommhip_integrator_state& st
     u.remove_cm = hip.cmRemovalPending && hip.momentumValid ? 1 : 0;
     u.inv_total_mass = totalMass > 0 ? 1.0 / totalMass : 0.0;
     u.cm_scratch = cmScratch.as<double>();
-    u.pos_wire = NULL; u.ranks = 1; u.rank = 0; u.slots_per_rank = 0; u.trailer_slot = 0;
+    u.pos_wire = NULL; u.ranks = 1; u.rank = 0; u.slots_per_rank = 0; u.trailer_slot = 0; u.dd_flags = NULL;
     static const bool noSmall = getenv("OPENMM_HIP_NO_SMALL_UNITS") != NULL;         // A/B knob
     u.small_units = smallUnits && !noSmall ? 1 : 0;
     u.box_len[0] = hip.box[0]; u.box_len[1] = hip.box[2]; u.box_len[2] = hip.box[5];
     if (hip.decomposed()) {
         u.pos_wire = hip.posWire.ptr; u.ranks = hip.domain.ranks; u.rank = hip.domain.rank;
         u.slots_per_rank = hip.slotsPerRank; u.trailer_slot = hip.trailerSlot;
+        u.dd_flags = hip.haloMode ? hip.ddFlags.as<int>() : NULL;
     }
     HIP_CHECK(ommhip_integrate_fused(integrator, &state, &u, hip.stream));
-    // every rank now needs everybody's new positions (and momentum trailer): one in-place all-gather on the same stream
-    if (hip.decomposed()) hip.allGatherPositions();
+    // the new positions travel on the same stream: the boundary sections to the two neighbouring slabs (halo mode; the momentum
+    // trailers go to everybody in the same group), or everything to everybody (in-place all-gather)
+    if (hip.decomposed()) hip.exchangePositions();
     hip.cmRemovalPending = false;
     hip.momentumValid = true;
 }
@@ -487,6 +489,32 @@ extern "C" __attribute__((visibility("default"))) int ommhip_plugin_nl_stats(lon
     return 0;
 }
 
+/* Diagnostics for tests and bench.py: how the most recently created decomposed Context exchanges positions.
+ * out[0] ranks, [1] 1 = halo mode (sections to the two neighbouring slabs) / 0 = replicated (all-gather), [2] slots per rank,
+ * [3] slots this rank converts per step (own + received sections; all slots when replicated), [4] bytes it sends per step,
+ * [5] bytes it receives per step, [6] re-sorts so far */
+extern "C" __attribute__((visibility("default"))) int ommhip_plugin_dd_info(long long* out) {
+    if (liveNonbondedKernels.empty()) return 1;
+    try { liveNonbondedKernels.back()->getDomainInfo(out); } catch (...) { return 2; }
+    return 0;
+}
+
+void HipCalcNonbondedForceKernel::getDomainInfo(long long* out) {
+    const int R = hip.domain.ranks, me = hip.domain.rank;
+    out[0] = R; out[1] = hip.haloMode ? 1 : 0; out[2] = hip.slotsPerRank;
+    const long long rec = 16;
+    if (hip.haloMode) {
+        long long active = 0;
+        for (int r = 0; r < hip.numActiveRanges; r++) active += hip.activeRange[2 * r + 1] - hip.activeRange[2 * r];
+        const int above = (me + 1) % R, below = (me + R - 1) % R;
+        out[3] = active;
+        out[4] = (long long) hip.haloPlan.down_bytes[me] + (long long) hip.haloPlan.up_bytes[me] + (long long) (R - 1) * hip.haloPlan.trailer_bytes;
+        out[5] = (long long) hip.haloPlan.down_bytes[above] + (long long) hip.haloPlan.up_bytes[below] + (long long) (R - 1) * hip.haloPlan.trailer_bytes;
+    }
+    else { out[3] = hip.paddedAtoms; out[4] = rec * hip.slotsPerRank * (R - 1); out[5] = out[4]; }
+    out[6] = hip.reorderCount;
+}
+
 /* Diagnostics: per i-block cost of the last list build (clock ticks, candidate blocks), as left by nl_find_interactions. */
 extern "C" __attribute__((visibility("default"))) int ommhip_plugin_nl_block_costs(float* ticks, float* candidates, int maxBlocks) {
     if (liveNonbondedKernels.empty()) return -1;
@@ -587,6 +615,8 @@ void HipCalcNonbondedForceKernel::setupPmeDecomposed() {
     pme.eterm = eterm.ptr; pme.grid_real = gridReal.ptr; pme.grid_complex = gridComplex.ptr; pme.grid_complex2 = gridComplex2.ptr;
     pme.twiddle_x = twiddleX.ptr; pme.twiddle_y = twiddleY.ptr; pme.twiddle_z = twiddleZ.ptr;
     pme.dd_ranks = R; pme.dd_rank = hip.domain.rank; pme.dd_halo = ddHalo; pme.comm = hip.domain.comm; pme.dd_error = ddError.as<int>();
+    // a rank spreads every atom whose order-5 stencil touches its planes: atoms up to five cells below and one above them
+    hip.pmeReachX = max(hip.pmeReachX, 6.0 * hip.box[0] / nx);
     etermDirty = true;
 }
 
@@ -614,6 +644,15 @@ double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool
     // of it -- 64 B of scattered read-modify-write per foreign atom and step saved.
     nl.pos_wire = hip.posWire.ptr;
     nl.pos_scatter = (hip.foreignPositionsNeeded || exclusionsSpanUnits || num14 > 0) ? hip.pos.ptr : NULL;
+    // halo mode: only this rank's slots and the sections its two neighbours send are current (HipContext::computeOrderDecomposed)
+    nl.num_active_ranges = hip.haloMode ? hip.numActiveRanges : 0;
+    for (int i = 0; i < 8; i++) nl.active_range[i] = hip.activeRange[i];
+    nl.wire_ref = hip.haloMode ? hip.wireRef.ptr : NULL;
+    nl.dd_guard_atom = hip.guardAtom.as<unsigned char>();
+    nl.dd_warn = hip.ddWarnFraction(); nl.dd_max = hip.ddMaxFraction();
+    nl.dd_flags = hip.haloMode ? hip.ddFlags.as<int>() : NULL;
+    nl.dd_ranks = hip.domain.ranks; nl.dd_slots_per_rank = hip.slotsPerRank; nl.dd_trailer_slot = hip.trailerSlot;
+    hip.pollDriftFlags();
     foldExclusions = numExclusionPairs > 0;
     checkDecomposedFlags();
     if (nl.max_chunks == 0) allocateNeighborList((int) (estimateChunks() * 1.4 / hip.domain.ranks) + 256);
@@ -677,7 +716,7 @@ double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool
     // 1-4 exceptions: evaluated by every rank, energy from rank 0 (as the bonded terms, HipTermForce::execute)
     ommhip_term_batch t14 = {OMMHIP_TERM_EXCEPTION14, {num14, exceptionAtomsD.as<int>(), exceptionParamsD.as<double>()},
                              exceptionsArePeriodic ? 1 : 0, chargeD.as<double>(), ewaldAlpha};
-    hip.addTerms(t14, includeEnergy && hip.domain.rank == 0);
+    hip.addTerms(t14, includeEnergy && hip.countsTermEnergy());
     double energy = 0;
     // host-side constants: returned by every rank (the device energies are summed over the ranks in finishComputation)
     if (includeEnergy)
@@ -874,6 +913,8 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     if (getenv("OPENMM_HIP_NL_PADDING") != NULL) paddingFraction = atof(getenv("OPENMM_HIP_NL_PADDING"));   // tuning knob, fraction of the cutoff
     padding = nonbondedMethod == NoCutoff ? 0.0 : paddingFraction * nonbondedCutoff;
     if (getenv("OPENMM_HIP_DIRECT_GRID") != NULL) directGridOverride = atoi(getenv("OPENMM_HIP_DIRECT_GRID"));
+    // decomposed runs: how far a rank must see beyond its slab (halo mode, HipContext::computeOrderDecomposed)
+    if (nonbondedMethod != NoCutoff) hip.haloReach = max(hip.haloReach, nonbondedCutoff + padding);
 
     // ---- device arrays
     const int P = hip.paddedAtoms;
@@ -1231,6 +1272,14 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
         nl.pbc = (hip.box[1] != 0.0 || hip.box[3] != 0.0 || hip.box[4] != 0.0) ? 2 : 1;
     }
     if (slotParamsDirty) {
+        if (hip.decomposed()) {
+            // every block starts without a bounding box (a hugely negative half extent: no block test can pass against it);
+            // ommhip_nl_prepare gives the blocks it converts their boxes -- all of them, or in halo mode those this rank sees
+            vector<float> none(4 * (size_t) (hip.paddedAtoms / OMMHIP_TILE), 0.f);
+            for (size_t i = 0; i < none.size(); i += 4) none[i] = none[i + 1] = none[i + 2] = -1e30f;
+            HIP_CHECK(ommhip_memcpy_h2d(blockHalf.ptr, none.data(), sizeof(float) * none.size(), hip.stream));
+            hip.sync();
+        }
         updateExclusionBlockRanges();
         HIP_CHECK(ommhip_set_slot_params(chargeD.as<double>(), sigmaD.as<double>(), epsilonD.as<double>(), hip.atomOfSlot.as<int>(), hip.paddedAtoms, posq.ptr, sigEps.ptr, hip.stream));
         slotParamsDirty = false;
@@ -1493,7 +1542,7 @@ void HipTermForce::execute(bool includeEnergy) {
     if (registrationId >= 0 && hip.termsLaunched(registrationId)) return;         // went out with the front launch of this evaluation
     // decomposed runs: every rank evaluates all bonded terms (they are few; forces on atoms it does not own are never read),
     // their energy is taken from rank 0 only
-    hip.addTerms(batch(), includeEnergy && (!hip.decomposed() || hip.domain.rank == 0), registrationId);
+    hip.addTerms(batch(), includeEnergy && hip.countsTermEnergy(), registrationId);
 }
 
 void HipCalcHarmonicBondForceKernel::initialize(const System& system, const HarmonicBondForce& force) {

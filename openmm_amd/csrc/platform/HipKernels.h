@@ -119,6 +119,7 @@ public:
     void positionsSet();
     /** out[0..6) = atoms, padded atoms, chunks in use, rows in use, chunk capacity, rebuilds so far (blocking). */
     void getNeighborListStats(long long* out);
+    void getDomainInfo(long long* out);
     int getBlockDiag(float* out, int columns, int maxBlocks);
     int getBlockHalves(float* out, int maxBlocks);
     int getBlockCosts(float* ticks, float* candidates, int maxBlocks);

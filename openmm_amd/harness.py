@@ -67,6 +67,17 @@ def _handle(p):
     return C.c_void_p(p)
 
 
+def domain_info():
+    """Diagnostics of the most recently created decomposed Context (ommhip_plugin_dd_info): [ranks, halo mode, slots per rank,
+    slots converted per step, bytes sent per step, bytes received per step, re-sorts so far]."""
+    path = next(iter(_loaded_plugins))
+    plugin = C.CDLL(path)
+    out = (C.c_longlong * 8)()
+    if plugin.ommhip_plugin_dd_info(out) != 0:
+        raise OpenMMError("no decomposed Context")
+    return [int(v) for v in out[:7]]
+
+
 def load_hip_platform(emulated=False):
     """Register the HIP platform through OpenMM's plugin loader.  Raises if the plugin is missing."""
     path = os.path.join(EMU_DIR if emulated else LIB_DIR, "libOpenMMHIP.so")

@@ -111,13 +111,16 @@ def run(props, w, steps):
     integ.step(steps)
     st1 = ctx.getState(getPositions=True, getVelocities=True, getEnergy=True, getForces=True)
     info = (ctx.getPlatformProperty("Ranks"), ctx.getPlatformProperty("CommId"))
+    global DD_INFO
+    DD_INFO = H.domain_info() if "Ranks" in props else None
     ctx.close()
     return st0, st1, info
 
 
 os.environ["OPENMM_HIP_REORDER_INTERVAL"] = "3"      # a re-sort (units change owner) inside the short run
 EXTRA_CASES = %s
-for label, w, grid in (("water", T.water_box(8, seed=5), 24), ("solvated chain", T.small_solvated_chain(seed=3), 24)) + EXTRA_CASES:
+STEPS = %d
+for label, w, grid in (("water, halo", T.water_box(8, seed=5), 24), ("solvated chain, halo", T.small_solvated_chain(seed=3), 24)) + EXTRA_CASES:
     # a 32^3 grid marks the case that runs with the (opt-in) tile spreading: 16 own planes per rank = one tile along x, clipped to the slab
     tiles = grid is not None and grid >= 32
     if tiles: os.environ["OPENMM_HIP_TILE_SPREAD_MIN_ATOMS"] = "1"
@@ -130,17 +133,42 @@ for label, w, grid in (("water", T.water_box(8, seed=5), 24), ("solvated chain",
     props = MR.domain_properties(dist, transport="gloo", device_index=device, emulated=%r)
     dd0, dd1, info = run(props, w, %d)
     assert info == (str(world), "callback"), info
+    if "halo" in label:
+        # ranks, halo mode, slots per rank, slots converted per step, bytes sent / received per step, re-sorts
+        assert DD_INFO[1] == 1, ("expected the halo exchange", DD_INFO)
+        if "sections" in label:
+            assert DD_INFO[3] < world * DD_INFO[2] and DD_INFO[5] < 16 * DD_INFO[2] * (world - 1), ("the halo should be smaller than the box", DD_INFO)
+        if "drift" in label:
+            print("re-sorts", DD_INFO[6], flush=True)
+            assert DD_INFO[6] >= 2, ("a drift-triggered re-sort was expected", DD_INFO)
+    if "replicated" in label:
+        assert DD_INFO[1] == 0, DD_INFO
     rms = np.sqrt((one0.forces ** 2).sum(1).mean())
     err0 = np.abs(dd0.forces - one0.forces).max() / rms
     assert err0 < 3e-5, ("initial forces", err0)       # float32 summation-order noise; TestCudaNonbondedForce.cpp:37-96 allows 1e-5 of each force in its multi-device mode
-    assert abs(dd0.potentialEnergy - one0.potentialEnergy) < 1e-6 * abs(one0.potentialEnergy) + 1e-3, (dd0.potentialEnergy, one0.potentialEnergy)
+    # (1e-6 of the magnitude, with the floor of tests/test_gpu_platform.py for lattice starts whose terms nearly cancel)
+    assert abs(dd0.potentialEnergy - one0.potentialEnergy) < 1e-6 * max(abs(one0.potentialEnergy), 5.0 * w.num_atoms) + 1e-3, (dd0.potentialEnergy, one0.potentialEnergy)
     dpos = np.abs(dd1.positions - one1.positions).max()
     dvel = np.abs(dd1.velocities - one1.velocities).max()
-    # float32 force noise (1e-5 of the RMS force) integrated over the run; the tile spreading rounds each contribution to max|q| 2^-24
-    assert dpos < 3e-7 and dvel < (1.5e-4 if tiles else 5e-5), ("trajectory", dpos, dvel)
-    assert abs(dd1.kineticEnergy - one1.kineticEnergy) < 1e-6 * one1.kineticEnergy
-    err1 = np.abs(dd1.forces - one1.forces).max() / rms
-    assert err1 < 1e-4, ("final forces", err1)
+    if STEPS <= 20:
+        # float32 force noise (1e-5 of the RMS force) integrated over the run; the tile spreading rounds each contribution to max|q| 2^-24
+        assert dpos < 3e-7 and dvel < (1.5e-4 if tiles else 5e-5), ("trajectory", dpos, dvel)
+        assert abs(dd1.kineticEnergy - one1.kineticEnergy) < 1e-6 * one1.kineticEnergy
+        err1 = np.abs(dd1.forces - one1.forces).max() / rms
+        assert err1 < 1e-4, ("final forces", err1)
+    else:
+        # a long run: the two trajectories drift apart as any two float32 runs of a chaotic system do (the replicated-position run of
+        # round 2 shows the same 2e-5 nm after 80 steps); what must hold is that the decomposed forces are right WHERE THE DECOMPOSED RUN
+        # IS -- a fresh single-rank Context evaluates them at its final positions
+        assert dpos < 1e-3, ("trajectory", dpos, dvel)
+        system, nb = w.build()
+        ctx = H.Context(system, H.Integrator(H.VERLET, 0.001), "HIP", dict(base))
+        ctx.setPositions(dd1.positions)
+        ref1 = ctx.getState(getForces=True, getEnergy=True)
+        ctx.close()
+        err1 = np.abs(dd1.forces - ref1.forces).max() / rms
+        assert err1 < 6e-5, ("final forces against a single-rank evaluation of the same positions", err1)
+        assert abs(dd1.potentialEnergy - ref1.potentialEnergy) < 1e-6 * max(abs(ref1.potentialEnergy), 5.0 * w.num_atoms) + 1e-3
     # every rank reports the same State
     check = torch.tensor([dd1.potentialEnergy, dd1.kineticEnergy, float(dd1.positions.sum())], dtype=torch.float64)
     both = [torch.zeros_like(check) for _ in range(world)]
@@ -154,14 +182,17 @@ dist.destroy_process_group()
 '''
 
 
-def _run_dd_child(tmp_path, emulated, device, steps, port, nproc=2, cases=None, extra_cases="()"):
+def _run_dd_child(tmp_path, emulated, device, steps, port, nproc=2, cases=None, extra_cases="()", env=None):
     """extra_cases: Python source of a tuple of further (label, workload, grid) cases; a grid >= 32 runs with tile spreading."""
     script = tmp_path / "dd_child.py"
-    text = DD_CHILD % (ROOT, emulated, device, extra_cases, steps, emulated, steps)
+    text = DD_CHILD % (ROOT, emulated, device, extra_cases, steps, steps, emulated, steps)
     if cases is not None:
-        text = text.replace('(("water", T.water_box(8, seed=5), 24), ("solvated chain", T.small_solvated_chain(seed=3), 24))', cases)
+        text = text.replace('(("water, halo", T.water_box(8, seed=5), 24), ("solvated chain, halo", T.small_solvated_chain(seed=3), 24))', cases)
     script.write_text(text)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if env and "OPENMM_HIP_REORDER_INTERVAL" in env:
+        text = text.replace('os.environ["OPENMM_HIP_REORDER_INTERVAL"] = "3"', 'os.environ["OPENMM_HIP_REORDER_INTERVAL"] = "%s"' % env["OPENMM_HIP_REORDER_INTERVAL"])
+        script.write_text(text)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **(env or {}))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          capture_output=True, text=True, timeout=1500, env=env)
@@ -181,6 +212,33 @@ def test_two_rank_domain_decomposition_whole_step_on_emulator(tmp_path):
     _run_dd_child(tmp_path, True, None, 4, 29547, extra_cases='(("water, tile spreading", T.water_box(8, seed=5), 32),)')
 
 
+def test_halo_exchange_with_distinct_sections_on_emulator(tmp_path):
+    """Halo mode proper: a 3.7 nm box with a 0.5 nm cutoff, where a slab is wider than twice the halo, so a rank's
+    range really has four sections (needed below / both / above / by nobody), a rank converts fewer slots than the box holds and
+    receives less than an all-gather would bring -- two ranks (both neighbours are the same peer) and four (ring neighbours that
+    are different ranks, second neighbours never seen).  Same bar as the replicated runs: trajectory of the single-rank run."""
+    import pytest
+    from conftest import EMU_BUILD
+    if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
+        pytest.skip("emulated plugin not built (run __graft_entry__.build())")
+    env = {"OPENMM_HIP_DD_DRIFT": "0.05"}
+    _run_dd_child(tmp_path, True, None, 4, 29561, env=env, cases='(("water, halo sections", T.water_box(12, seed=5, cutoff=0.5), None),)')
+    _run_dd_child(tmp_path, True, None, 4, 29565, nproc=4, env=env, cases='(("water, halo sections, 4 ranks", T.water_box(12, seed=5, cutoff=0.5), None),)')
+
+
+def test_halo_drift_guard_triggers_a_common_resort_on_emulator(tmp_path):
+    """An atom that drifts half the allowed margin raises a flag that travels in its rank's trailer; every rank finds it at the same
+    evaluation and they re-sort together (no agreement collective).  With a margin of 0.08 nm the fastest oxygens cross the warning
+    level (here 0.4 of it) within a few dozen steps: the run must re-sort by itself (OPENMM_HIP_REORDER_INTERVAL = 1000 never asks
+    for one) and still follow the single-rank trajectory."""
+    import pytest
+    from conftest import EMU_BUILD
+    if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
+        pytest.skip("emulated plugin not built (run __graft_entry__.build())")
+    _run_dd_child(tmp_path, True, None, 80, 29569, env={"OPENMM_HIP_DD_DRIFT": "0.08", "OPENMM_HIP_DD_WARN": "0.4", "OPENMM_HIP_REORDER_INTERVAL": "1000"},
+                  cases='(("water, halo drift", T.water_box(8, seed=5), 24),)')
+
+
 def test_four_rank_domain_decomposition_on_emulator(tmp_path):
     """Four slabs: every rank has two distinct ring neighbours for the potential planes, the all-to-alls move 4 x 4 chunks, and
     in a 2.5 nm box the 0.6 nm slabs are thinner than the cutoff -- each rank's partners span all the others."""
@@ -188,7 +246,7 @@ def test_four_rank_domain_decomposition_on_emulator(tmp_path):
     from conftest import EMU_BUILD
     if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
         pytest.skip("emulated plugin not built (run __graft_entry__.build())")
-    _run_dd_child(tmp_path, True, None, 3, 29557, nproc=4, cases='(("water, 4 ranks", T.water_box(8, seed=5), 24),)')
+    _run_dd_child(tmp_path, True, None, 3, 29557, nproc=4, cases='(("water, 4 ranks, replicated", T.water_box(8, seed=5), 24),)')
 
 
 LAUNCHER = r"""

@@ -274,7 +274,15 @@ def main():
                                                        "the latter counted from a device-wide synchronisation at their start -- i.e. its step without communication; "
                                                        "`value` and ms_per_step are NOT a measurement in this mode"}
     if decomposed:
-        out["config"]["parallelism"] = "dd%d (x slabs; all-gather of positions + 2 all-to-alls + halo planes per step)" % world
+        try:
+            di = H.domain_info()
+            out["config"]["parallelism"] = "dd%d (x slabs; %s + 2 all-to-alls + potential planes per step)" % (
+                world, "halo exchange of positions with the two neighbouring slabs" if di[1] else "all-gather of positions")
+            out["domain"] = {"exchange": "halo" if di[1] else "all-gather", "slots_per_rank": di[2], "slots_converted_per_step_rank0": di[3],
+                             "position_bytes_sent_per_step_rank0": di[4], "position_bytes_received_per_step_rank0": di[5], "re_sorts": di[6]}
+        except Exception as e:
+            out["config"]["parallelism"] = "dd%d (x slabs)" % world
+            out["domain"] = {"error": str(e)}
 
     if rank == 0:
         # ---- roofline of the dominant kernel (direct-space pair kernel)

@@ -550,11 +550,13 @@ __global__ __launch_bounds__(128) void k_step_units(IntArgs a, UnitArgs u) {
             unsigned long long seen = atomicExch((unsigned long long*) &out[0], (unsigned long long) __double_as_longlong(sx));
             seen |= atomicExch((unsigned long long*) &out[1], (unsigned long long) __double_as_longlong(sy));
             seen |= atomicExch((unsigned long long*) &out[2], (unsigned long long) __double_as_longlong(sz));
-            // the returned values are consumed before the counter is touched: the three exchanges have completed by then
+            // The returned values are consumed before the counter is touched: the three exchanges have completed by then.  Hardware
+            // assumption: a returning device-scope atomic has been performed at L2 when its value comes back.  The "memory" clobber is a
+            // compiler-only barrier (no buffer_wbl2): it keeps the counter's atomicAdd below from being moved above the exchanges.
 #ifdef OMMHIP_EMU
             (void) seen;
 #else
-            asm volatile("" :: "v"(seen));
+            asm volatile("" :: "v"(seen) : "memory");
 #endif
             last = atomicAdd(counter, 1) == (int) gridDim.x - 1;
         }

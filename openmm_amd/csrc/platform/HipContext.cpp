@@ -130,10 +130,14 @@ HipContext::HipContext(const System& system, int deviceIndex, bool hostMode, con
         memset(pinnedDdFlags, 0, sizeof(int) * 4);
         HIP_CHECK(ommhip_event_create_untimed(&ddFlagsEvent));
     }
-    // x drift of a unit's first atom between two re-sorts that the halo is cut for (nm).  A water molecule diffuses 0.07-0.1 nm (RMS, one
-    // axis) in the 500 steps = 1 ps between two scheduled re-sorts, the fastest of a million a few times that; at 0.75 of the margin
-    // the ranks re-sort early, together (pollDriftFlags).
-    haloDrift = getenv("OPENMM_HIP_DD_DRIFT") != NULL ? atof(getenv("OPENMM_HIP_DD_DRIFT")) : 0.4;
+    // x drift of a unit's first atom between two re-sorts that the halo is cut for (nm): the upper limit; computeOrderDecomposed takes
+    // what the slab widths allow.  At 0.75 of the margin the ranks re-sort early, together (pollDriftFlags).
+    // steps the host keeps enqueueing between the snapshot of a due re-sort and its application: they must outlast the host's work
+    // (35-55 ms at a million atoms = 15-25 steps there, ~100 steps of a rank of an 8-GPU run; 2 ms = 20 steps at DHFR size)
+    reorderLag = getenv("OPENMM_HIP_REORDER_LAG") != NULL ? atoi(getenv("OPENMM_HIP_REORDER_LAG")) : (decomposed() ? 128 : 48);
+    haloDriftMax = getenv("OPENMM_HIP_DD_DRIFT") != NULL ? atof(getenv("OPENMM_HIP_DD_DRIFT")) : 0.75;
+    haloDriftMin = min(haloDriftMax, 0.25);          // slabs that leave less than this: positions stay replicated
+    haloDrift = haloDriftMax;
     if (decomposed()) {
         vector<unsigned char> first(max(numAtoms, 1), 0);
         for (size_t u = 0; u + 1 < unitStart.size(); u++) first[unitAtomList[unitStart[u]]] = 1;
@@ -171,6 +175,8 @@ HipContext::~HipContext() {
     if (domain.comm != NULL) ommhip_comm_destroy(domain.comm);
     if (pinnedResult != NULL) ommhip_host_free(pinnedResult);
     if (pinnedDdFlags != NULL) ommhip_host_free(pinnedDdFlags);
+    if (pinnedSnapshot != NULL) ommhip_host_free(pinnedSnapshot);
+    if (snapshotEvent != NULL) ommhip_event_destroy(snapshotEvent);
     if (ddFlagsEvent != NULL) ommhip_event_destroy(ddFlagsEvent);
     if (pmeForkEvent != NULL) ommhip_event_destroy(pmeForkEvent);
     if (pmeDoneEvent != NULL) ommhip_event_destroy(pmeDoneEvent);
@@ -192,6 +198,7 @@ void HipContext::removeListener(HipContextListener* l) {
 }
 
 void HipContext::uploadPositions(const vector<Vec3>& positions) {
+    recoverIfFrozen();          // a frozen device state is brought up to date first: skipped steps must not be replayed on top of the new state
     vector<D4> tmp(numAtoms);
     for (int i = 0; i < numAtoms; i++) {
         if (positions[i][0] != positions[i][0] || positions[i][1] != positions[i][1] || positions[i][2] != positions[i][2])
@@ -208,7 +215,10 @@ void HipContext::recoverIfFrozen() {
     if (inRecovery || !listRecovery || !replaySteps) return;
     inRecovery = true;
     try {
-        const int skipped = listRecovery();
+        // steps the device skipped: those the synchronous check finds now plus those a force evaluation already found and left
+        // for the integrator (pendingReplay) -- a getState between the two must not see the frozen state under the current time
+        const int skipped = listRecovery() + pendingReplay;
+        pendingReplay = 0;
         if (skipped > 0) replaySteps(skipped);
     } catch (...) { inRecovery = false; throw; }
     inRecovery = false;
@@ -225,6 +235,7 @@ void HipContext::downloadPositions(vector<Vec3>& positions) {
 }
 
 void HipContext::uploadVelocities(const vector<Vec3>& velocities) {
+    recoverIfFrozen();
     vector<D4> tmp(numAtoms);
     for (int i = 0; i < numAtoms; i++) {
         tmp[i].x = velocities[i][0]; tmp[i].y = velocities[i][1]; tmp[i].z = velocities[i][2];
@@ -407,8 +418,9 @@ void HipContext::exchangePositions() {
 
 unsigned HipContext::ddWarnFraction() const {
     // the re-sort is requested at this part of the margin; what is left of it must outlast the (at most 12) steps until every rank has
-    // seen the flag: 0.1 nm at the defaults, i.e. an atom at 8 nm/ps all the way
-    static const double warn = getenv("OPENMM_HIP_DD_WARN") != NULL ? atof(getenv("OPENMM_HIP_DD_WARN")) : 0.75;
+    // seen the flag plus the reorderLag steps until the new order applies: 0.3 nm for 0.28 ps at the defaults, where a water molecule
+    // diffuses 0.05 nm (RMS, one axis)
+    static const double warn = getenv("OPENMM_HIP_DD_WARN") != NULL ? atof(getenv("OPENMM_HIP_DD_WARN")) : 0.5;
     return (unsigned) (warn * haloDrift / box[0] * 4294967296.0);
 }
 unsigned HipContext::ddMaxFraction() const { return (unsigned) (haloDrift / box[0] * 4294967296.0); }
@@ -425,7 +437,7 @@ void HipContext::pollDriftFlags() {
         if (pinnedDdFlags[0] != 0)
             throw OpenMMException("HIP platform: an atom drifted further along x between two re-sorts than the halo of the domain decomposition allows; "
                                   "lower OPENMM_HIP_REORDER_INTERVAL or raise OPENMM_HIP_DD_DRIFT");
-        if (pinnedDdFlags[2] != 0) reorderRequested = true;  // every rank reads the same word at the same evaluation: they re-sort together
+        if (pinnedDdFlags[2] != 0) reorderDue = true;        // every rank reads the same word at the same evaluation: they re-sort together
     }
 }
 
@@ -476,6 +488,7 @@ void HipContext::findUnits(const System& system) {
 
 void HipContext::stepTaken() {
     stepsSinceReorder++;
+    stepsSinceSnapshot++;
 }
 
 void HipContext::partitionBlocks(vector<int>& atomOfSlotLike) const {
@@ -630,9 +643,16 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
             extent = max(extent, sqrt(d2));
         }
     extent *= 1.1;                                // constraints hold distances to the first atom; flexible units get a little room
+    // The drift margin: as wide as the narrowest slab allows (the neighbours must hold everything a rank needs), up to haloDriftMax --
+    // the wider it is, the later the early re-sorts set in (one axis of a water molecule's diffusion is 0.07-0.1 nm RMS per ps; at
+    // 0.6 nm even the fastest of a million molecules stays inside until the scheduled re-sort).
+    double minWidth = L[0];
+    for (int g = 0; g < R; g++) minWidth = min(minWidth, bound[g + 1] - bound[g]);
+    haloDrift = haloDriftMax;
+    if (R > 2) haloDrift = max(0.0, min(haloDriftMax, 0.5 * (0.98 * minWidth - haloReach - extent)));
     const double T = haloReach + 2.0 * haloDrift + extent;
     static const bool noHalo = getenv("OPENMM_HIP_DD_REPLICATE") != NULL;          // A/B knob: always replicate positions (round-2 behaviour)
-    bool halo = R > 1 && haloReach > 0.0 && !noHalo && R <= OMMHIP_MAX_RANKS;
+    bool halo = R > 1 && haloReach > 0.0 && !noHalo && R <= OMMHIP_MAX_RANKS && haloDrift >= haloDriftMin;
     for (int g = 0; g < R && halo; g++) {
         if (R > 2 && bound[g + 1] - bound[g] < T) halo = false;
         // charge spreading: the rank's PME planes +- pmeReachX must lie inside what it sees
@@ -706,20 +726,60 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
     partitionBlocks(newAtomOfSlot);          // a rank's range is a whole number of blocks: no atom changes owner
 }
 
+void HipContext::takeSnapshot() {
+    // everything on the stream, nothing waits: (decomposed: exact positions of all atoms on every rank), a device copy -- the
+    // reference the drift guard will measure from -- and its download into pinned memory, then an event
+    if (decomposed()) gatherState();
+    const size_t bytes = sizeof(double) * 4 * (size_t) max(numAtoms, 1);
+    if (posSnapshot.ptr == NULL) {
+        posSnapshot.allocate(bytes);
+        HIP_CHECK(ommhip_host_malloc((void**) &pinnedSnapshot, bytes));
+        HIP_CHECK(ommhip_event_create_untimed(&snapshotEvent));
+    }
+    HIP_CHECK(ommhip_memcpy_d2d(posSnapshot.ptr, pos.ptr, bytes, stream));
+    HIP_CHECK(ommhip_memcpy_d2h(pinnedSnapshot, posSnapshot.ptr, bytes, stream));
+    HIP_CHECK(ommhip_event_record(snapshotEvent, stream));
+    snapshotPending = true;
+    stepsSinceSnapshot = 0;
+}
+
 bool HipContext::reorderIfNeeded() {
-    if (!reorderRequested && stepsSinceReorder < reorderInterval)
-        return false;
+    if (!reorderRequested) {
+        if (snapshotPending) {
+            if (stepsSinceSnapshot < reorderLag) return false;
+            HIP_CHECK(ommhip_event_sync(snapshotEvent));      // the GPU has reached the snapshot; reorderLag steps are queued behind it
+            snapshotPending = false;
+            vector<Vec3> positions(numAtoms);
+            for (int i = 0; i < numAtoms; i++) positions[i] = Vec3(pinnedSnapshot[4 * (size_t) i], pinnedSnapshot[4 * (size_t) i + 1], pinnedSnapshot[4 * (size_t) i + 2]);
+            return applyOrder(positions, true);
+        }
+        if (!reorderDue && stepsSinceReorder < reorderInterval) return false;
+        if (!usePeriodic && sortCutoff <= 0.0 && !decomposed()) { reorderDue = false; stepsSinceReorder = 0; return false; }
+        if (reorderLag > 0 && !hostMode && positionsValid) {
+            reorderDue = false;
+            takeSnapshot();
+            return false;
+        }
+    }
+    snapshotPending = false;                // superseded by a re-sort that cannot wait
+    reorderRequested = false;
+    reorderDue = false;
+    if (!usePeriodic && sortCutoff <= 0.0 && !decomposed()) {
+        stepsSinceReorder = 0;
+        return false;                       // identity order and no wrapping: nothing to do
+    }
+    vector<Vec3> positions;
+    downloadPositions(positions);           // decomposed: also completes pos[] and vel[] on this rank (units change owner below)
+    return applyOrder(positions, false);
+}
+
+bool HipContext::applyOrder(const vector<Vec3>& positions, bool fromSnapshot) {
     static const bool timing = getenv("OPENMM_HIP_TIMING") != NULL;          // diagnostics: wall time of the re-sort on stderr
     const std::chrono::steady_clock::time_point tStart = std::chrono::steady_clock::now();
     struct Report { bool on; std::chrono::steady_clock::time_point t0; int n;
                     ~Report() { if (on) fprintf(stderr, "HIP platform: re-sort of %d atoms took %.2f ms\n", n, 1e-3 * std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count()); } } report = {timing, tStart, numAtoms};
-    reorderRequested = false;
-    stepsSinceReorder = 0;
+    stepsSinceReorder = fromSnapshot ? stepsSinceSnapshot : 0;       // the age of the order
     reorderCount++;
-    if (!usePeriodic && sortCutoff <= 0.0 && !decomposed())
-        return false;                       // identity order and no wrapping: nothing to do
-    vector<Vec3> positions;
-    downloadPositions(positions);           // decomposed: also completes pos[] and vel[] on this rank (units change owner below)
     vector<int> wrapHost;
     bool orderChanged = false;
     if (decomposed()) {
@@ -737,19 +797,31 @@ bool HipContext::reorderIfNeeded() {
             if (hostAtomOfSlot[s] != order[s]) { orderChanged = true; break; }
         for (int s = 0; s < numAtoms; s++) { hostAtomOfSlot[s] = order[s]; hostSlotOfAtom[order[s]] = s; }
     }
+    const std::chrono::steady_clock::time_point tOrdered = std::chrono::steady_clock::now();
+    // a lagged re-sort of a decomposed run: the units change owner NOW -- every rank needs the current exact state of all atoms
+    if (decomposed() && fromSnapshot) gatherState();
     HIP_CHECK(ommhip_memcpy_h2d(wrap.ptr, wrapHost.data(), sizeof(int) * wrapHost.size(), stream));
     HIP_CHECK(ommhip_memcpy_h2d(atomOfSlot.ptr, hostAtomOfSlot.data(), sizeof(int) * paddedAtoms, stream));
     HIP_CHECK(ommhip_memcpy_h2d(slotOfAtom.ptr, hostSlotOfAtom.data(), sizeof(int) * numAtoms, stream));
     if (decomposed()) {
+        // the drift guard measures from the positions the sections were cut for: the snapshot's when the order comes from one
+        const double len[3] = {box[0], box[2], box[5]};
+        if (fromSnapshot) HIP_CHECK(ommhip_encode_wire(posSnapshot.ptr, atomOfSlot.as<int>(), 0, paddedAtoms, len, wireRef.ptr, stream));
         fillWireFromPos();
-        HIP_CHECK(ommhip_memcpy_d2d(wireRef.ptr, posWire.ptr, posWire.bytes, stream));       // the drift guard measures from here
+        if (!fromSnapshot) HIP_CHECK(ommhip_memcpy_d2d(wireRef.ptr, posWire.ptr, posWire.bytes, stream));
         HIP_CHECK(ommhip_memset(ddFlags.ptr, 0, ddFlags.bytes, stream));
         HIP_CHECK(ommhip_clear_trailer_flags(posWire.ptr, domain.ranks, slotsPerRank, trailerSlot, stream));
         memset(pinnedDdFlags, 0, sizeof(int) * 4);
         ddEvaluations = 0;
     }
     sync();
+    const std::chrono::steady_clock::time_point tUploaded = std::chrono::steady_clock::now();
     // wrap offsets may have changed even when the order did not: listeners rebuild their slot data either way
     for (size_t i = 0; i < listeners.size(); i++) listeners[i]->atomsReordered();
+    if (timing) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return 1e-3 * std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        fprintf(stderr, "HIP platform: re-sort phases (%s): order %.2f ms, upload %.2f ms, listeners %.2f ms%s\n", fromSnapshot ? "from a snapshot taken earlier" : "at once", ms(tStart, tOrdered),
+                ms(tOrdered, tUploaded), ms(tUploaded, std::chrono::steady_clock::now()), decomposed() ? (haloMode ? " (halo mode)" : " (replicated)") : "");
+    }
     return orderChanged;
 }

@@ -125,10 +125,18 @@ public:
     void saveForces();                                         // device copy of the force buffer (energy-only evaluations)
     void restoreForces();
     double reduceEnergy();                                      // blocking; also zeroes the buffer
-    /** Spatially re-sort atoms into slots if requested or due.  Returns true if the order changed. */
+    /** Spatially re-sort atoms into slots if requested or due.  Returns true if the order changed.
+     *  A re-sort that is merely DUE (the interval ran out, an atom neared the drift margin of a decomposed run) is taken off the
+     *  step: the positions are snapshotted on the stream (takeSnapshot) and the host goes on enqueueing `reorderLag` more steps; only
+     *  then does it wait for the snapshot, compute the order from it and apply it -- while the GPU works through those queued steps
+     *  instead of idling for the 35-55 ms the host needs at a million atoms.  The order is `reorderLag` steps old when it takes
+     *  effect (it is a locality heuristic; the drift guard of decomposed runs measures from the snapshot).  A re-sort that is
+     *  REQUESTED (new positions, a new box, host mode) happens at once.  Decomposed runs: every rank takes the same path at the
+     *  same step (the triggers are step counts and flags every rank sees alike). */
     bool reorderIfNeeded();
     void requestReorder() { reorderRequested = true; }
     void stepTaken();                                           // counts steps towards the next reorder
+    void requestReorderSoon() { reorderDue = true; }           // off the step (see reorderIfNeeded); decomposed runs: called on every rank at the same evaluation
 
     int getDeviceIndex() const { return deviceIndex; }
     void addListener(HipContextListener* l) { listeners.push_back(l); }
@@ -162,7 +170,8 @@ public:
     int activeRange[8];
     double haloReach = 0.0;               // list cutoff (cutoff + padding) of the nonbonded force, nm; 0 = no halo mode
     double pmeReachX = 0.0;               // how far (nm) beyond its PME planes a rank must see atoms for charge spreading
-    double haloDrift;                     // x drift since the re-sort an atom is allowed before the run must have re-sorted (nm)
+    double haloDrift;                     // x drift since the re-sort an atom is allowed before the run must have re-sorted (nm); set at every re-sort
+    double haloDriftMax, haloDriftMin;
     DeviceBuffer guardAtom;               // unsigned char[N]: 1 for the first atom of every integration unit (the atoms the drift guard watches)
     DeviceBuffer wireRef, ddFlags;        // wire records of the last re-sort; int[4] flags (ommhip_neighbor_list::dd_flags)
     int* pinnedDdFlags = NULL;
@@ -244,6 +253,15 @@ private:
     std::vector<int> launchedTermIds;          // ids whose terms already went out this evaluation (fused front launch)
     int nextTermId = 1;
     bool reorderRequested;
+    bool reorderDue = false;
+    // lagged re-sort
+    bool snapshotPending = false;
+    int stepsSinceSnapshot = 0, reorderLag;
+    DeviceBuffer posSnapshot;                // double4[N] positions at the snapshot (device copy: reference of the drift guard)
+    double* pinnedSnapshot = NULL;           // the same on the host
+    void* snapshotEvent = NULL;
+    void takeSnapshot();
+    bool applyOrder(const std::vector<Vec3>& positions, bool fromSnapshot);
     int deviceIndex;
     double* pinnedResult;
 };

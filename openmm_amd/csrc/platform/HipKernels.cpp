@@ -1,4 +1,5 @@
 #include "HipKernels.h"
+#include <chrono>
 #include "ReferenceConstraints.h"
 #include "ReferenceSETTLEAlgorithm.h"
 #include "ReferenceCCMAAlgorithm.h"
@@ -1272,6 +1273,10 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
         nl.pbc = (hip.box[1] != 0.0 || hip.box[3] != 0.0 || hip.box[4] != 0.0) ? 2 : 1;
     }
     if (slotParamsDirty) {
+        static const bool timing = getenv("OPENMM_HIP_TIMING") != NULL;
+        const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        struct Report { bool on; std::chrono::steady_clock::time_point t0;
+                        ~Report() { if (on) fprintf(stderr, "HIP platform: slot data of the nonbonded force after a re-sort: %.2f ms\n", 1e-3 * std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count()); } } report = {timing, t0};
         if (hip.decomposed()) {
             // every block starts without a bounding box (a hugely negative half extent: no block test can pass against it);
             // ommhip_nl_prepare gives the blocks it converts their boxes -- all of them, or in halo mode those this rank sees

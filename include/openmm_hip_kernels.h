@@ -69,6 +69,8 @@ enum {
     OMMHIP_PROFILE_NUM_TIMERS = 8
 };
 int ommhip_profile_enable(int every);   /* 0 = off; n >= 1 = time every n-th launch of each timer */
+/* the same, for the timers of `mask` only (bit per timer), with `reserve` event pairs per timer created up front */
+int ommhip_profile_enable_timers(int every, unsigned mask, int reserve);
 int ommhip_profile_reset(void);
 int ommhip_profile_begin(int timer, void* stream);
 int ommhip_profile_end(int timer, void* stream);

@@ -1,0 +1,177 @@
+// AMOEBA kernels of the OpenMM "HIP" platform (include/openmm_hip_amoeba.h): first native slice -- AmoebaVdwForce.
+//
+// Oracle: plugins/amoeba/platforms/reference/src/SimTKReference/AmoebaReferenceVdwForce.cpp (cited per function below).
+// Double precision throughout: AMOEBA's validation numbers (plugins/amoeba/tests/TestAmoebaVdwForce.h, from Tinker) are held to
+// 1e-4 and better, and this force is a small part of an AMOEBA step next to the multipoles.
+//
+// Formulation for wave64: one thread owns one interaction site i and walks through all sites j, 256 at a time staged in LDS
+// (site, atom position, type, flag: 64 bytes per j; every lane reads the same j at the same time -- LDS broadcast).  Each pair is
+// evaluated from both sides, so a thread only ever accumulates the force on its own site: no atomics in the loop, and the
+// exclusion list of i -- ascending -- is consumed with one cursor while j ascends.  The site force is shared between the atom and
+// its parent at the end (two fixed-point atomics per component).
+#include "common.h"
+#include "../../../include/openmm_hip_amoeba.h"
+
+using namespace omm;
+
+namespace {
+
+#define VDW_BLOCK 256
+
+struct VdwArgs {
+    int numAtoms, numTypes, paddedAtoms, alchemicalMethod, lennardJones, periodic, includeEnergy, energySlots;
+    const int* parent; const double* reduction; const int* type;
+    const double* sigma; const double* epsilon;
+    const int* exclStart; const int* exclAtoms;
+    const unsigned char* alchemical;
+    double epsilonScale, softcore, cutoff2, taperCutoff, c3, c4, c5;
+    BoxD box;
+    const double4* pos;
+    double4* reduced;
+    const int* slotOfAtom;
+    omm_fixed* force;
+    double* energyBuffer;
+};
+
+// AmoebaReferenceVdwForce::setReducedPositions (AmoebaReferenceVdwForce.cpp:173-189)
+__global__ void k_vdw_reduce(VdwArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.numAtoms) return;
+    const double4 x = a.pos[i];
+    const double red = a.reduction[i];
+    double4 r = x;
+    if (red != 0.0) {
+        const double4 p = a.pos[a.parent[i]];
+        r.x = red * (x.x - p.x) + p.x; r.y = red * (x.y - p.y) + p.y; r.z = red * (x.z - p.z) + p.z;
+    }
+    a.reduced[i] = r;
+}
+
+// one pair, seen from site i: energy of the pair and dE/dr / r (the force on i is -that times (r_i - r_j))
+// AmoebaReferenceVdwForce::calculatePairIxn (AmoebaReferenceVdwForce.cpp:106-171)
+__device__ __forceinline__ double vdw_pair(const VdwArgs& a, double r, double sigma, double epsilon, double softcore, double& dEdRoverR) {
+    double energy, dEdR;
+    if (a.lennardJones) {
+        const double pp1 = sigma / r, pp2 = pp1 * pp1, pp3 = pp2 * pp1, pp6 = pp3 * pp3, pp12 = pp6 * pp6;
+        energy = 4 * epsilon * (pp12 - pp6);
+        dEdR = -24 * epsilon * (2 * pp12 - pp6) / r;
+    }
+    else {
+        const double dhal = 0.07, ghal1 = 1.12, dhal1 = 1.07;
+        const double rho = r / sigma, rho2 = rho * rho, rho6 = rho2 * rho2 * rho2;
+        const double rhoplus = rho + dhal, rhodec2 = rhoplus * rhoplus, rhodec = rhodec2 * rhodec2 * rhodec2;
+        const double s1 = 1.0 / (softcore + rhodec * rhoplus);
+        const double s2 = 1.0 / (softcore + rho6 * rho + 0.12);
+        const double point72 = dhal1 * dhal1;
+        const double t1 = dhal1 * point72 * point72 * point72 * s1;
+        const double t2 = ghal1 * s2;
+        const double t2min = t2 - 2;
+        const double dt1 = -7.0 * rhodec * t1 * s1;
+        const double dt2 = -7.0 * rho6 * t2 * s2;
+        energy = epsilon * t1 * t2min;
+        dEdR = epsilon * (dt1 * t2min + t1 * dt2) / sigma;
+    }
+    if (a.periodic && r > a.taperCutoff) {
+        const double delta = r - a.taperCutoff;
+        const double taper = 1.0 + delta * delta * delta * (a.c3 + delta * (a.c4 + delta * a.c5));
+        const double dtaper = delta * delta * (3.0 * a.c3 + delta * (4.0 * a.c4 + delta * 5.0 * a.c5));
+        dEdR = energy * dtaper + dEdR * taper;
+        energy *= taper;
+    }
+    dEdRoverR = dEdR / r;
+    return energy;
+}
+
+__global__ __launch_bounds__(VDW_BLOCK) void k_vdw_pairs(VdwArgs a) {
+    __shared__ double4 sSite[VDW_BLOCK];
+    __shared__ double4 sAtom[VDW_BLOCK];
+    __shared__ int sType[VDW_BLOCK];
+    __shared__ unsigned char sAlch[VDW_BLOCK];
+    __shared__ double sEnergy[VDW_BLOCK / 64];
+    const int t = threadIdx.x;
+    const int i = blockIdx.x * VDW_BLOCK + t;
+    const bool active = i < a.numAtoms;
+    const int ii = active ? i : 0;
+    const double4 si = a.reduced[ii], xi = a.pos[ii];
+    const int typeI = a.type[ii];
+    const bool alchI = a.alchemical != nullptr && a.alchemical[ii] != 0;
+    int cursor = a.exclStart[ii];
+    const int exclEnd = a.exclStart[ii + 1];
+    int nextExcl = cursor < exclEnd ? a.exclAtoms[cursor] : 0x7fffffff;
+    double fx = 0, fy = 0, fz = 0, energy = 0;
+    for (int j0 = 0; j0 < a.numAtoms; j0 += VDW_BLOCK) {
+        const int jl = j0 + t;
+        __syncthreads();
+        if (jl < a.numAtoms) { sSite[t] = a.reduced[jl]; sAtom[t] = a.pos[jl]; sType[t] = a.type[jl]; sAlch[t] = a.alchemical != nullptr ? a.alchemical[jl] : 0; }
+        __syncthreads();
+        const int n = min(VDW_BLOCK, a.numAtoms - j0);
+        if (!active) continue;
+        for (int k = 0; k < n; k++) {
+            const int j = j0 + k;
+            // the exclusion list ascends, and so does j
+            while (nextExcl < j) { cursor++; nextExcl = cursor < exclEnd ? a.exclAtoms[cursor] : 0x7fffffff; }
+            if (j == i || j == nextExcl) continue;
+            if (a.periodic) {
+                // pair selection on the ATOM positions (the Reference's neighbour list is built on them)
+                const double4 xj = sAtom[k];
+                double dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
+                min_image_d(dx, dy, dz, a.box);
+                if (dx * dx + dy * dy + dz * dz > a.cutoff2) continue;
+            }
+            const double4 sj = sSite[k];
+            double dx = si.x - sj.x, dy = si.y - sj.y, dz = si.z - sj.z;
+            if (a.periodic) min_image_d(dx, dy, dz, a.box);
+            const double r = sqrt(dx * dx + dy * dy + dz * dz);
+            double sigma = a.sigma[typeI * a.numTypes + sType[k]], epsilon = a.epsilon[typeI * a.numTypes + sType[k]], softcore = 0.0;
+            const bool alchJ = sAlch[k] != 0;
+            if ((a.alchemicalMethod == 1 && alchI != alchJ) || (a.alchemicalMethod == 2 && (alchI || alchJ))) { epsilon *= a.epsilonScale; softcore = a.softcore; }
+            double dEdRoverR;
+            const double e = vdw_pair(a, r, sigma, epsilon, softcore, dEdRoverR);
+            fx -= dEdRoverR * dx; fy -= dEdRoverR * dy; fz -= dEdRoverR * dz;
+            energy += 0.5 * e;              // every pair is visited from both of its sites
+        }
+    }
+    if (active) {
+        // AmoebaReferenceVdwForce::addReducedForce (AmoebaReferenceVdwForce.cpp:92-104)
+        const int p = a.parent[i];
+        if (p == i) add_force(a.force, a.paddedAtoms, a.slotOfAtom[i], fx, fy, fz);
+        else {
+            const double red = a.reduction[i];
+            add_force(a.force, a.paddedAtoms, a.slotOfAtom[i], fx * red, fy * red, fz * red);
+            add_force(a.force, a.paddedAtoms, a.slotOfAtom[p], fx * (1.0 - red), fy * (1.0 - red), fz * (1.0 - red));
+        }
+    }
+    if (a.includeEnergy) {
+        energy = wave_sum(active ? energy : 0.0);
+        if ((t & 63) == 0) sEnergy[t >> 6] = energy;
+        __syncthreads();
+        if (t == 0) {
+            double e = 0;
+            for (int w = 0; w < VDW_BLOCK / 64; w++) e += sEnergy[w];
+            atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], e);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* v, const void* pos_d, const double box[6], const int* slot_of_atom_d, int padded_atoms,
+                                        long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
+    if (v->num_atoms <= 0) return 0;
+    if (v->reduced == nullptr || v->parent == nullptr || v->type == nullptr || v->excl_start == nullptr) return 1;
+    VdwArgs a;
+    a.numAtoms = v->num_atoms; a.numTypes = v->num_types; a.paddedAtoms = padded_atoms; a.alchemicalMethod = v->alchemical_method;
+    a.lennardJones = v->lennard_jones; a.periodic = v->periodic; a.includeEnergy = include_energy; a.energySlots = energy_slots;
+    a.parent = v->parent; a.reduction = v->reduction; a.type = v->type; a.sigma = v->sigma; a.epsilon = v->epsilon;
+    a.exclStart = v->excl_start; a.exclAtoms = v->excl_atoms; a.alchemical = v->alchemical;
+    a.epsilonScale = v->epsilon_scale; a.softcore = v->softcore; a.cutoff2 = v->cutoff * v->cutoff; a.taperCutoff = v->taper_cutoff;
+    a.c3 = v->taper_c3; a.c4 = v->taper_c4; a.c5 = v->taper_c5;
+    a.box.ax = box[0]; a.box.bx = box[1]; a.box.by = box[2]; a.box.cx = box[3]; a.box.cy = box[4]; a.box.cz = box[5];
+    a.pos = (const double4*) pos_d; a.reduced = (double4*) v->reduced; a.slotOfAtom = slot_of_atom_d;
+    a.force = force_d; a.energyBuffer = energy_buffer_d;
+    hipStream_t st = (hipStream_t) stream;
+    const int blocks = (a.numAtoms + VDW_BLOCK - 1) / VDW_BLOCK;
+    hipLaunchKernelGGL(k_vdw_reduce, dim3(blocks), dim3(VDW_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_vdw_pairs, dim3(blocks), dim3(VDW_BLOCK), 0, st, a);
+    return (int) hipGetLastError();
+}

@@ -82,6 +82,7 @@ struct ProfileTimer {
 };
 ProfileTimer timers[OMMHIP_PROFILE_NUM_TIMERS];
 int profileEnabled = 0;
+unsigned profileMask = ~0u;      // timers that record (bit per timer)
 void profile_drain(ProfileTimer& t) {
     for (size_t i = 0; i < t.used; i++) {
         float ms = 0;
@@ -95,13 +96,27 @@ void profile_drain(ProfileTimer& t) {
 }  // namespace
 
 extern "C" {
-int ommhip_profile_enable(int enabled) { profileEnabled = enabled < 0 ? 0 : enabled; return 0; }   /* n > 1: time every n-th launch */
+int ommhip_profile_enable(int enabled) { profileEnabled = enabled < 0 ? 0 : enabled; profileMask = ~0u; return 0; }   /* n > 1: time every n-th launch */
+int ommhip_profile_enable_timers(int every, unsigned mask, int reserve) {
+    // only the timers of `mask` record, and `reserve` event pairs per timer are created now rather than at their first use
+    // (an event pair costs more to create than a small kernel takes: a 20-step timed region should not pay for that)
+    profileEnabled = every < 0 ? 0 : every; profileMask = mask;
+    for (int i = 0; i < OMMHIP_PROFILE_NUM_TIMERS; i++) {
+        if (((mask >> i) & 1u) == 0) continue;
+        while ((int) timers[i].start.size() < reserve) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 1;
+            timers[i].start.push_back(a); timers[i].stop.push_back(b);
+        }
+    }
+    return 0;
+}
 int ommhip_profile_reset() {
     for (int i = 0; i < OMMHIP_PROFILE_NUM_TIMERS; i++) { profile_drain(timers[i]); timers[i].totalMs = 0; timers[i].calls = 0; }
     return 0;
 }
 int ommhip_profile_begin(int timer, void* stream) {
-    if (!profileEnabled || timer < 0 || timer >= OMMHIP_PROFILE_NUM_TIMERS) return 0;
+    if (!profileEnabled || timer < 0 || timer >= OMMHIP_PROFILE_NUM_TIMERS || ((profileMask >> timer) & 1u) == 0) return 0;
     ProfileTimer& t = timers[timer];
     t.open = (t.seq++ % (unsigned) profileEnabled) == 0;
     if (!t.open) return 0;

@@ -6,6 +6,8 @@
  * Reference implementation (the platforms/cpu precedent, CpuPlatform.cpp:63-77).
  */
 #include "HipPlatform.h"
+#include <typeinfo>
+#include <vector>
 #include "HipContext.h"
 #include "HipKernels.h"
 #include "ReferenceKernelFactory.h"
@@ -53,6 +55,24 @@ struct HipModeInfo {
     bool hasFallbackForces;
 };
 
+namespace {
+struct NativeKernel { string kernelName, forceType; KernelFactory* factory; };
+vector<NativeKernel>& nativeKernels() { static vector<NativeKernel> v; return v; }
+}
+
+void HipPlatform::registerNativeKernel(const string& kernelName, const string& forceType, KernelFactory* factory) {
+    for (size_t i = 0; i < nativeKernels().size(); i++)
+        if (nativeKernels()[i].kernelName == kernelName) { nativeKernels()[i].forceType = forceType; nativeKernels()[i].factory = factory; return; }
+    NativeKernel k = {kernelName, forceType, factory};
+    nativeKernels().push_back(k);
+}
+
+bool HipPlatform::isNativeForceType(const string& typeName) {
+    for (size_t i = 0; i < nativeKernels().size(); i++)
+        if (!nativeKernels()[i].forceType.empty() && typeName.find(nativeKernels()[i].forceType) != string::npos) return true;
+    return false;
+}
+
 static HipModeInfo classifyContext(ContextImpl& context) {
     HipModeInfo info = {false, false, false, false};
     const System& system = context.getSystem();
@@ -83,6 +103,8 @@ static HipModeInfo classifyContext(ContextImpl& context) {
             info.hostMode = true;       // these change state (or own an inner Context) on the host
             continue;
         }
+        if (HipPlatform::isNativeForceType(typeid(f).name()))
+            continue;                   // a native kernel from a plugin of its own (registerNativeKernel)
         // Any other Force: its Reference kernel only reads positions and adds forces.
         info.hasFallbackForces = true;
     }
@@ -218,6 +240,9 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
         if (ommhip_device_count(&count) == 0 && count > 0)
             deviceIndex = atoi(getenv("LOCAL_RANK")) % count;
     }
+    // native kernels of other plugins take precedence over Reference kernels registered for the same names (see registerNativeKernel)
+    for (size_t i = 0; i < nativeKernels().size(); i++)
+        const_cast<HipPlatform*>(this)->registerKernelFactory(nativeKernels()[i].kernelName, nativeKernels()[i].factory);
     HipModeInfo mode = classifyContext(context);
     // ---- one box on several GPUs (one process per GPU)
     HipDomain domain;

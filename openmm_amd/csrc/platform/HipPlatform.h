@@ -49,6 +49,14 @@ public:
     static PlatformData& getData(ContextImpl& context) {
         return *reinterpret_cast<PlatformData*>(context.getPlatformData());
     }
+    /** Native kernels that live in a plugin of their own (libOpenMMAmoebaHIP.so, the counterpart of the reference's
+     *  libOpenMMAmoebaCUDA): the plugin's registerKernelFactories() announces them here.  `forceType` is a fragment of the C++
+     *  type name of the Force the kernel serves ("AmoebaVdwForce"): a System holding such a Force then needs no fallback for it
+     *  (the kernel computes on the device state).  The announcement is repeated at every Context creation, because the AMOEBA
+     *  plugin's own Reference kernels register themselves with every platform derived from ReferencePlatform
+     *  (AmoebaReferenceKernelFactory.cpp:47-58) -- whichever of the two plugins was loaded last would otherwise win. */
+    static void registerNativeKernel(const std::string& kernelName, const std::string& forceType, KernelFactory* factory);
+    static bool isNativeForceType(const std::string& typeName);
 };
 
 /** ReferencePlatform::PlatformData (host vectors for fallback kernels) + the device context. */

@@ -246,6 +246,23 @@ def test_reference_test_bodies_on_emulated_platform(name):
             break
         out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "Done" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    if name in NATIVE_AMOEBA:
+        import re
+        m = re.search(r"native AMOEBA kernel evaluations: vdw (\d+) multipole (\d+)", out.stdout)
+        assert m is not None and int(m.group(1 if NATIVE_AMOEBA[name] == "vdw" else 2)) > 0, out.stdout[-500:]
+
+
+NATIVE_AMOEBA = {"AmoebaVdwForce": "vdw"}         # bodies whose forces must have gone through the native kernels of libOpenMMAmoebaHIP.so
+
+
+@needs_emu
+def test_amoeba_fallback_path_still_works_without_the_native_plugin():
+    """HIP_AMOEBA_FALLBACK_ONLY=1: the AMOEBA plugin's own Reference kernels as fallback forces on a HIP Context (round 2's path)."""
+    exe = os.path.join(EMU_BUILD, "tests", "TestHipAmoebaVdwForce")
+    if not os.path.exists(exe):
+        pytest.skip("not built")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, HIP_AMOEBA_FALLBACK_ONLY="1"))
+    assert out.returncode == 0 and "Done" in out.stdout and "evaluations: vdw 0 multipole 0" in out.stdout, out.stdout[-2000:]
 
 
 @needs_emu

@@ -64,8 +64,11 @@ def test_two_ranks_over_rccl_on_two_gpus(tmp_path):
     of a State download) on two streams with two communicators -- against the single-GPU run of the same box, including the case
     whose ranges have all four sections.  Skips on a box with one GPU (the gpurun boxes); the pattern is the reference's
     multi-device test, platforms/cuda/tests/TestCudaNonbondedForce.cpp:37-96."""
-    import torch
-    if torch.cuda.device_count() < 2:
+    import ctypes
+    from openmm_amd import capi
+    count = ctypes.c_int(0)
+    capi.load().device_count(ctypes.byref(count))        # (not torch.cuda: this process must not load a second HIP / RCCL user)
+    if count.value < 2:
         pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
     from test_multirank_cpu import _run_dd_child
     env = {"DD_TEST_TRANSPORT": "rccl", "OPENMM_HIP_DD_DRIFT": "0.05"}
@@ -92,6 +95,7 @@ system, nb = w.build()
 ctx = H.Context(system, H.Integrator(H.VERLET, 0.001), "HIP", props)
 ctx.setPositions(w.positions)
 st = ctx.getState(getForces=True, getEnergy=True)
+info = H.domain_info()
 ctx.close()
 idx = g["indices"]
 p = force_parity(w.positions, w.box, w.cutoff, st.forces[idx], g["forces"], subset=idx, rms=float(g["rms_force"]))
@@ -99,7 +103,6 @@ if rank == 0:
     print("water-1M on %%d ranks: force max-rel-err over the sampled atoms %%.3g (away from %%d edge pairs: %%.3g), E %%.3f vs %%.3f" %% (
         world, p["max_rel_err_all_atoms"], p["cutoff_edge_pairs"], p["max_rel_err"], st.potentialEnergy, float(g["energy"])), flush=True)
 assert p["max_rel_err_all_atoms"] < 1e-4
-info = H.domain_info()
 assert info[1] == 1 and info[3] < world * info[2], ("four 5.3 nm slabs: halo exchange expected", info)
 assert abs(st.potentialEnergy - float(g["energy"])) < 1e-5 * 5.0 * w.num_atoms
 if rank == 0:

@@ -20,9 +20,11 @@ REFERENCE_TEST_BODIES = ["NonbondedForce", "Ewald", "VerletIntegrator", "Settle"
                          "HarmonicBondForce", "HarmonicAngleForce", "PeriodicTorsionForce", "CMMotionRemover", "Checkpoints",
                          "CustomBondForce", "CustomExternalForce", "RBTorsionForce", "VirtualSites", "VariableVerletIntegrator",
                          "BrownianIntegrator", "MonteCarloBarostat", "CustomNonbondedForce", "GBSAOBCForce", "DispersionPME",
-                         # plugins/amoeba/tests: no native AMOEBA kernels -- the plugin's own Reference kernels,
-                         # registered on the HIP platform by the plugin itself, run as fallback forces beside the native path
+                         # plugins/amoeba/tests with libOpenMMAmoebaHIP.so loaded: AmoebaVdwForce (and the PME cases of
+                         # AmoebaMultipoleForce) run on the native kernels -- NATIVE_AMOEBA below says which evaluation counter must
+                         # move; AmoebaTorsionTorsionForce has no native kernel: the plugin's own Reference kernel runs as a fallback force
                          "AmoebaVdwForce", "AmoebaMultipoleForce", "AmoebaTorsionTorsionForce"]
+NATIVE_AMOEBA = {"AmoebaVdwForce": "vdw"}         # test body -> counter printed by tests/hip/HipAmoebaTests.h at exit
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -43,6 +45,11 @@ def test_reference_test_body(name):
             break
         out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "Done" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    if name in NATIVE_AMOEBA:
+        # a Context that silently fell back to the AMOEBA plugin's Reference kernels would pass the body too: the native kernels count their evaluations
+        import re
+        m = re.search(r"native AMOEBA kernel evaluations: vdw (\d+) multipole (\d+)", out.stdout)
+        assert m is not None and int(m.group(1 if NATIVE_AMOEBA[name] == "vdw" else 2)) > 0, out.stdout[-500:]
 
 
 def hip_state(w, groups=-1, recip_group=False, integrator=None):

@@ -10,7 +10,7 @@ import pytest
 
 from conftest import ROOT
 
-HEADERS = [os.path.join(ROOT, "include", "openmm_hip_kernels.h"), os.path.join(ROOT, "include", "openmm_hip_comm.h")]
+HEADERS = [os.path.join(ROOT, "include", "openmm_hip_kernels.h"), os.path.join(ROOT, "include", "openmm_hip_comm.h"), os.path.join(ROOT, "include", "openmm_hip_amoeba.h")]
 LIB = os.path.join(ROOT, "openmm_amd", "lib")
 
 

@@ -52,6 +52,7 @@ PAIR_FLOP = 45            # flop per evaluated pair (F_dir = 1
 # of the list FORMAT shows up in nonbonded.hip, which reads it.)
 KERNEL_SOURCES = ("nonbonded.hip", "force_front.hip", "pme.hip", "common.h")
 WORKLOADS = ["dhfr", "dhfr_like", "water1k", "water24k", "water98k", "apoa1", "water1m"]
+LATTICE_PREPARE_STEPS = 1000     # untimed relaxation of a generated (jittered-lattice) water box before warm-up and timing
 EMULATED = os.environ.get("BENCH_EMULATED") == "1"     # tests only: the CPU SIMT emulator build of the plugin (tests/emu), to run the N > 1 flow without a GPU
 
 
@@ -65,7 +66,7 @@ def parse_args():
     p.add_argument("--cpu-steps", type=int, default=150, help="steps of the CPU-platform baseline (0 disables it and the force-parity check)")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-scale-workload", action="store_true", help="N = 1: skip the single-GPU run of the strong-scaling workload")
-    p.add_argument("--prepare-steps", type=int, default=-1, help="untimed steps that relax a lattice start before warm-up (input preparation; default 200 for the water boxes, 0 for fixtures)")
+    p.add_argument("--prepare-steps", type=int, default=-1, help="untimed steps that relax a lattice start before warm-up (input preparation; default 1000 for the water boxes -- after 200 steps a jittered lattice is still melting: 9 % more list rows and 40 % more list rebuilds per step than after 3000, profiles/r04h_prepare_steps_water1m.txt -- 0 for fixtures)")
     p.add_argument("--transport", default="rccl", choices=["rccl", "gloo"], help="collectives of the decomposed run: RCCL (product) or host-staged gloo (rehearsal on one GPU)")
     p.add_argument("--profile-every", type=int, default=0, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region (0 = 7, or 2 for runs below 100 steps so that a 20-step run still holds 10 samples)")
     p.add_argument("--no-extra-workloads", action="store_true", help="N = 1: skip the short runs of BASELINE.json configs[2] (apoa1-sized) and of the benchmark script's own 4 fs step")
@@ -202,7 +203,7 @@ def main():
     decomposed = world > 1
     dt_ps = args.dt_fs * 1e-3
     w = make_workload(workload, seed=1)
-    prepare = args.prepare_steps if args.prepare_steps >= 0 else (0 if getattr(w, "velocities", None) is not None else 200)
+    prepare = args.prepare_steps if args.prepare_steps >= 0 else (0 if getattr(w, "velocities", None) is not None else LATTICE_PREPARE_STEPS)
     props = {"DeviceIndex": str(local_rank)}
     for kv in filter(None, args.props.split(",")):
         k, v = kv.split("=")
@@ -457,12 +458,12 @@ def main():
     if world == 1 and workload == "dhfr" and not args.no_scale_workload:
         try:
             sw = make_workload("water1m", seed=1)
-            ssys, snb, sinteg, sctx = start_platform(sw, "HIP", dt_ps, args.warmup, {"DeviceIndex": str(local_rank)}, seed=1, prepare=200)
+            ssys, snb, sinteg, sctx = start_platform(sw, "HIP", dt_ps, args.warmup, {"DeviceIndex": str(local_rank)}, seed=1, prepare=LATTICE_PREPARE_STEPS)
             s_elapsed, s_st = timed_run(sinteg, sctx, args.steps, barrier)
             out["scale_workload"] = {"workload": "%s: ONE box of %d atoms, PME grid %s, single GPU (the N = 1 point of the strong-scaling curve that "
                                                  "bench.py --gpus N reports for N > 1)" % (sw.name, sw.num_atoms, "x".join(str(g) for g in snb.getPMEParametersInContext(sctx)[1:])),
                                      "value": round(MR.ns_per_day(s_elapsed, args.steps, args.dt_fs), 3), "unit": "ns/day",
-                                     "ms_per_step": round(1e3 * s_elapsed / args.steps, 5), "steps": args.steps, "prepare_steps": 200}
+                                     "ms_per_step": round(1e3 * s_elapsed / args.steps, 5), "steps": args.steps, "prepare_steps": LATTICE_PREPARE_STEPS}
             sctx.close()
         except Exception as e:
             out["scale_workload"] = {"value": None, "error": str(e)}
@@ -472,7 +473,7 @@ def main():
         for key, wl_name, dt_fs in (("dhfr_4fs", "dhfr", 4.0), ("apoa1", "apoa1", 2.0)):
             try:
                 xw = w if wl_name == "dhfr" else make_workload(wl_name, seed=1)
-                xprep = 0 if getattr(xw, "velocities", None) is not None else 200
+                xprep = 0 if getattr(xw, "velocities", None) is not None else LATTICE_PREPARE_STEPS
                 xsys, xnb, xinteg, xctx = start_platform(xw, "HIP", dt_fs * 1e-3, args.warmup, {"DeviceIndex": str(local_rank)}, seed=1, prepare=xprep)
                 x_elapsed, x_st = timed_run(xinteg, xctx, args.steps, barrier)
                 if not np.isfinite(x_st.potentialEnergy):

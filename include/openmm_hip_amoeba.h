@@ -53,6 +53,59 @@ typedef struct ommhip_amoeba_vdw {
 int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* vdw, const void* pos_d, const double box[6], const int* slot_of_atom_d, int padded_atoms,
                              long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * AmoebaMultipoleForce with PME: permanent atomic multipoles (charge, dipole, traceless quadrupole in a local frame) and induced
+ * dipoles (polarisability alpha_i, Thole damping), Ewald-split.
+ * Reference: AmoebaReferencePmeMultipoleForce (AmoebaReferenceMultipoleForce.cpp:4800-6818) and its base class: frames
+ * :396-561 (applyRotationMatrixToParticle), chirality :354-378, scale maps :181-266, fixed field :5079-5201, self terms :6294-6333,
+ * reciprocal space :5204-6006, torque -> force :1476-1712, driver :1775-1850 / :6753-6775.
+ *
+ * Formulation of this implementation (not the Reference's quasi-internal spherical-harmonic one): every pair term is
+ * L_A L_B f(r) with the multipole operator L = q - mu.grad + Q:grad grad of each site acting on a radial kernel f given through
+ * the chain B_0 = f, B_n = -(1/r) dB_(n-1)/dr.  Three chains per pair: erfc-screened Coulomb minus (1 - m_ij) of the bare kernel
+ * (permanent-permanent), and the same with (1 - p_ij lambda_(2n+1)) / (1 - d_ij lambda_(2n+1)) for permanent multipoles against the
+ * two induced-dipole sets (lambda: Thole damping, a consistent derivative chain as well).  One device function evaluates energy,
+ * force and torque of L_A L_B f for any chain (amoeba_multipole.hip: mpole_pair).  Reciprocal space: the multipoles are spread
+ * with B-spline derivatives, convolved by the platform's own 3-D FFT (ommhip_pme_convolve), and the potential and its first three
+ * derivatives are read back at every atom.
+ *
+ * Supported: PME, polarization Direct (induced dipoles = alpha x field of the permanent multipoles).  The host falls back to the
+ * AMOEBA plugin's Reference kernel for everything else (NoCutoff, mutual / extrapolated polarization).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ommhip_amoeba_multipole {
+    int num_atoms;
+    /* per atom, device */
+    const double* charge;          /* [n] */
+    const double* mol_dipole;      /* [3n] local-frame dipole */
+    const double* mol_quadrupole;  /* [6n] local-frame quadrupole xx, xy, xz, yy, yz, zz */
+    const int* axis;               /* int4[n]: (axis type as AmoebaMultipoleForce::MultipoleAxisTypes, z atom, x atom, y atom; -1 = none) */
+    const double* thole;           /* [n] */
+    const double* damping;         /* [n] */
+    const double* polarity;        /* [n] */
+    /* pairs with scale factors different from one: CSR per atom (both directions), partners ascending; scales = (m, p, d, u) */
+    const int* special_start;      /* [n + 1] */
+    const int* special_atom;
+    const double* special_scale;   /* double4 per entry */
+    double cutoff, alpha;
+    /* work arrays, device, allocated by the caller */
+    double* lab_dipole;            /* [3n] */
+    double* lab_quadrupole;        /* [6n] */
+    double* field_d;               /* [3n] field of the permanent multipoles, d-scaled */
+    double* field_p;               /* [3n] ... p-scaled */
+    double* induced_d;             /* [3n] */
+    double* induced_p;             /* [3n] */
+    double* phi;                   /* [20n] reciprocal potential of the permanent multipoles and its derivatives up to third order (Cartesian) */
+    double* phi_induced;           /* [20n] the same for the induced dipoles (mu_d + mu_p) / 2 */
+    double* torque;                /* [3n] */
+    void* pme;                     /* const ommhip_pme*: grid sizes, box, moduli, eterm, real / complex grids, twiddles of the platform's PME */
+} ommhip_amoeba_multipole;
+
+/* Whole evaluation: frames -> reciprocal and real-space field -> induced dipoles -> energy, forces, torques -> forces. */
+int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp, const void* pos_d, const double box[6], const int* slot_of_atom_d, int padded_atoms,
+                                   long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
+/* Only as far as the induced dipoles (lab_dipole, induced_d, induced_p are left on the device): getInducedDipoles() and friends. */
+int ommhip_amoeba_multipole_induce(const ommhip_amoeba_multipole* mp, const void* pos_d, const double box[6], void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -316,6 +316,9 @@ int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, int padded_
  * phases as above (the collectives belong to OMMHIP_PME_AFTER_SPREAD). */
 int ommhip_pme_reciprocal_dd(const ommhip_pme* pme, const void* posq_d, int padded_atoms, int own_slot0, int own_slot1, const void* block_center_d,
                              const void* block_half_d, long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
+/* Only the middle: grid_real (charges, or multipole moments spread by somebody else) -> forward transform, influence function, backward
+ * transform -> grid_real (the reciprocal-space potential at the grid points).  Used by the AMOEBA multipole kernels (openmm_hip_amoeba.h). */
+int ommhip_pme_convolve(const ommhip_pme* pme, void* stream);
 /* test hook: forward (grid_real -> grid_complex) or backward (grid_complex -> grid_real) unnormalised 3-D transform */
 int ommhip_fft3d_r2c_c2r(const ommhip_pme* pme, int forward, void* stream);
 

@@ -1,10 +1,15 @@
 #include "HipAmoebaKernels.h"
 #include "openmm/AmoebaVdwForce.h"
+#include "openmm/AmoebaMultipoleForce.h"
+#include "openmm/NonbondedForce.h"
 #include "openmm/internal/AmoebaVdwForceImpl.h"
+#include "openmm/internal/NonbondedForceImpl.h"
 #include "openmm/internal/ContextImpl.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <set>
 #include <vector>
 
@@ -115,4 +120,276 @@ void HipCalcAmoebaVdwForceKernel::copyParametersToContext(ContextImpl& context, 
     if (numParticles != force.getNumParticles())
         throw OpenMMException("updateParametersInContext: The number of particles has changed");
     upload(force);
+}
+
+// ================================================================================================
+// AmoebaMultipoleForce (PME, direct polarization)
+// ================================================================================================
+namespace {
+vector<double> bsplineModuli(int n) {
+    // order-5 B-spline moduli, ReferencePME.cpp:98-193 (the convention of the platform's spread / FFT / influence-function kernels,
+    // which the AMOEBA kernels share): B-spline values at the knots, |DFT|^2, small moduli replaced by the mean of their neighbours
+    const int order = 5;
+    double data[order] = {1, 0, 0, 0, 0};
+    for (int k = 3; k <= order; k++) {
+        const double div = 1.0 / (k - 1.0);
+        data[k - 1] = 0;
+        for (int l = 1; l < k - 1; l++) data[k - l - 1] = div * (l * data[k - l - 2] + (k - l) * data[k - l - 1]);
+        data[0] = div * data[0];
+    }
+    vector<double> bs(max(n, order + 1), 0.0), mod(n);
+    for (int i = 1; i <= order; i++) bs[i] = data[i - 1];
+    for (int i = 0; i < n; i++) {
+        double sc = 0, ss = 0;
+        for (int j = 0; j < n; j++) {
+            const double arg = (2.0 * M_PI * i * j) / n;
+            sc += bs[j] * cos(arg);
+            ss += bs[j] * sin(arg);
+        }
+        mod[i] = sc * sc + ss * ss;
+    }
+    for (int i = 0; i < n; i++)
+        if (mod[i] < 1.0e-7) mod[i] = (mod[(i - 1 + n) % n] + mod[(i + 1) % n]) / 2;
+    // AMOEBA (Tinker) additionally applies the "optimal zeta" correction of the interpolation error to every modulus
+    // (AmoebaReferencePmeMultipoleForce::initializeBSplineModuli, AmoebaReferenceMultipoleForce.cpp:5048-5075)
+    const int jcut = 50;
+    for (int i = 0; i < n; i++) {
+        const int k = i + 1 > n / 2 ? i - n : i;
+        if (k == 0) continue;
+        double sum1 = 1.0, sum2 = 1.0;
+        const double factor = M_PI * k / n;
+        for (int j = 1; j <= jcut; j++) {
+            const double up = factor / (factor + M_PI * j), down = factor / (factor - M_PI * j);
+            sum1 += pow(up, order) + pow(down, order);
+            sum2 += pow(up, 2 * order) + pow(down, 2 * order);
+        }
+        const double zeta = sum2 / sum1;
+        mod[i] *= zeta * zeta;
+    }
+    return mod;
+}
+}
+
+HipCalcAmoebaMultipoleForceKernel::HipCalcAmoebaMultipoleForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data, KernelImpl* referenceKernel) :
+        CalcAmoebaMultipoleForceKernel(name, platform), data(data), reference(dynamic_cast<CalcAmoebaMultipoleForceKernel*>(referenceKernel)) {
+    memset(&mp, 0, sizeof(mp));
+    memset(&pme, 0, sizeof(pme));
+}
+
+HipCalcAmoebaMultipoleForceKernel::~HipCalcAmoebaMultipoleForceKernel() {
+    delete reference;
+}
+
+bool HipCalcAmoebaMultipoleForceKernel::supports(const AmoebaMultipoleForce& force, const System& system) {
+    if (getenv("OPENMM_HIP_REFERENCE_AMOEBA_MULTIPOLE") != NULL) return false;          // A/B knob: always the Reference kernel
+    if (force.getNonbondedMethod() != AmoebaMultipoleForce::PME || force.getPolarizationType() != AmoebaMultipoleForce::Direct) return false;
+    double alpha; int nx, ny, nz;
+    force.getPMEParameters(alpha, nx, ny, nz);
+    if (nx == 0 || alpha == 0.0) {
+        NonbondedForce nb;
+        nb.setEwaldErrorTolerance(force.getEwaldErrorTolerance());
+        nb.setCutoffDistance(force.getCutoffDistance());
+        NonbondedForceImpl::calcPMEParameters(system, nb, alpha, nx, ny, nz, false);
+    }
+    // the Reference transforms whatever grid it is given (fftpack); the platform's FFT wants 2-3-5-7-smooth sizes, even along z
+    return ommhip_fft_supported_size(nx) && ommhip_fft_supported_size(ny) && ommhip_fft_supported_size(nz) && nz % 2 == 0;
+}
+
+void HipCalcAmoebaMultipoleForceKernel::initialize(const System& system, const AmoebaMultipoleForce& force) {
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    numParticles = force.getNumMultipoles();
+    if (numParticles != system.getNumParticles())
+        throw OpenMMException("AmoebaMultipoleForce must have exactly as many particles as the System it belongs to.");
+    // AmoebaReferenceKernels.cpp:241-262
+    force.getPMEParameters(alphaEwald, gridSize[0], gridSize[1], gridSize[2]);
+    cutoff = force.getCutoffDistance();
+    if (gridSize[0] == 0 || alphaEwald == 0.0) {
+        NonbondedForce nb;
+        nb.setEwaldErrorTolerance(force.getEwaldErrorTolerance());
+        nb.setCutoffDistance(force.getCutoffDistance());
+        NonbondedForceImpl::calcPMEParameters(system, nb, alphaEwald, gridSize[0], gridSize[1], gridSize[2], false);
+    }
+    hip.usePeriodic = true;
+    if (reference != NULL) reference->initialize(system, force);
+    // ---- the platform's PME machinery on a grid of its own
+    const int nx = gridSize[0], ny = gridSize[1], nz = gridSize[2], nzc = nz / 2 + 1;
+    uploadVector(moduliX, bsplineModuli(nx), hip.stream);
+    uploadVector(moduliY, bsplineModuli(ny), hip.stream);
+    uploadVector(moduliZ, bsplineModuli(nz), hip.stream);
+    DeviceBuffer* tw[3] = {&twiddleX, &twiddleY, &twiddleZ};
+    for (int d = 0; d < 3; d++) {
+        const int n = gridSize[d];
+        vector<float> t(2 * (size_t) n);
+        for (int k = 0; k < n; k++) { t[2 * k] = (float) cos(2.0 * M_PI * k / n); t[2 * k + 1] = (float) -sin(2.0 * M_PI * k / n); }
+        uploadVector(*tw[d], t, hip.stream);
+    }
+    eterm.allocate(sizeof(float) * (size_t) nx * ny * nzc);
+    gridReal.allocate((sizeof(float) * (size_t) nx * ny * nz + 15) / 16 * 16);
+    gridComplex.allocate(sizeof(float) * 2 * (size_t) nx * ny * nzc);
+    pme.nx = nx; pme.ny = ny; pme.nz = nz; pme.alpha = alphaEwald;
+    pme.moduli_x = moduliX.as<double>(); pme.moduli_y = moduliY.as<double>(); pme.moduli_z = moduliZ.as<double>();
+    pme.eterm = eterm.ptr; pme.grid_real = gridReal.ptr; pme.grid_complex = gridComplex.ptr;
+    pme.twiddle_x = twiddleX.ptr; pme.twiddle_y = twiddleY.ptr; pme.twiddle_z = twiddleZ.ptr;
+    etermBuilt = false;
+    const size_t n = (size_t) max(numParticles, 1);
+    labDipole.allocate(sizeof(double) * 3 * n); labQuad.allocate(sizeof(double) * 6 * n);
+    fieldD.allocate(sizeof(double) * 3 * n); fieldP.allocate(sizeof(double) * 3 * n);
+    indD.allocate(sizeof(double) * 3 * n); indP.allocate(sizeof(double) * 3 * n);
+    phi.allocate(sizeof(double) * 20 * n); phiInd.allocate(sizeof(double) * 20 * n); torque.allocate(sizeof(double) * 3 * n);
+    upload(force);
+}
+
+void HipCalcAmoebaMultipoleForceKernel::upload(const AmoebaMultipoleForce& force) {
+    HipContext& hip = *data.hip;
+    // AmoebaReferenceKernels.cpp:170-231 (per-particle data) and AmoebaReferenceMultipoleForce::setupScaleMaps (:181-241)
+    vector<double> q(numParticles), d(3 * (size_t) numParticles), quad(6 * (size_t) numParticles), th(numParticles), dampF(numParticles), pol(numParticles);
+    vector<int> ax(4 * (size_t) numParticles);
+    vector<vector<vector<int> > > covalent(numParticles);
+    for (int i = 0; i < numParticles; i++) {
+        int axisType, atomZ, atomX, atomY;
+        vector<double> dip, qd;
+        force.getMultipoleParameters(i, q[i], dip, qd, axisType, atomZ, atomX, atomY, th[i], dampF[i], pol[i]);
+        for (int k = 0; k < 3; k++) d[3 * i + k] = dip[k];
+        quad[6 * i] = qd[0]; quad[6 * i + 1] = qd[1]; quad[6 * i + 2] = qd[2]; quad[6 * i + 3] = qd[4]; quad[6 * i + 4] = qd[5]; quad[6 * i + 5] = qd[8];
+        ax[4 * i] = axisType; ax[4 * i + 1] = atomZ; ax[4 * i + 2] = atomX; ax[4 * i + 3] = atomY;
+        force.getCovalentMaps(i, covalent[i]);
+    }
+    // scale factors of the covalently related pairs: (m, p, d, u), defined by the lists of the atom with the lower index (as the Reference
+    // looks them up), stored for both atoms of a pair
+    const double mScale[5] = {0.0, 0.0, 0.0, 0.4, 0.8}, pScale[5] = {0.0, 0.0, 0.0, 1.0, 1.0}, dScale[4] = {0.0, 1.0, 1.0, 1.0}, uScale[4] = {1.0, 1.0, 1.0, 1.0};
+    vector<map<int, vector<double> > > special(numParticles);
+    for (int i = 0; i < numParticles; i++) {
+        const vector<vector<int> >& info = covalent[i];
+        const vector<int>& p11 = info[AmoebaMultipoleForce::PolarizationCovalent11];
+        for (int list = 0; list < AmoebaMultipoleForce::PolarizationCovalent11; list++)
+            for (int j : info[list]) {
+                if (j < i) continue;
+                const bool half = list == AmoebaMultipoleForce::Covalent14 && find(p11.begin(), p11.end(), j) != p11.end();
+                vector<double>& s = special[i].insert(make_pair(j, vector<double>(4, 1.0))).first->second;
+                s[0] = mScale[list + 1]; s[1] = half ? 0.5 * pScale[list + 1] : pScale[list + 1];
+            }
+        for (int list = AmoebaMultipoleForce::PolarizationCovalent11; list < (int) info.size(); list++)
+            for (int j : info[list]) {
+                if (j < i) continue;
+                vector<double>& s = special[i].insert(make_pair(j, vector<double>(4, 1.0))).first->second;
+                s[2] = dScale[list - 4]; s[3] = uScale[list - 4];
+            }
+    }
+    for (int i = 0; i < numParticles; i++)
+        for (map<int, vector<double> >::const_iterator it = special[i].begin(); it != special[i].end(); ++it)
+            if (it->first > i) special[it->first][i] = it->second;
+    vector<int> start(numParticles + 1, 0), atoms;
+    vector<double> scales;
+    for (int i = 0; i < numParticles; i++) {
+        for (map<int, vector<double> >::const_iterator it = special[i].begin(); it != special[i].end(); ++it) {
+            if (it->first == i) continue;
+            atoms.push_back(it->first);
+            scales.insert(scales.end(), it->second.begin(), it->second.end());
+        }
+        start[i + 1] = (int) atoms.size();
+    }
+    uploadVector(charge, q, hip.stream); uploadVector(molDipole, d, hip.stream); uploadVector(molQuad, quad, hip.stream); uploadVector(axis, ax, hip.stream);
+    uploadVector(thole, th, hip.stream); uploadVector(damping, dampF, hip.stream); uploadVector(polarity, pol, hip.stream);
+    uploadVector(specStart, start, hip.stream); uploadVector(specAtom, atoms, hip.stream); uploadVector(specScale, scales, hip.stream);
+    mp.num_atoms = numParticles;
+    mp.charge = charge.as<double>(); mp.mol_dipole = molDipole.as<double>(); mp.mol_quadrupole = molQuad.as<double>(); mp.axis = axis.as<int>();
+    mp.thole = thole.as<double>(); mp.damping = damping.as<double>(); mp.polarity = polarity.as<double>();
+    mp.special_start = specStart.as<int>(); mp.special_atom = specAtom.as<int>(); mp.special_scale = specScale.as<double>();
+    mp.cutoff = cutoff; mp.alpha = alphaEwald;
+    mp.lab_dipole = labDipole.as<double>(); mp.lab_quadrupole = labQuad.as<double>(); mp.field_d = fieldD.as<double>(); mp.field_p = fieldP.as<double>();
+    mp.induced_d = indD.as<double>(); mp.induced_p = indP.as<double>(); mp.phi = phi.as<double>(); mp.phi_induced = phiInd.as<double>(); mp.torque = torque.as<double>();
+    mp.pme = &pme;
+}
+
+void HipCalcAmoebaMultipoleForceKernel::prepareGrid() {
+    HipContext& hip = *data.hip;
+    bool boxChanged = !etermBuilt;
+    for (int k = 0; k < 6; k++) if (lastBox[k] != hip.box[k]) boxChanged = true;
+    for (int k = 0; k < 6; k++) { pme.box[k] = hip.box[k]; lastBox[k] = hip.box[k]; }
+    if (boxChanged) { HIP_CHECK(ommhip_pme_build_eterm(&pme, hip.stream)); etermBuilt = true; }
+    const double minAllowedSize = 1.999999 * cutoff;
+    if (hip.box[0] < minAllowedSize || hip.box[2] < minAllowedSize || hip.box[5] < minAllowedSize)
+        throw OpenMMException("The periodic box size has decreased to less than twice the nonbonded cutoff.");
+}
+
+double HipCalcAmoebaMultipoleForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy) {
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    prepareGrid();
+    hip.ensureCleared();
+    HIP_CHECK(ommhip_amoeba_multipole_forces(&mp, hip.pos.ptr, hip.box, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.force.as<long long>(),
+                                             hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream));
+    nativeEvaluations[1]++;
+    return 0.0;        // summed on the device (HipCalcForcesAndEnergyKernel::finishComputation)
+}
+
+void HipCalcAmoebaMultipoleForceKernel::induce() {
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    prepareGrid();
+    HIP_CHECK(ommhip_amoeba_multipole_induce(&mp, hip.pos.ptr, hip.box, hip.stream));
+}
+
+void HipCalcAmoebaMultipoleForceKernel::download3(DeviceBuffer& buffer, vector<Vec3>& out) {
+    HipContext& hip = *data.hip;
+    vector<double> tmp(3 * (size_t) max(numParticles, 1));
+    HIP_CHECK(ommhip_memcpy_d2h(tmp.data(), buffer.ptr, sizeof(double) * 3 * (size_t) numParticles, hip.stream));
+    hip.sync();
+    out.resize(numParticles);
+    for (int i = 0; i < numParticles; i++) out[i] = Vec3(tmp[3 * i], tmp[3 * i + 1], tmp[3 * i + 2]);
+}
+
+void HipCalcAmoebaMultipoleForceKernel::getLabFramePermanentDipoles(ContextImpl& context, vector<Vec3>& dipoles) {
+    induce();
+    download3(labDipole, dipoles);
+}
+
+void HipCalcAmoebaMultipoleForceKernel::getInducedDipoles(ContextImpl& context, vector<Vec3>& dipoles) {
+    induce();
+    download3(indD, dipoles);
+}
+
+void HipCalcAmoebaMultipoleForceKernel::getTotalDipoles(ContextImpl& context, vector<Vec3>& dipoles) {
+    vector<Vec3> induced;
+    induce();
+    download3(labDipole, dipoles);
+    download3(indD, induced);
+    for (int i = 0; i < numParticles; i++) dipoles[i] += induced[i];
+}
+
+void HipCalcAmoebaMultipoleForceKernel::syncHostPositions(ContextImpl& context) {
+    // the Reference kernel reads the host copy of the state (ReferencePlatform::PlatformData)
+    HipContext& hip = *data.hip;
+    if (!hip.hostMode) {
+        hip.downloadPositions(*data.positions);
+        Vec3 a, b, c;
+        hip.getBox(a, b, c);
+        data.periodicBoxVectors[0] = a; data.periodicBoxVectors[1] = b; data.periodicBoxVectors[2] = c;
+        *data.periodicBoxSize = Vec3(a[0], b[1], c[2]);
+    }
+}
+
+void HipCalcAmoebaMultipoleForceKernel::getElectrostaticPotential(ContextImpl& context, const vector<Vec3>& inputGrid, vector<double>& outputElectrostaticPotential) {
+    if (reference == NULL) throw OpenMMException("HIP platform: getElectrostaticPotential needs the AMOEBA plugin's Reference kernels");
+    syncHostPositions(context);
+    reference->getElectrostaticPotential(context, inputGrid, outputElectrostaticPotential);
+}
+
+void HipCalcAmoebaMultipoleForceKernel::getSystemMultipoleMoments(ContextImpl& context, vector<double>& outputMultipoleMoments) {
+    if (reference == NULL) throw OpenMMException("HIP platform: getSystemMultipoleMoments needs the AMOEBA plugin's Reference kernels");
+    syncHostPositions(context);
+    reference->getSystemMultipoleMoments(context, outputMultipoleMoments);
+}
+
+void HipCalcAmoebaMultipoleForceKernel::copyParametersToContext(ContextImpl& context, const AmoebaMultipoleForce& force) {
+    if (numParticles != force.getNumMultipoles())
+        throw OpenMMException("updateParametersInContext: The number of multipoles has changed");
+    data.hip->setAsCurrent();
+    upload(force);
+    if (reference != NULL) reference->copyParametersToContext(context, force);
+}
+
+void HipCalcAmoebaMultipoleForceKernel::getPMEParameters(double& alpha, int& nx, int& ny, int& nz) const {
+    alpha = alphaEwald; nx = gridSize[0]; ny = gridSize[1]; nz = gridSize[2];
 }

@@ -30,5 +30,42 @@ private:
     DeviceBuffer parent, reduction, type, sigma, epsilon, exclStart, exclAtoms, alchemical, reduced;
 };
 
+/** amoebaKernels.h:82-139 CalcAmoebaMultipoleForceKernel for PME with direct polarization; Reference: AmoebaReferenceKernels.cpp:170-520 +
+ *  AmoebaReferencePmeMultipoleForce.  The factory hands every other configuration (NoCutoff, mutual / extrapolated polarization, grids
+ *  the platform's FFT does not take) to the AMOEBA plugin's own Reference kernel; so does this class for the two queries it does not
+ *  compute itself (electrostatic potential on a grid of points, system multipole moments). */
+class HipCalcAmoebaMultipoleForceKernel : public CalcAmoebaMultipoleForceKernel {
+public:
+    HipCalcAmoebaMultipoleForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data, KernelImpl* referenceKernel);
+    ~HipCalcAmoebaMultipoleForceKernel();
+    /** Can this force be computed natively?  (PME, direct polarization, FFT-friendly grid, rectangular or triclinic box.) */
+    static bool supports(const AmoebaMultipoleForce& force, const System& system);
+    void initialize(const System& system, const AmoebaMultipoleForce& force);
+    double execute(ContextImpl& context, bool includeForces, bool includeEnergy);
+    void getLabFramePermanentDipoles(ContextImpl& context, std::vector<Vec3>& dipoles);
+    void getInducedDipoles(ContextImpl& context, std::vector<Vec3>& dipoles);
+    void getTotalDipoles(ContextImpl& context, std::vector<Vec3>& dipoles);
+    void getElectrostaticPotential(ContextImpl& context, const std::vector<Vec3>& inputGrid, std::vector<double>& outputElectrostaticPotential);
+    void getSystemMultipoleMoments(ContextImpl& context, std::vector<double>& outputMultipoleMoments);
+    void copyParametersToContext(ContextImpl& context, const AmoebaMultipoleForce& force);
+    void getPMEParameters(double& alpha, int& nx, int& ny, int& nz) const;
+private:
+    void upload(const AmoebaMultipoleForce& force);
+    void prepareGrid();
+    void induce();
+    void download3(DeviceBuffer& buffer, std::vector<Vec3>& out);
+    void syncHostPositions(ContextImpl& context);
+    HipPlatform::PlatformData& data;
+    CalcAmoebaMultipoleForceKernel* reference;      // the AMOEBA plugin's Reference kernel (for the two queries above), owned
+    int numParticles = 0, gridSize[3] = {0, 0, 0};
+    double alphaEwald = 0, cutoff = 0, lastBox[6] = {0, 0, 0, 0, 0, 0};
+    bool etermBuilt = false;
+    ommhip_amoeba_multipole mp;
+    ommhip_pme pme;
+    DeviceBuffer charge, molDipole, molQuad, axis, thole, damping, polarity, specStart, specAtom, specScale;
+    DeviceBuffer labDipole, labQuad, fieldD, fieldP, indD, indP, phi, phiInd, torque;
+    DeviceBuffer moduliX, moduliY, moduliZ, twiddleX, twiddleY, twiddleZ, eterm, gridReal, gridComplex;
+};
+
 }  // namespace OpenMM
 #endif

@@ -1,0 +1,643 @@
+// AmoebaMultipoleForce with PME on the OpenMM "HIP" platform (include/openmm_hip_amoeba.h): permanent multipoles up to quadrupoles,
+// induced dipoles (direct polarization), Ewald-split, double precision on the atom side and the platform's float32 grids + FFT.
+//
+// Oracle: AmoebaReferencePmeMultipoleForce (plugins/amoeba/platforms/reference/src/SimTKReference/AmoebaReferenceMultipoleForce.cpp;
+// the functions are cited where they are restated).  The pair arithmetic is NOT the Reference's: that one rotates every pair into a
+// quasi-internal frame and works with spherical harmonics (:6335-6751).  Here every pair term is written as
+//
+//     W(A, B; f) = L_A L_B f(|r|),   r = r_B - r_A,   L_A = q_A - mu_A . grad + Q_A : grad grad,   L_B = q_B + mu_B . grad + Q_B : grad grad
+//
+// for a radial kernel f that enters only through the chain B_0 = f, B_(n+1) = -(1/r) dB_n/dr:
+//     grad^n f  =  sum over pairings of  (+-) B_k  x  (products of r and Kronecker deltas),
+// and one device function (mpole_pair) returns W, the force on site A and the torque on A's multipoles for ANY chain.  AMOEBA then
+// needs three chains per pair, all consistent derivative chains of their own scalar kernels:
+//     m:  erfc(alpha r)/r  -  (1 - m_ij) / r                                  permanent  x  permanent
+//     p:  erfc(alpha r)/r  -  (1 - p_ij lambda(r)) / r   (lambda: Thole)      permanent  x  induced dipoles "d"   (p-scaled field)
+//     d:  the same with d_ij                                                 permanent  x  induced dipoles "p"
+// With direct polarization mu_d = alpha E_d, mu_p = alpha E_p (fields of the permanent multipoles through chains d / p, plus the
+// reciprocal field and the self term) the polarization energy -1/2 sum mu_d . E_p equals 1/2 sum_pairs (W1 + W2 + W3 + W4) with
+//     W1 = W(mu_d,i / 2, M_j; p)   W2 = W(mu_p,i / 2, M_j; d)   W3 = W(M_i, mu_d,j / 2; p)   W4 = W(M_i, mu_p,j / 2; d)
+// (the form the Reference sums, :6456-6751), and its gradient at fixed dipoles is that of W1 + ... + W4 (no factor 1/2):
+//     dU = -1/2 sum (mu_p . dE_d + mu_d . dE_p).
+//
+// Wave64 formulation: one thread owns atom i and walks through all atoms j, 128 at a time staged in LDS (every lane reads the same
+// j: LDS broadcast); every pair is seen from both of its atoms, so a thread accumulates field / force / torque of its own atom only
+// and the loops hold no atomics.  This first native slice is O(N^2) in the pair scan (the distance test is cheap, the multipole
+// algebra runs only inside the cutoff); putting it on the tiled neighbour list of the NonbondedForce kernels is the next step.
+#include "common.h"
+#include "../../../include/openmm_hip_amoeba.h"
+#include "../../../include/openmm_hip_kernels.h"
+
+using namespace omm;
+
+namespace {
+
+#define MP_BLOCK 128
+#define MP_SQRT_PI 1.77245385090551602730
+
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 v3(double x, double y, double z) { V3 r = {x, y, z}; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ double normalize(V3& a) { const double n = sqrt(dot(a, a)); const double inv = n > 0 ? 1.0 / n : 0.0; a = a * inv; return n; }
+
+// symmetric 3x3 as (xx, xy, xz, yy, yz, zz)
+struct Sym { double xx, xy, xz, yy, yz, zz; };
+__device__ __forceinline__ V3 mul(const Sym& q, V3 v) { return v3(q.xx * v.x + q.xy * v.y + q.xz * v.z, q.xy * v.x + q.yy * v.y + q.yz * v.z, q.xz * v.x + q.yz * v.y + q.zz * v.z); }
+__device__ __forceinline__ double ddot(const Sym& a, const Sym& b) { return a.xx * b.xx + a.yy * b.yy + a.zz * b.zz + 2.0 * (a.xy * b.xy + a.xz * b.xz + a.yz * b.yz); }
+// antisymmetric part of the product A B of two symmetric matrices as a vector: ((AB)_yz - (AB)_zy, (AB)_zx - (AB)_xz, (AB)_xy - (AB)_yx)
+__device__ __forceinline__ V3 asym_product(const Sym& a, const Sym& b) {
+    const double yz = a.xy * b.xz + a.yy * b.yz + a.yz * b.zz, zy = a.xz * b.xy + a.yz * b.yy + a.zz * b.yz;
+    const double zx = a.xz * b.xx + a.yz * b.xy + a.zz * b.xz, xz = a.xx * b.xz + a.xy * b.yz + a.xz * b.zz;
+    const double xy = a.xx * b.xy + a.xy * b.yy + a.xz * b.yz, yx = a.xy * b.xx + a.yy * b.xy + a.yz * b.xz;
+    return v3(yz - zy, zx - xz, xy - yx);
+}
+
+struct Site { double q; V3 mu; Sym Q; };
+
+// W = L_A L_B f, the force on site A (= -dW/dr_A) and the torque on A's multipoles, for the kernel given by its chain B[0..5].
+// Quadrupoles are traceless (AMOEBA's are: rotations of a traceless local-frame tensor).
+__device__ __forceinline__ void mpole_pair(const Site& A, const Site& Bs, const V3 r, const double* B, double& W, V3& force, V3& torque) {
+    const V3 QAr = mul(A.Q, r), QBr = mul(Bs.Q, r);
+    const double muAr = dot(A.mu, r), muBr = dot(Bs.mu, r), rQAr = dot(r, QAr), rQBr = dot(r, QBr);
+    const double S1 = -Bs.q * B[1] + B[2] * muBr - B[3] * rQBr;
+    const double S2 = Bs.q * B[2] - B[3] * muBr + B[4] * rQBr;
+    const double S3 = -Bs.q * B[3] + B[4] * muBr - B[5] * rQBr;
+    const double phi = Bs.q * B[0] - B[1] * muBr + B[2] * rQBr;
+    const V3 gradPhi = S1 * r - B[1] * Bs.mu + 2.0 * B[2] * QBr;                       // the field of B at A (r-derivative of its potential)
+    const double muAmuB = dot(A.mu, Bs.mu), muAQBr = dot(A.mu, QBr), muBQAr = dot(Bs.mu, QAr), QArQBr = dot(QAr, QBr), QAQB = ddot(A.Q, Bs.Q);
+    const V3 QAmuB = mul(A.Q, Bs.mu), QBmuA = mul(Bs.Q, A.mu), QAQBr = mul(A.Q, QBr), QBQAr = mul(Bs.Q, QAr);
+    W = A.q * phi - dot(A.mu, gradPhi) + (S2 * rQAr + 2.0 * B[2] * muBQAr - 4.0 * B[3] * QArQBr + 2.0 * B[2] * QAQB);
+    // mu_A . Hessian(phi)
+    const V3 muAH = (S2 * muAr + B[2] * muAmuB - 2.0 * B[3] * muAQBr) * r + (B[2] * muAr) * Bs.mu - (2.0 * B[3] * muAr) * QBr + S1 * A.mu + 2.0 * B[2] * QBmuA;
+    // Q_A : third derivatives of phi
+    const V3 QAD = (S3 * rQAr - 2.0 * B[3] * muBQAr + 4.0 * B[4] * QArQBr - 2.0 * B[3] * QAQB) * r - (B[3] * rQAr) * Bs.mu + (2.0 * B[4] * rQAr) * QBr
+                   + (2.0 * S2) * QAr + (2.0 * B[2]) * QAmuB - (4.0 * B[3]) * (QBQAr + QAQBr);
+    force = A.q * gradPhi - muAH + QAD;
+    torque = cross(A.mu, gradPhi)
+             - 2.0 * (S2 * cross(QAr, r) + B[2] * (cross(QAmuB, r) + cross(QAr, Bs.mu)) - 2.0 * B[3] * (cross(QAQBr, r) + cross(QAr, QBr)) + 2.0 * B[2] * asym_product(A.Q, Bs.Q));
+}
+
+struct MpArgs {
+    int n, paddedAtoms, includeEnergy, energySlots, nx, ny, nz;
+    const double4* pos;
+    const double* charge; const double* molDipole; const double* molQuad; const int4* axis;
+    const double* thole; const double* damping; const double* polarity;
+    const int* specStart; const int* specAtom; const double4* specScale;
+    double cutoff2, alpha;
+    double* labDipole; double* labQuad; double* fieldD; double* fieldP; double* indD; double* indP; double* phi; double* phiInd; double* torque;
+    BoxD box;
+    double a[3][3];            // a[k][c] = d(grid coordinate k) / d(Cartesian c) = n_k * recip[c][k]
+    float* grid;
+    const int* slotOfAtom;
+    omm_fixed* force;
+    double* energyBuffer;
+};
+
+__device__ __forceinline__ V3 load3(const double* p, int i) { return v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+__device__ __forceinline__ void store3(double* p, int i, V3 v) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; }
+__device__ __forceinline__ Sym load6(const double* p, int i) { Sym q = {p[6 * i], p[6 * i + 1], p[6 * i + 2], p[6 * i + 3], p[6 * i + 4], p[6 * i + 5]}; return q; }
+__device__ __forceinline__ V3 position(const MpArgs& a, int i) { const double4 p = a.pos[i]; return v3(p.x, p.y, p.z); }
+
+// ------------------------------------------------------------------------------------------------
+// Local frames -> lab-frame multipoles.  AmoebaReferenceMultipoleForce::checkChiralCenterAtParticle (:354-378) and
+// applyRotationMatrixToParticle (:396-503); positions are used as they are (molecules are whole), as there.
+// axis types (AmoebaMultipoleForce::MultipoleAxisTypes): 0 ZThenX, 1 Bisector, 2 ZBisect, 3 ThreeFold, 4 ZOnly, 5 NoAxisType
+// ------------------------------------------------------------------------------------------------
+__global__ void k_mp_frames(MpArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int4 ax = a.axis[i];
+    V3 d = load3(a.molDipole, i);
+    Sym q = load6(a.molQuad, i);
+    store3(a.torque, i, v3(0, 0, 0));
+    if (ax.x == 5 || ax.y < 0) { store3(a.labDipole, i, d); for (int k = 0; k < 6; k++) a.labQuad[6 * i + k] = a.molQuad[6 * i + k]; return; }
+    const V3 xi = position(a, i);
+    if (ax.x == 0 && ax.w >= 0 && ax.z >= 0) {
+        // an inverted chiral centre flips the y components
+        const V3 py = position(a, ax.w);
+        const V3 ad = xi - py, bd = position(a, ax.y) - py, cd = position(a, ax.z) - py;
+        if (dot(cross(bd, cd), ad) < 0.0) { d.y = -d.y; q.xy = -q.xy; q.yz = -q.yz; }
+    }
+    V3 vz = position(a, ax.y) - xi, vx, vy;
+    normalize(vz);
+    if (ax.x == 4) vx = fabs(vz.x) < 0.866 ? v3(1, 0, 0) : v3(0, 1, 0);
+    else {
+        vx = position(a, ax.z) - xi;
+        if (ax.x == 1) { normalize(vx); vz = vz + vx; normalize(vz); }
+        else if (ax.x == 2) { normalize(vx); vy = position(a, ax.w) - xi; normalize(vy); vx = vx + vy; normalize(vx); }
+        else if (ax.x == 3) { normalize(vx); vy = position(a, ax.w) - xi; normalize(vy); vz = vz + vx + vy; normalize(vz); }
+    }
+    vx = vx - vz * dot(vz, vx);
+    normalize(vx);
+    vy = cross(vz, vx);
+    // lab = R^T local with rows of R = (vx, vy, vz)
+    store3(a.labDipole, i, d.x * vx + d.y * vy + d.z * vz);
+    const double R[3][3] = {{vx.x, vx.y, vx.z}, {vy.x, vy.y, vy.z}, {vz.x, vz.y, vz.z}};
+    const double m[3][3] = {{q.xx, q.xy, q.xz}, {q.xy, q.yy, q.yz}, {q.xz, q.yz, q.zz}};
+    double lab[3][3];
+    for (int c = 0; c < 3; c++)
+        for (int e = c; e < 3; e++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++)
+                for (int l = 0; l < 3; l++) s += R[k][c] * R[l][e] * m[k][l];
+            lab[c][e] = s;
+        }
+    a.labQuad[6 * i] = lab[0][0]; a.labQuad[6 * i + 1] = lab[0][1]; a.labQuad[6 * i + 2] = lab[0][2];
+    a.labQuad[6 * i + 3] = lab[1][1]; a.labQuad[6 * i + 4] = lab[1][2]; a.labQuad[6 * i + 5] = lab[2][2];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Order-5 B-spline weights of one coordinate and their first three derivatives with respect to the grid coordinate.
+// Same index convention as pme.hip (bspline): grid points index + 0..4 (mod n).  The k-th derivative of the order-5 spline is the
+// k-th backward difference of the order-(5 - k) spline.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bspline4(double u, int n, int& index, double (&th)[4][5]) {
+    const int ti = (int) floor(u);
+    const double w = u - ti;
+    index = ((ti % n) + n) % n;
+    double o2[2] = {1.0 - w, w};
+    double o3[3], o4[4], o5[5];
+    o3[0] = 0.5 * (1.0 - w) * o2[0]; o3[1] = 0.5 * ((w + 1.0) * o2[0] + (2.0 - w) * o2[1]); o3[2] = 0.5 * w * o2[1];
+    o4[0] = (1.0 / 3.0) * (1.0 - w) * o3[0];
+    o4[1] = (1.0 / 3.0) * ((w + 2.0) * o3[0] + (2.0 - w) * o3[1]);
+    o4[2] = (1.0 / 3.0) * ((w + 1.0) * o3[1] + (3.0 - w) * o3[2]);
+    o4[3] = (1.0 / 3.0) * w * o3[2];
+    o5[0] = 0.25 * (1.0 - w) * o4[0];
+    o5[1] = 0.25 * ((w + 3.0) * o4[0] + (2.0 - w) * o4[1]);
+    o5[2] = 0.25 * ((w + 2.0) * o4[1] + (3.0 - w) * o4[2]);
+    o5[3] = 0.25 * ((w + 1.0) * o4[2] + (4.0 - w) * o4[3]);
+    o5[4] = 0.25 * w * o4[3];
+    for (int k = 0; k < 5; k++) {
+        th[0][k] = o5[k];
+        const double a1 = k >= 1 ? o4[k - 1] : 0.0, a0 = k <= 3 ? o4[k] : 0.0;
+        th[1][k] = a1 - a0;
+        const double b2 = k >= 2 ? o3[k - 2] : 0.0, b1 = (k >= 1 && k <= 3) ? o3[k - 1] : 0.0, b0 = k <= 2 ? o3[k] : 0.0;
+        th[2][k] = b2 - 2.0 * b1 + b0;
+        const double c3 = k >= 3 ? o2[k - 3] : 0.0, c2 = (k >= 2 && k <= 3) ? o2[k - 2] : 0.0, c1 = (k >= 1 && k <= 2) ? o2[k - 1] : 0.0, c0 = k <= 1 ? o2[k] : 0.0;
+        th[3][k] = c3 - 3.0 * c2 + 3.0 * c1 - c0;
+    }
+}
+
+__device__ __forceinline__ void atom_splines(const MpArgs& a, V3 x, int (&idx)[3], double (&th)[3][4][5]) {
+    // grid coordinates u_k = sum_c a[k][c] x_c, wrapped into [0, n_k)
+    const int n[3] = {a.nx, a.ny, a.nz};
+    for (int k = 0; k < 3; k++) {
+        double u = a.a[k][0] * x.x + a.a[k][1] * x.y + a.a[k][2] * x.z;
+        u -= floor(u / n[k]) * n[k];
+        bspline4(u, n[k], idx[k], th[k]);
+    }
+}
+
+// Spreads L_i W(g; r_i) = [q + mu . grad_i + Q : grad_i grad_i] W for the permanent multipoles (INDUCED = false) or the dipoles
+// (mu_d + mu_p) / 2 (INDUCED = true) onto the float grid.  AmoebaReferencePmeMultipoleForce::spreadFixedMultipolesOntoGrid (:5380-5423),
+// spreadInducedDipolesOnGrid (:5572-5616); derivatives with respect to the atom position through the chain rule a[k][c].
+template <bool INDUCED>
+__global__ void k_mp_spread(MpArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    int idx[3];
+    double th[3][4][5];
+    atom_splines(a, position(a, i), idx, th);
+    const double q = INDUCED ? 0.0 : a.charge[i];
+    const V3 mu = INDUCED ? 0.5 * (load3(a.indD, i) + load3(a.indP, i)) : load3(a.labDipole, i);
+    // fractional moments: d_k = sum_c a[k][c] mu_c,  Q_kl = sum_cd a[k][c] a[l][d] Q_cd
+    double fd[3], fq[3][3];
+    const double muc[3] = {mu.x, mu.y, mu.z};
+    for (int k = 0; k < 3; k++) fd[k] = a.a[k][0] * muc[0] + a.a[k][1] * muc[1] + a.a[k][2] * muc[2];
+    if (!INDUCED) {
+        const Sym Q = load6(a.labQuad, i);
+        const double m[3][3] = {{Q.xx, Q.xy, Q.xz}, {Q.xy, Q.yy, Q.yz}, {Q.xz, Q.yz, Q.zz}};
+        for (int k = 0; k < 3; k++)
+            for (int l = 0; l < 3; l++) {
+                double s = 0;
+                for (int c = 0; c < 3; c++)
+                    for (int d = 0; d < 3; d++) s += a.a[k][c] * a.a[l][d] * m[c][d];
+                fq[k][l] = s;
+            }
+    }
+    for (int ix = 0; ix < 5; ix++) {
+        const int gx = (idx[0] + ix) % a.nx;
+        for (int iy = 0; iy < 5; iy++) {
+            const int gy = (idx[1] + iy) % a.ny;
+            const double t0 = th[0][0][ix], t1 = th[0][1][ix], t2 = th[0][2][ix], u0 = th[1][0][iy], u1 = th[1][1][iy], u2 = th[1][2][iy];
+            double term0, term1, term2 = 0.0;
+            if (INDUCED) { term0 = fd[0] * t1 * u0 + fd[1] * t0 * u1; term1 = fd[2] * t0 * u0; }
+            else {
+                term0 = q * t0 * u0 + fd[0] * t1 * u0 + fd[1] * t0 * u1 + fq[0][0] * t2 * u0 + fq[1][1] * t0 * u2 + 2.0 * fq[0][1] * t1 * u1;
+                term1 = fd[2] * t0 * u0 + 2.0 * fq[0][2] * t1 * u0 + 2.0 * fq[1][2] * t0 * u1;
+                term2 = fq[2][2] * t0 * u0;
+            }
+            for (int iz = 0; iz < 5; iz++) {
+                const int gz = (idx[2] + iz) % a.nz;
+                const double v = term0 * th[2][0][iz] + term1 * th[2][1][iz] + term2 * th[2][2][iz];
+                atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], (float) v);
+            }
+        }
+    }
+}
+
+// The convolved grid back at the atoms: potential and its derivatives up to third order, Cartesian, with respect to the atom position:
+//   out[0] phi | [1..3] x y z | [4..9] xx xy xz yy yz zz | [10..19] xxx xxy xxz xyy xyz xzz yyy yyz yzz zzz
+// AmoebaReferencePmeMultipoleForce::computeFixedPotentialFromGrid (:5464-5570) / computeInducedPotentialFromGrid (:5618-5818) and
+// transformPotentialToCartesianCoordinates (:5340-5378), here with the general chain rule for all three orders.
+__global__ void k_mp_potential(MpArgs a, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    int idx[3];
+    double th[3][4][5];
+    atom_splines(a, position(a, i), idx, th);
+    // fractional derivatives F[p][q][r] = sum_g grid(g) thx^(p) thy^(q) thz^(r),  p + q + r <= 3
+    double F[4][4][4];
+    for (int p = 0; p < 4; p++) for (int q = 0; q < 4; q++) for (int r = 0; r < 4; r++) F[p][q][r] = 0.0;
+    for (int ix = 0; ix < 5; ix++) {
+        const int gx = (idx[0] + ix) % a.nx;
+        for (int iy = 0; iy < 5; iy++) {
+            const int gy = (idx[1] + iy) % a.ny;
+            double z[4] = {0, 0, 0, 0};
+            for (int iz = 0; iz < 5; iz++) {
+                const double g = (double) a.grid[((size_t) gx * a.ny + gy) * a.nz + (idx[2] + iz) % a.nz];
+                for (int r = 0; r < 4; r++) z[r] += g * th[2][r][iz];
+            }
+            for (int p = 0; p < 4; p++)
+                for (int q = 0; p + q < 4; q++) {
+                    const double w = th[0][p][ix] * th[1][q][iy];
+                    for (int r = 0; p + q + r < 4; r++) F[p][q][r] += w * z[r];
+                }
+        }
+    }
+    // first, second and third fractional derivative tensors by index
+    double f1[3] = {F[1][0][0], F[0][1][0], F[0][0][1]};
+    double f2[3][3], f3[3][3][3];
+    for (int k = 0; k < 3; k++)
+        for (int l = 0; l < 3; l++) {
+            int e[3] = {0, 0, 0}; e[k]++; e[l]++;
+            f2[k][l] = F[e[0]][e[1]][e[2]];
+            for (int m = 0; m < 3; m++) { int e3[3] = {e[0], e[1], e[2]}; e3[m]++; f3[k][l][m] = F[e3[0]][e3[1]][e3[2]]; }
+        }
+    double* o = out + 20 * (size_t) i;
+    o[0] = F[0][0][0];
+    for (int c = 0; c < 3; c++) o[1 + c] = a.a[0][c] * f1[0] + a.a[1][c] * f1[1] + a.a[2][c] * f1[2];
+    int n2 = 4, n3 = 10;
+    for (int c = 0; c < 3; c++)
+        for (int d = c; d < 3; d++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) s += a.a[k][c] * a.a[l][d] * f2[k][l];
+            o[n2++] = s;
+            for (int e = d; e < 3; e++) {
+                double t = 0;
+                for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) for (int m = 0; m < 3; m++) t += a.a[k][c] * a.a[l][d] * a.a[m][e] * f3[k][l][m];
+                o[n3++] = t;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pair chains.  bn[0..5]: erfc(alpha r)/r and its chain (AmoebaReferencePmeMultipoleForce::calculateFixedMultipoleFieldPairIxn :5103-5118);
+// cn[n] = (2n - 1)!! / r^(2n+1); lam[n], n = 1..4: Thole damping of the rank-n term, lambda_3, lambda_5, lambda_7, lambda_9
+// (getDampedInverseDistances :4943-4985; lambda_9 continues the chain: d(lambda_(2n+1) c_n)/dr = -r lambda_(2n+3) c_(n+1)).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pair_chains(double alpha, double r2, double dampI, double dampJ, double tholeI, double tholeJ, double (&bn)[6], double (&cn)[6], double (&lam)[5]) {
+    const double r = sqrt(r2), ralpha = alpha * r, invR2 = 1.0 / r2;
+    const double exp2a = exp(-ralpha * ralpha), alsq2 = 2.0 * alpha * alpha;
+    double alsq2n = 1.0 / (MP_SQRT_PI * alpha);
+    bn[0] = erfc(ralpha) / r;
+    cn[0] = 1.0 / r;
+    for (int n = 1; n < 6; n++) {
+        alsq2n *= alsq2;
+        bn[n] = ((2 * n - 1) * bn[n - 1] + alsq2n * exp2a) * invR2;
+        cn[n] = (2 * n - 1) * cn[n - 1] * invR2;
+    }
+    lam[0] = lam[1] = lam[2] = lam[3] = lam[4] = 1.0;
+    const double damp = dampI * dampJ;
+    if (damp != 0.0) {
+        const double ratio = r / damp, au3 = (tholeI < tholeJ ? tholeI : tholeJ) * ratio * ratio * ratio;
+        if (au3 < 50.0) {
+            const double e = exp(-au3);
+            lam[1] = 1.0 - e;
+            lam[2] = 1.0 - e * (1.0 + au3);
+            lam[3] = 1.0 - e * (1.0 + au3 + 0.6 * au3 * au3);
+            lam[4] = 1.0 - e * (1.0 + au3 + (18.0 * au3 * au3 + 9.0 * au3 * au3 * au3) / 35.0);
+        }
+    }
+}
+
+struct PairScale { double m, p, d; };
+
+// scale factors of the pair (i, j) from i's list of special partners (ascending; the cursor moves with j)
+__device__ __forceinline__ PairScale pair_scale(const MpArgs& a, int j, int& cursor, int end, int& next) {
+    PairScale s = {1.0, 1.0, 1.0};
+    while (next < j) { cursor++; next = cursor < end ? a.specAtom[cursor] : 0x7fffffff; }
+    if (next == j) { const double4 v = a.specScale[cursor]; s.m = v.x; s.p = v.y; s.d = v.z; }
+    return s;
+}
+
+struct JSite { double x, y, z, q; V3 mu; Sym Q; double thole, damp; V3 ud, up; };
+
+// ------------------------------------------------------------------------------------------------
+// Field of the permanent multipoles at every atom (chains d and p, reciprocal part, self term) and the induced dipoles of direct
+// polarization.  calculateFixedMultipoleField (:5169-5201) + calculateFixedMultipoleFieldPairIxn (:5079-5167) + recordFixedMultipoleField
+// (:6008-6019) + initializeInducedDipoles (:6021-6026).  Fields in units of e / nm^2 (without the Coulomb constant), as there.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MP_BLOCK) void k_mp_field(MpArgs a) {
+    __shared__ JSite sj[MP_BLOCK];
+    const int t = threadIdx.x, i = blockIdx.x * MP_BLOCK + t;
+    const bool active = i < a.n;
+    const int ii = active ? i : 0;
+    const V3 xi = position(a, ii);
+    const double tholeI = a.thole[ii], dampI = a.damping[ii];
+    int cursor = a.specStart[ii];
+    const int specEnd = a.specStart[ii + 1];
+    int next = cursor < specEnd ? a.specAtom[cursor] : 0x7fffffff;
+    V3 ed = v3(0, 0, 0), ep = v3(0, 0, 0);
+    for (int j0 = 0; j0 < a.n; j0 += MP_BLOCK) {
+        __syncthreads();
+        if (j0 + t < a.n) {
+            const int j = j0 + t;
+            const V3 x = position(a, j);
+            JSite s;
+            s.x = x.x; s.y = x.y; s.z = x.z; s.q = a.charge[j]; s.mu = load3(a.labDipole, j); s.Q = load6(a.labQuad, j); s.thole = a.thole[j]; s.damp = a.damping[j];
+            s.ud = s.up = v3(0, 0, 0);
+            sj[t] = s;
+        }
+        __syncthreads();
+        if (!active) continue;
+        const int nj = min(MP_BLOCK, a.n - j0);
+        for (int k = 0; k < nj; k++) {
+            const int j = j0 + k;
+            if (j == i) continue;
+            const PairScale sc = pair_scale(a, j, cursor, specEnd, next);
+            const JSite& s = sj[k];
+            double dx = s.x - xi.x, dy = s.y - xi.y, dz = s.z - xi.z;
+            min_image_d(dx, dy, dz, a.box);
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            if (r2 > a.cutoff2) continue;
+            double bn[6], cn[6], lam[5];
+            pair_chains(a.alpha, r2, dampI, s.damp, tholeI, s.thole, bn, cn, lam);
+            const V3 r = v3(dx, dy, dz);
+            const V3 Qr = mul(s.Q, r);
+            const double mur = dot(s.mu, r), rQr = dot(r, Qr);
+            // field = S1 r - B1 mu + 2 B2 Q r  with  S1 = -q B1 + B2 (mu.r) - B3 (r.Q.r)
+            double b1 = bn[1] - (1.0 - sc.d * lam[1]) * cn[1], b2 = bn[2] - (1.0 - sc.d * lam[2]) * cn[2], b3 = bn[3] - (1.0 - sc.d * lam[3]) * cn[3];
+            ed = ed + (-s.q * b1 + b2 * mur - b3 * rQr) * r - b1 * s.mu + (2.0 * b2) * Qr;
+            b1 = bn[1] - (1.0 - sc.p * lam[1]) * cn[1]; b2 = bn[2] - (1.0 - sc.p * lam[2]) * cn[2]; b3 = bn[3] - (1.0 - sc.p * lam[3]) * cn[3];
+            ep = ep + (-s.q * b1 + b2 * mur - b3 * rQr) * r - b1 * s.mu + (2.0 * b2) * Qr;
+        }
+    }
+    if (!active) return;
+    // reciprocal field -grad phi (the grid carries the Coulomb constant: taken out again) and the self field 4 alpha^3 / (3 sqrt(pi)) mu
+    const double* phi = a.phi + 20 * (size_t) i;
+    const double selfTerm = (4.0 / 3.0) * a.alpha * a.alpha * a.alpha / MP_SQRT_PI;
+    const V3 common = v3(-phi[1], -phi[2], -phi[3]) * (1.0 / OMM_ONE_4PI_EPS0_D) + selfTerm * load3(a.labDipole, i);
+    ed = ed + common; ep = ep + common;
+    store3(a.fieldD, i, ed); store3(a.fieldP, i, ep);
+    const double pol = a.polarity[i];
+    store3(a.indD, i, pol * ed); store3(a.indP, i, pol * ep);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Energy, forces and torques: real-space pairs (permanent x permanent through chain m, permanent x induced through chains p and d),
+// reciprocal space from the two sets of potential derivatives, self terms.  calculatePmeDirectElectrostaticPairIxn (:6335-6751, here in
+// the Cartesian form described at the top), computeReciprocalSpaceFixedMultipoleForceAndEnergy (:5820-5897),
+// computeReciprocalSpaceInducedDipoleForceAndEnergy (:5899-6006), calculatePmeSelfEnergy / calculatePmeSelfTorque (:6294-6333).
+// ------------------------------------------------------------------------------------------------
+// energy, force and torque of a multipole with moments (q, mu, Q) in a potential given by its derivatives p[0..19]
+__device__ __forceinline__ void in_potential(double q, V3 mu, const Sym& Q, const double* p, double& energy, V3& force, V3& torque) {
+    const V3 g = v3(p[1], p[2], p[3]);
+    const Sym H = {p[4], p[5], p[6], p[7], p[8], p[9]};
+    energy = q * p[0] + dot(mu, g) + ddot(Q, H);
+    // third derivatives: xxx xxy xxz xyy xyz xzz yyy yyz yzz zzz
+    const double xxx = p[10], xxy = p[11], xxz = p[12], xyy = p[13], xyz = p[14], xzz = p[15], yyy = p[16], yyz = p[17], yzz = p[18], zzz = p[19];
+    const V3 QD = v3(Q.xx * xxx + Q.yy * xyy + Q.zz * xzz + 2.0 * (Q.xy * xxy + Q.xz * xxz + Q.yz * xyz),
+                     Q.xx * xxy + Q.yy * yyy + Q.zz * yzz + 2.0 * (Q.xy * xyy + Q.xz * xyz + Q.yz * yyz),
+                     Q.xx * xxz + Q.yy * yyz + Q.zz * zzz + 2.0 * (Q.xy * xyz + Q.xz * xzz + Q.yz * yzz));
+    force = v3(0, 0, 0) - (q * g + mul(H, mu) + QD);
+    torque = v3(0, 0, 0) - cross(mu, g) - 2.0 * asym_product(Q, H);
+}
+
+__global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
+    __shared__ JSite sj[MP_BLOCK];
+    __shared__ double sEnergy[MP_BLOCK / 64];
+    const int t = threadIdx.x, i = blockIdx.x * MP_BLOCK + t;
+    const bool active = i < a.n;
+    const int ii = active ? i : 0;
+    const V3 xi = position(a, ii);
+    Site Mi;
+    Mi.q = a.charge[ii]; Mi.mu = load3(a.labDipole, ii); Mi.Q = load6(a.labQuad, ii);
+    const V3 udI = load3(a.indD, ii), upI = load3(a.indP, ii);
+    const Sym zeroQ = {0, 0, 0, 0, 0, 0};
+    Site halfUdI = {0.0, 0.5 * udI, zeroQ}, halfUpI = {0.0, 0.5 * upI, zeroQ};
+    const double tholeI = a.thole[ii], dampI = a.damping[ii];
+    int cursor = a.specStart[ii];
+    const int specEnd = a.specStart[ii + 1];
+    int next = cursor < specEnd ? a.specAtom[cursor] : 0x7fffffff;
+    V3 force = v3(0, 0, 0), torque = v3(0, 0, 0);
+    double energy = 0.0;
+    for (int j0 = 0; j0 < a.n; j0 += MP_BLOCK) {
+        __syncthreads();
+        if (j0 + t < a.n) {
+            const int j = j0 + t;
+            const V3 x = position(a, j);
+            JSite s;
+            s.x = x.x; s.y = x.y; s.z = x.z; s.q = a.charge[j]; s.mu = load3(a.labDipole, j); s.Q = load6(a.labQuad, j); s.thole = a.thole[j]; s.damp = a.damping[j];
+            s.ud = load3(a.indD, j); s.up = load3(a.indP, j);
+            sj[t] = s;
+        }
+        __syncthreads();
+        if (!active) continue;
+        const int nj = min(MP_BLOCK, a.n - j0);
+        for (int k = 0; k < nj; k++) {
+            const int j = j0 + k;
+            if (j == i) continue;
+            const PairScale sc = pair_scale(a, j, cursor, specEnd, next);
+            const JSite& s = sj[k];
+            double dx = s.x - xi.x, dy = s.y - xi.y, dz = s.z - xi.z;
+            min_image_d(dx, dy, dz, a.box);
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            if (r2 > a.cutoff2) continue;
+            double bn[6], cn[6], lam[5], chain[6];
+            pair_chains(a.alpha, r2, dampI, s.damp, tholeI, s.thole, bn, cn, lam);
+            const V3 r = v3(dx, dy, dz);
+            Site Mj;
+            Mj.q = s.q; Mj.mu = s.mu; Mj.Q = s.Q;
+            double W; V3 f, tq;
+            // permanent x permanent
+            for (int n = 0; n < 6; n++) chain[n] = bn[n] - (1.0 - sc.m) * cn[n];
+            mpole_pair(Mi, Mj, r, chain, W, f, tq);
+            energy += 0.5 * W; force = force + f; torque = torque + tq;
+            // permanent x induced: chain p with the "d" dipoles, chain d with the "p" dipoles
+            const Site halfUdJ = {0.0, 0.5 * s.ud, zeroQ}, halfUpJ = {0.0, 0.5 * s.up, zeroQ};
+            chain[0] = 0.0; chain[5] = 0.0;
+            for (int n = 1; n < 5; n++) chain[n] = bn[n] - (1.0 - sc.p * lam[n]) * cn[n];
+            mpole_pair(halfUdI, Mj, r, chain, W, f, tq);          // W1: my induced dipole in j's permanent field (no torque: induced dipoles have no frame)
+            energy += 0.25 * W; force = force + f;
+            mpole_pair(Mi, halfUdJ, r, chain, W, f, tq);          // W3: my permanent multipoles in the field of j's induced dipole
+            energy += 0.25 * W; force = force + f; torque = torque + tq;
+            for (int n = 1; n < 5; n++) chain[n] = bn[n] - (1.0 - sc.d * lam[n]) * cn[n];
+            mpole_pair(halfUpI, Mj, r, chain, W, f, tq);          // W2
+            energy += 0.25 * W; force = force + f;
+            mpole_pair(Mi, halfUpJ, r, chain, W, f, tq);          // W4
+            energy += 0.25 * W; force = force + f; torque = torque + tq;
+        }
+    }
+    if (active) {
+        // pair quantities carry the Coulomb constant from here on
+        force = OMM_ONE_4PI_EPS0_D * force; torque = OMM_ONE_4PI_EPS0_D * torque; energy *= OMM_ONE_4PI_EPS0_D;
+        const V3 nu = 0.5 * (udI + upI);
+        // ---- reciprocal space (the potentials carry the Coulomb constant already)
+        const double* phi = a.phi + 20 * (size_t) i;
+        const double* phiInd = a.phiInd + 20 * (size_t) i;
+        double e; V3 f, tq;
+        in_potential(Mi.q, Mi.mu, Mi.Q, phi, e, f, tq);            // permanent multipoles in the potential of all permanent multipoles
+        energy += 0.5 * e; force = force + f; torque = torque + tq;
+        in_potential(Mi.q, Mi.mu, Mi.Q, phiInd, e, f, tq);         // ... and in the potential of the induced dipoles (mu_d + mu_p) / 2
+        force = force + f; torque = torque + tq;
+        const Sym zero = {0, 0, 0, 0, 0, 0};
+        in_potential(0.0, nu, zero, phi, e, f, tq);                // the induced dipole in the potential of the permanent multipoles
+        energy += 0.5 * e; force = force + f;
+        // ---- self terms
+        const double a2 = a.alpha * a.alpha, prefac = -a.alpha * OMM_ONE_4PI_EPS0_D / MP_SQRT_PI;
+        const double dxy = Mi.Q.xx - Mi.Q.yy;
+        const double qii = 9.0 * (Mi.Q.zz * Mi.Q.zz + (4.0 / 3.0) * (Mi.Q.xz * Mi.Q.xz + Mi.Q.yz * Mi.Q.yz + Mi.Q.xy * Mi.Q.xy) + (1.0 / 3.0) * dxy * dxy);
+        energy += prefac * (Mi.q * Mi.q + (2.0 / 3.0) * a2 * dot(Mi.mu, Mi.mu + nu) + (4.0 / 15.0) * a2 * a2 * qii);
+        torque = torque + ((4.0 / 3.0) * OMM_ONE_4PI_EPS0_D * a2 * a.alpha / MP_SQRT_PI) * cross(Mi.mu, nu);
+        store3(a.torque, i, torque);
+        add_force(a.force, a.paddedAtoms, a.slotOfAtom[i], force.x, force.y, force.z);
+    }
+    if (a.includeEnergy) {
+        energy = wave_sum(active ? energy : 0.0);
+        if ((t & 63) == 0) sEnergy[t >> 6] = energy;
+        __syncthreads();
+        if (t == 0) {
+            double e = 0;
+            for (int w = 0; w < MP_BLOCK / 64; w++) e += sEnergy[w];
+            atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], e);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Torques on the multipoles -> forces on the atoms that define their frames.  The rule is Tinker's chain rule as restated in
+// AmoebaReferenceMultipoleForce::mapTorqueToForceForParticle (:1476-1691): U = z atom, V = x atom, W = y atom (or U x V).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_mp_torque_to_force(MpArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int4 ax = a.axis[i];
+    if (ax.x == 5 || ax.y < 0) return;
+    const V3 tq = load3(a.torque, i), xi = position(a, i);
+    V3 u = position(a, ax.y) - xi, v, w;
+    const double nu = normalize(u);
+    if (ax.z >= 0) v = position(a, ax.z) - xi;
+    else v = fabs(u.x) < 0.866 ? v3(1, 0, 0) : v3(0, 1, 0);          // a z-only frame without an x atom: the direction the frame itself was completed with
+    const double nv = normalize(v);
+    if (ax.w >= 0 && (ax.x == 2 || ax.x == 3)) w = position(a, ax.w) - xi; else w = cross(u, v);
+    const double nw = normalize(w);
+    V3 uv = cross(v, u), uw = cross(w, u), vw = cross(w, v);
+    normalize(uv); normalize(uw); normalize(vw);
+    const double cuv = dot(u, v), suv = sqrt(1.0 - cuv * cuv), cuw = dot(u, w), suw = sqrt(1.0 - cuw * cuw), cvw = dot(v, w), svw = sqrt(1.0 - cvw * cvw);
+    const double du = -dot(u, tq), dv = -dot(v, tq), dw = -dot(w, tq);
+    V3 fu = v3(0, 0, 0), fv = v3(0, 0, 0), fw = v3(0, 0, 0);
+    if (ax.x == 0 || ax.x == 1) {
+        const double half = ax.x == 1 ? 0.5 : 1.0;
+        fu = (dv / (nu * suv)) * uv + (half * dw / nu) * uw;
+        fv = (-du / (nv * suv)) * uv + (ax.x == 1 ? 0.5 * dw / nv : 0.0) * vw;
+    }
+    else if (ax.x == 2) {
+        V3 rr = v + w, s = cross(u, rr);
+        normalize(rr); normalize(s);
+        V3 ur = cross(rr, u), us = cross(s, u);
+        normalize(ur); normalize(us);
+        const double cur = dot(u, rr), sur = sqrt(1.0 - cur * cur), cvs = dot(v, s), svs = sqrt(1.0 - cvs * cvs), cws = dot(w, s), sws = sqrt(1.0 - cws * cws);
+        V3 t1 = v - cvs * s, t2 = w - cws * s;
+        normalize(t1); normalize(t2);
+        const double ut1cos = dot(u, t1), ut1sin = sqrt(1.0 - ut1cos * ut1cos), ut2cos = dot(u, t2), ut2sin = sqrt(1.0 - ut2cos * ut2cos);
+        const double dr = -dot(rr, tq), ds = -dot(s, tq);
+        fu = (dr / (nu * sur)) * ur + (ds / nu) * us;
+        fv = (du / (nv * (ut1sin + ut2sin))) * (svs * s - cvs * t1);
+        fw = (du / (nw * (ut1sin + ut2sin))) * (sws * s - cws * t2);
+    }
+    else if (ax.x == 3) {
+        fu = (1.0 / 3.0) * ((dw / (nu * suw)) * uw + (dv / (nu * suv)) * uv - (du / (nu * suw)) * uw - (du / (nu * suv)) * uv);
+        fv = (1.0 / 3.0) * ((dw / (nv * svw)) * vw - (du / (nv * suv)) * uv - (dv / (nv * svw)) * vw + (dv / (nv * suv)) * uv);
+        fw = (1.0 / 3.0) * ((-du / (nw * suw)) * uw - (dv / (nw * svw)) * vw + (dw / (nw * suw)) * uw + (dw / (nw * svw)) * vw);
+    }
+    else if (ax.x == 4) fu = (dv / (nu * suv)) * uv + (dw / nu) * uw;
+    add_force(a.force, a.paddedAtoms, a.slotOfAtom[ax.y], -fu.x, -fu.y, -fu.z);
+    if (ax.x != 4 && ax.z >= 0) add_force(a.force, a.paddedAtoms, a.slotOfAtom[ax.z], -fv.x, -fv.y, -fv.z);
+    if ((ax.x == 2 || ax.x == 3) && ax.w >= 0) add_force(a.force, a.paddedAtoms, a.slotOfAtom[ax.w], -fw.x, -fw.y, -fw.z);
+    else fw = v3(0, 0, 0);
+    if (ax.x == 4) fv = v3(0, 0, 0);
+    const V3 fi = fu + fv + fw;
+    add_force(a.force, a.paddedAtoms, a.slotOfAtom[i], fi.x, fi.y, fi.z);
+}
+
+bool make_args(const ommhip_amoeba_multipole* mp, const void* pos_d, const double box[6], MpArgs& a) {
+    const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
+    if (mp->num_atoms <= 0 || pme == nullptr || pme->grid_real == nullptr || mp->axis == nullptr || mp->special_start == nullptr) return false;
+    a.n = mp->num_atoms; a.nx = pme->nx; a.ny = pme->ny; a.nz = pme->nz;
+    a.paddedAtoms = 0; a.includeEnergy = 0; a.energySlots = 1;
+    a.pos = (const double4*) pos_d;
+    a.charge = mp->charge; a.molDipole = mp->mol_dipole; a.molQuad = mp->mol_quadrupole; a.axis = (const int4*) mp->axis;
+    a.thole = mp->thole; a.damping = mp->damping; a.polarity = mp->polarity;
+    a.specStart = mp->special_start; a.specAtom = mp->special_atom; a.specScale = (const double4*) mp->special_scale;
+    a.cutoff2 = mp->cutoff * mp->cutoff; a.alpha = mp->alpha;
+    a.labDipole = mp->lab_dipole; a.labQuad = mp->lab_quadrupole; a.fieldD = mp->field_d; a.fieldP = mp->field_p;
+    a.indD = mp->induced_d; a.indP = mp->induced_p; a.phi = mp->phi; a.phiInd = mp->phi_induced; a.torque = mp->torque;
+    a.box.ax = box[0]; a.box.bx = box[1]; a.box.by = box[2]; a.box.cx = box[3]; a.box.cy = box[4]; a.box.cz = box[5];
+    // reciprocal box (ReferencePME.cpp:196-204): s_k = sum_c x_c R[c][k]
+    const double det = box[0] * box[2] * box[5];
+    double R[3][3] = {{box[2] * box[5] / det, 0, 0}, {-box[1] * box[5] / det, box[0] * box[5] / det, 0}, {(box[1] * box[4] - box[2] * box[3]) / det, -box[0] * box[4] / det, box[0] * box[2] / det}};
+    const int n[3] = {a.nx, a.ny, a.nz};
+    for (int k = 0; k < 3; k++)
+        for (int c = 0; c < 3; c++) a.a[k][c] = n[k] * R[c][k];
+    a.grid = (float*) pme->grid_real;
+    a.slotOfAtom = nullptr; a.force = nullptr; a.energyBuffer = nullptr;
+    return true;
+}
+
+// frames, reciprocal potential of the permanent multipoles, fields and induced dipoles
+void launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t st) {
+    const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
+    const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
+    const size_t gridBytes = sizeof(float) * (size_t) a.nx * a.ny * a.nz;
+    hipLaunchKernelGGL(k_mp_frames, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
+    hipMemsetAsync(a.grid, 0, gridBytes, st);
+    hipLaunchKernelGGL(k_mp_spread<false>, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
+    ommhip_pme_convolve(pme, st);
+    hipLaunchKernelGGL(k_mp_potential, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.phi);
+    hipLaunchKernelGGL(k_mp_field, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
+}
+
+}  // namespace
+
+extern "C" int ommhip_amoeba_multipole_induce(const ommhip_amoeba_multipole* mp, const void* pos_d, const double box[6], void* stream) {
+    MpArgs a;
+    if (!make_args(mp, pos_d, box, a)) return 1;
+    launch_induce(mp, a, (hipStream_t) stream);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp, const void* pos_d, const double box[6], const int* slot_of_atom_d, int padded_atoms,
+                                              long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
+    MpArgs a;
+    if (!make_args(mp, pos_d, box, a)) return 1;
+    a.paddedAtoms = padded_atoms; a.includeEnergy = include_energy; a.energySlots = energy_slots;
+    a.slotOfAtom = slot_of_atom_d; a.force = force_d; a.energyBuffer = energy_buffer_d;
+    hipStream_t st = (hipStream_t) stream;
+    const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
+    const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
+    launch_induce(mp, a, st);
+    // reciprocal potential of the induced dipoles
+    hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, st);
+    hipLaunchKernelGGL(k_mp_spread<true>, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
+    ommhip_pme_convolve(pme, st);
+    hipLaunchKernelGGL(k_mp_potential, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.phiInd);
+    hipLaunchKernelGGL(k_mp_forces, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_mp_torque_to_force, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
+    return (int) hipGetLastError();
+}

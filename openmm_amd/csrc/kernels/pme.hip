@@ -1302,6 +1302,25 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     return (int) hipGetLastError();
 }
 
+extern "C" int ommhip_pme_convolve(const ommhip_pme* pme, void* stream) {
+    hipStream_t st = (hipStream_t) stream;
+    const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
+    float2* cgrid = (float2*) pme->grid_complex;
+    FftArgs f;
+    f.diag = nullptr;
+    f.remapIn = f.remapOut = 0; f.remapNxl = f.remapNyl = 1;
+    f.eterm = nullptr; f.energyBuffer = nullptr; f.energySlots = 1; f.nzFull = nz;
+    launch_yz(pme, true, st);
+    f.plan = make_plan(nx); f.B = lines_per_group(nx); f.numOuter = ny; f.numInner = nzc;
+    f.inOuterStride = nzc; f.inInnerStride = 1; f.inElemStride = (long long) ny * nzc;
+    f.outOuterStride = nzc; f.outInnerStride = 1; f.outElemStride = (long long) ny * nzc;
+    f.mode = 3; f.sign = -1; f.twiddle = (const float2*) pme->twiddle_x; f.in = cgrid; f.out = cgrid;
+    f.eterm = (const float*) pme->eterm;
+    launch_fft(f, st);
+    launch_yz(pme, false, st);
+    return (int) hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // One rank of a slab-decomposed reciprocal-space evaluation.  Same kernels as above; what changes is which
 // planes / rows a launch covers and where the complex data sits, so that each of the two transposes is ONE all-to-all of

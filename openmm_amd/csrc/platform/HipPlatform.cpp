@@ -56,20 +56,22 @@ struct HipModeInfo {
 };
 
 namespace {
-struct NativeKernel { string kernelName, forceType; KernelFactory* factory; };
+struct NativeKernel { string kernelName, forceType; KernelFactory* factory; HipPlatform::NativeForceTest supported; };
 vector<NativeKernel>& nativeKernels() { static vector<NativeKernel> v; return v; }
 }
 
-void HipPlatform::registerNativeKernel(const string& kernelName, const string& forceType, KernelFactory* factory) {
+void HipPlatform::registerNativeKernel(const string& kernelName, const string& forceType, KernelFactory* factory, NativeForceTest supported) {
     for (size_t i = 0; i < nativeKernels().size(); i++)
-        if (nativeKernels()[i].kernelName == kernelName) { nativeKernels()[i].forceType = forceType; nativeKernels()[i].factory = factory; return; }
-    NativeKernel k = {kernelName, forceType, factory};
+        if (nativeKernels()[i].kernelName == kernelName) { nativeKernels()[i].forceType = forceType; nativeKernels()[i].factory = factory; nativeKernels()[i].supported = supported; return; }
+    NativeKernel k = {kernelName, forceType, factory, supported};
     nativeKernels().push_back(k);
 }
 
-bool HipPlatform::isNativeForceType(const string& typeName) {
+bool HipPlatform::isNativeForce(const Force& force, const System& system) {
+    const string typeName = typeid(force).name();
     for (size_t i = 0; i < nativeKernels().size(); i++)
-        if (!nativeKernels()[i].forceType.empty() && typeName.find(nativeKernels()[i].forceType) != string::npos) return true;
+        if (!nativeKernels()[i].forceType.empty() && typeName.find(nativeKernels()[i].forceType) != string::npos)
+            return nativeKernels()[i].supported == NULL || nativeKernels()[i].supported(force, system);
     return false;
 }
 
@@ -103,7 +105,7 @@ static HipModeInfo classifyContext(ContextImpl& context) {
             info.hostMode = true;       // these change state (or own an inner Context) on the host
             continue;
         }
-        if (HipPlatform::isNativeForceType(typeid(f).name()))
+        if (HipPlatform::isNativeForce(f, system))
             continue;                   // a native kernel from a plugin of its own (registerNativeKernel)
         // Any other Force: its Reference kernel only reads positions and adds forces.
         info.hasFallbackForces = true;

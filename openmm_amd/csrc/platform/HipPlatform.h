@@ -55,8 +55,11 @@ public:
      *  (the kernel computes on the device state).  The announcement is repeated at every Context creation, because the AMOEBA
      *  plugin's own Reference kernels register themselves with every platform derived from ReferencePlatform
      *  (AmoebaReferenceKernelFactory.cpp:47-58) -- whichever of the two plugins was loaded last would otherwise win. */
-    static void registerNativeKernel(const std::string& kernelName, const std::string& forceType, KernelFactory* factory);
-    static bool isNativeForceType(const std::string& typeName);
+    typedef bool (*NativeForceTest)(const Force& force, const System& system);
+    /** `supported` (optional): does the native kernel take THIS force object?  (A factory may hand configurations it does not cover
+     *  to the Reference kernel -- the Force is then a fallback force like any other.) */
+    static void registerNativeKernel(const std::string& kernelName, const std::string& forceType, KernelFactory* factory, NativeForceTest supported = NULL);
+    static bool isNativeForce(const Force& force, const System& system);
 };
 
 /** ReferencePlatform::PlatformData (host vectors for fallback kernels) + the device context. */

@@ -252,7 +252,19 @@ def test_reference_test_bodies_on_emulated_platform(name):
         assert m is not None and int(m.group(1 if NATIVE_AMOEBA[name] == "vdw" else 2)) > 0, out.stdout[-500:]
 
 
-NATIVE_AMOEBA = {"AmoebaVdwForce": "vdw"}         # bodies whose forces must have gone through the native kernels of libOpenMMAmoebaHIP.so
+NATIVE_AMOEBA = {"AmoebaVdwForce": "vdw", "AmoebaMultipoleForce": "multipole"}         # bodies whose forces must have gone through the native kernels of libOpenMMAmoebaHIP.so
+
+
+@needs_emu
+def test_native_amoeba_multipole_kernel_matches_the_plugins_reference_kernel():
+    """tests/hip/AmoebaParity.cpp: PME + direct polarization on the systems of the reference's own test body (4 waters, 2 ions + 2 waters,
+    216 waters: local frames, covalent scale factors, Thole damping, torques) -- the native kernel against the AMOEBA plugin's Reference
+    kernel run on the same HIP Context as a fallback force; the program fails above 1e-4 (measured: 1e-7 ... 3e-6)."""
+    exe = os.path.join(EMU_BUILD, "tests", "AmoebaParity")
+    if not os.path.exists(exe):
+        pytest.skip("not built")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "Done" in out.stdout and "multipole 3" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
 
 
 @needs_emu

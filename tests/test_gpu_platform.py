@@ -24,7 +24,7 @@ REFERENCE_TEST_BODIES = ["NonbondedForce", "Ewald", "VerletIntegrator", "Settle"
                          # AmoebaMultipoleForce) run on the native kernels -- NATIVE_AMOEBA below says which evaluation counter must
                          # move; AmoebaTorsionTorsionForce has no native kernel: the plugin's own Reference kernel runs as a fallback force
                          "AmoebaVdwForce", "AmoebaMultipoleForce", "AmoebaTorsionTorsionForce"]
-NATIVE_AMOEBA = {"AmoebaVdwForce": "vdw"}         # test body -> counter printed by tests/hip/HipAmoebaTests.h at exit
+NATIVE_AMOEBA = {"AmoebaVdwForce": "vdw", "AmoebaMultipoleForce": "multipole"}         # test body -> counter printed by tests/hip/HipAmoebaTests.h at exit
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -50,6 +50,17 @@ def test_reference_test_body(name):
         import re
         m = re.search(r"native AMOEBA kernel evaluations: vdw (\d+) multipole (\d+)", out.stdout)
         assert m is not None and int(m.group(1 if NATIVE_AMOEBA[name] == "vdw" else 2)) > 0, out.stdout[-500:]
+
+
+def test_native_amoeba_multipole_kernel_matches_the_plugins_reference_kernel():
+    """SURVEY 8(f)-4 / BASELINE configs[4], first native slice on the GPU: AmoebaMultipoleForce with PME and direct polarization computed by
+    libOpenMMAmoebaHIP.so against the AMOEBA plugin's Reference kernel on the systems of plugins/amoeba/tests/TestAmoebaMultipoleForce.h
+    (tests/hip/AmoebaParity.cpp; tolerance 1e-4 of the RMS force and of the energy, the north-star bar)."""
+    exe = os.path.join(PRODUCT_TESTS, "AmoebaParity")
+    assert os.path.exists(exe), "%s missing: run __graft_entry__.build() in the build container" % exe
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    print(out.stdout)
+    assert out.returncode == 0 and "Done" in out.stdout and "multipole 3" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
 
 
 def hip_state(w, groups=-1, recip_group=False, integrator=None):

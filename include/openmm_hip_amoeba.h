@@ -69,8 +69,12 @@ int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* vdw, const void* pos_d, co
  * with B-spline derivatives, convolved by the platform's own 3-D FFT (ommhip_pme_convolve), and the potential and its first three
  * derivatives are read back at every atom.
  *
- * Supported: PME, polarization Direct (induced dipoles = alpha x field of the permanent multipoles).  The host falls back to the
- * AMOEBA plugin's Reference kernel for everything else (NoCutoff, mutual / extrapolated polarization).
+ * Supported: PME with polarization Direct (induced dipoles = alpha x field of the permanent multipoles) or Mutual (the induced dipoles
+ * also polarize each other: (1/alpha - T) mu = E, solved for both dipole sets by preconditioned conjugate gradients -- each step
+ * one induced-dipole field evaluation in real and reciprocal space -- until the Reference's own measure, debye x the RMS of
+ * alpha (E + T mu) - mu (AmoebaReferenceMultipoleForce::convergeInduceDipolesByDIIS :939-1005), falls below the target; the energy
+ * keeps its form and the force gains the term -1/2 mu_d (dT/dx) mu_p).  The host falls back to the AMOEBA plugin's Reference kernel
+ * for everything else (NoCutoff, extrapolated polarization).
  * ------------------------------------------------------------------------------------------ */
 typedef struct ommhip_amoeba_multipole {
     int num_atoms;
@@ -97,6 +101,12 @@ typedef struct ommhip_amoeba_multipole {
     double* phi;                   /* [20n] reciprocal potential of the permanent multipoles and its derivatives up to third order (Cartesian) */
     double* phi_induced;           /* [20n] the same for the induced dipoles (mu_d + mu_p) / 2 */
     double* torque;                /* [3n] */
+    /* mutual polarization (mutual = 1) */
+    int mutual, max_iterations;
+    double target_epsilon;         /* AmoebaMultipoleForce::getMutualInducedTargetEpsilon() */
+    double* phi_induced_p;         /* [20n]: with mutual polarization phi_induced holds the potential of mu_d, this one that of mu_p */
+    double* solver;                /* [24n + 16] work vectors of the conjugate-gradient solver */
+    double* status;                /* HOST double[2], written by the calls: [0] epsilon reached, [1] iterations (or NULL) */
     void* pme;                     /* const ommhip_pme*: grid sizes, box, moduli, eterm, real / complex grids, twiddles of the platform's PME */
 } ommhip_amoeba_multipole;
 

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <sstream>
 #include <map>
 #include <set>
 #include <vector>
@@ -182,7 +183,8 @@ HipCalcAmoebaMultipoleForceKernel::~HipCalcAmoebaMultipoleForceKernel() {
 
 bool HipCalcAmoebaMultipoleForceKernel::supports(const AmoebaMultipoleForce& force, const System& system) {
     if (getenv("OPENMM_HIP_REFERENCE_AMOEBA_MULTIPOLE") != NULL) return false;          // A/B knob: always the Reference kernel
-    if (force.getNonbondedMethod() != AmoebaMultipoleForce::PME || force.getPolarizationType() != AmoebaMultipoleForce::Direct) return false;
+    if (force.getNonbondedMethod() != AmoebaMultipoleForce::PME) return false;
+    if (force.getPolarizationType() != AmoebaMultipoleForce::Direct && force.getPolarizationType() != AmoebaMultipoleForce::Mutual) return false;
     double alpha; int nx, ny, nz;
     force.getPMEParameters(alpha, nx, ny, nz);
     if (nx == 0 || alpha == 0.0) {
@@ -237,6 +239,8 @@ void HipCalcAmoebaMultipoleForceKernel::initialize(const System& system, const A
     fieldD.allocate(sizeof(double) * 3 * n); fieldP.allocate(sizeof(double) * 3 * n);
     indD.allocate(sizeof(double) * 3 * n); indP.allocate(sizeof(double) * 3 * n);
     phi.allocate(sizeof(double) * 20 * n); phiInd.allocate(sizeof(double) * 20 * n); torque.allocate(sizeof(double) * 3 * n);
+    mutual = force.getPolarizationType() == AmoebaMultipoleForce::Mutual;
+    if (mutual) { phiIndP.allocate(sizeof(double) * 20 * n); solver.allocate(sizeof(double) * (24 * n + 16)); }
     upload(force);
 }
 
@@ -300,6 +304,9 @@ void HipCalcAmoebaMultipoleForceKernel::upload(const AmoebaMultipoleForce& force
     mp.lab_dipole = labDipole.as<double>(); mp.lab_quadrupole = labQuad.as<double>(); mp.field_d = fieldD.as<double>(); mp.field_p = fieldP.as<double>();
     mp.induced_d = indD.as<double>(); mp.induced_p = indP.as<double>(); mp.phi = phi.as<double>(); mp.phi_induced = phiInd.as<double>(); mp.torque = torque.as<double>();
     mp.pme = &pme;
+    mp.mutual = mutual ? 1 : 0;
+    mp.max_iterations = force.getMutualInducedMaxIterations(); mp.target_epsilon = force.getMutualInducedTargetEpsilon();
+    mp.phi_induced_p = mutual ? phiIndP.as<double>() : NULL; mp.solver = mutual ? solver.as<double>() : NULL; mp.status = solverStatus;
 }
 
 void HipCalcAmoebaMultipoleForceKernel::prepareGrid() {
@@ -318,8 +325,9 @@ double HipCalcAmoebaMultipoleForceKernel::execute(ContextImpl& context, bool inc
     hip.setAsCurrent();
     prepareGrid();
     hip.ensureCleared();
-    HIP_CHECK(ommhip_amoeba_multipole_forces(&mp, hip.pos.ptr, hip.box, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.force.as<long long>(),
-                                             hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream));
+    const int rc = ommhip_amoeba_multipole_forces(&mp, hip.pos.ptr, hip.box, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.force.as<long long>(),
+                                                  hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream);
+    checkSolver(rc);
     nativeEvaluations[1]++;
     return 0.0;        // summed on the device (HipCalcForcesAndEnergyKernel::finishComputation)
 }
@@ -328,7 +336,17 @@ void HipCalcAmoebaMultipoleForceKernel::induce() {
     HipContext& hip = *data.hip;
     hip.setAsCurrent();
     prepareGrid();
-    HIP_CHECK(ommhip_amoeba_multipole_induce(&mp, hip.pos.ptr, hip.box, hip.stream));
+    checkSolver(ommhip_amoeba_multipole_induce(&mp, hip.pos.ptr, hip.box, hip.stream));
+}
+
+void HipCalcAmoebaMultipoleForceKernel::checkSolver(int rc) {
+    if (rc == -1) {
+        // AmoebaReferenceMultipoleForce::setup (AmoebaReferenceMultipoleForce.cpp:1811-1817)
+        std::stringstream message;
+        message << "Induced dipoles did not converge:  iterations=" << (int) solverStatus[1] << " eps=" << solverStatus[0];
+        throw OpenMMException(message.str());
+    }
+    HIP_CHECK(rc);
 }
 
 void HipCalcAmoebaMultipoleForceKernel::download3(DeviceBuffer& buffer, vector<Vec3>& out) {

@@ -30,7 +30,7 @@ private:
     DeviceBuffer parent, reduction, type, sigma, epsilon, exclStart, exclAtoms, alchemical, reduced;
 };
 
-/** amoebaKernels.h:82-139 CalcAmoebaMultipoleForceKernel for PME with direct polarization; Reference: AmoebaReferenceKernels.cpp:170-520 +
+/** amoebaKernels.h:82-139 CalcAmoebaMultipoleForceKernel for PME with direct or mutual polarization; Reference: AmoebaReferenceKernels.cpp:170-520 +
  *  AmoebaReferencePmeMultipoleForce.  The factory hands every other configuration (NoCutoff, mutual / extrapolated polarization, grids
  *  the platform's FFT does not take) to the AMOEBA plugin's own Reference kernel; so does this class for the two queries it does not
  *  compute itself (electrostatic potential on a grid of points, system multipole moments). */
@@ -53,17 +53,19 @@ private:
     void upload(const AmoebaMultipoleForce& force);
     void prepareGrid();
     void induce();
+    void checkSolver(int rc);
     void download3(DeviceBuffer& buffer, std::vector<Vec3>& out);
     void syncHostPositions(ContextImpl& context);
     HipPlatform::PlatformData& data;
     CalcAmoebaMultipoleForceKernel* reference;      // the AMOEBA plugin's Reference kernel (for the two queries above), owned
     int numParticles = 0, gridSize[3] = {0, 0, 0};
     double alphaEwald = 0, cutoff = 0, lastBox[6] = {0, 0, 0, 0, 0, 0};
-    bool etermBuilt = false;
+    bool etermBuilt = false, mutual = false;
+    double solverStatus[2] = {0, 0};          // epsilon reached and iterations of the last mutual-polarization solve
     ommhip_amoeba_multipole mp;
     ommhip_pme pme;
     DeviceBuffer charge, molDipole, molQuad, axis, thole, damping, polarity, specStart, specAtom, specScale;
-    DeviceBuffer labDipole, labQuad, fieldD, fieldP, indD, indP, phi, phiInd, torque;
+    DeviceBuffer labDipole, labQuad, fieldD, fieldP, indD, indP, phi, phiInd, phiIndP, solver, torque;
     DeviceBuffer moduliX, moduliY, moduliZ, twiddleX, twiddleY, twiddleZ, eterm, gridReal, gridComplex;
 };
 

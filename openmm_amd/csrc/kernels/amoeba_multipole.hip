@@ -90,6 +90,8 @@ struct MpArgs {
     const int* specStart; const int* specAtom; const double4* specScale;
     double cutoff2, alpha;
     double* labDipole; double* labQuad; double* fieldD; double* fieldP; double* indD; double* indP; double* phi; double* phiInd; double* torque;
+    int mutual;
+    double* phiIndP;           // mutual: potential of mu_p (phiInd then holds that of mu_d)
     BoxD box;
     double a[3][3];            // a[k][c] = d(grid coordinate k) / d(Cartesian c) = n_k * recip[c][k]
     float* grid;
@@ -196,15 +198,16 @@ __device__ __forceinline__ void atom_splines(const MpArgs& a, V3 x, int (&idx)[3
 // Spreads L_i W(g; r_i) = [q + mu . grad_i + Q : grad_i grad_i] W for the permanent multipoles (INDUCED = false) or the dipoles
 // (mu_d + mu_p) / 2 (INDUCED = true) onto the float grid.  AmoebaReferencePmeMultipoleForce::spreadFixedMultipolesOntoGrid (:5380-5423),
 // spreadInducedDipolesOnGrid (:5572-5616); derivatives with respect to the atom position through the chain rule a[k][c].
+// INDUCED: the dipoles sA * A + sB * B (B may be null)
 template <bool INDUCED>
-__global__ void k_mp_spread(MpArgs a) {
+__global__ void k_mp_spread(MpArgs a, const double* __restrict__ A, double sA, const double* __restrict__ B, double sB) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     int idx[3];
     double th[3][4][5];
     atom_splines(a, position(a, i), idx, th);
     const double q = INDUCED ? 0.0 : a.charge[i];
-    const V3 mu = INDUCED ? 0.5 * (load3(a.indD, i) + load3(a.indP, i)) : load3(a.labDipole, i);
+    const V3 mu = INDUCED ? sA * load3(A, i) + (B != nullptr ? sB * load3(B, i) : v3(0, 0, 0)) : load3(a.labDipole, i);
     // fractional moments: d_k = sum_c a[k][c] mu_c,  Q_kl = sum_cd a[k][c] a[l][d] Q_cd
     double fd[3], fq[3][3];
     const double muc[3] = {mu.x, mu.y, mu.z};
@@ -482,6 +485,15 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
             energy += 0.25 * W; force = force + f;
             mpole_pair(Mi, halfUpJ, r, chain, W, f, tq);          // W4
             energy += 0.25 * W; force = force + f; torque = torque + tq;
+            if (a.mutual) {
+                // the induced dipoles polarize each other: -1/2 mu_d (dT/dx) mu_p, the gradient of W(mu_d,i, mu_p,j) / 2 + W(mu_p,i, mu_d,j) / 2
+                // at fixed dipoles through the Thole-damped chain (u scale = 1, as in calculateDirectInducedDipolePairIxns :6172-6230)
+                for (int n = 1; n < 5; n++) chain[n] = bn[n] - (1.0 - lam[n]) * cn[n];
+                mpole_pair(halfUdI, halfUpJ, r, chain, W, f, tq);
+                force = force + 2.0 * f;
+                mpole_pair(halfUpI, halfUdJ, r, chain, W, f, tq);
+                force = force + 2.0 * f;
+            }
         }
     }
     if (active) {
@@ -490,7 +502,9 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
         const V3 nu = 0.5 * (udI + upI);
         // ---- reciprocal space (the potentials carry the Coulomb constant already)
         const double* phi = a.phi + 20 * (size_t) i;
-        const double* phiInd = a.phiInd + 20 * (size_t) i;
+        double phiNu[20];           // potential of (mu_d + mu_p) / 2
+        for (int k = 0; k < 20; k++) phiNu[k] = a.mutual ? 0.5 * (a.phiInd[20 * (size_t) i + k] + a.phiIndP[20 * (size_t) i + k]) : a.phiInd[20 * (size_t) i + k];
+        const double* phiInd = phiNu;
         double e; V3 f, tq;
         in_potential(Mi.q, Mi.mu, Mi.Q, phi, e, f, tq);            // permanent multipoles in the potential of all permanent multipoles
         energy += 0.5 * e; force = force + f; torque = torque + tq;
@@ -499,6 +513,13 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
         const Sym zero = {0, 0, 0, 0, 0, 0};
         in_potential(0.0, nu, zero, phi, e, f, tq);                // the induced dipole in the potential of the permanent multipoles
         energy += 0.5 * e; force = force + f;
+        if (a.mutual) {
+            // -1/2 [mu_d . grad grad phi(mu_p) + mu_p . grad grad phi(mu_d)]  (computeReciprocalSpaceInducedDipoleForceAndEnergy :5976-5980)
+            in_potential(0.0, udI, zero, a.phiIndP + 20 * (size_t) i, e, f, tq);
+            force = force + 0.5 * f;
+            in_potential(0.0, upI, zero, a.phiInd + 20 * (size_t) i, e, f, tq);
+            force = force + 0.5 * f;
+        }
         // ---- self terms
         const double a2 = a.alpha * a.alpha, prefac = -a.alpha * OMM_ONE_4PI_EPS0_D / MP_SQRT_PI;
         const double dxy = Mi.Q.xx - Mi.Q.yy;
@@ -517,6 +538,99 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
             for (int w = 0; w < MP_BLOCK / 64; w++) e += sEnergy[w];
             atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], e);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mutual polarization: field of two sets of dipoles (vD, vP) at every atom -- real space through the Thole-damped chain, the
+// reciprocal part from their two potentials, the self field.  calculateInducedDipoleFields (:6059-6152).
+// ------------------------------------------------------------------------------------------------
+struct JDipole { double x, y, z, thole, damp; V3 vd, vp; };
+
+__global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const double* __restrict__ vD, const double* __restrict__ vP, const double* __restrict__ phiD,
+                                                              const double* __restrict__ phiP, double* __restrict__ outD, double* __restrict__ outP) {
+    __shared__ JDipole sj[MP_BLOCK];
+    const int t = threadIdx.x, i = blockIdx.x * MP_BLOCK + t;
+    const bool active = i < a.n;
+    const int ii = active ? i : 0;
+    const V3 xi = position(a, ii);
+    const double tholeI = a.thole[ii], dampI = a.damping[ii];
+    V3 ed = v3(0, 0, 0), ep = v3(0, 0, 0);
+    for (int j0 = 0; j0 < a.n; j0 += MP_BLOCK) {
+        __syncthreads();
+        if (j0 + t < a.n) {
+            const int j = j0 + t;
+            const V3 x = position(a, j);
+            JDipole s;
+            s.x = x.x; s.y = x.y; s.z = x.z; s.thole = a.thole[j]; s.damp = a.damping[j]; s.vd = load3(vD, j); s.vp = load3(vP, j);
+            sj[t] = s;
+        }
+        __syncthreads();
+        if (!active) continue;
+        const int nj = min(MP_BLOCK, a.n - j0);
+        for (int k = 0; k < nj; k++) {
+            if (j0 + k == i) continue;
+            const JDipole& s = sj[k];
+            double dx = s.x - xi.x, dy = s.y - xi.y, dz = s.z - xi.z;
+            min_image_d(dx, dy, dz, a.box);
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            if (r2 > a.cutoff2) continue;
+            double bn[6], cn[6], lam[5];
+            pair_chains(a.alpha, r2, dampI, s.damp, tholeI, s.thole, bn, cn, lam);
+            const V3 r = v3(dx, dy, dz);
+            const double b1 = bn[1] - (1.0 - lam[1]) * cn[1], b2 = bn[2] - (1.0 - lam[2]) * cn[2];
+            ed = ed + (b2 * dot(s.vd, r)) * r - b1 * s.vd;
+            ep = ep + (b2 * dot(s.vp, r)) * r - b1 * s.vp;
+        }
+    }
+    if (!active) return;
+    const double selfTerm = (4.0 / 3.0) * a.alpha * a.alpha * a.alpha / MP_SQRT_PI, invK = 1.0 / OMM_ONE_4PI_EPS0_D;
+    const double* pd = phiD + 20 * (size_t) i;
+    const double* pp = phiP + 20 * (size_t) i;
+    store3(outD, i, ed - invK * v3(pd[1], pd[2], pd[3]) + selfTerm * load3(vD, i));
+    store3(outP, i, ep - invK * v3(pp[1], pp[2], pp[3]) + selfTerm * load3(vP, i));
+}
+
+// Conjugate gradients on (1/alpha - T) mu = E for both dipole sets at once.  Vectors (3n each) in `w`:
+//   0 rD  1 rP  2 zD  3 zP  4 pD  5 pP  6 tD  7 tP (T p)        sums (device double[16] behind them): see below
+// stage 0: start from mu = alpha E:  r = T mu (given in t), z = alpha r, p = z;  sums[0,1] = r.z (d, p), sums[4,5] = z.z
+// stage 1: Ap = p / alpha - t;  sums[2,3] = p.Ap
+// stage 2: mu += a p, r -= a Ap, z = alpha r;  sums[0,1] = r.z (new), sums[4,5] = z.z     (a = sums_old[0,1] / sums[2,3], given)
+// stage 3: p = z + b p                                                                      (b given)
+__global__ void k_mp_cg(MpArgs a, double* w, int stage, double cD, double cP) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n3 = 3 * (size_t) a.n;
+    double* sums = w + 8 * n3;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (i < a.n) {
+        const double pol = a.polarity[i], invPol = pol > 0 ? 1.0 / pol : 0.0;
+        double* rD = w; double* rP = w + n3; double* zD = w + 2 * n3; double* zP = w + 3 * n3; double* pD = w + 4 * n3; double* pP = w + 5 * n3; double* tD = w + 6 * n3; double* tP = w + 7 * n3;
+        if (stage == 0) {
+            const V3 rd = pol > 0 ? load3(tD, i) : v3(0, 0, 0), rp = pol > 0 ? load3(tP, i) : v3(0, 0, 0);
+            store3(rD, i, rd); store3(rP, i, rp); store3(zD, i, pol * rd); store3(zP, i, pol * rp); store3(pD, i, pol * rd); store3(pP, i, pol * rp);
+            s0 = pol * dot(rd, rd); s1 = pol * dot(rp, rp); s2 = pol * pol * dot(rd, rd); s3 = pol * pol * dot(rp, rp);
+        }
+        else if (stage == 1) {
+            const V3 pd = load3(pD, i), pp = load3(pP, i);
+            const V3 ad = invPol * pd - (pol > 0 ? load3(tD, i) : v3(0, 0, 0)), ap = invPol * pp - (pol > 0 ? load3(tP, i) : v3(0, 0, 0));
+            store3(tD, i, ad); store3(tP, i, ap);            // t now holds A p
+            s0 = dot(pd, ad); s1 = dot(pp, ap);
+        }
+        else if (stage == 2) {
+            const V3 rd = load3(rD, i) - cD * load3(tD, i), rp = load3(rP, i) - cP * load3(tP, i);
+            store3(a.indD, i, load3(a.indD, i) + cD * load3(pD, i)); store3(a.indP, i, load3(a.indP, i) + cP * load3(pP, i));
+            store3(rD, i, rd); store3(rP, i, rp); store3(zD, i, pol * rd); store3(zP, i, pol * rp);
+            s0 = pol * dot(rd, rd); s1 = pol * dot(rp, rp); s2 = pol * pol * dot(rd, rd); s3 = pol * pol * dot(rp, rp);
+        }
+        else {
+            store3(pD, i, load3(zD, i) + cD * load3(pD, i)); store3(pP, i, load3(zP, i) + cP * load3(pP, i));
+        }
+    }
+    if (stage == 3) return;
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+    if ((threadIdx.x & 63) == 0) {
+        if (stage == 1) { atomicAdd(&sums[2], s0); atomicAdd(&sums[3], s1); }
+        else { atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); atomicAdd(&sums[4], s2); atomicAdd(&sums[5], s3); }
     }
 }
 
@@ -588,6 +702,8 @@ bool make_args(const ommhip_amoeba_multipole* mp, const void* pos_d, const doubl
     a.cutoff2 = mp->cutoff * mp->cutoff; a.alpha = mp->alpha;
     a.labDipole = mp->lab_dipole; a.labQuad = mp->lab_quadrupole; a.fieldD = mp->field_d; a.fieldP = mp->field_p;
     a.indD = mp->induced_d; a.indP = mp->induced_p; a.phi = mp->phi; a.phiInd = mp->phi_induced; a.torque = mp->torque;
+    a.mutual = mp->mutual != 0 ? 1 : 0; a.phiIndP = mp->phi_induced_p;
+    if (a.mutual && (mp->phi_induced_p == nullptr || mp->solver == nullptr)) return false;
     a.box.ax = box[0]; a.box.bx = box[1]; a.box.by = box[2]; a.box.cx = box[3]; a.box.cy = box[4]; a.box.cz = box[5];
     // reciprocal box (ReferencePME.cpp:196-204): s_k = sum_c x_c R[c][k]
     const double det = box[0] * box[2] * box[5];
@@ -607,10 +723,66 @@ void launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream
     const size_t gridBytes = sizeof(float) * (size_t) a.nx * a.ny * a.nz;
     hipLaunchKernelGGL(k_mp_frames, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
     hipMemsetAsync(a.grid, 0, gridBytes, st);
-    hipLaunchKernelGGL(k_mp_spread<false>, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_mp_spread<false>, dim3(blocks), dim3(MP_BLOCK), 0, st, a, (const double*) nullptr, 0.0, (const double*) nullptr, 0.0);
     ommhip_pme_convolve(pme, st);
     hipLaunchKernelGGL(k_mp_potential, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.phi);
     hipLaunchKernelGGL(k_mp_field, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
+}
+
+// potential (and derivatives) of one set of dipoles at the atoms
+void dipole_potential(const ommhip_pme* pme, const MpArgs& a, const double* dipoles, double* out, hipStream_t st) {
+    const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
+    hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, st);
+    hipLaunchKernelGGL(k_mp_spread<true>, dim3(blocks), dim3(MP_BLOCK), 0, st, a, dipoles, 1.0, (const double*) nullptr, 0.0);
+    ommhip_pme_convolve(pme, st);
+    hipLaunchKernelGGL(k_mp_potential, dim3(blocks), dim3(MP_BLOCK), 0, st, a, out);
+}
+
+// Mutual polarization: conjugate gradients from the direct-polarization dipoles.  Leaves mu_d, mu_p and their potentials (phiInd, phiIndP).
+int solve_mutual(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t st) {
+    const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
+    const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
+    const size_t n3 = 3 * (size_t) a.n;
+    double* w = mp->solver;
+    double* sums = w + 8 * n3;
+    double* tD = w + 6 * n3; double* tP = w + 7 * n3; double* pD = w + 4 * n3; double* pP = w + 5 * n3;
+    double h[8];
+    const double debye = 48.033324;          // AmoebaReferenceMultipoleForce::_debye
+    auto readSums = [&]() -> int { hipError_t e = hipMemcpyAsync(h, sums, sizeof(double) * 8, hipMemcpyDeviceToHost, st); if (e != hipSuccess) return (int) e; return (int) hipStreamSynchronize(st); };
+    // T mu_0
+    dipole_potential(pme, a, a.indD, a.phiInd, st);
+    dipole_potential(pme, a, a.indP, a.phiIndP, st);
+    hipLaunchKernelGGL(k_mp_dipole_field, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, tD, tP);
+    hipMemsetAsync(sums, 0, sizeof(double) * 8, st);
+    hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 0, 0.0, 0.0);
+    int rc = readSums();
+    if (rc != 0) return rc;
+    double rzD = h[0], rzP = h[1], epsilon = debye * sqrt(fmax(h[4], h[5]) / a.n);
+    int iteration = 0;
+    while (epsilon >= mp->target_epsilon && iteration < mp->max_iterations) {
+        dipole_potential(pme, a, pD, a.phiInd, st);
+        dipole_potential(pme, a, pP, a.phiIndP, st);
+        hipLaunchKernelGGL(k_mp_dipole_field, dim3(blocks), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP);
+        hipMemsetAsync(sums, 0, sizeof(double) * 8, st);
+        hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 1, 0.0, 0.0);
+        rc = readSums();
+        if (rc != 0) return rc;
+        const double aD = h[2] != 0.0 ? rzD / h[2] : 0.0, aP = h[3] != 0.0 ? rzP / h[3] : 0.0;
+        hipMemsetAsync(sums, 0, sizeof(double) * 8, st);
+        hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 2, aD, aP);
+        rc = readSums();
+        if (rc != 0) return rc;
+        const double bD = rzD != 0.0 ? h[0] / rzD : 0.0, bP = rzP != 0.0 ? h[1] / rzP : 0.0;
+        rzD = h[0]; rzP = h[1];
+        epsilon = debye * sqrt(fmax(h[4], h[5]) / a.n);
+        hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 3, bD, bP);
+        iteration++;
+    }
+    if (mp->status != nullptr) { mp->status[0] = epsilon; mp->status[1] = iteration; }
+    // potentials of the converged dipoles (the force kernels read them)
+    dipole_potential(pme, a, a.indD, a.phiInd, st);
+    dipole_potential(pme, a, a.indP, a.phiIndP, st);
+    return epsilon < mp->target_epsilon ? 0 : -1;
 }
 
 }  // namespace
@@ -619,6 +791,7 @@ extern "C" int ommhip_amoeba_multipole_induce(const ommhip_amoeba_multipole* mp,
     MpArgs a;
     if (!make_args(mp, pos_d, box, a)) return 1;
     launch_induce(mp, a, (hipStream_t) stream);
+    if (a.mutual) { const int rc = solve_mutual(mp, a, (hipStream_t) stream); if (rc != 0) return rc; }
     return (int) hipGetLastError();
 }
 
@@ -632,11 +805,14 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
     const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
     const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
     launch_induce(mp, a, st);
-    // reciprocal potential of the induced dipoles
-    hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, st);
-    hipLaunchKernelGGL(k_mp_spread<true>, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
-    ommhip_pme_convolve(pme, st);
-    hipLaunchKernelGGL(k_mp_potential, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.phiInd);
+    if (a.mutual) { const int rc = solve_mutual(mp, a, st); if (rc != 0) return rc; }      // -1: not converged
+    else {
+        // reciprocal potential of the induced dipoles (mu_d + mu_p) / 2
+        hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, st);
+        hipLaunchKernelGGL(k_mp_spread<true>, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.indD, 0.5, a.indP, 0.5);
+        ommhip_pme_convolve(pme, st);
+        hipLaunchKernelGGL(k_mp_potential, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.phiInd);
+    }
     hipLaunchKernelGGL(k_mp_forces, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_mp_torque_to_force, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
     return (int) hipGetLastError();

@@ -13,13 +13,14 @@
 void runPlatformTests() {}
 
 typedef void (*Case)(std::vector<Vec3>& forces, double& energy);
-static void water4(std::vector<Vec3>& f, double& e) { setupAndGetForcesEnergyMultipoleWater(AmoebaMultipoleForce::PME, AmoebaMultipoleForce::Direct, 0.70, 20, f, e); }
-static void ionsAndWater(std::vector<Vec3>& f, double& e) { setupAndGetForcesEnergyMultipoleIonsAndWater(AmoebaMultipoleForce::PME, AmoebaMultipoleForce::Direct, 0.70, 20, "parity", f, e); }
+static AmoebaMultipoleForce::PolarizationType gPolarization = AmoebaMultipoleForce::Direct;
+static void water4(std::vector<Vec3>& f, double& e) { setupAndGetForcesEnergyMultipoleWater(AmoebaMultipoleForce::PME, gPolarization, 0.70, 20, f, e); }
+static void ionsAndWater(std::vector<Vec3>& f, double& e) { setupAndGetForcesEnergyMultipoleIonsAndWater(AmoebaMultipoleForce::PME, gPolarization, 0.70, 20, "parity", f, e); }
 static void water648(std::vector<Vec3>& f, double& e) {
     std::string name = "parity";
     std::vector<double> moments, potential;
     std::vector<Vec3> grid;
-    setupAndGetForcesEnergyMultipoleLargeWater(AmoebaMultipoleForce::PME, AmoebaMultipoleForce::Direct, 0.70, 24, name, f, e, moments, grid, potential);
+    setupAndGetForcesEnergyMultipoleLargeWater(AmoebaMultipoleForce::PME, gPolarization, 0.70, 24, name, f, e, moments, grid, potential);
 }
 
 // point multipoles given in the lab frame (NoAxisType), no covalent maps: which rank of the expansion / which part of the polarization is off?
@@ -95,9 +96,10 @@ int main(int argc, char* argv[]) {
     }
     try {
         setupKernels(argc, argv);
-        const char* names[] = {"4 waters", "2 ions + 2 waters", "216 waters"};
-        Case cases[] = {water4, ionsAndWater, water648};
-        for (int c = 0; c < 3; c++) {
+        const char* names[] = {"4 waters", "2 ions + 2 waters", "216 waters", "4 waters, mutual", "2 ions + 2 waters, mutual", "216 waters, mutual"};
+        Case cases[] = {water4, ionsAndWater, water648, water4, ionsAndWater, water648};
+        for (int c = 0; c < 6; c++) {
+            gPolarization = c < 3 ? AmoebaMultipoleForce::Direct : AmoebaMultipoleForce::Mutual;
             std::vector<Vec3> fn, fr;
             double en = 0, er = 0;
             unsetenv("OPENMM_HIP_REFERENCE_AMOEBA_MULTIPOLE");
@@ -108,7 +110,7 @@ int main(int argc, char* argv[]) {
             for (size_t i = 0; i < fr.size(); i++) rms += fr[i].dot(fr[i]);
             rms = std::sqrt(rms / fr.size());
             for (size_t i = 0; i < fr.size(); i++) { Vec3 d = fn[i] - fr[i]; worst = std::max(worst, std::sqrt(d.dot(d)) / rms); }
-            printf("%-20s atoms %4d  E native %.8f  E reference %.8f  rel %.2e   force max diff / rms %.2e\n", names[c], (int) fr.size(), en, er, std::fabs(en - er) / std::max(std::fabs(er), 1.0), worst);
+            printf("%-26s atoms %4d  E native %.8f  E reference %.8f  rel %.2e   force max diff / rms %.2e\n", names[c], (int) fr.size(), en, er, std::fabs(en - er) / std::max(std::fabs(er), 1.0), worst);
             if (getenv("AMOEBA_PARITY_VERBOSE") != NULL)
                 for (size_t i = 0; i < fr.size() && i < 12; i++) printf("   %2d  native % .6f % .6f % .6f   reference % .6f % .6f % .6f\n", (int) i, fn[i][0], fn[i][1], fn[i][2], fr[i][0], fr[i][1], fr[i][2]);
             if (worst > 1e-4 || std::fabs(en - er) > 1e-4 * std::max(std::fabs(er), 1.0)) bad++;

@@ -51,7 +51,7 @@ PAIR_FLOP = 45            # flop per evaluated pair (F_dir = 1
 # is quoted only while their hash matches.  (neighbor.hip -- the list BUILDER -- was part of the set until the end of round 2; a change
 # of the list FORMAT shows up in nonbonded.hip, which reads it.)
 KERNEL_SOURCES = ("nonbonded.hip", "force_front.hip", "pme.hip", "common.h")
-WORKLOADS = ["dhfr", "dhfr_like", "water1k", "water24k", "water98k", "apoa1", "water1m"]
+WORKLOADS = ["dhfr", "dhfr_like", "water1k", "water24k", "water98k", "apoa1", "water1m", "water1m_lattice"]
 LATTICE_PREPARE_STEPS = 1000     # untimed relaxation of a generated (jittered-lattice) water box before warm-up and timing
 EMULATED = os.environ.get("BENCH_EMULATED") == "1"     # tests only: the CPU SIMT emulator build of the plugin (tests/emu), to run the N > 1 flow without a GPU
 
@@ -120,8 +120,16 @@ def make_workload(name, seed):
     if name == "apoa1":
         return T.apoa1_like(seed=seed)           # 92 224 atoms in the apoa1 box (BASELINE.json configs[2] stand-in)
     if name == "water1m":
-        return T.water_box(69, seed=seed)        # 985 527 atoms, L = 21.4 nm (BASELINE.json configs[3]; lattice start)
+        return T.water_tiled(3)                  # 985 527 atoms, L = 21.4 nm (BASELINE.json configs[3]): 27 copies of an equilibrated tile
+    if name == "water1m_lattice":
+        return T.water_box(69, seed=seed)        # the same size as a jittered lattice (rounds 1-3 measured this: it melts at ~900 K)
     return T.water_box(32, seed=seed)
+
+
+def default_prepare(w):
+    """untimed steps before warm-up: none for an equilibrated fixture (`prepare_steps` of a tiled one: its copies decorrelate), the
+    relaxation of a generated lattice otherwise"""
+    return getattr(w, "prepare_steps", 0) if getattr(w, "velocities", None) is not None else LATTICE_PREPARE_STEPS
 
 
 def start_platform(w, platform, dt_ps, warmup, props=None, seed=1, prepare=0):
@@ -203,7 +211,7 @@ def main():
     decomposed = world > 1
     dt_ps = args.dt_fs * 1e-3
     w = make_workload(workload, seed=1)
-    prepare = args.prepare_steps if args.prepare_steps >= 0 else (0 if getattr(w, "velocities", None) is not None else LATTICE_PREPARE_STEPS)
+    prepare = args.prepare_steps if args.prepare_steps >= 0 else default_prepare(w)
     props = {"DeviceIndex": str(local_rank)}
     for kv in filter(None, args.props.split(",")):
         k, v = kv.split("=")
@@ -264,7 +272,9 @@ def main():
         "dtype": "f32",
         # N = 1: one run of the real benchmark System; N > 1: ONE fixed box over N GPUs (total work fixed)
         "data": ("real: examples/5dfr_solv-cube_equil.pdb with amber99sb + tip3p parameters (committed fixture tests/golden/dhfr_5dfr_amber99sb_tip3p.npz, equilibrated coordinates and velocities)"
-                 if workload == "dhfr" else "synthetic: %s (generated coordinates, standard TIP3P parameters)" % w.name),
+                 if workload == "dhfr" else
+                 ("synthetic: %s -- 27 copies of a 36 501-atom TIP3P box equilibrated for 60 ps at 300 K on this platform (tests/golden/water_tile_36501_equilibrated.npz, tools/make_water_tile.py)" % w.name)
+                 if workload == "water1m" else "synthetic: %s (generated coordinates, standard TIP3P parameters)" % w.name),
         "config": {"workload": "%s: %d atoms, PME cutoff 0.9 nm grid %s, LangevinMiddle %.0f fs, HBonds constraints + rigid water; %s" % (
             w.name, w.num_atoms, "x".join(str(g) for g in grid), args.dt_fs,
             ("ONE box domain-decomposed over %d GPUs (x slabs, %s collectives)" % (world, transport)) if decomposed else "single GPU"),
@@ -458,12 +468,12 @@ def main():
     if world == 1 and workload == "dhfr" and not args.no_scale_workload:
         try:
             sw = make_workload("water1m", seed=1)
-            ssys, snb, sinteg, sctx = start_platform(sw, "HIP", dt_ps, args.warmup, {"DeviceIndex": str(local_rank)}, seed=1, prepare=LATTICE_PREPARE_STEPS)
+            ssys, snb, sinteg, sctx = start_platform(sw, "HIP", dt_ps, args.warmup, {"DeviceIndex": str(local_rank)}, seed=1, prepare=default_prepare(sw))
             s_elapsed, s_st = timed_run(sinteg, sctx, args.steps, barrier)
             out["scale_workload"] = {"workload": "%s: ONE box of %d atoms, PME grid %s, single GPU (the N = 1 point of the strong-scaling curve that "
                                                  "bench.py --gpus N reports for N > 1)" % (sw.name, sw.num_atoms, "x".join(str(g) for g in snb.getPMEParametersInContext(sctx)[1:])),
                                      "value": round(MR.ns_per_day(s_elapsed, args.steps, args.dt_fs), 3), "unit": "ns/day",
-                                     "ms_per_step": round(1e3 * s_elapsed / args.steps, 5), "steps": args.steps, "prepare_steps": LATTICE_PREPARE_STEPS}
+                                     "ms_per_step": round(1e3 * s_elapsed / args.steps, 5), "steps": args.steps, "prepare_steps": default_prepare(sw)}
             sctx.close()
         except Exception as e:
             out["scale_workload"] = {"value": None, "error": str(e)}
@@ -473,7 +483,7 @@ def main():
         for key, wl_name, dt_fs in (("dhfr_4fs", "dhfr", 4.0), ("apoa1", "apoa1", 2.0)):
             try:
                 xw = w if wl_name == "dhfr" else make_workload(wl_name, seed=1)
-                xprep = 0 if getattr(xw, "velocities", None) is not None else LATTICE_PREPARE_STEPS
+                xprep = default_prepare(xw)
                 xsys, xnb, xinteg, xctx = start_platform(xw, "HIP", dt_fs * 1e-3, args.warmup, {"DeviceIndex": str(local_rank)}, seed=1, prepare=xprep)
                 x_elapsed, x_st = timed_run(xinteg, xctx, args.steps, barrier)
                 if not np.isfinite(x_st.potentialEnergy):

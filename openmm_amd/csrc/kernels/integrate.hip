@@ -427,7 +427,7 @@ struct UnitArgs {
     uint4* posWire;
     double invBox[3];
     int ranks, rank, slotsPerRank, trailerSlot;
-    const int* ddFlags;       // halo mode: [1] = an owned atom is near the drift margin -> fourth double of the trailer (every rank sees it one step later)
+    const int* ddFlags;       // halo mode: [1] = an owned atom is near (1) or close to the end of (3) the drift margin -> fourth double of the trailer (every rank sees it one step later)
 };
 
 // SMALL: no unit is a SHAKE cluster (only SETTLE waters and free atoms: every unit has at most three atoms) -- the state of a fourth
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(128) void k_step_units(IntArgs a, UnitArgs u) {
         sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
         if (threadIdx.x == 0) {
             u.cm[0] = sx; u.cm[1] = sy; u.cm[2] = sz; *counter = 0;
-            if (u.posWire != nullptr) *(double4*) (u.posWire + (size_t) u.rank * u.slotsPerRank + u.trailerSlot) = make_double4(sx, sy, sz, u.ddFlags != nullptr && u.ddFlags[1] != 0 ? 1.0 : 0.0);
+            if (u.posWire != nullptr) *(double4*) (u.posWire + (size_t) u.rank * u.slotsPerRank + u.trailerSlot) = make_double4(sx, sy, sz, u.ddFlags != nullptr ? (double) u.ddFlags[1] : 0.0);
         }
     }
 }

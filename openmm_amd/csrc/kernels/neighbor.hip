@@ -681,9 +681,9 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
     if (g == 0 && a.ddFlags != nullptr && a.posWire != nullptr) {
         // some rank saw one of its atoms near the drift margin one step ago (the flag travelled in its trailer): every rank raises
         // the same word at the same evaluation, the hosts re-sort together
-        bool any = false;
-        for (int r = 0; r < a.ddRanks; r++) any = any || ((const double4*) (a.posWire + (size_t) r * a.ddSlotsPerRank + a.ddTrailerSlot))->w != 0.0;
-        if (any) a.ddFlags[2] = 1;
+        int level = 0;                                         // 1: re-sort soon (off the step), 3: re-sort now
+        for (int r = 0; r < a.ddRanks; r++) level |= (int) ((const double4*) (a.posWire + (size_t) r * a.ddSlotsPerRank + a.ddTrailerSlot))->w;
+        if (level != 0) a.ddFlags[2] |= level;
     }
     const int atom = a.atomOfSlot[sl];
     const bool valid = inRange && atom >= 0;
@@ -701,7 +701,12 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
                 // drift along x since the re-sort (wrap-around arithmetic of the 32-bit fractions = minimum image)
                 const int d = (int) (u.x - a.wireRef[sl].x);
                 const unsigned ad = (unsigned) (d < 0 ? -d : d);
-                if (ad > a.ddWarn) a.ddFlags[1] = 1;
+                if (ad > a.ddWarn) {
+                    // [1]: what this rank tells the others through its trailer -- 1 near the margin, 3 when little of it is left
+                    // (a re-sort that lags would come too late); [3]: the largest drift seen (diagnostics)
+                    atomicOr(&a.ddFlags[1], ad - a.ddWarn > (a.ddMax - a.ddWarn) / 5 * 3 ? 3 : 1);
+                    atomicMax(&a.ddFlags[3], (int) (ad >> 1));
+                }
                 if (ad > a.ddMax) a.ddFlags[0] = 1;
             }
             if (a.posScatter != nullptr && !own) {

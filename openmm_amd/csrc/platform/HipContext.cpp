@@ -434,10 +434,17 @@ void HipContext::pollDriftFlags() {
     }
     else if ((n & 7) == 4) {
         HIP_CHECK(ommhip_event_sync(ddFlagsEvent));          // recorded four evaluations ago: long complete
-        if (pinnedDdFlags[0] != 0)
-            throw OpenMMException("HIP platform: an atom drifted further along x between two re-sorts than the halo of the domain decomposition allows; "
-                                  "lower OPENMM_HIP_REORDER_INTERVAL or raise OPENMM_HIP_DD_DRIFT");
-        if (pinnedDdFlags[2] != 0) reorderDue = true;        // every rank reads the same word at the same evaluation: they re-sort together
+        if (pinnedDdFlags[0] != 0) {
+            char detail[256];
+            snprintf(detail, sizeof(detail), " (rank %d: %.3f nm of the %.3f nm margin, order %d steps old, re-sort %d, interval %d, lag %d)", domain.rank,
+                     2.0 * pinnedDdFlags[3] / 4294967296.0 * box[0], haloDrift, stepsSinceReorder, reorderCount, reorderInterval, reorderLag);
+            throw OpenMMException(string("HIP platform: an atom drifted further along x between two re-sorts than the halo of the domain decomposition allows; "
+                                         "lower OPENMM_HIP_REORDER_INTERVAL or raise OPENMM_HIP_DD_DRIFT") + detail);
+        }
+        // every rank reads the same word at the same evaluation: they re-sort together -- off the step while the margin lasts, at once
+        // (the next step waits for it) when an atom has used 80 % of it: a hot system, e.g. a lattice start that melts
+        if ((pinnedDdFlags[2] & 2) != 0) reorderRequested = true;
+        else if (pinnedDdFlags[2] != 0) reorderDue = true;
     }
 }
 

@@ -182,6 +182,25 @@ def _load_fixture(w, filename):
     return w
 
 
+def water_tiled(reps=3):
+    """reps^3 copies of an equilibrated water box: tests/golden/water_tile_36501_equilibrated.npz holds 23^3 rigid TIP3P waters after
+    60 ps at 300 K on the HIP platform (tools/make_water_tile.py).  reps = 3 gives the 985 527 atoms and the 21.4 nm box of
+    `water_box(69)` -- BASELINE.json configs[3]'s size -- as a liquid at 300 K with thermal velocities, where the lattice start of
+    `water_box` melts at several hundred kelvin above that.  A periodic tiling of an equilibrium configuration is one itself; the
+    copies decorrelate within the first steps of a Langevin run (independent noise per atom)."""
+    import os
+    d = np.load(os.path.join(H.ROOT, "tests", "golden", "water_tile_36501_equilibrated.npz"))
+    L, n_side = float(d["box"]), int(d["n_side"])
+    w = water_box(n_side * reps, seed=0)                 # parameters, constraints, exceptions (the positions are replaced below)
+    assert abs(float(w.box[0][0]) - reps * L) < 1e-9 * L
+    shifts = np.stack(np.meshgrid(*[np.arange(reps)] * 3, indexing="ij"), -1).reshape(-1, 3) * L
+    w.positions = (d["positions"].astype(np.float64)[None, :, :] + shifts[:, None, :]).reshape(-1, 3)
+    w.velocities = np.tile(d["velocities"].astype(np.float64), (reps ** 3, 1))
+    w.name = "water-%d-equilibrated" % len(w.positions)
+    w.prepare_steps = 200                                # untimed steps before a measurement: the copies go their own ways
+    return w
+
+
 def dhfr():
     """The real DHFR benchmark System (examples/benchmark.py `pme`: 5dfr_solv-cube_equil.pdb, amber99sb + tip3p, PME 0.9 nm, HBonds,
     rigid water, CMMotionRemover) from the fixture tests/golden/dhfr_5dfr_amber99sb_tip3p.npz, which tools/make_dhfr_fixture.py

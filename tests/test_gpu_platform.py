@@ -219,6 +219,33 @@ def test_water1m_forces_within_1e4_of_reference():
     assert abs(st.potentialEnergy - float(g["energy"])) < 1e-5 * max(abs(float(g["energy"])), 5.0 * w.num_atoms)
 
 
+def test_water1m_tiled_forces_match_reference_of_the_tile():
+    """The bench's 1M-atom workload (testsystems.water_tiled(3): 27 copies of an equilibrated 36 501-atom box, PME grid 192^3) against the
+    Reference platform's forces of ONE tile as a periodic box on a 64^3 grid (tools/make_golden_water_tile_forces.py, oracle/_ref): the
+    same charge density on the same mesh spacing, so every copy of an atom feels the tile's force and the energy is 27 times the
+    tile's.  A full-size parity case on a liquid at 300 K; the lattice start above is the other one."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_forces_water_tile_36501_sample.npz"))
+    reps = 3
+    w = T.water_tiled(reps)
+    alpha, grid = float(g["pme"][0]), int(g["pme"][1])
+    w.pme_params = (alpha, reps * grid, reps * grid, reps * grid)
+    system, nb = w.build()
+    ctx = H.Context(system, H.Integrator(H.VERLET, 0.001), "HIP")
+    ctx.setPositions(w.positions)
+    st = ctx.getState(getForces=True, getEnergy=True)
+    assert tuple(nb.getPMEParametersInContext(ctx)[1:]) == (reps * grid,) * 3
+    ctx.close()
+    n_tile = w.num_atoms // reps ** 3
+    idx, rms = g["indices"], float(g["rms_force"])
+    f = st.forces.reshape(reps ** 3, n_tile, 3)[:, idx, :]
+    err = np.linalg.norm(f - g["forces"][None, :, :], axis=2) / rms
+    print("tiled water-1M: force max-rel-err over %d sampled atoms x %d copies %.3g, median %.3g; E / 27 = %.3f, E_ref(tile) = %.3f" % (
+        len(idx), reps ** 3, err.max(), np.median(err), st.potentialEnergy / reps ** 3, float(g["energy"])))
+    assert err.max() < 1e-4
+    assert np.median(err) < 4e-5
+    assert abs(st.potentialEnergy / reps ** 3 - float(g["energy"])) < 1e-5 * abs(float(g["energy"]))
+
+
 def test_dhfr_size_invariants():
     """Size-independent properties at the BASELINE size: constraints hold, temperature stays put, energy is finite
     after 300 LangevinMiddle steps; a repeated force evaluation is bit-identical for the direct-space part."""

@@ -241,6 +241,18 @@ def test_halo_drift_guard_triggers_a_common_resort_on_emulator(tmp_path):
                   cases='(("water, halo drift", T.water_box(8, seed=5), 24),)')
 
 
+def test_halo_drift_guard_resorts_at_once_when_the_margin_runs_out_on_emulator(tmp_path):
+    """A hot system (the bench's 1M-atom lattice start melts at 1700 K): an atom uses up the margin before a re-sort that lags could
+    apply.  At 80 % of the margin the flag in the trailer says so and every rank re-sorts at the next step instead -- here the lag
+    (1000 steps) is longer than the run, so only that path can keep the 0.12 nm margin from overflowing (which raises)."""
+    import pytest
+    from conftest import EMU_BUILD
+    if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
+        pytest.skip("emulated plugin not built (run __graft_entry__.build())")
+    _run_dd_child(tmp_path, True, None, 100, 29573, env={"OPENMM_HIP_DD_DRIFT": "0.12", "OPENMM_HIP_DD_WARN": "0.4", "OPENMM_HIP_REORDER_INTERVAL": "1000", "OPENMM_HIP_REORDER_LAG": "1000"},
+                  cases='(("water, halo drift", T.water_box(8, seed=5), 24),)')
+
+
 def test_four_rank_domain_decomposition_on_emulator(tmp_path):
     """Four slabs: every rank has two distinct ring neighbours for the potential planes, the all-to-alls move 4 x 4 chunks, and
     in a 2.5 nm box the 0.6 nm slabs are thinner than the cutoff -- each rank's partners span all the others."""

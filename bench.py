@@ -354,6 +354,7 @@ def main():
                                "traffic_source": traffic_source,
                                "algorithmic_bytes_per_launch": int(algo_bytes), "avg_kernel_us": round(avg_us, 3) if avg_us else None,
                                "rows": int(rows), "chunks": int(chunks), "rebuilds": int(stats[5]),
+                               "rows_as_built": int(stats[7]),          # before the per-step pruning to the cutoff itself (`rows` is what the pair kernel walks)
                                "pair_evals_per_launch": int(rows) * 64 * 32, "kernel_timers_us": timers, "kernel_sources_sha": sha,
                                "note": "working set is cache-resident at DHFR size (the kernel is FP32-issue bound there, see fp32_issue); see DESIGN.md (d)"}
             # the bound that actually applies to the pair kernel at this size: FP32 vector issue.  Evaluated pairs x 45 flop over

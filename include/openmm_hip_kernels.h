@@ -27,7 +27,7 @@ extern "C" {
 #define OMMHIP_TILE 32        /* atoms per i-block                       */
 #define OMMHIP_ROW 64         /* j-atoms per neighbour-list row          */
 #define OMMHIP_CHUNK_ROWS 2   /* rows per chunk                          */
-#define OMMHIP_NL_STATE_INTS 8
+#define OMMHIP_NL_STATE_INTS 12
 #define OMMHIP_NL_STATE_OVERFLOW 2   /* state word: a rebuild ran out of rows (sticky until the host clears it) */
 #define OMMHIP_NL_STATE_FROZEN 6     /* state word: integration steps skipped while the overflow word was set */
 
@@ -132,7 +132,9 @@ typedef struct ommhip_neighbor_list {
     const int* excl_start;     /* [num_atoms+1] CSR of excluded partners (atom indices) */
     const int* excl_atoms;
     const void* excl_block_range; /* int2[padded_atoms/32] or NULL: per i-block, lowest/highest block that holds an exclusion partner */
-    int* state;               /* int[OMMHIP_NL_STATE_INTS]: 0 rebuild-request, 1 chunks used, 2 overflow, 3 scratch, 4 #rebuilds, 5 scratch; zero-initialised by the caller */
+    int* state;               /* int[OMMHIP_NL_STATE_INTS]: 0 rebuild-request, 1 chunks used, 2 overflow, 3 scratch, 4 #rebuilds, 5 scratch,
+                               * 6 steps skipped (OMMHIP_NL_STATE_FROZEN), 7 chunks of the pruned list, 8-9 scratch, 10 pruning not possible;
+                               * zero-initialised by the caller */
     void* block_center;        /* float4[padded_atoms/32] */
     void* block_half;          /* float4[padded_atoms/32] */
     void* chunk_info;          /* int2[max_chunks]  (i-block, nrows | maskedRowBits<<8) */
@@ -206,7 +208,24 @@ typedef struct ommhip_neighbor_list {
     unsigned dd_warn, dd_max;
     int* dd_flags;                /* device int[4], zeroed by the host at every re-sort */
     int dd_ranks, dd_slots_per_rank, dd_trailer_slot;
+    /* The pruned ("inner") list, optional (all NULL = the pair kernel walks the rows above).  The rows above are built with
+     * cutoff + padding and live until an atom has moved padding / 2: at any one step only ~60 % of their j atoms lie within the
+     * cutoff itself of the i-block's bounding box.  With these arrays (same shapes as chunk_info / row_j / row_mask; block_runs:
+     * int[1 + 2 * 4] per i-block) every launch of the list builder -- it is enqueued at every step and returns at once unless a
+     * rebuild is due -- also re-packs each i-block's rows: entries whose j atom lies within the cutoff of the block's CURRENT
+     * bounding box (and whose mask is not empty) are compacted into fresh rows, and ommhip_nb_direct / ommhip_pairs_with_fft walk
+     * those.  The test is made on the coordinates the pair kernel itself uses, with a relative margin of 1e-4 on the squared
+     * cutoff: no pair inside the cutoff (or inside the rounding band the cutoff-edge path re-decides) is lost. */
+    void* chunk_info_inner;
+    int* row_j_inner;
+    unsigned* row_mask_inner;
+    int* block_runs;
 } ommhip_neighbor_list;
+
+/* sizeof() of the structs of this header as the library was compiled: 0 ommhip_neighbor_list, 1 ommhip_nonbonded_params, 2 ommhip_pme,
+ * 3 ommhip_term_batch, 4 ommhip_integrator_state, 5 ommhip_step_units, 6 ommhip_ccma; 0 for anything else.  A foreign-language
+ * binding (ctypes, cgo, JNI) checks its mirror against it when it loads the library. */
+size_t ommhip_struct_size(int which);
 
 typedef struct ommhip_nonbonded_params {
     int ewald;                 /* 1: erfc(alpha r) real-space Ewald/PME term, 0: reaction field / plain Coulomb */

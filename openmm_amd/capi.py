@@ -14,7 +14,7 @@ PRODUCT_LIB = os.path.join(_HERE, "lib", "libopenmm_hip_kernels.so")
 TILE = 32
 ROW = 64
 CHUNK_ROWS = 2
-NL_STATE_INTS = 8
+NL_STATE_INTS = 12
 
 
 class NeighborList(C.Structure):
@@ -28,6 +28,9 @@ class NeighborList(C.Structure):
         ("cell_start", C.c_void_p), ("cell_blocks", C.c_void_p), ("cell_boxes", C.c_void_p), ("cell_meta", C.c_void_p), ("max_cells", C.c_int), ("cell_min_blocks", C.c_int),
         ("first_block", C.c_int), ("owned_blocks", C.c_int), ("posq_rel", C.c_void_p),
         ("dd_mode", C.c_int), ("pos_wire", C.c_void_p), ("pos_scatter", C.c_void_p), ("posq_rel_lo", C.c_void_p),
+        ("num_active_ranges", C.c_int), ("active_range", C.c_int * 8), ("wire_ref", C.c_void_p), ("dd_guard_atom", C.c_void_p),
+        ("dd_warn", C.c_uint), ("dd_max", C.c_uint), ("dd_flags", C.c_void_p), ("dd_ranks", C.c_int), ("dd_slots_per_rank", C.c_int), ("dd_trailer_slot", C.c_int),
+        ("chunk_info_inner", C.c_void_p), ("row_j_inner", C.c_void_p), ("row_mask_inner", C.c_void_p), ("block_runs", C.c_void_p),
     ]
 
 
@@ -114,6 +117,13 @@ class Kernels:
         self.path = path
         self.lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
         self.lib.ommhip_error_string.restype = C.c_char_p
+        # the ctypes mirrors above against the structs the library was compiled with
+        self.lib.ommhip_struct_size.restype = C.c_size_t
+        self.lib.ommhip_struct_size.argtypes = [C.c_int]
+        for which, mirror in ((0, NeighborList), (1, NonbondedParams), (2, Pme)):
+            if self.lib.ommhip_struct_size(which) != C.sizeof(mirror):
+                raise KernelError("%s: ctypes mirror of struct %d has %d bytes, the library's has %d -- openmm_amd/capi.py is out of date with include/openmm_hip_kernels.h"
+                                  % (path, which, C.sizeof(mirror), self.lib.ommhip_struct_size(which)))
 
     def __getattr__(self, name):
         fn = getattr(self.lib, "ommhip_" + name)

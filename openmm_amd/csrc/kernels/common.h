@@ -10,6 +10,7 @@
 //   * A wavefront is 64 lanes.  Block sizes are multiples of 64.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #define OMM_TILE 32            // atoms per i-block
 #define OMM_ROW 64             // j-atoms per neighbour-list row (= one wavefront)
@@ -23,6 +24,15 @@
 typedef long long omm_fixed;   // 64-bit fixed-point force component
 
 namespace omm {
+
+// Does the list builder keep the per-step pruned rows of this list (ommhip_neighbor_list::chunk_info_inner), and the pair kernel walk
+// them?  One rule for both sides.  (A template so that this header need not know the struct; OPENMM_HIP_NO_PRUNE is an A/B knob.)
+template <class NL>
+inline bool list_is_pruned(const NL* nl) {
+    static const bool off = getenv("OPENMM_HIP_NO_PRUNE") != nullptr;
+    return !off && nl->cutoff > 0 && nl->pbc != 2 && nl->chunk_info_inner != nullptr && nl->row_j_inner != nullptr && nl->row_mask_inner != nullptr &&
+           nl->block_runs != nullptr && nl->posq_rel != nullptr;
+}
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
@@ -161,7 +171,9 @@ __device__ __forceinline__ void min_image(float& dx, float& dy, float& dz, const
 //   NUM_CHUNKS   chunks of the current list (published by the last builder workgroup; read by the pair kernel)
 //   OVERFLOW     sticky: a rebuild needed more chunks than allocated (host grows the arrays and clears it)
 //   ALLOC        working allocation counter of a rebuild in flight (zero at rest)
-enum { ST_REBUILD = 0, ST_NUM_CHUNKS = 1, ST_OVERFLOW = 2, ST_BLOCKS_DONE = 3, ST_REBUILD_COUNT = 4, ST_ALLOC = 5 };
+enum { ST_REBUILD = 0, ST_NUM_CHUNKS = 1, ST_OVERFLOW = 2, ST_BLOCKS_DONE = 3, ST_REBUILD_COUNT = 4, ST_ALLOC = 5,
+       ST_FROZEN = 6 /* integrate.hip */,
+       ST_NUM_CHUNKS_INNER = 7, ST_ALLOC_INNER = 8, ST_PRUNE_DONE = 9, ST_NO_PRUNE = 10 };
 
 inline Box make_box(const double* bv) {
     // bv = {ax, bx, by, cx, cy, cz}

@@ -39,6 +39,7 @@ namespace {
 #ifndef NL_ROUND
 #define NL_ROUND 4            // passes a wavefront runs between two workgroup-wide flush checks (NL_WAVES x NL_ROUND x 64 <= NL_LIST - NL_FLUSH)
 #endif
+#define NL_MAX_RUNS 8         // flushes of one i-block the pruning pass keeps track of (more: the pair kernel walks the unpruned rows)
 #ifndef NL_BIG_HALF
 #define NL_BIG_HALF 1.0       // blocks with a half extent above this fraction of the list cutoff are not binned
 #endif
@@ -74,6 +75,9 @@ struct NlArgs {
     int2* chunkInfo;
     int* rowJ;
     unsigned* rowMask;
+    // the pruned list (null: none) -- see ommhip_neighbor_list::chunk_info_inner
+    int2* chunkInfoInner; int* rowJInner; unsigned* rowMaskInner; int* blockRuns;
+    float cutoff, pruneCutoff2;       // the cutoff itself; its square with the margin of the prune test
     // cell-binned candidate search (large rectangular systems): blocks bucketed by the grid cell of their centre
     int cellMode, ncx, ncy, ncz;
     float cellInvX, cellInvY, cellInvZ;   // cells per nm
@@ -270,6 +274,7 @@ struct NlShared {
     int candY[NL_CAND];
     int rowMasked[NL_LIST / OMM_ROW];
     int candCount, listCount, chunkBase, candOverflow;
+    int runCount, runBase[NL_MAX_RUNS], runRows[NL_MAX_RUNS];      // what this workgroup flushed: first chunk and rows of every flush
     // the i atoms of X relative to its centre, one array per component: two neighbouring atoms come back with one 64-bit
     // broadcast read, ready for the packed-FP32 exact test
     float ix[OMM_TILE], iy[OMM_TILE], iz[OMM_TILE];
@@ -277,8 +282,7 @@ struct NlShared {
 
 // X = i-block of this workgroup, numWorkgroups = number of builder workgroups of the launch (for the hand-over at the end)
 template <int PBC>
-__device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const int numWorkgroups, NlShared& sh) {
-    if (a.state[ST_REBUILD] == 0) return;
+__device__ __forceinline__ void nl_build_body(const NlArgs& a, const int X, const int numWorkgroups, NlShared& sh) {
     int* const listJ = sh.listJ;
     unsigned* const listM = sh.listM;
     int* const candY = sh.candY;
@@ -308,7 +312,7 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
     const unsigned iValidMask = (unsigned) __ballot(iValid);
     const float4 cX = a.blockCenter[X], hX = a.blockHalf[X];
     const int2 exclRange = a.exclBlockRange != nullptr ? a.exclBlockRange[X] : make_int2(0, a.numBlocks);
-    if (t == 0) { sCandCount = 0; sListCount = 0; sChunkBase = 0; sCandOverflow = 0; }
+    if (t == 0) { sCandCount = 0; sListCount = 0; sChunkBase = 0; sCandOverflow = 0; sh.runCount = 0; }
     // i atoms relative to the block centre.  When the block plus the list cutoff fits inside half a box length on
     // every axis, the image of j nearest to the centre is also the image nearest to every i atom within range, so
     // the exact test needs no per-pair image search (pairs beyond the list cutoff can only come out farther).
@@ -326,7 +330,11 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
         const int nRows = final ? (total + OMM_ROW - 1) / OMM_ROW : total / OMM_ROW;
         const int nChunks = (nRows + OMM_CHUNK_ROWS - 1) / OMM_CHUNK_ROWS;
         if (nRows > 0) {
-            if (t == 0) sChunkBase = atomicAdd(&a.state[ST_ALLOC], nChunks);
+            if (t == 0) {
+                sChunkBase = atomicAdd(&a.state[ST_ALLOC], nChunks);
+                if (sh.runCount < NL_MAX_RUNS) { sh.runBase[sh.runCount] = sChunkBase; sh.runRows[sh.runCount] = nRows; }
+                sh.runCount++;
+            }
             __syncthreads();
             const int chunkBase = sChunkBase;
             for (int r = wave; r < nRows; r += NL_WAVES) {
@@ -621,6 +629,12 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
     if (cellDone) break;
     }
     flush(true);
+    if (a.blockRuns != nullptr && t <= NL_MAX_RUNS) {
+        // the run directory of X, for the pruning passes of the steps that follow
+        int* const dir = a.blockRuns + (size_t) X * (1 + 2 * NL_MAX_RUNS);
+        if (t == 0) { dir[0] = sh.runCount; if (sh.runCount > NL_MAX_RUNS) atomicOr(&a.state[ST_NO_PRUNE], 1); }
+        else if (t - 1 < min(sh.runCount, NL_MAX_RUNS)) { dir[2 * t - 1] = sh.runBase[t - 1]; dir[2 * t] = sh.runRows[t - 1]; }
+    }
 
     // Last workgroup out clears the rebuild request.
     if (t == 0) {
@@ -648,6 +662,129 @@ __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const
             a.state[ST_REBUILD] = 0;
             atomicAdd(&a.state[ST_REBUILD_COUNT], 1);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The pruned list of i-block X (every step): of the entries X's rows hold -- j atoms within cutoff + padding of an atom of X
+// when the list was built -- those whose j atom lies within the cutoff of X's CURRENT bounding box, packed into fresh rows.
+// The position of j in X's frame is formed exactly as the pair kernel forms it (block-relative coordinates plus the offset of
+// the two block centres in the nearest image), the box of X is the one nl_prepare has just computed from the same numbers.
+// Order of the entries is kept (row by row, lane by lane): the pruned rows are a deterministic function of the positions.
+// ------------------------------------------------------------------------------------------------
+template <int PBC>
+__device__ __forceinline__ void nl_prune_body(const NlArgs& a, const int X, const int numWorkgroups, const bool built, NlShared& sh) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int* const listJ = sh.listJ;
+    unsigned* const listM = sh.listM;
+    unsigned long long* const rowBallot = (unsigned long long*) sh.candY;            // [NL_LIST / OMM_ROW]
+    int* const rowOffset = sh.candY + 2 * (NL_LIST / OMM_ROW);                        // [NL_LIST / OMM_ROW + 1]
+    __syncthreads();                                           // the builder is done with its LDS (and its rows are written)
+    if (!built && t == 0) {
+        const int* const dir = a.blockRuns + (size_t) X * (1 + 2 * NL_MAX_RUNS);
+        const int n = dir[0];
+        sh.runCount = n;
+        for (int k = 0; k < min(n, NL_MAX_RUNS); k++) { sh.runBase[k] = dir[1 + 2 * k]; sh.runRows[k] = dir[2 + 2 * k]; }
+    }
+    __syncthreads();
+    const int numRuns = min(sh.runCount, NL_MAX_RUNS);
+    const float4 cX = a.blockCenter[X], hX = a.blockHalf[X];
+    // the cases in which one image per j atom serves all of X (the pair kernel's `single`); anything else is copied unpruned
+    bool exact = PBC == 0;
+    if (PBC == 1) exact = hX.w != 0.f && hX.x + a.cutoff < 0.5f * a.box.ax && hX.y + a.cutoff < 0.5f * a.box.by && hX.z + a.cutoff < 0.5f * a.box.cz;
+    for (int run = 0; run < numRuns; run++) {
+        const int base = sh.runBase[run];
+        int nRows = sh.runRows[run];
+        if ((long long) base * OMM_CHUNK_ROWS + nRows > (long long) a.maxChunks * OMM_CHUNK_ROWS) nRows = max(0, (a.maxChunks - base) * OMM_CHUNK_ROWS);     // the list overflowed
+        // pass 1: which entries stay
+        for (int r = wave; r < nRows; r += NL_WAVES) {
+            const size_t o = ((size_t) base * OMM_CHUNK_ROWS + r) * OMM_ROW + lane;
+            const int j = a.rowJ[o];
+            const unsigned m = a.rowMask[o];
+            bool keep = m != 0u;
+            if (keep && exact) {
+                float4 pj = a.posqRel[j];
+                const float4 cY = a.blockCenter[j >> 5];
+                float ox = cY.x - cX.x, oy = cY.y - cX.y, oz = cY.z - cX.z;
+                if (PBC == 1) {
+                    const float nx = rintf((cY.x - cX.x + pj.x) * a.box.invAx), ny = rintf((cY.y - cX.y + pj.y) * a.box.invBy), nz = rintf((cY.z - cX.z + pj.z) * a.box.invCz);
+                    ox = fmaf(-nx, a.box.axLo, fmaf(-nx, a.box.ax, cY.x)) - cX.x;
+                    oy = fmaf(-ny, a.box.byLo, fmaf(-ny, a.box.by, cY.y)) - cX.y;
+                    oz = fmaf(-nz, a.box.czLo, fmaf(-nz, a.box.cz, cY.z)) - cX.z;
+                }
+                const float dx = fmaxf(0.f, fabsf(pj.x + ox) - hX.x), dy = fmaxf(0.f, fabsf(pj.y + oy) - hX.y), dz = fmaxf(0.f, fabsf(pj.z + oz) - hX.z);
+                keep = dx * dx + dy * dy + dz * dz <= a.pruneCutoff2;
+            }
+            const unsigned long long b = __ballot(keep);
+            if (lane == 0) rowBallot[r] = b;
+        }
+        __syncthreads();
+        if (t == 0) {
+            int sum = 0;
+            for (int r = 0; r < nRows; r++) { rowOffset[r] = sum; sum += __popcll(rowBallot[r]); }
+            rowOffset[nRows] = sum;
+        }
+        __syncthreads();
+        // pass 2: compact into the staging area
+        for (int r = wave; r < nRows; r += NL_WAVES) {
+            const size_t o = ((size_t) base * OMM_CHUNK_ROWS + r) * OMM_ROW + lane;
+            const unsigned long long b = rowBallot[r];
+            if ((b >> lane) & 1ull) {
+                const int pos = rowOffset[r] + lane_prefix_count(b);
+                listJ[pos] = a.rowJ[o];
+                listM[pos] = a.rowMask[o];
+            }
+        }
+        __syncthreads();
+        // write the rows of the pruned list
+        const int total = rowOffset[nRows];
+        const int outRows = (total + OMM_ROW - 1) / OMM_ROW, outChunks = (outRows + OMM_CHUNK_ROWS - 1) / OMM_CHUNK_ROWS;
+        if (outRows > 0) {
+            if (t == 0) sh.chunkBase = atomicAdd(&a.state[ST_ALLOC_INNER], outChunks);
+            __syncthreads();
+            const int outBase = sh.chunkBase;
+            for (int r = wave; r < outRows; r += NL_WAVES) {
+                const int e = r * OMM_ROW + lane;
+                const bool valid = e < total;
+                const int j = valid ? listJ[e] : X * OMM_TILE;
+                const unsigned m = valid ? listM[e] : 0u;
+                const bool masked = __any(m != 0xFFFFFFFFu);
+                if (outBase + r / OMM_CHUNK_ROWS < a.maxChunks) {
+                    const size_t o = ((size_t) outBase * OMM_CHUNK_ROWS + r) * OMM_ROW + lane;
+                    a.rowJInner[o] = j;
+                    a.rowMaskInner[o] = m;
+                }
+                if (lane == 0) sh.rowMasked[r] = masked ? 1 : 0;
+            }
+            __syncthreads();
+            for (int c = t; c < outChunks; c += NL_THREADS) {
+                const int rowsIn = min(OMM_CHUNK_ROWS, outRows - OMM_CHUNK_ROWS * c);
+                int bits = 0;
+                for (int i = 0; i < rowsIn; i++) bits |= sh.rowMasked[OMM_CHUNK_ROWS * c + i] << i;
+                if (outBase + c < a.maxChunks) a.chunkInfoInner[outBase + c] = make_int2(X, rowsIn | (bits << 8));
+            }
+        }
+        __syncthreads();
+    }
+    // last workgroup out publishes the length of the pruned list and returns the working counters to zero
+    if (t == 0) {
+        const int done = atomicAdd(&a.state[ST_PRUNE_DONE], 1);
+        if (done == numWorkgroups - 1) {
+            a.state[ST_NUM_CHUNKS_INNER] = atomicExch(&a.state[ST_ALLOC_INNER], 0);
+            a.state[ST_PRUNE_DONE] = 0;
+        }
+    }
+}
+
+// One workgroup of the per-step list launch: X's rows are rebuilt if a rebuild is due, then (re-)pruned.
+template <int PBC>
+__device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const int numWorkgroups, NlShared& sh) {
+    // (read by every workgroup before the last one out of nl_build_body clears it: that one waits for all of them)
+    const bool rebuild = a.state[ST_REBUILD] != 0;
+    if (rebuild) nl_build_body<PBC>(a, X, numWorkgroups, sh);
+    if (a.rowJInner != nullptr) {
+        if (rebuild) __threadfence_block();                    // this workgroup's rows, read back below by other waves
+        nl_prune_body<PBC>(a, X, numWorkgroups, rebuild, sh);
     }
 }
 
@@ -814,6 +951,11 @@ NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
     a.state = nl->state;
     a.blockCenter = (float4*) nl->block_center; a.blockHalf = (float4*) nl->block_half;
     a.chunkInfo = (int2*) nl->chunk_info; a.rowJ = nl->row_j; a.rowMask = nl->row_mask;
+    a.chunkInfoInner = (int2*) nl->chunk_info_inner; a.rowJInner = nl->row_j_inner; a.rowMaskInner = nl->row_mask_inner; a.blockRuns = nl->block_runs;
+    a.cutoff = (float) nl->cutoff; a.pruneCutoff2 = (float) (nl->cutoff * nl->cutoff * (1.0 + 1e-4));
+    if (!list_is_pruned(nl)) {
+        a.chunkInfoInner = nullptr; a.rowJInner = nullptr; a.rowMaskInner = nullptr; a.blockRuns = nullptr;
+    }
     // cell mode: rectangular periodic boxes with enough blocks for the all-blocks scan to hurt
     a.cellMode = 0; a.bigHalf = 0.f; a.ncx = a.ncy = a.ncz = 1; a.cellInvX = a.cellInvY = a.cellInvZ = 0.f;
     a.cellStart = nl->cell_start; a.cellBlocks = nl->cell_blocks; a.cellMeta = nl->cell_meta; a.cellBoxes = (float4*) nl->cell_boxes;

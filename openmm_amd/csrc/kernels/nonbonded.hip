@@ -57,6 +57,10 @@ struct NbArgs {
     const int2* chunkInfo;
     const int* rowJ;
     const unsigned* rowMask;
+    // the pruned list (ommhip_neighbor_list::chunk_info_inner), walked instead of the rows above unless state[ST_NO_PRUNE] is set; null: none
+    const int2* chunkInfoInner;
+    const int* rowJInner;
+    const unsigned* rowMaskInner;
     const float4* blockCenter;   // per i-block bounding box (neighbor.hip); blockHalf.w = 1 when the block's atoms are image-coherent
     const float4* blockHalf;
     float cutoff;
@@ -373,7 +377,12 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
     // lets the compiler prove they are never written here and fetch the wave-uniform i-atom data
     // with scalar loads.
     const int lane = threadIdx.x & 63;
-    int numChunks = a.state[ST_NUM_CHUNKS];
+    // wave-uniform choice of the list: the per-step pruned rows when the builder keeps them
+    const bool pruned = a.rowJInner != nullptr && a.state[ST_NO_PRUNE] == 0;
+    const int2* __restrict__ const chunkInfo = pruned ? a.chunkInfoInner : a.chunkInfo;
+    const int* __restrict__ const rowJ = pruned ? a.rowJInner : a.rowJ;
+    const unsigned* __restrict__ const rowMask = pruned ? a.rowMaskInner : a.rowMask;
+    int numChunks = a.state[pruned ? ST_NUM_CHUNKS_INNER : ST_NUM_CHUNKS];
     if (numChunks > a.maxChunks) numChunks = a.maxChunks;
     double energyTotal = 0;
     constexpr int UNITS_PER_CHUNK = OMM_CHUNK_ROWS / UNIT_ROWS;
@@ -395,10 +404,10 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
 #pragma unroll
         for (int row = 0; row < UNIT_ROWS; row++) {
             const size_t r = ((size_t) c * OMM_CHUNK_ROWS + rowBase + row) * OMM_ROW + lane;
-            jWord[row] = a.rowJ[r];
-            mWord[row] = a.rowMask[r];
+            jWord[row] = rowJ[r];
+            mWord[row] = rowMask[r];
         }
-        const int2 info = a.chunkInfo[c];
+        const int2 info = chunkInfo[c];
         const int X = __builtin_amdgcn_readfirstlane(info.x);
         const int nrows = __builtin_amdgcn_readfirstlane(info.y & 0xff) - rowBase;       // rows of this unit
         const int maskedBits = __builtin_amdgcn_readfirstlane(info.y >> 8) >> rowBase;
@@ -632,6 +641,8 @@ static NbArgs make_nb_args(const ommhip_neighbor_list* nl, const ommhip_nonbonde
     a.box = make_box(nl->box);
     a.posq = (const float4*) nl->posq_rel; a.sigEps = (const float2*) sig_eps; a.state = nl->state;
     a.chunkInfo = (const int2*) nl->chunk_info; a.rowJ = nl->row_j; a.rowMask = nl->row_mask;
+    const bool pruned = list_is_pruned(nl);
+    a.chunkInfoInner = pruned ? (const int2*) nl->chunk_info_inner : nullptr; a.rowJInner = pruned ? nl->row_j_inner : nullptr; a.rowMaskInner = pruned ? nl->row_mask_inner : nullptr;
     a.blockCenter = (const float4*) nl->block_center; a.blockHalf = (const float4*) nl->block_half;
     a.cutoff = nl->cutoff > 0 ? (float) nl->cutoff : INFINITY;
     a.force = force; a.energyBuffer = energy_buffer;

@@ -55,6 +55,18 @@ int ommhip_event_record(void* event, void* stream) { return (int) hipEventRecord
 int ommhip_event_sync(void* event) { return (int) hipEventSynchronize((hipEvent_t) event); }
 int ommhip_event_elapsed_ms(void* start, void* stop, float* ms) { return (int) hipEventElapsedTime(ms, (hipEvent_t) start, (hipEvent_t) stop); }
 int ommhip_stream_wait_event(void* stream, void* event) { return (int) hipStreamWaitEvent((hipStream_t) stream, (hipEvent_t) event, 0); }
+size_t ommhip_struct_size(int which) {
+    switch (which) {
+        case 0: return sizeof(ommhip_neighbor_list);
+        case 1: return sizeof(ommhip_nonbonded_params);
+        case 2: return sizeof(ommhip_pme);
+        case 3: return sizeof(ommhip_term_batch);
+        case 4: return sizeof(ommhip_integrator_state);
+        case 5: return sizeof(ommhip_step_units);
+        case 6: return sizeof(ommhip_ccma);
+    }
+    return 0;
+}
 const char* ommhip_error_string(int code) {
     if (code >= 1000) {                      // 1000 + ncclResult_t (include/openmm_hip_comm.h)
         static thread_local char buf[64];

@@ -571,15 +571,23 @@ void HipCalcNonbondedForceKernel::getNeighborListStats(long long* out) {
     int state[OMMHIP_NL_STATE_INTS];
     HIP_CHECK(ommhip_memcpy_d2h(state, nlState.ptr, sizeof(state), hip.stream));
     hip.sync();
-    const int chunks = min(state[1], nl.max_chunks);
-    vector<int> info(2 * (size_t) max(chunks, 1));
-    if (chunks > 0) {
-        HIP_CHECK(ommhip_memcpy_d2h(info.data(), chunkInfo.ptr, sizeof(int) * 2 * (size_t) chunks, hip.stream));
-        hip.sync();
+    // [2], [3]: chunks and rows the pair kernel walks (the per-step pruned list when there is one); [6], [7]: those of the list as built
+    const bool pruned = nl.row_j_inner != NULL && state[10] == 0 && getenv("OPENMM_HIP_NO_PRUNE") == NULL && nl.pbc != 2;
+    long long count[2][2] = {{0, 0}, {0, 0}};
+    for (int which = 0; which < 2; which++) {
+        const int chunks = min(which == 0 ? state[1] : state[7], nl.max_chunks);
+        if (which == 1 && !pruned) { count[1][0] = count[0][0]; count[1][1] = count[0][1]; break; }
+        vector<int> info(2 * (size_t) max(chunks, 1));
+        if (chunks > 0) {
+            HIP_CHECK(ommhip_memcpy_d2h(info.data(), which == 0 ? chunkInfo.ptr : chunkInfoInner.ptr, sizeof(int) * 2 * (size_t) chunks, hip.stream));
+            hip.sync();
+        }
+        long long rows = 0;
+        for (int c = 0; c < chunks; c++) rows += info[2 * c + 1] & 0xff;
+        count[which][0] = chunks; count[which][1] = rows;
     }
-    long long rows = 0;
-    for (int c = 0; c < chunks; c++) rows += info[2 * c + 1] & 0xff;
-    out[0] = numParticles; out[1] = hip.paddedAtoms; out[2] = chunks; out[3] = rows; out[4] = nl.max_chunks; out[5] = state[4];
+    out[0] = numParticles; out[1] = hip.paddedAtoms; out[2] = count[1][0]; out[3] = count[1][1]; out[4] = nl.max_chunks; out[5] = state[4];
+    out[6] = count[0][0]; out[7] = count[0][1];
 }
 
 static vector<double> bsplineModuli(int n);
@@ -743,7 +751,7 @@ int HipCalcNonbondedForceKernel::recoverFromOverflow() {
     const int skipped = pinnedState[OMMHIP_NL_STATE_FROZEN];
     fprintf(stderr, "HIP platform: neighbour list overflowed (%d chunks needed, %d allocated); growing it and redoing %d step(s)\n", pinnedState[1], nl.max_chunks, skipped);
     allocateNeighborList((int) (std::max(pinnedState[1], nl.max_chunks) * 1.5) + 64);
-    const int zero[OMMHIP_NL_STATE_INTS] = {1, 0, 0, 0, pinnedState[4], 0, 0, 0};          // rebuild requested, overflow and frozen counters cleared
+    const int zero[OMMHIP_NL_STATE_INTS] = {1, 0, 0, 0, pinnedState[4], 0, 0, 0, 0, 0, 0, 0};          // rebuild requested, overflow and frozen counters cleared
     HIP_CHECK(ommhip_memcpy_h2d(nlState.ptr, zero, sizeof(zero), hip.stream));
     hip.sync();
     forceRebuild = true;
@@ -1153,6 +1161,17 @@ void HipCalcNonbondedForceKernel::allocateNeighborList(int maxChunks) {
     rowMask.allocate(sizeof(unsigned) * (size_t) maxChunks * OMMHIP_CHUNK_ROWS * OMMHIP_ROW);
     nl.max_chunks = maxChunks;
     nl.chunk_info = chunkInfo.ptr; nl.row_j = rowJ.as<int>(); nl.row_mask = rowMask.as<unsigned>();
+    // the per-step pruned list (include/openmm_hip_kernels.h, chunk_info_inner): same capacity -- it never holds more than the list it is cut from
+    if (nonbondedMethod != NoCutoff) {
+        chunkInfoInner.allocate(chunkInfo.bytes);
+        rowJInner.allocate(rowJ.bytes);
+        rowMaskInner.allocate(rowMask.bytes);
+        if (blockRuns.ptr == NULL) {
+            blockRuns.allocate(sizeof(int) * 17 * (size_t) (hip.paddedAtoms / OMMHIP_TILE));
+            HIP_CHECK(ommhip_memset(blockRuns.ptr, 0, blockRuns.bytes, hip.stream));
+        }
+        nl.chunk_info_inner = chunkInfoInner.ptr; nl.row_j_inner = rowJInner.as<int>(); nl.row_mask_inner = rowMaskInner.as<unsigned>(); nl.block_runs = blockRuns.as<int>();
+    }
 }
 
 void HipCalcNonbondedForceKernel::computeParameters(ContextImpl& context, bool forceUpdate) {

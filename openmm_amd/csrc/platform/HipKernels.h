@@ -169,7 +169,7 @@ private:
     bool slotParamsDirty, forceRebuild, etermDirty, hasInitializedParams;
     bool foldExclusions;       // this evaluation: the Ewald exclusion correction rides in the PME interpolation launch
     // device
-    DeviceBuffer chargeD, sigmaD, epsilonD, posq, posqRef, posqRel, posqRelLo, sigEps, exclStart, exclAtoms, nlState, blockCenter, blockHalf, chunkInfo, rowJ, rowMask;
+    DeviceBuffer chargeD, sigmaD, epsilonD, posq, posqRef, posqRel, posqRelLo, sigEps, exclStart, exclAtoms, nlState, blockCenter, blockHalf, chunkInfo, rowJ, rowMask, chunkInfoInner, rowJInner, rowMaskInner, blockRuns;
     DeviceBuffer exceptionAtomsD, exceptionParamsD, exclusionPairsD, ewaldStructure;
     DeviceBuffer moduliX, moduliY, moduliZ, eterm, gridReal, gridComplex, twiddleX, twiddleY, twiddleZ, tileCount, tileBlocks;
     double maxCharge;

@@ -28,7 +28,7 @@ def box6(box3):
     return (C.c_double * 6)(box3[0, 0], box3[1, 0], box3[1, 1], box3[2, 0], box3[2, 1], box3[2, 2])
 
 
-def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64, compact=False, cells=False, fused_pme=None, block_range=None, energy=True, lj_free_tail=False, ewald_tol=5e-4, positions=None, charges=None, edge_path=True, prepare=False):
+def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None, seed=0, grid=64, compact=False, cells=False, fused_pme=None, block_range=None, energy=True, lj_free_tail=False, ewald_tol=5e-4, positions=None, charges=None, edge_path=True, prepare=False, prune=True):
     """-> (forces[n,3], energy, oracle forces, oracle energy, nl state)
 
     compact=False: random slot order, list built by ommhip_nl_update on wrapped coordinates (general image search).
@@ -45,6 +45,7 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     lj_free_tail=True: epsilon = 0 for the atoms in the slots 12..31 of every block (a water box after the platform's
     in-block ordering): the single-image path leaves the Lennard-Jones arithmetic out for them.
     prepare=True: the per-step entry ommhip_nl_step (double positions in) also for the random slot order.
+    prune=False: without the per-step pruned list (the pair kernel walks the rows as built).
     positions / charges: given instead of drawn; edge_path=False: no posq_rel_lo, the float separation decides at the cutoff."""
     rng = np.random.default_rng(seed)
     box3 = np.eye(3) * L
@@ -105,7 +106,7 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
         nl.posq_rel_lo = K.upload(np.zeros((padded, 4), np.float32))
     nl.atom_of_slot, nl.slot_of_atom = d_aos, d_soa
     nl.excl_start, nl.excl_atoms = K.upload(start), K.upload(flat)
-    st = np.zeros(8, np.int32)
+    st = np.zeros(capi.NL_STATE_INTS, np.int32)
     st[0] = 1
     nl.state = K.upload(st)
     nb = padded // 32
@@ -113,6 +114,11 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
     nl.chunk_info = K.upload(np.zeros((maxc, 2), np.int32))
     nl.row_j = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.int32))
     nl.row_mask = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.uint32))
+    if prune:      # the per-step pruned list (what the platform always gives the builder)
+        nl.chunk_info_inner = K.upload(np.zeros((maxc, 2), np.int32))
+        nl.row_j_inner = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.int32))
+        nl.row_mask_inner = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.uint32))
+        nl.block_runs = K.upload(np.zeros(17 * nb, np.int32))
     if block_range is not None:
         nl.first_block, nl.owned_blocks = block_range
     if cells:      # force the cell-binned candidate search of large systems at test size
@@ -137,7 +143,7 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
         K.nl_step(C.byref(nl), d_pos, d_wrap, None)
     else:
         K.nl_update(C.byref(nl), None)
-    state = K.download(nl.state, 8, np.int32)
+    state = K.download(nl.state, capi.NL_STATE_INTS, np.int32)
     p = capi.NonbondedParams()
     p.ewald = 1 if method in (ONB.Ewald, ONB.PME) else 0
     alpha = float(np.sqrt(-np.log(2 * ewald_tol)) / cutoff) if p.ewald else 0.0
@@ -303,7 +309,7 @@ def run_pme(K, n, ng, L, triclinic=False, seed=2, alpha=2.6, tiles=None, sort_ce
     return f[:, :n].T, e, f_or, e_or
 
 
-def run_list_completeness(K, n, cutoff, box_lengths, sort_cell, cells, seed=0, padding=0.1):
+def run_list_completeness(K, n, cutoff, box_lengths, sort_cell, cells, seed=0, padding=0.1, prune=True):
     """Builds the neighbour list of n random atoms in a rectangular periodic box (slots sorted along a Morton curve through
     `sort_cell` bins, per-step entry ommhip_nl_step) and decodes it.  -> (missing pairs, duplicated pairs, pairs within the cutoff,
     list entries, nl state): every pair within the cutoff must be in the list exactly once (the brute-force side is
@@ -344,13 +350,18 @@ def run_list_completeness(K, n, cutoff, box_lengths, sort_cell, cells, seed=0, p
     nl.posq_rel = K.upload(np.zeros((padded, 4), np.float32))
     nl.atom_of_slot, nl.slot_of_atom = d_aos, d_soa
     nl.excl_start, nl.excl_atoms = K.upload(np.zeros(n + 1, np.int32)), K.upload(np.zeros(1, np.int32))
-    st = np.zeros(8, np.int32)
+    st = np.zeros(capi.NL_STATE_INTS, np.int32)
     st[0] = 1
     nl.state = K.upload(st)
     nl.block_center, nl.block_half = K.upload(np.zeros((nb, 4), np.float32)), K.upload(np.zeros((nb, 4), np.float32))
     nl.chunk_info = K.upload(np.zeros((maxc, 2), np.int32))
     nl.row_j = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.int32))
     nl.row_mask = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.uint32))
+    if prune:      # the per-step pruned list (what the platform always gives the builder)
+        nl.chunk_info_inner = K.upload(np.zeros((maxc, 2), np.int32))
+        nl.row_j_inner = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.int32))
+        nl.row_mask_inner = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.uint32))
+        nl.block_runs = K.upload(np.zeros(17 * nb, np.int32))
     if cells:
         nl.max_cells = 4 * nb + 64
         nl.cell_start = K.upload(np.zeros(2 * nl.max_cells + 2, np.int32))
@@ -359,27 +370,36 @@ def run_list_completeness(K, n, cutoff, box_lengths, sort_cell, cells, seed=0, p
         nl.cell_meta = K.upload(np.zeros(4, np.float32))
         nl.cell_min_blocks = 1
     K.nl_step(C.byref(nl), d_pos, d_wrap, None)
-    state = K.download(nl.state, 8, np.int32)
-    chunks = int(state[1])
-    assert state[2] == 0 and 0 < chunks <= maxc, state
-    info = K.download(nl.chunk_info, (maxc, 2), np.int32)[:chunks]
-    rows_j = K.download(nl.row_j, (maxc, capi.CHUNK_ROWS, capi.ROW), np.int32)[:chunks]
-    rows_m = K.download(nl.row_mask, (maxc, capi.CHUNK_ROWS, capi.ROW), np.uint32)[:chunks]
-    pairs = []
-    entries = 0
-    for c in range(chunks):
-        X, nrows = int(info[c, 0]), int(info[c, 1]) & 0xFF
-        j = rows_j[c, :nrows].ravel()
-        m = rows_m[c, :nrows].ravel()
-        keep = m != 0
-        j, m = j[keep], m[keep]
-        entries += len(j)
-        bits = (m[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1
-        jj, ii = np.nonzero(bits)
-        si, sj = X * 32 + ii, j[jj]
-        a, b = atom_of_slot[si], atom_of_slot[sj]
-        assert (a >= 0).all() and (b >= 0).all()
-        pairs.append(np.stack([np.minimum(a, b), np.maximum(a, b)], 1))
+    state = K.download(nl.state, capi.NL_STATE_INTS, np.int32)
+    assert state[2] == 0 and 0 < int(state[1]) <= maxc, state
+
+    def decode(chunks, d_info, d_j, d_m):
+        info = K.download(d_info, (maxc, 2), np.int32)[:chunks]
+        rows_j = K.download(d_j, (maxc, capi.CHUNK_ROWS, capi.ROW), np.int32)[:chunks]
+        rows_m = K.download(d_m, (maxc, capi.CHUNK_ROWS, capi.ROW), np.uint32)[:chunks]
+        pairs, entries = [], 0
+        for c in range(chunks):
+            X, nrows = int(info[c, 0]), int(info[c, 1]) & 0xFF
+            j = rows_j[c, :nrows].ravel()
+            m = rows_m[c, :nrows].ravel()
+            keep = m != 0
+            j, m = j[keep], m[keep]
+            entries += len(j)
+            bits = (m[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1
+            jj, ii = np.nonzero(bits)
+            si, sj = X * 32 + ii, j[jj]
+            a, b = atom_of_slot[si], atom_of_slot[sj]
+            assert (a >= 0).all() and (b >= 0).all()
+            pairs.append(np.stack([np.minimum(a, b), np.maximum(a, b)], 1))
+        return pairs, entries
+
+    pairs, entries = decode(int(state[1]), nl.chunk_info, nl.row_j, nl.row_mask)
+    global LAST_ENTRIES_AS_BUILT
+    LAST_ENTRIES_AS_BUILT = entries
+    if prune:
+        # what the pair kernel walks: the rows re-packed by the same launch to the j atoms within the cutoff itself of each block's box
+        assert state[10] == 0 and 0 < int(state[7]) <= int(state[1]), state
+        pairs, entries = decode(int(state[7]), nl.chunk_info_inner, nl.row_j_inner, nl.row_mask_inner)
     listed = np.concatenate(pairs).astype(np.int64)
     listed_key = listed[:, 0] * n + listed[:, 1]
     uniq, counts = np.unique(listed_key, return_counts=True)

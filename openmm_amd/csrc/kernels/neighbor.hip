@@ -667,18 +667,21 @@ __device__ __forceinline__ void nl_build_body(const NlArgs& a, const int X, cons
 
 // ------------------------------------------------------------------------------------------------
 // The pruned list of i-block X (every step): of the entries X's rows hold -- j atoms within cutoff + padding of an atom of X
-// when the list was built -- those whose j atom lies within the cutoff of X's CURRENT bounding box, packed into fresh rows.
+// when the list was built -- those whose j atom lies within the cutoff of an atom of X NOW, packed into fresh rows.
 // The position of j in X's frame is formed exactly as the pair kernel forms it (block-relative coordinates plus the offset of
-// the two block centres in the nearest image), the box of X is the one nl_prepare has just computed from the same numbers.
+// the two block centres in the nearest image) and compared with the block-relative coordinates of X's atoms; the squared
+// cutoff carries a relative margin of 1e-4, far above any rounding and above the band the cutoff-edge path re-decides.
 // Order of the entries is kept (row by row, lane by lane): the pruned rows are a deterministic function of the positions.
+// Each wavefront takes every NL_WAVES-th row of a run and keeps its entries in registers; the keep masks meet in LDS, every
+// wavefront scans them for itself, one atomic per run allocates the chunks.  Three barriers per run, no staging of entries.
 // ------------------------------------------------------------------------------------------------
+#define NL_RUN_ROWS (NL_LIST / OMM_ROW)              // rows of one flush at most
+#define NL_WAVE_ROWS (NL_RUN_ROWS / NL_WAVES)
 template <int PBC>
 __device__ __forceinline__ void nl_prune_body(const NlArgs& a, const int X, const int numWorkgroups, const bool built, NlShared& sh) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    int* const listJ = sh.listJ;
-    unsigned* const listM = sh.listM;
-    unsigned long long* const rowBallot = (unsigned long long*) sh.candY;            // [NL_LIST / OMM_ROW]
-    int* const rowOffset = sh.candY + 2 * (NL_LIST / OMM_ROW);                        // [NL_LIST / OMM_ROW + 1]
+    unsigned long long* const rowKeep = (unsigned long long*) sh.candY;               // [NL_RUN_ROWS] lanes that stay, per row of the run
+    unsigned long long* const rowCut = rowKeep + NL_RUN_ROWS;                          // [NL_RUN_ROWS] ... of those, the ones with a partial mask
     __syncthreads();                                           // the builder is done with its LDS (and its rows are written)
     if (!built && t == 0) {
         const int* const dir = a.blockRuns + (size_t) X * (1 + 2 * NL_MAX_RUNS);
@@ -686,24 +689,35 @@ __device__ __forceinline__ void nl_prune_body(const NlArgs& a, const int X, cons
         sh.runCount = n;
         for (int k = 0; k < min(n, NL_MAX_RUNS); k++) { sh.runBase[k] = dir[1 + 2 * k]; sh.runRows[k] = dir[2 + 2 * k]; }
     }
+    if (t < OMM_TILE) { const float4 pi = a.posqRel[X * OMM_TILE + t]; sh.ix[t] = pi.x; sh.iy[t] = pi.y; sh.iz[t] = pi.z; }
     __syncthreads();
     const int numRuns = min(sh.runCount, NL_MAX_RUNS);
     const float4 cX = a.blockCenter[X], hX = a.blockHalf[X];
     // the cases in which one image per j atom serves all of X (the pair kernel's `single`); anything else is copied unpruned
     bool exact = PBC == 0;
     if (PBC == 1) exact = hX.w != 0.f && hX.x + a.cutoff < 0.5f * a.box.ax && hX.y + a.cutoff < 0.5f * a.box.by && hX.z + a.cutoff < 0.5f * a.box.cz;
+    const float R2 = a.pruneCutoff2;
     for (int run = 0; run < numRuns; run++) {
         const int base = sh.runBase[run];
-        int nRows = sh.runRows[run];
+        int nRows = min(sh.runRows[run], NL_RUN_ROWS);
         if ((long long) base * OMM_CHUNK_ROWS + nRows > (long long) a.maxChunks * OMM_CHUNK_ROWS) nRows = max(0, (a.maxChunks - base) * OMM_CHUNK_ROWS);     // the list overflowed
-        // pass 1: which entries stay
-        for (int r = wave; r < nRows; r += NL_WAVES) {
-            const size_t o = ((size_t) base * OMM_CHUNK_ROWS + r) * OMM_ROW + lane;
-            const int j = a.rowJ[o];
-            const unsigned m = a.rowMask[o];
-            bool keep = m != 0u;
-            if (keep && exact) {
-                float4 pj = a.posqRel[j];
+        // pass 1: this wavefront's rows (wave, wave + NL_WAVES, ...): which entries stay
+        int jv[NL_WAVE_ROWS]; unsigned mv[NL_WAVE_ROWS];
+#pragma unroll
+        for (int q = 0; q < NL_WAVE_ROWS; q++) {
+            const int r = wave + q * NL_WAVES;
+            const size_t o = ((size_t) base * OMM_CHUNK_ROWS + min(r, max(nRows - 1, 0))) * OMM_ROW + lane;
+            jv[q] = r < nRows ? a.rowJ[o] : X * OMM_TILE;
+            mv[q] = r < nRows ? a.rowMask[o] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < NL_WAVE_ROWS; q++) {
+            const int r = wave + q * NL_WAVES;
+            if (r >= nRows) break;
+            bool keep = mv[q] != 0u;
+            if (exact) {
+                const int j = jv[q];
+                const float4 pj = a.posqRel[j];
                 const float4 cY = a.blockCenter[j >> 5];
                 float ox = cY.x - cX.x, oy = cY.y - cX.y, oz = cY.z - cX.z;
                 if (PBC == 1) {
@@ -712,59 +726,73 @@ __device__ __forceinline__ void nl_prune_body(const NlArgs& a, const int X, cons
                     oy = fmaf(-ny, a.box.byLo, fmaf(-ny, a.box.by, cY.y)) - cX.y;
                     oz = fmaf(-nz, a.box.czLo, fmaf(-nz, a.box.cz, cY.z)) - cX.z;
                 }
-                const float dx = fmaxf(0.f, fabsf(pj.x + ox) - hX.x), dy = fmaxf(0.f, fabsf(pj.y + oy) - hX.y), dz = fmaxf(0.f, fabsf(pj.z + oz) - hX.z);
-                keep = dx * dx + dy * dy + dz * dz <= a.pruneCutoff2;
-            }
-            const unsigned long long b = __ballot(keep);
-            if (lane == 0) rowBallot[r] = b;
-        }
-        __syncthreads();
-        if (t == 0) {
-            int sum = 0;
-            for (int r = 0; r < nRows; r++) { rowOffset[r] = sum; sum += __popcll(rowBallot[r]); }
-            rowOffset[nRows] = sum;
-        }
-        __syncthreads();
-        // pass 2: compact into the staging area
-        for (int r = wave; r < nRows; r += NL_WAVES) {
-            const size_t o = ((size_t) base * OMM_CHUNK_ROWS + r) * OMM_ROW + lane;
-            const unsigned long long b = rowBallot[r];
-            if ((b >> lane) & 1ull) {
-                const int pos = rowOffset[r] + lane_prefix_count(b);
-                listJ[pos] = a.rowJ[o];
-                listM[pos] = a.rowMask[o];
-            }
-        }
-        __syncthreads();
-        // write the rows of the pruned list
-        const int total = rowOffset[nRows];
-        const int outRows = (total + OMM_ROW - 1) / OMM_ROW, outChunks = (outRows + OMM_CHUNK_ROWS - 1) / OMM_CHUNK_ROWS;
-        if (outRows > 0) {
-            if (t == 0) sh.chunkBase = atomicAdd(&a.state[ST_ALLOC_INNER], outChunks);
-            __syncthreads();
-            const int outBase = sh.chunkBase;
-            for (int r = wave; r < outRows; r += NL_WAVES) {
-                const int e = r * OMM_ROW + lane;
-                const bool valid = e < total;
-                const int j = valid ? listJ[e] : X * OMM_TILE;
-                const unsigned m = valid ? listM[e] : 0u;
-                const bool masked = __any(m != 0xFFFFFFFFu);
-                if (outBase + r / OMM_CHUNK_ROWS < a.maxChunks) {
-                    const size_t o = ((size_t) outBase * OMM_CHUNK_ROWS + r) * OMM_ROW + lane;
-                    a.rowJInner[o] = j;
-                    a.rowMaskInner[o] = m;
+                const v2f jx = bc2(pj.x + ox), jy = bc2(pj.y + oy), jz = bc2(pj.z + oz);
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < OMM_TILE; k += 2) {
+                    const v2f ex = jx - mk2(sh.ix[k], sh.ix[k + 1]), ey = jy - mk2(sh.iy[k], sh.iy[k + 1]), ez = jz - mk2(sh.iz[k], sh.iz[k + 1]);
+                    const v2f r2 = ex * ex + ey * ey + ez * ez;
+                    any = any || !(r2.x >= R2) || !(r2.y >= R2);
                 }
-                if (lane == 0) sh.rowMasked[r] = masked ? 1 : 0;
+                keep = keep && any;
             }
-            __syncthreads();
-            for (int c = t; c < outChunks; c += NL_THREADS) {
-                const int rowsIn = min(OMM_CHUNK_ROWS, outRows - OMM_CHUNK_ROWS * c);
-                int bits = 0;
-                for (int i = 0; i < rowsIn; i++) bits |= sh.rowMasked[OMM_CHUNK_ROWS * c + i] << i;
-                if (outBase + c < a.maxChunks) a.chunkInfoInner[outBase + c] = make_int2(X, rowsIn | (bits << 8));
-            }
+            const unsigned long long kb = __ballot(keep), cb = __ballot(keep && mv[q] != 0xFFFFFFFFu);
+            if (lane == 0) { rowKeep[r] = kb; rowCut[r] = cb; }
         }
         __syncthreads();
+        // every wavefront: where each row's survivors go (lane r holds row r)
+        const unsigned long long myKeep = lane < nRows ? rowKeep[lane] : 0ull;
+        const int cnt = __popcll(myKeep);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < NL_RUN_ROWS; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+        const int total = __shfl(incl, NL_RUN_ROWS - 1);
+        const int excl = incl - cnt;                                  // first position of row `lane`
+        const int outRows = (total + OMM_ROW - 1) / OMM_ROW, outChunks = (outRows + OMM_CHUNK_ROWS - 1) / OMM_CHUNK_ROWS;
+        if (t == 0 && outChunks > 0) sh.chunkBase = atomicAdd(&a.state[ST_ALLOC_INNER], outChunks);
+        __syncthreads();
+        if (outChunks > 0) {
+            const int outBase = sh.chunkBase;
+            const size_t outFirst = (size_t) outBase * OMM_CHUNK_ROWS * OMM_ROW;
+            const bool fits = outBase + outChunks <= a.maxChunks;
+            // pass 2: the entries go straight to their places
+#pragma unroll
+            for (int q = 0; q < NL_WAVE_ROWS; q++) {
+                const int r = wave + q * NL_WAVES;
+                if (r >= nRows) break;
+                const unsigned long long kb = rowKeep[r];
+                const int first = __shfl(excl, r);
+                if (fits && ((kb >> lane) & 1ull)) {
+                    const size_t o = outFirst + first + lane_prefix_count(kb);
+                    a.rowJInner[o] = jv[q];
+                    a.rowMaskInner[o] = mv[q];
+                }
+            }
+            // the unused lanes of the last row
+            if (wave == 0 && fits) {
+                const int e = (outRows - 1) * OMM_ROW + lane;
+                if (e >= total) { a.rowJInner[outFirst + e] = X * OMM_TILE; a.rowMaskInner[outFirst + e] = 0u; }
+            }
+            // chunk headers: a row is flagged "masked" when a row of the run with partial masks among its survivors overlaps it
+            // (a superset of the rows that really hold one: the flag only selects the code path that looks at the masks)
+            if (t < outChunks && fits) {
+                const int rowsIn = min(OMM_CHUNK_ROWS, outRows - OMM_CHUNK_ROWS * t);
+                int bits = 0, pos = 0;
+                for (int r = 0; r < nRows; r++) {
+                    const int n = __popcll(rowKeep[r]);
+                    if (rowCut[r] != 0ull && n > 0)
+                        for (int i = 0; i < rowsIn; i++) {
+                            const int lo = (OMM_CHUNK_ROWS * t + i) * OMM_ROW;
+                            if (pos < lo + OMM_ROW && pos + n > lo) bits |= 1 << i;
+                        }
+                    pos += n;
+                }
+                // the last row's padding lanes carry an empty mask
+                if (OMM_CHUNK_ROWS * t + rowsIn == outRows && (total & (OMM_ROW - 1)) != 0) bits |= 1 << (rowsIn - 1);
+                a.chunkInfoInner[outBase + t] = make_int2(X, rowsIn | (bits << 8));
+            }
+        }
+        __syncthreads();                                       // rowKeep / rowCut / chunkBase are reused by the next run
     }
     // last workgroup out publishes the length of the pruned list and returns the working counters to zero
     if (t == 0) {

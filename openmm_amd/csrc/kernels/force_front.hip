@@ -12,6 +12,9 @@
 #include "pme.hip"
 #include "bonded.hip"
 #include "nonbonded.hip"
+#ifndef OMMHIP_EMU
+#include <hip/hip_ext.h>          // hipExtLaunchKernelGGL: events stamped by a kernel's own dispatch (timed launches)
+#endif
 
 namespace {
 
@@ -137,10 +140,23 @@ __global__ __launch_bounds__(PF_THREADS, 2) void pairs_fft_lines(NbArgs nb, FftA
 }
 
 template <int METHOD, bool ENERGY>
-void launch_pairs_fft(int stage, int pairBlocks, hipStream_t st, const NbArgs& nb, const PlaneArgs& plane, const FftArgs& fft, PairsFftStage s) {
+void launch_pairs_fft(int stage, int pairBlocks, hipStream_t st, const NbArgs& nb, const PlaneArgs& plane, const FftArgs& fft, PairsFftStage s, hipEvent_t evStart, hipEvent_t evStop) {
     const int grid = s.fftBlocks + pairBlocks;
+#ifndef OMMHIP_EMU
+    if (evStart != nullptr || evStop != nullptr) {
+        // a timed launch: the events ride on the kernel's own dispatch packet
+        if (stage == 1) hipExtLaunchKernelGGL((pairs_fft_lines<METHOD, ENERGY>), dim3(grid), dim3(PF_THREADS), 0, st, evStart, evStop, 0, nb, fft, s, nb.posq, nb.sigEps);
+        else hipExtLaunchKernelGGL((pairs_fft_plane<METHOD, ENERGY>), dim3(grid), dim3(PF_THREADS), 0, st, evStart, evStop, 0, nb, plane, s, nb.posq, nb.sigEps);
+        return;
+    }
+#else
+    if (evStart != nullptr) hipEventRecord(evStart, st);
+#endif
     if (stage == 1) hipLaunchKernelGGL((pairs_fft_lines<METHOD, ENERGY>), dim3(grid), dim3(PF_THREADS), 0, st, nb, fft, s, nb.posq, nb.sigEps);
     else hipLaunchKernelGGL((pairs_fft_plane<METHOD, ENERGY>), dim3(grid), dim3(PF_THREADS), 0, st, nb, plane, s, nb.posq, nb.sigEps);
+#ifdef OMMHIP_EMU
+    if (evStop != nullptr) hipEventRecord(evStop, st);
+#endif
 }
 
 }  // namespace
@@ -164,8 +180,10 @@ extern "C" int ommhip_pairs_with_fft(const ommhip_neighbor_list* nl, const ommhi
     }
     const NbArgs nb = make_nb_args(nl, p, sig_eps_d, force_d, energy_buffer_d, energy_slots);
     const FftArgs fft = make_xconv_args(pme, energy_buffer_d, energy_slots, include_energy);
-    ommhip_profile_begin(OMMHIP_TIMER_NB_DIRECT, stream);
+    void* evStart = nullptr; void* evStop = nullptr;
+    ommhip_profile_take(OMMHIP_TIMER_NB_DIRECT, &evStart, &evStop);
     for (int stage = 0; stage < 3; stage++) {
+        const hipEvent_t e0 = stage == 0 ? (hipEvent_t) evStart : nullptr, e1 = stage == 2 ? (hipEvent_t) evStop : nullptr;
         const PlaneArgs plane = make_plane_args(pme, stage == 0);
         PairsFftStage s;
         s.fftBlocks = stage == 1 ? fft.numOuter * ((fft.numInner + fft.B - 1) / fft.B) : nx;
@@ -175,10 +193,9 @@ extern "C" int ommhip_pairs_with_fft(const ommhip_neighbor_list* nl, const ommhi
         int pairBlocks = (int) ((shareChunks + PF_THREADS / 64 - 1) / (PF_THREADS / 64));
         pairBlocks = (pairBlocks + OMM_NUM_XCD - 1) / OMM_NUM_XCD * OMM_NUM_XCD;       // the same number on every XCD
         const bool energy = include_energy != 0;
-        if (use_ewald_poly(nb, nl, p, include_energy)) launch_pairs_fft<9, false>(stage, pairBlocks, st, nb, plane, fft, s);
-        else if (p->use_switch) { if (energy) launch_pairs_fft<3, true>(stage, pairBlocks, st, nb, plane, fft, s); else launch_pairs_fft<3, false>(stage, pairBlocks, st, nb, plane, fft, s); }
-        else { if (energy) launch_pairs_fft<1, true>(stage, pairBlocks, st, nb, plane, fft, s); else launch_pairs_fft<1, false>(stage, pairBlocks, st, nb, plane, fft, s); }
+        if (use_ewald_poly(nb, nl, p, include_energy)) launch_pairs_fft<9, false>(stage, pairBlocks, st, nb, plane, fft, s, e0, e1);
+        else if (p->use_switch) { if (energy) launch_pairs_fft<3, true>(stage, pairBlocks, st, nb, plane, fft, s, e0, e1); else launch_pairs_fft<3, false>(stage, pairBlocks, st, nb, plane, fft, s, e0, e1); }
+        else { if (energy) launch_pairs_fft<1, true>(stage, pairBlocks, st, nb, plane, fft, s, e0, e1); else launch_pairs_fft<1, false>(stage, pairBlocks, st, nb, plane, fft, s, e0, e1); }
     }
-    ommhip_profile_end(OMMHIP_TIMER_NB_DIRECT, stream);
     return (int) hipGetLastError();
 }

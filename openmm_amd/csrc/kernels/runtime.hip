@@ -149,6 +149,21 @@ int ommhip_profile_end(int timer, void* stream) {
     t.used++;
     return (int) e;
 }
+int ommhip_profile_take(int timer, void** start_event, void** stop_event) {
+    *start_event = nullptr; *stop_event = nullptr;
+    if (!profileEnabled || timer < 0 || timer >= OMMHIP_PROFILE_NUM_TIMERS || ((profileMask >> timer) & 1u) == 0) return 0;
+    ProfileTimer& t = timers[timer];
+    if ((t.seq++ % (unsigned) profileEnabled) != 0) return 0;
+    if (t.used == 4096) profile_drain(t);
+    if (t.used == t.start.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 0;
+        t.start.push_back(a); t.stop.push_back(b);
+    }
+    *start_event = t.start[t.used]; *stop_event = t.stop[t.used];
+    t.used++;
+    return 0;
+}
 int ommhip_profile_collect(int timer, long long* calls, double* total_ms) {
     if (timer < 0 || timer >= OMMHIP_PROFILE_NUM_TIMERS) return 1;
     profile_drain(timers[timer]);

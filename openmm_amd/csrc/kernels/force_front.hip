@@ -66,6 +66,7 @@ extern "C" int ommhip_force_front(const ommhip_neighbor_list* nl, const ommhip_p
     if (nl->pbc == 0) hipLaunchKernelGGL(force_front<0>, grid, dim3(256), 0, st, f);
     else if (nl->pbc == 1) hipLaunchKernelGGL(force_front<1>, grid, dim3(256), 0, st, f);
     else hipLaunchKernelGGL(force_front<2>, grid, dim3(256), 0, st, f);
+    launch_prune(f.nl, st);
     ommhip_profile_end(OMMHIP_TIMER_NL_UPDATE, stream);
     return (int) hipGetLastError();
 }

@@ -666,154 +666,179 @@ __device__ __forceinline__ void nl_build_body(const NlArgs& a, const int X, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// The pruned list of i-block X (every step): of the entries X's rows hold -- j atoms within cutoff + padding of an atom of X
-// when the list was built -- those whose j atom lies within the cutoff of an atom of X NOW, packed into fresh rows.
-// The position of j in X's frame is formed exactly as the pair kernel forms it (block-relative coordinates plus the offset of
-// the two block centres in the nearest image) and compared with the block-relative coordinates of X's atoms; the squared
-// cutoff carries a relative margin of 1e-4, far above any rounding and above the band the cutoff-edge path re-decides.
-// Order of the entries is kept (row by row, lane by lane): the pruned rows are a deterministic function of the positions.
-// Each wavefront takes every NL_WAVES-th row of a run and keeps its entries in registers; the keep masks meet in LDS, every
-// wavefront scans them for itself, one atomic per run allocates the chunks.  Three barriers per run, no staging of entries.
+// The pruned list (every step, a launch of its own behind the builder's): of the entries an i-block's rows hold -- j atoms within
+// cutoff + padding of an atom of X when the list was built -- those whose j atom lies within the cutoff of an atom of X NOW,
+// packed into fresh rows.  The position of j in X's frame is formed exactly as the pair kernel forms it (block-relative
+// coordinates plus the offset of the two block centres in the nearest image) and compared with the block-relative coordinates of
+// X's atoms; the squared cutoff carries a relative margin of 1e-4, far above any rounding and above the band the cutoff-edge
+// path re-decides.  Order of the entries is kept (row by row, lane by lane): the pruned rows are a deterministic function of
+// the positions.
+// One wavefront per i-block, no barrier after the first: pass 1 takes the rows four at a time (the two dependent memory round
+// trips -- indices, then the gathers -- are paid once per four rows) and leaves each row's keep mask in the lane of its number;
+// a wavefront scan places the rows, one atomic allocates the chunks, pass 2 re-reads the (cache-resident) rows and writes the
+// survivors to their places.  Few registers, 1.5 kB of LDS per workgroup: the launch is bound by memory latency and needs the
+// occupancy.
 // ------------------------------------------------------------------------------------------------
 #define NL_RUN_ROWS (NL_LIST / OMM_ROW)              // rows of one flush at most
-#define NL_WAVE_ROWS (NL_RUN_ROWS / NL_WAVES)
+#define NL_PRUNE_BATCH 4
+#ifdef OMMHIP_EMU
+#define OMM_WAVES_PER_EU(n)
+#else
+#define OMM_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#endif
 template <int PBC>
-__device__ __forceinline__ void nl_prune_body(const NlArgs& a, const int X, const int numWorkgroups, const bool built, NlShared& sh) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    unsigned long long* const rowKeep = (unsigned long long*) sh.candY;               // [NL_RUN_ROWS] lanes that stay, per row of the run
-    unsigned long long* const rowCut = rowKeep + NL_RUN_ROWS;                          // [NL_RUN_ROWS] ... of those, the ones with a partial mask
-    __syncthreads();                                           // the builder is done with its LDS (and its rows are written)
-    if (!built && t == 0) {
-        const int* const dir = a.blockRuns + (size_t) X * (1 + 2 * NL_MAX_RUNS);
-        const int n = dir[0];
-        sh.runCount = n;
-        for (int k = 0; k < min(n, NL_MAX_RUNS); k++) { sh.runBase[k] = dir[1 + 2 * k]; sh.runRows[k] = dir[2 + 2 * k]; }
-    }
-    if (t < OMM_TILE) { const float4 pi = a.posqRel[X * OMM_TILE + t]; sh.ix[t] = pi.x; sh.iy[t] = pi.y; sh.iz[t] = pi.z; }
+__global__ __launch_bounds__(256) void nl_prune_rows(NlArgs a) {
+    __shared__ float sIx[4][OMM_TILE], sIy[4][OMM_TILE], sIz[4][OMM_TILE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Xraw = a.firstBlock + blockIdx.x * 4 + wave;
+    const bool live = Xraw < a.firstBlock + a.ownedBlocks;
+    const int X = live ? Xraw : a.firstBlock;
+    if (lane < OMM_TILE) { const float4 pi = a.posqRel[X * OMM_TILE + lane]; sIx[wave][lane] = pi.x; sIy[wave][lane] = pi.y; sIz[wave][lane] = pi.z; }
     __syncthreads();
-    const int numRuns = min(sh.runCount, NL_MAX_RUNS);
-    const float4 cX = a.blockCenter[X], hX = a.blockHalf[X];
-    // the cases in which one image per j atom serves all of X (the pair kernel's `single`); anything else is copied unpruned
-    bool exact = PBC == 0;
-    if (PBC == 1) exact = hX.w != 0.f && hX.x + a.cutoff < 0.5f * a.box.ax && hX.y + a.cutoff < 0.5f * a.box.by && hX.z + a.cutoff < 0.5f * a.box.cz;
-    const float R2 = a.pruneCutoff2;
-    for (int run = 0; run < numRuns; run++) {
-        const int base = sh.runBase[run];
-        int nRows = min(sh.runRows[run], NL_RUN_ROWS);
-        if ((long long) base * OMM_CHUNK_ROWS + nRows > (long long) a.maxChunks * OMM_CHUNK_ROWS) nRows = max(0, (a.maxChunks - base) * OMM_CHUNK_ROWS);     // the list overflowed
-        // pass 1: this wavefront's rows (wave, wave + NL_WAVES, ...): which entries stay
-        int jv[NL_WAVE_ROWS]; unsigned mv[NL_WAVE_ROWS];
+    if (live) {
+        const float* const ix = sIx[wave]; const float* const iy = sIy[wave]; const float* const iz = sIz[wave];
+        const int* const dir = a.blockRuns + (size_t) X * (1 + 2 * NL_MAX_RUNS);
+        const int numRuns = min(dir[0], NL_MAX_RUNS);
+        const float4 cX = a.blockCenter[X], hX = a.blockHalf[X];
+        // the cases in which one image per j atom serves all of X (the pair kernel's `single`); anything else is copied unpruned
+        bool exact = PBC == 0;
+        if (PBC == 1) exact = hX.w != 0.f && hX.x + a.cutoff < 0.5f * a.box.ax && hX.y + a.cutoff < 0.5f * a.box.by && hX.z + a.cutoff < 0.5f * a.box.cz;
+        const float R2 = a.pruneCutoff2;
+        for (int run = 0; run < numRuns; run++) {
+            const int base = dir[1 + 2 * run];
+            int nRows = min(dir[2 + 2 * run], NL_RUN_ROWS);
+            if ((long long) base * OMM_CHUNK_ROWS + nRows > (long long) a.maxChunks * OMM_CHUNK_ROWS) nRows = max(0, (a.maxChunks - base) * OMM_CHUNK_ROWS);     // the list overflowed
+            const size_t inFirst = (size_t) base * OMM_CHUNK_ROWS * OMM_ROW;
+            // pass 1: keep masks; lane r ends up with those of row r
+            unsigned long long myKeep = 0ull; bool myCut = false;
+            for (int r0 = 0; r0 < nRows; r0 += NL_PRUNE_BATCH) {
+                int jv[NL_PRUNE_BATCH]; unsigned mv[NL_PRUNE_BATCH]; float4 pj[NL_PRUNE_BATCH], cY[NL_PRUNE_BATCH];
 #pragma unroll
-        for (int q = 0; q < NL_WAVE_ROWS; q++) {
-            const int r = wave + q * NL_WAVES;
-            const size_t o = ((size_t) base * OMM_CHUNK_ROWS + min(r, max(nRows - 1, 0))) * OMM_ROW + lane;
-            jv[q] = r < nRows ? a.rowJ[o] : X * OMM_TILE;
-            mv[q] = r < nRows ? a.rowMask[o] : 0u;
-        }
-#pragma unroll
-        for (int q = 0; q < NL_WAVE_ROWS; q++) {
-            const int r = wave + q * NL_WAVES;
-            if (r >= nRows) break;
-            bool keep = mv[q] != 0u;
-            if (exact) {
-                const int j = jv[q];
-                const float4 pj = a.posqRel[j];
-                const float4 cY = a.blockCenter[j >> 5];
-                float ox = cY.x - cX.x, oy = cY.y - cX.y, oz = cY.z - cX.z;
-                if (PBC == 1) {
-                    const float nx = rintf((cY.x - cX.x + pj.x) * a.box.invAx), ny = rintf((cY.y - cX.y + pj.y) * a.box.invBy), nz = rintf((cY.z - cX.z + pj.z) * a.box.invCz);
-                    ox = fmaf(-nx, a.box.axLo, fmaf(-nx, a.box.ax, cY.x)) - cX.x;
-                    oy = fmaf(-ny, a.box.byLo, fmaf(-ny, a.box.by, cY.y)) - cX.y;
-                    oz = fmaf(-nz, a.box.czLo, fmaf(-nz, a.box.cz, cY.z)) - cX.z;
+                for (int q = 0; q < NL_PRUNE_BATCH; q++) {
+                    const bool in = r0 + q < nRows;
+                    const size_t o = inFirst + (size_t) (in ? r0 + q : r0) * OMM_ROW + lane;
+                    jv[q] = a.rowJ[o]; mv[q] = in ? a.rowMask[o] : 0u;
                 }
-                const v2f jx = bc2(pj.x + ox), jy = bc2(pj.y + oy), jz = bc2(pj.z + oz);
-                bool any = false;
 #pragma unroll
-                for (int k = 0; k < OMM_TILE; k += 2) {
-                    const v2f ex = jx - mk2(sh.ix[k], sh.ix[k + 1]), ey = jy - mk2(sh.iy[k], sh.iy[k + 1]), ez = jz - mk2(sh.iz[k], sh.iz[k + 1]);
-                    const v2f r2 = ex * ex + ey * ey + ez * ez;
-                    any = any || !(r2.x >= R2) || !(r2.y >= R2);
+                for (int q = 0; q < NL_PRUNE_BATCH; q++) { pj[q] = a.posqRel[jv[q]]; cY[q] = a.blockCenter[jv[q] >> 5]; }
+                // j in X's frame, two copies per lane for the packed arithmetic
+                v2f jx[NL_PRUNE_BATCH], jy[NL_PRUNE_BATCH], jz[NL_PRUNE_BATCH];
+#pragma unroll
+                for (int q = 0; q < NL_PRUNE_BATCH; q++) {
+                    float ox = cY[q].x - cX.x, oy = cY[q].y - cX.y, oz = cY[q].z - cX.z;
+                    if (PBC == 1) {
+                        const float nx = rintf((cY[q].x - cX.x + pj[q].x) * a.box.invAx), ny = rintf((cY[q].y - cX.y + pj[q].y) * a.box.invBy), nz = rintf((cY[q].z - cX.z + pj[q].z) * a.box.invCz);
+                        ox = fmaf(-nx, a.box.axLo, fmaf(-nx, a.box.ax, cY[q].x)) - cX.x;
+                        oy = fmaf(-ny, a.box.byLo, fmaf(-ny, a.box.by, cY[q].y)) - cX.y;
+                        oz = fmaf(-nz, a.box.czLo, fmaf(-nz, a.box.cz, cY[q].z)) - cX.z;
+                    }
+                    jx[q] = bc2(pj[q].x + ox); jy[q] = bc2(pj[q].y + oy); jz[q] = bc2(pj[q].z + oz);
                 }
-                keep = keep && any;
+                bool any[NL_PRUNE_BATCH];
+#pragma unroll
+                for (int q = 0; q < NL_PRUNE_BATCH; q++) any[q] = !exact;
+                if (exact) {
+                    // two atoms of X per iteration (wave-uniform LDS reads), against the four rows of the batch.  The barrier keeps the
+                    // compiler from holding all 96 coordinates in registers across the loop over the batches (a third of the occupancy).
+                    asm volatile("" ::: "memory");
+#pragma unroll 4
+                    for (int k = 0; k < OMM_TILE; k += 2) {
+                        const v2f xi = mk2(ix[k], ix[k + 1]), yi = mk2(iy[k], iy[k + 1]), zi = mk2(iz[k], iz[k + 1]);
+#pragma unroll
+                        for (int q = 0; q < NL_PRUNE_BATCH; q++) {
+                            const v2f ex = jx[q] - xi, ey = jy[q] - yi, ez = jz[q] - zi;
+                            const v2f r2 = ex * ex + ey * ey + ez * ez;
+                            any[q] = any[q] || !(r2.x >= R2) || !(r2.y >= R2);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NL_PRUNE_BATCH; q++) {
+                    if (r0 + q >= nRows) break;
+                    const bool keep = mv[q] != 0u && any[q];
+                    const unsigned long long kb = __ballot(keep);
+                    const bool cut = __any(keep && mv[q] != 0xFFFFFFFFu);
+                    if (lane == r0 + q) { myKeep = kb; myCut = cut; }
+                }
             }
-            const unsigned long long kb = __ballot(keep), cb = __ballot(keep && mv[q] != 0xFFFFFFFFu);
-            if (lane == 0) { rowKeep[r] = kb; rowCut[r] = cb; }
-        }
-        __syncthreads();
-        // every wavefront: where each row's survivors go (lane r holds row r)
-        const unsigned long long myKeep = lane < nRows ? rowKeep[lane] : 0ull;
-        const int cnt = __popcll(myKeep);
-        int incl = cnt;
+            // where each row's survivors go
+            const int cnt = __popcll(myKeep);
+            int incl = cnt;
 #pragma unroll
-        for (int d = 1; d < NL_RUN_ROWS; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
-        const int total = __shfl(incl, NL_RUN_ROWS - 1);
-        const int excl = incl - cnt;                                  // first position of row `lane`
-        const int outRows = (total + OMM_ROW - 1) / OMM_ROW, outChunks = (outRows + OMM_CHUNK_ROWS - 1) / OMM_CHUNK_ROWS;
-        if (t == 0 && outChunks > 0) sh.chunkBase = atomicAdd(&a.state[ST_ALLOC_INNER], outChunks);
-        __syncthreads();
-        if (outChunks > 0) {
-            const int outBase = sh.chunkBase;
+            for (int d = 1; d < NL_RUN_ROWS; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+            const int total = __shfl(incl, NL_RUN_ROWS - 1);
+            const int excl = incl - cnt;                              // first position of row `lane`
+            const int outRows = (total + OMM_ROW - 1) / OMM_ROW, outChunks = (outRows + OMM_CHUNK_ROWS - 1) / OMM_CHUNK_ROWS;
+            if (outChunks == 0) continue;
+            int outBase = 0;
+            if (lane == 0) outBase = atomicAdd(&a.state[ST_ALLOC_INNER], outChunks);
+            outBase = __shfl(outBase, 0);
+            if (outBase + outChunks > a.maxChunks) continue;          // cannot happen unless the list as built overflowed
             const size_t outFirst = (size_t) outBase * OMM_CHUNK_ROWS * OMM_ROW;
-            const bool fits = outBase + outChunks <= a.maxChunks;
             // pass 2: the entries go straight to their places
-#pragma unroll
-            for (int q = 0; q < NL_WAVE_ROWS; q++) {
-                const int r = wave + q * NL_WAVES;
-                if (r >= nRows) break;
-                const unsigned long long kb = rowKeep[r];
+            for (int r = 0; r < nRows; r++) {
+                const unsigned kbLo = (unsigned) __shfl((int) (unsigned) myKeep, r), kbHi = (unsigned) __shfl((int) (unsigned) (myKeep >> 32), r);
+                const unsigned long long kb = ((unsigned long long) kbHi << 32) | kbLo;
                 const int first = __shfl(excl, r);
-                if (fits && ((kb >> lane) & 1ull)) {
-                    const size_t o = outFirst + first + lane_prefix_count(kb);
-                    a.rowJInner[o] = jv[q];
-                    a.rowMaskInner[o] = mv[q];
+                if (kb == 0ull) continue;
+                const size_t o = inFirst + (size_t) r * OMM_ROW + lane;
+                const int j = a.rowJ[o];
+                const unsigned m = a.rowMask[o];
+                if ((kb >> lane) & 1ull) {
+                    const size_t w = outFirst + first + lane_prefix_count(kb);
+                    a.rowJInner[w] = j;
+                    a.rowMaskInner[w] = m;
                 }
             }
             // the unused lanes of the last row
-            if (wave == 0 && fits) {
+            {
                 const int e = (outRows - 1) * OMM_ROW + lane;
                 if (e >= total) { a.rowJInner[outFirst + e] = X * OMM_TILE; a.rowMaskInner[outFirst + e] = 0u; }
             }
-            // chunk headers: a row is flagged "masked" when a row of the run with partial masks among its survivors overlaps it
-            // (a superset of the rows that really hold one: the flag only selects the code path that looks at the masks)
-            if (t < outChunks && fits) {
-                const int rowsIn = min(OMM_CHUNK_ROWS, outRows - OMM_CHUNK_ROWS * t);
-                int bits = 0, pos = 0;
-                for (int r = 0; r < nRows; r++) {
-                    const int n = __popcll(rowKeep[r]);
-                    if (rowCut[r] != 0ull && n > 0)
-                        for (int i = 0; i < rowsIn; i++) {
-                            const int lo = (OMM_CHUNK_ROWS * t + i) * OMM_ROW;
-                            if (pos < lo + OMM_ROW && pos + n > lo) bits |= 1 << i;
-                        }
-                    pos += n;
-                }
+            // chunk headers (lane c: chunk c): a row is flagged "masked" when a row of the run with partial masks among its
+            // survivors overlaps it (a superset of the rows that really hold one: the flag only selects the code path that looks
+            // at the masks)
+            int bits = 0;
+            const int rowsIn = min(OMM_CHUNK_ROWS, outRows - OMM_CHUNK_ROWS * lane);
+            for (int r = 0; r < nRows; r++) {
+                const int n = __shfl(cnt, r), pos = __shfl(excl, r);
+                const bool cutR = __shfl((int) myCut, r) != 0;
+                if (cutR && n > 0)
+                    for (int i = 0; i < OMM_CHUNK_ROWS; i++) {
+                        const int lo = (OMM_CHUNK_ROWS * lane + i) * OMM_ROW;
+                        if (i < rowsIn && pos < lo + OMM_ROW && pos + n > lo) bits |= 1 << i;
+                    }
+            }
+            if (lane < outChunks) {
                 // the last row's padding lanes carry an empty mask
-                if (OMM_CHUNK_ROWS * t + rowsIn == outRows && (total & (OMM_ROW - 1)) != 0) bits |= 1 << (rowsIn - 1);
-                a.chunkInfoInner[outBase + t] = make_int2(X, rowsIn | (bits << 8));
+                if (OMM_CHUNK_ROWS * lane + rowsIn == outRows && (total & (OMM_ROW - 1)) != 0) bits |= 1 << (rowsIn - 1);
+                a.chunkInfoInner[outBase + lane] = make_int2(X, rowsIn | (bits << 8));
             }
         }
-        __syncthreads();                                       // rowKeep / rowCut / chunkBase are reused by the next run
     }
     // last workgroup out publishes the length of the pruned list and returns the working counters to zero
-    if (t == 0) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
         const int done = atomicAdd(&a.state[ST_PRUNE_DONE], 1);
-        if (done == numWorkgroups - 1) {
+        if (done == (int) gridDim.x - 1) {
             a.state[ST_NUM_CHUNKS_INNER] = atomicExch(&a.state[ST_ALLOC_INNER], 0);
             a.state[ST_PRUNE_DONE] = 0;
         }
     }
 }
 
-// One workgroup of the per-step list launch: X's rows are rebuilt if a rebuild is due, then (re-)pruned.
+// One workgroup of the per-step list launch: X's rows are rebuilt if a rebuild is due.
 template <int PBC>
 __device__ __forceinline__ void nl_find_body(const NlArgs& a, const int X, const int numWorkgroups, NlShared& sh) {
-    // (read by every workgroup before the last one out of nl_build_body clears it: that one waits for all of them)
-    const bool rebuild = a.state[ST_REBUILD] != 0;
-    if (rebuild) nl_build_body<PBC>(a, X, numWorkgroups, sh);
-    if (a.rowJInner != nullptr) {
-        if (rebuild) __threadfence_block();                    // this workgroup's rows, read back below by other waves
-        nl_prune_body<PBC>(a, X, numWorkgroups, rebuild, sh);
-    }
+    if (a.state[ST_REBUILD] == 0) return;
+    nl_build_body<PBC>(a, X, numWorkgroups, sh);
+}
+
+static void launch_prune(const NlArgs& a, hipStream_t st) {
+    if (a.rowJInner == nullptr) return;
+    const dim3 grid((a.ownedBlocks + 3) / 4);
+    if (a.pbc == 0) hipLaunchKernelGGL(nl_prune_rows<0>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(nl_prune_rows<1>, grid, dim3(256), 0, st, a);
 }
 
 template <int PBC>
@@ -1012,6 +1037,7 @@ static void launch_find(const NlArgs& a, hipStream_t st) {
     if (a.pbc == 0) hipLaunchKernelGGL(nl_find_interactions<0>, dim3(a.ownedBlocks), dim3(NL_THREADS), 0, st, a);
     else if (a.pbc == 1) hipLaunchKernelGGL(nl_find_interactions<1>, dim3(a.ownedBlocks), dim3(NL_THREADS), 0, st, a);
     else hipLaunchKernelGGL(nl_find_interactions<2>, dim3(a.ownedBlocks), dim3(NL_THREADS), 0, st, a);
+    launch_prune(a, st);
 }
 
 // Per-step entry of the platform: conversion + displacement check + bounds in one launch, then the

@@ -1161,8 +1161,15 @@ void HipCalcNonbondedForceKernel::allocateNeighborList(int maxChunks) {
     rowMask.allocate(sizeof(unsigned) * (size_t) maxChunks * OMMHIP_CHUNK_ROWS * OMMHIP_ROW);
     nl.max_chunks = maxChunks;
     nl.chunk_info = chunkInfo.ptr; nl.row_j = rowJ.as<int>(); nl.row_mask = rowMask.as<unsigned>();
-    // the per-step pruned list (include/openmm_hip_kernels.h, chunk_info_inner): same capacity -- it never holds more than the list it is cut from
-    if (nonbondedMethod != NoCutoff) {
+    // The per-step pruned list (include/openmm_hip_kernels.h, chunk_info_inner): same capacity -- it never holds more than the list it
+    // is cut from.  For systems whose pair kernel is a launch of its own, bound by throughput (above the size up to which the fused
+    // launches are used, and decomposed runs): 30 % fewer rows for one more small launch per step.  Below that the pair work rides on
+    // the FFT launches, whose length the FFT stages set -- measured at DHFR size: 8.7 k -> 6.1 k rows, the three launches 57.2 -> 54.9 us,
+    // the extra launch 12 us.  OPENMM_HIP_PRUNE=0/1 overrides.
+    static const int frontMaxAtoms = getenv("OPENMM_HIP_FUSED_FRONT_MAX_ATOMS") != NULL ? atoi(getenv("OPENMM_HIP_FUSED_FRONT_MAX_ATOMS")) : 60000;
+    bool prune = numParticles > frontMaxAtoms || hip.decomposed();
+    if (getenv("OPENMM_HIP_PRUNE") != NULL) prune = atoi(getenv("OPENMM_HIP_PRUNE")) != 0;
+    if (nonbondedMethod != NoCutoff && prune) {
         chunkInfoInner.allocate(chunkInfo.bytes);
         rowJInner.allocate(rowJ.bytes);
         rowMaskInner.allocate(rowMask.bytes);

@@ -137,8 +137,8 @@ typedef struct ommhip_neighbor_list {
     const int* excl_atoms;
     const void* excl_block_range; /* int2[padded_atoms/32] or NULL: per i-block, lowest/highest block that holds an exclusion partner */
     int* state;               /* int[OMMHIP_NL_STATE_INTS]: 0 rebuild-request, 1 chunks used, 2 overflow, 3 scratch, 4 #rebuilds, 5 scratch,
-                               * 6 steps skipped (OMMHIP_NL_STATE_FROZEN), 7 chunks of the pruned list, 8-9 scratch, 10 pruning not possible;
-                               * zero-initialised by the caller */
+                               * 6 steps skipped (OMMHIP_NL_STATE_FROZEN), 7 chunks of the pruned list, 8-9 scratch, 10 pruning not possible,
+                               * 11 pruning requested; zero-initialised by the caller */
     void* block_center;        /* float4[padded_atoms/32] */
     void* block_half;          /* float4[padded_atoms/32] */
     void* chunk_info;          /* int2[max_chunks]  (i-block, nrows | maskedRowBits<<8) */
@@ -212,18 +212,21 @@ typedef struct ommhip_neighbor_list {
     unsigned dd_warn, dd_max;
     int* dd_flags;                /* device int[4], zeroed by the host at every re-sort */
     int dd_ranks, dd_slots_per_rank, dd_trailer_slot;
-    /* The pruned ("inner") list, optional (all NULL = the pair kernel walks the rows above).  The rows above are built with
-     * cutoff + padding and live until an atom has moved padding / 2: at any one step only ~60 % of their j atoms lie within the
-     * cutoff itself of the i-block's bounding box.  With these arrays (same shapes as chunk_info / row_j / row_mask; block_runs:
-     * int[1 + 2 * 4] per i-block) every launch of the list builder -- it is enqueued at every step and returns at once unless a
-     * rebuild is due -- also re-packs each i-block's rows: entries whose j atom lies within the cutoff of the block's CURRENT
-     * bounding box (and whose mask is not empty) are compacted into fresh rows, and ommhip_nb_direct / ommhip_pairs_with_fft walk
-     * those.  The test is made on the coordinates the pair kernel itself uses, with a relative margin of 1e-4 on the squared
-     * cutoff: no pair inside the cutoff (or inside the rounding band the cutoff-edge path re-decides) is lost. */
+    /* The pruned ("inner") list, optional (all NULL = the pair kernel walks the rows above): the dual pair list of GROMACS' Verlet
+     * scheme in this layout.  The rows above are built with cutoff + padding and live until an atom has moved padding / 2; with a
+     * generous padding that is many steps, but most of their j atoms are then far outside the cutoff at any one step.  With these
+     * arrays (same shapes as chunk_info / row_j / row_mask; block_runs: int[1 + 2 * 8] per i-block; posq_ref_inner like posq_ref)
+     * the list launches also keep a second list: for every i-block, the entries whose j atom lies within cutoff + inner_padding of
+     * one of the block's atoms (and whose mask is not empty), re-packed into fresh rows -- cut from the rows above, not from a new
+     * search, whenever the list was rebuilt or an atom has moved inner_padding / 2 since the last cut (checked on the device with
+     * the displacement check of the rows above; no host involvement).  ommhip_nb_direct / ommhip_pairs_with_fft walk the inner rows.
+     * The test is made on the coordinates the pair kernel itself uses, with a relative margin of 1e-4 on the squared distance. */
     void* chunk_info_inner;
     int* row_j_inner;
     unsigned* row_mask_inner;
     int* block_runs;
+    void* posq_ref_inner;      /* float4[padded_atoms]: positions at the last cut */
+    double inner_padding;
 } ommhip_neighbor_list;
 
 /* sizeof() of the structs of this header as the library was compiled: 0 ommhip_neighbor_list, 1 ommhip_nonbonded_params, 2 ommhip_pme,

@@ -31,6 +31,7 @@ class NeighborList(C.Structure):
         ("num_active_ranges", C.c_int), ("active_range", C.c_int * 8), ("wire_ref", C.c_void_p), ("dd_guard_atom", C.c_void_p),
         ("dd_warn", C.c_uint), ("dd_max", C.c_uint), ("dd_flags", C.c_void_p), ("dd_ranks", C.c_int), ("dd_slots_per_rank", C.c_int), ("dd_trailer_slot", C.c_int),
         ("chunk_info_inner", C.c_void_p), ("row_j_inner", C.c_void_p), ("row_mask_inner", C.c_void_p), ("block_runs", C.c_void_p),
+        ("posq_ref_inner", C.c_void_p), ("inner_padding", C.c_double),
     ]
 
 

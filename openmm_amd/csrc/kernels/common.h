@@ -31,7 +31,7 @@ template <class NL>
 inline bool list_is_pruned(const NL* nl) {
     static const bool off = getenv("OPENMM_HIP_NO_PRUNE") != nullptr;
     return !off && nl->cutoff > 0 && nl->pbc != 2 && nl->chunk_info_inner != nullptr && nl->row_j_inner != nullptr && nl->row_mask_inner != nullptr &&
-           nl->block_runs != nullptr && nl->posq_rel != nullptr;
+           nl->block_runs != nullptr && nl->posq_rel != nullptr && nl->posq_ref_inner != nullptr;
 }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -173,7 +173,7 @@ __device__ __forceinline__ void min_image(float& dx, float& dy, float& dz, const
 //   ALLOC        working allocation counter of a rebuild in flight (zero at rest)
 enum { ST_REBUILD = 0, ST_NUM_CHUNKS = 1, ST_OVERFLOW = 2, ST_BLOCKS_DONE = 3, ST_REBUILD_COUNT = 4, ST_ALLOC = 5,
        ST_FROZEN = 6 /* integrate.hip */,
-       ST_NUM_CHUNKS_INNER = 7, ST_ALLOC_INNER = 8, ST_PRUNE_DONE = 9, ST_NO_PRUNE = 10 };
+       ST_NUM_CHUNKS_INNER = 7, ST_ALLOC_INNER = 8, ST_PRUNE_DONE = 9, ST_NO_PRUNE = 10, ST_PRUNE_REQUEST = 11 };
 
 inline Box make_box(const double* bv) {
     // bv = {ax, bx, by, cx, cy, cz}

@@ -77,7 +77,8 @@ struct NlArgs {
     unsigned* rowMask;
     // the pruned list (null: none) -- see ommhip_neighbor_list::chunk_info_inner
     int2* chunkInfoInner; int* rowJInner; unsigned* rowMaskInner; int* blockRuns;
-    float cutoff, pruneCutoff2;       // the cutoff itself; its square with the margin of the prune test
+    float cutoff, pruneCutoff2;       // the cutoff itself; (cutoff + inner padding)^2 with the margin of the prune test
+    float4* posqRefInner; float maxDispInner2;      // positions at the last cut, (inner padding / 2)^2
     // cell-binned candidate search (large rectangular systems): blocks bucketed by the grid cell of their centre
     int cellMode, ncx, ncy, ncz;
     float cellInvX, cellInvY, cellInvZ;   // cells per nm
@@ -112,6 +113,19 @@ __device__ __forceinline__ void apply_pbc_rt(int pbc, float& dx, float& dy, floa
     else if (pbc == 2) min_image<true>(dx, dy, dz, b);
 }
 
+// the same question for the pruned list: more than inner padding / 2 since it was last cut?
+__device__ __forceinline__ void check_inner_displacement(const NlArgs& a, int s, bool valid, float4 p) {
+    if (a.posqRefInner == nullptr) return;
+    bool moved = false;
+    if (valid) {
+        const float4 r = a.posqRefInner[s];
+        float dx = p.x - r.x, dy = p.y - r.y, dz = p.z - r.z;
+        apply_pbc_rt(a.pbc, dx, dy, dz, a.box);
+        moved = !(dx * dx + dy * dy + dz * dz <= a.maxDispInner2);
+    }
+    if (__any(moved) && lane_id() == 0) atomicOr(&a.state[ST_PRUNE_REQUEST], 1);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Per-step: did any atom move more than padding/2 since the list was built?  (one thread per slot)
 // ------------------------------------------------------------------------------------------------
@@ -125,6 +139,7 @@ __global__ void nl_check_displacement(NlArgs a) {
         moved = !(dx * dx + dy * dy + dz * dz <= a.maxDisp2);   // NaN counts as moved
     }
     if (__any(moved) && lane_id() == 0) atomicOr(&a.state[ST_REBUILD], 1);
+    check_inner_displacement(a, s, s < a.paddedAtoms && a.atomOfSlot[s] >= 0, s < a.paddedAtoms ? a.posq[s] : make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -660,6 +675,7 @@ __device__ __forceinline__ void nl_build_body(const NlArgs& a, const int X, cons
             a.state[ST_NUM_CHUNKS] = atomicExch(&a.state[ST_ALLOC], 0);
             a.state[ST_BLOCKS_DONE] = 0;
             a.state[ST_REBUILD] = 0;
+            a.state[ST_PRUNE_REQUEST] = 1;                 // new rows: the pruned list is cut again by the launch that follows
             atomicAdd(&a.state[ST_REBUILD_COUNT], 1);
         }
     }
@@ -689,7 +705,18 @@ __device__ __forceinline__ void nl_build_body(const NlArgs& a, const int X, cons
 template <int PBC>
 __global__ __launch_bounds__(256) void nl_prune_rows(NlArgs a) {
     __shared__ float sIx[4][OMM_TILE], sIy[4][OMM_TILE], sIz[4][OMM_TILE];
+    // (read by every workgroup before the last one out clears it: that one waits for all of them)
+    if (a.state[ST_PRUNE_REQUEST] == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        // reference positions of the displacement check of this list: every slot the check looks at
+        const int total = a.numActive == 0 ? a.paddedAtoms : a.activeTotal;
+        for (int g = blockIdx.x * 256 + threadIdx.x; g < total; g += gridDim.x * 256) {
+            int sl;
+            active_slot(a, g, sl);
+            a.posqRefInner[sl] = a.posq[sl];
+        }
+    }
     const int Xraw = a.firstBlock + blockIdx.x * 4 + wave;
     const bool live = Xraw < a.firstBlock + a.ownedBlocks;
     const int X = live ? Xraw : a.firstBlock;
@@ -775,19 +802,26 @@ __global__ __launch_bounds__(256) void nl_prune_rows(NlArgs a) {
             outBase = __shfl(outBase, 0);
             if (outBase + outChunks > a.maxChunks) continue;          // cannot happen unless the list as built overflowed
             const size_t outFirst = (size_t) outBase * OMM_CHUNK_ROWS * OMM_ROW;
-            // pass 2: the entries go straight to their places
-            for (int r = 0; r < nRows; r++) {
-                const unsigned kbLo = (unsigned) __shfl((int) (unsigned) myKeep, r), kbHi = (unsigned) __shfl((int) (unsigned) (myKeep >> 32), r);
-                const unsigned long long kb = ((unsigned long long) kbHi << 32) | kbLo;
-                const int first = __shfl(excl, r);
-                if (kb == 0ull) continue;
-                const size_t o = inFirst + (size_t) r * OMM_ROW + lane;
-                const int j = a.rowJ[o];
-                const unsigned m = a.rowMask[o];
-                if ((kb >> lane) & 1ull) {
-                    const size_t w = outFirst + first + lane_prefix_count(kb);
-                    a.rowJInner[w] = j;
-                    a.rowMaskInner[w] = m;
+            // pass 2: the entries go straight to their places (the rows are re-read, from cache, four at a time)
+            for (int r0 = 0; r0 < nRows; r0 += NL_PRUNE_BATCH) {
+                int jv[NL_PRUNE_BATCH]; unsigned mv[NL_PRUNE_BATCH];
+#pragma unroll
+                for (int q = 0; q < NL_PRUNE_BATCH; q++) {
+                    const size_t o = inFirst + (size_t) (r0 + q < nRows ? r0 + q : r0) * OMM_ROW + lane;
+                    jv[q] = a.rowJ[o]; mv[q] = a.rowMask[o];
+                }
+#pragma unroll
+                for (int q = 0; q < NL_PRUNE_BATCH; q++) {
+                    const int r = r0 + q;
+                    if (r >= nRows) break;
+                    const unsigned kbLo = (unsigned) __shfl((int) (unsigned) myKeep, r), kbHi = (unsigned) __shfl((int) (unsigned) (myKeep >> 32), r);
+                    const unsigned long long kb = ((unsigned long long) kbHi << 32) | kbLo;
+                    const int first = __shfl(excl, r);
+                    if ((kb >> lane) & 1ull) {
+                        const size_t w = outFirst + first + lane_prefix_count(kb);
+                        a.rowJInner[w] = jv[q];
+                        a.rowMaskInner[w] = mv[q];
+                    }
                 }
             }
             // the unused lanes of the last row
@@ -823,6 +857,7 @@ __global__ __launch_bounds__(256) void nl_prune_rows(NlArgs a) {
         if (done == (int) gridDim.x - 1) {
             a.state[ST_NUM_CHUNKS_INNER] = atomicExch(&a.state[ST_ALLOC_INNER], 0);
             a.state[ST_PRUNE_DONE] = 0;
+            a.state[ST_PRUNE_REQUEST] = 0;
         }
     }
 }
@@ -927,6 +962,7 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
         moved = !(dx * dx + dy * dy + dz * dz <= a.maxDisp2);
     }
     if (__any(moved) && lane_id() == 0) atomicOr(&a.state[ST_REBUILD], 1);
+    if (checkDisplacement) check_inner_displacement(a, sl, valid, p);
     // bounding box of the 32-atom block, relative to its first atom
     const float4 p0 = make_float4(__shfl(p.x, 0, 32), __shfl(p.y, 0, 32), __shfl(p.z, 0, 32), 0.f);
     float dx = p.x - p0.x, dy = p.y - p0.y, dz = p.z - p0.z;
@@ -1005,9 +1041,10 @@ NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
     a.blockCenter = (float4*) nl->block_center; a.blockHalf = (float4*) nl->block_half;
     a.chunkInfo = (int2*) nl->chunk_info; a.rowJ = nl->row_j; a.rowMask = nl->row_mask;
     a.chunkInfoInner = (int2*) nl->chunk_info_inner; a.rowJInner = nl->row_j_inner; a.rowMaskInner = nl->row_mask_inner; a.blockRuns = nl->block_runs;
-    a.cutoff = (float) nl->cutoff; a.pruneCutoff2 = (float) (nl->cutoff * nl->cutoff * (1.0 + 1e-4));
+    a.cutoff = (float) nl->cutoff; a.pruneCutoff2 = (float) ((nl->cutoff + nl->inner_padding) * (nl->cutoff + nl->inner_padding) * (1.0 + 1e-4));
+    a.posqRefInner = (float4*) nl->posq_ref_inner; a.maxDispInner2 = (float) (0.25 * nl->inner_padding * nl->inner_padding);
     if (!list_is_pruned(nl)) {
-        a.chunkInfoInner = nullptr; a.rowJInner = nullptr; a.rowMaskInner = nullptr; a.blockRuns = nullptr;
+        a.chunkInfoInner = nullptr; a.rowJInner = nullptr; a.rowMaskInner = nullptr; a.blockRuns = nullptr; a.posqRefInner = nullptr;
     }
     // cell mode: rectangular periodic boxes with enough blocks for the all-blocks scan to hurt
     a.cellMode = 0; a.bigHalf = 0.f; a.ncx = a.ncy = a.ncz = 1; a.cellInvX = a.cellInvY = a.cellInvZ = 0.f;

@@ -1139,6 +1139,12 @@ void HipCalcNonbondedForceKernel::updateExclusionBlockRanges() {
     nl.excl_slot_start = exclSlotStart.as<int>(); nl.excl_slots = exclSlots.as<int>();
 }
 
+double HipCalcNonbondedForceKernel::innerPaddingFraction() {
+    // padding of the pruned list as a fraction of the cutoff (tuning knob OPENMM_HIP_NL_INNER_PADDING)
+    static const double f = getenv("OPENMM_HIP_NL_INNER_PADDING") != NULL ? atof(getenv("OPENMM_HIP_NL_INNER_PADDING")) : 0.06;
+    return f;
+}
+
 int HipCalcNonbondedForceKernel::estimateChunks() const {
     const int numBlocks = hip.paddedAtoms / OMMHIP_TILE;
     double rows;
@@ -1176,8 +1182,12 @@ void HipCalcNonbondedForceKernel::allocateNeighborList(int maxChunks) {
         if (blockRuns.ptr == NULL) {
             blockRuns.allocate(sizeof(int) * 17 * (size_t) (hip.paddedAtoms / OMMHIP_TILE));
             HIP_CHECK(ommhip_memset(blockRuns.ptr, 0, blockRuns.bytes, hip.stream));
+            posqRefInner.allocate(sizeof(float) * 4 * (size_t) hip.paddedAtoms);
+            HIP_CHECK(ommhip_memset(posqRefInner.ptr, 0, posqRefInner.bytes, hip.stream));
         }
         nl.chunk_info_inner = chunkInfoInner.ptr; nl.row_j_inner = rowJInner.as<int>(); nl.row_mask_inner = rowMaskInner.as<unsigned>(); nl.block_runs = blockRuns.as<int>();
+        nl.posq_ref_inner = posqRefInner.ptr;
+        nl.inner_padding = innerPaddingFraction() * nonbondedCutoff;
     }
 }
 

@@ -126,6 +126,7 @@ public:
 private:
     void computeParameters(ContextImpl& context, bool force);
     void allocateNeighborList(int maxChunks);
+    static double innerPaddingFraction();
     void setupPme();
     void fillPmeStruct();
     void launchPme(int includeEnergy, bool spreadDone = false, bool fftDone = false);
@@ -169,7 +170,7 @@ private:
     bool slotParamsDirty, forceRebuild, etermDirty, hasInitializedParams;
     bool foldExclusions;       // this evaluation: the Ewald exclusion correction rides in the PME interpolation launch
     // device
-    DeviceBuffer chargeD, sigmaD, epsilonD, posq, posqRef, posqRel, posqRelLo, sigEps, exclStart, exclAtoms, nlState, blockCenter, blockHalf, chunkInfo, rowJ, rowMask, chunkInfoInner, rowJInner, rowMaskInner, blockRuns;
+    DeviceBuffer chargeD, sigmaD, epsilonD, posq, posqRef, posqRel, posqRelLo, sigEps, exclStart, exclAtoms, nlState, blockCenter, blockHalf, chunkInfo, rowJ, rowMask, chunkInfoInner, rowJInner, rowMaskInner, blockRuns, posqRefInner;
     DeviceBuffer exceptionAtomsD, exceptionParamsD, exclusionPairsD, ewaldStructure;
     DeviceBuffer moduliX, moduliY, moduliZ, eterm, gridReal, gridComplex, twiddleX, twiddleY, twiddleZ, tileCount, tileBlocks;
     double maxCharge;

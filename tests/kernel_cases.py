@@ -119,6 +119,8 @@ def run_direct_space(K, n, method, cutoff, L, excl, triclinic=False, switch=None
         nl.row_j_inner = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.int32))
         nl.row_mask_inner = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.uint32))
         nl.block_runs = K.upload(np.zeros(17 * nb, np.int32))
+        nl.posq_ref_inner = K.upload(np.zeros((padded, 4), np.float32))
+        nl.inner_padding = 0.03 * cutoff
     if block_range is not None:
         nl.first_block, nl.owned_blocks = block_range
     if cells:      # force the cell-binned candidate search of large systems at test size
@@ -362,6 +364,8 @@ def run_list_completeness(K, n, cutoff, box_lengths, sort_cell, cells, seed=0, p
         nl.row_j_inner = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.int32))
         nl.row_mask_inner = K.upload(np.zeros(maxc * capi.CHUNK_ROWS * capi.ROW, np.uint32))
         nl.block_runs = K.upload(np.zeros(17 * nb, np.int32))
+        nl.posq_ref_inner = K.upload(np.zeros((padded, 4), np.float32))
+        nl.inner_padding = 0.03 * cutoff
     if cells:
         nl.max_cells = 4 * nb + 64
         nl.cell_start = K.upload(np.zeros(2 * nl.max_cells + 2, np.int32))

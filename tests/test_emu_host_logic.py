@@ -385,6 +385,14 @@ def test_neighbour_list_overflow_is_recovered_with_the_side_stream(tmp_path):
 
 
 @needs_emu
+def test_pruned_list_stays_complete_over_a_run(tmp_path):
+    """The dual pair list on the emulated platform (tests/pruned_list_case.py): rows cut to cutoff + 0.036 nm from rows built with
+    cutoff + 0.27 nm, re-cut on the device's own displacement check; forces after 12 and 24 steps against the Reference platform."""
+    from pruned_list_case import run_pruned_list_case
+    print(run_pruned_list_case(tmp_path, True, 10, 30, 2, 12))
+
+
+@needs_emu
 def test_native_ljpme_matches_the_reference_platform():
     """tests/ljpme_case.py on the emulated kernels (own process: one plugin build per process)."""
     import subprocess

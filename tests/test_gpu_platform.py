@@ -246,6 +246,13 @@ def test_water1m_tiled_forces_match_reference_of_the_tile():
     assert abs(st.potentialEnergy / reps ** 3 - float(g["energy"])) < 1e-5 * abs(float(g["energy"]))
 
 
+def test_pruned_list_stays_complete_over_a_run(tmp_path):
+    """The dual pair list (tests/pruned_list_case.py) on the GPU: 24 000 atoms, four legs of 60 steps, each ending with the forces
+    compared with the Reference platform's at the same positions."""
+    from pruned_list_case import run_pruned_list_case
+    print(run_pruned_list_case(tmp_path, False, 20, 64, 4, 60))
+
+
 def test_dhfr_size_invariants():
     """Size-independent properties at the BASELINE size: constraints hold, temperature stays put, energy is finite
     after 300 LangevinMiddle steps; a repeated force evaluation is bit-identical for the direct-space part."""

@@ -1167,13 +1167,12 @@ void HipCalcNonbondedForceKernel::allocateNeighborList(int maxChunks) {
     rowMask.allocate(sizeof(unsigned) * (size_t) maxChunks * OMMHIP_CHUNK_ROWS * OMMHIP_ROW);
     nl.max_chunks = maxChunks;
     nl.chunk_info = chunkInfo.ptr; nl.row_j = rowJ.as<int>(); nl.row_mask = rowMask.as<unsigned>();
-    // The per-step pruned list (include/openmm_hip_kernels.h, chunk_info_inner): same capacity -- it never holds more than the list it
-    // is cut from.  For systems whose pair kernel is a launch of its own, bound by throughput (above the size up to which the fused
-    // launches are used, and decomposed runs): 30 % fewer rows for one more small launch per step.  Below that the pair work rides on
-    // the FFT launches, whose length the FFT stages set -- measured at DHFR size: 8.7 k -> 6.1 k rows, the three launches 57.2 -> 54.9 us,
-    // the extra launch 12 us.  OPENMM_HIP_PRUNE=0/1 overrides.
-    static const int frontMaxAtoms = getenv("OPENMM_HIP_FUSED_FRONT_MAX_ATOMS") != NULL ? atoi(getenv("OPENMM_HIP_FUSED_FRONT_MAX_ATOMS")) : 60000;
-    bool prune = numParticles > frontMaxAtoms || hip.decomposed();
+    // The pruned ("inner") list of include/openmm_hip_kernels.h (chunk_info_inner; same capacity -- it never holds more than the list
+    // it is cut from): OFF unless OPENMM_HIP_PRUNE=1.  Measured on one MI355X (docs/EXPERIMENTS.md, round 3): it removes 25-30 % of the
+    // rows the pair kernel walks (4.9 -> 3.6 evaluations per pair inside the cutoff), but the pair kernel gets only 12-20 % faster
+    // (the rows that go are the ones it skipped through quickest) and a cut costs 0.6 ms at a million atoms every 2-4 steps: 2.25 ms
+    // per step at best against 2.18 without.  At DHFR size the pair work rides on the FFT launches and 30 % fewer rows shorten them by 4 %.
+    bool prune = false;
     if (getenv("OPENMM_HIP_PRUNE") != NULL) prune = atoi(getenv("OPENMM_HIP_PRUNE")) != 0;
     if (nonbondedMethod != NoCutoff && prune) {
         chunkInfoInner.allocate(chunkInfo.bytes);

@@ -92,6 +92,11 @@ void* omm_add_cmmotion_remover(void* s, int frequency) {
     catch (const std::exception& e) { lastError = e.what(); return NULL; }
 }
 
+void* omm_add_monte_carlo_barostat(void* s, double pressure, double temperature, int frequency, int seed) {
+    try { MonteCarloBarostat* f = new MonteCarloBarostat(pressure, temperature, frequency); f->setRandomNumberSeed(seed); ((System*) s)->addForce(f); return f; }
+    catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
+
 /* ---- Integrators: kind 0 Verlet, 1 Langevin, 2 LangevinMiddle */
 void* omm_integrator_create(int kind, double dt, double temperature, double friction, int seed, double constraintTol) {
     try {
@@ -143,6 +148,13 @@ int omm_context_set_parameter(void* c, const char* name, double v) { GUARD(((Con
 int omm_context_minimize(void* c, double tolerance, int maxIterations) { GUARD(LocalEnergyMinimizer::minimize(*(Context*) c, tolerance, maxIterations)) }
 int omm_context_reinitialize(void* c, int preserveState) { GUARD(((Context*) c)->reinitialize(preserveState != 0)) }
 /* flags: 1 positions, 2 velocities, 4 forces, 8 energy.  energies[0] = potential, [1] = kinetic, [2] = time. groups = -1 for all */
+int omm_context_get_box(void* c, double* b) {
+    GUARD(
+        Vec3 v[3];
+        ((Context*) c)->getState(0).getPeriodicBoxVectors(v[0], v[1], v[2]);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) b[3 * i + j] = v[i][j];
+    )
+}
 int omm_context_get_state(void* c, int flags, int groups, double* pos, double* vel, double* forces, double* energies) {
     GUARD(
         int types = 0;

@@ -760,7 +760,10 @@ int HipCalcNonbondedForceKernel::recoverFromOverflow() {
 }
 
 void HipCalcNonbondedForceKernel::atomsReordered() { slotParamsDirty = true; forceRebuild = true; }
-void HipCalcNonbondedForceKernel::boxChanged() { etermDirty = true; dispersionEtermDirty = true; forceRebuild = true; }
+void HipCalcNonbondedForceKernel::boxChanged() {
+    etermDirty = true; dispersionEtermDirty = true; forceRebuild = true;
+    if (hip.decomposed() && gridSize[0] > 0) hip.pmeReachX = 6.0 * hip.box[0] / gridSize[0];       // see setupPmeDecomposed
+}
 void HipCalcNonbondedForceKernel::positionsSet() { forceRebuild = true; }
 
 /* The "transposed" order of HipTermForce::upload for a list of term ids: neighbouring 1-4s share atoms, the lanes of a wavefront
@@ -1899,6 +1902,11 @@ void HipApplyMonteCarloBarostatKernel::scaleCoordinates(ContextImpl& context, do
         savedPos.allocate(hip.pos.bytes);
     }
     hip.recoverIfFrozen();
+    // One box on several GPUs: every rank scales ALL atoms, from the owners' exact positions -- the same doubles, the same result on
+    // every rank; the re-sort that follows (the box changes) cuts the slabs and sections for the new box.  The trial energies are sums
+    // over the ranks formed in rank order on every rank, and the barostat's random numbers come from the force's own seed: all ranks
+    // take the same decision.
+    if (hip.decomposed()) hip.gatherState();
     HIP_CHECK(ommhip_memcpy_d2d(savedPos.ptr, hip.pos.ptr, hip.pos.bytes, hip.stream));
     HIP_CHECK(ommhip_scale_molecule_centers(numMolecules, molStart.as<int>(), molAtoms.as<int>(), hip.pos.ptr, hip.box, scaleX, scaleY, scaleZ, hip.stream));
     hip.requestReorder();          // wrap counts and slot order refer to the old box

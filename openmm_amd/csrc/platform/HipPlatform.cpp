@@ -255,8 +255,8 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
     if (domain.ranks < 1 || domain.rank < 0 || domain.rank >= domain.ranks)
         throw OpenMMException("HIP platform: illegal Ranks/Rank properties");
     if (domain.ranks > 1 || !commId.empty()) {
-        if (mode.hostMode || mode.hasFallbackForces || mode.referenceNonbonded || mode.hasBarostat)
-            throw OpenMMException("HIP platform: a multi-GPU Context supports NonbondedForce (PME), HarmonicBond/Angle, PeriodicTorsion and CMMotionRemover with the Verlet, Langevin and LangevinMiddle integrators");
+        if (mode.hostMode || mode.hasFallbackForces || mode.referenceNonbonded)
+            throw OpenMMException("HIP platform: a multi-GPU Context supports NonbondedForce (PME), HarmonicBond/Angle, PeriodicTorsion, CMMotionRemover and the (isotropic or anisotropic) MonteCarloBarostat with the Verlet, Langevin and LangevinMiddle integrators");
         int count = 0;
         HIP_CHECK(ommhip_device_count(&count));
         if (deviceIndex < 0 || deviceIndex >= count) throw OpenMMException("HIP platform: illegal DeviceIndex");

@@ -50,7 +50,7 @@ def lib():
         for name in ("omm_last_error", "omm_platform_name", "omm_version", "omm_context_platform_name", "omm_context_platform_property"):
             getattr(_lib, name).restype = C.c_char_p
         for name in ("omm_system_create", "omm_nonbonded_create", "omm_add_harmonic_bonds", "omm_add_harmonic_angles",
-                     "omm_add_periodic_torsions", "omm_add_cmmotion_remover", "omm_integrator_create", "omm_context_create"):
+                     "omm_add_periodic_torsions", "omm_add_cmmotion_remover", "omm_add_monte_carlo_barostat", "omm_integrator_create", "omm_context_create"):
             getattr(_lib, name).restype = C.c_void_p
         _lib.omm_platform_speed.restype = C.c_double
     return _lib
@@ -146,6 +146,9 @@ class System:
 
     def addCMMotionRemover(self, frequency=1):
         return _handle(lib().omm_add_cmmotion_remover(self.h, frequency))
+
+    def addMonteCarloBarostat(self, pressure, temperature, frequency=25, seed=1):
+        return _handle(lib().omm_add_monte_carlo_barostat(self.h, C.c_double(pressure), C.c_double(temperature), frequency, seed))
 
 
 class NonbondedForce:
@@ -245,6 +248,11 @@ class Context:
 
     def setVelocitiesToTemperature(self, temperature, seed=1):
         _check(lib().omm_context_set_velocities_to_temperature(self.h, C.c_double(temperature), seed))
+
+    def getPeriodicBoxVectors(self):
+        box = np.zeros(9)
+        _check(lib().omm_context_get_box(self.h, _dp(box)))
+        return box.reshape(3, 3)
 
     def setPeriodicBoxVectors(self, a, b, c):
         box = np.ascontiguousarray(np.array([a, b, c], dtype=np.float64).reshape(9))

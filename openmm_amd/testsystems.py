@@ -59,6 +59,8 @@ class Workload:
             s.addPeriodicTorsionForce(*self.torsions)
         if self.cm_remover:
             s.addCMMotionRemover(1)
+        if getattr(self, "barostat", None) is not None:          # (pressure in bar, temperature, frequency, seed)
+            s.addMonteCarloBarostat(*self.barostat)
         return s, nb
 
 
@@ -179,6 +181,12 @@ def _load_fixture(w, filename):
             w.positions = data["positions"].astype(np.float64)
             w.velocities = data["velocities"].astype(np.float64)
             w.relaxed = True
+    return w
+
+
+def with_barostat(w, pressure, temperature, frequency, seed):
+    """The same workload with a MonteCarloBarostat (pressure in bar)."""
+    w.barostat = (pressure, temperature, frequency, seed)
     return w
 
 

@@ -54,7 +54,8 @@ def test_one_rank_with_rccl_reproduces_the_single_gpu_run(n_side, grid):
 def test_two_ranks_sharing_the_gpu_reproduce_the_single_gpu_run(tmp_path):
     from test_multirank_cpu import _run_dd_child
     out = _run_dd_child(tmp_path, False, 0, 10, 29561, env={"OPENMM_HIP_DD_DRIFT": "0.05"},
-                        extra_cases='(("water, tile spreading", T.water_box(8, seed=5), 32), ("water, halo sections", T.water_box(16, seed=5, cutoff=0.5), None))')
+                        extra_cases='(("water, tile spreading", T.water_box(8, seed=5), 32), ("water, halo sections", T.water_box(16, seed=5, cutoff=0.5), None), '
+                                    '("water, halo, barostat", T.with_barostat(T.water_box(8, seed=5), 1.0, 300.0, 2, 11), 24))')
     print(out)
 
 

@@ -112,6 +112,7 @@ def run(props, w, steps):
     st0 = ctx.getState(getForces=True, getEnergy=True, getPositions=True)
     integ.step(steps)
     st1 = ctx.getState(getPositions=True, getVelocities=True, getEnergy=True, getForces=True)
+    st1.box = ctx.getPeriodicBoxVectors()
     info = (ctx.getPlatformProperty("Ranks"), ctx.getPlatformProperty("CommId"))
     global DD_INFO
     DD_INFO = H.domain_info() if "Ranks" in props else None
@@ -152,6 +153,10 @@ for label, w, grid in (("water, halo", T.water_box(8, seed=5), 24), ("solvated c
     assert abs(dd0.potentialEnergy - one0.potentialEnergy) < 1e-6 * max(abs(one0.potentialEnergy), 5.0 * w.num_atoms) + 1e-3, (dd0.potentialEnergy, one0.potentialEnergy)
     dpos = np.abs(dd1.positions - one1.positions).max()
     dvel = np.abs(dd1.velocities - one1.velocities).max()
+    if "barostat" in label:
+        # the same Monte Carlo decisions on N GPUs as on one: the box went the same way (and did move)
+        assert np.abs(dd1.box - one1.box).max() < 1e-9 * one1.box.max(), (dd1.box, one1.box)
+        assert np.abs(np.diag(one1.box) - np.diag(w.box)).max() > 1e-6, "no volume move was accepted: the case tests nothing"
     if STEPS <= 20:
         # float32 force noise (1e-5 of the RMS force) integrated over the run; the tile spreading rounds each contribution to max|q| 2^-24
         big = w.num_atoms > 5000            # more atoms, a larger maximum of the same noise
@@ -251,6 +256,17 @@ def test_halo_drift_guard_resorts_at_once_when_the_margin_runs_out_on_emulator(t
         pytest.skip("emulated plugin not built (run __graft_entry__.build())")
     _run_dd_child(tmp_path, True, None, 100, 29573, env={"OPENMM_HIP_DD_DRIFT": "0.12", "OPENMM_HIP_DD_WARN": "0.4", "OPENMM_HIP_REORDER_INTERVAL": "1000", "OPENMM_HIP_REORDER_LAG": "1000"},
                   cases='(("water, halo drift", T.water_box(8, seed=5), 24),)')
+
+
+def test_two_rank_run_with_the_barostat_on_emulator(tmp_path):
+    """MonteCarloBarostat on a decomposed run: every rank scales all atoms from the owners' exact positions, the box
+    changes, the re-sort cuts slabs and halo sections for the new box; the trial energies are rank-ordered sums and the barostat's random
+    numbers come from its own seed, so all ranks take the decisions a single GPU takes.  Six steps, a volume move every second one."""
+    import pytest
+    from conftest import EMU_BUILD
+    if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
+        pytest.skip("emulated plugin not built (run __graft_entry__.build())")
+    _run_dd_child(tmp_path, True, None, 6, 29577, cases='(("water, halo, barostat", T.with_barostat(T.water_box(8, seed=5), 1.0, 300.0, 2, 11), 24),)')
 
 
 def test_four_rank_domain_decomposition_on_emulator(tmp_path):

@@ -207,8 +207,10 @@ public:
     int* freezeState = NULL;
     int pendingReplay = 0;                                   // skipped steps the integrator still has to redo
     std::function<int()> listRecovery;                       // set by the nonbonded kernel: synchronous check; fixes the list, returns skipped steps
+    std::function<bool()> listOverflowSeen;                  // set by the nonbonded kernel: do the state words last copied back (valid after a sync) show an overflow?
     std::function<void(int)> replaySteps;                    // set by the integrator kernel: redo that many steps
     void recoverIfFrozen();
+    bool recovering() const { return inRecovery; }          // inside recoverIfFrozen (the redone steps evaluate forces themselves)
 
     // ---- immutable after construction
     int numAtoms, paddedAtoms;

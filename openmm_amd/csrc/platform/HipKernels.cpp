@@ -339,6 +339,16 @@ double HipCalcForcesAndEnergyKernel::finishComputation(ContextImpl& context, boo
     hip.joinPme();
     double energy = 0;
     if (includeEnergy) energy = hip.reduceEnergy();
+    if (includeEnergy && !hip.hostMode && !hip.recovering() && !hip.decomposed() && hip.listOverflowSeen && hip.listOverflowSeen()) {
+        // The neighbour list overflowed at a device-triggered rebuild (the device has been skipping the integration since): an energy
+        // summed over an incomplete list must not leave the platform.  Undo this evaluation, grow the list, redo the skipped steps, and
+        // let ContextImpl::calcForcesAndEnergy (ContextImpl.cpp:298-307) evaluate again -- the reference's own remedy for an overflow.
+        if (!includeForce) hip.restoreForces();
+        if (hip.replaySteps) hip.recoverIfFrozen();
+        else hip.listRecovery();                  // no step was ever taken: nothing to redo, the list is grown and rebuilt
+        valid = false;
+        return 0;
+    }
     if (hip.hostMode) {
         if (includeForce) {
             vector<Vec3> deviceForces;
@@ -985,6 +995,7 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
         // steps are replayed after recoverFromOverflow() has grown the list (decomposed runs treat an overflow as an error)
         hip.freezeState = nlState.as<int>();
         hip.listRecovery = [this]() { return recoverFromOverflow(); };
+        hip.listOverflowSeen = [this]() { return stateCopyPending && (pinnedState[OMMHIP_NL_STATE_OVERFLOW] != 0 || pinnedState[1] > nl.max_chunks); };
     }
 
     params.ewald = (nonbondedMethod == Ewald || nonbondedMethod == PME || nonbondedMethod == LJPME) ? 1 : 0;
@@ -1434,7 +1445,9 @@ double HipCalcNonbondedForceKernel::execute(ContextImpl& context, bool includeFo
             HIP_CHECK(ommhip_nb_direct(&nl, &params, sigEps.ptr, hip.force.as<long long>(), hip.energyBuffer.as<double>(), HipContext::EnergySlots, ie, hip.stream));
             params.direct_grid = directGridOverride > 0 ? directGridOverride : 0;
         }
-        if ((++evaluationCount & 15) == 0) {
+        // the list's state words come back every 16th evaluation -- and with every energy: that evaluation ends in a host
+        // synchronisation anyway (HipContext::reduceEnergy), after which HipCalcForcesAndEnergyKernel::finishComputation looks at them
+        if ((++evaluationCount & 15) == 0 || includeEnergy) {
             HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
             stateCopyPending = true;
         }

@@ -262,6 +262,11 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
         if (deviceIndex < 0 || deviceIndex >= count) throw OpenMMException("HIP platform: illegal DeviceIndex");
         HIP_CHECK(ommhip_set_device(deviceIndex));       // the communicator binds to the current device
         if (commId.compare(0, 9, "callback:") == 0) {
+            // the host-staged transport of the tests and of bench.py's rehearsals: the property carries the address of a function this
+            // library will call -- accepted only from a process that says so itself, never from a property string alone
+            const char* allow = getenv("OPENMM_HIP_ALLOW_CALLBACK_COMM");
+            if (allow == NULL || allow[0] != '1')
+                throw OpenMMException("HIP platform: a \"callback:\" CommId (host-staged test transport) needs OPENMM_HIP_ALLOW_CALLBACK_COMM=1 in the environment; production runs pass the RCCL id from ommhip_comm_unique_id()");
             unsigned long long fn = 0, user = 0;
             if (sscanf(commId.c_str() + 9, "%llu:%llu", &fn, &user) < 1 || fn == 0)
                 throw OpenMMException("HIP platform: malformed callback CommId");
@@ -276,7 +281,14 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
             }
         }
     }
-    PlatformData* data = new PlatformData(context.getSystem(), deviceIndex, mode.hostMode, domain);
+    PlatformData* data = NULL;
+    try {
+        data = new PlatformData(context.getSystem(), deviceIndex, mode.hostMode, domain);
+    } catch (...) {
+        // the HipContext did not come to own the communicator (it destroys it otherwise): the peers must not be left waiting in it
+        if (domain.comm != NULL) ommhip_comm_destroy(domain.comm);
+        throw;
+    }
     { stringstream v; v << domain.ranks; data->propertyValues[HipRanks()] = v.str(); }
     { stringstream v; v << domain.rank; data->propertyValues[HipRank()] = v.str(); }
     data->propertyValues[HipCommId()] = domain.comm != NULL ? ommhip_comm_transport(domain.comm) : "";

@@ -64,6 +64,7 @@ def gloo_all_gather_callback(dist, group=None, serialize=False):
     idle at both ends); call serial_release() after the last step so that the next rank can finish."""
     import numpy as np
     import torch
+    os.environ["OPENMM_HIP_ALLOW_CALLBACK_COMM"] = "1"          # the plugin takes a callback address from a process that asks for it only
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)

@@ -28,7 +28,11 @@ def run(shrink, steps):
     c = H.Context(s, integ, "HIP", %r)
     c.setPositions(w.positions); c.applyConstraints(1e-6); c.setVelocitiesToTemperature(300.0, 2)
     integ.step(steps)
+    # an energy on its own first (ADVICE r2): while the device is frozen this evaluation is the one that finds the overflow -- it must
+    # come back with the energy of the complete list at the up-to-date positions, not with a sum over the rows that fitted
+    e = c.getState(getEnergy=True).potentialEnergy
     st = c.getState(getPositions=True, getVelocities=True, getEnergy=True)
+    assert abs(e - st.potentialEnergy) < 1e-9 * max(abs(e), 1.0), (e, st.potentialEnergy)
     c.close()
     return st
 
@@ -39,6 +43,7 @@ for steps in %r:        # 5: found at the download (getState); 40: found by the 
     print(steps, "steps: dpos", dpos, "dvel", dvel, "time", a.time, b.time, flush=True)
     assert a.time == b.time
     assert dpos < %g and dvel < %g, (dpos, dvel)
+    assert abs(a.potentialEnergy - b.potentialEnergy) < 2e-6 * max(abs(a.potentialEnergy), 5.0 * len(a.positions)), (a.potentialEnergy, b.potentialEnergy)
 print("OK")
 '''
 

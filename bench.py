@@ -86,8 +86,9 @@ def supervise(args, rank, world):
     if args.transport == "rccl":
         attempts.append(base + ["--transport", "rccl"])
         if not any(kv.startswith("DisablePmeStream=") for kv in extra):
-            # the most conservative RCCL configuration: one stream, one communicator, ncclAllGather instead of the direct sends
-            attempts.append((base + ["--transport", "rccl", "--props", ",".join(extra + ["DisablePmeStream=true"])], {"OPENMM_HIP_ALLGATHER": "ring"}))
+            # the most conservative RCCL configuration: one stream, one communicator, positions replicated by ncclAllGather instead of the
+            # halo exchange's grouped sends and receives
+            attempts.append((base + ["--transport", "rccl", "--props", ",".join(extra + ["DisablePmeStream=true"])], {"OPENMM_HIP_ALLGATHER": "ring", "OPENMM_HIP_DD_REPLICATE": "1"}))
     attempts.append(base + ["--transport", "gloo"])
     if args.serialize_ranks:
         os.environ["OMMHIP_COMM_DIAG"] = "1"          # inherited by the children

@@ -1018,7 +1018,7 @@ static void launch_fft(const FftArgs& fin, hipStream_t st) {
 #define PLANE_THREADS 512     // one plane has ~400 butterflies per pass: 512 threads finish a pass in one sweep
 
 struct PlaneArgs {
-    FftPlan planY, planZ;
+    FftPlan planY, planZ, planZh;      // planZh: nz / 2 points (large planes, fft_bigplane_kernel)
     int ny, nz, forward;
     const float2* twY; const float2* twZ;
     float* real;           // [nx][ny][nz]
@@ -1119,6 +1119,202 @@ __global__ __launch_bounds__(PLANE_THREADS) void fft_plane_kernel(PlaneArgs a) {
     fft_plane_body<PLANE_THREADS, PLANE_MAX>(a, blockIdx.x, sh);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Large planes (beyond PLANE_MAX, up to 192 x 192): the same fused (y, z) transform by ONE 1024-thread workgroup that takes a
+// whole CU's LDS.  Two things make a 192 x 192 plane fit into 160 KB: the z transform of the real rows runs as a complex
+// transform of HALF the length on (even, odd) pairs, followed by the usual split into the nz/2 + 1 Hermitian coefficients
+// (backward: the inverse recombination first), and the passes work IN PLACE -- every thread reads the inputs of all its
+// butterflies into registers, the workgroup meets at a barrier, then the outputs go to their (Stockham-permuted) places --
+// so there is one plane buffer instead of two.  With the line passes the (y, z) half of a 192^3 transform is two launches
+// and 2 x 171 MB of HBM traffic each way (36.8 + 36.8 us forward, 46.1 + 43.8 us backward on MI355X); here it is one launch
+// that reads the plane once and writes it once.  Layout as in the small kernel: element (y, kz) at kz * (ny + 1) + y.
+// ------------------------------------------------------------------------------------------------
+#define BIGPLANE_THREADS 1024
+#define BIGPLANE_CAP 19456    // complex elements of the plane buffer: (nz/2 + 1) * (ny + 1) <= CAP (152 KB + 4 KB of twiddles)
+#define BIGPLANE_PTS 20       // points per thread and pass: BIGPLANE_THREADS * BIGPLANE_PTS >= BIGPLANE_CAP
+
+#ifdef OMMHIP_EMU
+#define SCHED_FENCE()
+#define OPAQUE_S(x)
+#else
+#define OPAQUE_S(x) asm volatile("" : "+s"(x))
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+struct BigPlaneShared {
+    float2 buf[BIGPLANE_CAP];
+    float2 twYs[256];         // exp(-2 pi i k / ny)
+    float2 twZh[128];         // exp(-2 pi i k / (nz/2)): the half-length transform's table
+    float2 twZs[132];         // exp(-2 pi i k / nz), k <= nz/2: the split / recombination factors
+};
+
+// One radix-R pass over B lines of n points, in place: element e of line l at e*BP + l*LS.
+template <int R, bool FIRST>
+__device__ __forceinline__ void fft_pass_inplace(float2* __restrict__ buf, int n, int Ns, int B, int BP, int LS, int sign, const float2* __restrict__ tw) {
+    constexpr int MAXB = (BIGPLANE_PTS + R - 1) / R;
+    OPAQUE_S(B);                // or the (idx / B, idx % B) of every b would be computed once for all passes and kept in registers throughout
+    const int butterflies = n / R, total = butterflies * B;
+    const float fsign = (float) -sign, fs = (float) sign;
+    const int twStep = n / (Ns * R);
+    v2f o[MAXB][R];
+#pragma unroll
+    for (int b = 0; b < MAXB; b++) {
+        const int idx = threadIdx.x + b * BIGPLANE_THREADS;
+        if (idx < total) {
+            const int j = idx / B, line = idx - j * B;
+            const int k = FIRST ? 0 : j % Ns;
+            v2f v[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const float2 x = buf[(j + r * butterflies) * BP + line * LS];
+                if (FIRST || r == 0) v[r] = mk2(x.x, x.y);
+                else {
+                    const float2 w = tw[k * r * twStep];
+                    v[r] = cmulp(mk2(x.x, x.y), mk2(w.x, w.y * fsign));
+                }
+            }
+            butterfly<R>(v, o[b], fs);
+        }
+        SCHED_FENCE();          // one butterfly's reads and arithmetic at a time: interleaved, the unrolled iterations need more registers than 16 waves per CU leave
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < MAXB; b++) {
+        const int idx = threadIdx.x + b * BIGPLANE_THREADS;
+        if (idx < total) {
+            const int j = idx / B, line = idx - j * B;
+            const int q = FIRST ? j : j / Ns, k = FIRST ? 0 : j - q * Ns;
+            const int j0 = q * Ns * R + k;
+#pragma unroll
+            for (int p = 0; p < R; p++) buf[(j0 + p * Ns) * BP + line * LS] = make_float2(o[b][p].x, o[b][p].y);
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void fft_lines_inplace(const FftPlan& plan, float2* buf, int B, int BP, int LS, int sign, const float2* tw) {
+    int Ns = 1;
+    for (int s = 0; s < plan.numRadices; s++) {
+        const int R = (int) ((plan.radices >> (4 * s)) & 15ull);
+        if (s == 0) {
+            switch (R) {
+                case 2: fft_pass_inplace<2, true>(buf, plan.n, Ns, B, BP, LS, sign, tw); break;
+                case 3: fft_pass_inplace<3, true>(buf, plan.n, Ns, B, BP, LS, sign, tw); break;
+                case 4: fft_pass_inplace<4, true>(buf, plan.n, Ns, B, BP, LS, sign, tw); break;
+                case 5: fft_pass_inplace<5, true>(buf, plan.n, Ns, B, BP, LS, sign, tw); break;
+                case 7: fft_pass_inplace<7, true>(buf, plan.n, Ns, B, BP, LS, sign, tw); break;
+                default: fft_pass_inplace<8, true>(buf, plan.n, Ns, B, BP, LS, sign, tw); break;
+            }
+        }
+        else {
+            switch (R) {
+                case 2: fft_pass_inplace<2, false>(buf, plan.n, Ns, B, BP, LS, sign, tw); break;
+                case 3: fft_pass_inplace<3, false>(buf, plan.n, Ns, B, BP, LS, sign, tw); break;
+                case 4: fft_pass_inplace<4, false>(buf, plan.n, Ns, B, BP, LS, sign, tw); break;
+                case 5: fft_pass_inplace<5, false>(buf, plan.n, Ns, B, BP, LS, sign, tw); break;
+                case 7: fft_pass_inplace<7, false>(buf, plan.n, Ns, B, BP, LS, sign, tw); break;
+                default: fft_pass_inplace<8, false>(buf, plan.n, Ns, B, BP, LS, sign, tw); break;
+            }
+        }
+        Ns *= R;
+    }
+}
+
+__device__ __forceinline__ void fft_bigplane_body(const PlaneArgs& a, const int block, BigPlaneShared& sh) {
+    float2* const buf = sh.buf;
+    const int ny = a.ny, nz = a.nz, nh = nz / 2, nzc = nh + 1, S = ny + 1;
+    const int x = block, t = threadIdx.x;
+    constexpr int MAXLD = BIGPLANE_CAP / BIGPLANE_THREADS;
+    for (int i = t; i < ny; i += BIGPLANE_THREADS) sh.twYs[i] = a.twY[i];
+    for (int i = t; i < nh; i += BIGPLANE_THREADS) sh.twZh[i] = a.twZ[2 * i];
+    for (int i = t; i <= nh; i += BIGPLANE_THREADS) sh.twZs[i] = a.twZ[i];
+    const int pairs = nh / 2 + 1;                               // (k, nh - k), k = 0 .. nh/2
+    if (a.forward) {
+        // rows of real numbers as rows of nh complex numbers (even, odd): line y, element m at m*S + y
+        const float2* in = (const float2*) (a.real + (size_t) x * ny * nz);
+        float2 ld[MAXLD];
+#pragma unroll
+        for (int it = 0; it < MAXLD; it++) {
+            const int idx = t + it * BIGPLANE_THREADS;
+            ld[it] = idx < ny * nh ? in[idx] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < MAXLD; it++) {
+            const int idx = t + it * BIGPLANE_THREADS;
+            if (idx < ny * nh) { const int y = idx / nh, m = idx - y * nh; buf[m * S + y] = ld[it]; }
+        }
+        __syncthreads();
+        fft_lines_inplace(a.planZh, buf, ny, S, 1, -1, sh.twZh);
+        // split: Z[k] = Ev[k] + i Od[k] (transforms of the even and the odd samples), X[k] = Ev[k] + w^k Od[k], X[nh-k] = conj(Ev[k] - w^k Od[k])
+        for (int idx = t; idx < pairs * ny; idx += BIGPLANE_THREADS) {
+            const int k = idx / ny, y = idx - k * ny;
+            if (k == 0) {
+                const float2 z = buf[y];
+                buf[y] = make_float2(z.x + z.y, 0.f);
+                buf[nh * S + y] = make_float2(z.x - z.y, 0.f);
+            }
+            else {
+                const float2 p = buf[k * S + y], q = buf[(nh - k) * S + y], w = sh.twZs[k];
+                const float evx = 0.5f * (p.x + q.x), evy = 0.5f * (p.y - q.y);        // (p + conj q) / 2
+                const float odx = 0.5f * (p.y + q.y), ody = -0.5f * (p.x - q.x);       // (p - conj q) / (2i)
+                const float tx = w.x * odx - w.y * ody, ty = w.x * ody + w.y * odx;
+                buf[k * S + y] = make_float2(evx + tx, evy + ty);
+                if (nh - k != k) buf[(nh - k) * S + y] = make_float2(evx - tx, -(evy - ty));
+            }
+        }
+        __syncthreads();
+        fft_lines_inplace(a.planY, buf, nzc, 1, S, -1, sh.twYs);                       // lines = kz, elements = y
+        for (int idx = t; idx < ny * nzc; idx += BIGPLANE_THREADS) {
+            const int ky = idx / nzc, kz = idx - ky * nzc;
+            a.cplx[plane_cplx_index(a, x, ky, kz, nzc)] = buf[kz * S + ky];
+        }
+    }
+    else {
+        float2 ld[MAXLD];
+#pragma unroll
+        for (int it = 0; it < MAXLD; it++) {
+            const int idx = t + it * BIGPLANE_THREADS;
+            ld[it] = idx < ny * nzc ? a.cplx[plane_cplx_index(a, x, idx / nzc, idx % nzc, nzc)] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < MAXLD; it++) {
+            const int idx = t + it * BIGPLANE_THREADS;
+            if (idx < ny * nzc) { const int ky = idx / nzc, kz = idx - ky * nzc; buf[kz * S + ky] = ld[it]; }
+        }
+        __syncthreads();
+        fft_lines_inplace(a.planY, buf, nzc, 1, S, +1, sh.twYs);
+        // recombination: Z[k] = E[k] + i O[k] with E[k] = X[k] + conj X[nh-k], O[k] = conj(w)^k (X[k] - conj X[nh-k]); Z[nh-k] = conj(E[k] - i O[k]).
+        // The imaginary parts of X[0] and X[nh] would only add to the imaginary part of the real-space result: dropped, as taking .x does.
+        for (int idx = t; idx < pairs * ny; idx += BIGPLANE_THREADS) {
+            const int k = idx / ny, y = idx - k * ny;
+            if (k == 0) {
+                const float p = buf[y].x, q = buf[nh * S + y].x;
+                buf[y] = make_float2(p + q, p - q);
+            }
+            else {
+                const float2 p = buf[k * S + y], q = buf[(nh - k) * S + y], w = sh.twZs[k];
+                const float ex = p.x + q.x, ey = p.y - q.y;                            // p + conj q
+                const float dx = p.x - q.x, dy = p.y + q.y;                            // p - conj q
+                const float ox = w.x * dx + w.y * dy, oy = w.x * dy - w.y * dx;        // conj(w) * (p - conj q)
+                buf[k * S + y] = make_float2(ex - oy, ey + ox);                        // E + i O
+                if (nh - k != k) buf[(nh - k) * S + y] = make_float2(ex + oy, -(ey - ox));   // conj(E - i O)
+            }
+        }
+        __syncthreads();
+        fft_lines_inplace(a.planZh, buf, ny, S, 1, +1, sh.twZh);
+        float2* out = (float2*) (a.real + (size_t) x * ny * nz);
+        for (int idx = t; idx < ny * nh; idx += BIGPLANE_THREADS) {
+            const int y = idx / nh, m = idx - y * nh;
+            out[idx] = buf[m * S + y];
+        }
+    }
+}
+
+__global__ __launch_bounds__(BIGPLANE_THREADS) void fft_bigplane_kernel(PlaneArgs a) {
+    __shared__ BigPlaneShared sh;
+    fft_bigplane_body(a, blockIdx.x, sh);
+}
+
 FftPlan make_plan(int n) {
     FftPlan p;
     p.n = n; p.numRadices = 0; p.radices = 0;
@@ -1140,9 +1336,20 @@ int lines_per_group(int n) {
     return p;
 }
 
+// which fused plane kernel takes the (y, z) half of this grid: 1 the small one (two LDS buffers), 2 the large one (one workgroup
+// per CU, in place), 0 neither (line passes)
+int plane_kernel_kind(const ommhip_pme* pme) {
+    const int ny = pme->ny, nz = pme->nz;
+    if (pme->fft_mode == 1 || ny > 256 || nz > 256) return 0;
+    if (nz * (ny + 1) <= PLANE_MAX) return 1;
+    static const bool noBig = getenv("OPENMM_HIP_NO_BIG_PLANE") != nullptr;            // A/B knob
+    if (noBig || nz % 2 != 0 || (nz / 2 + 1) * (ny + 1) > BIGPLANE_CAP || make_plan(nz / 2).n != nz / 2) return 0;
+    return 2;
+}
+
 PlaneArgs make_plane_args(const ommhip_pme* pme, bool forward) {
     PlaneArgs p;
-    p.planY = make_plan(pme->ny); p.planZ = make_plan(pme->nz); p.ny = pme->ny; p.nz = pme->nz; p.forward = forward ? 1 : 0;
+    p.planY = make_plan(pme->ny); p.planZ = make_plan(pme->nz); p.planZh = make_plan(pme->nz / 2); p.ny = pme->ny; p.nz = pme->nz; p.forward = forward ? 1 : 0;
     p.twY = (const float2*) pme->twiddle_y; p.twZ = (const float2*) pme->twiddle_z;
     p.real = (float*) pme->grid_real; p.cplx = (float2*) pme->grid_complex;
     p.nxl = pme->nx; p.nyl = 0;
@@ -1169,13 +1376,11 @@ FftArgs make_xconv_args(const ommhip_pme* pme, double* energy_buffer_d, int ener
 void launch_yz(const ommhip_pme* pme, bool forward, hipStream_t st) {
     const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
     float2* cgrid = (float2*) pme->grid_complex;
-    if (nz * (ny + 1) <= PLANE_MAX && ny <= 256 && nz <= 256 && pme->fft_mode != 1) {
-        PlaneArgs p;
-        p.planY = make_plan(ny); p.planZ = make_plan(nz); p.ny = ny; p.nz = nz; p.forward = forward ? 1 : 0;
-        p.twY = (const float2*) pme->twiddle_y; p.twZ = (const float2*) pme->twiddle_z;
-        p.real = (float*) pme->grid_real; p.cplx = cgrid;
-        p.nxl = nx; p.nyl = 0;
-        hipLaunchKernelGGL(fft_plane_kernel, dim3(nx), dim3(PLANE_THREADS), 0, st, p);
+    if (const int kind = plane_kernel_kind(pme)) {
+        PlaneArgs p = make_plane_args(pme, forward);
+        p.cplx = cgrid;
+        if (kind == 1) hipLaunchKernelGGL(fft_plane_kernel, dim3(nx), dim3(PLANE_THREADS), 0, st, p);
+        else hipLaunchKernelGGL(fft_bigplane_kernel, dim3(nx), dim3(BIGPLANE_THREADS), 0, st, p);
         return;
     }
     FftArgs f;
@@ -1333,10 +1538,11 @@ void launch_yz_dd(const ommhip_pme* pme, bool forward, float* realOwn, hipStream
     const int R = pme->dd_ranks, nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1, nxl = nx / R, nyl = ny / R;
     float2* A = (float2*) pme->grid_complex;
     float2* B = (float2*) pme->grid_complex2;
-    if (nz * (ny + 1) <= PLANE_MAX && ny <= 256 && nz <= 256 && pme->fft_mode != 1) {
+    if (const int kind = plane_kernel_kind(pme)) {
         PlaneArgs p = make_plane_args(pme, forward);
         p.real = realOwn; p.cplx = A; p.nxl = nxl; p.nyl = nyl;
-        hipLaunchKernelGGL(fft_plane_kernel, dim3(nxl), dim3(PLANE_THREADS), 0, st, p);
+        if (kind == 1) hipLaunchKernelGGL(fft_plane_kernel, dim3(nxl), dim3(PLANE_THREADS), 0, st, p);
+        else hipLaunchKernelGGL(fft_bigplane_kernel, dim3(nxl), dim3(BIGPLANE_THREADS), 0, st, p);
         return;
     }
     FftArgs f;

@@ -147,6 +147,13 @@ def test_fft3d_against_numpy(K, ng, fft_mode):
     assert fwd < 1e-5 and back < 1e-5
 
 
+@pytest.mark.parametrize("ng", [(12, 105, 140), (128, 160, 144), (192, 192, 192)])
+def test_fft3d_large_planes_against_numpy(K, ng):
+    # planes beyond the small plane kernel's LDS: fft_bigplane_kernel (one 1024-thread workgroup per x plane, 156 KB of LDS, in place)
+    fwd, back = KC.run_fft(K, ng, fft_mode=0)
+    assert fwd < 1e-5 and back < 1e-5
+
+
 @pytest.mark.parametrize("n,ng,tric", [(500, (20, 24, 28), False), (500, (20, 24, 28), True), (3000, (32, 32, 32), False), (6000, (56, 56, 56), False)])
 def test_pme_reciprocal(K, n, ng, tric):
     f, e, f_or, e_or = KC.run_pme(K, n, ng, 3.0 if n <= 3000 else 6.2, tric, alpha=2.6 if n <= 3000 else 2.92)

@@ -48,6 +48,11 @@ typedef struct ommhip_amoeba_vdw {
     int periodic;                  /* 1: CutoffPeriodic (box given to the call), 0: NoCutoff */
     double cutoff, taper_cutoff, taper_c3, taper_c4, taper_c5;
     double* reduced;               /* device double4[num_atoms] scratch: the interaction sites */
+    /* Pair scan in the platform's slot order (optional; NULL = all atoms in atom order, O(N^2)): 256-slot tiles farther apart than the
+     * cutoff are skipped (CutoffPeriodic, rectangular boxes).  slot_of_atom / padded_atoms are the arguments of the call. */
+    const int* atom_of_slot;       /* device int[padded_atoms]: atom at each slot, -1 = padding */
+    double* tile_bounds;           /* device double4[2 * ceil(padded_atoms / 256)] work array */
+    int* excl_pos;                 /* device int[entries of excl_atoms] work array: the excluded partners as slots, rows sorted */
 } ommhip_amoeba_vdw;
 
 int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* vdw, const void* pos_d, const double box[6], const int* slot_of_atom_d, int padded_atoms,
@@ -108,6 +113,14 @@ typedef struct ommhip_amoeba_multipole {
     double* solver;                /* [24n + 16] work vectors of the conjugate-gradient solver */
     double* status;                /* HOST double[2], written by the calls: [0] epsilon reached, [1] iterations (or NULL) */
     void* pme;                     /* const ommhip_pme*: grid sizes, box, moduli, eterm, real / complex grids, twiddles of the platform's PME */
+    /* Pair scan in the platform's slot order (optional; all NULL / 0 = scan in atom order over all atoms, O(N^2)): with a spatially
+     * sorted order the real-space kernels skip the 128-slot tiles farther apart than the cutoff (rectangular boxes). */
+    const int* atom_of_slot;       /* device int[scan_slots]: atom at each slot, -1 = padding */
+    const int* slot_of_atom;       /* device int[num_atoms] */
+    int scan_slots;                /* the platform's padded atom count */
+    double* tile_bounds;           /* device double4[2 * ceil(scan_slots / 128)] work array: tile centres, then half extents */
+    int* special_pos;              /* device int[entries of special_atom] work array: the partners as slots, rows sorted */
+    double* special_scale_sorted;  /* device double4[entries] work array */
 } ommhip_amoeba_multipole;
 
 /* Whole evaluation: frames -> reciprocal and real-space field -> induced dipoles -> energy, forces, torques -> forces. */

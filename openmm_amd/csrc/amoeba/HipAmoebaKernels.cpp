@@ -95,6 +95,10 @@ void HipCalcAmoebaVdwForceKernel::upload(const AmoebaVdwForce& force) {
         vdw.taper_c5 = 6.0 / pow(vdw.taper_cutoff - cutoff, 5.0);
     }
     vdw.reduced = reduced.as<double>();
+    // the pair scan runs in the platform's slot order (256-slot tiles, far tiles skipped)
+    tileBounds.allocate(sizeof(double) * 4 * 2 * max(((size_t) hip.paddedAtoms + 255) / 256, (size_t) 1));
+    exclPos.allocate(sizeof(int) * max(flat.size(), (size_t) 1));
+    vdw.tile_bounds = tileBounds.as<double>(); vdw.excl_pos = exclPos.as<int>(); vdw.atom_of_slot = NULL;
 }
 
 double HipCalcAmoebaVdwForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy) {
@@ -110,6 +114,7 @@ double HipCalcAmoebaVdwForceKernel::execute(ContextImpl& context, bool includeFo
             throw OpenMMException("The periodic box size has decreased to less than twice the cutoff.");
     }
     hip.ensureCleared();
+    vdw.atom_of_slot = hip.atomOfSlot.as<int>();
     HIP_CHECK(ommhip_amoeba_vdw_forces(&vdw, hip.pos.ptr, hip.box, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.force.as<long long>(),
                                        hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream));
     nativeEvaluations[0]++;
@@ -307,6 +312,18 @@ void HipCalcAmoebaMultipoleForceKernel::upload(const AmoebaMultipoleForce& force
     mp.mutual = mutual ? 1 : 0;
     mp.max_iterations = force.getMutualInducedMaxIterations(); mp.target_epsilon = force.getMutualInducedTargetEpsilon();
     mp.phi_induced_p = mutual ? phiIndP.as<double>() : NULL; mp.solver = mutual ? solver.as<double>() : NULL; mp.status = solverStatus;
+    // the pair scan runs in the platform's slot order (tiles of 128 slots, far tiles skipped); the order itself is set per evaluation
+    const size_t tiles = ((size_t) hip.paddedAtoms + 127) / 128;
+    tileBounds.allocate(sizeof(double) * 4 * 2 * max(tiles, (size_t) 1));
+    specPos.allocate(sizeof(int) * max(atoms.size(), (size_t) 1));
+    specScaleSorted.allocate(sizeof(double) * 4 * max(atoms.size(), (size_t) 1));
+    mp.tile_bounds = tileBounds.as<double>(); mp.special_pos = specPos.as<int>(); mp.special_scale_sorted = specScaleSorted.as<double>();
+    mp.atom_of_slot = NULL; mp.slot_of_atom = NULL; mp.scan_slots = 0;
+}
+
+void HipCalcAmoebaMultipoleForceKernel::setScanOrder() {
+    HipContext& hip = *data.hip;
+    mp.atom_of_slot = hip.atomOfSlot.as<int>(); mp.slot_of_atom = hip.slotOfAtom.as<int>(); mp.scan_slots = hip.paddedAtoms;
 }
 
 void HipCalcAmoebaMultipoleForceKernel::prepareGrid() {
@@ -325,6 +342,7 @@ double HipCalcAmoebaMultipoleForceKernel::execute(ContextImpl& context, bool inc
     hip.setAsCurrent();
     prepareGrid();
     hip.ensureCleared();
+    setScanOrder();
     const int rc = ommhip_amoeba_multipole_forces(&mp, hip.pos.ptr, hip.box, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.force.as<long long>(),
                                                   hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream);
     checkSolver(rc);
@@ -336,6 +354,7 @@ void HipCalcAmoebaMultipoleForceKernel::induce() {
     HipContext& hip = *data.hip;
     hip.setAsCurrent();
     prepareGrid();
+    setScanOrder();
     checkSolver(ommhip_amoeba_multipole_induce(&mp, hip.pos.ptr, hip.box, hip.stream));
 }
 

@@ -27,7 +27,7 @@ private:
     bool usePBC = false;
     double cutoff = 0, dispersionCoefficient = 0, softcorePower = 0, softcoreAlpha = 0;
     ommhip_amoeba_vdw vdw;
-    DeviceBuffer parent, reduction, type, sigma, epsilon, exclStart, exclAtoms, alchemical, reduced;
+    DeviceBuffer parent, reduction, type, sigma, epsilon, exclStart, exclAtoms, alchemical, reduced, tileBounds, exclPos;
 };
 
 /** amoebaKernels.h:82-139 CalcAmoebaMultipoleForceKernel for PME with direct or mutual polarization; Reference: AmoebaReferenceKernels.cpp:170-520 +
@@ -53,6 +53,7 @@ private:
     void upload(const AmoebaMultipoleForce& force);
     void prepareGrid();
     void induce();
+    void setScanOrder();
     void checkSolver(int rc);
     void download3(DeviceBuffer& buffer, std::vector<Vec3>& out);
     void syncHostPositions(ContextImpl& context);
@@ -65,7 +66,7 @@ private:
     ommhip_amoeba_multipole mp;
     ommhip_pme pme;
     DeviceBuffer charge, molDipole, molQuad, axis, thole, damping, polarity, specStart, specAtom, specScale;
-    DeviceBuffer labDipole, labQuad, fieldD, fieldP, indD, indP, phi, phiInd, phiIndP, solver, torque;
+    DeviceBuffer labDipole, labQuad, fieldD, fieldP, indD, indP, phi, phiInd, phiIndP, solver, torque, tileBounds, specPos, specScaleSorted;
     DeviceBuffer moduliX, moduliY, moduliZ, twiddleX, twiddleY, twiddleZ, eterm, gridReal, gridComplex;
 };
 

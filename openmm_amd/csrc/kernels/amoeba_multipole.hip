@@ -20,13 +20,18 @@
 // (the form the Reference sums, :6456-6751), and its gradient at fixed dipoles is that of W1 + ... + W4 (no factor 1/2):
 //     dU = -1/2 sum (mu_p . dE_d + mu_d . dE_p).
 //
-// Wave64 formulation: one thread owns atom i and walks through all atoms j, 128 at a time staged in LDS (every lane reads the same
+// Wave64 formulation: one thread owns atom i and walks through atoms j, 128 at a time staged in LDS (every lane reads the same
 // j: LDS broadcast); every pair is seen from both of its atoms, so a thread accumulates field / force / torque of its own atom only
-// and the loops hold no atomics.  This first native slice is O(N^2) in the pair scan (the distance test is cheap, the multipole
-// algebra runs only inside the cutoff); putting it on the tiled neighbour list of the NonbondedForce kernels is the next step.
+// and the loops hold no atomics.  The scan runs in the platform's slot order (Hilbert-sorted 32-atom blocks, HipContext): a tile of
+// 128 consecutive slots is spatially compact, its bounding box is computed once per evaluation, and a workgroup skips the j tiles
+// farther from its own than the cutoff (rectangular boxes; block-uniform test, so the skip costs no divergence) -- O(N) tile visits
+// per workgroup that end at once instead of O(N) tiles staged and tested pair by pair.  Without a slot order (the C ABI called with
+// atom_of_slot = NULL) or in a triclinic box the scan visits every tile, as the first version did.
 #include "common.h"
 #include "../../../include/openmm_hip_amoeba.h"
 #include "../../../include/openmm_hip_kernels.h"
+#include <cstdio>
+#include <cstdlib>
 
 using namespace omm;
 
@@ -98,7 +103,26 @@ struct MpArgs {
     const int* slotOfAtom;
     omm_fixed* force;
     double* energyBuffer;
+    // pair scan in the platform's slot order (spatially sorted 32-atom blocks): scan position g holds atom order[g] (-1: padding);
+    // tiles of MP_BLOCK positions with bounding boxes, tiles farther apart than the cutoff are skipped.  order == nullptr: atom order, no skipping.
+    const int* order; int numScan, skipTiles;
+    double4* tileCenter; double4* tileHalf;
+    int* specPos; double4* specScaleSorted;        // the special-pair rows with partners as scan positions, ascending
 };
+
+// atom at scan position g (-1: none)
+__device__ __forceinline__ int scan_atom(const MpArgs& a, int g) { return g < a.numScan ? (a.order != nullptr ? a.order[g] : g) : -1; }
+
+// Are the tiles (MP_BLOCK scan positions each) ti and tj farther apart than the cutoff?  Rectangular boxes (skipTiles is 0 otherwise):
+// per axis the nearest-image distance of the centres minus the half extents.  Block-uniform.
+__device__ __forceinline__ bool tiles_far(const MpArgs& a, int ti, int tj) {
+    if (!a.skipTiles) return false;
+    const double4 ci = a.tileCenter[ti], hi = a.tileHalf[ti], cj = a.tileCenter[tj], hj = a.tileHalf[tj];
+    double dx = cj.x - ci.x, dy = cj.y - ci.y, dz = cj.z - ci.z;
+    dx -= rint(dx / a.box.ax) * a.box.ax; dy -= rint(dy / a.box.by) * a.box.by; dz -= rint(dz / a.box.cz) * a.box.cz;
+    const double gx = fmax(fabs(dx) - hi.x - hj.x, 0.0), gy = fmax(fabs(dy) - hi.y - hj.y, 0.0), gz = fmax(fabs(dz) - hi.z - hj.z, 0.0);
+    return gx * gx + gy * gy + gz * gz > a.cutoff2;        // an empty tile has half extents of -1e30: far from everything
+}
 
 __device__ __forceinline__ V3 load3(const double* p, int i) { return v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 __device__ __forceinline__ void store3(double* p, int i, V3 v) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; }
@@ -332,14 +356,62 @@ __device__ __forceinline__ void pair_chains(double alpha, double r2, double damp
 struct PairScale { double m, p, d; };
 
 // scale factors of the pair (i, j) from i's list of special partners (ascending; the cursor moves with j)
+// j: scan position of the partner (= its atom index without a scan order); the row is walked once, in step with the ascending j
 __device__ __forceinline__ PairScale pair_scale(const MpArgs& a, int j, int& cursor, int end, int& next) {
     PairScale s = {1.0, 1.0, 1.0};
-    while (next < j) { cursor++; next = cursor < end ? a.specAtom[cursor] : 0x7fffffff; }
-    if (next == j) { const double4 v = a.specScale[cursor]; s.m = v.x; s.p = v.y; s.d = v.z; }
+    const int* partner = a.order != nullptr ? a.specPos : a.specAtom;
+    while (next < j) { cursor++; next = cursor < end ? partner[cursor] : 0x7fffffff; }
+    if (next == j) { const double4 v = (a.order != nullptr ? a.specScaleSorted : a.specScale)[cursor]; s.m = v.x; s.p = v.y; s.d = v.z; }
     return s;
 }
+__device__ __forceinline__ int first_partner(const MpArgs& a, int cursor, int end) { return cursor < end ? (a.order != nullptr ? a.specPos : a.specAtom)[cursor] : 0x7fffffff; }
 
-struct JSite { double x, y, z, q; V3 mu; Sym Q; double thole, damp; V3 ud, up; };
+// Scan order only: the special-pair row of every atom re-keyed to scan positions and sorted (rows are short: covalent neighbours and the
+// polarization group), and the bounding boxes of the tiles.
+__global__ void k_mp_sort_special(MpArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int b = a.specStart[i], e = a.specStart[i + 1];
+    for (int c = b; c < e; c++) {
+        const int pos = a.slotOfAtom[a.specAtom[c]];
+        const double4 v = a.specScale[c];
+        int k = c;
+        while (k > b && a.specPos[k - 1] > pos) { a.specPos[k] = a.specPos[k - 1]; a.specScaleSorted[k] = a.specScaleSorted[k - 1]; k--; }
+        a.specPos[k] = pos; a.specScaleSorted[k] = v;
+    }
+}
+__global__ __launch_bounds__(MP_BLOCK) void k_mp_tile_bounds(MpArgs a) {
+    __shared__ double lo[3][MP_BLOCK], hi[3][MP_BLOCK];
+    __shared__ int firstValid;
+    const int t = threadIdx.x, g = blockIdx.x * MP_BLOCK + t, i = scan_atom(a, g);
+    if (t == 0) firstValid = MP_BLOCK;
+    __syncthreads();
+    if (i >= 0) atomicMin(&firstValid, t);
+    __syncthreads();
+    if (firstValid == MP_BLOCK) {
+        if (t == 0) { a.tileCenter[blockIdx.x] = make_double4(0, 0, 0, 0); a.tileHalf[blockIdx.x] = make_double4(-1e30, -1e30, -1e30, 0); }
+        return;
+    }
+    const double4 ref = a.pos[scan_atom(a, blockIdx.x * MP_BLOCK + firstValid)];
+    double d[3] = {0, 0, 0};
+    if (i >= 0) {
+        const double4 p = a.pos[i];
+        d[0] = p.x - ref.x; d[1] = p.y - ref.y; d[2] = p.z - ref.z;
+        min_image_d(d[0], d[1], d[2], a.box);
+    }
+    for (int k = 0; k < 3; k++) { lo[k][t] = d[k]; hi[k][t] = d[k]; }
+    __syncthreads();
+    for (int m = MP_BLOCK / 2; m >= 1; m >>= 1) {
+        if (t < m) for (int k = 0; k < 3; k++) { lo[k][t] = fmin(lo[k][t], lo[k][t + m]); hi[k][t] = fmax(hi[k][t], hi[k][t + m]); }
+        __syncthreads();
+    }
+    if (t == 0) {
+        a.tileCenter[blockIdx.x] = make_double4(ref.x + 0.5 * (lo[0][0] + hi[0][0]), ref.y + 0.5 * (lo[1][0] + hi[1][0]), ref.z + 0.5 * (lo[2][0] + hi[2][0]), 0);
+        a.tileHalf[blockIdx.x] = make_double4(0.5 * (hi[0][0] - lo[0][0]), 0.5 * (hi[1][0] - lo[1][0]), 0.5 * (hi[2][0] - lo[2][0]), 0);
+    }
+}
+
+struct JSite { double x, y, z, q; V3 mu; Sym Q; double thole, damp; V3 ud, up; int ok; };
 
 // ------------------------------------------------------------------------------------------------
 // Field of the permanent multipoles at every atom (chains d and p, reciprocal part, self term) and the induced dipoles of direct
@@ -348,31 +420,35 @@ struct JSite { double x, y, z, q; V3 mu; Sym Q; double thole, damp; V3 ud, up; }
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(MP_BLOCK) void k_mp_field(MpArgs a) {
     __shared__ JSite sj[MP_BLOCK];
-    const int t = threadIdx.x, i = blockIdx.x * MP_BLOCK + t;
-    const bool active = i < a.n;
+    const int t = threadIdx.x, g = blockIdx.x * MP_BLOCK + t, i = scan_atom(a, g);
+    const bool active = i >= 0;
     const int ii = active ? i : 0;
     const V3 xi = position(a, ii);
     const double tholeI = a.thole[ii], dampI = a.damping[ii];
     int cursor = a.specStart[ii];
     const int specEnd = a.specStart[ii + 1];
-    int next = cursor < specEnd ? a.specAtom[cursor] : 0x7fffffff;
+    int next = first_partner(a, cursor, specEnd);
     V3 ed = v3(0, 0, 0), ep = v3(0, 0, 0);
-    for (int j0 = 0; j0 < a.n; j0 += MP_BLOCK) {
+    for (int j0 = 0; j0 < a.numScan; j0 += MP_BLOCK) {
+        if (tiles_far(a, blockIdx.x, j0 / MP_BLOCK)) continue;
         __syncthreads();
-        if (j0 + t < a.n) {
-            const int j = j0 + t;
-            const V3 x = position(a, j);
-            JSite s;
-            s.x = x.x; s.y = x.y; s.z = x.z; s.q = a.charge[j]; s.mu = load3(a.labDipole, j); s.Q = load6(a.labQuad, j); s.thole = a.thole[j]; s.damp = a.damping[j];
-            s.ud = s.up = v3(0, 0, 0);
-            sj[t] = s;
+        {
+            const int j = scan_atom(a, j0 + t);
+            sj[t].ok = j >= 0;
+            if (j >= 0) {
+                const V3 x = position(a, j);
+                JSite s;
+                s.x = x.x; s.y = x.y; s.z = x.z; s.q = a.charge[j]; s.mu = load3(a.labDipole, j); s.Q = load6(a.labQuad, j); s.thole = a.thole[j]; s.damp = a.damping[j];
+                s.ud = s.up = v3(0, 0, 0); s.ok = 1;
+                sj[t] = s;
+            }
         }
         __syncthreads();
         if (!active) continue;
-        const int nj = min(MP_BLOCK, a.n - j0);
+        const int nj = min(MP_BLOCK, a.numScan - j0);
         for (int k = 0; k < nj; k++) {
             const int j = j0 + k;
-            if (j == i) continue;
+            if (j == g || !sj[k].ok) continue;
             const PairScale sc = pair_scale(a, j, cursor, specEnd, next);
             const JSite& s = sj[k];
             double dx = s.x - xi.x, dy = s.y - xi.y, dz = s.z - xi.z;
@@ -425,8 +501,8 @@ __device__ __forceinline__ void in_potential(double q, V3 mu, const Sym& Q, cons
 __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
     __shared__ JSite sj[MP_BLOCK];
     __shared__ double sEnergy[MP_BLOCK / 64];
-    const int t = threadIdx.x, i = blockIdx.x * MP_BLOCK + t;
-    const bool active = i < a.n;
+    const int t = threadIdx.x, g = blockIdx.x * MP_BLOCK + t, i = scan_atom(a, g);
+    const bool active = i >= 0;
     const int ii = active ? i : 0;
     const V3 xi = position(a, ii);
     Site Mi;
@@ -437,25 +513,29 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
     const double tholeI = a.thole[ii], dampI = a.damping[ii];
     int cursor = a.specStart[ii];
     const int specEnd = a.specStart[ii + 1];
-    int next = cursor < specEnd ? a.specAtom[cursor] : 0x7fffffff;
+    int next = first_partner(a, cursor, specEnd);
     V3 force = v3(0, 0, 0), torque = v3(0, 0, 0);
     double energy = 0.0;
-    for (int j0 = 0; j0 < a.n; j0 += MP_BLOCK) {
+    for (int j0 = 0; j0 < a.numScan; j0 += MP_BLOCK) {
+        if (tiles_far(a, blockIdx.x, j0 / MP_BLOCK)) continue;
         __syncthreads();
-        if (j0 + t < a.n) {
-            const int j = j0 + t;
-            const V3 x = position(a, j);
-            JSite s;
-            s.x = x.x; s.y = x.y; s.z = x.z; s.q = a.charge[j]; s.mu = load3(a.labDipole, j); s.Q = load6(a.labQuad, j); s.thole = a.thole[j]; s.damp = a.damping[j];
-            s.ud = load3(a.indD, j); s.up = load3(a.indP, j);
-            sj[t] = s;
+        {
+            const int j = scan_atom(a, j0 + t);
+            sj[t].ok = j >= 0;
+            if (j >= 0) {
+                const V3 x = position(a, j);
+                JSite s;
+                s.x = x.x; s.y = x.y; s.z = x.z; s.q = a.charge[j]; s.mu = load3(a.labDipole, j); s.Q = load6(a.labQuad, j); s.thole = a.thole[j]; s.damp = a.damping[j];
+                s.ud = load3(a.indD, j); s.up = load3(a.indP, j); s.ok = 1;
+                sj[t] = s;
+            }
         }
         __syncthreads();
         if (!active) continue;
-        const int nj = min(MP_BLOCK, a.n - j0);
+        const int nj = min(MP_BLOCK, a.numScan - j0);
         for (int k = 0; k < nj; k++) {
             const int j = j0 + k;
-            if (j == i) continue;
+            if (j == g || !sj[k].ok) continue;
             const PairScale sc = pair_scale(a, j, cursor, specEnd, next);
             const JSite& s = sj[k];
             double dx = s.x - xi.x, dy = s.y - xi.y, dz = s.z - xi.z;
@@ -545,31 +625,35 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
 // Mutual polarization: field of two sets of dipoles (vD, vP) at every atom -- real space through the Thole-damped chain, the
 // reciprocal part from their two potentials, the self field.  calculateInducedDipoleFields (:6059-6152).
 // ------------------------------------------------------------------------------------------------
-struct JDipole { double x, y, z, thole, damp; V3 vd, vp; };
+struct JDipole { double x, y, z, thole, damp; V3 vd, vp; int ok; };
 
 __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const double* __restrict__ vD, const double* __restrict__ vP, const double* __restrict__ phiD,
                                                               const double* __restrict__ phiP, double* __restrict__ outD, double* __restrict__ outP) {
     __shared__ JDipole sj[MP_BLOCK];
-    const int t = threadIdx.x, i = blockIdx.x * MP_BLOCK + t;
-    const bool active = i < a.n;
+    const int t = threadIdx.x, g = blockIdx.x * MP_BLOCK + t, i = scan_atom(a, g);
+    const bool active = i >= 0;
     const int ii = active ? i : 0;
     const V3 xi = position(a, ii);
     const double tholeI = a.thole[ii], dampI = a.damping[ii];
     V3 ed = v3(0, 0, 0), ep = v3(0, 0, 0);
-    for (int j0 = 0; j0 < a.n; j0 += MP_BLOCK) {
+    for (int j0 = 0; j0 < a.numScan; j0 += MP_BLOCK) {
+        if (tiles_far(a, blockIdx.x, j0 / MP_BLOCK)) continue;
         __syncthreads();
-        if (j0 + t < a.n) {
-            const int j = j0 + t;
-            const V3 x = position(a, j);
-            JDipole s;
-            s.x = x.x; s.y = x.y; s.z = x.z; s.thole = a.thole[j]; s.damp = a.damping[j]; s.vd = load3(vD, j); s.vp = load3(vP, j);
-            sj[t] = s;
+        {
+            const int j = scan_atom(a, j0 + t);
+            sj[t].ok = j >= 0;
+            if (j >= 0) {
+                const V3 x = position(a, j);
+                JDipole s;
+                s.x = x.x; s.y = x.y; s.z = x.z; s.thole = a.thole[j]; s.damp = a.damping[j]; s.vd = load3(vD, j); s.vp = load3(vP, j); s.ok = 1;
+                sj[t] = s;
+            }
         }
         __syncthreads();
         if (!active) continue;
-        const int nj = min(MP_BLOCK, a.n - j0);
+        const int nj = min(MP_BLOCK, a.numScan - j0);
         for (int k = 0; k < nj; k++) {
-            if (j0 + k == i) continue;
+            if (j0 + k == g || !sj[k].ok) continue;
             const JDipole& s = sj[k];
             double dx = s.x - xi.x, dy = s.y - xi.y, dz = s.z - xi.z;
             min_image_d(dx, dy, dz, a.box);
@@ -713,7 +797,28 @@ bool make_args(const ommhip_amoeba_multipole* mp, const void* pos_d, const doubl
         for (int c = 0; c < 3; c++) a.a[k][c] = n[k] * R[c][k];
     a.grid = (float*) pme->grid_real;
     a.slotOfAtom = nullptr; a.force = nullptr; a.energyBuffer = nullptr;
+    // the pair scan: in slot order with far tiles skipped when the caller provides the order and the work arrays
+    a.order = nullptr; a.numScan = a.n; a.skipTiles = 0; a.tileCenter = a.tileHalf = nullptr; a.specPos = nullptr; a.specScaleSorted = nullptr;
+    static const bool noTiles = getenv("OPENMM_HIP_AMOEBA_NO_TILES") != nullptr;         // A/B knob: the O(N^2) scan of the first version
+    if (!noTiles && mp->atom_of_slot != nullptr && mp->slot_of_atom != nullptr && mp->scan_slots >= a.n && mp->tile_bounds != nullptr && mp->special_pos != nullptr && mp->special_scale_sorted != nullptr) {
+        a.order = mp->atom_of_slot; a.slotOfAtom = mp->slot_of_atom; a.numScan = mp->scan_slots;
+        const int tiles = (a.numScan + MP_BLOCK - 1) / MP_BLOCK;
+        a.tileCenter = (double4*) mp->tile_bounds; a.tileHalf = a.tileCenter + tiles;
+        a.specPos = mp->special_pos; a.specScaleSorted = (double4*) mp->special_scale_sorted;
+        a.skipTiles = box[1] == 0.0 && box[3] == 0.0 && box[4] == 0.0 ? 1 : 0;
+        if (getenv("OPENMM_HIP_AMOEBA_DEBUG") != nullptr) fprintf(stderr, "amoeba scan: %d slots, %d tiles, skip %d\n", a.numScan, tiles, a.skipTiles);
+    }
     return true;
+}
+
+// number of workgroups of the pair-scan kernels (one thread per scan position)
+int scan_blocks(const MpArgs& a) { return (a.numScan + MP_BLOCK - 1) / MP_BLOCK; }
+
+// scan order: special-pair rows re-keyed to scan positions, tile bounding boxes (once per evaluation)
+void prepare_scan(const MpArgs& a, hipStream_t st) {
+    if (a.order == nullptr) return;
+    hipLaunchKernelGGL(k_mp_sort_special, dim3((a.n + 127) / 128), dim3(128), 0, st, a);
+    if (a.skipTiles) hipLaunchKernelGGL(k_mp_tile_bounds, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
 }
 
 // frames, reciprocal potential of the permanent multipoles, fields and induced dipoles
@@ -726,7 +831,8 @@ void launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream
     hipLaunchKernelGGL(k_mp_spread<false>, dim3(blocks), dim3(MP_BLOCK), 0, st, a, (const double*) nullptr, 0.0, (const double*) nullptr, 0.0);
     ommhip_pme_convolve(pme, st);
     hipLaunchKernelGGL(k_mp_potential, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.phi);
-    hipLaunchKernelGGL(k_mp_field, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
+    prepare_scan(a, st);
+    hipLaunchKernelGGL(k_mp_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
 }
 
 // potential (and derivatives) of one set of dipoles at the atoms
@@ -752,7 +858,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t
     // T mu_0
     dipole_potential(pme, a, a.indD, a.phiInd, st);
     dipole_potential(pme, a, a.indP, a.phiIndP, st);
-    hipLaunchKernelGGL(k_mp_dipole_field, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, tD, tP);
+    hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, tD, tP);
     hipMemsetAsync(sums, 0, sizeof(double) * 8, st);
     hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 0, 0.0, 0.0);
     int rc = readSums();
@@ -762,7 +868,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t
     while (epsilon >= mp->target_epsilon && iteration < mp->max_iterations) {
         dipole_potential(pme, a, pD, a.phiInd, st);
         dipole_potential(pme, a, pP, a.phiIndP, st);
-        hipLaunchKernelGGL(k_mp_dipole_field, dim3(blocks), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP);
+        hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP);
         hipMemsetAsync(sums, 0, sizeof(double) * 8, st);
         hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 1, 0.0, 0.0);
         rc = readSums();
@@ -813,7 +919,7 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
         ommhip_pme_convolve(pme, st);
         hipLaunchKernelGGL(k_mp_potential, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.phiInd);
     }
-    hipLaunchKernelGGL(k_mp_forces, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_mp_forces, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_mp_torque_to_force, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
     return (int) hipGetLastError();
 }

@@ -206,6 +206,111 @@ class NonbondedForce:
         return alpha.value, n[0], n[1], n[2]
 
 
+# ---- the AMOEBA forces with native kernels (libommharness_amoeba.so over plugins/amoeba/openmmapi)
+_alib = None
+Mutual, Direct, Extrapolated = 0, 1, 2                                   # AmoebaMultipoleForce::PolarizationType
+ZThenX, Bisector, ZBisect, ThreeFold, ZOnly, NoAxisType = range(6)       # AmoebaMultipoleForce::MultipoleAxisTypes
+Covalent12, Covalent13, Covalent14, Covalent15, PolarizationCovalent11 = range(5)
+
+
+def amoeba_lib():
+    global _alib
+    if _alib is None:
+        lib()
+        path = os.path.join(LIB_DIR, "libommharness_amoeba.so")
+        if not os.path.exists(path):
+            raise OpenMMError("AMOEBA harness library missing: %s (run __graft_entry__.build())" % path)
+        C.CDLL(os.path.join(HOST_LIB_DIR, "libOpenMMAmoeba.so"), mode=C.RTLD_GLOBAL)
+        _alib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        _alib.omm_amoeba_last_error.restype = C.c_char_p
+        _alib.omm_amoeba_multipole_create.restype = C.c_void_p
+        _alib.omm_amoeba_vdw_create.restype = C.c_void_p
+    return _alib
+
+
+def load_amoeba_plugins(emulated=False, native=True):
+    """The AMOEBA plugin's Reference kernels (they attach to every ReferencePlatform-derived platform, the HIP platform included, as
+    fallback forces) and -- native=True -- libOpenMMAmoebaHIP.so, whose kernels then take AmoebaVdwForce and AmoebaMultipoleForce (PME)."""
+    load_hip_platform(emulated)
+    paths = [os.path.join(HOST_LIB_DIR, "libOpenMMAmoebaReference.so")]
+    if native:
+        paths.append(os.path.join(EMU_DIR if emulated else LIB_DIR, "libOpenMMAmoebaHIP.so"))
+    for path in paths:
+        if path not in _loaded_plugins:
+            if path.endswith("AmoebaHIP.so"):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)      # so that ommhip_amoeba_native_evaluations can be found
+            _check(lib().omm_load_plugin(path.encode()))
+            _loaded_plugins.add(path)
+
+
+def amoeba_native_evaluations():
+    """(vdw, multipole) evaluations the native AMOEBA kernels performed in this process: a silent fallback to the Reference kernels shows as 0."""
+    fn = C.CDLL(None).ommhip_amoeba_native_evaluations
+    out = (C.c_longlong * 2)()
+    fn(out)
+    return int(out[0]), int(out[1])
+
+
+def _acheck(rc):
+    if rc != 0:
+        raise OpenMMError(amoeba_lib().omm_amoeba_last_error().decode())
+
+
+class AmoebaMultipoleForce:
+    NoCutoff, PME = 0, 1
+
+    def __init__(self, system, method=1, polarization=Mutual, cutoff=0.7, aEwald=0.0, grid=None, ewaldErrorTolerance=5e-4, mutualInducedTargetEpsilon=1e-5,
+                 mutualInducedMaxIterations=60):
+        g = np.ascontiguousarray(grid if grid is not None else [0, 0, 0], dtype=np.int32)
+        h = amoeba_lib().omm_amoeba_multipole_create(system.h, method, polarization, C.c_double(cutoff), C.c_double(aEwald), _ip(g), C.c_double(ewaldErrorTolerance),
+                                                     C.c_double(mutualInducedTargetEpsilon), mutualInducedMaxIterations)
+        if not h:
+            raise OpenMMError(amoeba_lib().omm_amoeba_last_error().decode())
+        self.h = C.c_void_p(h)
+
+    def addMultipoles(self, charge, dipole, quadrupole, axes, thole, damping, polarity):
+        """dipole (n, 3), quadrupole (n, 3, 3) in the molecular frame, axes (n, 4) = (axis type, z, x, y atom)"""
+        q = np.ascontiguousarray(charge, dtype=np.float64)
+        _acheck(amoeba_lib().omm_amoeba_multipole_add(self.h, len(q), _dp(q), _dp(np.ascontiguousarray(dipole, dtype=np.float64).reshape(-1)),
+                                                      _dp(np.ascontiguousarray(quadrupole, dtype=np.float64).reshape(-1)), _ip(np.ascontiguousarray(axes, dtype=np.int32).reshape(-1)),
+                                                      _dp(np.ascontiguousarray(thole, dtype=np.float64)), _dp(np.ascontiguousarray(damping, dtype=np.float64)),
+                                                      _dp(np.ascontiguousarray(polarity, dtype=np.float64))))
+
+    def setCovalentMaps(self, atoms, types, lists):
+        """entry e: setCovalentMap(atoms[e], types[e], lists[e])"""
+        start = np.zeros(len(lists) + 1, dtype=np.int32)
+        start[1:] = np.cumsum([len(l) for l in lists])
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(l, dtype=np.int32) for l in lists]) if len(lists) else np.zeros(1, np.int32), dtype=np.int32)
+        _acheck(amoeba_lib().omm_amoeba_multipole_set_covalent_maps(self.h, len(lists), _ip(np.ascontiguousarray(atoms, dtype=np.int32)), _ip(np.ascontiguousarray(types, dtype=np.int32)),
+                                                                    _ip(start), _ip(flat)))
+
+    def getInducedDipoles(self, context):
+        out = np.zeros((context.n, 3))
+        _acheck(amoeba_lib().omm_amoeba_multipole_get_induced_dipoles(self.h, context.h, _dp(out)))
+        return out
+
+
+class AmoebaVdwForce:
+    NoCutoff, CutoffPeriodic = 0, 1
+
+    def __init__(self, system, sigmaCombiningRule="CUBIC-MEAN", epsilonCombiningRule="HHG", method=1, cutoff=0.9, useDispersionCorrection=True):
+        h = amoeba_lib().omm_amoeba_vdw_create(system.h, sigmaCombiningRule.encode(), epsilonCombiningRule.encode(), method, C.c_double(cutoff), int(useDispersionCorrection))
+        if not h:
+            raise OpenMMError(amoeba_lib().omm_amoeba_last_error().decode())
+        self.h = C.c_void_p(h)
+
+    def addParticles(self, parent, sigma, epsilon, reduction):
+        p = np.ascontiguousarray(parent, dtype=np.int32)
+        _acheck(amoeba_lib().omm_amoeba_vdw_add(self.h, len(p), _ip(p), _dp(np.ascontiguousarray(sigma, dtype=np.float64)), _dp(np.ascontiguousarray(epsilon, dtype=np.float64)),
+                                                _dp(np.ascontiguousarray(reduction, dtype=np.float64))))
+
+    def setParticleExclusions(self, lists):
+        start = np.zeros(len(lists) + 1, dtype=np.int32)
+        start[1:] = np.cumsum([len(l) for l in lists])
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(l, dtype=np.int32) for l in lists]), dtype=np.int32)
+        _acheck(amoeba_lib().omm_amoeba_vdw_set_exclusions(self.h, len(lists), _ip(start), _ip(flat)))
+
+
 class Integrator:
     def __init__(self, kind, stepSize, temperature=300.0, friction=1.0, seed=1, constraintTolerance=1e-5):
         self.h = _handle(lib().omm_integrator_create(kind, C.c_double(stepSize), C.c_double(temperature), C.c_double(friction),

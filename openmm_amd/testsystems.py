@@ -113,6 +113,85 @@ def water_box(n_side, seed=0, density=33.4, rigid=True, method=H.PME, cutoff=0.9
     return w
 
 
+# AMOEBA water (wrappers/python/openmm/app/data/amoeba2009.xml: Multipole types 402 / 403 :13229-13230, Polarize :13642-13643, Vdw classes
+# 73 / 74 :12733-12734 with radiussize DIAMETER (sigma halved, forcefield.py AmoebaVdwGenerator), Bond :5851, Angle :6161; the same numbers
+# as plugins/amoeba/tests/TestAmoebaMultipoleForce.h:1180-1217).  Units: e, e nm, e nm^2, nm^3.
+AMOEBA_WATER = dict(
+    qO=-0.51966, qH=0.25983,
+    dO=(0.0, 0.0, 0.00755612136146), dH=(-0.00204209484795, 0.0, -0.00307875299958),
+    QO=((0.000354030721139, 0.0, 0.0), (0.0, -0.000390257077096, 0.0), (0.0, 0.0, 3.62263559571e-05)),
+    QH=((-3.42848248983e-05, 0.0, -1.89485963908e-06), (0.0, -0.000100240875193, 0.0), (-1.89485963908e-06, 0.0, 0.000134525700091)),
+    polO=0.000837, polH=0.000496, thole=0.39,
+    sigO=0.5 * 0.3405, epsO=0.46024, redO=1.0, sigH=0.5 * 0.2655, epsH=0.056484, redH=0.91,
+    mO=15.999, mH=1.008, dOH=0.09572, kBond=2 * 221584.64, angle=np.deg2rad(108.5), kAngle=2 * 0.0433973816335 * (180.0 / np.pi) ** 2)
+
+
+class AmoebaWaterWorkload:
+    """Water with the AMOEBA multipole (PME, mutual or direct polarization) and buffered 14-7 vdW forces -- the two AMOEBA forces the HIP
+    platform computes natively -- on given O, H, H coordinates.  AMOEBA's anharmonic bond / angle / Urey-Bradley terms are replaced by their
+    harmonic parts (HarmonicBondForce / HarmonicAngleForce, native as well): this System times the nonbonded AMOEBA path, it is not the
+    amoeba2009 water model to the letter."""
+
+    def __init__(self, positions, box, cutoff=0.7, vdw_cutoff=0.9, polarization=H.Mutual, epsilon=1e-5, ewald_tol=7.5e-4, grid=None, a_ewald=0.0, bonded=True):
+        self.positions = np.asarray(positions, dtype=np.float64)
+        self.box = np.asarray(box, dtype=np.float64)
+        self.cutoff, self.vdw_cutoff, self.polarization, self.epsilon, self.ewald_tol, self.grid, self.a_ewald, self.bonded = cutoff, vdw_cutoff, polarization, epsilon, ewald_tol, grid, a_ewald, bonded
+        self.name = "amoeba-water-%d" % len(self.positions)
+        nw = len(self.positions) // 3
+        a = AMOEBA_WATER
+        self.masses = np.tile([a["mO"], a["mH"], a["mH"]], nw)
+
+    @property
+    def num_atoms(self):
+        return len(self.positions)
+
+    def build(self):
+        """-> (System, AmoebaMultipoleForce, AmoebaVdwForce)"""
+        a = AMOEBA_WATER
+        nw = self.num_atoms // 3
+        o = 3 * np.arange(nw)
+        s = H.System()
+        s.addParticles(self.masses)
+        s.setDefaultPeriodicBoxVectors(*self.box)
+        mp = H.AmoebaMultipoleForce(s, H.AmoebaMultipoleForce.PME, self.polarization, self.cutoff, self.a_ewald, self.grid, self.ewald_tol, self.epsilon, 100)
+        axes = np.stack([np.stack([np.full(nw, H.Bisector), o + 1, o + 2, np.full(nw, -1)], -1),
+                         np.stack([np.full(nw, H.ZThenX), o, o + 2, np.full(nw, -1)], -1),
+                         np.stack([np.full(nw, H.ZThenX), o, o + 1, np.full(nw, -1)], -1)], 1).reshape(-1, 4)
+        pol = np.tile([a["polO"], a["polH"], a["polH"]], nw)
+        mp.addMultipoles(np.tile([a["qO"], a["qH"], a["qH"]], nw), np.tile(np.array([a["dO"], a["dH"], a["dH"]]), (nw, 1)),
+                         np.tile(np.array([a["QO"], a["QH"], a["QH"]]), (nw, 1, 1)), axes, np.full(3 * nw, a["thole"]), pol ** (1.0 / 6.0), pol)
+        atoms, types, lists = [], [], []
+        for w in range(nw):
+            i = 3 * w
+            for atom, t, l in ((i, H.Covalent12, (i + 1, i + 2)), (i + 1, H.Covalent12, (i,)), (i + 2, H.Covalent12, (i,)),
+                               (i + 1, H.Covalent13, (i + 2,)), (i + 2, H.Covalent13, (i + 1,)),
+                               (i, H.PolarizationCovalent11, (i, i + 1, i + 2)), (i + 1, H.PolarizationCovalent11, (i, i + 1, i + 2)), (i + 2, H.PolarizationCovalent11, (i, i + 1, i + 2))):
+                atoms.append(atom); types.append(t); lists.append(l)
+        mp.setCovalentMaps(atoms, types, lists)
+        vdw = H.AmoebaVdwForce(s, "CUBIC-MEAN", "HHG", H.AmoebaVdwForce.CutoffPeriodic, self.vdw_cutoff, True)
+        vdw.addParticles(np.stack([o, o, o], -1).reshape(-1), np.tile([a["sigO"], a["sigH"], a["sigH"]], nw), np.tile([a["epsO"], a["epsH"], a["epsH"]], nw),
+                         np.tile([a["redO"], a["redH"], a["redH"]], nw))
+        vdw.setParticleExclusions([(3 * (i // 3), 3 * (i // 3) + 1, 3 * (i // 3) + 2) for i in range(3 * nw)])
+        if self.bonded:
+            ob = np.stack([np.stack([o, o + 1], -1), np.stack([o, o + 2], -1)], 1).reshape(-1, 2)
+            s.addHarmonicBondForce(ob, np.full(len(ob), a["dOH"]), np.full(len(ob), a["kBond"]))
+            s.addHarmonicAngleForce(np.stack([o + 1, o, o + 2], -1), np.full(nw, a["angle"]), np.full(nw, a["kAngle"]))
+        return s, mp, vdw
+
+
+def amoeba_water_box(n_side, seed=0, **kw):
+    """n_side^3 AMOEBA waters on the jittered lattice of water_box()."""
+    w = water_box(n_side, seed=seed)
+    return AmoebaWaterWorkload(w.positions, w.box, **kw)
+
+
+def amoeba_water_tile(**kw):
+    """12 167 AMOEBA waters (36 501 atoms) on the coordinates of the equilibrated TIP3P tile (tests/golden/water_tile_36501_equilibrated.npz)."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "water_tile_36501_equilibrated.npz"))
+    return AmoebaWaterWorkload(d["positions"], np.eye(3) * float(d["box"]), **kw)
+
+
 def apoa1_like(seed=0):
     """BASELINE.json configs[2] stand-in (examples/apoa1.pdb is not in the reference tree): 92 224
     atoms in the apoa1 box 10.8861 x 10.8861 x 7.7758 nm -- 30 741 TIP3P waters on a jittered 36 x 35 x 25 lattice with

@@ -281,6 +281,18 @@ def test_native_amoeba_multipole_kernel_matches_the_plugins_reference_kernel():
 
 
 @needs_emu
+def test_amoeba_water_box_tile_scan_against_reference_kernel_and_full_scan(tmp_path):
+    """1 536-atom AMOEBA water box (12 tiles of 128 slots in a 2.5 nm box, some pairs of tiles beyond the 0.7 nm cutoff), direct
+    polarization: the tile-skipping pair scan of the native multipole and vdW kernels gives the Reference kernel's forces (float grids:
+    1e-6) and, to the last bit of the fixed-point force sums, the forces of the scan over all atoms."""
+    from amoeba_water_case import run_amoeba_water_case
+    r = run_amoeba_water_case(tmp_path, True, 8, 32, False)
+    print(r)
+    assert r["reference"][0] < 5e-6 and r["reference"][1] < 5e-6
+    assert r["full_scan"][0] < 1e-9 and r["full_scan"][1] < 1e-12
+
+
+@needs_emu
 def test_amoeba_fallback_path_still_works_without_the_native_plugin():
     """HIP_AMOEBA_FALLBACK_ONLY=1: the AMOEBA plugin's own Reference kernels as fallback forces on a HIP Context (round 2's path)."""
     exe = os.path.join(EMU_BUILD, "tests", "TestHipAmoebaVdwForce")

@@ -57,13 +57,13 @@ for step in "$@"; do
       cp openmm_amd/lib/libopenmm_hip_kernels.so /tmp/keep.so
       for rep in 1 2 3; do for v in old new; do
         cp build/ab/$v.so openmm_amd/lib/libopenmm_hip_kernels.so
-        timeout 600 python bench.py --steps ${STEPS:-3000} --warmup 300 --cpu-steps 0 --no-extra-workloads --no-scale-workload $a1 2>/dev/null | tail -1 | show $v
+        timeout ${RUN_TIMEOUT:-600} python bench.py --steps ${STEPS:-3000} --warmup 300 --cpu-steps 0 --no-extra-workloads --no-scale-workload $a1 2>/dev/null | tail -1 | show $v
       done; done 2>&1 | tee -a gpurun_out/${T}_ablib.txt
       cp /tmp/keep.so openmm_amd/lib/libopenmm_hip_kernels.so ;;
     abenv)
       for rep in 1 2; do for cfg in "$a1" "$a2" $a3; do
         ( if [ "$cfg" != "-" ]; then for kv in ${cfg//,/ }; do export "$kv"; done; fi
-          timeout 600 python bench.py --steps ${STEPS:-3000} --warmup 300 --cpu-steps 0 --no-extra-workloads --no-scale-workload $BENCH_ARGS 2>/dev/null | tail -1 | show "$cfg" )
+          timeout ${RUN_TIMEOUT:-600} python bench.py --steps ${STEPS:-3000} --warmup 300 --cpu-steps 0 --no-extra-workloads --no-scale-workload $BENCH_ARGS 2>/dev/null | tail -1 | show "$cfg" )
       done; done 2>&1 | tee -a gpurun_out/${T}_abenv.txt ;;
     ranks)
       t0=$(date +%s)

@@ -48,11 +48,17 @@ typedef struct ommhip_amoeba_vdw {
     int periodic;                  /* 1: CutoffPeriodic (box given to the call), 0: NoCutoff */
     double cutoff, taper_cutoff, taper_c3, taper_c4, taper_c5;
     double* reduced;               /* device double4[num_atoms] scratch: the interaction sites */
-    /* Pair scan in the platform's slot order (optional; NULL = all atoms in atom order, O(N^2)): 256-slot tiles farther apart than the
-     * cutoff are skipped (CutoffPeriodic, rectangular boxes).  slot_of_atom / padded_atoms are the arguments of the call. */
-    const int* atom_of_slot;       /* device int[padded_atoms]: atom at each slot, -1 = padding */
-    double* tile_bounds;           /* device double4[2 * ceil(padded_atoms / 256)] work array */
-    int* excl_pos;                 /* device int[entries of excl_atoms] work array: the excluded partners as slots, rows sorted */
+    /* CutoffPeriodic: pair lists rebuilt by every call (amoeba_pairs.h; see ommhip_amoeba_multipole below) -- partners within the cutoff by
+     * atom distance, exclusions left out -- when pair_list is given; without it (and for NoCutoff) every thread scans all atoms.
+     * S = padded_atoms with atom_of_slot, num_atoms without. */
+    const int* atom_of_slot;       /* device int[padded_atoms]: atom at each slot, -1 = padding (optional: spatial order -> far tiles skipped) */
+    double* tile_bounds;           /* device double4[2 * ceil(S / 128)] work array */
+    int* excl_pos;                 /* device int[entries of excl_atoms] work array: the excluded partners as scan positions, rows sorted */
+    int* pair_list;                /* device int[pair_cap * S] work array */
+    int* pair_count;               /* device int[S] work array */
+    int pair_cap;                  /* list entries per atom; a call that needs more returns -2 */
+    int* pair_overflow;            /* device int work word */
+    int* pair_needed;              /* HOST int written with the return code -2 (or NULL) */
 } ommhip_amoeba_vdw;
 
 int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* vdw, const void* pos_d, const double box[6], const int* slot_of_atom_d, int padded_atoms,
@@ -113,14 +119,21 @@ typedef struct ommhip_amoeba_multipole {
     double* solver;                /* [24n + 16] work vectors of the conjugate-gradient solver */
     double* status;                /* HOST double[2], written by the calls: [0] epsilon reached, [1] iterations (or NULL) */
     void* pme;                     /* const ommhip_pme*: grid sizes, box, moduli, eterm, real / complex grids, twiddles of the platform's PME */
-    /* Pair scan in the platform's slot order (optional; all NULL / 0 = scan in atom order over all atoms, O(N^2)): with a spatially
-     * sorted order the real-space kernels skip the 128-slot tiles farther apart than the cutoff (rectangular boxes). */
+    /* Pair lists, rebuilt by every call (amoeba_pairs.h): per atom the partners within the cutoff, found by a scan that only tests
+     * distances; the kernels with the long pair arithmetic (fixed field, induced-dipole field, forces) walk these lists.  With the
+     * platform's slot order (optional: atom_of_slot / slot_of_atom / scan_slots, NULL / 0 = atom order) the scan works on 128-slot tiles
+     * with bounding boxes and skips the tiles farther apart than the cutoff (rectangular boxes).  S = scan_slots, or num_atoms. */
     const int* atom_of_slot;       /* device int[scan_slots]: atom at each slot, -1 = padding */
     const int* slot_of_atom;       /* device int[num_atoms] */
     int scan_slots;                /* the platform's padded atom count */
-    double* tile_bounds;           /* device double4[2 * ceil(scan_slots / 128)] work array: tile centres, then half extents */
-    int* special_pos;              /* device int[entries of special_atom] work array: the partners as slots, rows sorted */
+    double* tile_bounds;           /* device double4[2 * ceil(S / 128)] work array: tile centres, then half extents */
+    int* special_pos;              /* device int[entries of special_atom] work array: the partners as scan positions, rows sorted */
     double* special_scale_sorted;  /* device double4[entries] work array */
+    int* pair_list;                /* device int[pair_cap * S] work array */
+    int* pair_count;               /* device int[S] work array */
+    int pair_cap;                  /* list entries per atom; a call that needs more returns -2 */
+    int* pair_overflow;            /* device int work word */
+    int* pair_needed;              /* HOST int written with the return code -2: the capacity that would have been enough (or NULL) */
 } ommhip_amoeba_multipole;
 
 /* Whole evaluation: frames -> reciprocal and real-space field -> induced dipoles -> energy, forces, torques -> forces. */

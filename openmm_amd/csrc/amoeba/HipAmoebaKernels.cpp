@@ -95,10 +95,26 @@ void HipCalcAmoebaVdwForceKernel::upload(const AmoebaVdwForce& force) {
         vdw.taper_c5 = 6.0 / pow(vdw.taper_cutoff - cutoff, 5.0);
     }
     vdw.reduced = reduced.as<double>();
-    // the pair scan runs in the platform's slot order (256-slot tiles, far tiles skipped)
-    tileBounds.allocate(sizeof(double) * 4 * 2 * max(((size_t) hip.paddedAtoms + 255) / 256, (size_t) 1));
-    exclPos.allocate(sizeof(int) * max(flat.size(), (size_t) 1));
-    vdw.tile_bounds = tileBounds.as<double>(); vdw.excl_pos = exclPos.as<int>(); vdw.atom_of_slot = NULL;
+    // CutoffPeriodic: per-atom pair lists in the platform's slot order, rebuilt at every evaluation (amoeba_pairs.h)
+    if (usePBC) {
+        tileBounds.allocate(sizeof(double) * 4 * 2 * max(((size_t) hip.paddedAtoms + 127) / 128, (size_t) 1));
+        exclPos.allocate(sizeof(int) * max(flat.size(), (size_t) 1));
+        pairCount.allocate(sizeof(int) * (size_t) hip.paddedAtoms);
+        pairOverflow.allocate(sizeof(int));
+        vdw.tile_bounds = tileBounds.as<double>(); vdw.excl_pos = exclPos.as<int>(); vdw.pair_count = pairCount.as<int>(); vdw.pair_overflow = pairOverflow.as<int>();
+        vdw.pair_needed = &pairNeeded;
+        // capacity: the partners of an atom at the density of the box, with room for fluctuations; a list that does not fit grows it
+        const double volume = hip.box[0] * hip.box[2] * hip.box[5];
+        // (OPENMM_HIP_AMOEBA_PAIR_CAP: a deliberately small first capacity, for the test of the growth path)
+    allocatePairList(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP") != NULL ? atoi(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP")) : (int) min((double) numParticles, 1.5 * 4.18879 * cutoff * cutoff * cutoff * numParticles / volume + 64.0));
+    }
+}
+
+void HipCalcAmoebaVdwForceKernel::allocatePairList(int cap) {
+    HipContext& hip = *data.hip;
+    vdw.pair_cap = max(cap, 1);
+    pairList.allocate(sizeof(int) * (size_t) vdw.pair_cap * hip.paddedAtoms);
+    vdw.pair_list = pairList.as<int>();
 }
 
 double HipCalcAmoebaVdwForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy) {
@@ -115,8 +131,14 @@ double HipCalcAmoebaVdwForceKernel::execute(ContextImpl& context, bool includeFo
     }
     hip.ensureCleared();
     vdw.atom_of_slot = hip.atomOfSlot.as<int>();
-    HIP_CHECK(ommhip_amoeba_vdw_forces(&vdw, hip.pos.ptr, hip.box, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.force.as<long long>(),
-                                       hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream));
+    for (int attempt = 0; ; attempt++) {
+        const int rc = ommhip_amoeba_vdw_forces(&vdw, hip.pos.ptr, hip.box, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.force.as<long long>(),
+                                                hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream);
+        if (rc != -2) { HIP_CHECK(rc); break; }
+        // the pair lists did not fit (nothing has been added to the forces yet: the list is built before the pair kernel runs)
+        if (attempt == 3 || pairNeeded == 0x7fffffff) throw OpenMMException("AmoebaVdwForce: the pair lists of the HIP platform cannot hold this System");
+        allocatePairList((int) min((long long) numParticles, (long long) pairNeeded * 5 / 4 + 16));
+    }
     nativeEvaluations[0]++;
     // the pair energy is summed on the device (HipCalcForcesAndEnergyKernel::finishComputation); the host adds the constant
     return includeEnergy && usePBC ? dispersionCoefficient / (hip.box[0] * hip.box[2] * hip.box[5]) : 0.0;
@@ -312,13 +334,33 @@ void HipCalcAmoebaMultipoleForceKernel::upload(const AmoebaMultipoleForce& force
     mp.mutual = mutual ? 1 : 0;
     mp.max_iterations = force.getMutualInducedMaxIterations(); mp.target_epsilon = force.getMutualInducedTargetEpsilon();
     mp.phi_induced_p = mutual ? phiIndP.as<double>() : NULL; mp.solver = mutual ? solver.as<double>() : NULL; mp.status = solverStatus;
-    // the pair scan runs in the platform's slot order (tiles of 128 slots, far tiles skipped); the order itself is set per evaluation
+    // per-atom pair lists in the platform's slot order, rebuilt at every evaluation (amoeba_pairs.h); the order itself is set per evaluation
     const size_t tiles = ((size_t) hip.paddedAtoms + 127) / 128;
     tileBounds.allocate(sizeof(double) * 4 * 2 * max(tiles, (size_t) 1));
     specPos.allocate(sizeof(int) * max(atoms.size(), (size_t) 1));
     specScaleSorted.allocate(sizeof(double) * 4 * max(atoms.size(), (size_t) 1));
+    pairCount.allocate(sizeof(int) * (size_t) hip.paddedAtoms);
+    pairOverflow.allocate(sizeof(int));
     mp.tile_bounds = tileBounds.as<double>(); mp.special_pos = specPos.as<int>(); mp.special_scale_sorted = specScaleSorted.as<double>();
+    mp.pair_count = pairCount.as<int>(); mp.pair_overflow = pairOverflow.as<int>(); mp.pair_needed = &pairNeeded;
     mp.atom_of_slot = NULL; mp.slot_of_atom = NULL; mp.scan_slots = 0;
+    const double volume = hip.box[0] * hip.box[2] * hip.box[5];
+    // (OPENMM_HIP_AMOEBA_PAIR_CAP: a deliberately small first capacity, for the test of the growth path)
+    allocatePairList(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP") != NULL ? atoi(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP")) : (int) min((double) numParticles, 1.5 * 4.18879 * cutoff * cutoff * cutoff * numParticles / volume + 64.0));
+}
+
+void HipCalcAmoebaMultipoleForceKernel::allocatePairList(int cap) {
+    HipContext& hip = *data.hip;
+    mp.pair_cap = max(cap, 1);
+    pairList.allocate(sizeof(int) * (size_t) mp.pair_cap * hip.paddedAtoms);
+    mp.pair_list = pairList.as<int>();
+}
+
+bool HipCalcAmoebaMultipoleForceKernel::growPairList(int rc, int attempt) {
+    if (rc != -2) return false;
+    if (attempt == 3 || pairNeeded == 0x7fffffff) throw OpenMMException("AmoebaMultipoleForce: the pair lists of the HIP platform cannot hold this System");
+    allocatePairList((int) min((long long) numParticles, (long long) pairNeeded * 5 / 4 + 16));
+    return true;
 }
 
 void HipCalcAmoebaMultipoleForceKernel::setScanOrder() {
@@ -343,8 +385,12 @@ double HipCalcAmoebaMultipoleForceKernel::execute(ContextImpl& context, bool inc
     prepareGrid();
     hip.ensureCleared();
     setScanOrder();
-    const int rc = ommhip_amoeba_multipole_forces(&mp, hip.pos.ptr, hip.box, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.force.as<long long>(),
-                                                  hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream);
+    int rc;
+    for (int attempt = 0; ; attempt++) {
+        rc = ommhip_amoeba_multipole_forces(&mp, hip.pos.ptr, hip.box, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.force.as<long long>(),
+                                            hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream);
+        if (!growPairList(rc, attempt)) break;        // -2: the pair lists did not fit (they are built before anything is added to the forces)
+    }
     checkSolver(rc);
     nativeEvaluations[1]++;
     return 0.0;        // summed on the device (HipCalcForcesAndEnergyKernel::finishComputation)
@@ -355,7 +401,12 @@ void HipCalcAmoebaMultipoleForceKernel::induce() {
     hip.setAsCurrent();
     prepareGrid();
     setScanOrder();
-    checkSolver(ommhip_amoeba_multipole_induce(&mp, hip.pos.ptr, hip.box, hip.stream));
+    int rc;
+    for (int attempt = 0; ; attempt++) {
+        rc = ommhip_amoeba_multipole_induce(&mp, hip.pos.ptr, hip.box, hip.stream);
+        if (!growPairList(rc, attempt)) break;
+    }
+    checkSolver(rc);
 }
 
 void HipCalcAmoebaMultipoleForceKernel::checkSolver(int rc) {

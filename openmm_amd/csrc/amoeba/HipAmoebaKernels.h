@@ -27,7 +27,9 @@ private:
     bool usePBC = false;
     double cutoff = 0, dispersionCoefficient = 0, softcorePower = 0, softcoreAlpha = 0;
     ommhip_amoeba_vdw vdw;
-    DeviceBuffer parent, reduction, type, sigma, epsilon, exclStart, exclAtoms, alchemical, reduced, tileBounds, exclPos;
+    void allocatePairList(int cap);
+    int pairNeeded = 0;
+    DeviceBuffer parent, reduction, type, sigma, epsilon, exclStart, exclAtoms, alchemical, reduced, tileBounds, exclPos, pairList, pairCount, pairOverflow;
 };
 
 /** amoebaKernels.h:82-139 CalcAmoebaMultipoleForceKernel for PME with direct or mutual polarization; Reference: AmoebaReferenceKernels.cpp:170-520 +
@@ -54,6 +56,9 @@ private:
     void prepareGrid();
     void induce();
     void setScanOrder();
+    void allocatePairList(int cap);
+    bool growPairList(int rc, int attempt);
+    int pairNeeded = 0;
     void checkSolver(int rc);
     void download3(DeviceBuffer& buffer, std::vector<Vec3>& out);
     void syncHostPositions(ContextImpl& context);
@@ -66,7 +71,7 @@ private:
     ommhip_amoeba_multipole mp;
     ommhip_pme pme;
     DeviceBuffer charge, molDipole, molQuad, axis, thole, damping, polarity, specStart, specAtom, specScale;
-    DeviceBuffer labDipole, labQuad, fieldD, fieldP, indD, indP, phi, phiInd, phiIndP, solver, torque, tileBounds, specPos, specScaleSorted;
+    DeviceBuffer labDipole, labQuad, fieldD, fieldP, indD, indP, phi, phiInd, phiIndP, solver, torque, tileBounds, specPos, specScaleSorted, pairList, pairCount, pairOverflow;
     DeviceBuffer moduliX, moduliY, moduliZ, twiddleX, twiddleY, twiddleZ, eterm, gridReal, gridComplex;
 };
 

@@ -11,6 +11,7 @@
 // its parent at the end (two fixed-point atomics per component).
 #include "common.h"
 #include "../../../include/openmm_hip_amoeba.h"
+#include "amoeba_pairs.h"
 #include <cstdlib>
 
 using namespace omm;
@@ -32,67 +33,12 @@ struct VdwArgs {
     const int* slotOfAtom;
     omm_fixed* force;
     double* energyBuffer;
-    // pair scan in the platform's slot order (amoeba_multipole.hip has the same arrangement): position g holds atom order[g] (-1: padding),
-    // tiles of VDW_BLOCK positions with bounding boxes of the ATOM positions, tiles farther apart than the cutoff are skipped
-    const int* order; int numScan, skipTiles;
-    double4* tileCenter; double4* tileHalf;
-    int* exclPos;                  // the exclusion rows with partners as scan positions, ascending
+    // scan positions: position g holds atom order[g] (the platform's slot order, -1: padding) or g itself
+    const int* order; int numScan;
+    const int* pairList; const int* pairCount; int listStride;      // pair lists (amoeba_pairs.h); nullptr: the scan over all atoms
 };
 
 __device__ __forceinline__ int scan_atom(const VdwArgs& a, int g) { return g < a.numScan ? (a.order != nullptr ? a.order[g] : g) : -1; }
-
-__device__ __forceinline__ bool tiles_far(const VdwArgs& a, int ti, int tj) {
-    if (!a.skipTiles) return false;
-    const double4 ci = a.tileCenter[ti], hi = a.tileHalf[ti], cj = a.tileCenter[tj], hj = a.tileHalf[tj];
-    double dx = cj.x - ci.x, dy = cj.y - ci.y, dz = cj.z - ci.z;
-    dx -= rint(dx / a.box.ax) * a.box.ax; dy -= rint(dy / a.box.by) * a.box.by; dz -= rint(dz / a.box.cz) * a.box.cz;
-    const double gx = fmax(fabs(dx) - hi.x - hj.x, 0.0), gy = fmax(fabs(dy) - hi.y - hj.y, 0.0), gz = fmax(fabs(dz) - hi.z - hj.z, 0.0);
-    return gx * gx + gy * gy + gz * gz > a.cutoff2;
-}
-
-// exclusion rows re-keyed to scan positions and sorted (insertion sort: rows hold the bonded neighbourhood of an atom)
-__global__ void k_vdw_sort_exclusions(VdwArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.numAtoms) return;
-    const int b = a.exclStart[i], e = a.exclStart[i + 1];
-    for (int c = b; c < e; c++) {
-        const int pos = a.slotOfAtom[a.exclAtoms[c]];
-        int k = c;
-        while (k > b && a.exclPos[k - 1] > pos) { a.exclPos[k] = a.exclPos[k - 1]; k--; }
-        a.exclPos[k] = pos;
-    }
-}
-
-__global__ __launch_bounds__(VDW_BLOCK) void k_vdw_tile_bounds(VdwArgs a) {
-    __shared__ double lo[3][VDW_BLOCK], hi[3][VDW_BLOCK];
-    __shared__ int firstValid;
-    const int t = threadIdx.x, g = blockIdx.x * VDW_BLOCK + t, i = scan_atom(a, g);
-    if (t == 0) firstValid = VDW_BLOCK;
-    __syncthreads();
-    if (i >= 0) atomicMin(&firstValid, t);
-    __syncthreads();
-    if (firstValid == VDW_BLOCK) {
-        if (t == 0) { a.tileCenter[blockIdx.x] = make_double4(0, 0, 0, 0); a.tileHalf[blockIdx.x] = make_double4(-1e30, -1e30, -1e30, 0); }
-        return;
-    }
-    const double4 ref = a.pos[scan_atom(a, blockIdx.x * VDW_BLOCK + firstValid)];
-    double d[3] = {0, 0, 0};
-    if (i >= 0) {
-        const double4 p = a.pos[i];
-        d[0] = p.x - ref.x; d[1] = p.y - ref.y; d[2] = p.z - ref.z;
-        min_image_d(d[0], d[1], d[2], a.box);
-    }
-    for (int k = 0; k < 3; k++) { lo[k][t] = d[k]; hi[k][t] = d[k]; }
-    __syncthreads();
-    for (int m = VDW_BLOCK / 2; m >= 1; m >>= 1) {
-        if (t < m) for (int k = 0; k < 3; k++) { lo[k][t] = fmin(lo[k][t], lo[k][t + m]); hi[k][t] = fmax(hi[k][t], hi[k][t + m]); }
-        __syncthreads();
-    }
-    if (t == 0) {
-        a.tileCenter[blockIdx.x] = make_double4(ref.x + 0.5 * (lo[0][0] + hi[0][0]), ref.y + 0.5 * (lo[1][0] + hi[1][0]), ref.z + 0.5 * (lo[2][0] + hi[2][0]), 0);
-        a.tileHalf[blockIdx.x] = make_double4(0.5 * (hi[0][0] - lo[0][0]), 0.5 * (hi[1][0] - lo[1][0]), 0.5 * (hi[2][0] - lo[2][0]), 0);
-    }
-}
 
 // AmoebaReferenceVdwForce::setReducedPositions (AmoebaReferenceVdwForce.cpp:173-189)
 __global__ void k_vdw_reduce(VdwArgs a) {
@@ -156,13 +102,12 @@ __global__ __launch_bounds__(VDW_BLOCK) void k_vdw_pairs(VdwArgs a) {
     const double4 si = a.reduced[ii], xi = a.pos[ii];
     const int typeI = a.type[ii];
     const bool alchI = a.alchemical != nullptr && a.alchemical[ii] != 0;
-    const int* exclPartner = a.order != nullptr ? a.exclPos : a.exclAtoms;       // partners as scan positions
+    const int* exclPartner = a.exclAtoms;
     int cursor = a.exclStart[ii];
     const int exclEnd = a.exclStart[ii + 1];
     int nextExcl = cursor < exclEnd ? exclPartner[cursor] : 0x7fffffff;
     double fx = 0, fy = 0, fz = 0, energy = 0;
     for (int j0 = 0; j0 < a.numScan; j0 += VDW_BLOCK) {
-        if (tiles_far(a, blockIdx.x, j0 / VDW_BLOCK)) continue;                    // block-uniform
         const int jl = scan_atom(a, j0 + t);
         __syncthreads();
         sType[t] = -1;
@@ -217,6 +162,55 @@ __global__ __launch_bounds__(VDW_BLOCK) void k_vdw_pairs(VdwArgs a) {
     }
 }
 
+// The same pair terms over the pair lists of amoeba_pairs.h (CutoffPeriodic): thread g owns the atom at scan position g and walks its own
+// list -- partners within the cutoff by ATOM distance, exclusions left out by the builder -- so every iteration is a pair that counts.
+__global__ __launch_bounds__(VDW_BLOCK) void k_vdw_pairs_list(VdwArgs a) {
+    __shared__ double sEnergy[VDW_BLOCK / 64];
+    const int t = threadIdx.x;
+    const int g = blockIdx.x * VDW_BLOCK + t, i = scan_atom(a, g);
+    const bool active = i >= 0;
+    const int ii = active ? i : 0;
+    const double4 si = a.reduced[ii];
+    const int typeI = a.type[ii];
+    const bool alchI = a.alchemical != nullptr && a.alchemical[ii] != 0;
+    double fx = 0, fy = 0, fz = 0, energy = 0;
+    const int cnt = active ? a.pairCount[g] : 0;
+    for (int k = 0; k < cnt; k++) {
+        const int j = scan_atom(a, a.pairList[(size_t) k * a.listStride + g] & PL_POS_MASK);
+        const double4 sj = a.reduced[j];
+        double dx = si.x - sj.x, dy = si.y - sj.y, dz = si.z - sj.z;
+        min_image_d(dx, dy, dz, a.box);
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        const int typeJ = a.type[j];
+        double sigma = a.sigma[typeI * a.numTypes + typeJ], epsilon = a.epsilon[typeI * a.numTypes + typeJ], softcore = 0.0;
+        const bool alchJ = a.alchemical != nullptr && a.alchemical[j] != 0;
+        if ((a.alchemicalMethod == 1 && alchI != alchJ) || (a.alchemicalMethod == 2 && (alchI || alchJ))) { epsilon *= a.epsilonScale; softcore = a.softcore; }
+        double dEdRoverR;
+        const double e = vdw_pair(a, r, sigma, epsilon, softcore, dEdRoverR);
+        fx -= dEdRoverR * dx; fy -= dEdRoverR * dy; fz -= dEdRoverR * dz;
+        energy += 0.5 * e;
+    }
+    if (active) {
+        const int p = a.parent[i];
+        if (p == i) add_force(a.force, a.paddedAtoms, a.slotOfAtom[i], fx, fy, fz);
+        else {
+            const double red = a.reduction[i];
+            add_force(a.force, a.paddedAtoms, a.slotOfAtom[i], fx * red, fy * red, fz * red);
+            add_force(a.force, a.paddedAtoms, a.slotOfAtom[p], fx * (1.0 - red), fy * (1.0 - red), fz * (1.0 - red));
+        }
+    }
+    if (a.includeEnergy) {
+        energy = wave_sum(active ? energy : 0.0);
+        if ((t & 63) == 0) sEnergy[t >> 6] = energy;
+        __syncthreads();
+        if (t == 0) {
+            double e = 0;
+            for (int w = 0; w < VDW_BLOCK / 64; w++) e += sEnergy[w];
+            atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], e);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* v, const void* pos_d, const double box[6], const int* slot_of_atom_d, int padded_atoms,
@@ -235,16 +229,29 @@ extern "C" int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* v, const void* 
     a.force = force_d; a.energyBuffer = energy_buffer_d;
     hipStream_t st = (hipStream_t) stream;
     const int blocks = (a.numAtoms + VDW_BLOCK - 1) / VDW_BLOCK;
-    a.order = nullptr; a.numScan = a.numAtoms; a.skipTiles = 0; a.tileCenter = a.tileHalf = nullptr; a.exclPos = nullptr;
-    static const bool noTiles = getenv("OPENMM_HIP_AMOEBA_NO_TILES") != nullptr;         // A/B knob: scan all atoms in atom order
-    if (!noTiles && v->atom_of_slot != nullptr && v->tile_bounds != nullptr && v->excl_pos != nullptr && padded_atoms >= a.numAtoms) {
-        a.order = v->atom_of_slot; a.numScan = padded_atoms; a.exclPos = v->excl_pos;
-        const int tiles = (a.numScan + VDW_BLOCK - 1) / VDW_BLOCK;
-        a.tileCenter = (double4*) v->tile_bounds; a.tileHalf = a.tileCenter + tiles;
-        a.skipTiles = a.periodic && box[1] == 0.0 && box[3] == 0.0 && box[4] == 0.0 ? 1 : 0;
-        hipLaunchKernelGGL(k_vdw_sort_exclusions, dim3((a.numAtoms + 127) / 128), dim3(128), 0, st, a);
-        if (a.skipTiles) hipLaunchKernelGGL(k_vdw_tile_bounds, dim3(tiles), dim3(VDW_BLOCK), 0, st, a);
+    a.pairList = nullptr; a.pairCount = nullptr; a.listStride = 0;
+    if (a.periodic && v->pair_list != nullptr && v->pair_count != nullptr && v->pair_overflow != nullptr && v->tile_bounds != nullptr && v->excl_pos != nullptr && v->pair_cap > 0) {
+        // CutoffPeriodic: pair lists (partners by atom distance, exclusions left out), then the pair terms over the lists
+        hipLaunchKernelGGL(k_vdw_reduce, dim3(blocks), dim3(VDW_BLOCK), 0, st, a);
+        a.order = nullptr; a.numScan = a.numAtoms;
+        if (v->atom_of_slot != nullptr && padded_atoms >= a.numAtoms) { a.order = v->atom_of_slot; a.numScan = padded_atoms; }
+        PairListArgs p;
+        p.n = a.numAtoms; p.numScan = a.numScan; p.cap = v->pair_cap; p.stride = a.numScan; p.excludeListed = 1;
+        static const bool noTilesList = getenv("OPENMM_HIP_AMOEBA_NO_TILES") != nullptr;
+        p.skipTiles = !noTilesList && box[1] == 0.0 && box[3] == 0.0 && box[4] == 0.0 ? 1 : 0;
+        p.pos = a.pos; p.order = a.order; p.slotOfAtom = a.slotOfAtom; p.box = a.box; p.cutoff2 = a.cutoff2;
+        const int tiles = (a.numScan + PL_BLOCK - 1) / PL_BLOCK;
+        p.tileCenter = (double4*) v->tile_bounds; p.tileHalf = p.tileCenter + tiles;
+        p.rowStart = a.exclStart; p.rowAtom = a.exclAtoms; p.rowPos = v->excl_pos; p.rowData = nullptr; p.rowDataIn = nullptr;
+        p.list = v->pair_list; p.count = v->pair_count; p.overflow = v->pair_overflow;
+        const int rc = pl_launch(p, v->pair_needed, st);
+        if (rc != 0) return rc;
+        a.pairList = v->pair_list; a.pairCount = v->pair_count; a.listStride = a.numScan;
+        hipLaunchKernelGGL(k_vdw_pairs_list, dim3((a.numScan + VDW_BLOCK - 1) / VDW_BLOCK), dim3(VDW_BLOCK), 0, st, a);
+        return (int) hipGetLastError();
     }
+    // no lists (NoCutoff, or a caller without the work arrays): every thread scans all atoms, in atom order
+    a.order = nullptr; a.numScan = a.numAtoms;
     hipLaunchKernelGGL(k_vdw_reduce, dim3(blocks), dim3(VDW_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_vdw_pairs, dim3((a.numScan + VDW_BLOCK - 1) / VDW_BLOCK), dim3(VDW_BLOCK), 0, st, a);
     return (int) hipGetLastError();

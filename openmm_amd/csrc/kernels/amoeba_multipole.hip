@@ -30,6 +30,7 @@
 #include "common.h"
 #include "../../../include/openmm_hip_amoeba.h"
 #include "../../../include/openmm_hip_kernels.h"
+#include "amoeba_pairs.h"
 #include <cstdio>
 #include <cstdlib>
 
@@ -103,26 +104,15 @@ struct MpArgs {
     const int* slotOfAtom;
     omm_fixed* force;
     double* energyBuffer;
-    // pair scan in the platform's slot order (spatially sorted 32-atom blocks): scan position g holds atom order[g] (-1: padding);
-    // tiles of MP_BLOCK positions with bounding boxes, tiles farther apart than the cutoff are skipped.  order == nullptr: atom order, no skipping.
-    const int* order; int numScan, skipTiles;
-    double4* tileCenter; double4* tileHalf;
-    int* specPos; double4* specScaleSorted;        // the special-pair rows with partners as scan positions, ascending
+    // pair lists (amoeba_pairs.h), built once per evaluation: thread g of the pair kernels owns the atom at scan position g -- order[g], the
+    // platform's slot order (-1: padding), or g itself without an order -- and walks pairList[k * listStride + g], k < pairCount[g]
+    const int* order; int numScan;
+    const int* pairList; const int* pairCount; int listStride;
+    const double4* specScaleSorted;                // scale factors of the special pairs, rows in the order the list entries index them
 };
 
 // atom at scan position g (-1: none)
 __device__ __forceinline__ int scan_atom(const MpArgs& a, int g) { return g < a.numScan ? (a.order != nullptr ? a.order[g] : g) : -1; }
-
-// Are the tiles (MP_BLOCK scan positions each) ti and tj farther apart than the cutoff?  Rectangular boxes (skipTiles is 0 otherwise):
-// per axis the nearest-image distance of the centres minus the half extents.  Block-uniform.
-__device__ __forceinline__ bool tiles_far(const MpArgs& a, int ti, int tj) {
-    if (!a.skipTiles) return false;
-    const double4 ci = a.tileCenter[ti], hi = a.tileHalf[ti], cj = a.tileCenter[tj], hj = a.tileHalf[tj];
-    double dx = cj.x - ci.x, dy = cj.y - ci.y, dz = cj.z - ci.z;
-    dx -= rint(dx / a.box.ax) * a.box.ax; dy -= rint(dy / a.box.by) * a.box.by; dz -= rint(dz / a.box.cz) * a.box.cz;
-    const double gx = fmax(fabs(dx) - hi.x - hj.x, 0.0), gy = fmax(fabs(dy) - hi.y - hj.y, 0.0), gz = fmax(fabs(dz) - hi.z - hj.z, 0.0);
-    return gx * gx + gy * gy + gz * gz > a.cutoff2;        // an empty tile has half extents of -1e30: far from everything
-}
 
 __device__ __forceinline__ V3 load3(const double* p, int i) { return v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 __device__ __forceinline__ void store3(double* p, int i, V3 v) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; }
@@ -356,62 +346,14 @@ __device__ __forceinline__ void pair_chains(double alpha, double r2, double damp
 struct PairScale { double m, p, d; };
 
 // scale factors of the pair (i, j) from i's list of special partners (ascending; the cursor moves with j)
-// j: scan position of the partner (= its atom index without a scan order); the row is walked once, in step with the ascending j
-__device__ __forceinline__ PairScale pair_scale(const MpArgs& a, int j, int& cursor, int end, int& next) {
+// scale factors of a list entry: tag = 1 + index of the partner in this atom's (sorted) row of special pairs, 0 = an ordinary pair
+__device__ __forceinline__ PairScale pair_scale(const MpArgs& a, int rowBegin, int entry) {
     PairScale s = {1.0, 1.0, 1.0};
-    const int* partner = a.order != nullptr ? a.specPos : a.specAtom;
-    while (next < j) { cursor++; next = cursor < end ? partner[cursor] : 0x7fffffff; }
-    if (next == j) { const double4 v = (a.order != nullptr ? a.specScaleSorted : a.specScale)[cursor]; s.m = v.x; s.p = v.y; s.d = v.z; }
+    const int tag = (entry >> 24) & 0x7f;
+    if (tag != 0) { const double4 v = a.specScaleSorted[rowBegin + tag - 1]; s.m = v.x; s.p = v.y; s.d = v.z; }
     return s;
 }
-__device__ __forceinline__ int first_partner(const MpArgs& a, int cursor, int end) { return cursor < end ? (a.order != nullptr ? a.specPos : a.specAtom)[cursor] : 0x7fffffff; }
 
-// Scan order only: the special-pair row of every atom re-keyed to scan positions and sorted (rows are short: covalent neighbours and the
-// polarization group), and the bounding boxes of the tiles.
-__global__ void k_mp_sort_special(MpArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    const int b = a.specStart[i], e = a.specStart[i + 1];
-    for (int c = b; c < e; c++) {
-        const int pos = a.slotOfAtom[a.specAtom[c]];
-        const double4 v = a.specScale[c];
-        int k = c;
-        while (k > b && a.specPos[k - 1] > pos) { a.specPos[k] = a.specPos[k - 1]; a.specScaleSorted[k] = a.specScaleSorted[k - 1]; k--; }
-        a.specPos[k] = pos; a.specScaleSorted[k] = v;
-    }
-}
-__global__ __launch_bounds__(MP_BLOCK) void k_mp_tile_bounds(MpArgs a) {
-    __shared__ double lo[3][MP_BLOCK], hi[3][MP_BLOCK];
-    __shared__ int firstValid;
-    const int t = threadIdx.x, g = blockIdx.x * MP_BLOCK + t, i = scan_atom(a, g);
-    if (t == 0) firstValid = MP_BLOCK;
-    __syncthreads();
-    if (i >= 0) atomicMin(&firstValid, t);
-    __syncthreads();
-    if (firstValid == MP_BLOCK) {
-        if (t == 0) { a.tileCenter[blockIdx.x] = make_double4(0, 0, 0, 0); a.tileHalf[blockIdx.x] = make_double4(-1e30, -1e30, -1e30, 0); }
-        return;
-    }
-    const double4 ref = a.pos[scan_atom(a, blockIdx.x * MP_BLOCK + firstValid)];
-    double d[3] = {0, 0, 0};
-    if (i >= 0) {
-        const double4 p = a.pos[i];
-        d[0] = p.x - ref.x; d[1] = p.y - ref.y; d[2] = p.z - ref.z;
-        min_image_d(d[0], d[1], d[2], a.box);
-    }
-    for (int k = 0; k < 3; k++) { lo[k][t] = d[k]; hi[k][t] = d[k]; }
-    __syncthreads();
-    for (int m = MP_BLOCK / 2; m >= 1; m >>= 1) {
-        if (t < m) for (int k = 0; k < 3; k++) { lo[k][t] = fmin(lo[k][t], lo[k][t + m]); hi[k][t] = fmax(hi[k][t], hi[k][t + m]); }
-        __syncthreads();
-    }
-    if (t == 0) {
-        a.tileCenter[blockIdx.x] = make_double4(ref.x + 0.5 * (lo[0][0] + hi[0][0]), ref.y + 0.5 * (lo[1][0] + hi[1][0]), ref.z + 0.5 * (lo[2][0] + hi[2][0]), 0);
-        a.tileHalf[blockIdx.x] = make_double4(0.5 * (hi[0][0] - lo[0][0]), 0.5 * (hi[1][0] - lo[1][0]), 0.5 * (hi[2][0] - lo[2][0]), 0);
-    }
-}
-
-struct JSite { double x, y, z, q; V3 mu; Sym Q; double thole, damp; V3 ud, up; int ok; };
 
 // ------------------------------------------------------------------------------------------------
 // Field of the permanent multipoles at every atom (chains d and p, reciprocal part, self term) and the induced dipoles of direct
@@ -419,38 +361,22 @@ struct JSite { double x, y, z, q; V3 mu; Sym Q; double thole, damp; V3 ud, up; i
 // (:6008-6019) + initializeInducedDipoles (:6021-6026).  Fields in units of e / nm^2 (without the Coulomb constant), as there.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(MP_BLOCK) void k_mp_field(MpArgs a) {
-    __shared__ JSite sj[MP_BLOCK];
     const int t = threadIdx.x, g = blockIdx.x * MP_BLOCK + t, i = scan_atom(a, g);
     const bool active = i >= 0;
     const int ii = active ? i : 0;
     const V3 xi = position(a, ii);
     const double tholeI = a.thole[ii], dampI = a.damping[ii];
-    int cursor = a.specStart[ii];
-    const int specEnd = a.specStart[ii + 1];
-    int next = first_partner(a, cursor, specEnd);
+    const int rowBegin = a.specStart[ii];
     V3 ed = v3(0, 0, 0), ep = v3(0, 0, 0);
-    for (int j0 = 0; j0 < a.numScan; j0 += MP_BLOCK) {
-        if (tiles_far(a, blockIdx.x, j0 / MP_BLOCK)) continue;
-        __syncthreads();
-        {
-            const int j = scan_atom(a, j0 + t);
-            sj[t].ok = j >= 0;
-            if (j >= 0) {
-                const V3 x = position(a, j);
-                JSite s;
-                s.x = x.x; s.y = x.y; s.z = x.z; s.q = a.charge[j]; s.mu = load3(a.labDipole, j); s.Q = load6(a.labQuad, j); s.thole = a.thole[j]; s.damp = a.damping[j];
-                s.ud = s.up = v3(0, 0, 0); s.ok = 1;
-                sj[t] = s;
-            }
-        }
-        __syncthreads();
-        if (!active) continue;
-        const int nj = min(MP_BLOCK, a.numScan - j0);
-        for (int k = 0; k < nj; k++) {
-            const int j = j0 + k;
-            if (j == g || !sj[k].ok) continue;
-            const PairScale sc = pair_scale(a, j, cursor, specEnd, next);
-            const JSite& s = sj[k];
+    const int cnt = active ? a.pairCount[g] : 0;
+    {
+        for (int k = 0; k < cnt; k++) {
+            const int entry = a.pairList[(size_t) k * a.listStride + g];
+            const int j = scan_atom(a, entry & PL_POS_MASK);
+            const PairScale sc = pair_scale(a, rowBegin, entry);
+            struct { double x, y, z, q; V3 mu; Sym Q; double thole, damp; } s;
+            { const V3 x = position(a, j); s.x = x.x; s.y = x.y; s.z = x.z; }
+            s.q = a.charge[j]; s.mu = load3(a.labDipole, j); s.Q = load6(a.labQuad, j); s.thole = a.thole[j]; s.damp = a.damping[j];
             double dx = s.x - xi.x, dy = s.y - xi.y, dz = s.z - xi.z;
             min_image_d(dx, dy, dz, a.box);
             const double r2 = dx * dx + dy * dy + dz * dz;
@@ -499,7 +425,6 @@ __device__ __forceinline__ void in_potential(double q, V3 mu, const Sym& Q, cons
 }
 
 __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
-    __shared__ JSite sj[MP_BLOCK];
     __shared__ double sEnergy[MP_BLOCK / 64];
     const int t = threadIdx.x, g = blockIdx.x * MP_BLOCK + t, i = scan_atom(a, g);
     const bool active = i >= 0;
@@ -511,33 +436,19 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
     const Sym zeroQ = {0, 0, 0, 0, 0, 0};
     Site halfUdI = {0.0, 0.5 * udI, zeroQ}, halfUpI = {0.0, 0.5 * upI, zeroQ};
     const double tholeI = a.thole[ii], dampI = a.damping[ii];
-    int cursor = a.specStart[ii];
-    const int specEnd = a.specStart[ii + 1];
-    int next = first_partner(a, cursor, specEnd);
+    const int rowBegin = a.specStart[ii];
     V3 force = v3(0, 0, 0), torque = v3(0, 0, 0);
     double energy = 0.0;
-    for (int j0 = 0; j0 < a.numScan; j0 += MP_BLOCK) {
-        if (tiles_far(a, blockIdx.x, j0 / MP_BLOCK)) continue;
-        __syncthreads();
-        {
-            const int j = scan_atom(a, j0 + t);
-            sj[t].ok = j >= 0;
-            if (j >= 0) {
-                const V3 x = position(a, j);
-                JSite s;
-                s.x = x.x; s.y = x.y; s.z = x.z; s.q = a.charge[j]; s.mu = load3(a.labDipole, j); s.Q = load6(a.labQuad, j); s.thole = a.thole[j]; s.damp = a.damping[j];
-                s.ud = load3(a.indD, j); s.up = load3(a.indP, j); s.ok = 1;
-                sj[t] = s;
-            }
-        }
-        __syncthreads();
-        if (!active) continue;
-        const int nj = min(MP_BLOCK, a.numScan - j0);
-        for (int k = 0; k < nj; k++) {
-            const int j = j0 + k;
-            if (j == g || !sj[k].ok) continue;
-            const PairScale sc = pair_scale(a, j, cursor, specEnd, next);
-            const JSite& s = sj[k];
+    const int cnt = active ? a.pairCount[g] : 0;
+    {
+        for (int k = 0; k < cnt; k++) {
+            const int entry = a.pairList[(size_t) k * a.listStride + g];
+            const int j = scan_atom(a, entry & PL_POS_MASK);
+            const PairScale sc = pair_scale(a, rowBegin, entry);
+            struct { double x, y, z, q; V3 mu; Sym Q; double thole, damp; V3 ud, up; } s;
+            { const V3 x = position(a, j); s.x = x.x; s.y = x.y; s.z = x.z; }
+            s.q = a.charge[j]; s.mu = load3(a.labDipole, j); s.Q = load6(a.labQuad, j); s.thole = a.thole[j]; s.damp = a.damping[j];
+            s.ud = load3(a.indD, j); s.up = load3(a.indP, j);
             double dx = s.x - xi.x, dy = s.y - xi.y, dz = s.z - xi.z;
             min_image_d(dx, dy, dz, a.box);
             const double r2 = dx * dx + dy * dy + dz * dz;
@@ -625,36 +536,22 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
 // Mutual polarization: field of two sets of dipoles (vD, vP) at every atom -- real space through the Thole-damped chain, the
 // reciprocal part from their two potentials, the self field.  calculateInducedDipoleFields (:6059-6152).
 // ------------------------------------------------------------------------------------------------
-struct JDipole { double x, y, z, thole, damp; V3 vd, vp; int ok; };
 
 __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const double* __restrict__ vD, const double* __restrict__ vP, const double* __restrict__ phiD,
                                                               const double* __restrict__ phiP, double* __restrict__ outD, double* __restrict__ outP) {
-    __shared__ JDipole sj[MP_BLOCK];
     const int t = threadIdx.x, g = blockIdx.x * MP_BLOCK + t, i = scan_atom(a, g);
     const bool active = i >= 0;
     const int ii = active ? i : 0;
     const V3 xi = position(a, ii);
     const double tholeI = a.thole[ii], dampI = a.damping[ii];
     V3 ed = v3(0, 0, 0), ep = v3(0, 0, 0);
-    for (int j0 = 0; j0 < a.numScan; j0 += MP_BLOCK) {
-        if (tiles_far(a, blockIdx.x, j0 / MP_BLOCK)) continue;
-        __syncthreads();
-        {
-            const int j = scan_atom(a, j0 + t);
-            sj[t].ok = j >= 0;
-            if (j >= 0) {
-                const V3 x = position(a, j);
-                JDipole s;
-                s.x = x.x; s.y = x.y; s.z = x.z; s.thole = a.thole[j]; s.damp = a.damping[j]; s.vd = load3(vD, j); s.vp = load3(vP, j); s.ok = 1;
-                sj[t] = s;
-            }
-        }
-        __syncthreads();
-        if (!active) continue;
-        const int nj = min(MP_BLOCK, a.numScan - j0);
-        for (int k = 0; k < nj; k++) {
-            if (j0 + k == g || !sj[k].ok) continue;
-            const JDipole& s = sj[k];
+    const int cnt = active ? a.pairCount[g] : 0;
+    {
+        for (int k = 0; k < cnt; k++) {
+            const int j = scan_atom(a, a.pairList[(size_t) k * a.listStride + g] & PL_POS_MASK);
+            struct { double x, y, z, thole, damp; V3 vd, vp; } s;
+            { const V3 x = position(a, j); s.x = x.x; s.y = x.y; s.z = x.z; }
+            s.thole = a.thole[j]; s.damp = a.damping[j]; s.vd = load3(vD, j); s.vp = load3(vP, j);
             double dx = s.x - xi.x, dy = s.y - xi.y, dz = s.z - xi.z;
             min_image_d(dx, dy, dz, a.box);
             const double r2 = dx * dx + dy * dy + dz * dz;
@@ -797,33 +694,38 @@ bool make_args(const ommhip_amoeba_multipole* mp, const void* pos_d, const doubl
         for (int c = 0; c < 3; c++) a.a[k][c] = n[k] * R[c][k];
     a.grid = (float*) pme->grid_real;
     a.slotOfAtom = nullptr; a.force = nullptr; a.energyBuffer = nullptr;
-    // the pair scan: in slot order with far tiles skipped when the caller provides the order and the work arrays
-    a.order = nullptr; a.numScan = a.n; a.skipTiles = 0; a.tileCenter = a.tileHalf = nullptr; a.specPos = nullptr; a.specScaleSorted = nullptr;
-    static const bool noTiles = getenv("OPENMM_HIP_AMOEBA_NO_TILES") != nullptr;         // A/B knob: the O(N^2) scan of the first version
-    if (!noTiles && mp->atom_of_slot != nullptr && mp->slot_of_atom != nullptr && mp->scan_slots >= a.n && mp->tile_bounds != nullptr && mp->special_pos != nullptr && mp->special_scale_sorted != nullptr) {
-        a.order = mp->atom_of_slot; a.slotOfAtom = mp->slot_of_atom; a.numScan = mp->scan_slots;
-        const int tiles = (a.numScan + MP_BLOCK - 1) / MP_BLOCK;
-        a.tileCenter = (double4*) mp->tile_bounds; a.tileHalf = a.tileCenter + tiles;
-        a.specPos = mp->special_pos; a.specScaleSorted = (double4*) mp->special_scale_sorted;
-        a.skipTiles = box[1] == 0.0 && box[3] == 0.0 && box[4] == 0.0 ? 1 : 0;
-        if (getenv("OPENMM_HIP_AMOEBA_DEBUG") != nullptr) fprintf(stderr, "amoeba scan: %d slots, %d tiles, skip %d\n", a.numScan, tiles, a.skipTiles);
-    }
+    // pair lists: scan positions = the platform's slots when the caller provides the order, atoms otherwise
+    if (mp->pair_list == nullptr || mp->pair_count == nullptr || mp->pair_overflow == nullptr || mp->special_pos == nullptr || mp->special_scale_sorted == nullptr || mp->tile_bounds == nullptr || mp->pair_cap < 1) return false;
+    a.order = nullptr; a.numScan = a.n;
+    if (mp->atom_of_slot != nullptr && mp->slot_of_atom != nullptr && mp->scan_slots >= a.n) { a.order = mp->atom_of_slot; a.slotOfAtom = mp->slot_of_atom; a.numScan = mp->scan_slots; }
+    a.pairList = mp->pair_list; a.pairCount = mp->pair_count; a.listStride = a.numScan;
+    a.specScaleSorted = (const double4*) mp->special_scale_sorted;
     return true;
 }
 
-// number of workgroups of the pair-scan kernels (one thread per scan position)
+// number of workgroups of the pair kernels (one thread per scan position)
 int scan_blocks(const MpArgs& a) { return (a.numScan + MP_BLOCK - 1) / MP_BLOCK; }
 
-// scan order: special-pair rows re-keyed to scan positions, tile bounding boxes (once per evaluation)
-void prepare_scan(const MpArgs& a, hipStream_t st) {
-    if (a.order == nullptr) return;
-    hipLaunchKernelGGL(k_mp_sort_special, dim3((a.n + 127) / 128), dim3(128), 0, st, a);
-    if (a.skipTiles) hipLaunchKernelGGL(k_mp_tile_bounds, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
+// the pair lists of this evaluation (amoeba_pairs.h); -2: the lists did not fit into pair_cap entries per atom (*pair_needed says how many would)
+int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st) {
+    PairListArgs p;
+    p.n = a.n; p.numScan = a.numScan; p.cap = mp->pair_cap; p.stride = a.numScan; p.excludeListed = 0;
+    static const bool noTiles = getenv("OPENMM_HIP_AMOEBA_NO_TILES") != nullptr;         // A/B knob: the builder looks at every tile
+    p.skipTiles = !noTiles && box[1] == 0.0 && box[3] == 0.0 && box[4] == 0.0 ? 1 : 0;
+    p.pos = a.pos; p.order = a.order; p.slotOfAtom = a.slotOfAtom; p.box = a.box; p.cutoff2 = a.cutoff2;
+    const int tiles = (a.numScan + PL_BLOCK - 1) / PL_BLOCK;
+    p.tileCenter = (double4*) mp->tile_bounds; p.tileHalf = p.tileCenter + tiles;
+    p.rowStart = a.specStart; p.rowAtom = a.specAtom; p.rowPos = mp->special_pos;
+    p.rowData = (double4*) mp->special_scale_sorted; p.rowDataIn = a.specScale;
+    p.list = mp->pair_list; p.count = mp->pair_count; p.overflow = mp->pair_overflow;
+    return pl_launch(p, mp->pair_needed, st);
 }
 
 // frames, reciprocal potential of the permanent multipoles, fields and induced dipoles
-void launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t st) {
+int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st) {
     const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
+    const int rc = build_pair_lists(mp, a, box, st);
+    if (rc != 0) return rc;
     const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
     const size_t gridBytes = sizeof(float) * (size_t) a.nx * a.ny * a.nz;
     hipLaunchKernelGGL(k_mp_frames, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
@@ -831,8 +733,8 @@ void launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream
     hipLaunchKernelGGL(k_mp_spread<false>, dim3(blocks), dim3(MP_BLOCK), 0, st, a, (const double*) nullptr, 0.0, (const double*) nullptr, 0.0);
     ommhip_pme_convolve(pme, st);
     hipLaunchKernelGGL(k_mp_potential, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.phi);
-    prepare_scan(a, st);
     hipLaunchKernelGGL(k_mp_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
+    return 0;
 }
 
 // potential (and derivatives) of one set of dipoles at the atoms
@@ -896,7 +798,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t
 extern "C" int ommhip_amoeba_multipole_induce(const ommhip_amoeba_multipole* mp, const void* pos_d, const double box[6], void* stream) {
     MpArgs a;
     if (!make_args(mp, pos_d, box, a)) return 1;
-    launch_induce(mp, a, (hipStream_t) stream);
+    { const int rc = launch_induce(mp, a, box, (hipStream_t) stream); if (rc != 0) return rc; }
     if (a.mutual) { const int rc = solve_mutual(mp, a, (hipStream_t) stream); if (rc != 0) return rc; }
     return (int) hipGetLastError();
 }
@@ -910,7 +812,7 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
     hipStream_t st = (hipStream_t) stream;
     const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
     const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
-    launch_induce(mp, a, st);
+    { const int rc = launch_induce(mp, a, box, st); if (rc != 0) return rc; }
     if (a.mutual) { const int rc = solve_mutual(mp, a, st); if (rc != 0) return rc; }      // -1: not converged
     else {
         // reciprocal potential of the induced dipoles (mu_d + mu_p) / 2

@@ -1,0 +1,169 @@
+// Per-atom pair lists of the AMOEBA kernels (amoeba.hip: vdW, amoeba_multipole.hip: multipoles), rebuilt at every evaluation.
+//
+// The AMOEBA pair terms are long (a multipole pair is three derivative chains with erfc / exp and ~1 000 double-precision operations), so
+// what matters is that a wavefront only ever executes them for pairs inside the cutoff.  A scan "one thread per atom i, every thread
+// of the wave looks at the same candidate j" -- the first version of these kernels -- runs the pair arithmetic whenever ANY of its 64
+// lanes has j inside the cutoff: with a spatially sorted order that is nearly every candidate of the neighbouring tiles, at 2-4 % of
+// the lanes.  Here the scan only TESTS distances (cheap) and writes, per atom, the list of its partners; the physics kernels then walk
+// their own lists, lane by lane, each iteration a pair inside the cutoff on (nearly) every lane.  The geometry is fixed within an
+// evaluation, so the list serves every kernel of the evaluation -- the induced-dipole field is evaluated ~10 times per step.
+//
+// Scan order: position g holds atom order[g] (the platform's slot order: Hilbert-sorted 32-atom blocks; -1 = padding), or g itself
+// without an order.  Tiles of PL_BLOCK positions carry bounding boxes; the builder skips the tiles farther from its own than the cutoff
+// (rectangular boxes).  An entry is  j's scan position | (1 + index of j in i's row of listed partners) << 24 :  the multipole kernels
+// find the scale factors of a covalently related pair through that index, the vdW kernel leaves listed partners (exclusions) out.
+// Layout: entry k of position g at list[k * stride + g] (coalesced across the lanes of a wave).
+#ifndef OMM_AMOEBA_PAIRS_H_
+#define OMM_AMOEBA_PAIRS_H_
+
+#include "common.h"
+
+namespace omm {
+
+#define PL_BLOCK 128
+#define PL_POS_MASK 0xFFFFFF
+#define PL_MAX_ROW 126            // listed partners per atom that an entry can index
+
+struct PairListArgs {
+    int n, numScan, skipTiles, cap, stride, excludeListed;
+    const double4* pos; const int* order; const int* slotOfAtom;
+    BoxD box; double cutoff2;
+    double4* tileCenter; double4* tileHalf;
+    const int* rowStart; const int* rowAtom;       // listed partners per atom (CSR by atom, ascending atom index)
+    int* rowPos;                                   // work array: the same rows as scan positions, ascending
+    double4* rowData; const double4* rowDataIn;    // optional payload carried along when the rows are re-sorted (multipole scale factors)
+    int* list; int* count; int* overflow;
+};
+
+__device__ __forceinline__ int pl_scan_atom(const PairListArgs& a, int g) { return g < a.numScan ? (a.order != nullptr ? a.order[g] : g) : -1; }
+
+namespace {      // kernels with internal linkage: the header is included by two translation units
+
+// rows of listed partners re-keyed to scan positions and sorted (insertion sort: rows hold the bonded neighbourhood of an atom)
+__global__ void pl_sort_rows(PairListArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int b = a.rowStart[i], e = a.rowStart[i + 1];
+    for (int c = b; c < e; c++) {
+        const int partner = a.rowAtom[c];
+        const int pos = a.order != nullptr ? a.slotOfAtom[partner] : partner;
+        double4 v = make_double4(0, 0, 0, 0);
+        if (a.rowData != nullptr) v = a.rowDataIn[c];
+        int k = c;
+        while (k > b && a.rowPos[k - 1] > pos) { a.rowPos[k] = a.rowPos[k - 1]; if (a.rowData != nullptr) a.rowData[k] = a.rowData[k - 1]; k--; }
+        a.rowPos[k] = pos;
+        if (a.rowData != nullptr) a.rowData[k] = v;
+    }
+}
+
+// bounding boxes of the tiles (nearest images relative to the tile's first atom; a tile without atoms gets half extents of -1e30)
+__global__ __launch_bounds__(PL_BLOCK) void pl_tile_bounds(PairListArgs a) {
+    __shared__ double lo[3][PL_BLOCK], hi[3][PL_BLOCK];
+    __shared__ int firstValid;
+    const int t = threadIdx.x, g = blockIdx.x * PL_BLOCK + t, i = pl_scan_atom(a, g);
+    if (t == 0) firstValid = PL_BLOCK;
+    __syncthreads();
+    if (i >= 0) atomicMin(&firstValid, t);
+    __syncthreads();
+    if (firstValid == PL_BLOCK) {
+        if (t == 0) { a.tileCenter[blockIdx.x] = make_double4(0, 0, 0, 0); a.tileHalf[blockIdx.x] = make_double4(-1e30, -1e30, -1e30, 0); }
+        return;
+    }
+    const double4 ref = a.pos[pl_scan_atom(a, blockIdx.x * PL_BLOCK + firstValid)];
+    double d[3] = {0, 0, 0};
+    if (i >= 0) {
+        const double4 p = a.pos[i];
+        d[0] = p.x - ref.x; d[1] = p.y - ref.y; d[2] = p.z - ref.z;
+        min_image_d(d[0], d[1], d[2], a.box);
+    }
+    for (int k = 0; k < 3; k++) { lo[k][t] = d[k]; hi[k][t] = d[k]; }
+    __syncthreads();
+    for (int m = PL_BLOCK / 2; m >= 1; m >>= 1) {
+        if (t < m) for (int k = 0; k < 3; k++) { lo[k][t] = fmin(lo[k][t], lo[k][t + m]); hi[k][t] = fmax(hi[k][t], hi[k][t + m]); }
+        __syncthreads();
+    }
+    if (t == 0) {
+        a.tileCenter[blockIdx.x] = make_double4(ref.x + 0.5 * (lo[0][0] + hi[0][0]), ref.y + 0.5 * (lo[1][0] + hi[1][0]), ref.z + 0.5 * (lo[2][0] + hi[2][0]), 0);
+        a.tileHalf[blockIdx.x] = make_double4(0.5 * (hi[0][0] - lo[0][0]), 0.5 * (hi[1][0] - lo[1][0]), 0.5 * (hi[2][0] - lo[2][0]), 0);
+    }
+}
+
+__device__ __forceinline__ bool pl_tiles_far(const PairListArgs& a, int ti, int tj) {
+    if (!a.skipTiles) return false;
+    const double4 ci = a.tileCenter[ti], hi = a.tileHalf[ti], cj = a.tileCenter[tj], hj = a.tileHalf[tj];
+    double dx = cj.x - ci.x, dy = cj.y - ci.y, dz = cj.z - ci.z;
+    dx -= rint(dx / a.box.ax) * a.box.ax; dy -= rint(dy / a.box.by) * a.box.by; dz -= rint(dz / a.box.cz) * a.box.cz;
+    const double gx = fmax(fabs(dx) - hi.x - hj.x, 0.0), gy = fmax(fabs(dy) - hi.y - hj.y, 0.0), gz = fmax(fabs(dz) - hi.z - hj.z, 0.0);
+    return gx * gx + gy * gy + gz * gz > a.cutoff2;
+}
+
+// One thread per scan position: partners within the cutoff (cutoff2 < 0: all atoms), in ascending scan position.
+__global__ __launch_bounds__(PL_BLOCK) void pl_build(PairListArgs a) {
+    __shared__ double4 sj[PL_BLOCK];               // .w < 0: no atom at this position
+    const int t = threadIdx.x, g = blockIdx.x * PL_BLOCK + t, i = pl_scan_atom(a, g);
+    const bool active = i >= 0;
+    const int ii = active ? i : 0;
+    const double4 xi = a.pos[ii];
+    const int rowBegin = a.rowStart != nullptr ? a.rowStart[ii] : 0, rowEnd = a.rowStart != nullptr ? a.rowStart[ii + 1] : 0;
+    int cursor = rowBegin;
+    int next = cursor < rowEnd ? a.rowPos[cursor] : 0x7fffffff;
+    int cnt = 0;
+    bool over = false;
+    for (int j0 = 0; j0 < a.numScan; j0 += PL_BLOCK) {
+        if (pl_tiles_far(a, blockIdx.x, j0 / PL_BLOCK)) continue;        // block-uniform
+        __syncthreads();
+        {
+            const int j = pl_scan_atom(a, j0 + t);
+            double4 p = make_double4(0, 0, 0, -1.0);
+            if (j >= 0) { p = a.pos[j]; p.w = 1.0; }
+            sj[t] = p;
+        }
+        __syncthreads();
+        if (!active) continue;
+        const int nj = min(PL_BLOCK, a.numScan - j0);
+        for (int k = 0; k < nj; k++) {
+            const int j = j0 + k;
+            const double4 p = sj[k];
+            if (j == g || p.w < 0.0) continue;
+            if (a.cutoff2 >= 0.0) {
+                double dx = p.x - xi.x, dy = p.y - xi.y, dz = p.z - xi.z;
+                min_image_d(dx, dy, dz, a.box);
+                if (dx * dx + dy * dy + dz * dz > a.cutoff2) continue;
+            }
+            while (next < j) { cursor++; next = cursor < rowEnd ? a.rowPos[cursor] : 0x7fffffff; }
+            int tag = 0;
+            if (next == j) {
+                if (a.excludeListed) continue;
+                tag = cursor - rowBegin + 1;
+                if (tag > PL_MAX_ROW) over = true;
+            }
+            if (cnt < a.cap) a.list[(size_t) cnt * a.stride + g] = j | (tag << 24);
+            else over = true;
+            cnt++;
+        }
+    }
+    if (g < a.numScan) a.count[g] = min(cnt, a.cap);
+    if (over) atomicMax(a.overflow, cnt > a.cap ? cnt : 0x7fffffff);          // the capacity that would have been enough (or: a row too long to index)
+}
+
+}  // namespace
+
+// Host side: re-key the rows, bound the tiles, build the list.  Returns 0, a hipError_t, or -2 when the list did not fit
+// (*needed = the longest list, or 0x7fffffff when a row of listed partners is too long to index).  `overflowHost` = pinned or plain host int.
+static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st) {
+    if (a.numScan > PL_POS_MASK) return 1;
+    hipMemsetAsync(a.overflow, 0, sizeof(int), st);
+    if (a.rowStart != nullptr) hipLaunchKernelGGL(pl_sort_rows, dim3((a.n + 127) / 128), dim3(128), 0, st, a);
+    const int tiles = (a.numScan + PL_BLOCK - 1) / PL_BLOCK;
+    if (a.skipTiles) hipLaunchKernelGGL(pl_tile_bounds, dim3(tiles), dim3(PL_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(pl_build, dim3(tiles), dim3(PL_BLOCK), 0, st, a);
+    int over = 0;
+    hipError_t e = hipMemcpyAsync(&over, a.overflow, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return (int) e;
+    if (over != 0) { if (needed != nullptr) *needed = over; return -2; }
+    return 0;
+}
+
+}  // namespace omm
+#endif

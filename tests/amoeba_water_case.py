@@ -1,6 +1,6 @@
 """AMOEBA water box through the Python harness (openmm_amd.testsystems.AmoebaWaterWorkload: AmoebaMultipoleForce PME + AmoebaVdwForce with
 the amoeba2009 water parameters): the native kernels of libOpenMMAmoebaHIP.so -- pair scan in the platform's slot order, tiles farther
-apart than the cutoff skipped -- against (a) the AMOEBA plugin's own Reference kernel for the multipole force
+apart than the cutoff skipped while the per-atom pair lists are built -- against (a) the AMOEBA plugin's own Reference kernel for the multipole force
 (OPENMM_HIP_REFERENCE_AMOEBA_MULTIPOLE=1 hands the force to it) and (b) the same native kernels scanning every tile in atom order
 (OPENMM_HIP_AMOEBA_NO_TILES=1, the first version, itself checked against the Reference by the reference's test bodies).  Shared by the
 CPU-emulator test and the GPU test; every variant runs in a process of its own (the knobs are read once per process)."""
@@ -31,7 +31,8 @@ def run_amoeba_water_case(tmp_path, emulated, n_side, grid, mutual, vdw_cutoff=0
     script = tmp_path / "amoeba_water_child.py"
     script.write_text(CHILD % (ROOT, emulated, n_side, "H.Mutual" if mutual else "H.Direct", vdw_cutoff, grid))
     res = {}
-    for name, env in (("tiles", {}), ("reference", {"OPENMM_HIP_REFERENCE_AMOEBA_MULTIPOLE": "1"}), ("full_scan", {"OPENMM_HIP_AMOEBA_NO_TILES": "1"})):
+    # full_scan: the list builder looks at every tile, and starts from lists of 8 entries per atom (two rounds of growing them)
+    for name, env in (("tiles", {}), ("reference", {"OPENMM_HIP_REFERENCE_AMOEBA_MULTIPOLE": "1"}), ("full_scan", {"OPENMM_HIP_AMOEBA_NO_TILES": "1", "OPENMM_HIP_AMOEBA_PAIR_CAP": "8"})):
         path = str(tmp_path / ("amoeba_%s.npy" % name))
         out = subprocess.run([sys.executable, str(script), path], capture_output=True, text=True, timeout=1500, env=dict(os.environ, **env))
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]

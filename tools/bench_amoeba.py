@@ -1,0 +1,31 @@
+"""Times the AMOEBA water workload of bench.py's `extra_workloads.amoeba_water` on its own (GPU box):
+    python tools/bench_amoeba.py [--n-side N | --tile] [--steps K] [--direct] [--grid G]
+prints one JSON line (ms per step, ns/day at 1 fs).  OPENMM_HIP_AMOEBA_NO_TILES=1 gives the scan over all atoms for an A/B."""
+import argparse, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from openmm_amd import harness as H, testsystems as T
+
+p = argparse.ArgumentParser()
+p.add_argument("--n-side", type=int, default=0)
+p.add_argument("--steps", type=int, default=10)
+p.add_argument("--direct", action="store_true")
+p.add_argument("--grid", type=int, default=80)
+a = p.parse_args()
+H.load_amoeba_plugins()
+kw = dict(cutoff=0.7, vdw_cutoff=0.9, polarization=H.Direct if a.direct else H.Mutual, epsilon=1e-5, ewald_tol=7.5e-4, grid=(a.grid,) * 3, a_ewald=float(np.sqrt(-np.log(2 * 7.5e-4)) / 0.7))
+w = T.amoeba_water_box(a.n_side, seed=3, **kw) if a.n_side else T.amoeba_water_tile(**kw)
+s, mp, vdw = w.build()
+integ = H.Integrator(H.VERLET, 0.001)
+ctx = H.Context(s, integ, "HIP")
+ctx.setPositions(w.positions)
+ctx.setVelocitiesToTemperature(300.0, 5)
+integ.step(2)
+e0 = ctx.getState(getEnergy=True).potentialEnergy
+t0 = time.perf_counter()
+integ.step(a.steps)
+e1 = ctx.getState(getEnergy=True).potentialEnergy
+dt = time.perf_counter() - t0
+print(json.dumps({"workload": w.name, "atoms": w.num_atoms, "polarization": "direct" if a.direct else "mutual", "grid": a.grid, "steps": a.steps,
+                  "ms_per_step": round(1e3 * dt / a.steps, 3), "ns_per_day_1fs": round(1e-6 * a.steps / dt * 86400, 4), "E0": e0, "E1": e1,
+                  "native_evaluations": H.amoeba_native_evaluations(), "no_tiles": os.environ.get("OPENMM_HIP_AMOEBA_NO_TILES") is not None}))

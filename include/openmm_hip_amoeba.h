@@ -55,8 +55,8 @@ typedef struct ommhip_amoeba_vdw {
     double* tile_bounds;           /* device double4[2 * ceil(S / 128)] work array */
     int* excl_pos;                 /* device int[entries of excl_atoms] work array: the excluded partners as scan positions, rows sorted */
     int* pair_list;                /* device int[pair_cap * S] work array */
-    int* pair_count;               /* device int[S] work array */
-    int pair_cap;                  /* list entries per atom; a call that needs more returns -2 */
+    int* pair_count;               /* device int[4 * S] work array (four sub-lists per atom) */
+    int pair_cap;                  /* list entries per atom (a multiple of 4: four sub-lists of pair_cap / 4); a call that needs more returns -2 */
     int* pair_overflow;            /* device int work word */
     int* pair_needed;              /* HOST int written with the return code -2 (or NULL) */
 } ommhip_amoeba_vdw;
@@ -130,8 +130,8 @@ typedef struct ommhip_amoeba_multipole {
     int* special_pos;              /* device int[entries of special_atom] work array: the partners as scan positions, rows sorted */
     double* special_scale_sorted;  /* device double4[entries] work array */
     int* pair_list;                /* device int[pair_cap * S] work array */
-    int* pair_count;               /* device int[S] work array */
-    int pair_cap;                  /* list entries per atom; a call that needs more returns -2 */
+    int* pair_count;               /* device int[4 * S] work array (four sub-lists per atom) */
+    int pair_cap;                  /* list entries per atom (a multiple of 4: four sub-lists of pair_cap / 4); a call that needs more returns -2 */
     int* pair_overflow;            /* device int work word */
     int* pair_needed;              /* HOST int written with the return code -2: the capacity that would have been enough (or NULL) */
 } ommhip_amoeba_multipole;

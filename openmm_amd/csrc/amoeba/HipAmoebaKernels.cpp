@@ -44,7 +44,7 @@ void HipCalcAmoebaVdwForceKernel::initialize(const System& system, const AmoebaV
     usePBC = force.getNonbondedMethod() == AmoebaVdwForce::CutoffPeriodic;
     cutoff = force.getCutoffDistance();
     dispersionCoefficient = force.getUseDispersionCorrection() ? AmoebaVdwForceImpl::calcDispersionCorrection(system, force) : 0.0;
-    if (usePBC) data.hip->usePeriodic = true;
+    if (usePBC) { data.hip->usePeriodic = true; data.hip->sortCutoff = max(data.hip->sortCutoff, cutoff); }      // spatial slot order: the pair lists are built tile by tile
     upload(force);
 }
 
@@ -99,20 +99,20 @@ void HipCalcAmoebaVdwForceKernel::upload(const AmoebaVdwForce& force) {
     if (usePBC) {
         tileBounds.allocate(sizeof(double) * 4 * 2 * max(((size_t) hip.paddedAtoms + 127) / 128, (size_t) 1));
         exclPos.allocate(sizeof(int) * max(flat.size(), (size_t) 1));
-        pairCount.allocate(sizeof(int) * (size_t) hip.paddedAtoms);
+        pairCount.allocate(sizeof(int) * 4 * (size_t) hip.paddedAtoms);
         pairOverflow.allocate(sizeof(int));
         vdw.tile_bounds = tileBounds.as<double>(); vdw.excl_pos = exclPos.as<int>(); vdw.pair_count = pairCount.as<int>(); vdw.pair_overflow = pairOverflow.as<int>();
         vdw.pair_needed = &pairNeeded;
         // capacity: the partners of an atom at the density of the box, with room for fluctuations; a list that does not fit grows it
         const double volume = hip.box[0] * hip.box[2] * hip.box[5];
         // (OPENMM_HIP_AMOEBA_PAIR_CAP: a deliberately small first capacity, for the test of the growth path)
-    allocatePairList(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP") != NULL ? atoi(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP")) : (int) min((double) numParticles, 1.5 * 4.18879 * cutoff * cutoff * cutoff * numParticles / volume + 64.0));
+    allocatePairList(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP") != NULL ? atoi(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP")) : (int) min(4.0 * numParticles, 2.0 * 4.18879 * cutoff * cutoff * cutoff * numParticles / volume + 128.0));
     }
 }
 
 void HipCalcAmoebaVdwForceKernel::allocatePairList(int cap) {
     HipContext& hip = *data.hip;
-    vdw.pair_cap = max(cap, 1);
+    vdw.pair_cap = (max(cap, 4) + 3) / 4 * 4;            // four sub-lists per atom
     pairList.allocate(sizeof(int) * (size_t) vdw.pair_cap * hip.paddedAtoms);
     vdw.pair_list = pairList.as<int>();
 }
@@ -137,7 +137,7 @@ double HipCalcAmoebaVdwForceKernel::execute(ContextImpl& context, bool includeFo
         if (rc != -2) { HIP_CHECK(rc); break; }
         // the pair lists did not fit (nothing has been added to the forces yet: the list is built before the pair kernel runs)
         if (attempt == 3 || pairNeeded == 0x7fffffff) throw OpenMMException("AmoebaVdwForce: the pair lists of the HIP platform cannot hold this System");
-        allocatePairList((int) min((long long) numParticles, (long long) pairNeeded * 5 / 4 + 16));
+        allocatePairList((int) min((long long) numParticles * 4, (long long) pairNeeded * 5 / 4 + 16));
     }
     nativeEvaluations[0]++;
     // the pair energy is summed on the device (HipCalcForcesAndEnergyKernel::finishComputation); the host adds the constant
@@ -240,6 +240,7 @@ void HipCalcAmoebaMultipoleForceKernel::initialize(const System& system, const A
         NonbondedForceImpl::calcPMEParameters(system, nb, alphaEwald, gridSize[0], gridSize[1], gridSize[2], false);
     }
     hip.usePeriodic = true;
+    hip.sortCutoff = max(hip.sortCutoff, cutoff);         // spatial slot order: the pair lists are built tile by tile
     if (reference != NULL) reference->initialize(system, force);
     // ---- the platform's PME machinery on a grid of its own
     const int nx = gridSize[0], ny = gridSize[1], nz = gridSize[2], nzc = nz / 2 + 1;
@@ -339,19 +340,19 @@ void HipCalcAmoebaMultipoleForceKernel::upload(const AmoebaMultipoleForce& force
     tileBounds.allocate(sizeof(double) * 4 * 2 * max(tiles, (size_t) 1));
     specPos.allocate(sizeof(int) * max(atoms.size(), (size_t) 1));
     specScaleSorted.allocate(sizeof(double) * 4 * max(atoms.size(), (size_t) 1));
-    pairCount.allocate(sizeof(int) * (size_t) hip.paddedAtoms);
+    pairCount.allocate(sizeof(int) * 4 * (size_t) hip.paddedAtoms);
     pairOverflow.allocate(sizeof(int));
     mp.tile_bounds = tileBounds.as<double>(); mp.special_pos = specPos.as<int>(); mp.special_scale_sorted = specScaleSorted.as<double>();
     mp.pair_count = pairCount.as<int>(); mp.pair_overflow = pairOverflow.as<int>(); mp.pair_needed = &pairNeeded;
     mp.atom_of_slot = NULL; mp.slot_of_atom = NULL; mp.scan_slots = 0;
     const double volume = hip.box[0] * hip.box[2] * hip.box[5];
     // (OPENMM_HIP_AMOEBA_PAIR_CAP: a deliberately small first capacity, for the test of the growth path)
-    allocatePairList(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP") != NULL ? atoi(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP")) : (int) min((double) numParticles, 1.5 * 4.18879 * cutoff * cutoff * cutoff * numParticles / volume + 64.0));
+    allocatePairList(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP") != NULL ? atoi(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP")) : (int) min(4.0 * numParticles, 2.0 * 4.18879 * cutoff * cutoff * cutoff * numParticles / volume + 128.0));
 }
 
 void HipCalcAmoebaMultipoleForceKernel::allocatePairList(int cap) {
     HipContext& hip = *data.hip;
-    mp.pair_cap = max(cap, 1);
+    mp.pair_cap = (max(cap, 4) + 3) / 4 * 4;             // four sub-lists per atom
     pairList.allocate(sizeof(int) * (size_t) mp.pair_cap * hip.paddedAtoms);
     mp.pair_list = pairList.as<int>();
 }
@@ -359,7 +360,7 @@ void HipCalcAmoebaMultipoleForceKernel::allocatePairList(int cap) {
 bool HipCalcAmoebaMultipoleForceKernel::growPairList(int rc, int attempt) {
     if (rc != -2) return false;
     if (attempt == 3 || pairNeeded == 0x7fffffff) throw OpenMMException("AmoebaMultipoleForce: the pair lists of the HIP platform cannot hold this System");
-    allocatePairList((int) min((long long) numParticles, (long long) pairNeeded * 5 / 4 + 16));
+    allocatePairList((int) min((long long) numParticles * 4, (long long) pairNeeded * 5 / 4 + 16));
     return true;
 }
 

@@ -35,7 +35,7 @@ struct VdwArgs {
     double* energyBuffer;
     // scan positions: position g holds atom order[g] (the platform's slot order, -1: padding) or g itself
     const int* order; int numScan;
-    const int* pairList; const int* pairCount; int listStride;      // pair lists (amoeba_pairs.h); nullptr: the scan over all atoms
+    const int* pairList; const int* pairCount; int listStride, listSubcap;      // pair lists (amoeba_pairs.h); nullptr: the scan over all atoms
 };
 
 __device__ __forceinline__ int scan_atom(const VdwArgs& a, int g) { return g < a.numScan ? (a.order != nullptr ? a.order[g] : g) : -1; }
@@ -174,9 +174,10 @@ __global__ __launch_bounds__(VDW_BLOCK) void k_vdw_pairs_list(VdwArgs a) {
     const int typeI = a.type[ii];
     const bool alchI = a.alchemical != nullptr && a.alchemical[ii] != 0;
     double fx = 0, fy = 0, fz = 0, energy = 0;
-    const int cnt = active ? a.pairCount[g] : 0;
-    for (int k = 0; k < cnt; k++) {
-        const int j = scan_atom(a, a.pairList[(size_t) k * a.listStride + g] & PL_POS_MASK);
+    PlSpan span = {0, 0, 0, 0};
+    if (active) span = pl_span(a.pairCount, a.listStride, g);
+    for (int k = 0; k < span.total; k++) {
+        const int j = scan_atom(a, pl_at(a.pairList, a.listStride, a.listSubcap, span, k, g) & PL_POS_MASK);
         const double4 sj = a.reduced[j];
         double dx = si.x - sj.x, dy = si.y - sj.y, dz = si.z - sj.z;
         min_image_d(dx, dy, dz, a.box);
@@ -230,13 +231,13 @@ extern "C" int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* v, const void* 
     hipStream_t st = (hipStream_t) stream;
     const int blocks = (a.numAtoms + VDW_BLOCK - 1) / VDW_BLOCK;
     a.pairList = nullptr; a.pairCount = nullptr; a.listStride = 0;
-    if (a.periodic && v->pair_list != nullptr && v->pair_count != nullptr && v->pair_overflow != nullptr && v->tile_bounds != nullptr && v->excl_pos != nullptr && v->pair_cap > 0) {
+    if (a.periodic && v->pair_list != nullptr && v->pair_count != nullptr && v->pair_overflow != nullptr && v->tile_bounds != nullptr && v->excl_pos != nullptr && v->pair_cap >= 4) {
         // CutoffPeriodic: pair lists (partners by atom distance, exclusions left out), then the pair terms over the lists
         hipLaunchKernelGGL(k_vdw_reduce, dim3(blocks), dim3(VDW_BLOCK), 0, st, a);
         a.order = nullptr; a.numScan = a.numAtoms;
         if (v->atom_of_slot != nullptr && padded_atoms >= a.numAtoms) { a.order = v->atom_of_slot; a.numScan = padded_atoms; }
         PairListArgs p;
-        p.n = a.numAtoms; p.numScan = a.numScan; p.cap = v->pair_cap; p.stride = a.numScan; p.excludeListed = 1;
+        p.n = a.numAtoms; p.numScan = a.numScan; p.subcap = v->pair_cap / PL_PARTS; p.stride = a.numScan; p.excludeListed = 1;
         static const bool noTilesList = getenv("OPENMM_HIP_AMOEBA_NO_TILES") != nullptr;
         p.skipTiles = !noTilesList && box[1] == 0.0 && box[3] == 0.0 && box[4] == 0.0 ? 1 : 0;
         p.pos = a.pos; p.order = a.order; p.slotOfAtom = a.slotOfAtom; p.box = a.box; p.cutoff2 = a.cutoff2;
@@ -246,7 +247,7 @@ extern "C" int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* v, const void* 
         p.list = v->pair_list; p.count = v->pair_count; p.overflow = v->pair_overflow;
         const int rc = pl_launch(p, v->pair_needed, st);
         if (rc != 0) return rc;
-        a.pairList = v->pair_list; a.pairCount = v->pair_count; a.listStride = a.numScan;
+        a.pairList = v->pair_list; a.pairCount = v->pair_count; a.listStride = a.numScan; a.listSubcap = v->pair_cap / PL_PARTS;
         hipLaunchKernelGGL(k_vdw_pairs_list, dim3((a.numScan + VDW_BLOCK - 1) / VDW_BLOCK), dim3(VDW_BLOCK), 0, st, a);
         return (int) hipGetLastError();
     }

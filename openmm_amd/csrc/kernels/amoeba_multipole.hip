@@ -107,7 +107,7 @@ struct MpArgs {
     // pair lists (amoeba_pairs.h), built once per evaluation: thread g of the pair kernels owns the atom at scan position g -- order[g], the
     // platform's slot order (-1: padding), or g itself without an order -- and walks pairList[k * listStride + g], k < pairCount[g]
     const int* order; int numScan;
-    const int* pairList; const int* pairCount; int listStride;
+    const int* pairList; const int* pairCount; int listStride, listSubcap;
     const double4* specScaleSorted;                // scale factors of the special pairs, rows in the order the list entries index them
 };
 
@@ -213,10 +213,15 @@ __device__ __forceinline__ void atom_splines(const MpArgs& a, V3 x, int (&idx)[3
 // (mu_d + mu_p) / 2 (INDUCED = true) onto the float grid.  AmoebaReferencePmeMultipoleForce::spreadFixedMultipolesOntoGrid (:5380-5423),
 // spreadInducedDipolesOnGrid (:5572-5616); derivatives with respect to the atom position through the chain rule a[k][c].
 // INDUCED: the dipoles sA * A + sB * B (B may be null)
+// Eight lanes per atom: lane l < 5 owns the stencil points with z offset l and walks through the 25 (x, y) offsets, so one atomic
+// instruction of a wave adds to 8 runs of 5 consecutive grid cells -- about 12 memory-side transactions (64-byte lines) instead of
+// the 64 that one-atom-per-lane costs; the float atomics, not the arithmetic, are what this kernel's time consists of.
+#define MP_SPREAD_LANES 8
 template <bool INDUCED>
 __global__ void k_mp_spread(MpArgs a, const double* __restrict__ A, double sA, const double* __restrict__ B, double sB) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = tid / MP_SPREAD_LANES, iz = tid % MP_SPREAD_LANES;
+    if (i >= a.n || iz >= 5) return;
     int idx[3];
     double th[3][4][5];
     atom_splines(a, position(a, i), idx, th);
@@ -237,6 +242,11 @@ __global__ void k_mp_spread(MpArgs a, const double* __restrict__ A, double sA, c
                 fq[k][l] = s;
             }
     }
+    // this lane's z weights (value, first and second derivative), picked with selects: a dynamic index would put the table into scratch
+    double w0 = 0, w1 = 0, w2 = 0;
+#pragma unroll
+    for (int z = 0; z < 5; z++) if (z == iz) { w0 = th[2][0][z]; w1 = th[2][1][z]; w2 = th[2][2][z]; }
+    const int gz = (idx[2] + iz) % a.nz;
     for (int ix = 0; ix < 5; ix++) {
         const int gx = (idx[0] + ix) % a.nx;
         for (int iy = 0; iy < 5; iy++) {
@@ -249,11 +259,8 @@ __global__ void k_mp_spread(MpArgs a, const double* __restrict__ A, double sA, c
                 term1 = fd[2] * t0 * u0 + 2.0 * fq[0][2] * t1 * u0 + 2.0 * fq[1][2] * t0 * u1;
                 term2 = fq[2][2] * t0 * u0;
             }
-            for (int iz = 0; iz < 5; iz++) {
-                const int gz = (idx[2] + iz) % a.nz;
-                const double v = term0 * th[2][0][iz] + term1 * th[2][1][iz] + term2 * th[2][2][iz];
-                atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], (float) v);
-            }
+            const double v = term0 * w0 + term1 * w1 + term2 * w2;
+            atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], (float) v);
         }
     }
 }
@@ -368,10 +375,11 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_field(MpArgs a) {
     const double tholeI = a.thole[ii], dampI = a.damping[ii];
     const int rowBegin = a.specStart[ii];
     V3 ed = v3(0, 0, 0), ep = v3(0, 0, 0);
-    const int cnt = active ? a.pairCount[g] : 0;
     {
-        for (int k = 0; k < cnt; k++) {
-            const int entry = a.pairList[(size_t) k * a.listStride + g];
+        PlSpan span = {0, 0, 0, 0};
+        if (active) span = pl_span(a.pairCount, a.listStride, g);
+        for (int k = 0; k < span.total; k++) {
+            const int entry = pl_at(a.pairList, a.listStride, a.listSubcap, span, k, g);
             const int j = scan_atom(a, entry & PL_POS_MASK);
             const PairScale sc = pair_scale(a, rowBegin, entry);
             struct { double x, y, z, q; V3 mu; Sym Q; double thole, damp; } s;
@@ -439,10 +447,11 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
     const int rowBegin = a.specStart[ii];
     V3 force = v3(0, 0, 0), torque = v3(0, 0, 0);
     double energy = 0.0;
-    const int cnt = active ? a.pairCount[g] : 0;
     {
-        for (int k = 0; k < cnt; k++) {
-            const int entry = a.pairList[(size_t) k * a.listStride + g];
+        PlSpan span = {0, 0, 0, 0};
+        if (active) span = pl_span(a.pairCount, a.listStride, g);
+        for (int k = 0; k < span.total; k++) {
+            const int entry = pl_at(a.pairList, a.listStride, a.listSubcap, span, k, g);
             const int j = scan_atom(a, entry & PL_POS_MASK);
             const PairScale sc = pair_scale(a, rowBegin, entry);
             struct { double x, y, z, q; V3 mu; Sym Q; double thole, damp; V3 ud, up; } s;
@@ -545,10 +554,11 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const do
     const V3 xi = position(a, ii);
     const double tholeI = a.thole[ii], dampI = a.damping[ii];
     V3 ed = v3(0, 0, 0), ep = v3(0, 0, 0);
-    const int cnt = active ? a.pairCount[g] : 0;
     {
-        for (int k = 0; k < cnt; k++) {
-            const int j = scan_atom(a, a.pairList[(size_t) k * a.listStride + g] & PL_POS_MASK);
+        PlSpan span = {0, 0, 0, 0};
+        if (active) span = pl_span(a.pairCount, a.listStride, g);
+        for (int k = 0; k < span.total; k++) {
+            const int j = scan_atom(a, pl_at(a.pairList, a.listStride, a.listSubcap, span, k, g) & PL_POS_MASK);
             struct { double x, y, z, thole, damp; V3 vd, vp; } s;
             { const V3 x = position(a, j); s.x = x.x; s.y = x.y; s.z = x.z; }
             s.thole = a.thole[j]; s.damp = a.damping[j]; s.vd = load3(vD, j); s.vp = load3(vP, j);
@@ -698,10 +708,13 @@ bool make_args(const ommhip_amoeba_multipole* mp, const void* pos_d, const doubl
     if (mp->pair_list == nullptr || mp->pair_count == nullptr || mp->pair_overflow == nullptr || mp->special_pos == nullptr || mp->special_scale_sorted == nullptr || mp->tile_bounds == nullptr || mp->pair_cap < 1) return false;
     a.order = nullptr; a.numScan = a.n;
     if (mp->atom_of_slot != nullptr && mp->slot_of_atom != nullptr && mp->scan_slots >= a.n) { a.order = mp->atom_of_slot; a.slotOfAtom = mp->slot_of_atom; a.numScan = mp->scan_slots; }
-    a.pairList = mp->pair_list; a.pairCount = mp->pair_count; a.listStride = a.numScan;
+    a.pairList = mp->pair_list; a.pairCount = mp->pair_count; a.listStride = a.numScan; a.listSubcap = mp->pair_cap / PL_PARTS;
+    if (a.listSubcap < 1) return false;
     a.specScaleSorted = (const double4*) mp->special_scale_sorted;
     return true;
 }
+
+int spread_blocks(const MpArgs& a) { return (int) (((size_t) a.n * MP_SPREAD_LANES + 255) / 256); }
 
 // number of workgroups of the pair kernels (one thread per scan position)
 int scan_blocks(const MpArgs& a) { return (a.numScan + MP_BLOCK - 1) / MP_BLOCK; }
@@ -709,7 +722,7 @@ int scan_blocks(const MpArgs& a) { return (a.numScan + MP_BLOCK - 1) / MP_BLOCK;
 // the pair lists of this evaluation (amoeba_pairs.h); -2: the lists did not fit into pair_cap entries per atom (*pair_needed says how many would)
 int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st) {
     PairListArgs p;
-    p.n = a.n; p.numScan = a.numScan; p.cap = mp->pair_cap; p.stride = a.numScan; p.excludeListed = 0;
+    p.n = a.n; p.numScan = a.numScan; p.subcap = a.listSubcap; p.stride = a.numScan; p.excludeListed = 0;
     static const bool noTiles = getenv("OPENMM_HIP_AMOEBA_NO_TILES") != nullptr;         // A/B knob: the builder looks at every tile
     p.skipTiles = !noTiles && box[1] == 0.0 && box[3] == 0.0 && box[4] == 0.0 ? 1 : 0;
     p.pos = a.pos; p.order = a.order; p.slotOfAtom = a.slotOfAtom; p.box = a.box; p.cutoff2 = a.cutoff2;
@@ -730,7 +743,7 @@ int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const doub
     const size_t gridBytes = sizeof(float) * (size_t) a.nx * a.ny * a.nz;
     hipLaunchKernelGGL(k_mp_frames, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
     hipMemsetAsync(a.grid, 0, gridBytes, st);
-    hipLaunchKernelGGL(k_mp_spread<false>, dim3(blocks), dim3(MP_BLOCK), 0, st, a, (const double*) nullptr, 0.0, (const double*) nullptr, 0.0);
+    hipLaunchKernelGGL(k_mp_spread<false>, dim3(spread_blocks(a)), dim3(256), 0, st, a, (const double*) nullptr, 0.0, (const double*) nullptr, 0.0);
     ommhip_pme_convolve(pme, st);
     hipLaunchKernelGGL(k_mp_potential, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.phi);
     hipLaunchKernelGGL(k_mp_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
@@ -741,7 +754,7 @@ int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const doub
 void dipole_potential(const ommhip_pme* pme, const MpArgs& a, const double* dipoles, double* out, hipStream_t st) {
     const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
     hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, st);
-    hipLaunchKernelGGL(k_mp_spread<true>, dim3(blocks), dim3(MP_BLOCK), 0, st, a, dipoles, 1.0, (const double*) nullptr, 0.0);
+    hipLaunchKernelGGL(k_mp_spread<true>, dim3(spread_blocks(a)), dim3(256), 0, st, a, dipoles, 1.0, (const double*) nullptr, 0.0);
     ommhip_pme_convolve(pme, st);
     hipLaunchKernelGGL(k_mp_potential, dim3(blocks), dim3(MP_BLOCK), 0, st, a, out);
 }
@@ -817,7 +830,7 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
     else {
         // reciprocal potential of the induced dipoles (mu_d + mu_p) / 2
         hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, st);
-        hipLaunchKernelGGL(k_mp_spread<true>, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.indD, 0.5, a.indP, 0.5);
+        hipLaunchKernelGGL(k_mp_spread<true>, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.indD, 0.5, a.indP, 0.5);
         ommhip_pme_convolve(pme, st);
         hipLaunchKernelGGL(k_mp_potential, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.phiInd);
     }

@@ -12,20 +12,26 @@
 // without an order.  Tiles of PL_BLOCK positions carry bounding boxes; the builder skips the tiles farther from its own than the cutoff
 // (rectangular boxes).  An entry is  j's scan position | (1 + index of j in i's row of listed partners) << 24 :  the multipole kernels
 // find the scale factors of a covalently related pair through that index, the vdW kernel leaves listed partners (exclusions) out.
-// Layout: entry k of position g at list[k * stride + g] (coalesced across the lanes of a wave).
+// Layout: PL_PARTS sub-lists per position -- the candidate tiles are dealt out to PL_PARTS workgroups per tile of owners, or the
+// builder would run on 2 wavefronts per 128 atoms --; entry k of sub-list p of position g at list[(p * subcap + k) * stride + g]
+// (coalesced across the lanes of a wave), its length at count[p * stride + g].
 #ifndef OMM_AMOEBA_PAIRS_H_
 #define OMM_AMOEBA_PAIRS_H_
 
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace omm {
 
 #define PL_BLOCK 128
 #define PL_POS_MASK 0xFFFFFF
 #define PL_MAX_ROW 126            // listed partners per atom that an entry can index
+#define PL_PARTS 4
+#define PL_FAR_CHUNK 4096          // tiles whose far / near flags are held in LDS at a time
 
 struct PairListArgs {
-    int n, numScan, skipTiles, cap, stride, excludeListed;
+    int n, numScan, skipTiles, subcap, stride, excludeListed;      // subcap: entries per sub-list
     const double4* pos; const int* order; const int* slotOfAtom;
     BoxD box; double cutoff2;
     double4* tileCenter; double4* tileHalf;
@@ -98,55 +104,113 @@ __device__ __forceinline__ bool pl_tiles_far(const PairListArgs& a, int ti, int 
 }
 
 // One thread per scan position: partners within the cutoff (cutoff2 < 0: all atoms), in ascending scan position.
+// The distance test runs once per candidate and thread, so it is kept to a subtraction and a comparison: where the workgroup's own
+// tile (half extents h) satisfies h + cutoff < L / 2 on every axis -- rectangular boxes -- the staging thread moves each candidate
+// to the periodic image nearest to the tile's centre c (one minimum-image reduction per staged atom, not one per pair), the own atom
+// is expressed in the same frame, and the image of j nearest to c is then the only one that can lie within the cutoff of any atom
+// of the tile.  Other boxes and oversized tiles reduce every pair (min_image_d).
 __global__ __launch_bounds__(PL_BLOCK) void pl_build(PairListArgs a) {
     __shared__ double4 sj[PL_BLOCK];               // .w < 0: no atom at this position
-    const int t = threadIdx.x, g = blockIdx.x * PL_BLOCK + t, i = pl_scan_atom(a, g);
+    __shared__ unsigned sNear[PL_FAR_CHUNK / 32];  // bit per candidate tile of the current chunk: within reach of this workgroup's tile
+    const int tileI = blockIdx.x / PL_PARTS, part = blockIdx.x % PL_PARTS;
+    const int t = threadIdx.x, g = tileI * PL_BLOCK + t, i = pl_scan_atom(a, g);
     const bool active = i >= 0;
     const int ii = active ? i : 0;
-    const double4 xi = a.pos[ii];
+    double4 xi = a.pos[ii];
+    bool tileFrame = false;
+    double4 c = make_double4(0, 0, 0, 0);
+    if (a.skipTiles && a.cutoff2 >= 0.0) {
+        const double4 h = a.tileHalf[tileI];
+        const double rc = sqrt(a.cutoff2);
+        c = a.tileCenter[tileI];
+        tileFrame = h.x >= 0.0 && h.x + rc < 0.5 * a.box.ax && h.y + rc < 0.5 * a.box.by && h.z + rc < 0.5 * a.box.cz;       // block-uniform
+        if (tileFrame) {
+            double dx = xi.x - c.x, dy = xi.y - c.y, dz = xi.z - c.z;
+            min_image_d(dx, dy, dz, a.box);
+            xi.x = dx; xi.y = dy; xi.z = dz;                      // relative to the tile's centre
+        }
+    }
     const int rowBegin = a.rowStart != nullptr ? a.rowStart[ii] : 0, rowEnd = a.rowStart != nullptr ? a.rowStart[ii + 1] : 0;
     int cursor = rowBegin;
     int next = cursor < rowEnd ? a.rowPos[cursor] : 0x7fffffff;
     int cnt = 0;
     bool over = false;
-    for (int j0 = 0; j0 < a.numScan; j0 += PL_BLOCK) {
-        if (pl_tiles_far(a, blockIdx.x, j0 / PL_BLOCK)) continue;        // block-uniform
+    int* const myList = a.list + (size_t) part * a.subcap * a.stride + g;
+    const int numTiles = (a.numScan + PL_BLOCK - 1) / PL_BLOCK;
+    for (int chunk = 0; chunk < numTiles; chunk += PL_FAR_CHUNK) {
+        // which tiles of this chunk are this workgroup's to look at: its share (every PL_PARTS-th) of those within reach -- all threads
+        // test in parallel (one tile each per round) instead of every thread loading every tile's box in turn
         __syncthreads();
-        {
-            const int j = pl_scan_atom(a, j0 + t);
-            double4 p = make_double4(0, 0, 0, -1.0);
-            if (j >= 0) { p = a.pos[j]; p.w = 1.0; }
-            sj[t] = p;
-        }
+        for (int w = t; w < PL_FAR_CHUNK / 32; w += PL_BLOCK) sNear[w] = 0u;
         __syncthreads();
-        if (!active) continue;
-        const int nj = min(PL_BLOCK, a.numScan - j0);
-        for (int k = 0; k < nj; k++) {
-            const int j = j0 + k;
-            const double4 p = sj[k];
-            if (j == g || p.w < 0.0) continue;
-            if (a.cutoff2 >= 0.0) {
-                double dx = p.x - xi.x, dy = p.y - xi.y, dz = p.z - xi.z;
-                min_image_d(dx, dy, dz, a.box);
-                if (dx * dx + dy * dy + dz * dz > a.cutoff2) continue;
+        for (int tj = chunk + t; tj < min(chunk + PL_FAR_CHUNK, numTiles); tj += PL_BLOCK)
+            if (tj % PL_PARTS == part && !pl_tiles_far(a, tileI, tj)) atomicOr(&sNear[(tj - chunk) >> 5], 1u << ((tj - chunk) & 31));
+        __syncthreads();
+        for (int w = 0; w < PL_FAR_CHUNK / 32; w++) {
+            unsigned bits = sNear[w];                                    // block-uniform
+            while (bits != 0u) {
+                const int b = __ffs((int) bits) - 1;
+                bits &= bits - 1u;
+                const int j0 = (chunk + w * 32 + b) * PL_BLOCK;
+                __syncthreads();
+                {
+                    const int j = pl_scan_atom(a, j0 + t);
+                    double4 p = make_double4(0, 0, 0, -1.0);
+                    if (j >= 0) {
+                        p = a.pos[j]; p.w = 1.0;
+                        if (tileFrame) {
+                            double dx = p.x - c.x, dy = p.y - c.y, dz = p.z - c.z;
+                            min_image_d(dx, dy, dz, a.box);
+                            p.x = dx; p.y = dy; p.z = dz;
+                        }
+                    }
+                    sj[t] = p;
+                }
+                __syncthreads();
+                if (!active) continue;
+                const int nj = min(PL_BLOCK, a.numScan - j0);
+                for (int k = 0; k < nj; k++) {
+                    const int j = j0 + k;
+                    const double4 p = sj[k];
+                    if (j == g || p.w < 0.0) continue;
+                    if (a.cutoff2 >= 0.0) {
+                        double dx = p.x - xi.x, dy = p.y - xi.y, dz = p.z - xi.z;
+                        if (!tileFrame) min_image_d(dx, dy, dz, a.box);
+                        if (dx * dx + dy * dy + dz * dz > a.cutoff2) continue;
+                    }
+                    while (next < j) { cursor++; next = cursor < rowEnd ? a.rowPos[cursor] : 0x7fffffff; }
+                    int tag = 0;
+                    if (next == j) {
+                        if (a.excludeListed) continue;
+                        tag = cursor - rowBegin + 1;
+                        if (tag > PL_MAX_ROW) over = true;
+                    }
+                    if (cnt < a.subcap) myList[(size_t) cnt * a.stride] = j | (tag << 24);
+                    else over = true;
+                    cnt++;
+                }
             }
-            while (next < j) { cursor++; next = cursor < rowEnd ? a.rowPos[cursor] : 0x7fffffff; }
-            int tag = 0;
-            if (next == j) {
-                if (a.excludeListed) continue;
-                tag = cursor - rowBegin + 1;
-                if (tag > PL_MAX_ROW) over = true;
-            }
-            if (cnt < a.cap) a.list[(size_t) cnt * a.stride + g] = j | (tag << 24);
-            else over = true;
-            cnt++;
         }
     }
-    if (g < a.numScan) a.count[g] = min(cnt, a.cap);
-    if (over) atomicMax(a.overflow, cnt > a.cap ? cnt : 0x7fffffff);          // the capacity that would have been enough (or: a row too long to index)
+    if (g < a.numScan) a.count[(size_t) part * a.stride + g] = min(cnt, a.subcap);
+    if (over) atomicMax(a.overflow, cnt > a.subcap ? cnt : 0x7fffffff);       // the sub-list length that would have been enough (or: a row too long to index)
 }
 
 }  // namespace
+
+// Consumers walk the four sub-lists as ONE list (a loop per sub-list would run to the longest sub-list of the wave four times over):
+//     const PlSpan span = pl_span(count, stride, g);   for (int k = 0; k < span.total; k++) entry = pl_at(list, stride, subcap, span, k, g);
+struct PlSpan { int c1, c2, c3, total; };          // where sub-lists 1, 2, 3 begin in the concatenation, and its length
+__device__ __forceinline__ PlSpan pl_span(const int* count, int stride, int g) {
+    PlSpan s;
+    s.c1 = count[g]; s.c2 = s.c1 + count[(size_t) stride + g]; s.c3 = s.c2 + count[2 * (size_t) stride + g]; s.total = s.c3 + count[3 * (size_t) stride + g];
+    return s;
+}
+__device__ __forceinline__ int pl_at(const int* list, int stride, int subcap, const PlSpan& s, int k, int g) {
+    const int p = (k >= s.c1) + (k >= s.c2) + (k >= s.c3);
+    const int kk = k - (p == 0 ? 0 : (p == 1 ? s.c1 : (p == 2 ? s.c2 : s.c3)));
+    return list[((size_t) p * subcap + kk) * stride + g];
+}
 
 // Host side: re-key the rows, bound the tiles, build the list.  Returns 0, a hipError_t, or -2 when the list did not fit
 // (*needed = the longest list, or 0x7fffffff when a row of listed partners is too long to index).  `overflowHost` = pinned or plain host int.
@@ -156,12 +220,12 @@ static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st) {
     if (a.rowStart != nullptr) hipLaunchKernelGGL(pl_sort_rows, dim3((a.n + 127) / 128), dim3(128), 0, st, a);
     const int tiles = (a.numScan + PL_BLOCK - 1) / PL_BLOCK;
     if (a.skipTiles) hipLaunchKernelGGL(pl_tile_bounds, dim3(tiles), dim3(PL_BLOCK), 0, st, a);
-    hipLaunchKernelGGL(pl_build, dim3(tiles), dim3(PL_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(pl_build, dim3(tiles * PL_PARTS), dim3(PL_BLOCK), 0, st, a);
     int over = 0;
     hipError_t e = hipMemcpyAsync(&over, a.overflow, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return (int) e;
-    if (over != 0) { if (needed != nullptr) *needed = over; return -2; }
+    if (over != 0) { if (needed != nullptr) *needed = over == 0x7fffffff ? over : over * PL_PARTS; return -2; }       // in entries per atom, as the caller sizes the list
     return 0;
 }
 

@@ -134,6 +134,8 @@ typedef struct ommhip_amoeba_multipole {
     int pair_cap;                  /* list entries per atom (a multiple of 4: four sub-lists of pair_cap / 4); a call that needs more returns -2 */
     int* pair_overflow;            /* device int work word */
     int* pair_needed;              /* HOST int written with the return code -2: the capacity that would have been enough (or NULL) */
+    double* pair_cache;            /* device double[5 * pair_cap * S] or NULL (mutual polarization): per list entry the separation and the two
+                                    * coefficients of the damped dipole-dipole chain, written once per evaluation and read by every solver iteration */
 } ommhip_amoeba_multipole;
 
 /* Whole evaluation: frames -> reciprocal and real-space field -> induced dipoles -> energy, forces, torques -> forces. */

@@ -355,6 +355,11 @@ void HipCalcAmoebaMultipoleForceKernel::allocatePairList(int cap) {
     mp.pair_cap = (max(cap, 4) + 3) / 4 * 4;             // four sub-lists per atom
     pairList.allocate(sizeof(int) * (size_t) mp.pair_cap * hip.paddedAtoms);
     mp.pair_list = pairList.as<int>();
+    // mutual polarization: 40 bytes per list entry that save the solver iterations their erfc / exp / Thole arithmetic (0.6 GB at 36 k atoms;
+    // left out when it would take more than 8 GB)
+    mp.pair_cache = NULL;
+    const size_t cacheBytes = sizeof(double) * 5 * (size_t) mp.pair_cap * hip.paddedAtoms;
+    if (mutual && cacheBytes <= ((size_t) 8 << 30) && getenv("OPENMM_HIP_AMOEBA_NO_PAIR_CACHE") == NULL) { pairCache.allocate(cacheBytes); mp.pair_cache = pairCache.as<double>(); }
 }
 
 bool HipCalcAmoebaMultipoleForceKernel::growPairList(int rc, int attempt) {

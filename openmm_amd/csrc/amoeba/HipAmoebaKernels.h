@@ -71,7 +71,7 @@ private:
     ommhip_amoeba_multipole mp;
     ommhip_pme pme;
     DeviceBuffer charge, molDipole, molQuad, axis, thole, damping, polarity, specStart, specAtom, specScale;
-    DeviceBuffer labDipole, labQuad, fieldD, fieldP, indD, indP, phi, phiInd, phiIndP, solver, torque, tileBounds, specPos, specScaleSorted, pairList, pairCount, pairOverflow;
+    DeviceBuffer labDipole, labQuad, fieldD, fieldP, indD, indP, phi, phiInd, phiIndP, solver, torque, tileBounds, specPos, specScaleSorted, pairList, pairCount, pairOverflow, pairCache;
     DeviceBuffer moduliX, moduliY, moduliZ, twiddleX, twiddleY, twiddleZ, eterm, gridReal, gridComplex;
 };
 

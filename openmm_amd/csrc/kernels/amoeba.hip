@@ -19,6 +19,7 @@ using namespace omm;
 namespace {
 
 #define VDW_BLOCK 256
+#define VDW_SPLIT 4            // lanes per atom in the list kernel (amoeba_multipole.hip: MP_SPLIT)
 
 struct VdwArgs {
     int numAtoms, numTypes, paddedAtoms, alchemicalMethod, lennardJones, periodic, includeEnergy, energySlots;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(VDW_BLOCK) void k_vdw_pairs(VdwArgs a) {
 __global__ __launch_bounds__(VDW_BLOCK) void k_vdw_pairs_list(VdwArgs a) {
     __shared__ double sEnergy[VDW_BLOCK / 64];
     const int t = threadIdx.x;
-    const int g = blockIdx.x * VDW_BLOCK + t, i = scan_atom(a, g);
+    const int g = (blockIdx.x * VDW_BLOCK + t) / VDW_SPLIT, q = t % VDW_SPLIT, i = scan_atom(a, g);      // VDW_SPLIT lanes share an atom's list
     const bool active = i >= 0;
     const int ii = active ? i : 0;
     const double4 si = a.reduced[ii];
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(VDW_BLOCK) void k_vdw_pairs_list(VdwArgs a) {
     double fx = 0, fy = 0, fz = 0, energy = 0;
     PlSpan span = {0, 0, 0, 0};
     if (active) span = pl_span(a.pairCount, a.listStride, g);
-    for (int k = 0; k < span.total; k++) {
+    for (int k = q; k < span.total; k += VDW_SPLIT) {
         const int j = scan_atom(a, pl_at(a.pairList, a.listStride, a.listSubcap, span, k, g) & PL_POS_MASK);
         const double4 sj = a.reduced[j];
         double dx = si.x - sj.x, dy = si.y - sj.y, dz = si.z - sj.z;
@@ -191,7 +192,10 @@ __global__ __launch_bounds__(VDW_BLOCK) void k_vdw_pairs_list(VdwArgs a) {
         fx -= dEdRoverR * dx; fy -= dEdRoverR * dy; fz -= dEdRoverR * dz;
         energy += 0.5 * e;
     }
-    if (active) {
+    fx += __shfl_xor(fx, 1); fy += __shfl_xor(fy, 1); fz += __shfl_xor(fz, 1); energy += __shfl_xor(energy, 1);
+    fx += __shfl_xor(fx, 2); fy += __shfl_xor(fy, 2); fz += __shfl_xor(fz, 2); energy += __shfl_xor(energy, 2);
+    if (q != 0) energy = 0.0;
+    if (active && q == 0) {
         const int p = a.parent[i];
         if (p == i) add_force(a.force, a.paddedAtoms, a.slotOfAtom[i], fx, fy, fz);
         else {
@@ -248,7 +252,7 @@ extern "C" int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* v, const void* 
         const int rc = pl_launch(p, v->pair_needed, st);
         if (rc != 0) return rc;
         a.pairList = v->pair_list; a.pairCount = v->pair_count; a.listStride = a.numScan; a.listSubcap = v->pair_cap / PL_PARTS;
-        hipLaunchKernelGGL(k_vdw_pairs_list, dim3((a.numScan + VDW_BLOCK - 1) / VDW_BLOCK), dim3(VDW_BLOCK), 0, st, a);
+        hipLaunchKernelGGL(k_vdw_pairs_list, dim3((unsigned) (((size_t) a.numScan * VDW_SPLIT + VDW_BLOCK - 1) / VDW_BLOCK)), dim3(VDW_BLOCK), 0, st, a);
         return (int) hipGetLastError();
     }
     // no lists (NoCutoff, or a caller without the work arrays): every thread scans all atoms, in atom order

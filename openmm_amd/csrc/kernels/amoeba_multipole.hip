@@ -108,6 +108,7 @@ struct MpArgs {
     // platform's slot order (-1: padding), or g itself without an order -- and walks pairList[k * listStride + g], k < pairCount[g]
     const int* order; int numScan;
     const int* pairList; const int* pairCount; int listStride, listSubcap;
+    double* pairCache; int pairCap;                // mutual polarization: per list entry (dx, dy, dz, b1, b2) of the Thole-damped dipole-dipole chain, planes of pairCap * listStride
     const double4* specScaleSorted;                // scale factors of the special pairs, rows in the order the list entries index them
 };
 
@@ -269,31 +270,47 @@ __global__ void k_mp_spread(MpArgs a, const double* __restrict__ A, double sA, c
 //   out[0] phi | [1..3] x y z | [4..9] xx xy xz yy yz zz | [10..19] xxx xxy xxz xyy xyz xzz yyy yyz yzz zzz
 // AmoebaReferencePmeMultipoleForce::computeFixedPotentialFromGrid (:5464-5570) / computeInducedPotentialFromGrid (:5618-5818) and
 // transformPotentialToCartesianCoordinates (:5340-5378), here with the general chain rule for all three orders.
+// Eight lanes per atom, as in the spreading kernel: lane l < 5 reads the stencil points with z offset l (the five lanes of an atom read
+// five consecutive grid cells) and sums them over the 25 (x, y) offsets into the ten (p, q) combinations; the z weights of the lane's
+// own offset turn those into its share of the 20 derivatives, and the shares meet through shuffles.  (One thread per atom held the
+// whole 3 x 4 x 5 weight table and 20 sums in registers and spilled.)
 __global__ void k_mp_potential(MpArgs a, double* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = tid / MP_SPREAD_LANES, iz = tid % MP_SPREAD_LANES;
+    const bool atom = i < a.n, mine = atom && iz < 5;
     int idx[3];
     double th[3][4][5];
-    atom_splines(a, position(a, i), idx, th);
-    // fractional derivatives F[p][q][r] = sum_g grid(g) thx^(p) thy^(q) thz^(r),  p + q + r <= 3
-    double F[4][4][4];
-    for (int p = 0; p < 4; p++) for (int q = 0; q < 4; q++) for (int r = 0; r < 4; r++) F[p][q][r] = 0.0;
-    for (int ix = 0; ix < 5; ix++) {
-        const int gx = (idx[0] + ix) % a.nx;
-        for (int iy = 0; iy < 5; iy++) {
-            const int gy = (idx[1] + iy) % a.ny;
-            double z[4] = {0, 0, 0, 0};
-            for (int iz = 0; iz < 5; iz++) {
-                const double g = (double) a.grid[((size_t) gx * a.ny + gy) * a.nz + (idx[2] + iz) % a.nz];
-                for (int r = 0; r < 4; r++) z[r] += g * th[2][r][iz];
-            }
-            for (int p = 0; p < 4; p++)
-                for (int q = 0; p + q < 4; q++) {
-                    const double w = th[0][p][ix] * th[1][q][iy];
-                    for (int r = 0; p + q + r < 4; r++) F[p][q][r] += w * z[r];
+    atom_splines(a, position(a, atom ? i : 0), idx, th);
+    double G[4][4];                    // G[p][q] = sum over (ix, iy) of grid(ix, iy, my z) thx^(p)[ix] thy^(q)[iy],  p + q <= 3
+    for (int p = 0; p < 4; p++) for (int q = 0; q < 4; q++) G[p][q] = 0.0;
+    if (mine) {
+        const int gz = (idx[2] + iz) % a.nz;
+        for (int ix = 0; ix < 5; ix++) {
+            const int gx = (idx[0] + ix) % a.nx;
+            for (int iy = 0; iy < 5; iy++) {
+                const int gy = (idx[1] + iy) % a.ny;
+                const double g = (double) a.grid[((size_t) gx * a.ny + gy) * a.nz + gz];
+                for (int p = 0; p < 4; p++) {
+                    const double gp = g * th[0][p][ix];
+                    for (int q = 0; p + q < 4; q++) G[p][q] += gp * th[1][q][iy];
                 }
+            }
         }
     }
+    // this lane's z weights by derivative order (selects, not a dynamic index into the table)
+    double wz[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int z = 0; z < 5; z++) if (z == iz) { wz[0] = th[2][0][z]; wz[1] = th[2][1][z]; wz[2] = th[2][2][z]; wz[3] = th[2][3][z]; }
+    // fractional derivatives F[p][q][r] = sum_g grid(g) thx^(p) thy^(q) thz^(r),  p + q + r <= 3: sum of the lanes' shares
+    double F[4][4][4];
+    for (int p = 0; p < 4; p++)
+        for (int q = 0; p + q < 4; q++)
+            for (int r = 0; p + q + r < 4; r++) {
+                double v = G[p][q] * wz[r];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+                F[p][q][r] = v;
+            }
+    if (!atom || iz != 0) return;
     // first, second and third fractional derivative tensors by index
     double f1[3] = {F[1][0][0], F[0][1][0], F[0][0][1]};
     double f2[3][3], f3[3][3][3];
@@ -350,6 +367,13 @@ __device__ __forceinline__ void pair_chains(double alpha, double r2, double damp
     }
 }
 
+// MP_SPLIT lanes share an atom in the pair kernels: lane q of the group walks entries q, q + MP_SPLIT, ... of the atom's list and the partial
+// sums meet through shuffles.  One thread per atom would put 2 wavefronts on a compute unit at 36 k atoms; the loops are gathers from
+// L2 / HBM with long arithmetic in between and need the latency hiding of several wavefronts per SIMD.
+#define MP_SPLIT 4
+__device__ __forceinline__ double split_sum(double v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v; }
+__device__ __forceinline__ V3 split_sum(V3 v) { return v3(split_sum(v.x), split_sum(v.y), split_sum(v.z)); }
+
 struct PairScale { double m, p, d; };
 
 // scale factors of the pair (i, j) from i's list of special partners (ascending; the cursor moves with j)
@@ -368,7 +392,7 @@ __device__ __forceinline__ PairScale pair_scale(const MpArgs& a, int rowBegin, i
 // (:6008-6019) + initializeInducedDipoles (:6021-6026).  Fields in units of e / nm^2 (without the Coulomb constant), as there.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(MP_BLOCK) void k_mp_field(MpArgs a) {
-    const int t = threadIdx.x, g = blockIdx.x * MP_BLOCK + t, i = scan_atom(a, g);
+    const int t = threadIdx.x, g = (blockIdx.x * MP_BLOCK + t) / MP_SPLIT, q = t % MP_SPLIT, i = scan_atom(a, g);
     const bool active = i >= 0;
     const int ii = active ? i : 0;
     const V3 xi = position(a, ii);
@@ -378,7 +402,7 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_field(MpArgs a) {
     {
         PlSpan span = {0, 0, 0, 0};
         if (active) span = pl_span(a.pairCount, a.listStride, g);
-        for (int k = 0; k < span.total; k++) {
+        for (int k = q; k < span.total; k += MP_SPLIT) {
             const int entry = pl_at(a.pairList, a.listStride, a.listSubcap, span, k, g);
             const int j = scan_atom(a, entry & PL_POS_MASK);
             const PairScale sc = pair_scale(a, rowBegin, entry);
@@ -388,9 +412,18 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_field(MpArgs a) {
             double dx = s.x - xi.x, dy = s.y - xi.y, dz = s.z - xi.z;
             min_image_d(dx, dy, dz, a.box);
             const double r2 = dx * dx + dy * dy + dz * dz;
-            if (r2 > a.cutoff2) continue;
             double bn[6], cn[6], lam[5];
-            pair_chains(a.alpha, r2, dampI, s.damp, tholeI, s.thole, bn, cn, lam);
+            const bool inside = !(r2 > a.cutoff2);
+            if (inside) pair_chains(a.alpha, r2, dampI, s.damp, tholeI, s.thole, bn, cn, lam);
+            if (a.pairCache != nullptr) {
+                // what the induced-dipole field of every solver iteration needs of this pair (k_mp_dipole_field): geometry and the two
+                // coefficients of the damped chain -- the erfc / exp / Thole arithmetic is done once per evaluation, not once per iteration
+                const size_t plane = (size_t) a.pairCap * a.listStride, at = (size_t) k * a.listStride + g;
+                a.pairCache[at] = dx; a.pairCache[plane + at] = dy; a.pairCache[2 * plane + at] = dz;
+                a.pairCache[3 * plane + at] = inside ? bn[1] - (1.0 - lam[1]) * cn[1] : 0.0;
+                a.pairCache[4 * plane + at] = inside ? bn[2] - (1.0 - lam[2]) * cn[2] : 0.0;
+            }
+            if (!inside) continue;
             const V3 r = v3(dx, dy, dz);
             const V3 Qr = mul(s.Q, r);
             const double mur = dot(s.mu, r), rQr = dot(r, Qr);
@@ -401,7 +434,8 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_field(MpArgs a) {
             ep = ep + (-s.q * b1 + b2 * mur - b3 * rQr) * r - b1 * s.mu + (2.0 * b2) * Qr;
         }
     }
-    if (!active) return;
+    ed = split_sum(ed); ep = split_sum(ep);
+    if (!active || q != 0) return;
     // reciprocal field -grad phi (the grid carries the Coulomb constant: taken out again) and the self field 4 alpha^3 / (3 sqrt(pi)) mu
     const double* phi = a.phi + 20 * (size_t) i;
     const double selfTerm = (4.0 / 3.0) * a.alpha * a.alpha * a.alpha / MP_SQRT_PI;
@@ -434,7 +468,7 @@ __device__ __forceinline__ void in_potential(double q, V3 mu, const Sym& Q, cons
 
 __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
     __shared__ double sEnergy[MP_BLOCK / 64];
-    const int t = threadIdx.x, g = blockIdx.x * MP_BLOCK + t, i = scan_atom(a, g);
+    const int t = threadIdx.x, g = (blockIdx.x * MP_BLOCK + t) / MP_SPLIT, q = t % MP_SPLIT, i = scan_atom(a, g);
     const bool active = i >= 0;
     const int ii = active ? i : 0;
     const V3 xi = position(a, ii);
@@ -450,7 +484,7 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
     {
         PlSpan span = {0, 0, 0, 0};
         if (active) span = pl_span(a.pairCount, a.listStride, g);
-        for (int k = 0; k < span.total; k++) {
+        for (int k = q; k < span.total; k += MP_SPLIT) {
             const int entry = pl_at(a.pairList, a.listStride, a.listSubcap, span, k, g);
             const int j = scan_atom(a, entry & PL_POS_MASK);
             const PairScale sc = pair_scale(a, rowBegin, entry);
@@ -496,7 +530,9 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
             }
         }
     }
-    if (active) {
+    force = split_sum(force); torque = split_sum(torque); energy = split_sum(energy);
+    if (q != 0) energy = 0.0;
+    if (active && q == 0) {
         // pair quantities carry the Coulomb constant from here on
         force = OMM_ONE_4PI_EPS0_D * force; torque = OMM_ONE_4PI_EPS0_D * torque; energy *= OMM_ONE_4PI_EPS0_D;
         const V3 nu = 0.5 * (udI + upI);
@@ -548,7 +584,7 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
 
 __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const double* __restrict__ vD, const double* __restrict__ vP, const double* __restrict__ phiD,
                                                               const double* __restrict__ phiP, double* __restrict__ outD, double* __restrict__ outP) {
-    const int t = threadIdx.x, g = blockIdx.x * MP_BLOCK + t, i = scan_atom(a, g);
+    const int t = threadIdx.x, g = (blockIdx.x * MP_BLOCK + t) / MP_SPLIT, q = t % MP_SPLIT, i = scan_atom(a, g);
     const bool active = i >= 0;
     const int ii = active ? i : 0;
     const V3 xi = position(a, ii);
@@ -557,24 +593,34 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const do
     {
         PlSpan span = {0, 0, 0, 0};
         if (active) span = pl_span(a.pairCount, a.listStride, g);
-        for (int k = 0; k < span.total; k++) {
+        for (int k = q; k < span.total; k += MP_SPLIT) {
             const int j = scan_atom(a, pl_at(a.pairList, a.listStride, a.listSubcap, span, k, g) & PL_POS_MASK);
-            struct { double x, y, z, thole, damp; V3 vd, vp; } s;
-            { const V3 x = position(a, j); s.x = x.x; s.y = x.y; s.z = x.z; }
-            s.thole = a.thole[j]; s.damp = a.damping[j]; s.vd = load3(vD, j); s.vp = load3(vP, j);
-            double dx = s.x - xi.x, dy = s.y - xi.y, dz = s.z - xi.z;
-            min_image_d(dx, dy, dz, a.box);
-            const double r2 = dx * dx + dy * dy + dz * dz;
-            if (r2 > a.cutoff2) continue;
-            double bn[6], cn[6], lam[5];
-            pair_chains(a.alpha, r2, dampI, s.damp, tholeI, s.thole, bn, cn, lam);
-            const V3 r = v3(dx, dy, dz);
-            const double b1 = bn[1] - (1.0 - lam[1]) * cn[1], b2 = bn[2] - (1.0 - lam[2]) * cn[2];
+            struct { V3 vd, vp; } s;
+            s.vd = load3(vD, j); s.vp = load3(vP, j);
+            V3 r;
+            double b1, b2;
+            if (a.pairCache != nullptr) {
+                const size_t plane = (size_t) a.pairCap * a.listStride, at = (size_t) k * a.listStride + g;
+                r = v3(a.pairCache[at], a.pairCache[plane + at], a.pairCache[2 * plane + at]);
+                b1 = a.pairCache[3 * plane + at]; b2 = a.pairCache[4 * plane + at];
+            }
+            else {
+                const V3 xj = position(a, j);
+                double dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
+                min_image_d(dx, dy, dz, a.box);
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                if (r2 > a.cutoff2) continue;
+                double bn[6], cn[6], lam[5];
+                pair_chains(a.alpha, r2, dampI, a.damping[j], tholeI, a.thole[j], bn, cn, lam);
+                r = v3(dx, dy, dz);
+                b1 = bn[1] - (1.0 - lam[1]) * cn[1]; b2 = bn[2] - (1.0 - lam[2]) * cn[2];
+            }
             ed = ed + (b2 * dot(s.vd, r)) * r - b1 * s.vd;
             ep = ep + (b2 * dot(s.vp, r)) * r - b1 * s.vp;
         }
     }
-    if (!active) return;
+    ed = split_sum(ed); ep = split_sum(ep);
+    if (!active || q != 0) return;
     const double selfTerm = (4.0 / 3.0) * a.alpha * a.alpha * a.alpha / MP_SQRT_PI, invK = 1.0 / OMM_ONE_4PI_EPS0_D;
     const double* pd = phiD + 20 * (size_t) i;
     const double* pp = phiP + 20 * (size_t) i;
@@ -711,13 +757,14 @@ bool make_args(const ommhip_amoeba_multipole* mp, const void* pos_d, const doubl
     a.pairList = mp->pair_list; a.pairCount = mp->pair_count; a.listStride = a.numScan; a.listSubcap = mp->pair_cap / PL_PARTS;
     if (a.listSubcap < 1) return false;
     a.specScaleSorted = (const double4*) mp->special_scale_sorted;
+    a.pairCache = a.mutual ? mp->pair_cache : nullptr; a.pairCap = a.listSubcap * PL_PARTS;
     return true;
 }
 
 int spread_blocks(const MpArgs& a) { return (int) (((size_t) a.n * MP_SPREAD_LANES + 255) / 256); }
 
-// number of workgroups of the pair kernels (one thread per scan position)
-int scan_blocks(const MpArgs& a) { return (a.numScan + MP_BLOCK - 1) / MP_BLOCK; }
+// number of workgroups of the pair kernels (MP_SPLIT threads per scan position)
+int scan_blocks(const MpArgs& a) { return (int) (((size_t) a.numScan * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK); }
 
 // the pair lists of this evaluation (amoeba_pairs.h); -2: the lists did not fit into pair_cap entries per atom (*pair_needed says how many would)
 int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st) {
@@ -745,7 +792,7 @@ int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const doub
     hipMemsetAsync(a.grid, 0, gridBytes, st);
     hipLaunchKernelGGL(k_mp_spread<false>, dim3(spread_blocks(a)), dim3(256), 0, st, a, (const double*) nullptr, 0.0, (const double*) nullptr, 0.0);
     ommhip_pme_convolve(pme, st);
-    hipLaunchKernelGGL(k_mp_potential, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.phi);
+    hipLaunchKernelGGL(k_mp_potential, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phi);
     hipLaunchKernelGGL(k_mp_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
     return 0;
 }
@@ -756,7 +803,7 @@ void dipole_potential(const ommhip_pme* pme, const MpArgs& a, const double* dipo
     hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, st);
     hipLaunchKernelGGL(k_mp_spread<true>, dim3(spread_blocks(a)), dim3(256), 0, st, a, dipoles, 1.0, (const double*) nullptr, 0.0);
     ommhip_pme_convolve(pme, st);
-    hipLaunchKernelGGL(k_mp_potential, dim3(blocks), dim3(MP_BLOCK), 0, st, a, out);
+    hipLaunchKernelGGL(k_mp_potential, dim3(spread_blocks(a)), dim3(256), 0, st, a, out);
 }
 
 // Mutual polarization: conjugate gradients from the direct-polarization dipoles.  Leaves mu_d, mu_p and their potentials (phiInd, phiIndP).
@@ -832,7 +879,7 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
         hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, st);
         hipLaunchKernelGGL(k_mp_spread<true>, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.indD, 0.5, a.indP, 0.5);
         ommhip_pme_convolve(pme, st);
-        hipLaunchKernelGGL(k_mp_potential, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.phiInd);
+        hipLaunchKernelGGL(k_mp_potential, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phiInd);
     }
     hipLaunchKernelGGL(k_mp_forces, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_mp_torque_to_force, dim3(blocks), dim3(MP_BLOCK), 0, st, a);

@@ -29,9 +29,10 @@ namespace omm {
 #define PL_MAX_ROW 126            // listed partners per atom that an entry can index
 #define PL_PARTS 4
 #define PL_FAR_CHUNK 4096          // tiles whose far / near flags are held in LDS at a time
+#define PL_ROW_LDS 40              // listed partners per atom that the builder keeps in LDS (longer rows go on in global memory)
 
 struct PairListArgs {
-    int n, numScan, skipTiles, subcap, stride, excludeListed;      // subcap: entries per sub-list
+    int n, numScan, skipTiles, subcap, stride, excludeListed, debug;      // subcap: entries per sub-list
     const double4* pos; const int* order; const int* slotOfAtom;
     BoxD box; double cutoff2;
     double4* tileCenter; double4* tileHalf;
@@ -131,8 +132,13 @@ __global__ __launch_bounds__(PL_BLOCK) void pl_build(PairListArgs a) {
         }
     }
     const int rowBegin = a.rowStart != nullptr ? a.rowStart[ii] : 0, rowEnd = a.rowStart != nullptr ? a.rowStart[ii + 1] : 0;
+    // The atom's listed partners, in LDS: a global load inside the candidate loop would have to wait for every list store issued before
+    // it (loads and stores share one in-order counter on this chip) -- a memory round trip per partner and lane, serialised over the wave.
+    __shared__ int sRow[PL_ROW_LDS][PL_BLOCK];
+    for (int cc = 0; cc < PL_ROW_LDS && rowBegin + cc < rowEnd; cc++) sRow[cc][t] = a.rowPos[rowBegin + cc];
+#define PL_PARTNER(cur) ((cur) < rowEnd ? ((cur) - rowBegin < PL_ROW_LDS ? sRow[(cur) - rowBegin][t] : a.rowPos[cur]) : 0x7fffffff)
     int cursor = rowBegin;
-    int next = cursor < rowEnd ? a.rowPos[cursor] : 0x7fffffff;
+    int next = PL_PARTNER(cursor);
     int cnt = 0;
     bool over = false;
     int* const myList = a.list + (size_t) part * a.subcap * a.stride + g;
@@ -169,29 +175,45 @@ __global__ __launch_bounds__(PL_BLOCK) void pl_build(PairListArgs a) {
                 __syncthreads();
                 if (!active) continue;
                 const int nj = min(PL_BLOCK, a.numScan - j0);
-                for (int k = 0; k < nj; k++) {
-                    const int j = j0 + k;
-                    const double4 p = sj[k];
-                    if (j == g || p.w < 0.0) continue;
-                    if (a.cutoff2 >= 0.0) {
-                        double dx = p.x - xi.x, dy = p.y - xi.y, dz = p.z - xi.z;
-                        if (!tileFrame) min_image_d(dx, dy, dz, a.box);
-                        if (dx * dx + dy * dy + dz * dz > a.cutoff2) continue;
+                // four candidates per round: their LDS reads are in flight together and the distance tests are straight-line code (one
+                // candidate per round is a chain of read -> wait -> compare -> branch, with nothing to overlap it at two waves per SIMD)
+                for (int k = 0; k < nj; k += 4) {
+                    double4 p[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) p[u] = sj[min(k + u, PL_BLOCK - 1)];
+                    bool inside[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int j = j0 + k + u;
+                        inside[u] = k + u < nj && j != g && p[u].w >= 0.0;
+                        if (a.cutoff2 >= 0.0) {
+                            double dx = p[u].x - xi.x, dy = p[u].y - xi.y, dz = p[u].z - xi.z;
+                            if (!tileFrame) min_image_d(dx, dy, dz, a.box);
+                            inside[u] = inside[u] && !(dx * dx + dy * dy + dz * dz > a.cutoff2);
+                        }
                     }
-                    while (next < j) { cursor++; next = cursor < rowEnd ? a.rowPos[cursor] : 0x7fffffff; }
-                    int tag = 0;
-                    if (next == j) {
-                        if (a.excludeListed) continue;
-                        tag = cursor - rowBegin + 1;
-                        if (tag > PL_MAX_ROW) over = true;
+                    if ((a.debug & 1) && p[0].x != 12345.0) continue;          // profiling: no appends
+                    if (!(inside[0] || inside[1] || inside[2] || inside[3])) continue;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (!inside[u]) continue;
+                        const int j = j0 + k + u;
+                        while (next < j) { cursor++; next = PL_PARTNER(cursor); }
+                        int tag = 0;
+                        if (next == j) {
+                            if (a.excludeListed) continue;
+                            tag = cursor - rowBegin + 1;
+                            if (tag > PL_MAX_ROW) over = true;
+                        }
+                        if (cnt < a.subcap && !(a.debug & 2)) myList[(size_t) cnt * a.stride] = j | (tag << 24);          // (debug 2: profiling without the stores)
+                        else over = true;
+                        cnt++;
                     }
-                    if (cnt < a.subcap) myList[(size_t) cnt * a.stride] = j | (tag << 24);
-                    else over = true;
-                    cnt++;
                 }
             }
         }
     }
+#undef PL_PARTNER
     if (g < a.numScan) a.count[(size_t) part * a.stride + g] = min(cnt, a.subcap);
     if (over) atomicMax(a.overflow, cnt > a.subcap ? cnt : 0x7fffffff);       // the sub-list length that would have been enough (or: a row too long to index)
 }
@@ -216,6 +238,8 @@ __device__ __forceinline__ int pl_at(const int* list, int stride, int subcap, co
 // (*needed = the longest list, or 0x7fffffff when a row of listed partners is too long to index).  `overflowHost` = pinned or plain host int.
 static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st) {
     if (a.numScan > PL_POS_MASK) return 1;
+    static const int debugMode = getenv("OPENMM_HIP_PL_DEBUG") != nullptr ? atoi(getenv("OPENMM_HIP_PL_DEBUG")) : 0;     // profiling only: wrong results
+    a.debug = debugMode;
     hipMemsetAsync(a.overflow, 0, sizeof(int), st);
     if (a.rowStart != nullptr) hipLaunchKernelGGL(pl_sort_rows, dim3((a.n + 127) / 128), dim3(128), 0, st, a);
     const int tiles = (a.numScan + PL_BLOCK - 1) / PL_BLOCK;

@@ -476,7 +476,25 @@ def main():
                                                  "bench.py --gpus N reports for N > 1)" % (sw.name, sw.num_atoms, "x".join(str(g) for g in snb.getPMEParametersInContext(sctx)[1:])),
                                      "value": round(MR.ns_per_day(s_elapsed, args.steps, args.dt_fs), 3), "unit": "ns/day",
                                      "ms_per_step": round(1e3 * s_elapsed / args.steps, 5), "steps": args.steps, "prepare_steps": default_prepare(sw)}
+            sgrid = snb.getPMEParametersInContext(sctx)[1:]
             sctx.close()
+            if not args.no_roofline:
+                # the 3-D FFT chain of this grid on its own: the same box with reciprocal space on the main stream (in the timed run above the
+                # chain shares the chip with the pair kernel on a side stream, and its timer measures that overlap), HIP events around the chain
+                fsys, fnb, finteg, fctx = start_platform(sw, "HIP", dt_ps, 5, {"DeviceIndex": str(local_rank), "DisablePmeStream": "true"}, seed=1, prepare=0)
+                kernels.lib.ommhip_profile_reset()
+                kernels.lib.ommhip_profile_enable_timers(1, 0x1f, 64)
+                finteg.step(40)
+                fctx.getState(getEnergy=True)
+                kernels.lib.ommhip_profile_enable(0)
+                ft = collect_timers(kernels)["pme_fft"]
+                fctx.close()
+                if ft["avg_us"]:
+                    hc = sgrid[0] * sgrid[1] * (sgrid[2] // 2 + 1)
+                    fa = 96.0 * hc / (ft["avg_us"] * 1e-6) / 1e9
+                    out["scale_workload"]["roofline_fft"] = {"bound": "hbm", "kernel": "forward plane transforms + x transform with convolution + backward plane transforms, reciprocal space on the main stream",
+                                                             "grid": list(sgrid), "algorithmic_bytes": 96 * hc, "avg_us": round(ft["avg_us"], 3), "achieved": round(fa, 2), "peak": HBM_PEAK_GBPS,
+                                                             "unit": "GB/s", "frac": round(fa / HBM_PEAK_GBPS, 5), "calls": ft["calls"]}
         except Exception as e:
             out["scale_workload"] = {"value": None, "error": str(e)}
     # ---- N = 1: driver-timed figures for BASELINE.json configs[2] (apoa1-sized) and for the benchmark script's own 4 fs step

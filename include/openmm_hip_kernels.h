@@ -291,7 +291,9 @@ typedef struct ommhip_pme {
                                 *    blocks that reach it and written once (no global atomics, no cleared grid needed); needs the tile_* and
                                 *    block_* fields below, a rectangular box and >= 32 cells per axis, else mode 0 is used */
     int grid_precleared;       /* 1: the caller zeroed grid_real on this stream already (fused clear), skip the memset */
-    int fft_mode;              /* 0: fused (y,z) plane kernel when a plane fits in LDS (default), 1: always separate line passes */
+    int fft_mode;              /* 0: fused (y,z) plane kernels where they pay (default: the small one when a plane fits two LDS buffers, the large
+                                * in-place one for planes up to 192 x 192 and at least 64 of them), 1: always separate line passes, 2: tests -- the
+                                * large plane kernel whenever the plane fits it */
     /* Optional: the Ewald exclusion correction (ReferenceLJCoulombIxn.cpp:462-523) folded into the interpolation
      * launch -- the lanes that gather an atom's 125 grid points also sum -qq erf(alpha r)/r over its excluded
      * partners, so the correction costs no launch and no extra atomics.  excl_start == NULL disables it. */

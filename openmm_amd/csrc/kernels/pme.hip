@@ -1338,12 +1338,15 @@ int lines_per_group(int n) {
 
 // which fused plane kernel takes the (y, z) half of this grid: 1 the small one (two LDS buffers), 2 the large one (one workgroup
 // per CU, in place), 0 neither (line passes)
-int plane_kernel_kind(const ommhip_pme* pme) {
+int plane_kernel_kind(const ommhip_pme* pme, int planes) {
     const int ny = pme->ny, nz = pme->nz;
     if (pme->fft_mode == 1 || ny > 256 || nz > 256) return 0;
     if (nz * (ny + 1) <= PLANE_MAX) return 1;
     static const bool noBig = getenv("OPENMM_HIP_NO_BIG_PLANE") != nullptr;            // A/B knob
     if (noBig || nz % 2 != 0 || (nz / 2 + 1) * (ny + 1) > BIGPLANE_CAP || make_plan(nz / 2).n != nz / 2) return 0;
+    // a workgroup of the large kernel takes ~50 us whatever the number of planes: a thin slab (8 ranks of a 192^3 grid: 24 planes) is
+    // served faster by the two line-pass launches (measured with the ranks serialised on one GPU: 0.59-0.66 against 0.62-0.70 ms per step)
+    if (planes < 64 && pme->fft_mode != 2) return 0;
     return 2;
 }
 
@@ -1376,7 +1379,7 @@ FftArgs make_xconv_args(const ommhip_pme* pme, double* energy_buffer_d, int ener
 void launch_yz(const ommhip_pme* pme, bool forward, hipStream_t st) {
     const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
     float2* cgrid = (float2*) pme->grid_complex;
-    if (const int kind = plane_kernel_kind(pme)) {
+    if (const int kind = plane_kernel_kind(pme, nx)) {
         PlaneArgs p = make_plane_args(pme, forward);
         p.cplx = cgrid;
         if (kind == 1) hipLaunchKernelGGL(fft_plane_kernel, dim3(nx), dim3(PLANE_THREADS), 0, st, p);
@@ -1538,7 +1541,7 @@ void launch_yz_dd(const ommhip_pme* pme, bool forward, float* realOwn, hipStream
     const int R = pme->dd_ranks, nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1, nxl = nx / R, nyl = ny / R;
     float2* A = (float2*) pme->grid_complex;
     float2* B = (float2*) pme->grid_complex2;
-    if (const int kind = plane_kernel_kind(pme)) {
+    if (const int kind = plane_kernel_kind(pme, nxl)) {
         PlaneArgs p = make_plane_args(pme, forward);
         p.real = realOwn; p.cplx = A; p.nxl = nxl; p.nyl = nyl;
         if (kind == 1) hipLaunchKernelGGL(fft_plane_kernel, dim3(nxl), dim3(PLANE_THREADS), 0, st, p);

@@ -32,7 +32,9 @@ def run(shrink, steps):
     # come back with the energy of the complete list at the up-to-date positions, not with a sum over the rows that fitted
     e = c.getState(getEnergy=True).potentialEnergy
     st = c.getState(getPositions=True, getVelocities=True, getEnergy=True)
-    assert abs(e - st.potentialEnergy) < 1e-9 * max(abs(e), 1.0), (e, st.potentialEnergy)
+    # (two evaluations of one configuration differ by ~1e-9 of the energy on the GPU: the charge grid is summed with float atomics; an energy from
+    # an incomplete list is off by 1e-3 and more)
+    assert abs(e - st.potentialEnergy) < 1e-7 * max(abs(e), 1.0), (e, st.potentialEnergy)
     c.close()
     return st
 

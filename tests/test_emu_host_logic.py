@@ -161,7 +161,7 @@ def test_fft_large_plane_kernel(K, ng):
     the real z transform as a half-length complex one + split / recombination): radices 8 4 3 | 5 7 | 8 8 3, self-paired and
     odd half lengths, against numpy's rfftn and a round trip."""
     assert ng[2] * (ng[1] + 1) > 9472          # beyond PLANE_MAX: the small plane kernel does not take these
-    fwd, back = KC.run_fft(K, ng, fft_mode=0)
+    fwd, back = KC.run_fft(K, ng, fft_mode=2)          # 2: the large plane kernel whatever the number of planes (by default only from 64 planes up)
     assert fwd < 1e-5 and back < 1e-5
 
 

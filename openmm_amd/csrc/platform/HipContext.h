@@ -206,6 +206,7 @@ public:
     bool deterministicForces = false;                        // platform property DeterministicForces: reproducible charge-grid sums (ommhip_pme::deterministic)
     int* freezeState = NULL;
     int pendingReplay = 0;                                   // skipped steps the integrator still has to redo
+    long long currentStepIndex = -1;                         // index of the step whose updateContextState is running (-1: none); differs from stepCount while skipped steps are redone
     std::function<int()> listRecovery;                       // set by the nonbonded kernel: synchronous check; fixes the list, returns skipped steps
     std::function<bool()> listOverflowSeen;                  // set by the nonbonded kernel: do the state words last copied back (valid after a sync) show an overflow?
     std::function<void(int)> replaySteps;                    // set by the integrator kernel: redo that many steps

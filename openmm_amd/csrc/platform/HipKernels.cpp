@@ -1710,7 +1710,9 @@ void HipIntegratorBase::runSteps(ContextImpl& context, const Integrator& integra
     long long next = firstIndex;
     while (next < endIndex) {
         if (!haveForces) {
+            hip.currentStepIndex = next;             // what a force's updateContextState decides by (CMMotionRemover's frequency): the step being (re)done
             context.updateContextState();
+            hip.currentStepIndex = -1;
             context.calcForcesAndEnergy(true, false, integrator.getIntegrationForceGroups());
             if (hip.pendingReplay > 0) {             // overflowed again meanwhile: the last pendingReplay launches did nothing
                 next -= hip.pendingReplay;
@@ -1879,8 +1881,10 @@ void HipRemoveCMMotionKernel::initialize(const System& system, const CMMotionRem
     scratch.allocate(sizeof(double) * 4 * 64);
 }
 void HipRemoveCMMotionKernel::execute(ContextImpl& context) {
-    if (data.stepCount % frequency != 0) return;
     HipContext& hip = *data.hip;
+    // a step that is redone after a neighbour-list overflow carries the index it had the first time: the removal falls on the
+    // same steps as in an undisturbed run, not on all or none of the replayed ones
+    if ((hip.currentStepIndex >= 0 ? hip.currentStepIndex : (long long) data.stepCount) % frequency != 0) return;
     hip.setAsCurrent();
     // The fused step (one launch per step) already holds the momentum of the current velocities and subtracts the
     // centre-of-mass velocity itself; velocities play no role in the force evaluation in between.

@@ -40,6 +40,7 @@ struct PairListArgs {
     int* rowPos;                                   // work array: the same rows as scan positions, ascending
     double4* rowData; const double4* rowDataIn;    // optional payload carried along when the rows are re-sorted (multipole scale factors)
     int* list; int* count; int* overflow;
+    long long* trace;                              // profiling (OPENMM_HIP_PL_DEBUG & 4): per workgroup start and end clock, hardware id
 };
 
 __device__ __forceinline__ int pl_scan_atom(const PairListArgs& a, int g) { return g < a.numScan ? (a.order != nullptr ? a.order[g] : g) : -1; }
@@ -111,6 +112,9 @@ __device__ __forceinline__ bool pl_tiles_far(const PairListArgs& a, int ti, int 
 // is expressed in the same frame, and the image of j nearest to c is then the only one that can lie within the cutoff of any atom
 // of the tile.  Other boxes and oversized tiles reduce every pair (min_image_d).
 __global__ __launch_bounds__(PL_BLOCK) void pl_build(PairListArgs a) {
+#ifndef OMMHIP_EMU
+    if (a.trace != nullptr && threadIdx.x == 0) { a.trace[3 * blockIdx.x] = (long long) wall_clock64(); a.trace[3 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long) (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf) << 32); }
+#endif
     __shared__ double4 sj[PL_BLOCK];               // .w < 0: no atom at this position
     __shared__ unsigned sNear[PL_FAR_CHUNK / 32];  // bit per candidate tile of the current chunk: within reach of this workgroup's tile
     const int tileI = blockIdx.x / PL_PARTS, part = blockIdx.x % PL_PARTS;
@@ -214,6 +218,9 @@ __global__ __launch_bounds__(PL_BLOCK) void pl_build(PairListArgs a) {
         }
     }
 #undef PL_PARTNER
+#ifndef OMMHIP_EMU
+    if (a.trace != nullptr && threadIdx.x == 0) a.trace[3 * blockIdx.x + 1] = (long long) wall_clock64();
+#endif
     if (g < a.numScan) a.count[(size_t) part * a.stride + g] = min(cnt, a.subcap);
     if (over) atomicMax(a.overflow, cnt > a.subcap ? cnt : 0x7fffffff);       // the sub-list length that would have been enough (or: a row too long to index)
 }
@@ -244,7 +251,28 @@ static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st) {
     if (a.rowStart != nullptr) hipLaunchKernelGGL(pl_sort_rows, dim3((a.n + 127) / 128), dim3(128), 0, st, a);
     const int tiles = (a.numScan + PL_BLOCK - 1) / PL_BLOCK;
     if (a.skipTiles) hipLaunchKernelGGL(pl_tile_bounds, dim3(tiles), dim3(PL_BLOCK), 0, st, a);
+    a.trace = nullptr;
+#ifndef OMMHIP_EMU
+    static long long* traceBuf = nullptr;
+    if (debugMode & 4) { if (traceBuf == nullptr) hipMalloc((void**) &traceBuf, sizeof(long long) * 3 * 65536); if (tiles * PL_PARTS <= 65536) a.trace = traceBuf; }
+#endif
     hipLaunchKernelGGL(pl_build, dim3(tiles * PL_PARTS), dim3(PL_BLOCK), 0, st, a);
+#ifndef OMMHIP_EMU
+    if (a.trace != nullptr) {
+        // wall_clock64 ticks at 100 MHz: start / end of every workgroup relative to the first start, and where it ran
+        const int n = tiles * PL_PARTS;
+        long long* h = (long long*) malloc(sizeof(long long) * 3 * n);
+        hipStreamSynchronize(st);
+        hipMemcpy(h, traceBuf, sizeof(long long) * 3 * n, hipMemcpyDeviceToHost);
+        long long t0 = h[0], t1 = h[1], life = 0, lifeMax = 0;
+        for (int b = 0; b < n; b++) { if (h[3 * b] < t0) t0 = h[3 * b]; if (h[3 * b + 1] > t1) t1 = h[3 * b + 1]; life += h[3 * b + 1] - h[3 * b]; if (h[3 * b + 1] - h[3 * b] > lifeMax) lifeMax = h[3 * b + 1] - h[3 * b]; }
+        int late = 0; for (int b = 0; b < n; b++) if (h[3 * b] - t0 > (t1 - t0) / 10) late++;
+        fprintf(stderr, "pl_build trace: %d workgroups, span %.1f us, mean life %.1f us, longest %.1f us, %d started after 10 %% of the span;", n, (t1 - t0) * 0.01, life * 0.01 / n, lifeMax * 0.01, late);
+        for (int b = 0; b < n; b += n / 12) fprintf(stderr, " [wg %d: %.0f-%.0f hw %llx]", b, (h[3 * b] - t0) * 0.01, (h[3 * b + 1] - t0) * 0.01, (unsigned long long) h[3 * b + 2]);
+        fprintf(stderr, "\n");
+        free(h);
+    }
+#endif
     int over = 0;
     hipError_t e = hipMemcpyAsync(&over, a.overflow, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);

@@ -634,10 +634,19 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const do
 // stage 1: Ap = p / alpha - t;  sums[2,3] = p.Ap
 // stage 2: mu += a p, r -= a Ap, z = alpha r;  sums[0,1] = r.z (new), sums[4,5] = z.z     (a = sums_old[0,1] / sums[2,3], given)
 // stage 3: p = z + b p                                                                      (b given)
+// The step lengths are formed on the device from the sums the previous stage left (sums[0,1] r.z of the current residual, [2,3] p.Ap,
+// [6,7] r.z of the new residual, [4,5] z.z for the convergence measure): the host reads the measure once per iteration instead of
+// fetching every dot product.  Stage 4 (one thread) moves the new r.z into place and clears the accumulators for the next iteration.
 __global__ void k_mp_cg(MpArgs a, double* w, int stage, double cD, double cP) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n3 = 3 * (size_t) a.n;
     double* sums = w + 8 * n3;
+    if (stage == 4) {
+        if (i == 0) { sums[0] = sums[6]; sums[1] = sums[7]; sums[8] = sums[4]; sums[9] = sums[5]; sums[2] = sums[3] = sums[4] = sums[5] = sums[6] = sums[7] = 0.0; }
+        return;
+    }
+    if (stage == 2) { cD = sums[2] != 0.0 ? sums[0] / sums[2] : 0.0; cP = sums[3] != 0.0 ? sums[1] / sums[3] : 0.0; }
+    if (stage == 3) { cD = sums[0] != 0.0 ? sums[6] / sums[0] : 0.0; cP = sums[1] != 0.0 ? sums[7] / sums[1] : 0.0; }
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (i < a.n) {
         const double pol = a.polarity[i], invPol = pol > 0 ? 1.0 / pol : 0.0;
@@ -667,6 +676,7 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double cD, double cP) {
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
     if ((threadIdx.x & 63) == 0) {
         if (stage == 1) { atomicAdd(&sums[2], s0); atomicAdd(&sums[3], s1); }
+        else if (stage == 2) { atomicAdd(&sums[6], s0); atomicAdd(&sums[7], s1); atomicAdd(&sums[4], s2); atomicAdd(&sums[5], s3); }
         else { atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); atomicAdd(&sums[4], s2); atomicAdd(&sums[5], s3); }
     }
 }
@@ -814,36 +824,31 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t
     double* w = mp->solver;
     double* sums = w + 8 * n3;
     double* tD = w + 6 * n3; double* tP = w + 7 * n3; double* pD = w + 4 * n3; double* pP = w + 5 * n3;
-    double h[8];
+    double h[16];
     const double debye = 48.033324;          // AmoebaReferenceMultipoleForce::_debye
-    auto readSums = [&]() -> int { hipError_t e = hipMemcpyAsync(h, sums, sizeof(double) * 8, hipMemcpyDeviceToHost, st); if (e != hipSuccess) return (int) e; return (int) hipStreamSynchronize(st); };
+    auto readSums = [&]() -> int { hipError_t e = hipMemcpyAsync(h, sums, sizeof(double) * 16, hipMemcpyDeviceToHost, st); if (e != hipSuccess) return (int) e; return (int) hipStreamSynchronize(st); };
     // T mu_0
     dipole_potential(pme, a, a.indD, a.phiInd, st);
     dipole_potential(pme, a, a.indP, a.phiIndP, st);
     hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, tD, tP);
-    hipMemsetAsync(sums, 0, sizeof(double) * 8, st);
+    hipMemsetAsync(sums, 0, sizeof(double) * 16, st);
     hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 0, 0.0, 0.0);
     int rc = readSums();
     if (rc != 0) return rc;
-    double rzD = h[0], rzP = h[1], epsilon = debye * sqrt(fmax(h[4], h[5]) / a.n);
+    double epsilon = debye * sqrt(fmax(h[4], h[5]) / a.n);
+    hipMemsetAsync(sums + 4, 0, sizeof(double) * 2, st);
     int iteration = 0;
     while (epsilon >= mp->target_epsilon && iteration < mp->max_iterations) {
         dipole_potential(pme, a, pD, a.phiInd, st);
         dipole_potential(pme, a, pP, a.phiIndP, st);
         hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP);
-        hipMemsetAsync(sums, 0, sizeof(double) * 8, st);
-        hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 1, 0.0, 0.0);
-        rc = readSums();
+        hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 1, 0.0, 0.0);      // Ap, p.Ap
+        hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 2, 0.0, 0.0);      // mu += a p, r -= a Ap (a from the device sums)
+        hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 3, 0.0, 0.0);      // p = z + b p
+        hipLaunchKernelGGL(k_mp_cg, dim3(1), dim3(64), 0, st, a, w, 4, 0.0, 0.0);                  // roll the sums
+        rc = readSums();                                                                          // the one host round trip of the iteration
         if (rc != 0) return rc;
-        const double aD = h[2] != 0.0 ? rzD / h[2] : 0.0, aP = h[3] != 0.0 ? rzP / h[3] : 0.0;
-        hipMemsetAsync(sums, 0, sizeof(double) * 8, st);
-        hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 2, aD, aP);
-        rc = readSums();
-        if (rc != 0) return rc;
-        const double bD = rzD != 0.0 ? h[0] / rzD : 0.0, bP = rzP != 0.0 ? h[1] / rzP : 0.0;
-        rzD = h[0]; rzP = h[1];
-        epsilon = debye * sqrt(fmax(h[4], h[5]) / a.n);
-        hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 3, bD, bP);
+        epsilon = debye * sqrt(fmax(h[8], h[9]) / a.n);
         iteration++;
     }
     if (mp->status != nullptr) { mp->status[0] = epsilon; mp->status[1] = iteration; }

@@ -134,6 +134,9 @@ typedef struct ommhip_amoeba_multipole {
     int pair_cap;                  /* list entries per atom (a multiple of 4: four sub-lists of pair_cap / 4); a call that needs more returns -2 */
     int* pair_overflow;            /* device int work word */
     int* pair_needed;              /* HOST int written with the return code -2: the capacity that would have been enough (or NULL) */
+    /* mutual polarization, optional: a second grid set (an ommhip_pme that shares everything but grid_real / grid_complex with `pme`), a side
+     * stream and two ordering events -- the potentials of the two dipole sets are then computed side by side */
+    void* pme2; void* stream2; void* event_a; void* event_b;
     double* pair_cache;            /* device double[5 * pair_cap * S] or NULL (mutual polarization): per list entry the separation and the two
                                     * coefficients of the damped dipole-dipole chain, written once per evaluation and read by every solver iteration */
 } ommhip_amoeba_multipole;

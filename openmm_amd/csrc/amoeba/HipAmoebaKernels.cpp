@@ -206,6 +206,7 @@ HipCalcAmoebaMultipoleForceKernel::HipCalcAmoebaMultipoleForceKernel(std::string
 
 HipCalcAmoebaMultipoleForceKernel::~HipCalcAmoebaMultipoleForceKernel() {
     delete reference;
+    if (sideStream != NULL) { data.hip->setAsCurrent(); ommhip_stream_destroy(sideStream); ommhip_event_destroy(eventA); ommhip_event_destroy(eventB); }
 }
 
 bool HipCalcAmoebaMultipoleForceKernel::supports(const AmoebaMultipoleForce& force, const System& system) {
@@ -335,6 +336,15 @@ void HipCalcAmoebaMultipoleForceKernel::upload(const AmoebaMultipoleForce& force
     mp.mutual = mutual ? 1 : 0;
     mp.max_iterations = force.getMutualInducedMaxIterations(); mp.target_epsilon = force.getMutualInducedTargetEpsilon();
     mp.phi_induced_p = mutual ? phiIndP.as<double>() : NULL; mp.solver = mutual ? solver.as<double>() : NULL; mp.status = solverStatus;
+    // mutual polarization: a second grid set and a side stream, so that the potentials of the two dipole sets are computed side by side
+    mp.pme2 = NULL; mp.stream2 = NULL; mp.event_a = mp.event_b = NULL;
+    if (mutual && getenv("OPENMM_HIP_AMOEBA_ONE_GRID") == NULL) {
+        const size_t nx = gridSize[0], ny = gridSize[1], nz = gridSize[2], nzc = nz / 2 + 1;
+        gridReal2.allocate((sizeof(float) * nx * ny * nz + 15) / 16 * 16);
+        gridComplex2.allocate(sizeof(float) * 2 * nx * ny * nzc);
+        if (sideStream == NULL) { HIP_CHECK(ommhip_stream_create(&sideStream)); HIP_CHECK(ommhip_event_create_untimed(&eventA)); HIP_CHECK(ommhip_event_create_untimed(&eventB)); }
+        mp.pme2 = &pme2; mp.stream2 = sideStream; mp.event_a = eventA; mp.event_b = eventB;
+    }
     // per-atom pair lists in the platform's slot order, rebuilt at every evaluation (amoeba_pairs.h); the order itself is set per evaluation
     const size_t tiles = ((size_t) hip.paddedAtoms + 127) / 128;
     tileBounds.allocate(sizeof(double) * 4 * 2 * max(tiles, (size_t) 1));
@@ -380,6 +390,7 @@ void HipCalcAmoebaMultipoleForceKernel::prepareGrid() {
     for (int k = 0; k < 6; k++) if (lastBox[k] != hip.box[k]) boxChanged = true;
     for (int k = 0; k < 6; k++) { pme.box[k] = hip.box[k]; lastBox[k] = hip.box[k]; }
     if (boxChanged) { HIP_CHECK(ommhip_pme_build_eterm(&pme, hip.stream)); etermBuilt = true; }
+    pme2 = pme; pme2.grid_real = gridReal2.ptr; pme2.grid_complex = gridComplex2.ptr;          // the twin: same box, tables and influence function, grids of its own
     const double minAllowedSize = 1.999999 * cutoff;
     if (hip.box[0] < minAllowedSize || hip.box[2] < minAllowedSize || hip.box[5] < minAllowedSize)
         throw OpenMMException("The periodic box size has decreased to less than twice the nonbonded cutoff.");

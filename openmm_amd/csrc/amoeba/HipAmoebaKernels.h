@@ -69,10 +69,11 @@ private:
     bool etermBuilt = false, mutual = false;
     double solverStatus[2] = {0, 0};          // epsilon reached and iterations of the last mutual-polarization solve
     ommhip_amoeba_multipole mp;
-    ommhip_pme pme;
+    ommhip_pme pme, pme2;
+    void* sideStream = NULL; void* eventA = NULL; void* eventB = NULL;
     DeviceBuffer charge, molDipole, molQuad, axis, thole, damping, polarity, specStart, specAtom, specScale;
     DeviceBuffer labDipole, labQuad, fieldD, fieldP, indD, indP, phi, phiInd, phiIndP, solver, torque, tileBounds, specPos, specScaleSorted, pairList, pairCount, pairOverflow, pairCache;
-    DeviceBuffer moduliX, moduliY, moduliZ, twiddleX, twiddleY, twiddleZ, eterm, gridReal, gridComplex;
+    DeviceBuffer moduliX, moduliY, moduliZ, twiddleX, twiddleY, twiddleZ, eterm, gridReal, gridComplex, gridReal2, gridComplex2;
 };
 
 }  // namespace OpenMM

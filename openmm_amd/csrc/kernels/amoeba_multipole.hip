@@ -816,6 +816,28 @@ void dipole_potential(const ommhip_pme* pme, const MpArgs& a, const double* dipo
     hipLaunchKernelGGL(k_mp_potential, dim3(spread_blocks(a)), dim3(256), 0, st, a, out);
 }
 
+// The potentials of two sets of dipoles.  The chain of one set -- clear, spread, three transform launches, read-back -- is six small launches
+// that leave most of the chip idle; with a second grid and a side stream (pme2, stream2, two ordering events: optional in the C ABI) the
+// chain of the second set runs beside that of the first.
+void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double* vD, double* outD, const double* vP, double* outP, hipStream_t st) {
+    const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
+    const ommhip_pme* pme2 = (const ommhip_pme*) mp->pme2;
+    if (pme2 == nullptr || mp->stream2 == nullptr || mp->event_a == nullptr || mp->event_b == nullptr || pme2->grid_real == nullptr || pme2->grid_real == pme->grid_real) {
+        dipole_potential(pme, a, vD, outD, st);
+        dipole_potential(pme, a, vP, outP, st);
+        return;
+    }
+    hipStream_t st2 = (hipStream_t) mp->stream2;
+    MpArgs a2 = a;
+    a2.grid = (float*) pme2->grid_real;
+    hipEventRecord((hipEvent_t) mp->event_a, st);                  // the dipoles (and everything else the side chain reads) are ready
+    hipStreamWaitEvent(st2, (hipEvent_t) mp->event_a, 0);
+    dipole_potential(pme2, a2, vP, outP, st2);
+    hipEventRecord((hipEvent_t) mp->event_b, st2);
+    dipole_potential(pme, a, vD, outD, st);
+    hipStreamWaitEvent(st, (hipEvent_t) mp->event_b, 0);           // the main stream goes on when both potentials are there
+}
+
 // Mutual polarization: conjugate gradients from the direct-polarization dipoles.  Leaves mu_d, mu_p and their potentials (phiInd, phiIndP).
 int solve_mutual(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t st) {
     const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
@@ -828,8 +850,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t
     const double debye = 48.033324;          // AmoebaReferenceMultipoleForce::_debye
     auto readSums = [&]() -> int { hipError_t e = hipMemcpyAsync(h, sums, sizeof(double) * 16, hipMemcpyDeviceToHost, st); if (e != hipSuccess) return (int) e; return (int) hipStreamSynchronize(st); };
     // T mu_0
-    dipole_potential(pme, a, a.indD, a.phiInd, st);
-    dipole_potential(pme, a, a.indP, a.phiIndP, st);
+    dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st);
     hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, tD, tP);
     hipMemsetAsync(sums, 0, sizeof(double) * 16, st);
     hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 0, 0.0, 0.0);
@@ -839,8 +860,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t
     hipMemsetAsync(sums + 4, 0, sizeof(double) * 2, st);
     int iteration = 0;
     while (epsilon >= mp->target_epsilon && iteration < mp->max_iterations) {
-        dipole_potential(pme, a, pD, a.phiInd, st);
-        dipole_potential(pme, a, pP, a.phiIndP, st);
+        dipole_potentials(mp, a, pD, a.phiInd, pP, a.phiIndP, st);
         hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP);
         hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 1, 0.0, 0.0);      // Ap, p.Ap
         hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 2, 0.0, 0.0);      // mu += a p, r -= a Ap (a from the device sums)
@@ -853,8 +873,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t
     }
     if (mp->status != nullptr) { mp->status[0] = epsilon; mp->status[1] = iteration; }
     // potentials of the converged dipoles (the force kernels read them)
-    dipole_potential(pme, a, a.indD, a.phiInd, st);
-    dipole_potential(pme, a, a.indP, a.phiIndP, st);
+    dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st);
     return epsilon < mp->target_epsilon ? 0 : -1;
 }
 

@@ -18,6 +18,10 @@
 //   flush    the LDS list is cut into 64-entry rows and written out; chunk indices come from one global atomic.
 #include "common.h"
 #include "../../../include/openmm_hip_kernels.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 using namespace omm;
 
@@ -51,6 +55,7 @@ struct NlArgs {
     int ddMode;                       // domain decomposition: partners are Y >= X plus the foreign blocks below firstBlock
     const uint4* posWire;             // DD: all positions as fixed-point box fractions, slot order (the all-gathered buffer)
     double4* posScatter;              // DD: atom-ordered positions, refreshed for foreign slots by nl_prepare
+    long long* trace;                 // profiling (OPENMM_HIP_NL_TRACE): per workgroup start / end clock of a rebuild
     int pbc;                 // 0 none, 1 orthorhombic, 2 triclinic
     float listCutoff2;       // (cutoff + padding)^2, +inf for NoCutoff
     float maxDisp2;          // (padding/2)^2
@@ -879,7 +884,14 @@ static void launch_prune(const NlArgs& a, hipStream_t st) {
 template <int PBC>
 __global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
     __shared__ NlShared sh;
+#ifndef OMMHIP_EMU
+    const bool traced = a.trace != nullptr && a.state[ST_REBUILD] != 0;          // profiling (OPENMM_HIP_NL_TRACE): start and end of every workgroup
+    if (traced && threadIdx.x == 0) a.trace[2 * blockIdx.x] = (long long) wall_clock64();
+#endif
     nl_find_body<PBC>(a, a.firstBlock + blockIdx.x, gridDim.x, sh);
+#ifndef OMMHIP_EMU
+    if (traced && threadIdx.x == 0) a.trace[2 * blockIdx.x + 1] = (long long) wall_clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1017,7 +1029,7 @@ NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
     a.firstBlock = 0; a.ownedBlocks = a.numBlocks;
     if (nl->owned_blocks > 0 && nl->first_block >= 0 && nl->first_block + nl->owned_blocks <= a.numBlocks) { a.firstBlock = nl->first_block; a.ownedBlocks = nl->owned_blocks; }
     a.ddMode = nl->dd_mode != 0 && a.ownedBlocks < a.numBlocks ? 1 : 0;
-    a.posWire = (const uint4*) nl->pos_wire; a.posScatter = (double4*) nl->pos_scatter;
+    a.posWire = (const uint4*) nl->pos_wire; a.posScatter = (double4*) nl->pos_scatter; a.trace = nullptr;
     a.numActive = 0; a.activeTotal = a.paddedAtoms;
     for (int r = 0; r < 4; r++) { a.activeBegin[r] = 0; a.activeEnd[r] = 0; }
     if (a.ddMode && nl->num_active_ranges > 0 && nl->num_active_ranges <= 4) {
@@ -1069,11 +1081,40 @@ NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
 
 }  // namespace
 
-static void launch_find(const NlArgs& a, hipStream_t st) {
+static void launch_find(const NlArgs& ain, hipStream_t st) {
+    NlArgs a = ain;
+    a.trace = nullptr;
+#ifndef OMMHIP_EMU
+    static const bool tracing = getenv("OPENMM_HIP_NL_TRACE") != nullptr;
+    static long long* traceBuf = nullptr;
+    if (tracing && a.ownedBlocks <= 65536) {
+        if (traceBuf == nullptr) hipMalloc((void**) &traceBuf, sizeof(long long) * 2 * 65536);
+        hipMemsetAsync(traceBuf, 0, sizeof(long long) * 2 * a.ownedBlocks, st);
+        a.trace = traceBuf;
+    }
+#endif
     if (a.cellMode) hipLaunchKernelGGL(nl_bin_blocks, dim3(1), dim3(1024), 0, st, a);
     if (a.pbc == 0) hipLaunchKernelGGL(nl_find_interactions<0>, dim3(a.ownedBlocks), dim3(NL_THREADS), 0, st, a);
     else if (a.pbc == 1) hipLaunchKernelGGL(nl_find_interactions<1>, dim3(a.ownedBlocks), dim3(NL_THREADS), 0, st, a);
     else hipLaunchKernelGGL(nl_find_interactions<2>, dim3(a.ownedBlocks), dim3(NL_THREADS), 0, st, a);
+#ifndef OMMHIP_EMU
+    if (a.trace != nullptr) {
+        // wall_clock64 ticks at 100 MHz.  Printed only for launches that rebuilt the list.
+        const int n = a.ownedBlocks;
+        std::vector<long long> h(2 * (size_t) n);
+        hipStreamSynchronize(st);
+        hipMemcpy(h.data(), a.trace, sizeof(long long) * 2 * n, hipMemcpyDeviceToHost);
+        if (h[0] != 0) {
+            long long t0 = h[0], t1 = h[1], life = 0;
+            std::vector<long long> lives(n);
+            for (int b = 0; b < n; b++) { t0 = std::min(t0, h[2 * b]); t1 = std::max(t1, h[2 * b + 1]); lives[b] = h[2 * b + 1] - h[2 * b]; life += lives[b]; }
+            std::vector<long long> sorted(lives); std::sort(sorted.begin(), sorted.end());
+            long long lastStart = 0; for (int b = 0; b < n; b++) lastStart = std::max(lastStart, h[2 * b] - t0);
+            fprintf(stderr, "nl_find trace: %d workgroups, span %.1f us, last start at %.1f us, life mean %.1f median %.1f p99 %.1f max %.1f us\n", n, (t1 - t0) * 0.01, lastStart * 0.01,
+                    life * 0.01 / n, sorted[n / 2] * 0.01, sorted[(size_t) n * 99 / 100] * 0.01, sorted[n - 1] * 0.01);
+        }
+    }
+#endif
     launch_prune(a, st);
 }
 

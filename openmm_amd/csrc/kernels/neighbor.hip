@@ -894,6 +894,20 @@ __global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
 #endif
 }
 
+// The same builder with resident workgroups that walk through the i-blocks (grid = a few workgroups per compute unit): at a million
+// atoms the one-block-per-workgroup launch keeps ~3.4 workgroups per CU in flight although 7 fit (30 798 workgroups living 66 us each
+// arrive at ~13 per microsecond: `OPENMM_HIP_NL_TRACE`).  Same-box A/B (`profiles/r05x_ab_resident_builder.txt`): 985 527 atoms 2.298 -> 2.22 ms per
+// step with 7, 10 or 14 workgroups per CU, 92 224 atoms 0.2950 -> 0.2888.  OPENMM_HIP_NL_PERSISTENT=<per CU> (default 8, 0 = one workgroup per block).
+template <int PBC>
+__global__ __launch_bounds__(NL_THREADS) void nl_find_interactions_resident(NlArgs a) {
+    __shared__ NlShared sh;
+    if (a.state[ST_REBUILD] == 0) return;          // read once: the last block to finish clears the request, and by then no block is left
+    for (int b = blockIdx.x; b < a.ownedBlocks; b += gridDim.x) {
+        nl_build_body<PBC>(a, a.firstBlock + b, a.ownedBlocks, sh);
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused per-step front end (one launch instead of three): double positions -> wrapped float posq,
 // displacement check against posqRef, and the block bounding boxes (recomputed every step; they are
@@ -1094,7 +1108,16 @@ static void launch_find(const NlArgs& ain, hipStream_t st) {
     }
 #endif
     if (a.cellMode) hipLaunchKernelGGL(nl_bin_blocks, dim3(1), dim3(1024), 0, st, a);
-    if (a.pbc == 0) hipLaunchKernelGGL(nl_find_interactions<0>, dim3(a.ownedBlocks), dim3(NL_THREADS), 0, st, a);
+    static const int residentPerCu = getenv("OPENMM_HIP_NL_PERSISTENT") != nullptr ? atoi(getenv("OPENMM_HIP_NL_PERSISTENT")) : 8;     // 0: one workgroup per i-block, as before
+    static int numCus = 0;
+    if (residentPerCu > 0 && numCus == 0) { hipDeviceProp_t prop; int dev = 0; hipGetDevice(&dev); numCus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256; }
+    if (residentPerCu > 0 && a.ownedBlocks > residentPerCu * numCus && a.trace == nullptr) {
+        const dim3 grid(residentPerCu * numCus);
+        if (a.pbc == 0) hipLaunchKernelGGL(nl_find_interactions_resident<0>, grid, dim3(NL_THREADS), 0, st, a);
+        else if (a.pbc == 1) hipLaunchKernelGGL(nl_find_interactions_resident<1>, grid, dim3(NL_THREADS), 0, st, a);
+        else hipLaunchKernelGGL(nl_find_interactions_resident<2>, grid, dim3(NL_THREADS), 0, st, a);
+    }
+    else if (a.pbc == 0) hipLaunchKernelGGL(nl_find_interactions<0>, dim3(a.ownedBlocks), dim3(NL_THREADS), 0, st, a);
     else if (a.pbc == 1) hipLaunchKernelGGL(nl_find_interactions<1>, dim3(a.ownedBlocks), dim3(NL_THREADS), 0, st, a);
     else hipLaunchKernelGGL(nl_find_interactions<2>, dim3(a.ownedBlocks), dim3(NL_THREADS), 0, st, a);
 #ifndef OMMHIP_EMU

@@ -82,7 +82,11 @@ def test_two_rank_force_decomposition_is_bit_exact(tmp_path):
         pytest.skip("emulated kernel library not built (run __graft_entry__.build())")
     script = tmp_path / "decomp_child.py"
     script.write_text(DECOMP_CHILD % (ROOT, ROOT, emu_lib))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    # OPENMM_HIP_NL_PERSISTENT=0: one builder workgroup per i-block for the whole list AND for the shares.  The comparison is bit for bit, and
+    # the order of the chunks in the list (the order in which the builder's workgroups allocate them -- deterministic only on the emulator)
+    # decides which chunks of an i-block a pair wavefront sums in float before it converts to fixed point; the resident builder
+    # workgroups that long lists get by default (the whole list here, not the shares) allocate in another order.
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", OPENMM_HIP_NL_PERSISTENT="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
                          capture_output=True, text=True, timeout=900, env=env)

@@ -243,6 +243,7 @@ void HipContext::uploadVelocities(const vector<Vec3>& velocities) {
     }
     if (numAtoms > 0) HIP_CHECK(ommhip_memcpy_h2d(vel.ptr, tmp.data(), sizeof(D4) * numAtoms, stream));
     momentumValid = false;
+    velocitiesConstrained = false;
     sync();
 }
 
@@ -494,6 +495,7 @@ void HipContext::findUnits(const System& system) {
 }
 
 void HipContext::stepTaken() {
+    velocitiesConstrained = true;
     stepsSinceReorder++;
     stepsSinceSnapshot++;
 }

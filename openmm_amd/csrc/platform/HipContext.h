@@ -236,6 +236,7 @@ public:
     // CM-motion removal folded into the fused step (HipConstraints::fusedStep): the remover only raises `pending`;
     // `momentumValid` says the device holds the total momentum of the current velocities.
     bool cmRemovalPending, momentumValid;
+    bool velocitiesConstrained = false;       // the velocities are what a native integration step left (they satisfy the constraints); false after an upload
 
 private:
     void computeOrder(const std::vector<Vec3>& positions, std::vector<int>& order, std::vector<int>& wrapOut);

@@ -931,7 +931,12 @@ void HipCalcNonbondedForceKernel::initialize(const System& system, const Nonbond
     // cover and loses again).  At a million atoms the pair kernel is throughput-bound (+16 % time for +20 % rows), but an atom
     // somewhere crosses half the padding every 2-3 steps and a rebuild costs two pair-kernel launches: 0.1 / 0.15 / 0.2 gave
     // 4.20 / 3.84 / 3.67 ms per step on one MI355X (profiles/r02c), so 0.2 it is at every size until the rebuild gets cheaper.
-    double paddingFraction = 0.2;
+    // Round 3, with the builder of today (resident workgroups, cell-sorted candidates) and a liquid at 300 K instead of the melting
+    // lattice those figures were taken on: 985 527 atoms 2.193 / 2.164 / 2.199 ms per step at 0.1 / 0.15 / 0.2, 92 224 atoms
+    // 0.284 / 0.286 / 0.289, DHFR (fused launches, where rows ride along) 0.1188 (0.12) / 0.1184 (0.16) / 0.1180 (0.2): 0.15 above
+    // the size of the fused front launch, 0.2 below (same-box A/B, profiles/r06a_ab_list_padding.txt).
+    const int fusedFrontMaxAtoms = getenv("OPENMM_HIP_FUSED_FRONT_MAX_ATOMS") != NULL ? atoi(getenv("OPENMM_HIP_FUSED_FRONT_MAX_ATOMS")) : 60000;
+    double paddingFraction = numParticles > fusedFrontMaxAtoms ? 0.15 : 0.2;
     if (getenv("OPENMM_HIP_NL_PADDING") != NULL) paddingFraction = atof(getenv("OPENMM_HIP_NL_PADDING"));   // tuning knob, fraction of the cutoff
     padding = nonbondedMethod == NoCutoff ? 0.0 : paddingFraction * nonbondedCutoff;
     if (getenv("OPENMM_HIP_DIRECT_GRID") != NULL) directGridOverride = atoi(getenv("OPENMM_HIP_DIRECT_GRID"));

@@ -35,10 +35,20 @@ template <int PBC>
 __global__ __launch_bounds__(256) void force_front(FrontArgs f) {
     __shared__ FrontShared sh;
     const int b = blockIdx.x;
+#ifndef OMM_FRONT_ORDER
+#define OMM_FRONT_ORDER 0
+#endif
+#if OMM_FRONT_ORDER == 0
     // heavy, rare work first in the grid so that it starts first
     if (b < f.nlBlocks) nl_find_body<PBC>(f.nl, f.nl.firstBlock + b, f.nlBlocks, sh.nl);
     else if (b < f.nlBlocks + f.spreadBlocks) pme_spread_body<false>(f.pme, b - f.nlBlocks, sh.spread);
     else terms_body(f.terms, b - f.nlBlocks - f.spreadBlocks, sh.termPartial);
+#else
+    // the work of every step first: the builder's workgroups, which leave at once on all steps but one in thirty, are dispatched behind it
+    if (b < f.termBlocks) terms_body(f.terms, b, sh.termPartial);
+    else if (b < f.termBlocks + f.spreadBlocks) pme_spread_body<false>(f.pme, b - f.termBlocks, sh.spread);
+    else nl_find_body<PBC>(f.nl, f.nl.firstBlock + b - f.termBlocks - f.spreadBlocks, f.nlBlocks, sh.nl);
+#endif
 }
 
 }  // namespace

@@ -56,6 +56,7 @@ struct NlArgs {
     const uint4* posWire;             // DD: all positions as fixed-point box fractions, slot order (the all-gathered buffer)
     double4* posScatter;              // DD: atom-ordered positions, refreshed for foreign slots by nl_prepare
     long long* trace;                 // profiling (OPENMM_HIP_NL_TRACE): per workgroup start / end clock of a rebuild
+    int xcdAware;                     // resident builder workgroups take the i-blocks of their XCD's eighth of the slot order
     int pbc;                 // 0 none, 1 orthorhombic, 2 triclinic
     float listCutoff2;       // (cutoff + padding)^2, +inf for NoCutoff
     float maxDisp2;          // (padding/2)^2
@@ -902,6 +903,17 @@ template <int PBC>
 __global__ __launch_bounds__(NL_THREADS) void nl_find_interactions_resident(NlArgs a) {
     __shared__ NlShared sh;
     if (a.state[ST_REBUILD] == 0) return;          // read once: the last block to finish clears the request, and by then no block is left
+    if (a.xcdAware && gridDim.x % 8 == 0) {
+        // workgroup w runs on XCD w % 8 (round-robin dispatch): it walks through the (w % 8)-th eighth of the i-blocks, whose candidate blocks
+        // -- spatial neighbours, close in the slot order -- then stay in that XCD's L2
+        const int x = blockIdx.x % 8, per = (a.ownedBlocks + 7) / 8;
+        for (int k = blockIdx.x / 8; k < per; k += gridDim.x / 8) {
+            const int b = x * per + k;
+            if (b < a.ownedBlocks) nl_build_body<PBC>(a, a.firstBlock + b, a.ownedBlocks, sh);          // block-uniform
+            __syncthreads();
+        }
+        return;
+    }
     for (int b = blockIdx.x; b < a.ownedBlocks; b += gridDim.x) {
         nl_build_body<PBC>(a, a.firstBlock + b, a.ownedBlocks, sh);
         __syncthreads();
@@ -1044,6 +1056,7 @@ NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
     if (nl->owned_blocks > 0 && nl->first_block >= 0 && nl->first_block + nl->owned_blocks <= a.numBlocks) { a.firstBlock = nl->first_block; a.ownedBlocks = nl->owned_blocks; }
     a.ddMode = nl->dd_mode != 0 && a.ownedBlocks < a.numBlocks ? 1 : 0;
     a.posWire = (const uint4*) nl->pos_wire; a.posScatter = (double4*) nl->pos_scatter; a.trace = nullptr;
+    { static const bool nlXcd = getenv("OPENMM_HIP_NL_XCD") != nullptr; a.xcdAware = nlXcd ? 1 : 0; }          // opt-in: measured +0.7 % step time at 1M atoms (docs/EXPERIMENTS.md)
     a.numActive = 0; a.activeTotal = a.paddedAtoms;
     for (int r = 0; r < 4; r++) { a.activeBegin[r] = 0; a.activeEnd[r] = 0; }
     if (a.ddMode && nl->num_active_ranges > 0 && nl->num_active_ranges <= 4) {

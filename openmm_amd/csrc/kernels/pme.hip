@@ -54,6 +54,7 @@ struct PmeArgs {
     // tile spreading (spread_mode 2): tiles of TILE^3 cells over the spread range (x: the own planes), ntx * nty * ntz of them
     int* tileCount; int* tileBlocks; int tileCap, ntx, nty, ntz, numBlocks;
     float tileScale;         // fixed-point scale of the LDS accumulation (a power of two)
+    int xcdBlocks;           // interpolation: workgroups per XCD when the launch is placed XCD-aware (0: plain order)
 };
 
 // one grid accumulation: float atomic, or -- for bit-reproducible sums -- an integer atomic on the same word
@@ -483,7 +484,12 @@ static bool launch_tile_spread(const ommhip_pme* pme, PmeArgs pa, const void* bl
 
 template <bool DD>
 __global__ __launch_bounds__(256) void pme_interpolate(PmeArgs a) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware placement (a.xcdBlocks > 0): workgroups go to the 8 XCDs round-robin by index, and every XCD has an L2 of its own; workgroup b
+    // takes the (b / 8)-th slot group of the (b % 8)-th eighth of the slots, so that an L2 sees one compact eighth of the grid (3.5 MB of a
+    // 192^3 grid) instead of all of it.  Same idea as the pair kernel's chunk placement.
+    int wg = blockIdx.x;
+    if (a.xcdBlocks > 0) { const int x = wg % 8, k = wg / 8; wg = k < a.xcdBlocks ? x * a.xcdBlocks + k : (int) gridDim.x; }
+    const int t = wg * blockDim.x + threadIdx.x;
     int slot = (DD ? a.ownSlot0 : 0) + (t >> 3);
     const int sub = t & 7;
     const bool valid = slot < (DD ? a.ownSlot1 : a.paddedAtoms);
@@ -1456,6 +1462,7 @@ static PmeArgs make_pme_args(const ommhip_pme* pme, const void* posq_d, int padd
     pa.planeLo = 0; pa.planeCount = nx; pa.haloLo = 0; pa.gridPlanes = nx; pa.ownSlot0 = 0; pa.ownSlot1 = padded_atoms;
     pa.ddError = nullptr; pa.blockCenter = nullptr; pa.blockHalf = nullptr;
     pa.detScale = pme->deterministic && pme->max_charge > 0 ? (float) (2147483648.0 / (64.0 * pme->max_charge)) : 0.f;
+    pa.xcdBlocks = 0;
     return pa;
 }
 
@@ -1505,7 +1512,13 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     ommhip_profile_end(OMMHIP_TIMER_PME_FFT, stream);
     }
     ommhip_profile_begin(OMMHIP_TIMER_PME_INTERPOLATE, stream);
-    hipLaunchKernelGGL(pme_interpolate<false>, dim3(spreadBlocks), dim3(256), 0, st, pa);
+    {
+        static const bool noXcd = getenv("OPENMM_HIP_XCD_INTERPOLATE") == nullptr;          // opt-in: measured neutral at 1M atoms, -1.7 % at 92 k (docs/EXPERIMENTS.md)
+        int blocks = spreadBlocks;
+        if (!noXcd && spreadBlocks >= 2048) { pa.xcdBlocks = (spreadBlocks + 7) / 8; blocks = pa.xcdBlocks * 8; }      // large systems: the grid no longer fits one L2
+        hipLaunchKernelGGL(pme_interpolate<false>, dim3(blocks), dim3(256), 0, st, pa);
+        pa.xcdBlocks = 0;
+    }
     ommhip_profile_end(OMMHIP_TIMER_PME_INTERPOLATE, stream);
     return (int) hipGetLastError();
 }

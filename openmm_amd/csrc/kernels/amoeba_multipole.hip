@@ -267,6 +267,94 @@ __global__ void k_mp_spread(MpArgs a, const double* __restrict__ A, double sA, c
     }
 }
 
+// Induced dipoles through LDS bricks (the scheme of the platform's charge spreading, pme.hip): one workgroup takes the 32 atoms of a block
+// of the slot order -- spatial neighbours, ~7 grid cells across --, accumulates their 125-point stencils in a 16^3 brick held in LDS (32-bit
+// fixed point, integer LDS atomics) and flushes the touched cells with z-contiguous float atomics: a few hundred memory-side transactions
+// per 32 atoms instead of ~37 per atom.  An atom whose stencil does not fit the brick adds to the grid directly.  Needs the slot order
+// (a.order); the dipoles are sA * A + sB * B as in k_mp_spread<true>.
+#define MPB_ATOMS 32
+#define MPB_BRICK 16
+#define MPB_ZS (MPB_BRICK + 1)
+__device__ __forceinline__ int mpb_wrap_rel(int d, int n) { if (d >= (n + 1) / 2) d -= n; if (d < -(n / 2)) d += n; return d; }
+
+__global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double* __restrict__ A, double sA, const double* __restrict__ B, double sB) {
+    __shared__ int brick[MPB_BRICK * MPB_BRICK * MPB_ZS];
+    __shared__ float th[MPB_ATOMS][3][5], dth[MPB_ATOMS][3][5], fd[MPB_ATOMS][3];
+    __shared__ int base[MPB_ATOMS][3], ok[MPB_ATOMS], ref[3], minRel[3];
+    __shared__ float sMax;
+    const int t = threadIdx.x, g0 = blockIdx.x * MPB_ATOMS;
+    const int n[3] = {a.nx, a.ny, a.nz};
+    if (t < 3) { minRel[t] = 1 << 30; ref[t] = -1; }
+    if (t == 0) sMax = 0.f;
+    for (int w = t; w < MPB_BRICK * MPB_BRICK * MPB_ZS; w += 256) brick[w] = 0;
+    __syncthreads();
+    // splines and fractional dipoles: thread (atom, k), k < 3: dimension k; k == 3: the dipole in grid coordinates
+    if (t < 4 * MPB_ATOMS) {
+        const int atom = t >> 2, k = t & 3, i = scan_atom(a, g0 + atom);
+        if (k == 3) ok[atom] = i >= 0;
+        if (i >= 0) {
+            if (k < 3) {
+                const V3 x = position(a, i);
+                double u = a.a[k][0] * x.x + a.a[k][1] * x.y + a.a[k][2] * x.z;
+                u -= floor(u / n[k]) * n[k];
+                int index; double w4[4][5];
+                bspline4(u, n[k], index, w4);
+                base[atom][k] = index;
+                for (int m = 0; m < 5; m++) { th[atom][k][m] = (float) w4[0][m]; dth[atom][k][m] = (float) w4[1][m]; }
+            }
+            else {
+                const V3 mu = sA * load3(A, i) + (B != nullptr ? sB * load3(B, i) : v3(0, 0, 0));
+                float sum = 0.f;
+                for (int c = 0; c < 3; c++) { const float f = (float) (a.a[c][0] * mu.x + a.a[c][1] * mu.y + a.a[c][2] * mu.z); fd[atom][c] = f; sum += fabsf(f); }
+                atomicMax((int*) &sMax, __float_as_int(sum));          // non-negative floats order like their bit patterns
+            }
+        }
+    }
+    __syncthreads();
+    if (t < 64) {
+        const unsigned long long valid = __ballot(t < MPB_ATOMS && ok[t < MPB_ATOMS ? t : 0] != 0);
+        if (valid != 0 && t == __ffsll((long long) valid) - 1) { ref[0] = base[t][0]; ref[1] = base[t][1]; ref[2] = base[t][2]; }
+    }
+    __syncthreads();
+    if (ref[0] < 0) return;                                    // no atom in this block (padding)
+    if (t < MPB_ATOMS && ok[t])
+        for (int d = 0; d < 3; d++) atomicMin(&minRel[d], mpb_wrap_rel(base[t][d] - ref[d], n[d]));
+    __syncthreads();
+    // fixed-point scale: 32 atoms of the largest |fd| sum stacked on one cell (weights: |theta'| <= 0.7, theta <= 0.6) stay below 2^30
+    const float scale = exp2f(floorf(30.f - log2f(fmaxf(MPB_ATOMS * 0.3f * sMax, 1e-30f))));
+    const int lane = t & 63, wave = t >> 6;
+    for (int kk = 0; kk < MPB_ATOMS / 4; kk++) {
+        const int atom = wave * (MPB_ATOMS / 4) + kk;
+        if (!ok[atom]) continue;                               // wave-uniform
+        int off[3];
+        bool fits = true;
+        for (int d = 0; d < 3; d++) { off[d] = mpb_wrap_rel(base[atom][d] - ref[d], n[d]) - minRel[d]; fits = fits && off[d] + 5 <= MPB_BRICK && MPB_BRICK <= n[d]; }
+        for (int pt = lane; pt < 125; pt += 64) {
+            const int ix = pt / 25, iy = (pt / 5) % 5, iz = pt % 5;
+            const float v = fd[atom][0] * dth[atom][0][ix] * th[atom][1][iy] * th[atom][2][iz] + fd[atom][1] * th[atom][0][ix] * dth[atom][1][iy] * th[atom][2][iz]
+                          + fd[atom][2] * th[atom][0][ix] * th[atom][1][iy] * dth[atom][2][iz];
+            if (fits) atomicAdd(&brick[((off[0] + ix) * MPB_BRICK + off[1] + iy) * MPB_ZS + off[2] + iz], __float2int_rn(v * scale));
+            else {
+                const int gx = (base[atom][0] + ix) % a.nx, gy = (base[atom][1] + iy) % a.ny, gz = (base[atom][2] + iz) % a.nz;
+                atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], v);
+            }
+        }
+    }
+    __syncthreads();
+    int org[3];
+    for (int d = 0; d < 3; d++) { org[d] = (ref[d] + minRel[d]) % n[d]; if (org[d] < 0) org[d] += n[d]; }
+    const float invScale = 1.f / scale;
+    for (int w = t; w < MPB_BRICK * MPB_BRICK * MPB_ZS; w += 256) {
+        const int fixed = brick[w];
+        if (fixed != 0) {
+            int gx = org[0] + w / (MPB_BRICK * MPB_ZS); gx -= gx >= a.nx ? a.nx : 0;
+            int gy = org[1] + (w / MPB_ZS) % MPB_BRICK; gy -= gy >= a.ny ? a.ny : 0;
+            int gz = org[2] + w % MPB_ZS; gz -= gz >= a.nz ? a.nz : 0;
+            atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], (float) fixed * invScale);
+        }
+    }
+}
+
 // The convolved grid back at the atoms: potential and its derivatives up to third order, Cartesian, with respect to the atom position:
 //   out[0] phi | [1..3] x y z | [4..9] xx xy xz yy yz zz | [10..19] xxx xxy xxz xyy xyz xzz yyy yyz yzz zzz
 // AmoebaReferencePmeMultipoleForce::computeFixedPotentialFromGrid (:5464-5570) / computeInducedPotentialFromGrid (:5618-5818) and
@@ -856,10 +944,19 @@ int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const doub
 }
 
 // potential (and derivatives) of one set of dipoles at the atoms
+// spread of one set of induced dipoles: LDS bricks in the slot order, the 8-lanes-per-atom kernel without one (or OPENMM_HIP_AMOEBA_NO_BRICKS, the A/B knob)
+void spread_induced(const MpArgs& a, const double* A, double sA, const double* B, double sB, hipStream_t st) {
+    static const bool noBricks = getenv("OPENMM_HIP_AMOEBA_NO_BRICKS") != nullptr;
+    if (a.order != nullptr && !noBricks && a.nx >= MPB_BRICK && a.ny >= MPB_BRICK && a.nz >= MPB_BRICK)
+        hipLaunchKernelGGL(k_mp_spread_bricks, dim3((a.numScan + MPB_ATOMS - 1) / MPB_ATOMS), dim3(256), 0, st, a, A, sA, B, sB);
+    else
+        hipLaunchKernelGGL(k_mp_spread<true>, dim3(spread_blocks(a)), dim3(256), 0, st, a, A, sA, B, sB);
+}
+
 void dipole_potential(const ommhip_pme* pme, const MpArgs& a, const double* dipoles, double* out, hipStream_t st) {
     const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
     hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, st);
-    hipLaunchKernelGGL(k_mp_spread<true>, dim3(spread_blocks(a)), dim3(256), 0, st, a, dipoles, 1.0, (const double*) nullptr, 0.0);
+    spread_induced(a, dipoles, 1.0, nullptr, 0.0, st);
     ommhip_pme_convolve(pme, st);
     hipLaunchKernelGGL(k_mp_potential, dim3(spread_blocks(a)), dim3(256), 0, st, a, out);
 }
@@ -953,7 +1050,7 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
     else {
         // reciprocal potential of the induced dipoles (mu_d + mu_p) / 2
         hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, st);
-        hipLaunchKernelGGL(k_mp_spread<true>, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.indD, 0.5, a.indP, 0.5);
+        spread_induced(a, a.indD, 0.5, a.indP, 0.5, st);
         ommhip_pme_convolve(pme, st);
         hipLaunchKernelGGL(k_mp_potential, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phiInd);
     }

@@ -671,10 +671,8 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
 // reciprocal part from their two potentials, the self field.  calculateInducedDipoleFields (:6059-6152).
 // ------------------------------------------------------------------------------------------------
 
-// solverSums != nullptr: the call is the "A p" of a solver iteration -- the field T p turns into A p = p / alpha - T p on the way out and the
-// dot products p . A p are added to solverSums[2], [3] (what stage 1 of k_mp_cg did in a launch of its own).
 __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const double* __restrict__ vD, const double* __restrict__ vP, const double* __restrict__ phiD,
-                                                              const double* __restrict__ phiP, double* __restrict__ outD, double* __restrict__ outP, double* solverSums) {
+                                                              const double* __restrict__ phiP, double* __restrict__ outD, double* __restrict__ outP) {
     const int t = threadIdx.x, g = (blockIdx.x * MP_BLOCK + t) / MP_SPLIT, q = t % MP_SPLIT, i = scan_atom(a, g);
     const bool active = i >= 0;
     const int ii = active ? i : 0;
@@ -711,24 +709,12 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const do
         }
     }
     ed = split_sum(ed); ep = split_sum(ep);
-    double s0 = 0.0, s1 = 0.0;
-    if (active && q == 0) {
-        const double selfTerm = (4.0 / 3.0) * a.alpha * a.alpha * a.alpha / MP_SQRT_PI, invK = 1.0 / OMM_ONE_4PI_EPS0_D;
-        const double* pd = phiD + 20 * (size_t) i;
-        const double* pp = phiP + 20 * (size_t) i;
-        const V3 pdv = load3(vD, i), ppv = load3(vP, i);
-        V3 fD = ed - invK * v3(pd[1], pd[2], pd[3]) + selfTerm * pdv, fP = ep - invK * v3(pp[1], pp[2], pp[3]) + selfTerm * ppv;
-        if (solverSums != nullptr) {
-            const double pol = a.polarity[i], invPol = pol > 0 ? 1.0 / pol : 0.0;
-            fD = invPol * pdv - (pol > 0 ? fD : v3(0, 0, 0)); fP = invPol * ppv - (pol > 0 ? fP : v3(0, 0, 0));
-            s0 = dot(pdv, fD); s1 = dot(ppv, fP);
-        }
-        store3(outD, i, fD); store3(outP, i, fP);
-    }
-    if (solverSums != nullptr) {
-        s0 = wave_sum(s0); s1 = wave_sum(s1);
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&solverSums[2], s0); atomicAdd(&solverSums[3], s1); }
-    }
+    if (!active || q != 0) return;
+    const double selfTerm = (4.0 / 3.0) * a.alpha * a.alpha * a.alpha / MP_SQRT_PI, invK = 1.0 / OMM_ONE_4PI_EPS0_D;
+    const double* pd = phiD + 20 * (size_t) i;
+    const double* pp = phiP + 20 * (size_t) i;
+    store3(outD, i, ed - invK * v3(pd[1], pd[2], pd[3]) + selfTerm * load3(vD, i));
+    store3(outP, i, ep - invK * v3(pp[1], pp[2], pp[3]) + selfTerm * load3(vP, i));
 }
 
 // Preconditioner of the conjugate gradients: z = M r with M = 2 alpha + alpha T_near alpha, the first terms of the Neumann series of
@@ -1010,7 +996,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t
     auto readSums = [&]() -> int { hipError_t e = hipMemcpyAsync(h, sums, sizeof(double) * 16, hipMemcpyDeviceToHost, st); if (e != hipSuccess) return (int) e; return (int) hipStreamSynchronize(st); };
     // T mu_0
     dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st);
-    hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, tD, tP, (double*) nullptr);
+    hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, tD, tP);
     hipMemsetAsync(sums, 0, sizeof(double) * 16, st);
     hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 0, 0.0, 0.0);
     if (a.precond) hipLaunchKernelGGL(k_mp_precond, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, w, 1);
@@ -1021,7 +1007,8 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t
     int iteration = 0;
     while (epsilon >= mp->target_epsilon && iteration < mp->max_iterations) {
         dipole_potentials(mp, a, pD, a.phiInd, pP, a.phiIndP, st);
-        hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP, sums);      // A p and p.Ap (stage 1 of k_mp_cg, folded in)
+        hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP);
+        hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 1, 0.0, 0.0);      // Ap, p.Ap
         hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 2, 0.0, 0.0);      // mu += a p, r -= a Ap (a from the device sums)
         if (a.precond) hipLaunchKernelGGL(k_mp_precond, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, w, 0);      // z = M r, r.z
         hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 3, 0.0, 0.0);      // p = z + b p

@@ -363,6 +363,9 @@ __global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double
 // five consecutive grid cells) and sums them over the 25 (x, y) offsets into the ten (p, q) combinations; the z weights of the lane's
 // own offset turn those into its share of the 20 derivatives, and the shares meet through shuffles.  (One thread per atom held the
 // whole 3 x 4 x 5 weight table and 20 sums in registers and spilled.)
+// MAXORD = 3: all 20 values; MAXORD = 1: the potential and its gradient only (out[0..3]) -- all that the induced-dipole field of a solver
+// iteration reads, at a third of the arithmetic.
+template <int MAXORD>
 __global__ void k_mp_potential(MpArgs a, double* __restrict__ out) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = tid / MP_SPREAD_LANES, iz = tid % MP_SPREAD_LANES;
@@ -370,8 +373,9 @@ __global__ void k_mp_potential(MpArgs a, double* __restrict__ out) {
     int idx[3];
     double th[3][4][5];
     atom_splines(a, position(a, atom ? i : 0), idx, th);
-    double G[4][4];                    // G[p][q] = sum over (ix, iy) of grid(ix, iy, my z) thx^(p)[ix] thy^(q)[iy],  p + q <= 3
-    for (int p = 0; p < 4; p++) for (int q = 0; q < 4; q++) G[p][q] = 0.0;
+    constexpr int NO = MAXORD + 1;
+    double G[NO][NO];                  // G[p][q] = sum over (ix, iy) of grid(ix, iy, my z) thx^(p)[ix] thy^(q)[iy],  p + q <= MAXORD
+    for (int p = 0; p < NO; p++) for (int q = 0; q < NO; q++) G[p][q] = 0.0;
     if (mine) {
         const int gz = (idx[2] + iz) % a.nz;
         for (int ix = 0; ix < 5; ix++) {
@@ -379,9 +383,9 @@ __global__ void k_mp_potential(MpArgs a, double* __restrict__ out) {
             for (int iy = 0; iy < 5; iy++) {
                 const int gy = (idx[1] + iy) % a.ny;
                 const double g = (double) a.grid[((size_t) gx * a.ny + gy) * a.nz + gz];
-                for (int p = 0; p < 4; p++) {
+                for (int p = 0; p < NO; p++) {
                     const double gp = g * th[0][p][ix];
-                    for (int q = 0; p + q < 4; q++) G[p][q] += gp * th[1][q][iy];
+                    for (int q = 0; p + q < NO; q++) G[p][q] += gp * th[1][q][iy];
                 }
             }
         }
@@ -390,40 +394,42 @@ __global__ void k_mp_potential(MpArgs a, double* __restrict__ out) {
     double wz[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int z = 0; z < 5; z++) if (z == iz) { wz[0] = th[2][0][z]; wz[1] = th[2][1][z]; wz[2] = th[2][2][z]; wz[3] = th[2][3][z]; }
-    // fractional derivatives F[p][q][r] = sum_g grid(g) thx^(p) thy^(q) thz^(r),  p + q + r <= 3: sum of the lanes' shares
-    double F[4][4][4];
-    for (int p = 0; p < 4; p++)
-        for (int q = 0; p + q < 4; q++)
-            for (int r = 0; p + q + r < 4; r++) {
+    // fractional derivatives F[p][q][r] = sum_g grid(g) thx^(p) thy^(q) thz^(r),  p + q + r <= MAXORD: sum of the lanes' shares
+    double F[NO][NO][NO];
+    for (int p = 0; p < NO; p++)
+        for (int q = 0; p + q < NO; q++)
+            for (int r = 0; p + q + r < NO; r++) {
                 double v = G[p][q] * wz[r];
                 v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
                 F[p][q][r] = v;
             }
     if (!atom || iz != 0) return;
-    // first, second and third fractional derivative tensors by index
-    double f1[3] = {F[1][0][0], F[0][1][0], F[0][0][1]};
-    double f2[3][3], f3[3][3][3];
-    for (int k = 0; k < 3; k++)
-        for (int l = 0; l < 3; l++) {
-            int e[3] = {0, 0, 0}; e[k]++; e[l]++;
-            f2[k][l] = F[e[0]][e[1]][e[2]];
-            for (int m = 0; m < 3; m++) { int e3[3] = {e[0], e[1], e[2]}; e3[m]++; f3[k][l][m] = F[e3[0]][e3[1]][e3[2]]; }
-        }
     double* o = out + 20 * (size_t) i;
+    const double f1[3] = {F[1][0][0], F[0][1][0], F[0][0][1]};
     o[0] = F[0][0][0];
     for (int c = 0; c < 3; c++) o[1 + c] = a.a[0][c] * f1[0] + a.a[1][c] * f1[1] + a.a[2][c] * f1[2];
-    int n2 = 4, n3 = 10;
-    for (int c = 0; c < 3; c++)
-        for (int d = c; d < 3; d++) {
-            double s = 0;
-            for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) s += a.a[k][c] * a.a[l][d] * f2[k][l];
-            o[n2++] = s;
-            for (int e = d; e < 3; e++) {
-                double t = 0;
-                for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) for (int m = 0; m < 3; m++) t += a.a[k][c] * a.a[l][d] * a.a[m][e] * f3[k][l][m];
-                o[n3++] = t;
+    if (MAXORD >= 3) {
+        // second and third fractional derivative tensors by index
+        double f2[3][3], f3[3][3][3];
+        for (int k = 0; k < 3; k++)
+            for (int l = 0; l < 3; l++) {
+                int e[3] = {0, 0, 0}; e[k]++; e[l]++;
+                f2[k][l] = F[e[0] % NO][e[1] % NO][e[2] % NO];
+                for (int m = 0; m < 3; m++) { int e3[3] = {e[0], e[1], e[2]}; e3[m]++; f3[k][l][m] = F[e3[0] % NO][e3[1] % NO][e3[2] % NO]; }
             }
-        }
+        int n2 = 4, n3 = 10;
+        for (int c = 0; c < 3; c++)
+            for (int d = c; d < 3; d++) {
+                double s2 = 0;
+                for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) s2 += a.a[k][c] * a.a[l][d] * f2[k][l];
+                o[n2++] = s2;
+                for (int e = d; e < 3; e++) {
+                    double t3 = 0;
+                    for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) for (int m = 0; m < 3; m++) t3 += a.a[k][c] * a.a[l][d] * a.a[m][e] * f3[k][l][m];
+                    o[n3++] = t3;
+                }
+            }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -938,7 +944,7 @@ int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const doub
     hipMemsetAsync(a.grid, 0, gridBytes, st);
     hipLaunchKernelGGL(k_mp_spread<false>, dim3(spread_blocks(a)), dim3(256), 0, st, a, (const double*) nullptr, 0.0, (const double*) nullptr, 0.0);
     ommhip_pme_convolve(pme, st);
-    hipLaunchKernelGGL(k_mp_potential, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phi);
+    hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phi);
     hipLaunchKernelGGL(k_mp_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
     return 0;
 }
@@ -953,23 +959,25 @@ void spread_induced(const MpArgs& a, const double* A, double sA, const double* B
         hipLaunchKernelGGL(k_mp_spread<true>, dim3(spread_blocks(a)), dim3(256), 0, st, a, A, sA, B, sB);
 }
 
-void dipole_potential(const ommhip_pme* pme, const MpArgs& a, const double* dipoles, double* out, hipStream_t st) {
+void dipole_potential(const ommhip_pme* pme, const MpArgs& a, const double* dipoles, double* out, hipStream_t st, bool fieldOnly = false) {
     const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
     hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, st);
     spread_induced(a, dipoles, 1.0, nullptr, 0.0, st);
     ommhip_pme_convolve(pme, st);
-    hipLaunchKernelGGL(k_mp_potential, dim3(spread_blocks(a)), dim3(256), 0, st, a, out);
+    if (fieldOnly) hipLaunchKernelGGL(k_mp_potential<1>, dim3(spread_blocks(a)), dim3(256), 0, st, a, out);
+    else hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, out);
 }
 
 // The potentials of two sets of dipoles.  The chain of one set -- clear, spread, three transform launches, read-back -- is six small launches
 // that leave most of the chip idle; with a second grid and a side stream (pme2, stream2, two ordering events: optional in the C ABI) the
 // chain of the second set runs beside that of the first.
-void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double* vD, double* outD, const double* vP, double* outP, hipStream_t st) {
+// fieldOnly: potential and gradient only (a solver iteration); the derivatives up to third order are computed for the converged dipoles
+void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double* vD, double* outD, const double* vP, double* outP, hipStream_t st, bool fieldOnly = false) {
     const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
     const ommhip_pme* pme2 = (const ommhip_pme*) mp->pme2;
     if (pme2 == nullptr || mp->stream2 == nullptr || mp->event_a == nullptr || mp->event_b == nullptr || pme2->grid_real == nullptr || pme2->grid_real == pme->grid_real) {
-        dipole_potential(pme, a, vD, outD, st);
-        dipole_potential(pme, a, vP, outP, st);
+        dipole_potential(pme, a, vD, outD, st, fieldOnly);
+        dipole_potential(pme, a, vP, outP, st, fieldOnly);
         return;
     }
     hipStream_t st2 = (hipStream_t) mp->stream2;
@@ -977,9 +985,9 @@ void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const
     a2.grid = (float*) pme2->grid_real;
     hipEventRecord((hipEvent_t) mp->event_a, st);                  // the dipoles (and everything else the side chain reads) are ready
     hipStreamWaitEvent(st2, (hipEvent_t) mp->event_a, 0);
-    dipole_potential(pme2, a2, vP, outP, st2);
+    dipole_potential(pme2, a2, vP, outP, st2, fieldOnly);
     hipEventRecord((hipEvent_t) mp->event_b, st2);
-    dipole_potential(pme, a, vD, outD, st);
+    dipole_potential(pme, a, vD, outD, st, fieldOnly);
     hipStreamWaitEvent(st, (hipEvent_t) mp->event_b, 0);           // the main stream goes on when both potentials are there
 }
 
@@ -995,7 +1003,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t
     const double debye = 48.033324;          // AmoebaReferenceMultipoleForce::_debye
     auto readSums = [&]() -> int { hipError_t e = hipMemcpyAsync(h, sums, sizeof(double) * 16, hipMemcpyDeviceToHost, st); if (e != hipSuccess) return (int) e; return (int) hipStreamSynchronize(st); };
     // T mu_0
-    dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st);
+    dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st, true);
     hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, tD, tP);
     hipMemsetAsync(sums, 0, sizeof(double) * 16, st);
     hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 0, 0.0, 0.0);
@@ -1006,7 +1014,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t
     hipMemsetAsync(sums + 4, 0, sizeof(double) * 2, st);
     int iteration = 0;
     while (epsilon >= mp->target_epsilon && iteration < mp->max_iterations) {
-        dipole_potentials(mp, a, pD, a.phiInd, pP, a.phiIndP, st);
+        dipole_potentials(mp, a, pD, a.phiInd, pP, a.phiIndP, st, true);
         hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP);
         hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 1, 0.0, 0.0);      // Ap, p.Ap
         hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 2, 0.0, 0.0);      // mu += a p, r -= a Ap (a from the device sums)
@@ -1052,7 +1060,7 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
         hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, st);
         spread_induced(a, a.indD, 0.5, a.indP, 0.5, st);
         ommhip_pme_convolve(pme, st);
-        hipLaunchKernelGGL(k_mp_potential, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phiInd);
+        hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phiInd);
     }
     hipLaunchKernelGGL(k_mp_forces, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_mp_torque_to_force, dim3(blocks), dim3(MP_BLOCK), 0, st, a);

@@ -465,8 +465,14 @@ __device__ __forceinline__ void pair_chains(double alpha, double r2, double damp
 // MP_SPLIT lanes share an atom in the pair kernels: lane q of the group walks entries q, q + MP_SPLIT, ... of the atom's list and the partial
 // sums meet through shuffles.  One thread per atom would put 2 wavefronts on a compute unit at 36 k atoms; the loops are gathers from
 // L2 / HBM with long arithmetic in between and need the latency hiding of several wavefronts per SIMD.
+#ifndef MP_SPLIT
 #define MP_SPLIT 4
-__device__ __forceinline__ double split_sum(double v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v; }
+#endif
+__device__ __forceinline__ double split_sum(double v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2);
+    if (MP_SPLIT >= 8) v += __shfl_xor(v, 4);
+    return v;
+}
 __device__ __forceinline__ V3 split_sum(V3 v) { return v3(split_sum(v.x), split_sum(v.y), split_sum(v.z)); }
 
 struct PairScale { double m, p, d; };

@@ -526,15 +526,29 @@ def main():
             ainteg = H.Integrator(H.VERLET, 0.001)
             actx = H.Context(asys, ainteg, "HIP", {"DeviceIndex": str(local_rank)})
             actx.setPositions(aw.positions)
+            # parity at the benchmarked size: the forces of the initial configuration against the AMOEBA plugin's Reference kernels on the
+            # Reference platform (committed golden of 12 000 sampled atoms, tools/make_golden_amoeba_water_tile.py; the golden was converged
+            # to 1e-6 D, this run solves to 1e-5 D as benchmark.py does: the figure includes that difference)
+            a_parity = None
+            try:
+                g = np.load(os.path.join(ROOT, "tests", "golden", "reference_forces_amoeba_water_tile_36501_mutual_sample.npz"))
+                f0 = actx.getState(getForces=True).forces
+                rel = np.linalg.norm(f0[g["indices"]] - g["forces"], axis=1) / np.maximum(np.linalg.norm(g["forces"], axis=1), float(g["rms_force"]))
+                a_parity = {"max_rel_err_vs_reference": float(rel.max()), "tolerance": 1e-4, "atoms_above_tolerance": int((rel > 1e-4).sum()), "sampled_atoms": int(len(rel)),
+                            "reference": "AMOEBA Reference kernels on the Reference platform, mutual epsilon 1e-6 (tests/golden/reference_forces_amoeba_water_tile_36501_mutual_sample.npz)"}
+            except Exception as e:
+                a_parity = {"max_rel_err_vs_reference": None, "error": str(e)}
             actx.setVelocitiesToTemperature(300.0, 5)
-            ainteg.step(2)
+            ainteg.step(6)                 # the solver's first guess uses the dipoles of up to four earlier steps
             actx.getState(getEnergy=True)
             a_steps = max(5, min(args.steps, 20))
+            builds0, solves0 = H.amoeba_list_builds(), H.amoeba_solver_iterations()
             t0 = time.perf_counter()
             ainteg.step(a_steps)
             a_st = actx.getState(getEnergy=True)
             a_elapsed = time.perf_counter() - t0
             after = H.amoeba_native_evaluations()
+            builds1, solves1 = H.amoeba_list_builds(), H.amoeba_solver_iterations()
             if not np.isfinite(a_st.potentialEnergy):
                 raise RuntimeError("potential energy is not finite")
             if after[0] - before[0] < a_steps or after[1] - before[1] < a_steps:
@@ -542,7 +556,10 @@ def main():
             out["extra_workloads"]["amoeba_water"] = {"workload": "%s: %d atoms, AmoebaMultipoleForce PME 80x80x80 mutual polarization (epsilon 1e-5, cutoff 0.7 nm) + AmoebaVdwForce "
                                                                   "(0.9 nm) on the native kernels, harmonic bonds / angles, Verlet 1 fs, single GPU" % (aw.name, aw.num_atoms),
                                                       "value": round(MR.ns_per_day(a_elapsed, a_steps, 1.0), 4), "unit": "ns/day", "ms_per_step": round(1e3 * a_elapsed / a_steps, 3),
-                                                      "steps": a_steps, "warmup": 2, "dtype": "f64 pair arithmetic, f32 grids",
+                                                      "steps": a_steps, "warmup": 6, "dtype": "f64 pair arithmetic, f32 grids and pair cache of the solver",
+                                                      "force_parity": a_parity,
+                                                      "solver_iterations_per_solve": round((solves1[1] - solves0[1]) / max(1, solves1[0] - solves0[0]), 2),
+                                                      "pair_list_builds_per_step": {"vdw": round((builds1[0] - builds0[0]) / a_steps, 3), "multipole": round((builds1[1] - builds0[1]) / a_steps, 3)},
                                                       "note": "stand-in for BASELINE.json configs[4] (amoeba-pme on DHFR): no amoeba2009 force-field reader here, water only"}
             actx.close()
         except Exception as e:

@@ -48,7 +48,7 @@ typedef struct ommhip_amoeba_vdw {
     int periodic;                  /* 1: CutoffPeriodic (box given to the call), 0: NoCutoff */
     double cutoff, taper_cutoff, taper_c3, taper_c4, taper_c5;
     double* reduced;               /* device double4[num_atoms] scratch: the interaction sites */
-    /* CutoffPeriodic: pair lists rebuilt by every call (amoeba_pairs.h; see ommhip_amoeba_multipole below) -- partners within the cutoff by
+    /* CutoffPeriodic: pair lists (amoeba_pairs.h; see ommhip_amoeba_multipole below; rebuilt by every call unless a skin is given) -- partners within the cutoff by
      * atom distance, exclusions left out -- when pair_list is given; without it (and for NoCutoff) every thread scans all atoms.
      * S = padded_atoms with atom_of_slot, num_atoms without. */
     const int* atom_of_slot;       /* device int[padded_atoms]: atom at each slot, -1 = padding (optional: spatial order -> far tiles skipped) */
@@ -59,6 +59,14 @@ typedef struct ommhip_amoeba_vdw {
     int pair_cap;                  /* list entries per atom (a multiple of 4: four sub-lists of pair_cap / 4); a call that needs more returns -2 */
     int* pair_overflow;            /* device int work word */
     int* pair_needed;              /* HOST int written with the return code -2 (or NULL) */
+    /* Verlet skin, optional (skin > 0 with both arrays): the lists hold the partners within cutoff + skin and are rebuilt only when some atom
+     * has moved by more than skin / 2 since the last build (decided on the device) or when the caller says so -- after a change of the slot
+     * order, the box, the parameters or the list capacity; the pair kernel re-tests the cutoff. */
+    double skin;
+    double* ref_pos;               /* device double4[num_atoms] work array: positions at the last build */
+    int* list_state;               /* device int[4] work words, zeroed by the caller once; [2] counts the builds */
+    int force_rebuild;
+    int* list_builds;              /* HOST int (or NULL), written by every call: list builds so far (diagnostics) */
 } ommhip_amoeba_vdw;
 
 int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* vdw, const void* pos_d, const double box[6], const int* slot_of_atom_d, int padded_atoms,
@@ -87,6 +95,7 @@ int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* vdw, const void* pos_d, co
  * keeps its form and the force gains the term -1/2 mu_d (dT/dx) mu_p).  The host falls back to the AMOEBA plugin's Reference kernel
  * for everything else (NoCutoff, extrapolated polarization).
  * ------------------------------------------------------------------------------------------ */
+#define OMMHIP_AMOEBA_MAX_HISTORY 6
 typedef struct ommhip_amoeba_multipole {
     int num_atoms;
     /* per atom, device */
@@ -119,7 +128,7 @@ typedef struct ommhip_amoeba_multipole {
     double* solver;                /* [24n + 16] work vectors of the conjugate-gradient solver */
     double* status;                /* HOST double[2], written by the calls: [0] epsilon reached, [1] iterations (or NULL) */
     void* pme;                     /* const ommhip_pme*: grid sizes, box, moduli, eterm, real / complex grids, twiddles of the platform's PME */
-    /* Pair lists, rebuilt by every call (amoeba_pairs.h): per atom the partners within the cutoff, found by a scan that only tests
+    /* Pair lists (amoeba_pairs.h; rebuilt by every call unless a skin is given): per atom the partners within the cutoff, found by a scan that only tests
      * distances; the kernels with the long pair arithmetic (fixed field, induced-dipole field, forces) walk these lists.  With the
      * platform's slot order (optional: atom_of_slot / slot_of_atom / scan_slots, NULL / 0 = atom order) the scan works on 128-slot tiles
      * with bounding boxes and skips the tiles farther apart than the cutoff (rectangular boxes).  S = scan_slots, or num_atoms. */
@@ -137,8 +146,24 @@ typedef struct ommhip_amoeba_multipole {
     /* mutual polarization, optional: a second grid set (an ommhip_pme that shares everything but grid_real / grid_complex with `pme`), a side
      * stream and two ordering events -- the potentials of the two dipole sets are then computed side by side */
     void* pme2; void* stream2; void* event_a; void* event_b;
-    double* pair_cache;            /* device double[5 * pair_cap * S] or NULL (mutual polarization): per list entry the separation and the two
+    float* pair_cache;             /* device float[5 * pair_cap * S] or NULL (mutual polarization): per list entry the separation and the two
                                     * coefficients of the damped dipole-dipole chain, written once per evaluation and read by every solver iteration */
+    /* Mutual polarization, optional: solutions of earlier calls, from which the solver extrapolates its first guess (the CUDA platform's and
+     * Tinker's remedy for the ~10 iterations a solve from the direct dipoles takes; the converged dipoles are the same to the tolerance).
+     * The caller owns the ring and says what it holds: a call starts from sum_k history_coeff[k] x record k, k < history_use, record 0
+     * = slot history_newest, record k = slot history_newest - k (mod history_slots); history_use = 0: from the direct dipoles.  It stores
+     * its converged (mu_d, mu_p) in slot history_store (-1: nowhere). */
+    double* history;               /* device double[history_slots * 6n] or NULL */
+    int history_slots, history_newest, history_store, history_use;
+    double history_coeff[OMMHIP_AMOEBA_MAX_HISTORY];
+    /* Verlet skin of the pair lists, optional: as in ommhip_amoeba_vdw */
+    double skin;
+    double* ref_pos;
+    int* list_state;
+    int force_rebuild;
+    int* list_builds;
+    int expected_iterations;       /* iterations the previous solve took (0 = unknown): that many minus one are enqueued before the host first waits for the
+                                    * convergence measure, which the device forms itself; status[1] reports what this call took */
 } ommhip_amoeba_multipole;
 
 /* Whole evaluation: frames -> reciprocal and real-space field -> induced dipoles -> energy, forces, torques -> forces. */

@@ -203,7 +203,8 @@ typedef struct ommhip_neighbor_list {
      * the last re-sort; an owned atom whose x fraction differs from it by more than dd_warn (units of 2^-32 box lengths) raises
      * dd_flags[1] -- which ommhip_integrate_fused puts into the rank's trailer, so that one step later every rank finds it in some
      * trailer and raises dd_flags[2]: the host reads that word at the same evaluation on all ranks and re-sorts -- and more than
-     * dd_max raises dd_flags[0] (the forces may be incomplete: the host ends the run). */
+     * dd_max adds bit 4 to the same words (the forces may be incomplete: every rank's host ends the run at the same evaluation;
+     * dd_flags[0] says on which rank it happened). */
     int num_active_ranges;
     int active_range[8];
     const void* wire_ref;

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
+#include <string>
 #include <map>
 #include <set>
 #include <vector>
@@ -25,12 +26,29 @@ void uploadVector(DeviceBuffer& buffer, const vector<T>& v, void* stream) {
     HIP_CHECK(ommhip_stream_sync(stream));       // v may be a temporary
 }
 long long nativeEvaluations[2] = {0, 0};
+long long solverIterations[2] = {0, 0};      // mutual-polarization solves and their iterations, summed
+int listBuilds[2] = {0, 0};        // pair-list builds of the most recently used vdW / multipole kernel (written by the kernel library at every call)
+// Verlet skin of the AMOEBA pair lists (nm): the lists reach this far beyond the cutoff and are rebuilt when an atom has moved by half of it.
+// A wider skin means fewer rebuilds and more list entries for every pair kernel to skip: at 1 fs steps of liquid water the optimum is broad
+// around 0.04-0.06 nm (a rebuild every 5-8 steps, +20 % entries).  0 = rebuild at every evaluation (the behaviour up to round 3).
+double listSkin() {
+    static const double skin = getenv("OPENMM_HIP_AMOEBA_SKIN") != NULL ? atof(getenv("OPENMM_HIP_AMOEBA_SKIN")) : 0.05;
+    return skin > 0.0 ? skin : 0.0;
+}
 }
 
 /* Diagnostics for the tests: how many force evaluations went through the native kernels ([0] vdW, [1] multipole) -- a Context that
  * silently fell back to the AMOEBA plugin's Reference kernels leaves these at zero. */
 extern "C" __attribute__((visibility("default"))) void ommhip_amoeba_native_evaluations(long long* out) {
     out[0] = nativeEvaluations[0]; out[1] = nativeEvaluations[1];
+}
+/* ... and how often the pair lists of the most recently used kernels were built ([0] vdW, [1] multipole): with the Verlet skin fewer than evaluations. */
+/* ... and the number of mutual-polarization solves and the sum of their iterations. */
+extern "C" __attribute__((visibility("default"))) void ommhip_amoeba_solver_iterations(long long* out) {
+    out[0] = solverIterations[0]; out[1] = solverIterations[1];
+}
+extern "C" __attribute__((visibility("default"))) void ommhip_amoeba_list_builds(long long* out) {
+    out[0] = listBuilds[0]; out[1] = listBuilds[1];
 }
 
 // ================================================================================================
@@ -103,16 +121,23 @@ void HipCalcAmoebaVdwForceKernel::upload(const AmoebaVdwForce& force) {
         pairOverflow.allocate(sizeof(int));
         vdw.tile_bounds = tileBounds.as<double>(); vdw.excl_pos = exclPos.as<int>(); vdw.pair_count = pairCount.as<int>(); vdw.pair_overflow = pairOverflow.as<int>();
         vdw.pair_needed = &pairNeeded;
+        vdw.skin = listSkin();
+        refPos.allocate(sizeof(double) * 4 * (size_t) max(numParticles, 1));
+        if (listState.ptr == NULL) { listState.allocate(sizeof(int) * 4); HIP_CHECK(ommhip_memset(listState.ptr, 0, listState.bytes, hip.stream)); }
+        vdw.ref_pos = refPos.as<double>(); vdw.list_state = listState.as<int>(); vdw.force_rebuild = 1; vdw.list_builds = &listBuilds[0];
+        listDirty = true;
         // capacity: the partners of an atom at the density of the box, with room for fluctuations; a list that does not fit grows it
         const double volume = hip.box[0] * hip.box[2] * hip.box[5];
         // (OPENMM_HIP_AMOEBA_PAIR_CAP: a deliberately small first capacity, for the test of the growth path)
-    allocatePairList(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP") != NULL ? atoi(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP")) : (int) min(4.0 * numParticles, 2.0 * 4.18879 * cutoff * cutoff * cutoff * numParticles / volume + 128.0));
+        // (updateParametersInContext comes through here again: a capacity the lists have grown to is kept)
+        allocatePairList(max(grownPairCap, getenv("OPENMM_HIP_AMOEBA_PAIR_CAP") != NULL ? atoi(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP")) : (int) min(4.0 * numParticles, 2.0 * 4.18879 * pow(cutoff + listSkin(), 3.0) * numParticles / volume + 128.0)));
     }
 }
 
 void HipCalcAmoebaVdwForceKernel::allocatePairList(int cap) {
     HipContext& hip = *data.hip;
     vdw.pair_cap = (max(cap, 4) + 3) / 4 * 4;            // four sub-lists per atom
+    listDirty = true;
     pairList.allocate(sizeof(int) * (size_t) vdw.pair_cap * hip.paddedAtoms);
     vdw.pair_list = pairList.as<int>();
 }
@@ -132,12 +157,14 @@ double HipCalcAmoebaVdwForceKernel::execute(ContextImpl& context, bool includeFo
     hip.ensureCleared();
     vdw.atom_of_slot = hip.atomOfSlot.as<int>();
     for (int attempt = 0; ; attempt++) {
+        vdw.force_rebuild = listDirty || listOrderVersion != hip.orderVersion || listBoxVersion != hip.boxVersion ? 1 : 0;
         const int rc = ommhip_amoeba_vdw_forces(&vdw, hip.pos.ptr, hip.box, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.force.as<long long>(),
                                                 hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream);
-        if (rc != -2) { HIP_CHECK(rc); break; }
+        if (rc != -2) { HIP_CHECK(rc); listDirty = false; listOrderVersion = hip.orderVersion; listBoxVersion = hip.boxVersion; break; }
         // the pair lists did not fit (nothing has been added to the forces yet: the list is built before the pair kernel runs)
         if (attempt == 3 || pairNeeded == 0x7fffffff) throw OpenMMException("AmoebaVdwForce: the pair lists of the HIP platform cannot hold this System");
-        allocatePairList((int) min((long long) numParticles * 4, (long long) pairNeeded * 5 / 4 + 16));
+        grownPairCap = (int) min((long long) numParticles * 4, (long long) pairNeeded * 5 / 4 + 16);
+        allocatePairList(grownPairCap);
     }
     nativeEvaluations[0]++;
     // the pair energy is summed on the device (HipCalcForcesAndEnergyKernel::finishComputation); the host adds the constant
@@ -151,7 +178,7 @@ void HipCalcAmoebaVdwForceKernel::copyParametersToContext(ContextImpl& context, 
 }
 
 // ================================================================================================
-// AmoebaMultipoleForce (PME, direct polarization)
+// AmoebaMultipoleForce (PME; direct and mutual polarization)
 // ================================================================================================
 namespace {
 vector<double> bsplineModuli(int n) {
@@ -269,7 +296,10 @@ void HipCalcAmoebaMultipoleForceKernel::initialize(const System& system, const A
     indD.allocate(sizeof(double) * 3 * n); indP.allocate(sizeof(double) * 3 * n);
     phi.allocate(sizeof(double) * 20 * n); phiInd.allocate(sizeof(double) * 20 * n); torque.allocate(sizeof(double) * 3 * n);
     mutual = force.getPolarizationType() == AmoebaMultipoleForce::Mutual;
-    if (mutual) { phiIndP.allocate(sizeof(double) * 20 * n); solver.allocate(sizeof(double) * (24 * n + 16)); }
+    if (mutual) {
+        phiIndP.allocate(sizeof(double) * 20 * n); solver.allocate(sizeof(double) * (24 * n + 16));
+        if (getenv("OPENMM_HIP_AMOEBA_NO_PREDICTOR") == NULL) history.allocate(sizeof(double) * 6 * n * HistorySlots);       // (A/B knob: every solve starts from the direct dipoles)
+    }
     upload(force);
 }
 
@@ -336,6 +366,8 @@ void HipCalcAmoebaMultipoleForceKernel::upload(const AmoebaMultipoleForce& force
     mp.mutual = mutual ? 1 : 0;
     mp.max_iterations = force.getMutualInducedMaxIterations(); mp.target_epsilon = force.getMutualInducedTargetEpsilon();
     mp.phi_induced_p = mutual ? phiIndP.as<double>() : NULL; mp.solver = mutual ? solver.as<double>() : NULL; mp.status = solverStatus;
+    mp.history = mutual && history.ptr != NULL ? history.as<double>() : NULL; mp.history_slots = HistorySlots; mp.history_newest = 0; mp.history_store = -1; mp.history_use = 0; mp.expected_iterations = 0;
+    historyValid = 0;                         // new parameters: the earlier solutions belong to another Hamiltonian
     // mutual polarization: a second grid set and a side stream, so that the potentials of the two dipole sets are computed side by side
     mp.pme2 = NULL; mp.stream2 = NULL; mp.event_a = mp.event_b = NULL;
     if (mutual && getenv("OPENMM_HIP_AMOEBA_ONE_GRID") == NULL) {
@@ -354,34 +386,48 @@ void HipCalcAmoebaMultipoleForceKernel::upload(const AmoebaMultipoleForce& force
     pairOverflow.allocate(sizeof(int));
     mp.tile_bounds = tileBounds.as<double>(); mp.special_pos = specPos.as<int>(); mp.special_scale_sorted = specScaleSorted.as<double>();
     mp.pair_count = pairCount.as<int>(); mp.pair_overflow = pairOverflow.as<int>(); mp.pair_needed = &pairNeeded;
+    mp.skin = listSkin();
+    refPos.allocate(sizeof(double) * 4 * (size_t) max(numParticles, 1));
+    if (listState.ptr == NULL) { listState.allocate(sizeof(int) * 4); HIP_CHECK(ommhip_memset(listState.ptr, 0, listState.bytes, hip.stream)); }
+    mp.ref_pos = refPos.as<double>(); mp.list_state = listState.as<int>(); mp.force_rebuild = 1; mp.list_builds = &listBuilds[1];
+    listDirty = true;
     mp.atom_of_slot = NULL; mp.slot_of_atom = NULL; mp.scan_slots = 0;
     const double volume = hip.box[0] * hip.box[2] * hip.box[5];
     // (OPENMM_HIP_AMOEBA_PAIR_CAP: a deliberately small first capacity, for the test of the growth path)
-    allocatePairList(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP") != NULL ? atoi(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP")) : (int) min(4.0 * numParticles, 2.0 * 4.18879 * cutoff * cutoff * cutoff * numParticles / volume + 128.0));
+    // (updateParametersInContext comes through here again: a capacity the lists have grown to is kept)
+    allocatePairList(max(grownPairCap, getenv("OPENMM_HIP_AMOEBA_PAIR_CAP") != NULL ? atoi(getenv("OPENMM_HIP_AMOEBA_PAIR_CAP")) : (int) min(4.0 * numParticles, 2.0 * 4.18879 * pow(cutoff + listSkin(), 3.0) * numParticles / volume + 128.0)));
 }
 
 void HipCalcAmoebaMultipoleForceKernel::allocatePairList(int cap) {
     HipContext& hip = *data.hip;
     mp.pair_cap = (max(cap, 4) + 3) / 4 * 4;             // four sub-lists per atom
+    listDirty = true;
     pairList.allocate(sizeof(int) * (size_t) mp.pair_cap * hip.paddedAtoms);
     mp.pair_list = pairList.as<int>();
-    // mutual polarization: 40 bytes per list entry that save the solver iterations their erfc / exp / Thole arithmetic (0.6 GB at 36 k atoms;
+    // mutual polarization: 20 bytes per list entry that save the solver iterations their erfc / exp / Thole arithmetic (0.3 GB at 36 k atoms;
     // left out when it would take more than 8 GB)
     mp.pair_cache = NULL;
-    const size_t cacheBytes = sizeof(double) * 5 * (size_t) mp.pair_cap * hip.paddedAtoms;
-    if (mutual && cacheBytes <= ((size_t) 8 << 30) && getenv("OPENMM_HIP_AMOEBA_NO_PAIR_CACHE") == NULL) { pairCache.allocate(cacheBytes); mp.pair_cache = pairCache.as<double>(); }
+    const size_t cacheBytes = sizeof(float) * 5 * (size_t) mp.pair_cap * hip.paddedAtoms;
+    if (mutual && cacheBytes <= ((size_t) 8 << 30) && getenv("OPENMM_HIP_AMOEBA_NO_PAIR_CACHE") == NULL) { pairCache.allocate(cacheBytes); mp.pair_cache = pairCache.as<float>(); }
 }
 
 bool HipCalcAmoebaMultipoleForceKernel::growPairList(int rc, int attempt) {
     if (rc != -2) return false;
     if (attempt == 3 || pairNeeded == 0x7fffffff) throw OpenMMException("AmoebaMultipoleForce: the pair lists of the HIP platform cannot hold this System");
-    allocatePairList((int) min((long long) numParticles * 4, (long long) pairNeeded * 5 / 4 + 16));
+    grownPairCap = (int) min((long long) numParticles * 4, (long long) pairNeeded * 5 / 4 + 16);
+    allocatePairList(grownPairCap);
     return true;
 }
 
 void HipCalcAmoebaMultipoleForceKernel::setScanOrder() {
     HipContext& hip = *data.hip;
     mp.atom_of_slot = hip.atomOfSlot.as<int>(); mp.slot_of_atom = hip.slotOfAtom.as<int>(); mp.scan_slots = hip.paddedAtoms;
+    // the pair lists are keyed by slots and built for one box: a new order or box (or new parameters / a new capacity: listDirty) asks for a rebuild
+    mp.force_rebuild = listDirty || listOrderVersion != hip.orderVersion || listBoxVersion != hip.boxVersion ? 1 : 0;
+}
+
+void HipCalcAmoebaMultipoleForceKernel::listBuilt() {
+    listDirty = false; listOrderVersion = data.hip->orderVersion; listBoxVersion = data.hip->boxVersion;
 }
 
 void HipCalcAmoebaMultipoleForceKernel::prepareGrid() {
@@ -402,13 +448,17 @@ double HipCalcAmoebaMultipoleForceKernel::execute(ContextImpl& context, bool inc
     prepareGrid();
     hip.ensureCleared();
     setScanOrder();
+    chooseFirstGuess();
     int rc;
     for (int attempt = 0; ; attempt++) {
         rc = ommhip_amoeba_multipole_forces(&mp, hip.pos.ptr, hip.box, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.force.as<long long>(),
                                             hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream);
         if (!growPairList(rc, attempt)) break;        // -2: the pair lists did not fit (they are built before anything is added to the forces)
+        setScanOrder();
     }
+    if (rc == 0 || rc == -1) listBuilt();
     checkSolver(rc);
+    recordSolve();
     nativeEvaluations[1]++;
     return 0.0;        // summed on the device (HipCalcForcesAndEnergyKernel::finishComputation)
 }
@@ -416,14 +466,76 @@ double HipCalcAmoebaMultipoleForceKernel::execute(ContextImpl& context, bool inc
 void HipCalcAmoebaMultipoleForceKernel::induce() {
     HipContext& hip = *data.hip;
     hip.setAsCurrent();
+    if (hip.hostMode) {
+        // host mode (virtual sites, a custom integrator, ...): the host vectors are authoritative and reach the device only at the start
+        // of a force evaluation -- a dipole query right after setPositions / setPeriodicBoxVectors must not see the old geometry
+        // (the CUDA platform re-evaluates when its multipoles are stale, CudaCalcAmoebaMultipoleForceKernel::ensureMultipolesValid)
+        hip.setBox(data.periodicBoxVectors[0], data.periodicBoxVectors[1], data.periodicBoxVectors[2]);
+        hip.uploadPositions(*data.positions);
+    }
     prepareGrid();
     setScanOrder();
+    chooseFirstGuess();
     int rc;
     for (int attempt = 0; ; attempt++) {
         rc = ommhip_amoeba_multipole_induce(&mp, hip.pos.ptr, hip.box, hip.stream);
         if (!growPairList(rc, attempt)) break;
+        setScanOrder();
     }
+    if (rc == 0 || rc == -1) listBuilt();
     checkSolver(rc);
+    recordSolve();
+}
+
+void HipCalcAmoebaMultipoleForceKernel::chooseFirstGuess() {
+    // Which earlier solutions may the solver start from?  Those of the immediately preceding steps of an undisturbed run: the step count
+    // moved on by one since the newest record, nobody edited positions or box in between (device mode: every uploadPositions is an edit;
+    // host mode uploads at every evaluation, there only the step count speaks), the parameters are the same (upload() resets).
+    // The same step again (an energy query after the step) starts from the last solution itself.
+    HipContext& hip = *data.hip;
+    const int newest = (historyNext + HistorySlots - 1) % HistorySlots;
+    mp.history_use = 0; mp.history_newest = newest; mp.history_store = historyNext; mp.expected_iterations = (int) solverStatus[1];
+    historySameStep = false;
+    if (!mutual || mp.history == NULL) return;
+    const bool edited = (!hip.hostMode && hip.positionsVersion != historyPositionsVersion) || hip.boxVersion != historyBoxVersion;
+    if (edited) historyValid = 0;
+    if (historyValid > 0 && (long long) data.stepCount == historyStep) {
+        historySameStep = true;
+        mp.history_use = 1;
+        mp.history_store = newest;              // replaces the newest record
+    }
+    else if (historyValid > 0 && (long long) data.stepCount == historyStep + 1) mp.history_use = historyValid;
+    else historyValid = 0;
+    // Coefficients.  One record: the last solution itself.  Consecutive steps: the predictor of Kolafa's always-stable scheme (J. Comput.
+    // Chem. 25, 335 (2004); Tinker's polpred ASPC is the same family), c_k = (-1)^(k+1) k C(2m, m - k) / C(2m - 2, m - 1) for m records --
+    // it damps the noise that solutions converged to epsilon carry, which plain polynomial extrapolation (OPENMM_HIP_AMOEBA_PREDICTOR=poly)
+    // amplifies.  OPENMM_HIP_AMOEBA_PREDICTOR_POINTS limits the number of records used (default 4).
+    static const bool poly = getenv("OPENMM_HIP_AMOEBA_PREDICTOR") != NULL && string(getenv("OPENMM_HIP_AMOEBA_PREDICTOR")) == "poly";
+    static const int maxPoints = getenv("OPENMM_HIP_AMOEBA_PREDICTOR_POINTS") != NULL ? max(1, min((int) HistorySlots, atoi(getenv("OPENMM_HIP_AMOEBA_PREDICTOR_POINTS")))) : 4;
+    if (!historySameStep) mp.history_use = min(mp.history_use, maxPoints);
+    for (int k = 0; k < OMMHIP_AMOEBA_MAX_HISTORY; k++) mp.history_coeff[k] = 0.0;
+    const int m = mp.history_use;
+    if (m == 1) mp.history_coeff[0] = 1.0;
+    else if (m > 1) {
+        struct Binomial { static double of(int n, int k) { if (k < 0 || k > n) return 0.0; double b = 1.0; for (int i = 1; i <= k; i++) b = b * (n - k + i) / i; return b; } };
+        for (int k = 1; k <= m; k++)
+            mp.history_coeff[k - 1] = poly ? ((k % 2) ? 1.0 : -1.0) * Binomial::of(m, k)
+                                           : ((k % 2) ? 1.0 : -1.0) * k * Binomial::of(2 * m, m - k) / Binomial::of(2 * m - 2, m - 1);
+    }
+    // iterations are only enqueued ahead of the convergence check when the last solve started from the same kind of guess
+    if (mp.history_use != lastHistoryUse) mp.expected_iterations = 0;
+    lastHistoryUse = mp.history_use;
+}
+
+void HipCalcAmoebaMultipoleForceKernel::recordSolve() {
+    if (mutual) { solverIterations[0]++; solverIterations[1] += (long long) solverStatus[1]; }
+    if (!mutual || mp.history == NULL) return;
+    HipContext& hip = *data.hip;
+    if (!historySameStep) {
+        historyNext = (historyNext + 1) % HistorySlots;
+        historyValid = min(historyValid + 1, (int) HistorySlots);
+    }
+    historyStep = data.stepCount; historyPositionsVersion = hip.positionsVersion; historyBoxVersion = hip.boxVersion;
 }
 
 void HipCalcAmoebaMultipoleForceKernel::checkSolver(int rc) {

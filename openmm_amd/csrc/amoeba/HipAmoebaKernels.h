@@ -28,19 +28,23 @@ private:
     double cutoff = 0, dispersionCoefficient = 0, softcorePower = 0, softcoreAlpha = 0;
     ommhip_amoeba_vdw vdw;
     void allocatePairList(int cap);
-    int pairNeeded = 0;
+    int pairNeeded = 0, grownPairCap = 0;      // grownPairCap: the capacity a list that did not fit was grown to (0: never)
+    // Verlet skin of the pair lists: rebuilt when an atom has moved by half of it (device side) or when slot order / box / parameters / capacity changed
+    bool listDirty = true;
+    long long listOrderVersion = -1, listBoxVersion = -1;
+    DeviceBuffer refPos, listState;
     DeviceBuffer parent, reduction, type, sigma, epsilon, exclStart, exclAtoms, alchemical, reduced, tileBounds, exclPos, pairList, pairCount, pairOverflow;
 };
 
 /** amoebaKernels.h:82-139 CalcAmoebaMultipoleForceKernel for PME with direct or mutual polarization; Reference: AmoebaReferenceKernels.cpp:170-520 +
- *  AmoebaReferencePmeMultipoleForce.  The factory hands every other configuration (NoCutoff, mutual / extrapolated polarization, grids
+ *  AmoebaReferencePmeMultipoleForce.  The factory hands every other configuration (NoCutoff, extrapolated polarization, grids
  *  the platform's FFT does not take) to the AMOEBA plugin's own Reference kernel; so does this class for the two queries it does not
  *  compute itself (electrostatic potential on a grid of points, system multipole moments). */
 class HipCalcAmoebaMultipoleForceKernel : public CalcAmoebaMultipoleForceKernel {
 public:
     HipCalcAmoebaMultipoleForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data, KernelImpl* referenceKernel);
     ~HipCalcAmoebaMultipoleForceKernel();
-    /** Can this force be computed natively?  (PME, direct polarization, FFT-friendly grid, rectangular or triclinic box.) */
+    /** Can this force be computed natively?  (PME, direct or mutual polarization, FFT-friendly grid, rectangular or triclinic box.) */
     static bool supports(const AmoebaMultipoleForce& force, const System& system);
     void initialize(const System& system, const AmoebaMultipoleForce& force);
     double execute(ContextImpl& context, bool includeForces, bool includeEnergy);
@@ -56,9 +60,13 @@ private:
     void prepareGrid();
     void induce();
     void setScanOrder();
+    void listBuilt();
     void allocatePairList(int cap);
     bool growPairList(int rc, int attempt);
-    int pairNeeded = 0;
+    int pairNeeded = 0, grownPairCap = 0;
+    bool listDirty = true;                     // Verlet skin of the pair lists, as in the vdW kernel
+    long long listOrderVersion = -1, listBoxVersion = -1;
+    DeviceBuffer refPos, listState;
     void checkSolver(int rc);
     void download3(DeviceBuffer& buffer, std::vector<Vec3>& out);
     void syncHostPositions(ContextImpl& context);
@@ -68,11 +76,19 @@ private:
     double alphaEwald = 0, cutoff = 0, lastBox[6] = {0, 0, 0, 0, 0, 0};
     bool etermBuilt = false, mutual = false;
     double solverStatus[2] = {0, 0};          // epsilon reached and iterations of the last mutual-polarization solve
+    // first guess of the solver from the solutions of the previous steps (ommhip_amoeba_multipole::history): a ring of HistorySlots records
+    static const int HistorySlots = OMMHIP_AMOEBA_MAX_HISTORY;
+    int historyNext = 0, historyValid = 0;    // slot the next solution goes to; how many of the most recent slots hold solutions of consecutive steps
+    long long historyStep = -1, historyPositionsVersion = -1, historyBoxVersion = -1;      // when the newest record was made
+    bool historySameStep = false;
+    int lastHistoryUse = -1;
+    void chooseFirstGuess();                  // before a solve: history_use / history_next / expected_iterations
+    void recordSolve();                       // after a successful one
     ommhip_amoeba_multipole mp;
     ommhip_pme pme, pme2;
     void* sideStream = NULL; void* eventA = NULL; void* eventB = NULL;
     DeviceBuffer charge, molDipole, molQuad, axis, thole, damping, polarity, specStart, specAtom, specScale;
-    DeviceBuffer labDipole, labQuad, fieldD, fieldP, indD, indP, phi, phiInd, phiIndP, solver, torque, tileBounds, specPos, specScaleSorted, pairList, pairCount, pairOverflow, pairCache;
+    DeviceBuffer labDipole, labQuad, fieldD, fieldP, indD, indP, phi, phiInd, phiIndP, solver, history, torque, tileBounds, specPos, specScaleSorted, pairList, pairCount, pairOverflow, pairCache;
     DeviceBuffer moduliX, moduliY, moduliZ, twiddleX, twiddleY, twiddleZ, eterm, gridReal, gridComplex, gridReal2, gridComplex2;
 };
 

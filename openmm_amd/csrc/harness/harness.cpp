@@ -5,6 +5,8 @@
  * It mirrors the public API names it wraps (openmmapi/include/openmm/*.h); it contains no physics.
  */
 #include "OpenMM.h"
+#include "ReferenceConstraints.h"
+#include "ReferenceSETTLEAlgorithm.h"
 #include <cstring>
 #include <map>
 #include <sstream>
@@ -37,6 +39,20 @@ int omm_system_num_particles(void* s) { return ((System*) s)->getNumParticles();
 int omm_system_set_box(void* s, const double* b) { GUARD(((System*) s)->setDefaultPeriodicBoxVectors(Vec3(b[0], b[1], b[2]), Vec3(b[3], b[4], b[5]), Vec3(b[6], b[7], b[8]))) }
 int omm_system_add_constraints(void* s, int n, const int* pairs, const double* dist) { GUARD(for (int i = 0; i < n; i++) ((System*) s)->addConstraint(pairs[2 * i], pairs[2 * i + 1], dist[i])) }
 int omm_system_num_constraints(void* s) { return ((System*) s)->getNumConstraints(); }
+
+/* The SETTLE clusters the Reference platform finds in a System (ReferenceConstraints.cpp:44-148): the checker of the HIP platform's
+ * own partition (tests only).  Returns the number of clusters; fills at most `capacity`: atoms[3i..], dist[2i..]. */
+int omm_reference_settle_clusters(void* s, int* atoms, double* dist, int capacity) {
+    try {
+        ReferenceConstraints constraints(*(System*) s);
+        ReferenceSETTLEAlgorithm* settle = dynamic_cast<ReferenceSETTLEAlgorithm*>(constraints.settle);
+        if (settle == NULL) return 0;
+        const int n = settle->getNumClusters();
+        for (int i = 0; i < n && i < capacity; i++)
+            settle->getClusterParameters(i, atoms[3 * i], atoms[3 * i + 1], atoms[3 * i + 2], dist[2 * i], dist[2 * i + 1]);
+        return n;
+    } catch (const std::exception& e) { lastError = e.what(); return -1; }
+}
 
 /* ---- NonbondedForce (openmmapi/include/openmm/NonbondedForce.h) */
 void* omm_nonbonded_create(void* s, int method, double cutoff, double ewaldTol, int useDispersion, int useSwitch, double switchDist) {

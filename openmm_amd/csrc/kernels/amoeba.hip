@@ -37,6 +37,7 @@ struct VdwArgs {
     // scan positions: position g holds atom order[g] (the platform's slot order, -1: padding) or g itself
     const int* order; int numScan;
     const int* pairList; const int* pairCount; int listStride, listSubcap;      // pair lists (amoeba_pairs.h); nullptr: the scan over all atoms
+    int listSkin;                                                               // the lists reach beyond the cutoff (Verlet skin): the pair kernel re-tests the atom distance
 };
 
 __device__ __forceinline__ int scan_atom(const VdwArgs& a, int g) { return g < a.numScan ? (a.order != nullptr ? a.order[g] : g) : -1; }
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(VDW_BLOCK) void k_vdw_pairs_list(VdwArgs a) {
     const int g = (blockIdx.x * VDW_BLOCK + t) / VDW_SPLIT, q = t % VDW_SPLIT, i = scan_atom(a, g);      // VDW_SPLIT lanes share an atom's list
     const bool active = i >= 0;
     const int ii = active ? i : 0;
-    const double4 si = a.reduced[ii];
+    const double4 si = a.reduced[ii], xi = a.pos[ii];
     const int typeI = a.type[ii];
     const bool alchI = a.alchemical != nullptr && a.alchemical[ii] != 0;
     double fx = 0, fy = 0, fz = 0, energy = 0;
@@ -182,6 +183,13 @@ __global__ __launch_bounds__(VDW_BLOCK) void k_vdw_pairs_list(VdwArgs a) {
         const double4 sj = a.reduced[j];
         double dx = si.x - sj.x, dy = si.y - sj.y, dz = si.z - sj.z;
         min_image_d(dx, dy, dz, a.box);
+        if (a.listSkin) {
+            // a list with a skin: the pair counts when the ATOMS are within the cutoff (the rule the list was built by, amoeba_pairs.h)
+            const double4 xj = a.pos[j];
+            double ax = xi.x - xj.x, ay = xi.y - xj.y, az = xi.z - xj.z;
+            min_image_d(ax, ay, az, a.box);
+            if (ax * ax + ay * ay + az * az > a.cutoff2) continue;
+        }
         const double r = sqrt(dx * dx + dy * dy + dz * dz);
         const int typeJ = a.type[j];
         double sigma = a.sigma[typeI * a.numTypes + typeJ], epsilon = a.epsilon[typeI * a.numTypes + typeJ], softcore = 0.0;
@@ -249,7 +257,15 @@ extern "C" int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* v, const void* 
         p.tileCenter = (double4*) v->tile_bounds; p.tileHalf = p.tileCenter + tiles;
         p.rowStart = a.exclStart; p.rowAtom = a.exclAtoms; p.rowPos = v->excl_pos; p.rowData = nullptr; p.rowDataIn = nullptr;
         p.list = v->pair_list; p.count = v->pair_count; p.overflow = v->pair_overflow;
-        const int rc = pl_launch(p, v->pair_needed, st);
+        // Verlet skin: the list holds the partners within cutoff + skin and lives until an atom has moved by skin / 2; the pair kernel re-tests
+        p.refPos = nullptr; p.state = nullptr; p.skinHalf2 = 0.0; p.forceRebuild = 1;
+        a.listSkin = 0;
+        if (v->skin > 0.0 && v->ref_pos != nullptr && v->list_state != nullptr) {
+            const double radius = v->cutoff + v->skin;
+            p.cutoff2 = radius * radius; p.refPos = (double4*) v->ref_pos; p.state = v->list_state; p.skinHalf2 = 0.25 * v->skin * v->skin; p.forceRebuild = v->force_rebuild != 0;
+            a.listSkin = 1;
+        }
+        const int rc = pl_launch(p, v->pair_needed, st, v->list_builds);
         if (rc != 0) return rc;
         a.pairList = v->pair_list; a.pairCount = v->pair_count; a.listStride = a.numScan; a.listSubcap = v->pair_cap / PL_PARTS;
         hipLaunchKernelGGL(k_vdw_pairs_list, dim3((unsigned) (((size_t) a.numScan * VDW_SPLIT + VDW_BLOCK - 1) / VDW_BLOCK)), dim3(VDW_BLOCK), 0, st, a);

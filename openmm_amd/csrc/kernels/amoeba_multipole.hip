@@ -40,6 +40,7 @@ using namespace omm;
 namespace {
 
 #define MP_BLOCK 128
+#define MP_CG_BLOCK 256          // the vector kernels of the solver (k_mp_cg)
 #define MP_SQRT_PI 1.77245385090551602730
 
 struct V3 { double x, y, z; };
@@ -110,7 +111,8 @@ struct MpArgs {
     const int* order; int numScan;
     const int* pairList; const int* pairCount; int listStride, listSubcap;
     int precond; double precondCut2;               // neighbour-pair preconditioner of the solver (needs the pair cache)
-    double* pairCache; int pairCap;                // mutual polarization: per list entry (dx, dy, dz, b1, b2) of the Thole-damped dipole-dipole chain, planes of pairCap * listStride
+    float* pairCache; int pairCap;                 // mutual polarization: per list entry (dx, dy, dz, b1, b2) of the Thole-damped dipole-dipole chain, float planes of pairCap * listStride
+    const double* doneFlag;                        // mutual polarization: sums[10] of the solver -- non-zero once the dipoles have converged: kernels of iterations enqueued ahead return at once
     const double4* specScaleSorted;                // scale factors of the special pairs, rows in the order the list entries index them
 };
 
@@ -222,6 +224,7 @@ __device__ __forceinline__ void atom_splines(const MpArgs& a, V3 x, int (&idx)[3
 #define MP_SPREAD_LANES 8
 template <bool INDUCED>
 __global__ void k_mp_spread(MpArgs a, const double* __restrict__ A, double sA, const double* __restrict__ B, double sB) {
+    if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = tid / MP_SPREAD_LANES, iz = tid % MP_SPREAD_LANES;
     if (i >= a.n || iz >= 5) return;
@@ -279,6 +282,7 @@ __global__ void k_mp_spread(MpArgs a, const double* __restrict__ A, double sA, c
 __device__ __forceinline__ int mpb_wrap_rel(int d, int n) { if (d >= (n + 1) / 2) d -= n; if (d < -(n / 2)) d += n; return d; }
 
 __global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double* __restrict__ A, double sA, const double* __restrict__ B, double sB) {
+    if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;           // an iteration enqueued ahead of the convergence check (solve_mutual)
     __shared__ int brick[MPB_BRICK * MPB_BRICK * MPB_ZS];
     __shared__ float th[MPB_ATOMS][3][5], dth[MPB_ATOMS][3][5], fd[MPB_ATOMS][3];
     __shared__ int base[MPB_ATOMS][3], ok[MPB_ATOMS], ref[3], minRel[3];
@@ -368,6 +372,7 @@ __global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double
 // iteration reads, at a third of the arithmetic.
 template <int MAXORD>
 __global__ void k_mp_potential(MpArgs a, double* __restrict__ out) {
+    if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = tid / MP_SPREAD_LANES, iz = tid % MP_SPREAD_LANES;
     const bool atom = i < a.n, mine = atom && iz < 5;
@@ -519,11 +524,13 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_field(MpArgs a) {
             if (inside) pair_chains(a.alpha, r2, dampI, s.damp, tholeI, s.thole, bn, cn, lam);
             if (a.pairCache != nullptr) {
                 // what the induced-dipole field of every solver iteration needs of this pair (k_mp_dipole_field): geometry and the two
-                // coefficients of the damped chain -- the erfc / exp / Thole arithmetic is done once per evaluation, not once per iteration
+                // coefficients of the damped chain -- the erfc / exp / Thole arithmetic is done once per evaluation, not once per iteration.
+                // Stored as float: the iterations stream this cache (20 bytes per entry and iteration: they are bound by it), their sums
+                // stay double, and the converged dipoles only have to meet the solver's tolerance; the forces do not read it.
                 const size_t plane = (size_t) a.pairCap * a.listStride, at = (size_t) k * a.listStride + g;
-                a.pairCache[at] = dx; a.pairCache[plane + at] = dy; a.pairCache[2 * plane + at] = dz;
-                a.pairCache[3 * plane + at] = inside ? bn[1] - (1.0 - lam[1]) * cn[1] : 0.0;
-                a.pairCache[4 * plane + at] = inside ? bn[2] - (1.0 - lam[2]) * cn[2] : 0.0;
+                a.pairCache[at] = (float) dx; a.pairCache[plane + at] = (float) dy; a.pairCache[2 * plane + at] = (float) dz;
+                a.pairCache[3 * plane + at] = inside ? (float) (bn[1] - (1.0 - lam[1]) * cn[1]) : 0.f;
+                a.pairCache[4 * plane + at] = inside ? (float) (bn[2] - (1.0 - lam[2]) * cn[2]) : 0.f;
             }
             if (!inside) continue;
             const V3 r = v3(dx, dy, dz);
@@ -684,8 +691,12 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
 // reciprocal part from their two potentials, the self field.  calculateInducedDipoleFields (:6059-6152).
 // ------------------------------------------------------------------------------------------------
 
+// cgStage >= 0 (solver work vectors in w, no preconditioner): the per-atom part of the conjugate-gradient stage that consumes this field is
+// done here instead of in a launch of its own (k_mp_cg describes the stages) -- 0: the residual of the first guess, z = p = alpha r and
+// their dot products; 1: A p = p / alpha - T p into the place of T p, and p . A p.  -1: the field is stored, nothing else.
 __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const double* __restrict__ vD, const double* __restrict__ vP, const double* __restrict__ phiD,
-                                                              const double* __restrict__ phiP, double* __restrict__ outD, double* __restrict__ outP) {
+                                                              const double* __restrict__ phiP, double* __restrict__ outD, double* __restrict__ outP, double* w, int cgStage) {
+    if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;           // an iteration enqueued ahead of the convergence check (solve_mutual)
     const int t = threadIdx.x, g = (blockIdx.x * MP_BLOCK + t) / MP_SPLIT, q = t % MP_SPLIT, i = scan_atom(a, g);
     const bool active = i >= 0;
     const int ii = active ? i : 0;
@@ -722,12 +733,40 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const do
         }
     }
     ed = split_sum(ed); ep = split_sum(ep);
-    if (!active || q != 0) return;
-    const double selfTerm = (4.0 / 3.0) * a.alpha * a.alpha * a.alpha / MP_SQRT_PI, invK = 1.0 / OMM_ONE_4PI_EPS0_D;
-    const double* pd = phiD + 20 * (size_t) i;
-    const double* pp = phiP + 20 * (size_t) i;
-    store3(outD, i, ed - invK * v3(pd[1], pd[2], pd[3]) + selfTerm * load3(vD, i));
-    store3(outP, i, ep - invK * v3(pp[1], pp[2], pp[3]) + selfTerm * load3(vP, i));
+    if (cgStage < 0 && (!active || q != 0)) return;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (active && q == 0) {
+        const double selfTerm = (4.0 / 3.0) * a.alpha * a.alpha * a.alpha / MP_SQRT_PI, invK = 1.0 / OMM_ONE_4PI_EPS0_D;
+        const double* pd = phiD + 20 * (size_t) i;
+        const double* pp = phiP + 20 * (size_t) i;
+        const V3 viD = load3(vD, i), viP = load3(vP, i);
+        const V3 td = ed - invK * v3(pd[1], pd[2], pd[3]) + selfTerm * viD, tp = ep - invK * v3(pp[1], pp[2], pp[3]) + selfTerm * viP;
+        if (cgStage < 0) { store3(outD, i, td); store3(outP, i, tp); }
+        else {
+            const size_t n3 = 3 * (size_t) a.n;
+            const double pol = a.polarity[i], invPol = pol > 0 ? 1.0 / pol : 0.0;
+            if (cgStage == 0) {
+                V3 rd = v3(0, 0, 0), rp = v3(0, 0, 0);
+                if (pol > 0) { rd = load3(a.fieldD, i) - invPol * viD + td; rp = load3(a.fieldP, i) - invPol * viP + tp; }
+                store3(w, i, rd); store3(w + n3, i, rp);
+                store3(w + 2 * n3, i, pol * rd); store3(w + 3 * n3, i, pol * rp); store3(w + 4 * n3, i, pol * rd); store3(w + 5 * n3, i, pol * rp);
+                s0 = pol * dot(rd, rd); s1 = pol * dot(rp, rp); s2 = pol * pol * dot(rd, rd); s3 = pol * pol * dot(rp, rp);
+            }
+            else {
+                const V3 ad = invPol * viD - (pol > 0 ? td : v3(0, 0, 0)), ap = invPol * viP - (pol > 0 ? tp : v3(0, 0, 0));
+                store3(outD, i, ad); store3(outP, i, ap);            // t now holds A p
+                s0 = dot(viD, ad); s1 = dot(viP, ap);
+            }
+        }
+    }
+    if (cgStage < 0) return;
+    double* sums = w + 8 * 3 * (size_t) a.n;
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    if (cgStage == 0) { s2 = wave_sum(s2); s3 = wave_sum(s3); }
+    if ((t & 63) == 0) {
+        if (cgStage == 0) { atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); atomicAdd(&sums[4], s2); atomicAdd(&sums[5], s3); }
+        else { atomicAdd(&sums[2], s0); atomicAdd(&sums[3], s1); }
+    }
 }
 
 // Preconditioner of the conjugate gradients: z = M r with M = 2 alpha + alpha T_near alpha, the first terms of the Neumann series of
@@ -736,6 +775,7 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const do
 // the pair cache k_mp_field wrote; symmetric by construction (T_ij = T_ji, both directions visited).  Also accumulates r.z: into sums[0,1] at
 // the start (initial = 1: p = z as well), into sums[6,7] inside an iteration.
 __global__ __launch_bounds__(MP_BLOCK) void k_mp_precond(MpArgs a, double* w, int initial) {
+    if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;
     const int t = threadIdx.x, g = (blockIdx.x * MP_BLOCK + t) / MP_SPLIT, q = t % MP_SPLIT, i = scan_atom(a, g);
     const bool active = i >= 0;
     const size_t n3 = 3 * (size_t) a.n;
@@ -773,29 +813,49 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_precond(MpArgs a, double* w, in
 
 // Conjugate gradients on (1/alpha - T) mu = E for both dipole sets at once.  Vectors (3n each) in `w`:
 //   0 rD  1 rP  2 zD  3 zP  4 pD  5 pP  6 tD  7 tP (T p)        sums (device double[16] behind them): see below
-// stage 0: start from mu = alpha E:  r = T mu (given in t), z = alpha r, p = z;  sums[0,1] = r.z (d, p), sums[4,5] = z.z
+// stage 0: start from the dipoles in indD / indP (alpha E, or a guess extrapolated from earlier solutions: k_mp_predict):
+//          r = E - mu / alpha + T mu  (T mu given in t; zero for mu = alpha E up to rounding of alpha / alpha), z = alpha r, p = z;
+//          sums[0,1] = r.z (d, p), sums[4,5] = z.z
 // stage 1: Ap = p / alpha - t;  sums[2,3] = p.Ap
 // stage 2: mu += a p, r -= a Ap, z = alpha r;  sums[0,1] = r.z (new), sums[4,5] = z.z     (a = sums_old[0,1] / sums[2,3], given)
 // stage 3: p = z + b p                                                                      (b given)
 // The step lengths are formed on the device from the sums the previous stage left (sums[0,1] r.z of the current residual, [2,3] p.Ap,
-// [6,7] r.z of the new residual, [4,5] z.z for the convergence measure): the host reads the measure once per iteration instead of
-// fetching every dot product.  Stage 4 (one thread) moves the new r.z into place and clears the accumulators for the next iteration.
-__global__ void k_mp_cg(MpArgs a, double* w, int stage, double cD, double cP) {
+// [6,7] r.z of the new residual, [4,5] z.z for the convergence measure).  Stage 4 (one thread) moves the new r.z into place, clears the
+// accumulators for the next iteration and forms the convergence measure itself -- debye x the RMS of alpha r, the Reference's epsilon
+// (convergeInduceDipolesByDIIS :939-1005) --: sums[12] = epsilon, sums[11] = iterations done, sums[10] = 1 once epsilon is below the target.
+// Every kernel of an iteration returns at once when sums[10] is set, so the host may enqueue iterations ahead of looking at the measure
+// (solve_mutual): no host round trip per iteration.
+__global__ void k_mp_cg(MpArgs a, double* w, int stage, double target, double unused) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n3 = 3 * (size_t) a.n;
     double* sums = w + 8 * n3;
-    if (stage == 4) {
-        if (i == 0) { sums[0] = sums[6]; sums[1] = sums[7]; sums[8] = sums[4]; sums[9] = sums[5]; sums[2] = sums[3] = sums[4] = sums[5] = sums[6] = sums[7] = 0.0; }
+    const double debye = 48.033324;          // AmoebaReferenceMultipoleForce::_debye
+    if (stage == 4 || stage == 5) {
+        // 5: after stage 0 (the measure of the first guess); 4: end of an iteration
+        if (i == 0 && sums[10] == 0.0) {
+            if (stage == 4) { sums[0] = sums[6]; sums[1] = sums[7]; sums[11] += 1.0; }
+            const double eps = debye * sqrt(fmax(sums[4], sums[5]) / a.n);
+            sums[12] = eps;
+            if (eps < target) sums[10] = 1.0;
+            sums[2] = sums[3] = sums[4] = sums[5] = sums[6] = sums[7] = 0.0;
+        }
         return;
     }
+    if (stage != 0 && sums[10] != 0.0) return;
+    double cD = 0.0, cP = 0.0;
     if (stage == 2) { cD = sums[2] != 0.0 ? sums[0] / sums[2] : 0.0; cP = sums[3] != 0.0 ? sums[1] / sums[3] : 0.0; }
     if (stage == 3) { cD = sums[0] != 0.0 ? sums[6] / sums[0] : 0.0; cP = sums[1] != 0.0 ? sums[7] / sums[1] : 0.0; }
+    __shared__ double red[4][MP_CG_BLOCK / 64];
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (i < a.n) {
         const double pol = a.polarity[i], invPol = pol > 0 ? 1.0 / pol : 0.0;
         double* rD = w; double* rP = w + n3; double* zD = w + 2 * n3; double* zP = w + 3 * n3; double* pD = w + 4 * n3; double* pP = w + 5 * n3; double* tD = w + 6 * n3; double* tP = w + 7 * n3;
         if (stage == 0) {
-            const V3 rd = pol > 0 ? load3(tD, i) : v3(0, 0, 0), rp = pol > 0 ? load3(tP, i) : v3(0, 0, 0);
+            V3 rd = v3(0, 0, 0), rp = v3(0, 0, 0);
+            if (pol > 0) {
+                rd = load3(a.fieldD, i) - invPol * load3(a.indD, i) + load3(tD, i);
+                rp = load3(a.fieldP, i) - invPol * load3(a.indP, i) + load3(tP, i);
+            }
             store3(rD, i, rd); store3(rP, i, rp);
             if (!a.precond) { store3(zD, i, pol * rd); store3(zP, i, pol * rp); store3(pD, i, pol * rd); store3(pP, i, pol * rp); s0 = pol * dot(rd, rd); s1 = pol * dot(rp, rp); }
             s2 = pol * pol * dot(rd, rd); s3 = pol * pol * dot(rp, rp);
@@ -817,13 +877,61 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double cD, double cP) {
             store3(pD, i, load3(zD, i) + cD * load3(pD, i)); store3(pP, i, load3(zP, i) + cP * load3(pP, i));
         }
     }
-    if (stage == 3) return;
+    if (stage == 3) {
+        // the block that finishes last ends the iteration (what stage 4 does as a launch of its own): every block has read the step
+        // lengths from the sums before it takes its ticket
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const unsigned ticket = atomicAdd((unsigned*) &sums[14], 1u);
+            if (ticket == gridDim.x - 1) {
+                *(unsigned*) &sums[14] = 0u;
+                sums[0] = sums[6]; sums[1] = sums[7]; sums[11] += 1.0;
+                const double eps = debye * sqrt(fmax(sums[4], sums[5]) / a.n);
+                sums[12] = eps;
+                sums[2] = sums[3] = sums[4] = sums[5] = sums[6] = sums[7] = 0.0;
+                __threadfence();
+                if (eps < target) sums[10] = 1.0;
+            }
+        }
+        return;
+    }
+    // one atomic per block and sum: every same-address atomic of a launch is serialised at the memory side
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; red[2][threadIdx.x >> 6] = s2; red[3][threadIdx.x >> 6] = s3; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s0 = s1 = s2 = s3 = 0.0;
+        for (int k = 0; k < (int) (blockDim.x >> 6); k++) { s0 += red[0][k]; s1 += red[1][k]; s2 += red[2][k]; s3 += red[3][k]; }
         if (stage == 1) { atomicAdd(&sums[2], s0); atomicAdd(&sums[3], s1); }
         else if (stage == 2) { atomicAdd(&sums[6], s0); atomicAdd(&sums[7], s1); atomicAdd(&sums[4], s2); atomicAdd(&sums[5], s3); }
         else { atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); atomicAdd(&sums[4], s2); atomicAdd(&sums[5], s3); }
     }
+}
+
+// First guess of the solver from the solutions of earlier calls: mu(t) ~ sum_k c_k mu(t - k dt), k = 1..count, with the caller's
+// coefficients.  history: ring of `slots` records of 6n doubles (mu_d, mu_p), `newest` = the slot of mu(t - dt).
+// store = 1: the converged dipoles go into slot `newest` instead (called after the solve).
+struct HistoryCoeff { double c[OMMHIP_AMOEBA_MAX_HISTORY]; };
+__global__ void k_mp_history(MpArgs a, double* history, int slots, int newest, int count, int store, HistoryCoeff coeff) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const size_t n3 = 3 * (size_t) a.n;
+    if (store) {
+        double* rec = history + (size_t) newest * 2 * n3;
+        store3(rec, i, load3(a.indD, i)); store3(rec + n3, i, load3(a.indP, i));
+        return;
+    }
+    if (!(a.polarity[i] > 0)) return;
+    V3 d = v3(0, 0, 0), p = v3(0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < OMMHIP_AMOEBA_MAX_HISTORY; k++) {
+        if (k >= count) break;
+        const double c = coeff.c[k];
+        const double* rec = history + (size_t) ((newest - k + slots) % slots) * 2 * n3;
+        d = d + c * load3(rec, i); p = p + c * load3(rec + n3, i);
+    }
+    store3(a.indD, i, d); store3(a.indP, i, p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -917,6 +1025,7 @@ bool make_args(const ommhip_amoeba_multipole* mp, const void* pos_d, const doubl
     // per iteration -- no gain; the default stays z = alpha r
     static const bool usePrecond = getenv("OPENMM_HIP_AMOEBA_PRECOND") != nullptr && atoi(getenv("OPENMM_HIP_AMOEBA_PRECOND")) != 0;
     a.precond = a.pairCache != nullptr && usePrecond ? 1 : 0; a.precondCut2 = 0.45 * 0.45;
+    a.doneFlag = nullptr;
     return true;
 }
 
@@ -937,7 +1046,13 @@ int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const d
     p.rowStart = a.specStart; p.rowAtom = a.specAtom; p.rowPos = mp->special_pos;
     p.rowData = (double4*) mp->special_scale_sorted; p.rowDataIn = a.specScale;
     p.list = mp->pair_list; p.count = mp->pair_count; p.overflow = mp->pair_overflow;
-    return pl_launch(p, mp->pair_needed, st);
+    // Verlet skin: the list holds the partners within cutoff + skin and lives until an atom has moved by skin / 2 (the pair kernels re-test)
+    p.refPos = nullptr; p.state = nullptr; p.skinHalf2 = 0.0; p.forceRebuild = 1;
+    if (mp->skin > 0.0 && mp->ref_pos != nullptr && mp->list_state != nullptr) {
+        const double radius = mp->cutoff + mp->skin;
+        p.cutoff2 = radius * radius; p.refPos = (double4*) mp->ref_pos; p.state = mp->list_state; p.skinHalf2 = 0.25 * mp->skin * mp->skin; p.forceRebuild = mp->force_rebuild != 0;
+    }
+    return pl_launch(p, mp->pair_needed, st, mp->list_builds);
 }
 
 // frames, reciprocal potential of the permanent multipoles, fields and induced dipoles
@@ -998,47 +1113,70 @@ void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const
     hipStreamWaitEvent(st, (hipEvent_t) mp->event_b, 0);           // the main stream goes on when both potentials are there
 }
 
-// Mutual polarization: conjugate gradients from the direct-polarization dipoles.  Leaves mu_d, mu_p and their potentials (phiInd, phiIndP).
-int solve_mutual(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t st) {
-    const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
+// Mutual polarization: conjugate gradients from the direct-polarization dipoles, or from a guess extrapolated from the solutions of the
+// previous calls (mp->history_use > 0).  Leaves mu_d, mu_p and their potentials (phiInd, phiIndP).
+// The convergence measure is formed on the device (k_mp_cg stage 4 / 5) and every kernel of an iteration gives up at once when it has
+// been met, so the host enqueues mp->expected_iterations - 1 iterations (what the previous call needed; 0 = unknown) before it first waits
+// for the measure, then one at a time: two host round trips per solve instead of one per iteration.  (The FFT launches of an iteration
+// enqueued in vain -- the call needed fewer iterations than the one before -- still run, on cleared grids.)
+int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st) {
     const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
     const size_t n3 = 3 * (size_t) a.n;
     double* w = mp->solver;
     double* sums = w + 8 * n3;
     double* tD = w + 6 * n3; double* tP = w + 7 * n3; double* pD = w + 4 * n3; double* pP = w + 5 * n3;
     double h[16];
-    const double debye = 48.033324;          // AmoebaReferenceMultipoleForce::_debye
     auto readSums = [&]() -> int { hipError_t e = hipMemcpyAsync(h, sums, sizeof(double) * 16, hipMemcpyDeviceToHost, st); if (e != hipSuccess) return (int) e; return (int) hipStreamSynchronize(st); };
-    // T mu_0
-    dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st, true);
-    hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, tD, tP);
+    const bool haveHistory = mp->history != nullptr && mp->history_slots >= 1;
+    const int use = haveHistory ? (mp->history_use < 0 ? 0 : (mp->history_use > OMMHIP_AMOEBA_MAX_HISTORY ? OMMHIP_AMOEBA_MAX_HISTORY : (mp->history_use > mp->history_slots ? mp->history_slots : mp->history_use))) : 0;
+    HistoryCoeff coeff;
+    for (int k = 0; k < OMMHIP_AMOEBA_MAX_HISTORY; k++) coeff.c[k] = mp->history_coeff[k];
     hipMemsetAsync(sums, 0, sizeof(double) * 16, st);
-    hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 0, 0.0, 0.0);
-    if (a.precond) hipLaunchKernelGGL(k_mp_precond, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, w, 1);
-    int rc = readSums();
-    if (rc != 0) return rc;
-    double epsilon = debye * sqrt(fmax(h[4], h[5]) / a.n);
-    hipMemsetAsync(sums + 4, 0, sizeof(double) * 2, st);
-    int iteration = 0;
-    while (epsilon >= mp->target_epsilon && iteration < mp->max_iterations) {
-        dipole_potentials(mp, a, pD, a.phiInd, pP, a.phiIndP, st, true);
-        hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP);
-        hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 1, 0.0, 0.0);      // Ap, p.Ap
-        hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 2, 0.0, 0.0);      // mu += a p, r -= a Ap (a from the device sums)
-        if (a.precond) hipLaunchKernelGGL(k_mp_precond, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, w, 0);      // z = M r, r.z
-        hipLaunchKernelGGL(k_mp_cg, dim3(blocks), dim3(MP_BLOCK), 0, st, a, w, 3, 0.0, 0.0);      // p = z + b p
-        hipLaunchKernelGGL(k_mp_cg, dim3(1), dim3(64), 0, st, a, w, 4, 0.0, 0.0);                  // roll the sums
-        rc = readSums();                                                                          // the one host round trip of the iteration
-        if (rc != 0) return rc;
-        epsilon = debye * sqrt(fmax(h[8], h[9]) / a.n);
-        iteration++;
+    if (use > 0) {
+        const int newest = (mp->history_newest % mp->history_slots + mp->history_slots) % mp->history_slots;
+        hipLaunchKernelGGL(k_mp_history, dim3(blocks), dim3(MP_BLOCK), 0, st, a, mp->history, mp->history_slots, newest, use, 0, coeff);
     }
-    if (mp->status != nullptr) { mp->status[0] = epsilon; mp->status[1] = iteration; }
+    // T mu_0 and the residual of the first guess
+    dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st, true);
+    const int cgBlocks = (a.n + MP_CG_BLOCK - 1) / MP_CG_BLOCK;
+    if (a.precond) {
+        hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, tD, tP, w, -1);
+        hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 0, 0.0, 0.0);
+        hipLaunchKernelGGL(k_mp_precond, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, w, 1);
+    }
+    else hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, tD, tP, w, 0);
+    hipLaunchKernelGGL(k_mp_cg, dim3(1), dim3(64), 0, st, a, w, 5, mp->target_epsilon, 0.0);
+    a.doneFlag = sums + 10;                   // from here on the kernels look at the convergence word
+    static const bool everyIteration = getenv("OPENMM_HIP_AMOEBA_CHECK_EVERY_ITERATION") != nullptr;       // A/B knob: one host round trip per iteration, as before
+    const int unchecked = everyIteration ? 0 : (mp->expected_iterations > 1 ? mp->expected_iterations - 1 : 0);
+    int rc = 0, enqueued = 0;
+    bool done = false;
+    if (unchecked == 0) { rc = readSums(); if (rc != 0) return rc; done = h[10] != 0.0; }
+    while (!done && enqueued < mp->max_iterations) {
+        dipole_potentials(mp, a, pD, a.phiInd, pP, a.phiIndP, st, true);
+        if (a.precond) {
+            hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP, w, -1);
+            hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 1, 0.0, 0.0);      // Ap, p.Ap
+        }
+        else hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP, w, 1);      // T p, Ap, p.Ap
+        hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 2, 0.0, 0.0);          // mu += a p, r -= a Ap (a from the device sums)
+        if (a.precond) hipLaunchKernelGGL(k_mp_precond, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, w, 0);      // z = M r, r.z
+        hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 3, mp->target_epsilon, 0.0);   // p = z + b p; the last block rolls the sums and forms the measure and the convergence word
+        enqueued++;
+        if (enqueued >= unchecked || enqueued == mp->max_iterations) { rc = readSums(); if (rc != 0) return rc; done = h[10] != 0.0; }
+    }
+    a.doneFlag = nullptr;
+    const double epsilon = h[12];
+    const int iterations = (int) h[11];
+    if (mp->status != nullptr) { mp->status[0] = epsilon; mp->status[1] = iterations; }
     static const bool report = getenv("OPENMM_HIP_AMOEBA_DEBUG") != nullptr;
-    if (report) fprintf(stderr, "amoeba solver: %d iterations, epsilon %.3g (target %.3g), preconditioner %d\n", iteration, epsilon, mp->target_epsilon, a.precond);
+    if (report) fprintf(stderr, "amoeba solver: %d iterations (%d enqueued, first guess from %d earlier solutions), epsilon %.3g (target %.3g), preconditioner %d\n", iterations, enqueued, use, epsilon, mp->target_epsilon, a.precond);
+    if (!done) return -1;
+    if (haveHistory && mp->history_store >= 0)
+        hipLaunchKernelGGL(k_mp_history, dim3(blocks), dim3(MP_BLOCK), 0, st, a, mp->history, mp->history_slots, mp->history_store % mp->history_slots, 0, 1, coeff);
     // potentials of the converged dipoles (the force kernels read them)
     dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st);
-    return epsilon < mp->target_epsilon ? 0 : -1;
+    return 0;
 }
 
 }  // namespace

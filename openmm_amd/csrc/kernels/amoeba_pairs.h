@@ -1,4 +1,5 @@
-// Per-atom pair lists of the AMOEBA kernels (amoeba.hip: vdW, amoeba_multipole.hip: multipoles), rebuilt at every evaluation.
+// Per-atom pair lists of the AMOEBA kernels (amoeba.hip: vdW, amoeba_multipole.hip: multipoles): built for the cutoff plus a skin and
+// kept until some atom has moved by half the skin (the device decides: pl_check), the consumers re-testing the cutoff per pair.
 //
 // The AMOEBA pair terms are long (a multipole pair is three derivative chains with erfc / exp and ~1 000 double-precision operations), so
 // what matters is that a wavefront only ever executes them for pairs inside the cutoff.  A scan "one thread per atom i, every thread
@@ -41,6 +42,10 @@ struct PairListArgs {
     double4* rowData; const double4* rowDataIn;    // optional payload carried along when the rows are re-sorted (multipole scale factors)
     int* list; int* count; int* overflow;
     long long* trace;                              // profiling (OPENMM_HIP_PL_DEBUG & 4): per workgroup start and end clock, hardware id
+    // Verlet skin (optional: state == nullptr rebuilds at every call).  cutoff2 above is then the LIST radius squared, (cutoff + skin)^2.
+    // state[0]: rebuild needed (pl_check: an atom moved more than skin / 2 since the positions in refPos, or the caller forces it),
+    // state[1]: ticket of pl_finish, state[2]: rebuilds so far.
+    double4* refPos; int* state; double skinHalf2; int forceRebuild;
 };
 
 __device__ __forceinline__ int pl_scan_atom(const PairListArgs& a, int g) { return g < a.numScan ? (a.order != nullptr ? a.order[g] : g) : -1; }
@@ -64,10 +69,39 @@ __global__ void pl_sort_rows(PairListArgs a) {
     }
 }
 
+// Does the list have to be rebuilt?  One thread per atom: moved by more than half the skin since the list was built (plain displacement:
+// the atom-ordered positions are continuous between re-sorts; a jump by a box vector simply asks for a rebuild).
+__global__ void pl_check(PairListArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && a.forceRebuild) a.state[0] = 1;
+    if (i >= a.n || a.forceRebuild) return;
+    const double4 p = a.pos[i], r = a.refPos[i];
+    const double dx = p.x - r.x, dy = p.y - r.y, dz = p.z - r.z;
+    if (dx * dx + dy * dy + dz * dz > a.skinHalf2) a.state[0] = 1;
+}
+
+// After a rebuild that fitted: the positions it was made for, and the request taken back by the block that finishes last.
+__global__ void pl_finish(PairListArgs a) {
+    if (a.state[0] == 0) return;
+    const bool fitted = *a.overflow == 0;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (fitted && i < a.n) a.refPos[i] = a.pos[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&a.state[1], 1) == (int) gridDim.x - 1) {
+            a.state[1] = 0;
+            __threadfence();
+            if (fitted) { a.state[2]++; a.state[0] = 0; }       // a list that did not fit stays requested: the caller grows it and calls again
+        }
+    }
+}
+
 // bounding boxes of the tiles (nearest images relative to the tile's first atom; a tile without atoms gets half extents of -1e30)
 __global__ __launch_bounds__(PL_BLOCK) void pl_tile_bounds(PairListArgs a) {
     __shared__ double lo[3][PL_BLOCK], hi[3][PL_BLOCK];
     __shared__ int firstValid;
+    if (a.state != nullptr && a.state[0] == 0) return;
     const int t = threadIdx.x, g = blockIdx.x * PL_BLOCK + t, i = pl_scan_atom(a, g);
     if (t == 0) firstValid = PL_BLOCK;
     __syncthreads();
@@ -112,6 +146,7 @@ __device__ __forceinline__ bool pl_tiles_far(const PairListArgs& a, int ti, int 
 // is expressed in the same frame, and the image of j nearest to c is then the only one that can lie within the cutoff of any atom
 // of the tile.  Other boxes and oversized tiles reduce every pair (min_image_d).
 __global__ __launch_bounds__(PL_BLOCK) void pl_build(PairListArgs a) {
+    if (a.state != nullptr && a.state[0] == 0) return;             // the list of an earlier call is still good
 #ifndef OMMHIP_EMU
     if (a.trace != nullptr && threadIdx.x == 0) { a.trace[3 * blockIdx.x] = (long long) wall_clock64(); a.trace[3 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long) (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf) << 32); }
 #endif
@@ -243,12 +278,15 @@ __device__ __forceinline__ int pl_at(const int* list, int stride, int subcap, co
 
 // Host side: re-key the rows, bound the tiles, build the list.  Returns 0, a hipError_t, or -2 when the list did not fit
 // (*needed = the longest list, or 0x7fffffff when a row of listed partners is too long to index).  `overflowHost` = pinned or plain host int.
-static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st) {
+static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st, int* buildsHost = nullptr) {
     if (a.numScan > PL_POS_MASK) return 1;
     static const int debugMode = getenv("OPENMM_HIP_PL_DEBUG") != nullptr ? atoi(getenv("OPENMM_HIP_PL_DEBUG")) : 0;     // profiling only: wrong results
     a.debug = debugMode;
     hipMemsetAsync(a.overflow, 0, sizeof(int), st);
-    if (a.rowStart != nullptr) hipLaunchKernelGGL(pl_sort_rows, dim3((a.n + 127) / 128), dim3(128), 0, st, a);
+    if (a.state == nullptr || a.refPos == nullptr) { a.state = nullptr; a.refPos = nullptr; a.forceRebuild = 1; }
+    if (a.state != nullptr) hipLaunchKernelGGL(pl_check, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+    // the rows of listed partners depend on the slot order and the parameters only: the caller forces a rebuild when either changed
+    if (a.rowStart != nullptr && a.forceRebuild) hipLaunchKernelGGL(pl_sort_rows, dim3((a.n + 127) / 128), dim3(128), 0, st, a);
     const int tiles = (a.numScan + PL_BLOCK - 1) / PL_BLOCK;
     if (a.skipTiles) hipLaunchKernelGGL(pl_tile_bounds, dim3(tiles), dim3(PL_BLOCK), 0, st, a);
     a.trace = nullptr;
@@ -257,6 +295,7 @@ static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st) {
     if (debugMode & 4) { if (traceBuf == nullptr) hipMalloc((void**) &traceBuf, sizeof(long long) * 3 * 65536); if (tiles * PL_PARTS <= 65536) a.trace = traceBuf; }
 #endif
     hipLaunchKernelGGL(pl_build, dim3(tiles * PL_PARTS), dim3(PL_BLOCK), 0, st, a);
+    if (a.state != nullptr) hipLaunchKernelGGL(pl_finish, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
 #ifndef OMMHIP_EMU
     if (a.trace != nullptr) {
         // wall_clock64 ticks at 100 MHz: start / end of every workgroup relative to the first start, and where it ran
@@ -275,6 +314,7 @@ static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st) {
 #endif
     int over = 0;
     hipError_t e = hipMemcpyAsync(&over, a.overflow, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && buildsHost != nullptr && a.state != nullptr) e = hipMemcpyAsync(buildsHost, a.state + 2, sizeof(int), hipMemcpyDeviceToHost, st);      // diagnostics: builds so far
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return (int) e;
     if (over != 0) { if (needed != nullptr) *needed = over == 0x7fffffff ? over : over * PL_PARTS; return -2; }       // in entries per atom, as the caller sizes the list

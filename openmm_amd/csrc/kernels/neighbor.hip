@@ -946,7 +946,7 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
         // the same word at the same evaluation, the hosts re-sort together
         int level = 0;                                         // 1: re-sort soon (off the step), 3: re-sort now
         for (int r = 0; r < a.ddRanks; r++) level |= (int) ((const double4*) (a.posWire + (size_t) r * a.ddSlotsPerRank + a.ddTrailerSlot))->w;
-        if (level != 0) a.ddFlags[2] |= level;
+        if (level != 0) a.ddFlags[2] |= level;               // bit 2 (4): some rank's atom left the margin -- every rank ends the run at the same evaluation
     }
     const int atom = a.atomOfSlot[sl];
     const bool valid = inRange && atom >= 0;
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
                     atomicOr(&a.ddFlags[1], ad - a.ddWarn > (a.ddMax - a.ddWarn) / 5 * 3 ? 3 : 1);
                     atomicMax(&a.ddFlags[3], (int) (ad >> 1));
                 }
-                if (ad > a.ddMax) a.ddFlags[0] = 1;
+                if (ad > a.ddMax) { atomicOr(&a.ddFlags[1], 7); a.ddFlags[0] = 1; }      // [0]: it happened on THIS rank (diagnostics); the decision travels in the trailer
             }
             if (a.posScatter != nullptr && !own) {
                 // atom-ordered copy of a foreign atom: the last known position moved by the minimum-image displacement

@@ -212,6 +212,7 @@ void HipContext::uploadPositions(const vector<Vec3>& positions) {
     if (decomposed()) fillWireFromPos();         // every rank was handed all positions: no communication
     sync();
     positionsValid = true;
+    positionsVersion++;
 }
 
 void HipContext::recoverIfFrozen() {
@@ -293,6 +294,7 @@ void HipContext::setBox(const Vec3& a, const Vec3& b, const Vec3& c) {
     boxVectors[0] = a; boxVectors[1] = b; boxVectors[2] = c;
     if (!changed) return;
     for (int i = 0; i < 6; i++) box[i] = nb[i];
+    boxVersion++;
     reorderRequested = true;       // wrap indices depend on the box
     for (size_t i = 0; i < listeners.size(); i++) listeners[i]->boxChanged();
 }
@@ -438,10 +440,12 @@ void HipContext::pollDriftFlags() {
     }
     else if ((n & 7) == 4) {
         HIP_CHECK(ommhip_event_sync(ddFlagsEvent));          // recorded four evaluations ago: long complete
-        if (pinnedDdFlags[0] != 0) {
+        if ((pinnedDdFlags[2] & 4) != 0) {
+            // the hard limit travels in the trailers like the warning levels: every rank finds it at the same evaluation and throws here,
+            // none is left waiting in a collective ([0]: it was one of this rank's atoms; [3]: the largest drift this rank saw)
             char detail[256];
-            snprintf(detail, sizeof(detail), " (rank %d: %.3f nm of the %.3f nm margin, order %d steps old, re-sort %d, interval %d, lag %d)", domain.rank,
-                     2.0 * pinnedDdFlags[3] / 4294967296.0 * box[0], haloDrift, stepsSinceReorder, reorderCount, reorderInterval, reorderLag);
+            snprintf(detail, sizeof(detail), " (rank %d%s: largest drift of its own atoms %.3f nm, margin %.3f nm, order %d steps old, re-sort %lld, interval %d, lag %d)", domain.rank,
+                     pinnedDdFlags[0] != 0 ? ", where it happened" : "", 2.0 * pinnedDdFlags[3] / 4294967296.0 * box[0], haloDrift, stepsSinceReorder, reorderCount, reorderInterval, reorderLag);
             throw OpenMMException(string("HIP platform: an atom drifted further along x between two re-sorts than the halo of the domain decomposition allows; "
                                          "lower OPENMM_HIP_REORDER_INTERVAL or raise OPENMM_HIP_DD_DRIFT") + detail);
         }
@@ -817,6 +821,7 @@ bool HipContext::applyOrder(const vector<Vec3>& positions, bool fromSnapshot) {
             if (hostAtomOfSlot[s] != order[s]) { orderChanged = true; break; }
         for (int s = 0; s < numAtoms; s++) { hostAtomOfSlot[s] = order[s]; hostSlotOfAtom[order[s]] = s; }
     }
+    if (orderChanged) orderVersion++;
     const std::chrono::steady_clock::time_point tOrdered = std::chrono::steady_clock::now();
     // a lagged re-sort of a decomposed run: the units change owner NOW -- every rank needs the current exact state of all atoms
     if (decomposed() && fromSnapshot) gatherState();

@@ -82,6 +82,11 @@ public:
     void addHostForces(const std::vector<Vec3>& forces);       // host forces -> fixed-point buffer
     void setBox(const Vec3& a, const Vec3& b, const Vec3& c);
     void getBox(Vec3& a, Vec3& b, Vec3& c) const { a = boxVectors[0]; b = boxVectors[1]; c = boxVectors[2]; }
+    /** Counters of state edits from outside the integration: every uploadPositions (setPositions, a checkpoint; in host mode every
+     *  evaluation) and every change of the box.  Kernels that carry information from one evaluation to the next (the first guess of the
+     *  AMOEBA dipole solver) compare them with the values they saw last. */
+    long long positionsVersion = 0, boxVersion = 0;
+    long long orderVersion = 0;              // counts the re-sorts that changed the slot order (slot-keyed data of other plugins' kernels: the AMOEBA pair lists)
 
     // ---- per-evaluation
     /** Request the start-of-evaluation clear of the force accumulator (+ extraClear buffer).  The clear is lazy: the
@@ -178,9 +183,9 @@ public:
     void* ddFlagsEvent = NULL;
     long long ddEvaluations = 0;
     long long reorderCount = 0;            // re-sorts so far (diagnostics)
-    /** Called once per force evaluation on decomposed runs: reads the drift flags back every 16 evaluations (asynchronously),
-     *  looks at them 8 evaluations later -- the same evaluation on every rank, and every rank finds the same words -- and
-     *  requests a re-sort, or ends the run when the hard limit was exceeded. */
+    /** Called once per force evaluation on decomposed runs: reads the drift flags back every 8 evaluations (asynchronously),
+     *  looks at them 4 evaluations later -- the same evaluation on every rank, and every rank finds the same words -- and
+     *  requests a re-sort, or ends the run (on every rank alike) when the hard limit was exceeded. */
     void pollDriftFlags();
     unsigned ddWarnFraction() const;      // thresholds in units of 2^-32 box lengths
     unsigned ddMaxFraction() const;

@@ -1,7 +1,5 @@
 #include "HipKernels.h"
 #include <chrono>
-#include "ReferenceConstraints.h"
-#include "ReferenceSETTLEAlgorithm.h"
 #include "ReferenceCCMAAlgorithm.h"
 #include "ReferenceVirtualSites.h"
 #include "SimTKOpenMMRealType.h"
@@ -41,29 +39,83 @@ void uploadVector(DeviceBuffer& buf, const vector<T>& v, void* stream) {
 // ================================================================================================
 // Constraints
 // ================================================================================================
+/* Which constraints form rigid three-atom molecules that SETTLE can treat: the rule of ReferenceConstraints.cpp:44-148, restated.
+ *   - only constraints with at least one massive end count (:54-66);
+ *   - a candidate atom takes part in exactly two of them, both leading to atoms that also take part in exactly two (:72-78);
+ *   - the three atoms must close a triangle (:83-95); every triangle is reported once, ordered by its lowest atom (:91-92);
+ *   - the central atom is the one whose two distances are equal AS FLOATS (:76-77, :114-137), the distances handed on are those
+ *     floats widened again (the Reference platform runs SETTLE with exactly these values); a triangle without two equal sides
+ *     is left to the general solver (:138-139).
+ * Output: atoms[4c .. 4c+2] = (central, second, third) as the Reference orders them, atoms[4c+3] = 0; dist[2c] = centre-to-other,
+ * dist[2c+1] = the distance between the two others. */
+void HipConstraints::findSettleClusters(const System& system, vector<int>& atoms, vector<double>& dist) {
+    const int numParticles = system.getNumParticles(), numConstraints = system.getNumConstraints();
+    vector<int> degree(numParticles, 0);
+    for (int c = 0; c < numConstraints; c++) {
+        int a, b; double d;
+        system.getConstraintParameters(c, a, b, d);
+        if (system.getParticleMass(a) != 0 || system.getParticleMass(b) != 0) { degree[a]++; degree[b]++; }
+    }
+    // the (at most two) distinct partners of every degree-2 atom among degree-2 atoms; a repeated pair keeps its last distance
+    struct Links { int n, other[2]; float d[2]; };
+    vector<Links> links(numParticles);
+    for (int i = 0; i < numParticles; i++) links[i].n = 0;
+    struct Add { static void link(Links& l, int other, float d) {
+        for (int k = 0; k < l.n && k < 2; k++)
+            if (l.other[k] == other) { l.d[k] = d; return; }
+        if (l.n < 2) { l.other[l.n] = other; l.d[l.n] = d; }
+        l.n++;                                  // a third distinct partner cannot happen at degree 2; kept for safety: n != 2 disqualifies
+    } };
+    for (int c = 0; c < numConstraints; c++) {
+        int a, b; double d;
+        system.getConstraintParameters(c, a, b, d);
+        if (system.getParticleMass(a) == 0 && system.getParticleMass(b) == 0) continue;
+        if (degree[a] != 2 || degree[b] != 2) continue;
+        Add::link(links[a], b, (float) d);
+        Add::link(links[b], a, (float) d);
+    }
+    struct Lookup { static bool find(const Links& l, int other, float& d) {
+        for (int k = 0; k < 2 && k < l.n; k++)
+            if (l.other[k] == other) { d = l.d[k]; return true; }
+        return false;
+    } };
+    atoms.clear(); dist.clear();
+    for (int p1 = 0; p1 < numParticles; p1++) {
+        if (links[p1].n != 2) continue;
+        const int p2 = min(links[p1].other[0], links[p1].other[1]), p3 = max(links[p1].other[0], links[p1].other[1]);
+        if (p1 > p2) continue;                                  // reported from its lowest atom
+        float d12 = 0, d13 = 0, d23 = 0;
+        if (links[p2].n != 2 || links[p3].n != 2 || !Lookup::find(links[p2], p3, d23)) continue;      // open chain, not a triangle
+        Lookup::find(links[p1], p2, d12);
+        Lookup::find(links[p1], p3, d13);
+        int order[3];
+        float dCentre, dOthers;
+        if (d12 == d13)      { order[0] = p1; order[1] = p2; order[2] = p3; dCentre = d12; dOthers = d23; }
+        else if (d12 == d23) { order[0] = p2; order[1] = p1; order[2] = p3; dCentre = d12; dOthers = d13; }
+        else if (d13 == d23) { order[0] = p3; order[1] = p1; order[2] = p2; dCentre = d13; dOthers = d12; }
+        else continue;
+        atoms.insert(atoms.end(), order, order + 3); atoms.push_back(0);
+        dist.push_back((double) dCentre); dist.push_back((double) dOthers);
+    }
+}
+
 HipConstraints::HipConstraints(const System& system, HipPlatform::PlatformData& data) : hip(*data.hip), numSettle(0), numShake(0), numCcma(0) {
     const int numParticles = system.getNumParticles();
     vector<double> masses(numParticles);
     for (int i = 0; i < numParticles; i++) masses[i] = system.getParticleMass(i);
     vector<bool> isSettleAtom(numParticles, false);
 
-    // ---- SETTLE clusters: taken from the partition the Reference platform already made
-    //      (ReferenceConstraints.cpp:44-148), so both platforms treat the same waters analytically.
-    ReferenceSETTLEAlgorithm* settle = dynamic_cast<ReferenceSETTLEAlgorithm*>(data.constraints->settle);
-    if (settle != NULL) {
-        numSettle = settle->getNumClusters();
-        vector<int> atoms(4 * (size_t) numSettle);
-        vector<double> dist(2 * (size_t) numSettle);
-        for (int i = 0; i < numSettle; i++) {
-            int a1, a2, a3;
-            double d1, d2;
-            settle->getClusterParameters(i, a1, a2, a3, d1, d2);
-            atoms[4 * i] = a1; atoms[4 * i + 1] = a2; atoms[4 * i + 2] = a3; atoms[4 * i + 3] = 0;
-            dist[2 * i] = d1; dist[2 * i + 1] = d2;
-            isSettleAtom[a1] = isSettleAtom[a2] = isSettleAtom[a3] = true;
-        }
-        uploadVector(settleAtoms, atoms, hip.stream);
-        uploadVector(settleDist, dist, hip.stream);
+    // ---- SETTLE clusters: found by findSettleClusters below, an own restatement of ReferenceConstraints.cpp:44-148 (same
+    //      waters, same central atom, same float-rounded distances as the Reference platform: tests/hip/TestHip.cpp compares the two)
+    vector<int> settleAtomsHost;
+    vector<double> settleDistHost;
+    findSettleClusters(system, settleAtomsHost, settleDistHost);
+    numSettle = (int) settleAtomsHost.size() / 4;
+    for (int i = 0; i < numSettle; i++)
+        for (int k = 0; k < 3; k++) isSettleAtom[settleAtomsHost[4 * i + k]] = true;
+    if (numSettle > 0) {
+        uploadVector(settleAtoms, settleAtomsHost, hip.stream);
+        uploadVector(settleDist, settleDistHost, hip.stream);
     }
 
     // ---- everything else (ReferenceConstraints.cpp:150-184 sends these to CCMA)
@@ -167,14 +219,11 @@ HipConstraints::HipConstraints(const System& system, HipPlatform::PlatformData& 
         vector<bool> covered(numParticles, false);
         if (numSettle > 0) {
             for (int i = 0; i < numSettle; i++) {
-                int a1, a2, a3;
-                double d1, d2;
-                settle->getClusterParameters(i, a1, a2, a3, d1, d2);
-                const int at[4] = {a1, a2, a3, -1};
-                const double d[4] = {d1, d2, 0.0, 1.0};
+                const int at[4] = {settleAtomsHost[4 * i], settleAtomsHost[4 * i + 1], settleAtomsHost[4 * i + 2], -1};
+                const double d[4] = {settleDistHost[2 * i], settleDistHost[2 * i + 1], 0.0, 1.0};
                 unitAtomsHost.insert(unitAtomsHost.end(), at, at + 4);
                 unitDistHost.insert(unitDistHost.end(), d, d + 4);
-                covered[a1] = covered[a2] = covered[a3] = true;
+                covered[at[0]] = covered[at[1]] = covered[at[2]] = true;
             }
         }
         for (int i = 0; i < numShake; i++) {
@@ -343,7 +392,11 @@ double HipCalcForcesAndEnergyKernel::finishComputation(ContextImpl& context, boo
         // The neighbour list overflowed at a device-triggered rebuild (the device has been skipping the integration since): an energy
         // summed over an incomplete list must not leave the platform.  Undo this evaluation, grow the list, redo the skipped steps, and
         // let ContextImpl::calcForcesAndEnergy (ContextImpl.cpp:298-307) evaluate again -- the reference's own remedy for an overflow.
-        if (!includeForce) hip.restoreForces();
+        if (!includeForce) {
+            hip.restoreForces();
+            // the fallback (Reference) kernels of this pass added to the host array: the retry must start from what was saved
+            if (hip.hasFallbackForces) *data.forces = savedHostForces;
+        }
         if (hip.replaySteps) hip.recoverIfFrozen();
         else hip.listRecovery();                  // no step was ever taken: nothing to redo, the list is grown and rebuilt
         valid = false;
@@ -527,6 +580,20 @@ void HipCalcNonbondedForceKernel::getDomainInfo(long long* out) {
 }
 
 /* Diagnostics: per i-block cost of the last list build (clock ticks, candidate blocks), as left by nl_find_interactions. */
+/* Test hook: the SETTLE partition this platform makes of a System (HipConstraints::findSettleClusters); returns the number of
+ * clusters, fills at most `capacity` of them. */
+extern "C" __attribute__((visibility("default"))) int ommhip_plugin_settle_clusters(const void* system, int* atoms, double* dist, int capacity) {
+    vector<int> a;
+    vector<double> d;
+    HipConstraints::findSettleClusters(*(const System*) system, a, d);
+    const int n = (int) a.size() / 4;
+    for (int i = 0; i < n && i < capacity; i++) {
+        for (int k = 0; k < 3; k++) atoms[3 * i + k] = a[4 * i + k];
+        dist[2 * i] = d[2 * i]; dist[2 * i + 1] = d[2 * i + 1];
+    }
+    return n;
+}
+
 extern "C" __attribute__((visibility("default"))) int ommhip_plugin_nl_block_costs(float* ticks, float* candidates, int maxBlocks) {
     if (liveNonbondedKernels.empty()) return -1;
     try { return liveNonbondedKernels.back()->getBlockCosts(ticks, candidates, maxBlocks); } catch (...) { return -2; }

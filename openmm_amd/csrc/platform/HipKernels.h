@@ -35,6 +35,9 @@ public:
     bool fusedStepAvailable() const { return !allUnitAtoms.empty(); }
     /** Launch the fused step; consumes a pending CM-motion removal and leaves the new total momentum on the device. */
     void fusedStep(int integrator, const ommhip_integrator_state& state, double tol);
+    /** The rigid three-atom molecules SETTLE treats (ReferenceConstraints.cpp:44-148 restated): int4 (centre, second, third, 0) and
+     *  two distances (centre - other, other - other) per cluster. */
+    static void findSettleClusters(const System& system, std::vector<int>& atoms, std::vector<double>& dist);
 private:
     /** Upload the integration units this rank owns (all of them on one GPU). */
     void uploadOwnedUnits();

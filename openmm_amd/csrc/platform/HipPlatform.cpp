@@ -53,6 +53,7 @@ struct HipModeInfo {
     bool hostMode;
     bool referenceNonbonded;     // LJPME: NonbondedForce itself falls back to Reference
     bool hasFallbackForces;
+    bool hasPluginNativeForces;  // forces evaluated by a native kernel of another plugin (registerNativeKernel), e.g. the AMOEBA forces
 };
 
 namespace {
@@ -76,7 +77,7 @@ bool HipPlatform::isNativeForce(const Force& force, const System& system) {
 }
 
 static HipModeInfo classifyContext(ContextImpl& context) {
-    HipModeInfo info = {false, false, false, false};
+    HipModeInfo info = {false, false, false, false, false};
     const System& system = context.getSystem();
     const Integrator& integrator = context.getIntegrator();
     if (dynamic_cast<const VerletIntegrator*>(&integrator) == NULL && dynamic_cast<const LangevinIntegrator*>(&integrator) == NULL &&
@@ -105,8 +106,10 @@ static HipModeInfo classifyContext(ContextImpl& context) {
             info.hostMode = true;       // these change state (or own an inner Context) on the host
             continue;
         }
-        if (HipPlatform::isNativeForce(f, system))
-            continue;                   // a native kernel from a plugin of its own (registerNativeKernel)
+        if (HipPlatform::isNativeForce(f, system)) {
+            info.hasPluginNativeForces = true;       // a native kernel from a plugin of its own (registerNativeKernel)
+            continue;
+        }
         // Any other Force: its Reference kernel only reads positions and adds forces.
         info.hasFallbackForces = true;
     }
@@ -255,6 +258,10 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
     if (domain.ranks < 1 || domain.rank < 0 || domain.rank >= domain.ranks)
         throw OpenMMException("HIP platform: illegal Ranks/Rank properties");
     if (domain.ranks > 1 || !commId.empty()) {
+        // Kernels of other plugins (the AMOEBA forces) know nothing of the decomposition: each rank would evaluate the whole system
+        // from positions that are current only for its own atoms and its halo, and add the full energy on every rank.
+        if (mode.hasPluginNativeForces)
+            throw OpenMMException("HIP platform: a multi-GPU Context cannot hold forces whose native kernels come from another plugin (AmoebaVdwForce, AmoebaMultipoleForce): they evaluate the whole system on one GPU");
         if (mode.hostMode || mode.hasFallbackForces || mode.referenceNonbonded)
             throw OpenMMException("HIP platform: a multi-GPU Context supports NonbondedForce (PME), HarmonicBond/Angle, PeriodicTorsion, CMMotionRemover and the (isotropic or anisotropic) MonteCarloBarostat with the Verlet, Langevin and LangevinMiddle integrators");
         int count = 0;

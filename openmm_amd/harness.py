@@ -251,6 +251,22 @@ def amoeba_native_evaluations():
     return int(out[0]), int(out[1])
 
 
+def amoeba_list_builds():
+    """(vdw, multipole) pair-list builds of the most recently used native AMOEBA kernels (Verlet skin: fewer than evaluations)."""
+    fn = C.CDLL(None).ommhip_amoeba_list_builds
+    out = (C.c_longlong * 2)()
+    fn(out)
+    return int(out[0]), int(out[1])
+
+
+def amoeba_solver_iterations():
+    """(solves, iterations summed) of the mutual-polarization solver of the native multipole kernels in this process."""
+    fn = C.CDLL(None).ommhip_amoeba_solver_iterations
+    out = (C.c_longlong * 2)()
+    fn(out)
+    return int(out[0]), int(out[1])
+
+
 def _acheck(rc):
     if rc != 0:
         raise OpenMMError(amoeba_lib().omm_amoeba_last_error().decode())

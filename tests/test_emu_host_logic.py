@@ -293,6 +293,40 @@ def test_amoeba_water_box_tile_scan_against_reference_kernel_and_full_scan(tmp_p
 
 
 @needs_emu
+def test_amoeba_dynamics_with_list_skin_and_predicted_dipoles_walks_the_same_trajectory(tmp_path):
+    """Eight Verlet steps of a relaxed 375-atom AMOEBA water box (mutual polarization to 1e-6 D) on the emulator: lists with a Verlet skin
+    rebuilt on displacement + the solver started from dipoles extrapolated from earlier steps + convergence decided on the device, against
+    rebuilding the lists and solving from the direct dipoles at every step (tests/amoeba_dynamics_case.py; the GPU test runs 12 steps)."""
+    from amoeba_dynamics_case import run_amoeba_dynamics_case
+    r = run_amoeba_dynamics_case(tmp_path, True, steps=8, minimize=15)
+    print(r)
+    assert r["dpos"] < 1e-6 and r["dforce"] < 5e-5 and r["denergy"] < 1e-6
+    ev, builds = r["now"]["evaluations"], r["now"]["builds"]
+    assert ev[0] >= 8 and ev[1] >= 8 and builds[0] <= ev[0] // 2 and builds[1] <= ev[1] // 2, "the lists were not reused"
+    assert sum(r["now"]["iterations"]) < sum(r["round3"]["iterations"]), "the extrapolated first guess saved no iterations"
+
+
+@needs_emu
+def test_multi_gpu_context_rejects_forces_with_plugin_native_kernels():
+    """The AMOEBA kernels of libOpenMMAmoebaHIP.so evaluate the whole system on one GPU: a Context spread over ranks must refuse them
+    (it used to accept them silently and return R times the energy) -- before any communicator is created."""
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+from openmm_amd import harness as H, testsystems as T
+H.load_amoeba_plugins(emulated=True)
+w = T.amoeba_water_box(4, seed=3, polarization=H.Direct, cutoff=0.6, vdw_cutoff=0.6, grid=(16,) * 3, a_ewald=5.4459052)
+s, mp, vdw = w.build()
+try:
+    H.Context(s, H.Integrator(H.VERLET, 0.001), "HIP", {"Ranks": "2", "Rank": "0", "CommId": "0" * 256})
+except H.OpenMMError as e:
+    print("REFUSED:", e)
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "REFUSED:" in out.stdout and "another plugin" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@needs_emu
 def test_amoeba_fallback_path_still_works_without_the_native_plugin():
     """HIP_AMOEBA_FALLBACK_ONLY=1: the AMOEBA plugin's own Reference kernels as fallback forces on a HIP Context (round 2's path)."""
     exe = os.path.join(EMU_BUILD, "tests", "TestHipAmoebaVdwForce")

@@ -7,11 +7,12 @@
    max_i |F_hip - F_ref| / RMS|F_ref| <= 1e-4 (BASELINE.json north_star), and size-independent invariants."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
 
-from conftest import PRODUCT_TESTS, max_rel_force_error
+from conftest import PRODUCT_TESTS, ROOT, max_rel_force_error
 from openmm_amd import harness as H, testsystems as T
 
 pytestmark = pytest.mark.gpu
@@ -74,6 +75,58 @@ def test_amoeba_water_box_tile_scan_against_reference_kernel_and_full_scan(tmp_p
     assert r["reference"][0] < (5e-5 if mutual else 5e-6) and r["reference"][1] < (5e-5 if mutual else 5e-6)
     # (the multipole grid is spread with float atomics: two runs of the SAME scan differ by a few 1e-7 on the GPU; on the emulator the two scans agree to the last bit)
     assert r["full_scan"][0] < (5e-5 if mutual else 3e-6) and r["full_scan"][1] < 1e-6
+
+
+AMOEBA_TILE_CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from openmm_amd import harness as H, testsystems as T
+H.load_amoeba_plugins()
+ewald_tol = 7.5e-4
+w = T.amoeba_water_tile(cutoff=0.7, vdw_cutoff=0.9, polarization=H.Mutual if %r else H.Direct, epsilon=1e-6, ewald_tol=ewald_tol, grid=(80, 80, 80),
+                        a_ewald=float(np.sqrt(-np.log(2 * ewald_tol)) / 0.7))
+s, mp, vdw = w.build()
+ctx = H.Context(s, H.Integrator(H.VERLET, 0.001), "HIP")
+ctx.setPositions(w.positions)
+st = ctx.getState(getForces=True, getEnergy=True)
+np.save(sys.argv[1], np.concatenate([st.forces.reshape(-1), [st.potentialEnergy], H.amoeba_native_evaluations()]))
+'''
+
+
+@pytest.mark.parametrize("kind", ["direct", "mutual"])
+def test_amoeba_water_tile_at_the_benchmarked_size_matches_the_reference_kernels(golden, tmp_path, kind):
+    """The AMOEBA workload bench.py times (extra_workloads.amoeba_water: 36 501 atoms, multipole PME 80^3 / 0.7 nm, vdW 0.9 nm, bonds and
+    angles) at its initial configuration against the AMOEBA plugin's Reference kernels on the Reference platform (a committed golden:
+    tools/make_golden_amoeba_water_tile.py; 12 000 sampled atoms): every sampled atom within 1e-4 of the RMS force.  Mutual polarization
+    is converged to 1e-6 D on both sides, so the bar is the kernel, not the solver."""
+    g = golden("reference_forces_amoeba_water_tile_36501_%s_sample.npz" % kind)
+    script = tmp_path / "amoeba_tile_child.py"
+    script.write_text(AMOEBA_TILE_CHILD % (ROOT, kind == "mutual"))
+    path = str(tmp_path / "amoeba_tile.npy")
+    out = subprocess.run([sys.executable, str(script), path], capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    v = np.load(path)
+    f, e, n_vdw, n_mp = v[:-3].reshape(-1, 3), v[-3], int(v[-2]), int(v[-1])
+    assert n_vdw == 1 and n_mp == 1, "the native kernels did not run"
+    idx = g["indices"]
+    rms = float(g["rms_force"])
+    rel = np.linalg.norm(f[idx] - g["forces"], axis=1) / np.maximum(np.linalg.norm(g["forces"], axis=1), rms)
+    print("AMOEBA water tile, %s: max-rel-err %.3g over %d sampled atoms, energy %.6f vs %.6f" % (kind, rel.max(), len(idx), e, float(g["energy"])))
+    assert rel.max() < 1e-4
+    assert abs(e - float(g["energy"])) < 2e-6 * abs(float(g["energy"]))
+
+
+def test_amoeba_dynamics_with_list_skin_and_predicted_dipoles_walks_the_same_trajectory(tmp_path):
+    """Twelve Verlet steps of a relaxed 375-atom AMOEBA water box, mutual polarization to 1e-6 D: pair lists with a Verlet skin that are
+    rebuilt on displacement, the solver started from dipoles extrapolated from the previous steps and its convergence decided on the
+    device -- against rebuilding and solving from the direct dipoles at every step, as round 3 did (tests/amoeba_dynamics_case.py)."""
+    from amoeba_dynamics_case import run_amoeba_dynamics_case
+    r = run_amoeba_dynamics_case(tmp_path, False)
+    print(r)
+    assert r["dpos"] < 1e-6 and r["dforce"] < 5e-5 and r["denergy"] < 1e-6
+    ev, builds = r["now"]["evaluations"], r["now"]["builds"]
+    assert ev[0] >= 12 and ev[1] >= 12 and builds[0] <= ev[0] // 2 and builds[1] <= ev[1] // 2, "the lists were not reused"
+    assert sum(r["now"]["iterations"]) < sum(r["round3"]["iterations"]), "the extrapolated first guess saved no iterations"
 
 
 def hip_state(w, groups=-1, recip_group=False, integrator=None):

@@ -532,10 +532,21 @@ def main():
             a_parity = None
             try:
                 g = np.load(os.path.join(ROOT, "tests", "golden", "reference_forces_amoeba_water_tile_36501_mutual_sample.npz"))
-                f0 = actx.getState(getForces=True).forces
-                rel = np.linalg.norm(f0[g["indices"]] - g["forces"], axis=1) / np.maximum(np.linalg.norm(g["forces"], axis=1), float(g["rms_force"]))
+
+                def rel_err(f):
+                    return np.linalg.norm(f[g["indices"]] - g["forces"], axis=1) / np.maximum(np.linalg.norm(g["forces"], axis=1), float(g["rms_force"]))
+                rel_run = rel_err(actx.getState(getForces=True).forces)
+                # the kernels' own distance from the Reference: the same System solved to the golden's 1e-6 D in a Context of its own
+                pw = T.amoeba_water_tile(cutoff=0.7, vdw_cutoff=0.9, polarization=H.Mutual, epsilon=1e-6, ewald_tol=7.5e-4, grid=(80, 80, 80), a_ewald=float(np.sqrt(-np.log(2 * 7.5e-4)) / 0.7))
+                psys, _, _ = pw.build()
+                pctx = H.Context(psys, H.Integrator(H.VERLET, 0.001), "HIP", {"DeviceIndex": str(local_rank)})
+                pctx.setPositions(pw.positions)
+                rel = rel_err(pctx.getState(getForces=True).forces)
+                pctx.close()
                 a_parity = {"max_rel_err_vs_reference": float(rel.max()), "tolerance": 1e-4, "atoms_above_tolerance": int((rel > 1e-4).sum()), "sampled_atoms": int(len(rel)),
-                            "reference": "AMOEBA Reference kernels on the Reference platform, mutual epsilon 1e-6 (tests/golden/reference_forces_amoeba_water_tile_36501_mutual_sample.npz)"}
+                            "max_rel_err_at_the_run_epsilon": float(rel_run.max()),
+                            "reference": "AMOEBA Reference kernels on the Reference platform, mutual epsilon 1e-6 (tests/golden/reference_forces_amoeba_water_tile_36501_mutual_sample.npz); "
+                                         "max_rel_err_vs_reference: this platform solved to the same 1e-6 D; max_rel_err_at_the_run_epsilon: solved to the 1e-5 D of the timed run (benchmark.py's setting)"}
             except Exception as e:
                 a_parity = {"max_rel_err_vs_reference": None, "error": str(e)}
             actx.setVelocitiesToTemperature(300.0, 5)
@@ -556,7 +567,7 @@ def main():
             out["extra_workloads"]["amoeba_water"] = {"workload": "%s: %d atoms, AmoebaMultipoleForce PME 80x80x80 mutual polarization (epsilon 1e-5, cutoff 0.7 nm) + AmoebaVdwForce "
                                                                   "(0.9 nm) on the native kernels, harmonic bonds / angles, Verlet 1 fs, single GPU" % (aw.name, aw.num_atoms),
                                                       "value": round(MR.ns_per_day(a_elapsed, a_steps, 1.0), 4), "unit": "ns/day", "ms_per_step": round(1e3 * a_elapsed / a_steps, 3),
-                                                      "steps": a_steps, "warmup": 6, "dtype": "f64 pair arithmetic, f32 grids and pair cache of the solver",
+                                                      "steps": a_steps, "warmup": 6, "dtype": "mixed: f32 pair arithmetic (covalently related pairs, sums, frames, solver vectors f64), f32 grids and solver pair cache",
                                                       "force_parity": a_parity,
                                                       "solver_iterations_per_solve": round((solves1[1] - solves0[1]) / max(1, solves1[0] - solves0[0]), 2),
                                                       "pair_list_builds_per_step": {"vdw": round((builds1[0] - builds0[0]) / a_steps, 3), "multipole": round((builds1[1] - builds0[1]) / a_steps, 3)},

@@ -7,7 +7,8 @@
  * CalcAmoebaMultipoleForceKernel (:82-139).  The oracle is the plugin's own Reference implementation
  * (plugins/amoeba/platforms/reference/src/SimTKReference/AmoebaReferenceVdwForce.cpp, AmoebaReferenceMultipoleForce.cpp).
  *
- * All arithmetic is double precision on the atom-ordered positions (pos_d: double4[num_atoms], HipContext::pos); forces are added
+ * Positions are the atom-ordered doubles (pos_d: double4[num_atoms], HipContext::pos); sums, frames, reciprocal-space read-back and
+ * the solver are double precision, the pair arithmetic float or double (mixed_precision), the grids float; forces are added
  * to the platform's 64-bit fixed-point buffer (slot order, through slot_of_atom_d), energies to energy_buffer_d[0..energy_slots).
  */
 #ifndef OPENMM_HIP_AMOEBA_H_
@@ -67,6 +68,7 @@ typedef struct ommhip_amoeba_vdw {
     int* list_state;               /* device int[4] work words, zeroed by the caller once; [2] counts the builds */
     int force_rebuild;
     int* list_builds;              /* HOST int (or NULL), written by every call: list builds so far (diagnostics) */
+    int mixed_precision;           /* 1: the pair arithmetic of the list kernel in float (separation formed in double, sums in double) */
 } ommhip_amoeba_vdw;
 
 int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* vdw, const void* pos_d, const double box[6], const int* slot_of_atom_d, int padded_atoms,
@@ -162,6 +164,8 @@ typedef struct ommhip_amoeba_multipole {
     int* list_state;
     int force_rebuild;
     int* list_builds;
+    int mixed_precision;           /* 1: the pair arithmetic of ordinary pairs in float (separations formed in double, sums in double; covalently related
+                                    * pairs stay in double) -- the "mixed" mode of the reference's GPU platforms; 0: everything in double */
     int expected_iterations;       /* iterations the previous solve took (0 = unknown): that many minus one are enqueued before the host first waits for the
                                     * convergence measure, which the device forms itself; status[1] reports what this call took */
 } ommhip_amoeba_multipole;

@@ -54,6 +54,10 @@ extern "C" __attribute__((visibility("default"))) void ommhip_amoeba_list_builds
 // ================================================================================================
 // AmoebaVdwForce
 // ================================================================================================
+HipCalcAmoebaVdwForceKernel::~HipCalcAmoebaVdwForceKernel() {
+    if (earlyId >= 0) data.hip->unregisterEarlyWork(earlyId);
+}
+
 void HipCalcAmoebaVdwForceKernel::initialize(const System& system, const AmoebaVdwForce& force) {
     // AmoebaReferenceKernels.cpp:656-667
     numParticles = system.getNumParticles();
@@ -64,6 +68,8 @@ void HipCalcAmoebaVdwForceKernel::initialize(const System& system, const AmoebaV
     dispersionCoefficient = force.getUseDispersionCorrection() ? AmoebaVdwForceImpl::calcDispersionCorrection(system, force) : 0.0;
     if (usePBC) { data.hip->usePeriodic = true; data.hip->sortCutoff = max(data.hip->sortCutoff, cutoff); }      // spatial slot order: the pair lists are built tile by tile
     upload(force);
+    if (earlyId < 0 && getenv("OPENMM_HIP_AMOEBA_VDW_MAIN_STREAM") == NULL)          // (A/B knob: the evaluation stays where execute() finds it, on the main stream)
+        earlyId = data.hip->registerEarlyWork(force.getForceGroup(), [this](ContextImpl& c, bool f, bool e) { launch(c, f, e); });
 }
 
 void HipCalcAmoebaVdwForceKernel::upload(const AmoebaVdwForce& force) {
@@ -105,6 +111,7 @@ void HipCalcAmoebaVdwForceKernel::upload(const AmoebaVdwForce& force) {
     softcorePower = force.getSoftcorePower(); softcoreAlpha = force.getSoftcoreAlpha();
     vdw.lennard_jones = force.getPotentialFunction() == AmoebaVdwForce::LennardJones ? 1 : 0;
     vdw.periodic = usePBC ? 1 : 0;
+    vdw.mixed_precision = getenv("OPENMM_HIP_AMOEBA_PRECISION") != NULL && string(getenv("OPENMM_HIP_AMOEBA_PRECISION")) == "double" ? 0 : 1;
     // AmoebaReferenceVdwForce::setTaperCoefficients (:69-81), taper between 0.9 cutoff and the cutoff
     vdw.cutoff = cutoff; vdw.taper_cutoff = 0.9 * cutoff;
     if (usePBC && vdw.taper_cutoff != cutoff) {
@@ -143,6 +150,16 @@ void HipCalcAmoebaVdwForceKernel::allocatePairList(int cap) {
 }
 
 double HipCalcAmoebaVdwForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy) {
+    HipContext& hip = *data.hip;
+    if (earlyId < 0 || !hip.earlyWorkLaunched(earlyId)) {
+        if (earlyId >= 0) hip.noteEarlyWorkLaunched(earlyId);
+        launch(context, includeForces, includeEnergy);
+    }
+    // the pair energy is summed on the device (HipCalcForcesAndEnergyKernel::finishComputation); the host adds the constant
+    return includeEnergy && usePBC ? dispersionCoefficient / (hip.box[0] * hip.box[2] * hip.box[5]) : 0.0;
+}
+
+void HipCalcAmoebaVdwForceKernel::launch(ContextImpl& context, bool includeForces, bool includeEnergy) {
     // AmoebaReferenceKernels.cpp:669-690
     HipContext& hip = *data.hip;
     hip.setAsCurrent();
@@ -156,19 +173,21 @@ double HipCalcAmoebaVdwForceKernel::execute(ContextImpl& context, bool includeFo
     }
     hip.ensureCleared();
     vdw.atom_of_slot = hip.atomOfSlot.as<int>();
+    // on the side stream (it waits for what the main stream holds so far: the clear of the force buffer); the main stream joins it in finishComputation
+    void* stream = earlyId >= 0 ? hip.pmeStream : hip.stream;
+    if (earlyId >= 0) hip.forkPme();
     for (int attempt = 0; ; attempt++) {
         vdw.force_rebuild = listDirty || listOrderVersion != hip.orderVersion || listBoxVersion != hip.boxVersion ? 1 : 0;
         const int rc = ommhip_amoeba_vdw_forces(&vdw, hip.pos.ptr, hip.box, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.force.as<long long>(),
-                                                hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream);
+                                                hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, stream);
         if (rc != -2) { HIP_CHECK(rc); listDirty = false; listOrderVersion = hip.orderVersion; listBoxVersion = hip.boxVersion; break; }
         // the pair lists did not fit (nothing has been added to the forces yet: the list is built before the pair kernel runs)
         if (attempt == 3 || pairNeeded == 0x7fffffff) throw OpenMMException("AmoebaVdwForce: the pair lists of the HIP platform cannot hold this System");
         grownPairCap = (int) min((long long) numParticles * 4, (long long) pairNeeded * 5 / 4 + 16);
         allocatePairList(grownPairCap);
     }
+    if (earlyId >= 0) hip.markPmeDone();
     nativeEvaluations[0]++;
-    // the pair energy is summed on the device (HipCalcForcesAndEnergyKernel::finishComputation); the host adds the constant
-    return includeEnergy && usePBC ? dispersionCoefficient / (hip.box[0] * hip.box[2] * hip.box[5]) : 0.0;
 }
 
 void HipCalcAmoebaVdwForceKernel::copyParametersToContext(ContextImpl& context, const AmoebaVdwForce& force) {
@@ -364,6 +383,8 @@ void HipCalcAmoebaMultipoleForceKernel::upload(const AmoebaMultipoleForce& force
     mp.induced_d = indD.as<double>(); mp.induced_p = indP.as<double>(); mp.phi = phi.as<double>(); mp.phi_induced = phiInd.as<double>(); mp.torque = torque.as<double>();
     mp.pme = &pme;
     mp.mutual = mutual ? 1 : 0;
+    // pair arithmetic: float by default ("mixed", what the reference's GPU platforms do in their mixed mode); OPENMM_HIP_AMOEBA_PRECISION=double keeps everything in double
+    mp.mixed_precision = getenv("OPENMM_HIP_AMOEBA_PRECISION") != NULL && string(getenv("OPENMM_HIP_AMOEBA_PRECISION")) == "double" ? 0 : 1;
     mp.max_iterations = force.getMutualInducedMaxIterations(); mp.target_epsilon = force.getMutualInducedTargetEpsilon();
     mp.phi_induced_p = mutual ? phiIndP.as<double>() : NULL; mp.solver = mutual ? solver.as<double>() : NULL; mp.status = solverStatus;
     mp.history = mutual && history.ptr != NULL ? history.as<double>() : NULL; mp.history_slots = HistorySlots; mp.history_newest = 0; mp.history_store = -1; mp.history_use = 0; mp.expected_iterations = 0;
@@ -447,6 +468,7 @@ double HipCalcAmoebaMultipoleForceKernel::execute(ContextImpl& context, bool inc
     hip.setAsCurrent();
     prepareGrid();
     hip.ensureCleared();
+    hip.launchEarlyWork(context, includeForces, includeEnergy);       // the solver below waits for the device: what other forces have to launch goes first
     setScanOrder();
     chooseFirstGuess();
     int rc;

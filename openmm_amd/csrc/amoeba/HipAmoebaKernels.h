@@ -17,11 +17,17 @@ namespace OpenMM {
 class HipCalcAmoebaVdwForceKernel : public CalcAmoebaVdwForceKernel {
 public:
     HipCalcAmoebaVdwForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : CalcAmoebaVdwForceKernel(name, platform), data(data) {}
+    ~HipCalcAmoebaVdwForceKernel();
     void initialize(const System& system, const AmoebaVdwForce& force);
     double execute(ContextImpl& context, bool includeForces, bool includeEnergy);
     void copyParametersToContext(ContextImpl& context, const AmoebaVdwForce& force);
 private:
     void upload(const AmoebaVdwForce& force);
+    /** The evaluation itself, on the platform's side stream: started by execute(), or earlier in the same evaluation by a kernel that is
+     *  about to keep the host busy (HipContext::launchEarlyWork: the multipole kernel's dipole solver) -- the pair kernel then runs beside
+     *  the solver's small launches instead of after them. */
+    void launch(ContextImpl& context, bool includeForces, bool includeEnergy);
+    int earlyId = -1;
     HipPlatform::PlatformData& data;
     int numParticles = 0;
     bool usePBC = false;

@@ -37,6 +37,7 @@ struct VdwArgs {
     // scan positions: position g holds atom order[g] (the platform's slot order, -1: padding) or g itself
     const int* order; int numScan;
     const int* pairList; const int* pairCount; int listStride, listSubcap;      // pair lists (amoeba_pairs.h); nullptr: the scan over all atoms
+    int mixed;                                                                  // the list kernel's pair arithmetic in float
     int listSkin;                                                               // the lists reach beyond the cutoff (Verlet skin): the pair kernel re-tests the atom distance
 };
 
@@ -58,37 +59,42 @@ __global__ void k_vdw_reduce(VdwArgs a) {
 
 // one pair, seen from site i: energy of the pair and dE/dr / r (the force on i is -that times (r_i - r_j))
 // AmoebaReferenceVdwForce::calculatePairIxn (AmoebaReferenceVdwForce.cpp:106-171)
-__device__ __forceinline__ double vdw_pair(const VdwArgs& a, double r, double sigma, double epsilon, double softcore, double& dEdRoverR) {
-    double energy, dEdR;
+// T = float: the pair arithmetic of the list kernel in "mixed" mode (separation formed in double, sums kept in double)
+template <class T>
+__device__ __forceinline__ T vdw_pair_t(const VdwArgs& a, T r, T sigma, T epsilon, T softcore, T& dEdRoverR) {
+    T energy, dEdR;
     if (a.lennardJones) {
-        const double pp1 = sigma / r, pp2 = pp1 * pp1, pp3 = pp2 * pp1, pp6 = pp3 * pp3, pp12 = pp6 * pp6;
-        energy = 4 * epsilon * (pp12 - pp6);
-        dEdR = -24 * epsilon * (2 * pp12 - pp6) / r;
+        const T pp1 = sigma / r, pp2 = pp1 * pp1, pp3 = pp2 * pp1, pp6 = pp3 * pp3, pp12 = pp6 * pp6;
+        energy = T(4) * epsilon * (pp12 - pp6);
+        dEdR = T(-24) * epsilon * (T(2) * pp12 - pp6) / r;
     }
     else {
-        const double dhal = 0.07, ghal1 = 1.12, dhal1 = 1.07;
-        const double rho = r / sigma, rho2 = rho * rho, rho6 = rho2 * rho2 * rho2;
-        const double rhoplus = rho + dhal, rhodec2 = rhoplus * rhoplus, rhodec = rhodec2 * rhodec2 * rhodec2;
-        const double s1 = 1.0 / (softcore + rhodec * rhoplus);
-        const double s2 = 1.0 / (softcore + rho6 * rho + 0.12);
-        const double point72 = dhal1 * dhal1;
-        const double t1 = dhal1 * point72 * point72 * point72 * s1;
-        const double t2 = ghal1 * s2;
-        const double t2min = t2 - 2;
-        const double dt1 = -7.0 * rhodec * t1 * s1;
-        const double dt2 = -7.0 * rho6 * t2 * s2;
+        const T dhal = T(0.07), ghal1 = T(1.12), dhal1 = T(1.07);
+        const T rho = r / sigma, rho2 = rho * rho, rho6 = rho2 * rho2 * rho2;
+        const T rhoplus = rho + dhal, rhodec2 = rhoplus * rhoplus, rhodec = rhodec2 * rhodec2 * rhodec2;
+        const T s1 = T(1) / (softcore + rhodec * rhoplus);
+        const T s2 = T(1) / (softcore + rho6 * rho + T(0.12));
+        const T point72 = dhal1 * dhal1;
+        const T t1 = dhal1 * point72 * point72 * point72 * s1;
+        const T t2 = ghal1 * s2;
+        const T t2min = t2 - T(2);
+        const T dt1 = T(-7) * rhodec * t1 * s1;
+        const T dt2 = T(-7) * rho6 * t2 * s2;
         energy = epsilon * t1 * t2min;
         dEdR = epsilon * (dt1 * t2min + t1 * dt2) / sigma;
     }
-    if (a.periodic && r > a.taperCutoff) {
-        const double delta = r - a.taperCutoff;
-        const double taper = 1.0 + delta * delta * delta * (a.c3 + delta * (a.c4 + delta * a.c5));
-        const double dtaper = delta * delta * (3.0 * a.c3 + delta * (4.0 * a.c4 + delta * 5.0 * a.c5));
+    if (a.periodic && r > (T) a.taperCutoff) {
+        const T delta = r - (T) a.taperCutoff;
+        const T taper = T(1) + delta * delta * delta * ((T) a.c3 + delta * ((T) a.c4 + delta * (T) a.c5));
+        const T dtaper = delta * delta * (T(3) * (T) a.c3 + delta * (T(4) * (T) a.c4 + delta * T(5) * (T) a.c5));
         dEdR = energy * dtaper + dEdR * taper;
         energy *= taper;
     }
     dEdRoverR = dEdR / r;
     return energy;
+}
+__device__ __forceinline__ double vdw_pair(const VdwArgs& a, double r, double sigma, double epsilon, double softcore, double& dEdRoverR) {
+    return vdw_pair_t<double>(a, r, sigma, epsilon, softcore, dEdRoverR);
 }
 
 __global__ __launch_bounds__(VDW_BLOCK) void k_vdw_pairs(VdwArgs a) {
@@ -195,8 +201,9 @@ __global__ __launch_bounds__(VDW_BLOCK) void k_vdw_pairs_list(VdwArgs a) {
         double sigma = a.sigma[typeI * a.numTypes + typeJ], epsilon = a.epsilon[typeI * a.numTypes + typeJ], softcore = 0.0;
         const bool alchJ = a.alchemical != nullptr && a.alchemical[j] != 0;
         if ((a.alchemicalMethod == 1 && alchI != alchJ) || (a.alchemicalMethod == 2 && (alchI || alchJ))) { epsilon *= a.epsilonScale; softcore = a.softcore; }
-        double dEdRoverR;
-        const double e = vdw_pair(a, r, sigma, epsilon, softcore, dEdRoverR);
+        double dEdRoverR, e;
+        if (a.mixed) { float d; e = (double) vdw_pair_t<float>(a, (float) r, (float) sigma, (float) epsilon, (float) softcore, d); dEdRoverR = (double) d; }
+        else e = vdw_pair(a, r, sigma, epsilon, softcore, dEdRoverR);
         fx -= dEdRoverR * dx; fy -= dEdRoverR * dy; fz -= dEdRoverR * dz;
         energy += 0.5 * e;
     }
@@ -231,6 +238,7 @@ extern "C" int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* v, const void* 
     if (v->num_atoms <= 0) return 0;
     if (v->reduced == nullptr || v->parent == nullptr || v->type == nullptr || v->excl_start == nullptr) return 1;
     VdwArgs a;
+    a.mixed = 0; a.listSkin = 0;
     a.numAtoms = v->num_atoms; a.numTypes = v->num_types; a.paddedAtoms = padded_atoms; a.alchemicalMethod = v->alchemical_method;
     a.lennardJones = v->lennard_jones; a.periodic = v->periodic; a.includeEnergy = include_energy; a.energySlots = energy_slots;
     a.parent = v->parent; a.reduction = v->reduction; a.type = v->type; a.sigma = v->sigma; a.epsilon = v->epsilon;
@@ -259,7 +267,7 @@ extern "C" int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* v, const void* 
         p.list = v->pair_list; p.count = v->pair_count; p.overflow = v->pair_overflow;
         // Verlet skin: the list holds the partners within cutoff + skin and lives until an atom has moved by skin / 2; the pair kernel re-tests
         p.refPos = nullptr; p.state = nullptr; p.skinHalf2 = 0.0; p.forceRebuild = 1;
-        a.listSkin = 0;
+        a.listSkin = 0; a.mixed = v->mixed_precision != 0 ? 1 : 0;
         if (v->skin > 0.0 && v->ref_pos != nullptr && v->list_state != nullptr) {
             const double radius = v->cutoff + v->skin;
             p.cutoff2 = radius * radius; p.refPos = (double4*) v->ref_pos; p.state = v->list_state; p.skinHalf2 = 0.25 * v->skin * v->skin; p.forceRebuild = v->force_rebuild != 0;

@@ -43,51 +43,138 @@ namespace {
 #define MP_CG_BLOCK 256          // the vector kernels of the solver (k_mp_cg)
 #define MP_SQRT_PI 1.77245385090551602730
 
-struct V3 { double x, y, z; };
+// Small vector algebra, templated on the scalar: double for the atom-side arithmetic, float for the pair arithmetic of the mixed-precision
+// kernels (the reference's GPU platforms compute AMOEBA pairs in `real` = float in their mixed mode too and accumulate in fixed point,
+// plugins/amoeba/platforms/common/src/kernels/multipoleElectrostatics.cc).
+template <class T> struct V3T { T x, y, z; };
+typedef V3T<double> V3;
+template <class T> __device__ __forceinline__ V3T<T> v3t(T x, T y, T z) { V3T<T> r = {x, y, z}; return r; }
 __device__ __forceinline__ V3 v3(double x, double y, double z) { V3 r = {x, y, z}; return r; }
-__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ V3 operator*(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ V3 operator*(double s, V3 a) { return v3(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+template <class T> __device__ __forceinline__ V3T<T> operator+(V3T<T> a, V3T<T> b) { return v3t<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class T> __device__ __forceinline__ V3T<T> operator-(V3T<T> a, V3T<T> b) { return v3t<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class T> __device__ __forceinline__ V3T<T> operator*(V3T<T> a, T s) { return v3t<T>(a.x * s, a.y * s, a.z * s); }
+template <class T> __device__ __forceinline__ V3T<T> operator*(T s, V3T<T> a) { return v3t<T>(a.x * s, a.y * s, a.z * s); }
+template <class T> __device__ __forceinline__ T dot(V3T<T> a, V3T<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T> __device__ __forceinline__ V3T<T> cross(V3T<T> a, V3T<T> b) { return v3t<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 __device__ __forceinline__ double normalize(V3& a) { const double n = sqrt(dot(a, a)); const double inv = n > 0 ? 1.0 / n : 0.0; a = a * inv; return n; }
+template <class T> __device__ __forceinline__ V3T<T> convert3(V3 a) { return v3t<T>((T) a.x, (T) a.y, (T) a.z); }
+template <class T> __device__ __forceinline__ V3 widen3(V3T<T> a) { return v3((double) a.x, (double) a.y, (double) a.z); }
 
 // symmetric 3x3 as (xx, xy, xz, yy, yz, zz)
-struct Sym { double xx, xy, xz, yy, yz, zz; };
-__device__ __forceinline__ V3 mul(const Sym& q, V3 v) { return v3(q.xx * v.x + q.xy * v.y + q.xz * v.z, q.xy * v.x + q.yy * v.y + q.yz * v.z, q.xz * v.x + q.yz * v.y + q.zz * v.z); }
-__device__ __forceinline__ double ddot(const Sym& a, const Sym& b) { return a.xx * b.xx + a.yy * b.yy + a.zz * b.zz + 2.0 * (a.xy * b.xy + a.xz * b.xz + a.yz * b.yz); }
+template <class T> struct SymT { T xx, xy, xz, yy, yz, zz; };
+typedef SymT<double> Sym;
+template <class T> __device__ __forceinline__ V3T<T> mul(const SymT<T>& q, V3T<T> v) { return v3t<T>(q.xx * v.x + q.xy * v.y + q.xz * v.z, q.xy * v.x + q.yy * v.y + q.yz * v.z, q.xz * v.x + q.yz * v.y + q.zz * v.z); }
+template <class T> __device__ __forceinline__ T ddot(const SymT<T>& a, const SymT<T>& b) { return a.xx * b.xx + a.yy * b.yy + a.zz * b.zz + T(2) * (a.xy * b.xy + a.xz * b.xz + a.yz * b.yz); }
 // antisymmetric part of the product A B of two symmetric matrices as a vector: ((AB)_yz - (AB)_zy, (AB)_zx - (AB)_xz, (AB)_xy - (AB)_yx)
-__device__ __forceinline__ V3 asym_product(const Sym& a, const Sym& b) {
-    const double yz = a.xy * b.xz + a.yy * b.yz + a.yz * b.zz, zy = a.xz * b.xy + a.yz * b.yy + a.zz * b.yz;
-    const double zx = a.xz * b.xx + a.yz * b.xy + a.zz * b.xz, xz = a.xx * b.xz + a.xy * b.yz + a.xz * b.zz;
-    const double xy = a.xx * b.xy + a.xy * b.yy + a.xz * b.yz, yx = a.xy * b.xx + a.yy * b.xy + a.yz * b.xz;
-    return v3(yz - zy, zx - xz, xy - yx);
+template <class T> __device__ __forceinline__ V3T<T> asym_product(const SymT<T>& a, const SymT<T>& b) {
+    const T yz = a.xy * b.xz + a.yy * b.yz + a.yz * b.zz, zy = a.xz * b.xy + a.yz * b.yy + a.zz * b.yz;
+    const T zx = a.xz * b.xx + a.yz * b.xy + a.zz * b.xz, xz = a.xx * b.xz + a.xy * b.yz + a.xz * b.zz;
+    const T xy = a.xx * b.xy + a.xy * b.yy + a.xz * b.yz, yx = a.xy * b.xx + a.yy * b.xy + a.yz * b.xz;
+    return v3t<T>(yz - zy, zx - xz, xy - yx);
 }
+template <class T> __device__ __forceinline__ SymT<T> convert6(const Sym& q) { SymT<T> r = {(T) q.xx, (T) q.xy, (T) q.xz, (T) q.yy, (T) q.yz, (T) q.zz}; return r; }
 
-struct Site { double q; V3 mu; Sym Q; };
+template <class T> struct SiteT { T q; V3T<T> mu; SymT<T> Q; };
+typedef SiteT<double> Site;
+template <class T> __device__ __forceinline__ SiteT<T> convert_site(const Site& s) { SiteT<T> r = {(T) s.q, convert3<T>(s.mu), convert6<T>(s.Q)}; return r; }
+
+// a derivative chain with a scale factor s and Thole damping lambda = 1 - oml:  bn - (1 - s lambda) cn  (pair_chains below makes bn, cn, oml)
+template <class T> __device__ __forceinline__ T scaled_chain(T bn, T cn, T oml, T s) { return bn - ((T(1) - s) + s * oml) * cn; }
 
 // W = L_A L_B f, the force on site A (= -dW/dr_A) and the torque on A's multipoles, for the kernel given by its chain B[0..5].
 // Quadrupoles are traceless (AMOEBA's are: rotations of a traceless local-frame tensor).
-__device__ __forceinline__ void mpole_pair(const Site& A, const Site& Bs, const V3 r, const double* B, double& W, V3& force, V3& torque) {
-    const V3 QAr = mul(A.Q, r), QBr = mul(Bs.Q, r);
-    const double muAr = dot(A.mu, r), muBr = dot(Bs.mu, r), rQAr = dot(r, QAr), rQBr = dot(r, QBr);
-    const double S1 = -Bs.q * B[1] + B[2] * muBr - B[3] * rQBr;
-    const double S2 = Bs.q * B[2] - B[3] * muBr + B[4] * rQBr;
-    const double S3 = -Bs.q * B[3] + B[4] * muBr - B[5] * rQBr;
-    const double phi = Bs.q * B[0] - B[1] * muBr + B[2] * rQBr;
-    const V3 gradPhi = S1 * r - B[1] * Bs.mu + 2.0 * B[2] * QBr;                       // the field of B at A (r-derivative of its potential)
-    const double muAmuB = dot(A.mu, Bs.mu), muAQBr = dot(A.mu, QBr), muBQAr = dot(Bs.mu, QAr), QArQBr = dot(QAr, QBr), QAQB = ddot(A.Q, Bs.Q);
-    const V3 QAmuB = mul(A.Q, Bs.mu), QBmuA = mul(Bs.Q, A.mu), QAQBr = mul(A.Q, QBr), QBQAr = mul(Bs.Q, QAr);
-    W = A.q * phi - dot(A.mu, gradPhi) + (S2 * rQAr + 2.0 * B[2] * muBQAr - 4.0 * B[3] * QArQBr + 2.0 * B[2] * QAQB);
+// AQ / BQ = false: the site is a bare dipole (an induced one: q = 0, Q = 0; no torque is returned for such an A) -- the terms that
+// vanish are not compiled; four of the five to seven calls per pair of the force kernel have a bare dipole on one side.
+template <class T, bool AQ, bool BQ>
+__device__ __forceinline__ void mpole_pair(const SiteT<T>& A, const SiteT<T>& Bs, const V3T<T> r, const T* B, T& W, V3T<T>& force, V3T<T>& torque) {
+    const T two = T(2), four = T(4);
+    const T muAr = dot(A.mu, r), muBr = dot(Bs.mu, r), muAmuB = dot(A.mu, Bs.mu);
+    V3T<T> QAr = v3t<T>(0, 0, 0), QBr = v3t<T>(0, 0, 0);
+    T rQAr = T(0), rQBr = T(0);
+    if constexpr (AQ) { QAr = mul(A.Q, r); rQAr = dot(r, QAr); }
+    if constexpr (BQ) { QBr = mul(Bs.Q, r); rQBr = dot(r, QBr); }
+    T S1 = B[2] * muBr, S2 = -B[3] * muBr;
+    if constexpr (BQ) { S1 += -Bs.q * B[1] - B[3] * rQBr; S2 += Bs.q * B[2] + B[4] * rQBr; }
+    V3T<T> gradPhi = S1 * r - B[1] * Bs.mu;                                  // the field of B at A (r-derivative of its potential)
+    if constexpr (BQ) gradPhi = gradPhi + (two * B[2]) * QBr;
+    W = -dot(A.mu, gradPhi);
     // mu_A . Hessian(phi)
-    const V3 muAH = (S2 * muAr + B[2] * muAmuB - 2.0 * B[3] * muAQBr) * r + (B[2] * muAr) * Bs.mu - (2.0 * B[3] * muAr) * QBr + S1 * A.mu + 2.0 * B[2] * QBmuA;
-    // Q_A : third derivatives of phi
-    const V3 QAD = (S3 * rQAr - 2.0 * B[3] * muBQAr + 4.0 * B[4] * QArQBr - 2.0 * B[3] * QAQB) * r - (B[3] * rQAr) * Bs.mu + (2.0 * B[4] * rQAr) * QBr
-                   + (2.0 * S2) * QAr + (2.0 * B[2]) * QAmuB - (4.0 * B[3]) * (QBQAr + QAQBr);
-    force = A.q * gradPhi - muAH + QAD;
-    torque = cross(A.mu, gradPhi)
-             - 2.0 * (S2 * cross(QAr, r) + B[2] * (cross(QAmuB, r) + cross(QAr, Bs.mu)) - 2.0 * B[3] * (cross(QAQBr, r) + cross(QAr, QBr)) + 2.0 * B[2] * asym_product(A.Q, Bs.Q));
+    V3T<T> muAH = (S2 * muAr + B[2] * muAmuB) * r + (B[2] * muAr) * Bs.mu + S1 * A.mu;
+    if constexpr (BQ) {
+        const T muAQBr = dot(A.mu, QBr);
+        muAH = muAH - (two * B[3] * muAQBr) * r - (two * B[3] * muAr) * QBr + (two * B[2]) * mul(Bs.Q, A.mu);
+    }
+    force = v3t<T>(0, 0, 0) - muAH;
+    torque = v3t<T>(0, 0, 0);
+    if constexpr (AQ) {
+        T S3 = B[4] * muBr, phi = -B[1] * muBr;
+        if constexpr (BQ) { S3 += -Bs.q * B[3] - B[5] * rQBr; phi += Bs.q * B[0] + B[2] * rQBr; }
+        const T muBQAr = dot(Bs.mu, QAr);
+        const V3T<T> QAmuB = mul(A.Q, Bs.mu);
+        W += A.q * phi + S2 * rQAr + two * B[2] * muBQAr;
+        // Q_A : third derivatives of phi
+        V3T<T> QAD = (S3 * rQAr - two * B[3] * muBQAr) * r - (B[3] * rQAr) * Bs.mu + (two * S2) * QAr + (two * B[2]) * QAmuB;
+        V3T<T> tq = S2 * cross(QAr, r) + B[2] * (cross(QAmuB, r) + cross(QAr, Bs.mu));
+        if constexpr (BQ) {
+            const T QArQBr = dot(QAr, QBr), QAQB = ddot(A.Q, Bs.Q);
+            const V3T<T> QAQBr = mul(A.Q, QBr), QBQAr = mul(Bs.Q, QAr);
+            W += -four * B[3] * QArQBr + two * B[2] * QAQB;
+            QAD = QAD + (four * B[4] * QArQBr - two * B[3] * QAQB) * r + (two * B[4] * rQAr) * QBr - (four * B[3]) * (QBQAr + QAQBr);
+            tq = tq - (two * B[3]) * (cross(QAQBr, r) + cross(QAr, QBr)) + (two * B[2]) * asym_product(A.Q, Bs.Q);
+        }
+        force = force + A.q * gradPhi + QAD;
+        torque = cross(A.mu, gradPhi) - two * tq;
+    }
+}
+
+// One pair of the force kernel, seen from atom i: permanent x permanent through chain m, permanent x induced through chains p and d, and
+// (mutual polarization) induced x induced.  Returns this pair's energy, force on i and torque on i's multipoles WITHOUT the Coulomb
+// constant.  udI ... upJ are the induced dipoles themselves (the halves of the energy expression are applied here).
+template <class T>
+__device__ __forceinline__ void forces_pair(const SiteT<T>& Mi, const SiteT<T>& Mj, V3T<T> udI, V3T<T> upI, V3T<T> udJ, V3T<T> upJ, V3T<T> r,
+                                            const T (&bn)[6], const T (&cn)[6], const T (&oml)[5], T scM, T scP, T scD, bool mutual,
+                                            T& energy, V3T<T>& force, V3T<T>& torque) {
+    const T half = T(0.5), quarter = T(0.25);
+    const SymT<T> zeroQ = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    const SiteT<T> halfUdI = {T(0), half * udI, zeroQ}, halfUpI = {T(0), half * upI, zeroQ}, halfUdJ = {T(0), half * udJ, zeroQ}, halfUpJ = {T(0), half * upJ, zeroQ};
+    T chain[6], W; V3T<T> f, tq;
+    // permanent x permanent
+    for (int n = 0; n < 6; n++) chain[n] = bn[n] - (T(1) - scM) * cn[n];
+    mpole_pair<T, true, true>(Mi, Mj, r, chain, W, f, tq);
+    energy = half * W; force = f; torque = tq;
+    // permanent x induced: chain p with the "d" dipoles, chain d with the "p" dipoles
+    chain[0] = T(0); chain[5] = T(0);
+    for (int n = 1; n < 5; n++) chain[n] = scaled_chain(bn[n], cn[n], oml[n], scP);
+    mpole_pair<T, false, true>(halfUdI, Mj, r, chain, W, f, tq);          // W1: my induced dipole in j's permanent field (no torque: induced dipoles have no frame)
+    energy += quarter * W; force = force + f;
+    mpole_pair<T, true, false>(Mi, halfUdJ, r, chain, W, f, tq);          // W3: my permanent multipoles in the field of j's induced dipole
+    energy += quarter * W; force = force + f; torque = torque + tq;
+    for (int n = 1; n < 5; n++) chain[n] = scaled_chain(bn[n], cn[n], oml[n], scD);
+    mpole_pair<T, false, true>(halfUpI, Mj, r, chain, W, f, tq);          // W2
+    energy += quarter * W; force = force + f;
+    mpole_pair<T, true, false>(Mi, halfUpJ, r, chain, W, f, tq);          // W4
+    energy += quarter * W; force = force + f; torque = torque + tq;
+    if (mutual) {
+        // the induced dipoles polarize each other: -1/2 mu_d (dT/dx) mu_p, the gradient of W(mu_d,i, mu_p,j) / 2 + W(mu_p,i, mu_d,j) / 2
+        // at fixed dipoles through the Thole-damped chain (u scale = 1, as in calculateDirectInducedDipolePairIxns :6172-6230)
+        for (int n = 1; n < 5; n++) chain[n] = bn[n] - oml[n] * cn[n];
+        mpole_pair<T, false, false>(halfUdI, halfUpJ, r, chain, W, f, tq);
+        force = force + T(2) * f;
+        mpole_pair<T, false, false>(halfUpI, halfUdJ, r, chain, W, f, tq);
+        force = force + T(2) * f;
+    }
+}
+
+// The field of partner j's permanent multipoles at atom i through the chains d and p (calculateFixedMultipoleFieldPairIxn :5079-5167):
+// field = S1 r - B1 mu + 2 B2 Q r  with  S1 = -q B1 + B2 (mu.r) - B3 (r.Q.r)
+template <class T>
+__device__ __forceinline__ void field_pair(const SiteT<T>& Mj, V3T<T> r, const T (&bn)[6], const T (&cn)[6], const T (&oml)[5], T scD, T scP, V3T<T>& ed, V3T<T>& ep) {
+    const V3T<T> Qr = mul(Mj.Q, r);
+    const T mur = dot(Mj.mu, r), rQr = dot(r, Qr);
+    T b1 = scaled_chain(bn[1], cn[1], oml[1], scD), b2 = scaled_chain(bn[2], cn[2], oml[2], scD), b3 = scaled_chain(bn[3], cn[3], oml[3], scD);
+    ed = (-Mj.q * b1 + b2 * mur - b3 * rQr) * r - b1 * Mj.mu + (T(2) * b2) * Qr;
+    b1 = scaled_chain(bn[1], cn[1], oml[1], scP); b2 = scaled_chain(bn[2], cn[2], oml[2], scP); b3 = scaled_chain(bn[3], cn[3], oml[3], scP);
+    ep = (-Mj.q * b1 + b2 * mur - b3 * rQr) * r - b1 * Mj.mu + (T(2) * b2) * Qr;
 }
 
 struct MpArgs {
@@ -440,30 +527,33 @@ __global__ void k_mp_potential(MpArgs a, double* __restrict__ out) {
 
 // ------------------------------------------------------------------------------------------------
 // Pair chains.  bn[0..5]: erfc(alpha r)/r and its chain (AmoebaReferencePmeMultipoleForce::calculateFixedMultipoleFieldPairIxn :5103-5118);
-// cn[n] = (2n - 1)!! / r^(2n+1); lam[n], n = 1..4: Thole damping of the rank-n term, lambda_3, lambda_5, lambda_7, lambda_9
+// cn[n] = (2n - 1)!! / r^(2n+1); lambda_(2n+1), n = 1..4: Thole damping of the rank-n term, lambda_3, lambda_5, lambda_7, lambda_9
 // (getDampedInverseDistances :4943-4985; lambda_9 continues the chain: d(lambda_(2n+1) c_n)/dr = -r lambda_(2n+3) c_(n+1)).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void pair_chains(double alpha, double r2, double dampI, double dampJ, double tholeI, double tholeJ, double (&bn)[6], double (&cn)[6], double (&lam)[5]) {
-    const double r = sqrt(r2), ralpha = alpha * r, invR2 = 1.0 / r2;
-    const double exp2a = exp(-ralpha * ralpha), alsq2 = 2.0 * alpha * alpha;
-    double alsq2n = 1.0 / (MP_SQRT_PI * alpha);
+// The damping enters as oml[n] = 1 - lambda_(2n+1), the exponentially small quantity itself (no 1 - (1 - e) in float), and a chain with a
+// scale factor s is  bn[n] - ((1 - s) + s oml[n]) cn[n]  (scaled_chain).
+template <class T>
+__device__ __forceinline__ void pair_chains(T alpha, T r2, T dampI, T dampJ, T tholeI, T tholeJ, T (&bn)[6], T (&cn)[6], T (&oml)[5]) {
+    const T r = sqrt(r2), ralpha = alpha * r, invR2 = T(1) / r2;
+    const T exp2a = exp(-ralpha * ralpha), alsq2 = T(2) * alpha * alpha;
+    T alsq2n = T(1) / (T(MP_SQRT_PI) * alpha);
     bn[0] = erfc(ralpha) / r;
-    cn[0] = 1.0 / r;
+    cn[0] = T(1) / r;
     for (int n = 1; n < 6; n++) {
         alsq2n *= alsq2;
-        bn[n] = ((2 * n - 1) * bn[n - 1] + alsq2n * exp2a) * invR2;
-        cn[n] = (2 * n - 1) * cn[n - 1] * invR2;
+        bn[n] = (T(2 * n - 1) * bn[n - 1] + alsq2n * exp2a) * invR2;
+        cn[n] = T(2 * n - 1) * cn[n - 1] * invR2;
     }
-    lam[0] = lam[1] = lam[2] = lam[3] = lam[4] = 1.0;
-    const double damp = dampI * dampJ;
-    if (damp != 0.0) {
-        const double ratio = r / damp, au3 = (tholeI < tholeJ ? tholeI : tholeJ) * ratio * ratio * ratio;
-        if (au3 < 50.0) {
-            const double e = exp(-au3);
-            lam[1] = 1.0 - e;
-            lam[2] = 1.0 - e * (1.0 + au3);
-            lam[3] = 1.0 - e * (1.0 + au3 + 0.6 * au3 * au3);
-            lam[4] = 1.0 - e * (1.0 + au3 + (18.0 * au3 * au3 + 9.0 * au3 * au3 * au3) / 35.0);
+    oml[0] = oml[1] = oml[2] = oml[3] = oml[4] = T(0);
+    const T damp = dampI * dampJ;
+    if (damp != T(0)) {
+        const T ratio = r / damp, au3 = (tholeI < tholeJ ? tholeI : tholeJ) * ratio * ratio * ratio;
+        if (au3 < T(50)) {
+            const T e = exp(-au3);
+            oml[1] = e;
+            oml[2] = e * (T(1) + au3);
+            oml[3] = e * (T(1) + au3 + T(0.6) * au3 * au3);
+            oml[4] = e * (T(1) + au3 + (T(18) * au3 * au3 + T(9) * au3 * au3 * au3) / T(35));
         }
     }
 }
@@ -498,6 +588,11 @@ __device__ __forceinline__ PairScale pair_scale(const MpArgs& a, int rowBegin, i
 // polarization.  calculateFixedMultipoleField (:5169-5201) + calculateFixedMultipoleFieldPairIxn (:5079-5167) + recordFixedMultipoleField
 // (:6008-6019) + initializeInducedDipoles (:6021-6026).  Fields in units of e / nm^2 (without the Coulomb constant), as there.
 // ------------------------------------------------------------------------------------------------
+// MIXED: the pair arithmetic of ordinary pairs in float (separations formed in double, sums kept in double).  The covalently related
+// pairs of an atom -- a few, with scale factors that subtract most of the bare kernel at short range: bn - (1 - s) cn loses its digits in
+// float there -- are taken from the atom's own row of special partners instead and stay in double: k_mp_special, a launch of its own
+// ahead of this one (inside this kernel its registers -- 256 and more for the force variant -- would set the occupancy of the float loop).
+template <bool MIXED>
 __global__ __launch_bounds__(MP_BLOCK) void k_mp_field(MpArgs a) {
     const int t = threadIdx.x, g = (blockIdx.x * MP_BLOCK + t) / MP_SPLIT, q = t % MP_SPLIT, i = scan_atom(a, g);
     const bool active = i >= 0;
@@ -512,35 +607,42 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_field(MpArgs a) {
         for (int k = q; k < span.total; k += MP_SPLIT) {
             const int entry = pl_at(a.pairList, a.listStride, a.listSubcap, span, k, g);
             const int j = scan_atom(a, entry & PL_POS_MASK);
-            const PairScale sc = pair_scale(a, rowBegin, entry);
-            struct { double x, y, z, q; V3 mu; Sym Q; double thole, damp; } s;
-            { const V3 x = position(a, j); s.x = x.x; s.y = x.y; s.z = x.z; }
-            s.q = a.charge[j]; s.mu = load3(a.labDipole, j); s.Q = load6(a.labQuad, j); s.thole = a.thole[j]; s.damp = a.damping[j];
-            double dx = s.x - xi.x, dy = s.y - xi.y, dz = s.z - xi.z;
+            const bool tagged = ((entry >> 24) & 0x7f) != 0;
+            const V3 xj = position(a, j);
+            double dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
             min_image_d(dx, dy, dz, a.box);
             const double r2 = dx * dx + dy * dy + dz * dz;
-            double bn[6], cn[6], lam[5];
             const bool inside = !(r2 > a.cutoff2);
-            if (inside) pair_chains(a.alpha, r2, dampI, s.damp, tholeI, s.thole, bn, cn, lam);
-            if (a.pairCache != nullptr) {
+            const size_t plane = (size_t) a.pairCap * a.listStride, at = (size_t) k * a.listStride + g;
+            if (a.pairCache != nullptr) { a.pairCache[at] = (float) dx; a.pairCache[plane + at] = (float) dy; a.pairCache[2 * plane + at] = (float) dz; }
+            if (!inside) {
+                if (a.pairCache != nullptr) { a.pairCache[3 * plane + at] = 0.f; a.pairCache[4 * plane + at] = 0.f; }
+                continue;
+            }
+            Site Mj;
+            Mj.q = a.charge[j]; Mj.mu = load3(a.labDipole, j); Mj.Q = load6(a.labQuad, j);
+            if (MIXED) {
+                float bn[6], cn[6], oml[5];
+                pair_chains<float>((float) a.alpha, (float) r2, (float) dampI, (float) a.damping[j], (float) tholeI, (float) a.thole[j], bn, cn, oml);
                 // what the induced-dipole field of every solver iteration needs of this pair (k_mp_dipole_field): geometry and the two
                 // coefficients of the damped chain -- the erfc / exp / Thole arithmetic is done once per evaluation, not once per iteration.
-                // Stored as float: the iterations stream this cache (20 bytes per entry and iteration: they are bound by it), their sums
-                // stay double, and the converged dipoles only have to meet the solver's tolerance; the forces do not read it.
-                const size_t plane = (size_t) a.pairCap * a.listStride, at = (size_t) k * a.listStride + g;
-                a.pairCache[at] = (float) dx; a.pairCache[plane + at] = (float) dy; a.pairCache[2 * plane + at] = (float) dz;
-                a.pairCache[3 * plane + at] = inside ? (float) (bn[1] - (1.0 - lam[1]) * cn[1]) : 0.f;
-                a.pairCache[4 * plane + at] = inside ? (float) (bn[2] - (1.0 - lam[2]) * cn[2]) : 0.f;
+                // Stored as float: the iterations stream this cache, their sums stay double, and the converged dipoles only have to meet the
+                // solver's tolerance; the forces do not read it.
+                if (a.pairCache != nullptr) { a.pairCache[3 * plane + at] = bn[1] - oml[1] * cn[1]; a.pairCache[4 * plane + at] = bn[2] - oml[2] * cn[2]; }
+                if (tagged) continue;                      // second loop, in double
+                V3T<float> fd, fp;
+                field_pair<float>(convert_site<float>(Mj), v3t<float>((float) dx, (float) dy, (float) dz), bn, cn, oml, 1.f, 1.f, fd, fp);
+                ed = ed + widen3(fd); ep = ep + widen3(fp);
             }
-            if (!inside) continue;
-            const V3 r = v3(dx, dy, dz);
-            const V3 Qr = mul(s.Q, r);
-            const double mur = dot(s.mu, r), rQr = dot(r, Qr);
-            // field = S1 r - B1 mu + 2 B2 Q r  with  S1 = -q B1 + B2 (mu.r) - B3 (r.Q.r)
-            double b1 = bn[1] - (1.0 - sc.d * lam[1]) * cn[1], b2 = bn[2] - (1.0 - sc.d * lam[2]) * cn[2], b3 = bn[3] - (1.0 - sc.d * lam[3]) * cn[3];
-            ed = ed + (-s.q * b1 + b2 * mur - b3 * rQr) * r - b1 * s.mu + (2.0 * b2) * Qr;
-            b1 = bn[1] - (1.0 - sc.p * lam[1]) * cn[1]; b2 = bn[2] - (1.0 - sc.p * lam[2]) * cn[2]; b3 = bn[3] - (1.0 - sc.p * lam[3]) * cn[3];
-            ep = ep + (-s.q * b1 + b2 * mur - b3 * rQr) * r - b1 * s.mu + (2.0 * b2) * Qr;
+            else {
+                double bn[6], cn[6], oml[5];
+                pair_chains<double>(a.alpha, r2, dampI, a.damping[j], tholeI, a.thole[j], bn, cn, oml);
+                if (a.pairCache != nullptr) { a.pairCache[3 * plane + at] = (float) (bn[1] - oml[1] * cn[1]); a.pairCache[4 * plane + at] = (float) (bn[2] - oml[2] * cn[2]); }
+                const PairScale sc = pair_scale(a, rowBegin, entry);
+                V3 fd, fp;
+                field_pair<double>(Mj, v3(dx, dy, dz), bn, cn, oml, sc.d, sc.p, fd, fp);
+                ed = ed + fd; ep = ep + fp;
+            }
         }
     }
     ed = split_sum(ed); ep = split_sum(ep);
@@ -550,6 +652,7 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_field(MpArgs a) {
     const double selfTerm = (4.0 / 3.0) * a.alpha * a.alpha * a.alpha / MP_SQRT_PI;
     const V3 common = v3(-phi[1], -phi[2], -phi[3]) * (1.0 / OMM_ONE_4PI_EPS0_D) + selfTerm * load3(a.labDipole, i);
     ed = ed + common; ep = ep + common;
+    if (MIXED) { ed = ed + load3(a.fieldD, i); ep = ep + load3(a.fieldP, i); }       // the covalently related partners: k_mp_special<false>, launched before
     store3(a.fieldD, i, ed); store3(a.fieldP, i, ep);
     const double pol = a.polarity[i];
     store3(a.indD, i, pol * ed); store3(a.indP, i, pol * ep);
@@ -575,6 +678,104 @@ __device__ __forceinline__ void in_potential(double q, V3 mu, const Sym& Q, cons
     torque = v3(0, 0, 0) - cross(mu, g) - 2.0 * asym_product(Q, H);
 }
 
+// Reciprocal-space and self terms of atom i (the potentials carry the Coulomb constant already): added to energy, force and torque.
+// computeReciprocalSpaceFixedMultipoleForceAndEnergy (:5820-5897), computeReciprocalSpaceInducedDipoleForceAndEnergy (:5899-6006),
+// calculatePmeSelfEnergy / calculatePmeSelfTorque (:6294-6333).
+__device__ __forceinline__ void reciprocal_and_self(const MpArgs& a, int i, const Site& Mi, V3 udI, V3 upI, double& energy, V3& force, V3& torque) {
+    const V3 nu = 0.5 * (udI + upI);
+    // ---- reciprocal space (the potentials carry the Coulomb constant already)
+    const double* phi = a.phi + 20 * (size_t) i;
+    double phiNu[20];           // potential of (mu_d + mu_p) / 2
+    for (int k = 0; k < 20; k++) phiNu[k] = a.mutual ? 0.5 * (a.phiInd[20 * (size_t) i + k] + a.phiIndP[20 * (size_t) i + k]) : a.phiInd[20 * (size_t) i + k];
+    const double* phiInd = phiNu;
+    double e; V3 f, tq;
+    in_potential(Mi.q, Mi.mu, Mi.Q, phi, e, f, tq);            // permanent multipoles in the potential of all permanent multipoles
+    energy += 0.5 * e; force = force + f; torque = torque + tq;
+    in_potential(Mi.q, Mi.mu, Mi.Q, phiInd, e, f, tq);         // ... and in the potential of the induced dipoles (mu_d + mu_p) / 2
+    force = force + f; torque = torque + tq;
+    const Sym zero = {0, 0, 0, 0, 0, 0};
+    in_potential(0.0, nu, zero, phi, e, f, tq);                // the induced dipole in the potential of the permanent multipoles
+    energy += 0.5 * e; force = force + f;
+    if (a.mutual) {
+        // -1/2 [mu_d . grad grad phi(mu_p) + mu_p . grad grad phi(mu_d)]  (computeReciprocalSpaceInducedDipoleForceAndEnergy :5976-5980)
+        in_potential(0.0, udI, zero, a.phiIndP + 20 * (size_t) i, e, f, tq);
+        force = force + 0.5 * f;
+        in_potential(0.0, upI, zero, a.phiInd + 20 * (size_t) i, e, f, tq);
+        force = force + 0.5 * f;
+    }
+    // ---- self terms
+    const double a2 = a.alpha * a.alpha, prefac = -a.alpha * OMM_ONE_4PI_EPS0_D / MP_SQRT_PI;
+    const double dxy = Mi.Q.xx - Mi.Q.yy;
+    const double qii = 9.0 * (Mi.Q.zz * Mi.Q.zz + (4.0 / 3.0) * (Mi.Q.xz * Mi.Q.xz + Mi.Q.yz * Mi.Q.yz + Mi.Q.xy * Mi.Q.xy) + (1.0 / 3.0) * dxy * dxy);
+    energy += prefac * (Mi.q * Mi.q + (2.0 / 3.0) * a2 * dot(Mi.mu, Mi.mu + nu) + (4.0 / 15.0) * a2 * a2 * qii);
+    torque = torque + ((4.0 / 3.0) * OMM_ONE_4PI_EPS0_D * a2 * a.alpha / MP_SQRT_PI) * cross(Mi.mu, nu);
+}
+
+// The covalently related partners of every atom (its row of special pairs: a handful, scale factors m / p / d below one) in double, for
+// the mixed-precision kernels: FORCES = false -- their part of the fixed field into fieldD / fieldP (k_mp_field<true> adds the rest);
+// FORCES = true -- their energy and force and the atom's reciprocal-space and self terms (added here), the torque of both left in a.torque
+// (k_mp_forces<true> adds the list pairs).  MP_SPLIT lanes per atom, as in the list kernels.
+template <bool FORCES>
+__global__ __launch_bounds__(MP_BLOCK) void k_mp_special(MpArgs a) {
+    __shared__ double sEnergy[MP_BLOCK / 64];
+    const int t = threadIdx.x, i = (blockIdx.x * MP_BLOCK + t) / MP_SPLIT, q = t % MP_SPLIT;
+    const bool active = i < a.n;
+    const int ii = active ? i : 0;
+    const V3 xi = position(a, ii);
+    Site Mi;
+    Mi.q = a.charge[ii]; Mi.mu = load3(a.labDipole, ii); Mi.Q = load6(a.labQuad, ii);
+    const V3 udI = FORCES ? load3(a.indD, ii) : v3(0, 0, 0), upI = FORCES ? load3(a.indP, ii) : v3(0, 0, 0);
+    const double tholeI = a.thole[ii], dampI = a.damping[ii];
+    const int rowBegin = a.specStart[ii], rowEnd = active ? a.specStart[ii + 1] : rowBegin;
+    V3 accA = v3(0, 0, 0), accB = v3(0, 0, 0);          // field d / p, or force / torque
+    double energy = 0.0;
+    for (int c = rowBegin + q; c < rowEnd; c += MP_SPLIT) {
+        const int j = a.specAtom[c];
+        const double4 scale = a.specScale[c];              // (m, p, d, u)
+        const V3 xj = position(a, j);
+        double dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
+        min_image_d(dx, dy, dz, a.box);
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        if (r2 > a.cutoff2) continue;
+        Site Mj;
+        Mj.q = a.charge[j]; Mj.mu = load3(a.labDipole, j); Mj.Q = load6(a.labQuad, j);
+        double bn[6], cn[6], oml[5];
+        pair_chains<double>(a.alpha, r2, dampI, a.damping[j], tholeI, a.thole[j], bn, cn, oml);
+        if (FORCES) {
+            double e; V3 f, tq;
+            forces_pair<double>(Mi, Mj, udI, upI, load3(a.indD, j), load3(a.indP, j), v3(dx, dy, dz), bn, cn, oml, scale.x, scale.y, scale.z, a.mutual != 0, e, f, tq);
+            energy += e; accA = accA + f; accB = accB + tq;
+        }
+        else {
+            V3 fd, fp;
+            field_pair<double>(Mj, v3(dx, dy, dz), bn, cn, oml, scale.z, scale.y, fd, fp);
+            accA = accA + fd; accB = accB + fp;
+        }
+    }
+    accA = split_sum(accA); accB = split_sum(accB); energy = split_sum(energy);
+    if (q != 0) energy = 0.0;
+    if (active && q == 0) {
+        if (FORCES) {
+            accA = OMM_ONE_4PI_EPS0_D * accA; accB = OMM_ONE_4PI_EPS0_D * accB; energy *= OMM_ONE_4PI_EPS0_D;
+            reciprocal_and_self(a, i, Mi, udI, upI, energy, accA, accB);           // everything of the atom that is not a pair of the list
+            store3(a.torque, i, accB);
+            add_force(a.force, a.paddedAtoms, a.slotOfAtom[i], accA.x, accA.y, accA.z);
+        }
+        else { store3(a.fieldD, i, accA); store3(a.fieldP, i, accB); }
+    }
+    if (FORCES && a.includeEnergy) {
+        energy = wave_sum(active ? energy : 0.0);
+        if ((t & 63) == 0) sEnergy[t >> 6] = energy;
+        __syncthreads();
+        if (t == 0) {
+            double e = 0;
+            for (int w = 0; w < MP_BLOCK / 64; w++) e += sEnergy[w];
+            atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], e);
+        }
+    }
+}
+
+template <bool MIXED>
 __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
     __shared__ double sEnergy[MP_BLOCK / 64];
     const int t = threadIdx.x, g = (blockIdx.x * MP_BLOCK + t) / MP_SPLIT, q = t % MP_SPLIT, i = scan_atom(a, g);
@@ -584,58 +785,43 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
     Site Mi;
     Mi.q = a.charge[ii]; Mi.mu = load3(a.labDipole, ii); Mi.Q = load6(a.labQuad, ii);
     const V3 udI = load3(a.indD, ii), upI = load3(a.indP, ii);
-    const Sym zeroQ = {0, 0, 0, 0, 0, 0};
-    Site halfUdI = {0.0, 0.5 * udI, zeroQ}, halfUpI = {0.0, 0.5 * upI, zeroQ};
     const double tholeI = a.thole[ii], dampI = a.damping[ii];
     const int rowBegin = a.specStart[ii];
     V3 force = v3(0, 0, 0), torque = v3(0, 0, 0);
     double energy = 0.0;
     {
+        // (MIXED: ordinary pairs in float from the list; the atom's covalently related partners in double by k_mp_special<true>: see k_mp_field)
+        const SiteT<float> MiF = convert_site<float>(Mi);
+        const V3T<float> udIF = convert3<float>(udI), upIF = convert3<float>(upI);
         PlSpan span = {0, 0, 0, 0};
         if (active) span = pl_span(a.pairCount, a.listStride, g);
         for (int k = q; k < span.total; k += MP_SPLIT) {
             const int entry = pl_at(a.pairList, a.listStride, a.listSubcap, span, k, g);
+            if (MIXED && ((entry >> 24) & 0x7f) != 0) continue;
             const int j = scan_atom(a, entry & PL_POS_MASK);
-            const PairScale sc = pair_scale(a, rowBegin, entry);
-            struct { double x, y, z, q; V3 mu; Sym Q; double thole, damp; V3 ud, up; } s;
-            { const V3 x = position(a, j); s.x = x.x; s.y = x.y; s.z = x.z; }
-            s.q = a.charge[j]; s.mu = load3(a.labDipole, j); s.Q = load6(a.labQuad, j); s.thole = a.thole[j]; s.damp = a.damping[j];
-            s.ud = load3(a.indD, j); s.up = load3(a.indP, j);
-            double dx = s.x - xi.x, dy = s.y - xi.y, dz = s.z - xi.z;
+            const V3 xj = position(a, j);
+            double dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
             min_image_d(dx, dy, dz, a.box);
             const double r2 = dx * dx + dy * dy + dz * dz;
             if (r2 > a.cutoff2) continue;
-            double bn[6], cn[6], lam[5], chain[6];
-            pair_chains(a.alpha, r2, dampI, s.damp, tholeI, s.thole, bn, cn, lam);
-            const V3 r = v3(dx, dy, dz);
             Site Mj;
-            Mj.q = s.q; Mj.mu = s.mu; Mj.Q = s.Q;
-            double W; V3 f, tq;
-            // permanent x permanent
-            for (int n = 0; n < 6; n++) chain[n] = bn[n] - (1.0 - sc.m) * cn[n];
-            mpole_pair(Mi, Mj, r, chain, W, f, tq);
-            energy += 0.5 * W; force = force + f; torque = torque + tq;
-            // permanent x induced: chain p with the "d" dipoles, chain d with the "p" dipoles
-            const Site halfUdJ = {0.0, 0.5 * s.ud, zeroQ}, halfUpJ = {0.0, 0.5 * s.up, zeroQ};
-            chain[0] = 0.0; chain[5] = 0.0;
-            for (int n = 1; n < 5; n++) chain[n] = bn[n] - (1.0 - sc.p * lam[n]) * cn[n];
-            mpole_pair(halfUdI, Mj, r, chain, W, f, tq);          // W1: my induced dipole in j's permanent field (no torque: induced dipoles have no frame)
-            energy += 0.25 * W; force = force + f;
-            mpole_pair(Mi, halfUdJ, r, chain, W, f, tq);          // W3: my permanent multipoles in the field of j's induced dipole
-            energy += 0.25 * W; force = force + f; torque = torque + tq;
-            for (int n = 1; n < 5; n++) chain[n] = bn[n] - (1.0 - sc.d * lam[n]) * cn[n];
-            mpole_pair(halfUpI, Mj, r, chain, W, f, tq);          // W2
-            energy += 0.25 * W; force = force + f;
-            mpole_pair(Mi, halfUpJ, r, chain, W, f, tq);          // W4
-            energy += 0.25 * W; force = force + f; torque = torque + tq;
-            if (a.mutual) {
-                // the induced dipoles polarize each other: -1/2 mu_d (dT/dx) mu_p, the gradient of W(mu_d,i, mu_p,j) / 2 + W(mu_p,i, mu_d,j) / 2
-                // at fixed dipoles through the Thole-damped chain (u scale = 1, as in calculateDirectInducedDipolePairIxns :6172-6230)
-                for (int n = 1; n < 5; n++) chain[n] = bn[n] - (1.0 - lam[n]) * cn[n];
-                mpole_pair(halfUdI, halfUpJ, r, chain, W, f, tq);
-                force = force + 2.0 * f;
-                mpole_pair(halfUpI, halfUdJ, r, chain, W, f, tq);
-                force = force + 2.0 * f;
+            Mj.q = a.charge[j]; Mj.mu = load3(a.labDipole, j); Mj.Q = load6(a.labQuad, j);
+            const V3 udJ = load3(a.indD, j), upJ = load3(a.indP, j);
+            if (MIXED) {
+                float bn[6], cn[6], oml[5], e;
+                pair_chains<float>((float) a.alpha, (float) r2, (float) dampI, (float) a.damping[j], (float) tholeI, (float) a.thole[j], bn, cn, oml);
+                V3T<float> f, tq;
+                forces_pair<float>(MiF, convert_site<float>(Mj), udIF, upIF, convert3<float>(udJ), convert3<float>(upJ), v3t<float>((float) dx, (float) dy, (float) dz),
+                                   bn, cn, oml, 1.f, 1.f, 1.f, a.mutual != 0, e, f, tq);
+                energy += (double) e; force = force + widen3(f); torque = torque + widen3(tq);
+            }
+            else {
+                const PairScale sc = pair_scale(a, rowBegin, entry);
+                double bn[6], cn[6], oml[5], e;
+                pair_chains<double>(a.alpha, r2, dampI, a.damping[j], tholeI, a.thole[j], bn, cn, oml);
+                V3 f, tq;
+                forces_pair<double>(Mi, Mj, udI, upI, udJ, upJ, v3(dx, dy, dz), bn, cn, oml, sc.m, sc.p, sc.d, a.mutual != 0, e, f, tq);
+                energy += e; force = force + f; torque = torque + tq;
             }
         }
     }
@@ -644,33 +830,8 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
     if (active && q == 0) {
         // pair quantities carry the Coulomb constant from here on
         force = OMM_ONE_4PI_EPS0_D * force; torque = OMM_ONE_4PI_EPS0_D * torque; energy *= OMM_ONE_4PI_EPS0_D;
-        const V3 nu = 0.5 * (udI + upI);
-        // ---- reciprocal space (the potentials carry the Coulomb constant already)
-        const double* phi = a.phi + 20 * (size_t) i;
-        double phiNu[20];           // potential of (mu_d + mu_p) / 2
-        for (int k = 0; k < 20; k++) phiNu[k] = a.mutual ? 0.5 * (a.phiInd[20 * (size_t) i + k] + a.phiIndP[20 * (size_t) i + k]) : a.phiInd[20 * (size_t) i + k];
-        const double* phiInd = phiNu;
-        double e; V3 f, tq;
-        in_potential(Mi.q, Mi.mu, Mi.Q, phi, e, f, tq);            // permanent multipoles in the potential of all permanent multipoles
-        energy += 0.5 * e; force = force + f; torque = torque + tq;
-        in_potential(Mi.q, Mi.mu, Mi.Q, phiInd, e, f, tq);         // ... and in the potential of the induced dipoles (mu_d + mu_p) / 2
-        force = force + f; torque = torque + tq;
-        const Sym zero = {0, 0, 0, 0, 0, 0};
-        in_potential(0.0, nu, zero, phi, e, f, tq);                // the induced dipole in the potential of the permanent multipoles
-        energy += 0.5 * e; force = force + f;
-        if (a.mutual) {
-            // -1/2 [mu_d . grad grad phi(mu_p) + mu_p . grad grad phi(mu_d)]  (computeReciprocalSpaceInducedDipoleForceAndEnergy :5976-5980)
-            in_potential(0.0, udI, zero, a.phiIndP + 20 * (size_t) i, e, f, tq);
-            force = force + 0.5 * f;
-            in_potential(0.0, upI, zero, a.phiInd + 20 * (size_t) i, e, f, tq);
-            force = force + 0.5 * f;
-        }
-        // ---- self terms
-        const double a2 = a.alpha * a.alpha, prefac = -a.alpha * OMM_ONE_4PI_EPS0_D / MP_SQRT_PI;
-        const double dxy = Mi.Q.xx - Mi.Q.yy;
-        const double qii = 9.0 * (Mi.Q.zz * Mi.Q.zz + (4.0 / 3.0) * (Mi.Q.xz * Mi.Q.xz + Mi.Q.yz * Mi.Q.yz + Mi.Q.xy * Mi.Q.xy) + (1.0 / 3.0) * dxy * dxy);
-        energy += prefac * (Mi.q * Mi.q + (2.0 / 3.0) * a2 * dot(Mi.mu, Mi.mu + nu) + (4.0 / 15.0) * a2 * a2 * qii);
-        torque = torque + ((4.0 / 3.0) * OMM_ONE_4PI_EPS0_D * a2 * a.alpha / MP_SQRT_PI) * cross(Mi.mu, nu);
+        if (!MIXED) reciprocal_and_self(a, i, Mi, udI, upI, energy, force, torque);          // (MIXED: k_mp_special<true> has added them)
+        if (MIXED) torque = torque + load3(a.torque, i);          // the covalently related partners: k_mp_special<true>, launched before (Coulomb constant included)
         store3(a.torque, i, torque);
         add_force(a.force, a.paddedAtoms, a.slotOfAtom[i], force.x, force.y, force.z);
     }
@@ -723,10 +884,10 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const do
                 min_image_d(dx, dy, dz, a.box);
                 const double r2 = dx * dx + dy * dy + dz * dz;
                 if (r2 > a.cutoff2) continue;
-                double bn[6], cn[6], lam[5];
-                pair_chains(a.alpha, r2, dampI, a.damping[j], tholeI, a.thole[j], bn, cn, lam);
+                double bn[6], cn[6], oml[5];
+                pair_chains<double>(a.alpha, r2, dampI, a.damping[j], tholeI, a.thole[j], bn, cn, oml);
                 r = v3(dx, dy, dz);
-                b1 = bn[1] - (1.0 - lam[1]) * cn[1]; b2 = bn[2] - (1.0 - lam[2]) * cn[2];
+                b1 = bn[1] - oml[1] * cn[1]; b2 = bn[2] - oml[2] * cn[2];
             }
             ed = ed + (b2 * dot(s.vd, r)) * r - b1 * s.vd;
             ep = ep + (b2 * dot(s.vp, r)) * r - b1 * s.vp;
@@ -1067,7 +1228,11 @@ int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const doub
     hipLaunchKernelGGL(k_mp_spread<false>, dim3(spread_blocks(a)), dim3(256), 0, st, a, (const double*) nullptr, 0.0, (const double*) nullptr, 0.0);
     ommhip_pme_convolve(pme, st);
     hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phi);
-    hipLaunchKernelGGL(k_mp_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
+    if (mp->mixed_precision) {
+        hipLaunchKernelGGL(k_mp_special<false>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, st, a);
+        hipLaunchKernelGGL(k_mp_field<true>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
+    }
+    else hipLaunchKernelGGL(k_mp_field<false>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
     return 0;
 }
 
@@ -1207,7 +1372,11 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
         ommhip_pme_convolve(pme, st);
         hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phiInd);
     }
-    hipLaunchKernelGGL(k_mp_forces, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
+    if (mp->mixed_precision) {
+        hipLaunchKernelGGL(k_mp_special<true>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, st, a);
+        hipLaunchKernelGGL(k_mp_forces<true>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
+    }
+    else hipLaunchKernelGGL(k_mp_forces<false>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_mp_torque_to_force, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
     return (int) hipGetLastError();
 }

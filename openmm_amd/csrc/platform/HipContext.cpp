@@ -391,6 +391,30 @@ void HipContext::collectFrontTerms(vector<ommhip_term_batch>& out, bool includeE
     }
 }
 
+int HipContext::registerEarlyWork(int group, const EarlyLaunch& launch) {
+    EarlyWork w = {nextTermId++, group, launch};
+    earlyWork.push_back(w);
+    return w.id;
+}
+
+void HipContext::unregisterEarlyWork(int id) {
+    for (size_t i = 0; i < earlyWork.size(); i++)
+        if (earlyWork[i].id == id) { earlyWork.erase(earlyWork.begin() + i); return; }
+}
+
+bool HipContext::earlyWorkLaunched(int id) const {
+    return std::find(launchedEarlyIds.begin(), launchedEarlyIds.end(), id) != launchedEarlyIds.end();
+}
+
+void HipContext::launchEarlyWork(ContextImpl& context, bool includeForces, bool includeEnergy) {
+    for (size_t i = 0; i < earlyWork.size(); i++) {
+        const EarlyWork w = earlyWork[i];
+        if (((currentGroups >> w.group) & 1) == 0 || earlyWorkLaunched(w.id)) continue;
+        launchedEarlyIds.push_back(w.id);
+        w.launch(context, includeForces, includeEnergy);
+    }
+}
+
 void HipContext::saveForces() {
     if (savedForce.ptr == NULL) savedForce.allocate(force.bytes);
     HIP_CHECK(ommhip_memcpy_d2d(savedForce.ptr, force.ptr, force.bytes, stream));

@@ -21,6 +21,7 @@
 namespace OpenMM {
 
 class System;
+class ContextImpl;
 
 #define HIP_CHECK(call) do { int rc__ = (call); if (rc__ != 0) { std::stringstream s__; \
     s__ << "HIP platform: " << #call << " failed with code " << rc__ << " (" << ommhip_error_string(rc__) << ") at " << __FILE__ << ":" << __LINE__; \
@@ -125,7 +126,17 @@ public:
     void collectFrontTerms(std::vector<ommhip_term_batch>& out, bool includeEnergy);
     int currentGroups = -1;
     /** Start of an evaluation: which force groups are evaluated; forgets what the previous evaluation launched. */
-    void beginEvaluation(int groups) { currentGroups = groups; launchedTermIds.clear(); }
+    void beginEvaluation(int groups) { currentGroups = groups; launchedTermIds.clear(); launchedEarlyIds.clear(); }
+    /** Work of one Force that another Force's kernel may start before the owner executes -- the same idea as registerTerms, for whole
+     *  kernels: a force whose evaluation blocks the host for a while (the AMOEBA dipole solver waits for its convergence measure) first
+     *  launches what the forces after it in the System would otherwise only enqueue once it has finished (the AMOEBA vdW kernel, on the
+     *  side stream).  The owner's execute() asks earlyWorkLaunched() and launches itself when nobody did. */
+    typedef std::function<void(ContextImpl&, bool, bool)> EarlyLaunch;        // (context, includeForces, includeEnergy)
+    int registerEarlyWork(int group, const EarlyLaunch& launch);
+    void unregisterEarlyWork(int id);
+    bool earlyWorkLaunched(int id) const;
+    void noteEarlyWorkLaunched(int id) { launchedEarlyIds.push_back(id); }
+    void launchEarlyWork(ContextImpl& context, bool includeForces, bool includeEnergy);
     void flushTerms();
     void saveForces();                                         // device copy of the force buffer (energy-only evaluations)
     void restoreForces();
@@ -260,6 +271,9 @@ private:
     struct TermRegistration { int id, group; ommhip_term_batch batch; };
     std::vector<TermRegistration> termRegistry;
     std::vector<int> launchedTermIds;          // ids whose terms already went out this evaluation (fused front launch)
+    struct EarlyWork { int id, group; EarlyLaunch launch; };
+    std::vector<EarlyWork> earlyWork;
+    std::vector<int> launchedEarlyIds;
     int nextTermId = 1;
     bool reorderRequested;
     bool reorderDue = false;

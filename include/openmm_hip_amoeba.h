@@ -164,6 +164,8 @@ typedef struct ommhip_amoeba_multipole {
     int* list_state;
     int force_rebuild;
     int* list_builds;
+    float* solver_gather;          /* device float[6 * S] or NULL (mutual polarization): the solver keeps the vectors whose field it takes as six floats per scan
+                                    * position here as well -- the induced-dipole field kernel gathers them from this copy */
     int mixed_precision;           /* 1: the pair arithmetic of ordinary pairs in float (separations formed in double, sums in double; covalently related
                                     * pairs stay in double) -- the "mixed" mode of the reference's GPU platforms; 0: everything in double */
     int expected_iterations;       /* iterations the previous solve took (0 = unknown): that many minus one are enqueued before the host first waits for the

@@ -77,6 +77,18 @@ typedef struct ommhip_halo_plan {
     size_t trailer_offset, trailer_bytes;
 } ommhip_halo_plan;
 int ommhip_comm_halo_exchange(ommhip_comm* comm, void* buffer_d, const ommhip_halo_plan* plan, void* stream);
+/* The way back: what a rank accumulated on atoms of its LOWER neighbour goes home.  With half-shell evaluation a pair of
+ * atoms of two neighbouring slabs is evaluated once, by the upper rank, which holds the lower rank's "up" section as part of its halo: the
+ * force on those atoms sits in the upper rank's fixed-point buffer and is returned here.  force_d: the platform's SoA force buffer, three
+ * components of padded_slots 64-bit elements in slot order.  The plan (identical on all ranks) names the up section of EVERY rank as
+ * global slot indices.  This rank sends, per component, the elements of its lower neighbour's section to that neighbour and receives
+ * those of its own section from its upper neighbour into staging_d (3 x num_slots[rank] elements, component-major), which a kernel then
+ * adds to force_d -- integer addition, so the sum does not depend on arrival order.  RCCL: one group of three sends and three receives.
+ * With one rank nothing moves. */
+typedef struct ommhip_halo_return_plan {
+    int first_slot[OMMHIP_MAX_RANKS], num_slots[OMMHIP_MAX_RANKS];
+} ommhip_halo_return_plan;
+int ommhip_comm_halo_return(ommhip_comm* comm, long long* force_d, int padded_slots, const ommhip_halo_return_plan* plan, long long* staging_d, void* stream);
 /* Host all-gather of small records (energies, momenta, flags): blocking; every rank then reduces the size records in the
  * same order, which makes sums bit-identical on all ranks. */
 int ommhip_comm_all_gather_host(ommhip_comm* comm, const void* send, void* recv, size_t bytes, void* stream);

@@ -184,6 +184,12 @@ typedef struct ommhip_neighbor_list {
      * position moved by the minimum-image displacement to the decoded one, so molecules stay whole -- for the kernels that
      * address atoms by index (exclusion correction, bonded terms). */
     int dd_mode;
+    /* Half-shell evaluation (with dd_mode = 1 and halo mode): a pair of atoms of two neighbouring slabs is evaluated ONCE, by the upper rank.
+     * The list of an owned block then holds the own blocks Y >= X and the blocks of [dd_eval_slot0, dd_eval_slot1) -- the lower neighbour's
+     * section, multiples of 32 slots -- the pair kernel KEEPS the forces on those atoms (and the whole pair energy), and the caller returns
+     * them to their owner afterwards (ommhip_comm_halo_return).  Blocks of the upper neighbour that this rank holds for charge spreading
+     * are converted and bounded like any active range but are nobody's partners here. */
+    int dd_half_shell, dd_eval_slot0, dd_eval_slot1;
     const void* pos_wire;
     void* pos_scatter;
     /* Optional float4[padded_atoms]: the low parts of posq_rel -- (double-precision position minus block centre) minus its float
@@ -388,6 +394,15 @@ typedef struct ommhip_term_batch {
      * forces on its own atoms (the rest lands in slots nobody reads), and counts the term's energy only if it owns the FIRST atom:
      * over the ranks every term is counted once. */
     int own_slot0, own_slot1;
+    /* Half-shell evaluation (half_shell = 1, with the fields above): a term is evaluated by ONE rank -- the one that owns at least one of
+     * its atoms and sees all of them in its own range or in [eval_slot0, eval_slot1), the lower neighbour's section it holds for its pairs --
+     * which keeps all the forces (those on the neighbour's atoms go home with ommhip_comm_halo_return) and counts the energy.  A term with
+     * an owned atom that this rank cannot evaluate must be the upper neighbour's: every owned atom of it in [up_slot0, up_slot1) (the
+     * section that neighbour holds) and the atoms out of sight owned by rank (rank + 1) % ranks (a slot's owner is slot / slots_per_rank);
+     * otherwise nobody would evaluate it and bit 8 is raised in error_flags[1] (ommhip_neighbor_list::dd_flags: it travels to all ranks in
+     * the trailer, and all of them end the run). */
+    int half_shell, eval_slot0, eval_slot1, up_slot0, up_slot1, rank, ranks, slots_per_rank;
+    int* error_flags;
 } ommhip_term_batch;
 int ommhip_term_forces_multi(int num_lists, const ommhip_term_batch* lists, const void* pos_d, const int* slot_of_atom_d, int padded_atoms,
                              const double box[6], long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);

@@ -27,7 +27,7 @@ class NeighborList(C.Structure):
         ("row_j", C.c_void_p), ("row_mask", C.c_void_p), ("excl_slot_start", C.c_void_p), ("excl_slots", C.c_void_p),
         ("cell_start", C.c_void_p), ("cell_blocks", C.c_void_p), ("cell_boxes", C.c_void_p), ("cell_meta", C.c_void_p), ("max_cells", C.c_int), ("cell_min_blocks", C.c_int),
         ("first_block", C.c_int), ("owned_blocks", C.c_int), ("posq_rel", C.c_void_p),
-        ("dd_mode", C.c_int), ("pos_wire", C.c_void_p), ("pos_scatter", C.c_void_p), ("posq_rel_lo", C.c_void_p),
+        ("dd_mode", C.c_int), ("dd_half_shell", C.c_int), ("dd_eval_slot0", C.c_int), ("dd_eval_slot1", C.c_int), ("pos_wire", C.c_void_p), ("pos_scatter", C.c_void_p), ("posq_rel_lo", C.c_void_p),
         ("num_active_ranges", C.c_int), ("active_range", C.c_int * 8), ("wire_ref", C.c_void_p), ("dd_guard_atom", C.c_void_p),
         ("dd_warn", C.c_uint), ("dd_max", C.c_uint), ("dd_flags", C.c_void_p), ("dd_ranks", C.c_int), ("dd_slots_per_rank", C.c_int), ("dd_trailer_slot", C.c_int),
         ("chunk_info_inner", C.c_void_p), ("row_j_inner", C.c_void_p), ("row_mask_inner", C.c_void_p), ("block_runs", C.c_void_p),

@@ -387,6 +387,12 @@ void HipCalcAmoebaMultipoleForceKernel::upload(const AmoebaMultipoleForce& force
     mp.mixed_precision = getenv("OPENMM_HIP_AMOEBA_PRECISION") != NULL && string(getenv("OPENMM_HIP_AMOEBA_PRECISION")) == "double" ? 0 : 1;
     mp.max_iterations = force.getMutualInducedMaxIterations(); mp.target_epsilon = force.getMutualInducedTargetEpsilon();
     mp.phi_induced_p = mutual ? phiIndP.as<double>() : NULL; mp.solver = mutual ? solver.as<double>() : NULL; mp.status = solverStatus;
+    mp.solver_gather = NULL;
+    if (mutual && getenv("OPENMM_HIP_AMOEBA_NO_GATHER_COPY") == NULL) {        // (A/B knob: the field kernel gathers the atom-ordered doubles)
+        solverGather.allocate(sizeof(float) * 6 * (size_t) hip.paddedAtoms);
+        HIP_CHECK(ommhip_memset(solverGather.ptr, 0, solverGather.bytes, hip.stream));
+        mp.solver_gather = solverGather.as<float>();
+    }
     mp.history = mutual && history.ptr != NULL ? history.as<double>() : NULL; mp.history_slots = HistorySlots; mp.history_newest = 0; mp.history_store = -1; mp.history_use = 0; mp.expected_iterations = 0;
     historyValid = 0;                         // new parameters: the earlier solutions belong to another Hamiltonian
     // mutual polarization: a second grid set and a side stream, so that the potentials of the two dipole sets are computed side by side

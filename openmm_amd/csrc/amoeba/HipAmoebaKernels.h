@@ -94,7 +94,7 @@ private:
     ommhip_pme pme, pme2;
     void* sideStream = NULL; void* eventA = NULL; void* eventB = NULL;
     DeviceBuffer charge, molDipole, molQuad, axis, thole, damping, polarity, specStart, specAtom, specScale;
-    DeviceBuffer labDipole, labQuad, fieldD, fieldP, indD, indP, phi, phiInd, phiIndP, solver, history, torque, tileBounds, specPos, specScaleSorted, pairList, pairCount, pairOverflow, pairCache;
+    DeviceBuffer labDipole, labQuad, fieldD, fieldP, indD, indP, phi, phiInd, phiIndP, solver, solverGather, history, torque, tileBounds, specPos, specScaleSorted, pairList, pairCount, pairOverflow, pairCache;
     DeviceBuffer moduliX, moduliY, moduliZ, twiddleX, twiddleY, twiddleZ, eterm, gridReal, gridComplex, gridReal2, gridComplex2;
 };
 

@@ -199,6 +199,7 @@ struct MpArgs {
     const int* pairList; const int* pairCount; int listStride, listSubcap;
     int precond; double precondCut2;               // neighbour-pair preconditioner of the solver (needs the pair cache)
     float* pairCache; int pairCap;                 // mutual polarization: per list entry (dx, dy, dz, b1, b2) of the Thole-damped dipole-dipole chain, float planes of pairCap * listStride
+    float* gather;                                 // mutual polarization: the vectors the induced-dipole field is taken of, (vD, vP) as six floats per SCAN POSITION (k_mp_dipole_field gathers them)
     const double* doneFlag;                        // mutual polarization: sums[10] of the solver -- non-zero once the dipoles have converged: kernels of iterations enqueued ahead return at once
     const double4* specScaleSorted;                // scale factors of the special pairs, rows in the order the list entries index them
 };
@@ -868,9 +869,16 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const do
         PlSpan span = {0, 0, 0, 0};
         if (active) span = pl_span(a.pairCount, a.listStride, g);
         for (int k = q; k < span.total; k += MP_SPLIT) {
-            const int j = scan_atom(a, pl_at(a.pairList, a.listStride, a.listSubcap, span, k, g) & PL_POS_MASK);
+            const int sj = pl_at(a.pairList, a.listStride, a.listSubcap, span, k, g) & PL_POS_MASK;
             struct { V3 vd, vp; } s;
-            s.vd = load3(vD, j); s.vp = load3(vP, j);
+            int j = -1;
+            if (a.gather != nullptr) {
+                // the partner's dipoles from the packed copy in scan order: no slot -> atom indirection, 24 bytes instead of 48, and partners
+                // that follow each other in the list (spatial neighbours) share cache lines -- the atom-ordered doubles are scattered
+                const float* v = a.gather + 6 * (size_t) sj;
+                s.vd = v3(v[0], v[1], v[2]); s.vp = v3(v[3], v[4], v[5]);
+            }
+            else { j = scan_atom(a, sj); s.vd = load3(vD, j); s.vp = load3(vP, j); }
             V3 r;
             double b1, b2;
             if (a.pairCache != nullptr) {
@@ -879,6 +887,7 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const do
                 b1 = a.pairCache[3 * plane + at]; b2 = a.pairCache[4 * plane + at];
             }
             else {
+                if (j < 0) j = scan_atom(a, sj);
                 const V3 xj = position(a, j);
                 double dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
                 min_image_d(dx, dy, dz, a.box);
@@ -911,6 +920,7 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const do
                 if (pol > 0) { rd = load3(a.fieldD, i) - invPol * viD + td; rp = load3(a.fieldP, i) - invPol * viP + tp; }
                 store3(w, i, rd); store3(w + n3, i, rp);
                 store3(w + 2 * n3, i, pol * rd); store3(w + 3 * n3, i, pol * rp); store3(w + 4 * n3, i, pol * rd); store3(w + 5 * n3, i, pol * rp);
+                // (the packed copy of p for the first iteration is written by k_mp_pack after this launch: other lanes are still reading the copy of mu_0)
                 s0 = pol * dot(rd, rd); s1 = pol * dot(rp, rp); s2 = pol * pol * dot(rd, rd); s3 = pol * pol * dot(rp, rp);
             }
             else {
@@ -1035,7 +1045,12 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double target, double un
             s2 = pol * pol * dot(rd, rd); s3 = pol * pol * dot(rp, rp);
         }
         else {
-            store3(pD, i, load3(zD, i) + cD * load3(pD, i)); store3(pP, i, load3(zP, i) + cP * load3(pP, i));
+            const V3 nd = load3(zD, i) + cD * load3(pD, i), np = load3(zP, i) + cP * load3(pP, i);
+            store3(pD, i, nd); store3(pP, i, np);
+            if (a.gather != nullptr) {
+                float* v = a.gather + 6 * (size_t) (a.slotOfAtom != nullptr && a.order != nullptr ? a.slotOfAtom[i] : i);
+                v[0] = (float) nd.x; v[1] = (float) nd.y; v[2] = (float) nd.z; v[3] = (float) np.x; v[4] = (float) np.y; v[5] = (float) np.z;
+            }
         }
     }
     if (stage == 3) {
@@ -1068,6 +1083,15 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double target, double un
         else if (stage == 2) { atomicAdd(&sums[6], s0); atomicAdd(&sums[7], s1); atomicAdd(&sums[4], s2); atomicAdd(&sums[5], s3); }
         else { atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); atomicAdd(&sums[4], s2); atomicAdd(&sums[5], s3); }
     }
+}
+
+// (vD, vP) of every atom as six floats at its scan position: what k_mp_dipole_field gathers (see there)
+__global__ void k_mp_pack(MpArgs a, const double* __restrict__ vD, const double* __restrict__ vP) {
+    if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    float* v = a.gather + 6 * (size_t) (a.slotOfAtom != nullptr && a.order != nullptr ? a.slotOfAtom[i] : i);
+    v[0] = (float) vD[3 * i]; v[1] = (float) vD[3 * i + 1]; v[2] = (float) vD[3 * i + 2]; v[3] = (float) vP[3 * i]; v[4] = (float) vP[3 * i + 1]; v[5] = (float) vP[3 * i + 2];
 }
 
 // First guess of the solver from the solutions of earlier calls: mu(t) ~ sum_k c_k mu(t - k dt), k = 1..count, with the caller's
@@ -1187,6 +1211,7 @@ bool make_args(const ommhip_amoeba_multipole* mp, const void* pos_d, const doubl
     static const bool usePrecond = getenv("OPENMM_HIP_AMOEBA_PRECOND") != nullptr && atoi(getenv("OPENMM_HIP_AMOEBA_PRECOND")) != 0;
     a.precond = a.pairCache != nullptr && usePrecond ? 1 : 0; a.precondCut2 = 0.45 * 0.45;
     a.doneFlag = nullptr;
+    a.gather = a.mutual ? mp->solver_gather : nullptr;
     return true;
 }
 
@@ -1304,6 +1329,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st) {
     // T mu_0 and the residual of the first guess
     dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st, true);
     const int cgBlocks = (a.n + MP_CG_BLOCK - 1) / MP_CG_BLOCK;
+    if (a.gather != nullptr) hipLaunchKernelGGL(k_mp_pack, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP);
     if (a.precond) {
         hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, tD, tP, w, -1);
         hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 0, 0.0, 0.0);
@@ -1311,6 +1337,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st) {
     }
     else hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, tD, tP, w, 0);
     hipLaunchKernelGGL(k_mp_cg, dim3(1), dim3(64), 0, st, a, w, 5, mp->target_epsilon, 0.0);
+    if (a.gather != nullptr) hipLaunchKernelGGL(k_mp_pack, dim3(blocks), dim3(MP_BLOCK), 0, st, a, pD, pP);      // p of the first iteration (later ones: stage 3 writes the copy itself)
     a.doneFlag = sums + 10;                   // from here on the kernels look at the convergence word
     static const bool everyIteration = getenv("OPENMM_HIP_AMOEBA_CHECK_EVERY_ITERATION") != nullptr;       // A/B knob: one host round trip per iteration, as before
     const int unchecked = everyIteration ? 0 : (mp->expected_iterations > 1 ? mp->expected_iterations - 1 : 0);

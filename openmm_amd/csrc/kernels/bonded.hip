@@ -24,6 +24,8 @@ namespace {
 struct TermList {
     int kind, numTerms, periodic, firstBlock;
     int ownSlot0, ownSlot1;    // halo mode of a decomposed run (ownSlot1 > ownSlot0): terms without an owned atom are skipped, the energy counts where the first atom is owned
+    int halfShell, evalSlot0, evalSlot1, upSlot0, upSlot1, rank, ranks, slotsPerRank;      // half-shell evaluation: ommhip_term_batch
+    int* errorFlags;
     double alpha;
     const int* atoms;          // numTerms * atomsPerTerm
     const double* params;      // numTerms * paramsPerTerm
@@ -196,14 +198,27 @@ __device__ __forceinline__ void terms_body(const TermArgs& a, const int block, d
     bool evaluate = t < l.numTerms, countEnergy = true;
     if (evaluate && l.ownSlot1 > l.ownSlot0) {
         const int perTerm = l.kind == OMMHIP_TERM_HARMONIC_ANGLE ? 3 : (l.kind == OMMHIP_TERM_PERIODIC_TORSION ? 4 : 2);
-        bool any = false;
+        bool any = false, all = true, handedUp = true;
         for (int k = 0; k < perTerm; k++) {
             const int slot = a.slotOfAtom[l.atoms[(size_t) t * perTerm + k]];
             const bool own = slot >= l.ownSlot0 && slot < l.ownSlot1;
             any = any || own;
             if (k == 0) countEnergy = own;
+            if (l.halfShell) {
+                const bool visible = own || (slot >= l.evalSlot0 && slot < l.evalSlot1);
+                all = all && visible;
+                // could the upper neighbour evaluate the term?  It holds my up section and its own atoms.
+                if (own) handedUp = handedUp && slot >= l.upSlot0 && slot < l.upSlot1;
+                else if (!visible) handedUp = handedUp && slot / l.slotsPerRank == (l.rank + 1) % l.ranks;
+                else handedUp = false;                       // an atom of the lower neighbour in a term that also leaves my sight: three slabs
+            }
         }
         evaluate = any;
+        if (l.halfShell) {
+            evaluate = any && all;
+            countEnergy = evaluate;
+            if (any && !all && !handedUp && l.errorFlags != nullptr) atomicOr(&l.errorFlags[1], 8);
+        }
     }
     if (evaluate) {
         const TermCtx c(a, l);
@@ -363,6 +378,9 @@ static int make_term_args(TermArgs& a, int num_lists, const ommhip_term_batch* l
         if (lists[i].kind < OMMHIP_TERM_EXCEPTION14 || lists[i].kind > OMMHIP_TERM_DISPERSION_EXCLUSION) return -1;
         TermList& l = a.list[a.numLists++];
         l.kind = lists[i].kind; l.numTerms = lists[i].terms.num_terms; l.periodic = lists[i].periodic; l.firstBlock = blocks; l.ownSlot0 = lists[i].own_slot0; l.ownSlot1 = lists[i].own_slot1;
+        l.halfShell = lists[i].half_shell != 0 && lists[i].own_slot1 > lists[i].own_slot0 && lists[i].slots_per_rank > 0 && lists[i].ranks > 1 ? 1 : 0;
+        l.evalSlot0 = lists[i].eval_slot0; l.evalSlot1 = lists[i].eval_slot1; l.upSlot0 = lists[i].up_slot0; l.upSlot1 = lists[i].up_slot1;
+        l.rank = lists[i].rank; l.ranks = lists[i].ranks; l.slotsPerRank = lists[i].slots_per_rank; l.errorFlags = lists[i].error_flags;
         l.alpha = lists[i].alpha; l.atoms = lists[i].terms.atoms; l.params = lists[i].terms.params; l.charge = lists[i].charge;
         blocks += (l.numTerms + 255) / 256;
     }

@@ -101,6 +101,14 @@ int stage_up(void* dst_d, const char* src, size_t bytes, hipStream_t st) {
     return (int) hipStreamSynchronize(st);
 }
 
+// forces a neighbour computed on this rank's atoms (ommhip_comm_halo_return): component-major staging -> the SoA force buffer
+__global__ void k_add_returned(long long* force, int paddedSlots, int first, int count, const long long* staging) {
+    const size_t g = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= 3 * (size_t) count) return;
+    const size_t k = g / count, s = g % count;
+    force[k * paddedSlots + first + s] += staging[g];
+}
+
 }  // namespace
 
 extern "C" {
@@ -337,6 +345,50 @@ int ommhip_comm_halo_exchange(ommhip_comm* c, void* buffer_d, const ommhip_halo_
     for (int p = 0; p < c->size && rc == 0 && plan->trailer_bytes > 0; p++)
         if (p != me) rc = stage_up(buf + (size_t) p * plan->rank_stride + plan->trailer_offset, c->hostRecv.data() + (size_t) p * rec + maxDown + maxUp, plan->trailer_bytes, st);
     return rc;
+}
+
+int ommhip_comm_halo_return(ommhip_comm* c, long long* force_d, int padded_slots, const ommhip_halo_return_plan* plan, long long* staging_d, void* stream) {
+    if (c->size > OMMHIP_MAX_RANKS) return 1;
+    if (c->size == 1) return 0;
+    hipStream_t st = (hipStream_t) stream;
+    const int me = c->rank, down = (me + c->size - 1) % c->size, up = (me + 1) % c->size;
+    const int sendFirst = plan->first_slot[down], sendCount = plan->num_slots[down], recvFirst = plan->first_slot[me], recvCount = plan->num_slots[me];
+    if (sendFirst < 0 || recvFirst < 0 || sendFirst + sendCount > padded_slots || recvFirst + recvCount > padded_slots) return 1;
+    bool received = false;
+#ifndef OMMHIP_EMU
+    if (c->rccl) {
+        RcclApi& api = rccl_api();
+        ncclComm_t nc = (ncclComm_t) c->nccl;
+        NCCL_TRY(api.groupStart());
+        // (two ranks: `down` and `up` are the same peer -- its sends and this rank's receives are matched in the order of issue, component by component)
+        for (int k = 0; k < 3; k++) {
+            if (sendCount > 0) NCCL_TRY(api.send(force_d + (size_t) k * padded_slots + sendFirst, sizeof(long long) * (size_t) sendCount, ncclChar, down, nc, st));
+            if (recvCount > 0) NCCL_TRY(api.recv(staging_d + (size_t) k * recvCount, sizeof(long long) * (size_t) recvCount, ncclChar, up, nc, st));
+        }
+        NCCL_TRY(api.groupEnd());
+        received = true;
+    }
+#endif
+    if (!received) {
+        // host transport: every rank contributes one record of 3 x (largest section) elements; a rank keeps its upper neighbour's
+        CommDiag diag;
+        int maxCount = 0;
+        for (int r = 0; r < c->size; r++) if (plan->num_slots[r] > maxCount) maxCount = plan->num_slots[r];
+        const size_t part = sizeof(long long) * (size_t) maxCount, rec = 3 * part;
+        if (rec == 0) return 0;
+        if (c->hostSend.size() < rec) c->hostSend.resize(rec);
+        int rc = 0;
+        for (int k = 0; k < 3 && rc == 0 && sendCount > 0; k++)
+            rc = stage_down(c, force_d + (size_t) k * padded_slots + sendFirst, sizeof(long long) * (size_t) sendCount, (size_t) k * part, st);
+        if (rc != 0) return rc;
+        c->hostRecv.resize((size_t) c->size * rec);
+        if (c->fn(c->user, c->hostSend.data(), c->hostRecv.data(), rec) != 0) return 1;
+        for (int k = 0; k < 3 && rc == 0 && recvCount > 0; k++)
+            rc = stage_up(staging_d + (size_t) k * recvCount, c->hostRecv.data() + (size_t) up * rec + (size_t) k * part, sizeof(long long) * (size_t) recvCount, st);
+        if (rc != 0) return rc;
+    }
+    if (recvCount > 0) hipLaunchKernelGGL(k_add_returned, dim3((unsigned) ((3 * (size_t) recvCount + 255) / 256)), dim3(256), 0, st, force_d, padded_slots, recvFirst, recvCount, staging_d);
+    return (int) hipGetLastError();
 }
 
 int ommhip_comm_all_gather_host(ommhip_comm* c, const void* send, void* recv, size_t bytes, void* stream) {

@@ -53,6 +53,7 @@ struct NlArgs {
     int numAtoms, paddedAtoms, numBlocks, maxChunks;
     int firstBlock, ownedBlocks;      // the list is built for the i-blocks [firstBlock, firstBlock + ownedBlocks)
     int ddMode;                       // domain decomposition: partners are Y >= X plus the foreign blocks below firstBlock
+    int ddHalfShell, evalBlock0, evalBlock1;   // ... or (half-shell evaluation): own blocks Y >= X plus the blocks [evalBlock0, evalBlock1) of the lower neighbour's section
     const uint4* posWire;             // DD: all positions as fixed-point box fractions, slot order (the all-gathered buffer)
     double4* posScatter;              // DD: atom-ordered positions, refreshed for foreign slots by nl_prepare
     long long* trace;                 // profiling (OPENMM_HIP_NL_TRACE): per workgroup start / end clock of a rebuild
@@ -302,6 +303,17 @@ struct NlShared {
 };
 
 // X = i-block of this workgroup, numWorkgroups = number of builder workgroups of the launch (for the hand-over at the end)
+// May block Y be a partner of the owned block X?  One GPU: Y >= X (every block pair once).  Decomposed, pairs across a slab boundary on
+// both sides: also the foreign blocks below the own range (those above are Y >= X).  Half-shell: own blocks Y >= X and the blocks of the lower
+// neighbour's section only -- the pairs with the upper neighbour's atoms are that rank's, whatever of its blocks this rank holds for spreading.
+__device__ __forceinline__ bool partner_allowed(const NlArgs& a, int X, int Y) {
+    if (a.ddHalfShell) {
+        const bool own = Y >= a.firstBlock && Y < a.firstBlock + a.ownedBlocks;
+        return own ? Y >= X : (Y >= a.evalBlock0 && Y < a.evalBlock1);
+    }
+    return Y >= X || (a.ddMode && Y < a.firstBlock);
+}
+
 template <int PBC>
 __device__ __forceinline__ void nl_build_body(const NlArgs& a, const int X, const int numWorkgroups, NlShared& sh) {
     int* const listJ = sh.listJ;
@@ -450,7 +462,7 @@ __device__ __forceinline__ void nl_build_body(const NlArgs& a, const int X, cons
             dx = fmaxf(0.f, fabsf(dx) - hX.x - hY.x);
             dy = fmaxf(0.f, fabsf(dy) - hX.y - hY.y);
             dz = fmaxf(0.f, fabsf(dz) - hX.z - hY.z);
-            if ((Y >= X || (a.ddMode && Y < a.firstBlock)) && !(dx * dx + dy * dy + dz * dz >= R2)) {
+            if (partner_allowed(a, X, Y) && !(dx * dx + dy * dy + dz * dz >= R2)) {
                 const int pos = atomicAdd(&sCandCount, 1);
                 if (pos < NL_CAND) candY[pos] = Y; else sCandOverflow = 1;
             }
@@ -516,7 +528,7 @@ __device__ __forceinline__ void nl_build_body(const NlArgs& a, const int X, cons
         const int numBig = __float_as_int(a.cellMeta[3]);
         for (int i = t; i < numBig; i += NL_THREADS) {
             const int Y = a.cellBlocks[a.numBlocks + i];
-            if ((Y >= X || (a.ddMode && Y < a.firstBlock)) && blockTest(Y)) {
+            if (partner_allowed(a, X, Y) && blockTest(Y)) {
                 const int pos = atomicAdd(&sCandCount, 1);
                 if (pos < NL_CAND) candY[pos] = Y; else sCandOverflow = 1;
             }
@@ -536,7 +548,7 @@ __device__ __forceinline__ void nl_build_body(const NlArgs& a, const int X, cons
         if (!cellDone) {
             for (int yb = window + wave * 64; yb < windowEnd; yb += NL_THREADS) {
                 const int Y = yb + lane;
-                appendCandidates(Y < windowEnd && blockTest(Y), Y);
+                appendCandidates(Y < windowEnd && (!a.ddHalfShell || partner_allowed(a, X, Y)) && blockTest(Y), Y);
             }
         }
         __syncthreads();
@@ -1055,6 +1067,7 @@ NlArgs make_nl_args(const ommhip_neighbor_list* nl) {
     a.firstBlock = 0; a.ownedBlocks = a.numBlocks;
     if (nl->owned_blocks > 0 && nl->first_block >= 0 && nl->first_block + nl->owned_blocks <= a.numBlocks) { a.firstBlock = nl->first_block; a.ownedBlocks = nl->owned_blocks; }
     a.ddMode = nl->dd_mode != 0 && a.ownedBlocks < a.numBlocks ? 1 : 0;
+    a.ddHalfShell = a.ddMode && nl->dd_half_shell != 0 ? 1 : 0; a.evalBlock0 = nl->dd_eval_slot0 / OMM_TILE; a.evalBlock1 = nl->dd_eval_slot1 / OMM_TILE;
     a.posWire = (const uint4*) nl->pos_wire; a.posScatter = (double4*) nl->pos_scatter; a.trace = nullptr;
     { static const bool nlXcd = getenv("OPENMM_HIP_NL_XCD") != nullptr; a.xcdAware = nlXcd ? 1 : 0; }          // opt-in: measured +0.7 % step time at 1M atoms (docs/EXPERIMENTS.md)
     a.numActive = 0; a.activeTotal = a.paddedAtoms;

@@ -37,6 +37,7 @@ struct NbArgs {
     int xcdAware;             // XCD-aware placement of the work units (ChunkSchedule)
     int ljHeadSplit;          // use the split loops for i-blocks whose atoms from OMM_LJ_HEAD on have epsilon = 0
     int ownSlot0, ownSlot1;   // domain decomposition: forces on j atoms outside [ownSlot0, ownSlot1) are dropped (their owner evaluates the pair too)
+    int keepSlot0, keepSlot1; // ... unless they lie in [keepSlot0, keepSlot1): half-shell evaluation, the lower neighbour's section -- force and energy of the pair are this rank's to compute
     float cutoff2, alpha, krf, crf, switchDist, invSwitchWidth;
     // Cutoff edge (posqLo != null): a pair is "inside" for the packed loops when r^2 < cutoff2 = rc^2 (1 + d), which includes every
     // pair whose float separation could be the rounding of a double-precision separation inside the cutoff; pairs in the band
@@ -502,7 +503,7 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
                 const float2 seLane = OMM_I_FROM_LANES ? ia.seLane : a.sigEps[X * OMM_TILE + (lane & (OMM_TILE - 1))];
                 fix_edge_pairs<METHOD, PBC, ENERGY>(a, iLane, seLane, X, j, pj, cX, cY, sej, qjK, m, PBC == 1 && single, fjx, fjy, fjz, energy);
             }
-            const bool jOwned = j >= a.ownSlot0 && j < a.ownSlot1;
+            const bool jOwned = (j >= a.ownSlot0 && j < a.ownSlot1) || (j >= a.keepSlot0 && j < a.keepSlot1);
             if (!(a.debugFlags & 1)) { if (jOwned) add_force(a.force, a.paddedAtoms, j, fjx, fjy, fjz); }
             else if (fjx == 12345.f) a.force[0] = 1;           // profiling knob: keep the arithmetic alive without the atomics
             if (ENERGY) {
@@ -611,7 +612,11 @@ static NbArgs make_nb_args(const ommhip_neighbor_list* nl, const ommhip_nonbonde
     static const bool ljHeadSplit = getenv("OPENMM_HIP_NO_LJ_SPLIT") == nullptr;            // A/B knob
     a.ljHeadSplit = ljHeadSplit ? 1 : 0;
     a.ownSlot0 = 0; a.ownSlot1 = nl->padded_atoms;
-    if (nl->dd_mode != 0 && nl->owned_blocks > 0) { a.ownSlot0 = nl->first_block * OMM_TILE; a.ownSlot1 = (nl->first_block + nl->owned_blocks) * OMM_TILE; }
+    a.keepSlot0 = a.keepSlot1 = 0;
+    if (nl->dd_mode != 0 && nl->owned_blocks > 0) {
+        a.ownSlot0 = nl->first_block * OMM_TILE; a.ownSlot1 = (nl->first_block + nl->owned_blocks) * OMM_TILE;
+        if (nl->dd_half_shell != 0) { a.keepSlot0 = nl->dd_eval_slot0; a.keepSlot1 = nl->dd_eval_slot1; }
+    }
     a.cutoff2 = nl->cutoff > 0 ? (float) (nl->cutoff * nl->cutoff) : INFINITY;
     a.cutoff2Lo = a.cutoff2; a.cutoff2d = nl->cutoff > 0 ? nl->cutoff * nl->cutoff : INFINITY;
     a.posqLo = (const float4*) nl->posq_rel_lo;

@@ -58,6 +58,24 @@ void parallelFor(int n, int threads, const F& body) {          // body(begin, en
     }
     for (size_t t = 0; t < pool.size(); t++) pool[t].join();
 }
+/* `count` independent tasks (the slabs of a decomposed order) on up to `threads` threads; an exception of a task is rethrown by the caller's thread. */
+template <class F>
+void parallelTasks(int count, int threads, const F& task) {          // task(index)
+    if (threads <= 1 || count <= 1) { for (int i = 0; i < count; i++) task(i); return; }
+    std::vector<std::thread> pool;
+    std::vector<std::string> errors(count);
+    std::vector<char> failed(count, 0);
+    const int workers = std::min(threads, count);
+    for (int t = 0; t < workers; t++)
+        pool.push_back(std::thread([&, t]() {
+            for (int i = t; i < count; i += workers) {
+                try { task(i); } catch (const std::exception& e) { failed[i] = 1; errors[i] = e.what(); }
+            }
+        }));
+    for (size_t t = 0; t < pool.size(); t++) pool[t].join();
+    for (int i = 0; i < count; i++)
+        if (failed[i]) throw OpenMMException(errors[i]);
+}
 /* Stable LSD radix sort of (key, value) pairs on the low `bits` bits of the key, 11 bits per pass. */
 void radixSortPairs(std::vector<std::pair<unsigned long long, int> >& v, int bits) {
     std::vector<std::pair<unsigned long long, int> > tmp(v.size());
@@ -344,7 +362,14 @@ void HipContext::flushTerms() {
 void HipContext::stampOwnership(ommhip_term_batch& batch) const {
     // halo mode: a rank evaluates the terms that touch its atoms and counts the energy of those whose first atom it owns (bonded.hip)
     batch.own_slot0 = batch.own_slot1 = 0;
+    batch.half_shell = 0; batch.eval_slot0 = batch.eval_slot1 = batch.up_slot0 = batch.up_slot1 = 0; batch.rank = domain.rank; batch.ranks = domain.ranks; batch.slots_per_rank = slotsPerRank;
+    batch.error_flags = NULL;
     if (haloMode) { batch.own_slot0 = ownSlot0; batch.own_slot1 = ownSlot1; }
+    if (haloMode && halfShell) {
+        // one rank evaluates a term that crosses a slab boundary -- the upper one, which sees the lower one's section -- and returns the forces
+        batch.half_shell = 1; batch.eval_slot0 = evalRange[0]; batch.eval_slot1 = evalRange[1]; batch.up_slot0 = returnRange[0]; batch.up_slot1 = returnRange[1];
+        batch.error_flags = ddFlags.as<int>();
+    }
 }
 
 bool HipContext::countsTermEnergy() const { return !decomposed() || haloMode || domain.rank == 0; }
@@ -446,6 +471,11 @@ void HipContext::exchangePositions() {
     else HIP_CHECK(ommhip_comm_all_gather(domain.comm, posWire.ptr, sizeof(unsigned) * 4 * (size_t) slotsPerRank, stream));
 }
 
+void HipContext::returnHaloForces() {
+    if (!halfShell) return;
+    HIP_CHECK(ommhip_comm_halo_return(domain.comm, force.as<long long>(), paddedAtoms, &returnPlan, returnStaging.as<long long>(), stream));
+}
+
 unsigned HipContext::ddWarnFraction() const {
     // the re-sort is requested at this part of the margin; what is left of it must outlast the (at most 12) steps until every rank has
     // seen the flag plus the reorderLag steps until the new order applies: 0.3 nm for 0.28 ps at the defaults, where a water molecule
@@ -464,6 +494,8 @@ void HipContext::pollDriftFlags() {
     }
     else if ((n & 7) == 4) {
         HIP_CHECK(ommhip_event_sync(ddFlagsEvent));          // recorded four evaluations ago: long complete
+        if ((pinnedDdFlags[2] & 8) != 0)
+            throw OpenMMException("HIP platform: a bonded term (or an exclusion / 1-4 pair) reaches across more than the halo of the domain decomposition: no rank holds all of its atoms");
         if ((pinnedDdFlags[2] & 4) != 0) {
             // the hard limit travels in the trailers like the warning levels: every rank finds it at the same evaluation and throws here,
             // none is left waiting in a collective ([0]: it was one of this rank's atoms; [3]: the largest drift this rank saw)
@@ -476,7 +508,7 @@ void HipContext::pollDriftFlags() {
         // every rank reads the same word at the same evaluation: they re-sort together -- off the step while the margin lasts, at once
         // (the next step waits for it) when an atom has used 80 % of it: a hot system, e.g. a lattice start that melts
         if ((pinnedDdFlags[2] & 2) != 0) reorderRequested = true;
-        else if (pinnedDdFlags[2] != 0) reorderDue = true;
+        else if ((pinnedDdFlags[2] & 3) != 0) reorderDue = true;
     }
 }
 
@@ -536,18 +568,23 @@ void HipContext::partitionBlocks(vector<int>& atomOfSlotLike) const {
     if (blockTailAtom.empty()) return;
     static const bool off = getenv("OPENMM_HIP_NO_LJ_PARTITION") != NULL;        // A/B knob
     if (off) return;
-    int tmp[OMMHIP_TILE];
-    for (size_t b = 0; b < atomOfSlotLike.size(); b += OMMHIP_TILE) {
-        const int n = (int) min((size_t) OMMHIP_TILE, atomOfSlotLike.size() - b);
-        int k = 0;
-        for (int pass = 0; pass < 3; pass++)
-            for (int i = 0; i < n; i++) {
-                const int atom = atomOfSlotLike[b + i];
-                const int cls = atom < 0 ? 2 : (blockTailAtom[atom] ? 1 : 0);
-                if (cls == pass) tmp[k++] = atom;
-            }
-        for (int i = 0; i < n; i++) atomOfSlotLike[b + i] = tmp[i];
-    }
+    const int numBlocks = (int) ((atomOfSlotLike.size() + OMMHIP_TILE - 1) / OMMHIP_TILE);
+    // (the blocks are independent; parallelFor splits ranges of at least 50 000 items, so the range is given in slots and cut at block boundaries)
+    parallelFor(numBlocks * OMMHIP_TILE, hostThreads(domain.ranks), [&](int begin, int end) {
+        int tmp[OMMHIP_TILE];
+        const size_t first = (size_t) (begin + OMMHIP_TILE - 1) / OMMHIP_TILE * OMMHIP_TILE, last = min(atomOfSlotLike.size(), (size_t) (end + OMMHIP_TILE - 1) / OMMHIP_TILE * OMMHIP_TILE);
+        for (size_t b = first; b < last; b += OMMHIP_TILE) {
+            const int n = (int) min((size_t) OMMHIP_TILE, atomOfSlotLike.size() - b);
+            int k = 0;
+            for (int pass = 0; pass < 3; pass++)
+                for (int i = 0; i < n; i++) {
+                    const int atom = atomOfSlotLike[b + i];
+                    const int cls = atom < 0 ? 2 : (blockTailAtom[atom] ? 1 : 0);
+                    if (cls == pass) tmp[k++] = atom;
+                }
+            for (int i = 0; i < n; i++) atomOfSlotLike[b + i] = tmp[i];
+        }
+    });
     static const bool diag = getenv("OPENMM_HIP_DIAG_BLOCKS") != NULL;          // diagnostics: blocks by their number of head (non-tail) atoms
     if (diag) {
         int hist[OMMHIP_TILE + 1] = {0};
@@ -629,9 +666,21 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
         throw OpenMMException("HIP platform: multi-GPU runs need a rectangular periodic box");
     const int R = domain.ranks, numUnits = (int) unitStart.size() - 1;
     const double L[3] = {box[0], box[2], box[5]};
+    static const bool phaseTiming = getenv("OPENMM_HIP_TIMING") != NULL && getenv("OPENMM_HIP_TIMING")[0] == '2';          // diagnostics: phases of this function on stderr
+    std::chrono::steady_clock::time_point tPhase = std::chrono::steady_clock::now();
+    auto phase = [&](const char* name) {
+        if (!phaseTiming) return;
+        const std::chrono::steady_clock::time_point now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  order phase %-28s %.2f ms\n", name, 1e-3 * std::chrono::duration_cast<std::chrono::microseconds>(now - tPhase).count());
+        tPhase = now;
+    };
     wrapOut.assign(4 * (size_t) numAtoms, 0);
     vector<Vec3> ref(numUnits);                      // wrapped position of the unit's first atom
-    for (int u = 0; u < numUnits; u++) {
+    const int threads = hostThreads(domain.ranks);
+    vector<double> extentOfThread(max(threads, 1) + 1, 0.0);      // largest distance of an atom from the first atom of its unit, per chunk of the loop below
+    parallelFor(numUnits, threads, [&](int begin, int end) {
+      double chunkExtent = 0.0;
+      for (int u = begin; u < end; u++) {
         const int a0 = unitAtomList[unitStart[u]];
         Vec3 p0 = positions[a0];
         for (int k = 0; k < 3; k++) {
@@ -643,19 +692,29 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
         // the other atoms go to the image nearest to the first one, so the unit stays in one piece
         for (int i = unitStart[u] + 1; i < unitStart[u + 1]; i++) {
             const int a = unitAtomList[i];
+            double d2 = 0;
             for (int k = 0; k < 3; k++) {
                 double d = positions[a][k] - positions[a0][k];
                 d -= floor(d / L[k] + 0.5) * L[k];
                 wrapOut[4 * a + k] = (int) floor((positions[a][k] - (p0[k] + d)) / L[k] + 0.5);
+                d2 += d * d;
             }
+            chunkExtent = max(chunkExtent, sqrt(d2));
         }
-    }
+      }
+      // (chunks are numbered by where they begin: parallelFor hands out equal pieces)
+      const int chunk = (numUnits + max(threads, 1) - 1) / max(threads, 1);
+      extentOfThread[min((int) extentOfThread.size() - 1, chunk > 0 ? begin / chunk : 0)] = chunkExtent;
+    });
+    phase("wrap offsets, unit extents");
     // ---- cut along x into R groups of (nearly) equal atom count
     vector<int> byX(numUnits);
     {
         vector<pair<unsigned long long, int> > xs(numUnits);
         const double scale = 4294967295.0 / L[0];
-        for (int u = 0; u < numUnits; u++) xs[u] = make_pair((unsigned long long) (max(0.0, min(L[0], ref[u][0])) * scale), u);
+        parallelFor(numUnits, threads, [&](int begin, int end) {
+            for (int u = begin; u < end; u++) xs[u] = make_pair((unsigned long long) (max(0.0, min(L[0], ref[u][0])) * scale), u);
+        });
         radixSortPairs(xs, 33);                  // 32-bit fixed-point x; ties stay in unit order
         for (int u = 0; u < numUnits; u++) byX[u] = xs[u].second;
     }
@@ -672,41 +731,52 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
         while (g + 1 < R) groupStart[++g] = numUnits;
     }
     // ---- halo mode?  A rank needs the positions of every atom that can come within the list cutoff of one of its own before the
-    //      next re-sort, and of every atom whose PME stencil can reach its planes: everything within T of its slab along x, T =
-    //      list cutoff + the drift allowed to the two atoms + the reach of a unit's atoms from its first one.  With more than two
-    //      ranks that must lie inside the two neighbouring slabs (each at least T wide); the decision is a pure function of the
-    //      gathered positions, so all ranks take it alike.  Otherwise positions stay replicated through the all-gather.
+    //      next re-sort, and of every atom whose PME stencil can reach its planes: everything within Tdn below / Tup above its slab along x
+    //      (computed further down).  With more than two ranks that must lie inside the two neighbouring slabs; the decision is a pure
+    //      function of the gathered positions, so all ranks take it alike.  Otherwise positions stay replicated through the all-gather.
+    phase("cut along x");
     vector<double> bound(R + 1, L[0]);           // slab of group g = [bound[g], bound[g + 1])
     bound[0] = 0.0;
     for (int g = 1; g < R; g++) bound[g] = groupStart[g] < numUnits ? ref[byX[groupStart[g]]][0] : L[0];
     double extent = 0.0;                          // largest distance of an atom from the first atom of its unit (a rigid unit may rotate: any of it can turn into x)
-    for (int u = 0; u < numUnits; u++)
-        for (int i = unitStart[u] + 1; i < unitStart[u + 1]; i++) {
-            double d2 = 0;
-            for (int k = 0; k < 3; k++) {
-                double d = positions[unitAtomList[i]][k] - positions[unitAtomList[unitStart[u]]][k];
-                d -= floor(d / L[k] + 0.5) * L[k];
-                d2 += d * d;
-            }
-            extent = max(extent, sqrt(d2));
-        }
+    for (size_t t = 0; t < extentOfThread.size(); t++) extent = max(extent, extentOfThread[t]);
     extent *= 1.1;                                // constraints hold distances to the first atom; flexible units get a little room
-    // The drift margin: as wide as the narrowest slab allows (the neighbours must hold everything a rank needs), up to haloDriftMax --
-    // the wider it is, the later the early re-sorts set in (one axis of a water molecule's diffusion is 0.07-0.1 nm RMS per ps; at
-    // 0.6 nm even the fastest of a million molecules stays inside until the scheduled re-sort).
+    // The drift margin (how far along x the first atom of a unit may move between two re-sorts): haloDriftMax unless the narrowest slab
+    // leaves less.  Round 3 let it grow to whatever the slabs allowed (0.7 nm on 8 ranks of the 1M-atom box: three slabs' worth of slots
+    // converted per step); now it is an upper limit chosen for the re-sort cadence (the re-sorts are off the step), and the halo is what
+    // the pairs and the PME stencils need.
     double minWidth = L[0];
     for (int g = 0; g < R; g++) minWidth = min(minWidth, bound[g + 1] - bound[g]);
     haloDrift = haloDriftMax;
     if (R > 2) haloDrift = max(0.0, min(haloDriftMax, 0.5 * (0.98 * minWidth - haloReach - extent)));
-    const double T = haloReach + 2.0 * haloDrift + extent;
+    // What a rank must see below / above its slab: the partners of its pairs (list cutoff + the drift of both atoms + a unit's reach) and the
+    // atoms whose PME stencils touch its planes g L / R ... (g + 1) L / R (one atom's drift; the stencil looks forward, so mostly below).
+    const double reachBelow = pmeReachBelow > 0.0 ? pmeReachBelow : pmeReachX, reachAbove = pmeReachAbove > 0.0 ? pmeReachAbove : pmeReachX;
+    const double Tpair = haloReach + 2.0 * haloDrift + extent;
+    double pmeBelow = 0.0, pmeAbove = 0.0;
+    if (reachBelow > 0.0 || reachAbove > 0.0)
+        for (int g = 0; g < R; g++) {
+            pmeBelow = max(pmeBelow, bound[g] - (g * L[0] / R - reachBelow - haloDrift - extent));
+            pmeAbove = max(pmeAbove, ((g + 1) * L[0] / R + reachAbove + haloDrift + extent) - bound[g + 1]);
+        }
     static const bool noHalo = getenv("OPENMM_HIP_DD_REPLICATE") != NULL;          // A/B knob: always replicate positions (round-2 behaviour)
+    static const bool bothSides = getenv("OPENMM_HIP_DD_BOTH_SIDES") != NULL;      // A/B knob: cross-boundary pairs on both sides, symmetric halo (round-3 behaviour)
     bool halo = R > 1 && haloReach > 0.0 && !noHalo && R <= OMMHIP_MAX_RANKS && haloDrift >= haloDriftMin;
-    for (int g = 0; g < R && halo; g++) {
-        if (R > 2 && bound[g + 1] - bound[g] < T) halo = false;
-        // charge spreading: the rank's PME planes +- pmeReachX must lie inside what it sees
-        if (pmeReachX > 0.0 && (g * L[0] / R - pmeReachX - haloDrift - extent < bound[g] - T || (g + 1) * L[0] / R + pmeReachX + haloDrift + extent > bound[g + 1] + T)) halo = false;
-    }
+    // Half-shell: a pair across a boundary is evaluated by the rank above it, which therefore needs Tup of its lower neighbour (pairs and
+    // stencils) and only Tdn of its upper one (stencils).  Needs slabs that hold what their upper neighbour asks for; with two ranks (one
+    // peer on both sides) also boundaries far enough apart that no pair could be claimed across both.
+    double Tup = max(Tpair, pmeBelow), Tdn = max(0.0, pmeAbove);
+    bool half = halo && !bothSides && (R > 2 ? minWidth >= Tup : minWidth >= Tup + max(Tdn, Tpair) + 0.05);
+    if (!half) { Tup = Tdn = max(Tpair, max(pmeBelow, pmeAbove)); }
+    if (halo && R > 2 && minWidth < Tup) halo = false;           // the neighbours do not hold everything a rank needs: positions stay replicated
+    if (!halo) half = false;
     haloMode = halo;
+    halfShell = half;
+    static const bool ddDebug = getenv("OPENMM_HIP_DD_DEBUG") != NULL;           // diagnostics: the decision and what it was made from
+    if (ddDebug && domain.rank == 0)
+        fprintf(stderr, "HIP platform: decomposition over %d ranks: narrowest slab %.3f nm, list reach %.3f, unit extent %.3f, drift margin %.3f (limit %.3f, floor %.3f), pairs need %.3f, "
+                        "stencils need %.3f below / %.3f above -> halo %d, half-shell %d, sections %.3f up / %.3f down\n", R, minWidth, haloReach, extent, haloDrift, haloDriftMax, haloDriftMin,
+                Tpair, pmeBelow, pmeAbove, halo ? 1 : 0, half ? 1 : 0, Tup, Tdn);
     // ---- Hilbert order inside each group (halo mode: inside each of the group's four sections)
     static const double binWidth = getenv("OPENMM_HIP_SORT_BIN") != NULL ? atof(getenv("OPENMM_HIP_SORT_BIN")) : 0.3;
     int maxCells = 1, ncell[3];
@@ -715,11 +785,12 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
     while ((1 << bits) < maxCells) bits++;
     newAtomOfSlot.assign(paddedAtoms, -1);
     ownedUnits.clear();
-    vector<pair<unsigned long long, int> > keyed;
     // sections of every rank's range, in slots relative to its start: down = [0, sectionEnd[1]), up = [sectionEnd[0], sectionEnd[2])
     vector<int> sectionEnd(4 * (size_t) R, 0);
-    for (int g = 0; g < R; g++) {
-        keyed.clear();
+    // (the slabs are independent of each other: one task per slab, each writing its own slot range)
+    parallelTasks(R, threads, [&](int g) {
+        vector<pair<unsigned long long, int> > keyed;
+        keyed.reserve(groupStart[g + 1] - groupStart[g]);
         for (int i = groupStart[g]; i < groupStart[g + 1]; i++) {
             const int u = byX[i];
             unsigned c[3];
@@ -727,7 +798,7 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
             // section: 0 = the rank below needs it, 1 = both neighbours, 2 = the rank above, 3 = nobody (most significant key bits)
             unsigned long long section = 0;
             if (halo) {
-                const bool down = ref[u][0] - bound[g] < T, up = bound[g + 1] - ref[u][0] < T;
+                const bool down = ref[u][0] - bound[g] < Tdn, up = bound[g + 1] - ref[u][0] < Tup;
                 section = down ? (up ? 1 : 0) : (up ? 2 : 3);
             }
             keyed.push_back(make_pair((section << (3 * bits)) | hilbertIndex(c[0], c[1], c[2], bits), u));
@@ -750,7 +821,8 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
             slot = (slot + OMMHIP_TILE - 1) / OMMHIP_TILE * OMMHIP_TILE;
             sectionEnd[4 * g + current++] = min(slot - g * slotsPerRank, slotsPerRank);
         }
-    }
+    });
+    phase("Hilbert order of the slabs");
     numActiveRanges = 0;
     memset(&haloPlan, 0, sizeof(haloPlan));
     if (halo) {
@@ -770,8 +842,34 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
         }
         for (int r = 0; r < 3; r++)
             if (ranges[r][1] > ranges[r][0]) { activeRange[2 * numActiveRanges] = ranges[r][0]; activeRange[2 * numActiveRanges + 1] = ranges[r][1]; numActiveRanges++; }
+        // half-shell: the partners from below, and what comes back from above
+        evalRange[0] = evalRange[1] = returnRange[0] = returnRange[1] = 0;
+        memset(&returnPlan, 0, sizeof(returnPlan));
+        if (halfShell) {
+            evalRange[0] = below * slotsPerRank + sectionEnd[4 * below]; evalRange[1] = below * slotsPerRank + sectionEnd[4 * below + 2];
+            returnRange[0] = me * slotsPerRank + sectionEnd[4 * me]; returnRange[1] = me * slotsPerRank + sectionEnd[4 * me + 2];
+            int largest = 0;
+            for (int g = 0; g < R; g++) {
+                returnPlan.first_slot[g] = g * slotsPerRank + sectionEnd[4 * g]; returnPlan.num_slots[g] = sectionEnd[4 * g + 2] - sectionEnd[4 * g];
+                largest = max(largest, returnPlan.num_slots[g]);
+            }
+            returnStaging.allocate(sizeof(long long) * 3 * (size_t) max(largest, 1));
+        }
     }
+    else { halfShell = false; evalRange[0] = evalRange[1] = returnRange[0] = returnRange[1] = 0; }
     partitionBlocks(newAtomOfSlot);          // a rank's range is a whole number of blocks: no atom changes owner
+    phase("block partition");
+}
+
+double HipContext::timeDecomposedOrder(const vector<Vec3>& positions, int repeats) {
+    double best = 1e30;
+    for (int k = 0; k < repeats; k++) {
+        vector<int> newAtomOfSlot, wrapHost;
+        const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        computeOrderDecomposed(positions, newAtomOfSlot, wrapHost);
+        best = min(best, 1e-3 * std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count());
+    }
+    return best;
 }
 
 void HipContext::takeSnapshot() {

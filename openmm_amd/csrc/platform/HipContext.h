@@ -154,6 +154,8 @@ public:
     void stepTaken();                                           // counts steps towards the next reorder
     void requestReorderSoon() { reorderDue = true; }           // off the step (see reorderIfNeeded); decomposed runs: called on every rank at the same evaluation
 
+    /** Diagnostics (tools/time_resort_host.py): wall time in ms of the host-side order computation of a decomposed run for these positions. */
+    double timeDecomposedOrder(const std::vector<Vec3>& positions, int repeats);
     int getDeviceIndex() const { return deviceIndex; }
     void addListener(HipContextListener* l) { listeners.push_back(l); }
     /** Atoms that should sit at the END of their 32-slot block (e.g. atoms without Lennard-Jones parameters: the pair kernel
@@ -182,6 +184,19 @@ public:
     //      r + 1 needs" are two contiguous (overlapping) runs of slots that travel without packing.
     bool haloMode = false;
     ommhip_halo_plan haloPlan;
+    // ---- half-shell mode (a refinement of halo mode, decided with it): a pair of atoms of two neighbouring slabs is evaluated ONCE, by the
+    //      rank above; that rank keeps the force on the lower rank's atom in its own buffer and hands it back after the force kernels
+    //      (returnHaloForces), so a rank needs its lower neighbour's "up" section for its pairs and only a thin "down" section of its
+    //      upper neighbour (for charge spreading: atoms whose PME stencil reaches its planes).  evalRange = the slots of the lower
+    //      neighbour's up section: partners of this rank's pair list, forces on them kept and returned; returnRange = this rank's own up
+    //      section, for which the upper neighbour returns forces.  Both-sides evaluation (round 3) remains the fallback: two ranks whose
+    //      two boundaries are too close, or OPENMM_HIP_DD_BOTH_SIDES=1.
+    bool halfShell = false;
+    int evalRange[2] = {0, 0}, returnRange[2] = {0, 0};
+    ommhip_halo_return_plan returnPlan;
+    DeviceBuffer returnStaging;                  // long long[3 * slots of the largest up section]: forces on this rank's atoms as its upper neighbour computed them
+    void returnHaloForces();                     // enqueued on the main stream by whoever completes the forces of an evaluation (finishComputation)
+    double pmeReachBelow = 0.0, pmeReachAbove = 0.0;      // how far (nm) below / above its PME planes a rank must see atoms for charge spreading (forward-only stencil: mostly below)
     int numActiveRanges = 0;              // slot ranges this rank has current wire records for (own + received sections); 0 = all
     int activeRange[8];
     double haloReach = 0.0;               // list cutoff (cutoff + padding) of the nonbonded force, nm; 0 = no halo mode

@@ -386,6 +386,7 @@ double HipCalcForcesAndEnergyKernel::finishComputation(ContextImpl& context, boo
     hip.ensureCleared();          // nobody folded the start-of-evaluation clear into a launch of its own
     hip.flushTerms();
     hip.joinPme();
+    if (hip.decomposed()) hip.returnHaloForces();      // half-shell evaluation: what this rank computed on its lower neighbour's atoms goes home (same call order on every rank)
     double energy = 0;
     if (includeEnergy) energy = hip.reduceEnergy();
     if (includeEnergy && !hip.hostMode && !hip.recovering() && !hip.decomposed() && hip.listOverflowSeen && hip.listOverflowSeen()) {
@@ -577,9 +578,35 @@ void HipCalcNonbondedForceKernel::getDomainInfo(long long* out) {
     }
     else { out[3] = hip.paddedAtoms; out[4] = rec * hip.slotsPerRank * (R - 1); out[5] = out[4]; }
     out[6] = hip.reorderCount;
+    out[7] = hip.halfShell ? 1 + (long long) (hip.evalRange[1] - hip.evalRange[0]) : 0;       // 0: pairs across a boundary on both sides; else 1 + the slots of the lower neighbour's section (forces returned)
 }
 
 /* Diagnostics: per i-block cost of the last list build (clock ticks, candidate blocks), as left by nl_find_interactions. */
+/* Diagnostics (tools/time_resort_host.py): host time of the order computation of a decomposed run -- a HipContext of `ranks` ranks over a
+ * communicator that is never used, reach / PME reach as a PME NonbondedForce with a 0.9 nm cutoff on a grid of `nx` planes would set them. */
+static int unusedAllGather(void*, const void*, void*, size_t) { return 1; }
+extern "C" __attribute__((visibility("default"))) double ommhip_plugin_time_decomposed_order(const void* system, const double* xyz, int ranks, int rank, int nx, int repeats, long long* info) {
+    try {
+        const System& sys = *(const System*) system;
+        HipDomain domain;
+        domain.ranks = ranks; domain.rank = rank;
+        if (ommhip_comm_create_callback(unusedAllGather, NULL, rank, ranks, &domain.comm) != 0) return -1.0;
+        HipContext hip(sys, 0, false, domain);
+        hip.usePeriodic = true; hip.sortCutoff = 0.9; hip.haloReach = 0.9 * 1.15;
+        hip.pmeReachX = 6.0 * hip.box[0] / nx; hip.pmeReachBelow = 6.0 * hip.box[0] / nx; hip.pmeReachAbove = 2.0 * hip.box[0] / nx;
+        vector<Vec3> positions(sys.getNumParticles());
+        for (int i = 0; i < sys.getNumParticles(); i++) positions[i] = Vec3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+        const double ms = hip.timeDecomposedOrder(positions, repeats);
+        if (info != NULL) {
+            info[0] = hip.haloMode ? 1 : 0; info[1] = hip.halfShell ? 1 : 0; info[2] = hip.slotsPerRank;
+            long long active = 0;
+            for (int r = 0; r < hip.numActiveRanges; r++) active += hip.activeRange[2 * r + 1] - hip.activeRange[2 * r];
+            info[3] = active; info[4] = hip.evalRange[1] - hip.evalRange[0]; info[5] = (long long) (1e6 * hip.haloDrift);
+        }
+        return ms;
+    } catch (const std::exception& e) { fprintf(stderr, "ommhip_plugin_time_decomposed_order: %s\n", e.what()); return -1.0; }
+}
+
 /* Test hook: the SETTLE partition this platform makes of a System (HipConstraints::findSettleClusters); returns the number of
  * clusters, fills at most `capacity` of them. */
 extern "C" __attribute__((visibility("default"))) int ommhip_plugin_settle_clusters(const void* system, int* atoms, double* dist, int capacity) {
@@ -703,6 +730,7 @@ void HipCalcNonbondedForceKernel::setupPmeDecomposed() {
     pme.dd_ranks = R; pme.dd_rank = hip.domain.rank; pme.dd_halo = ddHalo; pme.comm = hip.domain.comm; pme.dd_error = ddError.as<int>();
     // a rank spreads every atom whose order-5 stencil touches its planes: atoms up to five cells below and one above them
     hip.pmeReachX = max(hip.pmeReachX, 6.0 * hip.box[0] / nx);
+    hip.pmeReachBelow = max(hip.pmeReachBelow, 6.0 * hip.box[0] / nx); hip.pmeReachAbove = max(hip.pmeReachAbove, 2.0 * hip.box[0] / nx);
     etermDirty = true;
 }
 
@@ -738,6 +766,8 @@ double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool
     nl.dd_warn = hip.ddWarnFraction(); nl.dd_max = hip.ddMaxFraction();
     nl.dd_flags = hip.haloMode ? hip.ddFlags.as<int>() : NULL;
     nl.dd_ranks = hip.domain.ranks; nl.dd_slots_per_rank = hip.slotsPerRank; nl.dd_trailer_slot = hip.trailerSlot;
+    // half-shell: the pairs with the lower neighbour's section are evaluated here (forces on its atoms kept, returned in finishComputation)
+    nl.dd_half_shell = hip.haloMode && hip.halfShell ? 1 : 0; nl.dd_eval_slot0 = hip.evalRange[0]; nl.dd_eval_slot1 = hip.evalRange[1];
     hip.pollDriftFlags();
     foldExclusions = numExclusionPairs > 0;
     checkDecomposedFlags();
@@ -839,7 +869,9 @@ int HipCalcNonbondedForceKernel::recoverFromOverflow() {
 void HipCalcNonbondedForceKernel::atomsReordered() { slotParamsDirty = true; forceRebuild = true; }
 void HipCalcNonbondedForceKernel::boxChanged() {
     etermDirty = true; dispersionEtermDirty = true; forceRebuild = true;
-    if (hip.decomposed() && gridSize[0] > 0) hip.pmeReachX = 6.0 * hip.box[0] / gridSize[0];       // see setupPmeDecomposed
+    if (hip.decomposed() && gridSize[0] > 0) {       // see setupPmeDecomposed
+        hip.pmeReachX = 6.0 * hip.box[0] / gridSize[0]; hip.pmeReachBelow = 6.0 * hip.box[0] / gridSize[0]; hip.pmeReachAbove = 2.0 * hip.box[0] / gridSize[0];
+    }
 }
 void HipCalcNonbondedForceKernel::positionsSet() { forceRebuild = true; }
 

@@ -69,13 +69,14 @@ def _handle(p):
 
 def domain_info():
     """Diagnostics of the most recently created decomposed Context (ommhip_plugin_dd_info): [ranks, halo mode, slots per rank,
-    slots converted per step, bytes sent per step, bytes received per step, re-sorts so far]."""
+    slots converted per step, bytes sent per step, bytes received per step, re-sorts so far, half-shell: 0, or 1 + the slots of the
+    lower neighbour's section whose forces this rank computes and returns]."""
     path = next(iter(_loaded_plugins))
     plugin = C.CDLL(path)
     out = (C.c_longlong * 8)()
     if plugin.ommhip_plugin_dd_info(out) != 0:
         raise OpenMMError("no decomposed Context")
-    return [int(v) for v in out[:7]]
+    return [int(v) for v in out[:8]]
 
 
 def load_hip_platform(emulated=False):

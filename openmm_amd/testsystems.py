@@ -310,6 +310,12 @@ def dhfr():
     return w
 
 
+def with_cutoff(w, cutoff):
+    """The same workload with another nonbonded cutoff (tests of the domain decomposition want halos thinner than their small boxes)."""
+    w.cutoff = cutoff
+    return w
+
+
 def small_solvated_chain(seed=3):
     """The same construction at test size: a 150-atom chain (bonds, angles, torsions, 1-4s, X-H clusters) in ~660 waters."""
     return dhfr_like(seed=seed, n_side=9, chain_atoms=150, relaxed=False, L=2.75, n_target=2130, radius=0.9)

@@ -148,6 +148,10 @@ for label, w, grid in (("water, halo", T.water_box(8, seed=5), 24), ("solvated c
             assert DD_INFO[3] < world * DD_INFO[2] and DD_INFO[5] < 16 * DD_INFO[2] * (world - 1), ("the halo should be smaller than the box", DD_INFO)
         if "drift" in label:
             assert DD_INFO[6] >= 2, ("a drift-triggered re-sort was expected", DD_INFO)
+        if "half-shell" in label:
+            assert DD_INFO[7] > 1, ("expected half-shell evaluation with partners from the lower neighbour", DD_INFO)
+        if "both sides" in label:
+            assert DD_INFO[7] == 0, DD_INFO
     if "replicated" in label:
         assert DD_INFO[1] == 0, DD_INFO
     rms = np.sqrt((one0.forces ** 2).sum(1).mean())
@@ -186,7 +190,7 @@ for label, w, grid in (("water, halo", T.water_box(8, seed=5), 24), ("solvated c
     dist.all_gather(both, check)
     assert all(torch.equal(b, both[0]) for b in both), both
     if rank == 0:
-        print(label, "forces", err0, err1, "trajectory", dpos, dvel, flush=True)
+        print(label, "forces", err0, err1, "trajectory", dpos, dvel, "domain", DD_INFO, flush=True)
 if rank == 0:
     print("OK")
 dist.destroy_process_group()
@@ -233,8 +237,23 @@ def test_halo_exchange_with_distinct_sections_on_emulator(tmp_path):
     if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
         pytest.skip("emulated plugin not built (run __graft_entry__.build())")
     env = {"OPENMM_HIP_DD_DRIFT": "0.03"}
-    _run_dd_child(tmp_path, True, None, 4, 29561, env=env, cases='(("water, halo sections", T.water_box(12, seed=5, cutoff=0.5), None),)')
-    _run_dd_child(tmp_path, True, None, 4, 29565, nproc=4, env=env, cases='(("water, halo sections, 4 ranks", T.water_box(12, seed=5, cutoff=0.5), None),)')
+    _run_dd_child(tmp_path, True, None, 4, 29561, env=env, cases='(("water, halo sections, half-shell", T.water_box(12, seed=5, cutoff=0.5), None),)')
+    _run_dd_child(tmp_path, True, None, 4, 29565, nproc=4, env=env, cases='(("water, halo sections, half-shell, 4 ranks", T.water_box(12, seed=5, cutoff=0.5), None),)')
+
+
+def test_half_shell_evaluation_with_force_return_on_emulator(tmp_path):
+    """Half-shell mode: a pair -- and a bonded term -- that crosses a slab boundary is evaluated ONCE, by the rank above
+    the boundary, which holds the lower rank's boundary section and returns the forces it computed on those atoms (ommhip_comm_halo_return);
+    a rank sees only a thin section of its upper neighbour, for charge spreading.  Three ranks and a 150-atom chain (bonds, angles, torsions,
+    1-4s, exclusions, X-H clusters) that lies across both inner boundaries; the same box with the pairs on both sides (the round-3 scheme,
+    OPENMM_HIP_DD_BOTH_SIDES=1) as the control.  Same bar as every decomposed run: forces and trajectory of the single-rank run."""
+    import pytest
+    from conftest import EMU_BUILD
+    if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
+        pytest.skip("emulated plugin not built (run __graft_entry__.build())")
+    chain = 'T.with_cutoff(T.small_solvated_chain(seed=3), 0.4)'
+    _run_dd_child(tmp_path, True, None, 4, 29581, nproc=3, env={"OPENMM_HIP_DD_DRIFT": "0.02"}, cases='(("solvated chain, halo, half-shell", %s, 48),)' % chain)
+    _run_dd_child(tmp_path, True, None, 4, 29585, nproc=3, env={"OPENMM_HIP_DD_DRIFT": "0.02", "OPENMM_HIP_DD_BOTH_SIDES": "1"}, cases='(("solvated chain, halo, both sides", %s, 48),)' % chain)
 
 
 def test_halo_drift_guard_triggers_a_common_resort_on_emulator(tmp_path):

@@ -162,7 +162,8 @@ def kernel_sources_sha():
 def collect_timers(kernels):
     calls, total_ms = C.c_longlong(), C.c_double()
     timers = {}
-    for name, idx in (("nb_direct", 0), ("nl_update", 1), ("pme_spread", 2), ("pme_fft", 3), ("pme_interpolate", 4)):
+    for name, idx in (("nb_direct", 0), ("nl_update", 1), ("pme_spread", 2), ("pme_fft", 3), ("pme_interpolate", 4),
+                      ("pairs_fft_stage0", 5), ("pairs_fft_stage1", 6), ("pairs_fft_stage2", 7)):
         kernels.lib.ommhip_profile_collect(idx, C.byref(calls), C.byref(total_ms))
         timers[name] = {"calls": calls.value, "avg_us": (1e3 * total_ms.value / calls.value) if calls.value else None}
     return timers
@@ -291,10 +292,15 @@ def main():
     if decomposed:
         try:
             di = H.domain_info()
-            out["config"]["parallelism"] = "dd%d (x slabs; %s + 2 all-to-alls + potential planes per step)" % (
-                world, "halo exchange of positions with the two neighbouring slabs" if di[1] else "all-gather of positions")
+            half = len(di) > 7 and di[7] > 0
+            out["config"]["parallelism"] = "dd%d (x slabs; %s + 2 all-to-alls + potential planes%s per step)" % (
+                world, "halo exchange of positions with the two neighbouring slabs" if di[1] else "all-gather of positions",
+                " + forces on the lower neighbour's atoms returned (pairs across a boundary evaluated once)" if half else "")
             out["domain"] = {"exchange": "halo" if di[1] else "all-gather", "slots_per_rank": di[2], "slots_converted_per_step_rank0": di[3],
-                             "position_bytes_sent_per_step_rank0": di[4], "position_bytes_received_per_step_rank0": di[5], "re_sorts": di[6]}
+                             "slots_converted_over_slots_per_rank": round(di[3] / max(1, di[2]), 3),
+                             "position_bytes_sent_per_step_rank0": di[4], "position_bytes_received_per_step_rank0": di[5], "re_sorts": di[6],
+                             "pairs_across_boundaries": "once, by the upper rank (half-shell)" if half else "on both sides",
+                             "force_bytes_returned_per_step_rank0": 24 * (di[7] - 1) if half else 0}
         except Exception as e:
             out["config"]["parallelism"] = "dd%d (x slabs)" % world
             out["domain"] = {"error": str(e)}
@@ -334,6 +340,13 @@ def main():
             if fused:
                 algo_bytes += (real_b + cplx_b) + (2 * cplx_b + cplx_b // 2) + (cplx_b + real_b)
                 kernel_name = "pairs_fft_plane + pairs_fft_lines + pairs_fft_plane (pair kernel riding on the 3 FFT launches)"
+            # avg_us so far: HIP events around the group of launches (the gaps between the three fused launches included).  The launches' own
+            # dispatch timestamps -- start / stop events riding on each launch's packet -- give the kernel time proper: their sum is what the
+            # roofline fraction uses (and what a rocprofv3 kernel trace of the same command shows); the span is reported beside it.
+            span_us = avg_us
+            stage_us = [timers.get("pairs_fft_stage%d" % k, {}).get("avg_us") for k in range(3)]
+            if fused and all(v for v in stage_us):
+                avg_us = sum(stage_us)
             achieved = algo_bytes / (avg_us * 1e-6) / 1e9 if avg_us else None
             # HBM traffic of the same kernel from the PMC passes (rocprofv3 cannot run inside this process; the counters are
             # collected by tools/gpu_pmc2.sh on the same command and committed under profiles/ with the hash of the kernel
@@ -354,6 +367,9 @@ def main():
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5) if achieved else None, "traffic": traffic,
                                "traffic_source": traffic_source,
                                "algorithmic_bytes_per_launch": int(algo_bytes), "avg_kernel_us": round(avg_us, 3) if avg_us else None,
+                               "avg_kernel_us_source": ("sum of the three launches' own dispatch timestamps (hipExtLaunchKernelGGL start / stop events)" if fused and all(v for v in stage_us)
+                                                        else "HIP events around the launch"),
+                               "avg_span_us_including_launch_gaps": round(span_us, 3) if span_us else None,
                                "rows": int(rows), "chunks": int(chunks), "rebuilds": int(stats[5]),
                                "rows_as_built": int(stats[7]),          # before the per-step pruning to the cutoff itself (`rows` is what the pair kernel walks)
                                "pair_evals_per_launch": int(rows) * 64 * 32, "kernel_timers_us": timers, "kernel_sources_sha": sha,

@@ -66,6 +66,9 @@ enum {
     OMMHIP_TIMER_PME_SPREAD = 2,
     OMMHIP_TIMER_PME_FFT = 3,        /* the five FFT passes incl. the fused convolution */
     OMMHIP_TIMER_PME_INTERPOLATE = 4,
+    /* the three launches of ommhip_pairs_with_fft one by one, each from the start / stop timestamps of its own dispatch packet: their sum
+     * is kernel time without the gaps between the launches (timer 0 brackets all three, gaps included); sampled with timer 0 */
+    OMMHIP_TIMER_PAIRS_FFT_STAGE0 = 5, OMMHIP_TIMER_PAIRS_FFT_STAGE1 = 6, OMMHIP_TIMER_PAIRS_FFT_STAGE2 = 7,
     OMMHIP_PROFILE_NUM_TIMERS = 8
 };
 int ommhip_profile_enable(int every);   /* 0 = off; n >= 1 = time every n-th launch of each timer */
@@ -78,6 +81,7 @@ int ommhip_profile_end(int timer, void* stream);
  * events the caller attaches to its first / last kernel (hipExtLaunchKernelGGL stamps them with the kernel's own start / end time);
  * both NULL otherwise.  Used by the fused pair launches, where two event records cost 3 % of a 120 us step. */
 int ommhip_profile_take(int timer, void** start_event, void** stop_event);
+int ommhip_profile_take_if(int timer, int with_timer, void** start_event, void** stop_event);      /* a pair exactly when `with_timer` gave one out last */
 int ommhip_profile_collect(int timer, long long* calls, double* total_ms);   /* blocks until recorded events complete */
 
 /* ------------------------------------------------------------------------------------------
@@ -404,6 +408,11 @@ typedef struct ommhip_term_batch {
     int half_shell, eval_slot0, eval_slot1, up_slot0, up_slot1, rank, ranks, slots_per_rank;
     int* error_flags;
 } ommhip_term_batch;
+/* Test hook: the force reduction of the pair kernel on its own (kernels/nonbonded.hip, transpose_reduce32: gfx950's v_permlane32_swap /
+ * v_permlane16_swap halve two partial sums per instruction).  in_d: float[num_waves * 64 * 32], the 32 partial sums of every lane;
+ * out_d: float[num_waves * 64], lane l of a wave receives the wave-wide total of partial sum l >> 1.  No reference counterpart. */
+int ommhip_test_transpose_reduce(const float* in_d, float* out_d, int num_waves, void* stream);
+
 int ommhip_term_forces_multi(int num_lists, const ommhip_term_batch* lists, const void* pos_d, const int* slot_of_atom_d, int padded_atoms,
                              const double box[6], long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
 int ommhip_term_forces(int kind, const ommhip_term_list* terms, const void* pos_d, const int* slot_of_atom_d, int padded_atoms,

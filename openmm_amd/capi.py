@@ -104,6 +104,7 @@ SIGNATURES = {
     "pme_build_eterm": [C.POINTER(Pme), _P],
     "pme_reciprocal": [C.POINTER(Pme), _P, _I, _P, _P, _I, _I, _P],
     "fft3d_r2c_c2r": [C.POINTER(Pme), _I, _P],
+    "test_transpose_reduce": [_P, _P, _I, _P],
     "nb_direct": [C.POINTER(NeighborList), C.POINTER(NonbondedParams), _P, _P, _P, _I, _I, _P],
 }
 

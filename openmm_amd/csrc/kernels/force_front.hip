@@ -193,8 +193,23 @@ extern "C" int ommhip_pairs_with_fft(const ommhip_neighbor_list* nl, const ommhi
     const FftArgs fft = make_xconv_args(pme, energy_buffer_d, energy_slots, include_energy);
     void* evStart = nullptr; void* evStop = nullptr;
     ommhip_profile_take(OMMHIP_TIMER_NB_DIRECT, &evStart, &evStop);
+    hipEvent_t perLaunchStop = nullptr, bracketStop = nullptr;
+    (void) perLaunchStop; (void) bracketStop;
     for (int stage = 0; stage < 3; stage++) {
-        const hipEvent_t e0 = stage == 0 ? (hipEvent_t) evStart : nullptr, e1 = stage == 2 ? (hipEvent_t) evStop : nullptr;
+        hipEvent_t e0 = stage == 0 ? (hipEvent_t) evStart : nullptr, e1 = stage == 2 ? (hipEvent_t) evStop : nullptr;
+#ifndef OMMHIP_EMU
+        // ... and every launch of a timed call with a pair of its own (hipExtLaunchKernelGGL takes one start and one stop event: the
+        // bracketing pair gets the first start and the last stop from plain records around the loop instead)
+        void* ks = nullptr; void* ke = nullptr;
+        ommhip_profile_take_if(OMMHIP_TIMER_PAIRS_FFT_STAGE0 + stage, OMMHIP_TIMER_NB_DIRECT, &ks, &ke);
+        if (ks != nullptr && ke != nullptr) {
+            if (e0 != nullptr) hipEventRecord(e0, st);
+            e0 = (hipEvent_t) ks;
+            perLaunchStop = (hipEvent_t) ke; bracketStop = e1;
+            e1 = perLaunchStop;
+        }
+        else { perLaunchStop = nullptr; bracketStop = nullptr; }
+#endif
         const PlaneArgs plane = make_plane_args(pme, stage == 0);
         PairsFftStage s;
         s.fftBlocks = stage == 1 ? fft.numOuter * ((fft.numInner + fft.B - 1) / fft.B) : nx;
@@ -207,6 +222,9 @@ extern "C" int ommhip_pairs_with_fft(const ommhip_neighbor_list* nl, const ommhi
         if (use_ewald_poly(nb, nl, p, include_energy)) launch_pairs_fft<9, false>(stage, pairBlocks, st, nb, plane, fft, s, e0, e1);
         else if (p->use_switch) { if (energy) launch_pairs_fft<3, true>(stage, pairBlocks, st, nb, plane, fft, s, e0, e1); else launch_pairs_fft<3, false>(stage, pairBlocks, st, nb, plane, fft, s, e0, e1); }
         else { if (energy) launch_pairs_fft<1, true>(stage, pairBlocks, st, nb, plane, fft, s, e0, e1); else launch_pairs_fft<1, false>(stage, pairBlocks, st, nb, plane, fft, s, e0, e1); }
+#ifndef OMMHIP_EMU
+        if (perLaunchStop != nullptr && bracketStop != nullptr) hipEventRecord(bracketStop, st);
+#endif
     }
     return (int) hipGetLastError();
 }

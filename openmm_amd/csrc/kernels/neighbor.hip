@@ -109,6 +109,14 @@ __device__ __forceinline__ bool active_slot(const NlArgs& a, int g, int& s) {
     }
     return found;
 }
+// ... and the g-th BLOCK of the active ranges (they are whole numbers of blocks): the blocks a decomposed rank has positions for
+__device__ __forceinline__ bool active_block(const NlArgs& a, int g, int& b) {
+    if (a.numActive == 0) { b = g; return g < a.numBlocks; }
+    int s;
+    const bool ok = active_slot(a, g * OMM_TILE, s);
+    b = s / OMM_TILE;
+    return ok;
+}
 
 template <int PBC>
 __device__ __forceinline__ void apply_pbc(float& dx, float& dy, float& dz, const Box& b) {
@@ -223,17 +231,20 @@ __global__ __launch_bounds__(1024) void nl_bin_blocks(NlArgs a) {
     // A handful of blocks have large bounding boxes (stragglers of the spatial sort); binning them would force every
     // block to search as far as the largest of them reaches.  They go to a short list that everybody scans instead.
     float hx = 0.f, hy = 0.f, hz = 0.f;
-    for (int b0 = 0; b0 < a.numBlocks; b0 += 1024 * NL_BIN_BATCH) {
+    // (a decomposed rank in halo mode has positions for its own blocks and its neighbours' sections only: the other blocks are not even looked at)
+    const int numScan = a.numActive == 0 ? a.numBlocks : a.activeTotal / OMM_TILE;
+    for (int b0 = 0; b0 < numScan; b0 += 1024 * NL_BIN_BATCH) {
         float4 h[NL_BIN_BATCH], c[NL_BIN_BATCH];
+        int bb[NL_BIN_BATCH];
 #pragma unroll
         for (int u = 0; u < NL_BIN_BATCH; u++) {
-            const int b = min(b0 + u * 1024 + t, a.numBlocks - 1);
-            h[u] = a.blockHalf[b]; c[u] = a.blockCenter[b];
+            active_block(a, min(b0 + u * 1024 + t, numScan - 1), bb[u]);
+            h[u] = a.blockHalf[bb[u]]; c[u] = a.blockCenter[bb[u]];
         }
 #pragma unroll
         for (int u = 0; u < NL_BIN_BATCH; u++) {
-            const int b = b0 + u * 1024 + t;
-            if (b >= a.numBlocks) continue;
+            const int b = bb[u];
+            if (b0 + u * 1024 + t >= numScan) continue;
             if (h[u].x < 0.f) continue;                  // a block without atoms, or (halo mode) without current positions on this rank
             if (h[u].x > a.bigHalf || h[u].y > a.bigHalf || h[u].z > a.bigHalf) { a.cellBlocks[a.numBlocks + atomicAdd(&numBig, 1)] = b; continue; }
             atomicAdd(&count[cell_of(a, c[u]) + 1], 1);
@@ -265,17 +276,18 @@ __global__ __launch_bounds__(1024) void nl_bin_blocks(NlArgs a) {
     __syncthreads();
     // after the scan count[c + 1] holds the END of cell c, i.e. count[] is the CSR start array (count[0] = 0)
     for (int i = t; i <= ncells; i += 1024) a.cellStart[i] = count[i];
-    for (int b0 = 0; b0 < a.numBlocks; b0 += 1024 * NL_BIN_BATCH) {
+    for (int b0 = 0; b0 < numScan; b0 += 1024 * NL_BIN_BATCH) {
         float4 h[NL_BIN_BATCH], c[NL_BIN_BATCH];
+        int bb[NL_BIN_BATCH];
 #pragma unroll
         for (int u = 0; u < NL_BIN_BATCH; u++) {
-            const int b = min(b0 + u * 1024 + t, a.numBlocks - 1);
-            h[u] = a.blockHalf[b]; c[u] = a.blockCenter[b];
+            active_block(a, min(b0 + u * 1024 + t, numScan - 1), bb[u]);
+            h[u] = a.blockHalf[bb[u]]; c[u] = a.blockCenter[bb[u]];
         }
 #pragma unroll
         for (int u = 0; u < NL_BIN_BATCH; u++) {
-            const int b = b0 + u * 1024 + t;
-            if (b >= a.numBlocks) continue;
+            const int b = bb[u];
+            if (b0 + u * 1024 + t >= numScan) continue;
             if (h[u].x < 0.f || h[u].x > a.bigHalf || h[u].y > a.bigHalf || h[u].z > a.bigHalf) continue;
             const int cell = cell_of(a, c[u]);
             const int pos = count[cell] + atomicAdd(&cursor[cell], 1);

@@ -355,6 +355,17 @@ __device__ __forceinline__ float transpose_reduce32(float (&v)[OMM_TILE], int la
     return v[0] + __shfl_xor(v[0], 1);
 }
 
+// Test hook (ommhip_test_transpose_reduce): one wavefront, lane l starts with the 32 values in[32 l .. 32 l + 32) and ends with the
+// wave-wide total of column l >> 1 -- what the pair kernel does with the forces on its 32 i atoms.  The product build runs the
+// v_permlane32/16_swap form, the CPU emulator its shuffle twin: tests/test_gpu_kernels.py pins the former against plain sums.
+__global__ __launch_bounds__(64) void k_test_transpose_reduce(const float* __restrict__ in, float* __restrict__ out) {
+    const int lane = threadIdx.x;
+    float v[OMM_TILE];
+#pragma unroll
+    for (int k = 0; k < OMM_TILE; k++) v[k] = in[(size_t) blockIdx.x * 64 * OMM_TILE + lane * OMM_TILE + k];
+    out[(size_t) blockIdx.x * 64 + lane] = transpose_reduce32(v, lane);
+}
+
 // A wavefront's work units: of the part [fracLo, fracHi) / 64 of the list (fused launches split the list between several
 // launches; its length is only known on the device), the units first, first + stride, ...
 // xcd >= 0: XCD-aware placement.  Workgroups go to the 8 XCDs round-robin by index and every XCD has an L2 of its own, so
@@ -658,6 +669,12 @@ static NbArgs make_nb_args(const ommhip_neighbor_list* nl, const ommhip_nonbonde
 static bool use_ewald_poly(const NbArgs& a, const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, int include_energy) {
     static const bool off = getenv("OPENMM_HIP_NO_EWALD_POLY") != nullptr;              // A/B knob
     return !off && a.ewPolyScale != 0.f && nl->pbc == 1 && p->ewald && !p->use_switch && !p->ljpme && include_energy == 0;
+}
+
+extern "C" int ommhip_test_transpose_reduce(const float* in_d, float* out_d, int num_waves, void* stream) {
+    if (num_waves <= 0) return 1;
+    hipLaunchKernelGGL(k_test_transpose_reduce, dim3(num_waves), dim3(64), 0, (hipStream_t) stream, in_d, out_d);
+    return (int) hipGetLastError();
 }
 
 extern "C" int ommhip_nb_direct(const ommhip_neighbor_list* nl, const ommhip_nonbonded_params* p, const void* sig_eps,

@@ -91,6 +91,7 @@ struct ProfileTimer {
     long long calls = 0;
     unsigned seq = 0;      // launches seen; every profileEnabled-th one is timed
     bool open = false;
+    bool lastTaken = false;      // did the last ommhip_profile_take of this timer hand out an event pair?
 };
 ProfileTimer timers[OMMHIP_PROFILE_NUM_TIMERS];
 int profileEnabled = 0;
@@ -114,7 +115,8 @@ int ommhip_profile_enable_timers(int every, unsigned mask, int reserve) {
     // (an event pair costs more to create than a small kernel takes: a 20-step timed region should not pay for that)
     profileEnabled = every < 0 ? 0 : every; profileMask = mask;
     for (int i = 0; i < OMMHIP_PROFILE_NUM_TIMERS; i++) {
-        if (((mask >> i) & 1u) == 0) continue;
+        // (the per-launch timers of the fused pair + FFT launches follow timer 0)
+        if (((mask >> i) & 1u) == 0 && !(i >= OMMHIP_TIMER_PAIRS_FFT_STAGE0 && i <= OMMHIP_TIMER_PAIRS_FFT_STAGE2 && (mask & 1u) != 0)) continue;
         while ((int) timers[i].start.size() < reserve) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 1;
@@ -150,10 +152,20 @@ int ommhip_profile_end(int timer, void* stream) {
     return (int) e;
 }
 int ommhip_profile_take(int timer, void** start_event, void** stop_event) {
+    return ommhip_profile_take_if(timer, -1, start_event, stop_event);
+}
+/* with_timer >= 0: no sampling decision of its own -- a pair is handed out exactly when `with_timer` handed one out last (the per-launch
+ * timers of a group of launches follow the timer that brackets the group) */
+int ommhip_profile_take_if(int timer, int with_timer, void** start_event, void** stop_event) {
     *start_event = nullptr; *stop_event = nullptr;
-    if (!profileEnabled || timer < 0 || timer >= OMMHIP_PROFILE_NUM_TIMERS || ((profileMask >> timer) & 1u) == 0) return 0;
+    if (!profileEnabled || timer < 0 || timer >= OMMHIP_PROFILE_NUM_TIMERS) return 0;
+    if (with_timer < 0 && ((profileMask >> timer) & 1u) == 0) return 0;
     ProfileTimer& t = timers[timer];
-    if ((t.seq++ % (unsigned) profileEnabled) != 0) return 0;
+    if (with_timer >= 0) { if (with_timer >= OMMHIP_PROFILE_NUM_TIMERS || !timers[with_timer].lastTaken) return 0; }
+    else {
+        t.lastTaken = (t.seq++ % (unsigned) profileEnabled) == 0;
+        if (!t.lastTaken) return 0;
+    }
     if (t.used == 4096) profile_drain(t);
     if (t.used == t.start.size()) {
         hipEvent_t a, b;

@@ -58,6 +58,61 @@ void parallelFor(int n, int threads, const F& body) {          // body(begin, en
     }
     for (size_t t = 0; t < pool.size(); t++) pool[t].join();
 }
+/* A space-filling curve through an arbitrary W x H x D grid of cells: the generalised Hilbert curve of J. Cerveny ("gilbert",
+ * https://github.com/jakubcerveny/gilbert, BSD-2) -- the grid is split recursively into (nearly) halves whose sub-curves join end to
+ * start, with even-sized pieces preferred so that almost every step goes to a face neighbour (a few diagonal steps when a size is odd;
+ * never a jump).  The classical Hilbert curve needs a cube of 2^b cells per axis; the sections of a slab decomposition are thin plates
+ * (a few cells along x, the whole box along y and z), and a cube's curve clipped to such a plate leaves and re-enters it all the time:
+ * atoms that follow each other in the order then lie a box apart and their 32-atom block gets a box-sized bounding box -- the list
+ * builder's slowest workgroups (one block took as long as the whole launch, profiles/r07f_nl_trace_*.txt).
+ * rankOfCell[(x * H + y) * D + z] = position of the cell along the curve. */
+struct Gilbert {
+    std::vector<int>& rank; int H, D, next;
+    static int sgn(int v) { return v < 0 ? -1 : (v > 0 ? 1 : 0); }
+    static int half(int v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); }          // floor(v / 2)
+    void put(int x, int y, int z) { rank[((size_t) x * H + y) * D + z] = next++; }
+    void walk(int x, int y, int z, int ax, int ay, int az, int bx, int by, int bz, int cx, int cy, int cz) {
+        const int w = std::abs(ax + ay + az), h = std::abs(bx + by + bz), d = std::abs(cx + cy + cz);
+        const int dax = sgn(ax), day = sgn(ay), daz = sgn(az), dbx = sgn(bx), dby = sgn(by), dbz = sgn(bz), dcx = sgn(cx), dcy = sgn(cy), dcz = sgn(cz);
+        if (h == 1 && d == 1) { for (int i = 0; i < w; i++) { put(x, y, z); x += dax; y += day; z += daz; } return; }
+        if (w == 1 && d == 1) { for (int i = 0; i < h; i++) { put(x, y, z); x += dbx; y += dby; z += dbz; } return; }
+        if (w == 1 && h == 1) { for (int i = 0; i < d; i++) { put(x, y, z); x += dcx; y += dcy; z += dcz; } return; }
+        int ax2 = half(ax), ay2 = half(ay), az2 = half(az), bx2 = half(bx), by2 = half(by), bz2 = half(bz), cx2 = half(cx), cy2 = half(cy), cz2 = half(cz);
+        const int w2 = std::abs(ax2 + ay2 + az2), h2 = std::abs(bx2 + by2 + bz2), d2 = std::abs(cx2 + cy2 + cz2);
+        if ((w2 % 2) && w > 2) { ax2 += dax; ay2 += day; az2 += daz; }
+        if ((h2 % 2) && h > 2) { bx2 += dbx; by2 += dby; bz2 += dbz; }
+        if ((d2 % 2) && d > 2) { cx2 += dcx; cy2 += dcy; cz2 += dcz; }
+        if (2 * w > 3 * h && 2 * w > 3 * d) {             // long: split along the major axis only
+            walk(x, y, z, ax2, ay2, az2, bx, by, bz, cx, cy, cz);
+            walk(x + ax2, y + ay2, z + az2, ax - ax2, ay - ay2, az - az2, bx, by, bz, cx, cy, cz);
+        }
+        else if (3 * h > 4 * d) {                         // flat: not split along the third axis
+            walk(x, y, z, bx2, by2, bz2, cx, cy, cz, ax2, ay2, az2);
+            walk(x + bx2, y + by2, z + bz2, ax, ay, az, bx - bx2, by - by2, bz - bz2, cx, cy, cz);
+            walk(x + (ax - dax) + (bx2 - dbx), y + (ay - day) + (by2 - dby), z + (az - daz) + (bz2 - dbz), -bx2, -by2, -bz2, cx, cy, cz, -(ax - ax2), -(ay - ay2), -(az - az2));
+        }
+        else if (3 * d > 4 * h) {                         // ... or along the second
+            walk(x, y, z, cx2, cy2, cz2, ax2, ay2, az2, bx, by, bz);
+            walk(x + cx2, y + cy2, z + cz2, ax, ay, az, bx, by, bz, cx - cx2, cy - cy2, cz - cz2);
+            walk(x + (ax - dax) + (cx2 - dcx), y + (ay - day) + (cy2 - dcy), z + (az - daz) + (cz2 - dcz), -cx2, -cy2, -cz2, -(ax - ax2), -(ay - ay2), -(az - az2), bx, by, bz);
+        }
+        else {                                            // the regular case: five pieces
+            walk(x, y, z, bx2, by2, bz2, cx2, cy2, cz2, ax2, ay2, az2);
+            walk(x + bx2, y + by2, z + bz2, cx, cy, cz, ax2, ay2, az2, bx - bx2, by - by2, bz - bz2);
+            walk(x + (bx2 - dbx) + (cx - dcx), y + (by2 - dby) + (cy - dcy), z + (bz2 - dbz) + (cz - dcz), ax, ay, az, -bx2, -by2, -bz2, -(cx - cx2), -(cy - cy2), -(cz - cz2));
+            walk(x + (ax - dax) + bx2 + (cx - dcx), y + (ay - day) + by2 + (cy - dcy), z + (az - daz) + bz2 + (cz - dcz), -cx, -cy, -cz, -(ax - ax2), -(ay - ay2), -(az - az2), bx - bx2, by - by2, bz - bz2);
+            walk(x + (ax - dax) + (bx2 - dbx), y + (ay - day) + (by2 - dby), z + (az - daz) + (bz2 - dbz), -bx2, -by2, -bz2, cx2, cy2, cz2, -(ax - ax2), -(ay - ay2), -(az - az2));
+        }
+    }
+};
+void gilbertOrder(int W, int H, int D, std::vector<int>& rankOfCell) {
+    rankOfCell.assign((size_t) W * H * D, -1);
+    Gilbert g = {rankOfCell, H, D, 0};
+    if (W >= H && W >= D) g.walk(0, 0, 0, W, 0, 0, 0, H, 0, 0, 0, D);
+    else if (H >= W && H >= D) g.walk(0, 0, 0, 0, H, 0, W, 0, 0, 0, 0, D);
+    else g.walk(0, 0, 0, 0, 0, D, W, 0, 0, 0, H, 0);
+}
+
 /* `count` independent tasks (the slabs of a decomposed order) on up to `threads` threads; an exception of a task is rethrown by the caller's thread. */
 template <class F>
 void parallelTasks(int count, int threads, const F& task) {          // task(index)
@@ -156,6 +211,10 @@ HipContext::HipContext(const System& system, int deviceIndex, bool hostMode, con
     // Off the step a re-sort costs the GPU nothing, and a fresher order means fewer rows: one GPU re-sorts every 250 steps (985 527 atoms
     // 2.155 against 2.175 ms per step at 500 and 2.165 at 125; 92 224 atoms 0.2809 against 0.2833; DHFR unchanged: profiles/r06c_ab_reorder_interval.txt)
     if (getenv("OPENMM_HIP_REORDER_INTERVAL") == NULL && !decomposed()) reorderInterval = 250;
+    // The margin trades halo against re-sorts: the fastest of a million water molecules moves 0.2 nm along x -- the warning level of a 0.4 nm
+    // margin -- within ~60 steps, and every re-sort costs the host 10-20 ms plus the gather of the exact state; a rank of the 8-rank 1M-atom
+    // box would convert 2.0 x its own slots per step instead of 2.4 x and pay for it with a re-sort every 60-75 steps (measured: +0.5 ms per
+    // step in the serialised 8-rank run, profiles/r07c_*).  0.75 nm asks for one every ~300 steps.
     haloDriftMax = getenv("OPENMM_HIP_DD_DRIFT") != NULL ? atof(getenv("OPENMM_HIP_DD_DRIFT")) : 0.75;
     haloDriftMin = min(haloDriftMax, 0.25);          // slabs that leave less than this: positions stay replicated
     haloDrift = haloDriftMax;
@@ -659,6 +718,21 @@ void HipContext::computeOrder(const vector<Vec3>& positions, vector<int>& order,
     partitionBlocks(order);
 }
 
+const vector<int>& HipContext::curveThroughGrid(int W, int H, int D) {
+    const long long key = ((long long) W << 40) | ((long long) H << 20) | (long long) D;
+    {
+        std::lock_guard<std::mutex> lock(curveCacheMutex);
+        map<long long, vector<int> >::const_iterator found = curveCache.find(key);
+        if (found != curveCache.end()) return found->second;
+    }
+    vector<int> rank;
+    gilbertOrder(W, H, D, rank);          // outside the lock: other slabs go on with grids that are there already
+    std::lock_guard<std::mutex> lock(curveCacheMutex);
+    vector<int>& slot = curveCache[key];  // (entries are never removed while a re-sort runs: references stay valid; the cache is trimmed between re-sorts)
+    if (slot.empty()) slot.swap(rank);
+    return slot;
+}
+
 void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<int>& newAtomOfSlot, vector<int>& wrapOut) {
     // Slabs along x with equal numbers of atoms, whole units only; inside a slab the units follow a Hilbert curve, so
     // 32 consecutive slots are a compact group of atoms (the neighbour list's i-blocks) just as on one GPU.
@@ -666,6 +740,7 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
         throw OpenMMException("HIP platform: multi-GPU runs need a rectangular periodic box");
     const int R = domain.ranks, numUnits = (int) unitStart.size() - 1;
     const double L[3] = {box[0], box[2], box[5]};
+    if (curveCache.size() > 96) curveCache.clear();
     static const bool phaseTiming = getenv("OPENMM_HIP_TIMING") != NULL && getenv("OPENMM_HIP_TIMING")[0] == '2';          // diagnostics: phases of this function on stderr
     std::chrono::steady_clock::time_point tPhase = std::chrono::steady_clock::now();
     auto phase = [&](const char* name) {
@@ -777,37 +852,79 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
         fprintf(stderr, "HIP platform: decomposition over %d ranks: narrowest slab %.3f nm, list reach %.3f, unit extent %.3f, drift margin %.3f (limit %.3f, floor %.3f), pairs need %.3f, "
                         "stencils need %.3f below / %.3f above -> halo %d, half-shell %d, sections %.3f up / %.3f down\n", R, minWidth, haloReach, extent, haloDrift, haloDriftMax, haloDriftMin,
                 Tpair, pmeBelow, pmeAbove, halo ? 1 : 0, half ? 1 : 0, Tup, Tdn);
-    // ---- Hilbert order inside each group (halo mode: inside each of the group's four sections)
+    // ---- the order inside each slab: a space-filling curve through each of its (up to four) sections separately -- the generalised Hilbert
+    //      curve through a grid of ~binWidth cells FITTED to the section's extent (a plate: thin along x), see gilbertOrder
     static const double binWidth = getenv("OPENMM_HIP_SORT_BIN") != NULL ? atof(getenv("OPENMM_HIP_SORT_BIN")) : 0.3;
+    static const bool cubeCurve = getenv("OPENMM_HIP_DD_CUBE_CURVE") != NULL;          // A/B knob: the box-wide 2^b cube of round 3 clipped to the sections
     int maxCells = 1, ncell[3];
     for (int k = 0; k < 3; k++) { ncell[k] = max(1, min(1023, (int) floor(L[k] / binWidth) + 1)); maxCells = max(maxCells, ncell[k]); }
     int bits = 1;
     while ((1 << bits) < maxCells) bits++;
+    const int gridY = max(1, min(1023, (int) ceil(L[1] / binWidth))), gridZ = max(1, min(1023, (int) ceil(L[2] / binWidth)));
     newAtomOfSlot.assign(paddedAtoms, -1);
     ownedUnits.clear();
     // sections of every rank's range, in slots relative to its start: down = [0, sectionEnd[1]), up = [sectionEnd[0], sectionEnd[2])
     vector<int> sectionEnd(4 * (size_t) R, 0);
     // (the slabs are independent of each other: one task per slab, each writing its own slot range)
     parallelTasks(R, threads, [&](int g) {
-        vector<pair<unsigned long long, int> > keyed;
-        keyed.reserve(groupStart[g + 1] - groupStart[g]);
-        for (int i = groupStart[g]; i < groupStart[g + 1]; i++) {
-            const int u = byX[i];
-            unsigned c[3];
-            for (int k = 0; k < 3; k++) c[k] = (unsigned) max(0, min(ncell[k] - 1, (int) floor(ref[u][k] / binWidth)));
-            // section: 0 = the rank below needs it, 1 = both neighbours, 2 = the rank above, 3 = nobody (most significant key bits)
-            unsigned long long section = 0;
+        const int first = groupStart[g], count = groupStart[g + 1] - groupStart[g];
+        vector<pair<unsigned long long, int> > keyed(count);
+        // sections: 0 = the rank below needs it, 1 = both neighbours, 2 = the rank above, 3 = nobody (most significant key bits)
+        vector<unsigned char> sectionOf(count, 0);
+        double lo[4] = {1e300, 1e300, 1e300, 1e300}, hi[4] = {-1e300, -1e300, -1e300, -1e300};
+        // A section that comes out as a sliver -- a fraction of a nanometre thick, a few hundred atoms spread over the whole y-z face: its
+        // 32-atom blocks cannot be compact whatever the order -- is merged into its neighbour by asking for a little more than needed
+        // (sending an atom nobody needs is always safe): "nobody" joins "up only", a thin "both" is widened on either side.
+        double TupG = Tup, TdnG = Tdn;
+        if (halo) {
+            const double width = bound[g + 1] - bound[g], thin = 0.6;
+            const double nobody = width - TdnG - TupG;
+            if (nobody > 0.0 && nobody < thin) TupG = width - TdnG;
+            const double both = TdnG + TupG - width;
+            if (both > 0.0 && both < thin && width > thin) { const double grow = 0.5 * (thin - both); TdnG = min(width, TdnG + grow); TupG = min(width, TupG + grow); }
+        }
+        for (int i = 0; i < count; i++) {
+            const int u = byX[first + i];
+            int section = 0;
             if (halo) {
-                const bool down = ref[u][0] - bound[g] < Tdn, up = bound[g + 1] - ref[u][0] < Tup;
+                const bool down = ref[u][0] - bound[g] < TdnG, up = bound[g + 1] - ref[u][0] < TupG;
                 section = down ? (up ? 1 : 0) : (up ? 2 : 3);
             }
-            keyed.push_back(make_pair((section << (3 * bits)) | hilbertIndex(c[0], c[1], c[2], bits), u));
+            sectionOf[i] = (unsigned char) section;
+            lo[section] = min(lo[section], ref[u][0]); hi[section] = max(hi[section], ref[u][0]);
         }
-        radixSortPairs(keyed, 3 * bits + 2);
+        int keyBits = 3 * bits;
+        if (!cubeCurve) {
+            const vector<int>* curve[4] = {NULL, NULL, NULL, NULL};
+            int gridX[4] = {1, 1, 1, 1};
+            double widthX[4] = {1, 1, 1, 1};
+            keyBits = 1;
+            for (int sct = 0; sct < 4; sct++) {
+                if (hi[sct] < lo[sct]) continue;
+                gridX[sct] = max(1, min(1023, (int) ceil((hi[sct] - lo[sct]) / binWidth)));
+                widthX[sct] = max((hi[sct] - lo[sct]) * (1.0 + 1e-9), 1e-9) / gridX[sct];
+                curve[sct] = &curveThroughGrid(gridX[sct], gridY, gridZ);
+                while ((1ull << keyBits) < (unsigned long long) gridX[sct] * gridY * gridZ) keyBits++;
+            }
+            for (int i = 0; i < count; i++) {
+                const int u = byX[first + i], sct = sectionOf[i];
+                const int cx = max(0, min(gridX[sct] - 1, (int) floor((ref[u][0] - lo[sct]) / widthX[sct])));
+                const int cy = max(0, min(gridY - 1, (int) floor(ref[u][1] / L[1] * gridY))), cz = max(0, min(gridZ - 1, (int) floor(ref[u][2] / L[2] * gridZ)));
+                keyed[i] = make_pair(((unsigned long long) sct << keyBits) | (unsigned long long) (*curve[sct])[((size_t) cx * gridY + cy) * gridZ + cz], u);
+            }
+        }
+        else
+            for (int i = 0; i < count; i++) {
+                const int u = byX[first + i];
+                unsigned c[3];
+                for (int k = 0; k < 3; k++) c[k] = (unsigned) max(0, min(ncell[k] - 1, (int) floor(ref[u][k] / binWidth)));
+                keyed[i] = make_pair(((unsigned long long) sectionOf[i] << keyBits) | hilbertIndex(c[0], c[1], c[2], bits), u);
+            }
+        radixSortPairs(keyed, keyBits + 2);
         int slot = g * slotsPerRank, current = 0;
         for (size_t i = 0; i < keyed.size(); i++) {
             const int u = keyed[i].second;
-            const int section = (int) (keyed[i].first >> (3 * bits));
+            const int section = (int) (keyed[i].first >> keyBits);
             while (current < section) {          // a section ends: the next one starts on a block boundary
                 slot = (slot + OMMHIP_TILE - 1) / OMMHIP_TILE * OMMHIP_TILE;
                 sectionEnd[4 * g + current++] = slot - g * slotsPerRank;
@@ -861,13 +978,14 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
     phase("block partition");
 }
 
-double HipContext::timeDecomposedOrder(const vector<Vec3>& positions, int repeats) {
+double HipContext::timeDecomposedOrder(const vector<Vec3>& positions, int repeats, vector<int>* atomOfSlotOut) {
     double best = 1e30;
     for (int k = 0; k < repeats; k++) {
         vector<int> newAtomOfSlot, wrapHost;
         const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
         computeOrderDecomposed(positions, newAtomOfSlot, wrapHost);
         best = min(best, 1e-3 * std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count());
+        if (atomOfSlotOut != NULL) atomOfSlotOut->swap(newAtomOfSlot);
     }
     return best;
 }

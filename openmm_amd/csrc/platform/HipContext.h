@@ -14,6 +14,8 @@
 #include "openmm/Vec3.h"
 #include <cstddef>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -155,7 +157,7 @@ public:
     void requestReorderSoon() { reorderDue = true; }           // off the step (see reorderIfNeeded); decomposed runs: called on every rank at the same evaluation
 
     /** Diagnostics (tools/time_resort_host.py): wall time in ms of the host-side order computation of a decomposed run for these positions. */
-    double timeDecomposedOrder(const std::vector<Vec3>& positions, int repeats);
+    double timeDecomposedOrder(const std::vector<Vec3>& positions, int repeats, std::vector<int>* atomOfSlotOut = NULL);
     int getDeviceIndex() const { return deviceIndex; }
     void addListener(HipContextListener* l) { listeners.push_back(l); }
     /** Atoms that should sit at the END of their 32-slot block (e.g. atoms without Lennard-Jones parameters: the pair kernel
@@ -272,6 +274,11 @@ public:
 private:
     void computeOrder(const std::vector<Vec3>& positions, std::vector<int>& order, std::vector<int>& wrapOut);
     void computeOrderDecomposed(const std::vector<Vec3>& positions, std::vector<int>& newAtomOfSlot, std::vector<int>& wrapOut);
+    /** Position of every cell of a W x H x D grid along the space-filling curve the sections of a slab are ordered by (HipContext.cpp:
+     *  gilbertOrder); kept from re-sort to re-sort -- the same few grid sizes come back.  Safe to call from the threads of one re-sort. */
+    const std::vector<int>& curveThroughGrid(int W, int H, int D);
+    std::map<long long, std::vector<int> > curveCache;
+    std::mutex curveCacheMutex;
     void findUnits(const System& system);
     std::vector<HipContextListener*> listeners;
     std::vector<char> blockTailAtom;

@@ -596,8 +596,33 @@ extern "C" __attribute__((visibility("default"))) double ommhip_plugin_time_deco
         hip.pmeReachX = 6.0 * hip.box[0] / nx; hip.pmeReachBelow = 6.0 * hip.box[0] / nx; hip.pmeReachAbove = 2.0 * hip.box[0] / nx;
         vector<Vec3> positions(sys.getNumParticles());
         for (int i = 0; i < sys.getNumParticles(); i++) positions[i] = Vec3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
-        const double ms = hip.timeDecomposedOrder(positions, repeats);
+        vector<int> atomOfSlot;
+        const double ms = hip.timeDecomposedOrder(positions, repeats, &atomOfSlot);
         if (info != NULL) {
+            // how compact are this rank's 32-slot blocks?  Largest edge of each block's bounding box (minimum image relative to its first atom), in pm
+            vector<long long> edges;
+            for (int b = hip.ownSlot0 / OMMHIP_TILE; b < hip.ownSlot1 / OMMHIP_TILE; b++) {
+                double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+                int first = -1;
+                for (int k = 0; k < OMMHIP_TILE; k++) {
+                    const int atom = atomOfSlot[(size_t) b * OMMHIP_TILE + k];
+                    if (atom < 0) continue;
+                    if (first < 0) first = atom;
+                    for (int c = 0; c < 3; c++) {
+                        const double len = c == 0 ? hip.box[0] : (c == 1 ? hip.box[2] : hip.box[5]);
+                        double d = positions[atom][c] - positions[first][c];
+                        d -= floor(d / len + 0.5) * len;
+                        lo[c] = min(lo[c], d); hi[c] = max(hi[c], d);
+                    }
+                }
+                if (first >= 0) edges.push_back((long long) (1000.0 * max(hi[0] - lo[0], max(hi[1] - lo[1], hi[2] - lo[2]))));
+                if (first >= 0 && getenv("OPENMM_HIP_DD_DEBUG") != NULL && max(hi[0] - lo[0], max(hi[1] - lo[1], hi[2] - lo[2])) > 5.0)
+                    fprintf(stderr, "  big block %d of the rank's %d (sections end at blocks %d %d %d): extent %.2f %.2f %.2f\n", b - hip.ownSlot0 / OMMHIP_TILE, hip.slotsPerRank / OMMHIP_TILE,
+                            (int) (hip.haloPlan.up_offset[rank] / 16 / OMMHIP_TILE), (int) (hip.haloPlan.down_bytes[rank] / 16 / OMMHIP_TILE), (int) ((hip.haloPlan.up_offset[rank] + hip.haloPlan.up_bytes[rank]) / 16 / OMMHIP_TILE),
+                            hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
+            }
+            std::sort(edges.begin(), edges.end());
+            if (!edges.empty()) { info[6] = edges[edges.size() / 2]; info[7] = edges[edges.size() * 99 / 100]; info[8] = edges.back(); info[9] = (long long) edges.size(); }
             info[0] = hip.haloMode ? 1 : 0; info[1] = hip.halfShell ? 1 : 0; info[2] = hip.slotsPerRank;
             long long active = 0;
             for (int r = 0; r < hip.numActiveRanges; r++) active += hip.activeRange[2 * r + 1] - hip.activeRange[2 * r];

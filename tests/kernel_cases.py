@@ -412,3 +412,18 @@ def run_list_completeness(K, n, cutoff, box_lengths, sort_cell, cells, seed=0, p
     true_key = np.minimum(true[:, 0], true[:, 1]) * n + np.maximum(true[:, 0], true[:, 1])
     missing = int((~np.isin(true_key, uniq)).sum())
     return missing, int((counts > 1).sum()), len(true_key), entries, state
+
+
+def run_transpose_reduce(K, waves=7, seed=3):
+    """The pair kernel's force reduction on its own (ommhip_test_transpose_reduce): -> (what the kernel returns, plain float64 column sums).
+    Lane l of a wave must end with the wave-wide total of partial sum l >> 1."""
+    rng = np.random.default_rng(seed)
+    v = rng.normal(size=(waves, 64, 32)).astype(np.float32)
+    v[0] = (np.arange(64)[:, None] * 32 + np.arange(32)[None, :]).astype(np.float32)          # a pattern in which every misrouted element shows
+    d_in = K.upload(v)
+    d_out = K.malloc(4 * waves * 64)
+    K.test_transpose_reduce(d_in, d_out, waves, None)
+    got = K.download(d_out, (waves, 64), np.float32)
+    K.free(d_in); K.free(d_out)
+    expect = v.astype(np.float64).sum(axis=1)[:, np.arange(64) >> 1]
+    return got, expect

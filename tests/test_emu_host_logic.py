@@ -38,6 +38,14 @@ def test_direct_space_kernel_logic(K, n, method, tric, switch):
 
 
 @needs_emu
+def test_transpose_reduce_of_the_pair_kernel_on_the_emulator(K):
+    """transpose_reduce32 with the emulator's shuffle form of swap_add32 / swap_add16 (the GPU suite pins the permlane-swap instructions)."""
+    got, expect = KC.run_transpose_reduce(K)
+    assert np.allclose(got, expect, rtol=2e-6, atol=2e-5)
+    assert np.array_equal(got[0], expect[0].astype(np.float32))
+
+
+@needs_emu
 def test_direct_space_single_image_path(K):
     """Morton-sorted slots + the per-step entry (image-coherent blocks): most chunks take the single-image path."""
     f, e, f_or, e_or, state = KC.run_direct_space(K, 1200, ONB.PME, 0.7, 3.4, EXCL, compact=True)

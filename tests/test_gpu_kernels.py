@@ -181,3 +181,12 @@ def test_pme_spreading_by_grid_tiles(K, kw):
     f, e, f_or, e_or = KC.run_pme(K, 20000, (64, 60, 72), 6.4, sort_cell=0.4, **kw)
     assert np.abs(f - f_or).max() / np.sqrt((f_or ** 2).sum(1).mean()) < 2e-5
     assert abs(e - e_or) < 5e-6 * abs(e_or)
+
+
+def test_permlane_swap_transpose_reduce_against_plain_sums(K):
+    """The force reduction the pair kernel runs on gfx950 -- v_permlane32_swap / v_permlane16_swap halving two partial sums per instruction
+    (kernels/nonbonded.hip: swap_add32, swap_add16, transpose_reduce32) -- against float64 column sums.  The CPU emulator compiles a shuffle
+    twin of the two swap helpers (tests/test_emu_host_logic.py runs the same case on it), so only this test pins the instructions themselves."""
+    got, expect = KC.run_transpose_reduce(K)
+    assert np.allclose(got, expect, rtol=2e-6, atol=2e-5), np.abs(got - expect).max()
+    assert np.array_equal(got[0], expect[0].astype(np.float32))           # integers below 2^24: exact whatever the order of the additions

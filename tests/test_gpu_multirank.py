@@ -31,8 +31,17 @@ def _run(w, props, steps, seed=7):
     return st0, st1, info
 
 
-@pytest.mark.parametrize("n_side,grid", [(10, 32), (24, 0)])
-def test_one_rank_with_rccl_reproduces_the_single_gpu_run(n_side, grid):
+@pytest.mark.parametrize("n_side,grid,replicate", [(10, 32, False), (24, 0, False), (10, 32, True)])
+def test_one_rank_with_rccl_reproduces_the_single_gpu_run(n_side, grid, replicate, monkeypatch):
+    # (replicate: OPENMM_HIP_DD_REPLICATE=1, positions through the in-place all-gather of round 2 instead of the halo exchange -- the knob is
+    #  read once per process, so the case runs in a child)
+    if replicate:
+        import subprocess, sys
+        code = ("import os, sys, pytest; os.environ['OPENMM_HIP_DD_REPLICATE'] = '1'; "
+                "sys.exit(pytest.main(['-q', '-x', '-p', 'no:cacheprovider', '-m', 'gpu', '%s::test_one_rank_with_rccl_reproduces_the_single_gpu_run[10-32-False]']))" % os.path.abspath(__file__))
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.abspath(__file__)))
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        return
     H.load_hip_platform()
     w = T.water_box(n_side, seed=5)
     if grid:
@@ -54,7 +63,7 @@ def test_one_rank_with_rccl_reproduces_the_single_gpu_run(n_side, grid):
 def test_two_ranks_sharing_the_gpu_reproduce_the_single_gpu_run(tmp_path):
     from test_multirank_cpu import _run_dd_child
     out = _run_dd_child(tmp_path, False, 0, 10, 29561, env={"OPENMM_HIP_DD_DRIFT": "0.05"},
-                        extra_cases='(("water, tile spreading", T.water_box(8, seed=5), 32), ("water, halo sections", T.water_box(16, seed=5, cutoff=0.5), None), '
+                        extra_cases='(("water, tile spreading", T.water_box(8, seed=5), 32), ("water, halo sections, half-shell", T.water_box(16, seed=5, cutoff=0.5), None), '
                                     '("water, halo, barostat", T.with_barostat(T.water_box(8, seed=5), 1.0, 300.0, 2, 11), 24))')
     print(out)
 
@@ -75,8 +84,18 @@ def test_two_ranks_over_rccl_on_two_gpus(tmp_path):
     env = {"DD_TEST_TRANSPORT": "rccl", "OPENMM_HIP_DD_DRIFT": "0.05"}
     out = _run_dd_child(tmp_path, False, "rank", 10, 29581, env=env,
                         cases='(("water, halo", T.water_box(8, seed=5), 24), ("solvated chain, halo", T.small_solvated_chain(seed=3), 24), '
-                              '("water, halo sections", T.water_box(16, seed=5, cutoff=0.5), None))')
+                              '("water, halo sections, half-shell", T.water_box(16, seed=5, cutoff=0.5), None))')
     print(out)
+
+
+def test_three_ranks_sharing_the_gpu_half_shell_with_bonded_terms_across_boundaries(tmp_path):
+    """Half-shell evaluation on the GPU: three ranks (sharing it, collectives over gloo), a chain with bonds / angles / torsions / 1-4s /
+    exclusions across both inner slab boundaries -- pairs and terms evaluated once by the upper rank, the forces on the lower rank's atoms
+    returned -- and the round-3 scheme (both sides) as the control; tests/test_multirank_cpu.py runs the same on the emulator."""
+    from test_multirank_cpu import _run_dd_child
+    chain = 'T.with_cutoff(T.small_solvated_chain(seed=3), 0.4)'
+    print(_run_dd_child(tmp_path, False, 0, 6, 29591, nproc=3, env={"OPENMM_HIP_DD_DRIFT": "0.02"}, cases='(("solvated chain, halo, half-shell", %s, 48),)' % chain))
+    print(_run_dd_child(tmp_path, False, 0, 6, 29595, nproc=3, env={"OPENMM_HIP_DD_DRIFT": "0.02", "OPENMM_HIP_DD_BOTH_SIDES": "1"}, cases='(("solvated chain, halo, both sides", %s, 48),)' % chain))
 
 
 GOLDEN_CHILD = r'''
@@ -105,6 +124,9 @@ if rank == 0:
         world, p["max_rel_err_all_atoms"], p["cutoff_edge_pairs"], p["max_rel_err"], st.potentialEnergy, float(g["energy"])), flush=True)
 assert p["max_rel_err_all_atoms"] < 1e-4
 assert info[1] == 1 and info[3] < world * info[2], ("four 5.3 nm slabs: halo exchange expected", info)
+assert info[7] > 1, ("half-shell evaluation expected", info)
+if rank == 0:
+    print("domain:", info, flush=True)
 assert abs(st.potentialEnergy - float(g["energy"])) < 1e-5 * 5.0 * w.num_atoms
 if rank == 0:
     print("OK")

@@ -26,7 +26,8 @@ plugin.ommhip_plugin_time_decomposed_order.restype = C.c_double
 xyz = np.ascontiguousarray(w.positions, dtype=np.float64)
 nx = 64 * tiles
 for rank in (0, ranks // 2):
-    info = (C.c_longlong * 8)()
+    info = (C.c_longlong * 12)()
     ms = plugin.ommhip_plugin_time_decomposed_order(system.h, xyz.ctypes.data_as(C.POINTER(C.c_double)), ranks, rank, nx, repeats, info)
     print("rank %d of %d, %d atoms: order computed in %.1f ms; halo mode %d, half-shell %d, slots per rank %d, converted per step %d (%.2f x), pair partners from below %d, drift margin %.3f nm"
           % (rank, ranks, w.num_atoms, ms, info[0], info[1], info[2], info[3], info[3] / max(1, info[2]), info[4], info[5] * 1e-6))
+    print("    largest bounding-box edge of its %d blocks: median %.2f nm, 99th percentile %.2f nm, largest %.2f nm" % (info[9], info[6] * 1e-3, info[7] * 1e-3, info[8] * 1e-3))

@@ -94,10 +94,11 @@ int ommhip_amoeba_vdw_forces(const ommhip_amoeba_vdw* vdw, const void* pos_d, co
  * also polarize each other: (1/alpha - T) mu = E, solved for both dipole sets by preconditioned conjugate gradients -- each step
  * one induced-dipole field evaluation in real and reciprocal space -- until the Reference's own measure, debye x the RMS of
  * alpha (E + T mu) - mu (AmoebaReferenceMultipoleForce::convergeInduceDipolesByDIIS :939-1005), falls below the target; the energy
- * keeps its form and the force gains the term -1/2 mu_d (dT/dx) mu_p).  The host falls back to the AMOEBA plugin's Reference kernel
- * for everything else (NoCutoff, extrapolated polarization).
+ * keeps its form and the force gains the term -1/2 mu_d (dT/dx) mu_p) or Extrapolated (a fixed number of perturbation orders, see
+ * extrapolation_orders below).  The host falls back to the AMOEBA plugin's Reference kernel for everything else (NoCutoff).
  * ------------------------------------------------------------------------------------------ */
 #define OMMHIP_AMOEBA_MAX_HISTORY 6
+#define OMMHIP_AMOEBA_MAX_EXT_ORDERS 8
 typedef struct ommhip_amoeba_multipole {
     int num_atoms;
     /* per atom, device */
@@ -164,6 +165,13 @@ typedef struct ommhip_amoeba_multipole {
     int* list_state;
     int force_rebuild;
     int* list_builds;
+    /* Extrapolated polarization (mutual = 0, extrapolation_orders = K > 0; AmoebaMultipoleForce::Extrapolated with its K coefficients c_n):
+     * mu_0 = alpha E, mu_(n+1) = alpha T mu_n, induced dipoles = sum_n (sum_(j >= n) c_j) mu_n; K - 1 field evaluations, no iteration.
+     * Needs solver and phi_induced_p as the mutual solver does. */
+    int extrapolation_orders;
+    double ext_coefficients[OMMHIP_AMOEBA_MAX_EXT_ORDERS];
+    double* ext_dipoles;           /* device double[K * 6n]: (mu_d, mu_p) of every order */
+    double* ext_gradients;         /* device double[(K - 1) * 12n]: gradient (xx yy zz xy xz yz) of the field of orders 0 .. K - 2, d set then p set */
     float* solver_gather;          /* device float[6 * S] or NULL (mutual polarization): the solver keeps the vectors whose field it takes as six floats per scan
                                     * position here as well -- the induced-dipole field kernel gathers them from this copy */
     int mixed_precision;           /* 1: the pair arithmetic of ordinary pairs in float (separations formed in double, sums in double; covalently related

@@ -197,7 +197,7 @@ void HipCalcAmoebaVdwForceKernel::copyParametersToContext(ContextImpl& context, 
 }
 
 // ================================================================================================
-// AmoebaMultipoleForce (PME; direct and mutual polarization)
+// AmoebaMultipoleForce (PME; direct, mutual and extrapolated polarization)
 // ================================================================================================
 namespace {
 vector<double> bsplineModuli(int n) {
@@ -258,7 +258,10 @@ HipCalcAmoebaMultipoleForceKernel::~HipCalcAmoebaMultipoleForceKernel() {
 bool HipCalcAmoebaMultipoleForceKernel::supports(const AmoebaMultipoleForce& force, const System& system) {
     if (getenv("OPENMM_HIP_REFERENCE_AMOEBA_MULTIPOLE") != NULL) return false;          // A/B knob: always the Reference kernel
     if (force.getNonbondedMethod() != AmoebaMultipoleForce::PME) return false;
-    if (force.getPolarizationType() != AmoebaMultipoleForce::Direct && force.getPolarizationType() != AmoebaMultipoleForce::Mutual) return false;
+    if (force.getPolarizationType() != AmoebaMultipoleForce::Direct && force.getPolarizationType() != AmoebaMultipoleForce::Mutual &&
+            force.getPolarizationType() != AmoebaMultipoleForce::Extrapolated) return false;
+    if (force.getPolarizationType() == AmoebaMultipoleForce::Extrapolated &&
+            (force.getExtrapolationCoefficients().empty() || force.getExtrapolationCoefficients().size() > OMMHIP_AMOEBA_MAX_EXT_ORDERS || getenv("OPENMM_HIP_REFERENCE_AMOEBA_EXTRAPOLATED") != NULL)) return false;
     double alpha; int nx, ny, nz;
     force.getPMEParameters(alpha, nx, ny, nz);
     if (nx == 0 || alpha == 0.0) {
@@ -315,6 +318,12 @@ void HipCalcAmoebaMultipoleForceKernel::initialize(const System& system, const A
     indD.allocate(sizeof(double) * 3 * n); indP.allocate(sizeof(double) * 3 * n);
     phi.allocate(sizeof(double) * 20 * n); phiInd.allocate(sizeof(double) * 20 * n); torque.allocate(sizeof(double) * 3 * n);
     mutual = force.getPolarizationType() == AmoebaMultipoleForce::Mutual;
+    extrapolated = force.getPolarizationType() == AmoebaMultipoleForce::Extrapolated;
+    if (extrapolated) {
+        const size_t K = force.getExtrapolationCoefficients().size();
+        phiIndP.allocate(sizeof(double) * 20 * n); solver.allocate(sizeof(double) * (24 * n + 16));
+        extDipoles.allocate(sizeof(double) * 6 * n * K); extGradients.allocate(sizeof(double) * 12 * n * max(K - 1, (size_t) 1));
+    }
     if (mutual) {
         phiIndP.allocate(sizeof(double) * 20 * n); solver.allocate(sizeof(double) * (24 * n + 16));
         if (getenv("OPENMM_HIP_AMOEBA_NO_PREDICTOR") == NULL) history.allocate(sizeof(double) * 6 * n * HistorySlots);       // (A/B knob: every solve starts from the direct dipoles)
@@ -386,7 +395,15 @@ void HipCalcAmoebaMultipoleForceKernel::upload(const AmoebaMultipoleForce& force
     // pair arithmetic: float by default ("mixed", what the reference's GPU platforms do in their mixed mode); OPENMM_HIP_AMOEBA_PRECISION=double keeps everything in double
     mp.mixed_precision = getenv("OPENMM_HIP_AMOEBA_PRECISION") != NULL && string(getenv("OPENMM_HIP_AMOEBA_PRECISION")) == "double" ? 0 : 1;
     mp.max_iterations = force.getMutualInducedMaxIterations(); mp.target_epsilon = force.getMutualInducedTargetEpsilon();
-    mp.phi_induced_p = mutual ? phiIndP.as<double>() : NULL; mp.solver = mutual ? solver.as<double>() : NULL; mp.status = solverStatus;
+    mp.phi_induced_p = mutual || extrapolated ? phiIndP.as<double>() : NULL; mp.solver = mutual || extrapolated ? solver.as<double>() : NULL; mp.status = solverStatus;
+    mp.extrapolation_orders = 0; mp.ext_dipoles = NULL; mp.ext_gradients = NULL;
+    for (int k = 0; k < OMMHIP_AMOEBA_MAX_EXT_ORDERS; k++) mp.ext_coefficients[k] = 0.0;
+    if (extrapolated) {
+        const vector<double>& c = force.getExtrapolationCoefficients();
+        mp.extrapolation_orders = (int) c.size();
+        for (size_t k = 0; k < c.size(); k++) mp.ext_coefficients[k] = c[k];
+        mp.ext_dipoles = extDipoles.as<double>(); mp.ext_gradients = extGradients.as<double>();
+    }
     mp.solver_gather = NULL;
     if (mutual && getenv("OPENMM_HIP_AMOEBA_NO_GATHER_COPY") == NULL) {        // (A/B knob: the field kernel gathers the atom-ordered doubles)
         solverGather.allocate(sizeof(float) * 6 * (size_t) hip.paddedAtoms);

@@ -42,15 +42,15 @@ private:
     DeviceBuffer parent, reduction, type, sigma, epsilon, exclStart, exclAtoms, alchemical, reduced, tileBounds, exclPos, pairList, pairCount, pairOverflow;
 };
 
-/** amoebaKernels.h:82-139 CalcAmoebaMultipoleForceKernel for PME with direct or mutual polarization; Reference: AmoebaReferenceKernels.cpp:170-520 +
- *  AmoebaReferencePmeMultipoleForce.  The factory hands every other configuration (NoCutoff, extrapolated polarization, grids
+/** amoebaKernels.h:82-139 CalcAmoebaMultipoleForceKernel for PME with direct, mutual or extrapolated polarization; Reference: AmoebaReferenceKernels.cpp:170-520 +
+ *  AmoebaReferencePmeMultipoleForce.  The factory hands every other configuration (NoCutoff, grids
  *  the platform's FFT does not take) to the AMOEBA plugin's own Reference kernel; so does this class for the two queries it does not
  *  compute itself (electrostatic potential on a grid of points, system multipole moments). */
 class HipCalcAmoebaMultipoleForceKernel : public CalcAmoebaMultipoleForceKernel {
 public:
     HipCalcAmoebaMultipoleForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data, KernelImpl* referenceKernel);
     ~HipCalcAmoebaMultipoleForceKernel();
-    /** Can this force be computed natively?  (PME, direct or mutual polarization, FFT-friendly grid, rectangular or triclinic box.) */
+    /** Can this force be computed natively?  (PME, direct / mutual / extrapolated polarization, FFT-friendly grid, rectangular or triclinic box.) */
     static bool supports(const AmoebaMultipoleForce& force, const System& system);
     void initialize(const System& system, const AmoebaMultipoleForce& force);
     double execute(ContextImpl& context, bool includeForces, bool includeEnergy);
@@ -80,7 +80,7 @@ private:
     CalcAmoebaMultipoleForceKernel* reference;      // the AMOEBA plugin's Reference kernel (for the two queries above), owned
     int numParticles = 0, gridSize[3] = {0, 0, 0};
     double alphaEwald = 0, cutoff = 0, lastBox[6] = {0, 0, 0, 0, 0, 0};
-    bool etermBuilt = false, mutual = false;
+    bool etermBuilt = false, mutual = false, extrapolated = false;
     double solverStatus[2] = {0, 0};          // epsilon reached and iterations of the last mutual-polarization solve
     // first guess of the solver from the solutions of the previous steps (ommhip_amoeba_multipole::history): a ring of HistorySlots records
     static const int HistorySlots = OMMHIP_AMOEBA_MAX_HISTORY;
@@ -94,7 +94,7 @@ private:
     ommhip_pme pme, pme2;
     void* sideStream = NULL; void* eventA = NULL; void* eventB = NULL;
     DeviceBuffer charge, molDipole, molQuad, axis, thole, damping, polarity, specStart, specAtom, specScale;
-    DeviceBuffer labDipole, labQuad, fieldD, fieldP, indD, indP, phi, phiInd, phiIndP, solver, solverGather, history, torque, tileBounds, specPos, specScaleSorted, pairList, pairCount, pairOverflow, pairCache;
+    DeviceBuffer labDipole, labQuad, fieldD, fieldP, indD, indP, phi, phiInd, phiIndP, solver, solverGather, history, extDipoles, extGradients, torque, tileBounds, specPos, specScaleSorted, pairList, pairCount, pairOverflow, pairCache;
     DeviceBuffer moduliX, moduliY, moduliZ, twiddleX, twiddleY, twiddleZ, eterm, gridReal, gridComplex, gridReal2, gridComplex2;
 };
 

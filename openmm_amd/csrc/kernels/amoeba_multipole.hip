@@ -457,7 +457,8 @@ __global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double
 // own offset turn those into its share of the 20 derivatives, and the shares meet through shuffles.  (One thread per atom held the
 // whole 3 x 4 x 5 weight table and 20 sums in registers and spilled.)
 // MAXORD = 3: all 20 values; MAXORD = 1: the potential and its gradient only (out[0..3]) -- all that the induced-dipole field of a solver
-// iteration reads, at a third of the arithmetic.
+// iteration reads, at a third of the arithmetic; MAXORD = 2: up to the second derivatives (out[0..9]), the field gradient the
+// extrapolated-polarization scheme keeps of every order.
 template <int MAXORD>
 __global__ void k_mp_potential(MpArgs a, double* __restrict__ out) {
     if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;
@@ -502,14 +503,15 @@ __global__ void k_mp_potential(MpArgs a, double* __restrict__ out) {
     const double f1[3] = {F[1][0][0], F[0][1][0], F[0][0][1]};
     o[0] = F[0][0][0];
     for (int c = 0; c < 3; c++) o[1 + c] = a.a[0][c] * f1[0] + a.a[1][c] * f1[1] + a.a[2][c] * f1[2];
-    if (MAXORD >= 3) {
+    if (MAXORD >= 2) {
         // second and third fractional derivative tensors by index
         double f2[3][3], f3[3][3][3];
         for (int k = 0; k < 3; k++)
             for (int l = 0; l < 3; l++) {
                 int e[3] = {0, 0, 0}; e[k]++; e[l]++;
                 f2[k][l] = F[e[0] % NO][e[1] % NO][e[2] % NO];
-                for (int m = 0; m < 3; m++) { int e3[3] = {e[0], e[1], e[2]}; e3[m]++; f3[k][l][m] = F[e3[0] % NO][e3[1] % NO][e3[2] % NO]; }
+                if (MAXORD >= 3)
+                    for (int m = 0; m < 3; m++) { int e3[3] = {e[0], e[1], e[2]}; e3[m]++; f3[k][l][m] = F[e3[0] % NO][e3[1] % NO][e3[2] % NO]; }
             }
         int n2 = 4, n3 = 10;
         for (int c = 0; c < 3; c++)
@@ -517,11 +519,12 @@ __global__ void k_mp_potential(MpArgs a, double* __restrict__ out) {
                 double s2 = 0;
                 for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) s2 += a.a[k][c] * a.a[l][d] * f2[k][l];
                 o[n2++] = s2;
-                for (int e = d; e < 3; e++) {
-                    double t3 = 0;
-                    for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) for (int m = 0; m < 3; m++) t3 += a.a[k][c] * a.a[l][d] * a.a[m][e] * f3[k][l][m];
-                    o[n3++] = t3;
-                }
+                if (MAXORD >= 3)
+                    for (int e = d; e < 3; e++) {
+                        double t3 = 0;
+                        for (int k = 0; k < 3; k++) for (int l = 0; l < 3; l++) for (int m = 0; m < 3; m++) t3 += a.a[k][c] * a.a[l][d] * a.a[m][e] * f3[k][l][m];
+                        o[n3++] = t3;
+                    }
             }
     }
 }
@@ -940,6 +943,110 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const do
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Extrapolated polarization (OPT; Simmonett, Pickard, Ponder, Brooks, J. Chem. Phys. 145, 164101 (2016);
+// AmoebaReferenceMultipoleForce::convergeInduceDipolesByExtrapolation :891-937): mu_0 = alpha E, mu_(n+1) = alpha T mu_n, the induced
+// dipoles are sum_n P_n mu_n with P_n the partial sums of the extrapolation coefficients.  No iteration to convergence: K - 1 field
+// evaluations.  Energy and forces are those of direct polarization evaluated with the total dipoles plus, per atom,
+//     F_i += 1/2 sum_(l + m + 1 < K) P_(l+m+1) [ mu_d^(l) . G_p^(m) + mu_p^(l) . G_d^(m) ]           (:6787-6816)
+// where G^(m) is the GRADIENT at atom i of the field that the dipoles mu^(m) produce -- so every field evaluation also returns that:
+// real space from the Thole-damped chain one order up (calculateDirectInducedDipolePairIxns :6172-6290: E_ab = (mu.r) r_a r_b b3
+// - (mu_a r_b + mu_b r_a + delta_ab mu.r) b2), reciprocal space from the second derivatives of the dipoles' potential (:6080-6140).
+// ------------------------------------------------------------------------------------------------
+// field (3) and field gradient (xx, yy, zz, xy, xz, yz) of the dipole sets vD, vP at every atom.  MIXED: the pair chains in float.
+template <bool MIXED>
+__global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field_gradient(MpArgs a, const double* __restrict__ vD, const double* __restrict__ vP, const double* __restrict__ phiD,
+                                                                       const double* __restrict__ phiP, double* __restrict__ outD, double* __restrict__ outP,
+                                                                       double* __restrict__ gradD, double* __restrict__ gradP) {
+    const int t = threadIdx.x, g = (blockIdx.x * MP_BLOCK + t) / MP_SPLIT, q = t % MP_SPLIT, i = scan_atom(a, g);
+    const bool active = i >= 0;
+    const int ii = active ? i : 0;
+    const V3 xi = position(a, ii);
+    const double tholeI = a.thole[ii], dampI = a.damping[ii];
+    V3 ed = v3(0, 0, 0), ep = v3(0, 0, 0);
+    double gd[6] = {0, 0, 0, 0, 0, 0}, gp[6] = {0, 0, 0, 0, 0, 0};
+    PlSpan span = {0, 0, 0, 0};
+    if (active) span = pl_span(a.pairCount, a.listStride, g);
+    for (int k = q; k < span.total; k += MP_SPLIT) {
+        const int j = scan_atom(a, pl_at(a.pairList, a.listStride, a.listSubcap, span, k, g) & PL_POS_MASK);
+        const V3 xj = position(a, j);
+        double dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
+        min_image_d(dx, dy, dz, a.box);
+        const double r2 = dx * dx + dy * dy + dz * dz;
+        if (r2 > a.cutoff2) continue;
+        double b1, b2, b3;
+        if (MIXED) {
+            float bn[6], cn[6], oml[5];
+            pair_chains<float>((float) a.alpha, (float) r2, (float) dampI, (float) a.damping[j], (float) tholeI, (float) a.thole[j], bn, cn, oml);
+            b1 = bn[1] - oml[1] * cn[1]; b2 = bn[2] - oml[2] * cn[2]; b3 = bn[3] - oml[3] * cn[3];
+        }
+        else {
+            double bn[6], cn[6], oml[5];
+            pair_chains<double>(a.alpha, r2, dampI, a.damping[j], tholeI, a.thole[j], bn, cn, oml);
+            b1 = bn[1] - oml[1] * cn[1]; b2 = bn[2] - oml[2] * cn[2]; b3 = bn[3] - oml[3] * cn[3];
+        }
+        const V3 r = v3(dx, dy, dz);
+        const V3 vd = load3(vD, j), vp = load3(vP, j);
+        const double md = dot(vd, r), mp = dot(vp, r);
+        ed = ed + (b2 * md) * r - b1 * vd;
+        ep = ep + (b2 * mp) * r - b1 * vp;
+        gd[0] += md * dx * dx * b3 - (2.0 * vd.x * dx + md) * b2; gd[1] += md * dy * dy * b3 - (2.0 * vd.y * dy + md) * b2; gd[2] += md * dz * dz * b3 - (2.0 * vd.z * dz + md) * b2;
+        gd[3] += md * dx * dy * b3 - (vd.x * dy + vd.y * dx) * b2; gd[4] += md * dx * dz * b3 - (vd.x * dz + vd.z * dx) * b2; gd[5] += md * dy * dz * b3 - (vd.y * dz + vd.z * dy) * b2;
+        gp[0] += mp * dx * dx * b3 - (2.0 * vp.x * dx + mp) * b2; gp[1] += mp * dy * dy * b3 - (2.0 * vp.y * dy + mp) * b2; gp[2] += mp * dz * dz * b3 - (2.0 * vp.z * dz + mp) * b2;
+        gp[3] += mp * dx * dy * b3 - (vp.x * dy + vp.y * dx) * b2; gp[4] += mp * dx * dz * b3 - (vp.x * dz + vp.z * dx) * b2; gp[5] += mp * dy * dz * b3 - (vp.y * dz + vp.z * dy) * b2;
+    }
+    ed = split_sum(ed); ep = split_sum(ep);
+    for (int c = 0; c < 6; c++) { gd[c] = split_sum(gd[c]); gp[c] = split_sum(gp[c]); }
+    if (!active || q != 0) return;
+    const double selfTerm = (4.0 / 3.0) * a.alpha * a.alpha * a.alpha / MP_SQRT_PI, invK = 1.0 / OMM_ONE_4PI_EPS0_D;
+    const double* pd = phiD + 20 * (size_t) i;
+    const double* pp = phiP + 20 * (size_t) i;
+    store3(outD, i, ed - invK * v3(pd[1], pd[2], pd[3]) + selfTerm * load3(vD, i));
+    store3(outP, i, ep - invK * v3(pp[1], pp[2], pp[3]) + selfTerm * load3(vP, i));
+    // reciprocal part of the gradient: minus the second derivatives of the potential, out[4..9] = xx xy xz yy yz zz
+    const int at[6] = {4, 7, 9, 5, 6, 8};
+    for (int c = 0; c < 6; c++) { gradD[6 * (size_t) i + c] = gd[c] - invK * pd[at[c]]; gradP[6 * (size_t) i + c] = gp[c] - invK * pp[at[c]]; }
+}
+
+// stage 0: record the dipoles in indD / indP as order `order`;  stage 1: the next order, alpha x the field in fD / fP, into indD / indP and
+// the record;  stage 2: indD / indP = sum_n P_n record_n
+struct ExtCoeff { double p[OMMHIP_AMOEBA_MAX_EXT_ORDERS]; };
+__global__ void k_mp_ext_step(MpArgs a, double* records, int order, int orders, int stage, const double* __restrict__ fD, const double* __restrict__ fP, ExtCoeff coeff) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const size_t n3 = 3 * (size_t) a.n;
+    if (stage == 2) {
+        V3 d = v3(0, 0, 0), p = v3(0, 0, 0);
+        for (int k = 0; k < orders; k++) { d = d + coeff.p[k] * load3(records + (size_t) k * 2 * n3, i); p = p + coeff.p[k] * load3(records + (size_t) k * 2 * n3 + n3, i); }
+        store3(a.indD, i, d); store3(a.indP, i, p);
+        return;
+    }
+    if (stage == 1) { const double pol = a.polarity[i]; store3(a.indD, i, pol * load3(fD, i)); store3(a.indP, i, pol * load3(fP, i)); }
+    double* rec = records + (size_t) order * 2 * n3;
+    store3(rec, i, load3(a.indD, i)); store3(rec + n3, i, load3(a.indP, i));
+}
+
+// the dipole-response part of the extrapolated-polarization force (see above); gradients: `orders - 1` records of (G_d, G_p), 12 n doubles each
+__global__ void k_mp_ext_forces(MpArgs a, const double* __restrict__ records, const double* __restrict__ gradients, int orders, ExtCoeff coeff) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const size_t n3 = 3 * (size_t) a.n, n6 = 6 * (size_t) a.n;
+    V3 f = v3(0, 0, 0);
+    for (int l = 0; l < orders - 1; l++)
+        for (int m = 0; m < orders - 1 - l; m++) {
+            const double p = coeff.p[l + m + 1];
+            if (fabs(p) < 1e-6) continue;
+            const V3 ud = load3(records + (size_t) l * 2 * n3, i), up = load3(records + (size_t) l * 2 * n3 + n3, i);
+            const double* gD = gradients + (size_t) m * 2 * n6 + 6 * (size_t) i;
+            const double* gP = gradients + (size_t) m * 2 * n6 + n6 + 6 * (size_t) i;
+            // (xx, yy, zz, xy, xz, yz)
+            f = f + (0.5 * p) * v3(ud.x * gP[0] + ud.y * gP[3] + ud.z * gP[4], ud.x * gP[3] + ud.y * gP[1] + ud.z * gP[5], ud.x * gP[4] + ud.y * gP[5] + ud.z * gP[2]);
+            f = f + (0.5 * p) * v3(up.x * gD[0] + up.y * gD[3] + up.z * gD[4], up.x * gD[3] + up.y * gD[1] + up.z * gD[5], up.x * gD[4] + up.y * gD[5] + up.z * gD[2]);
+        }
+    f = OMM_ONE_4PI_EPS0_D * f;
+    add_force(a.force, a.paddedAtoms, a.slotOfAtom[i], f.x, f.y, f.z);
+}
+
 // Preconditioner of the conjugate gradients: z = M r with M = 2 alpha + alpha T_near alpha, the first terms of the Neumann series of
 // (1/alpha - T)^-1 with the pair tensor kept for partners closer than 0.45 nm and the diagonal doubled -- Tinker's choice (induce.f, uscale0a /
 // uscale0b: udiag = 2, usolvcut = 4.5 A).  Measured here: 8 -> 7 iterations on 12 167 waters at epsilon 1e-5, which does not pay for the extra list walk: opt-in.  The pairs and their damped tensor coefficients come from
@@ -1271,12 +1378,13 @@ void spread_induced(const MpArgs& a, const double* A, double sA, const double* B
         hipLaunchKernelGGL(k_mp_spread<true>, dim3(spread_blocks(a)), dim3(256), 0, st, a, A, sA, B, sB);
 }
 
-void dipole_potential(const ommhip_pme* pme, const MpArgs& a, const double* dipoles, double* out, hipStream_t st, bool fieldOnly = false) {
-    const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
+// maxOrder: derivatives of the potential wanted (1: gradient, a solver iteration; 2: + second derivatives, an order of the extrapolation; 3: all)
+void dipole_potential(const ommhip_pme* pme, const MpArgs& a, const double* dipoles, double* out, hipStream_t st, int maxOrder = 3) {
     hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, st);
     spread_induced(a, dipoles, 1.0, nullptr, 0.0, st);
     ommhip_pme_convolve(pme, st);
-    if (fieldOnly) hipLaunchKernelGGL(k_mp_potential<1>, dim3(spread_blocks(a)), dim3(256), 0, st, a, out);
+    if (maxOrder == 1) hipLaunchKernelGGL(k_mp_potential<1>, dim3(spread_blocks(a)), dim3(256), 0, st, a, out);
+    else if (maxOrder == 2) hipLaunchKernelGGL(k_mp_potential<2>, dim3(spread_blocks(a)), dim3(256), 0, st, a, out);
     else hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, out);
 }
 
@@ -1284,7 +1392,8 @@ void dipole_potential(const ommhip_pme* pme, const MpArgs& a, const double* dipo
 // that leave most of the chip idle; with a second grid and a side stream (pme2, stream2, two ordering events: optional in the C ABI) the
 // chain of the second set runs beside that of the first.
 // fieldOnly: potential and gradient only (a solver iteration); the derivatives up to third order are computed for the converged dipoles
-void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double* vD, double* outD, const double* vP, double* outP, hipStream_t st, bool fieldOnly = false) {
+void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double* vD, double* outD, const double* vP, double* outP, hipStream_t st, bool fieldOnlyFlag = false, int maxOrder = 0) {
+    const int fieldOnly = maxOrder > 0 ? maxOrder : (fieldOnlyFlag ? 1 : 3);
     const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
     const ommhip_pme* pme2 = (const ommhip_pme*) mp->pme2;
     if (pme2 == nullptr || mp->stream2 == nullptr || mp->event_a == nullptr || mp->event_b == nullptr || pme2->grid_real == nullptr || pme2->grid_real == pme->grid_real) {
@@ -1371,6 +1480,31 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st) {
     return 0;
 }
 
+// Extrapolated polarization: orders 1 .. K - 1 from the direct dipoles, the total dipoles, their potentials.  Leaves mu_d, mu_p (totals) in
+// indD / indP, every order in mp->ext_dipoles and the field gradients of orders 0 .. K - 2 in mp->ext_gradients.
+int solve_extrapolated(const ommhip_amoeba_multipole* mp, const MpArgs& a, hipStream_t st) {
+    const int K = mp->extrapolation_orders;
+    if (K < 1 || K > OMMHIP_AMOEBA_MAX_EXT_ORDERS || mp->ext_dipoles == nullptr || (K > 1 && mp->ext_gradients == nullptr) || mp->solver == nullptr || mp->phi_induced_p == nullptr) return 1;
+    const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
+    const size_t n3 = 3 * (size_t) a.n, n6 = 6 * (size_t) a.n;
+    double* fD = mp->solver + 6 * n3; double* fP = mp->solver + 7 * n3;
+    ExtCoeff coeff;
+    for (int k = 0; k < OMMHIP_AMOEBA_MAX_EXT_ORDERS; k++) {          // P_k = sum_(j >= k) c_j (AmoebaReferenceMultipoleForce.cpp:166-173)
+        coeff.p[k] = 0.0;
+        for (int j = k; j < K; j++) coeff.p[k] += mp->ext_coefficients[j];
+    }
+    hipLaunchKernelGGL(k_mp_ext_step, dim3(blocks), dim3(MP_BLOCK), 0, st, a, mp->ext_dipoles, 0, K, 0, (const double*) nullptr, (const double*) nullptr, coeff);
+    for (int order = 1; order < K; order++) {
+        dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st, false, 2);
+        double* gD = mp->ext_gradients + (size_t) (order - 1) * 2 * n6;
+        if (mp->mixed_precision) hipLaunchKernelGGL(k_mp_dipole_field_gradient<true>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, fD, fP, gD, gD + n6);
+        else hipLaunchKernelGGL(k_mp_dipole_field_gradient<false>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, fD, fP, gD, gD + n6);
+        hipLaunchKernelGGL(k_mp_ext_step, dim3(blocks), dim3(MP_BLOCK), 0, st, a, mp->ext_dipoles, order, K, 1, fD, fP, coeff);
+    }
+    hipLaunchKernelGGL(k_mp_ext_step, dim3(blocks), dim3(MP_BLOCK), 0, st, a, mp->ext_dipoles, 0, K, 2, (const double*) nullptr, (const double*) nullptr, coeff);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int ommhip_amoeba_multipole_induce(const ommhip_amoeba_multipole* mp, const void* pos_d, const double box[6], void* stream) {
@@ -1378,6 +1512,7 @@ extern "C" int ommhip_amoeba_multipole_induce(const ommhip_amoeba_multipole* mp,
     if (!make_args(mp, pos_d, box, a)) return 1;
     { const int rc = launch_induce(mp, a, box, (hipStream_t) stream); if (rc != 0) return rc; }
     if (a.mutual) { const int rc = solve_mutual(mp, a, (hipStream_t) stream); if (rc != 0) return rc; }
+    else if (mp->extrapolation_orders > 0) { const int rc = solve_extrapolated(mp, a, (hipStream_t) stream); if (rc != 0) return rc; }
     return (int) hipGetLastError();
 }
 
@@ -1393,6 +1528,7 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
     { const int rc = launch_induce(mp, a, box, st); if (rc != 0) return rc; }
     if (a.mutual) { const int rc = solve_mutual(mp, a, st); if (rc != 0) return rc; }      // -1: not converged
     else {
+        if (mp->extrapolation_orders > 0) { const int rc = solve_extrapolated(mp, a, st); if (rc != 0) return rc; }
         // reciprocal potential of the induced dipoles (mu_d + mu_p) / 2
         hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, st);
         spread_induced(a, a.indD, 0.5, a.indP, 0.5, st);
@@ -1404,6 +1540,11 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
         hipLaunchKernelGGL(k_mp_forces<true>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
     }
     else hipLaunchKernelGGL(k_mp_forces<false>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
+    if (!a.mutual && mp->extrapolation_orders > 1) {
+        ExtCoeff coeff;
+        for (int k = 0; k < OMMHIP_AMOEBA_MAX_EXT_ORDERS; k++) { coeff.p[k] = 0.0; for (int j = k; j < mp->extrapolation_orders; j++) coeff.p[k] += mp->ext_coefficients[j]; }
+        hipLaunchKernelGGL(k_mp_ext_forces, dim3(blocks), dim3(MP_BLOCK), 0, st, a, mp->ext_dipoles, mp->ext_gradients, mp->extrapolation_orders, coeff);
+    }
     hipLaunchKernelGGL(k_mp_torque_to_force, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
     return (int) hipGetLastError();
 }

@@ -96,10 +96,12 @@ int main(int argc, char* argv[]) {
     }
     try {
         setupKernels(argc, argv);
-        const char* names[] = {"4 waters", "2 ions + 2 waters", "216 waters", "4 waters, mutual", "2 ions + 2 waters, mutual", "216 waters, mutual"};
-        Case cases[] = {water4, ionsAndWater, water648, water4, ionsAndWater, water648};
-        for (int c = 0; c < 6; c++) {
-            gPolarization = c < 3 ? AmoebaMultipoleForce::Direct : AmoebaMultipoleForce::Mutual;
+        const char* names[] = {"4 waters", "2 ions + 2 waters", "216 waters", "4 waters, mutual", "2 ions + 2 waters, mutual", "216 waters, mutual",
+                               "4 waters, extrapolated", "2 ions + 2 waters, extrap.", "216 waters, extrapolated"};
+        Case cases[] = {water4, ionsAndWater, water648, water4, ionsAndWater, water648, water4, ionsAndWater, water648};
+        for (int c = 0; c < 9; c++) {
+            // (Extrapolated: the force's default coefficients, OPT3 -- four perturbation orders)
+            gPolarization = c < 3 ? AmoebaMultipoleForce::Direct : (c < 6 ? AmoebaMultipoleForce::Mutual : AmoebaMultipoleForce::Extrapolated);
             std::vector<Vec3> fn, fr;
             double en = 0, er = 0;
             unsetenv("OPENMM_HIP_REFERENCE_AMOEBA_MULTIPOLE");

@@ -285,7 +285,7 @@ def test_native_amoeba_multipole_kernel_matches_the_plugins_reference_kernel():
     if not os.path.exists(exe):
         pytest.skip("not built")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0 and "Done" in out.stdout and "multipole 6" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+    assert out.returncode == 0 and "Done" in out.stdout and "multipole 9" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
 
 
 @needs_emu

@@ -61,7 +61,7 @@ def test_native_amoeba_multipole_kernel_matches_the_plugins_reference_kernel():
     assert os.path.exists(exe), "%s missing: run __graft_entry__.build() in the build container" % exe
     out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     print(out.stdout)
-    assert out.returncode == 0 and "Done" in out.stdout and "multipole 6" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+    assert out.returncode == 0 and "Done" in out.stdout and "multipole 9" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
 
 
 @pytest.mark.parametrize("n_side,grid,mutual", [(8, 32, False), (12, 48, True)])

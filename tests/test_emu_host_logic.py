@@ -250,7 +250,7 @@ def test_pme_logic(K, tric):
 
 FAST_REFERENCE_TESTS = ["HarmonicBondForce", "HarmonicAngleForce", "PeriodicTorsionForce", "CMMotionRemover", "Checkpoints",
                         "CustomBondForce", "RBTorsionForce", "Settle", "NonbondedForce", "CustomExternalForce", "VirtualSites",
-                        "AmoebaVdwForce", "AmoebaMultipoleForce", "AmoebaTorsionTorsionForce"]
+                        "AmoebaVdwForce", "AmoebaMultipoleForce", "AmoebaTorsionTorsionForce", "AmoebaExtrapolatedPolarization"]
 
 
 @needs_emu
@@ -273,7 +273,7 @@ def test_reference_test_bodies_on_emulated_platform(name):
         assert m is not None and int(m.group(1 if NATIVE_AMOEBA[name] == "vdw" else 2)) > 0, out.stdout[-500:]
 
 
-NATIVE_AMOEBA = {"AmoebaVdwForce": "vdw", "AmoebaMultipoleForce": "multipole"}         # bodies whose forces must have gone through the native kernels of libOpenMMAmoebaHIP.so
+NATIVE_AMOEBA = {"AmoebaVdwForce": "vdw", "AmoebaMultipoleForce": "multipole", "AmoebaExtrapolatedPolarization": "multipole"}         # bodies whose forces must have gone through the native kernels of libOpenMMAmoebaHIP.so
 
 
 @needs_emu

@@ -24,8 +24,8 @@ REFERENCE_TEST_BODIES = ["NonbondedForce", "Ewald", "VerletIntegrator", "Settle"
                          # plugins/amoeba/tests with libOpenMMAmoebaHIP.so loaded: AmoebaVdwForce (and the PME cases of
                          # AmoebaMultipoleForce) run on the native kernels -- NATIVE_AMOEBA below says which evaluation counter must
                          # move; AmoebaTorsionTorsionForce has no native kernel: the plugin's own Reference kernel runs as a fallback force
-                         "AmoebaVdwForce", "AmoebaMultipoleForce", "AmoebaTorsionTorsionForce"]
-NATIVE_AMOEBA = {"AmoebaVdwForce": "vdw", "AmoebaMultipoleForce": "multipole"}         # test body -> counter printed by tests/hip/HipAmoebaTests.h at exit
+                         "AmoebaVdwForce", "AmoebaMultipoleForce", "AmoebaTorsionTorsionForce", "AmoebaExtrapolatedPolarization"]
+NATIVE_AMOEBA = {"AmoebaVdwForce": "vdw", "AmoebaMultipoleForce": "multipole", "AmoebaExtrapolatedPolarization": "multipole"}         # test body -> counter printed by tests/hip/HipAmoebaTests.h at exit
 
 
 @pytest.fixture(scope="module", autouse=True)

@@ -5,6 +5,7 @@
  */
 #include "OpenMM.h"
 #include "openmm/AmoebaMultipoleForce.h"
+#include "openmm/AmoebaTorsionTorsionForce.h"
 #include "openmm/AmoebaVdwForce.h"
 #include <string>
 #include <vector>
@@ -54,6 +55,24 @@ int omm_amoeba_multipole_set_covalent_maps(void* f, int entries, const int* atom
 int omm_amoeba_multipole_get_induced_dipoles(void* f, void* context, double* out) {
     GUARD(vector<Vec3> d; ((AmoebaMultipoleForce*) f)->getInducedDipoles(*(Context*) context, d);
           for (size_t i = 0; i < d.size(); i++) { out[3 * i] = d[i][0]; out[3 * i + 1] = d[i][1]; out[3 * i + 2] = d[i][2]; })
+}
+
+/* AmoebaTorsionTorsionForce (plugins/amoeba/openmmapi/include/openmm/AmoebaTorsionTorsionForce.h): atoms [6n] = five chain atoms + the
+ * chirality marker atom (or -1); grids [numGrids][nx][ny][columns] with columns = 3 (angle1, angle2, f: the force derives the spline
+ * derivatives itself) or 6 (+ fx, fy, fxy) */
+void* omm_amoeba_torsion_torsion_create(void* system, int n, const int* atoms, const int* gridIndex) {
+    try {
+        AmoebaTorsionTorsionForce* f = new AmoebaTorsionTorsionForce();
+        for (int i = 0; i < n; i++)
+            f->addTorsionTorsion(atoms[6 * i], atoms[6 * i + 1], atoms[6 * i + 2], atoms[6 * i + 3], atoms[6 * i + 4], atoms[6 * i + 5], gridIndex[i]);
+        ((System*) system)->addForce(f);
+        return f;
+    } catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
+int omm_amoeba_torsion_torsion_set_grid(void* f, int index, int nx, int ny, int columns, const double* values) {
+    GUARD(vector<vector<vector<double> > > grid(nx, vector<vector<double> >(ny, vector<double>(columns)));
+          for (int x = 0; x < nx; x++) for (int y = 0; y < ny; y++) for (int c = 0; c < columns; c++) grid[x][y][c] = values[((size_t) x * ny + y) * columns + c];
+          ((AmoebaTorsionTorsionForce*) f)->setTorsionTorsionGrid(index, grid))
 }
 
 /* sigmaRule / epsilonRule: the strings of AmoebaVdwForce ("CUBIC-MEAN", "HHG", ...); method: 0 NoCutoff, 1 CutoffPeriodic */

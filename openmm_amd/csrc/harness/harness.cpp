@@ -103,6 +103,54 @@ void* omm_add_periodic_torsions(void* s, int n, const int* atoms, const int* per
     try { PeriodicTorsionForce* f = new PeriodicTorsionForce(); for (int i = 0; i < n; i++) f->addTorsion(atoms[4 * i], atoms[4 * i + 1], atoms[4 * i + 2], atoms[4 * i + 3], periodicity[i], phase[i], k[i]); ((System*) s)->addForce(f); return f; }
     catch (const std::exception& e) { lastError = e.what(); return NULL; }
 }
+/* ---- Custom forces defined by an energy expression.  paramNames: the per-bond / per-angle parameter names joined by ','; params [n x numParams].
+ *      CustomBondForce / CustomAngleForce / CustomCompoundBondForce (openmmapi/include/openmm/Custom*Force.h) */
+static vector<string> splitNames(const char* names) {
+    vector<string> out;
+    string cur;
+    for (const char* c = names; c != NULL && *c; c++) {
+        if (*c == ',') { if (!cur.empty()) out.push_back(cur); cur.clear(); }
+        else cur += *c;
+    }
+    if (!cur.empty()) out.push_back(cur);
+    return out;
+}
+void* omm_add_custom_bond_force(void* s, const char* energy, const char* paramNames, int n, const int* atoms, const double* params) {
+    try {
+        CustomBondForce* f = new CustomBondForce(energy);
+        vector<string> names = splitNames(paramNames);
+        for (size_t i = 0; i < names.size(); i++) f->addPerBondParameter(names[i]);
+        const int np = (int) names.size();
+        for (int i = 0; i < n; i++) f->addBond(atoms[2 * i], atoms[2 * i + 1], vector<double>(params + (size_t) np * i, params + (size_t) np * (i + 1)));
+        ((System*) s)->addForce(f);
+        return f;
+    } catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
+void* omm_add_custom_angle_force(void* s, const char* energy, const char* paramNames, int n, const int* atoms, const double* params) {
+    try {
+        CustomAngleForce* f = new CustomAngleForce(energy);
+        vector<string> names = splitNames(paramNames);
+        for (size_t i = 0; i < names.size(); i++) f->addPerAngleParameter(names[i]);
+        const int np = (int) names.size();
+        for (int i = 0; i < n; i++) f->addAngle(atoms[3 * i], atoms[3 * i + 1], atoms[3 * i + 2], vector<double>(params + (size_t) np * i, params + (size_t) np * (i + 1)));
+        ((System*) s)->addForce(f);
+        return f;
+    } catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
+void* omm_add_custom_compound_bond_force(void* s, int particlesPerBond, const char* energy, const char* paramNames, int n, const int* atoms, const double* params) {
+    try {
+        CustomCompoundBondForce* f = new CustomCompoundBondForce(particlesPerBond, energy);
+        vector<string> names = splitNames(paramNames);
+        for (size_t i = 0; i < names.size(); i++) f->addPerBondParameter(names[i]);
+        const int np = (int) names.size();
+        for (int i = 0; i < n; i++)
+            f->addBond(vector<int>(atoms + (size_t) particlesPerBond * i, atoms + (size_t) particlesPerBond * (i + 1)), vector<double>(params + (size_t) np * i, params + (size_t) np * (i + 1)));
+        ((System*) s)->addForce(f);
+        return f;
+    } catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
+int omm_force_set_name(void* f, const char* name) { GUARD(((Force*) f)->setName(name)) }
+
 void* omm_add_cmmotion_remover(void* s, int frequency) {
     try { CMMotionRemover* f = new CMMotionRemover(frequency); ((System*) s)->addForce(f); return f; }
     catch (const std::exception& e) { lastError = e.what(); return NULL; }
@@ -124,6 +172,28 @@ void* omm_integrator_create(int kind, double dt, double temperature, double fric
         integ->setConstraintTolerance(constraintTol);
         return integ;
     } catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
+/* ---- CustomIntegrator (openmmapi/include/openmm/CustomIntegrator.h): the computation steps are added one by one.
+ *      kind: 0 global variable, 1 per-dof variable (declarations); 2 ComputeGlobal, 3 ComputePerDof, 4 ComputeSum (result, expression);
+ *      5 ConstrainPositions, 6 ConstrainVelocities, 7 UpdateContextState */
+void* omm_custom_integrator_create(double dt, int seed, double constraintTol) {
+    try { CustomIntegrator* c = new CustomIntegrator(dt); c->setRandomNumberSeed(seed); c->setConstraintTolerance(constraintTol); return c; }
+    catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
+int omm_custom_integrator_add(void* i, int kind, const char* name, const char* expression, double value) {
+    GUARD(CustomIntegrator* c = dynamic_cast<CustomIntegrator*>((Integrator*) i);
+          if (c == NULL) throw OpenMMException("not a CustomIntegrator");
+          switch (kind) {
+              case 0: c->addGlobalVariable(name, value); break;
+              case 1: c->addPerDofVariable(name, value); break;
+              case 2: c->addComputeGlobal(name, expression); break;
+              case 3: c->addComputePerDof(name, expression); break;
+              case 4: c->addComputeSum(name, expression); break;
+              case 5: c->addConstrainPositions(); break;
+              case 6: c->addConstrainVelocities(); break;
+              case 7: c->addUpdateContextState(); break;
+              default: throw OpenMMException("unknown CustomIntegrator step kind");
+          })
 }
 void omm_integrator_destroy(void* i) { delete (Integrator*) i; }
 int omm_integrator_step(void* i, int steps) { GUARD(((Integrator*) i)->step(steps)) }

@@ -9,6 +9,7 @@ check host logic without a GPU pass `emulated=True`, which loads the CPU-emulate
 tests/emu/_build instead; the two can not be mixed in one process.
 """
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -50,7 +51,8 @@ def lib():
         for name in ("omm_last_error", "omm_platform_name", "omm_version", "omm_context_platform_name", "omm_context_platform_property"):
             getattr(_lib, name).restype = C.c_char_p
         for name in ("omm_system_create", "omm_nonbonded_create", "omm_add_harmonic_bonds", "omm_add_harmonic_angles",
-                     "omm_add_periodic_torsions", "omm_add_cmmotion_remover", "omm_add_monte_carlo_barostat", "omm_integrator_create", "omm_context_create"):
+                     "omm_add_periodic_torsions", "omm_add_cmmotion_remover", "omm_add_monte_carlo_barostat", "omm_integrator_create", "omm_context_create",
+                     "omm_add_custom_bond_force", "omm_add_custom_angle_force", "omm_add_custom_compound_bond_force", "omm_custom_integrator_create"):
             getattr(_lib, name).restype = C.c_void_p
         _lib.omm_platform_speed.restype = C.c_double
     return _lib
@@ -145,6 +147,20 @@ class System:
         kk = np.ascontiguousarray(k, dtype=np.float64)
         return _handle(lib().omm_add_periodic_torsions(self.h, len(n), _ip(a), _ip(n), _dp(ph), _dp(kk)))
 
+    def _custom(self, fn, per, energy, names, atoms, params, *lead):
+        a = np.ascontiguousarray(atoms, dtype=np.int32).reshape(-1, per)
+        p = np.ascontiguousarray(params, dtype=np.float64).reshape(len(a), len(names))
+        return _handle(fn(self.h, *lead, energy.encode(), ",".join(names).encode(), len(a), _ip(a), _dp(p)))
+
+    def addCustomBondForce(self, energy, names, atoms, params):
+        return self._custom(lib().omm_add_custom_bond_force, 2, energy, names, atoms, params)
+
+    def addCustomAngleForce(self, energy, names, atoms, params):
+        return self._custom(lib().omm_add_custom_angle_force, 3, energy, names, atoms, params)
+
+    def addCustomCompoundBondForce(self, particlesPerBond, energy, names, atoms, params):
+        return self._custom(lib().omm_add_custom_compound_bond_force, particlesPerBond, energy, names, atoms, params, particlesPerBond)
+
     def addCMMotionRemover(self, frequency=1):
         return _handle(lib().omm_add_cmmotion_remover(self.h, frequency))
 
@@ -226,6 +242,7 @@ def amoeba_lib():
         _alib.omm_amoeba_last_error.restype = C.c_char_p
         _alib.omm_amoeba_multipole_create.restype = C.c_void_p
         _alib.omm_amoeba_vdw_create.restype = C.c_void_p
+        _alib.omm_amoeba_torsion_torsion_create.restype = C.c_void_p
     return _alib
 
 
@@ -328,6 +345,22 @@ class AmoebaVdwForce:
         _acheck(amoeba_lib().omm_amoeba_vdw_set_exclusions(self.h, len(lists), _ip(start), _ip(flat)))
 
 
+class AmoebaTorsionTorsionForce:
+    """plugins/amoeba/openmmapi/include/openmm/AmoebaTorsionTorsionForce.h; created attached to `system`.  atoms [n, 6] = the five chain
+    atoms and the chirality marker (-1: none); grids {index: array [nx, ny, 3 or 6]}."""
+
+    def __init__(self, system, atoms, grid_index, grids):
+        a = np.ascontiguousarray(atoms, dtype=np.int32).reshape(-1, 6)
+        g = np.ascontiguousarray(grid_index, dtype=np.int32)
+        h = amoeba_lib().omm_amoeba_torsion_torsion_create(system.h, len(a), _ip(a), _ip(g))
+        if not h:
+            raise OpenMMError(amoeba_lib().omm_amoeba_last_error().decode())
+        self.h = C.c_void_p(h)
+        for index, grid in sorted(grids.items()):
+            v = np.ascontiguousarray(grid, dtype=np.float64)
+            _acheck(amoeba_lib().omm_amoeba_torsion_torsion_set_grid(self.h, int(index), v.shape[0], v.shape[1], v.shape[2], _dp(v)))
+
+
 class Integrator:
     def __init__(self, kind, stepSize, temperature=300.0, friction=1.0, seed=1, constraintTolerance=1e-5):
         self.h = _handle(lib().omm_integrator_create(kind, C.c_double(stepSize), C.c_double(temperature), C.c_double(friction),
@@ -336,6 +369,81 @@ class Integrator:
 
     def step(self, steps):
         _check(lib().omm_integrator_step(self.h, steps))
+
+
+class CustomIntegrator(Integrator):
+    """openmmapi/include/openmm/CustomIntegrator.h: the steps are appended in the order of the calls."""
+
+    def __init__(self, stepSize, seed=1, constraintTolerance=1e-5):
+        self.h = _handle(lib().omm_custom_integrator_create(C.c_double(stepSize), seed, C.c_double(constraintTolerance)))
+        self.stepSize = stepSize
+
+    def _add(self, kind, name="", expression="", value=0.0):
+        _check(lib().omm_custom_integrator_add(self.h, kind, name.encode(), expression.encode(), C.c_double(value)))
+
+    def addGlobalVariable(self, name, value):
+        self._add(0, name, value=value)
+
+    def addPerDofVariable(self, name, value):
+        self._add(1, name, value=value)
+
+    def addComputeGlobal(self, name, expression):
+        self._add(2, name, expression)
+
+    def addComputePerDof(self, name, expression):
+        self._add(3, name, expression)
+
+    def addComputeSum(self, name, expression):
+        self._add(4, name, expression)
+
+    def addConstrainPositions(self):
+        self._add(5)
+
+    def addConstrainVelocities(self):
+        self._add(6)
+
+    def addUpdateContextState(self):
+        self._add(7)
+
+
+class MTSLangevinIntegrator(CustomIntegrator):
+    """wrappers/python/openmm/mtsintegrator.py:112-199 (BAOAB-RESPA): groups = [(force group, evaluations per step), ...].  As there, the
+    friction factors a and b are those of the FULL step and are applied once per innermost substep."""
+
+    def __init__(self, temperature, friction, dt, groups, seed=1, constraintTolerance=1e-5):
+        if len(groups) == 0:
+            raise ValueError("No force groups specified")
+        groups = sorted(groups, key=lambda g: g[1])
+        CustomIntegrator.__init__(self, dt, seed, constraintTolerance)
+        self.addGlobalVariable("a", math.exp(-friction * dt))
+        self.addGlobalVariable("b", math.sqrt(1 - math.exp(-2 * friction * dt)))
+        self.addGlobalVariable("kT", 8.31446261815324e-3 * temperature)
+        self.addPerDofVariable("x1", 0)
+        self.addUpdateContextState()
+        self._substeps(1, groups)
+        self.addConstrainVelocities()
+
+    def _substeps(self, parent, groups):
+        group, substeps = groups[0]
+        per_parent = substeps / parent
+        if per_parent < 1 or per_parent != int(per_parent):
+            raise ValueError("The number for substeps for each group must be a multiple of the number for the previous group")
+        if group < 0 or group > 31:
+            raise ValueError("Force group must be between 0 and 31")
+        kick = "v+0.5*(dt/%s)*f%s/m" % (substeps, group)
+        for _ in range(int(per_parent)):
+            self.addComputePerDof("v", kick)
+            if len(groups) == 1:
+                self.addComputePerDof("x", "x+(dt/%s)*v" % (2 * substeps))
+                self.addComputePerDof("v", "a*v + b*sqrt(kT/m)*gaussian")
+                self.addComputePerDof("x", "x+(dt/%s)*v" % (2 * substeps))
+                self.addComputePerDof("x1", "x")
+                self.addConstrainPositions()
+                self.addComputePerDof("v", "v+(x-x1)/(dt/%s)" % substeps)
+                self.addConstrainVelocities()
+            else:
+                self._substeps(substeps, groups[1:])
+            self.addComputePerDof("v", kick)
 
 
 class State:

@@ -179,6 +179,110 @@ class AmoebaWaterWorkload:
         return s, mp, vdw
 
 
+class AmoebaWorkload:
+    """A System with the complete AMOEBA force field from a description of forcefield_amoeba.create_description() -- the Forces that
+    wrappers/python/openmm/app/forcefield.py creates for amoeba2009.xml, in the force groups of examples/benchmark.py:69-73 (multipoles and
+    vdW in group 1, all valence terms in group 0).  The energy expressions of the Custom*Forces are the reference's (forcefield.py:3340,
+    3503, 3567-3576, 3732-3741, 4428, 4064-4072): they define the force field."""
+
+    RAD = 180.0 / np.pi
+
+    def __init__(self, description, cutoff=0.7, vdw_cutoff=0.9, polarization=H.Mutual, epsilon=1e-5, ewald_tol=7.5e-4, grid=None, a_ewald=0.0):
+        self.d = description
+        self.name = description["name"]
+        self.positions, self.box, self.masses = description["positions"], description["box"], description["masses"]
+        self.cutoff, self.vdw_cutoff, self.polarization, self.epsilon, self.ewald_tol, self.grid, self.a_ewald = cutoff, vdw_cutoff, polarization, epsilon, ewald_tol, grid, a_ewald
+
+    @property
+    def num_atoms(self):
+        return len(self.positions)
+
+    def build(self, valence=True, nonbonded=True):
+        """-> (System, AmoebaMultipoleForce or None, AmoebaVdwForce or None)"""
+        d = self.d
+        s = H.System()
+        s.addParticles(self.masses)
+        s.setDefaultPeriodicBoxVectors(*self.box)
+        self.handles = handles = {}          # force name -> handle (omm_force_set_group for per-term diagnostics)
+
+        def named(handle, name):
+            H.lib().omm_force_set_name(handle, name.encode())
+            handles[name] = handle
+        plane = ("projx = x2-nx*dot; projy = y2-ny*dot; projz = z2-nz*dot; dot = nx*(x2-x3) + ny*(y2-y3) + nz*(z2-z3); nx = px/norm; ny = py/norm; nz = pz/norm; "
+                 "norm = sqrt(px*px + py*py + pz*pz); px = (d1y*d2z-d1z*d2y); py = (d1z*d2x-d1x*d2z); pz = (d1x*d2y-d1y*d2x); "
+                 "d1x = x1-x4; d1y = y1-y4; d1z = z1-z4; d2x = x3-x4; d2y = y3-y4; d2z = z3-z4")
+        if valence:
+            atoms, par, cubic, quartic = d["bonds"]
+            named(s.addCustomBondForce("k*(d^2 + %s*d^3 + %s*d^4); d=r-r0" % (cubic, quartic), ["r0", "k"], atoms, par), "AmoebaBond")
+            atoms, par, poly = d["angles"]
+            sextic = "k*(d^2 + %s*d^3 + %s*d^4 + %s*d^5 + %s*d^6)" % tuple(poly)
+            named(s.addCustomAngleForce(sextic + "; d=%.15g*theta-theta0" % self.RAD, ["theta0", "k"], atoms, par), "AmoebaAngle")
+            atoms, par = d["inplane_angles"]
+            if len(atoms):
+                e = sextic + "; d=theta-theta0; theta = %.15g*pointangle(x1, y1, z1, projx, projy, projz, x3, y3, z3); " % self.RAD + plane
+                named(s.addCustomCompoundBondForce(4, e, ["theta0", "k"], atoms, par), "AmoebaInPlaneAngle")
+            atoms, k, poly = d["opbends"]
+            if len(atoms):
+                e = ("k*(theta^2 + %s*theta^3 + %s*theta^4 + %s*theta^5 + %s*theta^6); " % tuple(repr(float(v)) for v in poly) +
+                     "theta = %.15g*pointangle(x2, y2, z2, x4, y4, z4, projx, projy, projz); " % self.RAD + plane)
+                named(s.addCustomCompoundBondForce(4, e, ["k"], atoms, k), "AmoebaOutOfPlaneBend")
+            atoms, par = d["stretch_bends"]
+            if len(atoms):
+                e = "(k1*(distance(p1,p2)-r12) + k2*(distance(p2,p3)-r23))*(%.15g*(angle(p1,p2,p3)-theta0))" % self.RAD
+                named(s.addCustomCompoundBondForce(3, e, ["r12", "r23", "theta0", "k1", "k2"], atoms, par), "AmoebaStretchBend")
+            atoms, par = d["urey_bradleys"]
+            if len(atoms):
+                named(s.addHarmonicBondForce(atoms, par[:, 0], par[:, 1]), "AmoebaUreyBradley")
+            atoms, par = d["torsions"]
+            if len(atoms):
+                named(s.addPeriodicTorsionForce(atoms, par[:, 0].astype(np.int32), par[:, 1], par[:, 2]), "PeriodicTorsion")
+            atoms, k = d["pi_torsions"]
+            if len(atoms):
+                e = ("2*k*sin(phi)^2; phi = pointdihedral(x3+c1x, y3+c1y, z3+c1z, x3, y3, z3, x4, y4, z4, x4+c2x, y4+c2y, z4+c2z); "
+                     "c1x = (d14y*d24z-d14z*d24y); c1y = (d14z*d24x-d14x*d24z); c1z = (d14x*d24y-d14y*d24x); "
+                     "c2x = (d53y*d63z-d53z*d63y); c2y = (d53z*d63x-d53x*d63z); c2z = (d53x*d63y-d53y*d63x); "
+                     "d14x = x1-x4; d14y = y1-y4; d14z = z1-z4; d24x = x2-x4; d24y = y2-y4; d24z = z2-z4; "
+                     "d53x = x5-x3; d53y = y5-y3; d53z = z5-z3; d63x = x6-x3; d63y = y6-y3; d63z = z6-z3")
+                named(s.addCustomCompoundBondForce(6, e, ["k"], atoms, k), "AmoebaPiTorsion")
+            atoms, grid_index, grids = d["torsion_torsions"]
+            if len(atoms):
+                handles["AmoebaTorsionTorsion"] = H.AmoebaTorsionTorsionForce(s, atoms, grid_index, grids).h
+        mp = vdw = None
+        if nonbonded:
+            m = d["multipoles"]
+            mp = H.AmoebaMultipoleForce(s, H.AmoebaMultipoleForce.PME, self.polarization, self.cutoff, self.a_ewald, self.grid, self.ewald_tol, self.epsilon, 100)
+            mp.addMultipoles(m["charge"], m["dipole"], m["quadrupole"].reshape(-1, 3, 3), m["axes"], m["thole"], m["damping"], m["polarity"])
+            mp.setCovalentMaps([e[0] for e in m["covalent_maps"]], [e[1] for e in m["covalent_maps"]], [e[2] for e in m["covalent_maps"]])
+            v = d["vdw"]
+            vdw = H.AmoebaVdwForce(s, v["sigma_rule"], v["epsilon_rule"], H.AmoebaVdwForce.CutoffPeriodic, self.vdw_cutoff, True)
+            vdw.addParticles(v["parent"], v["sigma"], v["epsilon"], v["reduction"])
+            vdw.setParticleExclusions(v["exclusions"])
+            handles["AmoebaMultipole"], handles["AmoebaVdw"] = mp.h, vdw.h
+            H.lib().omm_force_set_group(mp.h, 1)
+            H.lib().omm_force_set_group(vdw.h, 1)
+        if getattr(self, "cm_remover", False):
+            s.addCMMotionRemover(1)
+        return s, mp, vdw
+
+
+def amoeba_dhfr(pin_grid=False, **kw):
+    """examples/benchmark.py `amoebapme` (BASELINE.json configs[4]): DHFR in water (23 558 atoms), amoeba2009, multipole PME cutoff 0.7 nm /
+    tolerance 7.5e-4, vdW cutoff 0.9 nm, no constraints, mutual polarization at epsilon 1e-5, CMMotionRemover -- from the fixture
+    tests/golden/amoeba_dhfr_5dfr_amoeba2009.npz (tools/make_amoeba_dhfr_fixture.py).  pin_grid: write the 64^3 grid and the alpha that
+    the tolerance rule gives into the force, so that every platform computes the same sum whatever its rounding of grid sizes."""
+    import os
+    from . import forcefield_amoeba as A
+    d = A.load_description(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "amoeba_dhfr_5dfr_amoeba2009.npz"))
+    kw.setdefault("cutoff", 0.7)
+    kw.setdefault("ewald_tol", 7.5e-4)
+    if pin_grid:
+        kw["grid"] = (64, 64, 64)
+        kw["a_ewald"] = float(np.sqrt(-np.log(2 * kw["ewald_tol"])) / kw["cutoff"])
+    w = AmoebaWorkload(d, **kw)
+    w.cm_remover = True
+    return w
+
+
 def amoeba_water_box(n_side, seed=0, **kw):
     """n_side^3 AMOEBA waters on the jittered lattice of water_box()."""
     w = water_box(n_side, seed=seed)

@@ -315,6 +315,20 @@ def test_amoeba_dynamics_with_list_skin_and_predicted_dipoles_walks_the_same_tra
 
 
 @needs_emu
+def test_amoeba2009_dhfr_solute_forces_and_mts_langevin_steps_against_reference_platform(tmp_path):
+    """Every kind of term amoeba2009 puts on a protein (the 2 489-atom solute of the amoebapme benchmark System) on the emulated HIP platform
+    against the Reference platform, by the force groups of examples/benchmark.py, and three steps of its MTSLangevinIntegrator with the
+    same seed (tests/amoeba_dhfr_case.py)."""
+    from amoeba_dhfr_case import run_amoeba_dhfr_case
+    r = run_amoeba_dhfr_case(tmp_path, True)
+    print(r)
+    assert r["native"][0] >= 1 and r["native"][1] >= 1, "the native AMOEBA kernels did not run"
+    assert r["force_valence"] < 1e-6 and r["energy_valence"] < 1e-9
+    assert r["force_nonbonded"] < 2e-4 and r["energy_nonbonded"] < 1e-5
+    assert r["dpos"] < 2e-6 and r["dvel"] < 2e-3
+
+
+@needs_emu
 def test_multi_gpu_context_rejects_forces_with_plugin_native_kernels():
     """The AMOEBA kernels of libOpenMMAmoebaHIP.so evaluate the whole system on one GPU: a Context spread over ranks must refuse them
     (it used to accept them silently and return R times the energy) -- before any communicator is created."""

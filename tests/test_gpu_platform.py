@@ -116,6 +116,56 @@ def test_amoeba_water_tile_at_the_benchmarked_size_matches_the_reference_kernels
     assert abs(e - float(g["energy"])) < 2e-6 * abs(float(g["energy"]))
 
 
+AMOEBA_DHFR_CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from openmm_amd import harness as H, testsystems as T
+H.load_amoeba_plugins()
+w = T.amoeba_dhfr(epsilon=1e-6, pin_grid=True)
+s, mp, vdw = w.build()
+integ = H.MTSLangevinIntegrator(300.0, 1.0, 0.002, [(0, 2), (1, 1)], seed=7)
+ctx = H.Context(s, integ, "HIP")
+ctx.setPositions(w.positions)
+out = {}
+for name, groups in (("valence", 1), ("nonbonded", 2)):
+    st = ctx.getState(getForces=True, getEnergy=True, groups=groups)
+    out["f_" + name], out["e_" + name] = st.forces, st.potentialEnergy
+out["native"] = np.array(H.amoeba_native_evaluations())
+ctx.setVelocitiesToTemperature(300.0, 5)
+integ.step(10)
+st = ctx.getState(getEnergy=True, getPositions=True)
+out["e_after"], out["ke_after"], out["moved"] = st.potentialEnergy, st.kineticEnergy, np.abs(st.positions - w.positions).max()
+np.savez(sys.argv[1], **out)
+'''
+
+
+def test_amoeba2009_dhfr_at_the_benchmarked_size_matches_the_reference_platform(golden, tmp_path):
+    """BASELINE.json configs[4] (examples/benchmark.py amoebapme: DHFR in water, 23 558 atoms, amoeba2009) at the PDB coordinates against
+    the Reference platform's forces of all atoms (committed golden: tools/make_amoeba_dhfr_fixture.py), by the benchmark's force groups:
+    every atom within 1e-4 of the RMS force, mutual polarization converged to 1e-6 D on both sides; then ten steps of the benchmark's
+    MTSLangevinIntegrator (2 fs outer step, valence terms twice per step) stay at 300 K."""
+    g = golden("reference_forces_amoeba_dhfr.npz")
+    script = tmp_path / "amoeba_dhfr_child.py"
+    script.write_text(AMOEBA_DHFR_CHILD % ROOT)
+    path = str(tmp_path / "amoeba_dhfr.npz")
+    out = subprocess.run([sys.executable, str(script), path], capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    z = np.load(path)
+    assert z["native"][0] >= 1 and z["native"][1] >= 1, "the native kernels did not run"
+    for name, ref, e_ref in (("valence", g["forces_valence"].astype(np.float64), float(g["energy_valence"])),
+                             ("nonbonded", g["forces_vdw"].astype(np.float64) + g["forces_multipole"].astype(np.float64), float(g["energy_vdw"]) + float(g["energy_multipole"]))):
+        f = z["f_" + name]
+        rms = np.sqrt((ref ** 2).sum(1).mean())
+        rel = np.linalg.norm(f - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), rms)
+        print("amoeba2009 DHFR, %s: max-rel-err %.3g over %d atoms, energy %.6f vs %.6f" % (name, rel.max(), len(rel), float(z["e_" + name]), e_ref))
+        assert rel.max() < 1e-4
+        assert abs(float(z["e_" + name]) - e_ref) < 3e-6 * abs(e_ref)
+    n = len(g["forces_valence"])
+    temperature = 2 * float(z["ke_after"]) / (3 * n * 8.31446261815324e-3)
+    print("after 10 MTS steps: T = %.1f K, potential energy %.1f kJ/mol, largest displacement %.4f nm" % (temperature, float(z["e_after"]), float(z["moved"])))
+    assert np.isfinite(float(z["e_after"])) and 250 < temperature < 350 and 1e-3 < float(z["moved"]) < 0.2
+
+
 def test_amoeba_dynamics_with_list_skin_and_predicted_dipoles_walks_the_same_trajectory(tmp_path):
     """Twelve Verlet steps of a relaxed 375-atom AMOEBA water box, mutual polarization to 1e-6 D: pair lists with a Verlet skin that are
     rebuilt on displacement, the solver started from dipoles extrapolated from the previous steps and its convergence decided on the

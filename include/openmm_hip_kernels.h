@@ -419,6 +419,43 @@ int ommhip_term_forces(int kind, const ommhip_term_list* terms, const void* pos_
                        const double box[6], int periodic, const double* charge_d, double alpha,
                        long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The valence terms of the AMOEBA force field (kernels/valence.hip), one thread per term, all lists of a call in one launch.
+ * They replace the Reference kernels of the Custom*Forces that wrappers/python/openmm/app/forcefield.py builds for an AMOEBA force field
+ * (CalcCustomBondForceKernel kernels.h:311, CalcCustomAngleForceKernel :381, CalcCustomCompoundBondForceKernel :873 -- only for the energy
+ * expressions quoted below, recognised by the platform; anything else stays with the Reference kernel) and of AmoebaTorsionTorsionForce
+ * (amoebaKernels.h CalcAmoebaTorsionTorsionForceKernel; AmoebaReferenceTorsionTorsionForce.cpp:283-530).  Positions are the unwrapped
+ * double positions in atom order, no periodic boundary conditions (the reference's forces do not use them either).
+ *   POLY_BOND          atoms (1,2)          params (r0, k)                     k (d^2 + c0 d^3 + c1 d^4), d = r - r0              forcefield.py:3368
+ *   POLY_ANGLE         atoms (1,2,3)        params (theta0, k)                 k (d^2 + c0 d^3 + c1 d^4 + c2 d^5 + c3 d^6), d = c4 theta - theta0   :3502
+ *   INPLANE_ANGLE      atoms (1,2,3,4)      params (theta0, k)                 the same polynomial of the angle 1-P-3, P = atom 2 projected onto the plane 1-3-4   :3565
+ *   OUT_OF_PLANE_BEND  atoms (1,2,3,4)      params (k)                         k (t^2 + c0 t^3 + ... + c3 t^6), t = c4 x the angle at atom 4 between atom 2 and P   :3730
+ *   STRETCH_BEND       atoms (1,2,3)        params (r12, r23, theta0, k1, k2)  (k1 (r(1,2) - r12) + k2 (r(2,3) - r23)) c0 (angle(1,2,3) - theta0)   :4428
+ *   PI_TORSION         atoms (1,...,6)      params (k)                         2 k sin^2(phi), phi between the planes of the substituents of the bond 3-4   :4039
+ *   TORSION_TORSION    atoms (a,b,c,d,e,m)  params (map offset, n)             bicubic map(phi(a,b,c,d), psi(b,c,d,e)), both negated if (m,b,d) is left-handed at c; m = -1: no test
+ *                                           the term's map: grids + offset, double[n][n][6] = (angle1, angle2, f, df/d1, df/d2, d2f/d1d2), angles in degrees, equally spaced
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    OMMHIP_VALENCE_POLY_BOND = 0,
+    OMMHIP_VALENCE_POLY_ANGLE = 1,
+    OMMHIP_VALENCE_INPLANE_ANGLE = 2,
+    OMMHIP_VALENCE_OUT_OF_PLANE_BEND = 3,
+    OMMHIP_VALENCE_STRETCH_BEND = 4,
+    OMMHIP_VALENCE_PI_TORSION = 5,
+    OMMHIP_VALENCE_TORSION_TORSION = 6
+};
+#define OMMHIP_MAX_VALENCE_LISTS 8
+typedef struct ommhip_valence_list {
+    int kind;
+    int num_terms;
+    const int* atoms;          /* device int[num_terms * atomsPerTerm], atom indices */
+    const double* params;      /* device double[num_terms * paramsPerTerm] */
+    double coefficients[6];    /* c0 ... of the table above (per Force, not per term) */
+    const double* grids;       /* TORSION_TORSION only: all maps, one after the other */
+} ommhip_valence_list;
+int ommhip_valence_forces(int num_lists, const ommhip_valence_list* lists, const void* pos_d, const int* slot_of_atom_d, int padded_atoms,
+                          long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
+
 /* The front of a force evaluation in ONE launch: after ommhip_nl_prepare, (a) the neighbour-list rebuild if one was
  * requested (ommhip_nl_rebuild_if_requested), (b) the PME charge spreading (ommhip_pme_reciprocal with
  * OMMHIP_PME_SPREAD_ONLY; pme may be NULL) and (c) the per-term forces (ommhip_term_forces_multi; num_lists may be 0) are

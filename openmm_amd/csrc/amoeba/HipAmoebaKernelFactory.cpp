@@ -3,6 +3,7 @@
 #include "HipAmoebaKernels.h"
 #include "AmoebaReferenceKernelFactory.h"
 #include "openmm/AmoebaMultipoleForce.h"
+#include "openmm/AmoebaTorsionTorsionForce.h"
 #include "openmm/KernelFactory.h"
 #include "openmm/System.h"
 #include "openmm/OpenMMException.h"
@@ -18,6 +19,15 @@ public:
         HipPlatform::PlatformData& data = HipPlatform::getData(context);
         if (name == CalcAmoebaVdwForceKernel::Name())
             return new HipCalcAmoebaVdwForceKernel(name, platform, data);
+        if (name == CalcAmoebaTorsionTorsionForceKernel::Name()) {
+            const System& system = context.getSystem();
+            for (int i = 0; i < system.getNumForces(); i++) {
+                const AmoebaTorsionTorsionForce* force = dynamic_cast<const AmoebaTorsionTorsionForce*>(&system.getForce(i));
+                if (force != NULL && HipCalcAmoebaTorsionTorsionForceKernel::supports(*force))
+                    return new HipCalcAmoebaTorsionTorsionForceKernel(name, platform, data);
+            }
+            return reference.createKernelImpl(name, platform, context);
+        }
         if (name == CalcAmoebaMultipoleForceKernel::Name()) {
             // native for PME with direct polarization; everything else is the AMOEBA plugin's own Reference kernel (a fallback force:
             // HipPlatform's classification asks the same question through nativeMultipole below)
@@ -35,6 +45,11 @@ private:
     AmoebaReferenceKernelFactory reference;
 };
 
+bool nativeTorsionTorsion(const Force& force, const System& system) {
+    const AmoebaTorsionTorsionForce* tt = dynamic_cast<const AmoebaTorsionTorsionForce*>(&force);
+    return tt != NULL && HipCalcAmoebaTorsionTorsionForceKernel::supports(*tt);
+}
+
 bool nativeMultipole(const Force& force, const System& system) {
     const AmoebaMultipoleForce* mp = dynamic_cast<const AmoebaMultipoleForce*>(&force);
     return mp != NULL && HipCalcAmoebaMultipoleForceKernel::supports(*mp, system);
@@ -51,6 +66,8 @@ extern "C" __attribute__((visibility("default"))) void registerKernelFactories()
         HipAmoebaKernelFactory* factory = new HipAmoebaKernelFactory();
         HipPlatform::registerNativeKernel(CalcAmoebaVdwForceKernel::Name(), "AmoebaVdwForce", factory);
         HipPlatform::registerNativeKernel(CalcAmoebaMultipoleForceKernel::Name(), "AmoebaMultipoleForce", factory, nativeMultipole);
+        HipPlatform::registerNativeKernel(CalcAmoebaTorsionTorsionForceKernel::Name(), "AmoebaTorsionTorsionForce", factory, nativeTorsionTorsion);
+        platform.registerKernelFactory(CalcAmoebaTorsionTorsionForceKernel::Name(), factory);
         platform.registerKernelFactory(CalcAmoebaVdwForceKernel::Name(), factory);
         platform.registerKernelFactory(CalcAmoebaMultipoleForceKernel::Name(), factory);
     }

@@ -655,3 +655,60 @@ void HipCalcAmoebaMultipoleForceKernel::copyParametersToContext(ContextImpl& con
 void HipCalcAmoebaMultipoleForceKernel::getPMEParameters(double& alpha, int& nx, int& ny, int& nz) const {
     alpha = alphaEwald; nx = gridSize[0]; ny = gridSize[1]; nz = gridSize[2];
 }
+
+
+// ================================================================================================
+// AmoebaTorsionTorsionForce
+// ================================================================================================
+bool HipCalcAmoebaTorsionTorsionForceKernel::supports(const AmoebaTorsionTorsionForce& force) {
+    static const bool off = getenv("OPENMM_HIP_REFERENCE_CUSTOM_FORCES") != NULL && getenv("OPENMM_HIP_REFERENCE_CUSTOM_FORCES")[0] == '1';      // A/B knob, as for the Custom*Forces
+    if (off || force.usesPeriodicBoundaryConditions() || force.getNumTorsionTorsionGrids() == 0) return false;
+    for (int g = 0; g < force.getNumTorsionTorsionGrids(); g++) {
+        const TorsionTorsionGrid& grid = force.getTorsionTorsionGrid(g);
+        if (grid.size() == 0) continue;                           // an index nobody defined
+        if (grid.size() < 2) return false;
+        for (size_t x = 0; x < grid.size(); x++) {
+            if (grid[x].size() != grid.size()) return false;
+            for (size_t y = 0; y < grid.size(); y++)
+                if (grid[x][y].size() != 6) return false;
+        }
+        if (grid[1][0][0] == grid[0][0][0]) return false;       // first index must run along the first angle
+    }
+    return true;
+}
+
+void HipCalcAmoebaTorsionTorsionForceKernel::initialize(const System& system, const AmoebaTorsionTorsionForce& force) {
+    if (!supports(force)) throw OpenMMException("HIP platform: internal error, an AmoebaTorsionTorsionForce the native kernel does not take reached it");
+    // the maps with the spline derivatives the Force computed (AmoebaTorsionTorsionForce.cpp:113-190), one after the other:
+    // [x][y][angle1, angle2, f, fx, fy, fxy]
+    vector<double> grids;
+    vector<size_t> offset;
+    vector<int> size;
+    for (int g = 0; g < force.getNumTorsionTorsionGrids(); g++) {
+        const TorsionTorsionGrid& grid = force.getTorsionTorsionGrid(g);
+        offset.push_back(grids.size());
+        size.push_back((int) grid.size());
+        for (size_t x = 0; x < grid.size(); x++)
+            for (size_t y = 0; y < grid.size(); y++)
+                grids.insert(grids.end(), grid[x][y].begin(), grid[x][y].end());
+    }
+    vector<int> atoms; vector<double> params;
+    for (int i = 0; i < force.getNumTorsionTorsions(); i++) {
+        int p[5], chiral, grid;
+        force.getTorsionTorsionParameters(i, p[0], p[1], p[2], p[3], p[4], chiral, grid);
+        if (grid < 0 || grid >= force.getNumTorsionTorsionGrids() || size[grid] < 2) throw OpenMMException("AmoebaTorsionTorsionForce: a torsion-torsion refers to a grid that was not set");
+        atoms.insert(atoms.end(), p, p + 5);
+        atoms.push_back(chiral);
+        params.push_back((double) offset[grid]);
+        params.push_back(size[grid]);
+    }
+    HipValenceForm form;
+    form.kind = OMMHIP_VALENCE_TORSION_TORSION;
+    terms.upload(form, 6, atoms, params);
+    terms.uploadGrids(grids);
+}
+
+double HipCalcAmoebaTorsionTorsionForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy) {
+    terms.execute(includeEnergy);
+    return 0.0;
+}

@@ -7,6 +7,8 @@
  * implementation it is checked against.
  */
 #include "HipPlatform.h"
+#include "HipValenceKernels.h"
+#include "openmm/AmoebaTorsionTorsionForce.h"
 #include "HipContext.h"
 #include "openmm/amoebaKernels.h"
 #include "openmm_hip_amoeba.h"
@@ -40,6 +42,20 @@ private:
     long long listOrderVersion = -1, listBoxVersion = -1;
     DeviceBuffer refPos, listState;
     DeviceBuffer parent, reduction, type, sigma, epsilon, exclStart, exclAtoms, alchemical, reduced, tileBounds, exclPos, pairList, pairCount, pairOverflow;
+};
+
+/** amoebaKernels.h:49-77 CalcAmoebaTorsionTorsionForceKernel; Reference: AmoebaReferenceKernels.cpp (ReferenceCalcAmoebaTorsionTorsionForceKernel) +
+ *  AmoebaReferenceTorsionTorsionForce.cpp:283-530.  One list of kernels/valence.hip (OMMHIP_VALENCE_TORSION_TORSION): it goes out in the same
+ *  launch as the other AMOEBA valence terms (HipContext::addValence). */
+class HipCalcAmoebaTorsionTorsionForceKernel : public CalcAmoebaTorsionTorsionForceKernel {
+public:
+    HipCalcAmoebaTorsionTorsionForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : CalcAmoebaTorsionTorsionForceKernel(name, platform), terms(data) {}
+    void initialize(const System& system, const AmoebaTorsionTorsionForce& force);
+    double execute(ContextImpl& context, bool includeForces, bool includeEnergy);
+    /** Can the native kernel take this Force?  (all maps square, of one size, with derivatives; no periodic boundary conditions) */
+    static bool supports(const AmoebaTorsionTorsionForce& force);
+private:
+    HipValenceTerms terms;
 };
 
 /** amoebaKernels.h:82-139 CalcAmoebaMultipoleForceKernel for PME with direct, mutual or extrapolated polarization; Reference: AmoebaReferenceKernels.cpp:170-520 +

@@ -418,6 +418,27 @@ void HipContext::flushTerms() {
     pendingTermIds.clear();
 }
 
+void HipContext::addValence(const ommhip_valence_list& list, bool includeEnergy) {
+    if (list.num_terms <= 0) return;
+    if (!pendingValence.empty() && (pendingValenceEnergy != includeEnergy || pendingValence.size() == OMMHIP_MAX_VALENCE_LISTS))
+        flushValence();
+    pendingValenceEnergy = includeEnergy;
+    pendingValence.push_back(list);
+}
+
+static long long valenceListsLaunched = 0;
+/* test hook: lists of kernels/valence.hip launched by this process so far */
+extern "C" __attribute__((visibility("default"))) long long ommhip_plugin_valence_lists_launched() { return valenceListsLaunched; }
+
+void HipContext::flushValence() {
+    if (pendingValence.empty()) return;
+    ensureCleared();
+    valenceListsLaunched += (long long) pendingValence.size();
+    HIP_CHECK(ommhip_valence_forces((int) pendingValence.size(), pendingValence.data(), pos.ptr, slotOfAtom.as<int>(), paddedAtoms,
+                                    force.as<long long>(), energyBuffer.as<double>(), EnergySlots, pendingValenceEnergy ? 1 : 0, stream));
+    pendingValence.clear();
+}
+
 void HipContext::stampOwnership(ommhip_term_batch& batch) const {
     // halo mode: a rank evaluates the terms that touch its atoms and counts the energy of those whose first atom it owns (bonded.hip)
     batch.own_slot0 = batch.own_slot1 = 0;

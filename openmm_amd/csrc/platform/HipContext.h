@@ -140,6 +140,9 @@ public:
     void noteEarlyWorkLaunched(int id) { launchedEarlyIds.push_back(id); }
     void launchEarlyWork(ContextImpl& context, bool includeForces, bool includeEnergy);
     void flushTerms();
+    /** The same for the lists of kernels/valence.hip (the AMOEBA valence terms): queued by their Forces, one launch per evaluation. */
+    void addValence(const ommhip_valence_list& list, bool includeEnergy);
+    void flushValence();
     void saveForces();                                         // device copy of the force buffer (energy-only evaluations)
     void restoreForces();
     double reduceEnergy();                                      // blocking; also zeroes the buffer
@@ -290,6 +293,8 @@ private:
     std::vector<ommhip_term_batch> pendingTerms;
     std::vector<int> pendingTermIds;
     bool pendingTermsEnergy = false;
+    std::vector<ommhip_valence_list> pendingValence;
+    bool pendingValenceEnergy = false;
     struct TermRegistration { int id, group; ommhip_term_batch batch; };
     std::vector<TermRegistration> termRegistry;
     std::vector<int> launchedTermIds;          // ids whose terms already went out this evaluation (fused front launch)

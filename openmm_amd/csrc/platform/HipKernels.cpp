@@ -385,6 +385,7 @@ double HipCalcForcesAndEnergyKernel::finishComputation(ContextImpl& context, boo
     HipContext& hip = *data.hip;
     hip.ensureCleared();          // nobody folded the start-of-evaluation clear into a launch of its own
     hip.flushTerms();
+    hip.flushValence();
     hip.joinPme();
     if (hip.decomposed()) hip.returnHaloForces();      // half-shell evaluation: what this rank computed on its lower neighbour's atoms goes home (same call order on every rank)
     double energy = 0;

@@ -10,6 +10,7 @@
 #include <vector>
 #include "HipContext.h"
 #include "HipKernels.h"
+#include "HipValenceKernels.h"
 #include "ReferenceKernelFactory.h"
 #include "openmm/Context.h"
 #include "openmm/KernelFactory.h"
@@ -54,6 +55,7 @@ struct HipModeInfo {
     bool referenceNonbonded;     // LJPME: NonbondedForce itself falls back to Reference
     bool hasFallbackForces;
     bool hasPluginNativeForces;  // forces evaluated by a native kernel of another plugin (registerNativeKernel), e.g. the AMOEBA forces
+    bool hasValenceForces;       // Custom*Forces with a recognised expression (the AMOEBA valence terms): native, single GPU only
 };
 
 namespace {
@@ -77,7 +79,7 @@ bool HipPlatform::isNativeForce(const Force& force, const System& system) {
 }
 
 static HipModeInfo classifyContext(ContextImpl& context) {
-    HipModeInfo info = {false, false, false, false, false};
+    HipModeInfo info = {false, false, false, false, false, false};
     const System& system = context.getSystem();
     const Integrator& integrator = context.getIntegrator();
     if (dynamic_cast<const VerletIntegrator*>(&integrator) == NULL && dynamic_cast<const LangevinIntegrator*>(&integrator) == NULL &&
@@ -110,6 +112,10 @@ static HipModeInfo classifyContext(ContextImpl& context) {
             info.hasPluginNativeForces = true;       // a native kernel from a plugin of its own (registerNativeKernel)
             continue;
         }
+        if (HipValenceForm::isNative(f)) {
+            info.hasValenceForces = true;            // a Custom*Force whose expression has a hand-written kernel (HipValenceKernels.h)
+            continue;
+        }
         // Any other Force: its Reference kernel only reads positions and adds forces.
         info.hasFallbackForces = true;
     }
@@ -133,6 +139,13 @@ public:
             return new HipCalcHarmonicAngleForceKernel(name, platform, data);
         if (name == CalcPeriodicTorsionForceKernel::Name())
             return new HipCalcPeriodicTorsionForceKernel(name, platform, data);
+        // Custom*Forces: native for the expressions of the AMOEBA valence terms, the Reference kernel (held inside) for everything else
+        if (name == CalcCustomBondForceKernel::Name())
+            return new HipCalcCustomBondForceKernel(name, platform, data, reference.createKernelImpl(name, platform, context));
+        if (name == CalcCustomAngleForceKernel::Name())
+            return new HipCalcCustomAngleForceKernel(name, platform, data, reference.createKernelImpl(name, platform, context));
+        if (name == CalcCustomCompoundBondForceKernel::Name())
+            return new HipCalcCustomCompoundBondForceKernel(name, platform, data, reference.createKernelImpl(name, platform, context));
         if (!hostMode) {
             if (name == UpdateStateDataKernel::Name())
                 return new HipUpdateStateDataKernel(name, platform, data);
@@ -176,6 +189,9 @@ HipPlatform::HipPlatform() {
     registerKernelFactory(CalcHarmonicBondForceKernel::Name(), factory);
     registerKernelFactory(CalcHarmonicAngleForceKernel::Name(), factory);
     registerKernelFactory(CalcPeriodicTorsionForceKernel::Name(), factory);
+    registerKernelFactory(CalcCustomBondForceKernel::Name(), factory);
+    registerKernelFactory(CalcCustomAngleForceKernel::Name(), factory);
+    registerKernelFactory(CalcCustomCompoundBondForceKernel::Name(), factory);
     registerKernelFactory(IntegrateVerletStepKernel::Name(), factory);
     registerKernelFactory(IntegrateLangevinStepKernel::Name(), factory);
     registerKernelFactory(IntegrateLangevinMiddleStepKernel::Name(), factory);
@@ -260,6 +276,8 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
     if (domain.ranks > 1 || !commId.empty()) {
         // Kernels of other plugins (the AMOEBA forces) know nothing of the decomposition: each rank would evaluate the whole system
         // from positions that are current only for its own atoms and its halo, and add the full energy on every rank.
+        if (mode.hasValenceForces)
+            throw OpenMMException("HIP platform: a multi-GPU Context cannot hold the Custom*Forces of an AMOEBA force field (their native kernels evaluate the whole system on one GPU)");
         if (mode.hasPluginNativeForces)
             throw OpenMMException("HIP platform: a multi-GPU Context cannot hold forces whose native kernels come from another plugin (AmoebaVdwForce, AmoebaMultipoleForce): they evaluate the whole system on one GPU");
         if (mode.hostMode || mode.hasFallbackForces || mode.referenceNonbonded)

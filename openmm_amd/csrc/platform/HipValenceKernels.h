@@ -1,0 +1,94 @@
+#ifndef OPENMM_HIP_VALENCE_KERNELS_H_
+#define OPENMM_HIP_VALENCE_KERNELS_H_
+/* Native kernels for the Custom*Forces an AMOEBA force field is made of.  The reference's platforms compile ANY energy expression at run
+ * time (CUDA: nvrtc); this platform has hand-written kernels (kernels/valence.hip) for the expressions that
+ * wrappers/python/openmm/app/forcefield.py writes for the AMOEBA valence terms, recognises those expressions (HipValenceForm) and leaves
+ * every other Custom*Force to its Reference kernel as a fallback force.  A kernel object learns which Force it serves only in
+ * initialize(), so each of the classes below carries the Reference kernel and hands everything over to it when the expression is not one
+ * of the known forms (HipPlatform's classification asks the same question, HipValenceForm::isNative, to decide whether the Context has
+ * fallback forces). */
+#include "HipPlatform.h"
+#include "HipContext.h"
+#include "openmm/CustomAngleForce.h"
+#include "openmm/CustomBondForce.h"
+#include "openmm/CustomCompoundBondForce.h"
+#include "openmm/kernels.h"
+#include <string>
+#include <vector>
+
+namespace OpenMM {
+
+/** What an energy expression was recognised as: the kind of kernels/valence.hip, its per-Force coefficients, and where each per-term
+ *  parameter of the kernel is found among the Force's per-bond parameters. */
+struct HipValenceForm {
+    int kind;                       // OMMHIP_VALENCE_*, -1: not recognised
+    double coefficients[6];
+    std::vector<int> paramIndex;    // kernel parameter p = per-bond parameter paramIndex[p] of the Force
+    HipValenceForm() : kind(-1) { for (int i = 0; i < 6; i++) coefficients[i] = 0; }
+    static HipValenceForm recognise(const CustomBondForce& force);
+    static HipValenceForm recognise(const CustomAngleForce& force);
+    static HipValenceForm recognise(const CustomCompoundBondForce& force);
+    /** Is this Force one of the three classes above with a recognised expression? */
+    static bool isNative(const Force& force);
+};
+
+/** One list of terms on the device and its launch (through HipContext::addValence: all lists of an evaluation share a launch). */
+class HipValenceTerms {
+public:
+    HipValenceTerms(HipPlatform::PlatformData& data) : data(data), numTerms(0) {}
+    void upload(const HipValenceForm& form, int atomsPerTerm, const std::vector<int>& atoms, const std::vector<double>& params);
+    void uploadParams(const std::vector<double>& params);
+    void uploadGrids(const std::vector<double>& grids);
+    void execute(bool includeEnergy);
+private:
+    HipPlatform::PlatformData& data;
+    HipValenceForm form;
+    int numTerms, paramsPerTerm = 0;
+    DeviceBuffer atomsD, paramsD, gridsD;
+};
+
+class HipCalcCustomBondForceKernel : public CalcCustomBondForceKernel {
+public:
+    HipCalcCustomBondForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data, KernelImpl* referenceKernel) : CalcCustomBondForceKernel(name, platform), reference(dynamic_cast<CalcCustomBondForceKernel*>(referenceKernel)), terms(data) {}
+    ~HipCalcCustomBondForceKernel() { delete reference; }
+    void initialize(const System& system, const CustomBondForce& force);
+    double execute(ContextImpl& context, bool includeForces, bool includeEnergy);
+    void copyParametersToContext(ContextImpl& context, const CustomBondForce& force);
+private:
+    void collect(const CustomBondForce& force, std::vector<int>* atoms, std::vector<double>& params) const;
+    CalcCustomBondForceKernel* reference;      // the Reference kernel: every expression without a native form is its business (a fallback force), owned
+    HipValenceForm form;
+    HipValenceTerms terms;
+};
+
+class HipCalcCustomAngleForceKernel : public CalcCustomAngleForceKernel {
+public:
+    HipCalcCustomAngleForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data, KernelImpl* referenceKernel) : CalcCustomAngleForceKernel(name, platform), reference(dynamic_cast<CalcCustomAngleForceKernel*>(referenceKernel)), terms(data) {}
+    ~HipCalcCustomAngleForceKernel() { delete reference; }
+    void initialize(const System& system, const CustomAngleForce& force);
+    double execute(ContextImpl& context, bool includeForces, bool includeEnergy);
+    void copyParametersToContext(ContextImpl& context, const CustomAngleForce& force);
+private:
+    void collect(const CustomAngleForce& force, std::vector<int>* atoms, std::vector<double>& params) const;
+    CalcCustomAngleForceKernel* reference;      // the Reference kernel: every expression without a native form is its business (a fallback force), owned
+    HipValenceForm form;
+    HipValenceTerms terms;
+};
+
+class HipCalcCustomCompoundBondForceKernel : public CalcCustomCompoundBondForceKernel {
+public:
+    HipCalcCustomCompoundBondForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data, KernelImpl* referenceKernel) : CalcCustomCompoundBondForceKernel(name, platform), reference(dynamic_cast<CalcCustomCompoundBondForceKernel*>(referenceKernel)), terms(data) {}
+    ~HipCalcCustomCompoundBondForceKernel() { delete reference; }
+    void initialize(const System& system, const CustomCompoundBondForce& force);
+    double execute(ContextImpl& context, bool includeForces, bool includeEnergy);
+    void copyParametersToContext(ContextImpl& context, const CustomCompoundBondForce& force);
+private:
+    void collect(const CustomCompoundBondForce& force, std::vector<int>* atoms, std::vector<double>& params) const;
+    CalcCustomCompoundBondForceKernel* reference;      // the Reference kernel: every expression without a native form is its business (a fallback force), owned
+    HipValenceForm form;
+    HipValenceTerms terms;
+};
+
+}  // namespace OpenMM
+
+#endif

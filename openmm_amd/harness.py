@@ -81,6 +81,13 @@ def domain_info():
     return [int(v) for v in out[:8]]
 
 
+def valence_lists_launched():
+    """Lists of kernels/valence.hip (AMOEBA valence terms) launched so far by the loaded HIP plugin."""
+    plugin = C.CDLL(next(p for p in _loaded_plugins if p.endswith("libOpenMMHIP.so")))
+    plugin.ommhip_plugin_valence_lists_launched.restype = C.c_longlong
+    return int(plugin.ommhip_plugin_valence_lists_launched())
+
+
 def load_hip_platform(emulated=False):
     """Register the HIP platform through OpenMM's plugin loader.  Raises if the plugin is missing."""
     path = os.path.join(EMU_DIR if emulated else LIB_DIR, "libOpenMMHIP.so")

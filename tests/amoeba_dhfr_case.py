@@ -30,7 +30,7 @@ for plat in ("Reference", "HIP"):
     st = ctx.getState(getPositions=True, getVelocities=True, getEnergy=True)
     out[plat + "_pos"], out[plat + "_vel"], out[plat + "_ke"] = st.positions, st.velocities, st.kineticEnergy
     if plat == "HIP":
-        out["native"] = np.array(H.amoeba_native_evaluations())
+        out["native"] = np.array(list(H.amoeba_native_evaluations()) + [H.valence_lists_launched()])
     ctx.close()
 np.savez(sys.argv[1], **out)
 '''
@@ -38,7 +38,7 @@ np.savez(sys.argv[1], **out)
 
 def run_amoeba_dhfr_case(tmp_path, emulated, atoms=2489, steps=3):
     """-> dict: worst force difference relative to the RMS force and relative energy difference per group, largest position / velocity
-    difference after `steps` MTS Langevin steps, native evaluation counts (vdw, multipole)"""
+    difference after `steps` MTS Langevin steps, native evaluation counts (vdw, multipole, lists of AMOEBA valence terms)"""
     import numpy as np
     script = tmp_path / "amoeba_dhfr_child.py"
     script.write_text(CHILD % (ROOT, emulated, atoms, steps, ROOT))

@@ -323,6 +323,7 @@ def test_amoeba2009_dhfr_solute_forces_and_mts_langevin_steps_against_reference_
     r = run_amoeba_dhfr_case(tmp_path, True)
     print(r)
     assert r["native"][0] >= 1 and r["native"][1] >= 1, "the native AMOEBA kernels did not run"
+    assert r["native"][2] >= 7, "the native kernels of the valence terms (bond, angle, in-plane angle, out-of-plane bend, stretch-bend, pi-torsion, torsion-torsion) did not run"
     assert r["force_valence"] < 1e-6 and r["energy_valence"] < 1e-9
     assert r["force_nonbonded"] < 2e-4 and r["energy_nonbonded"] < 1e-5
     assert r["dpos"] < 2e-6 and r["dvel"] < 2e-3

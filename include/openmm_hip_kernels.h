@@ -556,6 +556,56 @@ int ommhip_shifted_velocities(const ommhip_integrator_state* s, double shift, vo
 #define OMMHIP_KE_SCRATCH 1024
 int ommhip_kinetic_energy(const void* vel_d, const int* atom_of_slot_d, int first, int end, double* scratch_d, double* result_d, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * CustomIntegrator on the device (kernels/custom_integrator.hip).  Replaces the per-degree-of-freedom work of IntegrateCustomStepKernel
+ * (kernels.h:1329-1395; Reference: ReferenceCustomDynamics.cpp:227-370 update(), :357-380 computePerDof()).  The reference's GPU platforms
+ * turn every expression into source code and compile it at run time; here an expression becomes a short postfix program
+ * (ommhip_vm_instruction, translated by the platform from the Lepton expression tree) that one thread per atom interprets for its three
+ * degrees of freedom, in double precision.  Several consecutive ComputePerDof steps travel in ONE launch (a thread only ever touches its
+ * own atom, so they need no barrier between them).
+ *   variables of a program: x, v, f (the force array given with the step), m, gaussian, uniform, the per-DOF variables, and the global
+ *   variables (device array, the platform keeps it current)
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    OMMHIP_VM_CONSTANT = 0,     /* push value */
+    OMMHIP_VM_VARIABLE = 1,     /* push variable arg: 0 x, 1 v, 2 f, 3 m, 4 gaussian, 5 uniform, 6 + k: per-DOF variable k */
+    OMMHIP_VM_GLOBAL = 2,       /* push globals[arg] */
+    /* the operations of Lepton (libraries/lepton/include/lepton/Operation.h:65-67), in its order */
+    OMMHIP_VM_ADD = 3, OMMHIP_VM_SUBTRACT, OMMHIP_VM_MULTIPLY, OMMHIP_VM_DIVIDE, OMMHIP_VM_POWER, OMMHIP_VM_NEGATE, OMMHIP_VM_SQRT, OMMHIP_VM_EXP, OMMHIP_VM_LOG,
+    OMMHIP_VM_SIN, OMMHIP_VM_COS, OMMHIP_VM_SEC, OMMHIP_VM_CSC, OMMHIP_VM_TAN, OMMHIP_VM_COT, OMMHIP_VM_ASIN, OMMHIP_VM_ACOS, OMMHIP_VM_ATAN, OMMHIP_VM_ATAN2,
+    OMMHIP_VM_SINH, OMMHIP_VM_COSH, OMMHIP_VM_TANH, OMMHIP_VM_ERF, OMMHIP_VM_ERFC, OMMHIP_VM_STEP, OMMHIP_VM_DELTA, OMMHIP_VM_SQUARE, OMMHIP_VM_CUBE, OMMHIP_VM_RECIPROCAL,
+    OMMHIP_VM_ADD_CONSTANT, OMMHIP_VM_MULTIPLY_CONSTANT, OMMHIP_VM_POWER_CONSTANT, OMMHIP_VM_MIN, OMMHIP_VM_MAX, OMMHIP_VM_ABS, OMMHIP_VM_FLOOR, OMMHIP_VM_CEIL, OMMHIP_VM_SELECT
+};
+#define OMMHIP_VM_STACK 16           /* deepest stack a program may need */
+#define OMMHIP_VM_MAX_STEPS 8        /* ComputePerDof steps per launch */
+typedef struct ommhip_vm_instruction {
+    int op, arg;
+    double value;               /* CONSTANT, ADD_CONSTANT, MULTIPLY_CONSTANT, POWER_CONSTANT */
+} ommhip_vm_instruction;
+typedef struct ommhip_vm_step {
+    int first, count;           /* instructions [first, first + count) of the program array */
+    int target;                 /* 0: x, 1: v, 2 + k: per-DOF variable k, -1: the sum of the values over all degrees of freedom -> *sum_result */
+    int uses_random;            /* bit 0: gaussian, bit 1: uniform */
+    const double* force;        /* double[3 * num_atoms], atom order (ommhip_forces_to_atom_order), or NULL if f does not occur */
+    unsigned long long draw;    /* the random numbers of this step are a function of (seed, draw, atom) */
+} ommhip_vm_step;
+typedef struct ommhip_vm_state {
+    int num_atoms, num_per_dof;
+    void* pos;                  /* double4[num_atoms] */
+    void* vel;                  /* double4[num_atoms], w = 1 / m (0: a massless particle, skipped as in the reference) */
+    double* per_dof;            /* double[num_per_dof][3 * num_atoms] */
+    const double* globals;      /* device double[...] */
+    const ommhip_vm_instruction* program;   /* device */
+    unsigned long long seed;
+    double* sum_scratch;        /* device double[OMMHIP_KE_SCRATCH]; target -1 only */
+    double* sum_result;         /* device double */
+} ommhip_vm_state;
+/* steps[0 .. num_steps) one after the other for every degree of freedom; a step with target -1 must be the only one of its launch */
+int ommhip_vm_per_dof(const ommhip_vm_state* state, int num_steps, const ommhip_vm_step* steps, void* stream);
+/* fixed-point forces in slot order -> double[3 * num_atoms] in atom order (a copy the integrator can keep per force group while other
+ * groups are evaluated and atoms are re-sorted) */
+int ommhip_forces_to_atom_order(const long long* force_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, double* out_d, void* stream);
+
 /* SETTLE: atoms_d int4[n] (apex,b,c,-), dist_d double2[n] (apex-leg, base).  velocities=0: corrects
  * target_d (trial positions) against pos_d; velocities=1: corrects target_d (velocities). */
 int ommhip_settle(int num_clusters, const int* atoms_d, const double* dist_d, const void* pos_d, void* target_d,

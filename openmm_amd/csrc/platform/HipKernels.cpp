@@ -319,14 +319,14 @@ void HipConstraints::fusedStep(int integrator, const ommhip_integrator_state& st
     hip.momentumValid = true;
 }
 
-void HipConstraints::runCcma(void* target, bool velocities, double tol) {
+void HipConstraints::runCcma(void* target, bool velocities, double tol, void* reference) {
     // ReferenceCCMAAlgorithm.cpp:240-310 as a device-resident loop: batches of four iterations are enqueued without waiting;
     // the kernels of an iteration leave at once when an earlier one found every constraint converged, and the host looks at that
     // flag once per batch (the reference's GPU platforms poll a mapped flag every few iterations, CudaIntegrationUtilities.cpp:94-130).
     HIP_CHECK(ommhip_memset(ccma.converged, 0, sizeof(int) * 4, hip.stream));
     const int batch = 4;
     for (int done = 0; done < 150; done += batch) {
-        HIP_CHECK(ommhip_ccma_iterations(&ccma, hip.pos.ptr, target, hip.vel.ptr, velocities ? 1 : 0, tol, batch, hip.stream));
+        HIP_CHECK(ommhip_ccma_iterations(&ccma, reference, target, hip.vel.ptr, velocities ? 1 : 0, tol, batch, hip.stream));
         int state[4] = {0, 0, 0, 0};
         HIP_CHECK(ommhip_memcpy_d2h(state, ccma.converged, sizeof(state), hip.stream));
         hip.sync();
@@ -334,16 +334,18 @@ void HipConstraints::runCcma(void* target, bool velocities, double tol) {
     }
 }
 
-void HipConstraints::apply(void* target, double tol) {
-    if (numCcma > 0) runCcma(target, false, tol);
+void HipConstraints::apply(void* target, double tol, void* reference) {
+    if (reference == NULL) reference = hip.pos.ptr;
+    if (numCcma > 0) runCcma(target, false, tol, reference);
     HIP_CHECK(ommhip_constrain_clusters(numShake, shakeAtoms.as<int>(), shakeDist.as<double>(), numSettle, settleAtoms.as<int>(), settleDist.as<double>(),
-                                        hip.pos.ptr, target, hip.vel.ptr, 0, tol, 150, hip.stream));
+                                        reference, target, hip.vel.ptr, 0, tol, 150, hip.stream));
 }
 
-void HipConstraints::applyToVelocities(void* target, double tol) {
-    if (numCcma > 0) runCcma(target, true, tol);
+void HipConstraints::applyToVelocities(void* target, double tol, void* reference) {
+    if (reference == NULL) reference = hip.pos.ptr;
+    if (numCcma > 0) runCcma(target, true, tol, reference);
     HIP_CHECK(ommhip_constrain_clusters(numShake, shakeAtoms.as<int>(), shakeDist.as<double>(), numSettle, settleAtoms.as<int>(), settleDist.as<double>(),
-                                        hip.pos.ptr, target, hip.vel.ptr, 1, tol, 150, hip.stream));
+                                        reference, target, hip.vel.ptr, 1, tol, 150, hip.stream));
 }
 
 // ================================================================================================

@@ -26,9 +26,10 @@ public:
     void boxChanged() {}
     void positionsSet() {}
     /** Constrain trial positions `target` (double4[N]) against the reference positions ctx.pos. */
-    void apply(void* target, double tol);
+    /** reference: the constrained positions the directions are taken from; NULL = the Context's current positions */
+    void apply(void* target, double tol, void* reference = NULL);
     /** Remove constrained components from velocities `target` (double4[N], w = 1/m). */
-    void applyToVelocities(void* target, double tol);
+    void applyToVelocities(void* target, double tol, void* reference = NULL);
     bool hasConstraints() const { return numSettle + numShake + numCcma > 0; }
     /** True when every constraint sits in a SETTLE water or a SHAKE cluster, so a whole step fits one launch
      *  (ommhip_integrate_fused); OPENMM_HIP_DISABLE_FUSED_STEP=1 forces the staged kernels. */
@@ -47,7 +48,7 @@ private:
     int numUnits;
     double totalMass;
     DeviceBuffer unitAtoms, unitDist, cmScratch;
-    void runCcma(void* target, bool velocities, double tol);
+    void runCcma(void* target, bool velocities, double tol, void* reference);
     HipContext& hip;
     int numSettle, numShake, numCcma;
     DeviceBuffer settleAtoms, settleDist, shakeAtoms, shakeDist;

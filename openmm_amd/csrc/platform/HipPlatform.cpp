@@ -11,6 +11,7 @@
 #include "HipContext.h"
 #include "HipKernels.h"
 #include "HipValenceKernels.h"
+#include "HipCustomIntegrator.h"
 #include "ReferenceKernelFactory.h"
 #include "openmm/Context.h"
 #include "openmm/KernelFactory.h"
@@ -56,6 +57,7 @@ struct HipModeInfo {
     bool hasFallbackForces;
     bool hasPluginNativeForces;  // forces evaluated by a native kernel of another plugin (registerNativeKernel), e.g. the AMOEBA forces
     bool hasValenceForces;       // Custom*Forces with a recognised expression (the AMOEBA valence terms): native, single GPU only
+    bool customIntegrator;       // a CustomIntegrator run by the device interpreter (single GPU only)
 };
 
 namespace {
@@ -79,12 +81,16 @@ bool HipPlatform::isNativeForce(const Force& force, const System& system) {
 }
 
 static HipModeInfo classifyContext(ContextImpl& context) {
-    HipModeInfo info = {false, false, false, false, false, false};
+    HipModeInfo info = {false, false, false, false, false, false, false};
     const System& system = context.getSystem();
     const Integrator& integrator = context.getIntegrator();
     if (dynamic_cast<const VerletIntegrator*>(&integrator) == NULL && dynamic_cast<const LangevinIntegrator*>(&integrator) == NULL &&
-            dynamic_cast<const LangevinMiddleIntegrator*>(&integrator) == NULL)
-        info.hostMode = true;
+            dynamic_cast<const LangevinMiddleIntegrator*>(&integrator) == NULL) {
+        // a CustomIntegrator whose expressions all have a device form runs natively (HipCustomIntegrator.h); anything else integrates on the host
+        const CustomIntegrator* custom = dynamic_cast<const CustomIntegrator*>(&integrator);
+        if (custom == NULL || !HipIntegrateCustomStepKernel::supports(*custom)) info.hostMode = true;
+        else info.customIntegrator = true;
+    }
     for (int i = 0; i < system.getNumParticles(); i++)
         if (system.isVirtualSite(i)) info.hostMode = true;
     for (int i = 0; i < system.getNumForces(); i++) {
@@ -159,6 +165,8 @@ public:
                 return new HipIntegrateLangevinStepKernel(name, platform, data);
             if (name == IntegrateLangevinMiddleStepKernel::Name())
                 return new HipIntegrateLangevinMiddleStepKernel(name, platform, data);
+            if (name == IntegrateCustomStepKernel::Name())
+                return new HipIntegrateCustomStepKernel(name, platform, data);
             if (name == RemoveCMMotionKernel::Name())
                 return new HipRemoveCMMotionKernel(name, platform, data);
             if (name == ApplyMonteCarloBarostatKernel::Name())
@@ -195,6 +203,7 @@ HipPlatform::HipPlatform() {
     registerKernelFactory(IntegrateVerletStepKernel::Name(), factory);
     registerKernelFactory(IntegrateLangevinStepKernel::Name(), factory);
     registerKernelFactory(IntegrateLangevinMiddleStepKernel::Name(), factory);
+    registerKernelFactory(IntegrateCustomStepKernel::Name(), factory);
     registerKernelFactory(RemoveCMMotionKernel::Name(), factory);
     registerKernelFactory(ApplyMonteCarloBarostatKernel::Name(), factory);
     platformProperties.push_back(HipDeviceIndex());
@@ -202,10 +211,12 @@ HipPlatform::HipPlatform() {
     platformProperties.push_back(HipPrecision());
     platformProperties.push_back(HipDeterministicForces());
     platformProperties.push_back(HipDisablePmeStream());
+    platformProperties.push_back(HipIntegrationMode());
     platformProperties.push_back(HipRanks());
     platformProperties.push_back(HipRank());
     platformProperties.push_back(HipCommId());
     setPropertyDefaultValue(HipRanks(), "1");
+    setPropertyDefaultValue(HipIntegrationMode(), "");
     setPropertyDefaultValue(HipRank(), "0");
     setPropertyDefaultValue(HipCommId(), "");
     setPropertyDefaultValue(HipDeviceIndex(), "");
@@ -276,6 +287,8 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
     if (domain.ranks > 1 || !commId.empty()) {
         // Kernels of other plugins (the AMOEBA forces) know nothing of the decomposition: each rank would evaluate the whole system
         // from positions that are current only for its own atoms and its halo, and add the full energy on every rank.
+        if (mode.customIntegrator)
+            throw OpenMMException("HIP platform: a multi-GPU Context supports the Verlet, Langevin and LangevinMiddle integrators (a CustomIntegrator runs on one GPU)");
         if (mode.hasValenceForces)
             throw OpenMMException("HIP platform: a multi-GPU Context cannot hold the Custom*Forces of an AMOEBA force field (their native kernels evaluate the whole system on one GPU)");
         if (mode.hasPluginNativeForces)
@@ -327,6 +340,7 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
     ommhip_device_info(deviceIndex, name, 256, NULL, NULL);
     data->propertyValues[HipDeviceName()] = name;
     data->propertyValues[HipPrecision()] = "mixed";
+    data->propertyValues[HipIntegrationMode()] = mode.hostMode ? "host" : (mode.customIntegrator ? "device, custom integrator" : "device");
     data->propertyValues[HipDeterministicForces()] = (properties.find(HipDeterministicForces()) == properties.end() ?
             getPropertyDefaultValue(HipDeterministicForces()) : properties.find(HipDeterministicForces())->second);
     data->propertyValues[HipDisablePmeStream()] = (properties.find(HipDisablePmeStream()) == properties.end() ?

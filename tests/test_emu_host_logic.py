@@ -250,7 +250,8 @@ def test_pme_logic(K, tric):
 
 FAST_REFERENCE_TESTS = ["HarmonicBondForce", "HarmonicAngleForce", "PeriodicTorsionForce", "CMMotionRemover", "Checkpoints",
                         "CustomBondForce", "RBTorsionForce", "Settle", "NonbondedForce", "CustomExternalForce", "VirtualSites",
-                        "AmoebaVdwForce", "AmoebaMultipoleForce", "AmoebaTorsionTorsionForce", "AmoebaExtrapolatedPolarization"]
+                        "AmoebaVdwForce", "AmoebaMultipoleForce", "AmoebaTorsionTorsionForce", "AmoebaExtrapolatedPolarization",
+                        "CustomAngleForce", "CustomCompoundBondForce"]
 
 
 @needs_emu
@@ -289,6 +290,22 @@ def test_native_amoeba_multipole_kernel_matches_the_plugins_reference_kernel():
 
 
 @needs_emu
+def test_reference_custom_integrator_body_on_the_device_interpreter():
+    """tests/TestCustomIntegrator.h of the reference on the emulated HIP platform -- a CustomIntegrator whose expressions all have a device
+    form runs natively (HipCustomIntegrator.h: per-DOF computations as interpreted programs on the device, global computations and control
+    flow on the host), the others (tabulated functions, vector functions, deriv()) in host mode.  The long-running tests of the body
+    (thermostat statistics, RESPA energy conservation, ...: 30 minutes on the emulator) run on the GPU only (TestHipCustomIntegrator)."""
+    exe = os.path.join(EMU_BUILD, "tests", "TestHipCustomIntegratorParts")
+    if not os.path.exists(exe):
+        pytest.skip("not built")
+    picked = ["testSingleBond", "testConstraints", "testConstrainedMasslessParticles", "testSum", "testParameter", "testRandomDistributions", "testPerDofVariables", "testForceGroups",
+              "testIfBlock", "testWhileBlock", "testChangingGlobal", "testEnergyParameterDerivatives", "testChangeDT", "testTabulatedFunction", "testAlternatingGroups",
+              "testUpdateContextState", "testVectorFunctions", "testRecordEnergy", "testInitialTemperature", "testCheckpoint", "testSaveParameters"]
+    out = subprocess.run([exe] + picked, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and "%d tests, 0 failures" % len(picked) in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+@needs_emu
 def test_amoeba_water_box_tile_scan_against_reference_kernel_and_full_scan(tmp_path):
     """1 536-atom AMOEBA water box (12 tiles of 128 slots in a 2.5 nm box, some pairs of tiles beyond the 0.7 nm cutoff), direct
     polarization: the tile-skipping pair scan of the native multipole and vdW kernels gives the Reference kernel's forces (float grids:
@@ -317,8 +334,8 @@ def test_amoeba_dynamics_with_list_skin_and_predicted_dipoles_walks_the_same_tra
 @needs_emu
 def test_amoeba2009_dhfr_solute_forces_and_mts_langevin_steps_against_reference_platform(tmp_path):
     """Every kind of term amoeba2009 puts on a protein (the 2 489-atom solute of the amoebapme benchmark System) on the emulated HIP platform
-    against the Reference platform, by the force groups of examples/benchmark.py, and three steps of its MTSLangevinIntegrator with the
-    same seed (tests/amoeba_dhfr_case.py)."""
+    against the Reference platform, by the force groups of examples/benchmark.py, and three steps of its MTSLangevinIntegrator (as a CustomIntegrator on
+    the device interpreter; without friction, so that both platforms walk the same path), then the thermostat on its own (tests/amoeba_dhfr_case.py)."""
     from amoeba_dhfr_case import run_amoeba_dhfr_case
     r = run_amoeba_dhfr_case(tmp_path, True)
     print(r)
@@ -327,6 +344,9 @@ def test_amoeba2009_dhfr_solute_forces_and_mts_langevin_steps_against_reference_
     assert r["force_valence"] < 1e-6 and r["energy_valence"] < 1e-9
     assert r["force_nonbonded"] < 2e-4 and r["energy_nonbonded"] < 1e-5
     assert r["dpos"] < 2e-6 and r["dvel"] < 2e-3
+    assert r["mode"] == "device, custom integrator", "the MTS integrator did not run on the device interpreter"
+    assert r["evaluations_per_step"][1] < 2, "the slow force group was evaluated more than once per step (+ the closing energy query)"
+    assert 270 < r["thermostat_temperature"] < 330
 
 
 @needs_emu

@@ -21,9 +21,12 @@ REFERENCE_TEST_BODIES = ["NonbondedForce", "Ewald", "VerletIntegrator", "Settle"
                          "HarmonicBondForce", "HarmonicAngleForce", "PeriodicTorsionForce", "CMMotionRemover", "Checkpoints",
                          "CustomBondForce", "CustomExternalForce", "RBTorsionForce", "VirtualSites", "VariableVerletIntegrator",
                          "BrownianIntegrator", "MonteCarloBarostat", "CustomNonbondedForce", "GBSAOBCForce", "DispersionPME",
+                         # CustomIntegrator on the device interpreter (HipCustomIntegrator.h); Custom angle / compound-bond forces: native kernels for
+                         # the AMOEBA expressions, the Reference kernel inside for the expressions of these bodies
+                         "CustomIntegrator", "CustomAngleForce", "CustomCompoundBondForce",
                          # plugins/amoeba/tests with libOpenMMAmoebaHIP.so loaded: AmoebaVdwForce (and the PME cases of
                          # AmoebaMultipoleForce) run on the native kernels -- NATIVE_AMOEBA below says which evaluation counter must
-                         # move; AmoebaTorsionTorsionForce has no native kernel: the plugin's own Reference kernel runs as a fallback force
+                         # move; AmoebaTorsionTorsionForce runs on kernels/valence.hip
                          "AmoebaVdwForce", "AmoebaMultipoleForce", "AmoebaTorsionTorsionForce", "AmoebaExtrapolatedPolarization"]
 NATIVE_AMOEBA = {"AmoebaVdwForce": "vdw", "AmoebaMultipoleForce": "multipole", "AmoebaExtrapolatedPolarization": "multipole"}         # test body -> counter printed by tests/hip/HipAmoebaTests.h at exit
 
@@ -130,7 +133,8 @@ out = {}
 for name, groups in (("valence", 1), ("nonbonded", 2)):
     st = ctx.getState(getForces=True, getEnergy=True, groups=groups)
     out["f_" + name], out["e_" + name] = st.forces, st.potentialEnergy
-out["native"] = np.array(H.amoeba_native_evaluations())
+out["native"] = np.array(list(H.amoeba_native_evaluations()) + [H.valence_lists_launched()])
+out["mode"] = np.array(ctx.getPlatformProperty("IntegrationMode"))
 ctx.setVelocitiesToTemperature(300.0, 5)
 integ.step(10)
 st = ctx.getState(getEnergy=True, getPositions=True)
@@ -152,6 +156,8 @@ def test_amoeba2009_dhfr_at_the_benchmarked_size_matches_the_reference_platform(
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     z = np.load(path)
     assert z["native"][0] >= 1 and z["native"][1] >= 1, "the native kernels did not run"
+    assert z["native"][2] >= 7, "the native kernels of the valence terms did not run"
+    assert str(z["mode"]) == "device, custom integrator"
     for name, ref, e_ref in (("valence", g["forces_valence"].astype(np.float64), float(g["energy_valence"])),
                              ("nonbonded", g["forces_vdw"].astype(np.float64) + g["forces_multipole"].astype(np.float64), float(g["energy_vdw"]) + float(g["energy_multipole"]))):
         f = z["f_" + name]

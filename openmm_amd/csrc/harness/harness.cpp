@@ -195,6 +195,22 @@ int omm_custom_integrator_add(void* i, int kind, const char* name, const char* e
               default: throw OpenMMException("unknown CustomIntegrator step kind");
           })
 }
+int omm_custom_integrator_get_per_dof(void* i, int index, double* out) {
+    GUARD(CustomIntegrator* c = dynamic_cast<CustomIntegrator*>((Integrator*) i);
+          if (c == NULL) throw OpenMMException("not a CustomIntegrator");
+          vector<Vec3> values; c->getPerDofVariable(index, values);
+          for (size_t k = 0; k < values.size(); k++) { out[3 * k] = values[k][0]; out[3 * k + 1] = values[k][1]; out[3 * k + 2] = values[k][2]; })
+}
+int omm_custom_integrator_get_global(void* i, int index, double* out) {
+    GUARD(CustomIntegrator* c = dynamic_cast<CustomIntegrator*>((Integrator*) i);
+          if (c == NULL) throw OpenMMException("not a CustomIntegrator");
+          *out = c->getGlobalVariable(index))
+}
+int omm_custom_integrator_set_global(void* i, int index, double value) {
+    GUARD(CustomIntegrator* c = dynamic_cast<CustomIntegrator*>((Integrator*) i);
+          if (c == NULL) throw OpenMMException("not a CustomIntegrator");
+          c->setGlobalVariable(index, value))
+}
 void omm_integrator_destroy(void* i) { delete (Integrator*) i; }
 int omm_integrator_step(void* i, int steps) { GUARD(((Integrator*) i)->step(steps)) }
 int omm_integrator_set_step_size(void* i, double dt) { GUARD(((Integrator*) i)->setStepSize(dt)) }

@@ -412,6 +412,19 @@ class CustomIntegrator(Integrator):
     def addUpdateContextState(self):
         self._add(7)
 
+    def getPerDofVariable(self, index, num_atoms):
+        out = np.zeros((num_atoms, 3))
+        _check(lib().omm_custom_integrator_get_per_dof(self.h, index, _dp(out)))
+        return out
+
+    def getGlobalVariable(self, index):
+        out = C.c_double(0.0)
+        _check(lib().omm_custom_integrator_get_global(self.h, index, C.byref(out)))
+        return out.value
+
+    def setGlobalVariable(self, index, value):
+        _check(lib().omm_custom_integrator_set_global(self.h, index, C.c_double(value)))
+
 
 class MTSLangevinIntegrator(CustomIntegrator):
     """wrappers/python/openmm/mtsintegrator.py:112-199 (BAOAB-RESPA): groups = [(force group, evaluations per step), ...].  As there, the

@@ -290,6 +290,52 @@ def test_native_amoeba_multipole_kernel_matches_the_plugins_reference_kernel():
 
 
 @needs_emu
+def test_device_interpreter_evaluates_every_lepton_operation_like_the_reference():
+    """One CustomIntegrator step whose per-DOF expressions use every operation the interpreter of kernels/custom_integrator.hip knows (all of
+    Lepton's: arithmetic, powers, the transcendental functions, step / delta / select / min / max / abs / floor / ceil, constants folded and
+    not), global variables, a ComputeSum, a ComputeGlobal that feeds a later per-DOF step -- on the emulated HIP platform
+    (device mode) against the Reference platform: per-DOF variables to 1e-12 relative."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from openmm_amd import harness as H, testsystems as T
+H.load_hip_platform(emulated=True)
+w = T.water_box(3, seed=4, rigid=False, method=H.NoCutoff)
+exprs = ["x + v*0.5 - 2/m", "x*v", "v/(abs(x)+1)", "(abs(x)+0.1)^1.7", "(abs(v)+0.2)^(abs(x)+0.3)", "-x", "sqrt(abs(x))", "exp(-x*x)", "log(abs(x)+1)",
+         "sin(x)+cos(v)", "sec(x/10)+csc(x/10+1)", "tan(x/10)+cot(x/10+1)", "asin(sin(x))+acos(cos(v))+atan(x)", "atan2(x, v+0.1)", "sinh(x/4)+cosh(v/4)+tanh(x)",
+         "erf(x)+erfc(v)", "step(x-1)+delta(step(v))", "x^2+v^3+1/(abs(x)+1)", "3+x", "3*x", "x^3.5*0+abs(x)^3.5", "min(x,v)+max(x,v)", "floor(4*x)+ceil(4*v)",
+         "select(step(x-1), x, v)", "a*x+b*f/m+dt", "s*x + g"]
+res = {}
+for plat in ("Reference", "HIP"):
+    s, nb = w.build()
+    integ = H.CustomIntegrator(0.001, seed=3)
+    integ.addGlobalVariable("a", 0.3); integ.addGlobalVariable("b", -1.25); integ.addGlobalVariable("s", 0.0); integ.addGlobalVariable("g", 0.0)
+    for k in range(len(exprs)): integ.addPerDofVariable("r%%d" %% k, 0)
+    integ.addComputeSum("s", "m*v*v/2")
+    integ.addComputeGlobal("g", "sqrt(s)+a")
+    for k, e in enumerate(exprs): integ.addComputePerDof("r%%d" %% k, e)
+    ctx = H.Context(s, integ, plat)
+    ctx.setPositions(w.positions)
+    ctx.setVelocitiesToTemperature(300.0, 7)
+    integ.step(1)
+    res[plat] = [integ.getPerDofVariable(k, w.num_atoms) for k in range(len(exprs))] + [np.array([[integ.getGlobalVariable(2), integ.getGlobalVariable(3), 0.0]])]
+    if plat == "HIP": mode = ctx.getPlatformProperty("IntegrationMode")
+    ctx.close()
+worst = 0.0
+for k, (r, h) in enumerate(zip(res["Reference"], res["HIP"])):
+    err = np.abs(r - h).max() / max(1.0, np.abs(r).max())
+    name = (exprs + ["globals"])[k]
+    # (the expression with f carries the single-precision pair arithmetic of this platform's forces)
+    if not np.isfinite(r).all() or err > (1e-5 if "f" in name.replace("floor", "") else 1e-11): print("MISMATCH", k, name, err)
+    worst = max(worst, err)
+print("MODE", mode)
+print("WORST", worst)
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "MISMATCH" not in out.stdout and "MODE device, custom integrator" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+@needs_emu
 def test_reference_custom_integrator_body_on_the_device_interpreter():
     """tests/TestCustomIntegrator.h of the reference on the emulated HIP platform -- a CustomIntegrator whose expressions all have a device
     form runs natively (HipCustomIntegrator.h: per-DOF computations as interpreted programs on the device, global computations and control

@@ -560,8 +560,8 @@ int ommhip_kinetic_energy(const void* vel_d, const int* atom_of_slot_d, int firs
  * CustomIntegrator on the device (kernels/custom_integrator.hip).  Replaces the per-degree-of-freedom work of IntegrateCustomStepKernel
  * (kernels.h:1329-1395; Reference: ReferenceCustomDynamics.cpp:227-370 update(), :357-380 computePerDof()).  The reference's GPU platforms
  * turn every expression into source code and compile it at run time; here an expression becomes a short postfix program
- * (ommhip_vm_instruction, translated by the platform from the Lepton expression tree) that one thread per atom interprets for its three
- * degrees of freedom, in double precision.  Several consecutive ComputePerDof steps travel in ONE launch (a thread only ever touches its
+ * (ommhip_vm_instruction, translated by the platform from the Lepton expression tree) that one thread per degree of freedom interprets
+ * in double precision (value stack in LDS).  Several consecutive ComputePerDof steps travel in ONE launch (a thread only ever touches its
  * own atom, so they need no barrier between them).
  *   variables of a program: x, v, f (the force array given with the step), m, gaussian, uniform, the per-DOF variables, and the global
  *   variables (device array, the platform keeps it current)
@@ -597,7 +597,7 @@ typedef struct ommhip_vm_state {
     const double* globals;      /* device double[...] */
     const ommhip_vm_instruction* program;   /* device */
     unsigned long long seed;
-    double* sum_scratch;        /* device double[OMMHIP_KE_SCRATCH]; target -1 only */
+    double* sum_scratch;        /* device double[4096] (one partial sum per workgroup); target -1 only */
     double* sum_result;         /* device double */
 } ommhip_vm_state;
 /* steps[0 .. num_steps) one after the other for every degree of freedom; a step with target -1 must be the only one of its launch */

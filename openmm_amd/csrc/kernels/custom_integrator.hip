@@ -1,10 +1,10 @@
 // CustomIntegrator's per-degree-of-freedom computations on the device: a small stack machine that interprets the postfix form of a
-// Lepton expression, one thread per atom (its three degrees of freedom in turn), double precision.  See include/openmm_hip_kernels.h
+// Lepton expression, one thread per degree of freedom, double precision, the value stack in LDS.  See include/openmm_hip_kernels.h
 // (ommhip_vm_*) for the contract; Reference: ReferenceCustomDynamics.cpp:357-380 (computePerDof), :300-320 (ComputeSum).
 //
 // An integrator step is a handful of such computations of a few operations each over ~100 bytes of state per atom: the work is launch- and
-// bandwidth-bound, so consecutive computations share a launch and keep the atom's state in registers between them (x, v and the per-DOF
-// variables are re-read only from what the thread itself wrote).
+// bandwidth-bound, so consecutive computations share a launch and keep x and v of the degree of freedom in registers between them (the
+// per-DOF variables are re-read only from what the thread itself wrote).
 #include "common.h"
 #include "../../../include/openmm_hip_kernels.h"
 #include "rng.h"
@@ -23,115 +23,114 @@ struct DofVars {
     double x, v, f, m, gaussian, uniform;
 };
 
-__device__ __forceinline__ double vm_run(const ommhip_vm_state& s, const ommhip_vm_step& st, const DofVars& var, int atom, int axis) {
-    double stack[OMMHIP_VM_STACK];
+#define VM_BLOCK 64
+#define VM_MAX_BLOCKS 4096          // grid-stride beyond that (and the limit of the partial sums of a ComputeSum)
+
+// the value stack of a thread: column threadIdx.x of an LDS array (dynamic indexing of a private array would live in scratch memory)
+#define STACK(i) stack[(i) * VM_BLOCK + lane]
+
+__device__ __forceinline__ double vm_run(const ommhip_vm_state& s, const ommhip_vm_step& st, const DofVars& var, size_t dof, double* stack, const int lane) {
     int top = -1;                      // index of the top of the stack
     for (int pc = st.first; pc < st.first + st.count; pc++) {
         const ommhip_vm_instruction in = s.program[pc];
+        double a = top >= 0 ? STACK(top) : 0.0;
         switch (in.op) {
-            case OMMHIP_VM_CONSTANT: stack[++top] = in.value; break;
-            case OMMHIP_VM_VARIABLE:
+            case OMMHIP_VM_CONSTANT: STACK(++top) = in.value; break;
+            case OMMHIP_VM_VARIABLE: {
+                double value;
                 switch (in.arg) {
-                    case 0: stack[++top] = var.x; break;
-                    case 1: stack[++top] = var.v; break;
-                    case 2: stack[++top] = var.f; break;
-                    case 3: stack[++top] = var.m; break;
-                    case 4: stack[++top] = var.gaussian; break;
-                    case 5: stack[++top] = var.uniform; break;
-                    default: stack[++top] = s.per_dof[(size_t) (in.arg - 6) * 3 * s.num_atoms + 3 * atom + axis]; break;
+                    case 0: value = var.x; break;
+                    case 1: value = var.v; break;
+                    case 2: value = var.f; break;
+                    case 3: value = var.m; break;
+                    case 4: value = var.gaussian; break;
+                    case 5: value = var.uniform; break;
+                    default: value = s.per_dof[(size_t) (in.arg - 6) * 3 * s.num_atoms + dof]; break;
                 }
+                STACK(++top) = value;
                 break;
-            case OMMHIP_VM_GLOBAL: stack[++top] = s.globals[in.arg]; break;
-            case OMMHIP_VM_ADD: top--; stack[top] = stack[top] + stack[top + 1]; break;
-            case OMMHIP_VM_SUBTRACT: top--; stack[top] = stack[top] - stack[top + 1]; break;
-            case OMMHIP_VM_MULTIPLY: top--; stack[top] = stack[top] * stack[top + 1]; break;
-            case OMMHIP_VM_DIVIDE: top--; stack[top] = stack[top] / stack[top + 1]; break;
-            case OMMHIP_VM_POWER: top--; stack[top] = pow(stack[top], stack[top + 1]); break;
-            case OMMHIP_VM_NEGATE: stack[top] = -stack[top]; break;
-            case OMMHIP_VM_SQRT: stack[top] = sqrt(stack[top]); break;
-            case OMMHIP_VM_EXP: stack[top] = exp(stack[top]); break;
-            case OMMHIP_VM_LOG: stack[top] = log(stack[top]); break;
-            case OMMHIP_VM_SIN: stack[top] = sin(stack[top]); break;
-            case OMMHIP_VM_COS: stack[top] = cos(stack[top]); break;
-            case OMMHIP_VM_SEC: stack[top] = 1.0 / cos(stack[top]); break;
-            case OMMHIP_VM_CSC: stack[top] = 1.0 / sin(stack[top]); break;
-            case OMMHIP_VM_TAN: stack[top] = tan(stack[top]); break;
-            case OMMHIP_VM_COT: stack[top] = 1.0 / tan(stack[top]); break;
-            case OMMHIP_VM_ASIN: stack[top] = asin(stack[top]); break;
-            case OMMHIP_VM_ACOS: stack[top] = acos(stack[top]); break;
-            case OMMHIP_VM_ATAN: stack[top] = atan(stack[top]); break;
-            case OMMHIP_VM_ATAN2: top--; stack[top] = atan2(stack[top], stack[top + 1]); break;
-            case OMMHIP_VM_SINH: stack[top] = sinh(stack[top]); break;
-            case OMMHIP_VM_COSH: stack[top] = cosh(stack[top]); break;
-            case OMMHIP_VM_TANH: stack[top] = tanh(stack[top]); break;
-            case OMMHIP_VM_ERF: stack[top] = erf(stack[top]); break;
-            case OMMHIP_VM_ERFC: stack[top] = erfc(stack[top]); break;
-            case OMMHIP_VM_STEP: stack[top] = stack[top] >= 0.0 ? 1.0 : 0.0; break;
-            case OMMHIP_VM_DELTA: stack[top] = stack[top] == 0.0 ? 1.0 : 0.0; break;
-            case OMMHIP_VM_SQUARE: stack[top] = stack[top] * stack[top]; break;
-            case OMMHIP_VM_CUBE: stack[top] = stack[top] * stack[top] * stack[top]; break;
-            case OMMHIP_VM_RECIPROCAL: stack[top] = 1.0 / stack[top]; break;
-            case OMMHIP_VM_ADD_CONSTANT: stack[top] = stack[top] + in.value; break;
-            case OMMHIP_VM_MULTIPLY_CONSTANT: stack[top] = stack[top] * in.value; break;
-            case OMMHIP_VM_POWER_CONSTANT: stack[top] = pow(stack[top], in.value); break;
-            case OMMHIP_VM_MIN: top--; stack[top] = fmin(stack[top], stack[top + 1]); break;
-            case OMMHIP_VM_MAX: top--; stack[top] = fmax(stack[top], stack[top + 1]); break;
-            case OMMHIP_VM_ABS: stack[top] = fabs(stack[top]); break;
-            case OMMHIP_VM_FLOOR: stack[top] = floor(stack[top]); break;
-            case OMMHIP_VM_CEIL: stack[top] = ceil(stack[top]); break;
-            case OMMHIP_VM_SELECT: top -= 2; stack[top] = stack[top] != 0.0 ? stack[top + 1] : stack[top + 2]; break;
+            }
+            case OMMHIP_VM_GLOBAL: STACK(++top) = s.globals[in.arg]; break;
+            case OMMHIP_VM_ADD: top--; STACK(top) = STACK(top) + a; break;
+            case OMMHIP_VM_SUBTRACT: top--; STACK(top) = STACK(top) - a; break;
+            case OMMHIP_VM_MULTIPLY: top--; STACK(top) = STACK(top) * a; break;
+            case OMMHIP_VM_DIVIDE: top--; STACK(top) = STACK(top) / a; break;
+            case OMMHIP_VM_POWER: top--; STACK(top) = pow(STACK(top), a); break;
+            case OMMHIP_VM_NEGATE: STACK(top) = -a; break;
+            case OMMHIP_VM_SQRT: STACK(top) = sqrt(a); break;
+            case OMMHIP_VM_EXP: STACK(top) = exp(a); break;
+            case OMMHIP_VM_LOG: STACK(top) = log(a); break;
+            case OMMHIP_VM_SIN: STACK(top) = sin(a); break;
+            case OMMHIP_VM_COS: STACK(top) = cos(a); break;
+            case OMMHIP_VM_SEC: STACK(top) = 1.0 / cos(a); break;
+            case OMMHIP_VM_CSC: STACK(top) = 1.0 / sin(a); break;
+            case OMMHIP_VM_TAN: STACK(top) = tan(a); break;
+            case OMMHIP_VM_COT: STACK(top) = 1.0 / tan(a); break;
+            case OMMHIP_VM_ASIN: STACK(top) = asin(a); break;
+            case OMMHIP_VM_ACOS: STACK(top) = acos(a); break;
+            case OMMHIP_VM_ATAN: STACK(top) = atan(a); break;
+            case OMMHIP_VM_ATAN2: top--; STACK(top) = atan2(STACK(top), a); break;
+            case OMMHIP_VM_SINH: STACK(top) = sinh(a); break;
+            case OMMHIP_VM_COSH: STACK(top) = cosh(a); break;
+            case OMMHIP_VM_TANH: STACK(top) = tanh(a); break;
+            case OMMHIP_VM_ERF: STACK(top) = erf(a); break;
+            case OMMHIP_VM_ERFC: STACK(top) = erfc(a); break;
+            case OMMHIP_VM_STEP: STACK(top) = a >= 0.0 ? 1.0 : 0.0; break;
+            case OMMHIP_VM_DELTA: STACK(top) = a == 0.0 ? 1.0 : 0.0; break;
+            case OMMHIP_VM_SQUARE: STACK(top) = a * a; break;
+            case OMMHIP_VM_CUBE: STACK(top) = a * a * a; break;
+            case OMMHIP_VM_RECIPROCAL: STACK(top) = 1.0 / a; break;
+            case OMMHIP_VM_ADD_CONSTANT: STACK(top) = a + in.value; break;
+            case OMMHIP_VM_MULTIPLY_CONSTANT: STACK(top) = a * in.value; break;
+            case OMMHIP_VM_POWER_CONSTANT: STACK(top) = pow(a, in.value); break;
+            case OMMHIP_VM_MIN: top--; STACK(top) = fmin(STACK(top), a); break;
+            case OMMHIP_VM_MAX: top--; STACK(top) = fmax(STACK(top), a); break;
+            case OMMHIP_VM_ABS: STACK(top) = fabs(a); break;
+            case OMMHIP_VM_FLOOR: STACK(top) = floor(a); break;
+            case OMMHIP_VM_CEIL: STACK(top) = ceil(a); break;
+            case OMMHIP_VM_SELECT: top -= 2; STACK(top) = STACK(top) != 0.0 ? STACK(top + 1) : a; break;
             default: break;
         }
     }
-    return stack[0];
+    return STACK(0);
 }
 
-__global__ __launch_bounds__(128) void k_vm_per_dof(VmArgs a) {
-    __shared__ double partial[2];
+// one thread per degree of freedom (grid-stride): the steps of the launch one after the other, x and v of the thread's own degree of
+// freedom in registers between them
+__global__ __launch_bounds__(VM_BLOCK) void k_vm_per_dof(VmArgs a) {
+    __shared__ double stack[OMMHIP_VM_STACK * VM_BLOCK];
     const ommhip_vm_state& s = a.s;
-    const int atom = blockIdx.x * 128 + threadIdx.x;
+    const int lane = threadIdx.x;
+    const size_t numDof = 3 * (size_t) s.num_atoms;
     double sum = 0;
-    if (atom < s.num_atoms) {
-        double4* pos = (double4*) s.pos;
-        double4* vel = (double4*) s.vel;
-        double4 x = pos[atom], v = vel[atom];
-        if (v.w != 0.0) {
-            bool xChanged = false, vChanged = false;
-            for (int i = 0; i < a.numSteps; i++) {
-                const ommhip_vm_step& st = a.step[i];
-                double g[3] = {0, 0, 0};
-                float u[4] = {0, 0, 0, 0};
-                if (st.uses_random & 1) { const double3 n = gaussian3((unsigned) atom, st.draw, s.seed); g[0] = n.x; g[1] = n.y; g[2] = n.z; }
-                if (st.uses_random & 2) uniform4((unsigned) atom, st.draw, s.seed, u);
-                double result[3];
-#pragma unroll
-                for (int axis = 0; axis < 3; axis++) {
-                    DofVars var;
-                    var.x = axis == 0 ? x.x : (axis == 1 ? x.y : x.z);
-                    var.v = axis == 0 ? v.x : (axis == 1 ? v.y : v.z);
-                    var.f = st.force != nullptr ? st.force[3 * (size_t) atom + axis] : 0.0;
-                    var.m = 1.0 / v.w;
-                    var.gaussian = g[axis];
-                    var.uniform = (double) u[axis];
-                    result[axis] = vm_run(s, st, var, atom, axis);
-                }
-                if (st.target == 0) { x.x = result[0]; x.y = result[1]; x.z = result[2]; xChanged = true; }
-                else if (st.target == 1) { v.x = result[0]; v.y = result[1]; v.z = result[2]; vChanged = true; }
-                else if (st.target >= 2) {
-                    double* out = s.per_dof + (size_t) (st.target - 2) * 3 * s.num_atoms + 3 * (size_t) atom;
-                    out[0] = result[0]; out[1] = result[1]; out[2] = result[2];
-                }
-                else sum += result[0] + result[1] + result[2];
-            }
-            if (xChanged) pos[atom] = x;
-            if (vChanged) vel[atom] = v;
+    double* pos = (double*) s.pos;
+    double* vel = (double*) s.vel;
+    for (size_t dof = (size_t) blockIdx.x * VM_BLOCK + lane; dof < numDof; dof += (size_t) gridDim.x * VM_BLOCK) {
+        const int atom = (int) (dof / 3), axis = (int) (dof - 3 * (size_t) atom);
+        const double invMass = vel[4 * (size_t) atom + 3];
+        if (invMass == 0.0) continue;                 // a massless particle: skipped as in the reference
+        double x = pos[4 * (size_t) atom + axis], v = vel[4 * (size_t) atom + axis];
+        bool xChanged = false, vChanged = false;
+        for (int i = 0; i < a.numSteps; i++) {
+            const ommhip_vm_step& st = a.step[i];
+            DofVars var;
+            var.x = x; var.v = v; var.m = 1.0 / invMass;
+            var.f = st.force != nullptr ? st.force[dof] : 0.0;
+            var.gaussian = 0; var.uniform = 0;
+            if (st.uses_random & 1) { const double3 n = gaussian3((unsigned) atom, st.draw, s.seed); var.gaussian = axis == 0 ? n.x : (axis == 1 ? n.y : n.z); }
+            if (st.uses_random & 2) { float u[4]; uniform4((unsigned) atom, st.draw, s.seed, u); var.uniform = (double) (axis == 0 ? u[0] : (axis == 1 ? u[1] : u[2])); }
+            const double result = vm_run(s, st, var, dof, stack, lane);
+            if (st.target == 0) { x = result; xChanged = true; }
+            else if (st.target == 1) { v = result; vChanged = true; }
+            else if (st.target >= 2) s.per_dof[(size_t) (st.target - 2) * numDof + dof] = result;
+            else sum += result;
         }
+        if (xChanged) pos[4 * (size_t) atom + axis] = x;
+        if (vChanged) vel[4 * (size_t) atom + axis] = v;
     }
     if (a.numSteps == 1 && a.step[0].target < 0) {
         sum = wave_sum(sum);
-        if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = sum;
-        __syncthreads();
-        if (threadIdx.x == 0) s.sum_scratch[blockIdx.x] = partial[0] + partial[1];
+        if (lane == 0) s.sum_scratch[blockIdx.x] = sum;
     }
 }
 
@@ -162,9 +161,10 @@ extern "C" int ommhip_vm_per_dof(const ommhip_vm_state* state, int num_steps, co
     bool sums = false;
     for (int i = 0; i < num_steps; i++) { a.step[i] = steps[i]; sums = sums || steps[i].target < 0; }
     for (int i = num_steps; i < OMMHIP_VM_MAX_STEPS; i++) a.step[i] = steps[0];
-    const int blocks = (state->num_atoms + 127) / 128;
-    if (sums && (num_steps != 1 || blocks > OMMHIP_KE_SCRATCH * 64 || state->sum_scratch == NULL || state->sum_result == NULL)) return 1;
-    hipLaunchKernelGGL(k_vm_per_dof, dim3(blocks), dim3(128), 0, (hipStream_t) stream, a);
+    const size_t wanted = (3 * (size_t) state->num_atoms + VM_BLOCK - 1) / VM_BLOCK;
+    const int blocks = (int) (wanted < VM_MAX_BLOCKS ? wanted : VM_MAX_BLOCKS);
+    if (sums && (num_steps != 1 || state->sum_scratch == NULL || state->sum_result == NULL)) return 1;
+    hipLaunchKernelGGL(k_vm_per_dof, dim3(blocks), dim3(VM_BLOCK), 0, (hipStream_t) stream, a);
     if (sums) hipLaunchKernelGGL(k_vm_sum, dim3(1), dim3(64), 0, (hipStream_t) stream, (const double*) state->sum_scratch, blocks, state->sum_result);
     return (int) hipGetLastError();
 }

@@ -243,6 +243,7 @@ public:
     int* freezeState = NULL;
     int pendingReplay = 0;                                   // skipped steps the integrator still has to redo
     long long currentStepIndex = -1;                         // index of the step whose updateContextState is running (-1: none); differs from stepCount while skipped steps are redone
+    long long overflowRecoveries = 0;                        // how often listRecovery found an overflowed list and grew it
     std::function<int()> listRecovery;                       // set by the nonbonded kernel: synchronous check; fixes the list, returns skipped steps
     std::function<bool()> listOverflowSeen;                  // set by the nonbonded kernel: do the state words last copied back (valid after a sync) show an overflow?
     std::function<void(int)> replaySteps;                    // set by the integrator kernel: redo that many steps

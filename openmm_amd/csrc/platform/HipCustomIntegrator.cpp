@@ -259,12 +259,13 @@ void HipIntegrateCustomStepKernel::ensureForces(ContextImpl& context, int flags,
     recordChangedParameters(context);
     double e = 0;
     for (int attempt = 0; ; attempt++) {
+        const long long recoveriesBefore = hip.overflowRecoveries;
         e = context.calcForcesAndEnergy(computeForces, computeEnergy, flags);
         // a neighbour list that overflowed at this evaluation left incomplete forces: the integration kernels of the native integrators
-        // wait for the host on their own (ommhip_integrator_state::freeze_state); here the host looks at once, and evaluates again
-        if (!hip.listRecovery) break;
-        hip.listRecovery();
-        if (!hip.listOverflowSeen || !hip.listOverflowSeen() || attempt == 4) break;
+        // wait for the host on their own (ommhip_integrator_state::freeze_state); here the host looks at once -- a synchronisation per
+        // evaluation, only for Systems with a NonbondedForce -- and evaluates again with the list the recovery has grown
+        if (hip.listRecovery) hip.listRecovery();
+        if (hip.overflowRecoveries == recoveriesBefore || attempt == 4) break;
     }
     hip.pendingReplay = 0;
     if (computeForces) {

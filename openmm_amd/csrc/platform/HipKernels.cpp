@@ -884,6 +884,7 @@ int HipCalcNonbondedForceKernel::recoverFromOverflow() {
     stateCopyPending = false;
     if (pinnedState[OMMHIP_NL_STATE_OVERFLOW] == 0 && pinnedState[1] <= nl.max_chunks) return 0;
     const int skipped = pinnedState[OMMHIP_NL_STATE_FROZEN];
+    hip.overflowRecoveries++;
     fprintf(stderr, "HIP platform: neighbour list overflowed (%d chunks needed, %d allocated); growing it and redoing %d step(s)\n", pinnedState[1], nl.max_chunks, skipped);
     allocateNeighborList((int) (std::max(pinnedState[1], nl.max_chunks) * 1.5) + 64);
     const int zero[OMMHIP_NL_STATE_INTS] = {1, 0, 0, 0, pinnedState[4], 0, 0, 0, 0, 0, 0, 0};          // rebuild requested, overflow and frozen counters cleared

@@ -336,6 +336,21 @@ print("WORST", worst)
 
 
 @needs_emu
+def test_custom_integrator_with_constraints_pme_and_a_list_overflow(tmp_path):
+    """Velocity Verlet written as a CustomIntegrator on a rigid TIP3P box with PME: device interpreter against the Reference platform (SETTLE
+    through ConstrainPositions / ConstrainVelocities with the positions of the last constraint as reference, a ComputeSum global), and the
+    same run with a neighbour-list overflow in the middle against the undisturbed one (tests/custom_integrator_case.py)."""
+    from custom_integrator_case import run_custom_integrator_case
+    r = run_custom_integrator_case(tmp_path, True)
+    print(r)
+    assert r["mode"] == "device, custom integrator"
+    assert r["dpos"] < 5e-6 and r["dvel"] < 5e-4 and r["ke_rel"] < 1e-5 and r["ke_state_rel"] < 1e-5
+    assert r["constraints"] < 1e-6
+    assert r["overflows"] == 1 and r["times"][0] == r["times"][1]
+    assert r["overflow_dpos"] < 1e-7 and r["overflow_dvel"] < 1e-5          # (the grid sums of two runs differ in their float rounding)
+
+
+@needs_emu
 def test_reference_custom_integrator_body_on_the_device_interpreter():
     """tests/TestCustomIntegrator.h of the reference on the emulated HIP platform -- a CustomIntegrator whose expressions all have a device
     form runs natively (HipCustomIntegrator.h: per-DOF computations as interpreted programs on the device, global computations and control

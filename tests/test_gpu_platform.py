@@ -172,6 +172,19 @@ def test_amoeba2009_dhfr_at_the_benchmarked_size_matches_the_reference_platform(
     assert np.isfinite(float(z["e_after"])) and 250 < temperature < 450 and 1e-3 < float(z["moved"]) < 0.2
 
 
+def test_custom_integrator_with_constraints_pme_and_a_list_overflow(tmp_path):
+    """Velocity Verlet written as a CustomIntegrator on a rigid 5 184-atom TIP3P box with PME: the device interpreter against the Reference
+    platform, and the same run with a neighbour-list overflow in the middle against the undisturbed one (tests/custom_integrator_case.py)."""
+    from custom_integrator_case import run_custom_integrator_case
+    r = run_custom_integrator_case(tmp_path, False, n_side=12, grid=32, steps=12, cutoff=0.9)
+    print(r)
+    assert r["mode"] == "device, custom integrator"
+    assert r["dpos"] < 2e-5 and r["dvel"] < 2e-3 and r["ke_rel"] < 1e-4 and r["ke_state_rel"] < 1e-4
+    assert r["constraints"] < 1e-6
+    assert r["overflows"] == 1 and r["times"][0] == r["times"][1]
+    assert r["overflow_dpos"] < 2e-5 and r["overflow_dvel"] < 2e-3
+
+
 def test_amoeba_dynamics_with_list_skin_and_predicted_dipoles_walks_the_same_trajectory(tmp_path):
     """Twelve Verlet steps of a relaxed 375-atom AMOEBA water box, mutual polarization to 1e-6 D: pair lists with a Verlet skin that are
     rebuilt on displacement, the solver started from dipoles extrapolated from the previous steps and its convergence decided on the

@@ -241,7 +241,8 @@ typedef struct ommhip_neighbor_list {
 } ommhip_neighbor_list;
 
 /* sizeof() of the structs of this header as the library was compiled: 0 ommhip_neighbor_list, 1 ommhip_nonbonded_params, 2 ommhip_pme,
- * 3 ommhip_term_batch, 4 ommhip_integrator_state, 5 ommhip_step_units, 6 ommhip_ccma; 0 for anything else.  A foreign-language
+ * 3 ommhip_term_batch, 4 ommhip_integrator_state, 5 ommhip_step_units, 6 ommhip_ccma, 7 ommhip_valence_list, 8 ommhip_vm_instruction,
+ * 9 ommhip_vm_step, 10 ommhip_vm_state; 0 for anything else.  A foreign-language
  * binding (ctypes, cgo, JNI) checks its mirror against it when it loads the library. */
 size_t ommhip_struct_size(int which);
 

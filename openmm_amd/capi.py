@@ -59,6 +59,24 @@ class Pme(C.Structure):
 PME_ALL, PME_SPREAD_ONLY, PME_AFTER_SPREAD, PME_INTERPOLATE_ONLY = 0, 1, 2, 3      # Pme.phases
 
 
+class ValenceList(C.Structure):
+    """ommhip_valence_list (include/openmm_hip_kernels.h)"""
+    _fields_ = [("kind", C.c_int), ("num_terms", C.c_int), ("atoms", C.c_void_p), ("params", C.c_void_p), ("coefficients", C.c_double * 6), ("grids", C.c_void_p)]
+
+
+class VmInstruction(C.Structure):
+    _fields_ = [("op", C.c_int), ("arg", C.c_int), ("value", C.c_double)]
+
+
+class VmStep(C.Structure):
+    _fields_ = [("first", C.c_int), ("count", C.c_int), ("target", C.c_int), ("uses_random", C.c_int), ("force", C.c_void_p), ("draw", C.c_ulonglong)]
+
+
+class VmState(C.Structure):
+    _fields_ = [("num_atoms", C.c_int), ("num_per_dof", C.c_int), ("pos", C.c_void_p), ("vel", C.c_void_p), ("per_dof", C.c_void_p), ("globals", C.c_void_p),
+                ("program", C.c_void_p), ("seed", C.c_ulonglong), ("sum_scratch", C.c_void_p), ("sum_result", C.c_void_p)]
+
+
 class KernelError(RuntimeError):
     pass
 
@@ -106,6 +124,9 @@ SIGNATURES = {
     "fft3d_r2c_c2r": [C.POINTER(Pme), _I, _P],
     "test_transpose_reduce": [_P, _P, _I, _P],
     "nb_direct": [C.POINTER(NeighborList), C.POINTER(NonbondedParams), _P, _P, _P, _I, _I, _P],
+    "valence_forces": [_I, C.POINTER(ValenceList), _P, _P, _I, _P, _P, _I, _I, _P],
+    "vm_per_dof": [C.POINTER(VmState), _I, C.POINTER(VmStep), _P],
+    "forces_to_atom_order": [_P, _P, _I, _I, _P, _P],
 }
 
 
@@ -122,7 +143,7 @@ class Kernels:
         # the ctypes mirrors above against the structs the library was compiled with
         self.lib.ommhip_struct_size.restype = C.c_size_t
         self.lib.ommhip_struct_size.argtypes = [C.c_int]
-        for which, mirror in ((0, NeighborList), (1, NonbondedParams), (2, Pme)):
+        for which, mirror in ((0, NeighborList), (1, NonbondedParams), (2, Pme), (7, ValenceList), (8, VmInstruction), (9, VmStep), (10, VmState)):
             if self.lib.ommhip_struct_size(which) != C.sizeof(mirror):
                 raise KernelError("%s: ctypes mirror of struct %d has %d bytes, the library's has %d -- openmm_amd/capi.py is out of date with include/openmm_hip_kernels.h"
                                   % (path, which, C.sizeof(mirror), self.lib.ommhip_struct_size(which)))

@@ -64,6 +64,10 @@ size_t ommhip_struct_size(int which) {
         case 4: return sizeof(ommhip_integrator_state);
         case 5: return sizeof(ommhip_step_units);
         case 6: return sizeof(ommhip_ccma);
+        case 7: return sizeof(ommhip_valence_list);
+        case 8: return sizeof(ommhip_vm_instruction);
+        case 9: return sizeof(ommhip_vm_step);
+        case 10: return sizeof(ommhip_vm_state);
     }
     return 0;
 }

@@ -427,3 +427,100 @@ def run_transpose_reduce(K, waves=7, seed=3):
     K.free(d_in); K.free(d_out)
     expect = v.astype(np.float64).sum(axis=1)[:, np.arange(64) >> 1]
     return got, expect
+
+
+# ------------------------------------------------------------------------------------------------ AMOEBA valence terms (kernels/valence.hip)
+VALENCE_KINDS = {"poly_bond": (0, 2), "poly_angle": (1, 3), "inplane_angle": (2, 4), "out_of_plane_bend": (3, 4), "stretch_bend": (4, 3), "pi_torsion": (5, 6), "torsion_torsion": (6, 6)}
+RAD = 180.0 / np.pi
+
+
+def _valence_case(kind, rng, n_terms):
+    """random molecules of the term's size near a sensible geometry -> (positions, atoms, params, coefficients, grids or None, oracle energy function)"""
+    from oracle import valence as OV
+    per = VALENCE_KINDS[kind][1]
+    na = 5 if kind == "torsion_torsion" else per
+    atoms = np.arange(n_terms * na).reshape(n_terms, na)
+    # a zig-zag chain of `na` atoms per term, bond length ~0.15 nm, jittered; planar centres get their three partners around them
+    base = np.zeros((na, 3))
+    for k in range(1, na):
+        base[k] = base[k - 1] + 0.15 * np.array([np.cos(0.6 * (k % 2)), np.sin(0.6 * (k % 2)) * (1 if k % 4 < 2 else -1), 0.05 * k])
+    if kind in ("inplane_angle", "out_of_plane_bend"):
+        base = np.array([[0.14, 0.0, 0.0], [0.0, 0.0, 0.02], [-0.07, 0.12, 0.0], [-0.07, -0.12, 0.0]])        # 1, centre 2 slightly out of the plane, 3, 4
+    if kind == "pi_torsion":
+        base = np.array([[-0.07, 0.12, 0.0], [-0.07, -0.12, 0.01], [0.0, 0.0, 0.0], [0.14, 0.0, 0.0], [0.21, 0.12, 0.03], [0.21, -0.12, -0.02]])
+    pos = (base[None] + 0.02 * rng.normal(size=(n_terms, na, 3)) + rng.uniform(0, 3, size=(n_terms, 1, 3))).reshape(-1, 3)
+    c = np.zeros(6)
+    grids = None
+    if kind == "poly_bond":
+        params = np.stack([0.14 + 0.02 * rng.random(n_terms), 2e5 * (0.5 + rng.random(n_terms))], -1); c[:2] = (-25.5, 379.3125)
+        energy = lambda p: OV.poly_bond(p, atoms, params, c)
+    elif kind in ("poly_angle", "inplane_angle"):
+        params = np.stack([100.0 + 20 * rng.random(n_terms), 0.02 + 0.05 * rng.random(n_terms)], -1); c[:5] = (-0.014, 5.6e-5, -7e-7, 2.2e-8, RAD)
+        energy = (lambda p: OV.poly_angle(p, atoms, params, c)) if kind == "poly_angle" else (lambda p: OV.inplane_angle(p, atoms, params, c))
+    elif kind == "out_of_plane_bend":
+        params = (0.005 + 0.02 * rng.random(n_terms))[:, None]; c[:5] = (-0.014, 5.6e-5, -7e-7, 2.2e-8, RAD)
+        energy = lambda p: OV.out_of_plane_bend(p, atoms, params, c)
+    elif kind == "stretch_bend":
+        params = np.stack([0.14 + 0.01 * rng.random(n_terms), 0.15 + 0.01 * rng.random(n_terms), 1.8 + 0.3 * rng.random(n_terms), 50 * rng.random(n_terms), 80 * rng.random(n_terms)], -1); c[0] = RAD
+        energy = lambda p: OV.stretch_bend(p, atoms, params, c)
+    elif kind == "pi_torsion":
+        params = (20 + 30 * rng.random(n_terms))[:, None]
+        energy = lambda p: OV.pi_torsion(p, atoms, params, c)
+    else:
+        # two maps, each a bicubic polynomial of the two angles tabulated with its exact derivatives: the kernel's bicubic patch must
+        # reproduce it; the sixth atom of a term: the chirality marker (another atom of the system bonded nowhere in particular) or -1
+        n_grid = 25
+        coef = rng.normal(size=(2, 4, 4)) * np.array([1.0, 1e-2, 1e-4, 1e-6])[None, :, None] * np.array([1.0, 1e-2, 1e-4, 1e-6])[None, None, :]
+        ang = np.linspace(-180.0, 180.0, n_grid)
+        def surface_of(m):
+            def f(x, y, dx=0, dy=0):
+                out = np.zeros(np.broadcast(x, y).shape)
+                for i in range(4):
+                    for j in range(4):
+                        if i < dx or j < dy: continue
+                        ci = np.prod(np.arange(i, i - dx, -1)) if dx else 1.0
+                        cj = np.prod(np.arange(j, j - dy, -1)) if dy else 1.0
+                        out = out + coef[m, i, j] * ci * cj * x ** (i - dx) * y ** (j - dy)
+                return out
+            return f
+        tables = []
+        for m in range(2):
+            f = surface_of(m)
+            X, Y = np.meshgrid(ang, ang, indexing="ij")
+            tables.append(np.stack([X, Y, f(X, Y), f(X, Y, 1, 0), f(X, Y, 0, 1), f(X, Y, 1, 1)], -1))
+        grids = np.ascontiguousarray(np.stack(tables))
+        which = rng.integers(0, 2, n_terms)
+        marker = np.where(rng.random(n_terms) < 0.6, (atoms[:, 2] + 7) % (n_terms * na), -1)          # some atom of another term
+        atoms = np.concatenate([atoms, marker[:, None]], 1)
+        params = np.stack([which * grids[0].size, np.full(n_terms, n_grid)], -1).astype(np.float64)
+        def energy(p):
+            e = np.zeros(n_terms)
+            for m in range(2):
+                sel = which == m
+                if sel.any(): e[sel] = OV.torsion_torsion(p, atoms[sel], lambda x, y: surface_of(m)(x, y))
+            return e
+    return pos, atoms, params, c, grids, energy
+
+
+def run_valence(K, kind, n_terms=40, seed=1):
+    """-> (forces from ommhip_valence_forces, energy, oracle forces (central differences of the numpy energy), oracle energy)"""
+    from oracle import valence as OV
+    rng = np.random.default_rng(seed)
+    pos, atoms, params, c, grids, energy = _valence_case(kind, rng, n_terms)
+    n = len(pos)
+    padded = (n + 31) // 32 * 32
+    perm = rng.permutation(padded)[:n]                   # atom -> slot: the kernels index forces by slot
+    pos4 = np.zeros((n, 4)); pos4[:, :3] = pos
+    lst = capi.ValenceList()
+    lst.kind, lst.num_terms = VALENCE_KINDS[kind][0], n_terms
+    lst.atoms = K.upload(atoms.astype(np.int32)); lst.params = K.upload(params.astype(np.float64))
+    for i in range(6): lst.coefficients[i] = c[i]
+    lst.grids = K.upload(grids) if grids is not None else None
+    pos_d, slot_d = K.upload(pos4), K.upload(perm.astype(np.int32))
+    force_d = K.upload(np.zeros(3 * padded, dtype=np.int64)); e_d = K.upload(np.zeros(64)); out_d = K.upload(np.zeros(3 * n))
+    K.valence_forces(1, C.byref(lst), pos_d, slot_d, padded, force_d, e_d, 64, 1, None)
+    K.forces_to_atom_order(force_d, slot_d, n, padded, out_d, None)
+    K.stream_sync(None)
+    f = K.download(out_d, (n, 3), np.float64)
+    e = K.download(e_d, (64,), np.float64).sum()
+    return f, e, OV.forces(energy, pos), energy(pos).sum()

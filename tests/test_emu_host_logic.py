@@ -290,6 +290,17 @@ def test_native_amoeba_multipole_kernel_matches_the_plugins_reference_kernel():
 
 
 @needs_emu
+@pytest.mark.parametrize("kind", sorted(KC.VALENCE_KINDS))
+def test_valence_kernels_against_numpy_energies(K, kind):
+    """ommhip_valence_forces through the C ABI on the emulator: every AMOEBA valence term kind against the numpy restatement of its energy
+    (oracle/valence.py) and central differences of it -- the kernels differentiate the same expressions with dual numbers."""
+    f, e, f_or, e_or = KC.run_valence(K, kind)
+    scale = np.abs(f_or).max()
+    assert abs(e - e_or) < 1e-9 * max(1.0, abs(e_or)), (e, e_or)
+    assert np.abs(f - f_or).max() < 2e-6 * scale, (np.abs(f - f_or).max(), scale)
+
+
+@needs_emu
 def test_device_interpreter_evaluates_every_lepton_operation_like_the_reference():
     """One CustomIntegrator step whose per-DOF expressions use every operation the interpreter of kernels/custom_integrator.hip knows (all of
     Lepton's: arithmetic, powers, the transcendental functions, step / delta / select / min / max / abs / floor / ceil, constants folded and

@@ -120,6 +120,38 @@ def test_reference_platform_reproduces_the_golden_valence_energy_and_forces(desc
     ctx.close()
 
 
+def test_numpy_valence_energies_are_the_reference_platforms(description):
+    """oracle/valence.py (the checker of the kernel-level tests of kernels/valence.hip) pinned: its energies of the DHFR System's valence terms,
+    kind by kind, are the Reference platform's energies of the corresponding Custom*Forces."""
+    from openmm_amd import harness as H, testsystems as T
+    from oracle import valence as OV
+    if not os.path.exists(os.path.join(H.HOST_LIB_DIR, "libOpenMMAmoebaReference.so")):
+        pytest.skip("host OpenMM not built")
+    H.lib()
+    H._check(H.lib().omm_load_plugin(os.path.join(H.HOST_LIB_DIR, "libOpenMMAmoebaReference.so").encode()))
+    d = description
+    w = T.amoeba_dhfr()
+    s, mp, vdw = w.build(nonbonded=False)
+    names = list(w.handles)
+    for g, name in enumerate(names):
+        H.lib().omm_force_set_group(w.handles[name], g)
+    ctx = H.Context(s, H.Integrator(H.VERLET, 0.001), "Reference")
+    ctx.setPositions(w.positions)
+    ref = {name: ctx.getState(getEnergy=True, groups=1 << g).potentialEnergy for g, name in enumerate(names)}
+    ctx.close()
+    pos = d["positions"]
+    rad = 180.0 / np.pi
+    poly = [float(v) for v in d["angles"][2]]
+    ours = {"AmoebaBond": OV.poly_bond(pos, d["bonds"][0], d["bonds"][1], [float(d["bonds"][2]), float(d["bonds"][3])]).sum(),
+            "AmoebaAngle": OV.poly_angle(pos, d["angles"][0], d["angles"][1], poly + [rad]).sum(),
+            "AmoebaInPlaneAngle": OV.inplane_angle(pos, d["inplane_angles"][0], d["inplane_angles"][1], poly + [rad]).sum(),
+            "AmoebaOutOfPlaneBend": OV.out_of_plane_bend(pos, d["opbends"][0], d["opbends"][1][:, None], list(d["opbends"][2]) + [rad]).sum(),
+            "AmoebaStretchBend": OV.stretch_bend(pos, d["stretch_bends"][0], d["stretch_bends"][1], [rad]).sum(),
+            "AmoebaPiTorsion": OV.pi_torsion(pos, d["pi_torsions"][0], d["pi_torsions"][1][:, None], []).sum()}
+    for name, e in ours.items():
+        assert abs(e - ref[name]) < 1e-9 * abs(ref[name]), (name, e, ref[name])
+
+
 def test_subset_is_a_closed_system(description):
     from openmm_amd import forcefield_amoeba as A
     p = A.subset(description, PROTEIN_ATOMS)

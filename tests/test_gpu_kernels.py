@@ -190,3 +190,13 @@ def test_permlane_swap_transpose_reduce_against_plain_sums(K):
     got, expect = KC.run_transpose_reduce(K)
     assert np.allclose(got, expect, rtol=2e-6, atol=2e-5), np.abs(got - expect).max()
     assert np.array_equal(got[0], expect[0].astype(np.float32))           # integers below 2^24: exact whatever the order of the additions
+
+
+@pytest.mark.parametrize("kind", sorted(KC.VALENCE_KINDS))
+def test_valence_kernels_against_numpy_energies(K, kind):
+    """ommhip_valence_forces (kernels/valence.hip) through the C ABI: every AMOEBA valence term kind against the numpy restatement of its
+    energy (oracle/valence.py) and central differences of it."""
+    f, e, f_or, e_or = KC.run_valence(K, kind, n_terms=500)
+    scale = np.abs(f_or).max()
+    assert abs(e - e_or) < 1e-9 * max(1.0, abs(e_or)), (e, e_or)
+    assert np.abs(f - f_or).max() < 2e-6 * scale, (np.abs(f - f_or).max(), scale)

@@ -524,3 +524,51 @@ def run_valence(K, kind, n_terms=40, seed=1):
     f = K.download(out_d, (n, 3), np.float64)
     e = K.download(e_d, (64,), np.float64).sum()
     return f, e, OV.forces(energy, pos), energy(pos).sum()
+
+
+# ------------------------------------------------------------------------------------------------ CustomIntegrator interpreter (kernels/custom_integrator.hip)
+def run_vm(K, n=300, seed=2):
+    """Three computations in one launch of ommhip_vm_per_dof -- r0 = x + 2 v - f / m * g0 ; v = v * exp(-g1) + sqrt(abs(r0)) ; x = select(step(x), x, -x) + v --
+    and a sum of m v^2 / 2 in a launch of its own, programs written by hand in the postfix form of include/openmm_hip_kernels.h.
+    -> dict of (kernel result, numpy result) pairs; one massless particle must be left alone"""
+    rng = np.random.default_rng(seed)
+    pos = np.zeros((n, 4)); pos[:, :3] = rng.normal(size=(n, 3))
+    mass = 1.0 + 10 * rng.random(n); mass[5] = 0.0
+    vel = np.zeros((n, 4)); vel[:, :3] = rng.normal(size=(n, 3)); vel[:, 3] = np.where(mass > 0, 1.0 / np.where(mass > 0, mass, 1.0), 0.0)
+    force = rng.normal(size=(n, 3)) * 100
+    g = np.array([0.37, 0.05])
+    CONST, VAR, GLOBAL, ADD, SUB, MUL, DIV = 0, 1, 2, 3, 4, 5, 6
+    NEG, SQRT, EXP, STEP, MULC, ABS, SELECT = 8, 9, 10, 27, 33, 37, 40
+    prog = [
+        # r0 = x + 2 v - f / m * g0
+        (VAR, 0, 0), (VAR, 1, 0), (MULC, 0, 2.0), (ADD, 0, 0), (VAR, 2, 0), (VAR, 3, 0), (DIV, 0, 0), (GLOBAL, 0, 0), (MUL, 0, 0), (SUB, 0, 0),
+        # v = v exp(-g1) + sqrt(abs(r0))
+        (VAR, 1, 0), (GLOBAL, 1, 0), (NEG, 0, 0), (EXP, 0, 0), (MUL, 0, 0), (VAR, 6, 0), (ABS, 0, 0), (SQRT, 0, 0), (ADD, 0, 0),
+        # x = select(step(x), x, -x) + v
+        (VAR, 0, 0), (STEP, 0, 0), (VAR, 0, 0), (VAR, 0, 0), (NEG, 0, 0), (SELECT, 0, 0), (VAR, 1, 0), (ADD, 0, 0),
+        # sum: m v v / 2
+        (VAR, 3, 0), (VAR, 1, 0), (MUL, 0, 0), (VAR, 1, 0), (MUL, 0, 0), (MULC, 0, 0.5)]
+    instr = (capi.VmInstruction * len(prog))(*[capi.VmInstruction(op, arg, val) for op, arg, val in prog])
+    prog_d = K.malloc(C.sizeof(instr)); K.memcpy_h2d(prog_d, C.cast(instr, C.c_void_p), C.c_size_t(C.sizeof(instr)), None); K.stream_sync(None)
+    st = capi.VmState()
+    st.num_atoms, st.num_per_dof = n, 1
+    st.pos, st.vel = K.upload(pos), K.upload(vel)
+    st.per_dof = K.upload(np.zeros(3 * n)); st.globals = K.upload(g); st.program = prog_d; st.seed = 1
+    st.sum_scratch = K.upload(np.zeros(4096)); st.sum_result = K.upload(np.zeros(2))
+    force_d = K.upload(force.reshape(-1))
+    steps = (capi.VmStep * 3)(capi.VmStep(0, 10, 2, 0, force_d, 0), capi.VmStep(10, 9, 1, 0, None, 0), capi.VmStep(19, 8, 0, 0, None, 0))
+    K.vm_per_dof(C.byref(st), 3, steps, None)
+    total = (capi.VmStep * 1)(capi.VmStep(27, 6, -1, 0, None, 0))
+    K.vm_per_dof(C.byref(st), 1, total, None)
+    K.stream_sync(None)
+    out_pos, out_vel = K.download(st.pos, (n, 4), np.float64), K.download(st.vel, (n, 4), np.float64)
+    r0 = K.download(st.per_dof, (n, 3), np.float64)
+    s = K.download(st.sum_result, (2,), np.float64)[0]
+    live = mass > 0
+    m3 = mass[:, None]
+    e_r0 = np.where(live[:, None], pos[:, :3] + 2 * vel[:, :3] - force / np.where(live, mass, 1.0)[:, None] * g[0], 0.0)
+    e_v = np.where(live[:, None], vel[:, :3] * np.exp(-g[1]) + np.sqrt(np.abs(e_r0)), vel[:, :3])
+    e_x = np.where(live[:, None], np.where(pos[:, :3] >= 0, pos[:, :3], -pos[:, :3]) + e_v, pos[:, :3])
+    e_s = (0.5 * m3 * e_v ** 2)[live].sum()
+    return {"r0": (r0, e_r0), "v": (out_vel[:, :3], e_v), "x": (out_pos[:, :3], e_x), "sum": (np.array([s]), np.array([e_s])),
+            "inverse_mass_kept": (out_vel[:, 3], vel[:, 3])}

@@ -573,3 +573,12 @@ def test_native_ljpme_matches_the_reference_platform():
             "from ljpme_case import run_ljpme_case; run_ljpme_case(); print('OK')") % (ROOT, os.path.join(ROOT, "tests"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@needs_emu
+def test_custom_integrator_interpreter_through_the_c_abi(K):
+    """ommhip_vm_per_dof with hand-written postfix programs: three computations in one launch (a per-DOF variable, v, x -- each reading what
+    the one before wrote), a sum over the degrees of freedom, a massless particle left alone -- against numpy."""
+    for name, (got, expected) in KC.run_vm(K).items():
+        assert np.allclose(got, expected, rtol=1e-13, atol=1e-13), name
+

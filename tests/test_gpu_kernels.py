@@ -200,3 +200,11 @@ def test_valence_kernels_against_numpy_energies(K, kind):
     scale = np.abs(f_or).max()
     assert abs(e - e_or) < 1e-9 * max(1.0, abs(e_or)), (e, e_or)
     assert np.abs(f - f_or).max() < 2e-6 * scale, (np.abs(f - f_or).max(), scale)
+
+
+def test_custom_integrator_interpreter_through_the_c_abi(K):
+    """ommhip_vm_per_dof with hand-written postfix programs: three computations in one launch (a per-DOF variable, v, x -- each reading what
+    the one before wrote), a sum over the degrees of freedom, a massless particle left alone -- against numpy."""
+    for name, (got, expected) in KC.run_vm(K).items():
+        assert np.allclose(got, expected, rtol=1e-13, atol=1e-13), name
+

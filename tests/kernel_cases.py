@@ -448,7 +448,19 @@ def _valence_case(kind, rng, n_terms):
         base = np.array([[0.14, 0.0, 0.0], [0.0, 0.0, 0.02], [-0.07, 0.12, 0.0], [-0.07, -0.12, 0.0]])        # 1, centre 2 slightly out of the plane, 3, 4
     if kind == "pi_torsion":
         base = np.array([[-0.07, 0.12, 0.0], [-0.07, -0.12, 0.01], [0.0, 0.0, 0.0], [0.14, 0.0, 0.0], [0.21, 0.12, 0.03], [0.21, -0.12, -0.02]])
-    pos = (base[None] + 0.02 * rng.normal(size=(n_terms, na, 3)) + rng.uniform(0, 3, size=(n_terms, 1, 3))).reshape(-1, 3)
+    if kind == "torsion_torsion":
+        # a chain with both dihedrals well away from +-180 degrees (the tabulated polynomial is not periodic: a finite difference across
+        # the seam would be meaningless), built from internal coordinates: bond 0.15 nm, angle 110 degrees, dihedrals 65 and -75 degrees
+        def place(a, b, c, bond, angle, dihedral):
+            bc = (c - b) / np.linalg.norm(c - b)
+            nrm = np.cross(b - a, bc); nrm /= np.linalg.norm(nrm)
+            m = np.cross(nrm, bc)
+            d2 = np.array([-bond * np.cos(angle), bond * np.sin(angle) * np.cos(dihedral), bond * np.sin(angle) * np.sin(dihedral)])
+            return c + d2[0] * bc + d2[1] * m + d2[2] * nrm
+        base = np.zeros((5, 3)); base[1] = (0.15, 0, 0); base[2] = base[1] + 0.15 * np.array([np.cos(np.radians(70)), np.sin(np.radians(70)), 0])
+        base[3] = place(base[0], base[1], base[2], 0.15, np.radians(110), np.radians(65))
+        base[4] = place(base[1], base[2], base[3], 0.15, np.radians(110), np.radians(-75))
+    pos = (base[None] + (0.01 if kind == "torsion_torsion" else 0.02) * rng.normal(size=(n_terms, na, 3)) + rng.uniform(0, 3, size=(n_terms, 1, 3))).reshape(-1, 3)
     c = np.zeros(6)
     grids = None
     if kind == "poly_bond":

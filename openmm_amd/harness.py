@@ -426,6 +426,40 @@ class CustomIntegrator(Integrator):
         _check(lib().omm_custom_integrator_set_global(self.h, index, C.c_double(value)))
 
 
+class MTSIntegrator(CustomIntegrator):
+    """wrappers/python/openmm/mtsintegrator.py:30-110 (rRESPA, no thermostat): groups = [(force group, evaluations per step), ...]."""
+
+    def __init__(self, dt, groups, constraintTolerance=1e-5):
+        if len(groups) == 0:
+            raise ValueError("No force groups specified")
+        groups = sorted(groups, key=lambda g: g[1])
+        CustomIntegrator.__init__(self, dt, 1, constraintTolerance)
+        self.addPerDofVariable("x1", 0)
+        self.addUpdateContextState()
+        self._substeps(1, groups)
+        self.addConstrainVelocities()
+
+    def _substeps(self, parent, groups):
+        group, substeps = groups[0]
+        per_parent = substeps / parent
+        if per_parent < 1 or per_parent != int(per_parent):
+            raise ValueError("The number for substeps for each group must be a multiple of the number for the previous group")
+        if group < 0 or group > 31:
+            raise ValueError("Force group must be between 0 and 31")
+        kick = "v+0.5*(dt/%s)*f%s/m" % (substeps, group)
+        for _ in range(int(per_parent)):
+            self.addComputePerDof("v", kick)
+            if len(groups) == 1:
+                self.addComputePerDof("x", "x+(dt/%s)*v" % substeps)
+                self.addComputePerDof("x1", "x")
+                self.addConstrainPositions()
+                self.addComputePerDof("v", "v+(x-x1)/(dt/%s)" % substeps)
+                self.addConstrainVelocities()
+            else:
+                self._substeps(substeps, groups[1:])
+            self.addComputePerDof("v", kick)
+
+
 class MTSLangevinIntegrator(CustomIntegrator):
     """wrappers/python/openmm/mtsintegrator.py:112-199 (BAOAB-RESPA): groups = [(force group, evaluations per step), ...].  As there, the
     friction factors a and b are those of the FULL step and are applied once per innermost substep."""

@@ -301,6 +301,47 @@ def test_valence_kernels_against_numpy_energies(K, kind):
 
 
 @needs_emu
+def test_custom_forces_native_when_recognised_reference_kernel_otherwise():
+    """Three CustomBondForces and a CustomAngleForce on one System: the AMOEBA bond expression with its per-bond parameters declared in the
+    other order (native: the kernel's parameters are found by name), the same expression written differently (a*b instead of b*a: not
+    recognised -> the Reference kernel inside the same kernel object, a fallback force), a Morse bond (Reference), the AMOEBA angle
+    expression (native) -- forces and energy against the Reference platform, and the counter of native lists says which ran where."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from openmm_amd import harness as H
+H.load_hip_platform(emulated=True)
+rng = np.random.default_rng(3)
+n = 60
+pos = rng.uniform(0, 2.0, size=(n, 3))
+bonds = np.stack([np.arange(0, n - 1), np.arange(1, n)], -1)
+angles = np.stack([np.arange(0, n - 2), np.arange(1, n - 1), np.arange(2, n)], -1)
+r0 = 0.3 + 0.5 * rng.random(len(bonds)); k = 100 * (1 + rng.random(len(bonds))); theta0 = 100 + 20 * rng.random(len(angles))
+res = {}
+for plat in ("Reference", "HIP"):
+    s = H.System(); s.addParticles(np.full(n, 12.0))
+    s.addCustomBondForce("k*(d^2 + -25.5*d^3 + 379.3125*d^4); d=r-r0", ["k", "r0"], bonds, np.stack([k, r0], -1))                 # native, parameters swapped
+    s.addCustomBondForce("(d^2 + -25.5*d^3 + 379.3125*d^4)*k; d=r-r0", ["r0", "k"], bonds, np.stack([r0, 0.5 * k], -1))           # another shape: Reference
+    s.addCustomBondForce("D*(1-exp(-a*(r-r0)))^2", ["D", "a", "r0"], bonds, np.stack([k, np.full(len(bonds), 2.0), r0], -1))        # Reference
+    s.addCustomAngleForce("k*(d^2 + -0.014*d^3 + 5.6e-05*d^4 + -7e-07*d^5 + 2.2e-08*d^6); d=57.29577951308232*theta-theta0", ["theta0", "k"], angles,
+                          np.stack([theta0, 0.05 * np.ones(len(angles))], -1))                            # native
+    ctx = H.Context(s, H.Integrator(H.VERLET, 0.001), plat)
+    ctx.setPositions(pos)
+    before = H.valence_lists_launched() if plat == "HIP" else 0
+    st = ctx.getState(getForces=True, getEnergy=True)
+    res[plat] = (st.forces, st.potentialEnergy)
+    if plat == "HIP": print("LISTS", H.valence_lists_launched() - before, "MODE", ctx.getPlatformProperty("IntegrationMode"))
+    ctx.close()
+print("DF", np.abs(res["Reference"][0] - res["HIP"][0]).max() / np.abs(res["Reference"][0]).max(), "DE", abs(res["Reference"][1] - res["HIP"][1]) / abs(res["Reference"][1]))
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "LISTS 2 MODE device" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    import re
+    df, de = (float(v) for v in re.search(r"DF (\S+) DE (\S+)", out.stdout).groups())
+    assert df < 1e-9 and de < 1e-12, (df, de)
+
+
+@needs_emu
 def test_device_interpreter_evaluates_every_lepton_operation_like_the_reference():
     """One CustomIntegrator step whose per-DOF expressions use every operation the interpreter of kernels/custom_integrator.hip knows (all of
     Lepton's: arithmetic, powers, the transcendental functions, step / delta / select / min / max / abs / floor / ceil, constants folded and

@@ -68,7 +68,7 @@ def parse_args():
     p.add_argument("--no-scale-workload", action="store_true", help="N = 1: skip the single-GPU run of the strong-scaling workload")
     p.add_argument("--prepare-steps", type=int, default=-1, help="untimed steps that relax a lattice start before warm-up (input preparation; default 1000 for the water boxes -- after 200 steps a jittered lattice is still melting: 9 % more list rows and 40 % more list rebuilds per step than after 3000, profiles/r04h_prepare_steps_water1m.txt -- 0 for fixtures)")
     p.add_argument("--transport", default="rccl", choices=["rccl", "gloo"], help="collectives of the decomposed run: RCCL (product) or host-staged gloo (rehearsal on one GPU)")
-    p.add_argument("--profile-every", type=int, default=0, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region (0 = 7, or 2 for runs below 100 steps so that a 20-step run still holds 10 samples)")
+    p.add_argument("--profile-every", type=int, default=0, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region (0 = 7, or 4 for runs below 100 steps: a 20-step run then holds 6 samples and loses ~2 % to them)")
     p.add_argument("--no-extra-workloads", action="store_true", help="N = 1: skip the short runs of BASELINE.json configs[2] (apoa1-sized) and of the benchmark script's own 4 fs step")
     p.add_argument("--decompose", action="store_true", help="N = 1: run through the decomposed path with a one-rank RCCL communicator (overhead check on one GPU)")
     p.add_argument("--props", default="", help="extra HIP platform properties, e.g. DisablePmeStream=true")
@@ -245,9 +245,9 @@ def main():
     if profile:
         kernels.lib.ommhip_profile_reset()
         # the timed region is perturbed as little as possible: events are created beforehand; a short region (the driver's 20 steps) times
-        # only the dominant launch group, every 2nd launch (10 samples), a long one all five timers at every 7th launch
+        # only the dominant launch group, every 4th launch (6 samples), a long one all five timers at every 7th launch
         short = args.steps < 100 and args.profile_every <= 0
-        kernels.lib.ommhip_profile_enable_timers(args.profile_every if args.profile_every > 0 else (2 if short else 7), 0x1 if short else 0x1f, 64 if short else 512)
+        kernels.lib.ommhip_profile_enable_timers(args.profile_every if args.profile_every > 0 else (4 if short else 7), 0x1 if short else 0x1f, 64 if short else 512)
     serialized = decomposed and args.serialize_ranks and args.transport == "gloo"
     if serialized:
         barrier()
@@ -326,6 +326,22 @@ def main():
                     if k != "nb_direct":
                         timers[k] = probe[k]
                 timers["nb_direct"] = before["nb_direct"]
+            # The three fused launches one by one (their own dispatch timestamps: an event pair riding on every launch) are sampled AFTER the
+            # timed region -- 32 more steps, every launch -- because an event pair per launch costs ~40 us of host time per sampled step
+            # (a 20-step region with 10 such samples read 1 170 ns/day against 1 390 without: profiles/r09k_*); inside the region only the
+            # pair that brackets the group is taken (start stamped by the first launch, stop by the last), which costs ~1 %.
+            if world == 1 and timers["nb_direct"]["calls"] > 0:          # (one process: nobody else has to step along)
+                keep = dict(timers)
+                kernels.lib.ommhip_profile_enable_timers(1, 0x1 | (0x7 << 5), 64)
+                integ.step(32)
+                ctx.getState(getEnergy=True)
+                kernels.lib.ommhip_profile_enable(0)
+                after = collect_timers(kernels)
+                for k in range(3):
+                    timers["pairs_fft_stage%d" % k] = after.get("pairs_fft_stage%d" % k, {"calls": 0, "avg_us": None})
+                for k in keep:
+                    if not k.startswith("pairs_fft_stage"):
+                        timers[k] = keep[k]
             # algorithmic bytes of one launch: per row 64 j-slots x (index 4 + mask 4 + posq 16 + sigEps 8 + force 24)
             # plus per chunk 32 i-atoms x (posq 16 + sigEps 8 + force 24)
             algo_bytes = rows * 64 * 56 + chunks * 32 * 48
@@ -367,7 +383,7 @@ def main():
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5) if achieved else None, "traffic": traffic,
                                "traffic_source": traffic_source,
                                "algorithmic_bytes_per_launch": int(algo_bytes), "avg_kernel_us": round(avg_us, 3) if avg_us else None,
-                               "avg_kernel_us_source": ("sum of the three launches' own dispatch timestamps (hipExtLaunchKernelGGL start / stop events)" if fused and all(v for v in stage_us)
+                               "avg_kernel_us_source": ("sum of the three launches' own dispatch timestamps (hipExtLaunchKernelGGL start / stop events on every launch of 32 steps after the timed region; avg_span_us_including_launch_gaps is the in-region sample of the group)" if fused and all(v for v in stage_us)
                                                         else "HIP events around the launch"),
                                "avg_span_us_including_launch_gaps": round(span_us, 3) if span_us else None,
                                "rows": int(rows), "chunks": int(chunks), "rebuilds": int(stats[5]),

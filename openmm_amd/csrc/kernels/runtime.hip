@@ -119,8 +119,7 @@ int ommhip_profile_enable_timers(int every, unsigned mask, int reserve) {
     // (an event pair costs more to create than a small kernel takes: a 20-step timed region should not pay for that)
     profileEnabled = every < 0 ? 0 : every; profileMask = mask;
     for (int i = 0; i < OMMHIP_PROFILE_NUM_TIMERS; i++) {
-        // (the per-launch timers of the fused pair + FFT launches follow timer 0)
-        if (((mask >> i) & 1u) == 0 && !(i >= OMMHIP_TIMER_PAIRS_FFT_STAGE0 && i <= OMMHIP_TIMER_PAIRS_FFT_STAGE2 && (mask & 1u) != 0)) continue;
+        if (((mask >> i) & 1u) == 0) continue;
         while ((int) timers[i].start.size() < reserve) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 1;
@@ -163,7 +162,7 @@ int ommhip_profile_take(int timer, void** start_event, void** stop_event) {
 int ommhip_profile_take_if(int timer, int with_timer, void** start_event, void** stop_event) {
     *start_event = nullptr; *stop_event = nullptr;
     if (!profileEnabled || timer < 0 || timer >= OMMHIP_PROFILE_NUM_TIMERS) return 0;
-    if (with_timer < 0 && ((profileMask >> timer) & 1u) == 0) return 0;
+    if (((profileMask >> timer) & 1u) == 0) return 0;           // (a following timer needs its own bit too: every event pair on a launch costs)
     ProfileTimer& t = timers[timer];
     if (with_timer >= 0) { if (with_timer >= OMMHIP_PROFILE_NUM_TIMERS || !timers[with_timer].lastTaken) return 0; }
     else {

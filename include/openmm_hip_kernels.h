@@ -359,6 +359,9 @@ int ommhip_pme_reciprocal_dd(const ommhip_pme* pme, const void* posq_d, int padd
 /* Only the middle: grid_real (charges, or multipole moments spread by somebody else) -> forward transform, influence function, backward
  * transform -> grid_real (the reciprocal-space potential at the grid points).  Used by the AMOEBA multipole kernels (openmm_hip_amoeba.h). */
 int ommhip_pme_convolve(const ommhip_pme* pme, void* stream);
+/* The same for two grids of one shape in the same three launches (each launch fills a fraction of the chip for one grid).  -1: the shape
+ * is not covered (planes beyond the fused plane kernel): nothing was launched, call ommhip_pme_convolve twice. */
+int ommhip_pme_convolve2(const ommhip_pme* pme, const ommhip_pme* pme2, void* stream);
 /* test hook: forward (grid_real -> grid_complex) or backward (grid_complex -> grid_real) unnormalised 3-D transform */
 int ommhip_fft3d_r2c_c2r(const ommhip_pme* pme, int forward, void* stream);
 

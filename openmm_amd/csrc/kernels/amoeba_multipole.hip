@@ -190,6 +190,7 @@ struct MpArgs {
     BoxD box;
     double a[3][3];            // a[k][c] = d(grid coordinate k) / d(Cartesian c) = n_k * recip[c][k]
     float* grid;
+    float* grid2;                                  // second grid of a two-grid launch (blockIdx.y == 1), else unused
     const int* slotOfAtom;
     omm_fixed* force;
     double* energyBuffer;
@@ -369,8 +370,9 @@ __global__ void k_mp_spread(MpArgs a, const double* __restrict__ A, double sA, c
 #define MPB_ZS (MPB_BRICK + 1)
 __device__ __forceinline__ int mpb_wrap_rel(int d, int n) { if (d >= (n + 1) / 2) d -= n; if (d < -(n / 2)) d += n; return d; }
 
-__global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double* __restrict__ A, double sA, const double* __restrict__ B, double sB) {
+__global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double* __restrict__ A, double sA, const double* __restrict__ B, double sB, const double* __restrict__ A2) {
     if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;           // an iteration enqueued ahead of the convergence check (solve_mutual)
+    if (blockIdx.y == 1) { a.grid = a.grid2; A = A2; }                 // two-grid launch: the second set of dipoles onto the second grid
     __shared__ int brick[MPB_BRICK * MPB_BRICK * MPB_ZS];
     __shared__ float th[MPB_ATOMS][3][5], dth[MPB_ATOMS][3][5], fd[MPB_ATOMS][3];
     __shared__ int base[MPB_ATOMS][3], ok[MPB_ATOMS], ref[3], minRel[3];
@@ -460,8 +462,9 @@ __global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double
 // iteration reads, at a third of the arithmetic; MAXORD = 2: up to the second derivatives (out[0..9]), the field gradient the
 // extrapolated-polarization scheme keeps of every order.
 template <int MAXORD>
-__global__ void k_mp_potential(MpArgs a, double* __restrict__ out) {
+__global__ void k_mp_potential(MpArgs a, double* __restrict__ out, double* __restrict__ out2) {
     if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;
+    if (blockIdx.y == 1) { a.grid = a.grid2; out = out2; }
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = tid / MP_SPREAD_LANES, iz = tid % MP_SPREAD_LANES;
     const bool atom = i < a.n, mine = atom && iz < 5;
@@ -1303,7 +1306,7 @@ bool make_args(const ommhip_amoeba_multipole* mp, const void* pos_d, const doubl
     const int n[3] = {a.nx, a.ny, a.nz};
     for (int k = 0; k < 3; k++)
         for (int c = 0; c < 3; c++) a.a[k][c] = n[k] * R[c][k];
-    a.grid = (float*) pme->grid_real;
+    a.grid = (float*) pme->grid_real; a.grid2 = nullptr;
     a.slotOfAtom = nullptr; a.force = nullptr; a.energyBuffer = nullptr;
     // pair lists: scan positions = the platform's slots when the caller provides the order, atoms otherwise
     if (mp->pair_list == nullptr || mp->pair_count == nullptr || mp->pair_overflow == nullptr || mp->special_pos == nullptr || mp->special_scale_sorted == nullptr || mp->tile_bounds == nullptr || mp->pair_cap < 1) return false;
@@ -1359,7 +1362,7 @@ int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const doub
     hipMemsetAsync(a.grid, 0, gridBytes, st);
     hipLaunchKernelGGL(k_mp_spread<false>, dim3(spread_blocks(a)), dim3(256), 0, st, a, (const double*) nullptr, 0.0, (const double*) nullptr, 0.0);
     ommhip_pme_convolve(pme, st);
-    hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phi);
+    hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phi, (double*) nullptr);
     if (mp->mixed_precision) {
         hipLaunchKernelGGL(k_mp_special<false>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, st, a);
         hipLaunchKernelGGL(k_mp_field<true>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
@@ -1373,7 +1376,7 @@ int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const doub
 void spread_induced(const MpArgs& a, const double* A, double sA, const double* B, double sB, hipStream_t st) {
     static const bool noBricks = getenv("OPENMM_HIP_AMOEBA_NO_BRICKS") != nullptr;
     if (a.order != nullptr && !noBricks && a.nx >= MPB_BRICK && a.ny >= MPB_BRICK && a.nz >= MPB_BRICK)
-        hipLaunchKernelGGL(k_mp_spread_bricks, dim3((a.numScan + MPB_ATOMS - 1) / MPB_ATOMS), dim3(256), 0, st, a, A, sA, B, sB);
+        hipLaunchKernelGGL(k_mp_spread_bricks, dim3((a.numScan + MPB_ATOMS - 1) / MPB_ATOMS), dim3(256), 0, st, a, A, sA, B, sB, (const double*) nullptr);
     else
         hipLaunchKernelGGL(k_mp_spread<true>, dim3(spread_blocks(a)), dim3(256), 0, st, a, A, sA, B, sB);
 }
@@ -1383,9 +1386,9 @@ void dipole_potential(const ommhip_pme* pme, const MpArgs& a, const double* dipo
     hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, st);
     spread_induced(a, dipoles, 1.0, nullptr, 0.0, st);
     ommhip_pme_convolve(pme, st);
-    if (maxOrder == 1) hipLaunchKernelGGL(k_mp_potential<1>, dim3(spread_blocks(a)), dim3(256), 0, st, a, out);
-    else if (maxOrder == 2) hipLaunchKernelGGL(k_mp_potential<2>, dim3(spread_blocks(a)), dim3(256), 0, st, a, out);
-    else hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, out);
+    if (maxOrder == 1) hipLaunchKernelGGL(k_mp_potential<1>, dim3(spread_blocks(a)), dim3(256), 0, st, a, out, (double*) nullptr);
+    else if (maxOrder == 2) hipLaunchKernelGGL(k_mp_potential<2>, dim3(spread_blocks(a)), dim3(256), 0, st, a, out, (double*) nullptr);
+    else hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, out, (double*) nullptr);
 }
 
 // The potentials of two sets of dipoles.  The chain of one set -- clear, spread, three transform launches, read-back -- is six small launches
@@ -1399,6 +1402,32 @@ void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const
     if (pme2 == nullptr || mp->stream2 == nullptr || mp->event_a == nullptr || mp->event_b == nullptr || pme2->grid_real == nullptr || pme2->grid_real == pme->grid_real) {
         dipole_potential(pme, a, vD, outD, st, fieldOnly);
         dipole_potential(pme, a, vP, outP, st, fieldOnly);
+        return;
+    }
+    // Both chains in the SAME launches (blockIdx.y picks the set of dipoles and its grid): six launches per pair of potentials instead of
+    // twelve on two streams with two ordering events.  OPENMM_HIP_AMOEBA_TWO_STREAMS=1 restores the two streams (A/B).
+    static const bool twoStreams = getenv("OPENMM_HIP_AMOEBA_TWO_STREAMS") != nullptr && getenv("OPENMM_HIP_AMOEBA_TWO_STREAMS")[0] == '1';
+    static const bool noBricks2 = getenv("OPENMM_HIP_AMOEBA_NO_BRICKS") != nullptr;
+    if (!twoStreams && !noBricks2 && a.order != nullptr && a.nx >= MPB_BRICK && a.ny >= MPB_BRICK && a.nz >= MPB_BRICK && pme->nx == pme2->nx && pme->ny == pme2->ny && pme->nz == pme2->nz &&
+            pme->nz * (pme->ny + 1) <= 9472 && pme->fft_mode != 1) {
+        MpArgs b = a;
+        b.grid2 = (float*) pme2->grid_real;
+        const size_t gridBytes = sizeof(float) * (size_t) a.nx * a.ny * a.nz;
+        hipMemsetAsync(b.grid, 0, gridBytes, st);
+        hipMemsetAsync(b.grid2, 0, gridBytes, st);
+        hipLaunchKernelGGL(k_mp_spread_bricks, dim3((a.numScan + MPB_ATOMS - 1) / MPB_ATOMS, 2), dim3(256), 0, st, b, vD, 1.0, (const double*) nullptr, 0.0, vP);
+        if (ommhip_pme_convolve2(pme, pme2, st) == 0) {
+            if (fieldOnly == 1) hipLaunchKernelGGL(k_mp_potential<1>, dim3(spread_blocks(a), 2), dim3(256), 0, st, b, outD, outP);
+            else if (fieldOnly == 2) hipLaunchKernelGGL(k_mp_potential<2>, dim3(spread_blocks(a), 2), dim3(256), 0, st, b, outD, outP);
+            else hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a), 2), dim3(256), 0, st, b, outD, outP);
+            return;
+        }
+        // (shape not covered by the two-grid transform: the grids are spread already -- finish them one after the other)
+        ommhip_pme_convolve(pme, st);
+        ommhip_pme_convolve(pme2, st);
+        if (fieldOnly == 1) hipLaunchKernelGGL(k_mp_potential<1>, dim3(spread_blocks(a), 2), dim3(256), 0, st, b, outD, outP);
+        else if (fieldOnly == 2) hipLaunchKernelGGL(k_mp_potential<2>, dim3(spread_blocks(a), 2), dim3(256), 0, st, b, outD, outP);
+        else hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a), 2), dim3(256), 0, st, b, outD, outP);
         return;
     }
     hipStream_t st2 = (hipStream_t) mp->stream2;
@@ -1533,7 +1562,7 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
         hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, st);
         spread_induced(a, a.indD, 0.5, a.indP, 0.5, st);
         ommhip_pme_convolve(pme, st);
-        hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phiInd);
+        hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phiInd, (double*) nullptr);
     }
     if (mp->mixed_precision) {
         hipLaunchKernelGGL(k_mp_special<true>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, st, a);

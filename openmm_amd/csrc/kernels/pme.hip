@@ -1542,6 +1542,47 @@ extern "C" int ommhip_pme_convolve(const ommhip_pme* pme, void* stream) {
     return (int) hipGetLastError();
 }
 
+// The same for TWO grids of one shape in the same three launches (blockIdx.y picks the grid): the AMOEBA solver convolves the potentials of
+// two sets of induced dipoles per iteration, and each of these launches fills a fraction of the chip (openmm_hip_amoeba.h).
+namespace {
+__global__ __launch_bounds__(PLANE_THREADS) void fft_plane_kernel2(PlaneArgs a, PlaneArgs b) {
+    __shared__ PlaneShared<PLANE_MAX> sh;
+    fft_plane_body<PLANE_THREADS, PLANE_MAX>(blockIdx.y == 0 ? a : b, blockIdx.x, sh);
+}
+__global__ __launch_bounds__(FFT_THREADS) void fft_kernel2_xconv(FftArgs a, FftArgs b) {
+    __shared__ FftShared sh;
+    const FftArgs& f = blockIdx.y == 0 ? a : b;
+    fft_body_mode<FFT_THREADS, 3, false, false>(f, blockIdx.x, sh, gridDim.x, f.numOuter * ((f.numInner + f.B - 1) / f.B));
+}
+}  // namespace
+
+extern "C" int ommhip_pme_convolve2(const ommhip_pme* pme, const ommhip_pme* pme2, void* stream) {
+    hipStream_t st = (hipStream_t) stream;
+    if (pme->nx != pme2->nx || pme->ny != pme2->ny || pme->nz != pme2->nz || plane_kernel_kind(pme, pme->nx) != 1 || plane_kernel_kind(pme2, pme2->nx) != 1) return -1;
+    const int nx = pme->nx, ny = pme->ny, nz = pme->nz, nzc = nz / 2 + 1;
+    FftArgs f[2];
+    PlaneArgs fwd[2], bwd[2];
+    const ommhip_pme* both[2] = {pme, pme2};
+    for (int g = 0; g < 2; g++) {
+        float2* cgrid = (float2*) both[g]->grid_complex;
+        fwd[g] = make_plane_args(both[g], true); fwd[g].cplx = cgrid;
+        bwd[g] = make_plane_args(both[g], false); bwd[g].cplx = cgrid;
+        FftArgs& x = f[g];
+        x.diag = nullptr;
+        x.remapIn = x.remapOut = 0; x.remapNxl = x.remapNyl = 1;
+        x.energyBuffer = nullptr; x.energySlots = 1; x.nzFull = nz;
+        x.plan = make_plan(nx); x.B = lines_per_group(nx); x.numOuter = ny; x.numInner = nzc;
+        x.inOuterStride = nzc; x.inInnerStride = 1; x.inElemStride = (long long) ny * nzc;
+        x.outOuterStride = nzc; x.outInnerStride = 1; x.outElemStride = (long long) ny * nzc;
+        x.mode = 3; x.sign = -1; x.twiddle = (const float2*) both[g]->twiddle_x; x.in = cgrid; x.out = cgrid;
+        x.eterm = (const float*) both[g]->eterm;
+    }
+    hipLaunchKernelGGL(fft_plane_kernel2, dim3(nx, 2), dim3(PLANE_THREADS), 0, st, fwd[0], fwd[1]);
+    hipLaunchKernelGGL(fft_kernel2_xconv, dim3(fft_grid(f[0].numOuter * ((f[0].numInner + f[0].B - 1) / f[0].B)), 2), dim3(FFT_THREADS), 0, st, f[0], f[1]);
+    hipLaunchKernelGGL(fft_plane_kernel2, dim3(nx, 2), dim3(PLANE_THREADS), 0, st, bwd[0], bwd[1]);
+    return (int) hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // One rank of a slab-decomposed reciprocal-space evaluation.  Same kernels as above; what changes is which
 // planes / rows a launch covers and where the complex data sits, so that each of the two transposes is ONE all-to-all of

@@ -1413,8 +1413,8 @@ void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const
         MpArgs b = a;
         b.grid2 = (float*) pme2->grid_real;
         const size_t gridBytes = sizeof(float) * (size_t) a.nx * a.ny * a.nz;
-        hipMemsetAsync(b.grid, 0, gridBytes, st);
-        hipMemsetAsync(b.grid2, 0, gridBytes, st);
+        if ((gridBytes & 15) == 0) ommhip_clear2(b.grid, gridBytes, b.grid2, gridBytes, (void*) st);          // both grids in one launch
+        else { hipMemsetAsync(b.grid, 0, gridBytes, st); hipMemsetAsync(b.grid2, 0, gridBytes, st); }
         hipLaunchKernelGGL(k_mp_spread_bricks, dim3((a.numScan + MPB_ATOMS - 1) / MPB_ATOMS, 2), dim3(256), 0, st, b, vD, 1.0, (const double*) nullptr, 0.0, vP);
         if (ommhip_pme_convolve2(pme, pme2, st) == 0) {
             if (fieldOnly == 1) hipLaunchKernelGGL(k_mp_potential<1>, dim3(spread_blocks(a), 2), dim3(256), 0, st, b, outD, outP);

@@ -372,7 +372,10 @@ __device__ __forceinline__ int mpb_wrap_rel(int d, int n) { if (d >= (n + 1) / 2
 
 __global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double* __restrict__ A, double sA, const double* __restrict__ B, double sB, const double* __restrict__ A2) {
     if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;           // an iteration enqueued ahead of the convergence check (solve_mutual)
-    if (blockIdx.y == 1) { a.grid = a.grid2; A = A2; }                 // two-grid launch: the second set of dipoles onto the second grid
+    // two-grid launch: the second set of dipoles onto the second grid (the argument struct itself is left alone: a modified copy would
+    // move all of it from scalar kernel-argument loads to private memory)
+    float* const grid = blockIdx.y == 1 ? a.grid2 : a.grid;
+    if (blockIdx.y == 1) A = A2;
     __shared__ int brick[MPB_BRICK * MPB_BRICK * MPB_ZS];
     __shared__ float th[MPB_ATOMS][3][5], dth[MPB_ATOMS][3][5], fd[MPB_ATOMS][3];
     __shared__ int base[MPB_ATOMS][3], ok[MPB_ATOMS], ref[3], minRel[3];
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double
             if (fits) atomicAdd(&brick[((off[0] + ix) * MPB_BRICK + off[1] + iy) * MPB_ZS + off[2] + iz], __float2int_rn(v * scale));
             else {
                 const int gx = (base[atom][0] + ix) % a.nx, gy = (base[atom][1] + iy) % a.ny, gz = (base[atom][2] + iz) % a.nz;
-                atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], v);
+                atomicAdd(&grid[((size_t) gx * a.ny + gy) * a.nz + gz], v);
             }
         }
     }
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double
             int gx = org[0] + w / (MPB_BRICK * MPB_ZS); gx -= gx >= a.nx ? a.nx : 0;
             int gy = org[1] + (w / MPB_ZS) % MPB_BRICK; gy -= gy >= a.ny ? a.ny : 0;
             int gz = org[2] + w % MPB_ZS; gz -= gz >= a.nz ? a.nz : 0;
-            atomicAdd(&a.grid[((size_t) gx * a.ny + gy) * a.nz + gz], (float) fixed * invScale);
+            atomicAdd(&grid[((size_t) gx * a.ny + gy) * a.nz + gz], (float) fixed * invScale);
         }
     }
 }
@@ -464,7 +467,8 @@ __global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double
 template <int MAXORD>
 __global__ void k_mp_potential(MpArgs a, double* __restrict__ out, double* __restrict__ out2) {
     if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;
-    if (blockIdx.y == 1) { a.grid = a.grid2; out = out2; }
+    const float* const grid = blockIdx.y == 1 ? a.grid2 : a.grid;          // (see k_mp_spread_bricks)
+    if (blockIdx.y == 1) out = out2;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = tid / MP_SPREAD_LANES, iz = tid % MP_SPREAD_LANES;
     const bool atom = i < a.n, mine = atom && iz < 5;
@@ -480,7 +484,7 @@ __global__ void k_mp_potential(MpArgs a, double* __restrict__ out, double* __res
             const int gx = (idx[0] + ix) % a.nx;
             for (int iy = 0; iy < 5; iy++) {
                 const int gy = (idx[1] + iy) % a.ny;
-                const double g = (double) a.grid[((size_t) gx * a.ny + gy) * a.nz + gz];
+                const double g = (double) grid[((size_t) gx * a.ny + gy) * a.nz + gz];
                 for (int p = 0; p < NO; p++) {
                     const double gp = g * th[0][p][ix];
                     for (int q = 0; p + q < NO; q++) G[p][q] += gp * th[1][q][iy];

@@ -191,6 +191,7 @@ struct MpArgs {
     double a[3][3];            // a[k][c] = d(grid coordinate k) / d(Cartesian c) = n_k * recip[c][k]
     float* grid;
     float* grid2;                                  // second grid of a two-grid launch (blockIdx.y == 1), else unused
+    int clearGrids;                                // k_mp_cg stage 3 also zeroes grid and grid2 (for the spreading of the next iteration)
     const int* slotOfAtom;
     omm_fixed* force;
     double* energyBuffer;
@@ -1167,6 +1168,14 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double target, double un
             }
         }
     }
+    if (stage == 3 && a.clearGrids) {
+        // the two grids are dead between the read-back of this iteration's potentials and the spreading of the next one: zeroed here, not
+        // by a launch of their own in front of the spreading
+        const size_t quads = (size_t) a.nx * a.ny * a.nz / 4, total = (size_t) gridDim.x * blockDim.x;
+        float4* g0 = (float4*) a.grid; float4* g1 = (float4*) a.grid2;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x; k < quads; k += total) { g0[k] = z; g1[k] = z; }
+    }
     if (stage == 3) {
         // the block that finishes last ends the iteration (what stage 4 does as a launch of its own): every block has read the step
         // lengths from the sums before it takes its ticket
@@ -1310,7 +1319,7 @@ bool make_args(const ommhip_amoeba_multipole* mp, const void* pos_d, const doubl
     const int n[3] = {a.nx, a.ny, a.nz};
     for (int k = 0; k < 3; k++)
         for (int c = 0; c < 3; c++) a.a[k][c] = n[k] * R[c][k];
-    a.grid = (float*) pme->grid_real; a.grid2 = nullptr;
+    a.grid = (float*) pme->grid_real; a.grid2 = nullptr; a.clearGrids = 0;
     a.slotOfAtom = nullptr; a.force = nullptr; a.energyBuffer = nullptr;
     // pair lists: scan positions = the platform's slots when the caller provides the order, atoms otherwise
     if (mp->pair_list == nullptr || mp->pair_count == nullptr || mp->pair_overflow == nullptr || mp->special_pos == nullptr || mp->special_scale_sorted == nullptr || mp->tile_bounds == nullptr || mp->pair_cap < 1) return false;
@@ -1399,7 +1408,19 @@ void dipole_potential(const ommhip_pme* pme, const MpArgs& a, const double* dipo
 // that leave most of the chip idle; with a second grid and a side stream (pme2, stream2, two ordering events: optional in the C ABI) the
 // chain of the second set runs beside that of the first.
 // fieldOnly: potential and gradient only (a solver iteration); the derivatives up to third order are computed for the converged dipoles
-void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double* vD, double* outD, const double* vP, double* outP, hipStream_t st, bool fieldOnlyFlag = false, int maxOrder = 0) {
+// Do the two sets of induced dipoles travel through the same launches (dipole_potentials)?
+bool two_grid_launches(const ommhip_amoeba_multipole* mp, const MpArgs& a) {
+    const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
+    const ommhip_pme* pme2 = (const ommhip_pme*) mp->pme2;
+    static const bool twoStreams = getenv("OPENMM_HIP_AMOEBA_TWO_STREAMS") != nullptr && getenv("OPENMM_HIP_AMOEBA_TWO_STREAMS")[0] == '1';
+    static const bool noBricks = getenv("OPENMM_HIP_AMOEBA_NO_BRICKS") != nullptr;
+    if (pme2 == nullptr || pme2->grid_real == nullptr || pme2->grid_real == pme->grid_real) return false;
+    return !twoStreams && !noBricks && a.order != nullptr && a.nx >= MPB_BRICK && a.ny >= MPB_BRICK && a.nz >= MPB_BRICK && pme->nx == pme2->nx && pme->ny == pme2->ny &&
+           pme->nz == pme2->nz && pme->nz * (pme->ny + 1) <= 9472 && pme->fft_mode != 1 && ((size_t) a.nx * a.ny * a.nz) % 4 == 0;
+}
+
+// precleared: both grids are zero already (k_mp_cg stage 3 of the iteration before, two-grid launches only: two_grid_launches())
+void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double* vD, double* outD, const double* vP, double* outP, hipStream_t st, bool fieldOnlyFlag = false, int maxOrder = 0, bool precleared = false) {
     const int fieldOnly = maxOrder > 0 ? maxOrder : (fieldOnlyFlag ? 1 : 3);
     const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
     const ommhip_pme* pme2 = (const ommhip_pme*) mp->pme2;
@@ -1410,14 +1431,12 @@ void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const
     }
     // Both chains in the SAME launches (blockIdx.y picks the set of dipoles and its grid): six launches per pair of potentials instead of
     // twelve on two streams with two ordering events.  OPENMM_HIP_AMOEBA_TWO_STREAMS=1 restores the two streams (A/B).
-    static const bool twoStreams = getenv("OPENMM_HIP_AMOEBA_TWO_STREAMS") != nullptr && getenv("OPENMM_HIP_AMOEBA_TWO_STREAMS")[0] == '1';
-    static const bool noBricks2 = getenv("OPENMM_HIP_AMOEBA_NO_BRICKS") != nullptr;
-    if (!twoStreams && !noBricks2 && a.order != nullptr && a.nx >= MPB_BRICK && a.ny >= MPB_BRICK && a.nz >= MPB_BRICK && pme->nx == pme2->nx && pme->ny == pme2->ny && pme->nz == pme2->nz &&
-            pme->nz * (pme->ny + 1) <= 9472 && pme->fft_mode != 1) {
+    if (two_grid_launches(mp, a)) {
         MpArgs b = a;
         b.grid2 = (float*) pme2->grid_real;
         const size_t gridBytes = sizeof(float) * (size_t) a.nx * a.ny * a.nz;
-        if ((gridBytes & 15) == 0) ommhip_clear2(b.grid, gridBytes, b.grid2, gridBytes, (void*) st);          // both grids in one launch
+        if (precleared) { }
+        else if ((gridBytes & 15) == 0) ommhip_clear2(b.grid, gridBytes, b.grid2, gridBytes, (void*) st);          // both grids in one launch
         else { hipMemsetAsync(b.grid, 0, gridBytes, st); hipMemsetAsync(b.grid2, 0, gridBytes, st); }
         hipLaunchKernelGGL(k_mp_spread_bricks, dim3((a.numScan + MPB_ATOMS - 1) / MPB_ATOMS, 2), dim3(256), 0, st, b, vD, 1.0, (const double*) nullptr, 0.0, vP);
         if (ommhip_pme_convolve2(pme, pme2, st) == 0) {
@@ -1486,8 +1505,13 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st) {
     int rc = 0, enqueued = 0;
     bool done = false;
     if (unchecked == 0) { rc = readSums(); if (rc != 0) return rc; done = h[10] != 0.0; }
+    // two-grid launches: stage 3 of every iteration leaves the grids zeroed for the spreading of the next one
+    static const bool clearLaunch = getenv("OPENMM_HIP_AMOEBA_CLEAR_LAUNCH") != nullptr;   // A/B: the clear as its own launch
+    const bool clearInStage3 = two_grid_launches(mp, a) && !clearLaunch;
+    MpArgs aClear = a;
+    if (clearInStage3) { aClear.grid2 = (float*) ((const ommhip_pme*) mp->pme2)->grid_real; aClear.clearGrids = 1; }
     while (!done && enqueued < mp->max_iterations) {
-        dipole_potentials(mp, a, pD, a.phiInd, pP, a.phiIndP, st, true);
+        dipole_potentials(mp, a, pD, a.phiInd, pP, a.phiIndP, st, true, 0, clearInStage3 && enqueued > 0);
         if (a.precond) {
             hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP, w, -1);
             hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 1, 0.0, 0.0);      // Ap, p.Ap
@@ -1495,7 +1519,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st) {
         else hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP, w, 1);      // T p, Ap, p.Ap
         hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 2, 0.0, 0.0);          // mu += a p, r -= a Ap (a from the device sums)
         if (a.precond) hipLaunchKernelGGL(k_mp_precond, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, w, 0);      // z = M r, r.z
-        hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 3, mp->target_epsilon, 0.0);   // p = z + b p; the last block rolls the sums and forms the measure and the convergence word
+        hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, aClear, w, 3, mp->target_epsilon, 0.0);   // p = z + b p; the last block rolls the sums and forms the measure and the convergence word
         enqueued++;
         if (enqueued >= unchecked || enqueued == mp->max_iterations) { rc = readSums(); if (rc != 0) return rc; done = h[10] != 0.0; }
     }

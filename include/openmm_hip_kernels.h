@@ -102,8 +102,10 @@ int ommhip_set_slot_params(const double* charge_d, const double* sigma_d, const 
 int ommhip_forces_to_double(const long long* force_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, double* out_d, void* stream);
 /* force[slot] += in[3*atom..] (double) */
 int ommhip_add_forces_from_double(const double* in_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, long long* force_d, void* stream);
-/* wire[s] = fixed-point box fractions of pos[atom_of_slot[s]] for the valid slots of [slot0, slot1)  (ommhip_neighbor_list::pos_wire) */
-int ommhip_encode_wire(const void* pos_d, const int* atom_of_slot_d, int slot0, int slot1, const double box_len[3], void* wire_d, void* stream);
+/* wire[s] = fixed-point box fractions of pos[atom_of_slot[s]] for the valid slots of [slot0, slot1)  (ommhip_neighbor_list::pos_wire);
+ * box = (ax, bx, by, cx, cy, cz) of the reduced box vectors a = (ax, 0, 0), b = (bx, by, 0), c = (cx, cy, cz): the fractions are the
+ * coefficients of a, b, c, each wrapped into [0, 1) */
+int ommhip_encode_wire(const void* pos_d, const int* atom_of_slot_d, int slot0, int slot1, const double box[6], void* wire_d, void* stream);
 /* Decomposed runs: zero the flag word (fourth double) of every rank's trailer record in the wire buffer (ommhip_neighbor_list::dd_flags);
  * the momentum in the first three doubles stays.  Called at every re-sort. */
 int ommhip_clear_trailer_flags(void* wire_d, int ranks, int slots_per_rank, int trailer_slot, void* stream);
@@ -542,7 +544,8 @@ typedef struct ommhip_step_units {
      * doubles, into the two wire records [trailer_slot, trailer_slot + 1] of its range (trailer_slot even, no atoms there)
      * in addition to cm_scratch[0..2], and the CM velocity subtracted is the sum of the `ranks` trailers. */
     void* pos_wire;
-    double box_len[3];
+    double box_len[3];         /* ax, by, cz */
+    double box_skew[3];        /* bx, cx, cy (0 for a rectangular box) */
     int ranks, rank, slots_per_rank, trailer_slot;
     /* 1: no unit is a SHAKE cluster (SETTLE waters and free atoms only, at most three atoms per unit): the kernel variant without
      * the fourth atom's state and the SHAKE iteration is launched (fewer registers, more waves per SIMD) */

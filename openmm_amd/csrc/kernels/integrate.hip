@@ -392,7 +392,8 @@ struct UnitArgs {
     // momentum lives in two reserved records per rank of that buffer ("trailer": 32 bytes = three doubles), so the CM velocity
     // needs no collective of its own
     uint4* posWire;
-    double invBox[3];
+    double invBox[3];         // 1 / ax, 1 / by, 1 / cz
+    double skew[3];           // bx, cx, cy
     int ranks, rank, slotsPerRank, trailerSlot;
     const int* ddFlags;       // halo mode: [1] = an owned atom is near (1) or close to the end of (3) the drift margin -> fourth double of the trailer (every rank sees it one step later)
 };
@@ -486,7 +487,9 @@ __global__ __launch_bounds__(128) void k_step_units(IntArgs a, UnitArgs u) {
                 a.pos[ids[k]] = make_double4(xn[k].x, xn[k].y, xn[k].z, xw[k]);
                 if (u.posWire != nullptr) {
                     // fraction of the box edge in [0, 1) as 32-bit fixed point (the wrap into the box is the conversion's modulo)
-                    double fx = xn[k].x * u.invBox[0], fy = xn[k].y * u.invBox[1], fz = xn[k].z * u.invBox[2];
+                    // (coefficients of the box vectors c, b, a in turn; a rectangular box has skew = 0 and these are x / ax, y / by, z / cz)
+                    const double fz0 = xn[k].z * u.invBox[2], fy0 = (xn[k].y - fz0 * u.skew[2]) * u.invBox[1];
+                    double fx = (xn[k].x - fy0 * u.skew[0] - fz0 * u.skew[1]) * u.invBox[0], fy = fy0, fz = fz0;
                     fx -= floor(fx); fy -= floor(fy); fz -= floor(fz);
                     u.posWire[a.slotOfAtom[ids[k]]] = make_uint4((unsigned) (unsigned long long) (fx * 4294967296.0), (unsigned) (unsigned long long) (fy * 4294967296.0),
                                                                (unsigned) (unsigned long long) (fz * 4294967296.0), 0u);
@@ -709,7 +712,7 @@ extern "C" int ommhip_integrate_fused(int integrator, const ommhip_integrator_st
     u.tol = units->tol; u.invTotalMass = units->inv_total_mass;
     u.atoms = (const int4*) units->atoms; u.dist = (const double4*) units->dist; u.cm = units->cm_scratch;
     u.posWire = (uint4*) units->pos_wire;
-    for (int k = 0; k < 3; k++) u.invBox[k] = units->box_len[k] > 0 ? 1.0 / units->box_len[k] : 0.0;
+    for (int k = 0; k < 3; k++) { u.invBox[k] = units->box_len[k] > 0 ? 1.0 / units->box_len[k] : 0.0; u.skew[k] = units->box_skew[k]; }
     u.ranks = units->ranks; u.rank = units->rank; u.slotsPerRank = units->slots_per_rank; u.trailerSlot = units->trailer_slot;
     u.ddFlags = units->dd_flags;
     hipStream_t st = (hipStream_t) stream;

@@ -971,6 +971,10 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
         int level = 0;                                         // 1: re-sort soon (off the step), 3: re-sort now
         for (int r = 0; r < a.ddRanks; r++) level |= (int) ((const double4*) (a.posWire + (size_t) r * a.ddSlotsPerRank + a.ddTrailerSlot))->w;
         if (level != 0) a.ddFlags[2] |= level;               // bit 2 (4): some rank's atom left the margin -- every rank ends the run at the same evaluation
+        // This rank's list, as built last, fills 7/8 of its allocation: ask for a common re-sort NOW (level 3 travels in the trailer as
+        // the drift levels do) -- the rebuild after a re-sort is verified by the host, which grows the allocation to 1.5 x the list.  An
+        // overflow itself cannot be undone on a decomposed run (the other ranks have stepped on by the time they hear of it).
+        if (a.state[ST_NUM_CHUNKS] > a.maxChunks / 8 * 7) atomicOr(&a.ddFlags[1], 3);
     }
     const int atom = a.atomOfSlot[sl];
     const bool valid = inRange && atom >= 0;
@@ -979,13 +983,15 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
     if (valid) {
         if (a.posWire != nullptr) {
             // decomposed run: every slot -- own ones too, so that all ranks see the same numbers -- comes from the wire record,
-            // already wrapped into the box (rectangular by construction)
+            // already wrapped into the box: coefficients of the (reduced) box vectors, each in [0, 1)
             const uint4 u = a.posWire[sl];
             const double f = 1.0 / 4294967296.0;
-            xw = (double) u.x * f * boxd.ax; yw = (double) u.y * f * boxd.by; zw = (double) u.z * f * boxd.cz;
+            const double sx = (double) u.x * f, sy = (double) u.y * f, sz = (double) u.z * f;
+            xw = sx * boxd.ax + sy * boxd.bx + sz * boxd.cx; yw = sy * boxd.by + sz * boxd.cy; zw = sz * boxd.cz;
             const bool own = sl >= a.firstBlock * OMM_TILE && sl < (a.firstBlock + a.ownedBlocks) * OMM_TILE;
             if (a.wireRef != nullptr && own && (a.ddGuardAtom == nullptr || a.ddGuardAtom[atom] != 0)) {
-                // drift along x since the re-sort (wrap-around arithmetic of the 32-bit fractions = minimum image)
+                // drift along the first box fraction (x in a rectangular box: the slabs are cut in it) since the re-sort; wrap-around
+                // arithmetic of the 32-bit fractions = minimum image
                 const int d = (int) (u.x - a.wireRef[sl].x);
                 const unsigned ad = (unsigned) (d < 0 ? -d : d);
                 if (ad > a.ddWarn) {
@@ -1000,7 +1006,9 @@ __global__ __launch_bounds__(256) void nl_prepare(NlArgs a, const double4* __res
                 // atom-ordered copy of a foreign atom: the last known position moved by the minimum-image displacement
                 double4 o = a.posScatter[atom];
                 double dx = xw - o.x, dy = yw - o.y, dz = zw - o.z;
-                dx -= rint(dx / boxd.ax) * boxd.ax; dy -= rint(dy / boxd.by) * boxd.by; dz -= rint(dz / boxd.cz) * boxd.cz;
+                { const double n = rint(dz / boxd.cz); dx -= n * boxd.cx; dy -= n * boxd.cy; dz -= n * boxd.cz; }
+                { const double n = rint(dy / boxd.by); dx -= n * boxd.bx; dy -= n * boxd.by; }
+                dx -= rint(dx / boxd.ax) * boxd.ax;
                 o.x += dx; o.y += dy; o.z += dz;
                 a.posScatter[atom] = o;
             }

@@ -181,10 +181,11 @@ struct SpreadShared {
 
 template <bool DD>
 __device__ __forceinline__ void pme_spread_body(const PmeArgs& a, const int block, SpreadShared& sh) {
+    // a block without a bounding box: empty, or (halo mode) one this rank holds no current positions for -- whatever its slots contain
+    if (DD && a.blockHalf[block].x < 0.f) return;
     if (DD && a.recip.r10 == 0.f && a.recip.r20 == 0.f) {
         // rectangular box: blocks whose bounding box (+ stencil) lies clear of this rank's planes leave at once
         const float cx = a.blockCenter[block].x, hx = a.blockHalf[block].x;
-        if (hx < 0.f) return;                                                     // empty block
         const float lo = (cx - hx) * a.recip.r00 * a.nx - 1.f, hi = (cx + hx) * a.recip.r00 * a.nx + (float) PME_ORDER;
         if (hi - lo < (float) a.nx) {
             // distance (in planes, periodic) from the block's plane interval [lo, hi] to the own interval

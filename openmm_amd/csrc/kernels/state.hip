@@ -92,13 +92,15 @@ __global__ void k_posq_with_weights(const float4* __restrict__ posq, const doubl
 }
 
 // positions -> wire records (fixed-point fractions of the box edges), slot order
-__global__ void k_encode_wire(const double4* __restrict__ pos, const int* __restrict__ atomOfSlot, int slot0, int slot1, double ix, double iy, double iz, uint4* __restrict__ wire) {
+__global__ void k_encode_wire(const double4* __restrict__ pos, const int* __restrict__ atomOfSlot, int slot0, int slot1, double ix, double iy, double iz, double bx, double cx, double cy, uint4* __restrict__ wire) {
     const int s = slot0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= slot1) return;
     const int a = atomOfSlot[s];
     if (a < 0) return;
     const double4 p = pos[a];
-    double fx = p.x * ix, fy = p.y * iy, fz = p.z * iz;
+    // coefficients of the box vectors c, b, a in turn (a rectangular box: bx = cx = cy = 0, the same numbers as x / ax ...)
+    const double fz0 = p.z * iz, fy0 = (p.y - fz0 * cy) * iy;
+    double fx = (p.x - fy0 * bx - fz0 * cx) * ix, fy = fy0, fz = fz0;
     fx -= floor(fx); fy -= floor(fy); fz -= floor(fz);
     wire[s] = make_uint4((unsigned) (unsigned long long) (fx * 4294967296.0), (unsigned) (unsigned long long) (fy * 4294967296.0),
                          (unsigned) (unsigned long long) (fz * 4294967296.0), 0u);
@@ -225,9 +227,9 @@ extern "C" int ommhip_clear_trailer_flags(void* wire_d, int ranks, int slots_per
     return (int) hipGetLastError();
 }
 
-extern "C" int ommhip_encode_wire(const void* pos_d, const int* atom_of_slot_d, int slot0, int slot1, const double box_len[3], void* wire_d, void* stream) {
+extern "C" int ommhip_encode_wire(const void* pos_d, const int* atom_of_slot_d, int slot0, int slot1, const double box[6], void* wire_d, void* stream) {
     if (slot1 <= slot0) return 0;
     hipLaunchKernelGGL(k_encode_wire, dim3((slot1 - slot0 + 255) / 256), dim3(256), 0, (hipStream_t) stream,
-                       (const double4*) pos_d, atom_of_slot_d, slot0, slot1, 1.0 / box_len[0], 1.0 / box_len[1], 1.0 / box_len[2], (uint4*) wire_d);
+                       (const double4*) pos_d, atom_of_slot_d, slot0, slot1, 1.0 / box[0], 1.0 / box[2], 1.0 / box[5], box[1], box[3], box[4], (uint4*) wire_d);
     return (int) hipGetLastError();
 }

@@ -593,8 +593,7 @@ void HipContext::pollDriftFlags() {
 }
 
 void HipContext::fillWireFromPos() {
-    const double len[3] = {box[0], box[2], box[5]};
-    HIP_CHECK(ommhip_encode_wire(pos.ptr, atomOfSlot.as<int>(), 0, paddedAtoms, len, posWire.ptr, stream));
+    HIP_CHECK(ommhip_encode_wire(pos.ptr, atomOfSlot.as<int>(), 0, paddedAtoms, box, posWire.ptr, stream));
 }
 
 void HipContext::gatherState() {
@@ -757,8 +756,17 @@ const vector<int>& HipContext::curveThroughGrid(int W, int H, int D) {
 void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<int>& newAtomOfSlot, vector<int>& wrapOut) {
     // Slabs along x with equal numbers of atoms, whole units only; inside a slab the units follow a Hilbert curve, so
     // 32 consecutive slots are a compact group of atoms (the neighbour list's i-blocks) just as on one GPU.
-    if (!usePeriodic || box[1] != 0.0 || box[3] != 0.0 || box[4] != 0.0)
-        throw OpenMMException("HIP platform: multi-GPU runs need a rectangular periodic box");
+    // A triclinic box (reduced vectors a = (ax, 0, 0), b = (bx, by, 0), c = (cx, cy, cz)) is cut by planes parallel to b and c: the
+    // slab coordinate is xi = ax * (coefficient of a), which is x in a rectangular box, is periodic with ax whatever image an atom is in,
+    // and is what the first index of the PME grid counts -- so the planes of the grid a rank owns are a slab of xi as before.  Two
+    // points a distance d apart differ by at most kappa * d in xi (kappa = |grad xi| >= 1): every Cartesian length that enters the halo
+    // widths below -- list reach, unit extent -- is stretched by kappa; the drift margin is a length in xi to begin with (the guard
+    // of nl_prepare compares the first box fraction), and the stencil reaches are multiples of the grid spacing along xi.
+    if (!usePeriodic)
+        throw OpenMMException("HIP platform: multi-GPU runs need a periodic box");
+    const bool triclinic = box[1] != 0.0 || box[3] != 0.0 || box[4] != 0.0;
+    const double skewY = box[1] / box[2], skewZ = (box[4] * box[1] - box[3] * box[2]) / (box[2] * box[5]);      // d xi / dy, d xi / dz
+    const double kappa = sqrt(1.0 + skewY * skewY + skewZ * skewZ);
     const int R = domain.ranks, numUnits = (int) unitStart.size() - 1;
     const double L[3] = {box[0], box[2], box[5]};
     if (curveCache.size() > 96) curveCache.clear();
@@ -779,23 +787,53 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
       for (int u = begin; u < end; u++) {
         const int a0 = unitAtomList[unitStart[u]];
         Vec3 p0 = positions[a0];
-        for (int k = 0; k < 3; k++) {
-            const int w = (int) floor(p0[k] / L[k]);
-            wrapOut[4 * a0 + k] = w;
-            p0[k] -= w * L[k];
+        if (!triclinic)
+            for (int k = 0; k < 3; k++) {
+                const int w = (int) floor(p0[k] / L[k]);
+                wrapOut[4 * a0 + k] = w;
+                p0[k] -= w * L[k];
+            }
+        else {
+            // the image whose coefficients of c, b, a lie in [0, 1) (computeOrder does the same)
+            const int iz = (int) floor(p0[2] / box[5]);
+            p0[0] -= iz * box[3]; p0[1] -= iz * box[4]; p0[2] -= iz * box[5];
+            const int iy = (int) floor(p0[1] / box[2]);
+            p0[0] -= iy * box[1]; p0[1] -= iy * box[2];
+            const int ix = (int) floor(p0[0] / box[0]);
+            p0[0] -= ix * box[0];
+            wrapOut[4 * a0] = ix; wrapOut[4 * a0 + 1] = iy; wrapOut[4 * a0 + 2] = iz;
         }
         ref[u] = p0;
         // the other atoms go to the image nearest to the first one, so the unit stays in one piece
         for (int i = unitStart[u] + 1; i < unitStart[u + 1]; i++) {
             const int a = unitAtomList[i];
             double d2 = 0;
-            for (int k = 0; k < 3; k++) {
-                double d = positions[a][k] - positions[a0][k];
-                d -= floor(d / L[k] + 0.5) * L[k];
-                wrapOut[4 * a + k] = (int) floor((positions[a][k] - (p0[k] + d)) / L[k] + 0.5);
-                d2 += d * d;
+            if (!triclinic)
+                for (int k = 0; k < 3; k++) {
+                    double d = positions[a][k] - positions[a0][k];
+                    d -= floor(d / L[k] + 0.5) * L[k];
+                    wrapOut[4 * a + k] = (int) floor((positions[a][k] - (p0[k] + d)) / L[k] + 0.5);
+                    d2 += d * d;
+                }
+            else {
+                Vec3 d = positions[a] - positions[a0];
+                const int nz = (int) floor(d[2] / box[5] + 0.5);
+                d[0] -= nz * box[3]; d[1] -= nz * box[4]; d[2] -= nz * box[5];
+                const int ny = (int) floor(d[1] / box[2] + 0.5);
+                d[0] -= ny * box[1]; d[1] -= ny * box[2];
+                const int nx = (int) floor(d[0] / box[0] + 0.5);
+                d[0] -= nx * box[0];
+                wrapOut[4 * a] = wrapOut[4 * a0] + nx; wrapOut[4 * a + 1] = wrapOut[4 * a0 + 1] + ny; wrapOut[4 * a + 2] = wrapOut[4 * a0 + 2] + nz;
+                d2 = d.dot(d);
             }
             chunkExtent = max(chunkExtent, sqrt(d2));
+        }
+        // from here on the first coordinate of ref is the slab coordinate xi (a rectangular box: x itself)
+        if (triclinic) {
+            const double sz = p0[2] / box[5], sy = (p0[1] - sz * box[4]) / box[2];
+            double xi = p0[0] - sy * box[1] - sz * box[3];          // (the image above has x, y, z in [0, edge), not the three coefficients)
+            xi -= floor(xi / L[0]) * L[0];
+            ref[u][0] = max(0.0, min(L[0], xi));
         }
       }
       // (chunks are numbered by where they begin: parallelFor hands out equal pieces)
@@ -836,7 +874,8 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
     for (int g = 1; g < R; g++) bound[g] = groupStart[g] < numUnits ? ref[byX[groupStart[g]]][0] : L[0];
     double extent = 0.0;                          // largest distance of an atom from the first atom of its unit (a rigid unit may rotate: any of it can turn into x)
     for (size_t t = 0; t < extentOfThread.size(); t++) extent = max(extent, extentOfThread[t]);
-    extent *= 1.1;                                // constraints hold distances to the first atom; flexible units get a little room
+    extent *= 1.1 * kappa;                        // constraints hold distances to the first atom; flexible units get a little room
+    const double pairReach = haloReach * kappa;   // (both in xi)
     // The drift margin (how far along x the first atom of a unit may move between two re-sorts): haloDriftMax unless the narrowest slab
     // leaves less.  Round 3 let it grow to whatever the slabs allowed (0.7 nm on 8 ranks of the 1M-atom box: three slabs' worth of slots
     // converted per step); now it is an upper limit chosen for the re-sort cadence (the re-sorts are off the step), and the halo is what
@@ -844,11 +883,11 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
     double minWidth = L[0];
     for (int g = 0; g < R; g++) minWidth = min(minWidth, bound[g + 1] - bound[g]);
     haloDrift = haloDriftMax;
-    if (R > 2) haloDrift = max(0.0, min(haloDriftMax, 0.5 * (0.98 * minWidth - haloReach - extent)));
+    if (R > 2) haloDrift = max(0.0, min(haloDriftMax, 0.5 * (0.98 * minWidth - pairReach - extent)));
     // What a rank must see below / above its slab: the partners of its pairs (list cutoff + the drift of both atoms + a unit's reach) and the
     // atoms whose PME stencils touch its planes g L / R ... (g + 1) L / R (one atom's drift; the stencil looks forward, so mostly below).
     const double reachBelow = pmeReachBelow > 0.0 ? pmeReachBelow : pmeReachX, reachAbove = pmeReachAbove > 0.0 ? pmeReachAbove : pmeReachX;
-    const double Tpair = haloReach + 2.0 * haloDrift + extent;
+    const double Tpair = pairReach + 2.0 * haloDrift + extent;
     double pmeBelow = 0.0, pmeAbove = 0.0;
     if (reachBelow > 0.0 || reachAbove > 0.0)
         for (int g = 0; g < R; g++) {
@@ -873,6 +912,7 @@ void HipContext::computeOrderDecomposed(const vector<Vec3>& positions, vector<in
         fprintf(stderr, "HIP platform: decomposition over %d ranks: narrowest slab %.3f nm, list reach %.3f, unit extent %.3f, drift margin %.3f (limit %.3f, floor %.3f), pairs need %.3f, "
                         "stencils need %.3f below / %.3f above -> halo %d, half-shell %d, sections %.3f up / %.3f down\n", R, minWidth, haloReach, extent, haloDrift, haloDriftMax, haloDriftMin,
                 Tpair, pmeBelow, pmeAbove, halo ? 1 : 0, half ? 1 : 0, Tup, Tdn);
+    if (ddDebug && domain.rank == 0 && triclinic) fprintf(stderr, "HIP platform: triclinic box: slabs of the first box fraction, lengths stretched by %.4f\n", kappa);
     // ---- the order inside each slab: a space-filling curve through each of its (up to four) sections separately -- the generalised Hilbert
     //      curve through a grid of ~binWidth cells FITTED to the section's extent (a plate: thin along x), see gilbertOrder
     static const double binWidth = getenv("OPENMM_HIP_SORT_BIN") != NULL ? atof(getenv("OPENMM_HIP_SORT_BIN")) : 0.3;
@@ -1091,8 +1131,7 @@ bool HipContext::applyOrder(const vector<Vec3>& positions, bool fromSnapshot) {
     HIP_CHECK(ommhip_memcpy_h2d(slotOfAtom.ptr, hostSlotOfAtom.data(), sizeof(int) * numAtoms, stream));
     if (decomposed()) {
         // the drift guard measures from the positions the sections were cut for: the snapshot's when the order comes from one
-        const double len[3] = {box[0], box[2], box[5]};
-        if (fromSnapshot) HIP_CHECK(ommhip_encode_wire(posSnapshot.ptr, atomOfSlot.as<int>(), 0, paddedAtoms, len, wireRef.ptr, stream));
+        if (fromSnapshot) HIP_CHECK(ommhip_encode_wire(posSnapshot.ptr, atomOfSlot.as<int>(), 0, paddedAtoms, box, wireRef.ptr, stream));
         fillWireFromPos();
         if (!fromSnapshot) HIP_CHECK(ommhip_memcpy_d2d(wireRef.ptr, posWire.ptr, posWire.bytes, stream));
         HIP_CHECK(ommhip_memset(ddFlags.ptr, 0, ddFlags.bytes, stream));

@@ -306,6 +306,7 @@ void HipConstraints::fusedStep(int integrator, const ommhip_integrator_state& st
     static const bool noSmall = getenv("OPENMM_HIP_NO_SMALL_UNITS") != NULL;         // A/B knob
     u.small_units = smallUnits && !noSmall ? 1 : 0;
     u.box_len[0] = hip.box[0]; u.box_len[1] = hip.box[2]; u.box_len[2] = hip.box[5];
+    u.box_skew[0] = hip.box[1]; u.box_skew[1] = hip.box[3]; u.box_skew[2] = hip.box[4];
     if (hip.decomposed()) {
         u.pos_wire = hip.posWire.ptr; u.ranks = hip.domain.ranks; u.rank = hip.domain.rank;
         u.slots_per_rank = hip.slotsPerRank; u.trailer_slot = hip.trailerSlot;
@@ -775,10 +776,8 @@ double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool
     // owned blocks, halo planes, interpolation for the owned atoms.
     if (nonbondedMethod != PME || !includeDirect || !includeReciprocal)
         throw OpenMMException("HIP platform: multi-GPU runs support NonbondedForce with PME, direct and reciprocal space in one force group");
-    if (hip.box[1] != 0.0 || hip.box[3] != 0.0 || hip.box[4] != 0.0)
-        throw OpenMMException("HIP platform: multi-GPU runs need a rectangular periodic box");
     const int ie = includeEnergy ? 1 : 0;
-    nl.pbc = 1;
+    nl.pbc = (hip.box[1] != 0.0 || hip.box[3] != 0.0 || hip.box[4] != 0.0) ? 2 : 1;
     nl.dd_mode = 1;
     nl.first_block = hip.ownSlot0 / OMMHIP_TILE; nl.owned_blocks = hip.slotsPerRank / OMMHIP_TILE;
     // double-precision positions of foreign atoms (atom order) are refreshed per step only if something reads them: term lists of
@@ -800,9 +799,21 @@ double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool
     foldExclusions = numExclusionPairs > 0;
     checkDecomposedFlags();
     if (nl.max_chunks == 0) allocateNeighborList((int) (estimateChunks() * 1.4 / hip.domain.ranks) + 256);
+    // test hook: at the n-th evaluation pretend the allocation holds only 8 % more than the list -- past the 7/8 at which nl_prepare
+    // asks for a common re-sort (tests/test_multirank_cpu.py::test_nearly_full_list_triggers_a_common_resort_that_grows_it_on_emulator)
+    const int debugTightAfter = getenv("OPENMM_HIP_DEBUG_TIGHT_LIST_AFTER") != NULL ? atoi(getenv("OPENMM_HIP_DEBUG_TIGHT_LIST_AFTER")) : 0;      // read per evaluation
+    if (debugTightAfter > 0 && !debugShrinkDone && (int) evaluationCount == debugTightAfter && nl.max_chunks > 0) {
+        HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
+        hip.sync();
+        nl.max_chunks = std::min(nl.max_chunks, pinnedState[1] * 100 / 92 + 1);
+        debugShrinkDone = true;
+        if (getenv("OPENMM_HIP_DD_DEBUG") != NULL) fprintf(stderr, "HIP platform: rank %d: list of %d chunks, allocation set to %d\n", hip.domain.rank, pinnedState[1], nl.max_chunks);
+    }
     if (stateCopyPending && (pinnedState[2] != 0 || pinnedState[1] > nl.max_chunks)) {
-        // the ranks step in lockstep through the all-gather, so one of them cannot freeze and redo steps on its own:
-        // a list that outgrows 1.5x its verified size on a decomposed run ends the run instead of producing wrong forces
+        // the ranks step in lockstep through the all-gather, so one of them cannot freeze and redo steps on its own: a list that
+        // overflows on a decomposed run ends the run instead of producing wrong forces.  In halo mode it does not get that far: a list
+        // that fills 7/8 of its allocation makes every rank re-sort at once (nl_prepare, the drift flags' channel), and the rebuild
+        // after a re-sort is verified below and given 1.5 x its size.
         stringstream msg;
         msg << "HIP platform: the neighbour list of rank " << hip.domain.rank << " overflowed (" << pinnedState[1] << " chunks needed, " << nl.max_chunks
             << " allocated) on a multi-GPU run; the last steps are invalid";
@@ -821,6 +832,7 @@ double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool
         HIP_CHECK(ommhip_memcpy_d2h(pinnedState, nlState.ptr, sizeof(int) * OMMHIP_NL_STATE_INTS, hip.stream));
         hip.sync();
         if (pinnedState[2] == 0 && pinnedState[1] * 1.5 <= nl.max_chunks) { forceRebuild = false; break; }
+        if (getenv("OPENMM_HIP_DD_DEBUG") != NULL) fprintf(stderr, "HIP platform: rank %d: list of %d chunks, allocation %d -> %d\n", hip.domain.rank, pinnedState[1], nl.max_chunks, (int) (pinnedState[1] * 1.6) + 64);
         allocateNeighborList((int) (pinnedState[1] * 1.6) + 64);
     }
     fillPmeStruct();

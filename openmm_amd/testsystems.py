@@ -420,6 +420,20 @@ def with_cutoff(w, cutoff):
     return w
 
 
+def sheared(w, bx, cx, cy):
+    """A water-only workload of a cubic box in the triclinic box a = (L, 0, 0), b = (bx, L, 0), c = (cx, cy, L): every molecule (three
+    consecutive atoms) is moved as a whole by the shear of its oxygen, so the density and the molecules' shapes stay what they were."""
+    L = float(w.box[0][0])
+    o = np.repeat(w.positions[0::3], 3, axis=0)
+    shift = np.zeros_like(w.positions)
+    shift[:, 0] = o[:, 1] / L * bx + o[:, 2] / L * cx
+    shift[:, 1] = o[:, 2] / L * cy
+    w.positions = w.positions + shift
+    w.box = np.array([[L, 0.0, 0.0], [bx, L, 0.0], [cx, cy, L]])
+    w.name = getattr(w, "name", "water") + "-triclinic"
+    return w
+
+
 def small_solvated_chain(seed=3):
     """The same construction at test size: a 150-atom chain (bonds, angles, torsions, 1-4s, X-H clusters) in ~660 waters."""
     return dhfr_like(seed=seed, n_side=9, chain_atoms=150, relaxed=False, L=2.75, n_target=2130, radius=0.9)

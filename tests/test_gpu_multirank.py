@@ -88,6 +88,15 @@ def test_two_ranks_over_rccl_on_two_gpus(tmp_path):
     print(out)
 
 
+def test_three_ranks_sharing_the_gpu_in_a_triclinic_box(tmp_path):
+    """Slabs of the first box fraction in a triclinic box, half-shell evaluation, a re-sort inside the run; tests/test_multirank_cpu.py runs
+    the same on the emulator."""
+    from test_multirank_cpu import _run_dd_child
+    print(_run_dd_child(tmp_path, False, 0, 10, 29601, nproc=3, env={"OPENMM_HIP_DD_DRIFT": "0.03"},
+                        cases='(("water, triclinic, halo sections, half-shell", T.sheared(T.water_box(12, seed=5, cutoff=0.5), 0.6, -0.5, 0.8), None), '
+                              '("water, triclinic, halo sections, half-shell, larger", T.sheared(T.water_box(20, seed=5, cutoff=0.6), 1.5, -1.2, 2.0), None))'))
+
+
 def test_three_ranks_sharing_the_gpu_half_shell_with_bonded_terms_across_boundaries(tmp_path):
     """Half-shell evaluation on the GPU: three ranks (sharing it, collectives over gloo), a chain with bonds / angles / torsions / 1-4s /
     exclusions across both inner slab boundaries -- pairs and terms evaluated once by the upper rank, the forces on the lower rank's atoms

@@ -148,6 +148,8 @@ for label, w, grid in (("water, halo", T.water_box(8, seed=5), 24), ("solvated c
             assert DD_INFO[3] < world * DD_INFO[2] and DD_INFO[5] < 16 * DD_INFO[2] * (world - 1), ("the halo should be smaller than the box", DD_INFO)
         if "drift" in label:
             assert DD_INFO[6] >= 2, ("a drift-triggered re-sort was expected", DD_INFO)
+        if "tight list" in label:
+            assert DD_INFO[6] >= 2, ("a re-sort asked for by the nearly full list was expected", DD_INFO)
         if "half-shell" in label:
             assert DD_INFO[7] > 1, ("expected half-shell evaluation with partners from the lower neighbour", DD_INFO)
         if "both sides" in label:
@@ -256,6 +258,21 @@ def test_half_shell_evaluation_with_force_return_on_emulator(tmp_path):
     _run_dd_child(tmp_path, True, None, 4, 29585, nproc=3, env={"OPENMM_HIP_DD_DRIFT": "0.02", "OPENMM_HIP_DD_BOTH_SIDES": "1"}, cases='(("solvated chain, halo, both sides", %s, 48),)' % chain)
 
 
+def test_triclinic_box_domain_decomposition_on_emulator(tmp_path):
+    """A triclinic box on N ranks: the slabs are cut in the first box fraction (planes parallel to b and c), the wire records
+    are the three box fractions, and every Cartesian length that enters the halo widths is stretched by |grad xi|.  Three ranks with distinct
+    sections, half-shell evaluation and a re-sort inside the run; two ranks of a smaller box whose sections cover the slabs.  Same bar as every
+    decomposed run: forces and trajectory of the single-rank run of the same box."""
+    import pytest
+    from conftest import EMU_BUILD
+    if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
+        pytest.skip("emulated plugin not built (run __graft_entry__.build())")
+    env = {"OPENMM_HIP_DD_DRIFT": "0.03"}
+    _run_dd_child(tmp_path, True, None, 4, 29641, nproc=3, env=env,
+                  cases='(("water, triclinic, halo sections, half-shell", T.sheared(T.water_box(12, seed=5, cutoff=0.5), 0.6, -0.5, 0.8), None),)')
+    _run_dd_child(tmp_path, True, None, 4, 29645, env=env, cases='(("water, triclinic, halo", T.sheared(T.water_box(8, seed=5), 0.5, -0.4, 0.3), 24),)')
+
+
 def test_halo_drift_guard_triggers_a_common_resort_on_emulator(tmp_path):
     """An atom that drifts half the allowed margin raises a flag that travels in its rank's trailer; every rank finds it at the same
     evaluation and they re-sort together (no agreement collective).  With a margin of 0.06 nm the fastest oxygens cross the warning
@@ -279,6 +296,20 @@ def test_halo_drift_guard_resorts_at_once_when_the_margin_runs_out_on_emulator(t
         pytest.skip("emulated plugin not built (run __graft_entry__.build())")
     _run_dd_child(tmp_path, True, None, 100, 29573, env={"OPENMM_HIP_DD_DRIFT": "0.12", "OPENMM_HIP_DD_WARN": "0.4", "OPENMM_HIP_REORDER_INTERVAL": "1000", "OPENMM_HIP_REORDER_LAG": "1000"},
                   cases='(("water, halo drift", T.water_box(8, seed=5), 24),)')
+
+
+def test_nearly_full_list_triggers_a_common_resort_that_grows_it_on_emulator(tmp_path):
+    """A rank whose neighbour list fills 7/8 of its allocation raises level 3 in its trailer: every rank re-sorts at the next step, and the
+    rebuild after a re-sort is verified by the host and given 1.5 x its size -- so a list that grows during a run never gets as far as an
+    overflow, which a decomposed run cannot undo (it raises).  The test hook leaves 8 % of room at the third evaluation; no other reason for
+    a re-sort exists in the run (interval and lag 1000 steps, a drift margin nothing reaches)."""
+    import pytest
+    from conftest import EMU_BUILD
+    if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
+        pytest.skip("emulated plugin not built (run __graft_entry__.build())")
+    _run_dd_child(tmp_path, True, None, 40, 29649, env={"OPENMM_HIP_DD_DRIFT": "0.2", "OPENMM_HIP_REORDER_INTERVAL": "1000", "OPENMM_HIP_REORDER_LAG": "1000",
+                                                        "OPENMM_HIP_DEBUG_TIGHT_LIST_AFTER": "3"},
+                  cases='(("water, halo, tight list", T.water_box(8, seed=5), 24),)')
 
 
 def test_two_rank_run_with_the_barostat_on_emulator(tmp_path):

@@ -158,7 +158,10 @@ for label, w, grid in (("water, halo", T.water_box(8, seed=5), 24), ("solvated c
         assert DD_INFO[1] == 0, DD_INFO
     rms = np.sqrt((one0.forces ** 2).sum(1).mean())
     err0 = np.abs(dd0.forces - one0.forces).max() / rms
-    assert err0 < 3e-5, ("initial forces", err0)       # float32 summation-order noise; TestCudaNonbondedForce.cpp:37-96 allows 1e-5 of each force in its multi-device mode
+    # (a triclinic box: the decomposed run holds every atom in the image whose three box coefficients lie in [0, 1), the single-rank run in
+    # the image with x, y, z in [0, edge) -- other float32 roundings of the same positions; 24 000 atoms on the GPU: 3.5e-5 at the worst
+    # atom, 1.7e-5 at the 99.9th percentile, and the same figures with replicated positions, tools/diag_triclinic_dd_noise.py)
+    assert err0 < (6e-5 if "triclinic" in label else 3e-5), ("initial forces", err0)       # float32 summation-order noise; TestCudaNonbondedForce.cpp:37-96 allows 1e-5 of each force in its multi-device mode
     # (1e-6 of the magnitude, with the floor of tests/test_gpu_platform.py for lattice starts whose terms nearly cancel)
     assert abs(dd0.potentialEnergy - one0.potentialEnergy) < 1e-6 * max(abs(one0.potentialEnergy), 5.0 * w.num_atoms) + 1e-3, (dd0.potentialEnergy, one0.potentialEnergy)
     dpos = np.abs(dd1.positions - one1.positions).max()
@@ -170,7 +173,8 @@ for label, w, grid in (("water, halo", T.water_box(8, seed=5), 24), ("solvated c
     if STEPS <= 20:
         # float32 force noise (1e-5 of the RMS force) integrated over the run; the tile spreading rounds each contribution to max|q| 2^-24
         big = w.num_atoms > 5000            # more atoms, a larger maximum of the same noise
-        assert dpos < (1e-6 if big else 3e-7) and dvel < (1.5e-4 if tiles or big else 5e-5), ("trajectory", dpos, dvel)
+        loose = 3.0 if "triclinic" in label else 1.0      # the larger force noise of the other periodic images (above), integrated
+        assert dpos < loose * (1e-6 if big else 3e-7) and dvel < loose * (1.5e-4 if tiles or big else 5e-5), ("trajectory", dpos, dvel)
         assert abs(dd1.kineticEnergy - one1.kineticEnergy) < 1e-6 * one1.kineticEnergy
         err1 = np.abs(dd1.forces - one1.forces).max() / rms
         assert err1 < 1e-4, ("final forces", err1)

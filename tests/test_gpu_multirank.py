@@ -97,6 +97,15 @@ def test_three_ranks_sharing_the_gpu_in_a_triclinic_box(tmp_path):
                               '("water, triclinic, halo sections, half-shell, larger", T.sheared(T.water_box(20, seed=5, cutoff=0.6), 1.5, -1.2, 2.0), None))'))
 
 
+def test_nearly_full_list_makes_the_ranks_resort_and_grow_it(tmp_path):
+    """Two ranks sharing the GPU; the hook leaves the list 8 % of room at the third evaluation: level 3 in the trailer, a common re-sort (the
+    only one of the run), the verified rebuild grows the allocation (tests/test_multirank_cpu.py runs the same on the emulator)."""
+    from test_multirank_cpu import _run_dd_child
+    print(_run_dd_child(tmp_path, False, 0, 40, 29611, env={"OPENMM_HIP_DD_DRIFT": "0.2", "OPENMM_HIP_REORDER_INTERVAL": "1000", "OPENMM_HIP_REORDER_LAG": "1000",
+                                                           "OPENMM_HIP_DEBUG_TIGHT_LIST_AFTER": "3"},
+                        cases='(("water, halo, tight list", T.water_box(8, seed=5), 24), ("water, halo sections, half-shell, tight list", T.water_box(16, seed=5, cutoff=0.5), None))'))
+
+
 def test_three_ranks_sharing_the_gpu_half_shell_with_bonded_terms_across_boundaries(tmp_path):
     """Half-shell evaluation on the GPU: three ranks (sharing it, collectives over gloo), a chain with bonds / angles / torsions / 1-4s /
     exclusions across both inner slab boundaries -- pairs and terms evaluated once by the upper rank, the forces on the lower rank's atoms

@@ -420,17 +420,27 @@ def with_cutoff(w, cutoff):
     return w
 
 
-def sheared(w, bx, cx, cy):
-    """A water-only workload of a cubic box in the triclinic box a = (L, 0, 0), b = (bx, L, 0), c = (cx, cy, L): every molecule (three
-    consecutive atoms) is moved as a whole by the shear of its oxygen, so the density and the molecules' shapes stay what they were."""
+def sheared(w, bx, cx, cy, affine=False):
+    """A workload of a cubic box in the triclinic box a = (L, 0, 0), b = (bx, L, 0), c = (cx, cy, L): every molecule (the atoms connected by
+    bonds and constraints) is moved as a whole by the shear of its first atom, so the density and the molecules' shapes stay what they were.
+    That suits small molecules; a large one would be left in a cavity that no longer has its shape, so `affine` shears every atom instead
+    (bonds and angles a little distorted -- the caller applies the constraints; fine for tests that start unrelaxed anyway)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
     L = float(w.box[0][0])
-    o = np.repeat(w.positions[0::3], 3, axis=0)
+    n = len(w.positions)
+    edges = [np.asarray(t[0]).reshape(-1, 2) for t in (w.bonds, w.constraints) if t is not None and len(t[0])]
+    edges = np.concatenate(edges) if edges else np.zeros((0, 2), int)
+    _, molecule = connected_components(coo_matrix((np.ones(len(edges)), (edges[:, 0], edges[:, 1])), shape=(n, n)), directed=False)
+    first = np.full(molecule.max() + 1, n)
+    np.minimum.at(first, molecule, np.arange(n))
+    o = w.positions if affine else w.positions[first[molecule]]
     shift = np.zeros_like(w.positions)
     shift[:, 0] = o[:, 1] / L * bx + o[:, 2] / L * cx
     shift[:, 1] = o[:, 2] / L * cy
     w.positions = w.positions + shift
     w.box = np.array([[L, 0.0, 0.0], [bx, L, 0.0], [cx, cy, L]])
-    w.name = getattr(w, "name", "water") + "-triclinic"
+    w.name = getattr(w, "name", "workload") + "-triclinic"
     return w
 
 

@@ -95,6 +95,8 @@ def test_three_ranks_sharing_the_gpu_in_a_triclinic_box(tmp_path):
     print(_run_dd_child(tmp_path, False, 0, 10, 29601, nproc=3, env={"OPENMM_HIP_DD_DRIFT": "0.03"},
                         cases='(("water, triclinic, halo sections, half-shell", T.sheared(T.water_box(12, seed=5, cutoff=0.5), 0.6, -0.5, 0.8), None), '
                               '("water, triclinic, halo sections, half-shell, larger", T.sheared(T.water_box(20, seed=5, cutoff=0.6), 1.5, -1.2, 2.0), None))'))
+    print(_run_dd_child(tmp_path, False, 0, 6, 29605, nproc=3, env={"OPENMM_HIP_DD_DRIFT": "0.02"},
+                        cases='(("solvated chain, triclinic, halo, half-shell", T.sheared(T.with_cutoff(T.small_solvated_chain(seed=3), 0.4), 0.5, -0.4, 0.6, affine=True), 48),)'))
 
 
 def test_nearly_full_list_makes_the_ranks_resort_and_grow_it(tmp_path):

@@ -275,6 +275,10 @@ def test_triclinic_box_domain_decomposition_on_emulator(tmp_path):
     _run_dd_child(tmp_path, True, None, 4, 29641, nproc=3, env=env,
                   cases='(("water, triclinic, halo sections, half-shell", T.sheared(T.water_box(12, seed=5, cutoff=0.5), 0.6, -0.5, 0.8), None),)')
     _run_dd_child(tmp_path, True, None, 4, 29645, env=env, cases='(("water, triclinic, halo", T.sheared(T.water_box(8, seed=5), 0.5, -0.4, 0.3), 24),)')
+    # a chain with bonds / angles / torsions / 1-4s / exclusions across both inner boundaries (the foreign atoms' double-precision positions
+    # follow the wire records through the triclinic minimum image), half-shell evaluation; every atom sheared, constraints applied by the case
+    _run_dd_child(tmp_path, True, None, 4, 29643, nproc=3, env={"OPENMM_HIP_DD_DRIFT": "0.02"},
+                  cases='(("solvated chain, triclinic, halo, half-shell", T.sheared(T.with_cutoff(T.small_solvated_chain(seed=3), 0.4), 0.5, -0.4, 0.6, affine=True), 48),)')
     # ... and with a MonteCarloBarostat: the box changes (all three vectors scale), the slabs and sections are cut again for it
     _run_dd_child(tmp_path, True, None, 8, 29647, cases='(("water, triclinic, halo, barostat", T.with_barostat(T.sheared(T.water_box(8, seed=5), 0.5, -0.4, 0.3), 1.0, 300.0, 2, 11), 24),)')
 

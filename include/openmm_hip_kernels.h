@@ -244,7 +244,7 @@ typedef struct ommhip_neighbor_list {
 
 /* sizeof() of the structs of this header as the library was compiled: 0 ommhip_neighbor_list, 1 ommhip_nonbonded_params, 2 ommhip_pme,
  * 3 ommhip_term_batch, 4 ommhip_integrator_state, 5 ommhip_step_units, 6 ommhip_ccma, 7 ommhip_valence_list, 8 ommhip_vm_instruction,
- * 9 ommhip_vm_step, 10 ommhip_vm_state; 0 for anything else.  A foreign-language
+ * 9 ommhip_vm_step, 10 ommhip_vm_state, 11 ommhip_vm_bonds; 0 for anything else.  A foreign-language
  * binding (ctypes, cgo, JNI) checks its mirror against it when it loads the library. */
 size_t ommhip_struct_size(int which);
 
@@ -609,6 +609,23 @@ typedef struct ommhip_vm_state {
 } ommhip_vm_state;
 /* steps[0 .. num_steps) one after the other for every degree of freedom; a step with target -1 must be the only one of its launch */
 int ommhip_vm_per_dof(const ommhip_vm_state* state, int num_steps, const ommhip_vm_step* steps, void* stream);
+/* CustomBondForce with ANY energy expression of r, per-bond parameters and global parameters (openmmapi/include/openmm/CustomBondForce.h;
+ * Reference: ReferenceCustomBondIxn.cpp:74-110): two programs of the same interpreter, the energy and its derivative with respect to r
+ * (differentiated symbolically by the platform).  In the programs VARIABLE 0 is r, VARIABLE 6 + k the k-th per-bond parameter, GLOBAL g
+ * globals[g].  One thread per bond; force -dE/dr along the bond on both atoms, energies summed into energy_buffer. */
+typedef struct ommhip_vm_bonds {
+    int num_bonds, num_params;
+    int param_stride;                        /* a multiple of 3, >= num_bonds */
+    int periodic;                            /* minimum image of the bond vector in `box` */
+    const int* atoms;                        /* device int[2 * num_bonds] */
+    const double* params;                    /* device double[num_params][param_stride] */
+    const ommhip_vm_instruction* program;    /* device */
+    int energy_first, energy_count, deriv_first, deriv_count;
+    const double* globals;                   /* device */
+    double box[6];                           /* ax, bx, by, cx, cy, cz */
+} ommhip_vm_bonds;
+int ommhip_vm_bond_forces(const ommhip_vm_bonds* bonds, const void* pos_d, const int* slot_of_atom_d, int padded_atoms, long long* force_d,
+                          double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
 /* fixed-point forces in slot order -> double[3 * num_atoms] in atom order (a copy the integrator can keep per force group while other
  * groups are evaluated and atoms are re-sorted) */
 int ommhip_forces_to_atom_order(const long long* force_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, double* out_d, void* stream);

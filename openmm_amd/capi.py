@@ -77,6 +77,12 @@ class VmState(C.Structure):
                 ("program", C.c_void_p), ("seed", C.c_ulonglong), ("sum_scratch", C.c_void_p), ("sum_result", C.c_void_p)]
 
 
+class VmBonds(C.Structure):
+    _fields_ = [("num_bonds", C.c_int), ("num_params", C.c_int), ("param_stride", C.c_int), ("periodic", C.c_int), ("atoms", C.c_void_p), ("params", C.c_void_p),
+                ("program", C.c_void_p), ("energy_first", C.c_int), ("energy_count", C.c_int), ("deriv_first", C.c_int), ("deriv_count", C.c_int),
+                ("globals", C.c_void_p), ("box", C.c_double * 6)]
+
+
 class KernelError(RuntimeError):
     pass
 
@@ -126,6 +132,7 @@ SIGNATURES = {
     "nb_direct": [C.POINTER(NeighborList), C.POINTER(NonbondedParams), _P, _P, _P, _I, _I, _P],
     "valence_forces": [_I, C.POINTER(ValenceList), _P, _P, _I, _P, _P, _I, _I, _P],
     "vm_per_dof": [C.POINTER(VmState), _I, C.POINTER(VmStep), _P],
+    "vm_bond_forces": [C.POINTER(VmBonds), _P, _P, _I, _P, _P, _I, _I, _P],
     "forces_to_atom_order": [_P, _P, _I, _I, _P, _P],
 }
 
@@ -143,7 +150,7 @@ class Kernels:
         # the ctypes mirrors above against the structs the library was compiled with
         self.lib.ommhip_struct_size.restype = C.c_size_t
         self.lib.ommhip_struct_size.argtypes = [C.c_int]
-        for which, mirror in ((0, NeighborList), (1, NonbondedParams), (2, Pme), (7, ValenceList), (8, VmInstruction), (9, VmStep), (10, VmState)):
+        for which, mirror in ((0, NeighborList), (1, NonbondedParams), (2, Pme), (7, ValenceList), (8, VmInstruction), (9, VmStep), (10, VmState), (11, VmBonds)):
             if self.lib.ommhip_struct_size(which) != C.sizeof(mirror):
                 raise KernelError("%s: ctypes mirror of struct %d has %d bytes, the library's has %d -- openmm_amd/capi.py is out of date with include/openmm_hip_kernels.h"
                                   % (path, which, C.sizeof(mirror), self.lib.ommhip_struct_size(which)))

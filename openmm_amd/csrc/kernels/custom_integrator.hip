@@ -151,6 +151,48 @@ __global__ __launch_bounds__(256) void k_forces_to_atom_order(const omm_fixed* _
     out[3 * (size_t) atom + 2] = from_fixed(force[slot + 2 * paddedAtoms]);
 }
 
+
+struct VmBondArgs {
+    ommhip_vm_bonds b;
+    const double4* pos; const int* slotOfAtom; int paddedAtoms;
+    omm_fixed* force; double* energyBuffer; int energySlots, includeEnergy;
+};
+
+// CustomBondForce with an arbitrary expression: one thread per bond, the derivative program gives dE/dr, the energy program E
+__global__ __launch_bounds__(VM_BLOCK) void k_vm_bonds(VmBondArgs a) {
+    __shared__ double stack[OMMHIP_VM_STACK * VM_BLOCK];
+    const int lane = threadIdx.x;
+    // (the per-bond parameters are laid out as per-DOF variables are: parameter k of bond i at per_dof[k * 3 * num_atoms + i])
+    ommhip_vm_state s;
+    s.num_atoms = a.b.param_stride / 3; s.num_per_dof = a.b.num_params; s.per_dof = const_cast<double*>(a.b.params);
+    s.globals = a.b.globals; s.program = a.b.program;
+    ommhip_vm_step energyStep = {a.b.energy_first, a.b.energy_count, 0, 0, nullptr, 0}, derivStep = {a.b.deriv_first, a.b.deriv_count, 0, 0, nullptr, 0};
+    double energy = 0;
+    for (int bond = blockIdx.x * VM_BLOCK + lane; bond < a.b.num_bonds; bond += gridDim.x * VM_BLOCK) {
+        const int i = a.b.atoms[2 * bond], j = a.b.atoms[2 * bond + 1];
+        const double4 pi = a.pos[i], pj = a.pos[j];
+        double dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+        if (a.b.periodic) {
+            // ReferenceForce::getDeltaRPeriodicTriclinic
+            double n = floor(dz / a.b.box[5] + 0.5); dx -= n * a.b.box[3]; dy -= n * a.b.box[4]; dz -= n * a.b.box[5];
+            n = floor(dy / a.b.box[2] + 0.5); dx -= n * a.b.box[1]; dy -= n * a.b.box[2];
+            n = floor(dx / a.b.box[0] + 0.5); dx -= n * a.b.box[0];
+        }
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        DofVars var;
+        var.x = r; var.v = 0; var.f = 0; var.m = 0; var.gaussian = 0; var.uniform = 0;
+        const double dEdR = vm_run(s, derivStep, var, (size_t) bond, stack, lane);
+        if (a.includeEnergy) energy += vm_run(s, energyStep, var, (size_t) bond, stack, lane);
+        const double scale = r > 0 ? dEdR / r : 0.0;          // ReferenceCustomBondIxn.cpp:98-99
+        add_force(a.force, a.paddedAtoms, a.slotOfAtom[i], scale * dx, scale * dy, scale * dz);
+        add_force(a.force, a.paddedAtoms, a.slotOfAtom[j], -scale * dx, -scale * dy, -scale * dz);
+    }
+    if (a.includeEnergy) {
+        energy = wave_sum(energy);
+        if (lane == 0) atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], energy);
+    }
+}
+
 }  // namespace
 
 extern "C" int ommhip_vm_per_dof(const ommhip_vm_state* state, int num_steps, const ommhip_vm_step* steps, void* stream) {
@@ -172,5 +214,17 @@ extern "C" int ommhip_vm_per_dof(const ommhip_vm_state* state, int num_steps, co
 extern "C" int ommhip_forces_to_atom_order(const long long* force_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, double* out_d, void* stream) {
     if (num_atoms <= 0) return 0;
     hipLaunchKernelGGL(k_forces_to_atom_order, dim3((num_atoms + 255) / 256), dim3(256), 0, (hipStream_t) stream, (const omm_fixed*) force_d, slot_of_atom_d, num_atoms, padded_atoms, out_d);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_vm_bond_forces(const ommhip_vm_bonds* bonds, const void* pos_d, const int* slot_of_atom_d, int padded_atoms, long long* force_d,
+                                     double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
+    if (bonds->num_bonds <= 0) return 0;
+    VmBondArgs a;
+    a.b = *bonds;
+    a.pos = (const double4*) pos_d; a.slotOfAtom = slot_of_atom_d; a.paddedAtoms = padded_atoms;
+    a.force = (omm_fixed*) force_d; a.energyBuffer = energy_buffer_d; a.energySlots = energy_slots; a.includeEnergy = include_energy;
+    const int blocks = min(VM_MAX_BLOCKS, (bonds->num_bonds + VM_BLOCK - 1) / VM_BLOCK);
+    hipLaunchKernelGGL(k_vm_bonds, dim3(blocks), dim3(VM_BLOCK), 0, (hipStream_t) stream, a);
     return (int) hipGetLastError();
 }

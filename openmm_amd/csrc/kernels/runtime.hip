@@ -68,6 +68,7 @@ size_t ommhip_struct_size(int which) {
         case 8: return sizeof(ommhip_vm_instruction);
         case 9: return sizeof(ommhip_vm_step);
         case 10: return sizeof(ommhip_vm_state);
+        case 11: return sizeof(ommhip_vm_bonds);
     }
     return 0;
 }

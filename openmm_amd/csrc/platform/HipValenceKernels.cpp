@@ -4,10 +4,16 @@
  * literals are its coefficients.  The shapes are those of the strings wrappers/python/openmm/app/forcefield.py builds (:3368, :3502, :3565,
  * :3730, :4039, :4428). */
 #include "HipValenceKernels.h"
+#include "lepton/CompiledExpression.h"
+#include "lepton/ExpressionTreeNode.h"
+#include "lepton/Operation.h"
+#include "lepton/ParsedExpression.h"
+#include "lepton/Parser.h"
 #include "openmm/OpenMMException.h"
 #include "openmm/internal/ContextImpl.h"
 #include <cctype>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 using namespace OpenMM;
@@ -92,6 +98,8 @@ bool sexticCoefficients(const vector<double>& n, size_t at, double* c) {
 
 HipValenceForm HipValenceForm::recognise(const CustomBondForce& force) {
     HipValenceForm f, none;
+    static const bool noInterpreter = getenv("OPENMM_HIP_NO_INTERPRETED_FORCES") != NULL;       // A/B knob: only the hand-written forms
+    if (!noInterpreter && HipInterpretedBonds::supports(force)) none.kind = INTERPRETED_BOND;      // what an expression is when it is not the form below
     if (force.getNumGlobalParameters() > 0 || force.getNumEnergyParameterDerivatives() > 0 || force.usesPeriodicBoundaryConditions()) return none;
     vector<double> n;
     if (shapeOf(force.getEnergyFunction(), n) != "k*(d^#+#*d^#+#*d^#);d=r-r0" || n.size() != 5 || n[0] != 2 || n[2] != 3 || n[4] != 4) return none;
@@ -196,6 +204,126 @@ void HipValenceTerms::execute(bool includeEnergy) {
 }
 
 // ================================================================================================
+// ================================================================================================ interpreted CustomBondForce
+namespace {
+/* postfix form of an expression tree (the interpreter's operation codes follow Lepton's ids from ADD on); false if something has no device form */
+bool emitBondProgram(const Lepton::ExpressionTreeNode& node, const vector<string>& perBond, const vector<string>& globals, vector<ommhip_vm_instruction>& out, int& depth, int& maxDepth) {
+    using Lepton::Operation;
+    for (size_t i = 0; i < node.getChildren().size(); i++)
+        if (!emitBondProgram(node.getChildren()[i], perBond, globals, out, depth, maxDepth)) return false;
+    const Operation& op = node.getOperation();
+    ommhip_vm_instruction in = {0, 0, 0.0};
+    switch (op.getId()) {
+        case Operation::CONSTANT: in.op = OMMHIP_VM_CONSTANT; in.value = dynamic_cast<const Operation::Constant&>(op).getValue(); break;
+        case Operation::VARIABLE: {
+            const string name = op.getName();
+            in.op = OMMHIP_VM_VARIABLE; in.arg = -1;
+            if (name == "r") in.arg = 0;
+            for (size_t k = 0; k < perBond.size() && in.arg < 0; k++) if (perBond[k] == name) in.arg = 6 + (int) k;
+            for (size_t k = 0; k < globals.size() && in.arg < 0; k++) if (globals[k] == name) { in.op = OMMHIP_VM_GLOBAL; in.arg = (int) k; }
+            if (in.arg < 0) return false;
+            break;
+        }
+        case Operation::ADD_CONSTANT: in.op = OMMHIP_VM_ADD_CONSTANT; in.value = dynamic_cast<const Operation::AddConstant&>(op).getValue(); break;
+        case Operation::MULTIPLY_CONSTANT: in.op = OMMHIP_VM_MULTIPLY_CONSTANT; in.value = dynamic_cast<const Operation::MultiplyConstant&>(op).getValue(); break;
+        case Operation::POWER_CONSTANT: in.op = OMMHIP_VM_POWER_CONSTANT; in.value = dynamic_cast<const Operation::PowerConstant&>(op).getValue(); break;
+        case Operation::CUSTOM: return false;
+        default:
+            if ((int) op.getId() < (int) Operation::ADD || (int) op.getId() > (int) Operation::SELECT) return false;
+            in.op = OMMHIP_VM_ADD + ((int) op.getId() - (int) Operation::ADD);
+            break;
+    }
+    out.push_back(in);
+    depth += 1 - (int) node.getChildren().size();
+    maxDepth = max(maxDepth, depth);
+    return true;
+}
+}  // namespace
+
+bool HipInterpretedBonds::translate(const CustomBondForce& force, vector<ommhip_vm_instruction>& program, int counts[4]) {
+    if (force.getNumEnergyParameterDerivatives() > 0) return false;
+    vector<string> perBond, globals;
+    for (int i = 0; i < force.getNumPerBondParameters(); i++) perBond.push_back(force.getPerBondParameterName(i));
+    for (int i = 0; i < force.getNumGlobalParameters(); i++) globals.push_back(force.getGlobalParameterName(i));
+    try {
+        // the expressions the Reference kernel evaluates (ReferenceKernels.cpp, CalcCustomBondForceKernel::initialize): E and dE/dr, optimised
+        Lepton::ParsedExpression energy = Lepton::Parser::parse(force.getEnergyFunction()).optimize();
+        Lepton::ParsedExpression deriv = energy.differentiate("r").optimize();
+        program.clear();
+        int depth = 0, maxDepth = 0;
+        counts[0] = 0;
+        if (!emitBondProgram(energy.getRootNode(), perBond, globals, program, depth, maxDepth)) return false;
+        counts[1] = (int) program.size();
+        counts[2] = counts[1];
+        depth = 0;
+        if (!emitBondProgram(deriv.getRootNode(), perBond, globals, program, depth, maxDepth)) return false;
+        counts[3] = (int) program.size() - counts[2];
+        return maxDepth <= OMMHIP_VM_STACK;
+    }
+    catch (const std::exception&) { return false; }
+}
+
+bool HipInterpretedBonds::supports(const CustomBondForce& force) {
+    vector<ommhip_vm_instruction> program;
+    int counts[4];
+    return translate(force, program, counts);
+}
+
+void HipInterpretedBonds::initialize(const CustomBondForce& force) {
+    data.hip->setAsCurrent();
+    vector<ommhip_vm_instruction> program;
+    if (!translate(force, program, counts)) throw OpenMMException("HIP platform: internal error: a CustomBondForce that cannot be interpreted");
+    numBonds = force.getNumBonds(); numParams = force.getNumPerBondParameters();
+    stride = (max(numBonds, 1) + 2) / 3 * 3;
+    periodic = force.usesPeriodicBoundaryConditions();
+    vector<int> atoms(2 * (size_t) numBonds);
+    for (int i = 0; i < numBonds; i++) { vector<double> p; force.getBondParameters(i, atoms[2 * i], atoms[2 * i + 1], p); }
+    uploadVector(atomsD, atoms, data.hip->stream);
+    uploadVector(programD, program, data.hip->stream);
+    globalNames.clear(); globalValues.clear();
+    for (int i = 0; i < force.getNumGlobalParameters(); i++) { globalNames.push_back(force.getGlobalParameterName(i)); globalValues.push_back(force.getGlobalParameterDefaultValue(i)); }
+    uploadVector(globalsD, globalValues, data.hip->stream);
+    uploadParams(force);
+}
+
+void HipInterpretedBonds::uploadParams(const CustomBondForce& force) {
+    data.hip->setAsCurrent();
+    if (force.getNumBonds() != numBonds) throw OpenMMException("updateParametersInContext: The number of bonds has changed");
+    vector<double> params((size_t) max(numParams, 1) * stride, 0.0);
+    for (int i = 0; i < numBonds; i++) {
+        int p1, p2; vector<double> p;
+        force.getBondParameters(i, p1, p2, p);
+        for (int k = 0; k < numParams; k++) params[(size_t) k * stride + i] = p[k];
+    }
+    uploadVector(paramsD, params, data.hip->stream);
+}
+
+static long long interpretedBondLaunches = 0;
+/* test hook: launches of the interpreted CustomBondForce kernel by this process so far */
+extern "C" __attribute__((visibility("default"))) long long ommhip_plugin_interpreted_bond_launches() { return interpretedBondLaunches; }
+
+void HipInterpretedBonds::execute(ContextImpl& context, bool includeEnergy) {
+    if (numBonds == 0) return;
+    HipContext& hip = *data.hip;
+    hip.setAsCurrent();
+    bool changed = false;
+    for (size_t i = 0; i < globalNames.size(); i++) {
+        const double v = context.getParameter(globalNames[i]);
+        if (v != globalValues[i]) { globalValues[i] = v; changed = true; }
+    }
+    if (changed) uploadVector(globalsD, globalValues, hip.stream);
+    hip.ensureCleared();
+    ommhip_vm_bonds b;
+    b.num_bonds = numBonds; b.num_params = numParams; b.param_stride = stride; b.periodic = periodic ? 1 : 0;
+    b.atoms = atomsD.as<int>(); b.params = paramsD.as<double>(); b.program = (const ommhip_vm_instruction*) programD.ptr;
+    b.energy_first = counts[0]; b.energy_count = counts[1]; b.deriv_first = counts[2]; b.deriv_count = counts[3];
+    b.globals = globalsD.as<double>();
+    for (int k = 0; k < 6; k++) b.box[k] = hip.box[k];
+    interpretedBondLaunches++;
+    HIP_CHECK(ommhip_vm_bond_forces(&b, hip.pos.ptr, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.force.as<long long>(), hip.energyBuffer.as<double>(),
+                                    HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream));
+}
+
 void HipCalcCustomBondForceKernel::collect(const CustomBondForce& force, vector<int>* atoms, vector<double>& params) const {
     for (int i = 0; i < force.getNumBonds(); i++) {
         int p1, p2; vector<double> p;
@@ -206,22 +334,28 @@ void HipCalcCustomBondForceKernel::collect(const CustomBondForce& force, vector<
 }
 void HipCalcCustomBondForceKernel::initialize(const System& system, const CustomBondForce& force) {
     form = HipValenceForm::isNative(force) ? HipValenceForm::recognise(force) : HipValenceForm();
+    if (getenv("OPENMM_HIP_VALENCE_DEBUG") != NULL)          // diagnostics: which of the three ways this Force goes
+        fprintf(stderr, "HIP platform: CustomBondForce \"%s\": %s\n", force.getEnergyFunction().c_str(),
+                form.kind < 0 ? "Reference kernel (fallback force)" : (form.kind == HipValenceForm::INTERPRETED_BOND ? "interpreted on the device" : "hand-written kernel"));
     if (form.kind < 0) {
         if (reference == NULL) throw OpenMMException("HIP platform: no kernel for this CustomBondForce");
         reference->initialize(system, force);
         return;
     }
+    if (form.kind == HipValenceForm::INTERPRETED_BOND) { interpreted.initialize(force); return; }
     vector<int> atoms; vector<double> params;
     collect(force, &atoms, params);
     terms.upload(form, 2, atoms, params);
 }
 double HipCalcCustomBondForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy) {
     if (form.kind < 0) return reference->execute(context, includeForces, includeEnergy);
+    if (form.kind == HipValenceForm::INTERPRETED_BOND) { interpreted.execute(context, includeEnergy); return 0.0; }
     terms.execute(includeEnergy);
     return 0.0;
 }
 void HipCalcCustomBondForceKernel::copyParametersToContext(ContextImpl& context, const CustomBondForce& force) {
     if (form.kind < 0) { reference->copyParametersToContext(context, force); return; }
+    if (form.kind == HipValenceForm::INTERPRETED_BOND) { interpreted.uploadParams(force); return; }
     vector<double> params;
     collect(force, NULL, params);
     terms.uploadParams(params);

@@ -26,6 +26,8 @@ struct HipValenceForm {
     std::vector<int> paramIndex;    // kernel parameter p = per-bond parameter paramIndex[p] of the Force
     HipValenceForm() : kind(-1) { for (int i = 0; i < 6; i++) coefficients[i] = 0; }
     static HipValenceForm recognise(const CustomBondForce& force);
+    /** kind of a CustomBondForce whose expression is none of the known forms but can be interpreted on the device (HipInterpretedBonds) */
+    static const int INTERPRETED_BOND = 100;
     static HipValenceForm recognise(const CustomAngleForce& force);
     static HipValenceForm recognise(const CustomCompoundBondForce& force);
     /** Is this Force one of the three classes above with a recognised expression? */
@@ -47,9 +49,30 @@ private:
     DeviceBuffer atomsD, paramsD, gridsD;
 };
 
+/** A CustomBondForce with ANY expression of r, per-bond and global parameters (no tabulated functions, no energy parameter derivatives):
+ *  the energy and its symbolic derivative with respect to r as two programs of the CustomIntegrator's interpreter
+ *  (kernels/custom_integrator.hip, ommhip_vm_bond_forces).  The reference's GPU platforms compile such expressions at run time. */
+class HipInterpretedBonds {
+public:
+    HipInterpretedBonds(HipPlatform::PlatformData& data) : data(data) {}
+    /** Can this Force be interpreted?  (parses, only built-in operations, shallow enough for the interpreter's stack) */
+    static bool supports(const CustomBondForce& force);
+    void initialize(const CustomBondForce& force);
+    void uploadParams(const CustomBondForce& force);
+    void execute(ContextImpl& context, bool includeEnergy);
+private:
+    static bool translate(const CustomBondForce& force, std::vector<ommhip_vm_instruction>& program, int counts[4]);
+    HipPlatform::PlatformData& data;
+    int numBonds = 0, numParams = 0, stride = 3, counts[4] = {0, 0, 0, 0};
+    bool periodic = false;
+    std::vector<std::string> globalNames;
+    std::vector<double> globalValues;
+    DeviceBuffer atomsD, paramsD, programD, globalsD;
+};
+
 class HipCalcCustomBondForceKernel : public CalcCustomBondForceKernel {
 public:
-    HipCalcCustomBondForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data, KernelImpl* referenceKernel) : CalcCustomBondForceKernel(name, platform), reference(dynamic_cast<CalcCustomBondForceKernel*>(referenceKernel)), terms(data) {}
+    HipCalcCustomBondForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data, KernelImpl* referenceKernel) : CalcCustomBondForceKernel(name, platform), reference(dynamic_cast<CalcCustomBondForceKernel*>(referenceKernel)), terms(data), interpreted(data) {}
     ~HipCalcCustomBondForceKernel() { delete reference; }
     void initialize(const System& system, const CustomBondForce& force);
     double execute(ContextImpl& context, bool includeForces, bool includeEnergy);
@@ -59,6 +82,7 @@ private:
     CalcCustomBondForceKernel* reference;      // the Reference kernel: every expression without a native form is its business (a fallback force), owned
     HipValenceForm form;
     HipValenceTerms terms;
+    HipInterpretedBonds interpreted;
 };
 
 class HipCalcCustomAngleForceKernel : public CalcCustomAngleForceKernel {

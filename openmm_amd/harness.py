@@ -88,6 +88,13 @@ def valence_lists_launched():
     return int(plugin.ommhip_plugin_valence_lists_launched())
 
 
+def interpreted_bond_launches():
+    """Launches of the interpreted CustomBondForce kernel (any expression; kernels/custom_integrator.hip) by the loaded HIP plugin so far."""
+    plugin = C.CDLL(next(p for p in _loaded_plugins if p.endswith("libOpenMMHIP.so")))
+    plugin.ommhip_plugin_interpreted_bond_launches.restype = C.c_longlong
+    return int(plugin.ommhip_plugin_interpreted_bond_launches())
+
+
 def load_hip_platform(emulated=False):
     """Register the HIP platform through OpenMM's plugin loader.  Raises if the plugin is missing."""
     path = os.path.join(EMU_DIR if emulated else LIB_DIR, "libOpenMMHIP.so")

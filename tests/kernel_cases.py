@@ -584,3 +584,54 @@ def run_vm(K, n=300, seed=2):
     e_s = (0.5 * m3 * e_v ** 2)[live].sum()
     return {"r0": (r0, e_r0), "v": (out_vel[:, :3], e_v), "x": (out_pos[:, :3], e_x), "sum": (np.array([s]), np.array([e_s])),
             "inverse_mass_kept": (out_vel[:, 3], vel[:, 3])}
+
+
+def run_vm_bonds(K, n=200, n_bonds=500, seed=4):
+    """ommhip_vm_bond_forces: a Morse bond with a global scale, E = s D (1 - exp(-a (r - r0)))^2, energy and dE/dr programs written by hand in
+    the postfix form of include/openmm_hip_kernels.h; periodic in a triclinic box whose minimum image the bonds need (atoms scattered over
+    several cells).  -> (forces, energy, oracle forces (central differences of the numpy energy), oracle energy)"""
+    from oracle import valence as OV
+    rng = np.random.default_rng(seed)
+    box = np.array([2.0, 0.3, 2.2, -0.4, 0.5, 2.4])          # ax, bx, by, cx, cy, cz
+    a_, b_, c_ = np.array([box[0], 0, 0]), np.array([box[1], box[2], 0]), np.array([box[3], box[4], box[5]])
+    base = rng.uniform(0, 1, size=(n, 3)) @ np.stack([a_, b_, c_])
+    atoms = np.stack([rng.integers(0, n, n_bonds), rng.integers(0, n, n_bonds)], -1).astype(np.int32)
+    atoms = atoms[atoms[:, 0] != atoms[:, 1]]
+    n_bonds = len(atoms)
+    pos = base + rng.integers(-2, 3, size=(n, 3)) @ np.stack([a_, b_, c_])          # every atom in some other cell
+    D, a, r0 = 50 + 50 * rng.random(n_bonds), 1 + rng.random(n_bonds), 0.5 + rng.random(n_bonds)
+    scale = 0.7
+
+    def energy(p):
+        d = p[atoms[:, 1]] - p[atoms[:, 0]]
+        d -= np.floor(d[:, 2] / c_[2] + 0.5)[:, None] * c_
+        d -= np.floor(d[:, 1] / b_[1] + 0.5)[:, None] * b_
+        d -= np.floor(d[:, 0] / a_[0] + 0.5)[:, None] * a_
+        r = np.linalg.norm(d, axis=1)
+        return scale * D * (1 - np.exp(-a * (r - r0))) ** 2
+
+    CONST, VAR, GLOBAL, ADD, SUB, MUL = 0, 1, 2, 3, 4, 5
+    NEG, EXP, SQUARE, MULC = 8, 10, 29, 33
+    u = [(VAR, 7, 0), (NEG, 0, 0), (VAR, 0, 0), (VAR, 8, 0), (SUB, 0, 0), (MUL, 0, 0), (EXP, 0, 0)]          # exp(-a (r - r0)); parameters: 6 = D, 7 = a, 8 = r0
+    e_prog = [(GLOBAL, 0, 0), (VAR, 6, 0), (MUL, 0, 0), (CONST, 0, 1.0)] + u + [(SUB, 0, 0), (SQUARE, 0, 0), (MUL, 0, 0)]
+    d_prog = [(GLOBAL, 0, 0), (VAR, 6, 0), (MUL, 0, 0), (VAR, 7, 0), (MUL, 0, 0), (MULC, 0, 2.0), (CONST, 0, 1.0)] + u + [(SUB, 0, 0), (MUL, 0, 0)] + u + [(MUL, 0, 0)]
+    prog = e_prog + d_prog
+    instr = (capi.VmInstruction * len(prog))(*[capi.VmInstruction(op, arg, val) for op, arg, val in prog])
+    prog_d = K.malloc(C.sizeof(instr)); K.memcpy_h2d(prog_d, C.cast(instr, C.c_void_p), C.c_size_t(C.sizeof(instr)), None); K.stream_sync(None)
+    stride = (n_bonds + 2) // 3 * 3
+    params = np.zeros((3, stride)); params[0, :n_bonds], params[1, :n_bonds], params[2, :n_bonds] = D, a, r0
+    b = capi.VmBonds()
+    b.num_bonds, b.num_params, b.param_stride, b.periodic = n_bonds, 3, stride, 1
+    b.atoms, b.params, b.program = K.upload(atoms.reshape(-1)), K.upload(params.reshape(-1)), prog_d
+    b.energy_first, b.energy_count, b.deriv_first, b.deriv_count = 0, len(e_prog), len(e_prog), len(d_prog)
+    b.globals = K.upload(np.array([scale]))
+    for k in range(6): b.box[k] = box[k]
+    padded = (n + 31) // 32 * 32 + 32
+    perm = rng.permutation(padded)[:n]
+    pos4 = np.zeros((n, 4)); pos4[:, :3] = pos
+    pos_d, slot_d = K.upload(pos4), K.upload(perm.astype(np.int32))
+    force_d = K.upload(np.zeros(3 * padded, dtype=np.int64)); e_d = K.upload(np.zeros(64)); out_d = K.upload(np.zeros(3 * n))
+    K.vm_bond_forces(C.byref(b), pos_d, slot_d, padded, force_d, e_d, 64, 1, None)
+    K.forces_to_atom_order(force_d, slot_d, n, padded, out_d, None)
+    K.stream_sync(None)
+    return K.download(out_d, (n, 3), np.float64), K.download(e_d, (64,), np.float64).sum(), OV.forces(energy, pos, h=1e-6), energy(pos).sum()

@@ -302,10 +302,12 @@ def test_valence_kernels_against_numpy_energies(K, kind):
 
 @needs_emu
 def test_custom_forces_native_when_recognised_reference_kernel_otherwise():
-    """Three CustomBondForces and a CustomAngleForce on one System: the AMOEBA bond expression with its per-bond parameters declared in the
-    other order (native: the kernel's parameters are found by name), the same expression written differently (a*b instead of b*a: not
-    recognised -> the Reference kernel inside the same kernel object, a fallback force), a Morse bond (Reference), the AMOEBA angle
-    expression (native) -- forces and energy against the Reference platform, and the counter of native lists says which ran where."""
+    """Five CustomBondForces and a CustomAngleForce on one System: the AMOEBA bond expression with its per-bond parameters declared in the
+    other order (hand-written kernel: its parameters are found by name), the same expression written differently (a*b instead of b*a: not
+    recognised -> interpreted on the device from the Lepton tree and its symbolic derivative), a Morse bond (interpreted), an expression
+    nested deeper than the interpreter's stack (the Reference kernel inside the same kernel object, a fallback force), the AMOEBA angle
+    expression (hand-written kernel) -- forces and energy against the Reference platform, and the counters say which ran where.  (Global
+    parameters, periodic bonds and parameter updates of interpreted forces: the reference's TestCustomBondForce body, tests/hip.)"""
     code = r'''
 import sys, numpy as np
 sys.path.insert(0, %r)
@@ -322,20 +324,22 @@ for plat in ("Reference", "HIP"):
     s = H.System(); s.addParticles(np.full(n, 12.0))
     s.addCustomBondForce("k*(d^2 + -25.5*d^3 + 379.3125*d^4); d=r-r0", ["k", "r0"], bonds, np.stack([k, r0], -1))                 # native, parameters swapped
     s.addCustomBondForce("(d^2 + -25.5*d^3 + 379.3125*d^4)*k; d=r-r0", ["r0", "k"], bonds, np.stack([r0, 0.5 * k], -1))           # another shape: Reference
-    s.addCustomBondForce("D*(1-exp(-a*(r-r0)))^2", ["D", "a", "r0"], bonds, np.stack([k, np.full(len(bonds), 2.0), r0], -1))        # Reference
+    s.addCustomBondForce("D*(1-exp(-a*(r-r0)))^2", ["D", "a", "r0"], bonds, np.stack([k, np.full(len(bonds), 2.0), r0], -1))        # interpreted
+    deep = "r0*r" + "".join("+(r*%%d" %% (i + 2) for i in range(18)) + ")" * 18
+    s.addCustomBondForce(deep, ["r0"], bonds[:7], r0[:7, None])                                                                   # too deep for the stack: Reference
     s.addCustomAngleForce("k*(d^2 + -0.014*d^3 + 5.6e-05*d^4 + -7e-07*d^5 + 2.2e-08*d^6); d=57.29577951308232*theta-theta0", ["theta0", "k"], angles,
                           np.stack([theta0, 0.05 * np.ones(len(angles))], -1))                            # native
     ctx = H.Context(s, H.Integrator(H.VERLET, 0.001), plat)
     ctx.setPositions(pos)
-    before = H.valence_lists_launched() if plat == "HIP" else 0
+    before = (H.valence_lists_launched(), H.interpreted_bond_launches()) if plat == "HIP" else 0
     st = ctx.getState(getForces=True, getEnergy=True)
     res[plat] = (st.forces, st.potentialEnergy)
-    if plat == "HIP": print("LISTS", H.valence_lists_launched() - before, "MODE", ctx.getPlatformProperty("IntegrationMode"))
+    if plat == "HIP": print("LISTS", H.valence_lists_launched() - before[0], "INTERPRETED", H.interpreted_bond_launches() - before[1], "MODE", ctx.getPlatformProperty("IntegrationMode"))
     ctx.close()
 print("DF", np.abs(res["Reference"][0] - res["HIP"][0]).max() / np.abs(res["Reference"][0]).max(), "DE", abs(res["Reference"][1] - res["HIP"][1]) / abs(res["Reference"][1]))
 ''' % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "LISTS 2 MODE device" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.returncode == 0 and "LISTS 2 INTERPRETED 2 MODE device" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     import re
     df, de = (float(v) for v in re.search(r"DF (\S+) DE (\S+)", out.stdout).groups())
     assert df < 1e-9 and de < 1e-12, (df, de)
@@ -622,4 +626,13 @@ def test_custom_integrator_interpreter_through_the_c_abi(K):
     the one before wrote), a sum over the degrees of freedom, a massless particle left alone -- against numpy."""
     for name, (got, expected) in KC.run_vm(K).items():
         assert np.allclose(got, expected, rtol=1e-13, atol=1e-13), name
+
+
+@needs_emu
+def test_interpreted_custom_bond_force_through_the_c_abi(K):
+    """ommhip_vm_bond_forces: a Morse bond with a global parameter, programs for E and dE/dr written by hand, periodic in a triclinic box with
+    the atoms scattered over several cells -- energy and forces against numpy (forces: central differences of the numpy energy)."""
+    f, e, f_or, e_or = KC.run_vm_bonds(K)
+    assert abs(e - e_or) < 1e-11 * abs(e_or), (e, e_or)
+    assert np.abs(f - f_or).max() < 1e-6 * np.abs(f_or).max(), (np.abs(f - f_or).max(), np.abs(f_or).max())
 

@@ -208,3 +208,11 @@ def test_custom_integrator_interpreter_through_the_c_abi(K):
     for name, (got, expected) in KC.run_vm(K).items():
         assert np.allclose(got, expected, rtol=1e-13, atol=1e-13), name
 
+
+def test_interpreted_custom_bond_force_through_the_c_abi(K):
+    """ommhip_vm_bond_forces: a Morse bond with a global parameter, programs for E and dE/dr written by hand, periodic in a triclinic box with
+    the atoms scattered over several cells -- energy and forces against numpy (forces: central differences of the numpy energy)."""
+    f, e, f_or, e_or = KC.run_vm_bonds(K)
+    assert abs(e - e_or) < 1e-11 * abs(e_or), (e, e_or)
+    assert np.abs(f - f_or).max() < 1e-6 * np.abs(f_or).max(), (np.abs(f - f_or).max(), np.abs(f_or).max())
+

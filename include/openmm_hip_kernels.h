@@ -626,6 +626,10 @@ typedef struct ommhip_vm_bonds {
 } ommhip_vm_bonds;
 int ommhip_vm_bond_forces(const ommhip_vm_bonds* bonds, const void* pos_d, const int* slot_of_atom_d, int padded_atoms, long long* force_d,
                           double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
+/* The same for CustomAngleForce (CustomAngleForce.h; Reference: ReferenceCustomAngleIxn.cpp, ReferenceAngleBondIxn.cpp:95-150): VARIABLE 0 is
+ * theta (radians) of the atoms (a, b, c) with b at the apex, atoms = int[3 * num_bonds], the derivative program is dE/dtheta. */
+int ommhip_vm_angle_forces(const ommhip_vm_bonds* angles, const void* pos_d, const int* slot_of_atom_d, int padded_atoms, long long* force_d,
+                           double* energy_buffer_d, int energy_slots, int include_energy, void* stream);
 /* fixed-point forces in slot order -> double[3 * num_atoms] in atom order (a copy the integrator can keep per force group while other
  * groups are evaluated and atoms are re-sorted) */
 int ommhip_forces_to_atom_order(const long long* force_d, const int* slot_of_atom_d, int num_atoms, int padded_atoms, double* out_d, void* stream);

@@ -193,6 +193,50 @@ __global__ __launch_bounds__(VM_BLOCK) void k_vm_bonds(VmBondArgs a) {
     }
 }
 
+__device__ __forceinline__ void vm_min_image(const ommhip_vm_bonds& b, double& dx, double& dy, double& dz) {
+    if (!b.periodic) return;
+    double n = floor(dz / b.box[5] + 0.5); dx -= n * b.box[3]; dy -= n * b.box[4]; dz -= n * b.box[5];
+    n = floor(dy / b.box[2] + 0.5); dx -= n * b.box[1]; dy -= n * b.box[2];
+    n = floor(dx / b.box[0] + 0.5); dx -= n * b.box[0];
+}
+
+// CustomAngleForce with an arbitrary expression of theta: one thread per angle
+__global__ __launch_bounds__(VM_BLOCK) void k_vm_angles(VmBondArgs a) {
+    __shared__ double stack[OMMHIP_VM_STACK * VM_BLOCK];
+    const int lane = threadIdx.x;
+    ommhip_vm_state s;
+    s.num_atoms = a.b.param_stride / 3; s.num_per_dof = a.b.num_params; s.per_dof = const_cast<double*>(a.b.params);
+    s.globals = a.b.globals; s.program = a.b.program;
+    ommhip_vm_step energyStep = {a.b.energy_first, a.b.energy_count, 0, 0, nullptr, 0}, derivStep = {a.b.deriv_first, a.b.deriv_count, 0, 0, nullptr, 0};
+    double energy = 0;
+    for (int t = blockIdx.x * VM_BLOCK + lane; t < a.b.num_bonds; t += gridDim.x * VM_BLOCK) {
+        const int i = a.b.atoms[3 * t], j = a.b.atoms[3 * t + 1], k = a.b.atoms[3 * t + 2];
+        const double4 pi = a.pos[i], pj = a.pos[j], pk = a.pos[k];
+        double ux = pi.x - pj.x, uy = pi.y - pj.y, uz = pi.z - pj.z, wx = pk.x - pj.x, wy = pk.y - pj.y, wz = pk.z - pj.z;
+        vm_min_image(a.b, ux, uy, uz); vm_min_image(a.b, wx, wy, wz);
+        const double u2 = ux * ux + uy * uy + uz * uz, w2 = wx * wx + wy * wy + wz * wz;
+        double c = (ux * wx + uy * wy + uz * wz) / sqrt(u2 * w2);
+        c = fmin(1.0, fmax(-1.0, c));
+        DofVars var;
+        var.x = acos(c); var.v = 0; var.f = 0; var.m = 0; var.gaussian = 0; var.uniform = 0;
+        const double dEdTheta = vm_run(s, derivStep, var, (size_t) t, stack, lane);
+        if (a.includeEnergy) energy += vm_run(s, energyStep, var, (size_t) t, stack, lane);
+        // ReferenceAngleBondIxn.cpp:118-146: p = u x w, forces along p x u and p x w (the reference's delta vectors are -u and -w)
+        const double px = uy * wz - uz * wy, py = uz * wx - ux * wz, pz = ux * wy - uy * wx;
+        const double rp = fmax(sqrt(px * px + py * py + pz * pz), 1e-6);
+        const double termA = dEdTheta / (u2 * rp), termC = -dEdTheta / (w2 * rp);
+        const double fax = -termA * (uy * pz - uz * py), fay = -termA * (uz * px - ux * pz), faz = -termA * (ux * py - uy * px);
+        const double fcx = -termC * (wy * pz - wz * py), fcy = -termC * (wz * px - wx * pz), fcz = -termC * (wx * py - wy * px);
+        add_force(a.force, a.paddedAtoms, a.slotOfAtom[i], fax, fay, faz);
+        add_force(a.force, a.paddedAtoms, a.slotOfAtom[k], fcx, fcy, fcz);
+        add_force(a.force, a.paddedAtoms, a.slotOfAtom[j], -(fax + fcx), -(fay + fcy), -(faz + fcz));
+    }
+    if (a.includeEnergy) {
+        energy = wave_sum(energy);
+        if (lane == 0) atomicAdd(&a.energyBuffer[blockIdx.x % a.energySlots], energy);
+    }
+}
+
 }  // namespace
 
 extern "C" int ommhip_vm_per_dof(const ommhip_vm_state* state, int num_steps, const ommhip_vm_step* steps, void* stream) {
@@ -226,5 +270,17 @@ extern "C" int ommhip_vm_bond_forces(const ommhip_vm_bonds* bonds, const void* p
     a.force = (omm_fixed*) force_d; a.energyBuffer = energy_buffer_d; a.energySlots = energy_slots; a.includeEnergy = include_energy;
     const int blocks = min(VM_MAX_BLOCKS, (bonds->num_bonds + VM_BLOCK - 1) / VM_BLOCK);
     hipLaunchKernelGGL(k_vm_bonds, dim3(blocks), dim3(VM_BLOCK), 0, (hipStream_t) stream, a);
+    return (int) hipGetLastError();
+}
+
+extern "C" int ommhip_vm_angle_forces(const ommhip_vm_bonds* angles, const void* pos_d, const int* slot_of_atom_d, int padded_atoms, long long* force_d,
+                                      double* energy_buffer_d, int energy_slots, int include_energy, void* stream) {
+    if (angles->num_bonds <= 0) return 0;
+    VmBondArgs a;
+    a.b = *angles;
+    a.pos = (const double4*) pos_d; a.slotOfAtom = slot_of_atom_d; a.paddedAtoms = padded_atoms;
+    a.force = (omm_fixed*) force_d; a.energyBuffer = energy_buffer_d; a.energySlots = energy_slots; a.includeEnergy = include_energy;
+    const int blocks = min(VM_MAX_BLOCKS, (angles->num_bonds + VM_BLOCK - 1) / VM_BLOCK);
+    hipLaunchKernelGGL(k_vm_angles, dim3(blocks), dim3(VM_BLOCK), 0, (hipStream_t) stream, a);
     return (int) hipGetLastError();
 }

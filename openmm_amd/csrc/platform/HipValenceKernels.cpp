@@ -113,6 +113,8 @@ HipValenceForm HipValenceForm::recognise(const CustomBondForce& force) {
 
 HipValenceForm HipValenceForm::recognise(const CustomAngleForce& force) {
     HipValenceForm f, none;
+    static const bool noInterpreter = getenv("OPENMM_HIP_NO_INTERPRETED_FORCES") != NULL;
+    if (!noInterpreter && HipInterpretedBonds::supports(force)) none.kind = INTERPRETED_ANGLE;
     if (force.getNumGlobalParameters() > 0 || force.getNumEnergyParameterDerivatives() > 0 || force.usesPeriodicBoundaryConditions()) return none;
     vector<double> n;
     if (shapeOf(force.getEnergyFunction(), n) != "k*(d^#+#*d^#+#*d^#+#*d^#+#*d^#);d=#*theta-theta0" || n.size() != 10) return none;
@@ -207,10 +209,10 @@ void HipValenceTerms::execute(bool includeEnergy) {
 // ================================================================================================ interpreted CustomBondForce
 namespace {
 /* postfix form of an expression tree (the interpreter's operation codes follow Lepton's ids from ADD on); false if something has no device form */
-bool emitBondProgram(const Lepton::ExpressionTreeNode& node, const vector<string>& perBond, const vector<string>& globals, vector<ommhip_vm_instruction>& out, int& depth, int& maxDepth) {
+bool emitBondProgram(const Lepton::ExpressionTreeNode& node, const string& variable, const vector<string>& perBond, const vector<string>& globals, vector<ommhip_vm_instruction>& out, int& depth, int& maxDepth) {
     using Lepton::Operation;
     for (size_t i = 0; i < node.getChildren().size(); i++)
-        if (!emitBondProgram(node.getChildren()[i], perBond, globals, out, depth, maxDepth)) return false;
+        if (!emitBondProgram(node.getChildren()[i], variable, perBond, globals, out, depth, maxDepth)) return false;
     const Operation& op = node.getOperation();
     ommhip_vm_instruction in = {0, 0, 0.0};
     switch (op.getId()) {
@@ -218,7 +220,7 @@ bool emitBondProgram(const Lepton::ExpressionTreeNode& node, const vector<string
         case Operation::VARIABLE: {
             const string name = op.getName();
             in.op = OMMHIP_VM_VARIABLE; in.arg = -1;
-            if (name == "r") in.arg = 0;
+            if (name == variable) in.arg = 0;
             for (size_t k = 0; k < perBond.size() && in.arg < 0; k++) if (perBond[k] == name) in.arg = 6 + (int) k;
             for (size_t k = 0; k < globals.size() && in.arg < 0; k++) if (globals[k] == name) { in.op = OMMHIP_VM_GLOBAL; in.arg = (int) k; }
             if (in.arg < 0) return false;
@@ -240,23 +242,38 @@ bool emitBondProgram(const Lepton::ExpressionTreeNode& node, const vector<string
 }
 }  // namespace
 
-bool HipInterpretedBonds::translate(const CustomBondForce& force, vector<ommhip_vm_instruction>& program, int counts[4]) {
-    if (force.getNumEnergyParameterDerivatives() > 0) return false;
-    vector<string> perBond, globals;
-    for (int i = 0; i < force.getNumPerBondParameters(); i++) perBond.push_back(force.getPerBondParameterName(i));
-    for (int i = 0; i < force.getNumGlobalParameters(); i++) globals.push_back(force.getGlobalParameterName(i));
+HipInterpretedBonds::Description HipInterpretedBonds::describe(const CustomBondForce& force) {
+    Description d;
+    d.expression = force.getEnergyFunction(); d.variable = "r"; d.atomsPerTerm = 2;
+    d.numDerivatives = force.getNumEnergyParameterDerivatives(); d.periodic = force.usesPeriodicBoundaryConditions();
+    for (int i = 0; i < force.getNumPerBondParameters(); i++) d.perTerm.push_back(force.getPerBondParameterName(i));
+    for (int i = 0; i < force.getNumGlobalParameters(); i++) { d.globals.push_back(force.getGlobalParameterName(i)); d.globalDefaults.push_back(force.getGlobalParameterDefaultValue(i)); }
+    return d;
+}
+HipInterpretedBonds::Description HipInterpretedBonds::describe(const CustomAngleForce& force) {
+    Description d;
+    d.expression = force.getEnergyFunction(); d.variable = "theta"; d.atomsPerTerm = 3;
+    d.numDerivatives = force.getNumEnergyParameterDerivatives(); d.periodic = force.usesPeriodicBoundaryConditions();
+    for (int i = 0; i < force.getNumPerAngleParameters(); i++) d.perTerm.push_back(force.getPerAngleParameterName(i));
+    for (int i = 0; i < force.getNumGlobalParameters(); i++) { d.globals.push_back(force.getGlobalParameterName(i)); d.globalDefaults.push_back(force.getGlobalParameterDefaultValue(i)); }
+    return d;
+}
+
+bool HipInterpretedBonds::translate(const Description& d, vector<ommhip_vm_instruction>& program, int counts[4]) {
+    if (d.numDerivatives > 0) return false;
     try {
-        // the expressions the Reference kernel evaluates (ReferenceKernels.cpp, CalcCustomBondForceKernel::initialize): E and dE/dr, optimised
-        Lepton::ParsedExpression energy = Lepton::Parser::parse(force.getEnergyFunction()).optimize();
-        Lepton::ParsedExpression deriv = energy.differentiate("r").optimize();
+        // the expressions the Reference kernel evaluates (ReferenceKernels.cpp, CalcCustomBondForceKernel / CalcCustomAngleForceKernel::initialize):
+        // E and its derivative with respect to r / theta, optimised
+        Lepton::ParsedExpression energy = Lepton::Parser::parse(d.expression).optimize();
+        Lepton::ParsedExpression deriv = energy.differentiate(d.variable).optimize();
         program.clear();
         int depth = 0, maxDepth = 0;
         counts[0] = 0;
-        if (!emitBondProgram(energy.getRootNode(), perBond, globals, program, depth, maxDepth)) return false;
+        if (!emitBondProgram(energy.getRootNode(), d.variable, d.perTerm, d.globals, program, depth, maxDepth)) return false;
         counts[1] = (int) program.size();
         counts[2] = counts[1];
         depth = 0;
-        if (!emitBondProgram(deriv.getRootNode(), perBond, globals, program, depth, maxDepth)) return false;
+        if (!emitBondProgram(deriv.getRootNode(), d.variable, d.perTerm, d.globals, program, depth, maxDepth)) return false;
         counts[3] = (int) program.size() - counts[2];
         return maxDepth <= OMMHIP_VM_STACK;
     }
@@ -266,36 +283,58 @@ bool HipInterpretedBonds::translate(const CustomBondForce& force, vector<ommhip_
 bool HipInterpretedBonds::supports(const CustomBondForce& force) {
     vector<ommhip_vm_instruction> program;
     int counts[4];
-    return translate(force, program, counts);
+    return translate(describe(force), program, counts);
+}
+bool HipInterpretedBonds::supports(const CustomAngleForce& force) {
+    vector<ommhip_vm_instruction> program;
+    int counts[4];
+    return translate(describe(force), program, counts);
+}
+
+void HipInterpretedBonds::setup(const Description& d, const vector<int>& atoms) {
+    data.hip->setAsCurrent();
+    vector<ommhip_vm_instruction> program;
+    if (!translate(d, program, counts)) throw OpenMMException("HIP platform: internal error: a Custom*Force that cannot be interpreted");
+    atomsPerTerm = d.atomsPerTerm;
+    numBonds = (int) atoms.size() / atomsPerTerm; numParams = (int) d.perTerm.size();
+    stride = (max(numBonds, 1) + 2) / 3 * 3;
+    periodic = d.periodic;
+    uploadVector(atomsD, atoms, data.hip->stream);
+    uploadVector(programD, program, data.hip->stream);
+    globalNames = d.globals; globalValues = d.globalDefaults;
+    uploadVector(globalsD, globalValues, data.hip->stream);
+}
+
+void HipInterpretedBonds::uploadParamTable(const vector<vector<double> >& perTerm) {
+    data.hip->setAsCurrent();
+    if ((int) perTerm.size() != numBonds) throw OpenMMException("updateParametersInContext: The number of terms has changed");
+    vector<double> params((size_t) max(numParams, 1) * stride, 0.0);
+    for (int i = 0; i < numBonds; i++)
+        for (int k = 0; k < numParams; k++) params[(size_t) k * stride + i] = perTerm[i][k];
+    uploadVector(paramsD, params, data.hip->stream);
 }
 
 void HipInterpretedBonds::initialize(const CustomBondForce& force) {
-    data.hip->setAsCurrent();
-    vector<ommhip_vm_instruction> program;
-    if (!translate(force, program, counts)) throw OpenMMException("HIP platform: internal error: a CustomBondForce that cannot be interpreted");
-    numBonds = force.getNumBonds(); numParams = force.getNumPerBondParameters();
-    stride = (max(numBonds, 1) + 2) / 3 * 3;
-    periodic = force.usesPeriodicBoundaryConditions();
-    vector<int> atoms(2 * (size_t) numBonds);
-    for (int i = 0; i < numBonds; i++) { vector<double> p; force.getBondParameters(i, atoms[2 * i], atoms[2 * i + 1], p); }
-    uploadVector(atomsD, atoms, data.hip->stream);
-    uploadVector(programD, program, data.hip->stream);
-    globalNames.clear(); globalValues.clear();
-    for (int i = 0; i < force.getNumGlobalParameters(); i++) { globalNames.push_back(force.getGlobalParameterName(i)); globalValues.push_back(force.getGlobalParameterDefaultValue(i)); }
-    uploadVector(globalsD, globalValues, data.hip->stream);
+    vector<int> atoms(2 * (size_t) force.getNumBonds());
+    for (int i = 0; i < force.getNumBonds(); i++) { vector<double> p; force.getBondParameters(i, atoms[2 * i], atoms[2 * i + 1], p); }
+    setup(describe(force), atoms);
     uploadParams(force);
 }
-
 void HipInterpretedBonds::uploadParams(const CustomBondForce& force) {
-    data.hip->setAsCurrent();
-    if (force.getNumBonds() != numBonds) throw OpenMMException("updateParametersInContext: The number of bonds has changed");
-    vector<double> params((size_t) max(numParams, 1) * stride, 0.0);
-    for (int i = 0; i < numBonds; i++) {
-        int p1, p2; vector<double> p;
-        force.getBondParameters(i, p1, p2, p);
-        for (int k = 0; k < numParams; k++) params[(size_t) k * stride + i] = p[k];
-    }
-    uploadVector(paramsD, params, data.hip->stream);
+    vector<vector<double> > table(force.getNumBonds());
+    for (int i = 0; i < force.getNumBonds(); i++) { int p1, p2; force.getBondParameters(i, p1, p2, table[i]); }
+    uploadParamTable(table);
+}
+void HipInterpretedBonds::initialize(const CustomAngleForce& force) {
+    vector<int> atoms(3 * (size_t) force.getNumAngles());
+    for (int i = 0; i < force.getNumAngles(); i++) { vector<double> p; force.getAngleParameters(i, atoms[3 * i], atoms[3 * i + 1], atoms[3 * i + 2], p); }
+    setup(describe(force), atoms);
+    uploadParams(force);
+}
+void HipInterpretedBonds::uploadParams(const CustomAngleForce& force) {
+    vector<vector<double> > table(force.getNumAngles());
+    for (int i = 0; i < force.getNumAngles(); i++) { int p1, p2, p3; force.getAngleParameters(i, p1, p2, p3, table[i]); }
+    uploadParamTable(table);
 }
 
 static long long interpretedBondLaunches = 0;
@@ -320,8 +359,8 @@ void HipInterpretedBonds::execute(ContextImpl& context, bool includeEnergy) {
     b.globals = globalsD.as<double>();
     for (int k = 0; k < 6; k++) b.box[k] = hip.box[k];
     interpretedBondLaunches++;
-    HIP_CHECK(ommhip_vm_bond_forces(&b, hip.pos.ptr, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.force.as<long long>(), hip.energyBuffer.as<double>(),
-                                    HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream));
+    HIP_CHECK((atomsPerTerm == 2 ? ommhip_vm_bond_forces : ommhip_vm_angle_forces)(&b, hip.pos.ptr, hip.slotOfAtom.as<int>(), hip.paddedAtoms, hip.force.as<long long>(),
+                                                                                    hip.energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, hip.stream));
 }
 
 void HipCalcCustomBondForceKernel::collect(const CustomBondForce& force, vector<int>* atoms, vector<double>& params) const {
@@ -371,22 +410,28 @@ void HipCalcCustomAngleForceKernel::collect(const CustomAngleForce& force, vecto
 }
 void HipCalcCustomAngleForceKernel::initialize(const System& system, const CustomAngleForce& force) {
     form = HipValenceForm::isNative(force) ? HipValenceForm::recognise(force) : HipValenceForm();
+    if (getenv("OPENMM_HIP_VALENCE_DEBUG") != NULL)
+        fprintf(stderr, "HIP platform: CustomAngleForce \"%s\": %s\n", force.getEnergyFunction().c_str(),
+                form.kind < 0 ? "Reference kernel (fallback force)" : (form.kind == HipValenceForm::INTERPRETED_ANGLE ? "interpreted on the device" : "hand-written kernel"));
     if (form.kind < 0) {
         if (reference == NULL) throw OpenMMException("HIP platform: no kernel for this CustomAngleForce");
         reference->initialize(system, force);
         return;
     }
+    if (form.kind == HipValenceForm::INTERPRETED_ANGLE) { interpreted.initialize(force); return; }
     vector<int> atoms; vector<double> params;
     collect(force, &atoms, params);
     terms.upload(form, 3, atoms, params);
 }
 double HipCalcCustomAngleForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy) {
     if (form.kind < 0) return reference->execute(context, includeForces, includeEnergy);
+    if (form.kind == HipValenceForm::INTERPRETED_ANGLE) { interpreted.execute(context, includeEnergy); return 0.0; }
     terms.execute(includeEnergy);
     return 0.0;
 }
 void HipCalcCustomAngleForceKernel::copyParametersToContext(ContextImpl& context, const CustomAngleForce& force) {
     if (form.kind < 0) { reference->copyParametersToContext(context, force); return; }
+    if (form.kind == HipValenceForm::INTERPRETED_ANGLE) { interpreted.uploadParams(force); return; }
     vector<double> params;
     collect(force, NULL, params);
     terms.uploadParams(params);

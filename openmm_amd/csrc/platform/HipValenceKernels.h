@@ -27,7 +27,7 @@ struct HipValenceForm {
     HipValenceForm() : kind(-1) { for (int i = 0; i < 6; i++) coefficients[i] = 0; }
     static HipValenceForm recognise(const CustomBondForce& force);
     /** kind of a CustomBondForce whose expression is none of the known forms but can be interpreted on the device (HipInterpretedBonds) */
-    static const int INTERPRETED_BOND = 100;
+    static const int INTERPRETED_BOND = 100, INTERPRETED_ANGLE = 101;
     static HipValenceForm recognise(const CustomAngleForce& force);
     static HipValenceForm recognise(const CustomCompoundBondForce& force);
     /** Is this Force one of the three classes above with a recognised expression? */
@@ -59,11 +59,27 @@ public:
     static bool supports(const CustomBondForce& force);
     void initialize(const CustomBondForce& force);
     void uploadParams(const CustomBondForce& force);
+    /** the same for a CustomAngleForce: an expression of theta (ommhip_vm_angle_forces) */
+    static bool supports(const CustomAngleForce& force);
+    void initialize(const CustomAngleForce& force);
+    void uploadParams(const CustomAngleForce& force);
     void execute(ContextImpl& context, bool includeEnergy);
 private:
-    static bool translate(const CustomBondForce& force, std::vector<ommhip_vm_instruction>& program, int counts[4]);
+    /** what the two Force classes have in common, as the translation needs it */
+    struct Description {
+        std::string expression, variable;
+        std::vector<std::string> perTerm, globals;
+        std::vector<double> globalDefaults;
+        int atomsPerTerm, numDerivatives;
+        bool periodic;
+    };
+    static Description describe(const CustomBondForce& force);
+    static Description describe(const CustomAngleForce& force);
+    static bool translate(const Description& d, std::vector<ommhip_vm_instruction>& program, int counts[4]);
+    void setup(const Description& d, const std::vector<int>& atoms);
+    void uploadParamTable(const std::vector<std::vector<double> >& perTerm);
     HipPlatform::PlatformData& data;
-    int numBonds = 0, numParams = 0, stride = 3, counts[4] = {0, 0, 0, 0};
+    int numBonds = 0, numParams = 0, stride = 3, atomsPerTerm = 2, counts[4] = {0, 0, 0, 0};
     bool periodic = false;
     std::vector<std::string> globalNames;
     std::vector<double> globalValues;
@@ -87,7 +103,7 @@ private:
 
 class HipCalcCustomAngleForceKernel : public CalcCustomAngleForceKernel {
 public:
-    HipCalcCustomAngleForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data, KernelImpl* referenceKernel) : CalcCustomAngleForceKernel(name, platform), reference(dynamic_cast<CalcCustomAngleForceKernel*>(referenceKernel)), terms(data) {}
+    HipCalcCustomAngleForceKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data, KernelImpl* referenceKernel) : CalcCustomAngleForceKernel(name, platform), reference(dynamic_cast<CalcCustomAngleForceKernel*>(referenceKernel)), terms(data), interpreted(data) {}
     ~HipCalcCustomAngleForceKernel() { delete reference; }
     void initialize(const System& system, const CustomAngleForce& force);
     double execute(ContextImpl& context, bool includeForces, bool includeEnergy);
@@ -97,6 +113,7 @@ private:
     CalcCustomAngleForceKernel* reference;      // the Reference kernel: every expression without a native form is its business (a fallback force), owned
     HipValenceForm form;
     HipValenceTerms terms;
+    HipInterpretedBonds interpreted;
 };
 
 class HipCalcCustomCompoundBondForceKernel : public CalcCustomCompoundBondForceKernel {

@@ -302,11 +302,11 @@ def test_valence_kernels_against_numpy_energies(K, kind):
 
 @needs_emu
 def test_custom_forces_native_when_recognised_reference_kernel_otherwise():
-    """Five CustomBondForces and a CustomAngleForce on one System: the AMOEBA bond expression with its per-bond parameters declared in the
+    """Four CustomBondForces and two CustomAngleForces on one System: the AMOEBA bond expression with its per-bond parameters declared in the
     other order (hand-written kernel: its parameters are found by name), the same expression written differently (a*b instead of b*a: not
     recognised -> interpreted on the device from the Lepton tree and its symbolic derivative), a Morse bond (interpreted), an expression
     nested deeper than the interpreter's stack (the Reference kernel inside the same kernel object, a fallback force), the AMOEBA angle
-    expression (hand-written kernel) -- forces and energy against the Reference platform, and the counters say which ran where.  (Global
+    expression (hand-written kernel), another function of theta (interpreted) -- forces and energy against the Reference platform, and the counters say which ran where.  (Global
     parameters, periodic bonds and parameter updates of interpreted forces: the reference's TestCustomBondForce body, tests/hip.)"""
     code = r'''
 import sys, numpy as np
@@ -327,6 +327,7 @@ for plat in ("Reference", "HIP"):
     s.addCustomBondForce("D*(1-exp(-a*(r-r0)))^2", ["D", "a", "r0"], bonds, np.stack([k, np.full(len(bonds), 2.0), r0], -1))        # interpreted
     deep = "r0*r" + "".join("+(r*%%d" %% (i + 2) for i in range(18)) + ")" * 18
     s.addCustomBondForce(deep, ["r0"], bonds[:7], r0[:7, None])                                                                   # too deep for the stack: Reference
+    s.addCustomAngleForce("0.5*k*(theta-t0)^2 + k*cos(2*theta)/(1+theta)", ["t0", "k"], angles, np.stack([np.radians(theta0), 30 * np.ones(len(angles))], -1))   # interpreted
     s.addCustomAngleForce("k*(d^2 + -0.014*d^3 + 5.6e-05*d^4 + -7e-07*d^5 + 2.2e-08*d^6); d=57.29577951308232*theta-theta0", ["theta0", "k"], angles,
                           np.stack([theta0, 0.05 * np.ones(len(angles))], -1))                            # native
     ctx = H.Context(s, H.Integrator(H.VERLET, 0.001), plat)
@@ -339,7 +340,7 @@ for plat in ("Reference", "HIP"):
 print("DF", np.abs(res["Reference"][0] - res["HIP"][0]).max() / np.abs(res["Reference"][0]).max(), "DE", abs(res["Reference"][1] - res["HIP"][1]) / abs(res["Reference"][1]))
 ''' % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "LISTS 2 INTERPRETED 2 MODE device" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.returncode == 0 and "LISTS 2 INTERPRETED 3 MODE device" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     import re
     df, de = (float(v) for v in re.search(r"DF (\S+) DE (\S+)", out.stdout).groups())
     assert df < 1e-9 and de < 1e-12, (df, de)

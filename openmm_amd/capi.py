@@ -133,6 +133,7 @@ SIGNATURES = {
     "valence_forces": [_I, C.POINTER(ValenceList), _P, _P, _I, _P, _P, _I, _I, _P],
     "vm_per_dof": [C.POINTER(VmState), _I, C.POINTER(VmStep), _P],
     "vm_bond_forces": [C.POINTER(VmBonds), _P, _P, _I, _P, _P, _I, _I, _P],
+    "vm_angle_forces": [C.POINTER(VmBonds), _P, _P, _I, _P, _P, _I, _I, _P],
     "forces_to_atom_order": [_P, _P, _I, _I, _P, _P],
 }
 

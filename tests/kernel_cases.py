@@ -635,3 +635,52 @@ def run_vm_bonds(K, n=200, n_bonds=500, seed=4):
     K.forces_to_atom_order(force_d, slot_d, n, padded, out_d, None)
     K.stream_sync(None)
     return K.download(out_d, (n, 3), np.float64), K.download(e_d, (64,), np.float64).sum(), OV.forces(energy, pos, h=1e-6), energy(pos).sum()
+
+
+def run_vm_angles(K, n=150, n_angles=400, seed=6):
+    """ommhip_vm_angle_forces: E = k (theta - t0)^2 / 2 + g cos(theta) with a global g, programs for E and dE/dtheta written by hand; periodic in a
+    triclinic box with the atoms scattered over several cells.  -> (forces, energy, oracle forces (central differences), oracle energy)"""
+    from oracle import valence as OV
+    rng = np.random.default_rng(seed)
+    box = np.array([2.0, 0.3, 2.2, -0.4, 0.5, 2.4])
+    cell = np.array([[box[0], 0, 0], [box[1], box[2], 0], [box[3], box[4], box[5]]])
+    base = rng.uniform(0, 1, size=(n, 3)) @ cell
+    atoms = np.stack([rng.permutation(n)[:3] for _ in range(n_angles)]).astype(np.int32)
+    pos = base + rng.integers(-2, 3, size=(n, 3)) @ cell
+    k, t0, g = 50 + 50 * rng.random(n_angles), 1.0 + rng.random(n_angles), 3.5
+
+    def image(d):
+        d = d - np.floor(d[:, 2] / cell[2, 2] + 0.5)[:, None] * cell[2]
+        d = d - np.floor(d[:, 1] / cell[1, 1] + 0.5)[:, None] * cell[1]
+        return d - np.floor(d[:, 0] / cell[0, 0] + 0.5)[:, None] * cell[0]
+
+    def energy(p):
+        u, w = image(p[atoms[:, 0]] - p[atoms[:, 1]]), image(p[atoms[:, 2]] - p[atoms[:, 1]])
+        theta = np.arccos(np.clip((u * w).sum(1) / np.sqrt((u * u).sum(1) * (w * w).sum(1)), -1, 1))
+        return 0.5 * k * (theta - t0) ** 2 + g * np.cos(theta)
+
+    VAR, GLOBAL, ADD, SUB, MUL = 1, 2, 3, 4, 5
+    SIN, COS, SQUARE, MULC = 12, 13, 29, 33
+    d = [(VAR, 0, 0), (VAR, 7, 0), (SUB, 0, 0)]                          # theta - t0; parameters: 6 = k, 7 = t0
+    e_prog = [(VAR, 6, 0)] + d + [(SQUARE, 0, 0), (MUL, 0, 0), (MULC, 0, 0.5), (GLOBAL, 0, 0), (VAR, 0, 0), (COS, 0, 0), (MUL, 0, 0), (ADD, 0, 0)]
+    d_prog = [(VAR, 6, 0)] + d + [(MUL, 0, 0), (GLOBAL, 0, 0), (VAR, 0, 0), (SIN, 0, 0), (MUL, 0, 0), (SUB, 0, 0)]
+    prog = e_prog + d_prog
+    instr = (capi.VmInstruction * len(prog))(*[capi.VmInstruction(op, arg, val) for op, arg, val in prog])
+    prog_d = K.malloc(C.sizeof(instr)); K.memcpy_h2d(prog_d, C.cast(instr, C.c_void_p), C.c_size_t(C.sizeof(instr)), None); K.stream_sync(None)
+    stride = (n_angles + 2) // 3 * 3
+    params = np.zeros((2, stride)); params[0, :n_angles], params[1, :n_angles] = k, t0
+    b = capi.VmBonds()
+    b.num_bonds, b.num_params, b.param_stride, b.periodic = n_angles, 2, stride, 1
+    b.atoms, b.params, b.program = K.upload(atoms.reshape(-1)), K.upload(params.reshape(-1)), prog_d
+    b.energy_first, b.energy_count, b.deriv_first, b.deriv_count = 0, len(e_prog), len(e_prog), len(d_prog)
+    b.globals = K.upload(np.array([g]))
+    for i in range(6): b.box[i] = box[i]
+    padded = (n + 31) // 32 * 32 + 32
+    perm = rng.permutation(padded)[:n]
+    pos4 = np.zeros((n, 4)); pos4[:, :3] = pos
+    pos_d, slot_d = K.upload(pos4), K.upload(perm.astype(np.int32))
+    force_d = K.upload(np.zeros(3 * padded, dtype=np.int64)); e_d = K.upload(np.zeros(64)); out_d = K.upload(np.zeros(3 * n))
+    K.vm_angle_forces(C.byref(b), pos_d, slot_d, padded, force_d, e_d, 64, 1, None)
+    K.forces_to_atom_order(force_d, slot_d, n, padded, out_d, None)
+    K.stream_sync(None)
+    return K.download(out_d, (n, 3), np.float64), K.download(e_d, (64,), np.float64).sum(), OV.forces(energy, pos, h=1e-6), energy(pos).sum()

@@ -636,4 +636,8 @@ def test_interpreted_custom_bond_force_through_the_c_abi(K):
     f, e, f_or, e_or = KC.run_vm_bonds(K)
     assert abs(e - e_or) < 1e-11 * abs(e_or), (e, e_or)
     assert np.abs(f - f_or).max() < 1e-6 * np.abs(f_or).max(), (np.abs(f - f_or).max(), np.abs(f_or).max())
+    # ommhip_vm_angle_forces: k (theta - t0)^2 / 2 + g cos(theta), the same box
+    f, e, f_or, e_or = KC.run_vm_angles(K)
+    assert abs(e - e_or) < 1e-11 * abs(e_or), (e, e_or)
+    assert np.abs(f - f_or).max() < 1e-6 * np.abs(f_or).max(), (np.abs(f - f_or).max(), np.abs(f_or).max())
 

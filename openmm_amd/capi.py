@@ -83,6 +83,12 @@ class VmBonds(C.Structure):
                 ("globals", C.c_void_p), ("box", C.c_double * 6)]
 
 
+class Ccma(C.Structure):
+    """ommhip_ccma (include/openmm_hip_kernels.h)"""
+    _fields_ = [("num_constraints", C.c_int), ("atoms", C.c_void_p), ("distance", C.c_void_p), ("delta", C.c_void_p), ("delta2", C.c_void_p),
+                ("row_start", C.c_void_p), ("col", C.c_void_p), ("value", C.c_void_p), ("converged", C.c_void_p)]
+
+
 class KernelError(RuntimeError):
     pass
 
@@ -135,6 +141,12 @@ SIGNATURES = {
     "vm_bond_forces": [C.POINTER(VmBonds), _P, _P, _I, _P, _P, _I, _I, _P],
     "vm_angle_forces": [C.POINTER(VmBonds), _P, _P, _I, _P, _P, _I, _I, _P],
     "forces_to_atom_order": [_P, _P, _I, _I, _P, _P],
+    "settle": [_I, _P, _P, _P, _P, _P, _I, _P],
+    "shake": [_I, _P, _P, _P, _P, _P, _I, _D, _I, _P],
+    "constrain_clusters": [_I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _D, _I, _P],
+    "ccma_iteration": [C.POINTER(Ccma), _P, _P, _P, _I, _D, _I, _P],
+    "ccma_iterations": [C.POINTER(Ccma), _P, _P, _P, _I, _D, _I, _P],
+    "ewald_reciprocal": [_P, _P, _P, _I, _I, _D6, _D, _I, _I, _I, _P, _P, _P, _I, _I, _P],
 }
 
 
@@ -151,7 +163,7 @@ class Kernels:
         # the ctypes mirrors above against the structs the library was compiled with
         self.lib.ommhip_struct_size.restype = C.c_size_t
         self.lib.ommhip_struct_size.argtypes = [C.c_int]
-        for which, mirror in ((0, NeighborList), (1, NonbondedParams), (2, Pme), (7, ValenceList), (8, VmInstruction), (9, VmStep), (10, VmState), (11, VmBonds)):
+        for which, mirror in ((0, NeighborList), (1, NonbondedParams), (2, Pme), (6, Ccma), (7, ValenceList), (8, VmInstruction), (9, VmStep), (10, VmState), (11, VmBonds)):
             if self.lib.ommhip_struct_size(which) != C.sizeof(mirror):
                 raise KernelError("%s: ctypes mirror of struct %d has %d bytes, the library's has %d -- openmm_amd/capi.py is out of date with include/openmm_hip_kernels.h"
                                   % (path, which, C.sizeof(mirror), self.lib.ommhip_struct_size(which)))

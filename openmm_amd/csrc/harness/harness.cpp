@@ -7,6 +7,7 @@
 #include "OpenMM.h"
 #include "ReferenceConstraints.h"
 #include "ReferenceSETTLEAlgorithm.h"
+#include "ReferenceCCMAAlgorithm.h"
 #include <cstring>
 #include <map>
 #include <sstream>
@@ -51,6 +52,45 @@ int omm_reference_settle_clusters(void* s, int* atoms, double* dist, int capacit
         for (int i = 0; i < n && i < capacity; i++)
             settle->getClusterParameters(i, atoms[3 * i], atoms[3 * i + 1], atoms[3 * i + 2], dist[2 * i], dist[2 * i + 1]);
         return n;
+    } catch (const std::exception& e) { lastError = e.what(); return -1; }
+}
+
+/* The thresholded inverse coupling matrix the Reference platform's CCMA builds for a System (ReferenceCCMAAlgorithm.cpp:42-196), as
+ * (row, column, value) triplets over the CCMA constraints in the reference's order; constraint[2i..] = their atoms.  The checker of
+ * oracle/constraints.py::ccma_matrix (tests only).  Returns the number of triplets (at most `capacity` are written), -1 on error. */
+int omm_reference_ccma_matrix(void* s, int* rows, int* cols, double* values, int capacity, int* constraintAtoms, int constraintCapacity, int* numConstraints) {
+    try {
+        ReferenceConstraints constraints(*(System*) s);
+        ReferenceCCMAAlgorithm* ccma = dynamic_cast<ReferenceCCMAAlgorithm*>(constraints.ccma);
+        *numConstraints = 0;
+        if (ccma == NULL) return 0;
+        const System& system = *(System*) s;
+        // the CCMA constraints are the System's constraints that touch no SETTLE atom, in System order (ReferenceConstraints.cpp:150-165)
+        std::vector<char> isSettle(system.getNumParticles(), 0);
+        ReferenceSETTLEAlgorithm* settle = dynamic_cast<ReferenceSETTLEAlgorithm*>(constraints.settle);
+        if (settle != NULL)
+            for (int i = 0; i < settle->getNumClusters(); i++) {
+                int a, b, c2; double d1, d2;
+                settle->getClusterParameters(i, a, b, c2, d1, d2);
+                isSettle[a] = isSettle[b] = isSettle[c2] = 1;
+            }
+        int n = 0;
+        for (int i = 0; i < system.getNumConstraints(); i++) {
+            int a, b; double d;
+            system.getConstraintParameters(i, a, b, d);
+            if (isSettle[a]) continue;
+            if (n < constraintCapacity) { constraintAtoms[2 * n] = a; constraintAtoms[2 * n + 1] = b; }
+            n++;
+        }
+        *numConstraints = n;
+        int count = 0;
+        const auto& m = ccma->getMatrix();
+        for (int i = 0; i < (int) m.size(); i++)
+            for (const auto& e : m[i]) {
+                if (count < capacity) { rows[count] = i; cols[count] = e.first; values[count] = e.second; }
+                count++;
+            }
+        return count;
     } catch (const std::exception& e) { lastError = e.what(); return -1; }
 }
 
@@ -246,6 +286,7 @@ int omm_context_set_velocities(void* c, int n, const double* xyz) {
 int omm_context_set_velocities_to_temperature(void* c, double temperature, int seed) { GUARD(((Context*) c)->setVelocitiesToTemperature(temperature, seed)) }
 int omm_context_set_box(void* c, const double* b) { GUARD(((Context*) c)->setPeriodicBoxVectors(Vec3(b[0], b[1], b[2]), Vec3(b[3], b[4], b[5]), Vec3(b[6], b[7], b[8]))) }
 int omm_context_apply_constraints(void* c, double tol) { GUARD(((Context*) c)->applyConstraints(tol)) }
+int omm_context_apply_velocity_constraints(void* c, double tol) { GUARD(((Context*) c)->applyVelocityConstraints(tol)) }
 int omm_context_set_parameter(void* c, const char* name, double v) { GUARD(((Context*) c)->setParameter(name, v)) }
 int omm_context_minimize(void* c, double tolerance, int maxIterations) { GUARD(LocalEnergyMinimizer::minimize(*(Context*) c, tolerance, maxIterations)) }
 int omm_context_reinitialize(void* c, int preserveState) { GUARD(((Context*) c)->reinitialize(preserveState != 0)) }

@@ -621,7 +621,6 @@ __global__ __launch_bounds__(128) void k_ccma_delta(CcmaArgs a) {
     const V3 rp = xyz(a.target[at.x]) - xyz(a.target[at.y]);
     const double reduced = 0.5 / (a.velMass[at.x].w + a.velMass[at.y].w);
     double delta;
-    bool ok;
     if (a.velocities) {
         delta = -2.0 * reduced * dot(rp, r) / dot(r, r);
         ok = fabs(delta) <= a.tol;

@@ -208,6 +208,12 @@ HipConstraints::HipConstraints(const System& system, HipPlatform::PlatformData& 
         ccma.converged = ccmaConverged.as<int>();
     }
 
+    {   // which algorithm got how many constraints: Context.getPlatform().getPropertyValue(context, "ConstraintPartition") (tests)
+        stringstream partition;
+        partition << "settle " << numSettle << " shake " << numShake << " ccma " << numCcma;
+        data.propertyValues[HipPlatform::HipConstraintPartition()] = partition.str();
+    }
+
     // ---- integration units of the fused step: waters, SHAKE clusters, then every remaining atom on its own
     numUnits = 0;
     totalMass = 0;

@@ -212,11 +212,13 @@ HipPlatform::HipPlatform() {
     platformProperties.push_back(HipDeterministicForces());
     platformProperties.push_back(HipDisablePmeStream());
     platformProperties.push_back(HipIntegrationMode());
+    platformProperties.push_back(HipConstraintPartition());
     platformProperties.push_back(HipRanks());
     platformProperties.push_back(HipRank());
     platformProperties.push_back(HipCommId());
     setPropertyDefaultValue(HipRanks(), "1");
     setPropertyDefaultValue(HipIntegrationMode(), "");
+    setPropertyDefaultValue(HipConstraintPartition(), "");
     setPropertyDefaultValue(HipRank(), "0");
     setPropertyDefaultValue(HipCommId(), "");
     setPropertyDefaultValue(HipDeviceIndex(), "");

@@ -42,6 +42,8 @@ public:
     static const std::string& HipDisablePmeStream() { static const std::string key = "DisablePmeStream"; return key; }
     /** Read-only: "device" (native integrator, state in HBM), "device, custom integrator" or "host" (Reference integration kernels; see HipPlatform.cpp). */
     static const std::string& HipIntegrationMode() { static const std::string key = "IntegrationMode"; return key; }
+    /** read-only, filled when the Context's constraints are first needed: "settle <clusters> shake <clusters> ccma <constraints>" */
+    static const std::string& HipConstraintPartition() { static const std::string key = "ConstraintPartition"; return key; }
     /** One box on several GPUs, one process per GPU: "Ranks" = number of processes, "Rank" = this one's index, "CommId" = the
      *  ncclUniqueId (hex) created with ommhip_comm_unique_id() on rank 0 and distributed by the launcher, or
      *  "callback:<address of an ommhip_host_all_gather_fn>:<user pointer>" for the host-staged test transport. */

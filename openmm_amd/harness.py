@@ -555,6 +555,9 @@ class Context:
     def applyConstraints(self, tol):
         _check(lib().omm_context_apply_constraints(self.h, C.c_double(tol)))
 
+    def applyVelocityConstraints(self, tol):
+        _check(lib().omm_context_apply_velocity_constraints(self.h, C.c_double(tol)))
+
     def getState(self, getPositions=False, getVelocities=False, getForces=False, getEnergy=False, groups=-1):
         flags = (1 if getPositions else 0) | (2 if getVelocities else 0) | (4 if getForces else 0) | (8 if getEnergy else 0)
         pos = np.zeros((self.n, 3)) if getPositions else np.zeros((1, 3))

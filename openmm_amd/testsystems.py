@@ -581,3 +581,18 @@ def dhfr_like(seed=1, n_side=22, chain_atoms=2489, relaxed=True, L=6.223, n_targ
     if relaxed:
         _load_fixture(w, "dhfr_like_seed%d_equilibrated.npz" % seed)
     return w
+
+
+def constraint_zoo(seed=5, ccma_heavy=24):
+    """Every constraint algorithm of the platform in one System: the solvated chain of
+    `small_solvated_chain` -- rigid waters (SETTLE), X-H clusters (SHAKE) -- with the first `ccma_heavy` heavy-atom bonds of the chain
+    constrained as well (an "AllBonds" stretch: those atoms and their hydrogens form one connected constraint graph, which the
+    Reference platform and this one hand to CCMA; its coupling matrix takes the angles from the HarmonicAngleForce)."""
+    w = small_solvated_chain(seed=seed)
+    hv, hv_len, hv_k = w.bonds
+    take = np.arange(len(hv)) < ccma_heavy
+    w.constraints = (np.concatenate([w.constraints[0], hv[take]]), np.concatenate([w.constraints[1], hv_len[take]]))
+    w.bonds = (hv[~take], hv_len[~take], hv_k[~take])
+    w.name = "constraint-zoo-%d" % w.num_atoms
+    w.cm_remover = False
+    return w

@@ -684,3 +684,123 @@ def run_vm_angles(K, n=150, n_angles=400, seed=6):
     K.forces_to_atom_order(force_d, slot_d, n, padded, out_d, None)
     K.stream_sync(None)
     return K.download(out_d, (n, 3), np.float64), K.download(e_d, (64,), np.float64).sum(), OV.forces(energy, pos, h=1e-6), energy(pos).sum()
+
+
+def _zoo_partition():
+    """The constraint zoo (openmm_amd/testsystems.py::constraint_zoo) cut up as the platform cuts it: SETTLE waters, SHAKE clusters
+    (a centre whose 1-3 satellites carry no other constraint), everything else to CCMA -- here computed in numpy from the constraint
+    graph, independently of both the plugin and the Reference platform."""
+    from openmm_amd import testsystems as T
+    w = T.constraint_zoo()
+    pairs, dist = np.asarray(w.constraints[0], np.int64), np.asarray(w.constraints[1], np.float64)
+    n = w.num_atoms
+    degree = np.bincount(pairs.reshape(-1), minlength=n)
+    first_water = 150
+    water = (pairs[:, 0] >= first_water)
+    o = np.arange(first_water, n, 3)
+    settle = np.stack([o, o + 1, o + 2], 1).astype(np.int32)
+    # solute: satellites = atoms of degree 1 whose partner... a cluster is SHAKE-able when the centre's constraints all end in degree-1 atoms
+    nbr = [[] for _ in range(n)]
+    for (a, b), d in zip(pairs[~water], dist[~water]):
+        nbr[a].append((int(b), d)); nbr[b].append((int(a), d))
+    shake_atoms, shake_dist, in_shake = [], [], np.zeros(n, bool)
+    for c in range(first_water):
+        if degree[c] == 0 or in_shake[c]:
+            continue
+        if all(degree[s] == 1 for s, _ in nbr[c]) and len(nbr[c]) <= 3 and (degree[c] > 1 or w.masses[c] > w.masses[nbr[c][0][0]]):
+            sats = nbr[c]
+            shake_atoms.append([c] + [s for s, _ in sats] + [-1] * (3 - len(sats)))
+            shake_dist.append([d for _, d in sats] + [0.0] * (4 - len(sats)))
+            in_shake[[c] + [s for s, _ in sats]] = True
+    ccma_rows = [k for k, (a, b) in enumerate(pairs) if not water[k] and not in_shake[a] and not in_shake[b]]
+    assert all(in_shake[a] == in_shake[b] for a, b in pairs[~water])
+    return w, settle, np.array(shake_atoms, np.int32), np.array(shake_dist), pairs[ccma_rows].astype(np.int32), dist[ccma_rows]
+
+
+def run_constraints(K, velocities, seed=8, tol=1e-9):
+    """ommhip_settle, ommhip_shake and ommhip_ccma_iterations through the C ABI on the constraint zoo against oracle/constraints.py
+    (pinned to the Reference platform by tests/test_oracle_constraints.py).  Positions: a Verlet drift of ~300 K velocities from
+    constrained positions (distinct before / trial arrays); velocities: random velocities projected.
+    -> dict of (got, oracle) per algorithm + the CCMA iteration counts (device, oracle)."""
+    from oracle import constraints as OC
+    w, settle, shake_atoms, shake_dist, cc, cd = _zoo_partition()
+    rng = np.random.default_rng(seed)
+    n = w.num_atoms
+    inv = 1.0 / w.masses
+    angles = [(int(a), int(b), int(c), float(t)) for (a, b, c), t in zip(w.angles[0], w.angles[1])]
+    Kmat = OC.ccma_matrix(n, cc, cd, w.masses, angles)
+    # constrained start (the oracle's own solution of the builder's coordinates)
+    t3 = T3 = None
+    d_leg, d_base = w.constraints[1][-3], w.constraints[1][-1]
+    pos, _ = OC.ccma(w.positions, w.positions, inv, cc, cd, Kmat, 1e-12)
+    pos = OC.shake(pos, pos, inv, shake_atoms, shake_dist, 1e-12)
+    pos = OC.settle_positions(pos, pos, w.masses, settle, d_leg, d_base)
+    vel = rng.normal(0, 1.6, (n, 3)) * np.sqrt(inv)[:, None]
+    target = vel if velocities else pos + 0.002 * vel
+    pos4 = np.zeros((n, 4)); pos4[:, :3] = pos
+    vm4 = np.zeros((n, 4)); vm4[:, 3] = inv
+    t4 = np.zeros((n, 4)); t4[:, :3] = target; t4[:, 3] = inv if velocities else 0.0
+    d_pos, d_vm = K.upload(pos4), K.upload(vm4)
+    out = {}
+    # SETTLE
+    sa = np.full((len(settle), 4), -1, np.int32); sa[:, :3] = settle
+    sd = np.tile([d_leg, d_base], (len(settle), 1))
+    d_t = K.upload(t4)
+    K.settle(len(settle), K.upload(sa), K.upload(sd), d_pos, d_t, d_vm, int(velocities), None)
+    K.stream_sync(None)
+    got = K.download(d_t, (n, 4), np.float64)
+    want = OC.settle_velocities(pos, target, w.masses, settle) if velocities else OC.settle_positions(pos, target, w.masses, settle, d_leg, d_base)
+    assert np.array_equal(got[:, 3], t4[:, 3])
+    out["settle"] = (got[:, :3], want)
+    # SHAKE
+    d_t = K.upload(t4)
+    K.shake(len(shake_atoms), K.upload(shake_atoms), K.upload(shake_dist), d_pos, d_t, d_vm, int(velocities), tol, 150, None)
+    K.stream_sync(None)
+    out["shake"] = (K.download(d_t, (n, 4), np.float64)[:, :3], OC.shake(pos, target, inv, shake_atoms, shake_dist, tol, velocities=velocities))
+    # CCMA, device-resident batches as HipConstraints::runCcma drives them
+    rows = [np.nonzero(Kmat[r])[0] for r in range(len(cc))]
+    row_start = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    col = np.concatenate(rows).astype(np.int32)
+    val = np.concatenate([Kmat[r, rows[r]] for r in range(len(cc))])
+    c = capi.Ccma()
+    c.num_constraints = len(cc)
+    c.atoms, c.distance = K.upload(cc), K.upload(cd)
+    c.delta, c.delta2 = K.upload(np.zeros(len(cc))), K.upload(np.zeros(len(cc)))
+    c.row_start, c.col, c.value = K.upload(row_start), K.upload(col), K.upload(val)
+    c.converged = K.upload(np.zeros(4, np.int32))
+    d_t = K.upload(t4)
+    batches = 0
+    while batches < 40:
+        K.ccma_iterations(C.byref(c), d_pos, d_t, d_vm, int(velocities), tol, 4, None)
+        K.stream_sync(None)
+        batches += 1
+        state = K.download(c.converged, (4,), np.int32)
+        if state[2]:
+            break
+    want, iterations = OC.ccma(pos, target, inv, cc, cd, Kmat, tol, velocities=velocities)
+    out["ccma"] = (K.download(d_t, (n, 4), np.float64)[:, :3], want)
+    out["ccma_iterations"] = (int(state[3]), iterations, int(state[2]))
+    out["scale"] = float(np.abs(target).max())
+    return out
+
+
+def run_ewald_reciprocal(K, n=300, L=2.4, seed=12, kmax=(9, 11, 7)):
+    """ommhip_ewald_reciprocal (classic Ewald k-sum, rectangular box) against oracle.nonbonded.ewald_reciprocal (pinned to the Reference
+    platform and the Gromacs golden of TestEwald.h).  -> (forces, energy, oracle forces, oracle energy)"""
+    rng = np.random.default_rng(seed)
+    box3 = np.diag([L, 1.1 * L, 0.9 * L])
+    pos = rng.random((n, 3)) @ box3 + rng.integers(-1, 2, (n, 3)) @ box3       # some atoms outside the first cell
+    q = rng.normal(0, 0.6, n); q -= q.mean()
+    alpha = 3.1
+    padded = (n + 31) // 32 * 32 + 32
+    perm = rng.permutation(padded)[:n].astype(np.int32)
+    pos4 = np.zeros((n, 4)); pos4[:, :3] = pos
+    numk = kmax[0] * (2 * kmax[1] - 1) * (2 * kmax[2] - 1)
+    d_f, d_e, d_out = K.upload(np.zeros(3 * padded, np.int64)), K.upload(np.zeros(64)), K.upload(np.zeros(3 * n))
+    d_slot = K.upload(perm)
+    K.ewald_reciprocal(K.upload(pos4), K.upload(q), d_slot, n, padded, box6(box3), alpha, kmax[0], kmax[1], kmax[2], K.upload(np.zeros((numk, 2))),
+                       d_f, d_e, 64, 1, None)
+    K.forces_to_atom_order(d_f, d_slot, n, padded, d_out, None)
+    K.stream_sync(None)
+    f_or, e_or = ONB.ewald_reciprocal(pos, q, box3, alpha, kmax)
+    return K.download(d_out, (n, 3), np.float64), K.download(d_e, (64,), np.float64).sum(), f_or, e_or

@@ -220,3 +220,31 @@ def test_interpreted_custom_bond_force_through_the_c_abi(K):
     assert abs(e - e_or) < 1e-11 * abs(e_or), (e, e_or)
     assert np.abs(f - f_or).max() < 1e-6 * np.abs(f_or).max(), (np.abs(f - f_or).max(), np.abs(f_or).max())
 
+
+
+@pytest.mark.parametrize("velocities", [False, True])
+def test_settle_shake_and_ccma_through_the_c_abi(K, velocities):
+    """ommhip_settle / ommhip_shake / ommhip_ccma_iterations against oracle/constraints.py (itself pinned to
+    ReferenceSETTLEAlgorithm / ReferenceCCMAAlgorithm through the Reference platform, tests/test_oracle_constraints.py) on the constraint
+    zoo, positions (distinct before / trial arrays, as inside a step) and velocities.  SETTLE is analytic: 1e-12 of the coordinates;
+    the iterative ones stop inside the same tolerance band as the oracle, CCMA after the same number of iterations."""
+    out = KC.run_constraints(K, velocities)
+    scale = out["scale"]
+    got, want = out["settle"]
+    assert np.abs(got - want).max() < 1e-12 * scale
+    got, want = out["shake"]
+    assert np.abs(got - want).max() < 1e-12 * scale         # same Gauss-Seidel order, same stopping rule: the same numbers
+    got, want = out["ccma"]
+    device_iterations, oracle_iterations, converged = out["ccma_iterations"]
+    assert converged == 1, "the device never announced convergence"
+    assert np.abs(got - want).max() < 1e-11 * scale          # float atomics add the corrections of one atom in another order
+    # the device counts every delta kernel it ran up to and including the one that found everything converged
+    assert device_iterations == oracle_iterations + 1, (device_iterations, oracle_iterations)
+
+
+def test_ewald_reciprocal_sum_through_the_c_abi(K):
+    """ommhip_ewald_reciprocal against the numpy k-sum (pinned to the Reference platform and TestEwald.h's Gromacs
+    golden): forces to 1e-9 of the largest (fixed-point quantum 2^-32), energy 1e-12."""
+    f, e, f_or, e_or = KC.run_ewald_reciprocal(K)
+    assert abs(e - e_or) < 1e-11 * abs(e_or), (e, e_or)
+    assert np.abs(f - f_or).max() < 1e-9 * np.abs(f_or).max(), (np.abs(f - f_or).max(), np.abs(f_or).max())

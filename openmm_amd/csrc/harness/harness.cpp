@@ -8,6 +8,7 @@
 #include "ReferenceConstraints.h"
 #include "ReferenceSETTLEAlgorithm.h"
 #include "ReferenceCCMAAlgorithm.h"
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <sstream>
@@ -287,6 +288,25 @@ int omm_context_set_velocities_to_temperature(void* c, double temperature, int s
 int omm_context_set_box(void* c, const double* b) { GUARD(((Context*) c)->setPeriodicBoxVectors(Vec3(b[0], b[1], b[2]), Vec3(b[3], b[4], b[5]), Vec3(b[6], b[7], b[8]))) }
 int omm_context_apply_constraints(void* c, double tol) { GUARD(((Context*) c)->applyConstraints(tol)) }
 int omm_context_apply_velocity_constraints(void* c, double tol) { GUARD(((Context*) c)->applyVelocityConstraints(tol)) }
+/* Context::createCheckpoint / loadCheckpoint (openmmapi/include/openmm/Context.h): the blob is returned through a malloc'ed buffer the
+ * caller hands back to omm_free. */
+int omm_context_create_checkpoint(void* c, char** blob, long* size) {
+    GUARD(
+        std::stringstream stream(std::ios_base::out | std::ios_base::in | std::ios_base::binary);
+        ((Context*) c)->createCheckpoint(stream);
+        const std::string data = stream.str();
+        *size = (long) data.size();
+        *blob = (char*) malloc(data.size() > 0 ? data.size() : 1);
+        memcpy(*blob, data.data(), data.size());
+    )
+}
+int omm_context_load_checkpoint(void* c, const char* blob, long size) {
+    GUARD(
+        std::stringstream stream(std::string(blob, (size_t) size), std::ios_base::out | std::ios_base::in | std::ios_base::binary);
+        ((Context*) c)->loadCheckpoint(stream);
+    )
+}
+void omm_free(void* p) { free(p); }
 int omm_context_set_parameter(void* c, const char* name, double v) { GUARD(((Context*) c)->setParameter(name, v)) }
 int omm_context_minimize(void* c, double tolerance, int maxIterations) { GUARD(LocalEnergyMinimizer::minimize(*(Context*) c, tolerance, maxIterations)) }
 int omm_context_reinitialize(void* c, int preserveState) { GUARD(((Context*) c)->reinitialize(preserveState != 0)) }

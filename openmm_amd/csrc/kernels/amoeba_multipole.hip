@@ -1476,7 +1476,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st) {
     double* w = mp->solver;
     double* sums = w + 8 * n3;
     double* tD = w + 6 * n3; double* tP = w + 7 * n3; double* pD = w + 4 * n3; double* pP = w + 5 * n3;
-    double h[16];
+    double h[16] = {0};
     auto readSums = [&]() -> int { hipError_t e = hipMemcpyAsync(h, sums, sizeof(double) * 16, hipMemcpyDeviceToHost, st); if (e != hipSuccess) return (int) e; return (int) hipStreamSynchronize(st); };
     const bool haveHistory = mp->history != nullptr && mp->history_slots >= 1;
     const int use = haveHistory ? (mp->history_use < 0 ? 0 : (mp->history_use > OMMHIP_AMOEBA_MAX_HISTORY ? OMMHIP_AMOEBA_MAX_HISTORY : (mp->history_use > mp->history_slots ? mp->history_slots : mp->history_use))) : 0;
@@ -1523,6 +1523,8 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st) {
         enqueued++;
         if (enqueued >= unchecked || enqueued == mp->max_iterations) { rc = readSums(); if (rc != 0) return rc; done = h[10] != 0.0; }
     }
+    // nothing read yet (expected_iterations > 1 with max_iterations <= 0: the loop never ran): the first guess may already be converged
+    if (unchecked != 0 && enqueued == 0) { rc = readSums(); if (rc != 0) return rc; done = h[10] != 0.0; }
     a.doneFlag = nullptr;
     const double epsilon = h[12];
     const int iterations = (int) h[11];

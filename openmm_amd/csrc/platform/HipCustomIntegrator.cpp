@@ -33,9 +33,30 @@ bool treeIsTranslatable(const ExpressionTreeNode& node) {
     return true;
 }
 
+// Stack slots the postfix program of a tree needs (the count emit() arrives at): the children are evaluated left to right, child i
+// while i results are already waiting.
+int treeStackDepth(const ExpressionTreeNode& node) {
+    int need = 1;
+    for (size_t i = 0; i < node.getChildren().size(); i++)
+        need = max(need, (int) i + treeStackDepth(node.getChildren()[i]));
+    return need;
+}
+
 bool expressionIsTranslatable(const string& expression) {
-    try { return treeIsTranslatable(Parser::parse(expression).getRootNode()); }
+    try {
+        const ParsedExpression parsed = Parser::parse(expression);
+        // deeper than the interpreter's stack: host mode (the Reference kernel), not an exception at the first step.  An unknown variable
+        // is not looked for here: the Reference kernel rejects it as well.
+        return treeIsTranslatable(parsed.getRootNode()) && treeStackDepth(parsed.getRootNode()) <= OMMHIP_VM_STACK;
+    }
     catch (...) { return false; }      // an unknown function: tabulated, vector-valued, deriv()
+}
+
+bool treeUsesVariable(const ExpressionTreeNode& node, const string& name) {
+    if (node.getOperation().getId() == Operation::VARIABLE && node.getOperation().getName() == name) return true;
+    for (size_t i = 0; i < node.getChildren().size(); i++)
+        if (treeUsesVariable(node.getChildren()[i], name)) return true;
+    return false;
 }
 }  // namespace
 
@@ -67,10 +88,13 @@ void HipIntegrateCustomStepKernel::initialize(const System& system, const Custom
     numAtoms = system.getNumParticles();
     numPerDof = integrator.getNumPerDofVariables();
     numIntegratorGlobals = integrator.getNumGlobalVariables();
+    // The per-DOF noise is a pure function of (data.integratorSeed, data.customDraws, atom): both words travel in a checkpoint
+    // (HipUpdateStateDataKernel::createCheckpoint), so a restart -- in this Context or another -- continues the stream.  The random numbers of
+    // ComputeGlobal steps come from the host generator of the Reference platform, whose state the checkpoint carries as well.
     const int s = integrator.getRandomNumberSeed();
-    seed = s == 0 ? (unsigned long long) osrngseed() : (unsigned long long) (unsigned int) s;
-    SimTKOpenMMUtilities::setRandomNumberSeed((unsigned int) seed);          // the random numbers of ComputeGlobal steps are drawn on the host
-    data.integratorSeed = seed;
+    data.integratorSeed = s == 0 ? (unsigned long long) osrngseed() : (unsigned long long) (unsigned int) s;
+    data.customDraws = 0;
+    SimTKOpenMMUtilities::setRandomNumberSeed((unsigned int) data.integratorSeed);
     HipContext& hip = *data.hip;
     hip.setAsCurrent();
     perDofD.allocate(max((size_t) 16, sizeof(double) * 3 * numAtoms * max(numPerDof, 1)));
@@ -231,8 +255,13 @@ double HipIntegrateCustomStepKernel::evaluateOnHost(const ParsedExpression& expr
     for (size_t g = 0; g < globalNames.size(); g++) variables[globalNames[g]] = globalValues[g];
     variables["energy"] = energy;
     for (int i = 0; i < 32; i++) { stringstream name; name << "energy" << i; variables[name.str()] = energy; }
-    variables["uniform"] = SimTKOpenMMUtilities::getUniformlyDistributedRandomNumber();
-    variables["gaussian"] = SimTKOpenMMUtilities::getNormallyDistributedRandomNumber();
+    // drawn only when asked for (ReferenceCustomDynamics binds them lazily too): the host sequence stays the Reference kernel's
+    map<const ParsedExpression*, int>::iterator uses = hostRandomUse.find(&expression);
+    if (uses == hostRandomUse.end())
+        uses = hostRandomUse.insert(make_pair(&expression, (treeUsesVariable(expression.getRootNode(), "uniform") ? 1 : 0) |
+                                                              (treeUsesVariable(expression.getRootNode(), "gaussian") ? 2 : 0))).first;
+    if (uses->second & 1) variables["uniform"] = SimTKOpenMMUtilities::getUniformlyDistributedRandomNumber();
+    if (uses->second & 2) variables["gaussian"] = SimTKOpenMMUtilities::getNormallyDistributedRandomNumber();
     return expression.evaluate(variables);
 }
 
@@ -242,7 +271,7 @@ ommhip_vm_state HipIntegrateCustomStepKernel::vmState() {
     s.num_atoms = numAtoms; s.num_per_dof = numPerDof;
     s.pos = hip.pos.ptr; s.vel = hip.vel.ptr; s.per_dof = perDofD.as<double>();
     s.globals = globalsD.as<double>(); s.program = programD.as<ommhip_vm_instruction>();
-    s.seed = seed; s.sum_scratch = sumScratchD.as<double>(); s.sum_result = sumResultD.as<double>();
+    s.seed = data.integratorSeed; s.sum_scratch = sumScratchD.as<double>(); s.sum_result = sumResultD.as<double>();
     return s;
 }
 
@@ -265,7 +294,9 @@ void HipIntegrateCustomStepKernel::ensureForces(ContextImpl& context, int flags,
         // wait for the host on their own (ommhip_integrator_state::freeze_state); here the host looks at once -- a synchronisation per
         // evaluation, only for Systems with a NonbondedForce -- and evaluates again with the list the recovery has grown
         if (hip.listRecovery) hip.listRecovery();
-        if (hip.overflowRecoveries == recoveriesBefore || attempt == 4) break;
+        if (hip.overflowRecoveries == recoveriesBefore) break;
+        if (attempt == 4)
+            throw OpenMMException("HIP platform: the neighbour list overflowed at five evaluations in a row of one CustomIntegrator step; the forces would be incomplete");
     }
     hip.pendingReplay = 0;
     if (computeForces) {
@@ -283,7 +314,7 @@ void HipIntegrateCustomStepKernel::enqueue(const Program& program, int target, i
     ommhip_vm_step st;
     st.first = program.first; st.count = program.count; st.target = target; st.uses_random = program.usesRandom;
     st.force = usesForces ? forceCache[flags]->as<double>() : NULL;
-    st.draw = program.usesRandom ? draws++ : 0;
+    st.draw = program.usesRandom ? data.customDraws++ : 0;
     pending.push_back(st);
 }
 

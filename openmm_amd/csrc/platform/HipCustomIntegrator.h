@@ -51,7 +51,7 @@ private:
 
     bool compiled = false;
     int numAtoms = 0, numPerDof = 0, numIntegratorGlobals = 0;
-    unsigned long long seed = 0, draws = 0;
+    std::map<const Lepton::ParsedExpression*, int> hostRandomUse;      // bit 0: the expression reads `uniform`, bit 1: `gaussian`
     // the integrator's definition, analysed (CustomIntegratorUtilities::analyzeComputations)
     std::vector<CustomIntegrator::ComputationType> stepType;
     std::vector<std::string> stepVariable, perDofNames;

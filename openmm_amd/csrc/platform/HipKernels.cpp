@@ -3,6 +3,7 @@
 #include "ReferenceCCMAAlgorithm.h"
 #include "ReferenceVirtualSites.h"
 #include "SimTKOpenMMRealType.h"
+#include "SimTKOpenMMUtilities.h"
 #include "openmm/CMMotionRemover.h"
 #include "openmm/HarmonicAngleForce.h"
 #include "openmm/HarmonicBondForce.h"
@@ -481,11 +482,15 @@ void HipUpdateStateDataKernel::createCheckpoint(ContextImpl& context, ostream& s
     // same content as ReferenceUpdateStateDataKernel::createCheckpoint (ReferenceKernels.cpp:282-294).  The thermostat noise is a
     // pure function of (seed, stepCount, atom): instead of a generator state the checkpoint carries the resolved seed, so a run
     // restarted in another Context or process (where seed 0 would resolve differently) continues the same noise stream.
-    int version = 2;
+    // Version 3 adds what a CustomIntegrator's noise hangs on: the draw counter of its device computations and the state of the host
+    // generator its ComputeGlobal steps (and the barostat, and Reference kernels in host mode) draw from -- the last item is what
+    // ReferenceUpdateStateDataKernel::createCheckpoint saves too.
+    int version = 3;
     stream.write((char*) &version, sizeof(int));
     stream.write((char*) &data.time, sizeof(double));
     stream.write((char*) &data.stepCount, sizeof(int));
     stream.write((char*) &data.integratorSeed, sizeof(unsigned long long));
+    stream.write((char*) &data.customDraws, sizeof(unsigned long long));
     vector<Vec3> pos, vel;
     data.hip->downloadPositions(pos);
     data.hip->downloadVelocities(vel);
@@ -494,20 +499,23 @@ void HipUpdateStateDataKernel::createCheckpoint(ContextImpl& context, ostream& s
     Vec3 box[3];
     data.hip->getBox(box[0], box[1], box[2]);
     stream.write((char*) box, 3 * sizeof(Vec3));
+    SimTKOpenMMUtilities::createCheckpoint(stream);
 }
 void HipUpdateStateDataKernel::loadCheckpoint(ContextImpl& context, istream& stream) {
     int version;
     stream.read((char*) &version, sizeof(int));
-    if (version != 2) throw OpenMMException("Checkpoint was created with a different version of OpenMM");
+    if (version != 2 && version != 3) throw OpenMMException("Checkpoint was created with a different version of OpenMM");
     stream.read((char*) &data.time, sizeof(double));
     stream.read((char*) &data.stepCount, sizeof(int));
     stream.read((char*) &data.integratorSeed, sizeof(unsigned long long));
+    if (version >= 3) stream.read((char*) &data.customDraws, sizeof(unsigned long long));
     vector<Vec3> pos(data.hip->numAtoms), vel(data.hip->numAtoms);
     stream.read((char*) pos.data(), sizeof(Vec3) * pos.size());
     stream.read((char*) vel.data(), sizeof(Vec3) * vel.size());
     Vec3 box[3];
     stream.read((char*) box, 3 * sizeof(Vec3));
     if (!stream.good()) throw OpenMMException("HIP platform: the checkpoint is truncated");
+    if (version >= 3) SimTKOpenMMUtilities::loadCheckpoint(stream);
     setPeriodicBoxVectors(context, box[0], box[1], box[2]);
     setPositions(context, pos);
     setVelocities(context, vel);

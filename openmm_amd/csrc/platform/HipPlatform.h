@@ -76,6 +76,7 @@ public:
     const System* system;
     bool referenceNonbonded;
     unsigned long long integratorSeed;      // resolved seed of the Langevin thermostat noise (part of a checkpoint)
+    unsigned long long customDraws = 0;     // random per-DOF computations a device CustomIntegrator has issued so far: the counter its noise is keyed by (part of a checkpoint)
     std::map<std::string, std::string> propertyValues;
 private:
     HipConstraints* deviceConstraints;

@@ -555,6 +555,16 @@ class Context:
     def applyConstraints(self, tol):
         _check(lib().omm_context_apply_constraints(self.h, C.c_double(tol)))
 
+    def createCheckpoint(self):
+        blob, size = C.c_void_p(), C.c_long(0)
+        _check(lib().omm_context_create_checkpoint(self.h, C.byref(blob), C.byref(size)))
+        data = C.string_at(blob, size.value)
+        lib().omm_free(blob)
+        return data
+
+    def loadCheckpoint(self, data):
+        _check(lib().omm_context_load_checkpoint(self.h, C.c_char_p(data), C.c_long(len(data))))
+
     def applyVelocityConstraints(self, tol):
         _check(lib().omm_context_apply_velocity_constraints(self.h, C.c_double(tol)))
 

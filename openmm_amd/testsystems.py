@@ -596,3 +596,20 @@ def constraint_zoo(seed=5, ccma_heavy=24):
     w.name = "constraint-zoo-%d" % w.num_atoms
     w.cm_remover = False
     return w
+
+
+def nacl_amorph():
+    """The amorphous NaCl system of the reference's tests/TestEwald.h:98-220 (894 ions, Ewald summation, tolerance 1e-5) from the
+    committed fixture tests/golden/nacl_amorph.npz (positions, box, cutoff and the Gromacs energy copied from that test by
+    tools/make_golden_from_reference.py)."""
+    import os
+    g = np.load(os.path.join(H.ROOT, "tests", "golden", "nacl_amorph.npz"))
+    pos = g["positions"].astype(np.float64)
+    n = len(pos)
+    w = Workload("nacl-amorph-%d" % n)
+    w.positions, w.box = pos, np.eye(3) * float(g["box"])
+    w.masses = np.concatenate([np.full(n // 2, 22.99), np.full(n // 2, 35.45)])
+    w.charge, w.sigma, w.epsilon = np.concatenate([np.ones(n // 2), -np.ones(n // 2)]), np.ones(n), np.zeros(n)
+    w.method, w.cutoff, w.ewald_tol, w.dispersion = H.Ewald, float(g["cutoff"]), float(g["ewald_tol"]), False
+    w.gromacs_energy = float(g["gromacs_energy"])
+    return w

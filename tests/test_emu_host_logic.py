@@ -690,3 +690,79 @@ def test_verlet_trajectory_with_settle_shake_and_ccma_follows_the_reference_plat
         assert r[name]["dpos"] < 1e-6 and r[name]["dvel"] < 1e-4, r[name]
         assert r[name]["ke_rel"] < 1e-6 and r[name]["constraints"] < 1e-7
         assert r[name]["times"][0] == r[name]["times"][1]
+
+
+@needs_emu
+def test_ewald_ksum_forces_on_the_reference_tests_nacl_system_within_1e_4():
+    """Row a9 at the north-star tolerance on the emulated platform: the amorphous NaCl of tests/TestEwald.h (classic Ewald k-sum) against the
+    Reference platform, every atom within 1e-4 of the RMS force (the reference body itself asserts 1e-2)."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from openmm_amd import harness as H, testsystems as T
+H.load_hip_platform(emulated=True)
+w = T.nacl_amorph()
+st = {}
+for plat in ("Reference", "HIP"):
+    system, nb = w.build()
+    ctx = H.Context(system, H.Integrator(H.VERLET, 0.001), plat)
+    ctx.setPositions(w.positions)
+    st[plat] = ctx.getState(getForces=True, getEnergy=True)
+    ctx.close()
+fr, fh = st["Reference"].forces, st["HIP"].forces
+err = np.sqrt(((fh - fr) ** 2).sum(1)).max() / np.sqrt((fr ** 2).sum(1).mean())
+assert err < 1e-4, err
+assert abs(st["HIP"].potentialEnergy - st["Reference"].potentialEnergy) < 1e-5 * abs(st["Reference"].potentialEnergy)
+print("OK", err)
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1800)
+    assert "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@needs_emu
+def test_stochastic_integrators_continue_their_noise_from_a_checkpoint(tmp_path):
+    """A device CustomIntegrator with gaussian per-DOF noise and a host-drawn global (the benchmark's MTSLangevinIntegrator plus a ComputeGlobal
+    draw) and the native LangevinMiddle integrator: 6 steps after a checkpoint are the same whether the run went on, the Context was rewound
+    to the checkpoint, or a NEW Context with seed 0 loaded it (tests/checkpoint_case.py)."""
+    from checkpoint_case import run_checkpoint_case
+    r = run_checkpoint_case(tmp_path, True)
+    print(r)
+    assert r["custom"]["mode"] == "device, custom integrator" and r["native"]["mode"] == "device"
+    for kind in ("custom", "native"):
+        # loading a checkpoint re-sorts the atoms, so float sums (grid, pair forces) come in another order: not bitwise, but far below what other noise would do (~1e-3 nm)
+        assert max(r[kind]["same"][0], r[kind]["new"][0]) < 1e-6 and max(r[kind]["same"][1], r[kind]["new"][1]) < 1e-4, r[kind]        # one step of foreign noise moves an oxygen by 5e-5 nm
+        assert r[kind]["times"][0] == r[kind]["times"][1] == r[kind]["times"][2]
+
+
+@needs_emu
+def test_custom_integrator_too_deep_for_the_interpreter_runs_in_host_mode():
+    """An expression that needs more than OMMHIP_VM_STACK slots is found when the Context is classified (HipIntegrateCustomStepKernel::supports),
+    so the integrator runs on the Reference kernel instead of throwing at its first step (ADVICE r4)."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from openmm_amd import harness as H, testsystems as T
+H.load_hip_platform(emulated=True)
+w = T.water_box(3, seed=2, cutoff=0.4, method=H.CutoffPeriodic)
+modes = []
+for depth in (8, 24):
+    s, nb = w.build()
+    integ = H.CustomIntegrator(0.001, seed=1, constraintTolerance=1e-7)
+    expr = "v"
+    for k in range(depth):
+        expr = "0+(1*(%%s))" %% expr if k %% 2 else "v*0+(%%s)" %% expr          # right-nested: one more stack slot per level
+    integ.addComputePerDof("v", "v+dt*f/m")
+    integ.addComputePerDof("x", "x+dt*(" + expr + ")")
+    integ.addConstrainPositions()
+    c = H.Context(s, integ, "HIP")
+    c.setPositions(w.positions); c.applyConstraints(1e-7)
+    integ.step(2)
+    modes.append(c.getPlatformProperty("IntegrationMode"))
+    assert np.all(np.isfinite(c.getState(getPositions=True).positions))
+    c.close()
+print("MODES", modes)
+assert modes == ["device, custom integrator", "host"], modes
+print("OK")
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -636,3 +636,36 @@ def test_verlet_trajectory_with_settle_shake_and_ccma_follows_the_reference_plat
         assert r[name]["dpos"] < 1e-6 and r[name]["dvel"] < 1e-4, r[name]
         assert r[name]["ke_rel"] < 1e-6 and r[name]["constraints"] < 1e-7
         assert r[name]["times"][0] == r[name]["times"][1]
+
+
+def test_ewald_ksum_forces_on_the_reference_tests_nacl_system_within_1e_4():
+    """SURVEY.md §8 row a9 at the north-star tolerance: the amorphous NaCl of tests/TestEwald.h (894 ions, classic Ewald k-sum, tolerance
+    1e-5) on the HIP platform against the Reference platform -- every atom within 1e-4 of the RMS force, energy 1e-5 and inside
+    TestEwald.h's own band around the Gromacs value (the reference body asserts forces at 1e-2 only)."""
+    w = T.nacl_amorph()
+    st = {}
+    for plat in ("Reference", "HIP"):
+        system, nb = w.build()
+        ctx = H.Context(system, H.Integrator(H.VERLET, 0.001), plat)
+        ctx.setPositions(w.positions)
+        st[plat] = ctx.getState(getForces=True, getEnergy=True)
+        ctx.close()
+    err = max_rel_force_error(st["HIP"].forces, st["Reference"].forces)
+    print("nacl_amorph Ewald: force max-rel-err %.3g, E %.6f / %.6f" % (err, st["HIP"].potentialEnergy, st["Reference"].potentialEnergy))
+    assert err < 1e-4
+    assert abs(st["HIP"].potentialEnergy - st["Reference"].potentialEnergy) < 1e-5 * abs(st["Reference"].potentialEnergy)
+    assert abs(st["HIP"].potentialEnergy - w.gromacs_energy) < 1e-5 * abs(w.gromacs_energy) * 2
+
+
+def test_stochastic_integrators_continue_their_noise_from_a_checkpoint(tmp_path):
+    """A device CustomIntegrator with gaussian per-DOF noise and a host-drawn global (the benchmark's MTSLangevinIntegrator plus a ComputeGlobal
+    draw) and the native LangevinMiddle integrator: 6 steps after a checkpoint are the same whether the run went on, the Context was rewound
+    to the checkpoint, or a NEW Context with seed 0 loaded it (tests/checkpoint_case.py)."""
+    from checkpoint_case import run_checkpoint_case
+    r = run_checkpoint_case(tmp_path, False, n_side=8, grid=24, cutoff=0.9)
+    print(r)
+    assert r["custom"]["mode"] == "device, custom integrator" and r["native"]["mode"] == "device"
+    for kind in ("custom", "native"):
+        # loading a checkpoint re-sorts the atoms, so float sums (grid, pair forces) come in another order: not bitwise, but far below what other noise would do (~1e-3 nm)
+        assert max(r[kind]["same"][0], r[kind]["new"][0]) < 1e-6 and max(r[kind]["same"][1], r[kind]["new"][1]) < 1e-4, r[kind]
+        assert r[kind]["times"][0] == r[kind]["times"][1] == r[kind]["times"][2]

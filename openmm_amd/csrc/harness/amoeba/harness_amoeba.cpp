@@ -4,9 +4,11 @@
  * It mirrors the API names it wraps and contains no physics.
  */
 #include "OpenMM.h"
+#include "openmm/AmoebaGeneralizedKirkwoodForce.h"
 #include "openmm/AmoebaMultipoleForce.h"
 #include "openmm/AmoebaTorsionTorsionForce.h"
 #include "openmm/AmoebaVdwForce.h"
+#include "openmm/AmoebaWcaDispersionForce.h"
 #include <string>
 #include <vector>
 
@@ -91,6 +93,34 @@ void* omm_amoeba_vdw_create(void* system, const char* sigmaRule, const char* eps
 
 int omm_amoeba_vdw_add(void* f, int n, const int* parent, const double* sigma, const double* epsilon, const double* reduction) {
     GUARD(for (int i = 0; i < n; i++) ((AmoebaVdwForce*) f)->addParticle(parent[i], sigma[i], epsilon[i], reduction[i]))
+}
+
+/* AmoebaGeneralizedKirkwoodForce (plugins/amoeba/openmmapi/include/openmm/AmoebaGeneralizedKirkwoodForce.h) */
+void* omm_amoeba_gk_create(void* system, int n, const double* charge, const double* radius, const double* scale, double solventDielectric, double soluteDielectric,
+                           int includeCavityTerm, double probeRadius, double surfaceAreaFactor) {
+    try {
+        AmoebaGeneralizedKirkwoodForce* f = new AmoebaGeneralizedKirkwoodForce();
+        f->setSolventDielectric(solventDielectric);
+        f->setSoluteDielectric(soluteDielectric);
+        f->setIncludeCavityTerm(includeCavityTerm);
+        f->setProbeRadius(probeRadius);
+        f->setSurfaceAreaFactor(surfaceAreaFactor);
+        for (int i = 0; i < n; i++) f->addParticle(charge[i], radius[i], scale[i]);
+        ((System*) system)->addForce(f);
+        return f;
+    } catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
+
+/* AmoebaWcaDispersionForce (plugins/amoeba/openmmapi/include/openmm/AmoebaWcaDispersionForce.h); globals = (epso, epsh, rmino, rminh, awater, slevy, dispoff, shctd) */
+void* omm_amoeba_wca_create(void* system, int n, const double* radius, const double* epsilon, const double* globals) {
+    try {
+        AmoebaWcaDispersionForce* f = new AmoebaWcaDispersionForce();
+        f->setEpso(globals[0]); f->setEpsh(globals[1]); f->setRmino(globals[2]); f->setRminh(globals[3]);
+        f->setAwater(globals[4]); f->setSlevy(globals[5]); f->setDispoff(globals[6]); f->setShctd(globals[7]);
+        for (int i = 0; i < n; i++) f->addParticle(radius[i], epsilon[i]);
+        ((System*) system)->addForce(f);
+        return f;
+    } catch (const std::exception& e) { lastError = e.what(); return NULL; }
 }
 
 /* CSR: the exclusions of atom i are list[start[i] .. start[i + 1]) */

@@ -5,6 +5,7 @@
  * It mirrors the public API names it wraps (openmmapi/include/openmm/*.h); it contains no physics.
  */
 #include "OpenMM.h"
+#include "openmm/serialization/XmlSerializer.h"
 #include "ReferenceConstraints.h"
 #include "ReferenceSETTLEAlgorithm.h"
 #include "ReferenceCCMAAlgorithm.h"
@@ -41,6 +42,25 @@ int omm_system_num_particles(void* s) { return ((System*) s)->getNumParticles();
 int omm_system_set_box(void* s, const double* b) { GUARD(((System*) s)->setDefaultPeriodicBoxVectors(Vec3(b[0], b[1], b[2]), Vec3(b[3], b[4], b[5]), Vec3(b[6], b[7], b[8]))) }
 int omm_system_add_constraints(void* s, int n, const int* pairs, const double* dist) { GUARD(for (int i = 0; i < n; i++) ((System*) s)->addConstraint(pairs[2 * i], pairs[2 * i + 1], dist[i])) }
 int omm_system_num_constraints(void* s) { return ((System*) s)->getNumConstraints(); }
+
+/* XmlSerializer::deserialize<System> / serialize (serialization/include/openmm/serialization/XmlSerializer.h:60-76) */
+void* omm_system_from_xml(const char* text) {
+    try {
+        std::stringstream in(text);
+        return XmlSerializer::deserialize<System>(in);
+    } catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
+int omm_system_to_xml(void* s, char** text, long* size) {
+    GUARD(
+        std::stringstream out;
+        XmlSerializer::serialize<System>((System*) s, "System", out);
+        const std::string data = out.str();
+        *size = (long) data.size();
+        *text = (char*) malloc(data.size() + 1);
+        memcpy(*text, data.c_str(), data.size() + 1);
+    )
+}
+int omm_system_num_forces(void* s) { return ((System*) s)->getNumForces(); }
 
 /* The SETTLE clusters the Reference platform finds in a System (ReferenceConstraints.cpp:44-148): the checker of the HIP platform's
  * own partition (tests only).  Returns the number of clusters; fills at most `capacity`: atoms[3i..], dist[2i..]. */
@@ -192,6 +212,18 @@ void* omm_add_custom_compound_bond_force(void* s, int particlesPerBond, const ch
 }
 int omm_force_set_name(void* f, const char* name) { GUARD(((Force*) f)->setName(name)) }
 
+void* omm_add_gbsa_obc(void* s, int n, const double* charge, const double* radius, const double* scale, int method, double cutoff, double solventDielectric, double soluteDielectric) {
+    try {
+        GBSAOBCForce* f = new GBSAOBCForce();
+        for (int i = 0; i < n; i++) f->addParticle(charge[i], radius[i], scale[i]);
+        f->setNonbondedMethod((GBSAOBCForce::NonbondedMethod) method);
+        f->setCutoffDistance(cutoff);
+        f->setSolventDielectric(solventDielectric);
+        f->setSoluteDielectric(soluteDielectric);
+        ((System*) s)->addForce(f);
+        return f;
+    } catch (const std::exception& e) { lastError = e.what(); return NULL; }
+}
 void* omm_add_cmmotion_remover(void* s, int frequency) {
     try { CMMotionRemover* f = new CMMotionRemover(frequency); ((System*) s)->addForce(f); return f; }
     catch (const std::exception& e) { lastError = e.what(); return NULL; }

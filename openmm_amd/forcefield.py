@@ -92,6 +92,7 @@ class ForceField:
         self.propers, self.impropers = [], []      # (classes[4], [(periodicity, phase, k)])
         self.nonbonded = {}          # type -> (charge, sigma, epsilon)
         self.coulomb14, self.lj14 = 1.0, 1.0
+        self.gbsa = {}               # type -> (charge, radius, scale)   (<GBSAOBCForce>, e.g. amber99_obc.xml)
         for f in files:
             self._load(f if os.path.isabs(f) else os.path.join(data_dir, f))
 
@@ -129,6 +130,8 @@ class ForceField:
             self.coulomb14, self.lj14 = float(nb.attrib["coulomb14scale"]), float(nb.attrib["lj14scale"])
             for a in nb.findall("Atom"):
                 self.nonbonded[a.attrib["type"]] = (float(a.attrib["charge"]), float(a.attrib["sigma"]), float(a.attrib["epsilon"]))
+        for a in root.findall("GBSAOBCForce/Atom"):                   # GBSAOBCGenerator (forcefield.py:2676-2723)
+            self.gbsa[a.attrib["type"]] = (float(a.attrib["charge"]), float(a.attrib["radius"]), float(a.attrib["scale"]))
 
     # ---- residue <-> template graph matching (forcefield.py:_matchResidue)
     def match_residue(self, elements, bonds, external, cache):
@@ -191,8 +194,9 @@ def _match_graph(elements, bonds, external, template):
 
 
 # ------------------------------------------------------------------------------------------------ System
-def create_workload(pdb_path, ff, name, cutoff=0.9, constraints_hbonds=True, rigid_water=True):
-    """-> testsystems.Workload with the arrays ForceField.createSystem(PME, cutoff, HBonds) would put into the System."""
+def create_workload(pdb_path, ff, name, cutoff=0.9, constraints_hbonds=True, rigid_water=True, method=4):
+    """-> testsystems.Workload with the arrays ForceField.createSystem(method, cutoff, HBonds / None) would put into the System.
+    method: harness.NonbondedForce constants (0 NoCutoff ... 4 PME); a force field with a <GBSAOBCForce> section adds `w.gbsa`."""
     from .testsystems import Workload
     pdb = read_pdb(pdb_path)
     n = len(pdb["names"])
@@ -229,12 +233,16 @@ def create_workload(pdb_path, ff, name, cutoff=0.9, constraints_hbonds=True, rig
     w = Workload(name)
     w.template_names = template_names
     w.positions = pdb["positions"]
-    w.box = np.diag(pdb["box"])
+    w.box = np.diag(pdb["box"]) if pdb["box"] is not None else None
     w.masses = np.array([ff.types[t][2] for t in atom_type])
     w.charge = np.array([ff.nonbonded[t][0] for t in atom_type])
     w.sigma = np.array([ff.nonbonded[t][1] for t in atom_type])
     w.epsilon = np.array([ff.nonbonded[t][2] for t in atom_type])
-    w.method, w.cutoff, w.dispersion, w.cm_remover = 4, cutoff, True, True      # PME
+    w.method, w.cutoff, w.dispersion, w.cm_remover = method, cutoff, True, True
+    if ff.gbsa:
+        # (charge, radius, scale) per atom + the NonbondedForce's reaction field switched off (GBSAOBCGenerator.postprocessSystem)
+        w.gbsa = tuple(np.array([ff.gbsa[t][k] for t in atom_type]) for k in range(3))
+        w.reaction_field_dielectric = 1.0
     w.exception_bonds = np.array(bonds, dtype=np.int64)
     w.coulomb14, w.lj14 = ff.coulomb14, ff.lj14
 
@@ -341,3 +349,11 @@ def dhfr(data_dir=None, pdb_path="/root/reference/examples/5dfr_solv-cube_equil.
     """The `pme` test of examples/benchmark.py:87-90,133-138: DHFR in TIP3P water, amber99sb, PME 0.9 nm, HBonds, rigid water."""
     ff = ForceField("amber99sb.xml", "tip3p.xml", data_dir=data_dir)
     return create_workload(pdb_path, ff, "dhfr-23558 (5dfr_solv-cube_equil.pdb, amber99sb + tip3p)")
+
+
+def lysozyme_implicit(data_dir=None, pdb_path="/root/reference/wrappers/python/tests/systems/lysozyme-implicit.pdb"):
+    """The System of wrappers/python/tests/TestForceField.py:285-301 (test_Forces): T4 lysozyme, amber99sb + amber99_obc (GBSA-OBC),
+    createSystem's defaults -- NoCutoff, no constraints, CMMotionRemover.  The reference keeps golden forces of it
+    (tests/systems/lysozyme-implicit-forces.xml): the pin of this reader against the app layer."""
+    ff = ForceField("amber99sb.xml", "amber99_obc.xml", data_dir=data_dir)
+    return create_workload(pdb_path, ff, "lysozyme-implicit (amber99sb + amber99_obc)", cutoff=1.0, constraints_hbonds=False, rigid_water=True, method=0)

@@ -43,7 +43,8 @@ RAD_TO_DEG = 180.0 / math.pi
 class AmoebaForceField:
     """The parameter tables of one AMOEBA force-field file, keyed by atom CLASS (valence terms, vdW) or TYPE (multipoles)."""
 
-    def __init__(self, path):
+    def __init__(self, path, implicit_path=None):
+        """path: the force-field file (amoeba2009.xml, amoeba2013.xml); implicit_path: its generalized-Kirkwood companion (amoeba2013_gk.xml)"""
         root = ET.parse(path).getroot()
         self.base = FF.ForceField(path)          # atom types, residue templates and torsions: the plain reader
         self.class_of = {name: t[0] for name, t in self.base.types.items()}
@@ -95,6 +96,22 @@ class AmoebaForceField:
             alpha, thole = float(p.attrib["polarizability"]), float(p.attrib["thole"])
             groups = {int(p.attrib["pgrp%d" % i]) for i in range(1, 7) if "pgrp%d" % i in p.attrib}
             self.polarize[p.attrib["type"]] = (alpha, thole, 0.0 if thole == 0 else alpha ** (1.0 / 6.0), groups)
+        # amoeba2013.xml writes its torsions as <AmoebaTorsionForce> (three amplitude / phase pairs per definition) where amoeba2009.xml has a
+        # <PeriodicTorsionForce>; AmoebaTorsionGenerator (forcefield.py:3890-3993) turns them into PeriodicTorsionForce terms all the same
+        self.amoeba_torsions = None
+        e = root.find("AmoebaTorsionForce")
+        if e is not None:
+            self.amoeba_torsions = [(tuple(t.attrib["class%d" % i] for i in range(1, 5)),
+                                     [(i, float(t.attrib["angle%d" % i]), float(t.attrib["amp%d" % i])) for i in (1, 2, 3)]) for t in e.findall("Torsion")]
+        # implicit solvent: AmoebaGeneralizedKirkwoodGenerator (forcefield.py:5359-5617) + AmoebaWcaDispersionGenerator (:5287-5354)
+        self.gk = self.wca = None
+        if implicit_path is not None:
+            iroot = ET.parse(implicit_path).getroot()
+            e = iroot.find("AmoebaGeneralizedKirkwoodForce")
+            self.gk = {k: float(e.attrib[k]) for k in ("solventDielectric", "soluteDielectric", "includeCavityTerm", "probeRadius", "surfaceAreaFactor")}
+            e = iroot.find("AmoebaWcaDispersionForce")
+            self.wca = ({k: float(e.attrib[k]) for k in ("epso", "epsh", "rmino", "rminh", "awater", "slevy", "dispoff", "shctd")},
+                        {w.attrib["class"]: (float(w.attrib["radius"]), float(w.attrib["epsilon"])) for w in e.findall("WcaDispersion")})
 
 
 def axis_type(kz, kx, ky):
@@ -150,7 +167,7 @@ def create_description(pdb_path, ff, name):
             atom_type[i] = t["types"][m[local[i]]]
     cls = [ff.class_of[t] for t in atom_type]
     masses = np.array([ff.base.types[t][2] for t in atom_type])
-    d = dict(name=name, positions=pdb["positions"], box=np.diag(pdb["box"]), masses=masses, atom_type=np.array([int(t) for t in atom_type]),
+    d = dict(name=name, positions=pdb["positions"], box=np.diag(pdb["box"] if pdb["box"] is not None else [2.0, 2.0, 2.0]), masses=masses, atom_type=np.array([int(t) for t in atom_type]),
              template_names=template_names, bonds_topology=np.array(bonds, dtype=np.int64))
 
     # ---- bonds
@@ -246,6 +263,14 @@ def create_description(pdb_path, ff, name):
     for tor in sorted(propers):
         c = tuple(cls[x] for x in tor)
         key = min(c, c[::-1])
+        if key not in cache_p and ff.amoeba_torsions is not None:
+            # AmoebaTorsionGenerator.createForce (forcefield.py:3966-3991): the FIRST definition that fits forwards or backwards
+            match = None
+            for classes, terms in ff.amoeba_torsions:
+                if all(classes[q] in ("", c[q]) for q in range(4)) or all(classes[q] in ("", c[3 - q]) for q in range(4)):
+                    match = terms
+                    break
+            cache_p[key] = match
         if key not in cache_p:
             match = None
             for classes, terms in ff.base.propers:
@@ -451,6 +476,12 @@ def create_description(pdb_path, ff, name):
         for kind, sets in ((Covalent12, b12), (Covalent13, b13), (Covalent14, b14), (Covalent15, b15),
                            (PolarizationCovalent11, p11), (PolarizationCovalent12, p12), (PolarizationCovalent13, p13), (PolarizationCovalent14, p14)):
             maps.append((i, kind, sorted(sets[i])))
+    if ff.gk is not None:
+        # AmoebaGeneralizedKirkwoodGenerator.createForce: the multipole's charge, the Bondi radius of the element x 1.03, overlap scale 0.69
+        bondi = {"H": 0.12, "He": 0.14, "B": 0.18, "C": 0.170, "N": 0.155, "O": 0.152, "F": 0.147, "Ne": 0.154, "Si": 0.210, "P": 0.180, "S": 0.180, "Cl": 0.175}
+        d["gk"] = dict(ff.gk, charge=np.array([m["charge"] for m in chosen]), radius=np.array([bondi[e] * 1.03 for e in pdb["elements"]]), scale=np.full(n, 0.69))
+        globals_, table = ff.wca
+        d["wca"] = dict(globals_, radius=np.array([table[c][0] for c in cls]), epsilon=np.array([table[c][1] for c in cls]))
     d["multipoles"] = dict(charge=np.array([m["charge"] for m in chosen]), dipole=np.array([m["dipole"] for m in chosen]), quadrupole=np.array([m["quadrupole"] for m in chosen]),
                            axes=axes, thole=np.array([p[1] for p in pol]), damping=np.array([p[2] for p in pol]), polarity=np.array([p[0] for p in pol]), covalent_maps=maps)
     return d
@@ -572,3 +603,12 @@ def subset(d, num_atoms):
     if (out["multipoles"]["axes"][:, 1:] >= n).any() or (out["vdw"]["parent"] >= n).any():
         raise ValueError("the cut at atom %d goes through a molecule" % n)
     return out
+
+
+def alanine_dipeptide_implicit(data_dir=None, pdb_path="/root/reference/wrappers/python/tests/systems/alanine-dipeptide-implicit.pdb"):
+    """The System of wrappers/python/tests/TestForceField.py:1246-1262 (AmoebaTestForceField.test_Forces): alanine dipeptide,
+    ForceField('amoeba2013.xml', 'amoeba2013_gk.xml').createSystem(topology, polarization='direct') -- NoCutoff, generalized Kirkwood +
+    WCA dispersion.  The reference keeps golden forces of it (tests/systems/alanine-dipeptide-amoeba-forces.xml): the pin of this reader."""
+    data_dir = data_dir or next((p for p in FF.DATA_DIR_CANDIDATES if os.path.isdir(p)), None)
+    ff = AmoebaForceField(os.path.join(data_dir, "amoeba2013.xml"), os.path.join(data_dir, "amoeba2013_gk.xml"))
+    return create_description(pdb_path, ff, "alanine-dipeptide-implicit (amoeba2013 + amoeba2013_gk)")

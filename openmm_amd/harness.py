@@ -126,6 +126,28 @@ class System:
         self.h = _handle(lib().omm_system_create())
         self.forces = []
 
+    @classmethod
+    def from_xml(cls, text):
+        """XmlSerializer::deserialize<System> of the reference (serialization/include/openmm/serialization/XmlSerializer.h:74-76)"""
+        lib().omm_system_from_xml.restype = C.c_void_p
+        self = cls.__new__(cls)
+        self.h = _handle(lib().omm_system_from_xml(text.encode() if isinstance(text, str) else text))
+        self.forces = []
+        return self
+
+    def to_xml(self):
+        blob, size = C.c_void_p(), C.c_long(0)
+        _check(lib().omm_system_to_xml(self.h, C.byref(blob), C.byref(size)))
+        text = C.string_at(blob, size.value).decode()
+        lib().omm_free(blob)
+        return text
+
+    def getNumForces(self):
+        return lib().omm_system_num_forces(self.h)
+
+    def getNumConstraints(self):
+        return lib().omm_system_num_constraints(self.h)
+
     def addParticles(self, masses):
         m = np.ascontiguousarray(masses, dtype=np.float64)
         _check(lib().omm_system_add_particles(self.h, len(m), _dp(m)))
@@ -175,6 +197,14 @@ class System:
     def addCustomCompoundBondForce(self, particlesPerBond, energy, names, atoms, params):
         return self._custom(lib().omm_add_custom_compound_bond_force, particlesPerBond, energy, names, atoms, params, particlesPerBond)
 
+    def addGBSAOBCForce(self, charge, radius, scale, method=0, cutoff=1.0, solventDielectric=78.3, soluteDielectric=1.0):
+        """openmmapi/include/openmm/GBSAOBCForce.h; method: 0 NoCutoff, 1 CutoffNonPeriodic, 2 CutoffPeriodic"""
+        q, r, sc = (np.ascontiguousarray(a, dtype=np.float64) for a in (charge, radius, scale))
+        lib().omm_add_gbsa_obc.restype = C.c_void_p
+        h = _handle(lib().omm_add_gbsa_obc(self.h, len(q), _dp(q), _dp(r), _dp(sc), method, C.c_double(cutoff), C.c_double(solventDielectric), C.c_double(soluteDielectric)))
+        self.forces.append(h)
+        return h
+
     def addCMMotionRemover(self, frequency=1):
         return _handle(lib().omm_add_cmmotion_remover(self.h, frequency))
 
@@ -223,6 +253,9 @@ class NonbondedForce:
         n = (C.c_int * 3)()
         _check(lib().omm_nonbonded_get_ljpme_parameters_in_context(self.h, context.h, C.byref(alpha), n))
         return alpha.value, n[0], n[1], n[2]
+
+    def setReactionFieldDielectric(self, dielectric):
+        _check(lib().omm_nonbonded_set_reaction_field_dielectric(self.h, C.c_double(dielectric)))
 
     def setReciprocalSpaceForceGroup(self, group):
         _check(lib().omm_nonbonded_set_reciprocal_force_group(self.h, group))
@@ -357,6 +390,28 @@ class AmoebaVdwForce:
         start[1:] = np.cumsum([len(l) for l in lists])
         flat = np.ascontiguousarray(np.concatenate([np.asarray(l, dtype=np.int32) for l in lists]), dtype=np.int32)
         _acheck(amoeba_lib().omm_amoeba_vdw_set_exclusions(self.h, len(lists), _ip(start), _ip(flat)))
+
+
+def addAmoebaGeneralizedKirkwoodForce(system, charge, radius, scale, solventDielectric=78.3, soluteDielectric=1.0, includeCavityTerm=1, probeRadius=0.14, surfaceAreaFactor=-170.351730663):
+    """plugins/amoeba/openmmapi/include/openmm/AmoebaGeneralizedKirkwoodForce.h"""
+    q, r, sc = (np.ascontiguousarray(a, dtype=np.float64) for a in (charge, radius, scale))
+    amoeba_lib().omm_amoeba_gk_create.restype = C.c_void_p
+    h = amoeba_lib().omm_amoeba_gk_create(system.h, len(q), _dp(q), _dp(r), _dp(sc), C.c_double(solventDielectric), C.c_double(soluteDielectric), int(includeCavityTerm),
+                                          C.c_double(probeRadius), C.c_double(surfaceAreaFactor))
+    if not h:
+        raise OpenMMError(amoeba_lib().omm_amoeba_last_error().decode())
+    return C.c_void_p(h)
+
+
+def addAmoebaWcaDispersionForce(system, radius, epsilon, epso, epsh, rmino, rminh, awater, slevy, dispoff, shctd):
+    """plugins/amoeba/openmmapi/include/openmm/AmoebaWcaDispersionForce.h"""
+    r, e = (np.ascontiguousarray(a, dtype=np.float64) for a in (radius, epsilon))
+    g = np.ascontiguousarray([epso, epsh, rmino, rminh, awater, slevy, dispoff, shctd], dtype=np.float64)
+    amoeba_lib().omm_amoeba_wca_create.restype = C.c_void_p
+    h = amoeba_lib().omm_amoeba_wca_create(system.h, len(r), _dp(r), _dp(e), _dp(g))
+    if not h:
+        raise OpenMMError(amoeba_lib().omm_amoeba_last_error().decode())
+    return C.c_void_p(h)
 
 
 class AmoebaTorsionTorsionForce:

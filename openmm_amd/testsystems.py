@@ -45,6 +45,10 @@ class Workload:
             nb.createExceptionsFromBonds(self.exception_bonds, getattr(self, "coulomb14", 1.0 / 1.2), getattr(self, "lj14", 0.5))
         if self.exceptions is not None and len(self.exceptions[0]):
             nb.addExceptions(*self.exceptions)
+        if getattr(self, "reaction_field_dielectric", None) is not None:
+            nb.setReactionFieldDielectric(self.reaction_field_dielectric)
+        if getattr(self, "gbsa", None) is not None:               # (charge, radius, scale): GBSAOBCForce with the NonbondedForce's method and cutoff
+            s.addGBSAOBCForce(self.gbsa[0], self.gbsa[1], self.gbsa[2], 0 if self.method == H.NoCutoff else (1 if self.method == H.CutoffNonPeriodic else 2), self.cutoff)
         if self.pme_params is not None:
             nb.setPMEParameters(*self.pme_params)
         if getattr(self, "ljpme_params", None) is not None:
@@ -187,8 +191,9 @@ class AmoebaWorkload:
 
     RAD = 180.0 / np.pi
 
-    def __init__(self, description, cutoff=0.7, vdw_cutoff=0.9, polarization=H.Mutual, epsilon=1e-5, ewald_tol=7.5e-4, grid=None, a_ewald=0.0):
+    def __init__(self, description, cutoff=0.7, vdw_cutoff=0.9, polarization=H.Mutual, epsilon=1e-5, ewald_tol=7.5e-4, grid=None, a_ewald=0.0, no_cutoff=False):
         self.d = description
+        self.no_cutoff = no_cutoff          # createSystem's default nonbondedMethod (implicit-solvent Systems): multipoles and vdW over all pairs
         self.name = description["name"]
         self.positions, self.box, self.masses = description["positions"], description["box"], description["masses"]
         self.cutoff, self.vdw_cutoff, self.polarization, self.epsilon, self.ewald_tol, self.grid, self.a_ewald = cutoff, vdw_cutoff, polarization, epsilon, ewald_tol, grid, a_ewald
@@ -250,13 +255,18 @@ class AmoebaWorkload:
         mp = vdw = None
         if nonbonded:
             m = d["multipoles"]
-            mp = H.AmoebaMultipoleForce(s, H.AmoebaMultipoleForce.PME, self.polarization, self.cutoff, self.a_ewald, self.grid, self.ewald_tol, self.epsilon, 100)
+            mp = H.AmoebaMultipoleForce(s, H.AmoebaMultipoleForce.NoCutoff if self.no_cutoff else H.AmoebaMultipoleForce.PME, self.polarization, self.cutoff, self.a_ewald, self.grid, self.ewald_tol, self.epsilon, 100)
             mp.addMultipoles(m["charge"], m["dipole"], m["quadrupole"].reshape(-1, 3, 3), m["axes"], m["thole"], m["damping"], m["polarity"])
             mp.setCovalentMaps([e[0] for e in m["covalent_maps"]], [e[1] for e in m["covalent_maps"]], [e[2] for e in m["covalent_maps"]])
             v = d["vdw"]
-            vdw = H.AmoebaVdwForce(s, v["sigma_rule"], v["epsilon_rule"], H.AmoebaVdwForce.CutoffPeriodic, self.vdw_cutoff, True)
+            vdw = H.AmoebaVdwForce(s, v["sigma_rule"], v["epsilon_rule"], H.AmoebaVdwForce.NoCutoff if self.no_cutoff else H.AmoebaVdwForce.CutoffPeriodic, self.vdw_cutoff, True)
             vdw.addParticles(v["parent"], v["sigma"], v["epsilon"], v["reduction"])
             vdw.setParticleExclusions(v["exclusions"])
+            if "gk" in d:          # generalized Kirkwood + WCA dispersion (implicit solvent; forcefield.py:5287-5617)
+                g, wca = d["gk"], d["wca"]
+                handles["AmoebaGeneralizedKirkwood"] = H.addAmoebaGeneralizedKirkwoodForce(s, g["charge"], g["radius"], g["scale"], g["solventDielectric"], g["soluteDielectric"],
+                                                                                         int(g["includeCavityTerm"]), g["probeRadius"], g["surfaceAreaFactor"])
+                handles["AmoebaWcaDispersion"] = H.addAmoebaWcaDispersionForce(s, wca["radius"], wca["epsilon"], *[wca[k] for k in ("epso", "epsh", "rmino", "rminh", "awater", "slevy", "dispoff", "shctd")])
             handles["AmoebaMultipole"], handles["AmoebaVdw"] = mp.h, vdw.h
             H.lib().omm_force_set_group(mp.h, 1)
             H.lib().omm_force_set_group(vdw.h, 1)

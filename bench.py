@@ -69,6 +69,7 @@ def parse_args():
     p.add_argument("--prepare-steps", type=int, default=-1, help="untimed steps that relax a lattice start before warm-up (input preparation; default 1000 for the water boxes -- after 200 steps a jittered lattice is still melting: 9 % more list rows and 40 % more list rebuilds per step than after 3000, profiles/r04h_prepare_steps_water1m.txt -- 0 for fixtures)")
     p.add_argument("--transport", default="rccl", choices=["rccl", "gloo"], help="collectives of the decomposed run: RCCL (product) or host-staged gloo (rehearsal on one GPU)")
     p.add_argument("--profile-every", type=int, default=0, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region (0 = 7, or 4 for runs below 100 steps: a 20-step run then holds 6 samples and loses ~2 % to them)")
+    p.add_argument("--no-pmc", action="store_true", help="N = 1: do not spawn the rocprofv3 child runs (FETCH_SIZE / WRITE_SIZE passes of the dominant launch group, kernel trace of the amoeba_dhfr workload) after the timed region")
     p.add_argument("--no-extra-workloads", action="store_true", help="N = 1: skip the short runs of BASELINE.json configs[2] (apoa1-sized) and of the benchmark script's own 4 fs step")
     p.add_argument("--decompose", action="store_true", help="N = 1: run through the decomposed path with a one-rank RCCL communicator (overhead check on one GPU)")
     p.add_argument("--props", default="", help="extra HIP platform properties, e.g. DisablePmeStream=true")
@@ -177,6 +178,69 @@ def timed_run(integ, ctx, steps, barrier):
     elapsed = time.perf_counter() - t0
     barrier()
     return elapsed, st
+
+
+def rocprof_child(command, pmc=None, timeout=240):
+    """Run `command` (argv list) under rocprofv3 in a scratch directory and return the per-dispatch table of its kernels as a pandas
+    DataFrame (Kernel_Name, dur_us[, counter value]) -- or raise.  The recipe of MI355X_MICROARCH.md / tools/gpu_visit.sh: counters in a
+    pass of their own with --kernel-trace only (no other trace domain beside --pmc), one counter per pass, run from /tmp."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    import pandas as pd
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    tmp = tempfile.mkdtemp(prefix="ommhip_prof_", dir="/tmp")
+    try:
+        cmd = [exe] + (["--pmc", pmc] if pmc else []) + ["--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "p", "--"] + command
+        env = dict(os.environ, TMPDIR="/tmp", BENCH_PROFILER_CHILD="1")
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+        if r.returncode != 0:
+            raise RuntimeError("rocprofv3 child exited with %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
+        if pmc:
+            files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                raise RuntimeError("no counter_collection.csv")
+            df = pd.read_csv(files[0])
+            df = df[df["Counter_Name"] == pmc]
+            per = df.groupby(["Dispatch_Id", "Kernel_Name"], as_index=False).agg(value=("Counter_Value", "sum"), start=("Start_Timestamp", "first"), end=("End_Timestamp", "first"))
+        else:
+            files = glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True)
+            if not files:
+                raise RuntimeError("no kernel_trace.csv")
+            df = pd.read_csv(files[0])
+            per = df.rename(columns={"Start_Timestamp": "start", "End_Timestamp": "end"})[["Kernel_Name", "start", "end"]].copy()
+            per["value"] = 0.0
+        per["dur_us"] = (per["end"] - per["start"]) / 1e3
+        return per, r.stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def measure_group_traffic():
+    """HBM-side bytes of the dominant launch group (pairs_fft_plane x 2 + pairs_fft_lines) of THIS build on THIS box: two rocprofv3 child runs of
+    the default workload (FETCH_SIZE and WRITE_SIZE cannot share a pass), 40 + 10 steps each.  FETCH_SIZE is doubled (gfx950: it tallies the
+    128-byte requests of wide streaming reads at 64 bytes, MI355X_MICROARCH.md "HBM"); WRITE_SIZE is taken as reported (uncalibrated); both
+    are in KB.  -> dict for roofline.traffic / traffic_source."""
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "40", "--warmup", "10", "--cpu-steps", "0", "--no-roofline", "--no-scale-workload", "--no-extra-workloads", "--no-pmc"]
+    kb = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        per, _ = rocprof_child(child, pmc=counter)
+        for key in ("pairs_fft_plane", "pairs_fft_lines"):
+            sub = per[per["Kernel_Name"].str.contains(key)]
+            if len(sub) == 0:
+                raise RuntimeError("no dispatch of %s in the %s pass" % (key, counter))
+            kb[(counter, key)] = (float(sub["value"].mean()), int(len(sub)), float(sub["dur_us"].mean()))
+    fetch = 2.0 * (2 * kb[("FETCH_SIZE", "pairs_fft_plane")][0] + kb[("FETCH_SIZE", "pairs_fft_lines")][0])
+    write = 2 * kb[("WRITE_SIZE", "pairs_fft_plane")][0] + kb[("WRITE_SIZE", "pairs_fft_lines")][0]
+    return {"traffic": int(1024.0 * (fetch + write)),
+            "detail": {"fetch_size_kb_per_launch": {"pairs_fft_plane (x2)": round(kb[("FETCH_SIZE", "pairs_fft_plane")][0], 1), "pairs_fft_lines": round(kb[("FETCH_SIZE", "pairs_fft_lines")][0], 1)},
+                       "write_size_kb_per_launch": {"pairs_fft_plane (x2)": round(kb[("WRITE_SIZE", "pairs_fft_plane")][0], 1), "pairs_fft_lines": round(kb[("WRITE_SIZE", "pairs_fft_lines")][0], 1)},
+                       "dispatches_averaged": {"pairs_fft_plane": kb[("FETCH_SIZE", "pairs_fft_plane")][1], "pairs_fft_lines": kb[("FETCH_SIZE", "pairs_fft_lines")][1]},
+                       "kernel_us_under_the_profiler": {"pairs_fft_plane": round(kb[("FETCH_SIZE", "pairs_fft_plane")][2], 2), "pairs_fft_lines": round(kb[("FETCH_SIZE", "pairs_fft_lines")][2], 2)},
+                       "correction": "FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; KB -> bytes x 1024"}}
 
 
 def main():
@@ -344,7 +408,11 @@ def main():
                         timers[k] = keep[k]
             # algorithmic bytes of one launch: per row 64 j-slots x (index 4 + mask 4 + posq 16 + sigEps 8 + force 24)
             # plus per chunk 32 i-atoms x (posq 16 + sigEps 8 + force 24)
-            algo_bytes = rows * 64 * 56 + chunks * 32 * 48
+            algo_bytes_with_list_words = rows * 64 * 56 + chunks * 32 * 48
+            # `frac` is quoted on SURVEY.md 8(d)'s own formula: B_dir = 48 N + 52 * 32 * T with T = 32 x 32 tiles = 2 per 64-slot row (the i side
+            # once per atom, no mask word); the accounting above -- i side once per chunk, the mask word of every j slot -- is ~20 % more
+            # generous and is reported beside it as frac_counting_list_words ("what's weak" 6)
+            algo_bytes = 48 * w.num_atoms + 52 * 32 * (2 * rows)
             avg_us = timers["nb_direct"]["avg_us"]
             # Fused single-stream path: the pair kernel rides on the three FFT launches (ommhip_pairs_with_fft), the timer then
             # brackets those three launches and the algorithmic bytes include the FFT stages' grid traffic: real grid read +
@@ -355,6 +423,7 @@ def main():
             real_b, cplx_b = gx * gy * gz * 4, gx * gy * (gz // 2 + 1) * 8
             if fused:
                 algo_bytes += (real_b + cplx_b) + (2 * cplx_b + cplx_b // 2) + (cplx_b + real_b)
+                algo_bytes_with_list_words += (real_b + cplx_b) + (2 * cplx_b + cplx_b // 2) + (cplx_b + real_b)
                 kernel_name = "pairs_fft_plane + pairs_fft_lines + pairs_fft_plane (pair kernel riding on the 3 FFT launches)"
             # avg_us so far: HIP events around the group of launches (the gaps between the three fused launches included).  The launches' own
             # dispatch timestamps -- start / stop events riding on each launch's packet -- give the kernel time proper: their sum is what the
@@ -364,6 +433,7 @@ def main():
             if fused and all(v for v in stage_us):
                 avg_us = sum(stage_us)
             achieved = algo_bytes / (avg_us * 1e-6) / 1e9 if avg_us else None
+            achieved_list_words = algo_bytes_with_list_words / (avg_us * 1e-6) / 1e9 if avg_us else None
             # HBM traffic of the same kernel from the PMC passes (rocprofv3 cannot run inside this process; the counters are
             # collected by tools/gpu_pmc2.sh on the same command and committed under profiles/ with the hash of the kernel
             # sources they were taken from; a summary of other sources is stale and is not quoted)
@@ -379,9 +449,23 @@ def main():
                                       "the same command on the same kernel sources (hash checked): %s; visit %s" % (pmc["source"], pmc.get("visit", "date and box not recorded")))
                 else:
                     traffic_source = "stale: %s was collected from other kernel sources (%s, now %s)" % (os.path.basename(pmc_file), pmc.get("kernel_sources_sha"), sha)
+            # ... unless rocprofv3 is on this box: then the counters are collected now, from two child runs of this very command line's
+            # workload (after the timed region; ~15 s each)
+            traffic_detail = None
+            if workload == "dhfr" and fused and world == 1 and not args.no_pmc and not EMULATED and os.environ.get("BENCH_PROFILER_CHILD") != "1":
+                try:
+                    m = measure_group_traffic()
+                    traffic, traffic_detail = m["traffic"], m["detail"]
+                    traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) over two child runs of the "
+                                      "same workload on this box after the timed region (40 steps each); bytes per launch group = 2 x pairs_fft_plane + pairs_fft_lines")
+                except Exception as e:
+                    traffic_source = (traffic_source or "") + " [in-run PMC passes failed: %s]" % str(e)[:200]
             out["roofline"] = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5) if achieved else None, "traffic": traffic,
-                               "traffic_source": traffic_source,
+                               "traffic_source": traffic_source, "traffic_detail": traffic_detail,
+                               "algorithmic_bytes_formula": "SURVEY.md 8(d): B_dir = 48 N + 52*32*T, T = 2 tiles per 64-slot row" + (" + grid traffic of the three FFT stages as implemented (real read + complex written; complex read + written + influence function; complex read + real written)" if fused else ""),
+                               "frac_counting_list_words": round(achieved_list_words / HBM_PEAK_GBPS, 5) if achieved_list_words else None,
+                               "algorithmic_bytes_counting_list_words": int(algo_bytes_with_list_words),
                                "algorithmic_bytes_per_launch": int(algo_bytes), "avg_kernel_us": round(avg_us, 3) if avg_us else None,
                                "avg_kernel_us_source": ("sum of the three launches' own dispatch timestamps (hipExtLaunchKernelGGL start / stop events on every launch of 32 steps after the timed region; avg_span_us_including_launch_gaps is the in-region sample of the group)" if fused and all(v for v in stage_us)
                                                         else "HIP events around the launch"),
@@ -636,6 +720,16 @@ def main():
                     d_parity["max_rel_err_" + name] = float(rel.max())
                     d_parity["atoms_above_tolerance_" + name] = int((rel > 1e-4).sum())
                 pctx.close()
+                # ... and with the induced dipoles converged to the 1e-5 D of the timed run (benchmark.py's setting) instead of the golden's 1e-6:
+                # what is left is the truncation of the solve, which the Reference platform shows as well at that setting
+                # (profiles/r11/reference_platform_at_run_epsilon.txt: the Reference platform at 1e-5 D against its own 1e-6 D forces)
+                rw, rinteg, rctx = dhfr_context(1e-5, True)
+                f = rctx.getState(getForces=True, groups=2).forces
+                rms = float(np.sqrt((ref_nb ** 2).sum(1).mean()))
+                rel = np.linalg.norm(f - ref_nb, axis=1) / np.maximum(np.linalg.norm(ref_nb, axis=1), rms)
+                d_parity["max_rel_err_at_the_run_epsilon"] = float(rel.max())
+                d_parity["atoms_above_tolerance_at_the_run_epsilon"] = int((rel > 1e-4).sum())
+                rctx.close()
             except Exception as e:
                 d_parity = {"error": str(e)}
             before = H.amoeba_native_evaluations()
@@ -661,6 +755,37 @@ def main():
                                                      "steps": d_steps, "warmup": 6, "force_parity": d_parity,
                                                      "solver_iterations_per_solve": round((solves1[1] - solves0[1]) / max(1, solves1[0] - solves0[0]), 2),
                                                      "pair_list_builds_per_step": {"vdw": round((builds1[0] - builds0[0]) / d_steps, 3), "multipole": round((builds1[1] - builds0[1]) / d_steps, 3)}}
+            # roofline of this workload's dominant kernel, k_mp_dipole_field (the induced field of the current dipoles, once per solver
+            # iteration): per pair-list entry it streams the entry (4 B), the partner's packed dipoles (24 B) and the cached geometry / damped
+            # chain coefficients (20 B); entries = ordered pairs inside multipole cutoff + list skin (counted here with a k-d tree on the
+            # final configuration); duration = the kernel's own dispatches in a rocprofv3 --kernel-trace child run of tools/bench_amoeba.py
+            if not args.no_pmc and not EMULATED and os.environ.get("BENCH_PROFILER_CHILD") != "1":
+                try:
+                    from scipy.spatial import cKDTree
+                    endp = dctx.getState(getPositions=True).positions
+                    Lbox = np.diag(np.asarray(dw.box, float))
+                    wrapped = np.mod(endp, Lbox[None, :])
+                    wrapped[wrapped >= Lbox[None, :]] = 0.0
+                    skin = float(os.environ.get("OPENMM_HIP_AMOEBA_SKIN", "0.05"))
+                    tree = cKDTree(wrapped, boxsize=Lbox)
+                    entries = int(tree.count_neighbors(tree, 0.7 + skin)) - dw.num_atoms          # ordered pairs: every atom lists all its partners
+                    per, child_out = rocprof_child([sys.executable, os.path.join(ROOT, "tools", "bench_amoeba.py"), "--dhfr", "--steps", "10"], timeout=300)
+                    sub = per[per["Kernel_Name"].str.contains("k_mp_dipole_field")]
+                    sub = sub[~sub["Kernel_Name"].str.contains("gradient")]
+                    a_us = float(sub["dur_us"].mean())
+                    a_bytes = 48 * entries
+                    a_ach = a_bytes / (a_us * 1e-6) / 1e9
+                    total_us = float(per["dur_us"].sum())
+                    top = per.groupby("Kernel_Name")["dur_us"].agg(["sum", "count", "mean"]).sort_values("sum", ascending=False).head(6)
+                    out["extra_workloads"]["amoeba_dhfr"]["roofline"] = {
+                        "bound": "hbm", "kernel": "k_mp_dipole_field", "achieved": round(a_ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(a_ach / HBM_PEAK_GBPS, 5),
+                        "traffic": None, "algorithmic_bytes_per_launch": int(a_bytes), "list_entries": entries, "bytes_per_entry": 48,
+                        "avg_kernel_us": round(a_us, 3), "launches_in_the_traced_run": int(len(sub)), "share_of_kernel_time_in_the_traced_run": round(float(sub["dur_us"].sum()) / total_us, 4),
+                        "flops_per_launch": int(entries * 2 * 30), "flops_note": "two dipole sets x ~30 double-precision flop per entry: 0.03 of the fp64 vector peak -- the kernel streams its cache",
+                        "source": "rocprofv3 --kernel-trace child run of tools/bench_amoeba.py --dhfr --steps 10 on this box (16 steps with the warm-up), after the timed region",
+                        "top_kernels_us": {str(k)[:60]: {"total": round(float(v["sum"]), 1), "calls": int(v["count"]), "avg": round(float(v["mean"]), 2)} for k, v in top.iterrows()}}
+                except Exception as e:
+                    out["extra_workloads"]["amoeba_dhfr"]["roofline"] = {"error": str(e)[:300]}
             dctx.close()
         except Exception as e:
             out["extra_workloads"]["amoeba_dhfr"] = {"value": None, "error": str(e)}

@@ -1127,6 +1127,17 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double target, double un
         }
         return;
     }
+    if (stage == 6) {
+        // After convergence: mu += alpha r, the update the Reference's iteration has already applied when ITS measure (the size of that very
+        // update) falls below the target (convergeInduceDipolesByDIIS :939-1005) -- conjugate gradients stop with the residual of the
+        // dipoles they return, one such update short.  No field evaluation: r is the residual of the converged dipoles.
+        if (i < a.n) {
+            const double pol = a.polarity[i];
+            store3(a.indD, i, load3(a.indD, i) + pol * load3(w, i));
+            store3(a.indP, i, load3(a.indP, i) + pol * load3(w + n3, i));
+        }
+        return;
+    }
     if (stage != 0 && sums[10] != 0.0) return;
     double cD = 0.0, cP = 0.0;
     if (stage == 2) { cD = sums[2] != 0.0 ? sums[0] / sums[2] : 0.0; cP = sums[3] != 0.0 ? sums[1] / sums[3] : 0.0; }
@@ -1532,6 +1543,8 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st) {
     static const bool report = getenv("OPENMM_HIP_AMOEBA_DEBUG") != nullptr;
     if (report) fprintf(stderr, "amoeba solver: %d iterations (%d enqueued, first guess from %d earlier solutions), epsilon %.3g (target %.3g), preconditioner %d\n", iterations, enqueued, use, epsilon, mp->target_epsilon, a.precond);
     if (!done) return -1;
+    static const bool noPolish = getenv("OPENMM_HIP_AMOEBA_NO_POLISH") != nullptr;        // A/B knob
+    if (!noPolish) hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 6, 0.0, 0.0);
     if (haveHistory && mp->history_store >= 0)
         hipLaunchKernelGGL(k_mp_history, dim3(blocks), dim3(MP_BLOCK), 0, st, a, mp->history, mp->history_slots, mp->history_store % mp->history_slots, 0, 1, coeff);
     // potentials of the converged dipoles (the force kernels read them)

@@ -112,6 +112,11 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
     return v;
 }
+__device__ __forceinline__ int wave_min_int(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m); v = o < v ? o : v; }
+    return v;
+}
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));

@@ -319,6 +319,165 @@ __global__ __launch_bounds__(256) void pme_spread_lds(PmeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same with G consecutive 32-atom blocks per workgroup and a B^3 brick (round 5; systems whose spreading is a launch of its own).
+// What the brick scheme pays for is the flush: a grid cell receives one global atomic transaction from every brick that covers it --
+// with one block per brick ~17 per cell on the 192^3 grid of the 1M-atom box (4.3 M line transactions for 30 798 blocks), which IS the
+// kernel's time (profiles/r05b_atomics_by_scope.txt).  G consecutive blocks of the Hilbert order are a compact blob of G times the volume
+// but (G^(1/3) x edge + stencil)^3 cells: 128 atoms touch ~15^3 cells where four separate bricks flush 4 x 11^3.  Atoms whose stencil
+// leaves the brick (a blob longer than B - 5 cells along some axis) go through global atomics one by one, as before.
+// ------------------------------------------------------------------------------------------------
+template <int G, int B>
+struct SpreadSharedG {
+    int touches;
+    int brick[B * B * (B + 1)];
+    float brickScale;
+    float th[G * SPREAD_ATOMS][3][PME_ORDER];
+    int baseIdx[G * SPREAD_ATOMS][3];
+    float charge[G * SPREAD_ATOMS];
+    int ref[3];
+    int minRel[3];
+};
+
+template <bool DD, int G, int B, int THREADS>
+__global__ __launch_bounds__(THREADS) void pme_spread_group(PmeArgs a) {
+    constexpr int ATOMS = G * SPREAD_ATOMS, ZS = B + 1, WORDS = B * B * ZS, WAVES = THREADS / 64;
+    static_assert(ATOMS % WAVES == 0, "every wavefront takes the same number of atoms");
+    __shared__ SpreadSharedG<G, B> sh;
+    const int t = threadIdx.x;
+    const int slot0 = blockIdx.x * ATOMS;
+    if (t < 3) { sh.minRel[t] = 1 << 30; sh.ref[t] = -1; }
+    if (t == 0) sh.touches = DD ? 0 : 1;
+    for (int i = t; i < WORDS; i += THREADS) sh.brick[i] = 0;
+    // splines: (atom, dimension) pairs; an atom of a block this rank holds no current positions for (halo mode) counts as uncharged
+    for (int w = t; w < 4 * ATOMS; w += THREADS) {
+        const int atom = w >> 2, d = w & 3;
+        const int slot = slot0 + atom;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (slot < a.paddedAtoms && !(DD && a.blockHalf[slot / SPREAD_ATOMS].x < 0.f)) p = a.posq[slot];
+        if (d == 3) sh.charge[atom] = p.w;
+        else if (p.w != 0.f) {
+            const float frac = d == 0 ? p.x * a.recip.r00 + p.y * a.recip.r10 + p.z * a.recip.r20
+                             : (d == 1 ? p.y * a.recip.r11 + p.z * a.recip.r21 : p.z * a.recip.r22);
+            const int nd = d == 0 ? a.nx : (d == 1 ? a.ny : a.nz);
+            int idx; float theta[PME_ORDER], dtheta[PME_ORDER];
+            bspline(frac, nd, idx, theta, dtheta);
+            sh.baseIdx[atom][d] = idx;
+#pragma unroll
+            for (int k = 0; k < PME_ORDER; k++) sh.th[atom][d][k] = theta[k];
+        }
+    }
+    __syncthreads();
+    // reference cell = base index of the first charged atom; fixed-point scale from the largest charge (no more than SPREAD_ATOMS atoms of
+    // it can pile their largest weight, 0.6^3, onto one cell: the scale of the one-block brick holds for G blocks as well)
+    if (t < 64) {
+        int first = ATOMS;
+        float qmax = 0.f;
+        for (int i = t; i < ATOMS; i += 64) { const float q = sh.charge[i]; if (q != 0.f && i < first) first = i; qmax = fmaxf(qmax, fabsf(q)); }
+        first = wave_min_int(first);
+        qmax = wave_max(qmax);
+        if (t == 0) {
+            if (first < ATOMS) { sh.ref[0] = sh.baseIdx[first][0]; sh.ref[1] = sh.baseIdx[first][1]; sh.ref[2] = sh.baseIdx[first][2]; }
+            sh.brickScale = exp2f(floorf(30.f - log2f(fmaxf(SPREAD_ATOMS * qmax, 1e-20f))));
+        }
+    }
+    __syncthreads();
+    if (sh.ref[0] < 0) return;
+    const int n[3] = {a.nx, a.ny, a.nz};
+    for (int i = t; i < ATOMS; i += THREADS) {
+        if (sh.charge[i] == 0.f) continue;
+#pragma unroll
+        for (int d = 0; d < 3; d++) atomicMin(&sh.minRel[d], wrap_rel(sh.baseIdx[i][d] - sh.ref[d], n[d]));
+        if (DD) {
+            bool touch = false;
+#pragma unroll
+            for (int k = 0; k < PME_ORDER; k++) { int gx = sh.baseIdx[i][0] + k; gx -= gx >= a.nx ? a.nx : 0; touch = touch || spread_plane<DD>(a, gx) >= 0; }
+            if (touch) sh.touches = 1;
+        }
+    }
+    __syncthreads();
+    if (DD && sh.touches == 0) return;
+    {
+        const int lane = t & 63, wave = t >> 6;
+        const int ptA = lane, ptB = lane + 64;
+        const int ixA = ptA / 25, iyA = (ptA / 5) % 5, izA = ptA % 5;
+        const int ixB = ptB / 25, iyB = (ptB / 5) % 5, izB = ptB % 5;
+        const bool hasB = ptB < PME_ORDER * PME_ORDER * PME_ORDER;
+        const float scale = sh.brickScale;
+        for (int k = 0; k < ATOMS / WAVES; k++) {
+            const int atom = wave * (ATOMS / WAVES) + k;
+            const float q = sh.charge[atom];
+            if (q == 0.f) continue;                             // wave-uniform
+            int off[3];
+            bool fits = true;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                off[d] = wrap_rel(sh.baseIdx[atom][d] - sh.ref[d], n[d]) - sh.minRel[d];
+                fits = fits && off[d] + PME_ORDER <= B && B <= n[d];
+            }
+            const float vA = q * sh.th[atom][0][ixA] * sh.th[atom][1][iyA] * sh.th[atom][2][izA];
+            const float vB = hasB ? q * sh.th[atom][0][ixB] * sh.th[atom][1][iyB] * sh.th[atom][2][izB] : 0.f;
+            if (fits) {
+                atomicAdd(&sh.brick[((off[0] + ixA) * B + off[1] + iyA) * ZS + off[2] + izA], __float2int_rn(vA * scale));
+                if (hasB) atomicAdd(&sh.brick[((off[0] + ixB) * B + off[1] + iyB) * ZS + off[2] + izB], __float2int_rn(vB * scale));
+            }
+            else {
+                int gx = sh.baseIdx[atom][0] + ixA; gx -= gx >= a.nx ? a.nx : 0;
+                int gy = sh.baseIdx[atom][1] + iyA; gy -= gy >= a.ny ? a.ny : 0;
+                int gz = sh.baseIdx[atom][2] + izA; gz -= gz >= a.nz ? a.nz : 0;
+                gx = spread_plane<DD>(a, gx);
+                if (gx >= 0) grid_add(a, ((size_t) gx * a.ny + gy) * a.nz + gz, vA);
+                if (hasB) {
+                    gx = sh.baseIdx[atom][0] + ixB; gx -= gx >= a.nx ? a.nx : 0;
+                    gy = sh.baseIdx[atom][1] + iyB; gy -= gy >= a.ny ? a.ny : 0;
+                    gz = sh.baseIdx[atom][2] + izB; gz -= gz >= a.nz ? a.nz : 0;
+                    gx = spread_plane<DD>(a, gx);
+                    if (gx >= 0) grid_add(a, ((size_t) gx * a.ny + gy) * a.nz + gz, vB);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    int org[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) { org[d] = (sh.ref[d] + sh.minRel[d]) % n[d]; if (org[d] < 0) org[d] += n[d]; }
+    const float invScale = 1.f / sh.brickScale;
+    for (int i = t; i < WORDS; i += THREADS) {
+        const int fixed = sh.brick[i];
+        if (fixed != 0) {
+            const float v = (float) fixed * invScale;
+            int gx = org[0] + i / (B * ZS); gx -= gx >= a.nx ? a.nx : 0;
+            int gy = org[1] + (i / ZS) % B; gy -= gy >= a.ny ? a.ny : 0;
+            int gz = org[2] + i % ZS; gz -= gz >= a.nz ? a.nz : 0;
+            gx = spread_plane<DD>(a, gx);
+            if (gx >= 0) grid_add(a, ((size_t) gx * a.ny + gy) * a.nz + gz, v);
+        }
+    }
+}
+
+// blocks per brick of the stand-alone spreading launch: 1 (the 16^3 brick of the fused front launch), 4 (20^3) or 6 (22^3);
+// OPENMM_HIP_SPREAD_GROUP overrides the default
+static int spread_group_blocks(int padded_atoms) {
+    static const int env = getenv("OPENMM_HIP_SPREAD_GROUP") != nullptr ? atoi(getenv("OPENMM_HIP_SPREAD_GROUP")) : -1;
+    if (env >= 0) return env;
+    return padded_atoms >= 60000 ? 2 : 1;
+}
+template <bool DD>
+static void launch_spread(const PmeArgs& pa, int padded_atoms, hipStream_t st) {
+    const int g = spread_group_blocks(padded_atoms);          // 1, 2, 3, 4, 6; 14 / 18: four / eight blocks with 512-thread workgroups (A/B)
+    const int blocks = (padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS;
+    const bool bigEnough = pa.nx >= 24 && pa.ny >= 24 && pa.nz >= 24;
+    if (!bigEnough || g <= 1) hipLaunchKernelGGL(pme_spread_lds<DD>, dim3(blocks), dim3(256), 0, st, pa);
+    else if (g == 2) hipLaunchKernelGGL((pme_spread_group<DD, 2, 18, 256>), dim3((blocks + 1) / 2), dim3(256), 0, st, pa);
+    else if (g == 3) hipLaunchKernelGGL((pme_spread_group<DD, 3, 19, 192>), dim3((blocks + 2) / 3), dim3(192), 0, st, pa);
+    else if (g == 4) hipLaunchKernelGGL((pme_spread_group<DD, 4, 20, 256>), dim3((blocks + 3) / 4), dim3(256), 0, st, pa);
+    else if (g == 6) hipLaunchKernelGGL((pme_spread_group<DD, 6, 22, 256>), dim3((blocks + 5) / 6), dim3(256), 0, st, pa);
+    else if (g == 12) hipLaunchKernelGGL((pme_spread_group<DD, 2, 18, 512>), dim3((blocks + 1) / 2), dim3(512), 0, st, pa);
+    else if (g == 14) hipLaunchKernelGGL((pme_spread_group<DD, 4, 20, 512>), dim3((blocks + 3) / 4), dim3(512), 0, st, pa);
+    else hipLaunchKernelGGL((pme_spread_group<DD, 2, 18, 256>), dim3((blocks + 1) / 2), dim3(256), 0, st, pa);
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // Tile spreading (spread_mode 2, systems too large for the fused front launch).  The brick scheme above turns an atom's 125
 // scattered atomics into line-coalesced ones, but every grid cell still receives ~17 global atomic transactions (one per
 // block whose brick covers it): 4.3 M line transactions for 30 798 blocks on a 192^3 grid.  Here the roles are swapped: ONE
@@ -588,6 +747,134 @@ __global__ __launch_bounds__(256) void pme_interpolate(PmeArgs a) {
         exclEnergy = wave_sum(exclEnergy);
         if ((threadIdx.x & 63) == 0) atomicAdd(&a.energyBuffer[(blockIdx.x * 4 + (threadIdx.x >> 6)) % a.energySlots], exclEnergy);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Interpolation with FIVE lanes per atom (round 5): lane z of an atom walks the 25 (x, y) rows of the stencil at its own z offset, so the
+// x and y weights are indexed by the (unrolled) loop counters and only the z weight is picked per lane, once.  The eight-lane kernel above
+// picks all six weights of every point with compare / select chains (registers cannot be indexed by a lane-dependent value): ~40 VALU
+// instructions per stencil point against 3 here -- it was bound by exactly that (1M atoms: 105 M wavefront instructions, 4 cycles each,
+// = 170 us of its 235).  12 atoms per wavefront (lanes 60-63 idle); the five lanes of an atom read five consecutive floats of a z row.
+// Same arithmetic as ReferencePME.cpp:617-713 up to the order of the sums.
+// ------------------------------------------------------------------------------------------------
+#define INTERP_LANES 5
+#define INTERP_ATOMS_PER_WAVE 12
+template <bool DD>
+__global__ __launch_bounds__(256) void pme_interpolate_z(PmeArgs a) {
+    int wg = blockIdx.x;
+    if (a.xcdBlocks > 0) { const int x = wg % 8, k = wg / 8; wg = k < a.xcdBlocks ? x * a.xcdBlocks + k : (int) gridDim.x; }
+    const int lane = threadIdx.x & 63;
+    const int wave = wg * (int) (blockDim.x >> 6) + (int) (threadIdx.x >> 6);
+    const int sub = lane % INTERP_LANES, atomInWave = lane / INTERP_LANES;
+    int slot = (DD ? a.ownSlot0 : 0) + wave * INTERP_ATOMS_PER_WAVE + atomInWave;
+    const bool valid = atomInWave < INTERP_ATOMS_PER_WAVE && slot < (DD ? a.ownSlot1 : a.paddedAtoms) && wg < (int) gridDim.x;
+    if (!valid) slot = a.paddedAtoms - 1;
+    const float4 p = a.posq[slot];
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    if (valid && p.w != 0.f) {
+        int idx[3]; float th[3][PME_ORDER], dth[3][PME_ORDER];
+        atom_splines(a, p, idx, th, dth);
+        float wz = th[2][0], dz = dth[2][0];
+#pragma unroll
+        for (int k = 1; k < PME_ORDER; k++) { wz = sub == k ? th[2][k] : wz; dz = sub == k ? dth[2][k] : dz; }
+        int gz = idx[2] + sub; gz -= gz >= a.nz ? a.nz : 0;
+        size_t rowX[PME_ORDER]; int rowY[PME_ORDER];
+#pragma unroll
+        for (int k = 0; k < PME_ORDER; k++) {
+            int gx = idx[0] + k; gx -= gx >= a.nx ? a.nx : 0;
+            gx = gather_plane<DD>(a, gx);
+            if (DD && gx < 0) { *a.ddError = 1; gx = 0; }          // the atom drifted out of the planes this rank holds: flagged, the host re-sorts
+            rowX[k] = (size_t) gx * a.ny;
+            int gy = idx[1] + k; gy -= gy >= a.ny ? a.ny : 0;
+            rowY[k] = gy;
+        }
+        // all 25 gathers of this lane are issued back to back and consumed afterwards
+        float g[PME_ORDER][PME_ORDER];
+#pragma unroll
+        for (int ix = 0; ix < PME_ORDER; ix++)
+#pragma unroll
+            for (int iy = 0; iy < PME_ORDER; iy++) g[ix][iy] = a.grid[(rowX[ix] + rowY[iy]) * a.nz + gz];
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+        for (int ix = 0; ix < PME_ORDER; ix++) {
+            float r = 0.f, rd = 0.f;          // sum over y of theta_y g and of dtheta_y g
+#pragma unroll
+            for (int iy = 0; iy < PME_ORDER; iy++) { r += th[1][iy] * g[ix][iy]; rd += dth[1][iy] * g[ix][iy]; }
+            sx += dth[0][ix] * r; sy += th[0][ix] * rd; sz += th[0][ix] * r;
+        }
+        fx = sx * wz; fy = sy * wz; fz = sz * dz;
+    }
+    // Ewald exclusion correction of this atom (ReferenceLJCoulombIxn.cpp:462-523): lane `sub` takes partners sub, sub + 5, ...
+    float ex = 0.f, ey = 0.f, ez = 0.f;
+    double exclEnergy = 0.0;
+    if (a.exclStart != nullptr) {
+        const int atom = valid ? a.atomOfSlot[slot] : -1;
+        if (atom >= 0) {
+            const int e1 = a.exclStart[atom + 1];
+            int e = a.exclStart[atom] + sub;
+            if (e < e1) {
+                const double4 pi = a.pos[atom];
+                const double qi = OMM_ONE_4PI_EPS0_D * a.charge[atom];
+                for (; e < e1; e += INTERP_LANES) {
+                    const int j = a.exclAtoms[e];
+                    const double4 pj = a.pos[j];
+                    double ddx = pj.x - pi.x, ddy = pj.y - pi.y, ddz = pj.z - pi.z;
+                    if (a.exclPeriodic) min_image_d(ddx, ddy, ddz, a.boxd);
+                    const float dx = (float) ddx, dy = (float) ddy, dz = (float) ddz;
+                    const double qqd = qi * a.charge[j];
+                    const float qq = (float) qqd;
+                    const float r2 = dx * dx + dy * dy + dz * dz;
+                    const float invR = rsqrtf(r2), r = r2 * invR;
+                    const float ar = (float) a.alpha * r;
+                    const float erfAr = erff(ar);
+                    if (erfAr > 1e-6f) {
+                        const float sc = qq * invR * invR * invR * (erfAr - 2.0f * ar * expf(-ar * ar) * 0.56418958354775628695f);
+                        ex += sc * dx; ey += sc * dy; ez += sc * dz;
+                        exclEnergy -= 0.5 * qqd * (double) (invR * erfAr);         // every pair is visited from both ends
+                    }
+                    else
+                        exclEnergy -= 0.5 * a.alpha * 1.12837916709551257390 * qqd;
+                }
+            }
+        }
+    }
+    // the first lane of an atom collects the other four (lanes 60-63 hold zeros)
+    float tx = fx, ty = fy, tz = fz, ux = ex, uy = ey, uz = ez;
+#pragma unroll
+    for (int k = 1; k < INTERP_LANES; k++) {
+        tx += __shfl_down(fx, k); ty += __shfl_down(fy, k); tz += __shfl_down(fz, k);
+        if (a.exclStart != nullptr) { ux += __shfl_down(ex, k); uy += __shfl_down(ey, k); uz += __shfl_down(ez, k); }
+    }
+    if (valid && sub == 0 && p.w != 0.f) {          // an uncharged atom has no exclusion correction either
+        // ReferencePME.cpp:709-711
+        const float q = p.w;
+        const float gx = tx * a.nx, gy = ty * a.ny, gzf = tz * a.nz;
+        add_force(a.force, a.paddedAtoms, slot,
+                  ux - q * (gx * a.recip.r00),
+                  uy - q * (gx * a.recip.r10 + gy * a.recip.r11),
+                  uz - q * (gx * a.recip.r20 + gy * a.recip.r21 + gzf * a.recip.r22));
+    }
+    if (a.exclStart != nullptr && a.includeEnergy) {
+        exclEnergy = wave_sum(exclEnergy);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&a.energyBuffer[(blockIdx.x * 4 + (threadIdx.x >> 6)) % a.energySlots], exclEnergy);
+    }
+}
+
+// which interpolation kernel: five lanes per atom (default) or the eight-lane kernel of rounds 1-4 (OPENMM_HIP_INTERPOLATE_LANES=8, A/B)
+static bool interpolate_by_z() {
+    static const bool old = getenv("OPENMM_HIP_INTERPOLATE_LANES") != nullptr && atoi(getenv("OPENMM_HIP_INTERPOLATE_LANES")) == 8;
+    return !old;
+}
+template <bool DD>
+static void launch_interpolate(PmeArgs& pa, int slots, bool xcdPlacement, hipStream_t st) {
+    const int perBlock = interpolate_by_z() ? 4 * INTERP_ATOMS_PER_WAVE : 32;
+    int blocks = (slots + perBlock - 1) / perBlock;
+    if (xcdPlacement && blocks >= 2048) { pa.xcdBlocks = (blocks + 7) / 8; blocks = pa.xcdBlocks * 8; }      // large systems: the grid no longer fits one L2
+    if (blocks > 0) {
+        if (interpolate_by_z()) hipLaunchKernelGGL(pme_interpolate_z<DD>, dim3(blocks), dim3(256), 0, st, pa);
+        else hipLaunchKernelGGL(pme_interpolate<DD>, dim3(blocks), dim3(256), 0, st, pa);
+    }
+    pa.xcdBlocks = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1482,7 +1769,7 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
             if (pme->spread_mode == 1)
                 hipLaunchKernelGGL(pme_spread, dim3(spreadBlocks), dim3(256), 0, st, pa);             // direct global atomics (reference variant)
             else
-                hipLaunchKernelGGL(pme_spread_lds<false>, dim3((padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS), dim3(256), 0, st, pa);
+                launch_spread<false>(pa, padded_atoms, st);
         }
         if (pa.detScale > 0.f) {
             const size_t n = (size_t) nx * ny * nz;
@@ -1515,10 +1802,7 @@ extern "C" int ommhip_pme_reciprocal(const ommhip_pme* pme, const void* posq_d, 
     ommhip_profile_begin(OMMHIP_TIMER_PME_INTERPOLATE, stream);
     {
         static const bool noXcd = getenv("OPENMM_HIP_XCD_INTERPOLATE") == nullptr;          // opt-in: measured neutral at 1M atoms, -1.7 % at 92 k (docs/EXPERIMENTS.md)
-        int blocks = spreadBlocks;
-        if (!noXcd && spreadBlocks >= 2048) { pa.xcdBlocks = (spreadBlocks + 7) / 8; blocks = pa.xcdBlocks * 8; }      // large systems: the grid no longer fits one L2
-        hipLaunchKernelGGL(pme_interpolate<false>, dim3(blocks), dim3(256), 0, st, pa);
-        pa.xcdBlocks = 0;
+        launch_interpolate<false>(pa, padded_atoms, !noXcd, st);
     }
     ommhip_profile_end(OMMHIP_TIMER_PME_INTERPOLATE, stream);
     return (int) hipGetLastError();
@@ -1651,7 +1935,7 @@ extern "C" int ommhip_pme_reciprocal_dd(const ommhip_pme* pme, const void* posq_
         ommhip_profile_begin(OMMHIP_TIMER_PME_SPREAD, stream);
         if (!launch_tile_spread<true>(pme, pa, block_center_d, block_half_d, st)) {
             if (!pme->grid_precleared) hipMemsetAsync(real, 0, planeBytes * (size_t) pa.gridPlanes, st);
-            hipLaunchKernelGGL(pme_spread_lds<true>, dim3((padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS), dim3(256), 0, st, pa);
+            launch_spread<true>(pa, padded_atoms, st);
         }
         ommhip_profile_end(OMMHIP_TIMER_PME_SPREAD, stream);
     }
@@ -1684,7 +1968,7 @@ extern "C" int ommhip_pme_reciprocal_dd(const ommhip_pme* pme, const void* posq_
     }
     ommhip_profile_begin(OMMHIP_TIMER_PME_INTERPOLATE, stream);
     const int ownSlots = own_slot1 - own_slot0;
-    if (ownSlots > 0) hipLaunchKernelGGL(pme_interpolate<true>, dim3((ownSlots * 8 + 255) / 256), dim3(256), 0, st, pa);
+    if (ownSlots > 0) launch_interpolate<true>(pa, ownSlots, false, st);
     ommhip_profile_end(OMMHIP_TIMER_PME_INTERPOLATE, stream);
     return (int) hipGetLastError();
 }

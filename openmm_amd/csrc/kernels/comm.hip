@@ -299,7 +299,10 @@ int ommhip_comm_ring_exchange(ommhip_comm* c, const void* send_down_d, void* rec
 
 int ommhip_comm_halo_exchange(ommhip_comm* c, void* buffer_d, const ommhip_halo_plan* plan, void* stream) {
     if (c->size > OMMHIP_MAX_RANKS) return 1;
-    if (c->size == 1) return 0;                     // the only slab holds everything already
+    // One rank: the only slab holds everything already.  Over RCCL the group is issued all the same -- the rank is its own neighbour on
+    // both sides, every section lands on itself -- so that a one-rank run walks the call pattern of the real thing (tests; the platform
+    // never exchanges halos with one rank).
+    if (c->size == 1 && !c->rccl) return 0;
     hipStream_t st = (hipStream_t) stream;
     char* buf = (char*) buffer_d;
     const int me = c->rank, down = (me + c->size - 1) % c->size, up = (me + 1) % c->size;
@@ -349,7 +352,7 @@ int ommhip_comm_halo_exchange(ommhip_comm* c, void* buffer_d, const ommhip_halo_
 
 int ommhip_comm_halo_return(ommhip_comm* c, long long* force_d, int padded_slots, const ommhip_halo_return_plan* plan, long long* staging_d, void* stream) {
     if (c->size > OMMHIP_MAX_RANKS) return 1;
-    if (c->size == 1) return 0;
+    if (c->size == 1 && !c->rccl) return 0;         // (one rank over RCCL: the section goes to itself and is added once more -- tests only)
     hipStream_t st = (hipStream_t) stream;
     const int me = c->rank, down = (me + c->size - 1) % c->size, up = (me + 1) % c->size;
     const int sendFirst = plan->first_slot[down], sendCount = plan->num_slots[down], recvFirst = plan->first_slot[me], recvCount = plan->num_slots[me];

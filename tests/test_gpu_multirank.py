@@ -167,3 +167,73 @@ def test_million_atom_box_on_four_ranks_matches_the_reference_golden(tmp_path):
                           "--master-port", "29571", str(script)], capture_output=True, text=True, timeout=1500, env=env)
     assert "OK" in out.stdout, out.stdout[-3000:] + out.stderr[-4000:]
     print(out.stdout)
+
+
+def test_one_rank_over_rccl_walks_every_collective_of_the_decomposed_step():
+    """Every collective of include/openmm_hip_comm.h through librccl with a one-rank communicator, driven through the C ABI with the buffers
+    of a decomposed step in miniature (VERDICT r4 "missing" 2: the first 8-GPU run must not be the first execution of these calls):
+    ncclCommSplit (ommhip_comm_duplicate) and traffic on the split communicator from a second stream while the first is busy; the in-place
+    all-gather; the all-to-all and the ring exchange of the slab FFT (grouped ncclSend / ncclRecv with the rank itself, distinct buffers:
+    the data really travels); the halo exchange's group -- both boundary sections, in place; the halo return's group of three sends and
+    three receives into the staging buffer followed by the integer add (the rank is its own upper neighbour: its section doubles, every
+    other slot stays); the host all-gather of small records.  What one GPU cannot show -- two peers, xGMI -- is
+    test_two_ranks_over_rccl_on_two_gpus."""
+    import ctypes as C
+    from openmm_amd import capi
+    K = capi.load()
+    lib = K.lib
+    ident = MR.new_rccl_id()
+    comm, side = C.c_void_p(), C.c_void_p()
+    assert lib.ommhip_comm_create_rccl(ident.encode(), 0, 1, C.byref(comm)) == 0
+    lib.ommhip_comm_transport.restype = C.c_char_p
+    assert lib.ommhip_comm_transport(comm) == b"rccl"
+    assert lib.ommhip_comm_duplicate(comm, C.byref(side)) == 0                    # ncclCommSplit
+    assert lib.ommhip_comm_size(side) == 1 and lib.ommhip_comm_rank(side) == 0
+    main_stream, side_stream = C.c_void_p(), C.c_void_p()
+    K.stream_create(C.byref(main_stream)); K.stream_create(C.byref(side_stream))
+    rng = np.random.default_rng(5)
+    sz = C.c_size_t
+    # ---- all-to-all + ring exchange on the split communicator / side stream, all-gather and halo traffic on the main one, interleaved
+    n = 1 << 18
+    a2a_send = rng.integers(0, 255, n, dtype=np.uint8)
+    d_send, d_recv = K.upload(a2a_send), K.upload(np.zeros(n, np.uint8))
+    assert lib.ommhip_comm_all_to_all(side, d_send, d_recv, sz(n), side_stream) == 0
+    planes_down, planes_up = rng.normal(size=5000).astype(np.float32), rng.normal(size=3000).astype(np.float32)
+    d_down, d_up = K.upload(planes_down), K.upload(planes_up)
+    d_from_up, d_from_down = K.upload(np.zeros(5000, np.float32)), K.upload(np.zeros(3000, np.float32))
+    assert lib.ommhip_comm_ring_exchange(side, d_down, d_from_up, sz(planes_down.nbytes), d_up, d_from_down, sz(planes_up.nbytes), side_stream) == 0
+    # positions: in-place all-gather (replicated fallback) ...
+    slots = 4096
+    wire = rng.integers(0, 2 ** 32, (slots, 4), dtype=np.uint32)
+    d_wire = K.upload(wire)
+    assert lib.ommhip_comm_all_gather(comm, d_wire, sz(wire.nbytes), main_stream) == 0
+    # ... and the halo exchange: down section = blocks [0, 40), up section = blocks [88, 128) of this rank's 128 blocks, trailer at the end
+    class HaloPlan(C.Structure):
+        _fields_ = [("rank_stride", sz), ("down_offset", sz * 64), ("down_bytes", sz * 64), ("up_offset", sz * 64), ("up_bytes", sz * 64), ("trailer_offset", sz), ("trailer_bytes", sz)]
+    plan = HaloPlan()
+    plan.rank_stride = wire.nbytes
+    plan.down_offset[0], plan.down_bytes[0] = 0, 40 * 32 * 16
+    plan.up_offset[0], plan.up_bytes[0] = 88 * 32 * 16, 40 * 32 * 16
+    plan.trailer_offset, plan.trailer_bytes = (slots - 2) * 16, 32
+    assert lib.ommhip_comm_halo_exchange(comm, d_wire, C.byref(plan), main_stream) == 0
+    # forces: the halo return (half-shell evaluation) -- section [1024, 1024 + 700) of a 4096-slot SoA buffer
+    class ReturnPlan(C.Structure):
+        _fields_ = [("first_slot", C.c_int * 64), ("num_slots", C.c_int * 64)]
+    rplan = ReturnPlan()
+    rplan.first_slot[0], rplan.num_slots[0] = 1024, 700
+    force = rng.integers(-2 ** 40, 2 ** 40, 3 * slots, dtype=np.int64)
+    d_force, d_staging = K.upload(force), K.upload(np.zeros(3 * 700, np.int64))
+    assert lib.ommhip_comm_halo_return(comm, d_force, slots, C.byref(rplan), d_staging, main_stream) == 0
+    rec_in, rec_out = np.array([3.25, -1.5]), np.zeros(2)
+    assert lib.ommhip_comm_all_gather_host(comm, rec_in.ctypes.data_as(C.c_void_p), rec_out.ctypes.data_as(C.c_void_p), sz(16), main_stream) == 0
+    K.stream_sync(main_stream); K.stream_sync(side_stream)
+    assert np.array_equal(K.download(d_recv, (n,), np.uint8), a2a_send)
+    assert np.array_equal(K.download(d_from_up, (5000,), np.float32), planes_down)          # what went down comes back from above
+    assert np.array_equal(K.download(d_from_down, (3000,), np.float32), planes_up)
+    assert np.array_equal(K.download(d_wire, (slots, 4), np.uint32), wire)                  # sections landed on themselves
+    assert np.array_equal(K.download(d_staging, (3, 700), np.int64), force.reshape(3, slots)[:, 1024:1724])      # the bytes went through ncclSend / ncclRecv
+    expect = force.reshape(3, slots).copy()
+    expect[:, 1024:1724] *= 2
+    assert np.array_equal(K.download(d_force, (3, slots), np.int64), expect)
+    assert np.array_equal(rec_out, rec_in)
+    assert lib.ommhip_comm_destroy(side) == 0 and lib.ommhip_comm_destroy(comm) == 0

@@ -153,11 +153,14 @@ __device__ __forceinline__ float2 rl2(float2 v, int k) { return make_float2(rl(v
 
 // NOLJ: both i atoms have epsilon = 0 (wave-uniform, decided by the caller from the i-block's parameters): the whole
 // Lennard-Jones part -- a fifth of the packed arithmetic -- is left out; its terms would all carry the factor eps_i eps_j = 0.
+// Two i atoms as the packed loops take them: (atom k, atom k + 1) per component.
+struct IPair { v2f x, y, z, q, sig, eps; };
+
 template <int METHOD, bool ENERGY, bool MASKED, bool NOLJ = false>
-__device__ __forceinline__ void pair_ixn2(const NbArgs& a, const float4 pi0, const float4 pi1, const float2 se0, const float2 se1,
+__device__ __forceinline__ void pair_ixn2(const NbArgs& a, const IPair& ip,
                                           const float4 pj, const float2 sej, const float qjK, bool bit0, bool bit1,
                                           v2f& fix, v2f& fiy, v2f& fiz, v2f& fjx, v2f& fjy, v2f& fjz, v2f& energy, unsigned long long& edge) {
-    const v2f dx = bc2(pj.x) - mk2(pi0.x, pi1.x), dy = bc2(pj.y) - mk2(pi0.y, pi1.y), dz = bc2(pj.z) - mk2(pi0.z, pi1.z);
+    const v2f dx = bc2(pj.x) - ip.x, dy = bc2(pj.y) - ip.y, dz = bc2(pj.z) - ip.z;
     const v2f r2 = r2_of(dx, dy, dz);
     bool in0 = r2.x < a.cutoff2, in1 = r2.y < a.cutoff2;
     mask_accumulate(edge, wave_ballot(in0), wave_ballot(r2.x < a.cutoff2Lo));
@@ -168,14 +171,14 @@ __device__ __forceinline__ void pair_ixn2(const NbArgs& a, const float4 pi0, con
     const v2f invR2 = invR * invR;
     v2f ljF = bc2(0.f), ljE = bc2(0.f), dispF = bc2(0.f);
     if (!NOLJ) {
-        const v2f sig = mk2(se0.x, se1.x) + bc2(sej.x);
-        const v2f eps = mk2(se0.y, se1.y) * bc2(sej.y);
+        const v2f sig = ip.sig + bc2(sej.x);
+        const v2f eps = ip.eps * bc2(sej.y);
         v2f s2 = sig * invR; s2 = s2 * s2;
         const v2f s6 = s2 * s2 * s2;
         ljF = eps * (bc2(12.f) * s6 - bc2(6.f)) * s6;
         ljE = eps * (s6 - bc2(1.f)) * s6;
         if (METHOD & 4) {
-            const v2f c6 = mk2(8.f * se0.x * se0.x * se0.x * se0.y, 8.f * se1.x * se1.x * se1.x * se1.y) * bc2(8.f * sej.x * sej.x * sej.x * sej.y);
+            const v2f c6 = (bc2(8.f) * ip.sig * ip.sig * ip.sig * ip.eps) * bc2(8.f * sej.x * sej.x * sej.x * sej.y);
             const v2f x = bc2(a.dispAlpha2) * r2;
             const v2f argd = -x * bc2(1.44269504088896340736f);
             const v2f ex = mk2(__builtin_amdgcn_exp2f(argd.x), __builtin_amdgcn_exp2f(argd.y));
@@ -195,7 +198,7 @@ __device__ __forceinline__ void pair_ixn2(const NbArgs& a, const float4 pi0, con
             ljE = ljE * sw;
         }
     }
-    const v2f qq = mk2(pi0.w, pi1.w) * bc2(qjK);
+    const v2f qq = ip.q * bc2(qjK);
     if ((METHOD & 8) && !ENERGY) {
         // Real-space Ewald force without exp and rcp (forces only): the bracket of ReferenceLJCoulombIxn.cpp:396-399 over r^3 is
         //   [erfc(ar) + 2 ar exp(-(ar)^2) / sqrt(pi)] / r^3 = 1 / r^3 - alpha^3 g(z),   z = (alpha r)^2,
@@ -249,12 +252,41 @@ __device__ __forceinline__ void pair_ixn2(const NbArgs& a, const float4 pi0, con
 #ifndef OMM_I_FROM_LANES
 #define OMM_I_FROM_LANES 1
 #endif
+// OMM_I_FROM_LANES = 2: the block's atoms as six arrays of 32 floats in LDS (x, y, z, q, sigma, epsilon; one copy per wavefront, written
+// once per chunk), read with ds_read_b64 at compile-time offsets -- every lane reads the same address (a broadcast), the two floats land in
+// a register pair a packed instruction takes as it is.  The LDS pipe is otherwise idle in this kernel; the lane form spends 8-12 VALU
+// issue slots per pair of atoms on v_readlane_b32, a fifth of the loop (the list builder reads its i atoms this way: neighbor.hip).
+#define OMM_I_LDS_FLOATS (6 * OMM_TILE)
 struct IAtoms {
     const float4* __restrict__ ip; const float2* __restrict__ ise;     // memory form
     float4 pLane; float2 seLane;                                       // lane form
+    const float* lds;                                                  // LDS form
     // k is a compile-time constant after unrolling: v_readlane_b32 with an immediate lane
-    __device__ __forceinline__ float4 posq(int k) const { return OMM_I_FROM_LANES ? rl4(pLane, k) : ip[k]; }
-    __device__ __forceinline__ float2 sigEps(int k) const { return OMM_I_FROM_LANES ? rl2(seLane, k) : ise[k]; }
+    __device__ __forceinline__ float4 posq(int k) const {
+        if (OMM_I_FROM_LANES == 2) return make_float4(lds[k], lds[OMM_TILE + k], lds[2 * OMM_TILE + k], lds[3 * OMM_TILE + k]);
+        return OMM_I_FROM_LANES ? rl4(pLane, k) : ip[k];
+    }
+    __device__ __forceinline__ float2 sigEps(int k) const {
+        if (OMM_I_FROM_LANES == 2) return make_float2(lds[4 * OMM_TILE + k], lds[5 * OMM_TILE + k]);
+        return OMM_I_FROM_LANES ? rl2(seLane, k) : ise[k];
+    }
+    template <bool NOLJ>
+    __device__ __forceinline__ IPair pair(int k) const {
+        IPair r;
+        if (OMM_I_FROM_LANES == 2) {
+            const v2f* p = (const v2f*) lds;
+            r.x = p[(0 * OMM_TILE + k) / 2]; r.y = p[(1 * OMM_TILE + k) / 2]; r.z = p[(2 * OMM_TILE + k) / 2]; r.q = p[(3 * OMM_TILE + k) / 2];
+            if (!NOLJ) { r.sig = p[(4 * OMM_TILE + k) / 2]; r.eps = p[(5 * OMM_TILE + k) / 2]; }
+            else { r.sig = bc2(0.f); r.eps = bc2(0.f); }
+        }
+        else {
+            const float4 p0 = posq(k), p1 = posq(k + 1);
+            r.x = mk2(p0.x, p1.x); r.y = mk2(p0.y, p1.y); r.z = mk2(p0.z, p1.z); r.q = mk2(p0.w, p1.w);
+            if (!NOLJ) { const float2 s0 = sigEps(k), s1 = sigEps(k + 1); r.sig = mk2(s0.x, s1.x); r.eps = mk2(s0.y, s1.y); }
+            else { r.sig = bc2(0.f); r.eps = bc2(0.f); }
+        }
+        return r;
+    }
 };
 
 // i atoms [K0, K1) of a block against the j atom of this lane, two per call (single-image path).
@@ -264,8 +296,13 @@ __device__ __forceinline__ void row_pairs2(const NbArgs& a, const IAtoms& ia, co
                                            v2f& fj2x, v2f& fj2y, v2f& fj2z, v2f& energy2, unsigned long long& edge) {
 #pragma unroll
     for (int k = K0; k < K1; k += 2) {
+#if OMM_I_FROM_LANES == 2 && !defined(OMMHIP_EMU)
+        // keep the LDS reads of an iteration inside it: hoisted freely, the 16 x 6 register pairs of a row's i atoms are all requested up
+        // front and the kernel -- two registers short of its budget as it is -- spills them
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         v2f ax = mk2(fix[k], fix[k + 1]), ay = mk2(fiy[k], fiy[k + 1]), az = mk2(fiz[k], fiz[k + 1]);
-        pair_ixn2<METHOD, ENERGY, MASKED, NOLJ>(a, ia.posq(k), ia.posq(k + 1), ia.sigEps(k), ia.sigEps(k + 1), pj, sej, qjK, MASKED ? ((m >> k) & 1u) != 0 : true,
+        pair_ixn2<METHOD, ENERGY, MASKED, NOLJ>(a, ia.template pair<NOLJ>(k), pj, sej, qjK, MASKED ? ((m >> k) & 1u) != 0 : true,
                                                 MASKED ? ((m >> (k + 1)) & 1u) != 0 : true, ax, ay, az, fj2x, fj2y, fj2z, energy2, edge);
         fix[k] = ax.x; fix[k + 1] = ax.y; fiy[k] = ay.x; fiy[k + 1] = ay.y; fiz[k] = az.x; fiz[k + 1] = az.y;
     }
@@ -389,6 +426,12 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
     // lets the compiler prove they are never written here and fetch the wave-uniform i-atom data
     // with scalar loads.
     const int lane = threadIdx.x & 63;
+#if OMM_I_FROM_LANES == 2
+    __shared__ float iLdsAll[4][OMM_I_LDS_FLOATS];          // one copy per wavefront of the workgroup (the fused launches run four)
+    float* const iLds = iLdsAll[(threadIdx.x >> 6) & 3];
+#else
+    float* const iLds = nullptr;
+#endif
     // wave-uniform choice of the list: the per-step pruned rows when the builder keeps them
     const bool pruned = a.rowJInner != nullptr && a.state[ST_NO_PRUNE] == 0;
     const int2* __restrict__ const chunkInfo = pruned ? a.chunkInfoInner : a.chunkInfo;
@@ -426,7 +469,13 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
         if (nrows <= 0) continue;
         IAtoms ia;
         ia.ip = posqI + X * OMM_TILE; ia.ise = sigEpsI + X * OMM_TILE;
+        ia.lds = iLds;
         if (OMM_I_FROM_LANES) { ia.pLane = a.posq[X * OMM_TILE + (lane & (OMM_TILE - 1))]; ia.seLane = a.sigEps[X * OMM_TILE + (lane & (OMM_TILE - 1))]; }
+        if (OMM_I_FROM_LANES == 2 && lane < OMM_TILE) {
+            // (the reads of the previous chunk are complete: a wavefront's LDS operations execute in order)
+            iLds[0 * OMM_TILE + lane] = ia.pLane.x; iLds[1 * OMM_TILE + lane] = ia.pLane.y; iLds[2 * OMM_TILE + lane] = ia.pLane.z; iLds[3 * OMM_TILE + lane] = ia.pLane.w;
+            iLds[4 * OMM_TILE + lane] = ia.seLane.x; iLds[5 * OMM_TILE + lane] = ia.seLane.y;
+        }
         float fix[OMM_TILE], fiy[OMM_TILE], fiz[OMM_TILE];
 #pragma unroll
         for (int k = 0; k < OMM_TILE; k++) { fix[k] = 0.f; fiy[k] = 0.f; fiz[k] = 0.f; }
@@ -510,8 +559,8 @@ __device__ __forceinline__ void nb_direct_body(const NbArgs& a, const float4* __
             }
             if (edge != 0) {
                 // wave-uniform and rare (a few rows per step): pairs within float rounding of the cutoff are re-decided in double
-                const float4 iLane = OMM_I_FROM_LANES ? ia.pLane : a.posq[X * OMM_TILE + (lane & (OMM_TILE - 1))];
-                const float2 seLane = OMM_I_FROM_LANES ? ia.seLane : a.sigEps[X * OMM_TILE + (lane & (OMM_TILE - 1))];
+                const float4 iLane = OMM_I_FROM_LANES == 1 ? ia.pLane : a.posq[X * OMM_TILE + (lane & (OMM_TILE - 1))];
+                const float2 seLane = OMM_I_FROM_LANES == 1 ? ia.seLane : a.sigEps[X * OMM_TILE + (lane & (OMM_TILE - 1))];
                 fix_edge_pairs<METHOD, PBC, ENERGY>(a, iLane, seLane, X, j, pj, cX, cY, sej, qjK, m, PBC == 1 && single, fjx, fjy, fjz, energy);
             }
             const bool jOwned = (j >= a.ownSlot0 && j < a.ownSlot1) || (j >= a.keepSlot0 && j < a.keepSlot1);

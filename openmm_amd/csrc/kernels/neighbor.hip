@@ -607,6 +607,11 @@ __device__ __forceinline__ void nl_build_body(const NlArgs& a, const int X, cons
                     const v2f jx = bc2(dx), jy = bc2(dy), jz = bc2(dz);
 #pragma unroll
                     for (int k = 0; k < OMM_TILE; k += 2) {
+#if defined(OMM_NL_PIN_LDS_READS) && !defined(OMMHIP_EMU)
+                        // A/B: keep the three LDS reads of an iteration inside it.  Left alone the compiler reads all 32 atoms once per i-block
+                        // into 96 VGPRs (144 in all: three wavefronts per SIMD); pinned, the kernel needs ~60 and the CU holds seven workgroups.
+                        if (k % OMM_NL_PIN_LDS_READS == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
                         const v2f ex = jx - mk2(sh.ix[k], sh.ix[k + 1]), ey = jy - mk2(sh.iy[k], sh.iy[k + 1]), ez = jz - mk2(sh.iz[k], sh.iz[k + 1]);
                         const v2f r2 = ex * ex + ey * ey + ez * ez;
                         any = any || !(r2.x >= R2) || !(r2.y >= R2);
@@ -923,23 +928,35 @@ __global__ __launch_bounds__(NL_THREADS) void nl_find_interactions(NlArgs a) {
 // atoms the one-block-per-workgroup launch keeps ~3.4 workgroups per CU in flight although 7 fit (30 798 workgroups living 66 us each
 // arrive at ~13 per microsecond: `OPENMM_HIP_NL_TRACE`).  Same-box A/B (`profiles/r05x_ab_resident_builder.txt`): 985 527 atoms 2.298 -> 2.22 ms per
 // step with 7, 10 or 14 workgroups per CU, 92 224 atoms 0.2950 -> 0.2888.  OPENMM_HIP_NL_PERSISTENT=<per CU> (default 8, 0 = one workgroup per block).
+// Register budget of the resident builder: left to itself the compiler takes 143 VGPRs for the loop around the builder's body (loop-invariant
+// values kept across i-blocks) -- three wavefronts per SIMD, so three of the seven workgroups a CU's LDS would hold.  Asked for four
+// wavefronts it fits 128 without spilling, for five it spills four (94): same-box, 985 527 atoms, one stream: 2.096 / 2.050 / 2.063 ms per step
+// at 3 / 4 / 5 (`profiles/r11/r11m_ab_builder_occupancy.txt`; a rebuild 1.14 -> 0.87 ms).
+#ifndef OMM_NL_RESIDENT_WAVES
+#define OMM_NL_RESIDENT_WAVES 4
+#endif
+#ifdef OMMHIP_EMU
+#define OMM_NL_RESIDENT_ATTR
+#else
+#define OMM_NL_RESIDENT_ATTR __attribute__((amdgpu_waves_per_eu(OMM_NL_RESIDENT_WAVES)))
+#endif
 template <int PBC>
-__global__ __launch_bounds__(NL_THREADS) void nl_find_interactions_resident(NlArgs a) {
+__global__ __launch_bounds__(NL_THREADS) OMM_NL_RESIDENT_ATTR void nl_find_interactions_resident(NlArgs a) {
     __shared__ NlShared sh;
     if (a.state[ST_REBUILD] == 0) return;          // read once: the last block to finish clears the request, and by then no block is left
+    // ONE call site of the builder's body for both ways of walking through the i-blocks (round 5): with a call in each branch the body was
+    // inlined twice and the kernel took 144 VGPRs -- three wavefronts per SIMD, three workgroups per CU -- where one copy takes 95 (five).
+    int first = blockIdx.x, stride = gridDim.x, base = 0, limit = a.ownedBlocks;
     if (a.xcdAware && gridDim.x % 8 == 0) {
         // workgroup w runs on XCD w % 8 (round-robin dispatch): it walks through the (w % 8)-th eighth of the i-blocks, whose candidate blocks
         // -- spatial neighbours, close in the slot order -- then stay in that XCD's L2
-        const int x = blockIdx.x % 8, per = (a.ownedBlocks + 7) / 8;
-        for (int k = blockIdx.x / 8; k < per; k += gridDim.x / 8) {
-            const int b = x * per + k;
-            if (b < a.ownedBlocks) nl_build_body<PBC>(a, a.firstBlock + b, a.ownedBlocks, sh);          // block-uniform
-            __syncthreads();
-        }
-        return;
+        limit = (a.ownedBlocks + 7) / 8;
+        base = (int) (blockIdx.x % 8) * limit;
+        first = blockIdx.x / 8; stride = gridDim.x / 8;
     }
-    for (int b = blockIdx.x; b < a.ownedBlocks; b += gridDim.x) {
-        nl_build_body<PBC>(a, a.firstBlock + b, a.ownedBlocks, sh);
+    for (int k = first; k < limit; k += stride) {
+        const int b = base + k;
+        if (b < a.ownedBlocks) nl_build_body<PBC>(a, a.firstBlock + b, a.ownedBlocks, sh);          // block-uniform
         __syncthreads();
     }
 }

@@ -759,8 +759,18 @@ __global__ __launch_bounds__(256) void pme_interpolate(PmeArgs a) {
 // ------------------------------------------------------------------------------------------------
 #define INTERP_LANES 5
 #define INTERP_ATOMS_PER_WAVE 12
+// register budget: 99 VGPRs (four wavefronts per SIMD) left alone; asked for six the compiler fits 68 without spilling (seven per SIMD):
+// 177 -> 171 us at 1M atoms, 23.0 -> 22.0 at 92 k (`profiles/r11/r11n_ab_interpolate_occupancy.txt`)
+#ifndef OMM_INTERP_WAVES
+#define OMM_INTERP_WAVES 6
+#endif
+#ifdef OMMHIP_EMU
+#define OMM_INTERP_ATTR
+#else
+#define OMM_INTERP_ATTR __attribute__((amdgpu_waves_per_eu(OMM_INTERP_WAVES)))
+#endif
 template <bool DD>
-__global__ __launch_bounds__(256) void pme_interpolate_z(PmeArgs a) {
+__global__ __launch_bounds__(256) OMM_INTERP_ATTR void pme_interpolate_z(PmeArgs a) {
     int wg = blockIdx.x;
     if (a.xcdBlocks > 0) { const int x = wg % 8, k = wg / 8; wg = k < a.xcdBlocks ? x * a.xcdBlocks + k : (int) gridDim.x; }
     const int lane = threadIdx.x & 63;

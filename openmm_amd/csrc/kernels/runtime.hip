@@ -1,5 +1,6 @@
 // C-ABI veneer over the HIP runtime (device memory, streams, events) -- see include/openmm_hip_kernels.h.
 // The host-side plugin never includes hip_runtime.h; everything it needs goes through these calls.
+#include <cstdint>
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
@@ -40,8 +41,34 @@ int ommhip_memset(void* dst_d, int value, size_t bytes, void* stream) {
     if (bytes == 0) return 0;
     return (int) hipMemsetAsync(dst_d, value, bytes, (hipStream_t) stream);
 }
-int ommhip_stream_create(void** stream) { return (int) hipStreamCreateWithFlags((hipStream_t*) stream, hipStreamNonBlocking); }
+// A/B knob OPENMM_HIP_PME_CUS=n: the high-priority (reciprocal-space) stream is created on the first n bits of the CU mask and the ordinary
+// streams on the rest, so that the two streams' kernels run on disjoint compute units instead of queueing behind each other's resident
+// wavefronts (hipExtStreamCreateWithCUMask; consecutive mask bits go round the XCDs, so both sets spread over all eight).
+static int cu_split() {
+    static const int n = getenv("OPENMM_HIP_PME_CUS") != nullptr ? atoi(getenv("OPENMM_HIP_PME_CUS")) : 0;
+    return n;
+}
+static int create_masked(void** stream, bool side) {
+#ifndef OMMHIP_EMU
+    int dev = 0; hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
+    const int cus = prop.multiProcessorCount, n = cu_split();
+    if (n <= 0 || n >= cus) return 1;
+    uint32_t mask[16] = {0};
+    for (int i = 0; i < cus && i < 512; i++)
+        if ((i < n) == side) mask[i / 32] |= 1u << (i % 32);
+    return (int) hipExtStreamCreateWithCUMask((hipStream_t*) stream, (uint32_t) ((cus + 31) / 32), mask);
+#else
+    return 1;
+#endif
+}
+int ommhip_stream_create(void** stream) {
+    if (cu_split() > 0 && create_masked(stream, false) == 0) return 0;
+    return (int) hipStreamCreateWithFlags((hipStream_t*) stream, hipStreamNonBlocking);
+}
 int ommhip_stream_create_priority(void** stream, int high_priority) {
+    if (high_priority && cu_split() > 0 && create_masked(stream, true) == 0) return 0;
     int least = 0, greatest = 0;
     hipDeviceGetStreamPriorityRange(&least, &greatest);           // numerically lower = higher priority
     return (int) hipStreamCreateWithPriority((hipStream_t*) stream, hipStreamNonBlocking, high_priority ? greatest : least);

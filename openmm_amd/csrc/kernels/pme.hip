@@ -459,7 +459,7 @@ __global__ __launch_bounds__(THREADS) void pme_spread_group(PmeArgs a) {
 static int spread_group_blocks(int padded_atoms) {
     static const int env = getenv("OPENMM_HIP_SPREAD_GROUP") != nullptr ? atoi(getenv("OPENMM_HIP_SPREAD_GROUP")) : -1;
     if (env >= 0) return env;
-    return padded_atoms >= 60000 ? 2 : 1;
+    return padded_atoms >= 200000 ? 2 : 1;          // 92 k atoms: one and two blocks within 0.3 % (profiles/r11/r11s_ab_misc.txt), 985 k: -2.5 %
 }
 template <bool DD>
 static void launch_spread(const PmeArgs& pa, int padded_atoms, hipStream_t st) {

@@ -607,11 +607,6 @@ __device__ __forceinline__ void nl_build_body(const NlArgs& a, const int X, cons
                     const v2f jx = bc2(dx), jy = bc2(dy), jz = bc2(dz);
 #pragma unroll
                     for (int k = 0; k < OMM_TILE; k += 2) {
-#if defined(OMM_NL_PIN_LDS_READS) && !defined(OMMHIP_EMU)
-                        // A/B: keep the three LDS reads of an iteration inside it.  Left alone the compiler reads all 32 atoms once per i-block
-                        // into 96 VGPRs (144 in all: three wavefronts per SIMD); pinned, the kernel needs ~60 and the CU holds seven workgroups.
-                        if (k % OMM_NL_PIN_LDS_READS == 0) __builtin_amdgcn_sched_barrier(0);
-#endif
                         const v2f ex = jx - mk2(sh.ix[k], sh.ix[k + 1]), ey = jy - mk2(sh.iy[k], sh.iy[k + 1]), ez = jz - mk2(sh.iz[k], sh.iz[k + 1]);
                         const v2f r2 = ex * ex + ey * ey + ez * ez;
                         any = any || !(r2.x >= R2) || !(r2.y >= R2);

@@ -402,6 +402,26 @@ def water_tiled(reps=3):
     return w
 
 
+def water_row(n_side, reps, seed=0, cutoff=0.4):
+    """`reps` copies of `water_box(n_side)` side by side along x: a long thin box (reps L x L x L) for runs on MANY ranks, whose x-slabs
+    must each be wider than the halo -- 8 slabs of a cubic box small enough for the CPU emulator would not be.  The copies
+    are identical at the start, which periodic boundaries allow; independent Langevin noise separates them."""
+    c = water_box(n_side, seed=seed, cutoff=cutoff)
+    L, n = float(c.box[0][0]), len(c.positions)
+    w = Workload("water-row-%d" % (n * reps))
+    w.positions = (c.positions[None, :, :] + np.arange(reps)[:, None, None] * np.array([L, 0.0, 0.0])).reshape(-1, 3)
+    w.box = np.diag([reps * L, L, L])
+    for name in ("masses", "charge", "sigma", "epsilon"):
+        setattr(w, name, np.tile(getattr(c, name), reps))
+    offs = (np.arange(reps) * n)[:, None, None]
+    pairs, qq, sig, eps = c.exceptions
+    w.exceptions = ((pairs[None] + offs).reshape(-1, 2), np.tile(qq, reps), np.tile(sig, reps), np.tile(eps, reps))
+    cp, cd = c.constraints
+    w.constraints = ((cp[None] + offs).reshape(-1, 2), np.tile(cd, reps))
+    w.method, w.cutoff = c.method, c.cutoff
+    return w
+
+
 def dhfr():
     """The real DHFR benchmark System (examples/benchmark.py `pme`: 5dfr_solv-cube_equil.pdb, amber99sb + tip3p, PME 0.9 nm, HBonds,
     rigid water, CMMotionRemover) from the fixture tests/golden/dhfr_5dfr_amber99sb_tip3p.npz, which tools/make_dhfr_fixture.py

@@ -130,11 +130,11 @@ EXTRA_CASES = %s
 STEPS = %d
 for label, w, grid in (("water, halo", T.water_box(8, seed=5), 24), ("solvated chain, halo", T.small_solvated_chain(seed=3), 24)) + EXTRA_CASES:
     # a 32^3 grid marks the case that runs with the (opt-in) tile spreading: 16 own planes per rank = one tile along x, clipped to the slab
-    tiles = grid is not None and grid >= 32
+    tiles = isinstance(grid, int) and grid >= 32
     if tiles: os.environ["OPENMM_HIP_TILE_SPREAD_MIN_ATOMS"] = "1"
     else: os.environ.pop("OPENMM_HIP_TILE_SPREAD_MIN_ATOMS", None)
     if grid:
-        w.pme_params = (float(np.sqrt(-np.log(2 * w.ewald_tol)) / w.cutoff), grid, grid, grid)
+        w.pme_params = (float(np.sqrt(-np.log(2 * w.ewald_tol)) / w.cutoff),) + (tuple(grid) if isinstance(grid, tuple) else (grid, grid, grid))
     w.cm_remover = True
     base = {} if device is None else {"DeviceIndex": str(device)}
     one0, one1, _ = run(dict(base), w, %d if STEPS <= 20 else 0)                # single-rank run of the same box, on every rank
@@ -206,7 +206,7 @@ dist.destroy_process_group()
 
 
 def _run_dd_child(tmp_path, emulated, device, steps, port, nproc=2, cases=None, extra_cases="()", env=None):
-    """extra_cases: Python source of a tuple of further (label, workload, grid) cases; a grid >= 32 runs with tile spreading."""
+    """extra_cases: Python source of a tuple of further (label, workload, grid) cases; a cubic grid >= 32 runs with tile spreading, a tuple is (nx, ny, nz)."""
     script = tmp_path / "dd_child.py"
     text = DD_CHILD % (ROOT, emulated, device, extra_cases, steps, steps, emulated, steps)
     if cases is not None:
@@ -333,6 +333,22 @@ def test_two_rank_run_with_the_barostat_on_emulator(tmp_path):
     if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
         pytest.skip("emulated plugin not built (run __graft_entry__.build())")
     _run_dd_child(tmp_path, True, None, 6, 29577, cases='(("water, halo, barostat", T.with_barostat(T.water_box(8, seed=5), 1.0, 300.0, 2, 11), 24),)')
+
+
+def test_eight_rank_domain_decomposition_on_emulator(tmp_path):
+    """The decomposed step at the world size the scaling run uses (8 x-slabs): a 9.9 x 1.24 x 1.24 nm row of water boxes, 0.4 nm
+    cutoff, so every slab (1.24 nm) is wider than twice the halo and the run is in halo mode with half-shell evaluation -- ring
+    neighbours are six different pairs of ranks, second neighbours are never seen, the PME all-to-alls run among eight.  Same bar as
+    the two-rank runs: forces and trajectory of the single-rank run of the same box.  The PME grid is pinned (192 x 24 x 24): a decomposed
+    run rounds nx and ny up to multiples of the world size (HipKernels.cpp findLegalFftDimension), and two different grids differ by the
+    Ewald tolerance (1e-3 of the RMS force here), not by float32 noise."""
+    import pytest
+    from conftest import EMU_BUILD
+    if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
+        pytest.skip("emulated plugin not built (run __graft_entry__.build())")
+    out = _run_dd_child(tmp_path, True, None, 4, 29671, nproc=8, env={"OPENMM_HIP_DD_DRIFT": "0.03"},
+                        cases='(("water row, halo sections, half-shell, 8 ranks", T.water_row(4, 8, seed=5), (192, 24, 24)),)')
+    assert "domain [8, 1," in out, out[-1500:]            # eight ranks, halo mode
 
 
 def test_four_rank_domain_decomposition_on_emulator(tmp_path):

@@ -178,77 +178,141 @@ __global__ __launch_bounds__(PL_BLOCK) void pl_build(PairListArgs a) {
 #define PL_PARTNER(cur) ((cur) < rowEnd ? ((cur) - rowBegin < PL_ROW_LDS ? sRow[(cur) - rowBegin][t] : a.rowPos[cur]) : 0x7fffffff)
     int cursor = rowBegin;
     int next = PL_PARTNER(cursor);
-    int cnt = 0;
-    bool over = false;
+    int cnt = 0;                                   // partners found so far; what exceeds the sub-list's capacity is counted, not stored
+    bool tagOver = false;                          // a listed partner beyond the 126 that an entry can index
     int* const myList = a.list + (size_t) part * a.subcap * a.stride + g;
     const int numTiles = (a.numScan + PL_BLOCK - 1) / PL_BLOCK;
+    // A staged tile is four 32-slot blocks of the platform's spatial order -- compact clouds of ~0.7 nm.  Their bounding boxes (in the tile
+    // frame) let a wavefront leave out a whole block that none of its 64 owners can reach: the tile-against-tile test above passes ~6 000
+    // candidates per owner for the ~400 inside a 0.95 nm list radius, the block test brings that to ~1 500 (round 5).
+    // In the tile frame the tests run in FLOAT on structure-of-arrays copies (coordinates relative to the tile centre are a few nm: 2e-7 nm
+    // of rounding), two candidates per packed instruction, against the list radius widened by 1e-5 -- the list is a superset of the double
+    // one by a hair, and every consumer re-tests the cutoff in double anyway.  An empty position holds 1e30: it fails the test by itself.
+    __shared__ __attribute__((aligned(16))) float sxf[PL_BLOCK], syf[PL_BLOCK], szf[PL_BLOCK];
+    __shared__ float sbLo[PL_BLOCK / 32][3], sbHi[PL_BLOCK / 32][3];
+    const float xf = (float) xi.x, yf = (float) xi.y, zf = (float) xi.z;
+    const float radius2f = (float) (a.cutoff2 * (1.0 + 1e-5)), boxRadius2f = (float) (a.cutoff2 * (1.0 + 3e-5));
+    const bool floatFrame = tileFrame && a.cutoff2 >= 0.0;               // block-uniform
+    // the candidate tile after the current one is loaded while the current one is tested (a staging is two dependent global loads and
+    // the kernel runs at one or two wavefronts per SIMD: nothing else would cover them)
+    auto stage_load = [&](int tj) -> double4 {              // the loads only: what is done with them waits until the tile is its turn
+        const int j = pl_scan_atom(a, tj * PL_BLOCK + t);
+        double4 p = make_double4(0, 0, 0, -1.0);
+        if (j >= 0) { p = a.pos[j]; p.w = 1.0; }
+        return p;
+    };
     for (int chunk = 0; chunk < numTiles; chunk += PL_FAR_CHUNK) {
         // which tiles of this chunk are this workgroup's to look at: its share (every PL_PARTS-th) of those within reach -- all threads
         // test in parallel (one tile each per round) instead of every thread loading every tile's box in turn
         __syncthreads();
         for (int w = t; w < PL_FAR_CHUNK / 32; w += PL_BLOCK) sNear[w] = 0u;
         __syncthreads();
-        for (int tj = chunk + t; tj < min(chunk + PL_FAR_CHUNK, numTiles); tj += PL_BLOCK)
+        const int chunkTiles = min(PL_FAR_CHUNK, numTiles - chunk);
+        for (int tj = chunk + t; tj < chunk + chunkTiles; tj += PL_BLOCK)
             if (tj % PL_PARTS == part && !pl_tiles_far(a, tileI, tj)) atomicOr(&sNear[(tj - chunk) >> 5], 1u << ((tj - chunk) & 31));
         __syncthreads();
-        for (int w = 0; w < PL_FAR_CHUNK / 32; w++) {
-            unsigned bits = sNear[w];                                    // block-uniform
-            while (bits != 0u) {
-                const int b = __ffs((int) bits) - 1;
-                bits &= bits - 1u;
-                const int j0 = (chunk + w * 32 + b) * PL_BLOCK;
-                __syncthreads();
-                {
-                    const int j = pl_scan_atom(a, j0 + t);
-                    double4 p = make_double4(0, 0, 0, -1.0);
-                    if (j >= 0) {
-                        p = a.pos[j]; p.w = 1.0;
-                        if (tileFrame) {
-                            double dx = p.x - c.x, dy = p.y - c.y, dz = p.z - c.z;
-                            min_image_d(dx, dy, dz, a.box);
-                            p.x = dx; p.y = dy; p.z = dz;
-                        }
-                    }
-                    sj[t] = p;
+        const int words = (chunkTiles + 31) / 32;
+        int w = 0;
+        unsigned bits = sNear[0];                                        // block-uniform, as everything that steers the loop
+        auto next_tile = [&]() -> int {
+            while (bits == 0u) { if (++w >= words) return -1; bits = sNear[w]; }
+            const int b = __ffs((int) bits) - 1;
+            bits &= bits - 1u;
+            return chunk + w * 32 + b;
+        };
+        int tileJ = next_tile();
+        double4 staged = make_double4(0, 0, 0, -1.0);
+        if (tileJ >= 0) staged = stage_load(tileJ);
+        while (tileJ >= 0) {
+            const int j0 = tileJ * PL_BLOCK;
+            const int tileNext = next_tile();
+            if (tileFrame && staged.w >= 0.0) {
+                double dx = staged.x - c.x, dy = staged.y - c.y, dz = staged.z - c.z;
+                min_image_d(dx, dy, dz, a.box);
+                staged.x = dx; staged.y = dy; staged.z = dz;
+            }
+            __syncthreads();
+            sj[t] = staged;
+            if (floatFrame) {
+                const bool here = staged.w >= 0.0;
+                const float px = here ? (float) staged.x : 1e30f, py = here ? (float) staged.y : 1e30f, pz = here ? (float) staged.z : 1e30f;
+                sxf[t] = px; syf[t] = py; szf[t] = pz;
+                float lo[3] = {px, py, pz}, hi[3] = {here ? px : -1e30f, here ? py : -1e30f, here ? pz : -1e30f};
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1)
+#pragma unroll
+                    for (int d = 0; d < 3; d++) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], m)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], m)); }
+                if ((t & 31) == 0) for (int d = 0; d < 3; d++) { sbLo[t >> 5][d] = lo[d]; sbHi[t >> 5][d] = hi[d]; }
+            }
+            __syncthreads();
+            if (tileNext >= 0) staged = stage_load(tileNext);            // in flight during the tests below
+            tileJ = tileNext;
+            auto append = [&](int j) {
+                while (next < j) { cursor++; next = PL_PARTNER(cursor); }
+                int tag = 0;
+                if (next == j) {
+                    if (a.excludeListed) return;
+                    tag = cursor - rowBegin + 1;
+                    if (tag > PL_MAX_ROW) tagOver = true;
                 }
-                __syncthreads();
-                if (!active) continue;
-                const int nj = min(PL_BLOCK, a.numScan - j0);
-                // four candidates per round: their LDS reads are in flight together and the distance tests are straight-line code (one
-                // candidate per round is a chain of read -> wait -> compare -> branch, with nothing to overlap it at two waves per SIMD)
-                for (int k = 0; k < nj; k += 4) {
-                    double4 p[4];
+                if (cnt < a.subcap && !(a.debug & 2)) myList[(size_t) cnt * a.stride] = j | (tag << 24);          // (debug 2: profiling without the stores)
+                cnt++;
+            };
+            if (floatFrame) {
+                const v2f x2 = bc2(xf), y2 = bc2(yf), z2 = bc2(zf);
+                const int self = j0 == tileI * PL_BLOCK ? t : -1;       // the own position, when the own tile is the candidate
+                for (int kb = 0; kb < PL_BLOCK; kb += 32) {
+                    // distance from the own atom to the block's box: no owner of this wavefront within the list radius -> the block is left out
+                    const int sb = kb >> 5;
+                    const float gx = fmaxf(fmaxf(sbLo[sb][0] - xf, xf - sbHi[sb][0]), 0.f), gy = fmaxf(fmaxf(sbLo[sb][1] - yf, yf - sbHi[sb][1]), 0.f),
+                                gz = fmaxf(fmaxf(sbLo[sb][2] - zf, zf - sbHi[sb][2]), 0.f);
+                    if (!__any(active && r2_of(gx, gy, gz) <= boxRadius2f)) continue;          // (every lane takes part: wave-uniform control flow)
+                    // eight candidates per round, two per packed instruction; the partners in the block as a bit mask, appended in ascending order
+                    // (one append loop per block, not per round: a wavefront runs it as often as its busiest lane has partners)
+                    unsigned blockMask = 0u;
 #pragma unroll
-                    for (int u = 0; u < 4; u++) p[u] = sj[min(k + u, PL_BLOCK - 1)];
-                    bool inside[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int j = j0 + k + u;
-                        inside[u] = k + u < nj && j != g && p[u].w >= 0.0;
-                        if (a.cutoff2 >= 0.0) {
-                            double dx = p[u].x - xi.x, dy = p[u].y - xi.y, dz = p[u].z - xi.z;
-                            if (!tileFrame) min_image_d(dx, dy, dz, a.box);
-                            inside[u] = inside[u] && !(dx * dx + dy * dy + dz * dz > a.cutoff2);
-                        }
+                    for (int k = kb; k < kb + 32; k += 8) {
+                        const float4 xa = *(const float4*) &sxf[k], xb = *(const float4*) &sxf[k + 4], ya = *(const float4*) &syf[k], yb = *(const float4*) &syf[k + 4],
+                                     za = *(const float4*) &szf[k], zb = *(const float4*) &szf[k + 4];
+                        const v2f d0 = r2_of(mk2(xa.x, xa.y) - x2, mk2(ya.x, ya.y) - y2, mk2(za.x, za.y) - z2), d1 = r2_of(mk2(xa.z, xa.w) - x2, mk2(ya.z, ya.w) - y2, mk2(za.z, za.w) - z2),
+                                  d2 = r2_of(mk2(xb.x, xb.y) - x2, mk2(yb.x, yb.y) - y2, mk2(zb.x, zb.y) - z2), d3 = r2_of(mk2(xb.z, xb.w) - x2, mk2(yb.z, yb.w) - y2, mk2(zb.z, zb.w) - z2);
+                        unsigned mask = (d0.x <= radius2f ? 1u : 0u) | (d0.y <= radius2f ? 2u : 0u) | (d1.x <= radius2f ? 4u : 0u) | (d1.y <= radius2f ? 8u : 0u)
+                                      | (d2.x <= radius2f ? 16u : 0u) | (d2.y <= radius2f ? 32u : 0u) | (d3.x <= radius2f ? 64u : 0u) | (d3.y <= radius2f ? 128u : 0u);
+                        blockMask |= mask << (k - kb);
                     }
-                    if ((a.debug & 1) && p[0].x != 12345.0) continue;          // profiling: no appends
-                    if (!(inside[0] || inside[1] || inside[2] || inside[3])) continue;
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (!inside[u]) continue;
-                        const int j = j0 + k + u;
-                        while (next < j) { cursor++; next = PL_PARTNER(cursor); }
-                        int tag = 0;
-                        if (next == j) {
-                            if (a.excludeListed) continue;
-                            tag = cursor - rowBegin + 1;
-                            if (tag > PL_MAX_ROW) over = true;
-                        }
-                        if (cnt < a.subcap && !(a.debug & 2)) myList[(size_t) cnt * a.stride] = j | (tag << 24);          // (debug 2: profiling without the stores)
-                        else over = true;
-                        cnt++;
+                    if ((unsigned) (self - kb) < 32u) blockMask &= ~(1u << (self - kb));
+                    if (!active || (a.debug & 1)) blockMask = 0u;                                 // (debug 1: profiling without the appends)
+                    while (blockMask != 0u) {
+                        const int u = __ffs((int) blockMask) - 1;
+                        blockMask &= blockMask - 1u;
+                        append(j0 + kb + u);
                     }
                 }
+                continue;
+            }
+            // boxes the tile frame does not serve (triclinic, or a tile too large for the box), and the scan without a cutoff: double, every pair
+            // reduced to its nearest image; four candidates per round
+            const int nj = min(PL_BLOCK, a.numScan - j0);
+            for (int k = 0; k < nj; k += 4) {
+                double4 p[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) p[u] = sj[min(k + u, PL_BLOCK - 1)];
+                bool inside[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int j = j0 + k + u;
+                    inside[u] = active && k + u < nj && j != g && p[u].w >= 0.0;
+                    if (a.cutoff2 >= 0.0) {
+                        double dx = p[u].x - xi.x, dy = p[u].y - xi.y, dz = p[u].z - xi.z;
+                        if (!tileFrame) min_image_d(dx, dy, dz, a.box);
+                        inside[u] = inside[u] && !(dx * dx + dy * dy + dz * dz > a.cutoff2);
+                    }
+                }
+                if ((a.debug & 1) && p[0].x != 12345.0) continue;          // profiling: no appends
+                if (!(inside[0] || inside[1] || inside[2] || inside[3])) continue;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (inside[u]) append(j0 + k + u);
             }
         }
     }
@@ -257,7 +321,8 @@ __global__ __launch_bounds__(PL_BLOCK) void pl_build(PairListArgs a) {
     if (a.trace != nullptr && threadIdx.x == 0) a.trace[3 * blockIdx.x + 1] = (long long) wall_clock64();
 #endif
     if (g < a.numScan) a.count[(size_t) part * a.stride + g] = min(cnt, a.subcap);
-    if (over) atomicMax(a.overflow, cnt > a.subcap ? cnt : 0x7fffffff);       // the sub-list length that would have been enough (or: a row too long to index)
+    if (cnt > a.subcap) atomicMax(a.overflow, cnt);                           // the sub-list length that would have been enough
+    if (tagOver) atomicMax(a.overflow, 0x7fffffff);                           // or: a row too long to index
 }
 
 }  // namespace

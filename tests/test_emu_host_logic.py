@@ -436,6 +436,20 @@ def test_amoeba_water_box_tile_scan_against_reference_kernel_and_full_scan(tmp_p
 
 
 @needs_emu
+def test_amoeba_list_builder_leaves_out_blocks_in_the_tile_frame(tmp_path):
+    """3 000-atom AMOEBA water box (3.1 nm: every tile's half extent + list radius stays below half the box, so the builder works in the
+    tile frame -- candidates moved once to the image nearest to the owner tile, 32-slot blocks that no owner of a wavefront can reach left
+    out by their bounding boxes, round 5): the same forces as the scan over all atoms, to the last bit of the fixed-point sums."""
+    from amoeba_water_case import run_amoeba_water_case
+    r = run_amoeba_water_case(tmp_path, True, 10, 40, False, vdw_cutoff=0.8, with_reference=False)
+    print(r)
+    assert r["full_scan"][0] < 1e-9 and r["full_scan"][1] < 1e-12
+    # the same with lists that start at 8 entries per atom: the builder reports what would have fitted, the plugin grows them
+    r = run_amoeba_water_case(tmp_path, True, 10, 40, False, vdw_cutoff=0.8, with_reference=False, tiles_env={"OPENMM_HIP_AMOEBA_PAIR_CAP": "8"})
+    assert r["full_scan"][0] < 1e-9 and r["full_scan"][1] < 1e-12
+
+
+@needs_emu
 def test_amoeba_dynamics_with_list_skin_and_predicted_dipoles_walks_the_same_trajectory(tmp_path):
     """Eight Verlet steps of a relaxed 375-atom AMOEBA water box (mutual polarization to 1e-6 D) on the emulator: lists with a Verlet skin
     rebuilt on displacement + the solver started from dipoles extrapolated from earlier steps + convergence decided on the device, against

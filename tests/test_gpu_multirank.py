@@ -143,7 +143,7 @@ if rank == 0:
     print("water-1M on %%d ranks: force max-rel-err over the sampled atoms %%.3g (away from %%d edge pairs: %%.3g), E %%.3f vs %%.3f" %% (
         world, p["max_rel_err_all_atoms"], p["cutoff_edge_pairs"], p["max_rel_err"], st.potentialEnergy, float(g["energy"])), flush=True)
 assert p["max_rel_err_all_atoms"] < 1e-4
-assert info[1] == 1 and info[3] < world * info[2], ("four 5.3 nm slabs: halo exchange expected", info)
+assert info[1] == 1 and info[3] < world * info[2], ("slabs of 5.3 nm (4 ranks) or 2.7 nm (8): halo exchange expected", info)
 assert info[7] > 1, ("half-shell evaluation expected", info)
 if rank == 0:
     print("domain:", info, flush=True)
@@ -154,17 +154,20 @@ dist.destroy_process_group()
 '''
 
 
-def test_million_atom_box_on_four_ranks_matches_the_reference_golden(tmp_path):
-    """BASELINE.json configs[3] through the decomposed path: the 985 527-atom box on four ranks (sharing this GPU, collectives over
-    gloo) against the sampled Reference-platform golden -- the same bar as the single-GPU test."""
+@pytest.mark.parametrize("world", [4, 8])
+def test_million_atom_box_on_several_ranks_matches_the_reference_golden(tmp_path, world):
+    """BASELINE.json configs[3] through the decomposed path: the 985 527-atom box on four and on eight ranks (sharing this GPU,
+    collectives over gloo; eight 2.7 nm slabs are the decomposition the scaling run uses) against the sampled Reference-platform
+    golden -- the same bar as the single-GPU test."""
     import subprocess
     import sys
     from conftest import ROOT
     script = tmp_path / "golden_child.py"
     script.write_text(GOLDEN_CHILD % (ROOT, ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
-                          "--master-port", "29571", str(script)], capture_output=True, text=True, timeout=1500, env=env)
+    port = str(29571 + world)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                          "--master-port", port, str(script)], capture_output=True, text=True, timeout=1500, env=env)
     assert "OK" in out.stdout, out.stdout[-3000:] + out.stderr[-4000:]
     print(out.stdout)
 

@@ -178,6 +178,12 @@ typedef struct ommhip_amoeba_multipole {
                                     * pairs stay in double) -- the "mixed" mode of the reference's GPU platforms; 0: everything in double */
     int expected_iterations;       /* iterations the previous solve took (0 = unknown): that many minus one are enqueued before the host first waits for the
                                     * convergence measure, which the device forms itself; status[1] reports what this call took */
+    /* Optional hook (NULL = none): called once per call of ommhip_amoeba_multipole_forces, on the calling thread, after the pair-list build and the
+     * work that does not need the lists (frames, reciprocal potential of the permanent multipoles) have been ENQUEUED on `stream` and before the
+     * host waits for the build's overflow word.  A caller with independent work for another stream (the platform's AmoebaVdwForce, whose own list
+     * build ends in a host wait as well) launches it here, so that the two builds run side by side instead of one after the other. */
+    void (*after_lists_enqueued)(void* arg);
+    void* after_lists_arg;
 } ommhip_amoeba_multipole;
 
 /* Whole evaluation: frames -> reciprocal and real-space field -> induced dipoles -> energy, forces, torques -> forces. */

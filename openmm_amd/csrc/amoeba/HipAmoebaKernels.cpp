@@ -499,7 +499,16 @@ double HipCalcAmoebaMultipoleForceKernel::execute(ContextImpl& context, bool inc
     hip.setAsCurrent();
     prepareGrid();
     hip.ensureCleared();
-    hip.launchEarlyWork(context, includeForces, includeEnergy);       // the solver below waits for the device: what other forces have to launch goes first
+    // What other forces have to launch goes before the solver (which waits for the device) -- and, since round 5, AFTER this force's list build and
+    // list-free work have been enqueued: the call below hands control back through `after_lists_enqueued` at that point.  The AmoebaVdwForce's
+    // launch ends in a host wait for its own list build on the side stream; the two builds now run side by side.  The side stream waits for the
+    // fork point recorded here (the cleared force buffer), not for what this force enqueues in between.
+    struct EarlyLaunch { HipContext* hip; ContextImpl* context; bool forces, energy; } early = {&hip, &context, includeForces, includeEnergy};
+    static const bool earlyFirst = getenv("OPENMM_HIP_AMOEBA_EARLY_FIRST") != NULL;       // A/B: the order before round 5
+    if (earlyFirst) hip.launchEarlyWork(context, includeForces, includeEnergy);
+    else hip.preparePmeFork();
+    mp.after_lists_enqueued = [](void* arg) { EarlyLaunch* e = (EarlyLaunch*) arg; e->hip->launchEarlyWork(*e->context, e->forces, e->energy); };
+    mp.after_lists_arg = &early;
     setScanOrder();
     chooseFirstGuess();
     int rc;
@@ -509,6 +518,9 @@ double HipCalcAmoebaMultipoleForceKernel::execute(ContextImpl& context, bool inc
         if (!growPairList(rc, attempt)) break;        // -2: the pair lists did not fit (they are built before anything is added to the forces)
         setScanOrder();
     }
+    mp.after_lists_enqueued = NULL; mp.after_lists_arg = NULL;
+    hip.launchEarlyWork(context, includeForces, includeEnergy);       // (already launched unless the call failed before its hook)
+    hip.pmeForkRecorded = false;
     if (rc == 0 || rc == -1) listBuilt();
     checkSolver(rc);
     recordSolve();

@@ -1356,7 +1356,8 @@ int spread_blocks(const MpArgs& a) { return (int) (((size_t) a.n * MP_SPREAD_LAN
 int scan_blocks(const MpArgs& a) { return (int) (((size_t) a.numScan * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK); }
 
 // the pair lists of this evaluation (amoeba_pairs.h); -2: the lists did not fit into pair_cap entries per atom (*pair_needed says how many would)
-int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st) {
+template <class Between>
+int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st, Between between) {
     PairListArgs p;
     p.n = a.n; p.numScan = a.numScan; p.subcap = a.listSubcap; p.stride = a.numScan; p.excludeListed = 0;
     static const bool noTiles = getenv("OPENMM_HIP_AMOEBA_NO_TILES") != nullptr;         // A/B knob: the builder looks at every tile
@@ -1373,21 +1374,29 @@ int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const d
         const double radius = mp->cutoff + mp->skin;
         p.cutoff2 = radius * radius; p.refPos = (double4*) mp->ref_pos; p.state = mp->list_state; p.skinHalf2 = 0.25 * mp->skin * mp->skin; p.forceRebuild = mp->force_rebuild != 0;
     }
-    return pl_launch(p, mp->pair_needed, st, mp->list_builds);
+    return pl_launch(p, mp->pair_needed, st, mp->list_builds, between);
 }
+int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st) { return build_pair_lists(mp, a, box, st, [] {}); }
 
 // frames, reciprocal potential of the permanent multipoles, fields and induced dipoles
-int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st) {
+int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st, bool hook = false) {
     const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
-    const int rc = build_pair_lists(mp, a, box, st);
+    // Frames and the reciprocal potential of the permanent multipoles need no lists: they are enqueued behind the builder's kernels BEFORE the
+    // host waits for the builder's overflow word (the device goes on while the host waits, and the caller's hook -- the platform launches its
+    // AmoebaVdwForce there, whose own list build then runs beside this one -- gets its turn).  A call that returns -2 has written work arrays only.
+    static const bool hookFirst = getenv("OPENMM_HIP_AMOEBA_HOOK_LAST") == nullptr;       // A/B
+    const int rc = build_pair_lists(mp, a, box, st, [&] {
+        if (hook && mp->after_lists_enqueued != nullptr && hookFirst) mp->after_lists_enqueued(mp->after_lists_arg);
+        const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
+        const size_t gridBytes = sizeof(float) * (size_t) a.nx * a.ny * a.nz;
+        hipLaunchKernelGGL(k_mp_frames, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
+        hipMemsetAsync(a.grid, 0, gridBytes, st);
+        hipLaunchKernelGGL(k_mp_spread<false>, dim3(spread_blocks(a)), dim3(256), 0, st, a, (const double*) nullptr, 0.0, (const double*) nullptr, 0.0);
+        ommhip_pme_convolve(pme, st);
+        hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phi, (double*) nullptr);
+        if (hook && mp->after_lists_enqueued != nullptr && !hookFirst) mp->after_lists_enqueued(mp->after_lists_arg);
+    });
     if (rc != 0) return rc;
-    const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
-    const size_t gridBytes = sizeof(float) * (size_t) a.nx * a.ny * a.nz;
-    hipLaunchKernelGGL(k_mp_frames, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
-    hipMemsetAsync(a.grid, 0, gridBytes, st);
-    hipLaunchKernelGGL(k_mp_spread<false>, dim3(spread_blocks(a)), dim3(256), 0, st, a, (const double*) nullptr, 0.0, (const double*) nullptr, 0.0);
-    ommhip_pme_convolve(pme, st);
-    hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phi, (double*) nullptr);
     if (mp->mixed_precision) {
         hipLaunchKernelGGL(k_mp_special<false>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, st, a);
         hipLaunchKernelGGL(k_mp_field<true>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
@@ -1598,7 +1607,7 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
     hipStream_t st = (hipStream_t) stream;
     const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
     const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
-    { const int rc = launch_induce(mp, a, box, st); if (rc != 0) return rc; }
+    { const int rc = launch_induce(mp, a, box, st, true); if (rc != 0) return rc; }
     if (a.mutual) { const int rc = solve_mutual(mp, a, st); if (rc != 0) return rc; }      // -1: not converged
     else {
         if (mp->extrapolation_orders > 0) { const int rc = solve_extrapolated(mp, a, st); if (rc != 0) return rc; }

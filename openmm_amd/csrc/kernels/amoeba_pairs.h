@@ -343,7 +343,10 @@ __device__ __forceinline__ int pl_at(const int* list, int stride, int subcap, co
 
 // Host side: re-key the rows, bound the tiles, build the list.  Returns 0, a hipError_t, or -2 when the list did not fit
 // (*needed = the longest list, or 0x7fffffff when a row of listed partners is too long to index).  `overflowHost` = pinned or plain host int.
-static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st, int* buildsHost = nullptr) {
+// `between` (optional) runs after the builder's kernels have been enqueued and before the host waits for the overflow word: work that does not
+// need the lists goes there, on this stream or another.
+template <class Between>
+static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st, int* buildsHost, Between between) {
     if (a.numScan > PL_POS_MASK) return 1;
     static const int debugMode = getenv("OPENMM_HIP_PL_DEBUG") != nullptr ? atoi(getenv("OPENMM_HIP_PL_DEBUG")) : 0;     // profiling only: wrong results
     a.debug = debugMode;
@@ -377,6 +380,7 @@ static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st, int* bu
         free(h);
     }
 #endif
+    between();
     int over = 0;
     hipError_t e = hipMemcpyAsync(&over, a.overflow, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess && buildsHost != nullptr && a.state != nullptr) e = hipMemcpyAsync(buildsHost, a.state + 2, sizeof(int), hipMemcpyDeviceToHost, st);      // diagnostics: builds so far
@@ -385,6 +389,7 @@ static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st, int* bu
     if (over != 0) { if (needed != nullptr) *needed = over == 0x7fffffff ? over : over * PL_PARTS; return -2; }       // in entries per atom, as the caller sizes the list
     return 0;
 }
+static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st, int* buildsHost = nullptr) { return pl_launch(a, needed, st, buildsHost, [] {}); }
 
 }  // namespace omm
 #endif

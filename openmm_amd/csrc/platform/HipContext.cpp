@@ -384,8 +384,15 @@ void HipContext::ensureCleared() {
 }
 
 void HipContext::forkPme() {
-    HIP_CHECK(ommhip_event_record(pmeForkEvent, stream));
+    // (a fork point recorded earlier -- preparePmeFork -- stands: the side stream then waits for what the main stream held THEN)
+    if (!pmeForkRecorded) HIP_CHECK(ommhip_event_record(pmeForkEvent, stream));
+    pmeForkRecorded = false;
     HIP_CHECK(ommhip_stream_wait_event(pmeStream, pmeForkEvent));
+}
+
+void HipContext::preparePmeFork() {
+    HIP_CHECK(ommhip_event_record(pmeForkEvent, stream));
+    pmeForkRecorded = true;
 }
 
 void HipContext::markPmeDone() {

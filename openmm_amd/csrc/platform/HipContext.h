@@ -109,6 +109,10 @@ public:
     void* pmeStream;
     bool usePmeStream;
     void forkPme();
+    /** Records the fork point NOW; the next forkPme() waits for this point instead of recording its own -- for work that is enqueued on the main
+     *  stream before the side stream's work is launched but does not have to precede it (the AMOEBA multipole list build, HipAmoebaKernels.cpp). */
+    void preparePmeFork();
+    bool pmeForkRecorded = false;
     void markPmeDone();
     void joinPme();
     void addTerms(const ommhip_term_batch& batch, bool includeEnergy, int id = -1);

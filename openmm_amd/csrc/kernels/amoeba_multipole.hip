@@ -371,7 +371,10 @@ __global__ void k_mp_spread(MpArgs a, const double* __restrict__ A, double sA, c
 #define MPB_ZS (MPB_BRICK + 1)
 __device__ __forceinline__ int mpb_wrap_rel(int d, int n) { if (d >= (n + 1) / 2) d -= n; if (d < -(n / 2)) d += n; return d; }
 
-__global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double* __restrict__ A, double sA, const double* __restrict__ B, double sB, const double* __restrict__ A2) {
+// cgw (optional, two-grid launches of the solver): the solver's work vectors -- the dipoles to spread are the NEW search direction p = z + b p,
+// formed here per atom, stored, and packed for k_mp_dipole_field's gather (k_mp_cg stage 3 as a launch of its own otherwise); b = sums[8 + set],
+// left by the last block of stage 7.
+__global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double* __restrict__ A, double sA, const double* __restrict__ B, double sB, const double* __restrict__ A2, double* cgw) {
     if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;           // an iteration enqueued ahead of the convergence check (solve_mutual)
     // two-grid launch: the second set of dipoles onto the second grid (the argument struct itself is left alone: a modified copy would
     // move all of it from scalar kernel-argument loads to private memory)
@@ -402,7 +405,16 @@ __global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double
                 for (int m = 0; m < 5; m++) { th[atom][k][m] = (float) w4[0][m]; dth[atom][k][m] = (float) w4[1][m]; }
             }
             else {
-                const V3 mu = sA * load3(A, i) + (B != nullptr ? sB * load3(B, i) : v3(0, 0, 0));
+                V3 mu;
+                if (cgw != nullptr) {
+                    const size_t n3 = 3 * (size_t) a.n;
+                    const int set = blockIdx.y;
+                    double* const pv = cgw + (4 + set) * n3;
+                    mu = load3(cgw + (2 + set) * n3, i) + cgw[8 * n3 + 8 + set] * load3(pv, i);
+                    store3(pv, i, mu);
+                    if (a.gather != nullptr) { float* v = a.gather + 6 * (size_t) (g0 + atom) + 3 * set; v[0] = (float) mu.x; v[1] = (float) mu.y; v[2] = (float) mu.z; }
+                }
+                else mu = sA * load3(A, i) + (B != nullptr ? sB * load3(B, i) : v3(0, 0, 0));
                 float sum = 0.f;
                 for (int c = 0; c < 3; c++) { const float f = (float) (a.a[c][0] * mu.x + a.a[c][1] * mu.y + a.a[c][2] * mu.z); fd[atom][c] = f; sum += fabsf(f); }
                 atomicMax((int*) &sMax, __float_as_int(sum));          // non-negative floats order like their bit patterns
@@ -1141,6 +1153,8 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double target, double un
     }
     if (stage != 0 && sums[10] != 0.0) return;
     double cD = 0.0, cP = 0.0;
+    const bool closing = stage == 7;          // stage 2 that also ends the iteration (the direction update rides in the next spreading launch)
+    if (closing) stage = 2;
     if (stage == 2) { cD = sums[2] != 0.0 ? sums[0] / sums[2] : 0.0; cP = sums[3] != 0.0 ? sums[1] / sums[3] : 0.0; }
     if (stage == 3) { cD = sums[0] != 0.0 ? sums[6] / sums[0] : 0.0; cP = sums[1] != 0.0 ? sums[7] / sums[1] : 0.0; }
     __shared__ double red[4][MP_CG_BLOCK / 64];
@@ -1180,7 +1194,7 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double target, double un
             }
         }
     }
-    if (stage == 3 && a.clearGrids) {
+    if ((stage == 3 || closing) && a.clearGrids) {
         // the two grids are dead between the read-back of this iteration's potentials and the spreading of the next one: zeroed here, not
         // by a launch of their own in front of the spreading
         const size_t quads = (size_t) a.nx * a.ny * a.nz / 4, total = (size_t) gridDim.x * blockDim.x;
@@ -1217,6 +1231,25 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double target, double un
         if (stage == 1) { atomicAdd(&sums[2], s0); atomicAdd(&sums[3], s1); }
         else if (stage == 2) { atomicAdd(&sums[6], s0); atomicAdd(&sums[7], s1); atomicAdd(&sums[4], s2); atomicAdd(&sums[5], s3); }
         else { atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); atomicAdd(&sums[4], s2); atomicAdd(&sums[5], s3); }
+        if (closing) {
+            // The block that finishes last ends the iteration: b = r'.z' / r.z for the direction update (k_mp_spread_bricks reads it), the
+            // sums rolled over, the convergence measure and word.  The four accumulators are being added to by THIS launch -- at the memory
+            // side, while this XCD's L2 may hold a line of them from the loads above: they are read, and cleared, by exchanges.
+            __threadfence();
+            const unsigned ticket = atomicAdd((unsigned*) &sums[14], 1u);
+            if (ticket == gridDim.x - 1) {
+                *(unsigned*) &sums[14] = 0u;
+                const double rzD = __longlong_as_double((long long) atomicExch((unsigned long long*) &sums[6], 0ull)), rzP = __longlong_as_double((long long) atomicExch((unsigned long long*) &sums[7], 0ull));
+                const double zzD = __longlong_as_double((long long) atomicExch((unsigned long long*) &sums[4], 0ull)), zzP = __longlong_as_double((long long) atomicExch((unsigned long long*) &sums[5], 0ull));
+                sums[8] = sums[0] != 0.0 ? rzD / sums[0] : 0.0; sums[9] = sums[1] != 0.0 ? rzP / sums[1] : 0.0;
+                sums[0] = rzD; sums[1] = rzP; sums[11] += 1.0;
+                sums[2] = sums[3] = 0.0;
+                const double eps = debye * sqrt(fmax(zzD, zzP) / a.n);
+                sums[12] = eps;
+                __threadfence();
+                if (eps < target) sums[10] = 1.0;
+            }
+        }
     }
 }
 
@@ -1410,7 +1443,7 @@ int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const doub
 void spread_induced(const MpArgs& a, const double* A, double sA, const double* B, double sB, hipStream_t st) {
     static const bool noBricks = getenv("OPENMM_HIP_AMOEBA_NO_BRICKS") != nullptr;
     if (a.order != nullptr && !noBricks && a.nx >= MPB_BRICK && a.ny >= MPB_BRICK && a.nz >= MPB_BRICK)
-        hipLaunchKernelGGL(k_mp_spread_bricks, dim3((a.numScan + MPB_ATOMS - 1) / MPB_ATOMS), dim3(256), 0, st, a, A, sA, B, sB, (const double*) nullptr);
+        hipLaunchKernelGGL(k_mp_spread_bricks, dim3((a.numScan + MPB_ATOMS - 1) / MPB_ATOMS), dim3(256), 0, st, a, A, sA, B, sB, (const double*) nullptr, (double*) nullptr);
     else
         hipLaunchKernelGGL(k_mp_spread<true>, dim3(spread_blocks(a)), dim3(256), 0, st, a, A, sA, B, sB);
 }
@@ -1441,7 +1474,7 @@ bool two_grid_launches(const ommhip_amoeba_multipole* mp, const MpArgs& a) {
 }
 
 // precleared: both grids are zero already (k_mp_cg stage 3 of the iteration before, two-grid launches only: two_grid_launches())
-void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double* vD, double* outD, const double* vP, double* outP, hipStream_t st, bool fieldOnlyFlag = false, int maxOrder = 0, bool precleared = false) {
+void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double* vD, double* outD, const double* vP, double* outP, hipStream_t st, bool fieldOnlyFlag = false, int maxOrder = 0, bool precleared = false, double* cgw = nullptr) {
     const int fieldOnly = maxOrder > 0 ? maxOrder : (fieldOnlyFlag ? 1 : 3);
     const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
     const ommhip_pme* pme2 = (const ommhip_pme*) mp->pme2;
@@ -1459,7 +1492,7 @@ void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const
         if (precleared) { }
         else if ((gridBytes & 15) == 0) ommhip_clear2(b.grid, gridBytes, b.grid2, gridBytes, (void*) st);          // both grids in one launch
         else { hipMemsetAsync(b.grid, 0, gridBytes, st); hipMemsetAsync(b.grid2, 0, gridBytes, st); }
-        hipLaunchKernelGGL(k_mp_spread_bricks, dim3((a.numScan + MPB_ATOMS - 1) / MPB_ATOMS, 2), dim3(256), 0, st, b, vD, 1.0, (const double*) nullptr, 0.0, vP);
+        hipLaunchKernelGGL(k_mp_spread_bricks, dim3((a.numScan + MPB_ATOMS - 1) / MPB_ATOMS, 2), dim3(256), 0, st, b, vD, 1.0, (const double*) nullptr, 0.0, vP, cgw);
         if (ommhip_pme_convolve2(pme, pme2, st) == 0) {
             if (fieldOnly == 1) hipLaunchKernelGGL(k_mp_potential<1>, dim3(spread_blocks(a), 2), dim3(256), 0, st, b, outD, outP);
             else if (fieldOnly == 2) hipLaunchKernelGGL(k_mp_potential<2>, dim3(spread_blocks(a), 2), dim3(256), 0, st, b, outD, outP);
@@ -1531,6 +1564,17 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st) {
     const bool clearInStage3 = two_grid_launches(mp, a) && !clearLaunch;
     MpArgs aClear = a;
     if (clearInStage3) { aClear.grid2 = (float*) ((const ommhip_pme*) mp->pme2)->grid_real; aClear.clearGrids = 1; }
+    // The direction update p = z + b p of iteration k rides in the spreading launch of iteration k + 1 (two-grid launches, no preconditioner):
+    // stage 7 = stage 2 + the grid clear + the end of the iteration; seven launches per iteration instead of eight.
+    static const bool noFold = getenv("OPENMM_HIP_AMOEBA_STAGE3_LAUNCH") != nullptr;       // A/B: stage 3 as its own launch
+    const bool fold = clearInStage3 && !a.precond && !noFold;
+    while (!done && enqueued < mp->max_iterations && fold) {
+        dipole_potentials(mp, a, pD, a.phiInd, pP, a.phiIndP, st, true, 0, enqueued > 0, enqueued > 0 ? w : nullptr);
+        hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP, w, 1);      // T p, Ap, p.Ap
+        hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, aClear, w, 7, mp->target_epsilon, 0.0);
+        enqueued++;
+        if (enqueued >= unchecked || enqueued == mp->max_iterations) { rc = readSums(); if (rc != 0) return rc; done = h[10] != 0.0; }
+    }
     while (!done && enqueued < mp->max_iterations) {
         dipole_potentials(mp, a, pD, a.phiInd, pP, a.phiIndP, st, true, 0, clearInStage3 && enqueued > 0);
         if (a.precond) {

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <sstream>
 #include <string>
 #include <map>
@@ -503,11 +504,16 @@ double HipCalcAmoebaMultipoleForceKernel::execute(ContextImpl& context, bool inc
     // list-free work have been enqueued: the call below hands control back through `after_lists_enqueued` at that point.  The AmoebaVdwForce's
     // launch ends in a host wait for its own list build on the side stream; the two builds now run side by side.  The side stream waits for the
     // fork point recorded here (the cleared force buffer), not for what this force enqueues in between.
-    struct EarlyLaunch { HipContext* hip; ContextImpl* context; bool forces, energy; } early = {&hip, &context, includeForces, includeEnergy};
+    struct EarlyLaunch { HipContext* hip; ContextImpl* context; bool forces, energy; std::exception_ptr error; } early = {&hip, &context, includeForces, includeEnergy, nullptr};
     static const bool earlyFirst = getenv("OPENMM_HIP_AMOEBA_EARLY_FIRST") != NULL;       // A/B: the order before round 5
     if (earlyFirst) hip.launchEarlyWork(context, includeForces, includeEnergy);
     else hip.preparePmeFork();
-    mp.after_lists_enqueued = [](void* arg) { EarlyLaunch* e = (EarlyLaunch*) arg; e->hip->launchEarlyWork(*e->context, e->forces, e->energy); };
+    mp.after_lists_enqueued = [](void* arg) {
+        // (an exception of the other force's launch -- "the periodic box size has decreased ..." -- does not travel through the C ABI: kept, rethrown below)
+        EarlyLaunch* e = (EarlyLaunch*) arg;
+        try { e->hip->launchEarlyWork(*e->context, e->forces, e->energy); }
+        catch (...) { if (!e->error) e->error = std::current_exception(); }
+    };
     mp.after_lists_arg = &early;
     setScanOrder();
     chooseFirstGuess();
@@ -519,8 +525,9 @@ double HipCalcAmoebaMultipoleForceKernel::execute(ContextImpl& context, bool inc
         setScanOrder();
     }
     mp.after_lists_enqueued = NULL; mp.after_lists_arg = NULL;
-    hip.launchEarlyWork(context, includeForces, includeEnergy);       // (already launched unless the call failed before its hook)
     hip.pmeForkRecorded = false;
+    if (early.error) std::rethrow_exception(early.error);
+    hip.launchEarlyWork(context, includeForces, includeEnergy);       // (already launched unless the call failed before its hook)
     if (rc == 0 || rc == -1) listBuilt();
     checkSolver(rc);
     recordSolve();

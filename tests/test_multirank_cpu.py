@@ -372,11 +372,11 @@ good = ("import os, torch, torch.distributed as dist\ndist.init_process_group('g
         "print('note'); print('{\"attempt\": %%s, \"port\": %%s, \"sum\": %%d}' %% (os.environ['BENCH_ATTEMPT'], os.environ['MASTER_PORT'], int(t.item())))")
 t0 = time.monotonic()
 idx, lines, notes = MR.run_attempts([[sys.executable, "-c", hang], [sys.executable, "-c", crash], [sys.executable, "-c", good]],
-                                    rank, world, "127.0.0.1", int(os.environ["MASTER_PORT"]), timeout_s=8.0)
+                                    rank, world, "127.0.0.1", int(os.environ["MASTER_PORT"]), timeout_s=20.0)      # (the good attempt imports torch: 8 s were not enough beside the 8-rank emulator test on 8 cores)
 took = time.monotonic() - t0
 out = json.loads([l for l in lines if l.startswith("{")][-1])
 assert idx == 2 and out["attempt"] == 2 and out["port"] == int(os.environ["MASTER_PORT"]) + 3 and out["sum"] == world, (idx, out)
-assert len(notes) == 2 and took < 30.0, (notes, took)
+assert len(notes) == 2 and took < 80.0, (notes, took)
 print("RANK", rank, "OK", notes, flush=True)
 """
 

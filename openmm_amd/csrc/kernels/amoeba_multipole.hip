@@ -1131,6 +1131,13 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double target, double un
     const double debye = 48.033324;          // AmoebaReferenceMultipoleForce::_debye
     if (stage == 4 || stage == 5) {
         // 5: after stage 0 (the measure of the first guess); 4: end of an iteration
+        if (stage == 5 && a.clearGrids) {
+            // (launched over all blocks then: the two grids zeroed for the spreading of the first iteration, as stage 3 / 7 do for the later ones)
+            const size_t quads = (size_t) a.nx * a.ny * a.nz / 4, total = (size_t) gridDim.x * blockDim.x;
+            float4* g0 = (float4*) a.grid; float4* g1 = (float4*) a.grid2;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x; k < quads; k += total) { g0[k] = z; g1[k] = z; }
+        }
         if (i == 0 && sums[10] == 0.0) {
             if (stage == 4) { sums[0] = sums[6]; sums[1] = sums[7]; sums[11] += 1.0; }
             const double eps = debye * sqrt(fmax(sums[4], sums[5]) / a.n);
@@ -1551,25 +1558,32 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st) {
         hipLaunchKernelGGL(k_mp_precond, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, w, 1);
     }
     else hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, tD, tP, w, 0);
-    hipLaunchKernelGGL(k_mp_cg, dim3(1), dim3(64), 0, st, a, w, 5, mp->target_epsilon, 0.0);
-    if (a.gather != nullptr) hipLaunchKernelGGL(k_mp_pack, dim3(blocks), dim3(MP_BLOCK), 0, st, a, pD, pP);      // p of the first iteration (later ones: stage 3 writes the copy itself)
-    a.doneFlag = sums + 10;                   // from here on the kernels look at the convergence word
-    static const bool everyIteration = getenv("OPENMM_HIP_AMOEBA_CHECK_EVERY_ITERATION") != nullptr;       // A/B knob: one host round trip per iteration, as before
-    const int unchecked = everyIteration ? 0 : (mp->expected_iterations > 1 ? mp->expected_iterations - 1 : 0);
-    int rc = 0, enqueued = 0;
-    bool done = false;
-    if (unchecked == 0) { rc = readSums(); if (rc != 0) return rc; done = h[10] != 0.0; }
     // two-grid launches: stage 3 of every iteration leaves the grids zeroed for the spreading of the next one
     static const bool clearLaunch = getenv("OPENMM_HIP_AMOEBA_CLEAR_LAUNCH") != nullptr;   // A/B: the clear as its own launch
     const bool clearInStage3 = two_grid_launches(mp, a) && !clearLaunch;
     MpArgs aClear = a;
     if (clearInStage3) { aClear.grid2 = (float*) ((const ommhip_pme*) mp->pme2)->grid_real; aClear.clearGrids = 1; }
     // The direction update p = z + b p of iteration k rides in the spreading launch of iteration k + 1 (two-grid launches, no preconditioner):
-    // stage 7 = stage 2 + the grid clear + the end of the iteration; seven launches per iteration instead of eight.
+    // stage 7 = stage 2 + the grid clear + the end of the iteration; seven launches per iteration instead of eight.  The first iteration's
+    // spreading takes the same path with b = 0 (the sums start cleared): it packs p = z for the field kernel's gather, and stage 5 has
+    // zeroed the grids for it.
     static const bool noFold = getenv("OPENMM_HIP_AMOEBA_STAGE3_LAUNCH") != nullptr;       // A/B: stage 3 as its own launch
-    const bool fold = clearInStage3 && !a.precond && !noFold;
+    const bool fold = clearInStage3 && !a.precond && !noFold && a.gather != nullptr;
+    if (fold) hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, aClear, w, 5, mp->target_epsilon, 0.0);
+    else {
+        hipLaunchKernelGGL(k_mp_cg, dim3(1), dim3(64), 0, st, a, w, 5, mp->target_epsilon, 0.0);
+        if (a.gather != nullptr) hipLaunchKernelGGL(k_mp_pack, dim3(blocks), dim3(MP_BLOCK), 0, st, a, pD, pP);      // p of the first iteration (later ones: stage 3 writes the copy itself)
+    }
+    a.doneFlag = sums + 10;                   // from here on the kernels look at the convergence word
+    aClear.doneFlag = a.doneFlag;
+    static const bool everyIteration = getenv("OPENMM_HIP_AMOEBA_CHECK_EVERY_ITERATION") != nullptr;       // A/B knob: one host round trip per iteration, as before
+    static const int enqueueSlack = getenv("OPENMM_HIP_AMOEBA_ENQUEUE_SLACK") != nullptr ? atoi(getenv("OPENMM_HIP_AMOEBA_ENQUEUE_SLACK")) : 0;       // 0: as many as the last solve took (round 5; 1 before: -0.7 %, profiles/r11/r11ag_*)
+    const int unchecked = everyIteration ? 0 : (mp->expected_iterations > enqueueSlack ? mp->expected_iterations - enqueueSlack : 0);
+    int rc = 0, enqueued = 0;
+    bool done = false;
+    if (unchecked == 0) { rc = readSums(); if (rc != 0) return rc; done = h[10] != 0.0; }
     while (!done && enqueued < mp->max_iterations && fold) {
-        dipole_potentials(mp, a, pD, a.phiInd, pP, a.phiIndP, st, true, 0, enqueued > 0, enqueued > 0 ? w : nullptr);
+        dipole_potentials(mp, a, pD, a.phiInd, pP, a.phiIndP, st, true, 0, true, w);
         hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP, w, 1);      // T p, Ap, p.Ap
         hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, aClear, w, 7, mp->target_epsilon, 0.0);
         enqueued++;
@@ -1601,8 +1615,9 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st) {
     if (!noPolish) hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 6, 0.0, 0.0);
     if (haveHistory && mp->history_store >= 0)
         hipLaunchKernelGGL(k_mp_history, dim3(blocks), dim3(MP_BLOCK), 0, st, a, mp->history, mp->history_slots, mp->history_store % mp->history_slots, 0, 1, coeff);
-    // potentials of the converged dipoles (the force kernels read them)
-    dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st);
+    // potentials of the converged dipoles (the force kernels read them).  After a folded solve the grids are still zero: the stage 7 that found
+    // the convergence cleared them, and what was enqueued behind it has left at once (the transforms ran on zeros)
+    dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st, false, 0, fold && enqueued > 0);
     return 0;
 }
 

@@ -1,5 +1,5 @@
 // Per-atom pair lists of the AMOEBA kernels (amoeba.hip: vdW, amoeba_multipole.hip: multipoles): built for the cutoff plus a skin and
-// kept until some atom has moved by half the skin (the device decides: pl_check), the consumers re-testing the cutoff per pair.
+// kept until some atom has moved by half the skin (the device decides: pl_check_body in pl_prepare), the consumers re-testing the cutoff per pair.
 //
 // The AMOEBA pair terms are long (a multipole pair is three derivative chains with erfc / exp and ~1 000 double-precision operations), so
 // what matters is that a wavefront only ever executes them for pairs inside the cutoff.  A scan "one thread per atom i, every thread
@@ -43,7 +43,7 @@ struct PairListArgs {
     int* list; int* count; int* overflow;
     long long* trace;                              // profiling (OPENMM_HIP_PL_DEBUG & 4): per workgroup start and end clock, hardware id
     // Verlet skin (optional: state == nullptr rebuilds at every call).  cutoff2 above is then the LIST radius squared, (cutoff + skin)^2.
-    // state[0]: rebuild needed (pl_check: an atom moved more than skin / 2 since the positions in refPos, or the caller forces it),
+    // state[0]: rebuild needed (pl_prepare: an atom moved more than skin / 2 since the positions in refPos, or the caller forces it),
     // state[1]: ticket of pl_finish, state[2]: rebuilds so far.
     double4* refPos; int* state; double skinHalf2; int forceRebuild;
 };
@@ -71,8 +71,7 @@ __global__ void pl_sort_rows(PairListArgs a) {
 
 // Does the list have to be rebuilt?  One thread per atom: moved by more than half the skin since the list was built (plain displacement:
 // the atom-ordered positions are continuous between re-sorts; a jump by a box vector simply asks for a rebuild).
-__global__ void pl_check(PairListArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pl_check_body(const PairListArgs& a, int i) {
     if (i == 0 && a.forceRebuild) a.state[0] = 1;
     if (i >= a.n || a.forceRebuild) return;
     const double4 p = a.pos[i], r = a.refPos[i];
@@ -98,10 +97,13 @@ __global__ void pl_finish(PairListArgs a) {
 }
 
 // bounding boxes of the tiles (nearest images relative to the tile's first atom; a tile without atoms gets half extents of -1e30)
-__global__ __launch_bounds__(PL_BLOCK) void pl_tile_bounds(PairListArgs a) {
+// One launch in front of the builder (round 5; three before): workgroups [0, tiles) bound the tiles -- whether or not the list will be rebuilt:
+// that is being decided by the workgroups behind them, which look at the displacements (pl_check_body); thread 0 clears the overflow word.
+__global__ __launch_bounds__(PL_BLOCK) void pl_prepare(PairListArgs a, int tiles) {
     __shared__ double lo[3][PL_BLOCK], hi[3][PL_BLOCK];
     __shared__ int firstValid;
-    if (a.state != nullptr && a.state[0] == 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.overflow = 0;
+    if ((int) blockIdx.x >= tiles) { if (a.state != nullptr) pl_check_body(a, ((int) blockIdx.x - tiles) * PL_BLOCK + (int) threadIdx.x); return; }
     const int t = threadIdx.x, g = blockIdx.x * PL_BLOCK + t, i = pl_scan_atom(a, g);
     if (t == 0) firstValid = PL_BLOCK;
     __syncthreads();
@@ -350,13 +352,14 @@ static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st, int* bu
     if (a.numScan > PL_POS_MASK) return 1;
     static const int debugMode = getenv("OPENMM_HIP_PL_DEBUG") != nullptr ? atoi(getenv("OPENMM_HIP_PL_DEBUG")) : 0;     // profiling only: wrong results
     a.debug = debugMode;
-    hipMemsetAsync(a.overflow, 0, sizeof(int), st);
     if (a.state == nullptr || a.refPos == nullptr) { a.state = nullptr; a.refPos = nullptr; a.forceRebuild = 1; }
-    if (a.state != nullptr) hipLaunchKernelGGL(pl_check, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+    const int tiles = (a.numScan + PL_BLOCK - 1) / PL_BLOCK;
+    {
+        const int boundTiles = a.skipTiles ? tiles : 0, checkBlocks = a.state != nullptr ? (a.n + PL_BLOCK - 1) / PL_BLOCK : 0;
+        hipLaunchKernelGGL(pl_prepare, dim3(boundTiles + checkBlocks > 0 ? boundTiles + checkBlocks : 1), dim3(PL_BLOCK), 0, st, a, boundTiles);
+    }
     // the rows of listed partners depend on the slot order and the parameters only: the caller forces a rebuild when either changed
     if (a.rowStart != nullptr && a.forceRebuild) hipLaunchKernelGGL(pl_sort_rows, dim3((a.n + 127) / 128), dim3(128), 0, st, a);
-    const int tiles = (a.numScan + PL_BLOCK - 1) / PL_BLOCK;
-    if (a.skipTiles) hipLaunchKernelGGL(pl_tile_bounds, dim3(tiles), dim3(PL_BLOCK), 0, st, a);
     a.trace = nullptr;
 #ifndef OMMHIP_EMU
     static long long* traceBuf = nullptr;

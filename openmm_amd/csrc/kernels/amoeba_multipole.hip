@@ -200,6 +200,7 @@ struct MpArgs {
     const int* order; int numScan;
     const int* pairList; const int* pairCount; int listStride, listSubcap;
     int precond; double precondCut2;               // neighbour-pair preconditioner of the solver (needs the pair cache)
+    int specialAdds;                               // mixed precision: k_mp_forces<true> ran first and STORED its torques, k_mp_special<true> adds to them (0: the other way round)
     float* pairCache; int pairCap;                 // mutual polarization: per list entry (dx, dy, dz, b1, b2) of the Thole-damped dipole-dipole chain, float planes of pairCap * listStride
     float* gather;                                 // mutual polarization: the vectors the induced-dipole field is taken of, (vD, vP) as six floats per SCAN POSITION (k_mp_dipole_field gathers them)
     const double* doneFlag;                        // mutual polarization: sums[10] of the solver -- non-zero once the dipoles have converged: kernels of iterations enqueued ahead return at once
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_special(MpArgs a) {
         if (FORCES) {
             accA = OMM_ONE_4PI_EPS0_D * accA; accB = OMM_ONE_4PI_EPS0_D * accB; energy *= OMM_ONE_4PI_EPS0_D;
             reciprocal_and_self(a, i, Mi, udI, upI, energy, accA, accB);           // everything of the atom that is not a pair of the list
-            store3(a.torque, i, accB);
+            store3(a.torque, i, a.specialAdds ? accB + load3(a.torque, i) : accB);
             add_force(a.force, a.paddedAtoms, a.slotOfAtom[i], accA.x, accA.y, accA.z);
         }
         else { store3(a.fieldD, i, accA); store3(a.fieldP, i, accB); }
@@ -855,7 +856,7 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
         // pair quantities carry the Coulomb constant from here on
         force = OMM_ONE_4PI_EPS0_D * force; torque = OMM_ONE_4PI_EPS0_D * torque; energy *= OMM_ONE_4PI_EPS0_D;
         if (!MIXED) reciprocal_and_self(a, i, Mi, udI, upI, energy, force, torque);          // (MIXED: k_mp_special<true> has added them)
-        if (MIXED) torque = torque + load3(a.torque, i);          // the covalently related partners: k_mp_special<true>, launched before (Coulomb constant included)
+        if (MIXED && !a.specialAdds) torque = torque + load3(a.torque, i);          // the covalently related partners: k_mp_special<true>, launched before (Coulomb constant included) -- or behind, adding to these (specialAdds)
         store3(a.torque, i, torque);
         add_force(a.force, a.paddedAtoms, a.slotOfAtom[i], force.x, force.y, force.z);
     }
@@ -1385,6 +1386,7 @@ bool make_args(const ommhip_amoeba_multipole* mp, const void* pos_d, const doubl
     // per iteration -- no gain; the default stays z = alpha r
     static const bool usePrecond = getenv("OPENMM_HIP_AMOEBA_PRECOND") != nullptr && atoi(getenv("OPENMM_HIP_AMOEBA_PRECOND")) != 0;
     a.precond = a.pairCache != nullptr && usePrecond ? 1 : 0; a.precondCut2 = 0.45 * 0.45;
+    a.specialAdds = 0;
     a.doneFlag = nullptr;
     a.gather = a.mutual ? mp->solver_gather : nullptr;
     return true;
@@ -1421,26 +1423,39 @@ int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const d
 // frames, reciprocal potential of the permanent multipoles, fields and induced dipoles
 int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st, bool hook = false) {
     const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
-    // Frames and the reciprocal potential of the permanent multipoles need no lists: they are enqueued behind the builder's kernels BEFORE the
-    // host waits for the builder's overflow word (the device goes on while the host waits, and the caller's hook -- the platform launches its
-    // AmoebaVdwForce there, whose own list build then runs beside this one -- gets its turn).  A call that returns -2 has written work arrays only.
+    // Frames and the reciprocal potential of the permanent multipoles need no lists.  With the side stream of the mutual solver at hand
+    // (stream2, event_a / event_b; round 5) that chain -- clear, spread, three transform launches, read-back: ~110 us of small launches on
+    // DHFR -- runs BESIDE the list build (190 us at one or two wavefronts per SIMD) and the covalently-related pairs, and the main stream
+    // waits for it in front of the field kernel, whose last lines read the potential.  Without one it is enqueued behind the builder's kernels
+    // BEFORE the host waits for the builder's overflow word.  Either way the caller's hook -- the platform launches its AmoebaVdwForce there,
+    // whose own list build then runs beside this one -- gets its turn before that wait.  A call that returns -2 has written work arrays only.
     static const bool hookFirst = getenv("OPENMM_HIP_AMOEBA_HOOK_LAST") == nullptr;       // A/B
+    static const bool noSide = getenv("OPENMM_HIP_AMOEBA_RECIPROCAL_INLINE") != nullptr;   // A/B: the chain on the main stream
+    hipStream_t st2 = (hipStream_t) mp->stream2;
+    const bool side = !noSide && st2 != nullptr && mp->event_a != nullptr && mp->event_b != nullptr;
+    const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
+    auto reciprocal = [&](hipStream_t s) {
+        hipMemsetAsync(a.grid, 0, sizeof(float) * (size_t) a.nx * a.ny * a.nz, s);
+        hipLaunchKernelGGL(k_mp_spread<false>, dim3(spread_blocks(a)), dim3(256), 0, s, a, (const double*) nullptr, 0.0, (const double*) nullptr, 0.0);
+        ommhip_pme_convolve(pme, s);
+        hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, s, a, a.phi, (double*) nullptr);
+    };
+    hipLaunchKernelGGL(k_mp_frames, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
+    if (side) {
+        hipEventRecord((hipEvent_t) mp->event_a, st);                  // the lab-frame multipoles are there
+        hipStreamWaitEvent(st2, (hipEvent_t) mp->event_a, 0);
+        reciprocal(st2);
+        hipEventRecord((hipEvent_t) mp->event_b, st2);
+    }
     const int rc = build_pair_lists(mp, a, box, st, [&] {
         if (hook && mp->after_lists_enqueued != nullptr && hookFirst) mp->after_lists_enqueued(mp->after_lists_arg);
-        const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
-        const size_t gridBytes = sizeof(float) * (size_t) a.nx * a.ny * a.nz;
-        hipLaunchKernelGGL(k_mp_frames, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
-        hipMemsetAsync(a.grid, 0, gridBytes, st);
-        hipLaunchKernelGGL(k_mp_spread<false>, dim3(spread_blocks(a)), dim3(256), 0, st, a, (const double*) nullptr, 0.0, (const double*) nullptr, 0.0);
-        ommhip_pme_convolve(pme, st);
-        hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phi, (double*) nullptr);
+        if (!side) reciprocal(st);
         if (hook && mp->after_lists_enqueued != nullptr && !hookFirst) mp->after_lists_enqueued(mp->after_lists_arg);
     });
-    if (rc != 0) return rc;
-    if (mp->mixed_precision) {
-        hipLaunchKernelGGL(k_mp_special<false>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, st, a);
-        hipLaunchKernelGGL(k_mp_field<true>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
-    }
+    if (rc != 0) { if (side) hipStreamWaitEvent(st, (hipEvent_t) mp->event_b, 0); return rc; }      // (the side chain does not outlive the call)
+    if (mp->mixed_precision) hipLaunchKernelGGL(k_mp_special<false>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, st, a);
+    if (side) hipStreamWaitEvent(st, (hipEvent_t) mp->event_b, 0);     // the field kernel's last lines read the reciprocal potential
+    if (mp->mixed_precision) hipLaunchKernelGGL(k_mp_field<true>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
     else hipLaunchKernelGGL(k_mp_field<false>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
     return 0;
 }
@@ -1531,7 +1546,7 @@ void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const
 // been met, so the host enqueues mp->expected_iterations - 1 iterations (what the previous call needed; 0 = unknown) before it first waits
 // for the measure, then one at a time: two host round trips per solve instead of one per iteration.  (The FFT launches of an iteration
 // enqueued in vain -- the call needed fewer iterations than the one before -- still run, on cleared grids.)
-int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st) {
+int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bool finalOnSide = false) {
     const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
     const size_t n3 = 3 * (size_t) a.n;
     double* w = mp->solver;
@@ -1617,7 +1632,16 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st) {
         hipLaunchKernelGGL(k_mp_history, dim3(blocks), dim3(MP_BLOCK), 0, st, a, mp->history, mp->history_slots, mp->history_store % mp->history_slots, 0, 1, coeff);
     // potentials of the converged dipoles (the force kernels read them).  After a folded solve the grids are still zero: the stage 7 that found
     // the convergence cleared them, and what was enqueued behind it has left at once (the transforms ran on zeros)
-    dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st, false, 0, fold && enqueued > 0);
+    if (finalOnSide) {
+        // (round 5) on the solver's side stream: the caller runs the list pairs of the force kernel, which read no potential, beside this chain
+        // and waits for event_b in front of the kernel that does (ommhip_amoeba_multipole_forces)
+        hipStream_t st2 = (hipStream_t) mp->stream2;
+        hipEventRecord((hipEvent_t) mp->event_a, st);
+        hipStreamWaitEvent(st2, (hipEvent_t) mp->event_a, 0);
+        dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st2, false, 0, fold && enqueued > 0);
+        hipEventRecord((hipEvent_t) mp->event_b, st2);
+    }
+    else dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st, false, 0, fold && enqueued > 0);
     return 0;
 }
 
@@ -1667,7 +1691,12 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
     const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
     const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
     { const int rc = launch_induce(mp, a, box, st, true); if (rc != 0) return rc; }
-    if (a.mutual) { const int rc = solve_mutual(mp, a, st); if (rc != 0) return rc; }      // -1: not converged
+    // Mutual polarization, mixed precision: the potentials of the converged dipoles (~100 us of small launches) are formed on the side stream while
+    // k_mp_forces<true> -- the list pairs: no potential read -- runs on this one; k_mp_special<true>, which adds the reciprocal-space and self
+    // terms, follows behind the wait and ADDS its torques to the ones the pair kernel stored (the other order before round 5).
+    static const bool finalInline = getenv("OPENMM_HIP_AMOEBA_FINAL_INLINE") != nullptr;       // A/B
+    const bool finalOnSide = a.mutual && mp->mixed_precision && !finalInline && mp->stream2 != nullptr && mp->event_a != nullptr && mp->event_b != nullptr && two_grid_launches(mp, a);
+    if (a.mutual) { const int rc = solve_mutual(mp, a, st, finalOnSide); if (rc != 0) return rc; }      // -1: not converged
     else {
         if (mp->extrapolation_orders > 0) { const int rc = solve_extrapolated(mp, a, st); if (rc != 0) return rc; }
         // reciprocal potential of the induced dipoles (mu_d + mu_p) / 2
@@ -1676,7 +1705,13 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
         ommhip_pme_convolve(pme, st);
         hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phiInd, (double*) nullptr);
     }
-    if (mp->mixed_precision) {
+    if (mp->mixed_precision && finalOnSide) {
+        a.specialAdds = 1;
+        hipLaunchKernelGGL(k_mp_forces<true>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
+        hipStreamWaitEvent(st, (hipEvent_t) mp->event_b, 0);
+        hipLaunchKernelGGL(k_mp_special<true>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, st, a);
+    }
+    else if (mp->mixed_precision) {
         hipLaunchKernelGGL(k_mp_special<true>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, st, a);
         hipLaunchKernelGGL(k_mp_forces<true>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
     }

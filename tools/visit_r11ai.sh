@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 5, visit ai: AMOEBA -- the reciprocal potential of the permanent multipoles on the solver's side stream, beside the list build
+# (OPENMM_HIP_AMOEBA_RECIPROCAL_INLINE=1: on the main stream as before); parity at the run's epsilon; AMOEBA GPU tests
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+run() { echo -n "$1  "; env $2 timeout 300 python tools/bench_amoeba.py $3 --steps 40 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['ns_per_day'], d['solver_iterations_per_solve'], d['E1'])"; }
+for rep in 1 2 3; do
+  run "dhfr  inline     " OPENMM_HIP_AMOEBA_RECIPROCAL_INLINE=1 --dhfr
+  run "dhfr  side stream" X=1 --dhfr
+done | tee gpurun_out/r11ai_amoeba.txt
+for rep in 1 2; do
+  run "water inline     " OPENMM_HIP_AMOEBA_RECIPROCAL_INLINE=1 ""
+  run "water side stream" X=1 ""
+done | tee -a gpurun_out/r11ai_amoeba.txt
+timeout 600 python tools/diag_amoeba_run_epsilon.py 2>&1 | tail -3 | tee -a gpurun_out/r11ai_amoeba.txt
+timeout 1500 python -m pytest tests/test_gpu_platform.py -q -x -k "amoeba" 2>&1 | tail -3 | tee gpurun_out/r11ai_pytest.txt

@@ -928,6 +928,12 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const do
         }
     }
     ed = split_sum(ed); ep = split_sum(ep);
+    if (cgStage == 2) {
+        // pairs only: the real-space part, stored raw -- the reciprocal part is being formed on the side stream meanwhile, k_mp_cg stage 9 (or 10)
+        // puts the two together (solve_mutual, overlap mode)
+        if (active && q == 0) { store3(outD, i, ed); store3(outP, i, ep); }
+        return;
+    }
     if (cgStage < 0 && (!active || q != 0)) return;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (active && q == 0) {
@@ -1163,13 +1169,30 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double target, double un
     double cD = 0.0, cP = 0.0;
     const bool closing = stage == 7;          // stage 2 that also ends the iteration (the direction update rides in the next spreading launch)
     if (closing) stage = 2;
+    // overlap mode (solve_mutual): 8 = stage 3 with b from sums[8, 9] and without the end of the iteration (stage 7 has done that);
+    // 9 = stage 1 on t = the RAW real-space field of p (k_mp_dipole_field, cgStage 2), completed here with the reciprocal field -grad phi
+    // and the self field; 10 = stage 0 likewise for the first guess
+    const bool plainP = stage == 8, fromRaw = stage == 9 || stage == 10;
+    if (plainP) stage = 3;
+    if (stage == 9) stage = 1;
+    if (stage == 10) stage = 0;
+    const double selfTerm = (4.0 / 3.0) * a.alpha * a.alpha * a.alpha / MP_SQRT_PI, invK = 1.0 / OMM_ONE_4PI_EPS0_D;
     if (stage == 2) { cD = sums[2] != 0.0 ? sums[0] / sums[2] : 0.0; cP = sums[3] != 0.0 ? sums[1] / sums[3] : 0.0; }
     if (stage == 3) { cD = sums[0] != 0.0 ? sums[6] / sums[0] : 0.0; cP = sums[1] != 0.0 ? sums[7] / sums[1] : 0.0; }
+    if (plainP) { cD = sums[8]; cP = sums[9]; }
     __shared__ double red[4][MP_CG_BLOCK / 64];
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (i < a.n) {
         const double pol = a.polarity[i], invPol = pol > 0 ? 1.0 / pol : 0.0;
         double* rD = w; double* rP = w + n3; double* zD = w + 2 * n3; double* zP = w + 3 * n3; double* pD = w + 4 * n3; double* pP = w + 5 * n3; double* tD = w + 6 * n3; double* tP = w + 7 * n3;
+        if (fromRaw) {
+            // t holds the real-space field of the vectors (mu_0, or p): + reciprocal field + self field = T v, as k_mp_dipole_field's own last lines
+            const double* fd = a.phiInd + 20 * (size_t) i;
+            const double* fp = a.phiIndP + 20 * (size_t) i;
+            const V3 vd = stage == 0 ? load3(a.indD, i) : load3(pD, i), vp = stage == 0 ? load3(a.indP, i) : load3(pP, i);
+            store3(tD, i, load3(tD, i) - invK * v3(fd[1], fd[2], fd[3]) + selfTerm * vd);
+            store3(tP, i, load3(tP, i) - invK * v3(fp[1], fp[2], fp[3]) + selfTerm * vp);
+        }
         if (stage == 0) {
             V3 rd = v3(0, 0, 0), rp = v3(0, 0, 0);
             if (pol > 0) {
@@ -1210,6 +1233,7 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double target, double un
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         for (size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x; k < quads; k += total) { g0[k] = z; g1[k] = z; }
     }
+    if (plainP) return;
     if (stage == 3) {
         // the block that finishes last ends the iteration (what stage 4 does as a launch of its own): every block has read the step
         // lengths from the sums before it takes its ticket
@@ -1597,6 +1621,25 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bo
     int rc = 0, enqueued = 0;
     bool done = false;
     if (unchecked == 0) { rc = readSums(); if (rc != 0) return rc; done = h[10] != 0.0; }
+    // Overlap mode (round 5): the reciprocal-space chain of an iteration -- spread, three transform launches, read-back: ~85 us of small launches --
+    // on the side stream, the real-space pairs of k_mp_dipole_field (~90 us at one or two wavefronts per SIMD) on this one, both started by the
+    // direction update (stage 8) and met by stage 9, which puts the two parts of T p together and forms p . A p; stage 7 ends the iteration.
+    static const bool noOverlap = getenv("OPENMM_HIP_AMOEBA_NO_OVERLAP") != nullptr;       // A/B: the chain of round 5's first half (fold)
+    hipStream_t st2 = (hipStream_t) mp->stream2;
+    const bool overlap = fold && !noOverlap && st2 != nullptr && mp->event_a != nullptr && mp->event_b != nullptr;
+    while (!done && enqueued < mp->max_iterations && overlap) {
+        hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 8, 0.0, 0.0);              // p = z + b p (b = 0 at first), packed for the gather
+        hipEventRecord((hipEvent_t) mp->event_a, st);
+        hipStreamWaitEvent(st2, (hipEvent_t) mp->event_a, 0);
+        dipole_potentials(mp, a, pD, a.phiInd, pP, a.phiIndP, st2, true, 0, true);                             // (grids zeroed by stage 5 / the last stage 7)
+        hipEventRecord((hipEvent_t) mp->event_b, st2);
+        hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP, w, 2);      // real-space field of p, raw
+        hipStreamWaitEvent(st, (hipEvent_t) mp->event_b, 0);
+        hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 9, 0.0, 0.0);              // T p complete, A p, p . A p
+        hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, aClear, w, 7, mp->target_epsilon, 0.0);
+        enqueued++;
+        if (enqueued >= unchecked || enqueued == mp->max_iterations) { rc = readSums(); if (rc != 0) return rc; done = h[10] != 0.0; }
+    }
     while (!done && enqueued < mp->max_iterations && fold) {
         dipole_potentials(mp, a, pD, a.phiInd, pP, a.phiIndP, st, true, 0, true, w);
         hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP, w, 1);      // T p, Ap, p.Ap

@@ -1588,10 +1588,28 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bo
         hipLaunchKernelGGL(k_mp_history, dim3(blocks), dim3(MP_BLOCK), 0, st, a, mp->history, mp->history_slots, newest, use, 0, coeff);
     }
     // T mu_0 and the residual of the first guess
-    dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st, true);
     const int cgBlocks = (a.n + MP_CG_BLOCK - 1) / MP_CG_BLOCK;
+    static const bool noOverlap0 = getenv("OPENMM_HIP_AMOEBA_NO_OVERLAP") != nullptr;
+    const bool overlap0 = !noOverlap0 && !a.precond && a.gather != nullptr && mp->stream2 != nullptr && mp->event_a != nullptr && mp->event_b != nullptr && two_grid_launches(mp, a);
+    if (overlap0) {
+        // as an iteration in overlap mode (below): the reciprocal chain of mu_0 on the side stream, its real-space pairs on this one, stage 10 = stage 0
+        // on the two parts put together
+        hipStream_t s2 = (hipStream_t) mp->stream2;
+        hipEventRecord((hipEvent_t) mp->event_a, st);                  // mu_0 is there (the direct dipoles, or the predictor's)
+        hipStreamWaitEvent(s2, (hipEvent_t) mp->event_a, 0);
+        dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, s2, true);
+        hipEventRecord((hipEvent_t) mp->event_b, s2);
+        hipLaunchKernelGGL(k_mp_pack, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP);
+        hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, tD, tP, w, 2);
+        hipStreamWaitEvent(st, (hipEvent_t) mp->event_b, 0);
+        hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 10, 0.0, 0.0);
+    }
+    else {
+    dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st, true);
     if (a.gather != nullptr) hipLaunchKernelGGL(k_mp_pack, dim3(blocks), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP);
-    if (a.precond) {
+    }
+    if (overlap0) { }
+    else if (a.precond) {
         hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, a.indD, a.indP, a.phiInd, a.phiIndP, tD, tP, w, -1);
         hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 0, 0.0, 0.0);
         hipLaunchKernelGGL(k_mp_precond, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, w, 1);

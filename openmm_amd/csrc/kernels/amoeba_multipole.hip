@@ -200,6 +200,7 @@ struct MpArgs {
     const int* order; int numScan;
     const int* pairList; const int* pairCount; int listStride, listSubcap;
     int precond; double precondCut2;               // neighbour-pair preconditioner of the solver (needs the pair cache)
+    int pairsOnly;                                 // k_mp_field stops after the pair sums (k_mp_field_finish follows behind the wait for the reciprocal potential)
     int specialAdds;                               // mixed precision: k_mp_forces<true> ran first and STORED its torques, k_mp_special<true> adds to them (0: the other way round)
     float* pairCache; int pairCap;                 // mutual polarization: per list entry (dx, dy, dz, b1, b2) of the Thole-damped dipole-dipole chain, float planes of pairCap * listStride
     float* gather;                                 // mutual polarization: the vectors the induced-dipole field is taken of, (vD, vP) as six floats per SCAN POSITION (k_mp_dipole_field gathers them)
@@ -672,12 +673,30 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_field(MpArgs a) {
     }
     ed = split_sum(ed); ep = split_sum(ep);
     if (!active || q != 0) return;
+    if (MIXED) { ed = ed + load3(a.fieldD, i); ep = ep + load3(a.fieldP, i); }       // the covalently related partners: k_mp_special<false>, launched before
+    if (a.pairsOnly) {
+        // the reciprocal potential is still being formed on the side stream: k_mp_field_finish adds it (and the self field) behind the wait
+        store3(a.fieldD, i, ed); store3(a.fieldP, i, ep);
+        return;
+    }
     // reciprocal field -grad phi (the grid carries the Coulomb constant: taken out again) and the self field 4 alpha^3 / (3 sqrt(pi)) mu
     const double* phi = a.phi + 20 * (size_t) i;
     const double selfTerm = (4.0 / 3.0) * a.alpha * a.alpha * a.alpha / MP_SQRT_PI;
     const V3 common = v3(-phi[1], -phi[2], -phi[3]) * (1.0 / OMM_ONE_4PI_EPS0_D) + selfTerm * load3(a.labDipole, i);
     ed = ed + common; ep = ep + common;
-    if (MIXED) { ed = ed + load3(a.fieldD, i); ep = ep + load3(a.fieldP, i); }       // the covalently related partners: k_mp_special<false>, launched before
+    store3(a.fieldD, i, ed); store3(a.fieldP, i, ep);
+    const double pol = a.polarity[i];
+    store3(a.indD, i, pol * ed); store3(a.indP, i, pol * ep);
+}
+
+// the last lines of k_mp_field as a launch of their own (MpArgs::pairsOnly): reciprocal and self field added to the pair sums, direct dipoles
+__global__ void k_mp_field_finish(MpArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const double* phi = a.phi + 20 * (size_t) i;
+    const double selfTerm = (4.0 / 3.0) * a.alpha * a.alpha * a.alpha / MP_SQRT_PI;
+    const V3 common = v3(-phi[1], -phi[2], -phi[3]) * (1.0 / OMM_ONE_4PI_EPS0_D) + selfTerm * load3(a.labDipole, i);
+    const V3 ed = load3(a.fieldD, i) + common, ep = load3(a.fieldP, i) + common;
     store3(a.fieldD, i, ed); store3(a.fieldP, i, ep);
     const double pol = a.polarity[i];
     store3(a.indD, i, pol * ed); store3(a.indP, i, pol * ep);
@@ -1410,7 +1429,7 @@ bool make_args(const ommhip_amoeba_multipole* mp, const void* pos_d, const doubl
     // per iteration -- no gain; the default stays z = alpha r
     static const bool usePrecond = getenv("OPENMM_HIP_AMOEBA_PRECOND") != nullptr && atoi(getenv("OPENMM_HIP_AMOEBA_PRECOND")) != 0;
     a.precond = a.pairCache != nullptr && usePrecond ? 1 : 0; a.precondCut2 = 0.45 * 0.45;
-    a.specialAdds = 0;
+    a.specialAdds = 0; a.pairsOnly = 0;
     a.doneFlag = nullptr;
     a.gather = a.mutual ? mp->solver_gather : nullptr;
     return true;
@@ -1478,9 +1497,16 @@ int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const doub
     });
     if (rc != 0) { if (side) hipStreamWaitEvent(st, (hipEvent_t) mp->event_b, 0); return rc; }      // (the side chain does not outlive the call)
     if (mp->mixed_precision) hipLaunchKernelGGL(k_mp_special<false>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, st, a);
-    if (side) hipStreamWaitEvent(st, (hipEvent_t) mp->event_b, 0);     // the field kernel's last lines read the reciprocal potential
-    if (mp->mixed_precision) hipLaunchKernelGGL(k_mp_field<true>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
-    else hipLaunchKernelGGL(k_mp_field<false>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
+    // the field kernel's last lines read the reciprocal potential: with the side chain they are a launch of their own behind the wait, and the
+    // pair sums -- 127 us on DHFR -- run beside the chain as well
+    MpArgs b = a;
+    b.pairsOnly = side ? 1 : 0;
+    if (mp->mixed_precision) hipLaunchKernelGGL(k_mp_field<true>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, b);
+    else hipLaunchKernelGGL(k_mp_field<false>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, b);
+    if (side) {
+        hipStreamWaitEvent(st, (hipEvent_t) mp->event_b, 0);
+        hipLaunchKernelGGL(k_mp_field_finish, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
+    }
     return 0;
 }
 

@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 5, visit am: AMOEBA -- k_mp_field in two launches (pair sums beside the reciprocal chain, last lines behind the wait); overlap solver as in visit al
+# (OPENMM_HIP_AMOEBA_NO_OVERLAP=1: on the main stream as before); parity at the run's epsilon; AMOEBA GPU tests
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+run() { echo -n "$1  "; env $2 timeout 300 python tools/bench_amoeba.py $3 --steps 40 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['ns_per_day'], d['solver_iterations_per_solve'], d['E1'])"; }
+for rep in 1 2 3; do
+  run "dhfr  one stream " OPENMM_HIP_AMOEBA_NO_OVERLAP=1 --dhfr
+  run "dhfr  overlap    " X=1 --dhfr
+done | tee gpurun_out/r11am_amoeba.txt
+for rep in 1 2; do
+  run "water one stream " OPENMM_HIP_AMOEBA_NO_OVERLAP=1 ""
+  run "water overlap    " X=1 ""
+done | tee -a gpurun_out/r11am_amoeba.txt
+timeout 600 python tools/diag_amoeba_run_epsilon.py 2>&1 | tail -3 | tee -a gpurun_out/r11am_amoeba.txt
+timeout 1500 python -m pytest tests/test_gpu_platform.py -q -x -k "amoeba" 2>&1 | tail -3 | tee gpurun_out/r11am_pytest.txt

@@ -427,7 +427,9 @@ void HipCalcAmoebaMultipoleForceKernel::upload(const AmoebaMultipoleForce& force
         const size_t nx = gridSize[0], ny = gridSize[1], nz = gridSize[2], nzc = nz / 2 + 1;
         gridReal2.allocate((sizeof(float) * nx * ny * nz + 15) / 16 * 16);
         gridComplex2.allocate(sizeof(float) * 2 * nx * ny * nzc);
-        if (sideStream == NULL) { HIP_CHECK(ommhip_stream_create(&sideStream)); HIP_CHECK(ommhip_event_create_untimed(&eventA)); HIP_CHECK(ommhip_event_create_untimed(&eventB)); }
+        // (high priority: its chains of small launches -- spreading, transforms, read-back -- run beside the long pair kernels of the main stream
+        // and are the longer side of every solver iteration: profiles/r11/r11ao_amoeba_dhfr_timeline.txt)
+        if (sideStream == NULL) { HIP_CHECK(ommhip_stream_create_priority(&sideStream, getenv("OPENMM_HIP_AMOEBA_SIDE_NORMAL") == NULL ? 1 : 0)); HIP_CHECK(ommhip_event_create_untimed(&eventA)); HIP_CHECK(ommhip_event_create_untimed(&eventB)); }
         mp.pme2 = &pme2; mp.stream2 = sideStream; mp.event_a = eventA; mp.event_b = eventB;
     }
     // per-atom pair lists in the platform's slot order, rebuilt at every evaluation (amoeba_pairs.h); the order itself is set per evaluation

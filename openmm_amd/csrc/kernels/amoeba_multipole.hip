@@ -1441,8 +1441,18 @@ int spread_blocks(const MpArgs& a) { return (int) (((size_t) a.n * MP_SPREAD_LAN
 int scan_blocks(const MpArgs& a) { return (int) (((size_t) a.numScan * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK); }
 
 // the pair lists of this evaluation (amoeba_pairs.h); -2: the lists did not fit into pair_cap entries per atom (*pair_needed says how many would)
+// two pinned host words per call for the deferred list check (overflow word, build counter); a small ring: one call is in flight per host thread
+int* deferred_words() {
+    static int* ring = nullptr;
+    static int next = 0;
+    if (ring == nullptr && hipHostMalloc((void**) &ring, sizeof(int) * 2 * 16, 0) != hipSuccess) { ring = nullptr; return nullptr; }
+    int* w = ring + 2 * (next++ % 16);
+    w[0] = 0; w[1] = 0;
+    return w;
+}
+
 template <class Between>
-int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st, Between between) {
+int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st, Between between, int* deferred = nullptr) {
     PairListArgs p;
     p.n = a.n; p.numScan = a.numScan; p.subcap = a.listSubcap; p.stride = a.numScan; p.excludeListed = 0;
     static const bool noTiles = getenv("OPENMM_HIP_AMOEBA_NO_TILES") != nullptr;         // A/B knob: the builder looks at every tile
@@ -1459,12 +1469,12 @@ int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const d
         const double radius = mp->cutoff + mp->skin;
         p.cutoff2 = radius * radius; p.refPos = (double4*) mp->ref_pos; p.state = mp->list_state; p.skinHalf2 = 0.25 * mp->skin * mp->skin; p.forceRebuild = mp->force_rebuild != 0;
     }
-    return pl_launch(p, mp->pair_needed, st, mp->list_builds, between);
+    return pl_launch(p, mp->pair_needed, st, mp->list_builds, between, deferred);
 }
 int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st) { return build_pair_lists(mp, a, box, st, [] {}); }
 
 // frames, reciprocal potential of the permanent multipoles, fields and induced dipoles
-int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st, bool hook = false) {
+int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st, bool hook = false, int* deferred = nullptr) {
     const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
     // Frames and the reciprocal potential of the permanent multipoles need no lists.  With the side stream of the mutual solver at hand
     // (stream2, event_a / event_b; round 5) that chain -- clear, spread, three transform launches, read-back: ~110 us of small launches on
@@ -1490,11 +1500,14 @@ int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const doub
         reciprocal(st2);
         hipEventRecord((hipEvent_t) mp->event_b, st2);
     }
+    // deferred (round 5): the builder's overflow word is looked at after the caller's next wait on this stream -- the solver's first look at its
+    // convergence measure -- instead of by a wait of its own here: everything up to the force kernels writes work arrays only.  The hook then
+    // runs at the end of this function, with the list build, the field kernels and the side chain already enqueued.
     const int rc = build_pair_lists(mp, a, box, st, [&] {
-        if (hook && mp->after_lists_enqueued != nullptr && hookFirst) mp->after_lists_enqueued(mp->after_lists_arg);
+        if (deferred == nullptr && hook && mp->after_lists_enqueued != nullptr && hookFirst) mp->after_lists_enqueued(mp->after_lists_arg);
         if (!side) reciprocal(st);
-        if (hook && mp->after_lists_enqueued != nullptr && !hookFirst) mp->after_lists_enqueued(mp->after_lists_arg);
-    });
+        if (deferred == nullptr && hook && mp->after_lists_enqueued != nullptr && !hookFirst) mp->after_lists_enqueued(mp->after_lists_arg);
+    }, deferred);
     if (rc != 0) { if (side) hipStreamWaitEvent(st, (hipEvent_t) mp->event_b, 0); return rc; }      // (the side chain does not outlive the call)
     if (mp->mixed_precision) hipLaunchKernelGGL(k_mp_special<false>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, st, a);
     // the field kernel's last lines read the reciprocal potential: with the side chain they are a launch of their own behind the wait, and the
@@ -1507,7 +1520,13 @@ int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const doub
         hipStreamWaitEvent(st, (hipEvent_t) mp->event_b, 0);
         hipLaunchKernelGGL(k_mp_field_finish, dim3(blocks), dim3(MP_BLOCK), 0, st, a);
     }
+    if (deferred != nullptr && hook && mp->after_lists_enqueued != nullptr) mp->after_lists_enqueued(mp->after_lists_arg);
     return 0;
+}
+
+// the deferred list check, after a wait on the stream the lists were built on: 0, or -2 as build_pair_lists returns it
+int deferred_lists_result(const ommhip_amoeba_multipole* mp, const int* deferred) {
+    return pl_deferred_result(deferred, mp->pair_needed, mp->list_builds, mp->skin > 0.0 && mp->ref_pos != nullptr && mp->list_state != nullptr);
 }
 
 // potential (and derivatives) of one set of dipoles at the atoms
@@ -1596,14 +1615,24 @@ void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const
 // been met, so the host enqueues mp->expected_iterations - 1 iterations (what the previous call needed; 0 = unknown) before it first waits
 // for the measure, then one at a time: two host round trips per solve instead of one per iteration.  (The FFT launches of an iteration
 // enqueued in vain -- the call needed fewer iterations than the one before -- still run, on cleared grids.)
-int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bool finalOnSide = false) {
+int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bool finalOnSide = false, int* deferred = nullptr) {
     const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
     const size_t n3 = 3 * (size_t) a.n;
     double* w = mp->solver;
     double* sums = w + 8 * n3;
     double* tD = w + 6 * n3; double* tP = w + 7 * n3; double* pD = w + 4 * n3; double* pP = w + 5 * n3;
     double h[16] = {0};
-    auto readSums = [&]() -> int { hipError_t e = hipMemcpyAsync(h, sums, sizeof(double) * 16, hipMemcpyDeviceToHost, st); if (e != hipSuccess) return (int) e; return (int) hipStreamSynchronize(st); };
+    bool listsChecked = deferred == nullptr;
+    auto readSums = [&]() -> int {
+        hipError_t e = hipMemcpyAsync(h, sums, sizeof(double) * 16, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return (int) e;
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return (int) e;
+        // the first wait of the call on this stream: what the list builder found (deferred check) -- lists that did not fit end the call here,
+        // before anything has been added to the forces or the history
+        if (!listsChecked) { listsChecked = true; return deferred_lists_result(mp, deferred); }
+        return 0;
+    };
     const bool haveHistory = mp->history != nullptr && mp->history_slots >= 1;
     const int use = haveHistory ? (mp->history_use < 0 ? 0 : (mp->history_use > OMMHIP_AMOEBA_MAX_HISTORY ? OMMHIP_AMOEBA_MAX_HISTORY : (mp->history_use > mp->history_slots ? mp->history_slots : mp->history_use))) : 0;
     HistoryCoeff coeff;
@@ -1777,13 +1806,15 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
     hipStream_t st = (hipStream_t) stream;
     const ommhip_pme* pme = (const ommhip_pme*) mp->pme;
     const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
-    { const int rc = launch_induce(mp, a, box, st, true); if (rc != 0) return rc; }
+    static const bool checkAtOnce = getenv("OPENMM_HIP_AMOEBA_LIST_CHECK_AT_ONCE") != nullptr;       // A/B: the host waits for the list build at once
+    int* const deferred = checkAtOnce ? nullptr : deferred_words();
+    { const int rc = launch_induce(mp, a, box, st, true, deferred); if (rc != 0) return rc; }
     // Mutual polarization, mixed precision: the potentials of the converged dipoles (~100 us of small launches) are formed on the side stream while
     // k_mp_forces<true> -- the list pairs: no potential read -- runs on this one; k_mp_special<true>, which adds the reciprocal-space and self
     // terms, follows behind the wait and ADDS its torques to the ones the pair kernel stored (the other order before round 5).
     static const bool finalInline = getenv("OPENMM_HIP_AMOEBA_FINAL_INLINE") != nullptr;       // A/B
     const bool finalOnSide = a.mutual && mp->mixed_precision && !finalInline && mp->stream2 != nullptr && mp->event_a != nullptr && mp->event_b != nullptr && two_grid_launches(mp, a);
-    if (a.mutual) { const int rc = solve_mutual(mp, a, st, finalOnSide); if (rc != 0) return rc; }      // -1: not converged
+    if (a.mutual) { const int rc = solve_mutual(mp, a, st, finalOnSide, deferred); if (rc != 0) return rc; }      // -1: not converged; -2: the lists (deferred check)
     else {
         if (mp->extrapolation_orders > 0) { const int rc = solve_extrapolated(mp, a, st); if (rc != 0) return rc; }
         // reciprocal potential of the induced dipoles (mu_d + mu_p) / 2
@@ -1791,6 +1822,13 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
         spread_induced(a, a.indD, 0.5, a.indP, 0.5, st);
         ommhip_pme_convolve(pme, st);
         hipLaunchKernelGGL(k_mp_potential<3>, dim3(spread_blocks(a)), dim3(256), 0, st, a, a.phiInd, (double*) nullptr);
+    }
+    if (deferred != nullptr && !a.mutual) {
+        // no solver wait on the way: one here, before the first kernel that adds to the forces
+        const hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return (int) e;
+        const int rc = deferred_lists_result(mp, deferred);
+        if (rc != 0) return rc;
     }
     if (mp->mixed_precision && finalOnSide) {
         a.specialAdds = 1;

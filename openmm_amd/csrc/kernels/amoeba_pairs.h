@@ -348,7 +348,7 @@ __device__ __forceinline__ int pl_at(const int* list, int stride, int subcap, co
 // `between` (optional) runs after the builder's kernels have been enqueued and before the host waits for the overflow word: work that does not
 // need the lists goes there, on this stream or another.
 template <class Between>
-static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st, int* buildsHost, Between between) {
+static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st, int* buildsHost, Between between, int* deferred = nullptr) {
     if (a.numScan > PL_POS_MASK) return 1;
     static const int debugMode = getenv("OPENMM_HIP_PL_DEBUG") != nullptr ? atoi(getenv("OPENMM_HIP_PL_DEBUG")) : 0;     // profiling only: wrong results
     a.debug = debugMode;
@@ -384,6 +384,15 @@ static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st, int* bu
     }
 #endif
     between();
+    if (deferred != nullptr) {
+        // deferred check (round 5): the overflow word and the build counter travel to PINNED host words behind the builder's kernels and the
+        // call returns at once -- the caller looks at them (pl_deferred_result) after its next wait on this stream, before anything is added
+        // to the forces.  Lists that overflowed are truncated, never overrun: what walks them meanwhile fills work arrays with numbers
+        // that the repeated call overwrites.
+        hipError_t e = hipMemcpyAsync(&deferred[0], a.overflow, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && a.state != nullptr) e = hipMemcpyAsync(&deferred[1], a.state + 2, sizeof(int), hipMemcpyDeviceToHost, st);
+        return (int) e;
+    }
     int over = 0;
     hipError_t e = hipMemcpyAsync(&over, a.overflow, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess && buildsHost != nullptr && a.state != nullptr) e = hipMemcpyAsync(buildsHost, a.state + 2, sizeof(int), hipMemcpyDeviceToHost, st);      // diagnostics: builds so far
@@ -393,6 +402,13 @@ static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st, int* bu
     return 0;
 }
 static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st, int* buildsHost = nullptr) { return pl_launch(a, needed, st, buildsHost, [] {}); }
+// What a deferred pl_launch found, once the stream has been waited for: 0, or -2 with *needed as pl_launch leaves it.
+static inline int pl_deferred_result(const int* deferred, int* needed, int* buildsHost, bool haveState) {
+    if (buildsHost != nullptr && haveState) *buildsHost = deferred[1];
+    const int over = deferred[0];
+    if (over != 0) { if (needed != nullptr) *needed = over == 0x7fffffff ? over : over * PL_PARTS; return -2; }
+    return 0;
+}
 
 }  // namespace omm
 #endif

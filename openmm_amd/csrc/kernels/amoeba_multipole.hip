@@ -200,6 +200,7 @@ struct MpArgs {
     const int* order; int numScan;
     const int* pairList; const int* pairCount; int listStride, listSubcap;
     int precond; double precondCut2;               // neighbour-pair preconditioner of the solver (needs the pair cache)
+    double* torque2;                               // k_mp_special<true> leaves its torques HERE (it runs beside k_mp_forces<true>, which stores into torque); k_mp_torque_to_force adds the two
     int pairsOnly;                                 // k_mp_field stops after the pair sums (k_mp_field_finish follows behind the wait for the reciprocal potential)
     int specialAdds;                               // mixed precision: k_mp_forces<true> ran first and STORED its torques, k_mp_special<true> adds to them (0: the other way round)
     float* pairCache; int pairCap;                 // mutual polarization: per list entry (dx, dy, dz, b1, b2) of the Thole-damped dipole-dipole chain, float planes of pairCap * listStride
@@ -802,7 +803,8 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_special(MpArgs a) {
         if (FORCES) {
             accA = OMM_ONE_4PI_EPS0_D * accA; accB = OMM_ONE_4PI_EPS0_D * accB; energy *= OMM_ONE_4PI_EPS0_D;
             reciprocal_and_self(a, i, Mi, udI, upI, energy, accA, accB);           // everything of the atom that is not a pair of the list
-            store3(a.torque, i, a.specialAdds ? accB + load3(a.torque, i) : accB);
+            if (a.torque2 != nullptr) store3(a.torque2, i, accB);
+            else store3(a.torque, i, a.specialAdds ? accB + load3(a.torque, i) : accB);
             add_force(a.force, a.paddedAtoms, a.slotOfAtom[i], accA.x, accA.y, accA.z);
         }
         else { store3(a.fieldD, i, accA); store3(a.fieldP, i, accB); }
@@ -1347,7 +1349,7 @@ __global__ void k_mp_torque_to_force(MpArgs a) {
     if (i >= a.n) return;
     const int4 ax = a.axis[i];
     if (ax.x == 5 || ax.y < 0) return;
-    const V3 tq = load3(a.torque, i), xi = position(a, i);
+    const V3 tq = a.torque2 != nullptr ? load3(a.torque, i) + load3(a.torque2, i) : load3(a.torque, i), xi = position(a, i);
     V3 u = position(a, ax.y) - xi, v, w;
     const double nu = normalize(u);
     if (ax.z >= 0) v = position(a, ax.z) - xi;
@@ -1429,7 +1431,7 @@ bool make_args(const ommhip_amoeba_multipole* mp, const void* pos_d, const doubl
     // per iteration -- no gain; the default stays z = alpha r
     static const bool usePrecond = getenv("OPENMM_HIP_AMOEBA_PRECOND") != nullptr && atoi(getenv("OPENMM_HIP_AMOEBA_PRECOND")) != 0;
     a.precond = a.pairCache != nullptr && usePrecond ? 1 : 0; a.precondCut2 = 0.45 * 0.45;
-    a.specialAdds = 0; a.pairsOnly = 0;
+    a.specialAdds = 0; a.pairsOnly = 0; a.torque2 = nullptr;
     a.doneFlag = nullptr;
     a.gather = a.mutual ? mp->solver_gather : nullptr;
     return true;
@@ -1831,10 +1833,18 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
         if (rc != 0) return rc;
     }
     if (mp->mixed_precision && finalOnSide) {
+        // k_mp_special<true> follows the potentials on the side stream -- beside the pair kernel too -- and leaves its torques in a vector of their
+        // own (the solver's t_d: free by now); k_mp_torque_to_force, behind the wait, adds the two.  Forces and energies meet in atomics anyway.
+        static const bool specialOnMain = getenv("OPENMM_HIP_AMOEBA_SPECIAL_ON_MAIN") != nullptr;       // A/B
         a.specialAdds = 1;
+        if (!specialOnMain) {
+            a.torque2 = mp->solver + 6 * 3 * (size_t) a.n;
+            hipLaunchKernelGGL(k_mp_special<true>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, (hipStream_t) mp->stream2, a);
+            hipEventRecord((hipEvent_t) mp->event_b, (hipStream_t) mp->stream2);
+        }
         hipLaunchKernelGGL(k_mp_forces<true>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
         hipStreamWaitEvent(st, (hipEvent_t) mp->event_b, 0);
-        hipLaunchKernelGGL(k_mp_special<true>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, st, a);
+        if (specialOnMain) hipLaunchKernelGGL(k_mp_special<true>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, st, a);
     }
     else if (mp->mixed_precision) {
         hipLaunchKernelGGL(k_mp_special<true>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, st, a);

@@ -1625,10 +1625,11 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bo
     double* tD = w + 6 * n3; double* tP = w + 7 * n3; double* pD = w + 4 * n3; double* pP = w + 5 * n3;
     double h[16] = {0};
     bool listsChecked = deferred == nullptr;
+    hipStream_t sumsStream = st;              // the stream whose kernels form the sums (the side stream while it carries the iterations' spine)
     auto readSums = [&]() -> int {
-        hipError_t e = hipMemcpyAsync(h, sums, sizeof(double) * 16, hipMemcpyDeviceToHost, st);
+        hipError_t e = hipMemcpyAsync(h, sums, sizeof(double) * 16, hipMemcpyDeviceToHost, sumsStream);
         if (e != hipSuccess) return (int) e;
-        e = hipStreamSynchronize(st);
+        e = hipStreamSynchronize(sumsStream);
         if (e != hipSuccess) return (int) e;
         // the first wait of the call on this stream: what the list builder found (deferred check) -- lists that did not fit end the call here,
         // before anything has been added to the forces or the history
@@ -1702,6 +1703,33 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bo
     static const bool noOverlap = getenv("OPENMM_HIP_AMOEBA_NO_OVERLAP") != nullptr;       // A/B: the chain of round 5's first half (fold)
     hipStream_t st2 = (hipStream_t) mp->stream2;
     const bool overlap = fold && !noOverlap && st2 != nullptr && mp->event_a != nullptr && mp->event_b != nullptr;
+    // Which stream carries the iteration's spine -- direction update, reciprocal chain, vector stages -- and which the pair kernel alone?  The
+    // reciprocal chain is the longer half (r11as timeline: 106 against 70 us): with the spine on the SIDE stream the vector stages follow the chain
+    // in stream order and the wait for the pair kernel's event finds it signalled already -- the ~14 us of join latency per iteration leave the
+    // critical path, and the small launches run at the side stream's priority.  OPENMM_HIP_AMOEBA_SPINE_MAIN=1: the spine on the main stream.
+    static const bool spineMain = getenv("OPENMM_HIP_AMOEBA_SPINE_MAIN") != nullptr;
+    const bool spineSide = overlap && !spineMain;
+    if (spineSide && !done && enqueued < mp->max_iterations) {
+        hipEventRecord((hipEvent_t) mp->event_a, st);                  // the residual of the first guess, stage 5
+        hipStreamWaitEvent(st2, (hipEvent_t) mp->event_a, 0);
+        sumsStream = st2;
+        while (!done && enqueued < mp->max_iterations) {
+            hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st2, a, w, 8, 0.0, 0.0);         // p = z + b p (b = 0 at first), packed for the gather
+            hipEventRecord((hipEvent_t) mp->event_a, st2);
+            hipStreamWaitEvent(st, (hipEvent_t) mp->event_a, 0);
+            hipLaunchKernelGGL(k_mp_dipole_field, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a, pD, pP, a.phiInd, a.phiIndP, tD, tP, w, 2);      // real-space field of p, raw
+            hipEventRecord((hipEvent_t) mp->event_b, st);
+            dipole_potentials(mp, a, pD, a.phiInd, pP, a.phiIndP, st2, true, 0, true);                         // (grids zeroed by stage 5 / the last stage 7)
+            hipStreamWaitEvent(st2, (hipEvent_t) mp->event_b, 0);
+            hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st2, a, w, 9, 0.0, 0.0);         // T p complete, A p, p . A p
+            hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st2, aClear, w, 7, mp->target_epsilon, 0.0);
+            enqueued++;
+            if (enqueued >= unchecked || enqueued == mp->max_iterations) { rc = readSums(); if (rc != 0) return rc; done = h[10] != 0.0; }
+        }
+        sumsStream = st;
+        hipEventRecord((hipEvent_t) mp->event_a, st2);                 // the main stream goes on behind the spine
+        hipStreamWaitEvent(st, (hipEvent_t) mp->event_a, 0);
+    }
     while (!done && enqueued < mp->max_iterations && overlap) {
         hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 8, 0.0, 0.0);              // p = z + b p (b = 0 at first), packed for the gather
         hipEventRecord((hipEvent_t) mp->event_a, st);

@@ -1617,7 +1617,11 @@ void dipole_potentials(const ommhip_amoeba_multipole* mp, const MpArgs& a, const
 // been met, so the host enqueues mp->expected_iterations - 1 iterations (what the previous call needed; 0 = unknown) before it first waits
 // for the measure, then one at a time: two host round trips per solve instead of one per iteration.  (The FFT launches of an iteration
 // enqueued in vain -- the call needed fewer iterations than the one before -- still run, on cleared grids.)
-int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bool finalOnSide = false, int* deferred = nullptr) {
+// mainBesideFinal (finalOnSide only): called when everything in front of the final potentials has been enqueued on `st` and before the side chain
+// is -- the caller launches THERE what the main stream runs beside that chain (the pair force kernel), so that it does not queue on the host
+// behind the side chain's seven launches (50 us in the r11ax timeline).
+template <class MainBesideFinal>
+int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bool finalOnSide, int* deferred, MainBesideFinal mainBesideFinal) {
     const int blocks = (a.n + MP_BLOCK - 1) / MP_BLOCK;
     const size_t n3 = 3 * (size_t) a.n;
     double* w = mp->solver;
@@ -1783,6 +1787,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bo
         // and waits for event_b in front of the kernel that does (ommhip_amoeba_multipole_forces)
         hipStream_t st2 = (hipStream_t) mp->stream2;
         hipEventRecord((hipEvent_t) mp->event_a, st);
+        mainBesideFinal();
         hipStreamWaitEvent(st2, (hipEvent_t) mp->event_a, 0);
         dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st2, false, 0, fold && enqueued > 0);
         hipEventRecord((hipEvent_t) mp->event_b, st2);
@@ -1790,6 +1795,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bo
     else dipole_potentials(mp, a, a.indD, a.phiInd, a.indP, a.phiIndP, st, false, 0, fold && enqueued > 0);
     return 0;
 }
+int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bool finalOnSide = false, int* deferred = nullptr) { return solve_mutual(mp, a, st, finalOnSide, deferred, [] {}); }
 
 // Extrapolated polarization: orders 1 .. K - 1 from the direct dipoles, the total dipoles, their potentials.  Leaves mu_d, mu_p (totals) in
 // indD / indP, every order in mp->ext_dipoles and the field gradients of orders 0 .. K - 2 in mp->ext_gradients.
@@ -1844,7 +1850,16 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
     // terms, follows behind the wait and ADDS its torques to the ones the pair kernel stored (the other order before round 5).
     static const bool finalInline = getenv("OPENMM_HIP_AMOEBA_FINAL_INLINE") != nullptr;       // A/B
     const bool finalOnSide = a.mutual && mp->mixed_precision && !finalInline && mp->stream2 != nullptr && mp->event_a != nullptr && mp->event_b != nullptr && two_grid_launches(mp, a);
-    if (a.mutual) { const int rc = solve_mutual(mp, a, st, finalOnSide, deferred); if (rc != 0) return rc; }      // -1: not converged; -2: the lists (deferred check)
+    bool pairForcesLaunched = false;
+    if (a.mutual) {
+        const int rc = solve_mutual(mp, a, st, finalOnSide, deferred, [&] {
+            if (!mp->mixed_precision) return;
+            MpArgs f = a; f.specialAdds = 1;
+            hipLaunchKernelGGL(k_mp_forces<true>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, f);
+            pairForcesLaunched = true;
+        });
+        if (rc != 0) return rc;      // -1: not converged; -2: the lists (deferred check)
+    }
     else {
         if (mp->extrapolation_orders > 0) { const int rc = solve_extrapolated(mp, a, st); if (rc != 0) return rc; }
         // reciprocal potential of the induced dipoles (mu_d + mu_p) / 2
@@ -1870,7 +1885,7 @@ extern "C" int ommhip_amoeba_multipole_forces(const ommhip_amoeba_multipole* mp,
             hipLaunchKernelGGL(k_mp_special<true>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, (hipStream_t) mp->stream2, a);
             hipEventRecord((hipEvent_t) mp->event_b, (hipStream_t) mp->stream2);
         }
-        hipLaunchKernelGGL(k_mp_forces<true>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
+        if (!pairForcesLaunched) hipLaunchKernelGGL(k_mp_forces<true>, dim3(scan_blocks(a)), dim3(MP_BLOCK), 0, st, a);
         hipStreamWaitEvent(st, (hipEvent_t) mp->event_b, 0);
         if (specialOnMain) hipLaunchKernelGGL(k_mp_special<true>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, st, a);
     }

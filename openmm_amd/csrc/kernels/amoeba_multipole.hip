@@ -200,6 +200,7 @@ struct MpArgs {
     const int* order; int numScan;
     const int* pairList; const int* pairCount; int listStride, listSubcap;
     int precond; double precondCut2;               // neighbour-pair preconditioner of the solver (needs the pair cache)
+    const int* listOverflow; const int* listBuilds; // the list builder's overflow word and build counter (device): k_mp_cg stage 5 copies them into sums[13], sums[15]
     double* torque2;                               // k_mp_special<true> leaves its torques HERE (it runs beside k_mp_forces<true>, which stores into torque); k_mp_torque_to_force adds the two
     int pairsOnly;                                 // k_mp_field stops after the pair sums (k_mp_field_finish follows behind the wait for the reciprocal potential)
     int specialAdds;                               // mixed precision: k_mp_forces<true> ran first and STORED its torques, k_mp_special<true> adds to them (0: the other way round)
@@ -1166,6 +1167,11 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double target, double un
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             for (size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x; k < quads; k += total) { g0[k] = z; g1[k] = z; }
         }
+        if (i == 0 && stage == 5) {
+            // what the list builder found travels to the host with the sums (the deferred list check of solve_mutual)
+            sums[13] = a.listOverflow != nullptr ? (double) *a.listOverflow : 0.0;
+            sums[15] = a.listBuilds != nullptr ? (double) *a.listBuilds : 0.0;
+        }
         if (i == 0 && sums[10] == 0.0) {
             if (stage == 4) { sums[0] = sums[6]; sums[1] = sums[7]; sums[11] += 1.0; }
             const double eps = debye * sqrt(fmax(sums[4], sums[5]) / a.n);
@@ -1432,6 +1438,7 @@ bool make_args(const ommhip_amoeba_multipole* mp, const void* pos_d, const doubl
     static const bool usePrecond = getenv("OPENMM_HIP_AMOEBA_PRECOND") != nullptr && atoi(getenv("OPENMM_HIP_AMOEBA_PRECOND")) != 0;
     a.precond = a.pairCache != nullptr && usePrecond ? 1 : 0; a.precondCut2 = 0.45 * 0.45;
     a.specialAdds = 0; a.pairsOnly = 0; a.torque2 = nullptr;
+    a.listOverflow = mp->pair_overflow; a.listBuilds = mp->skin > 0.0 && mp->ref_pos != nullptr && mp->list_state != nullptr ? mp->list_state + 2 : nullptr;
     a.doneFlag = nullptr;
     a.gather = a.mutual ? mp->solver_gather : nullptr;
     return true;
@@ -1454,7 +1461,7 @@ int* deferred_words() {
 }
 
 template <class Between>
-int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st, Between between, int* deferred = nullptr) {
+int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st, Between between, int* deferred = nullptr, bool deferredCopies = true) {
     PairListArgs p;
     p.n = a.n; p.numScan = a.numScan; p.subcap = a.listSubcap; p.stride = a.numScan; p.excludeListed = 0;
     static const bool noTiles = getenv("OPENMM_HIP_AMOEBA_NO_TILES") != nullptr;         // A/B knob: the builder looks at every tile
@@ -1471,7 +1478,7 @@ int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const d
         const double radius = mp->cutoff + mp->skin;
         p.cutoff2 = radius * radius; p.refPos = (double4*) mp->ref_pos; p.state = mp->list_state; p.skinHalf2 = 0.25 * mp->skin * mp->skin; p.forceRebuild = mp->force_rebuild != 0;
     }
-    return pl_launch(p, mp->pair_needed, st, mp->list_builds, between, deferred);
+    return pl_launch(p, mp->pair_needed, st, mp->list_builds, between, deferred, deferredCopies);
 }
 int build_pair_lists(const ommhip_amoeba_multipole* mp, const MpArgs& a, const double box[6], hipStream_t st) { return build_pair_lists(mp, a, box, st, [] {}); }
 
@@ -1509,7 +1516,7 @@ int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const doub
         if (deferred == nullptr && hook && mp->after_lists_enqueued != nullptr && hookFirst) mp->after_lists_enqueued(mp->after_lists_arg);
         if (!side) reciprocal(st);
         if (deferred == nullptr && hook && mp->after_lists_enqueued != nullptr && !hookFirst) mp->after_lists_enqueued(mp->after_lists_arg);
-    }, deferred);
+    }, deferred, !a.mutual);          // (mutual polarization: the solver's stage 5 puts the two words among its sums)
     if (rc != 0) { if (side) hipStreamWaitEvent(st, (hipEvent_t) mp->event_b, 0); return rc; }      // (the side chain does not outlive the call)
     if (mp->mixed_precision) hipLaunchKernelGGL(k_mp_special<false>, dim3((unsigned) (((size_t) a.n * MP_SPLIT + MP_BLOCK - 1) / MP_BLOCK)), dim3(MP_BLOCK), 0, st, a);
     // the field kernel's last lines read the reciprocal potential: with the side chain they are a launch of their own behind the wait, and the
@@ -1637,7 +1644,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bo
         if (e != hipSuccess) return (int) e;
         // the first wait of the call on this stream: what the list builder found (deferred check) -- lists that did not fit end the call here,
         // before anything has been added to the forces or the history
-        if (!listsChecked) { listsChecked = true; return deferred_lists_result(mp, deferred); }
+        if (!listsChecked) { listsChecked = true; deferred[0] = (int) h[13]; deferred[1] = (int) h[15]; return deferred_lists_result(mp, deferred); }
         return 0;
     };
     const bool haveHistory = mp->history != nullptr && mp->history_slots >= 1;

@@ -348,7 +348,7 @@ __device__ __forceinline__ int pl_at(const int* list, int stride, int subcap, co
 // `between` (optional) runs after the builder's kernels have been enqueued and before the host waits for the overflow word: work that does not
 // need the lists goes there, on this stream or another.
 template <class Between>
-static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st, int* buildsHost, Between between, int* deferred = nullptr) {
+static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st, int* buildsHost, Between between, int* deferred = nullptr, bool deferredCopies = true) {
     if (a.numScan > PL_POS_MASK) return 1;
     static const int debugMode = getenv("OPENMM_HIP_PL_DEBUG") != nullptr ? atoi(getenv("OPENMM_HIP_PL_DEBUG")) : 0;     // profiling only: wrong results
     a.debug = debugMode;
@@ -389,6 +389,8 @@ static inline int pl_launch(PairListArgs a, int* needed, hipStream_t st, int* bu
         // call returns at once -- the caller looks at them (pl_deferred_result) after its next wait on this stream, before anything is added
         // to the forces.  Lists that overflowed are truncated, never overrun: what walks them meanwhile fills work arrays with numbers
         // that the repeated call overwrites.
+        // (deferredCopies = false: the caller has the two words carried to the host by a copy of its own -- the multipole solver reads them with its sums)
+        if (!deferredCopies) return 0;
         hipError_t e = hipMemcpyAsync(&deferred[0], a.overflow, sizeof(int), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && a.state != nullptr) e = hipMemcpyAsync(&deferred[1], a.state + 2, sizeof(int), hipMemcpyDeviceToHost, st);
         return (int) e;

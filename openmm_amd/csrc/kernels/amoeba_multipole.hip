@@ -200,6 +200,7 @@ struct MpArgs {
     const int* order; int numScan;
     const int* pairList; const int* pairCount; int listStride, listSubcap;
     int precond; double precondCut2;               // neighbour-pair preconditioner of the solver (needs the pair cache)
+    const double* needDone;                        // kernels of a tail enqueued before the host has seen the convergence word run only if it is set (solve_mutual)
     const int* listOverflow; const int* listBuilds; // the list builder's overflow word and build counter (device): k_mp_cg stage 5 copies them into sums[13], sums[15]
     double* torque2;                               // k_mp_special<true> leaves its torques HERE (it runs beside k_mp_forces<true>, which stores into torque); k_mp_torque_to_force adds the two
     int pairsOnly;                                 // k_mp_field stops after the pair sums (k_mp_field_finish follows behind the wait for the reciprocal potential)
@@ -380,6 +381,7 @@ __device__ __forceinline__ int mpb_wrap_rel(int d, int n) { if (d >= (n + 1) / 2
 // left by the last block of stage 7.
 __global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double* __restrict__ A, double sA, const double* __restrict__ B, double sB, const double* __restrict__ A2, double* cgw) {
     if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;           // an iteration enqueued ahead of the convergence check (solve_mutual)
+    if (a.needDone != nullptr && *a.needDone == 0.0) return;           // the tail enqueued ahead of it: only once converged
     // two-grid launch: the second set of dipoles onto the second grid (the argument struct itself is left alone: a modified copy would
     // move all of it from scalar kernel-argument loads to private memory)
     float* const grid = blockIdx.y == 1 ? a.grid2 : a.grid;
@@ -484,6 +486,7 @@ __global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double
 template <int MAXORD>
 __global__ void k_mp_potential(MpArgs a, double* __restrict__ out, double* __restrict__ out2) {
     if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;
+    if (a.needDone != nullptr && *a.needDone == 0.0) return;
     const float* const grid = blockIdx.y == 1 ? a.grid2 : a.grid;          // (see k_mp_spread_bricks)
     if (blockIdx.y == 1) out = out2;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1176,12 +1179,13 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double target, double un
             if (stage == 4) { sums[0] = sums[6]; sums[1] = sums[7]; sums[11] += 1.0; }
             const double eps = debye * sqrt(fmax(sums[4], sums[5]) / a.n);
             sums[12] = eps;
-            if (eps < target) sums[10] = 1.0;
+            if (eps < target && sums[13] == 0.0) sums[10] = 1.0;          // (sums[13]: the list builder's overflow word -- such a solve never 'converges')
             sums[2] = sums[3] = sums[4] = sums[5] = sums[6] = sums[7] = 0.0;
         }
         return;
     }
     if (stage == 6) {
+        if (unused != 0.0 && sums[10] == 0.0) return;          // enqueued before the host has seen the convergence word: only once converged
         // After convergence: mu += alpha r, the update the Reference's iteration has already applied when ITS measure (the size of that very
         // update) falls below the target (convergeInduceDipolesByDIIS :939-1005) -- conjugate gradients stop with the residual of the
         // dipoles they return, one such update short.  No field evaluation: r is the residual of the converged dipoles.
@@ -1275,7 +1279,7 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double target, double un
                 sums[12] = eps;
                 sums[2] = sums[3] = sums[4] = sums[5] = sums[6] = sums[7] = 0.0;
                 __threadfence();
-                if (eps < target) sums[10] = 1.0;
+                if (eps < target && sums[13] == 0.0) sums[10] = 1.0;          // (sums[13]: the list builder's overflow word -- such a solve never 'converges')
             }
         }
         return;
@@ -1306,7 +1310,7 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double target, double un
                 const double eps = debye * sqrt(fmax(zzD, zzP) / a.n);
                 sums[12] = eps;
                 __threadfence();
-                if (eps < target) sums[10] = 1.0;
+                if (eps < target && sums[13] == 0.0) sums[10] = 1.0;          // (sums[13]: the list builder's overflow word -- such a solve never 'converges')
             }
         }
     }
@@ -1328,6 +1332,7 @@ struct HistoryCoeff { double c[OMMHIP_AMOEBA_MAX_HISTORY]; };
 __global__ void k_mp_history(MpArgs a, double* history, int slots, int newest, int count, int store, HistoryCoeff coeff) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
+    if (a.needDone != nullptr && *a.needDone == 0.0) return;
     const size_t n3 = 3 * (size_t) a.n;
     if (store) {
         double* rec = history + (size_t) newest * 2 * n3;
@@ -1437,7 +1442,7 @@ bool make_args(const ommhip_amoeba_multipole* mp, const void* pos_d, const doubl
     // per iteration -- no gain; the default stays z = alpha r
     static const bool usePrecond = getenv("OPENMM_HIP_AMOEBA_PRECOND") != nullptr && atoi(getenv("OPENMM_HIP_AMOEBA_PRECOND")) != 0;
     a.precond = a.pairCache != nullptr && usePrecond ? 1 : 0; a.precondCut2 = 0.45 * 0.45;
-    a.specialAdds = 0; a.pairsOnly = 0; a.torque2 = nullptr;
+    a.specialAdds = 0; a.pairsOnly = 0; a.torque2 = nullptr; a.needDone = nullptr;
     a.listOverflow = mp->pair_overflow; a.listBuilds = mp->skin > 0.0 && mp->ref_pos != nullptr && mp->list_state != nullptr ? mp->list_state + 2 : nullptr;
     a.doneFlag = nullptr;
     a.gather = a.mutual ? mp->solver_gather : nullptr;
@@ -1458,6 +1463,14 @@ int* deferred_words() {
     int* w = ring + 2 * (next++ % 16);
     w[0] = 0; w[1] = 0;
     return w;
+}
+
+// sixteen pinned doubles per call for the solver's sums when they are read behind an event (a small ring, as above)
+double* pinned_sums() {
+    static double* ring = nullptr;
+    static int next = 0;
+    if (ring == nullptr && hipHostMalloc((void**) &ring, sizeof(double) * 16 * 8, 0) != hipSuccess) { ring = nullptr; return nullptr; }
+    return ring + 16 * (next++ % 8);
 }
 
 template <class Between>
@@ -1720,6 +1733,12 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bo
     // critical path, and the small launches run at the side stream's priority.  OPENMM_HIP_AMOEBA_SPINE_MAIN=1: the spine on the main stream.
     static const bool spineMain = getenv("OPENMM_HIP_AMOEBA_SPINE_MAIN") != nullptr;
     const bool spineSide = overlap && !spineMain;
+    static const bool noSpeculation = getenv("OPENMM_HIP_AMOEBA_NO_SPECULATIVE_TAIL") != nullptr;       // A/B
+    static const bool noPolish = getenv("OPENMM_HIP_AMOEBA_NO_POLISH") != nullptr;        // A/B knob
+    static hipEvent_t sumsEvent = nullptr;
+    if (sumsEvent == nullptr && hipEventCreateWithFlags(&sumsEvent, hipEventDisableTiming) != hipSuccess) sumsEvent = nullptr;
+    const bool speculate = spineSide && finalOnSide && !noSpeculation && sumsEvent != nullptr && unchecked > 0;
+    bool tailEnqueued = false;
     if (spineSide && !done && enqueued < mp->max_iterations) {
         hipEventRecord((hipEvent_t) mp->event_a, st);                  // the residual of the first guess, stage 5
         hipStreamWaitEvent(st2, (hipEvent_t) mp->event_a, 0);
@@ -1735,11 +1754,44 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bo
             hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st2, a, w, 9, 0.0, 0.0);         // T p complete, A p, p . A p
             hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st2, aClear, w, 7, mp->target_epsilon, 0.0);
             enqueued++;
+            if (speculate && !tailEnqueued && enqueued >= unchecked && enqueued < mp->max_iterations) {
+                // The first look at the sums, with the TAIL of the solve enqueued in front of it (round 5): the sums travel to pinned memory behind
+                // an event of their own, and while the host waits for that event the device already has the last update, the history record and
+                // the chain of the converged dipoles' potentials in its queues -- all of them kernels that leave at once unless the
+                // convergence word is set (stage 6 with its last argument, MpArgs::needDone).  Converged (the usual case: as many iterations
+                // as the last solve took): the 40 us the host needs to notice are no longer on the critical path.  Not converged: the tail
+                // has done nothing, the loop goes on and the tail is enqueued again, the ordinary way, at the end.
+                double* const hp = pinned_sums();
+                if (hp != nullptr) {
+                    hipMemcpyAsync(hp, sums, sizeof(double) * 16, hipMemcpyDeviceToHost, st2);
+                    hipEventRecord(sumsEvent, st2);
+                    hipEventRecord((hipEvent_t) mp->event_a, st2);             // the main stream goes on behind the spine
+                    hipStreamWaitEvent(st, (hipEvent_t) mp->event_a, 0);
+                    MpArgs t = a;
+                    t.doneFlag = nullptr; t.needDone = sums + 10;
+                    if (!noPolish) hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, t, w, 6, 0.0, 1.0);
+                    if (haveHistory && mp->history_store >= 0)
+                        hipLaunchKernelGGL(k_mp_history, dim3(blocks), dim3(MP_BLOCK), 0, st, t, mp->history, mp->history_slots, mp->history_store % mp->history_slots, 0, 1, coeff);
+                    hipEventRecord((hipEvent_t) mp->event_a, st);
+                    hipStreamWaitEvent(st2, (hipEvent_t) mp->event_a, 0);
+                    dipole_potentials(mp, t, a.indD, a.phiInd, a.indP, a.phiIndP, st2, false, 0, true);
+                    hipEventRecord((hipEvent_t) mp->event_b, st2);
+                    const hipError_t e = hipEventSynchronize(sumsEvent);
+                    if (e != hipSuccess) return (int) e;
+                    for (int k = 0; k < 16; k++) h[k] = hp[k];
+                    if (!listsChecked) { listsChecked = true; deferred[0] = (int) h[13]; deferred[1] = (int) h[15]; rc = deferred_lists_result(mp, deferred); if (rc != 0) return rc; }
+                    done = h[10] != 0.0;
+                    tailEnqueued = done;
+                    continue;
+                }
+            }
             if (enqueued >= unchecked || enqueued == mp->max_iterations) { rc = readSums(); if (rc != 0) return rc; done = h[10] != 0.0; }
         }
         sumsStream = st;
-        hipEventRecord((hipEvent_t) mp->event_a, st2);                 // the main stream goes on behind the spine
-        hipStreamWaitEvent(st, (hipEvent_t) mp->event_a, 0);
+        if (!tailEnqueued) {
+            hipEventRecord((hipEvent_t) mp->event_a, st2);             // the main stream goes on behind the spine
+            hipStreamWaitEvent(st, (hipEvent_t) mp->event_a, 0);
+        }
     }
     while (!done && enqueued < mp->max_iterations && overlap) {
         hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 8, 0.0, 0.0);              // p = z + b p (b = 0 at first), packed for the gather
@@ -1783,7 +1835,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bo
     static const bool report = getenv("OPENMM_HIP_AMOEBA_DEBUG") != nullptr;
     if (report) fprintf(stderr, "amoeba solver: %d iterations (%d enqueued, first guess from %d earlier solutions), epsilon %.3g (target %.3g), preconditioner %d\n", iterations, enqueued, use, epsilon, mp->target_epsilon, a.precond);
     if (!done) return -1;
-    static const bool noPolish = getenv("OPENMM_HIP_AMOEBA_NO_POLISH") != nullptr;        // A/B knob
+    if (tailEnqueued) { mainBesideFinal(); return 0; }          // (the last update, the history record and the final potentials are in the queues already)
     if (!noPolish) hipLaunchKernelGGL(k_mp_cg, dim3(cgBlocks), dim3(MP_CG_BLOCK), 0, st, a, w, 6, 0.0, 0.0);
     if (haveHistory && mp->history_store >= 0)
         hipLaunchKernelGGL(k_mp_history, dim3(blocks), dim3(MP_BLOCK), 0, st, a, mp->history, mp->history_slots, mp->history_store % mp->history_slots, 0, 1, coeff);

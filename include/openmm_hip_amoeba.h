@@ -147,7 +147,10 @@ typedef struct ommhip_amoeba_multipole {
     int* pair_overflow;            /* device int work word */
     int* pair_needed;              /* HOST int written with the return code -2: the capacity that would have been enough (or NULL) */
     /* mutual polarization, optional: a second grid set (an ommhip_pme that shares everything but grid_real / grid_complex with `pme`), a side
-     * stream and two ordering events -- the potentials of the two dipole sets are then computed side by side */
+     * stream and two ordering events.  With them the potentials of the two dipole sets travel through the same launches on two grids, and
+     * (round 5) the side stream carries what needs neither the pair lists nor each other's results beside the long pair kernels of `stream`:
+     * the reciprocal potential of the permanent multipoles, the reciprocal chain and the vector stages of every solver iteration, the
+     * potentials of the converged dipoles.  Best created with a higher priority than `stream`. */
     void* pme2; void* stream2; void* event_a; void* event_b;
     float* pair_cache;             /* device float[5 * pair_cap * S] or NULL (mutual polarization): per list entry the separation and the two
                                     * coefficients of the damped dipole-dipole chain, written once per evaluation and read by every solver iteration */

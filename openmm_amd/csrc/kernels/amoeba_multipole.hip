@@ -32,6 +32,7 @@
 #include "../../../include/openmm_hip_amoeba.h"
 #include "../../../include/openmm_hip_kernels.h"
 #include "amoeba_pairs.h"
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -1457,20 +1458,19 @@ int scan_blocks(const MpArgs& a) { return (int) (((size_t) a.numScan * MP_SPLIT 
 // the pair lists of this evaluation (amoeba_pairs.h); -2: the lists did not fit into pair_cap entries per atom (*pair_needed says how many would)
 // two pinned host words per call for the deferred list check (overflow word, build counter); a small ring: one call is in flight per host thread
 int* deferred_words() {
-    static int* ring = nullptr;
-    static int next = 0;
-    if (ring == nullptr && hipHostMalloc((void**) &ring, sizeof(int) * 2 * 16, 0) != hipSuccess) { ring = nullptr; return nullptr; }
-    int* w = ring + 2 * (next++ % 16);
+    static int* const ring = [] { int* r = nullptr; return hipHostMalloc((void**) &r, sizeof(int) * 2 * 16, 0) == hipSuccess ? r : (int*) nullptr; }();
+    static std::atomic<unsigned> next(0);
+    if (ring == nullptr) return nullptr;
+    int* w = ring + 2 * (next.fetch_add(1) % 16);
     w[0] = 0; w[1] = 0;
     return w;
 }
 
 // sixteen pinned doubles per call for the solver's sums when they are read behind an event (a small ring, as above)
 double* pinned_sums() {
-    static double* ring = nullptr;
-    static int next = 0;
-    if (ring == nullptr && hipHostMalloc((void**) &ring, sizeof(double) * 16 * 8, 0) != hipSuccess) { ring = nullptr; return nullptr; }
-    return ring + 16 * (next++ % 8);
+    static double* const ring = [] { double* r = nullptr; return hipHostMalloc((void**) &r, sizeof(double) * 16 * 8, 0) == hipSuccess ? r : (double*) nullptr; }();
+    static std::atomic<unsigned> next(0);
+    return ring == nullptr ? nullptr : ring + 16 * (next.fetch_add(1) % 8);
 }
 
 template <class Between>

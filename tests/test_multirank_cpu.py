@@ -369,7 +369,8 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 hang = "import os, sys, time\nif os.environ['RANK'] == '1': time.sleep(600)\nprint('{\"attempt\": 0}')"
 crash = "import os, sys\nif os.environ['RANK'] == '0': sys.exit(3)\nimport time; time.sleep(600)"
 good = ("import os, torch, torch.distributed as dist\ndist.init_process_group('gloo')\nt = torch.ones(1); dist.all_reduce(t)\n"
-        "print('note'); print('{\"attempt\": %%s, \"port\": %%s, \"sum\": %%d}' %% (os.environ['BENCH_ATTEMPT'], os.environ['MASTER_PORT'], int(t.item())))")
+        "print('note'); print('{\"attempt\": %%s, \"port\": %%s, \"sum\": %%d}' %% (os.environ['BENCH_ATTEMPT'], os.environ['MASTER_PORT'], int(t.item())), flush=True)\n"
+        "dist.destroy_process_group()")      # (as bench.py ends: without it gloo's threads are torn down by the interpreter's exit, which aborts now and then on a busy machine)
 t0 = time.monotonic()
 idx, lines, notes = MR.run_attempts([[sys.executable, "-c", hang], [sys.executable, "-c", crash], [sys.executable, "-c", good]],
                                     rank, world, "127.0.0.1", int(os.environ["MASTER_PORT"]), timeout_s=20.0)      # (the good attempt imports torch: 8 s were not enough beside the 8-rank emulator test on 8 cores)

@@ -406,7 +406,7 @@ def test_bench_multi_gpu_flow_on_emulator_falls_back_and_reports_one_line():
     env = dict(os.environ, BENCH_EMULATED="1")
     proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                            "--master-port", "29671", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                           "--workload", "water1k", "--cpu-steps", "0", "--no-roofline", "--prepare-steps", "0", "--attempt-timeout", "200"],
+                           "--workload", "water1k", "--cpu-steps", "0", "--prepare-steps", "0", "--attempt-timeout", "200"],          # (WITH the roofline section, as the driver runs it: whatever rank 0 does there alone must not involve the Context -- the hang of rounds 4 - 5)
                           capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
     out = json.loads(proc.stdout.strip().splitlines()[-1])

@@ -43,6 +43,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this stack needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails otherwise); the GPU boxes export it -- kept if set
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector (non-matrix) peak

@@ -68,9 +68,9 @@ def parse_args():
     p.add_argument("--cpu-steps", type=int, default=150, help="steps of the CPU-platform baseline (0 disables it and the force-parity check)")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-scale-workload", action="store_true", help="N = 1: skip the single-GPU run of the strong-scaling workload")
-    p.add_argument("--prepare-steps", type=int, default=-1, help="untimed steps that relax a lattice start before warm-up (input preparation; default 1000 for the water boxes -- after 200 steps a jittered lattice is still melting: 9 % more list rows and 40 % more list rebuilds per step than after 3000, profiles/r04h_prepare_steps_water1m.txt -- 0 for fixtures)")
+    p.add_argument("--prepare-steps", type=int, default=-1, help="untimed steps that relax a lattice start before warm-up (input preparation; default 1000 for the water boxes -- after 200 steps a jittered lattice is still melting: 9 %% more list rows and 40 %% more list rebuilds per step than after 3000, profiles/r04h_prepare_steps_water1m.txt -- 0 for fixtures)")
     p.add_argument("--transport", default="rccl", choices=["rccl", "gloo"], help="collectives of the decomposed run: RCCL (product) or host-staged gloo (rehearsal on one GPU)")
-    p.add_argument("--profile-every", type=int, default=0, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region (0 = 7, or 4 for runs below 100 steps: a 20-step run then holds 6 samples and loses ~2 % to them)")
+    p.add_argument("--profile-every", type=int, default=0, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region (0 = 7, or 4 for runs below 100 steps: a 20-step run then holds 6 samples and loses ~2 %% to them)")
     p.add_argument("--no-pmc", action="store_true", help="N = 1: do not spawn the rocprofv3 child runs (FETCH_SIZE / WRITE_SIZE passes of the dominant launch group, kernel trace of the amoeba_dhfr workload) after the timed region")
     p.add_argument("--no-extra-workloads", action="store_true", help="N = 1: skip the short runs of BASELINE.json configs[2] (apoa1-sized) and of the benchmark script's own 4 fs step")
     p.add_argument("--decompose", action="store_true", help="N = 1: run through the decomposed path with a one-rank RCCL communicator (overhead check on one GPU)")

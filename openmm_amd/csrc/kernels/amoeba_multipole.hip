@@ -1735,7 +1735,7 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bo
     const bool spineSide = overlap && !spineMain;
     static const bool noSpeculation = getenv("OPENMM_HIP_AMOEBA_NO_SPECULATIVE_TAIL") != nullptr;       // A/B
     static const bool noPolish = getenv("OPENMM_HIP_AMOEBA_NO_POLISH") != nullptr;        // A/B knob
-    static hipEvent_t sumsEvent = nullptr;
+    static thread_local hipEvent_t sumsEvent = nullptr;      // (per host thread: two Contexts stepped from two threads must not share it)
     if (sumsEvent == nullptr && hipEventCreateWithFlags(&sumsEvent, hipEventDisableTiming) != hipSuccess) sumsEvent = nullptr;
     const bool speculate = spineSide && finalOnSide && !noSpeculation && sumsEvent != nullptr && unchecked > 0;
     bool tailEnqueued = false;

@@ -240,3 +240,24 @@ def test_one_rank_over_rccl_walks_every_collective_of_the_decomposed_step():
     assert np.array_equal(K.download(d_force, (3, slots), np.int64), expect)
     assert np.array_equal(rec_out, rec_in)
     assert lib.ommhip_comm_destroy(side) == 0 and lib.ommhip_comm_destroy(comm) == 0
+
+
+def test_bench_launcher_flow_with_two_ranks(tmp_path):
+    """`bench.py --gpus 2` started the way the driver starts it (torch.distributed.run, no extra flags: the roofline section runs): on a box
+    with one GPU both RCCL configurations end at once ("rank 1 has no GPU"), the launchers move to the host-staged transport together (two
+    ranks on GPU 0), the 985 527-atom box is stepped on two ranks and rank 0 prints ONE JSON line.  Rounds 4 - 5 hung here -- rank 0 took four
+    probe steps of the decomposed run alone in its roofline section -- and no test ran this flow on a GPU without --no-roofline."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_DEBUG_HANG="500")
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29721", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--attempt-timeout", "240"],
+                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    out = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 20 and out["value"] > 0
+    assert out["single_gpu_same_box"]["value"] > out["value"] * 0.1
+    assert out["single_gpu_same_box"]["initial_energy_kj_mol"]["rel_diff"] < 1e-5
+    print(out["value"], out["ms_per_step"], out["config"]["workload"][-200:])

@@ -1548,7 +1548,10 @@ int launch_induce(const ommhip_amoeba_multipole* mp, const MpArgs& a, const doub
 
 // the deferred list check, after a wait on the stream the lists were built on: 0, or -2 as build_pair_lists returns it
 int deferred_lists_result(const ommhip_amoeba_multipole* mp, const int* deferred) {
-    return pl_deferred_result(deferred, mp->pair_needed, mp->list_builds, mp->skin > 0.0 && mp->ref_pos != nullptr && mp->list_state != nullptr);
+    const int rc = pl_deferred_result(deferred, mp->pair_needed, mp->list_builds, mp->skin > 0.0 && mp->ref_pos != nullptr && mp->list_state != nullptr);
+    static const bool report = getenv("OPENMM_HIP_AMOEBA_DEBUG") != nullptr;
+    if (report && rc == -2) fprintf(stderr, "amoeba lists: did not fit (found at the deferred check): %d entries per atom needed\n", mp->pair_needed != nullptr ? *mp->pair_needed : -1);
+    return rc;
 }
 
 // potential (and derivatives) of one set of dipoles at the atoms

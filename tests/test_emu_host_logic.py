@@ -450,6 +450,18 @@ def test_amoeba_list_builder_leaves_out_blocks_in_the_tile_frame(tmp_path):
 
 
 @needs_emu
+def test_amoeba_mutual_solver_learns_of_overflowed_lists_at_its_first_wait(tmp_path):
+    """Mutual polarization with pair lists that start at 8 entries per atom: the multipole call does not wait for its list builder (round 5:
+    the overflow word travels to the host among the solver's sums), runs field kernels and solver iterations on the truncated lists, learns
+    of the overflow at the solver's first wait and returns -2 before anything has been added to the forces or the history; the plugin
+    grows the lists and calls again.  Forces and energy: those of the scan over all atoms (which grows its lists the same way)."""
+    from amoeba_water_case import run_amoeba_water_case
+    r = run_amoeba_water_case(tmp_path, True, 6, 24, True, with_reference=False, tiles_env={"OPENMM_HIP_AMOEBA_PAIR_CAP": "8"})
+    print(r)
+    assert r["full_scan"][0] < 1e-6 and r["full_scan"][1] < 1e-9          # (two converged solves: equal to the solver's tolerance, not to the last bit)
+
+
+@needs_emu
 def test_amoeba_dynamics_with_list_skin_and_predicted_dipoles_walks_the_same_trajectory(tmp_path):
     """Eight Verlet steps of a relaxed 375-atom AMOEBA water box (mutual polarization to 1e-6 D) on the emulator: lists with a Verlet skin
     rebuilt on displacement + the solver started from dipoles extrapolated from earlier steps + convergence decided on the device, against

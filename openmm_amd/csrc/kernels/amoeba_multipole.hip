@@ -1457,8 +1457,10 @@ int scan_blocks(const MpArgs& a) { return (int) (((size_t) a.numScan * MP_SPLIT 
 
 // the pair lists of this evaluation (amoeba_pairs.h); -2: the lists did not fit into pair_cap entries per atom (*pair_needed says how many would)
 // two pinned host words per call for the deferred list check (overflow word, build counter); a small ring: one call is in flight per host thread
+// (portable pinned memory: the ring is shared by the Contexts of every device of the process)
+#define OMMHIP_MP_MAX_DEVICES 64
 int* deferred_words() {
-    static int* const ring = [] { int* r = nullptr; return hipHostMalloc((void**) &r, sizeof(int) * 2 * 16, 0) == hipSuccess ? r : (int*) nullptr; }();
+    static int* const ring = [] { int* r = nullptr; return hipHostMalloc((void**) &r, sizeof(int) * 2 * 16, hipHostMallocPortable) == hipSuccess ? r : (int*) nullptr; }();
     static std::atomic<unsigned> next(0);
     if (ring == nullptr) return nullptr;
     int* w = ring + 2 * (next.fetch_add(1) % 16);
@@ -1468,7 +1470,7 @@ int* deferred_words() {
 
 // sixteen pinned doubles per call for the solver's sums when they are read behind an event (a small ring, as above)
 double* pinned_sums() {
-    static double* const ring = [] { double* r = nullptr; return hipHostMalloc((void**) &r, sizeof(double) * 16 * 8, 0) == hipSuccess ? r : (double*) nullptr; }();
+    static double* const ring = [] { double* r = nullptr; return hipHostMalloc((void**) &r, sizeof(double) * 16 * 8, hipHostMallocPortable) == hipSuccess ? r : (double*) nullptr; }();
     static std::atomic<unsigned> next(0);
     return ring == nullptr ? nullptr : ring + 16 * (next.fetch_add(1) % 8);
 }
@@ -1738,8 +1740,17 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bo
     const bool spineSide = overlap && !spineMain;
     static const bool noSpeculation = getenv("OPENMM_HIP_AMOEBA_NO_SPECULATIVE_TAIL") != nullptr;       // A/B
     static const bool noPolish = getenv("OPENMM_HIP_AMOEBA_NO_POLISH") != nullptr;        // A/B knob
-    static thread_local hipEvent_t sumsEvent = nullptr;      // (per host thread: two Contexts stepped from two threads must not share it)
-    if (sumsEvent == nullptr && hipEventCreateWithFlags(&sumsEvent, hipEventDisableTiming) != hipSuccess) sumsEvent = nullptr;
+    // One event per host thread AND device: an event belongs to the device that was current when it was created, and a thread may drive
+    // Contexts on several GPUs (DeviceIndex); recording it on another device's stream fails.
+    static thread_local hipEvent_t sumsEvents[OMMHIP_MP_MAX_DEVICES] = {};
+    hipEvent_t sumsEvent = nullptr;
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < OMMHIP_MP_MAX_DEVICES) {
+            if (sumsEvents[dev] == nullptr && hipEventCreateWithFlags(&sumsEvents[dev], hipEventDisableTiming) != hipSuccess) sumsEvents[dev] = nullptr;
+            sumsEvent = sumsEvents[dev];
+        }
+    }
     const bool speculate = spineSide && finalOnSide && !noSpeculation && sumsEvent != nullptr && unchecked > 0;
     bool tailEnqueued = false;
     if (spineSide && !done && enqueued < mp->max_iterations) {
@@ -1765,9 +1776,8 @@ int solve_mutual(const ommhip_amoeba_multipole* mp, MpArgs a, hipStream_t st, bo
                 // as the last solve took): the 40 us the host needs to notice are no longer on the critical path.  Not converged: the tail
                 // has done nothing, the loop goes on and the tail is enqueued again, the ordinary way, at the end.
                 double* const hp = pinned_sums();
-                if (hp != nullptr) {
-                    hipMemcpyAsync(hp, sums, sizeof(double) * 16, hipMemcpyDeviceToHost, st2);
-                    hipEventRecord(sumsEvent, st2);
+                // (a copy or an event that could not be enqueued: the ordinary, synchronous look at the sums below)
+                if (hp != nullptr && hipMemcpyAsync(hp, sums, sizeof(double) * 16, hipMemcpyDeviceToHost, st2) == hipSuccess && hipEventRecord(sumsEvent, st2) == hipSuccess) {
                     hipEventRecord((hipEvent_t) mp->event_a, st2);             // the main stream goes on behind the spine
                     hipStreamWaitEvent(st, (hipEvent_t) mp->event_a, 0);
                     MpArgs t = a;

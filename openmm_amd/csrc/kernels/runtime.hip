@@ -15,7 +15,9 @@ int ommhip_device_info(int device, char* name, int name_len, int* num_cus, size_
     hipError_t e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) return (int) e;
     if (name != nullptr && name_len > 0) {
-        snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+        // (some driver stacks leave the marketing name empty: the architecture, CU count and memory then say what the device is)
+        if (prop.name[0] != 0) snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+        else snprintf(name, name_len, "AMD GPU, %d CUs, %.0f GB (%s)", prop.multiProcessorCount, (double) prop.totalGlobalMem / 1073741824.0, prop.gcnArchName);
     }
     if (num_cus != nullptr) *num_cus = prop.multiProcessorCount;
     if (total_mem != nullptr) *total_mem = prop.totalGlobalMem;

@@ -1701,6 +1701,114 @@ void HipCalcNonbondedForceKernel::getLJPMEParameters(double& alpha, int& nx, int
 }
 
 // ================================================================================================
+// CalcPmeReciprocalForce (kernels.h:1493-1560): reciprocal space alone, host arrays in and out
+// ================================================================================================
+HipCalcPmeReciprocalForceKernel::HipCalcPmeReciprocalForceKernel(std::string name, const Platform& platform, int deviceIndex) : CalcPmeReciprocalForceKernel(name, platform),
+        deviceIndex(deviceIndex), numParticles(0), paddedAtoms(0), alpha(0.0), deterministic(false), includeEnergy(false), started(false), stream(NULL), pinnedEnergy(NULL) {
+    grid[0] = grid[1] = grid[2] = 0;
+    memset(&pme, 0, sizeof(pme));
+    for (int i = 0; i < 6; i++) lastBox[i] = 0.0;
+}
+
+HipCalcPmeReciprocalForceKernel::~HipCalcPmeReciprocalForceKernel() {
+    if (stream != NULL) { ommhip_stream_sync(stream); ommhip_stream_destroy(stream); }
+    if (pinnedEnergy != NULL) ommhip_host_free(pinnedEnergy);
+}
+
+void HipCalcPmeReciprocalForceKernel::initialize(int gridx, int gridy, int gridz, int numParticles, double alpha, bool deterministic) {
+    // the caller chose the grid (NonbondedForceImpl::calcPMEParameters rounds to FFT-friendly sizes of ITS transform): this one takes
+    // lengths that factor into 2, 3, 5 and 7 and fit a line buffer in LDS
+    if (!ommhip_fft_supported_size(gridx) || !ommhip_fft_supported_size(gridy) || !ommhip_fft_supported_size(gridz))
+        throw OpenMMException("HIP platform: CalcPmeReciprocalForceKernel: grid dimensions must factor into 2, 3, 5 and 7");
+    if (deviceIndex >= 0) HIP_CHECK(ommhip_set_device(deviceIndex));
+    if (stream == NULL) HIP_CHECK(ommhip_stream_create(&stream));
+    if (pinnedEnergy == NULL) HIP_CHECK(ommhip_host_malloc((void**) &pinnedEnergy, sizeof(double) * 8));
+    this->numParticles = numParticles; this->alpha = alpha; this->deterministic = deterministic;
+    grid[0] = gridx; grid[1] = gridy; grid[2] = gridz;
+    paddedAtoms = max(OMMHIP_TILE, (numParticles + OMMHIP_TILE - 1) / OMMHIP_TILE * OMMHIP_TILE);
+    const int nzc = gridz / 2 + 1;
+    uploadVector(moduliX, bsplineModuli(gridx), stream);
+    uploadVector(moduliY, bsplineModuli(gridy), stream);
+    uploadVector(moduliZ, bsplineModuli(gridz), stream);
+    DeviceBuffer* tw[3] = {&twiddleX, &twiddleY, &twiddleZ};
+    for (int d = 0; d < 3; d++) {
+        const int n = grid[d];
+        vector<float> t(2 * (size_t) n);
+        for (int k = 0; k < n; k++) { t[2 * k] = (float) cos(2.0 * M_PI * k / n); t[2 * k + 1] = (float) -sin(2.0 * M_PI * k / n); }
+        uploadVector(*tw[d], t, stream);
+    }
+    eterm.allocate(sizeof(float) * (size_t) gridx * gridy * nzc);
+    gridReal.allocate((sizeof(float) * (size_t) gridx * gridy * gridz + 15) / 16 * 16);
+    gridComplex.allocate(sizeof(float) * 2 * (size_t) gridx * gridy * nzc);
+    posq.allocate(sizeof(float) * 4 * (size_t) paddedAtoms);
+    force.allocate(sizeof(long long) * 3 * (size_t) paddedAtoms);
+    forceDouble.allocate(sizeof(double) * 3 * (size_t) max(numParticles, 1));
+    energyBuffer.allocate(sizeof(double) * HipContext::EnergySlots);
+    energyResult.allocate(sizeof(double) * 8);
+    HIP_CHECK(ommhip_memset(energyBuffer.ptr, 0, energyBuffer.bytes, stream));
+    vector<int> identity(max(numParticles, 1));
+    for (int i = 0; i < numParticles; i++) identity[i] = i;          // slot order = atom order: the caller's posq is taken as it comes
+    uploadVector(slotOfAtom, identity, stream);
+    memset(&pme, 0, sizeof(pme));
+    pme.nx = gridx; pme.ny = gridy; pme.nz = gridz; pme.alpha = alpha;
+    pme.moduli_x = moduliX.as<double>(); pme.moduli_y = moduliY.as<double>(); pme.moduli_z = moduliZ.as<double>();
+    pme.eterm = eterm.ptr; pme.grid_real = gridReal.ptr; pme.grid_complex = gridComplex.ptr;
+    pme.twiddle_x = twiddleX.ptr; pme.twiddle_y = twiddleY.ptr; pme.twiddle_z = twiddleZ.ptr;
+    pme.phases = OMMHIP_PME_ALL;
+    for (int i = 0; i < 6; i++) lastBox[i] = 0.0;
+    HIP_CHECK(ommhip_stream_sync(stream));
+}
+
+void HipCalcPmeReciprocalForceKernel::beginComputation(IO& io, const Vec3* periodicBoxVectors, bool includeEnergy) {
+    if (stream == NULL) throw OpenMMException("HIP platform: CalcPmeReciprocalForceKernel::beginComputation before initialize");
+    if (deviceIndex >= 0) HIP_CHECK(ommhip_set_device(deviceIndex));
+    this->includeEnergy = includeEnergy;
+    const double box[6] = {periodicBoxVectors[0][0], periodicBoxVectors[1][0], periodicBoxVectors[1][1], periodicBoxVectors[2][0], periodicBoxVectors[2][1], periodicBoxVectors[2][2]};
+    bool boxChanged = false;
+    for (int i = 0; i < 6; i++) { if (box[i] != lastBox[i]) boxChanged = true; pme.box[i] = lastBox[i] = box[i]; }
+    if (boxChanged) HIP_CHECK(ommhip_pme_build_eterm(&pme, stream));
+    // posq: x, y, z, q per atom, as the reference's GPU platforms hand it over (CudaKernels.cpp PmeIO); padding slots carry no charge
+    vector<float> hostPosq(4 * (size_t) paddedAtoms, 0.f);
+    const float* in = io.getPosq();
+    double maxCharge = 0.0;
+    for (int i = 0; i < numParticles; i++) {
+        for (int k = 0; k < 4; k++) hostPosq[4 * (size_t) i + k] = in[4 * (size_t) i + k];
+        maxCharge = max(maxCharge, (double) fabs(in[4 * (size_t) i + 3]));
+    }
+    for (int i = numParticles; i < paddedAtoms; i++)
+        for (int k = 0; k < 3; k++) hostPosq[4 * (size_t) i + k] = numParticles > 0 ? in[k] : 0.f;
+    pme.deterministic = deterministic ? 1 : 0; pme.max_charge = maxCharge;
+    HIP_CHECK(ommhip_memcpy_h2d(posq.ptr, hostPosq.data(), sizeof(float) * hostPosq.size(), stream));
+    HIP_CHECK(ommhip_memset(force.ptr, 0, force.bytes, stream));
+    HIP_CHECK(ommhip_pme_reciprocal(&pme, posq.ptr, paddedAtoms, force.as<long long>(), energyBuffer.as<double>(), HipContext::EnergySlots, includeEnergy ? 1 : 0, stream));
+    HIP_CHECK(ommhip_forces_to_double(force.as<long long>(), slotOfAtom.as<int>(), numParticles, paddedAtoms, forceDouble.as<double>(), stream));
+    hostForceDouble.resize(3 * (size_t) max(numParticles, 1));
+    HIP_CHECK(ommhip_stream_sync(stream));          // (hostPosq goes out of scope)
+    if (numParticles > 0) HIP_CHECK(ommhip_memcpy_d2h(hostForceDouble.data(), forceDouble.ptr, sizeof(double) * 3 * (size_t) numParticles, stream));
+    if (includeEnergy) {
+        HIP_CHECK(ommhip_reduce_energy(energyBuffer.as<double>(), HipContext::EnergySlots, energyResult.as<double>(), stream));
+        HIP_CHECK(ommhip_memcpy_d2h(pinnedEnergy, energyResult.ptr, sizeof(double), stream));
+    }
+    started = true;
+}
+
+double HipCalcPmeReciprocalForceKernel::finishComputation(IO& io) {
+    if (!started) throw OpenMMException("HIP platform: CalcPmeReciprocalForceKernel::finishComputation without beginComputation");
+    started = false;
+    if (deviceIndex >= 0) HIP_CHECK(ommhip_set_device(deviceIndex));
+    HIP_CHECK(ommhip_stream_sync(stream));
+    hostForce.assign(4 * (size_t) max(numParticles, 1), 0.f);
+    for (int i = 0; i < numParticles; i++)
+        for (int k = 0; k < 3; k++) hostForce[4 * (size_t) i + k] = (float) hostForceDouble[3 * (size_t) i + k];
+    io.setForce(hostForce.data());
+    return includeEnergy ? pinnedEnergy[0] : 0.0;
+}
+
+void HipCalcPmeReciprocalForceKernel::getPMEParameters(double& alpha, int& nx, int& ny, int& nz) const {
+    alpha = this->alpha; nx = grid[0]; ny = grid[1]; nz = grid[2];
+}
+
+// ================================================================================================
 // Bonded terms
 // ================================================================================================
 ommhip_term_batch HipTermForce::batch() const {

@@ -108,6 +108,32 @@ public:
     void computePositions(ContextImpl& context) {}
 };
 
+/** kernels.h:1493-1560 CalcPmeReciprocalForceKernel + ::IO -- reciprocal space on its own (the optional sub-boundary of SURVEY.md 8(b): the
+ *  reference's GPU platforms can hand reciprocal space to such a kernel, plugins/cpupme is its CPU implementation).  Host posq in, host float
+ *  forces out through the IO object; in between ommhip_pme_reciprocal: spreading, the hand-written 3-D FFT with the influence function, interpolation.
+ *  Usable without a Context (constructed directly, as plugins/cpupme/tests/TestCpuPme.cpp does) on the current device, or through
+ *  HipKernelFactory on the Context's device. */
+class HipCalcPmeReciprocalForceKernel : public CalcPmeReciprocalForceKernel {
+public:
+    HipCalcPmeReciprocalForceKernel(std::string name, const Platform& platform, int deviceIndex = -1);
+    ~HipCalcPmeReciprocalForceKernel();
+    void initialize(int gridx, int gridy, int gridz, int numParticles, double alpha, bool deterministic);
+    void beginComputation(IO& io, const Vec3* periodicBoxVectors, bool includeEnergy);
+    double finishComputation(IO& io);
+    void getPMEParameters(double& alpha, int& nx, int& ny, int& nz) const;
+private:
+    int deviceIndex, numParticles, paddedAtoms, grid[3];
+    double alpha;
+    bool deterministic, includeEnergy, started;
+    void* stream;
+    ommhip_pme pme;
+    DeviceBuffer moduliX, moduliY, moduliZ, twiddleX, twiddleY, twiddleZ, eterm, gridReal, gridComplex, posq, force, forceDouble, slotOfAtom, energyBuffer, energyResult;
+    std::vector<float> hostForce;
+    std::vector<double> hostForceDouble;
+    double lastBox[6];
+    double* pinnedEnergy;
+};
+
 /** kernels.h:556-614 CalcNonbondedForceKernel; Reference: ReferenceKernels.cpp:864-1121. */
 class HipCalcNonbondedForceKernel : public CalcNonbondedForceKernel, public HipContextListener {
 public:

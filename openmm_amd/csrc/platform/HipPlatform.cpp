@@ -32,6 +32,7 @@
 #include "openmm/LangevinMiddleIntegrator.h"
 #include "openmm/VerletIntegrator.h"
 #include "openmm/kernels.h"
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <sstream>
@@ -58,6 +59,7 @@ struct HipModeInfo {
     bool hasPluginNativeForces;  // forces evaluated by a native kernel of another plugin (registerNativeKernel), e.g. the AMOEBA forces
     bool hasValenceForces;       // Custom*Forces with a recognised expression (the AMOEBA valence terms): native, single GPU only
     bool customIntegrator;       // a CustomIntegrator run by the device interpreter (single GPU only)
+    std::string fallbackNames;   // class names of the Forces that run as Reference kernels (the FallbackForces property)
 };
 
 namespace {
@@ -81,7 +83,7 @@ bool HipPlatform::isNativeForce(const Force& force, const System& system) {
 }
 
 static HipModeInfo classifyContext(ContextImpl& context) {
-    HipModeInfo info = {false, false, false, false, false, false, false};
+    HipModeInfo info = {false, false, false, false, false, false, false, ""};
     const System& system = context.getSystem();
     const Integrator& integrator = context.getIntegrator();
     if (dynamic_cast<const VerletIntegrator*>(&integrator) == NULL && dynamic_cast<const LangevinIntegrator*>(&integrator) == NULL &&
@@ -98,7 +100,7 @@ static HipModeInfo classifyContext(ContextImpl& context) {
         if (const NonbondedForce* nb = dynamic_cast<const NonbondedForce*>(&f)) {
             // LJPME is native too (dispersion grid + direct-space correction); OPENMM_HIP_REFERENCE_LJPME=1 restores the Reference kernel (A/B)
             char* refLj = getenv("OPENMM_HIP_REFERENCE_LJPME");
-            if (nb->getNonbondedMethod() == NonbondedForce::LJPME && refLj != NULL && string(refLj) == "1") { info.referenceNonbonded = true; info.hasFallbackForces = true; }
+            if (nb->getNonbondedMethod() == NonbondedForce::LJPME && refLj != NULL && string(refLj) == "1") { info.referenceNonbonded = true; info.hasFallbackForces = true; info.fallbackNames += string(info.fallbackNames.empty() ? "" : ",") + "NonbondedForce"; }
             continue;
         }
         if (dynamic_cast<const HarmonicBondForce*>(&f) != NULL || dynamic_cast<const HarmonicAngleForce*>(&f) != NULL ||
@@ -124,6 +126,15 @@ static HipModeInfo classifyContext(ContextImpl& context) {
         }
         // Any other Force: its Reference kernel only reads positions and adds forces.
         info.hasFallbackForces = true;
+        {
+            // (the mangled class name without its length prefixes: "N6OpenMM12GBSAOBCForceE" -> "GBSAOBCForce")
+            string n = typeid(f).name();
+            const size_t at = n.find("OpenMM");
+            if (at != string::npos) n = n.substr(at + 6);
+            while (!n.empty() && isdigit((unsigned char) n[0])) n.erase(0, 1);
+            if (!n.empty() && n[n.size() - 1] == 'E') n.erase(n.size() - 1);
+            info.fallbackNames += (info.fallbackNames.empty() ? "" : ",") + n;
+        }
     }
     char* forceHost = getenv("OPENMM_HIP_FORCE_HOST_MODE");
     if (forceHost != NULL && string(forceHost) == "1") info.hostMode = true;
@@ -139,6 +150,8 @@ public:
             return new HipCalcForcesAndEnergyKernel(name, platform, data);
         if (name == CalcNonbondedForceKernel::Name() && !data.referenceNonbonded)
             return new HipCalcNonbondedForceKernel(name, platform, data);
+        if (name == CalcPmeReciprocalForceKernel::Name())
+            return new HipCalcPmeReciprocalForceKernel(name, platform, data.hip->getDeviceIndex());
         if (name == CalcHarmonicBondForceKernel::Name())
             return new HipCalcHarmonicBondForceKernel(name, platform, data);
         if (name == CalcHarmonicAngleForceKernel::Name())
@@ -194,6 +207,7 @@ HipPlatform::HipPlatform() {
     registerKernelFactory(ApplyConstraintsKernel::Name(), factory);
     registerKernelFactory(VirtualSitesKernel::Name(), factory);
     registerKernelFactory(CalcNonbondedForceKernel::Name(), factory);
+    registerKernelFactory(CalcPmeReciprocalForceKernel::Name(), factory);
     registerKernelFactory(CalcHarmonicBondForceKernel::Name(), factory);
     registerKernelFactory(CalcHarmonicAngleForceKernel::Name(), factory);
     registerKernelFactory(CalcPeriodicTorsionForceKernel::Name(), factory);
@@ -213,12 +227,14 @@ HipPlatform::HipPlatform() {
     platformProperties.push_back(HipDisablePmeStream());
     platformProperties.push_back(HipIntegrationMode());
     platformProperties.push_back(HipConstraintPartition());
+    platformProperties.push_back(HipFallbackForces());
     platformProperties.push_back(HipRanks());
     platformProperties.push_back(HipRank());
     platformProperties.push_back(HipCommId());
     setPropertyDefaultValue(HipRanks(), "1");
     setPropertyDefaultValue(HipIntegrationMode(), "");
     setPropertyDefaultValue(HipConstraintPartition(), "");
+    setPropertyDefaultValue(HipFallbackForces(), "");
     setPropertyDefaultValue(HipRank(), "0");
     setPropertyDefaultValue(HipCommId(), "");
     setPropertyDefaultValue(HipDeviceIndex(), "");
@@ -343,6 +359,7 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
     data->propertyValues[HipDeviceName()] = name;
     data->propertyValues[HipPrecision()] = "mixed";
     data->propertyValues[HipIntegrationMode()] = mode.hostMode ? "host" : (mode.customIntegrator ? "device, custom integrator" : "device");
+    data->propertyValues[HipFallbackForces()] = mode.hostMode ? "host mode" : (mode.fallbackNames.empty() ? "none" : mode.fallbackNames);
     data->propertyValues[HipDeterministicForces()] = (properties.find(HipDeterministicForces()) == properties.end() ?
             getPropertyDefaultValue(HipDeterministicForces()) : properties.find(HipDeterministicForces())->second);
     data->propertyValues[HipDisablePmeStream()] = (properties.find(HipDisablePmeStream()) == properties.end() ?

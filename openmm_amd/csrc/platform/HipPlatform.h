@@ -43,6 +43,8 @@ public:
     /** Read-only: "device" (native integrator, state in HBM), "device, custom integrator" or "host" (Reference integration kernels; see HipPlatform.cpp). */
     static const std::string& HipIntegrationMode() { static const std::string key = "IntegrationMode"; return key; }
     /** read-only, filled when the Context's constraints are first needed: "settle <clusters> shake <clusters> ccma <constraints>" */
+    /** Read-only: the Forces of the System that run as Reference kernels on a host copy of the positions ("none" when every Force has a native kernel). */
+    static const std::string& HipFallbackForces() { static const std::string key = "FallbackForces"; return key; }
     static const std::string& HipConstraintPartition() { static const std::string key = "ConstraintPartition"; return key; }
     /** One box on several GPUs, one process per GPU: "Ranks" = number of processes, "Rank" = this one's index, "CommId" = the
      *  ncclUniqueId (hex) created with ommhip_comm_unique_id() on rank 0 and distributed by the launcher, or

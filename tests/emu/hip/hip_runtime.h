@@ -63,7 +63,7 @@ enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNotReady = 600 };
 typedef struct emuStream* hipStream_t;
 typedef struct emuEvent* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
-enum { hipHostMallocDefault = 0, hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipEventDefault = 0 };
+enum { hipHostMallocDefault = 0, hipHostMallocPortable = 1, hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipEventDefault = 0 };
 struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcessorCount; size_t totalGlobalMem; int clockRate; };
 
 extern "C" {

@@ -251,7 +251,9 @@ def test_pme_logic(K, tric):
 FAST_REFERENCE_TESTS = ["HarmonicBondForce", "HarmonicAngleForce", "PeriodicTorsionForce", "CMMotionRemover", "Checkpoints",
                         "CustomBondForce", "RBTorsionForce", "Settle", "NonbondedForce", "CustomExternalForce", "VirtualSites",
                         "AmoebaVdwForce", "AmoebaMultipoleForce", "AmoebaTorsionTorsionForce", "AmoebaExtrapolatedPolarization",
-                        "CustomAngleForce", "CustomCompoundBondForce"]
+                        "CustomAngleForce", "CustomCompoundBondForce",
+                        # tests/hip/TestHipPmeKernel.cpp: CalcPmeReciprocalForceKernel + ::IO, the HIP twin of plugins/cpupme/tests/TestCpuPme.cpp's testPME
+                        "PmeKernel"]
 
 
 @needs_emu

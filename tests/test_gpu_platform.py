@@ -27,7 +27,9 @@ REFERENCE_TEST_BODIES = ["NonbondedForce", "Ewald", "VerletIntegrator", "Settle"
                          # plugins/amoeba/tests with libOpenMMAmoebaHIP.so loaded: AmoebaVdwForce (and the PME cases of
                          # AmoebaMultipoleForce) run on the native kernels -- NATIVE_AMOEBA below says which evaluation counter must
                          # move; AmoebaTorsionTorsionForce runs on kernels/valence.hip
-                         "AmoebaVdwForce", "AmoebaMultipoleForce", "AmoebaTorsionTorsionForce", "AmoebaExtrapolatedPolarization"]
+                         "AmoebaVdwForce", "AmoebaMultipoleForce", "AmoebaTorsionTorsionForce", "AmoebaExtrapolatedPolarization",
+                         # tests/hip/TestHipPmeKernel.cpp: CalcPmeReciprocalForceKernel + ::IO (kernels.h:1493-1560), the HIP twin of plugins/cpupme/tests/TestCpuPme.cpp's testPME
+                         "PmeKernel"]
 NATIVE_AMOEBA = {"AmoebaVdwForce": "vdw", "AmoebaMultipoleForce": "multipole", "AmoebaExtrapolatedPolarization": "multipole"}         # test body -> counter printed by tests/hip/HipAmoebaTests.h at exit
 
 

@@ -14,6 +14,7 @@
 #   ranks:N[:bench-args]         N ranks of the decomposed run on the visible GPUs (RCCL when there are N GPUs, else the launcher falls back)
 #   serial:N                     N ranks serialised on one GPU over the host-staged transport: per-rank compute per step
 #   serialtrace:N                the same under rocprofv3 --kernel-trace --stats (per-rank kernel statistics)
+#   serialtimeline:N[:count]     the same under rocprofv3: timeline of the busiest rank's last dispatches + its kernel statistics
 #   sh:"command"                 anything else
 cd "$(dirname "$0")/.."
 R=$(pwd); T=${TAG:-visit}
@@ -75,10 +76,16 @@ for step in "$@"; do
         > gpurun_out/${T}_serialized_n$a1.json 2> gpurun_out/${T}_serialized_n$a1.err; echo "serialized N=$a1 exit $?"
       tail -1 gpurun_out/${T}_serialized_n$a1.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['per_rank_compute_ms_per_step']['ranks'], d['per_rank_compute_ms_per_step']['collectives_per_step'])" ;;
     serialtrace)     # the same under rocprofv3: kernel statistics of every rank's process (one file per rank; the busiest is shown)
-      ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_sn$a1 -o trace -- python -m torch.distributed.run --nnodes=1 --nproc-per-node $a1 --master-addr 127.0.0.1 --master-port $((29500 + RANDOM % 400)) $R/bench.py --gpus $a1 --steps 60 --warmup 5 --transport gloo --serialize-ranks --no-scale-workload --no-roofline \
+      ( cd /tmp && export TMPDIR=/tmp BENCH_NO_HARD_EXIT=1 && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_sn$a1 -o trace -- python -m torch.distributed.run --nnodes=1 --nproc-per-node $a1 --master-addr 127.0.0.1 --master-port $((29500 + RANDOM % 400)) $R/bench.py --gpus $a1 --steps 60 --warmup 5 --transport gloo --serialize-ranks --no-scale-workload --no-roofline \
         > $R/gpurun_out/${T}_serialtrace_n$a1.json 2> $R/gpurun_out/${T}_serialtrace_n$a1.err; echo "rocprof serialized N=$a1 exit $?" )
       k=0; for f in $(find gpurun_out/prof_sn$a1 -name "*kernel_stats.csv" | xargs ls -S); do k=$((k+1)); cp $f gpurun_out/${T}_serial_n${a1}_kernel_stats_$k.csv; done
       head -22 gpurun_out/${T}_serial_n${a1}_kernel_stats_1.csv | cut -c1-200; rm -rf gpurun_out/prof_sn$a1 ;;
+    serialtimeline)  # the same under rocprofv3: the last dispatches of the busiest rank's process as a timeline (what runs beside what, per queue)
+      ( cd /tmp && export TMPDIR=/tmp BENCH_NO_HARD_EXIT=1 && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_st$a1 -o trace -- python -m torch.distributed.run --nnodes=1 --nproc-per-node $a1 --master-addr 127.0.0.1 --master-port $((29500 + RANDOM % 400)) $R/bench.py --gpus $a1 --steps 40 --warmup 5 --transport gloo --serialize-ranks --no-scale-workload --no-roofline \
+        > $R/gpurun_out/${T}_serialtimeline_n$a1.json 2> $R/gpurun_out/${T}_serialtimeline_n$a1.err; echo "rocprof serialized N=$a1 exit $?" )
+      f=$(find gpurun_out/prof_st$a1 -name "*kernel_trace.csv" | xargs -r ls -S | head -1)
+      if [ -n "$f" ]; then python tools/rocpd_timeline.py $f ${a2:-160} > gpurun_out/${T}_serial_n${a1}_timeline.txt 2>&1; cp ${f%kernel_trace.csv}kernel_stats.csv gpurun_out/${T}_serial_n${a1}_kernel_stats.csv; else find gpurun_out/prof_st$a1 | head; fi
+      tail -${a2:-160} gpurun_out/${T}_serial_n${a1}_timeline.txt | cut -c1-150; rm -rf gpurun_out/prof_st$a1 ;;
     sh) bash -c "$a1" ;;
     *) echo "unknown step $kind" ;;
   esac

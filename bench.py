@@ -70,7 +70,7 @@ def parse_args():
     p.add_argument("--no-scale-workload", action="store_true", help="N = 1: skip the single-GPU run of the strong-scaling workload")
     p.add_argument("--prepare-steps", type=int, default=-1, help="untimed steps that relax a lattice start before warm-up (input preparation; default 1000 for the water boxes -- after 200 steps a jittered lattice is still melting: 9 %% more list rows and 40 %% more list rebuilds per step than after 3000, profiles/r04h_prepare_steps_water1m.txt -- 0 for fixtures)")
     p.add_argument("--transport", default="rccl", choices=["rccl", "gloo"], help="collectives of the decomposed run: RCCL (product) or host-staged gloo (rehearsal on one GPU)")
-    p.add_argument("--profile-every", type=int, default=0, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region (0 = 7, or 4 for runs below 100 steps: a 20-step run then holds 6 samples and loses ~2 %% to them)")
+    p.add_argument("--profile-every", type=int, default=0, help="HIP-event timing of every n-th launch of each profiled kernel inside the timed region (0 = 7: a 20-step run then holds 3 samples)")
     p.add_argument("--no-pmc", action="store_true", help="N = 1: do not spawn the rocprofv3 child runs (FETCH_SIZE / WRITE_SIZE passes of the dominant launch group, kernel trace of the amoeba_dhfr workload) after the timed region")
     p.add_argument("--no-extra-workloads", action="store_true", help="N = 1: skip the short runs of BASELINE.json configs[2] (apoa1-sized) and of the benchmark script's own 4 fs step")
     p.add_argument("--decompose", action="store_true", help="N = 1: run through the decomposed path with a one-rank RCCL communicator (overhead check on one GPU)")
@@ -283,9 +283,9 @@ def main():
     if profile:
         kernels.lib.ommhip_profile_reset()
         # the timed region is perturbed as little as possible: events are created beforehand; a short region (the driver's 20 steps) times
-        # only the dominant launch group, every 4th launch (6 samples), a long one all five timers at every 7th launch
+        # only the dominant launch group, a long one all five timers -- at every 7th launch either way (three samples in 20 steps)
         short = args.steps < 100 and args.profile_every <= 0
-        kernels.lib.ommhip_profile_enable_timers(args.profile_every if args.profile_every > 0 else (4 if short else 7), 0x1 if short else 0x1f, 64 if short else 512)
+        kernels.lib.ommhip_profile_enable_timers(args.profile_every if args.profile_every > 0 else 7, 0x1 if short else 0x1f, 64 if short else 512)
     serialized = decomposed and args.serialize_ranks and args.transport == "gloo"
     if serialized:
         barrier()

@@ -343,6 +343,11 @@ typedef struct ommhip_pme {
     int tile_cap, max_tiles;
     const void* block_center;  /* device float4[padded_atoms / 32] */
     const void* block_half;
+    /* Slab decomposition in halo mode: the slot ranges this rank holds current positions for (its own slots and the sections its neighbours
+     * send: ommhip_neighbor_list::active_range); the spreading launch then covers these ranges only instead of every slot of the box.
+     * dd_num_active_ranges = 0: all slots (blocks without positions are skipped through block_half as before). */
+    int dd_num_active_ranges;
+    int dd_active_range[8];
 } ommhip_pme;
 enum { OMMHIP_PME_ALL = 0, OMMHIP_PME_SPREAD_ONLY = 1, OMMHIP_PME_AFTER_SPREAD = 2, OMMHIP_PME_INTERPOLATE_ONLY = 3 };
 

@@ -53,6 +53,7 @@ class Pme(C.Structure):
         ("charge", C.c_void_p), ("excl_periodic", C.c_int), ("phases", C.c_int), ("deterministic", C.c_int), ("max_charge", C.c_double), ("dispersion", C.c_int),
         ("dd_ranks", C.c_int), ("dd_rank", C.c_int), ("dd_halo", C.c_int), ("grid_complex2", C.c_void_p), ("comm", C.c_void_p), ("dd_error", C.c_void_p),
         ("tile_count", C.c_void_p), ("tile_blocks", C.c_void_p), ("tile_cap", C.c_int), ("max_tiles", C.c_int), ("block_center", C.c_void_p), ("block_half", C.c_void_p),
+        ("dd_num_active_ranges", C.c_int), ("dd_active_range", C.c_int * 8),
     ]
 
 

@@ -55,6 +55,9 @@ struct PmeArgs {
     int* tileCount; int* tileBlocks; int tileCap, ntx, nty, ntz, numBlocks;
     float tileScale;         // fixed-point scale of the LDS accumulation (a power of two)
     int xcdBlocks;           // interpolation: workgroups per XCD when the launch is placed XCD-aware (0: plain order)
+    // DD spreading over the ranges of slots with current positions only: range r = slots [activeBegin[r], activeEnd[r]), its workgroups are
+    // [activeGroup0[r], activeGroup0[r + 1]) of the launch (set by launch_spread for its group size); numActive = 0: every slot
+    int numActive, activeBegin[4], activeEnd[4], activeGroup0[5];
 };
 
 // one grid accumulation: float atomic, or -- for bit-reproducible sums -- an integer atomic on the same word
@@ -344,16 +347,24 @@ __global__ __launch_bounds__(THREADS) void pme_spread_group(PmeArgs a) {
     static_assert(ATOMS % WAVES == 0, "every wavefront takes the same number of atoms");
     __shared__ SpreadSharedG<G, B> sh;
     const int t = threadIdx.x;
-    const int slot0 = blockIdx.x * ATOMS;
+    int slot0 = blockIdx.x * ATOMS, slotEnd = a.paddedAtoms;
+    if (DD && a.numActive > 0) {
+        // the launch covers the ranges this rank has positions for: which range is this workgroup's, and where in it
+        int r = 0;
+        while (r + 1 < a.numActive && (int) blockIdx.x >= a.activeGroup0[r + 1]) r++;
+        slot0 = a.activeBegin[r] + ((int) blockIdx.x - a.activeGroup0[r]) * ATOMS;
+        slotEnd = a.activeEnd[r];
+    }
     if (t < 3) { sh.minRel[t] = 1 << 30; sh.ref[t] = -1; }
     if (t == 0) sh.touches = DD ? 0 : 1;
-    for (int i = t; i < WORDS; i += THREADS) sh.brick[i] = 0;
+    // (single GPU: the brick is zeroed here, beside the loads; decomposed: after the workgroups that touch none of this rank's planes have left)
+    if (!DD) for (int i = t; i < WORDS; i += THREADS) sh.brick[i] = 0;
     // splines: (atom, dimension) pairs; an atom of a block this rank holds no current positions for (halo mode) counts as uncharged
     for (int w = t; w < 4 * ATOMS; w += THREADS) {
         const int atom = w >> 2, d = w & 3;
         const int slot = slot0 + atom;
         float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (slot < a.paddedAtoms && !(DD && a.blockHalf[slot / SPREAD_ATOMS].x < 0.f)) p = a.posq[slot];
+        if (slot < slotEnd && !(DD && a.blockHalf[slot / SPREAD_ATOMS].x < 0.f)) p = a.posq[slot];
         if (d == 3) sh.charge[atom] = p.w;
         else if (p.w != 0.f) {
             const float frac = d == 0 ? p.x * a.recip.r00 + p.y * a.recip.r10 + p.z * a.recip.r20
@@ -396,6 +407,10 @@ __global__ __launch_bounds__(THREADS) void pme_spread_group(PmeArgs a) {
     }
     __syncthreads();
     if (DD && sh.touches == 0) return;
+    if (DD) {
+        for (int i = t; i < WORDS; i += THREADS) sh.brick[i] = 0;
+        __syncthreads();
+    }
     {
         const int lane = t & 63, wave = t >> 6;
         const int ptA = lane, ptB = lane + 64;
@@ -462,10 +477,20 @@ static int spread_group_blocks(int padded_atoms) {
     return padded_atoms >= 200000 ? 2 : 1;          // 92 k atoms: one and two blocks within 0.3 % (profiles/r11/r11s_ab_misc.txt), 985 k: -2.5 %
 }
 template <bool DD>
-static void launch_spread(const PmeArgs& pa, int padded_atoms, hipStream_t st) {
+static void launch_spread(const PmeArgs& pain, int padded_atoms, hipStream_t st) {
+    PmeArgs pa = pain;
     const int g = spread_group_blocks(padded_atoms);          // 1, 2, 3, 4, 6; 14 / 18: four / eight blocks with 512-thread workgroups (A/B)
-    const int blocks = (padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS;
+    int blocks = (padded_atoms + SPREAD_ATOMS - 1) / SPREAD_ATOMS;
     const bool bigEnough = pa.nx >= 24 && pa.ny >= 24 && pa.nz >= 24;
+    static const bool allSlots = getenv("OPENMM_HIP_DD_SPREAD_ALL_SLOTS") != nullptr;          // A/B knob: the launch over every slot of the box (rounds 2-5)
+    if (DD && pa.numActive > 0 && bigEnough && g == 2 && !allSlots) {
+        // decomposed, halo mode: workgroups for the slot ranges with current positions only (a third of the box at eight ranks)
+        pa.activeGroup0[0] = 0;
+        for (int r = 0; r < pa.numActive; r++) pa.activeGroup0[r + 1] = pa.activeGroup0[r] + ((pa.activeEnd[r] - pa.activeBegin[r]) / SPREAD_ATOMS + 1) / 2;
+        hipLaunchKernelGGL((pme_spread_group<DD, 2, 18, 256>), dim3(pa.activeGroup0[pa.numActive] > 0 ? pa.activeGroup0[pa.numActive] : 1), dim3(256), 0, st, pa);
+        return;
+    }
+    pa.numActive = 0;
     if (!bigEnough || g <= 1) hipLaunchKernelGGL(pme_spread_lds<DD>, dim3(blocks), dim3(256), 0, st, pa);
     else if (g == 2) hipLaunchKernelGGL((pme_spread_group<DD, 2, 18, 256>), dim3((blocks + 1) / 2), dim3(256), 0, st, pa);
     else if (g == 3) hipLaunchKernelGGL((pme_spread_group<DD, 3, 19, 192>), dim3((blocks + 2) / 3), dim3(192), 0, st, pa);
@@ -1761,6 +1786,9 @@ static PmeArgs make_pme_args(const ommhip_pme* pme, const void* posq_d, int padd
     pa.ddError = nullptr; pa.blockCenter = nullptr; pa.blockHalf = nullptr;
     pa.detScale = pme->deterministic && pme->max_charge > 0 ? (float) (2147483648.0 / (64.0 * pme->max_charge)) : 0.f;
     pa.xcdBlocks = 0;
+    pa.numActive = 0;
+    for (int r = 0; r < 4; r++) { pa.activeBegin[r] = pa.activeEnd[r] = 0; pa.activeGroup0[r] = 0; }
+    pa.activeGroup0[4] = 0;
     return pa;
 }
 
@@ -1935,6 +1963,10 @@ extern "C" int ommhip_pme_reciprocal_dd(const ommhip_pme* pme, const void* posq_
     PmeArgs pa = make_pme_args(pme, posq_d, padded_atoms, force_d, energy_buffer_d, energy_slots, include_energy);
     pa.planeLo = rank * nxl; pa.planeCount = nxl; pa.haloLo = D; pa.gridPlanes = nxl + 2 * D + 4;
     pa.ownSlot0 = own_slot0; pa.ownSlot1 = own_slot1; pa.ddError = pme->dd_error;
+    if (pme->dd_num_active_ranges > 0 && pme->dd_num_active_ranges <= 4) {
+        pa.numActive = pme->dd_num_active_ranges;
+        for (int r = 0; r < pa.numActive; r++) { pa.activeBegin[r] = pme->dd_active_range[2 * r]; pa.activeEnd[r] = pme->dd_active_range[2 * r + 1]; }
+    }
     pa.blockCenter = (const float4*) block_center_d; pa.blockHalf = (const float4*) block_half_d;
     float* real = (float*) pme->grid_real;
     float* realOwn = real + (size_t) D * ny * nz;

@@ -290,6 +290,7 @@ void HipContext::uploadPositions(const vector<Vec3>& positions) {
     sync();
     positionsValid = true;
     positionsVersion++;
+    noteStateMutation();
 }
 
 void HipContext::recoverIfFrozen() {
@@ -325,6 +326,7 @@ void HipContext::uploadVelocities(const vector<Vec3>& velocities) {
     if (numAtoms > 0) HIP_CHECK(ommhip_memcpy_h2d(vel.ptr, tmp.data(), sizeof(D4) * numAtoms, stream));
     momentumValid = false;
     velocitiesConstrained = false;
+    noteStateMutation();
     sync();
 }
 
@@ -539,8 +541,13 @@ void HipContext::restoreForces() {
 
 double HipContext::reduceEnergy() {
     HIP_CHECK(ommhip_reduce_energy(energyBuffer.as<double>(), EnergySlots, energyResult.as<double>(), stream));
-    HIP_CHECK(ommhip_memcpy_d2h(pinnedResult, energyResult.ptr, sizeof(double), stream));
+    // the kinetic energy the caller is about to ask for (Context::getState) rides on the same copy and the same wait
+    static const bool noPrefetch = getenv("OPENMM_HIP_NO_KE_PREFETCH") != NULL;          // A/B and test knob
+    const bool withKinetic = !decomposed() && !hostMode && !noPrefetch && prefetchKineticEnergy && prefetchKineticEnergy();
+    HIP_CHECK(ommhip_memcpy_d2h(pinnedResult, energyResult.ptr, sizeof(double) * (withKinetic ? 2 : 1), stream));
     sync();
+    kineticEnergyPrefetched = withKinetic;
+    if (withKinetic) { prefetchedKineticEnergy = pinnedResult[1]; kineticEnergyMutations = stateMutations; }
     return decomposed() ? sumOverRanks(pinnedResult[0]) : pinnedResult[0];
 }
 
@@ -644,6 +651,7 @@ void HipContext::findUnits(const System& system) {
 }
 
 void HipContext::stepTaken() {
+    noteStateMutation();
     velocitiesConstrained = true;
     stepsSinceReorder++;
     stepsSinceSnapshot++;

@@ -147,6 +147,20 @@ public:
     /** The same for the lists of kernels/valence.hip (the AMOEBA valence terms): queued by their Forces, one launch per evaluation. */
     void addValence(const ommhip_valence_list& list, bool includeEnergy);
     void flushValence();
+    /** Energy queries (Context::getState(Energy) = one evaluation with energies + the kinetic energy) with ONE host round trip: an integrator
+     *  whose kinetic energy is that of the velocities as they stand (LangevinMiddle) registers how to enqueue that sum; reduceEnergy() then
+     *  enqueues it behind the evaluation and reads both numbers with one copy, and the integrator's computeKineticEnergy() -- which
+     *  Context::getState calls next -- takes the number from here unless the state was touched in between (stateMutations).  Consumed once. */
+    std::function<bool()> prefetchKineticEnergy;              // enqueues the sum into energyResult[1]; false: not applicable right now
+    long long stateMutations = 0;                             // counts steps, uploads, constraint passes, CM removals: anything that changes velocities
+    void noteStateMutation() { stateMutations++; }
+    bool kineticEnergyPrefetched = false;
+    long long kineticEnergyMutations = 0;
+    double prefetchedKineticEnergy = 0.0;
+    /** The native Verlet / Langevin / LangevinMiddle integrators evaluate the forces anew at the start of every step, so an energy-only
+     *  evaluation need not put the previous forces back (two copies of the force buffer per energy query); false: save and restore
+     *  (ReferenceKernels.cpp:190-199), as a CustomIntegrator's force caches need it. */
+    bool forcesRecomputedEveryStep = false;
     void saveForces();                                         // device copy of the force buffer (energy-only evaluations)
     void restoreForces();
     double reduceEnergy();                                      // blocking; also zeroes the buffer

@@ -343,6 +343,7 @@ void HipConstraints::runCcma(void* target, bool velocities, double tol, void* re
 }
 
 void HipConstraints::apply(void* target, double tol, void* reference) {
+    hip.noteStateMutation();
     if (reference == NULL) reference = hip.pos.ptr;
     if (numCcma > 0) runCcma(target, false, tol, reference);
     HIP_CHECK(ommhip_constrain_clusters(numShake, shakeAtoms.as<int>(), shakeDist.as<double>(), numSettle, settleAtoms.as<int>(), settleDist.as<double>(),
@@ -350,6 +351,7 @@ void HipConstraints::apply(void* target, double tol, void* reference) {
 }
 
 void HipConstraints::applyToVelocities(void* target, double tol, void* reference) {
+    if (target == hip.vel.ptr) hip.noteStateMutation();          // (the kinetic-energy query constrains a COPY of the velocities: not a mutation)
     if (reference == NULL) reference = hip.pos.ptr;
     if (numCcma > 0) runCcma(target, true, tol, reference);
     HIP_CHECK(ommhip_constrain_clusters(numShake, shakeAtoms.as<int>(), shakeDist.as<double>(), numSettle, settleAtoms.as<int>(), settleDist.as<double>(),
@@ -385,7 +387,7 @@ void HipCalcForcesAndEnergyKernel::beginComputation(ContextImpl& context, bool i
         (*data.energyParameterDerivatives)[it->first] = 0;
     // An energy-only evaluation must leave the forces of the last full evaluation intact (ReferenceKernels.cpp:190-191,198-199):
     // the leapfrog kinetic energy reads them afterwards.
-    if (!includeForce && !hip.hostMode)
+    if (!includeForce && !hip.hostMode && !hip.forcesRecomputedEveryStep)
         hip.saveForces();
     hip.clearForces();
     hip.beginEvaluation(groups);
@@ -405,7 +407,7 @@ double HipCalcForcesAndEnergyKernel::finishComputation(ContextImpl& context, boo
         // summed over an incomplete list must not leave the platform.  Undo this evaluation, grow the list, redo the skipped steps, and
         // let ContextImpl::calcForcesAndEnergy (ContextImpl.cpp:298-307) evaluate again -- the reference's own remedy for an overflow.
         if (!includeForce) {
-            hip.restoreForces();
+            if (!hip.forcesRecomputedEveryStep) hip.restoreForces();
             // the fallback (Reference) kernels of this pass added to the host array: the retry must start from what was saved
             if (hip.hasFallbackForces) *data.forces = savedHostForces;
         }
@@ -428,7 +430,7 @@ double HipCalcForcesAndEnergyKernel::finishComputation(ContextImpl& context, boo
     }
     else {
         if (!includeForce) {
-            hip.restoreForces();
+            if (!hip.forcesRecomputedEveryStep) hip.restoreForces();
             if (hip.hasFallbackForces) *data.forces = savedHostForces;
         }
         else if (hip.hasFallbackForces)
@@ -850,6 +852,9 @@ double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool
         allocateNeighborList((int) (pinnedState[1] * 1.6) + 64);
     }
     fillPmeStruct();
+    // spreading looks at the slots this rank holds positions for (halo mode), not at every slot of the box
+    pme.dd_num_active_ranges = hip.haloMode ? hip.numActiveRanges : 0;
+    for (int i = 0; i < 8; i++) pme.dd_active_range[i] = hip.activeRange[i];
     const bool sideStream = hip.usePmeStream && hip.pmeComm != NULL;
     if (sideStream) {
         // Two streams: reciprocal space -- spreading, slab FFT with its two all-to-alls, halo planes, interpolation -- on the
@@ -2002,6 +2007,12 @@ double HipIntegratorBase::kineticEnergy(double timeShift) {
     // No time shift and velocities as a native step left them: they are what the Reference would get back from its constraint pass (it
     // leaves velocities inside its tolerance alone), so the sum runs over them directly -- two launches fewer in every energy query.
     const bool asTheyAre = timeShift == 0.0 && (!constraints.hasConstraints() || hip.velocitiesConstrained) && getenv("OPENMM_HIP_KE_ALWAYS_CONSTRAIN") == NULL;
+    if (asTheyAre && hip.kineticEnergyPrefetched && hip.kineticEnergyMutations == hip.stateMutations) {
+        // summed behind the energy evaluation this query began with and read with its energy (HipContext::reduceEnergy): no second round trip
+        hip.kineticEnergyPrefetched = false;
+        return hip.prefetchedKineticEnergy;
+    }
+    hip.kineticEnergyPrefetched = false;
     void* const velocities = asTheyAre ? hip.vel.ptr : hip.tempVel.ptr;
     if (!asTheyAre) {
         ommhip_integrator_state s;
@@ -2067,6 +2078,7 @@ static unsigned long long resolveSeed(int seed) {
 
 void HipIntegrateLangevinStepKernel::initialize(const System& system, const LangevinIntegrator& integrator) {
     data.integratorSeed = resolveSeed(integrator.getRandomNumberSeed());
+    data.hip->forcesRecomputedEveryStep = true;
 }
 void HipIntegrateLangevinStepKernel::launchStep(ContextImpl& context, const LangevinIntegrator& integrator, long long stepIndex) {
     // ReferenceStochasticDynamics.cpp:89-194
@@ -2106,6 +2118,17 @@ double HipIntegrateLangevinStepKernel::computeKineticEnergy(ContextImpl& context
 
 void HipIntegrateLangevinMiddleStepKernel::initialize(const System& system, const LangevinMiddleIntegrator& integrator) {
     data.integratorSeed = resolveSeed(integrator.getRandomNumberSeed());
+    data.hip->forcesRecomputedEveryStep = true;
+    // the kinetic energy of this integrator is that of the velocities as they stand (ReferenceKernels.cpp:2450-2453, time shift 0): an
+    // energy evaluation can sum it behind its own kernels (HipContext::reduceEnergy), one host round trip per Context::getState(Energy)
+    HipPlatform::PlatformData* const d = &data;
+    data.hip->prefetchKineticEnergy = [d]() -> bool {
+        HipContext& hip = *d->hip;
+        HipConstraints& constraints = d->getDeviceConstraints(*d->system);
+        if (constraints.hasConstraints() && !hip.velocitiesConstrained) return false;
+        if (getenv("OPENMM_HIP_KE_ALWAYS_CONSTRAIN") != NULL) return false;
+        return ommhip_kinetic_energy(hip.vel.ptr, NULL, 0, hip.numAtoms, hip.energyResult.as<double>() + 8, hip.energyResult.as<double>() + 1, hip.stream) == 0;
+    };
 }
 void HipIntegrateLangevinMiddleStepKernel::launchStep(ContextImpl& context, const LangevinMiddleIntegrator& integrator, long long stepIndex) {
     // ReferenceLangevinMiddleDynamics.cpp:92-127
@@ -2167,6 +2190,7 @@ void HipRemoveCMMotionKernel::execute(ContextImpl& context) {
     }
     if (hip.decomposed()) hip.gatherState();     // all velocities on every rank; each removes the same centre-of-mass motion
     HIP_CHECK(ommhip_remove_cm_motion(hip.vel.ptr, hip.numAtoms, scratch.as<double>(), hip.stream));
+    hip.noteStateMutation();
     hip.momentumValid = false;
 }
 

@@ -286,7 +286,7 @@ protected:
 class HipIntegrateVerletStepKernel : public IntegrateVerletStepKernel, public HipIntegratorBase {
 public:
     HipIntegrateVerletStepKernel(std::string name, const Platform& platform, HipPlatform::PlatformData& data) : IntegrateVerletStepKernel(name, platform), HipIntegratorBase(data) {}
-    void initialize(const System& system, const VerletIntegrator& integrator) {}
+    void initialize(const System& system, const VerletIntegrator& integrator) { data.hip->forcesRecomputedEveryStep = true; }
     void execute(ContextImpl& context, const VerletIntegrator& integrator);
     double computeKineticEnergy(ContextImpl& context, const VerletIntegrator& integrator);
 private:

@@ -350,15 +350,18 @@ __global__ __launch_bounds__(THREADS) void pme_spread_group(PmeArgs a) {
     int slot0 = blockIdx.x * ATOMS, slotEnd = a.paddedAtoms;
     if (DD && a.numActive > 0) {
         // the launch covers the ranges this rank has positions for: which range is this workgroup's, and where in it
-        int r = 0;
-        while (r + 1 < a.numActive && (int) blockIdx.x >= a.activeGroup0[r + 1]) r++;
-        slot0 = a.activeBegin[r] + ((int) blockIdx.x - a.activeGroup0[r]) * ATOMS;
-        slotEnd = a.activeEnd[r];
+        // (compile-time indices only: a run-time index into an array of the by-value argument struct moves the whole struct to private memory)
+        const int g = (int) blockIdx.x;
+        int begin = a.activeBegin[0], first = 0, end = a.activeEnd[0];
+#pragma unroll
+        for (int r = 1; r < 4; r++)
+            if (r < a.numActive && g >= a.activeGroup0[r]) { begin = a.activeBegin[r]; first = a.activeGroup0[r]; end = a.activeEnd[r]; }
+        slot0 = begin + (g - first) * ATOMS;
+        slotEnd = end;
     }
     if (t < 3) { sh.minRel[t] = 1 << 30; sh.ref[t] = -1; }
     if (t == 0) sh.touches = DD ? 0 : 1;
-    // (single GPU: the brick is zeroed here, beside the loads; decomposed: after the workgroups that touch none of this rank's planes have left)
-    if (!DD) for (int i = t; i < WORDS; i += THREADS) sh.brick[i] = 0;
+    for (int i = t; i < WORDS; i += THREADS) sh.brick[i] = 0;
     // splines: (atom, dimension) pairs; an atom of a block this rank holds no current positions for (halo mode) counts as uncharged
     for (int w = t; w < 4 * ATOMS; w += THREADS) {
         const int atom = w >> 2, d = w & 3;
@@ -407,10 +410,6 @@ __global__ __launch_bounds__(THREADS) void pme_spread_group(PmeArgs a) {
     }
     __syncthreads();
     if (DD && sh.touches == 0) return;
-    if (DD) {
-        for (int i = t; i < WORDS; i += THREADS) sh.brick[i] = 0;
-        __syncthreads();
-    }
     {
         const int lane = t & 63, wave = t >> 6;
         const int ptA = lane, ptB = lane + 64;

@@ -2077,7 +2077,7 @@ static unsigned long long resolveSeed(int seed) {
 }
 
 void HipIntegrateLangevinStepKernel::initialize(const System& system, const LangevinIntegrator& integrator) {
-    data.integratorSeed = resolveSeed(integrator.getRandomNumberSeed());
+    data.integratorSeed = data.forcedSeed != 0 ? data.forcedSeed : resolveSeed(integrator.getRandomNumberSeed());          // (forcedSeed: the ranks of a device list share one)
     data.hip->forcesRecomputedEveryStep = true;
 }
 void HipIntegrateLangevinStepKernel::launchStep(ContextImpl& context, const LangevinIntegrator& integrator, long long stepIndex) {
@@ -2117,7 +2117,7 @@ double HipIntegrateLangevinStepKernel::computeKineticEnergy(ContextImpl& context
 }
 
 void HipIntegrateLangevinMiddleStepKernel::initialize(const System& system, const LangevinMiddleIntegrator& integrator) {
-    data.integratorSeed = resolveSeed(integrator.getRandomNumberSeed());
+    data.integratorSeed = data.forcedSeed != 0 ? data.forcedSeed : resolveSeed(integrator.getRandomNumberSeed());
     data.hip->forcesRecomputedEveryStep = true;
     // the kinetic energy of this integrator is that of the velocities as they stand (ReferenceKernels.cpp:2450-2453, time shift 0): an
     // energy evaluation can sum it behind its own kernels (HipContext::reduceEnergy), one host round trip per Context::getState(Energy)

@@ -12,6 +12,7 @@
 #include "HipKernels.h"
 #include "HipValenceKernels.h"
 #include "HipCustomIntegrator.h"
+#include "HipParallel.h"
 #include "ReferenceKernelFactory.h"
 #include "openmm/Context.h"
 #include "openmm/KernelFactory.h"
@@ -145,6 +146,17 @@ class HipKernelFactory : public KernelFactory {
 public:
     KernelImpl* createKernelImpl(std::string name, const Platform& platform, ContextImpl& context) const {
         HipPlatform::PlatformData& data = HipPlatform::getData(context);
+        KernelImpl* kernel = createOwnKernel(name, platform, context, data);
+        data.kernelsByName[name].push_back(kernel);
+        if (data.group != NULL) {
+            // the user's Context of a device list: its kernels also drive the peer kernels of the inner ranks (HipParallel.h)
+            KernelImpl* wrapped = hipMakeParallelKernel(name, platform, data, kernel);
+            if (wrapped != NULL) return wrapped;
+        }
+        return kernel;
+    }
+private:
+    KernelImpl* createOwnKernel(const std::string& name, const Platform& platform, ContextImpl& context, HipPlatform::PlatformData& data) const {
         const bool hostMode = data.hip->hostMode;
         if (name == CalcForcesAndEnergyKernel::Name())
             return new HipCalcForcesAndEnergyKernel(name, platform, data);
@@ -187,7 +199,6 @@ public:
         }
         return reference.createKernelImpl(name, platform, context);
     }
-private:
     ReferenceKernelFactory reference;
 };
 
@@ -280,9 +291,22 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
         throw OpenMMException("HIP platform: Precision must be 'mixed' (single-precision pair and PME arithmetic, 64-bit fixed-point force accumulation, "
                               "double-precision integration and constraints); 'single' and 'double' modes do not exist on this platform");
     int deviceIndex = 0;
-    if (devicePropValue.find(',') != string::npos)
-        throw OpenMMException("HIP platform: one Context drives one device; multi-GPU runs use one process per GPU (see bench.py)");
-    if (!devicePropValue.empty())
+    vector<int> deviceList;
+    if (devicePropValue.find(',') != string::npos) {
+        // a list of devices: ONE box over all of them, each device a rank of the decomposition (HipParallel.h)
+        stringstream list(devicePropValue);
+        string item;
+        while (getline(list, item, ',')) {
+            int d = -1;
+            if (!(stringstream(item) >> d) || d < 0) throw OpenMMException("HIP platform: illegal DeviceIndex list '" + devicePropValue + "'");
+            deviceList.push_back(d);
+        }
+        if (deviceList.size() < 2) throw OpenMMException("HIP platform: illegal DeviceIndex list '" + devicePropValue + "'");
+        if (properties.find(HipRanks()) != properties.end() || properties.find(HipCommId()) != properties.end())
+            throw OpenMMException("HIP platform: give either a list of devices (one process) or Ranks / Rank / CommId (one process per device), not both");
+        deviceIndex = deviceList[0];
+    }
+    else if (!devicePropValue.empty())
         stringstream(devicePropValue) >> deviceIndex;
     else if (getenv("LOCAL_RANK") != NULL) {
         // one process per GPU under torch.distributed.run: default to this rank's device
@@ -302,6 +326,15 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
     if (properties.find(HipCommId()) != properties.end()) commId = properties.find(HipCommId())->second;
     if (domain.ranks < 1 || domain.rank < 0 || domain.rank >= domain.ranks)
         throw OpenMMException("HIP platform: illegal Ranks/Rank properties");
+    HipRankGroup* group = NULL;
+    if (!deviceList.empty()) {
+        if (mode.customIntegrator || mode.hostMode)
+            throw OpenMMException("HIP platform: a Context over a list of devices supports the Verlet, Langevin and LangevinMiddle integrators");
+        // the threads of the other devices start creating their Contexts now; this thread goes on as rank 0 and meets them in the communicator
+        group = new HipRankGroup(*this, context, deviceList, properties);
+        domain.ranks = (int) deviceList.size(); domain.rank = 0; commId = group->commId();
+    }
+    unsigned long long forcedSeed = group != NULL ? group->seed() : 0;
     if (domain.ranks > 1 || !commId.empty()) {
         // Kernels of other plugins (the AMOEBA forces) know nothing of the decomposition: each rank would evaluate the whole system
         // from positions that are current only for its own atoms and its halo, and add the full energy on every rank.
@@ -317,7 +350,14 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
         HIP_CHECK(ommhip_device_count(&count));
         if (deviceIndex < 0 || deviceIndex >= count) throw OpenMMException("HIP platform: illegal DeviceIndex");
         HIP_CHECK(ommhip_set_device(deviceIndex));       // the communicator binds to the current device
-        if (commId.compare(0, 9, "callback:") == 0) {
+        if (commId.compare(0, 10, "inprocess:") == 0) {
+            // the ranks of a device list that share a device (or have no RCCL): host-staged all-gather between the threads of this process
+            const int token = atoi(commId.c_str() + 10);
+            void* user = hipInProcessUser(token, domain.rank);
+            if (user == NULL) throw OpenMMException("HIP platform: unknown in-process communicator");
+            HIP_CHECK(ommhip_comm_create_callback(hipInProcessAllGather, user, domain.rank, domain.ranks, &domain.comm));
+        }
+        else if (commId.compare(0, 9, "callback:") == 0) {
             // the host-staged transport of the tests and of bench.py's rehearsals: the property carries the address of a function this
             // library will call -- accepted only from a process that says so itself, never from a property string alone
             const char* allow = getenv("OPENMM_HIP_ALLOW_CALLBACK_COMM");
@@ -340,7 +380,10 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
     PlatformData* data = NULL;
     try {
         data = new PlatformData(context.getSystem(), deviceIndex, mode.hostMode, domain);
+        data->group = group;
+        data->forcedSeed = forcedSeed;
     } catch (...) {
+        delete group;
         // the HipContext did not come to own the communicator (it destroys it otherwise): the peers must not be left waiting in it
         if (domain.comm != NULL) ommhip_comm_destroy(domain.comm);
         throw;
@@ -352,7 +395,7 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
     data->hip->hasFallbackForces = mode.hasFallbackForces;
     stringstream dev;
     dev << deviceIndex;
-    data->propertyValues[HipDeviceIndex()] = dev.str();
+    data->propertyValues[HipDeviceIndex()] = deviceList.empty() ? dev.str() : devicePropValue;
     char name[256];
     name[0] = 0;
     ommhip_device_info(deviceIndex, name, 256, NULL, NULL);
@@ -391,6 +434,7 @@ HipPlatform::PlatformData::PlatformData(const System& system, int deviceIndex, b
 }
 
 HipPlatform::PlatformData::~PlatformData() {
+    delete group;          // the inner ranks of a device list end with the user's Context
     delete deviceConstraints;
     delete hip;
 }

@@ -14,11 +14,13 @@
 #include "openmm/internal/ContextImpl.h"
 #include <map>
 #include <string>
+#include <vector>
 
 namespace OpenMM {
 
 class HipContext;
 class HipConstraints;
+class HipRankGroup;
 struct HipDomain;
 
 class HipPlatform : public ReferencePlatform {
@@ -55,6 +57,8 @@ public:
     static PlatformData& getData(ContextImpl& context) {
         return *reinterpret_cast<PlatformData*>(context.getPlatformData());
     }
+    /** The ContextImpl behind a Context (Platform::getContextImpl is protected): the inner Contexts of a device list (HipParallel.h). */
+    ContextImpl& implOf(Context& context) const { return getContextImpl(context); }
     /** Native kernels that live in a plugin of their own (libOpenMMAmoebaHIP.so, the counterpart of the reference's
      *  libOpenMMAmoebaCUDA): the plugin's registerKernelFactories() announces them here.  `forceType` is a fragment of the C++
      *  type name of the Force the kernel serves ("AmoebaVdwForce"): a System holding such a Force then needs no fallback for it
@@ -80,6 +84,11 @@ public:
     unsigned long long integratorSeed;      // resolved seed of the Langevin thermostat noise (part of a checkpoint)
     unsigned long long customDraws = 0;     // random per-DOF computations a device CustomIntegrator has issued so far: the counter its noise is keyed by (part of a checkpoint)
     std::map<std::string, std::string> propertyValues;
+    /** Every native kernel of this Context by name, in creation order: how the wrapper kernels of a Context over a device list find
+     *  their peers in the inner Contexts (HipParallel.h). */
+    std::map<std::string, std::vector<KernelImpl*> > kernelsByName;
+    HipRankGroup* group = NULL;             // the user's Context of a device list only: the inner ranks (owned)
+    unsigned long long forcedSeed = 0;      // != 0: the thermostat seed every rank of a device list uses (a seed of 0 would be drawn per rank)
 private:
     HipConstraints* deviceConstraints;
 };

@@ -24,7 +24,8 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
-#define __shared__ static
+// (thread_local: one copy per HOST thread -- the ranks of a device-list Context run their kernels on threads of one process, tests/hip/TestHipParallel.cpp)
+#define __shared__ static thread_local
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
 

@@ -253,7 +253,11 @@ FAST_REFERENCE_TESTS = ["HarmonicBondForce", "HarmonicAngleForce", "PeriodicTors
                         "AmoebaVdwForce", "AmoebaMultipoleForce", "AmoebaTorsionTorsionForce", "AmoebaExtrapolatedPolarization",
                         "CustomAngleForce", "CustomCompoundBondForce",
                         # tests/hip/TestHipPmeKernel.cpp: CalcPmeReciprocalForceKernel + ::IO, the HIP twin of plugins/cpupme/tests/TestCpuPme.cpp's testPME
-                        "PmeKernel"]
+                        "PmeKernel",
+                        # tests/hip/TestHipParallel.cpp: ONE Context over a device list ("d,d") -- the HIP twin of testParallelComputation
+                        # (platforms/cuda/tests/TestCudaNonbondedForce.cpp:37-96); the dynamics part of it runs on the GPU only
+                        "Parallel"]
+EMU_TEST_ARGS = {"Parallel": ["quick"]}
 
 
 @needs_emu
@@ -262,7 +266,7 @@ def test_reference_test_bodies_on_emulated_platform(name):
     exe = os.path.join(EMU_BUILD, "tests", "TestHip" + name)
     if not os.path.exists(exe):
         pytest.skip("not built")
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([exe] + EMU_TEST_ARGS.get(name, []), capture_output=True, text=True, timeout=900)
     # Bodies that draw their seed from the clock check statistics with ASSERT_USUALLY_*: the reference's own message says such a
     # failure "may occasionally" happen (openmmapi/include/openmm/internal/AssertionUtilities.h:59-61), so those -- and only those -- get two more draws.
     for attempt in range(2):

@@ -29,7 +29,10 @@ REFERENCE_TEST_BODIES = ["NonbondedForce", "Ewald", "VerletIntegrator", "Settle"
                          # move; AmoebaTorsionTorsionForce runs on kernels/valence.hip
                          "AmoebaVdwForce", "AmoebaMultipoleForce", "AmoebaTorsionTorsionForce", "AmoebaExtrapolatedPolarization",
                          # tests/hip/TestHipPmeKernel.cpp: CalcPmeReciprocalForceKernel + ::IO (kernels.h:1493-1560), the HIP twin of plugins/cpupme/tests/TestCpuPme.cpp's testPME
-                         "PmeKernel"]
+                         "PmeKernel",
+                         # tests/hip/TestHipParallel.cpp: ONE Context over a device list ("d,d": two and three ranks on threads of this process) against a
+                         # single-device Context -- the HIP twin of testParallelComputation (platforms/cuda/tests/TestCudaNonbondedForce.cpp:37-96) + dynamics
+                         "Parallel"]
 NATIVE_AMOEBA = {"AmoebaVdwForce": "vdw", "AmoebaMultipoleForce": "multipole", "AmoebaExtrapolatedPolarization": "multipole"}         # test body -> counter printed by tests/hip/HipAmoebaTests.h at exit
 
 

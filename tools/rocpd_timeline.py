@@ -8,7 +8,13 @@ if sys.argv[1].endswith(".csv"):
     # a *_kernel_trace.csv of rocprofv3 --output-format csv
     import csv
     with open(sys.argv[1]) as f:
-        rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Queue_Id", 0) or 0), r["Kernel_Name"]) for r in csv.DictReader(f))
+        rows = []
+        for r in csv.DictReader(f):
+            try:
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Queue_Id", 0) or 0), r["Kernel_Name"]))
+            except (ValueError, TypeError, KeyError):          # a line another process of the run was still writing
+                continue
+        rows.sort()
 else:
     db = sqlite3.connect(sys.argv[1])
     cur = db.cursor()

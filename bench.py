@@ -173,6 +173,54 @@ def collect_timers(kernels):
     return timers
 
 
+def kernel_rooflines(kernels, plugin, integ, ctx, num_atoms, grid, cutoff_pairs=None, steps=40):
+    """Rooflines of the step's kernels other than the 3-D FFT on a Context whose reciprocal space runs on the MAIN stream (every kernel on its
+    own, HIP events around each launch): SURVEY.md 8(d)'s algorithmic bytes (B_dir, B_spr, B_int, B_nl -- the list rebuild per REBUILD, its
+    launches that found nothing to do left out) over the measured durations, and the pair kernel's FP32 issue fraction.  -> dict"""
+    before = (C.c_longlong * 8)()
+    plugin.ommhip_plugin_nl_stats(before)
+    kernels.lib.ommhip_profile_reset()
+    kernels.lib.ommhip_profile_enable_timers(1, 0x1f, 4 * steps)
+    integ.step(steps)
+    ctx.getState(getEnergy=True)
+    kernels.lib.ommhip_profile_enable(0)
+    t = collect_timers(kernels)
+    after = (C.c_longlong * 8)()
+    plugin.ommhip_plugin_nl_stats(after)
+    rows, rebuilds = int(after[3]), int(after[5] - before[5])
+    n, g, p = num_atoms, grid[0] * grid[1] * grid[2], 125
+
+    def obj(kernel, bytes_, us, extra=None):
+        if not us:
+            return {"kernel": kernel, "avg_us": None}
+        a = bytes_ / (us * 1e-6) / 1e9
+        o = {"bound": "hbm", "kernel": kernel, "algorithmic_bytes": int(bytes_), "avg_us": round(us, 2), "achieved": round(a, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBPS, 5)}
+        o.update(extra or {})
+        return o
+    out = {"source": "%d steps after the timed region on a Context with reciprocal space on the main stream (DisablePmeStream=true), HIP events around every launch; bytes: SURVEY.md 8(d)" % steps}
+    pair_us = t["nb_direct"]["avg_us"]
+    out["direct"] = obj("nb_direct", 48 * n + 52 * 32 * (2 * rows), pair_us, {"rows": rows, "formula": "B_dir = 48 N + 52*32*T, T = 2 tiles per 64-slot row"})
+    if pair_us:
+        evals = rows * 64 * 32
+        fi = {"bound": "fp32 vector issue", "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "flop_per_pair": PAIR_FLOP, "pair_evals_per_launch": evals,
+              "achieved": round(evals * PAIR_FLOP / (pair_us * 1e-6) / 1e12, 3)}
+        fi["frac"] = round(fi["achieved"] / FP32_VECTOR_PEAK_TFLOPS, 5)
+        if cutoff_pairs:
+            fi["pairs_inside_cutoff"] = int(cutoff_pairs)
+            fi["evals_per_useful_pair"] = round(evals / max(cutoff_pairs, 1), 3)
+            fi["useful_frac"] = round(cutoff_pairs * PAIR_FLOP / (pair_us * 1e-6) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5)
+        out["direct"]["fp32_issue"] = fi
+    out["spread"] = obj("pme_spread (LDS bricks, coalesced atomics)", 16 * n + 4 * p * n * 2 + 4 * g, t["pme_spread"]["avg_us"], {"formula": "B_spr = 16 N + 4 P N 2 (RMW) + 4 G (clear)"})
+    out["interpolate"] = obj("pme_interpolate", 16 * n + 4 * p * n + 24 * n, t["pme_interpolate"]["avg_us"], {"formula": "B_int = 16 N + 4 P N + 24 N"})
+    nl_us = t["nl_update"]["avg_us"]
+    if nl_us and rebuilds > 0 and t["nl_update"]["calls"] > 0:
+        # the timer brackets the rebuild launches of EVERY step (they leave at once when no rebuild is due): time per rebuild = the sum over the calls
+        per_rebuild = nl_us * t["nl_update"]["calls"] / rebuilds
+        out["list_rebuild"] = obj("nl_bin_blocks + nl_find_interactions (per rebuild)", 16 * n + 32 * (n // 32) + 4 * 32 * (2 * rows), per_rebuild,
+                                  {"rebuilds": rebuilds, "steps": steps, "formula": "B_nl = 16 N + 32 Nblk + 4*32*T_list per rebuild"})
+    return out
+
+
 def timed_run(integ, ctx, steps, barrier):
     barrier()
     t0 = time.perf_counter()
@@ -576,11 +624,14 @@ def main():
                 # the 3-D FFT chain of this grid on its own: the same box with reciprocal space on the main stream (in the timed run above the
                 # chain shares the chip with the pair kernel on a side stream, and its timer measures that overlap), HIP events around the chain
                 fsys, fnb, finteg, fctx = start_platform(sw, "HIP", dt_ps, 5, {"DeviceIndex": str(local_rank), "DisablePmeStream": "true"}, seed=1, prepare=0)
-                kernels.lib.ommhip_profile_reset()
-                kernels.lib.ommhip_profile_enable_timers(1, 0x1f, 64)
-                finteg.step(40)
-                fctx.getState(getEnergy=True)
-                kernels.lib.ommhip_profile_enable(0)
+                try:
+                    # pairs inside the cutoff of this box: the water tile's number density x the cutoff sphere (a homogeneous liquid; counted exactly for DHFR)
+                    vol = float(np.prod(np.diag(np.asarray(sw.box, float))))
+                    pairs_in = 0.5 * sw.num_atoms * (sw.num_atoms / vol) * 4.0 / 3.0 * np.pi * sw.cutoff ** 3
+                    out["scale_workload"]["roofline_kernels"] = kernel_rooflines(kernels, plugin, finteg, fctx, sw.num_atoms, sgrid, cutoff_pairs=pairs_in)
+                    out["scale_workload"]["roofline_kernels"]["direct"]["fp32_issue"]["pairs_inside_cutoff_source"] = "number density x cutoff sphere (homogeneous liquid)"
+                except Exception as e:
+                    out["scale_workload"]["roofline_kernels"] = {"error": str(e)[:200]}
                 ft = collect_timers(kernels)["pme_fft"]
                 fctx.close()
                 if ft["avg_us"]:
@@ -606,7 +657,18 @@ def main():
                                                    xw.name, xw.num_atoms, "x".join(str(g) for g in xnb.getPMEParametersInContext(xctx)[1:]), dt_fs),
                                                "value": round(MR.ns_per_day(x_elapsed, args.steps, dt_fs), 3), "unit": "ns/day",
                                                "ms_per_step": round(1e3 * x_elapsed / args.steps, 5), "steps": args.steps, "warmup": args.warmup, "prepare_steps": xprep}
+                xgrid = xnb.getPMEParametersInContext(xctx)[1:]
                 xctx.close()
+                if key == "apoa1" and not args.no_roofline:
+                    # BASELINE.json configs[2]: rooflines of its kernels, each on its own (a second Context with reciprocal space on the main stream)
+                    try:
+                        rsys, rnb, rinteg, rctx = start_platform(xw, "HIP", dt_fs * 1e-3, 5, {"DeviceIndex": str(local_rank), "DisablePmeStream": "true"}, seed=1, prepare=0)
+                        vol = float(np.prod(np.diag(np.asarray(xw.box, float))))
+                        pairs_in = 0.5 * xw.num_atoms * (xw.num_atoms / vol) * 4.0 / 3.0 * np.pi * xw.cutoff ** 3
+                        out["extra_workloads"][key]["roofline_kernels"] = kernel_rooflines(kernels, plugin, rinteg, rctx, xw.num_atoms, xgrid, cutoff_pairs=pairs_in)
+                        rctx.close()
+                    except Exception as e:
+                        out["extra_workloads"][key]["roofline_kernels"] = {"error": str(e)[:200]}
             except Exception as e:
                 out["extra_workloads"][key] = {"value": None, "error": str(e)}
         # BASELINE.json configs[4] (amoeba-pme, amoeba2009 DHFR) and the larger AMOEBA water tile: ONE child process with ONE overall timeout

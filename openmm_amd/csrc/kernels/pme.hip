@@ -495,6 +495,9 @@ static void launch_spread(const PmeArgs& pain, int padded_atoms, hipStream_t st)
     else if (g == 3) hipLaunchKernelGGL((pme_spread_group<DD, 3, 19, 192>), dim3((blocks + 2) / 3), dim3(192), 0, st, pa);
     else if (g == 4) hipLaunchKernelGGL((pme_spread_group<DD, 4, 20, 256>), dim3((blocks + 3) / 4), dim3(256), 0, st, pa);
     else if (g == 6) hipLaunchKernelGGL((pme_spread_group<DD, 6, 22, 256>), dim3((blocks + 5) / 6), dim3(256), 0, st, pa);
+    else if (g == 8) hipLaunchKernelGGL((pme_spread_group<DD, 8, 22, 1024>), dim3((blocks + 7) / 8), dim3(1024), 0, st, pa);
+    else if (g == 16) hipLaunchKernelGGL((pme_spread_group<DD, 16, 26, 1024>), dim3((blocks + 15) / 16), dim3(1024), 0, st, pa);
+    else if (g == 88) hipLaunchKernelGGL((pme_spread_group<DD, 8, 22, 512>), dim3((blocks + 7) / 8), dim3(512), 0, st, pa);
     else if (g == 12) hipLaunchKernelGGL((pme_spread_group<DD, 2, 18, 512>), dim3((blocks + 1) / 2), dim3(512), 0, st, pa);
     else if (g == 14) hipLaunchKernelGGL((pme_spread_group<DD, 4, 20, 512>), dim3((blocks + 3) / 4), dim3(512), 0, st, pa);
     else hipLaunchKernelGGL((pme_spread_group<DD, 2, 18, 256>), dim3((blocks + 1) / 2), dim3(256), 0, st, pa);

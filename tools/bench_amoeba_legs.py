@@ -173,6 +173,34 @@ def run(steps, device, no_pmc):
                     "flops_per_launch": int(entries * 2 * 30), "flops_note": "two dipole sets x ~30 double-precision flop per entry: 0.03 of the fp64 vector peak -- the kernel streams its cache",
                     "source": "rocprofv3 --kernel-trace child run of tools/bench_amoeba.py --dhfr --steps 10 on this box (16 steps with the warm-up), after the timed region",
                     "top_kernels_us": {str(k)[:60]: {"total": round(float(v["sum"]), 1), "calls": int(v["count"]), "avg": round(float(v["mean"]), 2)} for k, v in top.iterrows()}}
+                # HBM-side traffic of the three long kernels of this workload from the PMC counters: two more child runs (FETCH_SIZE and
+                # WRITE_SIZE cannot share a pass; --kernel-trace only beside --pmc), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+                try:
+                    child = [sys.executable, os.path.join(ROOT, "tools", "bench_amoeba.py"), "--dhfr", "--steps", "6"]
+                    kb = {}
+                    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                        cper, _ = rocprof_child(child, pmc=counter, timeout=300)
+                        for key, pattern, exclude in (("k_mp_dipole_field", "k_mp_dipole_field", "gradient"), ("k_mp_forces<true>", "k_mp_forces<true>", None), ("k_mp_field<true>", "k_mp_field<true>", None)):
+                            csub = cper[cper["Kernel_Name"].str.contains(pattern, regex=False)]
+                            if exclude is not None:
+                                csub = csub[~csub["Kernel_Name"].str.contains(exclude)]
+                            if len(csub) > 0:
+                                kb[(counter, key)] = (float(csub["value"].mean()), float(csub["dur_us"].mean()), int(len(csub)))
+                    traffic = {}
+                    for key in ("k_mp_dipole_field", "k_mp_forces<true>", "k_mp_field<true>"):
+                        if ("FETCH_SIZE", key) in kb and ("WRITE_SIZE", key) in kb:
+                            bytes_ = 1024.0 * (2.0 * kb[("FETCH_SIZE", key)][0] + kb[("WRITE_SIZE", key)][0])
+                            us = kb[("FETCH_SIZE", key)][1]
+                            traffic[key] = {"traffic_bytes_per_launch": int(bytes_), "fetch_kb_as_reported": round(kb[("FETCH_SIZE", key)][0], 1), "write_kb_as_reported": round(kb[("WRITE_SIZE", key)][0], 1),
+                                            "kernel_us_under_the_profiler": round(us, 2), "hbm_side_gb_per_s": round(bytes_ / (us * 1e-6) / 1e9, 1),
+                                            "frac_of_hbm_peak": round(bytes_ / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4), "dispatches_averaged": kb[("FETCH_SIZE", key)][2]}
+                    if "k_mp_dipole_field" in traffic:
+                        legs["amoeba_dhfr"]["roofline"]["traffic"] = traffic["k_mp_dipole_field"]["traffic_bytes_per_launch"]
+                    legs["amoeba_dhfr"]["roofline"]["traffic_by_kernel"] = traffic
+                    legs["amoeba_dhfr"]["roofline"]["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs (separate passes, --kernel-trace only) of tools/bench_amoeba.py "
+                                                                         "--dhfr --steps 6 on this box; FETCH_SIZE x 2 (gfx950), KB -> bytes x 1024")
+                except Exception as e:
+                    legs["amoeba_dhfr"]["roofline"]["traffic_source"] = "PMC passes failed: %s" % str(e)[:200]
             except Exception as e:
                 legs["amoeba_dhfr"]["roofline"] = {"error": str(e)[:300]}
         dctx.close()

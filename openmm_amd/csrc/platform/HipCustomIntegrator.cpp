@@ -44,7 +44,9 @@ int treeStackDepth(const ExpressionTreeNode& node) {
 
 bool expressionIsTranslatable(const string& expression) {
     try {
-        const ParsedExpression parsed = Parser::parse(expression);
+        // the tree compile() will translate: CustomIntegratorUtilities::analyzeComputations hands out the OPTIMIZED expression
+        // (CustomIntegratorUtilities.cpp:108-114), whose depth may differ from the parsed one's
+        const ParsedExpression parsed = Parser::parse(expression).optimize();
         // deeper than the interpreter's stack: host mode (the Reference kernel), not an exception at the first step.  An unknown variable
         // is not looked for here: the Reference kernel rejects it as well.
         return treeIsTranslatable(parsed.getRootNode()) && treeStackDepth(parsed.getRootNode()) <= OMMHIP_VM_STACK;

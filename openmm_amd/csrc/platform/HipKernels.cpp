@@ -517,7 +517,15 @@ void HipUpdateStateDataKernel::loadCheckpoint(ContextImpl& context, istream& str
     Vec3 box[3];
     stream.read((char*) box, 3 * sizeof(Vec3));
     if (!stream.good()) throw OpenMMException("HIP platform: the checkpoint is truncated");
+    // Version 3 carries the state of the host generator (SimTKOpenMMUtilities: ONE generator per process, as on the Reference platform --
+    // loading a checkpoint in one Context therefore also sets the host draws of every other Context of the process).  A version-2 blob has
+    // neither that nor the draw counter of a device CustomIntegrator: both restart from the checkpoint's own seed, so that a restart from
+    // such a blob is at least reproducible instead of continuing from whatever the live Context had drawn.
     if (version >= 3) SimTKOpenMMUtilities::loadCheckpoint(stream);
+    else {
+        data.customDraws = 0;
+        SimTKOpenMMUtilities::setRandomNumberSeed((uint32_t) data.integratorSeed);
+    }
     setPeriodicBoxVectors(context, box[0], box[1], box[2]);
     setPositions(context, pos);
     setVelocities(context, vel);

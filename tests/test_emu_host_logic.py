@@ -782,7 +782,7 @@ for depth in (8, 24):
     integ = H.CustomIntegrator(0.001, seed=1, constraintTolerance=1e-7)
     expr = "v"
     for k in range(depth):
-        expr = "0+(1*(%%s))" %% expr if k %% 2 else "v*0+(%%s)" %% expr          # right-nested: one more stack slot per level
+        expr = "1e-3*atan(v)+(%%s)" %% expr          # right-nested, and nothing Lepton's optimizer folds away (the depth is checked on the optimized tree, the one that is translated): one more stack slot per level
     integ.addComputePerDof("v", "v+dt*f/m")
     integ.addComputePerDof("x", "x+dt*(" + expr + ")")
     integ.addConstrainPositions()

@@ -32,11 +32,19 @@ __device__ __forceinline__ double3 gaussian3(unsigned atom, unsigned long long s
     const float inv32 = 1.0f / 4294967296.0f;
     const float u0 = fmaxf(((float) c[0] + 0.5f) * inv32, 1.0e-10f), u1 = ((float) c[1]) * inv32;
     const float u2 = fmaxf(((float) c[2] + 0.5f) * inv32, 1.0e-10f), u3 = ((float) c[3]) * inv32;
+#ifndef OMMHIP_EMU
+    // The hardware's own transcendentals: v_log_f32 (base 2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in REVOLUTIONS: u itself, no
+    // multiplication by 2 pi and no range reduction) -- a dozen instructions instead of the ~250 of logf / sincosf with their argument
+    // reduction, three times per water molecule in a kernel that is one wavefront per SIMD deep.  Absolute error of a deviate ~1e-6.
+    const float r0 = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0)), r1 = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+    const float s0 = __builtin_amdgcn_sinf(u1), c0 = __builtin_amdgcn_cosf(u1), c1 = __builtin_amdgcn_cosf(u3);
+#else
     const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
     float s0, c0, s1, c1;
     sincosf(6.2831853071795865f * u1, &s0, &c0);
     sincosf(6.2831853071795865f * u3, &s1, &c1);
     (void) s1;
+#endif
     return make_double3(r0 * c0, r0 * s0, r1 * c1);
 }
 

@@ -172,6 +172,52 @@ def test_million_atom_box_on_several_ranks_matches_the_reference_golden(tmp_path
     print(out.stdout)
 
 
+def test_million_atom_box_over_a_device_list_matches_the_reference_golden():
+    """The same golden through the reference's OWN multi-device interface: ONE Context, `DeviceIndex = "0,0,0,0,0,0,0,0"` -- eight ranks on
+    threads of this process (platform/HipParallel.h; a device named twice meets through the host-staged all-gather between the threads)
+    -- and, after the forces, twenty LangevinMiddle steps with the state queries a user makes."""
+    from openmm_amd.parity import force_parity
+    from conftest import ROOT
+    H.load_hip_platform()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_forces_water985527_sample.npz"))
+    w = T.water_box(int(g["n_side"]), seed=int(g["seed"]))
+    w.pme_params = (float(g["pme"][0]), int(g["pme"][1]), int(g["pme"][2]), int(g["pme"][3]))
+    system, nb = w.build()
+    integ = H.Integrator(H.LANGEVIN_MIDDLE, 0.002, 300.0, 1.0, seed=3, constraintTolerance=1e-5)
+    ctx = H.Context(system, integ, "HIP", {"DeviceIndex": ",".join(["0"] * 8)})
+    assert ctx.getPlatformProperty("Ranks") == "8" and ctx.getPlatformProperty("DeviceIndex") == "0,0,0,0,0,0,0,0"
+    ctx.setPositions(w.positions)
+    st = ctx.getState(getForces=True, getEnergy=True)
+    idx = g["indices"]
+    p = force_parity(w.positions, w.box, w.cutoff, st.forces[idx], g["forces"], subset=idx, rms=float(g["rms_force"]))
+    print("water-1M over a list of 8 devices: force max-rel-err over the sampled atoms %.3g, E %.3f vs %.3f" % (p["max_rel_err_all_atoms"], st.potentialEnergy, float(g["energy"])))
+    assert p["max_rel_err_all_atoms"] < 1e-4
+    assert abs(st.potentialEnergy - float(g["energy"])) < 1e-5 * 5.0 * w.num_atoms
+    ctx.applyConstraints(1e-5)
+    ctx.setVelocitiesToTemperature(300.0, 1)
+    integ.step(20)
+    after = ctx.getState(getPositions=True, getEnergy=True)
+    assert np.all(np.isfinite(after.positions)) and np.isfinite(after.potentialEnergy)
+    pos = after.positions.reshape(-1, 3, 3)
+    assert np.abs(np.linalg.norm(pos[:, 0] - pos[:, 1], axis=1) - T.TIP3P["dOH"]).max() < 1e-4
+    ctx.close()
+    # the same twenty steps on ONE device (same thermostat seed: the noise is keyed by seed, step and atom): the same energies
+    system1, nb1 = w.build()
+    integ1 = H.Integrator(H.LANGEVIN_MIDDLE, 0.002, 300.0, 1.0, seed=3, constraintTolerance=1e-5)
+    ctx1 = H.Context(system1, integ1, "HIP", {"DeviceIndex": "0"})
+    ctx1.setPositions(w.positions)
+    ctx1.applyConstraints(1e-5)
+    ctx1.setVelocitiesToTemperature(300.0, 1)
+    integ1.step(20)
+    single = ctx1.getState(getPositions=True, getEnergy=True)
+    ctx1.close()
+    print("after 20 steps: E_pot %.3f (list of 8) vs %.3f (one device), E_kin %.3f vs %.3f, largest position difference %.2e nm" % (
+        after.potentialEnergy, single.potentialEnergy, after.kineticEnergy, single.kineticEnergy, np.abs(after.positions - single.positions).max()))
+    assert abs(after.potentialEnergy - single.potentialEnergy) < 1e-5 * abs(single.potentialEnergy)
+    assert abs(after.kineticEnergy - single.kineticEnergy) < 1e-4 * abs(single.kineticEnergy)
+    assert np.abs(after.positions - single.positions).max() < 1e-4
+
+
 def test_one_rank_over_rccl_walks_every_collective_of_the_decomposed_step():
     """Every collective of include/openmm_hip_comm.h through librccl with a one-rank communicator, driven through the C ABI with the buffers
     of a decomposed step in miniature (VERDICT r4 "missing" 2: the first 8-GPU run must not be the first execution of these calls):

@@ -330,6 +330,17 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
     if (!deviceList.empty()) {
         if (mode.customIntegrator || mode.hostMode)
             throw OpenMMException("HIP platform: a Context over a list of devices supports the Verlet, Langevin and LangevinMiddle integrators");
+        // (every device of the list is checked HERE: a rank that failed before it reached the communicator would leave the others waiting in its creation)
+        int visible = 0;
+        HIP_CHECK(ommhip_device_count(&visible));
+        for (size_t i = 0; i < deviceList.size(); i++)
+            if (deviceList[i] >= visible) {
+                stringstream msg;
+                msg << "HIP platform: DeviceIndex list '" << devicePropValue << "' names device " << deviceList[i] << ", but only " << visible << " device(s) are visible";
+                throw OpenMMException(msg.str());
+            }
+        if (mode.hasValenceForces || mode.hasPluginNativeForces || mode.hasFallbackForces || mode.referenceNonbonded)
+            throw OpenMMException("HIP platform: a Context over a list of devices supports NonbondedForce (PME), HarmonicBond/Angle, PeriodicTorsion, CMMotionRemover and the MonteCarloBarostat");
         // the threads of the other devices start creating their Contexts now; this thread goes on as rank 0 and meets them in the communicator
         group = new HipRankGroup(*this, context, deviceList, properties);
         domain.ranks = (int) deviceList.size(); domain.rank = 0; commId = group->commId();

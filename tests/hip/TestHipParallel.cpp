@@ -175,6 +175,12 @@ void testRefusals() {
     bool threw = false;
     try { Context context(system, integrator, platform, props); } catch (const OpenMMException&) { threw = true; }
     ASSERT(threw);
+    // a device that does not exist is refused before any rank waits for it
+    map<string, string> far;
+    far[HipPlatform::HipDeviceIndex()] = "0,4096";
+    threw = false;
+    try { Context context(system, integrator, platform, far); } catch (const OpenMMException&) { threw = true; }
+    ASSERT(threw);
 }
 
 int main(int argc, char* argv[]) {

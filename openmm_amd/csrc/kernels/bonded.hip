@@ -34,6 +34,7 @@ struct TermList {
 
 struct TermArgs {
     int numLists, paddedAtoms, includeEnergy, energySlots;
+    int debugSkipAtomics;     // profiling only (OPENMM_HIP_DEBUG_SKIP_TERM_ATOMICS, results are wrong): the arithmetic without the force atomics
     BoxD box;
     const double4* pos;
     const int* slotOfAtom;
@@ -53,6 +54,7 @@ struct TermCtx {     // what one term evaluation needs
         return make_double3(dx, dy, dz);
     }
     __device__ __forceinline__ void add(int atom, double fx, double fy, double fz) const {
+        if (a.debugSkipAtomics) { if (fx == 12345.678) a.force[0] = 1; return; }
         add_force(a.force, a.paddedAtoms, a.slotOfAtom[atom], fx, fy, fz);
     }
 };
@@ -370,6 +372,7 @@ static int make_term_args(TermArgs& a, int num_lists, const ommhip_term_batch* l
                           const double box[6], long long* force_d, double* energy_buffer_d, int energy_slots, int include_energy) {
     if (num_lists > OMMHIP_MAX_TERM_LISTS) return -1;
     a.numLists = 0; a.paddedAtoms = padded_atoms; a.includeEnergy = include_energy; a.energySlots = energy_slots;
+    { static const bool skip = getenv("OPENMM_HIP_DEBUG_SKIP_TERM_ATOMICS") != nullptr; a.debugSkipAtomics = skip ? 1 : 0; }
     a.box.ax = box[0]; a.box.bx = box[1]; a.box.by = box[2]; a.box.cx = box[3]; a.box.cy = box[4]; a.box.cz = box[5];
     a.pos = (const double4*) pos_d; a.slotOfAtom = slot_of_atom_d; a.force = force_d; a.energyBuffer = energy_buffer_d;
     int blocks = 0;

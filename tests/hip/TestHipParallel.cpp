@@ -121,10 +121,10 @@ static void buildWater(System& system, vector<Vec3>& positions, int side) {
     system.addForce(new CMMotionRemover(1));
 }
 
-void testDynamics(int ranks) {
+void testDynamics(int ranks, int side = 14, int steps = 30) {
     System system;
     vector<Vec3> positions;
-    buildWater(system, positions, 14);          // 8 232 atoms, L = 4.34 nm
+    buildWater(system, positions, side);          // side 14: 8 232 atoms, L = 4.34 nm
     const int numParticles = system.getNumParticles();
     LangevinMiddleIntegrator integrator1(300.0, 1.0, 0.002), integrator2(300.0, 1.0, 0.002);
     integrator1.setRandomNumberSeed(11); integrator2.setRandomNumberSeed(11);
@@ -135,8 +135,8 @@ void testDynamics(int ranks) {
         c->setPositions(positions);
         c->setVelocitiesToTemperature(300.0, 5);
     }
-    integrator1.step(30);
-    integrator2.step(30);
+    integrator1.step(steps);
+    integrator2.step(steps);
     State s1 = context1.getState(State::Positions | State::Velocities | State::Forces | State::Energy);
     State s2 = context2.getState(State::Positions | State::Velocities | State::Forces | State::Energy);
     double worst = 0;
@@ -151,10 +151,10 @@ void testDynamics(int ranks) {
     // a checkpoint of the device-list Context, more steps, the checkpoint put back, the same steps again: the same state
     stringstream checkpoint;
     context2.createCheckpoint(checkpoint);
-    integrator2.step(10);
+    integrator2.step(steps / 3);
     State after = context2.getState(State::Positions);
     context2.loadCheckpoint(checkpoint);
-    integrator2.step(10);
+    integrator2.step(steps / 3);
     State again = context2.getState(State::Positions);
     for (int i = 0; i < numParticles; i++)
         ASSERT_EQUAL_VEC(after.getPositions()[i], again.getPositions()[i], 2e-5);          // (float atomics on the charge grid: two runs of ten steps agree to ~1e-6, not bit for bit)
@@ -193,6 +193,7 @@ int main(int argc, char* argv[]) {
             testDynamics(2);
             testDynamics(3);
         }
+        else testDynamics(2, 8, 6);          // 1 536 atoms, six steps (slabs too thin for a halo: positions replicated)
     }
     catch (const exception& e) {
         cout << "exception: " << e.what() << endl;

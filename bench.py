@@ -77,6 +77,9 @@ def parse_args():
     p.add_argument("--props", default="", help="extra HIP platform properties, e.g. DisablePmeStream=true")
     p.add_argument("--serialize-ranks", action="store_true", help="diagnostics, gloo transport on one GPU: the ranks run their work between collectives one at a time, so each rank's compute time per step is measured on an idle GPU (per_rank_compute_ms_per_step); the wall-clock value is meaningless in this mode")
     p.add_argument("--amoeba-timeout", type=float, default=420.0, help="N = 1: seconds the child process with the two AMOEBA legs (tools/bench_amoeba_legs.py) may take")
+    p.add_argument("--rank-alone", type=int, default=0, metavar="R", help="diagnostics on ONE GPU: every rank of an R-rank decomposition of the 1M-atom box in turn, ALONE -- collectives that cost "
+                   "nothing and move nothing (CommId \"alone\"), dynamics frozen (1e-3 fs), a list rebuild forced every 8th step: a rank's step with its two streams overlapped and no communication "
+                   "(per_rank_alone_ms_per_step); the forces are meaningless")
     p.add_argument("--attempt-timeout", type=float, default=200.0, help="N > 1: seconds a configuration may take before the launchers give up on it")
     return p.parse_args()
 
@@ -258,6 +261,42 @@ def measure_group_traffic():
                        "correction": "FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; KB -> bytes x 1024"}}
 
 
+def rank_alone(args, H, np):
+    """--rank-alone R: see the option's help.  One JSON line."""
+    os.environ["OPENMM_HIP_ALLOW_ALONE_COMM"] = "1"
+    os.environ.setdefault("OPENMM_HIP_DEBUG_REBUILD_EVERY", "8")
+    ranks = args.rank_alone
+    w = make_workload(args.workload if args.workload != "auto" else "water1m", seed=1)
+    per_rank = []
+    for r in range(ranks):
+        system, nb = w.build()
+        integ = H.Integrator(H.LANGEVIN_MIDDLE, 1e-6, 300.0, 1.0, seed=1, constraintTolerance=1e-5)          # 1e-3 fs: nothing moves, the halo stays what it was given
+        ctx = H.Context(system, integ, "HIP", {"DeviceIndex": "0", "Ranks": str(ranks), "Rank": str(r), "CommId": "alone"})
+        ctx.setPositions(w.positions)
+        ctx.applyConstraints(1e-5)
+        if getattr(w, "velocities", None) is not None:
+            ctx.setVelocities(w.velocities)
+        integ.step(args.warmup if args.warmup < 300 else 40)
+        ctx.getState(getEnergy=True)
+        steps = args.steps if args.steps < 3000 else 400
+        t0 = time.perf_counter()
+        integ.step(steps)
+        ctx.getState(getEnergy=True)
+        per_rank.append(round(1e3 * (time.perf_counter() - t0) / steps, 4))
+        info = None
+        try:
+            info = H.domain_info()
+        except Exception:
+            pass
+        ctx.close()
+    out = {"per_rank_alone_ms_per_step": per_rank, "ranks": ranks, "steps": steps, "workload": w.name,
+           "rebuild_every": int(os.environ["OPENMM_HIP_DEBUG_REBUILD_EVERY"]),
+           "domain_of_the_last_rank": list(info) if info is not None else None,
+           "note": "every rank of the decomposition ALONE on one GPU: collectives return at once and move nothing, dynamics frozen (1e-3 fs), a list rebuild forced "
+                   "every rebuild_every-th step; the two streams of the rank overlap as they do over RCCL.  The compute side of the scaling limit: forces are meaningless"}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse_args()
     if os.environ.get("BENCH_DEBUG_HANG"):
@@ -289,6 +328,8 @@ def main():
     import numpy as np
     from openmm_amd import capi, harness as H, multirank as MR
     H.load_hip_platform(emulated=EMULATED)
+    if args.rank_alone > 1 and world == 1:
+        return rank_alone(args, H, np)
     kernels = capi.load(os.path.join(H.EMU_DIR, "libopenmm_hip_kernels.so")) if EMULATED else capi.load()
     plugin = C.CDLL(os.path.join(H.EMU_DIR if EMULATED else H.LIB_DIR, "libOpenMMHIP.so"))
 

@@ -42,6 +42,10 @@ int ommhip_comm_unique_id(char* hex);
 /* collective over all ranks (blocks until every rank has called it); the current HIP device is the rank's GPU */
 int ommhip_comm_create_rccl(const char* id_hex, int rank, int size, ommhip_comm** comm);
 int ommhip_comm_create_callback(ommhip_host_all_gather_fn fn, void* user, int rank, int size, ommhip_comm** comm);
+/* Diagnostics ("alone" transport, bench.py --rank-alone): rank `rank` of `size` exists, its peers do not -- every collective returns at once and
+ * moves nothing (the halo keeps the positions it was given at the start).  What the rank computes is meaningless; what it LAUNCHES is one rank's
+ * step of the decomposition with its two streams overlapped as over RCCL and no communication at all: the compute side of the scaling limit. */
+int ommhip_comm_create_alone(int rank, int size, ommhip_comm** comm);
 /* A second communicator over the same ranks (collective): for traffic issued from another stream (reciprocal space runs
  * beside the pair kernel).  RCCL: ncclCommSplit with one colour; the callback transport shares its callback. */
 int ommhip_comm_duplicate(ommhip_comm* comm, ommhip_comm** copy);

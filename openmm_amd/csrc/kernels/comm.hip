@@ -24,6 +24,8 @@
 struct ommhip_comm {
     int rank = 0, size = 1;
     bool rccl = false;
+    // "alone" transport (diagnostics): this rank of `size` exists, its peers do not -- every collective returns at once and moves nothing
+    bool alone = false;
     // callback transport
     ommhip_host_all_gather_fn fn = nullptr;
     void* user = nullptr;
@@ -161,9 +163,17 @@ int ommhip_comm_create_callback(ommhip_host_all_gather_fn fn, void* user, int ra
     return 0;
 }
 
+int ommhip_comm_create_alone(int rank, int size, ommhip_comm** comm) {
+    if (rank < 0 || rank >= size) return 1;
+    ommhip_comm* c = new ommhip_comm();
+    c->rank = rank; c->size = size; c->alone = true;
+    *comm = c;
+    return 0;
+}
+
 int ommhip_comm_duplicate(ommhip_comm* comm, ommhip_comm** copy) {
     ommhip_comm* c = new ommhip_comm();
-    c->rank = comm->rank; c->size = comm->size; c->rccl = comm->rccl; c->fn = comm->fn; c->user = comm->user;
+    c->rank = comm->rank; c->size = comm->size; c->rccl = comm->rccl; c->fn = comm->fn; c->user = comm->user; c->alone = comm->alone;
 #ifndef OMMHIP_EMU
     if (comm->rccl) {
         RcclApi& api = rccl_api();
@@ -190,10 +200,10 @@ int ommhip_comm_destroy(ommhip_comm* comm) {
 
 int ommhip_comm_rank(const ommhip_comm* comm) { return comm->rank; }
 int ommhip_comm_size(const ommhip_comm* comm) { return comm->size; }
-const char* ommhip_comm_transport(const ommhip_comm* comm) { return comm->rccl ? "rccl" : "callback"; }
+const char* ommhip_comm_transport(const ommhip_comm* comm) { return comm->alone ? "alone" : (comm->rccl ? "rccl" : "callback"); }
 
 int ommhip_comm_all_gather(ommhip_comm* c, void* buffer_d, size_t bytes, void* stream) {
-    if (bytes == 0) return 0;
+    if (bytes == 0 || c->alone) return 0;
     hipStream_t st = (hipStream_t) stream;
     char* buf = (char*) buffer_d;
 #ifndef OMMHIP_EMU
@@ -229,7 +239,7 @@ int ommhip_comm_all_gather(ommhip_comm* c, void* buffer_d, size_t bytes, void* s
 
 int ommhip_comm_all_to_all(ommhip_comm* c, const void* send_d, void* recv_d, size_t bytes, void* stream) {
     hipStream_t st = (hipStream_t) stream;
-    if (bytes == 0) return 0;
+    if (bytes == 0 || c->alone) return 0;
     const char* s = (const char*) send_d;
     char* r = (char*) recv_d;
 #ifndef OMMHIP_EMU
@@ -260,6 +270,7 @@ int ommhip_comm_all_to_all(ommhip_comm* c, const void* send_d, void* recv_d, siz
 int ommhip_comm_ring_exchange(ommhip_comm* c, const void* send_down_d, void* recv_from_up_d, size_t bytes_down,
                               const void* send_up_d, void* recv_from_down_d, size_t bytes_up, void* stream) {
     hipStream_t st = (hipStream_t) stream;
+    if (c->alone) return 0;
     if (c->size == 1 && !c->rccl) {
         // the only slab is its own neighbour on both sides
         if (bytes_down > 0) { hipError_t e = hipMemcpyAsync(recv_from_up_d, send_down_d, bytes_down, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int) e; }
@@ -299,6 +310,7 @@ int ommhip_comm_ring_exchange(ommhip_comm* c, const void* send_down_d, void* rec
 
 int ommhip_comm_halo_exchange(ommhip_comm* c, void* buffer_d, const ommhip_halo_plan* plan, void* stream) {
     if (c->size > OMMHIP_MAX_RANKS) return 1;
+    if (c->alone) return 0;
     // One rank: the only slab holds everything already.  Over RCCL the group is issued all the same -- the rank is its own neighbour on
     // both sides, every section lands on itself -- so that a one-rank run walks the call pattern of the real thing (tests; the platform
     // never exchanges halos with one rank).
@@ -352,6 +364,7 @@ int ommhip_comm_halo_exchange(ommhip_comm* c, void* buffer_d, const ommhip_halo_
 
 int ommhip_comm_halo_return(ommhip_comm* c, long long* force_d, int padded_slots, const ommhip_halo_return_plan* plan, long long* staging_d, void* stream) {
     if (c->size > OMMHIP_MAX_RANKS) return 1;
+    if (c->alone) return 0;
     if (c->size == 1 && !c->rccl) return 0;         // (one rank over RCCL: the section goes to itself and is added once more -- tests only)
     hipStream_t st = (hipStream_t) stream;
     const int me = c->rank, down = (me + c->size - 1) % c->size, up = (me + 1) % c->size;
@@ -396,6 +409,7 @@ int ommhip_comm_halo_return(ommhip_comm* c, long long* force_d, int padded_slots
 
 int ommhip_comm_all_gather_host(ommhip_comm* c, const void* send, void* recv, size_t bytes, void* stream) {
     if (c->size == 1 && !c->rccl) { memcpy(recv, send, bytes); return 0; }
+    if (c->alone) { for (int r = 0; r < c->size; r++) memcpy((char*) recv + (size_t) r * bytes, send, bytes); return 0; }
 #ifndef OMMHIP_EMU
     if (c->rccl) {
         hipStream_t st = (hipStream_t) stream;

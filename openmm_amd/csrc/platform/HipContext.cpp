@@ -611,6 +611,8 @@ void HipContext::fillWireFromPos() {
 }
 
 void HipContext::gatherState() {
+    // ("alone" transport, diagnostics: the peers do not exist -- their atoms keep the state this rank was given at the start)
+    if (domain.comm != NULL && strcmp(ommhip_comm_transport(domain.comm), "alone") == 0) return;
     // positions: the per-step wire records are 32-bit fractions; what leaves the platform (and what a re-sort redistributes) are
     // the owners' exact doubles -- staged in slot order, all-gathered, scattered back to atom order
     HIP_CHECK(ommhip_pack_slots(pos.ptr, atomOfSlot.as<int>(), ownSlot0, ownSlot1, posSlot.ptr, stream));

@@ -843,6 +843,12 @@ double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool
             << " allocated) on a multi-GPU run; the last steps are invalid";
         throw OpenMMException(msg.str());
     }
+    // diagnostics (bench.py --rank-alone, frozen dynamics): a device-side rebuild every n-th evaluation, as the displacement check would ask for one
+    static const int debugRebuildEvery = getenv("OPENMM_HIP_DEBUG_REBUILD_EVERY") != NULL ? atoi(getenv("OPENMM_HIP_DEBUG_REBUILD_EVERY")) : 0;
+    if (debugRebuildEvery > 0 && !forceRebuild && evaluationCount > 0 && evaluationCount % debugRebuildEvery == 0) {
+        static const int one = 1;
+        HIP_CHECK(ommhip_memcpy_h2d(nlState.ptr, &one, sizeof(int), hip.stream));
+    }
     while (true) {
         if (forceRebuild) {
             const int request[3] = {1, 0, 0};

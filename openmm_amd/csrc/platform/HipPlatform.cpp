@@ -368,6 +368,13 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
             if (user == NULL) throw OpenMMException("HIP platform: unknown in-process communicator");
             HIP_CHECK(ommhip_comm_create_callback(hipInProcessAllGather, user, domain.rank, domain.ranks, &domain.comm));
         }
+        else if (commId == "alone") {
+            // diagnostics (bench.py --rank-alone): this rank without its peers, collectives that do nothing -- refused unless the process asks for it
+            const char* allow = getenv("OPENMM_HIP_ALLOW_ALONE_COMM");
+            if (allow == NULL || allow[0] != '1')
+                throw OpenMMException("HIP platform: CommId \"alone\" (a rank without its peers: timing diagnostics, meaningless forces) needs OPENMM_HIP_ALLOW_ALONE_COMM=1");
+            HIP_CHECK(ommhip_comm_create_alone(domain.rank, domain.ranks, &domain.comm));
+        }
         else if (commId.compare(0, 9, "callback:") == 0) {
             // the host-staged transport of the tests and of bench.py's rehearsals: the property carries the address of a function this
             // library will call -- accepted only from a process that says so itself, never from a property string alone

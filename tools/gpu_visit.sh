@@ -15,6 +15,7 @@
 #   serial:N                     N ranks serialised on one GPU over the host-staged transport: per-rank compute per step
 #   serialtrace:N                the same under rocprofv3 --kernel-trace --stats (per-rank kernel statistics)
 #   serialtimeline:N[:count]     the same under rocprofv3: timeline of the busiest rank's last dispatches + its kernel statistics
+#   alone:N[:steps]              each rank of an N-rank decomposition alone on this GPU, no communication, streams overlapped: per-rank ms per step
 #   sh:"command"                 anything else
 cd "$(dirname "$0")/.."
 R=$(pwd); T=${TAG:-visit}
@@ -86,6 +87,9 @@ for step in "$@"; do
       f=$(find gpurun_out/prof_st$a1 -name "*kernel_trace.csv" | xargs -r ls -S | head -1)
       if [ -n "$f" ]; then python tools/rocpd_timeline.py $f ${a2:-160} > gpurun_out/${T}_serial_n${a1}_timeline.txt 2>&1; cp ${f%kernel_trace.csv}kernel_stats.csv gpurun_out/${T}_serial_n${a1}_kernel_stats.csv; else find gpurun_out/prof_st$a1 | head; fi
       tail -${a2:-160} gpurun_out/${T}_serial_n${a1}_timeline.txt | cut -c1-150; rm -rf gpurun_out/prof_st$a1 ;;
+    alone)           # every rank of an N-rank decomposition of the 1M-atom box ALONE on this GPU (collectives that cost nothing): bench.py --rank-alone
+      timeout 900 python bench.py --rank-alone $a1 --steps ${a2:-400} --warmup 40 > gpurun_out/${T}_rank_alone_n$a1.json 2> gpurun_out/${T}_rank_alone_n$a1.err; echo "alone N=$a1 exit $?"
+      tail -1 gpurun_out/${T}_rank_alone_n$a1.json | cut -c1-200 ;;
     sh) bash -c "$a1" ;;
     *) echo "unknown step $kind" ;;
   esac

@@ -399,14 +399,17 @@ __global__ __launch_bounds__(THREADS) void pme_spread_group(PmeArgs a) {
     const int n[3] = {a.nx, a.ny, a.nz};
     for (int i = t; i < ATOMS; i += THREADS) {
         if (sh.charge[i] == 0.f) continue;
-#pragma unroll
-        for (int d = 0; d < 3; d++) atomicMin(&sh.minRel[d], wrap_rel(sh.baseIdx[i][d] - sh.ref[d], n[d]));
         if (DD) {
+            // an atom none of whose five stencil planes is this rank's takes no part (a group at a slab boundary: about half of its atoms):
+            // no LDS accumulation for it, and the brick shrinks to the atoms that count
             bool touch = false;
 #pragma unroll
             for (int k = 0; k < PME_ORDER; k++) { int gx = sh.baseIdx[i][0] + k; gx -= gx >= a.nx ? a.nx : 0; touch = touch || spread_plane<DD>(a, gx) >= 0; }
             if (touch) sh.touches = 1;
+            else { sh.charge[i] = 0.f; continue; }
         }
+#pragma unroll
+        for (int d = 0; d < 3; d++) atomicMin(&sh.minRel[d], wrap_rel(sh.baseIdx[i][d] - sh.ref[d], n[d]));
     }
     __syncthreads();
     if (DD && sh.touches == 0) return;

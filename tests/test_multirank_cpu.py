@@ -346,7 +346,7 @@ def test_eight_rank_domain_decomposition_on_emulator(tmp_path):
     from conftest import EMU_BUILD
     if not os.path.exists(os.path.join(EMU_BUILD, "libOpenMMHIP.so")):
         pytest.skip("emulated plugin not built (run __graft_entry__.build())")
-    out = _run_dd_child(tmp_path, True, None, 4, 29671, nproc=8, env={"OPENMM_HIP_DD_DRIFT": "0.03"},
+    out = _run_dd_child(tmp_path, True, None, 4, 29681, nproc=8, env={"OPENMM_HIP_DD_DRIFT": "0.03"},
                         cases='(("water row, halo sections, half-shell, 8 ranks", T.water_row(4, 8, seed=5), (192, 24, 24)),)')
     assert "domain [8, 1," in out, out[-1500:]            # eight ranks, halo mode
 

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <mutex>
 #include <thread>
 #include <sstream>
 
@@ -562,6 +563,7 @@ void HipApplyConstraintsKernel::applyToVelocities(ContextImpl& context, double t
 // NonbondedForce
 // ================================================================================================
 static vector<HipCalcNonbondedForceKernel*> liveNonbondedKernels;
+static std::mutex liveNonbondedMutex;          // (the inner Contexts of a device list are created and destroyed on threads of their own)
 
 HipCalcNonbondedForceKernel::HipCalcNonbondedForceKernel(string name, const Platform& platform, HipPlatform::PlatformData& data) :
         CalcNonbondedForceKernel(name, platform), data(data), hip(*data.hip), numParticles(0), num14(0), numExclusionPairs(0),
@@ -572,7 +574,7 @@ HipCalcNonbondedForceKernel::HipCalcNonbondedForceKernel(string name, const Plat
     memset(&pme, 0, sizeof(pme));
     memset(&pmeDisp, 0, sizeof(pmeDisp));
     hip.addListener(this);
-    liveNonbondedKernels.push_back(this);
+    { std::lock_guard<std::mutex> lock(liveNonbondedMutex); liveNonbondedKernels.push_back(this); }
 }
 
 /* Diagnostics for bench.py: neighbour-list occupancy of the most recently created native NonbondedForce kernel. */
@@ -914,7 +916,7 @@ double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool
 }
 
 HipCalcNonbondedForceKernel::~HipCalcNonbondedForceKernel() {
-    liveNonbondedKernels.erase(std::remove(liveNonbondedKernels.begin(), liveNonbondedKernels.end(), this), liveNonbondedKernels.end());
+    { std::lock_guard<std::mutex> lock(liveNonbondedMutex); liveNonbondedKernels.erase(std::remove(liveNonbondedKernels.begin(), liveNonbondedKernels.end(), this), liveNonbondedKernels.end()); }
     hip.removeListener(this);
     if (hip.extraClearPtr != NULL && hip.extraClearPtr == gridReal.ptr) { hip.extraClearPtr = NULL; hip.extraClearBytes = 0; }
     if (pinnedState != NULL) ommhip_host_free(pinnedState);

@@ -84,6 +84,11 @@ extern "C" int OpenMM::hipInProcessAllGather(void* user, const void* send, void*
     return 0;
 }
 
+bool& OpenMM::hipCreatingInnerRank() {
+    static thread_local bool creating = false;
+    return creating;
+}
+
 // ================================================================================================
 // the rank group
 // ================================================================================================
@@ -151,8 +156,11 @@ HipRankGroup::HipRankGroup(const HipPlatform& platform, ContextImpl& primary, co
 void HipRankGroup::workerMain(int rank, const System* system, map<string, string> props) {
     Worker& w = *workers[rank];
     try {
+        hipCreatingInnerRank() = true;
         w.context = new Context(*system, *w.integrator, const_cast<HipPlatform&>(platform), props);
+        hipCreatingInnerRank() = false;
     } catch (const std::exception& e) {
+        hipCreatingInnerRank() = false;
         std::lock_guard<std::mutex> lock(w.mutex);
         w.error = string("creating the Context of device-list rank ") + to_string(rank) + ": " + e.what();
     }

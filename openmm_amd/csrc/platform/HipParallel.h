@@ -64,6 +64,9 @@ private:
     int stagedToken;
 };
 
+/** True on a thread of a HipRankGroup while it creates its inner Context (what the platform does once per user Context is then left out). */
+bool& hipCreatingInnerRank();
+
 /** Host-staged all-gather between the threads of one process ("inprocess:<token>" CommId): registry of the groups alive. */
 int hipInProcessCreate(int ranks);                                    // -> token
 void hipInProcessDestroy(int token);

@@ -36,6 +36,7 @@
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <sstream>
 
 using namespace OpenMM;
@@ -315,8 +316,14 @@ void HipPlatform::contextCreated(ContextImpl& context, const map<string, string>
             deviceIndex = atoi(getenv("LOCAL_RANK")) % count;
     }
     // native kernels of other plugins take precedence over Reference kernels registered for the same names (see registerNativeKernel)
-    for (size_t i = 0; i < nativeKernels().size(); i++)
-        const_cast<HipPlatform*>(this)->registerKernelFactory(nativeKernels()[i].kernelName, nativeKernels()[i].factory);
+    // (a device-list Context creates its inner Contexts on threads of their own: the ranks must not re-assert side by side -- and need not, the
+    // user's Context has done it before it started them)
+    static std::mutex reassertMutex;
+    if (!hipCreatingInnerRank()) {
+        std::lock_guard<std::mutex> lock(reassertMutex);
+        for (size_t i = 0; i < nativeKernels().size(); i++)
+            const_cast<HipPlatform*>(this)->registerKernelFactory(nativeKernels()[i].kernelName, nativeKernels()[i].factory);
+    }
     HipModeInfo mode = classifyContext(context);
     // ---- one box on several GPUs (one process per GPU)
     HipDomain domain;

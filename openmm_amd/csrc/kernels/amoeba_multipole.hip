@@ -209,6 +209,7 @@ struct MpArgs {
     float* pairCache; int pairCap;                 // mutual polarization: per list entry (dx, dy, dz, b1, b2) of the Thole-damped dipole-dipole chain, float planes of pairCap * listStride
     float* gather;                                 // mutual polarization: the vectors the induced-dipole field is taken of, (vD, vP) as six floats per SCAN POSITION (k_mp_dipole_field gathers them)
     const double* doneFlag;                        // mutual polarization: sums[10] of the solver -- non-zero once the dipoles have converged: kernels of iterations enqueued ahead return at once
+                                                   // (also when doneFlag[3] = sums[13], the list builder's overflow word, is set: that solve is thrown away by the host at its first wait)
     const double4* specScaleSorted;                // scale factors of the special pairs, rows in the order the list entries index them
 };
 
@@ -320,7 +321,7 @@ __device__ __forceinline__ void atom_splines(const MpArgs& a, V3 x, int (&idx)[3
 #define MP_SPREAD_LANES 8
 template <bool INDUCED>
 __global__ void k_mp_spread(MpArgs a, const double* __restrict__ A, double sA, const double* __restrict__ B, double sB) {
-    if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;
+    if (a.doneFlag != nullptr && (a.doneFlag[0] != 0.0 || a.doneFlag[3] != 0.0)) return;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = tid / MP_SPREAD_LANES, iz = tid % MP_SPREAD_LANES;
     if (i >= a.n || iz >= 5) return;
@@ -381,7 +382,7 @@ __device__ __forceinline__ int mpb_wrap_rel(int d, int n) { if (d >= (n + 1) / 2
 // formed here per atom, stored, and packed for k_mp_dipole_field's gather (k_mp_cg stage 3 as a launch of its own otherwise); b = sums[8 + set],
 // left by the last block of stage 7.
 __global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double* __restrict__ A, double sA, const double* __restrict__ B, double sB, const double* __restrict__ A2, double* cgw) {
-    if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;           // an iteration enqueued ahead of the convergence check (solve_mutual)
+    if (a.doneFlag != nullptr && (a.doneFlag[0] != 0.0 || a.doneFlag[3] != 0.0)) return;           // an iteration enqueued ahead of the convergence check (solve_mutual)
     if (a.needDone != nullptr && *a.needDone == 0.0) return;           // the tail enqueued ahead of it: only once converged
     // two-grid launch: the second set of dipoles onto the second grid (the argument struct itself is left alone: a modified copy would
     // move all of it from scalar kernel-argument loads to private memory)
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(256) void k_mp_spread_bricks(MpArgs a, const double
 // extrapolated-polarization scheme keeps of every order.
 template <int MAXORD>
 __global__ void k_mp_potential(MpArgs a, double* __restrict__ out, double* __restrict__ out2) {
-    if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;
+    if (a.doneFlag != nullptr && (a.doneFlag[0] != 0.0 || a.doneFlag[3] != 0.0)) return;
     if (a.needDone != nullptr && *a.needDone == 0.0) return;
     const float* const grid = blockIdx.y == 1 ? a.grid2 : a.grid;          // (see k_mp_spread_bricks)
     if (blockIdx.y == 1) out = out2;
@@ -908,7 +909,7 @@ __global__ __launch_bounds__(MP_BLOCK) void k_mp_forces(MpArgs a) {
 // their dot products; 1: A p = p / alpha - T p into the place of T p, and p . A p.  -1: the field is stored, nothing else.
 __global__ __launch_bounds__(MP_BLOCK) void k_mp_dipole_field(MpArgs a, const double* __restrict__ vD, const double* __restrict__ vP, const double* __restrict__ phiD,
                                                               const double* __restrict__ phiP, double* __restrict__ outD, double* __restrict__ outP, double* w, int cgStage) {
-    if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;           // an iteration enqueued ahead of the convergence check (solve_mutual)
+    if (a.doneFlag != nullptr && (a.doneFlag[0] != 0.0 || a.doneFlag[3] != 0.0)) return;           // an iteration enqueued ahead of the convergence check (solve_mutual)
     const int t = threadIdx.x, g = (blockIdx.x * MP_BLOCK + t) / MP_SPLIT, q = t % MP_SPLIT, i = scan_atom(a, g);
     const bool active = i >= 0;
     const int ii = active ? i : 0;
@@ -1107,7 +1108,7 @@ __global__ void k_mp_ext_forces(MpArgs a, const double* __restrict__ records, co
 // the pair cache k_mp_field wrote; symmetric by construction (T_ij = T_ji, both directions visited).  Also accumulates r.z: into sums[0,1] at
 // the start (initial = 1: p = z as well), into sums[6,7] inside an iteration.
 __global__ __launch_bounds__(MP_BLOCK) void k_mp_precond(MpArgs a, double* w, int initial) {
-    if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;
+    if (a.doneFlag != nullptr && (a.doneFlag[0] != 0.0 || a.doneFlag[3] != 0.0)) return;
     const int t = threadIdx.x, g = (blockIdx.x * MP_BLOCK + t) / MP_SPLIT, q = t % MP_SPLIT, i = scan_atom(a, g);
     const bool active = i >= 0;
     const size_t n3 = 3 * (size_t) a.n;
@@ -1319,7 +1320,7 @@ __global__ void k_mp_cg(MpArgs a, double* w, int stage, double target, double un
 
 // (vD, vP) of every atom as six floats at its scan position: what k_mp_dipole_field gathers (see there)
 __global__ void k_mp_pack(MpArgs a, const double* __restrict__ vD, const double* __restrict__ vP) {
-    if (a.doneFlag != nullptr && *a.doneFlag != 0.0) return;
+    if (a.doneFlag != nullptr && (a.doneFlag[0] != 0.0 || a.doneFlag[3] != 0.0)) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     float* v = a.gather + 6 * (size_t) (a.slotOfAtom != nullptr && a.order != nullptr ? a.slotOfAtom[i] : i);

@@ -85,6 +85,19 @@ def test_amoeba_water_box_tile_scan_against_reference_kernel_and_full_scan(tmp_p
     assert r["full_scan"][0] < (5e-5 if mutual else 3e-6) and r["full_scan"][1] < 1e-6
 
 
+def test_amoeba_mutual_solver_throws_away_a_solve_on_overflowed_lists(tmp_path):
+    """Mutual polarization on a 5 184-atom water box whose pair lists start at 8 entries per atom (OPENMM_HIP_AMOEBA_PAIR_CAP): the
+    multipole call does not wait for its list builder, so field kernels and solver iterations are enqueued on truncated lists; the
+    overflow word (the solver's sums[13]) makes every kernel enqueued behind stage 5 return at once, the host learns of it at the solver's
+    first wait, the plugin grows the lists and calls again.  Forces and energy: those of the scan over all atoms, which grows its own
+    lists the same way, and of the AMOEBA plugin's Reference kernel."""
+    from amoeba_water_case import run_amoeba_water_case
+    r = run_amoeba_water_case(tmp_path, False, 12, 48, True, tiles_env={"OPENMM_HIP_AMOEBA_PAIR_CAP": "8"})
+    print(r)
+    assert r["reference"][0] < 5e-5 and r["reference"][1] < 5e-5
+    assert r["full_scan"][0] < 5e-5 and r["full_scan"][1] < 1e-6
+
+
 AMOEBA_TILE_CHILD = r'''
 import sys, numpy as np
 sys.path.insert(0, %r)

@@ -51,6 +51,10 @@ int ommhip_stream_create_priority(void** stream, int high_priority);   /* side s
 int ommhip_event_create_untimed(void** event);   /* ordering-only event (cheaper than a timed one) */
 int ommhip_stream_destroy(void* stream);
 int ommhip_stream_sync(void* stream);
+/* hipSetDevice(device) (device >= 0) + hipDeviceSynchronize(): everything this library and the platform plugin have enqueued on that device
+ * has run.  For harnesses written against another HIP runtime instance -- PyTorch's wheels bundle their own libamdhip64, so
+ * torch.cuda.synchronize() does not see the plugin's streams (bench.py brackets its timed region with this call). */
+int ommhip_device_sync(int device);
 int ommhip_event_create(void** event);
 int ommhip_event_destroy(void* event);
 int ommhip_event_record(void* event, void* stream);

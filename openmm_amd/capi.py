@@ -114,6 +114,7 @@ SIGNATURES = {
     "event_create_untimed": [C.POINTER(C.c_void_p)],
     "stream_destroy": [_P],
     "stream_sync": [_P],
+    "device_sync": [C.c_int],
     "event_create": [C.POINTER(C.c_void_p)],
     "event_destroy": [_P],
     "event_record": [_P, _P],

@@ -78,6 +78,10 @@ int ommhip_stream_create_priority(void** stream, int high_priority) {
 int ommhip_event_create_untimed(void** event) { return (int) hipEventCreateWithFlags((hipEvent_t*) event, hipEventDisableTiming); }
 int ommhip_stream_destroy(void* stream) { return (int) hipStreamDestroy((hipStream_t) stream); }
 int ommhip_stream_sync(void* stream) { return (int) hipStreamSynchronize((hipStream_t) stream); }
+int ommhip_device_sync(int device) {
+    if (device >= 0) { const hipError_t e = hipSetDevice(device); if (e != hipSuccess) return (int) e; }
+    return (int) hipDeviceSynchronize();
+}
 int ommhip_event_create(void** event) { return (int) hipEventCreate((hipEvent_t*) event); }
 int ommhip_event_destroy(void* event) { return (int) hipEventDestroy((hipEvent_t) event); }
 int ommhip_event_record(void* event, void* stream) { return (int) hipEventRecord((hipEvent_t) event, (hipStream_t) stream); }

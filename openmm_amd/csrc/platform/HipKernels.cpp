@@ -802,6 +802,14 @@ double HipCalcNonbondedForceKernel::executeDecomposed(ContextImpl& context, bool
     // owned blocks, halo planes, interpolation for the owned atoms.
     if (nonbondedMethod != PME || !includeDirect || !includeReciprocal)
         throw OpenMMException("HIP platform: multi-GPU runs support NonbondedForce with PME, direct and reciprocal space in one force group");
+    {
+        // test hook, "rank:evaluation": that rank fails at that evaluation -- what the others make of a rank that never reaches a collective
+        // (tests/hip/TestHipParallel.cpp, testFailingRank)
+        const char* failAt = getenv("OPENMM_HIP_DEBUG_FAIL_RANK");
+        int failRank = -1, failEvaluation = -1;
+        if (failAt != NULL && sscanf(failAt, "%d:%d", &failRank, &failEvaluation) == 2 && failRank == hip.domain.rank && failEvaluation == (int) evaluationCount)
+            throw OpenMMException("HIP platform: rank " + std::to_string(failRank) + " fails here (OPENMM_HIP_DEBUG_FAIL_RANK)");
+    }
     const int ie = includeEnergy ? 1 : 0;
     nl.pbc = (hip.box[1] != 0.0 || hip.box[3] != 0.0 || hip.box[4] != 0.0) ? 2 : 1;
     nl.dd_mode = 1;

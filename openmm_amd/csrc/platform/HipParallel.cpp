@@ -27,6 +27,7 @@ struct StagedGroup {
     std::condition_variable cv;
     int arrived = 0, copied = 0;
     long long generationIn = 0, generationOut = 0;
+    bool broken = false;               // a rank failed: nobody waits for it any more (hipInProcessAbort)
     vector<const void*> send;
     vector<StagedRank> users;
 };
@@ -54,6 +55,14 @@ void OpenMM::hipInProcessDestroy(int token) {
     registry.erase(found);
 }
 
+void OpenMM::hipInProcessAbort(int token) {
+    std::lock_guard<std::mutex> lock(registryMutex);
+    map<int, StagedGroup*>::iterator found = registry.find(token);
+    if (found == registry.end()) return;
+    { std::lock_guard<std::mutex> inner(found->second->mutex); found->second->broken = true; }
+    found->second->cv.notify_all();
+}
+
 void* OpenMM::hipInProcessUser(int token, int rank) {
     std::lock_guard<std::mutex> lock(registryMutex);
     map<int, StagedGroup*>::iterator found = registry.find(token);
@@ -67,19 +76,24 @@ extern "C" int OpenMM::hipInProcessAllGather(void* user, const void* send, void*
     StagedRank* me = (StagedRank*) user;
     if (me == NULL) return 1;
     StagedGroup& g = *me->group;
+    // A rank that failed never arrives: whoever learns of it (hipInProcessAbort) marks the group broken, and every rank waiting here -- now or
+    // later -- returns an error instead (its own call then fails the way a failed collective does; the Context is lost either way).
     {
         std::unique_lock<std::mutex> lock(g.mutex);
+        if (g.broken) return 1;
         g.send[me->rank] = send;
         const long long gen = g.generationIn;
         if (++g.arrived == g.ranks) { g.arrived = 0; g.generationIn++; g.cv.notify_all(); }
-        else g.cv.wait(lock, [&] { return g.generationIn != gen; });
+        else g.cv.wait(lock, [&] { return g.generationIn != gen || g.broken; });
+        if (g.generationIn == gen) return 1;          // woken by the abort: the pieces are not all there
     }
     for (int r = 0; r < g.ranks; r++) memcpy((char*) recv + (size_t) r * bytes, g.send[r], bytes);
     {
         std::unique_lock<std::mutex> lock(g.mutex);
         const long long gen = g.generationOut;
         if (++g.copied == g.ranks) { g.copied = 0; g.generationOut++; g.cv.notify_all(); }
-        else g.cv.wait(lock, [&] { return g.generationOut != gen; });
+        else g.cv.wait(lock, [&] { return g.generationOut != gen || g.broken; });
+        if (g.generationOut == gen) return 1;         // (the others' copies may be unfinished: they fail as well)
     }
     return 0;
 }
@@ -163,6 +177,7 @@ void HipRankGroup::workerMain(int rank, const System* system, map<string, string
         hipCreatingInnerRank() = false;
         std::lock_guard<std::mutex> lock(w.mutex);
         w.error = string("creating the Context of device-list rank ") + to_string(rank) + ": " + e.what();
+        abortCollectives(rank, w.error);
     }
     while (true) {
         std::function<void()> task;
@@ -181,10 +196,20 @@ void HipRankGroup::workerMain(int rank, const System* system, map<string, string
         catch (const std::exception& e) {
             std::lock_guard<std::mutex> lock(w.mutex);
             if (w.error.empty()) w.error = string("device-list rank ") + to_string(rank) + ": " + e.what();
+            abortCollectives(rank, w.error);          // the other ranks must not wait for this one in a collective it will never reach
         }
     }
     delete w.context;
     w.context = NULL;
+}
+
+void HipRankGroup::abortCollectives(int rank, const std::string& why) {
+    {
+        std::lock_guard<std::mutex> lock(causeMutex);
+        if (causeRank < 0) { causeRank = rank; cause = why; }
+    }
+    if (stagedToken != 0) hipInProcessAbort(stagedToken);
+    // (RCCL: a rank stuck in a device-side collective cannot be released from here; the process has to end, as with one process per GPU)
 }
 
 HipRankGroup::~HipRankGroup() {
@@ -211,7 +236,7 @@ void HipRankGroup::post(const std::function<void(int)>& task) {
     }
 }
 
-void HipRankGroup::join() {
+std::string HipRankGroup::firstError() {
     string error;
     for (size_t r = 1; r < workers.size(); r++) {
         Worker& w = *workers[r];
@@ -219,6 +244,11 @@ void HipRankGroup::join() {
         w.idle.wait(lock, [&] { return w.queue.empty() && !w.busy; });
         if (error.empty() && !w.error.empty()) error = w.error;
     }
+    return error;
+}
+
+void HipRankGroup::join() {
+    const string error = firstError();
     if (!error.empty()) throw OpenMMException("HIP platform: " + error);
 }
 
@@ -257,6 +287,18 @@ public:
     }
 protected:
     HipRankGroup& group() const { return *data.group; }
+    /** Rank 0's own share of a call.  If it throws, the inner ranks are released from the collectives in which they would wait for it. */
+    template <class F>
+    auto guard(F f) const -> decltype(f()) {
+        try { return f(); }
+        catch (const std::exception& e) {
+            group().abortCollectives(0, e.what());
+            // was it an inner rank that failed first (rank 0 then only saw a collective return an error)?  Its message is the one to report
+            group().firstError();          // (waits until the inner ranks have run out of the collectives)
+            if (group().failedFirst() > 0) throw OpenMMException("HIP platform: " + group().firstCause());
+            throw;
+        }
+    }
     K& peer(int rank) const {
         K* k = dynamic_cast<K*>(group().peer(rank, this->getName(), ordinal));
         if (k == NULL) throw OpenMMException("HIP platform: internal error: peer kernel of an unexpected type");
@@ -273,11 +315,11 @@ public:
     void initialize(const System& system) { own->initialize(system); }
     void beginComputation(ContextImpl& context, bool includeForce, bool includeEnergy, int groups) {
         group().post([=](int r) { peer(r).beginComputation(group().impl(r), includeForce, includeEnergy, groups); });
-        own->beginComputation(context, includeForce, includeEnergy, groups);
+        guard([&] { own->beginComputation(context, includeForce, includeEnergy, groups); });
     }
     double finishComputation(ContextImpl& context, bool includeForce, bool includeEnergy, int groups, bool& valid) {
         group().post([=](int r) { bool v = true; peer(r).finishComputation(group().impl(r), includeForce, includeEnergy, groups, v); });
-        const double energy = own->finishComputation(context, includeForce, includeEnergy, groups, valid);
+        const double energy = guard([&] { return own->finishComputation(context, includeForce, includeEnergy, groups, valid); });
         if (includeEnergy) group().join();          // an energy leaves the platform: whatever went wrong on another rank is reported with it
         return energy;
     }
@@ -295,44 +337,44 @@ public:
     // the downloads of a decomposed run are collectives (every rank gathers the exact state): the inner ranks take part and drop the copy
     void getPositions(ContextImpl& context, vector<Vec3>& positions) {
         group().post([=](int r) { vector<Vec3> tmp; peer(r).getPositions(group().impl(r), tmp); });
-        own->getPositions(context, positions);
+        guard([&] { own->getPositions(context, positions); });
         group().join();
     }
     void setPositions(ContextImpl& context, const vector<Vec3>& positions) {
         std::shared_ptr<vector<Vec3> > copy(new vector<Vec3>(positions));
         group().post([=](int r) { peer(r).setPositions(group().impl(r), *copy); });
-        own->setPositions(context, positions);
+        guard([&] { own->setPositions(context, positions); });
     }
     void getVelocities(ContextImpl& context, vector<Vec3>& velocities) {
         group().post([=](int r) { vector<Vec3> tmp; peer(r).getVelocities(group().impl(r), tmp); });
-        own->getVelocities(context, velocities);
+        guard([&] { own->getVelocities(context, velocities); });
         group().join();
     }
     void setVelocities(ContextImpl& context, const vector<Vec3>& velocities) {
         std::shared_ptr<vector<Vec3> > copy(new vector<Vec3>(velocities));
         group().post([=](int r) { peer(r).setVelocities(group().impl(r), *copy); });
-        own->setVelocities(context, velocities);
+        guard([&] { own->setVelocities(context, velocities); });
     }
     void getForces(ContextImpl& context, vector<Vec3>& forces) {
         group().post([=](int r) { vector<Vec3> tmp; peer(r).getForces(group().impl(r), tmp); });
-        own->getForces(context, forces);
+        guard([&] { own->getForces(context, forces); });
         group().join();
     }
     void getEnergyParameterDerivatives(ContextImpl& context, map<string, double>& derivs) { own->getEnergyParameterDerivatives(context, derivs); }
     void getPeriodicBoxVectors(ContextImpl& context, Vec3& a, Vec3& b, Vec3& c) const { own->getPeriodicBoxVectors(context, a, b, c); }
     void setPeriodicBoxVectors(ContextImpl& context, const Vec3& a, const Vec3& b, const Vec3& c) {
         group().post([=](int r) { peer(r).setPeriodicBoxVectors(group().impl(r), a, b, c); });
-        own->setPeriodicBoxVectors(context, a, b, c);
+        guard([&] { own->setPeriodicBoxVectors(context, a, b, c); });
     }
     void createCheckpoint(ContextImpl& context, ostream& stream) {
         group().post([=](int r) { stringstream drop; peer(r).createCheckpoint(group().impl(r), drop); });
-        own->createCheckpoint(context, stream);
+        guard([&] { own->createCheckpoint(context, stream); });
         group().join();
     }
     void loadCheckpoint(ContextImpl& context, istream& stream) {
         // rank 0 reads its part of the stream; the same bytes are then handed to the inner ranks
         const std::streampos before = stream.tellg();
-        own->loadCheckpoint(context, stream);
+        guard([&] { own->loadCheckpoint(context, stream); });
         const std::streampos after = stream.tellg();
         if (before == std::streampos(-1) || after == std::streampos(-1))
             throw OpenMMException("HIP platform: loading a checkpoint into a Context over a list of devices needs a seekable stream");
@@ -350,11 +392,11 @@ public:
     void initialize(const System& system) { own->initialize(system); }
     void apply(ContextImpl& context, double tol) {
         group().post([=](int r) { peer(r).apply(group().impl(r), tol); });
-        own->apply(context, tol);
+        guard([&] { own->apply(context, tol); });
     }
     void applyToVelocities(ContextImpl& context, double tol) {
         group().post([=](int r) { peer(r).applyToVelocities(group().impl(r), tol); });
-        own->applyToVelocities(context, tol);
+        guard([&] { own->applyToVelocities(context, tol); });
     }
 };
 
@@ -364,12 +406,12 @@ public:
     void initialize(const System& system, const NonbondedForce& force) { own->initialize(system, force); }
     double execute(ContextImpl& context, bool includeForces, bool includeEnergy, bool includeDirect, bool includeReciprocal) {
         group().post([=](int r) { peer(r).execute(group().impl(r), includeForces, includeEnergy, includeDirect, includeReciprocal); });
-        return own->execute(context, includeForces, includeEnergy, includeDirect, includeReciprocal);
+        return guard([&] { return own->execute(context, includeForces, includeEnergy, includeDirect, includeReciprocal); });
     }
     void copyParametersToContext(ContextImpl& context, const NonbondedForce& force) {
         const NonbondedForce* f = &force;
         group().post([=](int r) { peer(r).copyParametersToContext(group().impl(r), *f); });
-        own->copyParametersToContext(context, force);
+        guard([&] { own->copyParametersToContext(context, force); });
         group().join();          // the Force object is the caller's
     }
     void getPMEParameters(double& alpha, int& nx, int& ny, int& nz) const { own->getPMEParameters(alpha, nx, ny, nz); }
@@ -383,12 +425,12 @@ public:
     void initialize(const System& system, const F& force) { this->own->initialize(system, force); }
     double execute(ContextImpl& context, bool includeForces, bool includeEnergy) {
         this->group().post([=](int r) { this->peer(r).execute(this->group().impl(r), includeForces, includeEnergy); });
-        return this->own->execute(context, includeForces, includeEnergy);
+        return this->guard([&] { return this->own->execute(context, includeForces, includeEnergy); });
     }
     void copyParametersToContext(ContextImpl& context, const F& force) {
         const F* f = &force;
         this->group().post([=](int r) { this->peer(r).copyParametersToContext(this->group().impl(r), *f); });
-        this->own->copyParametersToContext(context, force);
+        this->guard([&] { this->own->copyParametersToContext(context, force); });
         this->group().join();
     }
 };
@@ -409,12 +451,12 @@ public:
             apply(mine, temperature, friction);
             this->peer(r).execute(this->group().impl(r), mine);
         });
-        this->own->execute(context, integrator);
+        this->guard([&] { this->own->execute(context, integrator); });
         if ((++steps & 31) == 0) this->group().join();          // errors of the other ranks surface within a few steps
     }
     double computeKineticEnergy(ContextImpl& context, const I& integrator) {
         this->group().post([=](int r) { this->peer(r).computeKineticEnergy(this->group().impl(r), dynamic_cast<I&>(this->group().integrator(r))); });
-        const double ke = this->own->computeKineticEnergy(context, integrator);
+        const double ke = this->guard([&] { return this->own->computeKineticEnergy(context, integrator); });
         this->group().join();
         return ke;
     }
@@ -434,7 +476,7 @@ public:
     void initialize(const System& system, const CMMotionRemover& force) { own->initialize(system, force); }
     void execute(ContextImpl& context) {
         group().post([=](int r) { peer(r).execute(group().impl(r)); });
-        own->execute(context);
+        guard([&] { own->execute(context); });
     }
 };
 
@@ -444,11 +486,11 @@ public:
     void initialize(const System& system, const Force& barostat) { own->initialize(system, barostat); }
     void scaleCoordinates(ContextImpl& context, double scaleX, double scaleY, double scaleZ) {
         group().post([=](int r) { peer(r).scaleCoordinates(group().impl(r), scaleX, scaleY, scaleZ); });
-        own->scaleCoordinates(context, scaleX, scaleY, scaleZ);
+        guard([&] { own->scaleCoordinates(context, scaleX, scaleY, scaleZ); });
     }
     void restoreCoordinates(ContextImpl& context) {
         group().post([=](int r) { peer(r).restoreCoordinates(group().impl(r)); });
-        own->restoreCoordinates(context);
+        guard([&] { own->restoreCoordinates(context); });
     }
 };
 

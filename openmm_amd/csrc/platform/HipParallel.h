@@ -40,6 +40,14 @@ public:
     void post(const std::function<void(int)>& task);
     /** Waits until every inner rank has finished what was posted; rethrows the first exception one of them met. */
     void join();
+    /** The same wait; returns the first inner rank's error message ("" if none) instead of throwing. */
+    std::string firstError();
+    /** A rank has failed (its thread calls this; the wrapper kernels do for rank 0): ranks waiting for it in a collective of the host-staged
+     *  transport return with an error instead of waiting for ever.  The Context is lost; its destruction no longer hangs. */
+    void abortCollectives(int rank, const std::string& why);
+    /** The rank whose failure was reported first (-1: none) and its message. */
+    int failedFirst() { std::lock_guard<std::mutex> lock(causeMutex); return causeRank; }
+    std::string firstCause() { std::lock_guard<std::mutex> lock(causeMutex); return cause; }
     ContextImpl& impl(int rank);
     Integrator& integrator(int rank);
     /** The ordinal-th kernel named `name` of an inner Context (kernels are created in the same order in every Context of one System). */
@@ -62,6 +70,9 @@ private:
     std::string commIdValue;
     unsigned long long sharedSeed;
     int stagedToken;
+    std::mutex causeMutex;
+    int causeRank = -1;
+    std::string cause;
 };
 
 /** True on a thread of a HipRankGroup while it creates its inner Context (what the platform does once per user Context is then left out). */
@@ -70,6 +81,7 @@ bool& hipCreatingInnerRank();
 /** Host-staged all-gather between the threads of one process ("inprocess:<token>" CommId): registry of the groups alive. */
 int hipInProcessCreate(int ranks);                                    // -> token
 void hipInProcessDestroy(int token);
+void hipInProcessAbort(int token);                                     // every present and future wait of the group ends with an error
 /** The callback transport's function and the `user` pointer of one rank of a group (valid until hipInProcessDestroy). */
 void* hipInProcessUser(int token, int rank);
 extern "C" int hipInProcessAllGather(void* user, const void* send, void* recv, size_t bytes);

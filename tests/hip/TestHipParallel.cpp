@@ -165,6 +165,32 @@ void testDynamics(int ranks, int side = 14, int steps = 30) {
     }
 }
 
+/* A rank that fails in the middle of a run (OPENMM_HIP_DEBUG_FAIL_RANK = "rank:evaluation": its nonbonded kernel throws there) never reaches
+ * the collectives the others wait in.  With the host-staged transport between the threads the waits end with an error, the user's call throws
+ * an OpenMMException that names the rank which failed first, and the Context can be destroyed -- no thread is left waiting. */
+void testFailingRank(int failing, int side) {
+    System system;
+    vector<Vec3> positions;
+    buildWater(system, positions, side);
+    LangevinMiddleIntegrator integrator0(300.0, 1.0, 0.002), integrator(300.0, 1.0, 0.002);
+    Context single(system, integrator0, platform);          // (only to learn the device the tests run on)
+    const string failAt = to_string(failing) + ":5";
+    setenv("OPENMM_HIP_DEBUG_FAIL_RANK", failAt.c_str(), 1);
+    string message;
+    {
+        Context context(system, integrator, platform, listOf(single, 2));
+        context.setPositions(positions);
+        context.setVelocitiesToTemperature(300.0, 5);
+        try {
+            integrator.step(40);                                           // (the inner ranks' errors surface at the next join: every 32 steps, or with an energy)
+            context.getState(State::Energy);
+        }
+        catch (const OpenMMException& e) { message = e.what(); }
+    }                                                                      // ... and the destructor returns
+    unsetenv("OPENMM_HIP_DEBUG_FAIL_RANK");
+    ASSERT(message.find("rank " + to_string(failing) + " fails here") != string::npos);
+}
+
 void testRefusals() {
     System system;
     system.addParticle(1.0);
@@ -189,6 +215,8 @@ int main(int argc, char* argv[]) {
         const bool quick = argc > 1 && string(argv[1]) == "quick";          // the CPU emulator: the force comparison only
         testParallelComputation();
         testRefusals();
+        testFailingRank(1, 8);
+        testFailingRank(0, 8);
         if (!quick) {
             testDynamics(2);
             testDynamics(3);
